@@ -1,0 +1,186 @@
+/* jxgpu.h -- C ABI of libjxgpu.so: the MI355X (gfx950) implementation of JanusX's mixed-model hot path.
+ *
+ * Drop-in boundary: the reference exposes this path as PyO3 functions of the `janusx.janusx` extension
+ * module (/root/reference/src/lib.rs:691-1005).  Each entry point below names the reference function it
+ * replaces (file:line).  Plain pointers and sizes only; no Python/torch types.
+ *
+ * Two layers:
+ *   jxg_*  device layer : every pointer is a DEVICE pointer (HBM), `stream` is a hipStream_t (may be NULL).
+ *                         Used when inputs are already resident in HBM (bench.py, multi-GPU pipeline).
+ *   jx_*   host layer   : every pointer is a HOST pointer; the call stages through HBM itself.  These have
+ *                         the argument meaning of the reference's PyO3 functions (numpy arrays -> C arrays).
+ *
+ * Return value: 0 on success, non-zero on failure; `jx_last_error()` returns a thread-local message
+ * (the reference raises RuntimeError(msg), e.g. src/stats/grm.rs:3079-3086).
+ * Per-SNP numerical failures are not errors: rows are (NaN, NaN, 1.0) for the exact scan
+ * (src/stats/lmm.rs:74-81) and (NaN, NaN, NaN) for the fixed-lambda scan (src/stats/fvlmm.rs:1753-1761).
+ */
+#ifndef JXGPU_H
+#define JXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXG_TILE 128          /* sample tile of the internal packed layout ("P32": 128 samples = 32 bytes) */
+#define JXG_MAX_COV 15        /* max fixed-effect columns (incl. intercept) handled by the scan kernels */
+
+const char *jx_last_error(void);
+int jx_version(void);
+int jxg_device_count(void);
+int jxg_set_device(int dev);
+/* device properties: out[0]=CU count, out[1]=clock kHz, out[2]=total HBM MiB, out[3]=LDS bytes/CU */
+int jxg_device_info(int64_t *out4);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device layer
+ * ---------------------------------------------------------------------------------------------- */
+
+/* number of 128-sample tiles and padded sample count for n samples */
+int jxg_num_tiles(int n);
+
+/* A1. Re-tile a PLINK SNP-major 2-bit payload (m, bps) into the internal P32 layout
+ *   p32[(tile * m_out + j) * 32 + b]  =  samples tile*128 + 4b .. 4b+3 of output SNP j,
+ * optionally gathering a sample subset (sample_idx, n_sel) and a row subset (row_idx, m_out).
+ * Samples beyond n_sel are encoded 01 (missing).  Replaces the subset/gather plans of
+ * src/math/bedmath.rs:1359-1441 and `SubsetDecodePlan`. */
+int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, int64_t m_src,
+                   const int32_t *d_sample_idx, int n_sel, const int64_t *d_row_idx, int64_t m_out,
+                   uint8_t *d_p32, void *stream);
+
+/* A1. per-SNP (missing, het, hom_alt) counts over the n_sel real samples of a P32 buffer
+ * -> d_counts (m,3) int32.  src/io/gfreader.rs:1378-1395 `count_packed_row_counts`. */
+int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, int32_t *d_counts, void *stream);
+
+/* A3+A4. acc(lower tiles) += Z Z^T over the SNPs rows[k], k in [0, mk), where
+ * z = lut[k][code] (4 f32 values per SNP indexed by the 2-bit code; lut[k][1] must be 0).
+ * d_rows may be NULL (identity).  d_acc is (n_pad, n_pad) f64 row-major, n_pad = 128*tiles; only tiles
+ * (ti >= tj) are written.  Numerics: value LUT split into fp16 hi+lo, three MFMA products with f32
+ * accumulation over <= kchunk SNPs, f64 merge -- the counterpart of the reference's f32 SSYRK per block +
+ * f64 merge (src/stats/grm.rs:1638-1667, 1700-1772).  precision: 0 = fp16x2 split (default), 1 = exact
+ * f32 MFMA.  kchunk <= 0 selects the default (8192). */
+int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
+                       const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
+                       void *stream);
+
+/* A5. K = acc * inv_scale, mirrored lower -> upper, written as (n,n) f32 or f64 row-major.
+ * src/stats/grm.rs:2771-2785 `grm_scale_and_symmetrize_raw_f64`. */
+int jxg_grm_finalize(const double *d_acc, int n, double inv_scale, void *d_out, int out_is_f64,
+                     void *stream);
+
+/* B1. symmetric eigendecomposition, f64, ascending.  d_a (n,n) is overwritten with U^T row-major
+ * (row j = eigenvector j); d_w receives the n eigenvalues.  Replaces LAPACK dsyevd/dsyevr behind
+ * src/math/eigh.rs:1422-1528 (rocSOLVER dsyevd on the device).  `ridge` is added to the diagonal first
+ * (python/janusx/assoc/workflow.py:5639-5641). */
+int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream);
+
+/* a <- (a + a^T)/2 (src/math/eigh.rs:179-207); dst = src^T; dst (k,k) f64 = src[idx, idx] of an (n,n)
+ * f32/f64 matrix (trait-sample subset, python/janusx/assoc/workflow.py:5509-5560). */
+int jxg_symmetrize_f64(double *d_a, int n, void *stream);
+int jxg_transpose_f64(const double *d_src, double *d_dst, int n, void *stream);
+int jxg_gather_sub_f64(const void *d_src, int src_is_f64, int n, const int32_t *d_idx, int k, double *d_dst,
+                       void *stream);
+
+/* f64 U^T -> f32 U^T (row-major), python/janusx/pyBLUP/assoc.py:1818 (`Dh`). */
+int jxg_cast_f64_to_f32(const double *d_src, float *d_dst, int64_t count, void *stream);
+
+/* C1. X~ = U^T X, y~ = U^T y; U^T f32, f64 accumulation.  d_xy (n, q) f64 row-major (covariates and y
+ * side by side) -> d_out (n, q).  src/stats/reml.rs:109-198. */
+int jxg_rotate_xy(const float *d_ut, int n, const double *d_xy, int q, double *d_out, void *stream);
+
+/* C2-C4. null REML: Brent on log10(lambda) in [low, high].  d_out3 (DEVICE) = (lbd, ml, reml).
+ * src/stats/reml.rs:572-616 `lmm_reml_null_f32`. */
+int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double low,
+                      double high, int max_iter, double tol, double *d_out3, void *stream);
+
+/* D2 (prep). split f32 U^T (n,n) into two fp16 planes (n_pad, n_pad), scaled by 2^scale_exp, zero padded. */
+int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *d_lo, int scale_exp, void *stream);
+
+/* D1+D2. rotate a block of SNP rows straight from the packed payload:
+ *   out[r, j] = sum_i lut[r][code(rows[r], i)] * u_t[j, i],   r in [0, nrows), j in [0, n)
+ * lut (nrows,4) f32 holds the already centred design values (src/decode/decode.rs:192-271);
+ * d_out (nrows, n) f32 row-major.  src/stats/lmm.rs:728-784 `rotate_snp_block_with_ut_blas`. */
+int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                      const float *d_lut, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
+                      float *d_out, void *stream);
+
+/* D2 (dense input). out[r, j] = sum_i g[r, i] * u_t[j, i] in exact f32 (f32 MFMA).
+ * src/stats/lmm.rs:520-552 `rotate_snp_block_with_ut`. */
+int jxg_rotate_dense_f32(const float *d_g, int nrows, int n, const float *d_ut, float *d_out, void *stream);
+
+/* D3-D5. exact per-SNP scan of an already rotated block: Brent over -REML per SNP, GLS beta/SE, Wald p.
+ * warm = 0: no warm start (reference core API, src/stats/lmm.rs:1577-1579); warm = 1: every SNP starts at
+ * init_log10_lbd.  d_out (nrows, 3 or 4) f64 = [beta, se, p(, plrt)]; d_evals (nrows) int32 or NULL.
+ * src/stats/lmm.rs:94-199. */
+int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                 const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                 double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                 void *stream);
+
+/* E1. fixed-lambda cache (device vectors): w f32(n), py f32(n), wx f32(n,p); scalars to HOST out:
+ * a_chol (p*p), ypy, log_det_v, df.  src/stats/fvlmm.rs:1484-1563. */
+int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double lbd,
+                      float *d_w, float *d_py, float *d_wx, double *h_a_chol, double *h_scalars3);
+
+/* E2. fixed-lambda scan of a rotated block -> d_out (nrows,3) f64.  src/stats/fvlmm.rs:1691-1805. */
+int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
+                   const float *d_wx, const double *h_a_chol, double ypy, int df, double *d_out,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host layer (reference PyO3 signatures with C arrays)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* `grm_packed_f32` / `grm_packed_f64_with_stats` (src/stats/grm.rs:3053-3066, 5611-5651).
+ * packed (m, ceil(n_samples/4)) u8; row_flip (m) u8 0/1; row_maf (m) f32; sample_indices (n_sel) i64 or
+ * NULL.  out_k (n,n) f32 or f64; out_row_sum (m) f64 or NULL; out_varsum (1) f64 or NULL. */
+int jx_grm_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                  const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
+                  void *out_k, int out_is_f64, double *out_row_sum, double *out_varsum);
+
+/* `grm_stream_bed_f32` (src/stats/grm.rs:4676-4703) on an in-memory payload: QC pass + GRM.
+ * out_k (n,n) f32; out_eff_m (1); out_keep (m) u8 or NULL. */
+int jx_grm_stream_payload_f32(const uint8_t *packed, int64_t m, int n_samples, int method,
+                              float maf_threshold, float max_missing_rate, float het_threshold,
+                              float *out_k, int64_t *out_eff_m, uint8_t *out_keep);
+
+/* `rust_eigh_from_array_f64` (src/math/eigh.rs:1621-1703): a (n,n) f64 row-major (symmetrised
+ * (A+A^T)/2 like eigh.rs:179) -> evals (n) ascending, evecs (n,n) row-major, columns = eigenvectors
+ * (NULL = values only still computes vectors internally). */
+int jx_eigh_f64(const double *a, int n, double diag_shift, double *evals, double *evecs);
+
+/* `lmm_rotate_x_y_with_ut_f64` (src/stats/reml.rs:107-198). */
+int jx_lmm_rotate_x_y_with_ut_f64(const float *u_t, int n, const double *x, int q, const double *y,
+                                  double *out_x, double *out_y);
+
+/* `lmm_reml_null_f32` (src/stats/reml.rs:570-616) -> out3 = (lbd, ml, reml). */
+int jx_lmm_reml_null(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                     double high, int max_iter, double tol, double *out3);
+
+/* `lmm_reml_chunk_f32` (src/stats/lmm.rs:333-335; rotated input) and `lmm_reml_chunk_from_snp_f32`
+ * (src/stats/lmm.rs:1479-1630; u_t != NULL -> rotate first).  has_nullml -> 4 output columns. */
+int jx_lmm_reml_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                      double high, const float *snp_chunk, int64_t m_chunk, const float *u_t, int max_iter,
+                      double tol, int has_nullml, double nullml, double *out);
+
+/* `fvlmm_assoc_chunk_f32` / `fvlmm_assoc_chunk_from_snp_f32` (src/stats/fvlmm.rs:1941-1994, 2114-2262). */
+int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p,
+                         double log10_lbd, const float *snp_chunk, int64_t m_chunk, const float *u_t,
+                         double *out);
+
+/* `lmm_reml_assoc_packed_f32` (src/stats/lmm.rs:3040-3362) and its fixed-lambda sibling
+ * (`fvlmm_assoc_packed` core of src/stats/fvlmm.rs:4958-5190 with a caller-rotated null model).
+ * model: 0 = exact per-SNP REML (lmm), 1 = fixed lambda (fvlmm; `low` carries log10 lambda).
+ * warm: 0 none (parity contract), 1 seed with init_log10_lbd.  out (m, 3). */
+int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                    const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                    const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
+                    double high, int max_iter, double tol, int warm, double init_log10_lbd, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXGPU_H */

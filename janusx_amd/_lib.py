@@ -1,0 +1,80 @@
+"""ctypes loader for libjxgpu.so (the HIP/C-ABI product library).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C janusx_amd/csrc``.  There is no CPU
+fallback: if the shared object is missing or a call fails, a RuntimeError is raised (the reference raises
+RuntimeError from its PyO3 layer too, e.g. src/stats/grm.rs:3079-3086).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjxgpu.so")
+_LIB = None
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_l = C.c_int64
+c_d = C.c_double
+c_f = C.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/jxgpu.h one to one
+SIGNATURES = {
+    "jx_last_error": [],
+    "jx_version": [],
+    "jxg_device_count": [],
+    "jxg_set_device": [c_i],
+    "jxg_device_info": [c_p],
+    "jxg_num_tiles": [c_i],
+    "jxg_repack_p32": [c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_l, c_p, c_p],
+    "jxg_row_counts_p32": [c_p, c_l, c_i, c_p, c_p],
+    "jxg_grm_accumulate": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
+    "jxg_grm_finalize": [c_p, c_i, c_d, c_p, c_i, c_p],
+    "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
+    "jxg_symmetrize_f64": [c_p, c_i, c_p],
+    "jxg_transpose_f64": [c_p, c_p, c_i, c_p],
+    "jxg_gather_sub_f64": [c_p, c_i, c_i, c_p, c_i, c_p, c_p],
+    "jxg_cast_f64_to_f32": [c_p, c_p, c_l, c_p],
+    "jxg_rotate_xy": [c_p, c_i, c_p, c_i, c_p, c_p],
+    "jxg_lmm_reml_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_p, c_p],
+    "jxg_ut_split": [c_p, c_i, c_p, c_p, c_i, c_p],
+    "jxg_rotate_packed": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "jxg_rotate_dense_f32": [c_p, c_i, c_i, c_p, c_p, c_p],
+    "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
+    "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
+    "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
+    "jx_grm_stream_payload_f32": [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p],
+    "jx_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
+    "jx_lmm_rotate_x_y_with_ut_f64": [c_p, c_i, c_p, c_i, c_p, c_p, c_p],
+    "jx_lmm_reml_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_p],
+    "jx_lmm_reml_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_i, c_d, c_i, c_d, c_p],
+    "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_p],
+    "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
+                        c_d, c_p],
+}
+_RESTYPES = {"jx_last_error": C.c_char_p}
+
+
+def lib():
+    """Load libjxgpu.so (once). Raises RuntimeError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C janusx_amd/csrc` (there is no CPU fallback)")
+        h = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _LIB = h
+    return _LIB
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().jx_last_error()
+        raise RuntimeError(msg.decode("utf-8", "replace") if msg else f"libjxgpu call failed ({status})")

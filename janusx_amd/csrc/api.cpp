@@ -1,0 +1,518 @@
+// Host layer of libjxgpu: reference-shaped entry points (host arrays in, host arrays out) that stage through
+// HBM and drive the device layer; per-SNP statistics / filter logic (integer counts -> f32/f64 decisions) is
+// done on the host exactly as the reference writes it, so the kept-SNP set is bit-exact.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "jx_common.h"
+
+namespace jx {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+
+int launch_symmetrize(double *d_a, int n, hipStream_t st);
+int launch_transpose_f64(const double *src, double *dst, int n, hipStream_t st);
+
+// ---- value LUTs (host) ---------------------------------------------------------------------------
+
+// GRM design LUT indexed by the 2-bit code [00, 01(missing), 10, 11]
+// (src/decode/decode.rs:813-839, src/math/bedmath.rs:1208-1224, decode.rs:558-566).
+static void grm_lut_from_maf(float maf, bool flip, int method, float out[4]) {
+    float p = maf;
+    if (p < 0.0f) p = 0.0f;
+    if (p > 1.0f) p = 1.0f;
+    const float mean_g = 2.0f * p;
+    const float var = 2.0f * p * (1.0f - p);
+    float sc = 1.0f;
+    if (method == 2) sc = (var > 1e-12f) ? (1.0f / sqrtf(var)) : 0.0f;
+    const float g0 = flip ? 2.0f : 0.0f, g1 = 1.0f, g2 = flip ? 0.0f : 2.0f;
+    out[0] = (g0 - mean_g) * sc;
+    out[1] = 0.0f;
+    out[2] = (g1 - mean_g) * sc;
+    out[3] = (g2 - mean_g) * sc;
+}
+
+// scan design LUT: [0, mu, 1, 2] (or flipped) minus the actual row mean
+// (src/decode/decode.rs:163-189, 218-221). counts = (missing, het, hom_alt) over the n selected samples.
+static void scan_lut_from_counts(float maf, bool flip, const int32_t *cnt, int n, float out[4]) {
+    const float mu = (float)fmax(2.0 * (double)maf, 0.0);
+    const float v0 = flip ? 2.0f : 0.0f, v2 = 1.0f, v3 = flip ? 0.0f : 2.0f;
+    const double c00 = (double)(n - cnt[0] - cnt[1] - cnt[2]);
+    const double sum = c00 * (double)v0 + (double)cnt[0] * (double)mu + (double)cnt[1] * (double)v2 +
+                       (double)cnt[2] * (double)v3;
+    const float mean = (float)(sum / (double)n);
+    out[0] = v0 - mean;
+    out[1] = mu - mean;
+    out[2] = v2 - mean;
+    out[3] = v3 - mean;
+}
+
+// denominators, src/stats/grm.rs:91-111 (full-sample centred) and bedmath.rs:1411-1438 (subset route)
+static double grm_varsum(const float *row_maf, int64_t m, int method, bool full) {
+    if (method != 1) return (double)m;
+    double acc = 0.0;
+    if (full) {
+        for (int64_t j = 0; j < m; ++j) {
+            const double p = (double)row_maf[j];
+            const double v = 2.0 * p * (1.0 - p);
+            if (isfinite(v) && v > 0.0) acc += v;
+        }
+    } else {
+        for (int64_t j = 0; j < m; ++j) {
+            float p0 = row_maf[j];
+            p0 = p0 < 0.0f ? 0.0f : (p0 > 1.0f ? 1.0f : p0);
+            const float mean_g = 2.0f * p0;
+            float pg = 0.5f * mean_g;
+            pg = pg < 0.0f ? 0.0f : (pg > 1.0f ? 1.0f : pg);
+            float v = 2.0f * pg * (1.0f - pg);
+            if (v < 0.0f) v = 0.0f;
+            acc += (double)v;
+        }
+    }
+    return acc;
+}
+
+struct SampleSel {
+    std::vector<int32_t> idx;
+    bool identity = true;
+    int n = 0;
+};
+
+static int make_sample_sel(const int64_t *sample_indices, int n_sel, int n_samples, SampleSel &s) {
+    if (!sample_indices) {
+        s.identity = true;
+        s.n = n_samples;
+        return 0;
+    }
+    if (n_sel <= 0) return fail("sample_indices must not be empty");
+    s.idx.resize(n_sel);
+    s.identity = (n_sel == n_samples);
+    for (int i = 0; i < n_sel; ++i) {
+        const int64_t v = sample_indices[i];
+        if (v < 0 || v >= n_samples)
+            return fail("sample index out of range: " + std::to_string(v) + " >= " + std::to_string(n_samples));
+        s.idx[i] = (int32_t)v;
+        if (v != i) s.identity = false;
+    }
+    s.n = n_sel;
+    return 0;
+}
+
+// Upload a PLINK payload and re-tile it to P32 (with optional sample subset). p32 must stay alive.
+static int stage_p32(const uint8_t *packed, int64_t m, int n_samples, const SampleSel &sel, DevBuf &p32) {
+    const int64_t bps = (n_samples + 3) / 4;
+    DevBuf raw, didx;
+    if (raw.alloc((size_t)(m * bps))) return 1;
+    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m * bps), hipMemcpyHostToDevice));
+    const int32_t *d_idx = nullptr;
+    if (!sel.identity) {
+        if (didx.alloc(sizeof(int32_t) * sel.idx.size())) return 1;
+        JX_HIP(hipMemcpy(didx.p, sel.idx.data(), sizeof(int32_t) * sel.idx.size(), hipMemcpyHostToDevice));
+        d_idx = didx.as<int32_t>();
+    }
+    const int nt = num_tiles(sel.n);
+    if (p32.alloc((size_t)nt * (size_t)m * 32)) return 1;
+    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m, d_idx, sel.n, nullptr, m, p32.as<uint8_t>(), nullptr))
+        return 1;
+    JX_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+extern "C" const char *jx_last_error(void) { return g_err.c_str(); }
+extern "C" int jx_version(void) { return 100; }
+
+extern "C" int jxg_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+extern "C" int jxg_set_device(int dev) {
+    JX_HIP(hipSetDevice(dev));
+    return 0;
+}
+
+extern "C" int jxg_device_info(int64_t *out4) {
+    int dev = 0;
+    JX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t pr;
+    JX_HIP(hipGetDeviceProperties(&pr, dev));
+    out4[0] = pr.multiProcessorCount;
+    out4[1] = pr.clockRate;
+    out4[2] = (int64_t)(pr.totalGlobalMem >> 20);
+    out4[3] = (int64_t)pr.maxSharedMemoryPerMultiProcessor;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grm_packed_f32 / grm_packed_f64_with_stats (src/stats/grm.rs:204-360, 3066, 5611)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int jx_grm_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                             const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
+                             void *out_k, int out_is_f64, double *out_row_sum, double *out_varsum) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (method != 1 && method != 2)
+        return fail("unsupported method=" + std::to_string(method) + "; expected 1 (centered) or 2 (standardized)");
+    if (m <= 0) return fail("packed must contain at least one SNP row");
+    SampleSel sel;
+    if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
+    const int n = sel.n;
+    const double D = grm_varsum(row_maf, m, method, sel.identity);
+    if (!(isfinite(D) && D > 0.0)) return fail("invalid centered GRM denominator: sum(2p(1-p)) <= 0");
+
+    std::vector<float> lut((size_t)m * 4);
+    for (int64_t j = 0; j < m; ++j) {
+        grm_lut_from_maf(row_maf[j], row_flip[j] != 0, method, &lut[(size_t)j * 4]);
+        if (out_row_sum) {
+            float p = row_maf[j];
+            p = p < 0.0f ? 0.0f : (p > 1.0f ? 1.0f : p);
+            // decode.rs:795-799 (method 2) / :841 (method 1): mean_g * n_out
+            out_row_sum[j] = (method == 2) ? 2.0 * (double)p * (double)n : (double)(2.0f * p) * (double)n;
+        }
+    }
+    DevBuf p32, dlut, acc, dout;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    if (dlut.alloc(lut.size() * sizeof(float))) return 1;
+    JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
+    if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
+    JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
+    if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, nullptr))
+        return 1;
+    const size_t esz = out_is_f64 ? sizeof(double) : sizeof(float);
+    if (dout.alloc(esz * (size_t)n * (size_t)n)) return 1;
+    if (jxg_grm_finalize(acc.as<double>(), n, 1.0 / D, dout.p, out_is_f64, nullptr)) return 1;
+    JX_HIP(hipMemcpy(out_k, dout.p, esz * (size_t)n * (size_t)n, hipMemcpyDeviceToHost));
+    if (out_varsum) *out_varsum = (method == 1) ? D : (double)m;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grm_stream_bed_f32 on an in-memory payload (src/stats/grm.rs:1465-1536 prepare, 4690-5455 driver)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int jx_grm_stream_payload_f32(const uint8_t *packed, int64_t m, int n_samples, int method,
+                                         float maf_threshold, float max_missing_rate, float het_threshold,
+                                         float *out_k, int64_t *out_eff_m, uint8_t *out_keep) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (method != 1 && method != 2) return fail("unsupported method=" + std::to_string(method));
+    if (m <= 0) return fail("No SNPs remained after filtering; GRM is empty.");
+    // grm.rs:4709-4711 threshold clamps
+    const float maf_thr = fminf(fmaxf(maf_threshold, 0.0f), 0.5f);
+    const float miss_thr = fminf(fmaxf(max_missing_rate, 0.0f), 1.0f);
+    const float het_thr = fminf(fmaxf(het_threshold, 0.0f), 1.0f);
+    SampleSel sel;
+    make_sample_sel(nullptr, 0, n_samples, sel);
+    DevBuf p32, dcnt;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)m)) return 1;
+    if (jxg_row_counts_p32(p32.as<uint8_t>(), m, n_samples, dcnt.as<int32_t>(), nullptr)) return 1;
+    std::vector<int32_t> cnt((size_t)m * 3);
+    JX_HIP(hipMemcpy(cnt.data(), dcnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+
+    std::vector<int32_t> rows;
+    std::vector<float> lut;
+    rows.reserve(m);
+    lut.reserve((size_t)m * 4);
+    double varsum = 0.0;
+    const double eps = (double)1e-12f;
+    for (int64_t j = 0; j < m; ++j) {
+        if (out_keep) out_keep[j] = 0;
+        const int64_t missing = cnt[j * 3], het = cnt[j * 3 + 1], hom = cnt[j * 3 + 2];
+        const int64_t nm = n_samples - missing;
+        if (het_thr > 0.0f && nm > 0) {
+            const double het_rate = (double)het / (double)nm;
+            if (het_rate > (double)het_thr) continue;
+        }
+        const double missing_rate = 1.0 - ((double)nm / (double)n_samples);
+        if (missing_rate > (double)miss_thr) continue;
+        float mean_g, sc;
+        bool flip = false;
+        double var = 0.0;
+        if (nm == 0) {
+            if (maf_thr > 0.0f) continue;
+            mean_g = 0.0f;
+            sc = (method == 2) ? 0.0f : 1.0f;
+        } else {
+            double alt_sum = (double)(het + 2 * hom);
+            double alt_freq = alt_sum / (2.0 * (double)nm);
+            flip = alt_freq > 0.5;
+            if (flip) {
+                alt_sum = 2.0 * (double)nm - alt_sum;
+                alt_freq = alt_sum / (2.0 * (double)nm);
+            }
+            const double maf = fmin(alt_freq, 1.0 - alt_freq);
+            if (maf < (double)maf_thr) continue;
+            mean_g = (float)(alt_sum / (double)nm);
+            var = fmax(2.0 * alt_freq * (1.0 - alt_freq), 0.0);
+            sc = 1.0f;
+            if (method == 2) sc = (var > eps) ? (float)(1.0 / sqrt(var)) : 0.0f;
+        }
+        if (out_keep) out_keep[j] = 1;
+        rows.push_back((int32_t)j);
+        varsum += var;
+        const float g0 = flip ? 2.0f : 0.0f, g2 = flip ? 0.0f : 2.0f;
+        // decode.rs:446-461 `apply_prepared_grm_stream_row_copy_f32`
+        lut.push_back((g0 - mean_g) * sc);
+        lut.push_back(0.0f);
+        lut.push_back((1.0f - mean_g) * sc);
+        lut.push_back((g2 - mean_g) * sc);
+    }
+    const int64_t eff = (int64_t)rows.size();
+    if (out_eff_m) *out_eff_m = eff;
+    if (eff == 0) return fail("No SNPs remained after filtering; GRM is empty.");
+    const double D = (method == 1) ? varsum : (double)eff;
+    if (!(isfinite(D) && D > 0.0)) return fail("invalid centered GRM denominator: sum(2p(1-p)) <= 0");
+
+    DevBuf drows, dlut, acc, dout;
+    if (drows.alloc(rows.size() * sizeof(int32_t))) return 1;
+    JX_HIP(hipMemcpy(drows.p, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (dlut.alloc(lut.size() * sizeof(float))) return 1;
+    JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int n = n_samples;
+    const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
+    if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
+    JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
+    if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), dlut.as<float>(), eff, acc.as<double>(), 0, 0,
+                           nullptr))
+        return 1;
+    if (dout.alloc(sizeof(float) * (size_t)n * (size_t)n)) return 1;
+    if (jxg_grm_finalize(acc.as<double>(), n, 1.0 / D, dout.p, 0, nullptr)) return 1;
+    JX_HIP(hipMemcpy(out_k, dout.p, sizeof(float) * (size_t)n * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rust_eigh_from_array_f64 (src/math/eigh.rs:1621-1703)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int jx_eigh_f64(const double *a, int n, double diag_shift, double *evals, double *evecs) {
+    if (n <= 0) return fail("matrix must be non-empty");
+    DevBuf da, dw, dt;
+    const size_t nn = (size_t)n * (size_t)n;
+    if (da.alloc(sizeof(double) * nn)) return 1;
+    if (dw.alloc(sizeof(double) * (size_t)n)) return 1;
+    JX_HIP(hipMemcpy(da.p, a, sizeof(double) * nn, hipMemcpyHostToDevice));
+    if (launch_symmetrize(da.as<double>(), n, nullptr)) return 1;  // eigh.rs:179
+    if (jxg_eigh_f64(da.as<double>(), n, diag_shift, dw.as<double>(), nullptr)) return 1;
+    JX_HIP(hipMemcpy(evals, dw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    if (evecs) {
+        if (dt.alloc(sizeof(double) * nn)) return 1;
+        if (launch_transpose_f64(da.as<double>(), dt.as<double>(), n, nullptr)) return 1;  // U^T -> U (columns = vectors)
+        JX_HIP(hipMemcpy(evecs, dt.p, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int jx_lmm_rotate_x_y_with_ut_f64(const float *u_t, int n, const double *x, int q, const double *y,
+                                             double *out_x, double *out_y) {
+    if (n <= 0) return fail("y must not be empty");
+    if (q < 0 || q > 15) return fail("x must have between 0 and 15 columns");
+    const int qq = q + 1;
+    std::vector<double> xy((size_t)n * qq);
+    for (int i = 0; i < n; ++i) {
+        for (int c = 0; c < q; ++c) xy[(size_t)i * qq + c] = x[(size_t)i * q + c];
+        xy[(size_t)i * qq + q] = y[i];
+    }
+    DevBuf dut, dxy, dout;
+    if (dut.alloc(sizeof(float) * (size_t)n * n)) return 1;
+    if (dxy.alloc(sizeof(double) * xy.size())) return 1;
+    if (dout.alloc(sizeof(double) * xy.size())) return 1;
+    JX_HIP(hipMemcpy(dut.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+    JX_HIP(hipMemcpy(dxy.p, xy.data(), sizeof(double) * xy.size(), hipMemcpyHostToDevice));
+    if (jxg_rotate_xy(dut.as<float>(), n, dxy.as<double>(), qq, dout.as<double>(), nullptr)) return 1;
+    JX_HIP(hipMemcpy(xy.data(), dout.p, sizeof(double) * xy.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        for (int c = 0; c < q; ++c) out_x[(size_t)i * q + c] = xy[(size_t)i * qq + c];
+        out_y[i] = xy[(size_t)i * qq + q];
+    }
+    return 0;
+}
+
+namespace {
+struct NullDev {
+    DevBuf s, x, y;
+    int upload(const double *hs, const double *hx, const double *hy, int n, int p) {
+        if (s.alloc(sizeof(double) * (size_t)n) || x.alloc(sizeof(double) * (size_t)n * p) ||
+            y.alloc(sizeof(double) * (size_t)n))
+            return 1;
+        JX_HIP(hipMemcpy(s.p, hs, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        JX_HIP(hipMemcpy(x.p, hx, sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice));
+        JX_HIP(hipMemcpy(y.p, hy, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+}  // namespace
+
+extern "C" int jx_lmm_reml_null(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                                double high, int max_iter, double tol, double *out3) {
+    if (low >= high) return fail("low must be < high");
+    NullDev nd;
+    DevBuf o;
+    if (nd.upload(s, xcov, y_rot, n, p) || o.alloc(3 * sizeof(double))) return 1;
+    if (jxg_lmm_reml_null(nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), n, p, low, high, max_iter, tol,
+                          o.as<double>(), nullptr))
+        return 1;
+    JX_HIP(hipMemcpy(out3, o.p, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static const int64_t kBlockRows = 4096;  // rotate/scan block (rows x n f32 kept in HBM)
+
+extern "C" int jx_lmm_reml_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                                 double high, const float *snp_chunk, int64_t m_chunk, const float *u_t, int max_iter,
+                                 double tol, int has_nullml, double nullml, double *out) {
+    if (low >= high) return fail("low must be < high");
+    if (m_chunk <= 0) return 0;
+    const int cols = has_nullml ? 4 : 3;
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    DevBuf dut, dg, drot, dout;
+    if (u_t) {
+        if (dut.alloc(sizeof(float) * (size_t)n * n)) return 1;
+        JX_HIP(hipMemcpy(dut.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+        if (drot.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    }
+    if (dg.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)kBlockRows * cols)) return 1;
+    for (int64_t r0 = 0; r0 < m_chunk; r0 += kBlockRows) {
+        const int rows = (int)std::min<int64_t>(kBlockRows, m_chunk - r0);
+        JX_HIP(hipMemcpy(dg.p, snp_chunk + (size_t)r0 * n, sizeof(float) * (size_t)rows * n, hipMemcpyHostToDevice));
+        const float *grot = dg.as<float>();
+        if (u_t) {
+            if (jxg_rotate_dense_f32(dg.as<float>(), rows, n, dut.as<float>(), drot.as<float>(), nullptr)) return 1;
+            grot = drot.as<float>();
+        }
+        if (jxg_lmm_scan(grot, rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low, high, tol,
+                         max_iter, 0, 0.0, has_nullml, nullml, dout.as<double>(), nullptr, nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)r0 * cols, dout.p, sizeof(double) * (size_t)rows * cols, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+namespace {
+struct FvDev {
+    DevBuf w, py, wx;
+    std::vector<double> a_chol;
+    double sc[3];
+    int prepare(const NullDev &nd, int n, int p, double lbd) {
+        if (w.alloc(sizeof(float) * (size_t)n) || py.alloc(sizeof(float) * (size_t)n) ||
+            wx.alloc(sizeof(float) * (size_t)n * p))
+            return 1;
+        a_chol.assign((size_t)p * p, 0.0);
+        return jxg_fvlmm_prepare(nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), n, p, lbd, w.as<float>(),
+                                 py.as<float>(), wx.as<float>(), a_chol.data(), sc);
+    }
+};
+}  // namespace
+
+extern "C" int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p,
+                                    double log10_lbd, const float *snp_chunk, int64_t m_chunk, const float *u_t,
+                                    double *out) {
+    if (m_chunk <= 0) return 0;
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    FvDev fv;
+    if (fv.prepare(nd, n, p, pow(10.0, log10_lbd))) return 1;
+    DevBuf dut, dg, drot, dout;
+    if (u_t) {
+        if (dut.alloc(sizeof(float) * (size_t)n * n)) return 1;
+        JX_HIP(hipMemcpy(dut.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+        if (drot.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    }
+    if (dg.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)kBlockRows * 3)) return 1;
+    for (int64_t r0 = 0; r0 < m_chunk; r0 += kBlockRows) {
+        const int rows = (int)std::min<int64_t>(kBlockRows, m_chunk - r0);
+        JX_HIP(hipMemcpy(dg.p, snp_chunk + (size_t)r0 * n, sizeof(float) * (size_t)rows * n, hipMemcpyHostToDevice));
+        const float *grot = dg.as<float>();
+        if (u_t) {
+            if (jxg_rotate_dense_f32(dg.as<float>(), rows, n, dut.as<float>(), drot.as<float>(), nullptr)) return 1;
+            grot = drot.as<float>();
+        }
+        if (jxg_fvlmm_scan(grot, rows, n, p, fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(), fv.a_chol.data(),
+                           fv.sc[0], (int)fv.sc[2], dout.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)r0 * 3, dout.p, sizeof(double) * (size_t)rows * 3, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lmm_reml_assoc_packed_f32 (src/stats/lmm.rs:3040-3362) / fixed-lambda sibling
+// ---------------------------------------------------------------------------------------------------
+extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                               const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                               const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
+                               double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
+                               double *out) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (model == 0 && low >= high) return fail("low must be < high");
+    if (model == 0 && !(isfinite(tol) && tol > 0.0)) return fail("tol must be positive and finite");
+    if (m <= 0) return 0;
+    SampleSel sel;
+    if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
+    const int n = sel.n;
+    DevBuf p32, dcnt;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)m)) return 1;
+    if (jxg_row_counts_p32(p32.as<uint8_t>(), m, n, dcnt.as<int32_t>(), nullptr)) return 1;
+    std::vector<int32_t> cnt((size_t)m * 3);
+    JX_HIP(hipMemcpy(cnt.data(), dcnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<float> lut((size_t)m * 4);
+    for (int64_t j = 0; j < m; ++j)
+        scan_lut_from_counts(row_maf[j], row_flip[j] != 0, &cnt[(size_t)j * 3], n, &lut[(size_t)j * 4]);
+
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    FvDev fv;
+    if (model == 1 && fv.prepare(nd, n, p, pow(10.0, low))) return 1;
+
+    const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
+    DevBuf dut, uhi, ulo, dlut, drot, dout;
+    if (dut.alloc(sizeof(float) * (size_t)n * n)) return 1;
+    JX_HIP(hipMemcpy(dut.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+    if (uhi.alloc(sizeof(uint16_t) * (size_t)(npad * npad)) || ulo.alloc(sizeof(uint16_t) * (size_t)(npad * npad)))
+        return 1;
+    const int scale_exp = 10;
+    if (jxg_ut_split(dut.as<float>(), n, uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, nullptr)) return 1;
+    dut.release();
+    if (dlut.alloc(lut.size() * sizeof(float))) return 1;
+    JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int64_t brows = 8192;
+    if (drot.alloc(sizeof(float) * (size_t)brows * n)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)brows * 3)) return 1;
+    DevBuf drows;
+    if (drows.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
+    std::vector<int32_t> hrows((size_t)brows);
+    for (int64_t r0 = 0; r0 < m; r0 += brows) {
+        const int rows = (int)std::min<int64_t>(brows, m - r0);
+        for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
+        JX_HIP(hipMemcpy(drows.p, hrows.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
+        if (jxg_rotate_packed(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows, dlut.as<float>() + (size_t)r0 * 4,
+                              uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, drot.as<float>(), nullptr))
+            return 1;
+        if (model == 0) {
+            if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
+                             high, tol, max_iter, warm, init_log10_lbd, 0, 0.0, dout.as<double>(), nullptr, nullptr))
+                return 1;
+        } else {
+            if (jxg_fvlmm_scan(drot.as<float>(), rows, n, p, fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(),
+                               fv.a_chol.data(), fv.sc[0], (int)fv.sc[2], dout.as<double>(), nullptr))
+                return 1;
+        }
+        JX_HIP(hipMemcpy(out + (size_t)r0 * 3, dout.p, sizeof(double) * (size_t)rows * 3, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}

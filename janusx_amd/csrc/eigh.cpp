@@ -1,0 +1,52 @@
+// Symmetric eigendecomposition on the device (rocSOLVER dsyevd), replacing LAPACK dsyevd/dsyevr behind
+// src/math/eigh.rs:1422-1528 (`symmetric_eigh_f64_row_major_with_driver`).
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <mutex>
+
+#include "jx_common.h"
+
+namespace jx {
+// kernels from k_misc.hip
+int launch_add_diag(double *d_a, int n, int64_t ld, double ridge, hipStream_t st);
+int launch_symmetrize(double *d_a, int n, hipStream_t st);
+
+static rocblas_handle g_handle = nullptr;
+static std::mutex g_handle_mu;
+
+static rocblas_handle get_handle() {
+    std::lock_guard<std::mutex> lk(g_handle_mu);
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success) g_handle = nullptr;
+    }
+    return g_handle;
+}
+}  // namespace jx
+
+using namespace jx;
+
+// d_a: (n,n) symmetric, f64. On return row j of d_a (row-major) = eigenvector j (= column j of the
+// column-major LAPACK result), eigenvalues ascending in d_w.
+extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream) {
+    if (n <= 0) return fail("jxg_eigh_f64: n must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    rocblas_handle h = get_handle();
+    if (!h) return fail("rocblas_create_handle failed");
+    if (rocblas_set_stream(h, st) != rocblas_status_success) return fail("rocblas_set_stream failed");
+    if (ridge != 0.0) {
+        if (launch_add_diag(d_a, n, n, ridge, st)) return 1;
+    }
+    DevBuf e, info;
+    if (e.alloc(sizeof(double) * (size_t)n)) return 1;
+    if (info.alloc(sizeof(rocblas_int))) return 1;
+    // symmetric input: row-major == column-major; the lower triangle is referenced.
+    rocblas_status rs = rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, n, d_a, n, d_w,
+                                         e.as<double>(), info.as<rocblas_int>());
+    if (rs != rocblas_status_success) return fail("rocsolver_dsyevd failed with status " + std::to_string((int)rs));
+    rocblas_int hinfo = 0;
+    JX_HIP(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    if (hinfo != 0) return fail("rocsolver_dsyevd did not converge (info=" + std::to_string(hinfo) + ")");
+    return 0;
+}

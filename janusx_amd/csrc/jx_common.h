@@ -1,0 +1,63 @@
+// Shared host/device helpers for libjxgpu (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/jxgpu.h"
+
+namespace jx {
+
+void set_error(const std::string &msg);
+int fail(const std::string &msg);
+
+#define JX_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (call);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            return ::jx::fail(std::string(#call) + " failed: " + hipGetErrorString(_e) + " (" +       \
+                              __FILE__ + ":" + std::to_string(__LINE__) + ")");                       \
+        }                                                                                             \
+    } while (0)
+
+#define JX_LAUNCH_CHECK()                                                                             \
+    do {                                                                                              \
+        hipError_t _e = hipGetLastError();                                                            \
+        if (_e != hipSuccess) {                                                                       \
+            return ::jx::fail(std::string("kernel launch failed: ") + hipGetErrorString(_e) + " (" +  \
+                              __FILE__ + ":" + std::to_string(__LINE__) + ")");                       \
+        }                                                                                             \
+    } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int num_tiles(int n) { return ceil_div(n, JXG_TILE); }
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t nbytes) {
+        release();
+        if (nbytes == 0) nbytes = 16;
+        hipError_t e = hipMalloc(&p, nbytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(std::string("hipMalloc(") + std::to_string(nbytes) + ") failed: " + hipGetErrorString(e));
+        }
+        bytes = nbytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace jx

@@ -1,0 +1,145 @@
+// 2-bit genotype payload kernels: re-tiling into the P32 layout and per-SNP popcounts.
+// Reference semantics: src/math/bedmath.rs:20-27 (codes), src/io/gfreader.rs:1378-1395 (counts).
+#include "jx_common.h"
+
+namespace jx {
+
+// One thread produces one dword (16 samples) of the P32 image.
+//   dst[(tile * m_out + j) * 32 + 4*d .. +3]  <- samples tile*128 + 16*d .. +15 of source row row_idx[j]
+// Identity sample order + 4-byte-aligned source rows take the word-copy path; everything else gathers.
+__global__ __launch_bounds__(256) void repack_p32_kernel(const uint8_t *__restrict__ src, int64_t bps, int n_src,
+                                                         const int32_t *__restrict__ sample_idx, int n_sel,
+                                                         const int64_t *__restrict__ row_idx, int64_t m_out,
+                                                         uint32_t *__restrict__ dst, int nt) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_tile = m_out * 8;  // dwords per tile
+    if (gid >= per_tile * nt) return;
+    const int tile = (int)(gid / per_tile);
+    const int64_t rem = gid - (int64_t)tile * per_tile;
+    const int64_t j = rem >> 3;
+    const int d = (int)(rem & 7);
+    const int64_t srow = row_idx ? row_idx[j] : j;
+    const uint8_t *row = src + srow * bps;
+    const int s0 = tile * JXG_TILE + d * 16;
+    uint32_t w = 0;
+    if (sample_idx == nullptr) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int s = s0 + 4 * b;  // first sample of this byte
+            uint32_t byte;
+            if (s + 3 < n_sel) {
+                byte = row[s >> 2];
+            } else {
+                byte = 0x55u;  // all missing
+                if (s < n_sel) {
+                    const uint32_t raw = row[s >> 2];
+                    const int valid = n_sel - s;  // 1..3 valid samples
+                    const uint32_t mask = (1u << (2 * valid)) - 1u;
+                    byte = (raw & mask) | (0x55u & ~mask);
+                }
+            }
+            w |= byte << (8 * b);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int s = s0 + i;
+            uint32_t code = 1u;  // missing
+            if (s < n_sel) {
+                const int sid = sample_idx[s];
+                code = (row[sid >> 2] >> (2 * (sid & 3))) & 3u;
+            }
+            w |= code << (2 * i);
+        }
+    }
+    dst[gid] = w;
+}
+
+// counts[j] = (missing, het, hom_alt) over the real samples; padding samples are stored as 01 and removed
+// from `missing` afterwards by the host (n_pad - n_sel).  One thread per (SNP, tile) record of 32 bytes.
+__global__ __launch_bounds__(256) void row_counts_p32_kernel(const uint4 *__restrict__ p32, int64_t m, int nt,
+                                                             int32_t *__restrict__ counts) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= m * nt) return;
+    const int tile = (int)(gid / m);
+    const int64_t j = gid - (int64_t)tile * m;
+    const uint4 *rec = p32 + ((int64_t)tile * m + j) * 2;
+    int mis = 0, het = 0, hom = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint4 v = rec[h];
+        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = ws[k] & 0x55555555u;
+            const uint32_t hi = (ws[k] >> 1) & 0x55555555u;
+            mis += __popc(lo & ~hi);
+            het += __popc(hi & ~lo);
+            hom += __popc(hi & lo);
+        }
+    }
+    if (mis) atomicAdd(&counts[j * 3 + 0], mis);
+    if (het) atomicAdd(&counts[j * 3 + 1], het);
+    if (hom) atomicAdd(&counts[j * 3 + 2], hom);
+}
+
+__global__ void fix_pad_missing_kernel(int32_t *counts, int64_t m, int pad) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) counts[j * 3] -= pad;
+}
+
+__global__ void cast_f64_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, int64_t count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) dst[i] = (float)src[i];
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+extern "C" int jxg_num_tiles(int n) { return num_tiles(n); }
+
+extern "C" int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, int64_t m_src,
+                              const int32_t *d_sample_idx, int n_sel, const int64_t *d_row_idx, int64_t m_out,
+                              uint8_t *d_p32, void *stream) {
+    (void)m_src;
+    if (n_sel <= 0 || m_out <= 0) return fail("jxg_repack_p32: empty input");
+    const int nt = num_tiles(n_sel);
+    const int64_t total = m_out * 8 * nt;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail("jxg_repack_p32: grid too large");
+    hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_packed, bps,
+                       n_src, d_sample_idx, n_sel, d_row_idx, m_out, (uint32_t *)d_p32, nt);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, int32_t *d_counts, void *stream) {
+    const int nt = num_tiles(n_sel);
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * 3 * (size_t)m, st));
+    const int64_t total = m * nt;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail("jxg_row_counts_p32: grid too large");
+    hipLaunchKernelGGL(row_counts_p32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)d_p32, m, nt,
+                       d_counts);
+    JX_LAUNCH_CHECK();
+    const int pad = nt * JXG_TILE - n_sel;
+    if (pad > 0) {
+        hipLaunchKernelGGL(fix_pad_missing_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_counts, m,
+                           pad);
+        JX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int jxg_cast_f64_to_f32(const double *d_src, float *d_dst, int64_t count, void *stream) {
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 65535 * 16) blocks = 65535 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_f64_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_src, d_dst,
+                       count);
+    JX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,395 @@
+// Eigenvector rotation G~ = G U on MFMA.
+//
+// Reference: rotate_snp_block_with_ut_blas (src/stats/lmm.rs:728-784, cblas_sgemm RowMajor NoTrans x Trans),
+// pure-Rust rotate_snp_block_with_ut (src/stats/lmm.rs:520-552), design decode
+// decode_centered_block_packed_f32 (src/decode/decode.rs:192-271).
+//     out[r, j] = sum_i g[r, i] * u_t[j, i]
+//
+// Packed route (jxg_rotate_packed): A = design rows decoded on the fly from the 2-bit P32 payload through a
+// per-SNP fp16 hi/lo LUT; B = U^T pre-split into two fp16 planes scaled by 2^scale_exp.  Three
+// v_mfma_f32_32x32x16_f16 products (hi*hi + hi*lo + lo*hi) with f32 accumulation reproduce an f32 GEMM to
+// ~2^-22 per operand.  Dense route (jxg_rotate_dense_f32): exact f32 MFMA (v_mfma_f32_32x32x2_f32).
+#include <hip/hip_fp16.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int R_BK = 32;      // samples (k) per step
+constexpr int R_PITCH = 80;   // bytes per row of a [row][k] fp16 image: 64 B + 16 B skew (conflict-free b128)
+constexpr int R_IMG = 128 * R_PITCH;
+
+__device__ __forceinline__ uint2 make_selectors_r(uint32_t byte) {
+    const uint32_t c0 = byte & 3u, c1 = (byte >> 2) & 3u, c2 = (byte >> 4) & 3u, c3 = (byte >> 6) & 3u;
+    uint2 s;
+    s.x = (2u * c0) | ((2u * c0 + 1u) << 8) | ((2u * c1) << 16) | ((2u * c1 + 1u) << 24);
+    s.y = (2u * c2) | ((2u * c2 + 1u) << 8) | ((2u * c3) << 16) | ((2u * c3 + 1u) << 24);
+    return s;
+}
+
+// f32 U^T (n,n) -> fp16 planes (n_pad, n_pad): hi = f16(u * 2^e), lo = f16(u * 2^e - hi); zero padding.
+__global__ __launch_bounds__(256) void ut_split_kernel(const float *__restrict__ ut, int n, int64_t npad,
+                                                       __half *__restrict__ hi, __half *__restrict__ lo,
+                                                       float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * npad) return;
+    const int64_t r = idx / npad, c = idx - r * npad;
+    float v = 0.0f;
+    if (r < n && c < n) v = ut[r * (int64_t)n + c] * scale;
+    const __half h = __float2half_rn(v);
+    const __half l = __float2half_rn(v - __half2float(h));
+    hi[idx] = h;
+    lo[idx] = l;
+}
+
+__global__ __launch_bounds__(256) void lut_split_r_kernel(const float *__restrict__ lut, int64_t mk,
+                                                          uint4 *__restrict__ out, int *__restrict__ flags) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= mk) return;
+    uint16_t hi[4], lo[4];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float v = lut[k * 4 + c];
+        if (!(fabsf(v) <= 30000.0f)) bad = true;
+        const __half h = __float2half_rn(v);
+        const __half l = __float2half_rn(v - __half2float(h));
+        hi[c] = __half_as_ushort(h);
+        lo[c] = __half_as_ushort(l);
+    }
+    uint4 o;
+    o.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    o.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    o.z = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    o.w = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    out[k] = o;
+    if (bad) atomicOr(flags, 1);
+}
+
+// grid: x = column tile (eigenvector index j), y = row tile (SNP rows). 256 threads = 4 waves (2x2 of 64x64).
+// waves 0-1 decode the A panel (128 SNP rows x 32 samples), waves 2-3 stage the two U planes.
+__global__ __launch_bounds__(256, 2) void rotate_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                              const int32_t *__restrict__ rows, int nrows,
+                                                              const uint4 *__restrict__ lut16,
+                                                              const __half *__restrict__ uhi,
+                                                              const __half *__restrict__ ulo, int64_t npad, int n,
+                                                              float out_scale, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 2048];
+    uint8_t *sAh = smem;
+    uint8_t *sAl = smem + R_IMG;
+    uint8_t *sBh = smem + 2 * R_IMG;
+    uint8_t *sBl = smem + 3 * R_IMG;
+    uint2 *seltab = reinterpret_cast<uint2 *>(smem + 4 * R_IMG);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int j0 = blockIdx.x * 128;
+    const int r0 = blockIdx.y * 128;
+
+    seltab[tid] = make_selectors_r((uint32_t)tid);
+
+    // ---- loader roles -------------------------------------------------------------------------
+    const bool is_decoder = tid < 128;
+    // decoder: thread = SNP row r0 + tid
+    const uint8_t *arec = nullptr;
+    uint4 L = make_uint4(0, 0, 0, 0);
+    if (is_decoder) {
+        const int r = r0 + tid;
+        if (r < nrows) {
+            const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+            arec = p32 + rec * 32;
+            L = lut16[r];
+        }
+    }
+    // stager: u = tid - 128; chunk id = u + 128*c (c = 0..3): row = id >> 2, part = id & 3 (16 B each)
+    const int u = tid - 128;
+
+    uint2 wa = make_uint2(0, 0);
+    u32x4 bh[4], bl[4];
+    auto prefetch = [&](int kstep) {
+        if (is_decoder) {
+            if (arec) {
+                const int tile = kstep >> 2, sub = kstep & 3;
+                wa = *reinterpret_cast<const uint2 *>(arec + (int64_t)tile * m_total * 32 + sub * 8);
+            }
+        } else {
+            const int64_t kcol = (int64_t)kstep * R_BK;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int id = u + 128 * c;
+                const int row = id >> 2, part = id & 3;
+                const int64_t off = (int64_t)(j0 + row) * npad + kcol + part * 8;
+                bh[c] = *reinterpret_cast<const u32x4 *>(uhi + off);
+                bl[c] = *reinterpret_cast<const u32x4 *>(ulo + off);
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const int nk = (int)(npad / R_BK);
+    const int h = lane >> 5;
+    const int frag_off = (lane & 31) * R_PITCH + h * 16;
+
+    prefetch(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        if (is_decoder) {
+            // 8 payload bytes = 32 samples -> 64 B hi + 64 B lo in row `tid`
+            uint8_t *dh = sAh + tid * R_PITCH;
+            uint8_t *dl = sAl + tid * R_PITCH;
+            const uint32_t ws[2] = {wa.x, wa.y};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t w = ws[half];
+                u32x4 h0, h1, l0, l1;
+                const uint2 s0 = seltab[w & 0xffu];
+                const uint2 s1 = seltab[(w >> 8) & 0xffu];
+                const uint2 s2 = seltab[(w >> 16) & 0xffu];
+                const uint2 s3 = seltab[w >> 24];
+                h0.x = __builtin_amdgcn_perm(L.y, L.x, s0.x);
+                h0.y = __builtin_amdgcn_perm(L.y, L.x, s0.y);
+                h0.z = __builtin_amdgcn_perm(L.y, L.x, s1.x);
+                h0.w = __builtin_amdgcn_perm(L.y, L.x, s1.y);
+                h1.x = __builtin_amdgcn_perm(L.y, L.x, s2.x);
+                h1.y = __builtin_amdgcn_perm(L.y, L.x, s2.y);
+                h1.z = __builtin_amdgcn_perm(L.y, L.x, s3.x);
+                h1.w = __builtin_amdgcn_perm(L.y, L.x, s3.y);
+                l0.x = __builtin_amdgcn_perm(L.w, L.z, s0.x);
+                l0.y = __builtin_amdgcn_perm(L.w, L.z, s0.y);
+                l0.z = __builtin_amdgcn_perm(L.w, L.z, s1.x);
+                l0.w = __builtin_amdgcn_perm(L.w, L.z, s1.y);
+                l1.x = __builtin_amdgcn_perm(L.w, L.z, s2.x);
+                l1.y = __builtin_amdgcn_perm(L.w, L.z, s2.y);
+                l1.z = __builtin_amdgcn_perm(L.w, L.z, s3.x);
+                l1.w = __builtin_amdgcn_perm(L.w, L.z, s3.y);
+                *reinterpret_cast<u32x4 *>(dh + half * 32) = h0;
+                *reinterpret_cast<u32x4 *>(dh + half * 32 + 16) = h1;
+                *reinterpret_cast<u32x4 *>(dl + half * 32) = l0;
+                *reinterpret_cast<u32x4 *>(dl + half * 32 + 16) = l1;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int id = u + 128 * c;
+                const int row = id >> 2, part = id & 3;
+                *reinterpret_cast<u32x4 *>(sBh + row * R_PITCH + part * 16) = bh[c];
+                *reinterpret_cast<u32x4 *>(sBl + row * R_PITCH + part * 16) = bl[c];
+            }
+        }
+        __syncthreads();
+        if (ks + 1 < nk) prefetch(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 ah[2], al[2], bhf[2], blf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int off = (wm * 64 + mi * 32) * R_PITCH + frag_off + kk * 32;
+                ah[mi] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sAh + off));
+                al[mi] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sAl + off));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int off = (wn * 64 + ni * 32) * R_PITCH + frag_off + kk * 32;
+                bhf[ni] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sBh + off));
+                blf[ni] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sBl + off));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bhf[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], blf[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bhf[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int gj = j0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = r0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gr < nrows && gj < n) out[(int64_t)gr * n + gj] = acc[mi][ni][r] * out_scale;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Exact f32 NT GEMM on v_mfma_f32_32x32x2_f32:  C[M][N] = A[M][K] * B[N][K]^T  (row-major, any sizes).
+// 128x128 tile, 4 waves (2x2 of 64x64), BK = 16.  LDS images [row][16 k] f32 with pitch 80 B.
+// ---------------------------------------------------------------------------------------------------
+constexpr int S_BK = 16;
+constexpr int S_PITCH = 80;  // 16 floats + 16 B skew
+
+__global__ __launch_bounds__(256, 2) void sgemm_nt_f32_kernel(const float *__restrict__ A, int M, int64_t lda,
+                                                              const float *__restrict__ B, int N, int64_t ldb, int K,
+                                                              float *__restrict__ C, int64_t ldc) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 128 * S_PITCH];
+    uint8_t *sA = smem;
+    uint8_t *sB = smem + 128 * S_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+
+    // loader: 128 rows x 16 k per operand = 512 float4 chunks -> 2 per thread per operand
+    float4 ra[2], rb[2];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = tid + 256 * c;
+            const int row = id >> 2, part = id & 3;
+            const int kc = k0 + part * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            const int gm = m0 + row, gn = n0 + row;
+            if (gm < M) {
+                const float *p = A + (int64_t)gm * lda + kc;
+                if (kc + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+                    va = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (kc + 0 < K) va.x = p[0];
+                    if (kc + 1 < K) va.y = p[1];
+                    if (kc + 2 < K) va.z = p[2];
+                    if (kc + 3 < K) va.w = p[3];
+                }
+            }
+            if (gn < N) {
+                const float *p = B + (int64_t)gn * ldb + kc;
+                if (kc + 3 < K && ((((uintptr_t)p) & 15) == 0)) {
+                    vb = *reinterpret_cast<const float4 *>(p);
+                } else {
+                    if (kc + 0 < K) vb.x = p[0];
+                    if (kc + 1 < K) vb.y = p[1];
+                    if (kc + 2 < K) vb.z = p[2];
+                    if (kc + 3 < K) vb.w = p[3];
+                }
+            }
+            ra[c] = va;
+            rb[c] = vb;
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const int h = lane >> 5;
+    prefetch(0);
+    for (int k0 = 0; k0 < K; k0 += S_BK) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = tid + 256 * c;
+            const int row = id >> 2, part = id & 3;
+            *reinterpret_cast<float4 *>(sA + row * S_PITCH + part * 16) = ra[c];
+            *reinterpret_cast<float4 *>(sB + row * S_PITCH + part * 16) = rb[c];
+        }
+        __syncthreads();
+        if (k0 + S_BK < K) prefetch(k0 + S_BK);
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            // lane (row, h) reads 4 consecutive k at kq*8 + 4*h; MFMA t pairs k = {kq*8+t, kq*8+4+t}
+            float4 fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi] = *reinterpret_cast<const float4 *>(sA + (wm * 64 + mi * 32 + (lane & 31)) * S_PITCH +
+                                                           kq * 32 + h * 16);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                fb[ni] = *reinterpret_cast<const float4 *>(sB + (wn * 64 + ni * 32 + (lane & 31)) * S_PITCH +
+                                                           kq * 32 + h * 16);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int gj = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gr < M && gj < N) C[(int64_t)gr * ldc + gj] = acc[mi][ni][r];
+            }
+        }
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+extern "C" int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *d_lo, int scale_exp,
+                            void *stream) {
+    const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
+    const int64_t total = npad * npad;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail("jxg_ut_split: grid too large");
+    hipLaunchKernelGGL(ut_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_ut, n, npad,
+                       (__half *)d_hi, (__half *)d_lo, ldexpf(1.0f, scale_exp));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                 const float *d_lut, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
+                                 float *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = num_tiles(n);
+    const int64_t npad = (int64_t)nt * JXG_TILE;
+    DevBuf lut16, flags;
+    if (lut16.alloc(sizeof(uint4) * (size_t)nrows)) return 1;
+    if (flags.alloc(sizeof(int))) return 1;
+    JX_HIP(hipMemsetAsync(flags.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(lut_split_r_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, d_lut,
+                       (int64_t)nrows, lut16.as<uint4>(), flags.as<int>());
+    JX_LAUNCH_CHECK();
+    dim3 grid(nt, (nrows + 127) / 128);
+    hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, lut16.as<uint4>(),
+                       (const __half *)d_uhi, (const __half *)d_ulo, npad, n, ldexpf(1.0f, -scale_exp), d_out);
+    JX_LAUNCH_CHECK();
+    int hflag = 0;
+    JX_HIP(hipMemcpyAsync(&hflag, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    if (hflag) return fail("jxg_rotate_packed: design values exceed the fp16 split range");
+    return 0;
+}
+
+extern "C" int jxg_rotate_dense_f32(const float *d_g, int nrows, int n, const float *d_ut, float *d_out,
+                                    void *stream) {
+    if (nrows <= 0) return 0;
+    dim3 grid((n + 127) / 128, (nrows + 127) / 128);
+    hipLaunchKernelGGL(sgemm_nt_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_g, nrows, (int64_t)n, d_ut, n,
+                       (int64_t)n, n, d_out, (int64_t)n);
+    JX_LAUNCH_CHECK();
+    return 0;
+}

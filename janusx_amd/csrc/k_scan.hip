@@ -1,0 +1,737 @@
+// Per-SNP mixed-model kernels on the rotated scale: REML/ML likelihoods, Brent, GLS beta/SE, Wald p,
+// fixed-lambda quadratic forms, X/y rotation, null-model fit.
+//
+// Reference: src/stats/reml.rs:109-198 (rotate X,y), :255-362 (reml_loglike), :364-470 (ml_loglike),
+// :472-568 (final_beta_se), :572-616 (null fit); src/math/brent.rs (Brent); src/math/linalg.rs:2-17, 341-398;
+// src/stats/lmm.rs:94-199 (exact scan); src/stats/fvlmm.rs:1484-1563, 1691-1805 (fixed-lambda scan).
+//
+// One 256-thread workgroup per SNP.  Every objective evaluation is two passes over the n rotated samples
+// (normal equations, then the explicit residual quadratic form, exactly the reference's formulas) with f64
+// wave-shuffle + LDS reductions; the tiny Cholesky/Brent logic runs redundantly in every lane on identical
+// reduced values, so control flow stays workgroup-uniform.
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum NV per-thread values over the workgroup; result broadcast to all threads (in place).
+template <int NV>
+__device__ __forceinline__ void block_sum(double *v, int nv, double *red /* [SCAN_WAVES][NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (k < nv) {
+            const double s = wave_sum(v[k]);
+            if (lane == 0) red[wave * NV + k] = s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (k < nv) {
+            double s = red[k];
+#pragma unroll
+            for (int w = 1; w < SCAN_WAVES; ++w) s += red[w * NV + k];
+            v[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// src/math/linalg.rs:341-363. Fully unrolled with compile-time indices (runtime-indexed register arrays
+// would be demoted to scratch); on a failed pivot the factorisation continues on garbage and reports false.
+template <int MAXD>
+__device__ __forceinline__ bool chol_inplace(double *a, int dim) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {
+        if (i < dim) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double sum = a[i * MAXD + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) sum -= a[i * MAXD + k] * a[j * MAXD + k];
+                if (i == j) {
+                    if (!(sum > 1e-18)) ok = false;
+                    a[i * MAXD + j] = sqrt(sum);
+                } else {
+                    a[i * MAXD + j] = sum / a[j * MAXD + j];
+                }
+            }
+        }
+    }
+    return ok;
+}
+
+// src/stats/reml.rs:46-66 (forward then backward substitution with the lower factor)
+template <int MAXD>
+__device__ __forceinline__ void chol_solve(const double *l, int dim, const double *b, double *x) {
+    double y[MAXD];
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) {
+        y[i] = 0.0;
+        if (i < dim) {
+            double sum = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) sum -= l[i * MAXD + k] * y[k];
+            y[i] = sum / l[i * MAXD + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < MAXD; ++ii) {
+        const int i = MAXD - 1 - ii;
+        if (i < dim) {
+            double sum = y[i];
+#pragma unroll
+            for (int k = i + 1; k < MAXD; ++k)
+                if (k < dim) sum -= l[k * MAXD + i] * x[k];
+            x[i] = sum / l[i * MAXD + i];
+        }
+    }
+}
+
+template <int MAXD>
+__device__ __forceinline__ double pick(const double *v, int idx) {  // v[idx] with compile-time indexing
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k)
+        if (k == idx) r = v[k];
+    return r;
+}
+
+template <int MAXD>
+struct EvalOut {
+    bool ok;
+    double q;        // r' V^-1 r
+    double logdetv;  // sum ln(s+lbd)
+    double logdetx;  // 2 * sum ln L_kk
+    double beta_k;   // last coefficient
+    double ainv_kk;  // [(X'V^-1X + ridge)^-1]_kk
+};
+
+// One full evaluation of the normal equations at lambda (reml.rs:286-344). `g` may be null (null model).
+template <int MAXD>
+__device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const double *__restrict__ xcov,
+                               const double *__restrict__ y, const float *__restrict__ g, int n, int p_cov,
+                               double *shm /* LDS scratch */, EvalOut<MAXD> &o, bool want_ainv) {
+    constexpr int NA = MAXD * (MAXD + 1) / 2;
+    constexpr int NV = NA + MAXD + 2;
+    const int dim = p_cov + (g ? 1 : 0);
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    // v layout: [0, NA) lower triangle row-major (r, c<=r); [NA, NA+MAXD) b; NA+MAXD logdet; NA+MAXD+1 bad count
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double vv = s[i] + lbd;
+        if (vv <= 0.0) v[NA + MAXD + 1] += 1.0;
+        const double vi = 1.0 / vv;
+        const double yi = y[i];
+        double xr[MAXD];
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            if (r < p_cov)
+                xr[r] = xcov[(int64_t)i * p_cov + r];
+            else if (r == p_cov && g)
+                xr[r] = (double)g[i];
+            else
+                xr[r] = 0.0;
+        }
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            const double vx = vi * xr[r];
+            v[NA + r] += vx * yi;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                v[idx] += vx * xr[c];
+                ++idx;
+            }
+        }
+        v[NA + MAXD] += log(vv);
+    }
+    const int nv_used = NV;  // reduce everything (unused slots are zeros)
+    block_sum<NV>(v, nv_used, shm);
+
+    o.ok = true;
+    o.logdetv = v[NA + MAXD];
+    if (v[NA + MAXD + 1] > 0.0) o.ok = false;
+
+    double a[MAXD * MAXD];
+    double b[MAXD], beta[MAXD];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            b[r] = v[NA + r];
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                a[r * MAXD + c] = v[idx];
+                a[c * MAXD + r] = v[idx];
+                ++idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) a[r * MAXD + r] += 1e-6;
+    if (!chol_inplace<MAXD>(a, dim)) o.ok = false;
+    if (!o.ok) {
+        o.q = 0.0;
+        o.logdetx = 0.0;
+        o.beta_k = 0.0;
+        o.ainv_kk = 0.0;
+        return;  // uniform across the workgroup: every thread sees the same reduced values
+    }
+    chol_solve<MAXD>(a, dim, b, beta);
+    double ld = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) ld += log(a[r * MAXD + r]);
+    o.logdetx = 2.0 * ld;
+    o.beta_k = pick<MAXD>(beta, dim - 1);
+    o.ainv_kk = 0.0;
+    if (want_ainv) {
+        double e[MAXD], xk[MAXD];
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) e[r] = (r == dim - 1) ? 1.0 : 0.0;
+        chol_solve<MAXD>(a, dim, e, xk);
+        o.ainv_kk = pick<MAXD>(xk, dim - 1);
+    }
+    // pass 2: explicit residual quadratic form (reml.rs:327-344)
+    double qv[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double vi = 1.0 / (s[i] + lbd);
+        double xb = 0.0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            if (r < p_cov)
+                xb += xcov[(int64_t)i * p_cov + r] * beta[r];
+            else if (r == p_cov && g)
+                xb += (double)g[i] * beta[r];
+        }
+        const double ri = y[i] - xb;
+        qv[0] += vi * ri * ri;
+    }
+    block_sum<1>(qv, 1, shm);
+    o.q = qv[0];
+}
+
+// -reml_loglike (the Brent objective). Failure -> +1e8 (reference returns -1e8 for the log-likelihood).
+template <int MAXD>
+__device__ double neg_reml(double x, const double *s, const double *xcov, const double *y, const float *g, int n,
+                           int p_cov, double *shm) {
+    const double lbd = pow(10.0, x);
+    const int dim = p_cov + (g ? 1 : 0);
+    if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return 1e8;
+    EvalOut<MAXD> o;
+    eval_normal_eq<MAXD>(lbd, s, xcov, y, g, n, p_cov, shm, o, false);
+    if (!o.ok) return 1e8;
+    const double nf = (double)n, pf = (double)dim;
+    const double total = (nf - pf) * log(o.q) + o.logdetv + o.logdetx;
+    const double c = (nf - pf) * (log(nf - pf) - 1.0 - log(2.0 * M_PI)) / 2.0;
+    const double reml = c - 0.5 * total;
+    return isfinite(reml) ? -reml : 1e8;
+}
+
+// src/math/brent.rs:1-136, verbatim control flow (including `e` not being updated on parabolic steps).
+template <int MAXD>
+__device__ void brent_reml(const double *s, const double *xcov, const double *y, const float *g, int n, int p_cov,
+                           double low, double high, double tol, int max_iter, bool has_init, double init,
+                           double *shm, double &xbest, double &fbest, int &evals) {
+    double a = low, c = high;
+    if (!(a < c)) {
+        const double t = a;
+        a = c;
+        c = t;
+    }
+    const double eps = 2.220446049250313e-16;
+    tol = fmax(fabs(tol), 1e-12);
+    double x = (has_init && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
+    double w = x, v = x;
+    double fx = neg_reml<MAXD>(x, s, xcov, y, g, n, p_cov, shm);
+    double fw = fx, fv = fx;
+    double d = 0.0, e = 0.0;
+    evals = 1;
+    for (int it = 0; it < max_iter; ++it) {
+        const double m = 0.5 * (a + c);
+        const double tol1 = tol * fabs(x) + eps;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x - m) <= tol2 - 0.5 * (c - a)) break;
+        double u;
+        bool use_par = false;
+        if (fabs(e) > tol1) {
+            double pq = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw));
+            double q = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)));
+            if (q > 0.0)
+                pq = -pq;
+            else
+                q = -q;
+            bool ok = false;
+            if (fabs(q) > eps) {
+                const double sstep = pq / q;
+                u = x + sstep;
+                if ((u - a) >= tol2 && (c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(e)) ok = true;
+            }
+            if (ok) {
+                d = pq / q;
+                u = x + d;
+                if ((u - a) < tol2 || (c - u) < tol2) d = (x < m) ? tol1 : -tol1;
+                use_par = true;
+            }
+        }
+        if (!use_par) {
+            e = (x < m) ? (c - x) : (a - x);
+            d = 0.3819660 * e;
+        }
+        if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
+        u = x + d;
+        const double fu = neg_reml<MAXD>(u, s, xcov, y, g, n, p_cov, shm);
+        ++evals;
+        if (fu <= fx) {
+            if (u >= x)
+                a = x;
+            else
+                c = x;
+            v = w;
+            fv = fw;
+            w = x;
+            fw = fx;
+            x = u;
+            fx = fu;
+        } else {
+            if (u >= x)
+                c = u;
+            else
+                a = u;
+            if (fu <= fw || w == x) {
+                v = w;
+                fv = fw;
+                w = u;
+                fw = fu;
+            } else if (fu <= fv || v == x || v == w) {
+                v = u;
+                fv = fu;
+            }
+        }
+    }
+    xbest = x;
+    fbest = fx;
+}
+
+__device__ __forceinline__ double chi2_sf_df1_dev(double stat) {  // src/math/linalg.rs:7-17
+    if (!isfinite(stat) || stat <= 0.0) return 1.0;
+    double p = erfc(sqrt(0.5 * stat));
+    if (!isfinite(p)) return 1.0;
+    if (p < 2.2250738585072014e-308) p = 2.2250738585072014e-308;
+    if (p > 1.0) p = 1.0;
+    return p;
+}
+
+// src/stats/lmm.rs:94-199: one workgroup per rotated SNP row.
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__restrict__ grot, int nrows, int n,
+                                                                const double *__restrict__ s,
+                                                                const double *__restrict__ xcov,
+                                                                const double *__restrict__ y, int p_cov, double low,
+                                                                double high, double tol, int max_iter, int warm,
+                                                                double init, int with_plrt, double nullml,
+                                                                double *__restrict__ out,
+                                                                int32_t *__restrict__ evals_out) {
+    constexpr int NV = MAXD * (MAXD + 1) / 2 + MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    const int out_cols = with_plrt ? 4 : 3;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float *g = grot + (int64_t)r * n;
+        double *o = out + (int64_t)r * out_cols;
+        // lmm.rs:63-72: ssq of the rotated row
+        double ssq[1] = {0.0};
+        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+            const double v = (double)g[i];
+            ssq[0] += v * v;
+        }
+        block_sum<1>(ssq, 1, shm);
+        if (!isfinite(ssq[0]) || ssq[0] <= 1e-12) {
+            if (threadIdx.x == 0) {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = 1.0;
+                if (with_plrt) o[3] = 1.0;
+                if (evals_out) evals_out[r] = 0;
+            }
+            continue;
+        }
+        double xb, fb;
+        int ne = 0;
+        brent_reml<MAXD>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, warm != 0, init, shm, xb, fb, ne);
+        // final_beta_se (reml.rs:472-568)
+        const double lbd = pow(10.0, xb);
+        const int dim = p_cov + 1;
+        double beta = nan(""), se = nan("");
+        double qfin = 0.0, ldv = 0.0;
+        bool have = false;
+        if (isfinite(lbd) && lbd > 0.0 && n > dim) {
+            EvalOut<MAXD> e;
+            eval_normal_eq<MAXD>(lbd, s, xcov, y, g, n, p_cov, shm, e, true);
+            if (e.ok) {
+                const double sigma2 = e.q / ((double)n - (double)dim);
+                const double var = sigma2 * e.ainv_kk;
+                if (var > 0.0 && isfinite(var)) {
+                    beta = e.beta_k;
+                    se = sqrt(var);
+                }
+                qfin = e.q;
+                ldv = e.logdetv;
+                have = true;
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (evals_out) evals_out[r] = ne;
+            if (isfinite(beta) && isfinite(se) && se > 0.0) {
+                const double z = beta / se;
+                double pv = 2.0 * (0.5 * erfc(fabs(z) / 1.4142135623730951));
+                if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                if (pv > 1.0) pv = 1.0;
+                o[0] = beta;
+                o[1] = se;
+                o[2] = isfinite(pv) ? pv : 1.0;
+                if (with_plrt) {
+                    // ml_loglike at the optimum (reml.rs:364-470): same normal equations, ML constant
+                    double plrt = 1.0;
+                    if (have && isfinite(qfin) && qfin > 0.0) {
+                        const double nf = (double)n;
+                        const double ml = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * log(qfin) + ldv);
+                        if (isfinite(ml)) {
+                            double stat = 2.0 * (ml - nullml);
+                            if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                            plrt = chi2_sf_df1_dev(stat);
+                        }
+                    }
+                    o[3] = plrt;
+                }
+            } else {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = 1.0;
+                if (with_plrt) o[3] = 1.0;
+            }
+        }
+    }
+}
+
+// Null model: Brent on -REML without a SNP column, then ML at the optimum (reml.rs:572-616).
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm_null_kernel(const double *__restrict__ s,
+                                                                const double *__restrict__ xcov,
+                                                                const double *__restrict__ y, int n, int p_cov,
+                                                                double low, double high, double tol, int max_iter,
+                                                                double *__restrict__ out3) {
+    constexpr int NV = MAXD * (MAXD + 1) / 2 + MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    double xb, fb;
+    int ne = 0;
+    brent_reml<MAXD>(s, xcov, y, nullptr, n, p_cov, low, high, tol, max_iter, false, 0.0, shm, xb, fb, ne);
+    const double lbd = pow(10.0, xb);
+    double ml = -1e8;
+    if (isfinite(lbd) && lbd > 0.0 && n > p_cov) {
+        EvalOut<MAXD> e;
+        eval_normal_eq<MAXD>(lbd, s, xcov, y, nullptr, n, p_cov, shm, e, false);
+        if (e.ok && isfinite(e.q) && e.q > 0.0) {
+            const double nf = (double)n;
+            const double v = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * log(e.q) + e.logdetv);
+            ml = isfinite(v) ? v : -1e8;
+        }
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = lbd;
+        out3[1] = ml;
+        out3[2] = -fb;
+    }
+}
+
+// X~ = U^T [X | y]: one workgroup per output row (reml.rs:157-170: f32 U^T widened, f64 accumulation).
+__global__ __launch_bounds__(SCAN_THREADS) void rotate_xy_kernel(const float *__restrict__ ut, int n,
+                                                                 const double *__restrict__ xy, int q,
+                                                                 double *__restrict__ out) {
+    __shared__ double shm[SCAN_WAVES * 16];
+    const int i = blockIdx.x;
+    const float *row = ut + (int64_t)i * n;
+    double v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = 0.0;
+    for (int j = threadIdx.x; j < n; j += SCAN_THREADS) {
+        const double u = (double)row[j];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < q) v[c] += u * xy[(int64_t)j * q + c];
+    }
+    block_sum<16>(v, q, shm);
+    if (threadIdx.x == 0)
+        for (int c = 0; c < q; ++c) out[(int64_t)i * q + c] = v[c];
+}
+
+// Fixed-lambda cache, single workgroup (fvlmm.rs:1484-1563). scal = (ypy, log_det_v, status) ; a_chol p*p.
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void fvlmm_prepare_kernel(const double *__restrict__ s,
+                                                                     const double *__restrict__ xcov,
+                                                                     const double *__restrict__ y, int n, int p,
+                                                                     double lbd, float *__restrict__ w,
+                                                                     float *__restrict__ py, float *__restrict__ wx,
+                                                                     double *__restrict__ a_chol_out,
+                                                                     double *__restrict__ scal) {
+    constexpr int NA = MAXD * (MAXD + 1) / 2;
+    constexpr int NV = NA + MAXD + 3;
+    __shared__ double shm[SCAN_WAVES * NV];
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double vv = s[i] + lbd;
+        if (!(isfinite(vv) && vv > 0.0)) v[NA + MAXD + 2] += 1.0;
+        const float wf = (float)(1.0 / vv);
+        w[i] = wf;
+        v[NA + MAXD + 1] += log(vv);
+        const double wi = (double)wf;
+        const double yi = y[i];
+        v[NA + MAXD] += wi * yi * yi;
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            const double xir = (r < p) ? xcov[(int64_t)i * p + r] : 0.0;
+            v[NA + r] += wi * xir * yi;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                const double xic = (c < p) ? xcov[(int64_t)i * p + c] : 0.0;
+                v[idx] += wi * xir * xic;
+                ++idx;
+            }
+        }
+    }
+    block_sum<NV>(v, NV, shm);
+    double a[MAXD * MAXD], b[MAXD], aib[MAXD];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            b[r] = v[NA + r];
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                a[r * MAXD + c] = v[idx];
+                a[c * MAXD + r] = v[idx];
+                ++idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < p) a[r * MAXD + r] += 1e-6;
+    double status = 0.0;
+    if (v[NA + MAXD + 2] > 0.0) status = 1.0;                        // non-positive s[i]+lbd
+    if (status == 0.0 && !chol_inplace<MAXD>(a, p)) status = 2.0;     // X'WX not SPD
+    if (status != 0.0) {
+        if (threadIdx.x == 0) {
+            scal[0] = 0.0;
+            scal[1] = 0.0;
+            scal[2] = status;
+        }
+        return;
+    }
+    chol_solve<MAXD>(a, p, b, aib);
+    double dotv = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < p) dotv += b[r] * aib[r];
+    const double ypy = fmax(v[NA + MAXD] - dotv, 0.0);
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double wi = (double)w[i];
+        double x_aib = 0.0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            if (r < p) {
+                const double xir = xcov[(int64_t)i * p + r];
+                wx[(int64_t)i * p + r] = (float)(wi * xir);
+                x_aib += xir * aib[r];
+            }
+        }
+        py[i] = (float)(wi * (y[i] - x_aib));
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r)
+#pragma unroll
+            for (int c = 0; c < MAXD; ++c)
+                if (r < p && c < p) a_chol_out[r * p + c] = (c <= r) ? a[r * MAXD + c] : 0.0;
+        scal[0] = ypy;
+        scal[1] = v[NA + MAXD + 1];
+        scal[2] = 0.0;
+    }
+}
+
+// Fixed-lambda scan (fvlmm.rs:1691-1805): num = g.Py~, c = g.WX~, d = sum w g^2, Schur complement, Wald test.
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *__restrict__ grot, int nrows, int n,
+                                                                  int p, const float *__restrict__ w,
+                                                                  const float *__restrict__ py,
+                                                                  const float *__restrict__ wx,
+                                                                  const double *__restrict__ a_chol, double ypy,
+                                                                  int df, double *__restrict__ out) {
+    constexpr int NV = MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    double l[MAXD * MAXD];
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) l[r * MAXD + c] = (r < p && c < p) ? a_chol[r * p + c] : (r == c ? 1.0 : 0.0);
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const float *g = grot + (int64_t)r * n;
+        double v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = 0.0;
+        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+            const double gi = (double)g[i];
+            v[0] += (double)w[i] * gi * gi;
+            v[1] += gi * (double)py[i];
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k)
+                if (k < p) v[2 + k] += gi * (double)wx[(int64_t)i * p + k];
+        }
+        block_sum<NV>(v, 2 + p, shm);
+        if (threadIdx.x == 0) {
+            double *o = out + (int64_t)r * 3;
+            double c[MAXD], aic[MAXD];
+            // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) c[k] = (k < p) ? (double)(float)v[2 + k] : 0.0;
+            chol_solve<MAXD>(l, p, c, aic);
+            double ct = 0.0;
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k)
+                if (k < p) ct += c[k] * aic[k];
+            const double schur = v[0] - ct;
+            if (schur <= 1e-12 || !isfinite(schur)) {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = nan("");
+            } else {
+                const double nu = (double)(float)v[1];
+                const double beta = nu / schur;
+                const double rwr = fmax(ypy - (nu * nu) / schur, 0.0);
+                const double sigma2 = rwr / (double)df;
+                const double se = sqrt(sigma2 / schur);
+                double pv = 1.0;
+                if (isfinite(se) && se > 0.0 && isfinite(beta)) {
+                    pv = 2.0 * (0.5 * erfc(fabs(beta / se) / 1.4142135623730951));
+                    if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                    if (pv > 1.0) pv = 1.0;
+                }
+                o[0] = beta;
+                o[1] = se;
+                o[2] = pv;
+            }
+        }
+    }
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+#define JX_DISPATCH_DIM(dim, EXPR)                       \
+    do {                                                 \
+        if ((dim) <= 2) {                                \
+            constexpr int MAXD = 2;                      \
+            EXPR;                                        \
+        } else if ((dim) <= 4) {                         \
+            constexpr int MAXD = 4;                      \
+            EXPR;                                        \
+        } else if ((dim) <= 8) {                         \
+            constexpr int MAXD = 8;                      \
+            EXPR;                                        \
+        } else {                                         \
+            constexpr int MAXD = 16;                     \
+            EXPR;                                        \
+        }                                                \
+    } while (0)
+
+extern "C" int jxg_rotate_xy(const float *d_ut, int n, const double *d_xy, int q, double *d_out, void *stream) {
+    if (q < 1 || q > 16) return fail("jxg_rotate_xy: q must be in [1,16]");
+    hipLaunchKernelGGL(rotate_xy_kernel, dim3(n), dim3(SCAN_THREADS), 0, (hipStream_t)stream, d_ut, n, d_xy, q, d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
+                                 double low, double high, int max_iter, double tol, double *d_out3, void *stream) {
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_reml_null: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(lmm_null_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
+                                          d_s, d_xcov, d_y, n, p, low, high, tol, max_iter, d_out3));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                            const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                            double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                            void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    const int dim = p + 1;
+    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    JX_DISPATCH_DIM(dim, hipLaunchKernelGGL(lmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                            (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high,
+                                            tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out, d_evals));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
+                                 double lbd, float *d_w, float *d_py, float *d_wx, double *h_a_chol,
+                                 double *h_scalars3) {
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_prepare: p out of range");
+    DevBuf tmp;
+    if (tmp.alloc(sizeof(double) * (size_t)(p * p + 3))) return 1;
+    double *d_a = tmp.as<double>();
+    double *d_sc = d_a + p * p;
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_prepare_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, (hipStream_t)0,
+                                          d_s, d_xcov, d_y, n, p, lbd, d_w, d_py, d_wx, d_a, d_sc));
+    JX_LAUNCH_CHECK();
+    double sc[3];
+    JX_HIP(hipMemcpy(sc, d_sc, sizeof(sc), hipMemcpyDeviceToHost));
+    if (sc[2] == 1.0) return fail("non-positive s[i]+lbd");
+    if (sc[2] == 2.0) return fail("X'WX not SPD");
+    JX_HIP(hipMemcpy(h_a_chol, d_a, sizeof(double) * p * p, hipMemcpyDeviceToHost));
+    const int df = n - p - 1;
+    if (df <= 0) return fail("df <= 0");
+    h_scalars3[0] = sc[0];
+    h_scalars3[1] = sc[1];
+    h_scalars3[2] = (double)df;
+    return 0;
+}
+
+extern "C" int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
+                              const float *d_wx, const double *h_a_chol, double ypy, int df, double *d_out,
+                              void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_scan: p out of range");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf a;
+    if (a.alloc(sizeof(double) * p * p)) return 1;
+    JX_HIP(hipMemcpyAsync(a.p, h_a_chol, sizeof(double) * p * p, hipMemcpyHostToDevice, st));
+    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0, st, d_grot,
+                                          nrows, n, p, d_w, d_py, d_wx, a.as<double>(), ypy, df, d_out));
+    JX_LAUNCH_CHECK();
+    JX_HIP(hipStreamSynchronize(st));
+    return 0;
+}

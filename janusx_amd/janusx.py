@@ -1,0 +1,379 @@
+"""Drop-in mirror of the reference's native module ``janusx.janusx`` for the mixed-model hot path.
+
+Every function here has the name, argument meaning, defaults and error behaviour of the PyO3 function it
+replaces (signatures: /root/reference/src/lib.rs:691-1005 registrations, ``#[pyo3(signature=...)]`` at the cited
+lines) and forwards to the HIP library through the C ABI (``include/jxgpu.h``, host layer).  Arguments that only
+steer CPU threading in the reference (``threads``, ``block_cols``, ``rotate_block_rows``, ``mmap_window_mb``) are
+accepted and ignored; ``progress_callback(done, total)`` is called once at completion.
+
+A reference call site such as ``jxrs.grm_packed_f32(packed, n, flip, maf, idx, method=1)`` works unchanged
+with ``import janusx_amd.janusx as jxrs``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _opt_idx(a):
+    if a is None:
+        return None, 0
+    a = _c(a, np.int64).ravel()
+    return a, int(a.shape[0])
+
+
+def _done(cb, total):
+    if cb is not None:
+        cb(int(total), int(total))
+
+
+# ------------------------------------------------------------------------------------------------
+# GRM  (src/stats/grm.rs)
+# ------------------------------------------------------------------------------------------------
+
+def _grm_packed(packed, n_samples, row_flip, row_maf, sample_indices, method, out_dtype, with_stats):
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    m = int(packed.shape[0])
+    n_samples = int(n_samples)
+    if n_samples <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if m == 0:
+        raise RuntimeError("packed must contain at least one SNP row")
+    bps = (n_samples + 3) // 4
+    if packed.shape[1] != bps:
+        raise RuntimeError(f"packed length mismatch: got {packed.size}, expected {m * bps}")
+    flip = _c(np.asarray(row_flip).astype(np.uint8), np.uint8).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if maf.shape[0] != m or flip.shape[0] != m:
+        raise RuntimeError(f"row_maf length mismatch: got {maf.shape[0]}, expected {m}")
+    idx, n_sel = _opt_idx(sample_indices)
+    n = n_sel if idx is not None else n_samples
+    out = np.empty((n, n), dtype=out_dtype)
+    row_sum = np.zeros(m, dtype=np.float64) if with_stats else None
+    varsum = np.zeros(1, dtype=np.float64)
+    check(lib().jx_grm_packed(_p(packed), m, n_samples, _p(flip), _p(maf), _p(idx), n_sel, int(method), _p(out),
+                              1 if out_dtype == np.float64 else 0, _p(row_sum), _p(varsum)))
+    return out, row_sum, float(varsum[0])
+
+
+def grm_packed_f32(packed, n_samples, row_flip, row_maf, sample_indices=None, method=1, block_cols=65536,
+                   threads=0, progress_callback=None, progress_every=0):
+    """src/stats/grm.rs:3053-3066 -> f32 (n, n)."""
+    k, _, _ = _grm_packed(packed, n_samples, row_flip, row_maf, sample_indices, method, np.float32, False)
+    _done(progress_callback, np.asarray(packed).shape[0])
+    return k
+
+
+def grm_packed_f64(packed, n_samples, row_flip, row_maf, sample_indices=None, method=1, block_cols=65536,
+                   threads=0, progress_callback=None, progress_every=0):
+    """src/stats/grm.rs:3596 -> f64 (n, n) (same f32-block/f64-merge arithmetic as the f32 entry)."""
+    k, _, _ = _grm_packed(packed, n_samples, row_flip, row_maf, sample_indices, method, np.float64, False)
+    _done(progress_callback, np.asarray(packed).shape[0])
+    return k
+
+
+def grm_packed_f32_with_stats(packed, n_samples, row_flip, row_maf, sample_indices=None, method=1,
+                              block_cols=65536, threads=0, progress_callback=None, progress_every=0):
+    """src/stats/grm.rs:5583 -> (f32 (n,n), row_sum f64 (m), varsum)."""
+    k, rs, vs = _grm_packed(packed, n_samples, row_flip, row_maf, sample_indices, method, np.float32, True)
+    _done(progress_callback, np.asarray(packed).shape[0])
+    return k, rs, vs
+
+
+def grm_packed_f64_with_stats(packed, n_samples, row_flip, row_maf, sample_indices=None, method=1,
+                              block_cols=65536, threads=0, progress_callback=None, progress_every=0):
+    """src/stats/grm.rs:5611-5651 -> (f64 (n,n), row_sum f64 (m), varsum)."""
+    k, rs, vs = _grm_packed(packed, n_samples, row_flip, row_maf, sample_indices, method, np.float64, True)
+    _done(progress_callback, np.asarray(packed).shape[0])
+    return k, rs, vs
+
+
+def _read_bed_payload(prefix):
+    """PLINK .bed payload as (m, bps) uint8 plus n_samples (src/stats/lmm.rs:1050-1061, gfcore.rs:307-323)."""
+    from .bed import read_bed_payload
+    return read_bed_payload(prefix)
+
+
+def grm_stream_bed_f32(prefix, method=1, maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0,
+                       snps_only=False, block_cols=65536, threads=0, progress_callback=None, progress_every=0,
+                       mmap_window_mb=None):
+    """src/stats/grm.rs:4676-4703 -> (f32 (n,n), eff_m, n_samples)."""
+    packed, n_samples, bim = _read_bed_payload(prefix)
+    if snps_only:
+        from .bed import snps_only_mask
+        packed = np.ascontiguousarray(packed[snps_only_mask(bim)])
+    k, eff, _ = grm_stream_payload_f32(packed, n_samples, method, maf_threshold, max_missing_rate, het_threshold)
+    _done(progress_callback, packed.shape[0])
+    return k, int(eff), int(n_samples)
+
+
+def grm_stream_payload_f32(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
+                           het_threshold=0.0):
+    """In-memory form of `grm_stream_bed_f32` -> (K f32, eff_m, keep mask)."""
+    packed = _c(packed, np.uint8)
+    m = int(packed.shape[0])
+    n = int(n_samples)
+    out = np.empty((n, n), dtype=np.float32)
+    eff = np.zeros(1, dtype=np.int64)
+    keep = np.zeros(m, dtype=np.uint8)
+    check(lib().jx_grm_stream_payload_f32(_p(packed), m, n, int(method), float(maf_threshold),
+                                          float(max_missing_rate), float(het_threshold), _p(out), _p(eff), _p(keep)))
+    return out, int(eff[0]), keep.astype(bool)
+
+
+def grm_stream_bed_f32_to_npy(prefix, out_path, method=1, maf_threshold=0.02, max_missing_rate=0.05,
+                              het_threshold=0.0, snps_only=False, block_cols=65536, threads=0,
+                              progress_callback=None, progress_every=0, mmap_window_mb=None):
+    """src/stats/grm.rs:5517-5545: writes NPY v1 f32 C-order, returns (eff_m, n_samples)."""
+    k, eff, n = grm_stream_bed_f32(prefix, method, maf_threshold, max_missing_rate, het_threshold, snps_only)
+    tmp = f"{out_path}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        np.lib.format.write_array(fh, np.ascontiguousarray(k, dtype=np.float32), version=(1, 0))
+    os.replace(tmp, out_path)
+    _done(progress_callback, eff)
+    return eff, n
+
+
+# ------------------------------------------------------------------------------------------------
+# eigh  (src/math/eigh.rs)
+# ------------------------------------------------------------------------------------------------
+
+def rust_eigh_from_array_f64(a, threads=0, driver=None, jobz="V", require_lapack=False, diag_shift=0.0):
+    """src/math/eigh.rs:1621-1703 -> 10-tuple (evals asc, evecs (columns) or None, blas_backend, evd_backend,
+    n, threads_before, threads_in_stage, threads_after, lapack_used, elapsed_s)."""
+    a = _c(a, np.float64)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise RuntimeError("matrix must be square")
+    n = int(a.shape[0])
+    t0 = time.perf_counter()
+    evals = np.empty(n, dtype=np.float64)
+    want = str(jobz).upper() != "N"
+    evecs = np.empty((n, n), dtype=np.float64) if want else None
+    check(lib().jx_eigh_f64(_p(a), n, float(diag_shift), _p(evals), _p(evecs)))
+    return (evals, evecs, "rocblas", "rocsolver_dsyevd", n, 0, 0, 0, True, time.perf_counter() - t0)
+
+
+rust_eigh_from_array_f64_inplace = rust_eigh_from_array_f64
+
+
+def rust_eigh_from_matrix_file_f64(path, threads=0, driver=None, jobz="V", require_lapack=False, diag_shift=0.0):
+    """src/math/eigh.rs:1707-1786: `.npy` (f32/f64 C-order) or whitespace text matrix."""
+    a = np.load(path) if str(path).endswith(".npy") else np.loadtxt(path)
+    return rust_eigh_from_array_f64(np.asarray(a, dtype=np.float64), threads, driver, jobz, require_lapack, diag_shift)
+
+
+def rust_eigh_from_matrix_file_subset_f64(path, subset, threads=0, driver=None, jobz="V", require_lapack=False,
+                                          diag_shift=0.0):
+    """src/math/eigh.rs:1788-1880."""
+    a = np.load(path, mmap_mode="r") if str(path).endswith(".npy") else np.loadtxt(path)
+    ix = np.asarray(subset, dtype=np.int64)
+    sub = np.asarray(a[np.ix_(ix, ix)], dtype=np.float64)
+    return rust_eigh_from_array_f64(sub, threads, driver, jobz, require_lapack, diag_shift)
+
+
+def rust_sgemm_backend():
+    return "hip-mfma-gfx950"
+
+
+def rust_eigh_lapack_backend():
+    return "rocsolver"
+
+
+def rust_blas_get_num_threads():
+    return 0
+
+
+def rust_blas_set_num_threads(n):
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# null model helpers  (src/stats/reml.rs)
+# ------------------------------------------------------------------------------------------------
+
+def lmm_rotate_x_y_with_ut_f64(u_t, x, y, threads=0):
+    """src/stats/reml.rs:107-198 -> (f64 (n,q), f64 (n,1))."""
+    y = _c(y, np.float64).ravel()
+    n = int(y.shape[0])
+    if n == 0:
+        raise RuntimeError("y must not be empty")
+    x = _c(x, np.float64)
+    if x.ndim != 2:
+        raise RuntimeError("x must be 2D (n, q)")
+    if x.shape[0] != n:
+        raise RuntimeError(f"x rows must equal len(y): rows={x.shape[0]}, len(y)={n}")
+    u_t = _c(u_t, np.float32)
+    if u_t.ndim != 2 or u_t.shape != (n, n):
+        raise RuntimeError("u_t must be shape (n, n) and row-major U^T")
+    q = int(x.shape[1])
+    ox = np.empty((n, q), dtype=np.float64)
+    oy = np.empty((n, 1), dtype=np.float64)
+    check(lib().jx_lmm_rotate_x_y_with_ut_f64(_p(u_t), n, _p(x), q, _p(y), _p(ox), _p(oy)))
+    return ox, oy
+
+
+def _null_args(s, xcov, y_rot):
+    s = _c(s, np.float64).ravel()
+    xcov = _c(xcov, np.float64)
+    y = _c(y_rot, np.float64).ravel()
+    n = int(y.shape[0])
+    if xcov.ndim != 2 or xcov.shape[0] != n:
+        raise RuntimeError("Xcov.n_rows must equal len(y_rot)")
+    if s.shape[0] != n:
+        raise RuntimeError("len(S) must equal len(y_rot)")
+    return s, xcov, y, n, int(xcov.shape[1])
+
+
+def lmm_reml_null_f32(s, xcov, y_rot, low, high, max_iter=50, tol=1e-2):
+    """src/stats/reml.rs:570-616 -> (lbd, ml, reml)."""
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    out = np.zeros(3, dtype=np.float64)
+    check(lib().jx_lmm_reml_null(_p(s), _p(xcov), _p(y), n, p, float(low), float(high), int(max_iter), float(tol),
+                                 _p(out)))
+    return float(out[0]), float(out[1]), float(out[2])
+
+
+# ------------------------------------------------------------------------------------------------
+# exact per-SNP scan  (src/stats/lmm.rs)
+# ------------------------------------------------------------------------------------------------
+
+def _chunk(s, xcov, y_rot, low, high, chunk, u_t, max_iter, tol, nullml, what):
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    g = _c(chunk, np.float32)
+    if g.ndim != 2 or g.shape[1] != n:
+        raise RuntimeError(f"{what} must be (m_chunk, n)")
+    if u_t is not None:
+        u_t = _c(u_t, np.float32)
+        if u_t.shape != (n, n):
+            raise RuntimeError("u_t must be (n, n) and row-major U^T")
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    m = int(g.shape[0])
+    cols = 4 if nullml is not None else 3
+    out = np.zeros((m, cols), dtype=np.float64)
+    check(lib().jx_lmm_reml_chunk(_p(s), _p(xcov), _p(y), n, p, float(low), float(high), _p(g), m, _p(u_t),
+                                  int(max_iter), float(tol), 1 if nullml is not None else 0,
+                                  float(nullml if nullml is not None else 0.0), _p(out)))
+    return out
+
+
+def lmm_reml_chunk_f32(s, xcov, y_rot, low, high, g_rot_chunk, max_iter=50, tol=1e-2, threads=0, nullml=None):
+    """src/stats/lmm.rs:333-335 (already rotated rows) -> f64 (m, 3 or 4)."""
+    return _chunk(s, xcov, y_rot, low, high, g_rot_chunk, None, max_iter, tol, nullml, "g_rot_chunk")
+
+
+def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_iter=50, tol=1e-2, threads=0,
+                                nullml=None, rotate_block_rows=256):
+    """src/stats/lmm.rs:1479-1630 (rotate then scan, no warm start) -> f64 (m, 3 or 4)."""
+    return _chunk(s, xcov, y_rot, low, high, snp_chunk, u_t, max_iter, tol, nullml, "snp_chunk")
+
+
+def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
+                  low, high, max_iter, tol, warm, init):
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    packed = _c(packed, np.uint8)
+    if row_indices is not None:
+        ri = np.asarray(row_indices, dtype=np.int64)
+        packed = np.ascontiguousarray(packed[ri])
+    m = int(packed.shape[0])
+    flip = _c(np.asarray(row_flip).astype(np.uint8), np.uint8).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    u_t = _c(u_t, np.float32)
+    if u_t.shape != (n, n):
+        raise RuntimeError("u_t must be (n, n) and row-major U^T")
+    idx, n_sel = _opt_idx(sample_indices)
+    n_eff = n_sel if idx is not None else int(n_samples)
+    if n_eff != n:
+        raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
+    out = np.zeros((m, 3), dtype=np.float64)
+    check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
+                                _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
+                                int(warm), float(init), _p(out)))
+    return out
+
+
+def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices=None,
+                              row_indices=None, low=-5.0, high=5.0, max_iter=50, tol=1e-2, threads=0, model="add",
+                              progress_callback=None, progress_every=0, nullml=None, init_log10_lbd=None,
+                              rotate_block_rows=256):
+    """src/stats/lmm.rs:3040-3362 -> f64 (m, 3).
+
+    Warm start: the reference chains each SNP's optimum into the next one *per rayon work split*
+    (lmm.rs:134-140), which makes its output depend on thread scheduling.  This implementation is
+    deterministic: every SNP starts from `init_log10_lbd` when given (the head of the reference's chain),
+    else from the interval midpoint (the reference's `JX_LMM_UNIFIED_NO_WARM_START` / core-API behaviour)."""
+    if str(model) != "add":
+        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
+    if nullml is not None:
+        raise RuntimeError("nullml/plrt output is not built for the packed route yet")
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    if not (np.isfinite(tol) and tol > 0):
+        raise RuntimeError("tol must be positive and finite")
+    warm, init = 0, 0.0
+    if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
+        warm, init = 1, float(min(max(init_log10_lbd, low), high))
+    out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
+                        low, high, max_iter, tol, warm, init)
+    _done(progress_callback, out.shape[0])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fixed-lambda scan  (src/stats/fvlmm.rs)
+# ------------------------------------------------------------------------------------------------
+
+def _fv_chunk(s, xcov, y_rot, log10_lbd, chunk, u_t, nullml, what):
+    if nullml is not None:
+        raise RuntimeError("nullml/plrt output is not built for the fixed-lambda route yet")
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    g = _c(chunk, np.float32)
+    if g.ndim != 2 or g.shape[1] != n:
+        raise RuntimeError(f"{what} must be (m_chunk, n)")
+    if u_t is not None:
+        u_t = _c(u_t, np.float32)
+        if u_t.shape != (n, n):
+            raise RuntimeError("u_t must be (n, n) and row-major U^T")
+    m = int(g.shape[0])
+    out = np.zeros((m, 3), dtype=np.float64)
+    check(lib().jx_fvlmm_assoc_chunk(_p(s), _p(xcov), _p(y), n, p, float(log10_lbd), _p(g), m, _p(u_t), _p(out)))
+    return out
+
+
+def fvlmm_assoc_chunk_f32(s, xcov, y_rot, log10_lbd, g_rot_chunk, threads=0, nullml=None):
+    """src/stats/fvlmm.rs:1941-1994 -> f64 (m, 3)."""
+    return _fv_chunk(s, xcov, y_rot, log10_lbd, g_rot_chunk, None, nullml, "g_rot_chunk")
+
+
+def fvlmm_assoc_chunk_from_snp_f32(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, threads=0, nullml=None,
+                                   rotate_block_rows=512):
+    """src/stats/fvlmm.rs:2114-2262 -> f64 (m, 3)."""
+    return _fv_chunk(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, nullml, "snp_chunk")
+
+
+def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, log10_lbd,
+                           sample_indices=None, row_indices=None, threads=0, progress_callback=None,
+                           progress_every=0, rotate_block_rows=512):
+    """Array-returning core of `fvlmm_assoc_packed_f32_to_tsv` (src/stats/fvlmm.rs:4958-5190) with a
+    caller-rotated null model -> f64 (m, 3)."""
+    out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 1,
+                        float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0)
+    _done(progress_callback, out.shape[0])
+    return out

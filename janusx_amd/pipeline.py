@@ -1,0 +1,329 @@
+"""HBM-resident end-to-end mixed-model pipeline: GRM -> eigh -> null REML -> per-SNP scan.
+
+This is the path `bench.py` times and the multi-GPU driver shards.  torch is used only as plumbing (device
+buffers, streams, `torch.distributed`); every computation is a libjxgpu kernel called through the C ABI.
+
+Mirrors the reference's call stack for `jx gwas -lmm/-fvlmm`:
+  build_grm_streaming (python/janusx/assoc/workflow.py:2928) -> grm_stream_bed_f32 (src/stats/grm.rs:4690)
+  _gwas_eigh_from_grm (workflow.py:5509, ridge 1e-6)      -> rust_eigh_* (src/math/eigh.rs:1422)
+  LMM._initialize_from_spectral (python/janusx/pyBLUP/assoc.py:1726-1876)
+  lmm_reml_assoc_bed_to_tsv_f32 / fvlmm_assoc_bed_to_tsv_f32 (src/stats/lmm.rs:2513, src/stats/fvlmm.rs:2502)
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import stats as st
+from ._lib import check, lib
+
+SCALE_EXP = 10  # U^T planes are scaled by 2^10 before the fp16 split (keeps the lo plane out of subnormals)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class NullFit:
+    lbd: float
+    ml0: float
+    reml0: float
+    sigma_g2: float
+    sigma_e2: float
+    pve: float
+    bounds: tuple
+
+
+@dataclass
+class StageTimes:
+    t: dict = field(default_factory=dict)
+
+    def add(self, key, dt):
+        self.t[key] = self.t.get(key, 0.0) + dt
+
+
+class Panel:
+    """A 2-bit genotype payload resident in HBM in the internal P32 tiling."""
+
+    def __init__(self, packed: torch.Tensor, n_samples: int, sample_idx=None):
+        assert packed.is_cuda and packed.dtype == torch.uint8 and packed.dim() == 2
+        self.device = packed.device
+        self.m = int(packed.shape[0])
+        self.n_src = int(n_samples)
+        bps = int(packed.shape[1])
+        if bps != (self.n_src + 3) // 4:
+            raise RuntimeError(f"packed length mismatch: got {bps} bytes per SNP, expected {(self.n_src + 3) // 4}")
+        idx_t = None
+        if sample_idx is not None:
+            idx = np.asarray(sample_idx, dtype=np.int64)
+            if idx.size == 0:
+                raise RuntimeError("sample_indices must not be empty")
+            if idx.min() < 0 or idx.max() >= self.n_src:
+                raise RuntimeError(f"sample index out of range: {int(idx.max())} >= {self.n_src}")
+            if not (idx.size == self.n_src and np.array_equal(idx, np.arange(self.n_src))):
+                idx_t = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+            self.n = int(idx.size)
+        else:
+            self.n = self.n_src
+        self.nt = lib().jxg_num_tiles(self.n)
+        self.npad = self.nt * 128
+        self.p32 = torch.empty((self.nt, self.m, 32), dtype=torch.uint8, device=self.device)
+        check(lib().jxg_repack_p32(_ptr(packed), bps, self.n_src, self.m, _ptr(idx_t), self.n, None, self.m,
+                                   _ptr(self.p32), _stream()))
+        self._counts = None
+
+    def counts(self) -> np.ndarray:
+        """(m,3) int32 (missing, het, hom_alt) over the selected samples (host copy, cached)."""
+        if self._counts is None:
+            c = torch.empty((self.m, 3), dtype=torch.int32, device=self.device)
+            check(lib().jxg_row_counts_p32(_ptr(self.p32), self.m, self.n, _ptr(c), _stream()))
+            self._counts = c.cpu().numpy()
+        return self._counts
+
+
+def grm_accumulate(panel: Panel, rows: np.ndarray, lut: np.ndarray, acc: torch.Tensor = None, kchunk=0):
+    """acc (npad,npad) f64 += Z Z^T over the given SNP rows with their (len(rows),4) f32 value LUT."""
+    dev = panel.device
+    if acc is None:
+        acc = torch.zeros((panel.npad, panel.npad), dtype=torch.float64, device=dev)
+    if len(rows) == 0:
+        return acc
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    check(lib().jxg_grm_accumulate(_ptr(panel.p32), panel.m, panel.n, _ptr(rows_t), _ptr(lut_t), len(rows),
+                                   _ptr(acc), int(kchunk), 0, _stream()))
+    return acc
+
+
+def grm_finalize(acc: torch.Tensor, n: int, scale: float, dtype=torch.float32):
+    out = torch.empty((n, n), dtype=dtype, device=acc.device)
+    check(lib().jxg_grm_finalize(_ptr(acc), n, 1.0 / float(scale), _ptr(out), 1 if dtype == torch.float64 else 0,
+                                 _stream()))
+    return out
+
+
+def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
+    """K (n,n) f32/f64 on device -> (S f64 (k), U^T f64 (k,k) row j = eigenvector j)."""
+    dev = k.device
+    n = int(k.shape[0])
+    idx = np.arange(n, dtype=np.int32) if subset_idx is None else np.asarray(subset_idx, dtype=np.int32)
+    kk = int(idx.shape[0])
+    idx_t = torch.from_numpy(idx).to(dev)
+    a = torch.empty((kk, kk), dtype=torch.float64, device=dev)
+    check(lib().jxg_gather_sub_f64(_ptr(k), 1 if k.dtype == torch.float64 else 0, n, _ptr(idx_t), kk, _ptr(a),
+                                   _stream()))
+    check(lib().jxg_symmetrize_f64(_ptr(a), kk, _stream()))
+    w = torch.empty(kk, dtype=torch.float64, device=dev)
+    check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
+    return w, a
+
+
+class SpectralModel:
+    """Device-resident counterpart of `LMM.from_spectral` (python/janusx/pyBLUP/assoc.py:1702-1876)."""
+
+    def __init__(self, s: torch.Tensor, ut64: torch.Tensor, x: np.ndarray, y: np.ndarray):
+        dev = s.device
+        self.n = n = int(s.shape[0])
+        self.S = s
+        self.ut = torch.empty((n, n), dtype=torch.float32, device=dev)  # Dh = float32(U^T)
+        check(lib().jxg_cast_f64_to_f32(_ptr(ut64), _ptr(self.ut), n * n, _stream()))
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+        if x.ndim != 2 or x.shape[0] != n or y.shape[0] != n:
+            raise RuntimeError(f"design row mismatch: got {x.shape[0]}, expected {n}")
+        self.p = p = int(x.shape[1])
+        xy = torch.from_numpy(np.concatenate([x, y[:, None]], axis=1)).to(dev)
+        rot = torch.empty_like(xy)
+        check(lib().jxg_rotate_xy(_ptr(self.ut), n, _ptr(xy), p + 1, _ptr(rot), _stream()))
+        self.xcov = rot[:, :p].contiguous()
+        self.y = rot[:, p].contiguous()
+        out3 = torch.empty(3, dtype=torch.float64, device=dev)
+        check(lib().jxg_lmm_reml_null(_ptr(self.S), _ptr(self.xcov), _ptr(self.y), n, p, -5.0, 5.0, 50, 1e-3,
+                                      _ptr(out3), _stream()))
+        lbd, ml0, reml0 = [float(v) for v in out3.cpu().numpy()]
+        self.null = self._profile(lbd, ml0, reml0)
+        self._planes = None
+        self._fv = None
+
+    def _profile(self, lbd, ml0, reml0) -> NullFit:
+        # assoc.py:907-951 `_lmm_profile_exact_vc` + :1845-1876 (host, O(n p^2))
+        s = np.maximum(self.S.cpu().numpy(), 0.0)
+        x = self.xcov.cpu().numpy()
+        y = self.y.cpu().numpy()
+        n, p = x.shape
+        sg2 = se2 = float("nan")
+        if math.isfinite(lbd) and lbd > 0.0 and n - p > 0:
+            v_inv = 1.0 / np.maximum(s + lbd, 1e-30)
+            a = (x.T * v_inv) @ x
+            b = (x.T * v_inv) @ y
+            try:
+                beta = np.linalg.solve(a, b)
+            except np.linalg.LinAlgError:
+                beta = np.linalg.lstsq(a, b, rcond=None)[0]
+            r = y - x @ beta
+            q = float(np.dot(v_inv, r * r))
+            if math.isfinite(q) and q > 0.0:
+                sg2 = q / float(n - p)
+                se2 = lbd * sg2
+        trace_mean = float(np.sum(s) / float(max(1, n)))
+        ssum = sg2 + se2
+        if math.isfinite(ssum) and ssum > 0.0:
+            vg = sg2 * max(trace_mean, 0.0)
+            den = vg + se2
+            pve = vg / den if (math.isfinite(den) and den > 0.0) else sg2 / ssum
+        else:
+            vg0 = float(np.mean(s))
+            pve = vg0 / (vg0 + lbd) if (vg0 + lbd) > 0 else float("nan")
+        if pve > 0.95 or pve < 0.05 or (not math.isfinite(lbd)) or lbd <= 0.0:
+            bounds = (-5.0, 5.0)
+        else:
+            bounds = (math.log10(lbd) - 2.0, math.log10(lbd) + 2.0)
+        return NullFit(lbd, ml0, reml0, sg2, se2, pve, bounds)
+
+    def planes(self):
+        if self._planes is None:
+            nt = lib().jxg_num_tiles(self.n)
+            npad = nt * 128
+            hi = torch.empty((npad, npad), dtype=torch.float16, device=self.S.device)
+            lo = torch.empty((npad, npad), dtype=torch.float16, device=self.S.device)
+            check(lib().jxg_ut_split(_ptr(self.ut), self.n, _ptr(hi), _ptr(lo), SCALE_EXP, _stream()))
+            self._planes = (hi, lo)
+        return self._planes
+
+    def fv_cache(self, log10_lbd=None):
+        lbd = self.null.lbd if log10_lbd is None else 10.0 ** float(log10_lbd)
+        if self._fv is None or self._fv[0] != lbd:
+            dev = self.S.device
+            n, p = self.n, self.p
+            w = torch.empty(n, dtype=torch.float32, device=dev)
+            py = torch.empty(n, dtype=torch.float32, device=dev)
+            wx = torch.empty((n, p), dtype=torch.float32, device=dev)
+            a = np.zeros((p, p), dtype=np.float64)
+            sc = np.zeros(3, dtype=np.float64)
+            torch.cuda.current_stream().synchronize()
+            check(lib().jxg_fvlmm_prepare(_ptr(self.S), _ptr(self.xcov), _ptr(self.y), n, p, float(lbd), _ptr(w),
+                                          _ptr(py), _ptr(wx), a.ctypes.data, sc.ctypes.data))
+            self._fv = (lbd, w, py, wx, a, float(sc[0]), float(sc[1]), int(sc[2]))
+        return self._fv
+
+
+def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
+              high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
+              times: StageTimes = None):
+    """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML) or 'fvlmm' (fixed lambda).
+    Returns a (len(rows), 3) f64 device tensor [beta, se, p] (and the per-SNP Brent evaluation counts)."""
+    dev = panel.device
+    n = model.n
+    if panel.n != n:
+        raise RuntimeError(f"selected sample count {panel.n} != model n {n}")
+    mk = len(rows)
+    out = torch.empty((mk, 3), dtype=torch.float64, device=dev)
+    evals = torch.zeros(mk, dtype=torch.int32, device=dev) if return_evals else None
+    if mk == 0:
+        return (out, evals) if return_evals else out
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    hi, lo = model.planes()
+    if mode == "lmm":
+        lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
+        warm = 1 if init_log10_lbd is not None else 0
+        init = float(init_log10_lbd) if init_log10_lbd is not None else 0.0
+    else:
+        lbd, w, py, wx, a_chol, ypy, _, df = model.fv_cache(init_log10_lbd)
+    br = int(min(block_rows, mk))
+    grot = torch.empty((br, n), dtype=torch.float32, device=dev)
+    for r0 in range(0, mk, br):
+        nr = min(br, mk - r0)
+        t0 = time.perf_counter()
+        check(lib().jxg_rotate_packed(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                      lut_t[r0:].data_ptr(), _ptr(hi), _ptr(lo), SCALE_EXP, _ptr(grot), _stream()))
+        if times is not None:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            times.add("rotate", t1 - t0)
+            t0 = t1
+        o = out[r0:]
+        if mode == "lmm":
+            check(lib().jxg_lmm_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p,
+                                     lo_b, hi_b, float(tol), int(max_iter), warm, init, 0, 0.0, o.data_ptr(),
+                                     evals[r0:].data_ptr() if evals is not None else None, _stream()))
+        else:
+            check(lib().jxg_fvlmm_scan(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), a_chol.ctypes.data,
+                                       ypy, df, o.data_ptr(), _stream()))
+        if times is not None:
+            torch.cuda.synchronize()
+            times.add("scan", time.perf_counter() - t0)
+    return (out, evals) if return_evals else out
+
+
+@dataclass
+class GwasResult:
+    keep: np.ndarray        # (m,) bool, kept SNPs in BED order
+    af: np.ndarray          # (m_kept,) f32
+    miss: np.ndarray        # (m_kept,) f32
+    stats: np.ndarray       # (m_kept, 3) f64 beta, se, p
+    null: NullFit
+    grm_eff_m: int
+    times: dict
+
+
+def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndarray = None, mode="lmm",
+             maf=0.02, geno=0.05, het=1.0, grm_method=1, max_iter=30, tol=1e-2, timing=True) -> GwasResult:
+    """Single-GPU `jx gwas -lmm/-fvlmm` on an HBM-resident payload (all samples phenotyped)."""
+    tm = StageTimes()
+
+    def tick():
+        if timing:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    t0 = tick()
+    panel = Panel(packed, n_samples)
+    counts = panel.counts()
+    n = panel.n
+    # GRM: `grm_stream_bed_f32` defaults maf/geno from the CLI, het filter off (workflow.py:3095)
+    gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, grm_method, maf, geno, 0.0)
+    grows = np.nonzero(gkeep)[0]
+    if len(grows) == 0:
+        raise RuntimeError("No SNPs remained after filtering; GRM is empty.")
+    glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
+    denom = float(np.sum(var[grows])) if grm_method == 1 else float(len(grows))
+    if not (math.isfinite(denom) and denom > 0.0):
+        raise RuntimeError("invalid centered GRM denominator: sum(2p(1-p)) <= 0")
+    t1 = tick()
+    tm.add("prep", t1 - t0)
+    acc = grm_accumulate(panel, grows, glut)
+    k32 = grm_finalize(acc, n, denom, torch.float32)
+    del acc
+    t2 = tick()
+    tm.add("grm", t2 - t1)
+    s, ut64 = eigh_from_grm(k32, 1e-6)
+    t3 = tick()
+    tm.add("eigh", t3 - t2)
+    x = np.ones((n, 1)) if covar is None else np.concatenate([np.ones((n, 1)), np.asarray(covar, dtype=np.float64)], 1)
+    model = SpectralModel(s, ut64, x, y)
+    del ut64
+    t4 = tick()
+    tm.add("null", t4 - t3)
+    keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
+    rows = np.nonzero(keep)[0]
+    lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
+    if mode == "lmm":
+        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol,
+                        times=tm if timing else None)
+    else:
+        out = scan_rows(panel, model, rows, lut, "fvlmm", times=tm if timing else None)
+    res = out.cpu().numpy()
+    t5 = tick()
+    tm.add("scan_total", t5 - t4)
+    tm.add("total", t5 - t0)
+    return GwasResult(keep, af[rows], miss[rows], res, model.null, len(grows), tm.t)

@@ -1,0 +1,132 @@
+"""Per-SNP statistics, QC filters and design-value LUTs from integer genotype counts (host side, vectorised).
+
+The counts come from the GPU (`jxg_row_counts_p32`); everything below is O(m) float logic that must agree
+bit for bit with the reference so that the kept-SNP set, `af` and `miss` columns are identical.  numpy float32 /
+float64 arithmetic is IEEE like Rust's, so the expressions are written with the reference's types and order:
+
+* `gwas_scan_row_stats`   : src/stats/lmm.rs:1258-1320  (all compares in f32)
+* `stream_grm_row_prepare`: src/stats/grm.rs:1465-1536  (all in f64, thresholds widened from f32)
+* `grm_lut_from_maf`      : src/decode/decode.rs:813-839, 558-566 (packed GRM route)
+* `scan_lut_from_counts`  : src/decode/decode.rs:163-189, 218-221 (scan design rows)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def gwas_scan_row_stats(counts: np.ndarray, n: int, maf_thr: float, miss_thr: float, het_thr: float):
+    """counts (m,3) int = (missing, het, hom_alt) over the n selected samples.
+    -> keep (bool), af (f32 alt_freq), miss_rate (f32)."""
+    counts = np.asarray(counts, dtype=np.int64)
+    missing, het, hom = counts[:, 0], counts[:, 1], counts[:, 2]
+    maf_thr, miss_thr, het_thr = F32(maf_thr), F32(miss_thr), F32(het_thr)
+    nm = np.maximum(n - missing, 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        miss_rate = (missing.astype(np.float32) / F32(n)) if n > 0 else np.ones(len(missing), dtype=np.float32)
+        keep = ~(miss_rate > miss_thr)
+        zero_nm = nm == 0
+        nmf = nm.astype(np.float32)
+        if het_thr > F32(0.0):
+            het_rate = het.astype(np.float32) / nmf
+            keep &= ~((~zero_nm) & (het_rate > het_thr))
+        alt_sum = (het + 2 * hom).astype(np.float32)
+        alt_freq = alt_sum / (F32(2.0) * nmf)
+        maf_v = np.minimum(alt_freq, F32(1.0) - alt_freq)
+        keep &= ~((~zero_nm) & (maf_v < maf_thr))
+    if maf_thr > F32(0.0):
+        keep &= ~zero_nm
+    af = np.where(zero_nm, F32(0.0), alt_freq).astype(np.float32)
+    return keep, af, miss_rate.astype(np.float32)
+
+
+def stream_grm_row_prepare(counts: np.ndarray, n_samples: int, method: int, maf_thr: float, miss_thr: float,
+                           het_thr: float):
+    """-> keep, mean_g (f32), std_scale (f32), flip (bool), var (f64). Thresholds are clamped like
+    src/stats/grm.rs:4709-4711."""
+    counts = np.asarray(counts, dtype=np.int64)
+    missing, het, hom = counts[:, 0], counts[:, 1], counts[:, 2]
+    maf_thr32 = F32(min(max(float(maf_thr), 0.0), 0.5))
+    miss_thr32 = F32(min(max(float(miss_thr), 0.0), 1.0))
+    het_thr32 = F32(min(max(float(het_thr), 0.0), 1.0))
+    maf_thr64, miss_thr64, het_thr64 = float(maf_thr32), float(miss_thr32), float(het_thr32)
+    eps64 = float(F32(1e-12))
+    nm = n_samples - missing
+    nmf = nm.astype(np.float64)
+    m = len(missing)
+    keep = np.ones(m, dtype=bool)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if het_thr32 > F32(0.0):
+            keep &= ~((nm > 0) & ((het.astype(np.float64) / nmf) > het_thr64))
+        missing_rate = 1.0 - (nmf / float(n_samples))
+        keep &= ~(missing_rate > miss_thr64)
+        zero_nm = nm == 0
+        if maf_thr32 > F32(0.0):
+            keep &= ~zero_nm
+        alt_sum = (het + 2 * hom).astype(np.float64)
+        alt_freq = alt_sum / (2.0 * nmf)
+        flip = alt_freq > 0.5
+        alt_sum = np.where(flip, 2.0 * nmf - alt_sum, alt_sum)
+        alt_freq = np.where(flip, alt_sum / (2.0 * nmf), alt_freq)
+        maf = np.minimum(alt_freq, 1.0 - alt_freq)
+        keep &= ~((~zero_nm) & (maf < maf_thr64))
+        mean_g = (alt_sum / nmf).astype(np.float32)
+        var = np.maximum(2.0 * alt_freq * (1.0 - alt_freq), 0.0)
+        if method == 2:
+            scale = np.where(var > eps64, (1.0 / np.sqrt(var)), 0.0).astype(np.float32)
+        else:
+            scale = np.ones(m, dtype=np.float32)
+    flip = np.where(zero_nm, False, flip)
+    mean_g = np.where(zero_nm, F32(0.0), mean_g).astype(np.float32)
+    scale = np.where(zero_nm, F32(0.0 if method == 2 else 1.0), scale).astype(np.float32)
+    var = np.where(zero_nm, 0.0, var)
+    return keep, mean_g, scale, flip, var
+
+
+def grm_lut_from_mean_scale(mean_g, scale, flip):
+    """(m,4) f32 LUT indexed by code [00, 01, 10, 11] for the stream-GRM route (decode.rs:446-461)."""
+    mean_g = np.asarray(mean_g, dtype=np.float32)
+    scale = np.asarray(scale, dtype=np.float32)
+    flip = np.asarray(flip, dtype=bool)
+    g0 = np.where(flip, F32(2.0), F32(0.0)).astype(np.float32)
+    g2 = np.where(flip, F32(0.0), F32(2.0)).astype(np.float32)
+    lut = np.zeros((len(mean_g), 4), dtype=np.float32)
+    lut[:, 0] = (g0 - mean_g) * scale
+    lut[:, 2] = (F32(1.0) - mean_g) * scale
+    lut[:, 3] = (g2 - mean_g) * scale
+    return lut
+
+
+def grm_lut_from_maf(row_maf, row_flip, method: int):
+    """Packed-GRM LUT from the passed maf (decode.rs:813-839 / bedmath.rs:1208-1224; eps = 1e-12 f32)."""
+    p = np.clip(np.asarray(row_maf, dtype=np.float32), F32(0.0), F32(1.0))
+    mean_g = (F32(2.0) * p).astype(np.float32)
+    var = (F32(2.0) * p * (F32(1.0) - p)).astype(np.float32)
+    if method == 2:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            scale = np.where(var > F32(1e-12), F32(1.0) / np.sqrt(var), F32(0.0)).astype(np.float32)
+    else:
+        scale = np.ones_like(p)
+    return grm_lut_from_mean_scale(mean_g, scale, row_flip)
+
+
+def scan_lut_from_counts(row_maf, row_flip, counts, n: int):
+    """(m,4) f32 scan design LUT: [0, mu, 1, 2] (or flipped), minus the actual row mean
+    (f64 sum / n -> f32; the sum of f32 values {0,1,2,mu} is exact in f64, so counts reproduce it)."""
+    maf = np.asarray(row_maf, dtype=np.float32)
+    flip = np.asarray(row_flip, dtype=bool)
+    counts = np.asarray(counts, dtype=np.int64)
+    mu = np.maximum(2.0 * maf.astype(np.float64), 0.0).astype(np.float32)
+    v0 = np.where(flip, F32(2.0), F32(0.0)).astype(np.float32)
+    v3 = np.where(flip, F32(0.0), F32(2.0)).astype(np.float32)
+    c00 = (n - counts[:, 0] - counts[:, 1] - counts[:, 2]).astype(np.float64)
+    total = (c00 * v0.astype(np.float64) + counts[:, 0] * mu.astype(np.float64) + counts[:, 1] * 1.0 +
+             counts[:, 2] * v3.astype(np.float64))
+    mean = (total / float(n)).astype(np.float32)
+    lut = np.empty((len(maf), 4), dtype=np.float32)
+    lut[:, 0] = v0 - mean
+    lut[:, 1] = mu - mean
+    lut[:, 2] = F32(1.0) - mean
+    lut[:, 3] = v3 - mean
+    return lut

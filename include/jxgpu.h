@@ -130,6 +130,11 @@ int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_
                    const float *d_wx, const double *h_a_chol, double ypy, int df, double *d_out,
                    void *stream);
 
+/* Duration (ms, HIP events on the launch stream) of the MFMA kernel(s) issued by the most recent
+ * jxg_grm_accumulate (which = 0) or jxg_rotate_packed (which = 1) call of this process.  Counterpart of the
+ * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
+float jxg_last_kernel_ms(int which);
+
 /* ------------------------------------------------------------------------------------------------
  * Host layer (reference PyO3 signatures with C arrays)
  * ---------------------------------------------------------------------------------------------- */

@@ -44,6 +44,7 @@ SIGNATURES = {
     "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
     "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jxg_last_kernel_ms": [c_i],
     "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
     "jx_grm_stream_payload_f32": [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p],
     "jx_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
@@ -54,7 +55,7 @@ SIGNATURES = {
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_p],
 }
-_RESTYPES = {"jx_last_error": C.c_char_p}
+_RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float}
 
 
 def lib():
@@ -65,6 +66,15 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C janusx_amd/csrc` (there is no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64/rocBLAS/rocSOLVER under the same SONAMEs as /opt/rocm.
+        # If libjxgpu pulled the /opt/rocm copies in first and torch arrived later, the process would hold two
+        # HIP runtimes (observed on the GPU box: "no ROCm-capable device is detected" at the first launch).
+        # Importing torch first, when it is installed, keeps one runtime per process; without torch the
+        # /opt/rocm runtime is used and everything works standalone.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         h = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)

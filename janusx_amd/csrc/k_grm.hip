@@ -268,6 +268,23 @@ __global__ __launch_bounds__(256) void grm_finalize_kernel(const double *__restr
 
 using namespace jx;
 
+namespace jx {
+float g_last_ms[4] = {0.f, 0.f, 0.f, 0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2: reserved
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int init() {
+        if (!a) {
+            JX_HIP(hipEventCreate(&a));
+            JX_HIP(hipEventCreate(&b));
+        }
+        return 0;
+    }
+};
+static EventPair g_grm_ev;
+}  // namespace jx
+
+extern "C" float jxg_last_kernel_ms(int which) { return (which >= 0 && which < 4) ? g_last_ms[which] : 0.f; }
+
 extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
                                   const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
                                   void *stream) {
@@ -297,6 +314,8 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
     // Few tiles: spread SNP chunks over blockIdx.y with f64 atomics so the chip is filled.
     // Many tiles: one launch per chunk, the owning workgroup does a plain f64 read-modify-write.
     const bool atomic_mode = ntiles < 1024 && nchunks > 1;
+    if (g_grm_ev.init()) return 1;
+    JX_HIP(hipEventRecord(g_grm_ev.a, st));
     if (atomic_mode) {
         // shrink chunks if that is what it takes to reach ~4 workgroups per CU
         int64_t want = (4 * 256 + ntiles - 1) / ntiles;
@@ -317,7 +336,9 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
             JX_LAUNCH_CHECK();
         }
     }
+    JX_HIP(hipEventRecord(g_grm_ev.b, st));
     JX_HIP(hipStreamSynchronize(st));  // lut16 is freed on return
+    JX_HIP(hipEventElapsedTime(&g_last_ms[0], g_grm_ev.a, g_grm_ev.b));
     return 0;
 }
 

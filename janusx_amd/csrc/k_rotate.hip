@@ -347,6 +347,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_f32_kernel(const float *__res
 
 using namespace jx;
 
+namespace jx {
+extern float g_last_ms[4];
+static hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
+}  // namespace jx
+
 extern "C" int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *d_lo, int scale_exp,
                             void *stream) {
     const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
@@ -373,13 +378,20 @@ extern "C" int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, c
     hipLaunchKernelGGL(lut_split_r_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, d_lut,
                        (int64_t)nrows, lut16.as<uint4>(), flags.as<int>());
     JX_LAUNCH_CHECK();
+    if (!g_rot_a) {
+        JX_HIP(hipEventCreate(&g_rot_a));
+        JX_HIP(hipEventCreate(&g_rot_b));
+    }
     dim3 grid(nt, (nrows + 127) / 128);
+    JX_HIP(hipEventRecord(g_rot_a, st));
     hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, lut16.as<uint4>(),
                        (const __half *)d_uhi, (const __half *)d_ulo, npad, n, ldexpf(1.0f, -scale_exp), d_out);
     JX_LAUNCH_CHECK();
+    JX_HIP(hipEventRecord(g_rot_b, st));
     int hflag = 0;
     JX_HIP(hipMemcpyAsync(&hflag, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
+    JX_HIP(hipEventElapsedTime(&g_last_ms[1], g_rot_a, g_rot_b));
     if (hflag) return fail("jxg_rotate_packed: design values exceed the fp16 split range");
     return 0;
 }

@@ -1,0 +1,42 @@
+"""SNP-sharded multi-GPU helpers (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests).  The reference has no distributed layer; the partition
+follows SURVEY.md §8(e): contiguous SNP ranges per rank, one sum-reduction of the partial n x n GRM
+accumulators (+ the scalar denominators), SNP-independent scan afterwards, results gathered in BED order.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(m: int, rank: int, world: int):
+    """Contiguous SNP range [lo, hi) of `rank`; ranges tile [0, m) in BED order."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return (m * rank) // world, (m * (rank + 1)) // world
+
+
+def allreduce_sum_(t):
+    """In-place sum over ranks (no-op when torch.distributed is not initialised)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return t
+
+
+def gather_rows(local, counts=None):
+    """Concatenate per-rank (rows_r, c) tensors in rank order on every rank (BED order of the SNP shards)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)

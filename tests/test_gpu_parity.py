@@ -269,3 +269,38 @@ def test_pipeline_end_to_end(oracle, oracle_c):
         be, se, pe = _assoc_err(res.stats, ref)
         # end-to-end: GRM (f32) and eigenvectors come from different f32/f64 summation orders on the two sides
         assert max(be, se) < 1e-4, (mode, be, se, pe)
+
+
+def test_golden_fixture_gpu():
+    """HIP path against the committed golden fixture (tests/golden/panel_small.npz)."""
+    import os
+    from janusx_amd import janusx as jxrs
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "panel_small.npz"))
+    n = int(gold["n"])
+    packed = gold["packed"]
+    for method, key in ((1, "k_stream_m1"), (2, "k_stream_m2")):
+        k, eff, keep = jxrs.grm_stream_payload_f32(packed, n, method, 0.02, 0.05, 0.0)
+        assert eff == gold["eff_m"][method - 1] and np.array_equal(keep, gold["gkeep"])
+        assert _grm_err(k, gold[key]) < TOL
+    pk = np.ascontiguousarray(packed[gold["keep"]])
+    zf = np.zeros(pk.shape[0], dtype=bool)
+    af = gold["af"][gold["keep"]]
+    assert _grm_err(jxrs.grm_packed_f32(pk, n, zf, af, None, method=1), gold["k_packed_m1"]) < TOL
+    assert _grm_err(jxrs.grm_packed_f32(pk, n, zf, af, gold["sub"], method=1), gold["k_packed_m1_sub"]) < TOL
+    assert _grm_err(jxrs.grm_packed_f32(pk, n, zf, af, None, method=2), gold["k_packed_m2"]) < TOL
+    ev, vec, *_ = jxrs.rust_eigh_from_array_f64(gold["k_stream_m1"].astype(np.float64), diag_shift=1e-6)
+    assert np.max(np.abs(ev - gold["S"])) < 1e-10
+    lbd, ml, reml = jxrs.lmm_reml_null_f32(gold["S"], gold["Xcov"], gold["yrot"], -5.0, 5.0, 50, 1e-3)
+    assert abs(lbd - gold["lbd"]) < 1e-7 * gold["lbd"] and abs(ml - gold["ml0"]) < 1e-8 * abs(gold["ml0"])
+    lo, hi = gold["bounds"]
+    out = jxrs.lmm_reml_chunk_f32(gold["S"], gold["Xcov"], gold["yrot"], lo, hi, gold["grot"], max_iter=30, tol=1e-2)
+    be, se, pe = _assoc_err(out, gold["lmm"])
+    assert max(be, se) < 1e-8, (be, se, pe)
+    fout = jxrs.fvlmm_assoc_chunk_f32(gold["S"], gold["Xcov"], gold["yrot"], math.log10(float(gold["lbd"])), gold["grot"])
+    be, se, pe = _assoc_err(fout, gold["fvlmm"])
+    assert max(be, se) < TOL, (be, se, pe)
+    # packed route end to end on the fixture panel (decode + fp16x2 rotation + scan)
+    out2 = jxrs.lmm_reml_assoc_packed_f32(pk, n, zf, af, gold["S"], gold["Xcov"], gold["yrot"], gold["Dh"],
+                                          low=lo, high=hi, max_iter=30, tol=1e-2)
+    be, se, pe = _assoc_err(out2, gold["lmm"])
+    assert max(be, se) < TOL, (be, se, pe)

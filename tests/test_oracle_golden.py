@@ -1,0 +1,144 @@
+"""CPU tests: the oracle against (a) the reference's own unit-test vectors, (b) values produced by the
+reference's pure-numpy helpers (stored in tests/golden/panel_small.npz by gen_fixtures.py), (c) itself
+(numpy restatement vs C restatement), and the committed fixture as a regression pin."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "panel_small.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_pack_codes_layout(oracle):
+    # src/math/bedmath.rs:1528-1534: sample i at bits 2*(i&3) of byte i>>2
+    codes = np.array([[0, 2, 3, 1, 0, 3, 2, 0]], dtype=np.uint8)
+    p = oracle.pack_codes(codes)
+    assert p.tolist() == [[0 | (2 << 2) | (3 << 4) | (1 << 6), 0 | (3 << 2) | (2 << 4) | (0 << 6)]]
+    assert np.array_equal(oracle.unpack_codes(p, 8), codes)
+
+
+def test_reference_decode_vectors(oracle):
+    # near_full_additive_decode_matches_gather_decode (bedmath.rs:1537-1573): LUT [0, 2*maf, 1, 2]
+    codes = np.array([0, 2, 3, 1, 0, 3, 2, 0], dtype=np.uint8)
+    idx = [0, 1, 2, 3, 5, 6, 7]
+    lut = oracle.scan_value_lut_f32(np.float32(0.25), False)
+    assert lut.tolist() == [0.0, 0.5, 1.0, 2.0]
+    assert lut[codes[idx]].tolist() == [0.0, 1.0, 2.0, 0.5, 2.0, 1.0, 0.0]
+    # near_full_standardized (bedmath.rs:1576-1628): flipped LUT with mean .6 and inv_sd 1.25
+    from janusx_amd import stats
+    l2 = stats.grm_lut_from_mean_scale(np.float32([0.6]), np.float32([1.25]), [True])[0]
+    exp = np.float32([(np.float32(2.0) - np.float32(0.6)) * np.float32(1.25), 0.0,
+                      (np.float32(1.0) - np.float32(0.6)) * np.float32(1.25),
+                      (np.float32(0.0) - np.float32(0.6)) * np.float32(1.25)])
+    assert np.array_equal(l2, exp)
+    # centered_subset_decode_uses_global_mean_for_method1 (bedmath.rs:1630-1660)
+    codes = np.array([[0, 0, 0, 2, 2, 2, 2, 2]], dtype=np.uint8)
+    packed = oracle.pack_codes(codes)
+    z = oracle.decode_grm_block_f32(packed, 8, [False], np.float32([0.625]), [0, 1, 2], 1, 0, 1)
+    assert np.allclose(z, [[-1.25, -1.25, -1.25]], atol=1e-6)
+    v = oracle.grm_varsum(np.float32([0.625]), 1, False)
+    assert abs(v - 2.0 * 0.625 * (1 - 0.625)) < 1e-9
+
+
+def test_reference_scalar_vectors(oracle):
+    # src/math/linalg.rs:374-380: chi2 inverse sf of 1.8885e-19 is ~81.8
+    assert 0.5 < oracle.chi2_sf_df1(81.8) / 1.8885e-19 < 2.0
+    assert oracle.chi2_sf_df1(float("nan")) == 1.0 and oracle.chi2_sf_df1(0.0) == 1.0
+    assert abs(oracle.normal_sf(0.0) - 0.5) < 1e-16
+    # src/math/eigh.rs:1982-1998
+    s, u = oracle.eigh_sym(np.array([[2.0, 1.0], [1.0, 2.0]]))
+    assert np.allclose(s, [1.0, 3.0], atol=1e-9) and np.allclose(u.T @ u, np.eye(2), atol=1e-9)
+
+
+def test_brent_known_function(oracle):
+    x, fx, ev = oracle.brent_minimize(lambda t: (t - 1.234) ** 2 + 3.0, -5.0, 5.0, 1e-8, 100)
+    assert abs(x - 1.234) < 1e-6 and abs(fx - 3.0) < 1e-10
+    # max_iter bound: evaluations = 1 + iterations
+    _, _, ev = oracle.brent_minimize(lambda t: abs(t - 0.3), -5.0, 5.0, 1e-12, 7)
+    assert ev == 8
+    # init outside the bracket falls back to the midpoint
+    x0, _, _ = oracle.brent_minimize(lambda t: (t - 1.0) ** 2, 0.0, 4.0, 1e-3, 0, init_x=9.0)
+    assert x0 == 2.0
+
+
+def test_reference_nullreml_values(oracle, oracle_c, gold):
+    """REML formula pinned to values computed by the reference's own `LMM._NULLREML` (assoc.py:1917)."""
+    for lam, val in zip(gold["ref_lams"], gold["ref_nullreml"]):
+        for fn in (oracle.reml_loglike, oracle_c.reml_loglike):
+            mine = fn(math.log10(lam), gold["S"], gold["Xcov"], gold["yrot"], None)
+            assert abs(mine - val) < 1e-6 * max(1.0, abs(val))
+    assert "LMM._NULLREML" in str(gold["reference_checked"])
+
+
+def test_python_vs_c_oracle(oracle, oracle_c, gold):
+    s, x, y, grot = gold["S"], gold["Xcov"], gold["yrot"], gold["grot"]
+    for t in (-2.0, 0.0, 1.5):
+        snp = grot[7].astype(np.float64)
+        assert abs(oracle.reml_loglike(t, s, x, y, snp) - oracle_c.reml_loglike(t, s, x, y, snp)) < 1e-9
+        assert abs(oracle.ml_loglike(t, s, x, y, snp) - oracle_c.ml_loglike(t, s, x, y, snp)) < 1e-9
+        b1 = oracle.final_beta_se(t, s, x, y, snp)
+        b2 = oracle_c.final_beta_se(t, s, x, y, snp)
+        assert np.allclose(b1, b2, rtol=1e-10)
+    lo, hi = gold["bounds"]
+    a = oracle.lmm_scan_rotated_block(grot[:40], s, x, y, lo, hi, 30, 1e-2)
+    b = oracle_c.lmm_scan_rotated_block(grot[:40], s, x, y, lo, hi, 30, 1e-2)
+    assert np.allclose(a, b, rtol=1e-7, equal_nan=True)
+    n1 = oracle.lmm_reml_null(s, x, y, -5, 5, 50, 1e-3)
+    n2 = oracle_c.lmm_reml_null(s, x, y, -5, 5, 50, 1e-3)
+    assert np.allclose(n1, n2, rtol=1e-9)
+
+
+def test_fixture_regression(oracle, oracle_c, gold):
+    n = int(gold["n"])
+    packed = gold["packed"]
+    mi, he, ho = oracle.row_counts(packed, n)
+    assert np.array_equal(np.stack([mi, he, ho], 1), gold["counts"])
+    c2 = oracle_c.row_counts(packed, n)
+    assert np.array_equal(np.stack(c2, 1), gold["counts"])
+    keep, af, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    assert np.array_equal(keep, gold["keep"]) and np.array_equal(af, gold["af"]) and np.array_equal(miss, gold["miss"])
+    k1, eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    assert eff == gold["eff_m"][0] and np.allclose(k1, gold["k_stream_m1"], rtol=0, atol=1e-6)
+    s, u = oracle.gwas_eigh_from_grm(k1)
+    assert np.allclose(s, gold["S"], rtol=0, atol=1e-9)
+    nm = oracle.spectral_null_model(gold["y"], gold["x"], s, u)
+    assert abs(nm.lbd_null - gold["lbd"]) < 1e-6 * gold["lbd"]
+    assert abs(nm.ML0 - gold["ml0"]) < 1e-7 * abs(gold["ml0"]) and abs(nm.pve - gold["pve"]) < 1e-6
+    lo, hi = gold["bounds"]
+    out = oracle_c.lmm_scan_rotated_block(gold["grot"], gold["S"], gold["Xcov"], gold["yrot"], lo, hi, 30, 1e-2)
+    assert np.allclose(out, gold["lmm"], rtol=1e-9, equal_nan=True)
+    fv = oracle.fvlmm_assoc_rotated_block(gold["grot"], oracle.fvlmm_prepare_cache(gold["S"], gold["Xcov"],
+                                                                                  gold["yrot"], float(gold["lbd"])))
+    assert np.allclose(fv, gold["fvlmm"], rtol=1e-9, equal_nan=True)
+
+
+def test_edge_rows(oracle, gold):
+    """all-missing / monomorphic / all-het rows: filters and the (NaN, NaN, 1) convention."""
+    n = int(gold["n"])
+    keep = gold["keep"]
+    assert not keep[0] and not keep[1] and not keep[2]      # all missing, monomorphic ref/alt fail maf
+    assert keep[3]                                          # all het: maf 0.5 passes with het_thr 1.0
+    assert not keep[4]                                      # 50 % missing fails geno 0.05
+    gk = gold["gkeep"]
+    assert gk[5] and gold["gflip"][5]                       # alt_freq > 0.5 flips in the stream GRM
+    # a constant design row is centred to zero -> (NaN, NaN, 1.0) (src/stats/lmm.rs:74-81)
+    z = np.zeros((1, n), dtype=np.float32)
+    out = oracle.lmm_scan_rotated_block(z, gold["S"], gold["Xcov"], gold["yrot"], -5, 5, 30, 1e-2)
+    assert math.isnan(out[0, 0]) and math.isnan(out[0, 1]) and out[0, 2] == 1.0
+
+
+def test_tsv_format(oracle, gold):
+    txt = str(gold["tsv"])
+    lines = txt.splitlines()
+    assert lines[0] == "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald"
+    assert oracle.rust_fmt_e4(1.0) == "1.0000e0" and oracle.rust_fmt_e4(1.2345e-3) == "1.2345e-3"
+    assert oracle.rust_fmt_e4(float("nan")) == "NaN" and oracle.rust_fmt_e4(float("inf")) == "inf"
+    row = oracle.format_assoc_row("2", 77, ".", "A", "T", np.float32(0.25), np.float32(0.0), float("nan"), float("nan"), 1.0)
+    assert row == "2\t77\t2_77\tA\tT\t0.2500\t0.0000\tNaN\tNaN\tNaN\t1.0000e0\n"
+    assert len(lines) == 13 and all(len(l.split("\t")) == 11 for l in lines)

@@ -139,6 +139,11 @@ float jxg_last_kernel_ms(int which);
  * Host layer (reference PyO3 signatures with C arrays)
  * ---------------------------------------------------------------------------------------------- */
 
+/* per-SNP (missing, het, hom_alt) counts over the selected samples -> out_counts (m,3) int32
+ * (src/io/gfreader.rs:1378-1395 `count_packed_row_counts`, the QC input of src/stats/lmm.rs:1258-1320). */
+int jx_row_counts(const uint8_t *packed, int64_t m, int n_samples, const int64_t *sample_indices, int n_sel,
+                  int32_t *out_counts);
+
 /* `grm_packed_f32` / `grm_packed_f64_with_stats` (src/stats/grm.rs:3053-3066, 5611-5651).
  * packed (m, ceil(n_samples/4)) u8; row_flip (m) u8 0/1; row_maf (m) f32; sample_indices (n_sel) i64 or
  * NULL.  out_k (n,n) f32 or f64; out_row_sum (m) f64 or NULL; out_varsum (1) f64 or NULL. */

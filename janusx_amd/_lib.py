@@ -45,6 +45,7 @@ SIGNATURES = {
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
     "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
+    "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],
     "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
     "jx_grm_stream_payload_f32": [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p],
     "jx_eigh_f64": [c_p, c_i, c_d, c_p, c_p],

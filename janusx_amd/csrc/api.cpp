@@ -156,6 +156,22 @@ extern "C" int jxg_device_info(int64_t *out4) {
     return 0;
 }
 
+// per-SNP (missing, het, hom_alt) over the selected samples (src/io/gfreader.rs:1378-1395
+// `count_packed_row_counts[_selected]`), host arrays in/out.
+extern "C" int jx_row_counts(const uint8_t *packed, int64_t m, int n_samples, const int64_t *sample_indices,
+                             int n_sel, int32_t *out_counts) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (m <= 0) return 0;
+    SampleSel sel;
+    if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
+    DevBuf p32, dcnt;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)m)) return 1;
+    if (jxg_row_counts_p32(p32.as<uint8_t>(), m, sel.n, dcnt.as<int32_t>(), nullptr)) return 1;
+    JX_HIP(hipMemcpy(out_counts, dcnt.p, sizeof(int32_t) * 3 * (size_t)m, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // grm_packed_f32 / grm_packed_f64_with_stats (src/stats/grm.rs:204-360, 3066, 5611)
 // ---------------------------------------------------------------------------------------------------

@@ -377,3 +377,190 @@ def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot,
                         float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0)
     _done(progress_callback, out.shape[0])
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BED -> QC -> scan -> TSV entry points (src/stats/lmm.rs:2488-2751, src/stats/fvlmm.rs:2482-2526,
+# orchestration of src/stats/lmm.rs:975-1477 `run_unified_bed_scan_to_tsv_common`)
+# ------------------------------------------------------------------------------------------------
+
+def bed_row_counts(packed, n_samples, sample_indices=None):
+    """(m,3) int32 (missing, het, hom_alt) over the selected samples (src/io/gfreader.rs:1378-1395)."""
+    packed = _c(packed, np.uint8)
+    m = int(packed.shape[0])
+    idx, n_sel = _opt_idx(sample_indices)
+    out = np.zeros((m, 3), dtype=np.int32)
+    check(lib().jx_row_counts(_p(packed), m, int(n_samples), _p(idx), n_sel, _p(out)))
+    return out
+
+
+def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model, snps_only,
+                     sample_ids, row_indices, row_flip, row_missing, row_maf, mode, low, high, max_iter, tol, nullml,
+                     init_log10_lbd, progress_callback):
+    from . import stats as st
+    from .bed import read_bed_payload, read_fam_ids, snps_only_mask
+    from .tsv import write_assoc_tsv
+    if str(genetic_model) != "add":
+        raise RuntimeError(f"unsupported genetic model '{genetic_model}' (only 'add' is built)")
+    if nullml is not None:
+        raise RuntimeError("nullml/plrt output is not built for the BED route yet")
+    s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
+    if n <= p + 1:
+        raise RuntimeError("n must be > p+1")
+    packed, n_fam, bim = read_bed_payload(bed_prefix)
+    if sample_ids is not None:
+        fam = read_fam_ids(bed_prefix)
+        pos = {sid: i for i, sid in enumerate(fam)}
+        try:
+            sidx = np.array([pos[str(x)] for x in sample_ids], dtype=np.int64)
+        except KeyError as e:
+            raise RuntimeError(f"sample id not found in FAM: {e}") from None
+    else:
+        sidx = None
+    n_sel = n_fam if sidx is None else int(sidx.shape[0])
+    if n_sel != n:
+        raise RuntimeError(f"selected sample count {n_sel} != len(y_rot) {n}")
+    prepared = [row_indices, row_flip, row_missing, row_maf]
+    if any(v is not None for v in prepared) and not all(v is not None for v in prepared):
+        raise RuntimeError("prepared row metadata must provide all or none of: row_indices, row_flip, row_missing, row_maf")
+    m = int(packed.shape[0])
+    if row_indices is not None:
+        rows = np.asarray(row_indices, dtype=np.int64)
+        flip = np.asarray(row_flip).astype(bool)
+        af = np.asarray(row_maf, dtype=np.float32)
+        miss = np.asarray(row_missing, dtype=np.float32)
+    else:
+        counts = bed_row_counts(packed, n_fam, sidx)
+        keep, af_all, miss_all = st.gwas_scan_row_stats(counts, n, maf_thr, miss_thr, het_thr)
+        if snps_only:
+            keep &= snps_only_mask(bim)
+        rows = np.nonzero(keep)[0]
+        flip = np.zeros(len(rows), dtype=bool)
+        af = af_all[rows]
+        miss = miss_all[rows]
+    pk = np.ascontiguousarray(packed[rows])
+    if mode == "lmm":
+        warm, init = 0, 0.0
+        if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
+            warm, init = 1, float(min(max(init_log10_lbd, low), high))
+        res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init)
+    else:
+        res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 1, float(low), float(low) + 1.0, 0,
+                            1e-2, 0, 0.0)
+    chrom = [bim.chrom[j] for j in rows]
+    posv = [bim.pos[j] for j in rows]
+    snp = [bim.snp[j] for j in rows]
+    a0 = [bim.a0[j] for j in rows]
+    a1 = [bim.a1[j] for j in rows]
+    written = write_assoc_tsv(out_tsv, chrom, posv, snp, a0, a1, af, miss, res)
+    _done(progress_callback, m)
+    return written
+
+
+def lmm_reml_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr,
+                                  genetic_model="add", snps_only=False, sample_ids=None, row_indices=None,
+                                  row_flip=None, row_missing=None, row_maf=None, low=-5.0, high=5.0, max_iter=30,
+                                  tol=1e-2, threads=0, nullml=None, init_log10_lbd=None, rotate_block_rows=512,
+                                  progress_callback=None, progress_every=0, mmap_window_mb=None):
+    """src/stats/lmm.rs:2488-2751 (the default `jx gwas -lmm` kernel call) -> rows written.
+    Deterministic start (see `lmm_reml_assoc_packed_f32`)."""
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    if not (np.isfinite(tol) and tol > 0):
+        raise RuntimeError("tol must be positive and finite")
+    return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
+                            snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm", low, high,
+                            max_iter, tol, nullml, init_log10_lbd, progress_callback)
+
+
+def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u_t, maf_thr, miss_thr, het_thr,
+                               genetic_model="add", snps_only=False, sample_ids=None, row_indices=None,
+                               row_flip=None, row_missing=None, row_maf=None, threads=0, nullml=None,
+                               rotate_block_rows=512, progress_callback=None, progress_every=0, mmap_window_mb=None):
+    """src/stats/fvlmm.rs:2482-2526 (the default `jx gwas -fvlmm` kernel call) -> (rows, pve, log_det_v)."""
+    rows = _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
+                            snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "fvlmm",
+                            float(log10_lbd), None, 0, 1e-2, nullml, None, progress_callback)
+    s_ = np.asarray(s, dtype=np.float64).ravel()
+    lbd = 10.0 ** float(log10_lbd)
+    vg = float(np.mean(np.clip(s_, 0.0, None)))
+    pve = vg / (vg + lbd) if (vg + lbd) > 0 else float("nan")
+    return rows, pve, float(np.sum(np.log(s_ + lbd)))
+
+
+def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_missing, s, xcov, y_rot, u_t,
+                                     chrom, pos, snp, allele0, allele1, out_tsv, sample_indices=None,
+                                     row_indices=None, low=-5.0, high=5.0, max_iter=50, tol=1e-2, threads=0,
+                                     model="add", progress_callback=None, progress_every=0, nullml=None,
+                                     init_log10_lbd=None, rotate_block_rows=256, bed_prefix=None):
+    """src/stats/lmm.rs:3364-3790 -> rows written (metadata lists empty => read the BIM via `bed_prefix`)."""
+    from .tsv import write_assoc_tsv
+    out = lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices,
+                                    row_indices, low, high, max_iter, tol, threads, model, None, 0, nullml,
+                                    init_log10_lbd, rotate_block_rows)
+    m = out.shape[0]
+    if not len(chrom):
+        if not bed_prefix:
+            raise RuntimeError("metadata lists are empty and bed_prefix is not set")
+        from .bed import read_bim
+        bim = read_bim(bed_prefix)
+        sel = np.arange(m) if row_indices is None else np.asarray(row_indices, dtype=np.int64)
+        chrom = [bim.chrom[j] for j in sel]
+        pos = [bim.pos[j] for j in sel]
+        snp = [bim.snp[j] for j in sel]
+        allele0 = [bim.a0[j] for j in sel]
+        allele1 = [bim.a1[j] for j in sel]
+    written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
+                              np.asarray(row_missing, dtype=np.float32), out)
+    _done(progress_callback, m)
+    return written
+
+
+# ------------------------------------------------------------------------------------------------
+# LMM -> LM fallback decision (src/stats/gwas_unified.rs:54-175); O(n p^2) host arithmetic, as in the reference
+# ------------------------------------------------------------------------------------------------
+
+def gwas_lmm_lm_null_lrt_decision(y, x_cov, lmm_ml0, alpha=0.05, boundary_mixture=True):
+    """-> (switch_to_lm, lrt_stat, pval, lm_ml0). `x_cov` excludes the intercept (it is prepended here)."""
+    import math
+    if not math.isfinite(lmm_ml0):
+        raise RuntimeError("lmm_ml0 must be finite")
+    if not (math.isfinite(alpha) and 0.0 < alpha < 1.0):
+        raise RuntimeError("alpha must be in (0,1)")
+    y = _c(y, np.float64).ravel()
+    x = _c(x_cov, np.float64)
+    if x.ndim != 2:
+        raise RuntimeError("x_cov must be 2D")
+    n, p_cov = y.shape[0], x.shape[1]
+    if x.shape[0] != n:
+        raise RuntimeError("x_cov rows must equal len(y)")
+    if n <= p_cov + 1:
+        raise RuntimeError("insufficient samples: require n > p_cov + 1")
+    xd = np.concatenate([np.ones((n, 1)), x], axis=1)
+    xtx = xd.T @ xd
+    xty = xd.T @ y
+    try:
+        chol = np.linalg.cholesky(xtx)
+    except np.linalg.LinAlgError:
+        try:
+            chol = np.linalg.cholesky(xtx + 1e-8 * np.eye(p_cov + 1))
+        except np.linalg.LinAlgError:
+            raise RuntimeError("failed to compute LM null log-likelihood") from None
+    beta = np.linalg.solve(chol.T, np.linalg.solve(chol, xty))
+    r = y - xd @ beta
+    rss = float(np.dot(r, r))
+    if not (math.isfinite(rss) and rss > 0.0):
+        raise RuntimeError("failed to compute LM null log-likelihood")
+    n_f = float(n)
+    lm_ml0 = n_f * (math.log(n_f) - 1.0 - math.log(2.0 * math.pi)) / 2.0 - 0.5 * n_f * math.log(rss)
+    stat = 2.0 * (float(lmm_ml0) - lm_ml0)
+    if not math.isfinite(stat) or stat < 0.0:
+        stat = 0.0
+    pval = 1.0 if stat <= 0.0 else math.erfc(math.sqrt(0.5 * stat))
+    pval = min(max(pval, 2.2250738585072014e-308), 1.0) if math.isfinite(pval) else 1.0
+    if boundary_mixture:
+        pval *= 0.5
+    if not math.isfinite(pval):
+        pval = 1.0
+    pval = min(max(pval, 2.2250738585072014e-308), 1.0)
+    return bool(pval >= alpha), stat, pval, lm_ml0

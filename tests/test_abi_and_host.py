@@ -112,3 +112,35 @@ def test_boundary_argument_validation():
         jxrs.lmm_reml_null_f32(np.ones(3), np.ones((4, 1)), np.ones(4), -1.0, 1.0)
     with pytest.raises(RuntimeError, match="u_t must be"):
         jxrs.lmm_rotate_x_y_with_ut_f64(np.ones((3, 3), np.float32), np.ones((4, 1)), np.ones(4))
+
+
+def test_tsv_text_matches_oracle_format(oracle):
+    from janusx_amd import tsv
+    rng = np.random.default_rng(5)
+    vals = [(0.1234567, 0.0456, 1e-3), (-2.5e-5, 3.3e-4, 0.93), (1.0, 1e-9, 0.0), (float("nan"), float("nan"), 1.0),
+            (0.5, 0.0, 0.2), (3.0, 0.5, 1e-320), (7.25, 0.25, float("nan"))]
+    for _ in range(200):
+        vals.append((float(rng.normal()), float(abs(rng.normal()) * 0.1), float(10 ** rng.uniform(-30, 0))))
+    for b, s, p in vals:
+        a = tsv.format_row("3", 12345, ".", "A", "C", np.float32(0.31415), np.float32(0.0123), b, s, p)
+        r = oracle.format_assoc_row("3", 12345, ".", "A", "C", np.float32(0.31415), np.float32(0.0123), b, s, p)
+        assert a == r
+    assert tsv.HEADER3 == oracle.TSV_HEADER
+
+
+def test_lm_fallback_decision(oracle):
+    from janusx_amd import janusx as jxrs
+    rng = np.random.default_rng(6)
+    n = 150
+    x = rng.normal(size=(n, 2))
+    y = x @ np.array([0.5, -0.2]) + rng.normal(size=n)
+    lm = oracle.lm_null_ml(y, np.concatenate([np.ones((n, 1)), x], 1))
+    sw, stat, p, lm_ml0 = jxrs.gwas_lmm_lm_null_lrt_decision(y, x, lm + 0.4)
+    assert abs(lm_ml0 - lm) < 1e-9 and abs(stat - 0.8) < 1e-8
+    assert abs(p - 0.5 * oracle.chi2_sf_df1(0.8)) < 1e-12 and sw is True
+    sw2, stat2, p2, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x, lm + 10.0)
+    assert sw2 is False and p2 < 0.05
+    sw3, stat3, p3, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x, lm - 3.0)
+    assert stat3 == 0.0 and p3 == 0.5 and sw3 is True
+    with pytest.raises(RuntimeError, match="alpha"):
+        jxrs.gwas_lmm_lm_null_lrt_decision(y, x, lm, alpha=1.5)

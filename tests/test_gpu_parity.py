@@ -304,3 +304,40 @@ def test_golden_fixture_gpu():
                                           low=lo, high=hi, max_iter=30, tol=1e-2)
     be, se, pe = _assoc_err(out2, gold["lmm"])
     assert max(be, se) < TOL, (be, se, pe)
+
+
+def test_bed_to_tsv_routes(oracle, oracle_c, null_case, tmp_path):
+    """`jx gwas -lmm/-fvlmm` kernel entry points: BED file -> QC -> scan -> TSV (rows in BED order)."""
+    from janusx_amd import janusx as jxrs
+    n, m, packed, g, y, x, nm = null_case
+    prefix = str(tmp_path / "panel")
+    ids = [f"s{i}" for i in range(n)]
+    bim = bed.Bim([str(1 + j % 5) for j in range(m)], [("." if j % 7 == 0 else f"rs{j}") for j in range(m)],
+                  [100 + j for j in range(m)], ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    out = str(tmp_path / "res.lmm.tsv")
+    lo, hi = nm.bounds
+    rows = jxrs.lmm_reml_assoc_bed_to_tsv_f32(prefix, out, nm.S, nm.Xcov, nm.y, nm.Dh, 0.02, 0.05, 1.0,
+                                              sample_ids=ids, low=lo, high=hi, max_iter=30, tol=1e-2)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    kept = np.nonzero(keep)[0]
+    assert rows == len(kept)
+    lines = open(out).read().splitlines()
+    assert lines[0].split("\t") == ["chrom", "pos", "snp", "allele0", "allele1", "af", "miss", "beta", "se", "chisq", "pwald"]
+    assert len(lines) == rows + 1
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, rows=kept)
+    ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2)
+    for i, (ln, j) in enumerate(zip(lines[1:], kept)):
+        f = ln.split("\t")
+        assert f[0] == bim.chrom[j] and int(f[1]) == bim.pos[j]
+        assert f[2] == (bim.snp[j] if bim.snp[j] != "." else f"{bim.chrom[j]}_{bim.pos[j]}")
+        assert f[5] == f"{float(maf[j]):.4f}" and f[6] == f"{float(miss[j]):.4f}"
+        assert abs(float(f[7]) - ref[i, 0]) <= 1.01e-4 and abs(float(f[8]) - ref[i, 1]) <= 1.01e-4
+        assert abs(float(f[10]) - ref[i, 2]) <= 2e-4 * ref[i, 2] + 1e-300
+    # fixed lambda route returns (rows, pve, log_det_v)
+    out2 = str(tmp_path / "res.fvlmm.tsv")
+    r2, pve, ldv = jxrs.fvlmm_assoc_bed_to_tsv_f32(prefix, out2, nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null), nm.Dh,
+                                                   0.02, 0.05, 1.0)
+    assert r2 == rows and abs(ldv - float(np.sum(np.log(nm.S + nm.lbd_null)))) < 1e-9
+    assert len(open(out2).read().splitlines()) == rows + 1

@@ -107,6 +107,14 @@ int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, const int32_
                       const float *d_lut, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
                       float *d_out, void *stream);
 
+/* D1+D2 split form for block loops: `jxg_lut_split` converts (mk,4) f32 design LUTs into the 16-byte fp16 hi/lo
+ * records once (range-checked, synchronises once); `jxg_rotate_packed16` then only launches the MFMA kernel
+ * (no allocation, no synchronisation) on rows[r] / lut16[r], r in [0, nrows). */
+int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void *stream);
+int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                        const void *d_lut16, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
+                        float *d_out, void *stream);
+
 /* D2 (dense input). out[r, j] = sum_i g[r, i] * u_t[j, i] in exact f32 (f32 MFMA).
  * src/stats/lmm.rs:520-552 `rotate_snp_block_with_ut`. */
 int jxg_rotate_dense_f32(const float *d_g, int nrows, int n, const float *d_ut, float *d_out, void *stream);
@@ -119,6 +127,26 @@ int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const
                  const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
                  double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
                  void *stream);
+
+/* D3 split form for block loops: the lambda-only REML sums (sum ln v, X'V^-1X, X'V^-1y, y'V^-1y) are tabulated
+ * once per (model, [low, high]) as 32-term Chebyshev series per width-2 segment in a caller-provided device
+ * workspace of jxg_lmm_tables_bytes() bytes (0 = this configuration needs jxg_lmm_scan_exact); jxg_lmm_scan_tab
+ * then scans rotated blocks with one pass over the n samples per objective evaluation, without allocating or
+ * synchronising.  jxg_lmm_scan = build + scan. */
+int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high);
+int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double low,
+                         double high, void *d_work, void *stream);
+int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p, double low,
+                     double high, const void *d_work, double tol, int max_iter, int warm, double init_log10_lbd,
+                     int with_plrt, double nullml, double *d_out, int32_t *d_evals, void *stream);
+
+/* Same contract as jxg_lmm_scan, evaluated with the reference's two-pass formulas (normal equations + explicit
+ * residual quadratic form per evaluation, src/stats/reml.rs:286-344) instead of the tabulated lambda-only sums;
+ * selected automatically when high - low > 16 or when JXGPU_SCAN_EXACT is set.  Used to validate the fast path. */
+int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                       const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                       double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                       void *stream);
 
 /* E1. fixed-lambda cache (device vectors): w f32(n), py f32(n), wx f32(n,p); scalars to HOST out:
  * a_chol (p*p), ypy, log_det_v, df.  src/stats/fvlmm.rs:1484-1563. */
@@ -134,6 +162,10 @@ int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_
  * jxg_grm_accumulate (which = 0) or jxg_rotate_packed (which = 1) call of this process.  Counterpart of the
  * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
 float jxg_last_kernel_ms(int which);
+
+/* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
+int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
+                       const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host layer (reference PyO3 signatures with C arrays)

@@ -40,10 +40,17 @@ SIGNATURES = {
     "jxg_lmm_reml_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_p, c_p],
     "jxg_ut_split": [c_p, c_i, c_p, c_p, c_i, c_p],
     "jxg_rotate_packed": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "jxg_lut_split": [c_p, c_l, c_p, c_p],
+    "jxg_rotate_packed16": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "jxg_rotate_dense_f32": [c_p, c_i, c_i, c_p, c_p, c_p],
     "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
+    "jxg_lmm_tables_bytes": [c_i, c_i, c_d, c_d],
+    "jxg_lmm_tables_build": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_p],
+    "jxg_lmm_scan_tab": [c_p, c_i, c_i, c_p, c_p, c_i, c_d, c_d, c_p, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
+    "jxg_lmm_scan_exact": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
     "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
     "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],
     "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
@@ -56,7 +63,7 @@ SIGNATURES = {
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_p],
 }
-_RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float}
+_RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64}
 
 
 def lib():

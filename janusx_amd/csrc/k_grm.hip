@@ -270,6 +270,8 @@ using namespace jx;
 
 namespace jx {
 float g_last_ms[4] = {0.f, 0.f, 0.f, 0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2: reserved
+int g_timer_pending[4] = {0, 0, 0, 0};
+extern hipEvent_t g_rot_a, g_rot_b;
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     int init() {
@@ -283,7 +285,14 @@ struct EventPair {
 static EventPair g_grm_ev;
 }  // namespace jx
 
-extern "C" float jxg_last_kernel_ms(int which) { return (which >= 0 && which < 4) ? g_last_ms[which] : 0.f; }
+extern "C" float jxg_last_kernel_ms(int which) {
+    if (which < 0 || which >= 4) return 0.f;
+    if (which == 1 && g_timer_pending[1] && g_rot_b) {
+        if (hipEventSynchronize(g_rot_b) == hipSuccess) (void)hipEventElapsedTime(&g_last_ms[1], g_rot_a, g_rot_b);
+        g_timer_pending[1] = 0;
+    }
+    return g_last_ms[which];
+}
 
 extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
                                   const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,

@@ -349,7 +349,8 @@ using namespace jx;
 
 namespace jx {
 extern float g_last_ms[4];
-static hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
+extern int g_timer_pending[4];
+hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
 }  // namespace jx
 
 extern "C" int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *d_lo, int scale_exp,
@@ -364,36 +365,56 @@ extern "C" int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *
     return 0;
 }
 
-extern "C" int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
-                                 const float *d_lut, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
-                                 float *d_out, void *stream) {
+extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void *stream) {
+    if (mk <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int *flags = nullptr;
+    JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));
+    JX_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
+    hipLaunchKernelGGL(lut_split_r_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_lut, mk,
+                       (uint4 *)d_lut16, flags);
+    JX_LAUNCH_CHECK();
+    int hflag = 0;
+    JX_HIP(hipMemcpyAsync(&hflag, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    JX_HIP(hipFreeAsync(flags, st));
+    if (hflag) return fail("design values exceed the fp16 split range (|z| > 3e4)");
+    return 0;
+}
+
+extern "C" int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                   const void *d_lut16, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
+                                   float *d_out, void *stream) {
     if (nrows <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int nt = num_tiles(n);
     const int64_t npad = (int64_t)nt * JXG_TILE;
-    DevBuf lut16, flags;
-    if (lut16.alloc(sizeof(uint4) * (size_t)nrows)) return 1;
-    if (flags.alloc(sizeof(int))) return 1;
-    JX_HIP(hipMemsetAsync(flags.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(lut_split_r_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, d_lut,
-                       (int64_t)nrows, lut16.as<uint4>(), flags.as<int>());
-    JX_LAUNCH_CHECK();
     if (!g_rot_a) {
         JX_HIP(hipEventCreate(&g_rot_a));
         JX_HIP(hipEventCreate(&g_rot_b));
     }
     dim3 grid(nt, (nrows + 127) / 128);
     JX_HIP(hipEventRecord(g_rot_a, st));
-    hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, lut16.as<uint4>(),
-                       (const __half *)d_uhi, (const __half *)d_ulo, npad, n, ldexpf(1.0f, -scale_exp), d_out);
+    hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
+                       (const uint4 *)d_lut16, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
+                       ldexpf(1.0f, -scale_exp), d_out);
     JX_LAUNCH_CHECK();
     JX_HIP(hipEventRecord(g_rot_b, st));
-    int hflag = 0;
-    JX_HIP(hipMemcpyAsync(&hflag, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    JX_HIP(hipStreamSynchronize(st));
-    JX_HIP(hipEventElapsedTime(&g_last_ms[1], g_rot_a, g_rot_b));
-    if (hflag) return fail("jxg_rotate_packed: design values exceed the fp16 split range");
+    g_timer_pending[1] = 1;
     return 0;
+}
+
+extern "C" int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                 const float *d_lut, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
+                                 float *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    void *lut16 = nullptr;
+    JX_HIP(hipMallocAsync(&lut16, sizeof(uint4) * (size_t)nrows, st));
+    int rc = jxg_lut_split(d_lut, nrows, lut16, stream);
+    if (!rc) rc = jxg_rotate_packed16(d_p32, m_total, n, d_rows, nrows, lut16, d_uhi, d_ulo, scale_exp, d_out, stream);
+    (void)hipFreeAsync(lut16, st);
+    return rc;
 }
 
 extern "C" int jxg_rotate_dense_f32(const float *d_g, int nrows, int n, const float *d_ut, float *d_out,

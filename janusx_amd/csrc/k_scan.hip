@@ -9,105 +9,9 @@
 // (normal equations, then the explicit residual quadratic form, exactly the reference's formulas) with f64
 // wave-shuffle + LDS reductions; the tiny Cholesky/Brent logic runs redundantly in every lane on identical
 // reduced values, so control flow stays workgroup-uniform.
-#include "jx_common.h"
+#include "scan_common.h"
 
 namespace jx {
-
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_WAVES = SCAN_THREADS / 64;
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Sum NV per-thread values over the workgroup; result broadcast to all threads (in place).
-template <int NV>
-__device__ __forceinline__ void block_sum(double *v, int nv, double *red /* [SCAN_WAVES][NV] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (k < nv) {
-            const double s = wave_sum(v[k]);
-            if (lane == 0) red[wave * NV + k] = s;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        if (k < nv) {
-            double s = red[k];
-#pragma unroll
-            for (int w = 1; w < SCAN_WAVES; ++w) s += red[w * NV + k];
-            v[k] = s;
-        }
-    }
-    __syncthreads();
-}
-
-// src/math/linalg.rs:341-363. Fully unrolled with compile-time indices (runtime-indexed register arrays
-// would be demoted to scratch); on a failed pivot the factorisation continues on garbage and reports false.
-template <int MAXD>
-__device__ __forceinline__ bool chol_inplace(double *a, int dim) {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i) {
-        if (i < dim) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double sum = a[i * MAXD + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) sum -= a[i * MAXD + k] * a[j * MAXD + k];
-                if (i == j) {
-                    if (!(sum > 1e-18)) ok = false;
-                    a[i * MAXD + j] = sqrt(sum);
-                } else {
-                    a[i * MAXD + j] = sum / a[j * MAXD + j];
-                }
-            }
-        }
-    }
-    return ok;
-}
-
-// src/stats/reml.rs:46-66 (forward then backward substitution with the lower factor)
-template <int MAXD>
-__device__ __forceinline__ void chol_solve(const double *l, int dim, const double *b, double *x) {
-    double y[MAXD];
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i) {
-        y[i] = 0.0;
-        if (i < dim) {
-            double sum = b[i];
-#pragma unroll
-            for (int k = 0; k < i; ++k) sum -= l[i * MAXD + k] * y[k];
-            y[i] = sum / l[i * MAXD + i];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MAXD; ++i) x[i] = 0.0;
-#pragma unroll
-    for (int ii = 0; ii < MAXD; ++ii) {
-        const int i = MAXD - 1 - ii;
-        if (i < dim) {
-            double sum = y[i];
-#pragma unroll
-            for (int k = i + 1; k < MAXD; ++k)
-                if (k < dim) sum -= l[k * MAXD + i] * x[k];
-            x[i] = sum / l[i * MAXD + i];
-        }
-    }
-}
-
-template <int MAXD>
-__device__ __forceinline__ double pick(const double *v, int idx) {  // v[idx] with compile-time indexing
-    double r = 0.0;
-#pragma unroll
-    for (int k = 0; k < MAXD; ++k)
-        if (k == idx) r = v[k];
-    return r;
-}
 
 template <int MAXD>
 struct EvalOut {
@@ -120,7 +24,7 @@ struct EvalOut {
 };
 
 // One full evaluation of the normal equations at lambda (reml.rs:286-344). `g` may be null (null model).
-template <int MAXD>
+template <int MAXD, bool WAVE>
 __device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const double *__restrict__ xcov,
                                const double *__restrict__ y, const float *__restrict__ g, int n, int p_cov,
                                double *shm /* LDS scratch */, EvalOut<MAXD> &o, bool want_ainv) {
@@ -131,7 +35,8 @@ __device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const d
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = 0.0;
     // v layout: [0, NA) lower triangle row-major (r, c<=r); [NA, NA+MAXD) b; NA+MAXD logdet; NA+MAXD+1 bad count
-    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+#pragma unroll 2
+    for (int i = Par<WAVE>::tid(); i < n; i += Par<WAVE>::kThreads) {
         const double vv = s[i] + lbd;
         if (vv <= 0.0) v[NA + MAXD + 1] += 1.0;
         const double vi = 1.0 / vv;
@@ -160,7 +65,7 @@ __device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const d
         v[NA + MAXD] += log(vv);
     }
     const int nv_used = NV;  // reduce everything (unused slots are zeros)
-    block_sum<NV>(v, nv_used, shm);
+    Par<WAVE>::template sum<NV>(v, nv_used, shm);
 
     o.ok = true;
     o.logdetv = v[NA + MAXD];
@@ -209,7 +114,8 @@ __device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const d
     }
     // pass 2: explicit residual quadratic form (reml.rs:327-344)
     double qv[1] = {0.0};
-    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+#pragma unroll 2
+    for (int i = Par<WAVE>::tid(); i < n; i += Par<WAVE>::kThreads) {
         const double vi = 1.0 / (s[i] + lbd);
         double xb = 0.0;
 #pragma unroll
@@ -222,19 +128,19 @@ __device__ void eval_normal_eq(double lbd, const double *__restrict__ s, const d
         const double ri = y[i] - xb;
         qv[0] += vi * ri * ri;
     }
-    block_sum<1>(qv, 1, shm);
+    Par<WAVE>::template sum<1>(qv, 1, shm);
     o.q = qv[0];
 }
 
 // -reml_loglike (the Brent objective). Failure -> +1e8 (reference returns -1e8 for the log-likelihood).
-template <int MAXD>
+template <int MAXD, bool WAVE>
 __device__ double neg_reml(double x, const double *s, const double *xcov, const double *y, const float *g, int n,
                            int p_cov, double *shm) {
     const double lbd = pow(10.0, x);
     const int dim = p_cov + (g ? 1 : 0);
     if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return 1e8;
     EvalOut<MAXD> o;
-    eval_normal_eq<MAXD>(lbd, s, xcov, y, g, n, p_cov, shm, o, false);
+    eval_normal_eq<MAXD, WAVE>(lbd, s, xcov, y, g, n, p_cov, shm, o, false);
     if (!o.ok) return 1e8;
     const double nf = (double)n, pf = (double)dim;
     const double total = (nf - pf) * log(o.q) + o.logdetv + o.logdetx;
@@ -244,7 +150,7 @@ __device__ double neg_reml(double x, const double *s, const double *xcov, const 
 }
 
 // src/math/brent.rs:1-136, verbatim control flow (including `e` not being updated on parabolic steps).
-template <int MAXD>
+template <int MAXD, bool WAVE>
 __device__ void brent_reml(const double *s, const double *xcov, const double *y, const float *g, int n, int p_cov,
                            double low, double high, double tol, int max_iter, bool has_init, double init,
                            double *shm, double &xbest, double &fbest, int &evals) {
@@ -258,7 +164,7 @@ __device__ void brent_reml(const double *s, const double *xcov, const double *y,
     tol = fmax(fabs(tol), 1e-12);
     double x = (has_init && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
     double w = x, v = x;
-    double fx = neg_reml<MAXD>(x, s, xcov, y, g, n, p_cov, shm);
+    double fx = neg_reml<MAXD, WAVE>(x, s, xcov, y, g, n, p_cov, shm);
     double fw = fx, fv = fx;
     double d = 0.0, e = 0.0;
     evals = 1;
@@ -295,7 +201,7 @@ __device__ void brent_reml(const double *s, const double *xcov, const double *y,
         }
         if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
         u = x + d;
-        const double fu = neg_reml<MAXD>(u, s, xcov, y, g, n, p_cov, shm);
+        const double fu = neg_reml<MAXD, WAVE>(u, s, xcov, y, g, n, p_cov, shm);
         ++evals;
         if (fu <= fx) {
             if (u >= x)
@@ -328,16 +234,10 @@ __device__ void brent_reml(const double *s, const double *xcov, const double *y,
     fbest = fx;
 }
 
-__device__ __forceinline__ double chi2_sf_df1_dev(double stat) {  // src/math/linalg.rs:7-17
-    if (!isfinite(stat) || stat <= 0.0) return 1.0;
-    double p = erfc(sqrt(0.5 * stat));
-    if (!isfinite(p)) return 1.0;
-    if (p < 2.2250738585072014e-308) p = 2.2250738585072014e-308;
-    if (p > 1.0) p = 1.0;
-    return p;
-}
 
-// src/stats/lmm.rs:94-199: one workgroup per rotated SNP row.
+// src/stats/lmm.rs:94-199: one WAVE per rotated SNP row (4 rows in flight per workgroup, no barriers, no LDS):
+// every lane owns the samples lane, lane+64, ...; reductions are wave butterflies, so each wave follows its own
+// Brent trajectory with wave-uniform control flow.
 template <int MAXD>
 __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__restrict__ grot, int nrows, int n,
                                                                 const double *__restrict__ s,
@@ -347,21 +247,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
                                                                 double init, int with_plrt, double nullml,
                                                                 double *__restrict__ out,
                                                                 int32_t *__restrict__ evals_out) {
-    constexpr int NV = MAXD * (MAXD + 1) / 2 + MAXD + 2;
-    __shared__ double shm[SCAN_WAVES * NV];
+    constexpr bool WAVE = true;
+    double *shm = nullptr;
     const int out_cols = with_plrt ? 4 : 3;
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
         const float *g = grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         // lmm.rs:63-72: ssq of the rotated row
         double ssq[1] = {0.0};
-        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        for (int i = lane; i < n; i += 64) {
             const double v = (double)g[i];
             ssq[0] += v * v;
         }
-        block_sum<1>(ssq, 1, shm);
+        ssq[0] = wave_allsum(ssq[0]);
         if (!isfinite(ssq[0]) || ssq[0] <= 1e-12) {
-            if (threadIdx.x == 0) {
+            if (lane == 0) {
                 o[0] = nan("");
                 o[1] = nan("");
                 o[2] = 1.0;
@@ -372,7 +274,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
         }
         double xb, fb;
         int ne = 0;
-        brent_reml<MAXD>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, warm != 0, init, shm, xb, fb, ne);
+        brent_reml<MAXD, WAVE>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, warm != 0, init, shm, xb, fb, ne);
         // final_beta_se (reml.rs:472-568)
         const double lbd = pow(10.0, xb);
         const int dim = p_cov + 1;
@@ -381,7 +283,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
         bool have = false;
         if (isfinite(lbd) && lbd > 0.0 && n > dim) {
             EvalOut<MAXD> e;
-            eval_normal_eq<MAXD>(lbd, s, xcov, y, g, n, p_cov, shm, e, true);
+            eval_normal_eq<MAXD, WAVE>(lbd, s, xcov, y, g, n, p_cov, shm, e, true);
             if (e.ok) {
                 const double sigma2 = e.q / ((double)n - (double)dim);
                 const double var = sigma2 * e.ainv_kk;
@@ -394,7 +296,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
                 have = true;
             }
         }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             if (evals_out) evals_out[r] = ne;
             if (isfinite(beta) && isfinite(se) && se > 0.0) {
                 const double z = beta / se;
@@ -439,12 +341,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_null_kernel(const double *__
     __shared__ double shm[SCAN_WAVES * NV];
     double xb, fb;
     int ne = 0;
-    brent_reml<MAXD>(s, xcov, y, nullptr, n, p_cov, low, high, tol, max_iter, false, 0.0, shm, xb, fb, ne);
+    brent_reml<MAXD, false>(s, xcov, y, nullptr, n, p_cov, low, high, tol, max_iter, false, 0.0, shm, xb, fb, ne);
     const double lbd = pow(10.0, xb);
     double ml = -1e8;
     if (isfinite(lbd) && lbd > 0.0 && n > p_cov) {
         EvalOut<MAXD> e;
-        eval_normal_eq<MAXD>(lbd, s, xcov, y, nullptr, n, p_cov, shm, e, false);
+        eval_normal_eq<MAXD, false>(lbd, s, xcov, y, nullptr, n, p_cov, shm, e, false);
         if (e.ok && isfinite(e.q) && e.q > 0.0) {
             const double nf = (double)n;
             const double v = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * log(e.q) + e.logdetv);
@@ -679,15 +581,16 @@ extern "C" int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const 
     return 0;
 }
 
-extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+extern "C" int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
                             const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
                             double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
                             void *stream) {
     if (nrows <= 0) return 0;
-    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan: p out of range");
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_exact: p out of range");
     if (!(low < high)) return fail("low must be < high");
     const int dim = p + 1;
-    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(dim, hipLaunchKernelGGL(lmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                             (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high,
                                             tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out, d_evals));
@@ -716,6 +619,19 @@ extern "C" int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const 
     h_scalars3[0] = sc[0];
     h_scalars3[1] = sc[1];
     h_scalars3[2] = (double)df;
+    return 0;
+}
+
+extern "C" int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
+                                  const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out,
+                                  void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_scan: p out of range");
+    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                          (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df,
+                                          d_out));
+    JX_LAUNCH_CHECK();
     return 0;
 }
 

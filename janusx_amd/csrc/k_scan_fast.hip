@@ -1,0 +1,596 @@
+// Exact per-SNP REML scan, fast formulation.
+//
+// Same objective, same Brent control flow and same outputs as `lmm_scan_kernel` (k_scan.hip, the line-by-line
+// restatement of src/stats/lmm.rs:94-199 / src/stats/reml.rs:255-568), but each objective evaluation touches the
+// n rotated samples ONCE and only for the SNP-specific sums:
+//
+//   REML(x; g) needs, at lambda = 10^x,   A = X'V^-1X,  b = X'V^-1y,  y'V^-1y,  sum ln v      (lambda-only)
+//                                          c = X'V^-1g,  g'V^-1g,  g'V^-1y                       (per SNP)
+//   and  r'V^-1r = y'V^-1y - 2 beta'b + beta'A0 beta  (A0 = normal matrix without the 1e-6 ridge).
+//
+// * The lambda-only sums are analytic in x on a strip |Im x| < pi/ln 10 (their only singularities sit at
+//   10^x = -s_i), so on segments of width <= 2 a 32-term Chebyshev series reproduces them to ~3e-16 relative
+//   (rho = 3.05, rho^-32 = 3e-16).  They are tabulated once per call (`cheb_nodes_kernel`, 32 nodes per segment,
+//   exact f64 sums) and evaluated by Clenshaw recurrences inside the scan.
+// * y is shifted by the null GLS fit at the interval midpoint (y_c = y - X beta_mid): REML, beta_g and SE are
+//   invariant to it (X spans the shift) and the moment form of r'V^-1r no longer cancels a large mean.
+// * 1/(s_i + lambda): v_rcp_f64 seed + two Newton steps (<= 1 ulp), instead of the IEEE division sequence.
+// One wave per SNP, no LDS, no barriers.  `jxg_lmm_scan_exact` keeps the two-pass reference formulation.
+#include <stdlib.h>
+
+#include "scan_common.h"
+
+namespace jx {
+
+constexpr int CH_N = 32;          // Chebyshev terms per segment
+constexpr int CH_MAXSEG = 8;      // (high - low) <= 16
+
+struct ChebHeader {
+    int nseg;
+    int nf;       // number of tabulated functions: 1 + NAc + p + 1
+    double low;
+    double segw;
+};
+
+__device__ __forceinline__ double fast_rcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
+// y_c = y - X beta_mid, beta_mid = GLS fit of the null model at lambda_mid (single workgroup).
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void yshift_kernel(const double *__restrict__ s,
+                                                              const double *__restrict__ xcov,
+                                                              const double *__restrict__ y, int n, int p, double lbd,
+                                                              double *__restrict__ yc, double *__restrict__ smin_out) {
+    constexpr int NA = MAXD * (MAXD + 1) / 2;
+    constexpr int NV = NA + MAXD;
+    __shared__ double shm[SCAN_WAVES * NV];
+    __shared__ double smin_sh[SCAN_WAVES];
+    double v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
+    double smin = 1e300;
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double si = s[i];
+        smin = fmin(smin, si);
+        const double vi = 1.0 / (si + lbd);
+        const double yi = y[i];
+        double xr[MAXD];
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) xr[r] = (r < p) ? xcov[(int64_t)i * p + r] : 0.0;
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            const double vx = vi * xr[r];
+            v[NA + r] += vx * yi;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                v[idx] += vx * xr[c];
+                ++idx;
+            }
+        }
+    }
+    block_sum<NV>(v, NV, shm);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) smin = fmin(smin, __shfl_xor(smin, off, 64));
+    if ((threadIdx.x & 63) == 0) smin_sh[threadIdx.x >> 6] = smin;
+    __syncthreads();
+    double a[MAXD * MAXD], b[MAXD], beta[MAXD];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            b[r] = v[NA + r];
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                a[r * MAXD + c] = v[idx];
+                a[c * MAXD + r] = v[idx];
+                ++idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < p) a[r * MAXD + r] += 1e-6;
+    const bool ok = chol_inplace<MAXD>(a, p);
+    chol_solve<MAXD>(a, p, b, beta);
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        double xb = 0.0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r)
+            if (r < p) xb += xcov[(int64_t)i * p + r] * beta[r];
+        yc[i] = ok ? (y[i] - xb) : y[i];
+    }
+    if (threadIdx.x == 0) {
+        double m = smin_sh[0];
+        for (int w = 1; w < SCAN_WAVES; ++w) m = fmin(m, smin_sh[w]);
+        smin_out[0] = m;
+    }
+}
+
+// One workgroup per Chebyshev node: exact f64 sums of the lambda-only functions at x_k.
+// vals[(seg * nf + f) * CH_N + k];  f = 0: sum ln v; 1..NAc: lower triangle of X'V^-1X; then X'V^-1 y_c; y_c'V^-1y_c.
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void cheb_nodes_kernel(const double *__restrict__ s,
+                                                                  const double *__restrict__ xcov,
+                                                                  const double *__restrict__ yc, int n, int p,
+                                                                  double low, double segw, int nf,
+                                                                  double *__restrict__ vals) {
+    constexpr int NA = MAXD * (MAXD + 1) / 2;
+    constexpr int NV = NA + MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    const int seg = blockIdx.x / CH_N, k = blockIdx.x % CH_N;
+    const double t = cos(M_PI * ((double)k + 0.5) / (double)CH_N);
+    const double x = low + segw * ((double)seg + 0.5) + 0.5 * segw * t;
+    const double lbd = pow(10.0, x);
+    double v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = 0.0;
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double vv = s[i] + lbd;
+        const double vi = 1.0 / vv;
+        const double yi = yc[i];
+        double xr[MAXD];
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) xr[r] = (r < p) ? xcov[(int64_t)i * p + r] : 0.0;
+        v[NA + MAXD] += log(vv);
+        v[NA + MAXD + 1] += vi * yi * yi;
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) {
+            const double vx = vi * xr[r];
+            v[NA + r] += vx * yi;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                v[idx] += vx * xr[c];
+                ++idx;
+            }
+        }
+    }
+    block_sum<NV>(v, NV, shm);
+    if (threadIdx.x == 0) {
+        double *o = vals + (int64_t)seg * nf * CH_N;
+        o[0 * CH_N + k] = v[NA + MAXD];
+        int f = 1;
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                if (r < p) {
+                    o[f * CH_N + k] = v[idx];
+                    ++f;
+                }
+                ++idx;
+            }
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r)
+            if (r < p) {
+                o[f * CH_N + k] = v[NA + r];
+                ++f;
+            }
+        o[f * CH_N + k] = v[NA + MAXD + 1];
+    }
+}
+
+// node values -> Chebyshev coefficients (DCT-II), one thread per (seg, f, j)
+__global__ void cheb_coef_kernel(const double *__restrict__ vals, int total_funcs, double *__restrict__ coef) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_funcs * CH_N) return;
+    const int fn = gid / CH_N, j = gid % CH_N;
+    const double *v = vals + (int64_t)fn * CH_N;
+    double acc = 0.0;
+    for (int k = 0; k < CH_N; ++k) acc += v[k] * cos(M_PI * (double)j * ((double)k + 0.5) / (double)CH_N);
+    coef[gid] = acc * (2.0 / (double)CH_N);
+}
+
+__device__ __forceinline__ double clenshaw(const double *__restrict__ c, double t) {
+    double b1 = 0.0, b2 = 0.0;
+    const double t2 = 2.0 * t;
+#pragma unroll 8
+    for (int j = CH_N - 1; j >= 1; --j) {
+        const double b0 = fma(t2, b1, c[j] - b2);
+        b2 = b1;
+        b1 = b0;
+    }
+    return fma(t, b1, 0.5 * c[0] - b2);
+}
+
+template <int MAXD>
+struct FastEval {
+    bool ok;
+    double reml_neg;  // Brent objective (-REML), 1e8 on failure
+    double q, logdetv, beta_k, ainv_kk;
+};
+
+// One evaluation for the SNP owned by this wave. MAXD bounds dim = p + 1.
+template <int MAXD>
+__device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const double *__restrict__ coef,
+                                          double smin, const double *__restrict__ s,
+                                          const double *__restrict__ xcov, const double *__restrict__ yc,
+                                          const float *__restrict__ g, int n, int p, bool want_ainv,
+                                          FastEval<MAXD> &o) {
+    const int dim = p + 1;
+    const int lane = threadIdx.x & 63;
+    o.ok = false;
+    o.reml_neg = 1e8;
+    o.q = 0.0;
+    o.logdetv = 0.0;
+    o.beta_k = 0.0;
+    o.ainv_kk = 0.0;
+    const double lbd = jx_pow10(x);
+    if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return;
+    if (smin + lbd <= 0.0) return;
+
+    // ---- SNP-specific sums: c[r] = sum g x_r / v, gg = sum g^2 / v, gy = sum g y_c / v -------------------
+    double acc[MAXD + 1];
+#pragma unroll
+    for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
+#pragma unroll 4
+    for (int i = lane; i < n; i += 64) {
+        const double vi = fast_rcp(s[i] + lbd);
+        const double gi = (double)g[i];
+        const double gv = gi * vi;
+#pragma unroll
+        for (int r = 0; r < MAXD - 1; ++r)
+            if (r < p) acc[r] = fma(gv, xcov[(int64_t)i * p + r], acc[r]);
+        acc[MAXD - 1] = fma(gv, gi, acc[MAXD - 1]);
+        acc[MAXD] = fma(gv, yc[i], acc[MAXD]);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+
+    // ---- lambda-only sums from the Chebyshev tables ---------------------------------------------------
+    int seg = (int)((x - hd.low) / hd.segw);
+    if (seg < 0) seg = 0;
+    if (seg >= hd.nseg) seg = hd.nseg - 1;
+    const double t = (x - (hd.low + hd.segw * ((double)seg + 0.5))) / (0.5 * hd.segw);
+    const double *cf = coef + (int64_t)seg * hd.nf * CH_N;
+    // lane f evaluates tabulated function f (nf <= 64 is guaranteed by the host wrapper), results are then
+    // read across lanes: one 32-term Clenshaw per evaluation instead of nf of them.
+    const double myval = clenshaw(cf + (lane < hd.nf ? lane : 0) * CH_N, t);
+    const double logdetv = __shfl(myval, 0, 64);
+    double a0[MAXD * MAXD], a[MAXD * MAXD], b[MAXD], beta[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD * MAXD; ++k) a0[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD - 1; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            const double val = __shfl(myval, 1 + r * (r + 1) / 2 + c, 64);
+            if (r < p) {
+                a0[r * MAXD + c] = val;
+                a0[c * MAXD + r] = val;
+            }
+        }
+    const int fb = 1 + p * (p + 1) / 2;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) b[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD - 1; ++r) {
+        const double val = __shfl(myval, fb + r, 64);
+        if (r < p) b[r] = val;
+    }
+    const double yy = __shfl(myval, fb + p, 64);
+    // SNP row/column at index p (compile-time positions via select)
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) {
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) {
+            if (r == p && c < p) a0[r * MAXD + c] = acc[c < MAXD - 1 ? c : 0];
+            if (c == p && r < p) a0[r * MAXD + c] = acc[r < MAXD - 1 ? r : 0];
+            if (r == p && c == p) a0[r * MAXD + c] = acc[MAXD - 1];
+        }
+        if (r == p) b[r] = acc[MAXD];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD * MAXD; ++k) a[k] = a0[k];
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) a[r * MAXD + r] += 1e-6;
+    if (!chol_inplace<MAXD>(a, dim)) return;
+    chol_solve<MAXD>(a, dim, b, beta);
+    // r'V^-1 r = yy - 2 beta'b + beta'A0 beta
+    double bb = 0.0, bab = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) {
+        if (r < dim) {
+            bb += beta[r] * b[r];
+            double row = 0.0;
+#pragma unroll
+            for (int c = 0; c < MAXD; ++c)
+                if (c < dim) row += a0[r * MAXD + c] * beta[c];
+            bab += beta[r] * row;
+        }
+    }
+    const double q = yy - 2.0 * bb + bab;
+    double ld = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) ld += jx_log(a[r * MAXD + r]);
+    const double nf = (double)n, pf = (double)dim;
+    const double total = (nf - pf) * jx_log(q) + logdetv + 2.0 * ld;
+    const double cst = (nf - pf) * (jx_log(nf - pf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0;
+    const double reml = cst - 0.5 * total;
+    o.ok = true;
+    o.reml_neg = isfinite(reml) ? -reml : 1e8;
+    o.q = q;
+    o.logdetv = logdetv;
+    o.beta_k = pick<MAXD>(beta, dim - 1);
+    if (want_ainv) {
+        double e[MAXD], xk[MAXD];
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r) e[r] = (r == dim - 1) ? 1.0 : 0.0;
+        chol_solve<MAXD>(a, dim, e, xk);
+        o.ainv_kk = pick<MAXD>(xk, dim - 1);
+    }
+}
+
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_fast_kernel(
+    const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s, const double *__restrict__ xcov,
+    const double *__restrict__ yc, int p, const ChebHeader hd, const double *__restrict__ coef,
+    const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
+    int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out) {
+    const int out_cols = with_plrt ? 4 : 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const double smin = smin_ptr[0];
+    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
+        const float *g = grot + (int64_t)r * n;
+        double *o = out + (int64_t)r * out_cols;
+        double ssq = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const double v = (double)g[i];
+            ssq += v * v;
+        }
+        ssq = wave_allsum(ssq);
+        if (!isfinite(ssq) || ssq <= 1e-12) {
+            if (lane == 0) {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = 1.0;
+                if (with_plrt) o[3] = 1.0;
+                if (evals_out) evals_out[r] = 0;
+            }
+            continue;
+        }
+        FastEval<MAXD> ev;
+        // ---- Brent (src/math/brent.rs:1-136, verbatim control flow) -----------------------------------
+        double a = low, c = high;
+        if (!(a < c)) {
+            const double tt = a;
+            a = c;
+            c = tt;
+        }
+        const double eps = 2.220446049250313e-16;
+        const double tol = fmax(fabs(tol_in), 1e-12);
+        double x = (warm && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
+        double w = x, v = x;
+        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, false, ev);
+        double fx = ev.reml_neg, fw = fx, fv = fx;
+        double d = 0.0, e = 0.0;
+        int evals = 1;
+        for (int it = 0; it < max_iter; ++it) {
+            const double m = 0.5 * (a + c);
+            const double tol1 = tol * fabs(x) + eps;
+            const double tol2 = 2.0 * tol1;
+            if (fabs(x - m) <= tol2 - 0.5 * (c - a)) break;
+            double u;
+            bool use_par = false;
+            if (fabs(e) > tol1) {
+                double pq = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw));
+                double q = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)));
+                if (q > 0.0)
+                    pq = -pq;
+                else
+                    q = -q;
+                bool ok = false;
+                if (fabs(q) > eps) {
+                    const double sstep = pq / q;
+                    u = x + sstep;
+                    if ((u - a) >= tol2 && (c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(e)) ok = true;
+                }
+                if (ok) {
+                    d = pq / q;
+                    u = x + d;
+                    if ((u - a) < tol2 || (c - u) < tol2) d = (x < m) ? tol1 : -tol1;
+                    use_par = true;
+                }
+            }
+            if (!use_par) {
+                e = (x < m) ? (c - x) : (a - x);
+                d = 0.3819660 * e;
+            }
+            if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
+            u = x + d;
+            fast_eval<MAXD>(u, hd, coef, smin, s, xcov, yc, g, n, p, false, ev);
+            const double fu = ev.reml_neg;
+            ++evals;
+            if (fu <= fx) {
+                if (u >= x)
+                    a = x;
+                else
+                    c = x;
+                v = w;
+                fv = fw;
+                w = x;
+                fw = fx;
+                x = u;
+                fx = fu;
+            } else {
+                if (u >= x)
+                    c = u;
+                else
+                    a = u;
+                if (fu <= fw || w == x) {
+                    v = w;
+                    fv = fw;
+                    w = u;
+                    fw = fu;
+                } else if (fu <= fv || v == x || v == w) {
+                    v = u;
+                    fv = fu;
+                }
+            }
+        }
+        // ---- final_beta_se (src/stats/reml.rs:472-568) at the optimum ------------------------------------
+        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, true, ev);
+        double beta = nan(""), se = nan("");
+        const int dim = p + 1;
+        if (ev.ok) {
+            const double sigma2 = ev.q / ((double)n - (double)dim);
+            const double var = sigma2 * ev.ainv_kk;
+            if (var > 0.0 && isfinite(var)) {
+                beta = ev.beta_k;
+                se = sqrt(var);
+            }
+        }
+        if (lane == 0) {
+            if (evals_out) evals_out[r] = evals;
+            if (isfinite(beta) && isfinite(se) && se > 0.0) {
+                const double z = beta / se;
+                double pv = 2.0 * (0.5 * jx_erfc(fabs(z) / 1.4142135623730951));
+                if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                if (pv > 1.0) pv = 1.0;
+                o[0] = beta;
+                o[1] = se;
+                o[2] = isfinite(pv) ? pv : 1.0;
+                if (with_plrt) {
+                    double plrt = 1.0;
+                    if (ev.ok && isfinite(ev.q) && ev.q > 0.0) {
+                        const double nf = (double)n;
+                        const double ml =
+                            nf * (jx_log(nf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * jx_log(ev.q) + ev.logdetv);
+                        if (isfinite(ml)) {
+                            double stat = 2.0 * (ml - nullml);
+                            if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                            plrt = chi2_sf_df1_dev(stat);
+                        }
+                    }
+                    o[3] = plrt;
+                }
+            } else {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = 1.0;
+                if (with_plrt) o[3] = 1.0;
+            }
+        }
+    }
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+#define JX_DISPATCH_DIM_F(dim, EXPR)                     \
+    do {                                                 \
+        if ((dim) <= 2) {                                \
+            constexpr int MAXD = 2;                      \
+            EXPR;                                        \
+        } else if ((dim) <= 4) {                         \
+            constexpr int MAXD = 4;                      \
+            EXPR;                                        \
+        } else if ((dim) <= 8) {                         \
+            constexpr int MAXD = 8;                      \
+            EXPR;                                        \
+        } else {                                         \
+            constexpr int MAXD = 16;                     \
+            EXPR;                                        \
+        }                                                \
+    } while (0)
+
+extern "C" int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                                  const double *d_y, int p, double low, double high, double tol, int max_iter,
+                                  int warm, double init_log10_lbd, int with_plrt, double nullml, double *d_out,
+                                  int32_t *d_evals, void *stream);
+
+// Workspace layout (doubles): [0] smin | [8..8+n) y_c | coef (total_funcs*CH_N) | vals (total_funcs*CH_N)
+static bool fast_path_ok(int p, double low, double high) {
+    return (high - low) <= 2.0 * CH_MAXSEG && (1 + p * (p + 1) / 2 + p + 1) <= 64 && !getenv("JXGPU_SCAN_EXACT");
+}
+
+static ChebHeader make_header(int p, double low, double high) {
+    ChebHeader hd;
+    hd.nseg = (int)ceil((high - low) / 2.0);
+    if (hd.nseg < 1) hd.nseg = 1;
+    hd.segw = (high - low) / hd.nseg;
+    hd.low = low;
+    hd.nf = 1 + p * (p + 1) / 2 + p + 1;
+    return hd;
+}
+
+extern "C" int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high) {
+    if (!fast_path_ok(p, low, high)) return 0;
+    const ChebHeader hd = make_header(p, low, high);
+    return (int64_t)sizeof(double) * (8 + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N);
+}
+
+extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
+                                    double low, double high, void *d_work, void *stream) {
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_tables_build: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_tables_build: configuration needs the exact scan path");
+    hipStream_t st = (hipStream_t)stream;
+    const ChebHeader hd = make_header(p, low, high);
+    const int total_funcs = hd.nseg * hd.nf;
+    double *w = (double *)d_work;
+    double *smin = w, *yc = w + 8, *coef = yc + n, *vals = coef + (int64_t)total_funcs * CH_N;
+    const double lbd_mid = pow(10.0, 0.5 * (low + high));
+    JX_DISPATCH_DIM_F(p, hipLaunchKernelGGL(yshift_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, st, d_s, d_xcov, d_y,
+                                            n, p, lbd_mid, yc, smin));
+    JX_LAUNCH_CHECK();
+    JX_DISPATCH_DIM_F(p, hipLaunchKernelGGL(cheb_nodes_kernel<MAXD>, dim3(hd.nseg * CH_N), dim3(SCAN_THREADS), 0, st,
+                                            d_s, d_xcov, yc, n, p, low, hd.segw, hd.nf, vals));
+    JX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cheb_coef_kernel, dim3((total_funcs * CH_N + 255) / 256), dim3(256), 0, st, vals, total_funcs,
+                       coef);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
+                                double low, double high, const void *d_work, double tol, int max_iter, int warm,
+                                double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                                void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_tab: p out of range");
+    if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_scan_tab: configuration needs the exact scan path");
+    const ChebHeader hd = make_header(p, low, high);
+    const double *w = (const double *)d_work;
+    const double *smin = w, *yc = w + 8, *coef = yc + n;
+    const int dim = p + 1;
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
+    JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL(lmm_scan_fast_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                              (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, yc, p, hd, coef, smin,
+                                              low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out,
+                                              d_evals));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                            const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                            double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                            void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    if (!fast_path_ok(p, low, high))
+        return jxg_lmm_scan_exact(d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high, tol, max_iter, warm,
+                                  init_log10_lbd, with_plrt, nullml, d_out, d_evals, stream);
+    hipStream_t st = (hipStream_t)stream;
+    void *work = nullptr;
+    JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
+    int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
+    if (!rc)
+        rc = jxg_lmm_scan_tab(d_grot, nrows, n, d_s, d_xcov, p, low, high, work, tol, max_iter, warm, init_log10_lbd,
+                              with_plrt, nullml, d_out, d_evals, stream);
+    (void)hipFreeAsync(work, st);
+    return rc;
+}

@@ -233,35 +233,58 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
     hi, lo = model.planes()
+    # one-off per call: fp16 hi/lo LUT records (range-checked) and, for the exact scan, the Chebyshev tables of the
+    # lambda-only REML sums; the block loop below then only launches kernels (no allocation, no host sync).
+    lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
+    check(lib().jxg_lut_split(_ptr(lut_t), mk, _ptr(lut16), _stream()))
+    tables = None
     if mode == "lmm":
         lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
         warm = 1 if init_log10_lbd is not None else 0
         init = float(init_log10_lbd) if init_log10_lbd is not None else 0.0
+        nbytes = int(lib().jxg_lmm_tables_bytes(n, model.p, lo_b, hi_b))
+        if nbytes > 0:
+            tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            check(lib().jxg_lmm_tables_build(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b,
+                                             _ptr(tables), _stream()))
     else:
         lbd, w, py, wx, a_chol, ypy, _, df = model.fv_cache(init_log10_lbd)
+        a_dev = torch.from_numpy(a_chol).to(dev)
     br = int(min(block_rows, mk))
-    grot = torch.empty((br, n), dtype=torch.float32, device=dev)
-    for r0 in range(0, mk, br):
+    nbuf = 2 if mk > br else 1
+    grots = [torch.empty((br, n), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    ev_rot = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((mk + br - 1) // br)]
+    ev_scan = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(len(ev_rot))]
+    for bi, r0 in enumerate(range(0, mk, br)):
         nr = min(br, mk - r0)
-        t0 = time.perf_counter()
-        check(lib().jxg_rotate_packed(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
-                                      lut_t[r0:].data_ptr(), _ptr(hi), _ptr(lo), SCALE_EXP, _ptr(grot), _stream()))
+        grot = grots[bi % nbuf]
         if times is not None:
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            times.add("rotate", t1 - t0)
-            t0 = t1
+            ev_rot[bi][0].record()
+        check(lib().jxg_rotate_packed16(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                        lut16[r0:].data_ptr(), _ptr(hi), _ptr(lo), SCALE_EXP, _ptr(grot), _stream()))
+        if times is not None:
+            ev_rot[bi][1].record()
+            ev_scan[bi][0].record()
         o = out[r0:]
         if mode == "lmm":
-            check(lib().jxg_lmm_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p,
-                                     lo_b, hi_b, float(tol), int(max_iter), warm, init, 0, 0.0, o.data_ptr(),
-                                     evals[r0:].data_ptr() if evals is not None else None, _stream()))
+            ev_p = evals[r0:].data_ptr() if evals is not None else None
+            if tables is not None:
+                check(lib().jxg_lmm_scan_tab(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), model.p, lo_b, hi_b,
+                                             _ptr(tables), float(tol), int(max_iter), warm, init, 0, 0.0,
+                                             o.data_ptr(), ev_p, _stream()))
+            else:
+                check(lib().jxg_lmm_scan_exact(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y),
+                                               model.p, lo_b, hi_b, float(tol), int(max_iter), warm, init, 0, 0.0,
+                                               o.data_ptr(), ev_p, _stream()))
         else:
-            check(lib().jxg_fvlmm_scan(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), a_chol.ctypes.data,
-                                       ypy, df, o.data_ptr(), _stream()))
+            check(lib().jxg_fvlmm_scan_dev(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev),
+                                           ypy, df, o.data_ptr(), _stream()))
         if times is not None:
-            torch.cuda.synchronize()
-            times.add("scan", time.perf_counter() - t0)
+            ev_scan[bi][1].record()
+    if times is not None:
+        torch.cuda.synchronize()
+        times.add("rotate", sum(a.elapsed_time(b) for a, b in ev_rot) * 1e-3)
+        times.add("scan", sum(a.elapsed_time(b) for a, b in ev_scan) * 1e-3)
     return (out, evals) if return_evals else out
 
 

@@ -3,6 +3,9 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include <mutex>
 
 #include "jx_common.h"
@@ -11,6 +14,8 @@ namespace jx {
 // kernels from k_misc.hip
 int launch_add_diag(double *d_a, int n, int64_t ld, double ridge, hipStream_t st);
 int launch_symmetrize(double *d_a, int n, hipStream_t st);
+// k_sytrd.hip: two-kernels-per-column Householder tridiagonalisation, LAPACK dsytrd(lower) output format
+int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau);
 
 static rocblas_handle g_handle = nullptr;
 static std::mutex g_handle_mu;
@@ -41,9 +46,27 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
     if (e.alloc(sizeof(double) * (size_t)n)) return 1;
     if (info.alloc(sizeof(rocblas_int))) return 1;
     // symmetric input: row-major == column-major; the lower triangle is referenced.
-    rocblas_status rs = rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, n, d_a, n, d_w,
-                                         e.as<double>(), info.as<rocblas_int>());
-    if (rs != rocblas_status_success) return fail("rocsolver_dsyevd failed with status " + std::to_string((int)rs));
+    const char *mode = getenv("JXGPU_EIGH");
+    const bool use_lib = (n < 256) || (mode && strcmp(mode, "rocsolver") == 0);
+    if (use_lib) {
+        rocblas_status rs = rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, n, d_a, n, d_w,
+                                             e.as<double>(), info.as<rocblas_int>());
+        if (rs != rocblas_status_success)
+            return fail("rocsolver_dsyevd failed with status " + std::to_string((int)rs));
+    } else {
+        // own tridiagonalisation (k_sytrd.hip) + rocSOLVER divide & conquer on T + back-transformation Z = Q C
+        DevBuf tau, c;
+        if (tau.alloc(sizeof(double) * (size_t)n)) return 1;
+        if (c.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
+        if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
+        rocblas_status rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
+                                             info.as<rocblas_int>());
+        if (rs != rocblas_status_success) return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
+        rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
+                              tau.as<double>(), c.as<double>(), n);
+        if (rs != rocblas_status_success) return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+        JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     rocblas_int hinfo = 0;
     JX_HIP(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));

@@ -1,0 +1,463 @@
+// Householder tridiagonalisation (LAPACK dsytrd, lower, column-major output format) with TWO kernels per column.
+//
+// Replaces the panel factorisation of rocSOLVER's dsytrd, which issues five tiny latrd_* kernels per column
+// (measured 155 ms of the 213 ms dsyevd at n = 5000; profiles/r01_bench_c2_lmm_kernel_stats.csv) behind
+// src/math/eigh.rs:1422-1528 (reference: LAPACK dsyevd on the CPU).  Output is exactly LAPACK's: d, e, tau and the
+// reflectors below the sub-diagonal of A, so rocSOLVER's dstedc + dormtr finish the eigendecomposition.
+//
+// Blocked algorithm (dlatrd): inside a panel of NB columns the trailing matrix is NOT updated; column j needs
+//   (1) a_j  -= V W(j,:)' + W V(j,:)'          (2) larfg -> v, tau, beta
+//   (3) y = T v (symv on the stale trailing matrix)   (4) w = tau (y - V (W'v) - W (V'v)) + alpha v
+// and the panel ends with T -= V W' + W V' (rocBLAS dsyr2k).  Global dependencies per column are folded into
+// two launches by moving every scalar reduction to where its inputs are already being streamed:
+//   sytrd_symv_kernel  B(j): tiles of the lower trailing matrix -> y (f64 atomics), v'Tv; row chunks -> V'v, W'v,
+//                            scaled reflector written to A / Vt; beta, tau derived in every block from the
+//                            norm accumulated by the previous launch.
+//   sytrd_update_kernel S(j): row-parallel w (alpha from v'Tv and (V'v).(W'v), no extra pass), then the
+//                            update of column j+1 and its norm for the next reflector.
+// Accumulators are double-buffered by column parity so no launch zeroes what a concurrent block still reads.
+#include <rocblas/rocblas.h>
+#include <stdlib.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int TD_NB = 64;     // panel width
+constexpr int TD_TS = 64;     // symv tile
+constexpr int TD_THREADS = 256;
+
+struct TdAcc {            // one per column parity
+    double *y;            // (n)
+    double *t1;           // (NB)  V'v
+    double *t2;           // (NB)  W'v
+    double *sc;           // [0] v'Tv, [1] norm^2 of the next column below its first sub-diagonal entry
+};
+
+struct TdParams {
+    double *a;            // (n,n) column-major, lower
+    int64_t ld;
+    int n;
+    double *w;            // (n, NB) column-major panel W
+    double *vt;           // (n, NB) row-major copy of the panel V (explicit unit entries)
+    double *wt;           // (n, NB) row-major copy of W
+    double *ubuf;         // (n) unscaled updated column j (rows j+1..)
+    double *vbuf;         // (n) scaled reflector of column j
+    double *d, *e, *tau;
+    TdAcc acc[2];
+};
+
+__device__ __forceinline__ void larfg_scalars(double alpha0, double xnorm2, int nt, double &beta, double &tau,
+                                              double &scale) {
+    // LAPACK dlarfg without the safmin rescaling loop (inputs here are O(1) kinship entries)
+    if (nt <= 1 || !(xnorm2 > 0.0)) {
+        beta = alpha0;
+        tau = 0.0;
+        scale = 0.0;
+    } else {
+        const double nrm = sqrt(alpha0 * alpha0 + xnorm2);
+        beta = (alpha0 >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha0) / beta;
+        scale = 1.0 / (alpha0 - beta);
+    }
+}
+
+// Panel start (column j = j0, no pending updates): d_j, unscaled column -> ubuf, norm^2 -> acc[par].sc[1].
+__global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams P, int j) {
+    const int par = j & 1;
+    const int r = j + 1 + blockIdx.x * TD_THREADS + threadIdx.x;
+    double sq = 0.0;
+    if (r < P.n) {
+        const double u = P.a[r + (int64_t)j * P.ld];
+        P.ubuf[r] = u;
+        if (r >= j + 2) sq = u * u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.d[j] = P.a[j + (int64_t)j * P.ld];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0 && sq != 0.0) unsafeAtomicAdd(&P.acc[par].sc[1], sq);
+}
+
+// B(j): see file header.  grid = nstrips + row chunks.
+// Symv work unit ("strip"): one 64-row block x up to K consecutive 64-column tiles of the lower triangle.  The next
+// tile's 8 x 16-byte loads per thread are issued before the current tile is reduced out of LDS, so every
+// workgroup keeps 32 KB in flight; the row product accumulates in registers across the strip (one atomic per row
+// per strip), the mirrored column product is reduced per tile.
+__global__ __launch_bounds__(TD_THREADS) void sytrd_symv_kernel(TdParams P, int j, int j0, int ktiles,
+                                                                int nstrips) {
+    __shared__ __attribute__((aligned(16))) double tile[TD_TS][TD_TS + 2];  // tile[c][r], pitch 66 (16-B rows)
+    __shared__ double vr[TD_TS], vc[TD_TS];
+    __shared__ double red[4][TD_TS];
+    __shared__ double red1[TD_THREADS / 64];
+    const int par = j & 1;
+    const int n = P.n;
+    const int nt = n - j - 1;       // trailing dimension
+    const int base = j + 1;         // first trailing row/col
+    const int i = j - j0;           // columns already in the panel
+    const int tid = threadIdx.x;
+
+    if ((int)blockIdx.x < nstrips) {
+        // ---- locate the strip: row block rb (rb+1 tiles), first tile cb0 ---------------------------------
+        // uniform decomposition: nsx strips per row block, strips entirely above the diagonal exit at once
+        const int side = (nt + TD_TS - 1) / TD_TS;
+        const int nsx = (side + ktiles - 1) / ktiles;
+        const int rb = blockIdx.x / nsx;
+        const int cb0 = (blockIdx.x - rb * nsx) * ktiles;
+        if (cb0 > rb) return;
+        const int cb1 = (cb0 + ktiles < rb + 1) ? (cb0 + ktiles) : (rb + 1);
+        const int r0 = rb * TD_TS;
+        const int rp = tid & 31, cg = tid >> 5;
+        const int rr0 = r0 + 2 * rp;
+        double2 tv[8];
+        auto load_tile = [&](int cb) {
+            const int c0 = cb * TD_TS;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = c0 + cg + 8 * q;
+                double2 val = make_double2(0.0, 0.0);
+                if (c < nt) {
+                    const double *src = P.a + (base + rr0) + (int64_t)(base + c) * P.ld;
+                    if (rr0 + 1 < nt) {
+                        val = *reinterpret_cast<const double2 *>(src);
+                    } else if (rr0 < nt) {
+                        val.x = src[0];
+                    }
+                }
+                tv[q] = val;
+            }
+        };
+        load_tile(cb0);
+        // raw reflector pieces: rows of this strip (threads 0..63) and columns of the first tile (64..127)
+        double raw_r = 0.0, raw_c = 0.0;
+        if (tid < TD_TS) {
+            const int vi = r0 + tid;
+            if (vi < nt) raw_r = P.ubuf[base + vi];
+        } else if (tid < 2 * TD_TS) {
+            const int vi = cb0 * TD_TS + tid - TD_TS;
+            if (vi < nt) raw_c = P.ubuf[base + vi];
+        }
+        double beta, tau, scale;
+        larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
+        if (tid < TD_TS) {
+            const int vi = r0 + tid;
+            vr[tid] = (vi < nt) ? (vi == 0 ? 1.0 : raw_r * scale) : 0.0;
+        }
+        const int tr = tid & 63, tg = tid >> 6;
+        const int qc = tid >> 2, qs = tid & 3;
+        double p = 0.0, contrib = 0.0;
+        for (int cb = cb0; cb < cb1; ++cb) {
+            const int c0 = cb * TD_TS;
+            const bool diag = (cb == rb);
+            if (tid >= TD_TS && tid < 2 * TD_TS) {
+                const int vi = c0 + tid - TD_TS;
+                vc[tid - TD_TS] = (vi < nt) ? (vi == 0 ? 1.0 : raw_c * scale) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cc = cg + 8 * q;
+                double2 val = tv[q];
+                if (diag) {  // keep the lower triangle (incl. diagonal) of a diagonal tile
+                    if (2 * rp < cc) val.x = 0.0;
+                    if (2 * rp + 1 < cc) val.y = 0.0;
+                }
+                *reinterpret_cast<double2 *>(&tile[cc][2 * rp]) = val;
+            }
+            __syncthreads();
+            if (cb + 1 < cb1) {  // next tile and its reflector piece in flight while this tile is reduced
+                load_tile(cb + 1);
+                if (tid >= TD_TS && tid < 2 * TD_TS) {
+                    const int vi = (cb + 1) * TD_TS + tid - TD_TS;
+                    raw_c = (vi < nt) ? P.ubuf[base + vi] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < TD_TS / 4; ++q4) p += tile[tg + 4 * q4][tr] * vc[tg + 4 * q4];
+            double q = 0.0;
+#pragma unroll
+            for (int q4 = 0; q4 < TD_TS / 4; ++q4) {
+                const int rr = qs + 4 * q4;
+                const double val = tile[qc][rr];
+                if (!diag || rr != qc) q += val * vr[rr];
+            }
+            q += __shfl_xor(q, 1, 64);
+            q += __shfl_xor(q, 2, 64);
+            if (qs == 0) {
+                if (c0 + qc < nt && q != 0.0) unsafeAtomicAdd(&P.acc[par].y[base + c0 + qc], q);
+                contrib += vc[qc] * q;
+            }
+            __syncthreads();
+        }
+        red[tg][tr] = p;
+        __syncthreads();
+        if (tid < TD_TS) {
+            const double pr = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            if (r0 + tid < nt && pr != 0.0) unsafeAtomicAdd(&P.acc[par].y[base + r0 + tid], pr);
+            contrib += vr[tid] * pr;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) contrib += __shfl_down(contrib, off, 64);
+        if ((tid & 63) == 0) red1[tid >> 6] = contrib;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = red1[0] + red1[1] + red1[2] + red1[3];
+            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par].sc[0], tot);
+        }
+        return;
+    }
+    const int ntiles = nstrips;
+    double beta, tau, scale;
+    larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
+
+    // ---- row chunk (64 rows): scaled reflector out, V'v and W'v partial sums -----------------------------
+    const int chunk = blockIdx.x - ntiles;
+    const int rrow0 = chunk * TD_TS;  // relative row of this block's first row
+    __shared__ double vsh[TD_TS];
+    __shared__ double part[2][4][TD_NB];
+    if (tid < TD_TS) {
+        const int rr = rrow0 + tid;
+        double v = 0.0;
+        if (rr < nt) {
+            v = (rr == 0) ? 1.0 : P.ubuf[base + rr] * scale;
+            P.a[(base + rr) + (int64_t)j * P.ld] = v;  // explicit reflector (unit entry included) while in the panel
+            P.vbuf[base + rr] = v;
+            P.vt[(int64_t)(base + rr) * TD_NB + i] = v;
+        }
+        vsh[tid] = v;
+    }
+    if (chunk == 0 && tid == 0) {
+        P.e[j] = beta;
+        P.tau[j] = tau;
+        // zero the norm accumulator of the other parity (S(j) accumulates into it)
+        P.acc[par ^ 1].sc[1] = 0.0;
+    }
+    if (i > 0) {
+        __syncthreads();
+        // t1[k] += sum_r Vt[r][k] v_r ; t2[k] += sum_r Wt[r][k] v_r : thread (k = tid & 63, sub = tid >> 6), 16 rows
+        const int k = tid & 63, sub = tid >> 6;
+        double s1 = 0.0, s2 = 0.0;
+        if (k < i) {
+            double vv[16], a1[16], a2[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rloc = sub * 16 + q;
+                const bool okr = (rrow0 + rloc) < nt;
+                const int64_t row = (int64_t)(base + rrow0 + (okr ? rloc : 0)) * TD_NB;
+                vv[q] = okr ? vsh[rloc] : 0.0;
+                a1[q] = P.vt[row + k];
+                a2[q] = P.wt[row + k];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                s1 += a1[q] * vv[q];
+                s2 += a2[q] * vv[q];
+            }
+        }
+        part[0][sub][k] = s1;
+        part[1][sub][k] = s2;
+        __syncthreads();
+        if (tid < i) {
+            const double a1 = part[0][0][tid] + part[0][1][tid] + part[0][2][tid] + part[0][3][tid];
+            const double a2 = part[1][0][tid] + part[1][1][tid] + part[1][2][tid] + part[1][3][tid];
+            if (a1 != 0.0) unsafeAtomicAdd(&P.acc[par].t1[tid], a1);
+            if (a2 != 0.0) unsafeAtomicAdd(&P.acc[par].t2[tid], a2);
+        }
+    }
+}
+
+// S(j): see file header. Four threads per trailing row (16 panel columns each), 64 rows per block.
+__global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, int j, int j0, int do_next) {
+    __shared__ double t1s[TD_NB], t2s[TD_NB], vj1[TD_NB], wj1k[TD_NB];
+    __shared__ double scal[2];
+    __shared__ double redn[TD_THREADS / 64];
+    const int par = j & 1;
+    const int n = P.n;
+    const int base = j + 1;
+    const int nt = n - j - 1;
+    const int i = j - j0;
+    const int tid = threadIdx.x;
+    const double tau = P.tau[j];
+    // row-side loads are independent of the scalars below: issue them first
+    const int rloc = tid >> 2, q = tid & 3;
+    const int rr = blockIdx.x * TD_TS + rloc;  // relative trailing row
+    const bool okr = rr < nt;
+    const int r = base + (okr ? rr : 0);
+    double2 vv[8], ww[8];
+    {
+        const double2 *vrow = reinterpret_cast<const double2 *>(P.vt + (int64_t)r * TD_NB + q * 16);
+        const double2 *wrow = reinterpret_cast<const double2 *>(P.wt + (int64_t)r * TD_NB + q * 16);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            vv[h] = vrow[h];
+            ww[h] = wrow[h];
+        }
+    }
+    const double v_r = P.vbuf[r];
+    const double y_r = P.acc[par].y[r];
+    const double a_next = do_next ? P.a[r + (int64_t)(j + 1) * P.ld] : 0.0;
+    if (tid < TD_NB) {
+        const double a1 = (tid < i) ? P.acc[par].t1[tid] : 0.0;
+        const double a2 = (tid < i) ? P.acc[par].t2[tid] : 0.0;
+        const double b1 = (tid < i) ? P.vt[(int64_t)base * TD_NB + tid] : 0.0;
+        const double b2 = (tid < i) ? P.wt[(int64_t)base * TD_NB + tid] : 0.0;
+        t1s[tid] = a1;
+        t2s[tid] = a2;
+        vj1[tid] = b1;
+        wj1k[tid] = b2;
+        double dot = a1 * a2;
+        double s1 = b1 * a2 + b2 * a1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off, 64);
+            s1 += __shfl_xor(s1, off, 64);
+        }
+        if (tid == 0) {
+            const double yv = P.acc[par].sc[0];
+            const double alpha = -0.5 * tau * tau * (yv - 2.0 * dot);
+            // w at the first trailing row (v = 1 there): needed by every row for the next-column update
+            scal[0] = alpha;
+            scal[1] = tau * (P.acc[par].y[base] - s1) + alpha;
+        }
+    }
+    __syncthreads();
+    const double alpha = scal[0], w_first = scal[1];
+    double s1 = 0.0, s2 = 0.0;
+    {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int k0 = q * 16 + 2 * h;
+            if (k0 < i) {
+                s1 += vv[h].x * t2s[k0] + ww[h].x * t1s[k0];
+                s2 += vv[h].x * wj1k[k0] + ww[h].x * vj1[k0];
+            }
+            if (k0 + 1 < i) {
+                s1 += vv[h].y * t2s[k0 + 1] + ww[h].y * t1s[k0 + 1];
+                s2 += vv[h].y * wj1k[k0 + 1] + ww[h].y * vj1[k0 + 1];
+            }
+        }
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    double sq = 0.0;
+    if (okr && q == 0) {
+        const double v = v_r;
+        const double w = tau * (y_r - s1) + alpha * v;
+        P.w[r + (int64_t)i * n] = w;
+        P.wt[(int64_t)r * TD_NB + i] = w;
+        if (do_next) {
+            // column j+1 with the i+1 pending reflector pairs applied (rows >= j+1)
+            const double unew = a_next - s2 - (v * w_first + w);
+            if (rr == 0) {
+                P.d[j + 1] = unew;
+                P.a[r + (int64_t)(j + 1) * P.ld] = unew;
+            } else {
+                P.ubuf[r] = unew;
+                if (rr >= 2) sq = unew * unew;
+            }
+        }
+        P.acc[par ^ 1].y[r] = 0.0;
+    }
+    if (blockIdx.x == 0) {
+        if (tid < TD_NB) {
+            P.acc[par ^ 1].t1[tid] = 0.0;
+            P.acc[par ^ 1].t2[tid] = 0.0;
+        }
+        if (tid == 0) P.acc[par ^ 1].sc[0] = 0.0;
+    }
+    if (do_next) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if ((tid & 63) == 0) redn[tid >> 6] = sq;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = redn[0] + redn[1] + redn[2] + redn[3];
+            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par ^ 1].sc[1], tot);
+        }
+    }
+}
+
+// after the last panel: restore e on the sub-diagonal (LAPACK layout) and read the last diagonal entry
+__global__ void sytrd_finish_kernel(TdParams P) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P.n - 1) P.a[(j + 1) + (int64_t)j * P.ld] = P.e[j];
+    if (j == P.n - 1) P.d[j] = P.a[j + (int64_t)j * P.ld];
+}
+
+// d_a: (n,n) column-major symmetric (lower referenced), overwritten with the LAPACK dsytrd(lower) result.
+int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau) {
+    if (n < 2) {
+        if (n == 1) JX_HIP(hipMemcpyAsync(d_d, d_a, sizeof(double), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    DevBuf work;
+    const size_t nn = (size_t)n;
+    // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
+    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (nn + 2 * TD_NB + 2);
+    if (work.alloc(sizeof(double) * doubles)) return 1;
+    double *p = work.as<double>();
+    TdParams P;
+    P.a = d_a;
+    P.ld = n;
+    P.n = n;
+    P.w = p; p += nn * TD_NB;
+    P.vt = p; p += nn * TD_NB;
+    P.wt = p; p += nn * TD_NB;
+    P.ubuf = p; p += nn;
+    P.vbuf = p; p += nn;
+    double *acc_begin = p;
+    for (int q = 0; q < 2; ++q) {
+        P.acc[q].y = p; p += nn;
+        P.acc[q].t1 = p; p += TD_NB;
+        P.acc[q].t2 = p; p += TD_NB;
+        P.acc[q].sc = p; p += 2;
+    }
+    const size_t acc_bytes = sizeof(double) * (size_t)(p - acc_begin);
+    P.d = d_d;
+    P.e = d_e;
+    P.tau = d_tau;
+    const double minus1 = -1.0, one = 1.0;
+    for (int j0 = 0; j0 < n - 1; j0 += TD_NB) {
+        const int pw = (n - 1 - j0 < TD_NB) ? (n - 1 - j0) : TD_NB;
+        JX_HIP(hipMemsetAsync(acc_begin, 0, acc_bytes, st));
+        {
+            const int rows = n - j0 - 1;
+            hipLaunchKernelGGL(sytrd_panel_start_kernel, dim3((rows + TD_THREADS - 1) / TD_THREADS), dim3(TD_THREADS),
+                               0, st, P, j0);
+        }
+        for (int i = 0; i < pw; ++i) {
+            const int j = j0 + i;
+            const int nt = n - j - 1;
+            const int nchunks = (nt + TD_TS - 1) / TD_TS;
+            // strips: one 64-row block x K consecutive tiles; K grows with the tile count so that ~1000-2000
+            // workgroups stay in flight
+            const int side = (nt + TD_TS - 1) / TD_TS;
+            const int64_t ntiles = (int64_t)side * (side + 1) / 2;
+            static const int kt_env = getenv("JXGPU_SYTRD_KT") ? atoi(getenv("JXGPU_SYTRD_KT")) : 0;
+            int ktiles = kt_env > 0 ? kt_env : (int)((ntiles + 767) / 768);
+            if (ktiles < 1) ktiles = 1;
+            if (ktiles > 64) ktiles = 64;
+            const int nstrips = side * ((side + ktiles - 1) / ktiles);
+            hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0, ktiles,
+                               nstrips);
+            hipLaunchKernelGGL(sytrd_update_kernel, dim3(nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
+                               (i + 1 < pw) ? 1 : 0);
+        }
+        JX_LAUNCH_CHECK();
+        const int j1 = j0 + pw;      // first row/col of the trailing matrix after this panel
+        const int n2 = n - j1;
+        if (n2 > 0) {
+            // T -= V W' + W V'  (lower), V = A(j1:n, j0:j1), W = w(j1:n, 0:pw)
+            rocblas_status rs = rocblas_dsyr2k(h, rocblas_fill_lower, rocblas_operation_none, n2, pw, &minus1,
+                                               d_a + j1 + (int64_t)j0 * n, n, P.w + j1, n, &one,
+                                               d_a + j1 + (int64_t)j1 * n, n);
+            if (rs != rocblas_status_success) return fail("rocblas_dsyr2k failed: " + std::to_string((int)rs));
+        }
+    }
+    hipLaunchKernelGGL(sytrd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+    JX_LAUNCH_CHECK();
+    JX_HIP(hipStreamSynchronize(st));  // workspace is freed on return
+    return 0;
+}
+
+}  // namespace jx

@@ -1,4 +1,5 @@
-"""Times the device eigendecomposition (jxg_eigh_f64) for a few n. GPU box only."""
+"""Times / validates the device eigendecomposition (jxg_eigh_f64) for a few n. GPU box only.
+usage: time_eigh.py n1 n2 ...   (env JXGPU_EIGH=rocsolver selects the library path)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +12,7 @@ def main():
         g = torch.Generator(device=dev); g.manual_seed(1)
         z = torch.randn((n, n + 64), generator=g, device=dev, dtype=torch.float32)
         k = (z @ z.T / (n + 64)).to(torch.float64)
+        k = 0.5 * (k + k.T)
         del z
         for rep in range(2):
             a = k.clone()
@@ -18,11 +20,15 @@ def main():
             torch.cuda.synchronize(); t0 = time.perf_counter()
             check(lib().jxg_eigh_f64(a.data_ptr(), n, 1e-6, w.data_ptr(), torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        # residual check on a few vectors
-        v = a[-3:]  # rows = eigenvectors
         kk = k + 1e-6 * torch.eye(n, device=dev, dtype=torch.float64)
-        res = float((v @ kk - w[-3:, None] * v).abs().max())
-        print(f"n={n} eigh {dt*1e3:.1f} ms  resid {res:.2e}", flush=True)
-        del a, k, kk
+        v = a  # rows = eigenvectors
+        res = float((v @ kk - w[:, None] * v).abs().max())
+        orth = float((v @ v.T - torch.eye(n, device=dev, dtype=torch.float64)).abs().max())
+        wref = torch.linalg.eigvalsh(kk) if n <= 6000 else None
+        werr = float((w - wref).abs().max()) if wref is not None else float("nan")
+        asc = bool((w[1:] >= w[:-1]).all())
+        print(f"n={n} mode={os.environ.get('JXGPU_EIGH','custom')} eigh {dt*1e3:.1f} ms  resid {res:.2e} orth {orth:.2e} "
+              f"eval_err {werr:.2e} ascending {asc}", flush=True)
+        del a, k, kk, v
 
 main()

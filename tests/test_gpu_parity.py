@@ -372,4 +372,6 @@ def test_fast_scan_matches_exact_scan(oracle, null_case, monkeypatch):
             b, eb = outs[k + 2]
             assert np.array_equal(ea, eb), "Brent evaluation counts differ between fast and exact scan"
             be, se, pe = _assoc_err(a, b)
-            assert max(be, se) < 1e-7 and pe < 1e-6, (shift, k, be, se, pe)
+            # shift = 1e4 makes the two-pass reference formulation itself lose ~6 digits in the normal equations
+            lim = 1e-7 if shift == 0.0 else 1e-5
+            assert max(be, se) < lim and pe < 10 * lim, (shift, k, be, se, pe)

@@ -15,6 +15,7 @@
 //  * three v_mfma_f32_32x32x16_f16 products per k-step (hi*hi + hi*lo + lo*hi) into one f32 accumulator,
 //    flushed into the f64 HBM accumulator after <= kchunk SNPs (f32 block / f64 merge like the reference).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "jx_common.h"
 
@@ -27,8 +28,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int G_BK = 32;        // SNPs per step
-constexpr int G_PITCH = 320;    // bytes per SNP row of an LDS image (128 samples * 2 B + 64 B skew)
-constexpr int G_IMG = G_BK * G_PITCH;
 
 // value LUT (mk,4) f32 -> (mk) x {hi[4], lo[4]} fp16; flags[0] |= 1 if a value leaves the safe fp16 range.
 __global__ __launch_bounds__(256) void lut_split_kernel(const float *__restrict__ lut, int64_t mk,
@@ -68,44 +67,44 @@ __device__ __forceinline__ uint2 make_selectors(uint32_t byte) {
 }
 
 // 16 samples (one payload dword) -> 16 hi + 16 lo fp16 values, written as 2+2 ds_write_b128.
-__device__ __forceinline__ void decode16_to_lds(uint32_t w, const uint4 L, const uint2 *__restrict__ seltab,
-                                                uint8_t *dst_hi, uint8_t *dst_lo) {
+// `half_off` = byte distance between the two 16-byte halves of a plane (see the slot layout in the kernel).
+// Selectors come from a 16-entry table indexed by a payload NIBBLE (two samples): 16 dwords sit on 16 distinct
+// banks, so the lookup is conflict-free for any genotype distribution (the 256-entry byte table measured ~8-way
+// conflicts: common genotype bytes share their low five bits).
+__device__ __forceinline__ void decode16_to_lds(uint32_t w, const uint4 L, const uint32_t *__restrict__ seltab,
+                                                uint8_t *dst_hi, uint8_t *dst_lo, int half_off) {
     u32x4 h0, h1, l0, l1;
-    {
-        const uint2 s0 = seltab[w & 0xffu];
-        const uint2 s1 = seltab[(w >> 8) & 0xffu];
-        h0.x = __builtin_amdgcn_perm(L.y, L.x, s0.x);
-        h0.y = __builtin_amdgcn_perm(L.y, L.x, s0.y);
-        h0.z = __builtin_amdgcn_perm(L.y, L.x, s1.x);
-        h0.w = __builtin_amdgcn_perm(L.y, L.x, s1.y);
-        l0.x = __builtin_amdgcn_perm(L.w, L.z, s0.x);
-        l0.y = __builtin_amdgcn_perm(L.w, L.z, s0.y);
-        l0.z = __builtin_amdgcn_perm(L.w, L.z, s1.x);
-        l0.w = __builtin_amdgcn_perm(L.w, L.z, s1.y);
-    }
-    {
-        const uint2 s2 = seltab[(w >> 16) & 0xffu];
-        const uint2 s3 = seltab[w >> 24];
-        h1.x = __builtin_amdgcn_perm(L.y, L.x, s2.x);
-        h1.y = __builtin_amdgcn_perm(L.y, L.x, s2.y);
-        h1.z = __builtin_amdgcn_perm(L.y, L.x, s3.x);
-        h1.w = __builtin_amdgcn_perm(L.y, L.x, s3.y);
-        l1.x = __builtin_amdgcn_perm(L.w, L.z, s2.x);
-        l1.y = __builtin_amdgcn_perm(L.w, L.z, s2.y);
-        l1.z = __builtin_amdgcn_perm(L.w, L.z, s3.x);
-        l1.w = __builtin_amdgcn_perm(L.w, L.z, s3.y);
-    }
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = seltab[(w >> (4 * i)) & 15u];
+    h0.x = __builtin_amdgcn_perm(L.y, L.x, s[0]);
+    h0.y = __builtin_amdgcn_perm(L.y, L.x, s[1]);
+    h0.z = __builtin_amdgcn_perm(L.y, L.x, s[2]);
+    h0.w = __builtin_amdgcn_perm(L.y, L.x, s[3]);
+    h1.x = __builtin_amdgcn_perm(L.y, L.x, s[4]);
+    h1.y = __builtin_amdgcn_perm(L.y, L.x, s[5]);
+    h1.z = __builtin_amdgcn_perm(L.y, L.x, s[6]);
+    h1.w = __builtin_amdgcn_perm(L.y, L.x, s[7]);
+    l0.x = __builtin_amdgcn_perm(L.w, L.z, s[0]);
+    l0.y = __builtin_amdgcn_perm(L.w, L.z, s[1]);
+    l0.z = __builtin_amdgcn_perm(L.w, L.z, s[2]);
+    l0.w = __builtin_amdgcn_perm(L.w, L.z, s[3]);
+    l1.x = __builtin_amdgcn_perm(L.w, L.z, s[4]);
+    l1.y = __builtin_amdgcn_perm(L.w, L.z, s[5]);
+    l1.z = __builtin_amdgcn_perm(L.w, L.z, s[6]);
+    l1.w = __builtin_amdgcn_perm(L.w, L.z, s[7]);
     *reinterpret_cast<u32x4 *>(dst_hi) = h0;
-    *reinterpret_cast<u32x4 *>(dst_hi + 16) = h1;
+    *reinterpret_cast<u32x4 *>(dst_hi + half_off) = h1;
     *reinterpret_cast<u32x4 *>(dst_lo) = l0;
-    *reinterpret_cast<u32x4 *>(dst_lo + 16) = l1;
+    *reinterpret_cast<u32x4 *>(dst_lo + half_off) = l1;
 }
 
 // MFMA operand (8 consecutive k for this lane's sample) from a [k][sample] image: two transposed reads.
+template <int PITCH>
 __device__ __forceinline__ half8 tr_frag(const uint8_t *img_lane_base) {
     typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
     const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4 *)(img_lane_base));
-    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4 *)(img_lane_base + 4 * G_PITCH));
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4 *)(img_lane_base + 4 * PITCH));
     u32x4 r;
     const u32x2 ua = __builtin_bit_cast(u32x2, a);
     const u32x2 ub = __builtin_bit_cast(u32x2, b);
@@ -116,61 +115,105 @@ __device__ __forceinline__ half8 tr_frag(const uint8_t *img_lane_base) {
     return __builtin_bit_cast(half8, r);
 }
 
-__global__ __launch_bounds__(256, 2) void grm_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
-                                                           const int32_t *__restrict__ rows,
-                                                           const uint4 *__restrict__ lut16, int64_t k_begin,
-                                                           int64_t k_end, int kchunk, double *__restrict__ acc,
-                                                           int64_t ld, int use_atomic) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * G_IMG + 2048];
-    uint8_t *sAh = smem;
-    uint8_t *sAl = smem + G_IMG;
-    uint8_t *sBh = smem + 2 * G_IMG;
-    uint8_t *sBl = smem + 3 * G_IMG;
-    uint2 *seltab = reinterpret_cast<uint2 *>(smem + 4 * G_IMG);
+// TM x TN output tile per workgroup, WM x WN per wave (multiples of 32), 64 * (TM/WM) * (TN/WN) threads.
+//   <128,128,64,64>  : 4 waves, small n (many tiles needed to fill the chip)
+//   <256,128,128,64> : 4 waves of 128x64: each LDS fragment read feeds 1.33x and each decoded byte 1.33x more MFMAs
+//                      (the 128x128 shape is LDS-bound: ~930 LDS cycles vs 768 MFMA cycles per 32-SNP step);
+//                      2 workgroups per CU keep one decoding while the other issues MFMAs
+//   DBUF: two LDS image sets; the decode of step k+1 is issued in the same barrier interval as the MFMAs of step k
+//   (one barrier per step, VALU/LDS-write work rides in the MFMA issue gaps) at 2 workgroups per CU.
+template <int TM, int TN, int WM, int WN, bool DBUF>
+__global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 ? 3 : 2))) void grm_f16x2_kernel(
+    const uint8_t *__restrict__ p32, int64_t m_total, const int32_t *__restrict__ rows,
+    const uint4 *__restrict__ lut16, int64_t k_begin, int64_t k_end, int kchunk, int nt128,
+    double *__restrict__ acc, int64_t ld, int use_atomic) {
+    constexpr int NWN = TN / WN;
+    constexpr int NTHREADS = 64 * (TM / WM) * NWN;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    // LDS image row (one SNP, TM samples as fp16): the 16 decoded samples of payload dword d are stored as two
+    // 16-byte halves in slots d and DW + d (DW = dwords per row), so the DW lanes that decode one SNP row write
+    // DW * 16 contiguous bytes per ds_write_b128 (conflict-free; the natural order is 2-way conflicted), and the
+    // pitch (row bytes + 32) puts the four rows of a transposed read on disjoint banks (pitch/4 = 8 mod 64).
+    constexpr int PA = TM * 2 + 32;   // bytes per SNP row of the A images
+    constexpr int PB = TN * 2 + 32;
+    constexpr int IMG_A = G_BK * PA, IMG_B = G_BK * PB;
+    constexpr int DWA = TM / 16, DWB = TN / 16;  // payload dwords per SNP row of each panel
+    constexpr int NA = G_BK * DWA / NTHREADS, NB = G_BK * DWB / NTHREADS;  // payload dwords per thread per step
+    static_assert(NA * NTHREADS == G_BK * DWA && NB * NTHREADS == G_BK * DWB, "panel dwords must divide evenly");
+    constexpr int SET = 2 * IMG_A + 2 * IMG_B;  // one set of the four images
+    __shared__ __attribute__((aligned(16))) uint8_t smem[(DBUF ? 2 : 1) * SET + 64];
+    uint32_t *seltab = reinterpret_cast<uint32_t *>(smem + (DBUF ? 2 : 1) * SET);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
 
-    seltab[tid] = make_selectors((uint32_t)tid);
+    if (tid < 16) seltab[tid] = make_selectors((uint32_t)tid).x;  // selector of codes (t & 3, t >> 2)
 
-    // lower-triangular tile pair (ti >= tj) from the linear block index
+    // output tiles covering the lower triangle: row block ti (TM rows) x column blocks tj (TN columns) with
+    // tj * TN < (ti + 1) * TM; RATIO = TM / TN column blocks per row-block step
+    constexpr int RATIO = TM / TN;
     const int t = blockIdx.x;
-    int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((int64_t)ti * (ti + 1) / 2 > t) --ti;
-    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - (int)((int64_t)ti * (ti + 1) / 2);
+    int ti, tj;
+    if (RATIO == 1) {
+        ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((int64_t)ti * (ti + 1) / 2 > t) --ti;
+        while ((int64_t)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tj = t - (int)((int64_t)ti * (ti + 1) / 2);
+    } else {  // RATIO == 2: row block ti owns 2 * ti + 2 column blocks, ti * (ti + 1) precede it
+        ti = (int)((sqrtf(4.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((int64_t)ti * (ti + 1) > t) --ti;
+        while ((int64_t)(ti + 1) * (ti + 2) <= t) ++ti;
+        tj = t - (int)((int64_t)ti * (ti + 1));
+    }
 
     const int64_t k0 = k_begin + (int64_t)blockIdx.y * kchunk;
     const int64_t k1 = (k0 + kchunk < k_end) ? (k0 + kchunk) : k_end;
 
-    const int kk = tid >> 3;  // SNP within the step
-    const int d = tid & 7;    // dword (16 samples) within the 128-sample tile
-    const uint8_t *baseA = p32 + (int64_t)ti * m_total * 32 + 4 * d;
-    const uint8_t *baseB = p32 + (int64_t)tj * m_total * 32 + 4 * d;
-
-    uint32_t wA = 0, wB = 0;
-    uint4 L = make_uint4(0, 0, 0, 0);
+    // decode mapping: payload dword idx = tid + u * NTHREADS -> (SNP kk of the step, dword d of the panel row)
+    uint32_t wA[NA], wB[NB];
+    uint4 LA[NA], LB[NB];
     auto prefetch = [&](int64_t kbase) {
-        const int64_t k = kbase + kk;
-        if (k < k1) {
-            const int64_t rec = rows ? (int64_t)rows[k] : k;
-            wA = *reinterpret_cast<const uint32_t *>(baseA + rec * 32);
-            wB = *reinterpret_cast<const uint32_t *>(baseB + rec * 32);
-            L = lut16[k];
-        } else {
-            wA = 0;
-            wB = 0;
-            L = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + u * NTHREADS;
+            const int kk = idx / DWA, d = idx % DWA;
+            const int rec128 = ti * (TM / 128) + (d >> 3);
+            const int64_t k = kbase + kk;
+            wA[u] = 0x55555555u;
+            LA[u] = make_uint4(0, 0, 0, 0);
+            if (k < k1) {
+                const int64_t rec = rows ? (int64_t)rows[k] : k;
+                if (rec128 < nt128)
+                    wA[u] = *reinterpret_cast<const uint32_t *>(p32 + ((int64_t)rec128 * m_total + rec) * 32 +
+                                                                4 * (d & 7));
+                LA[u] = lut16[k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + u * NTHREADS;
+            const int kk = idx / DWB, d = idx % DWB;
+            const int rec128 = tj * (TN / 128) + (d >> 3);
+            const int64_t k = kbase + kk;
+            wB[u] = 0x55555555u;
+            LB[u] = make_uint4(0, 0, 0, 0);
+            if (k < k1) {
+                const int64_t rec = rows ? (int64_t)rows[k] : k;
+                if (rec128 < nt128)
+                    wB[u] = *reinterpret_cast<const uint32_t *>(p32 + ((int64_t)rec128 * m_total + rec) * 32 +
+                                                                4 * (d & 7));
+                LB[u] = lut16[k];
+            }
         }
     };
 
-    floatx16 c[2][2];
+    floatx16 c[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[mi][ni][r] = 0.0f;
 
@@ -179,58 +222,95 @@ __global__ __launch_bounds__(256, 2) void grm_f16x2_kernel(const uint8_t *__rest
     const int h = lane >> 5;          // k half of the MFMA operand
     const int q = (lane & 15) >> 2;   // row of the 4x16 block this lane addresses
     const int pp = lane & 3;          // 4-column group this lane addresses
-    const int lane_off = (8 * h + q) * G_PITCH + (16 * (g & 1) + 4 * pp) * 2;
+    // byte offset of samples 4*pp..4*pp+3 of 16-sample block `blk` inside a row: ((pp >> 1) * DW + blk) * 16 + (pp & 1) * 8
+    const int offA = (8 * h + q) * PA + ((pp >> 1) * DWA + (g & 1)) * 16 + (pp & 1) * 8;
+    const int offB = (8 * h + q) * PB + ((pp >> 1) * DWB + (g & 1)) * 16 + (pp & 1) * 8;
 
-    prefetch(k0);
-    __syncthreads();  // selector table ready
-
-    for (int64_t kbase = k0; kbase < k1; kbase += G_BK) {
-        decode16_to_lds(wA, L, seltab, sAh + kk * G_PITCH + d * 32, sAl + kk * G_PITCH + d * 32);
-        decode16_to_lds(wB, L, seltab, sBh + kk * G_PITCH + d * 32, sBl + kk * G_PITCH + d * 32);
-        __syncthreads();
-        prefetch(kbase + G_BK);
+    auto decode_to = [&](uint8_t *base) {
+        uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + 2 * IMG_A, *sBl = base + 2 * IMG_A + IMG_B;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + u * NTHREADS;
+            const int kk = idx / DWA, d = idx % DWA;
+            decode16_to_lds(wA[u], LA[u], seltab, sAh + kk * PA + d * 16, sAl + kk * PA + d * 16, DWA * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int idx = tid + u * NTHREADS;
+            const int kk = idx / DWB, d = idx % DWB;
+            decode16_to_lds(wB[u], LB[u], seltab, sBh + kk * PB + d * 16, sBl + kk * PB + d * 16, DWB * 16);
+        }
+    };
+    auto mfma_from = [&](const uint8_t *base) {
+        const uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + 2 * IMG_A, *sBl = base + 2 * IMG_A + IMG_B;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 ah[2], al[2], bh[2], bl[2];
+            half8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int off = ks * 16 * G_PITCH + lane_off + (wm * 64 + mi * 32) * 2;
-                ah[mi] = tr_frag(sAh + off);
-                al[mi] = tr_frag(sAl + off);
+            for (int mi = 0; mi < MI; ++mi) {
+                const int off = ks * 16 * PA + offA + ((wm * WM + mi * 32) / 16) * 16;
+                ah[mi] = tr_frag<PA>(sAh + off);
+                al[mi] = tr_frag<PA>(sAl + off);
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int off = ks * 16 * G_PITCH + lane_off + (wn * 64 + ni * 32) * 2;
-                bh[ni] = tr_frag(sBh + off);
-                bl[ni] = tr_frag(sBl + off);
+            for (int ni = 0; ni < NI; ++ni) {
+                const int off = ks * 16 * PB + offB + ((wn * WN + ni * 32) / 16) * 16;
+                bh[ni] = tr_frag<PB>(sBh + off);
+                bl[ni] = tr_frag<PB>(sBl + off);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], c[mi][ni], 0, 0, 0);
                     c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], c[mi][ni], 0, 0, 0);
                     c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], c[mi][ni], 0, 0, 0);
                 }
         }
+    };
+
+    prefetch(k0);
+    __syncthreads();  // selector table ready
+    if constexpr (!DBUF) {
+        for (int64_t kbase = k0; kbase < k1; kbase += G_BK) {
+            decode_to(smem);
+            __syncthreads();
+            prefetch(kbase + G_BK);
+            mfma_from(smem);
+            __syncthreads();
+        }
+    } else {
+        decode_to(smem);
+        prefetch(k0 + G_BK);
         __syncthreads();
+        int cur = 0;
+        for (int64_t kbase = k0; kbase < k1; kbase += G_BK) {
+            // same barrier interval: decode step k+1 into the other image set, MFMAs of step k from this one
+            if (kbase + G_BK < k1) decode_to(smem + (cur ^ 1) * SET);
+            prefetch(kbase + 2 * G_BK);
+            mfma_from(smem + cur * SET);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // f64 merge: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int64_t gj = (int64_t)tj * JXG_TILE + wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int64_t gj = (int64_t)tj * TN + wn * WN + ni * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t gi = (int64_t)ti * JXG_TILE + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                double *dst = acc + gi * ld + gj;
-                const double v = (double)c[mi][ni][r];
-                if (use_atomic) {
-                    unsafeAtomicAdd(dst, v);
-                } else {
-                    *dst += v;
+                const int64_t gi = (int64_t)ti * TM + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gi < ld && gj < ld) {
+                    double *dst = acc + gi * ld + gj;
+                    const double v = (double)c[mi][ni][r];
+                    if (use_atomic) {
+                        unsafeAtomicAdd(dst, v);
+                    } else {
+                        *dst += v;
+                    }
                 }
             }
         }
@@ -285,6 +365,20 @@ struct EventPair {
 static EventPair g_grm_ev;
 }  // namespace jx
 
+extern "C" int jxg_debug_occupancy(int *out) {
+    int a = -1, b = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)grm_f16x2_kernel<128, 128, 64, 64, false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void *)grm_f16x2_kernel<128, 128, 64, 64, true>, 256, 0);
+    hipFuncAttributes fa, fb;
+    (void)hipFuncGetAttributes(&fa, (const void *)grm_f16x2_kernel<128, 128, 64, 64, false>);
+    (void)hipFuncGetAttributes(&fb, (const void *)grm_f16x2_kernel<128, 128, 64, 64, true>);
+    out[0] = a; out[1] = b; out[2] = fa.numRegs; out[3] = fb.numRegs; out[4] = (int)fa.sharedSizeBytes; out[5] = (int)fb.sharedSizeBytes;
+    hipDeviceProp_t pr;
+    (void)hipGetDeviceProperties(&pr, 0);
+    out[6] = (int)pr.maxSharedMemoryPerMultiProcessor; out[7] = (int)pr.sharedMemPerBlock; out[8] = pr.regsPerMultiprocessor; out[9] = pr.regsPerBlock;
+    return 0;
+}
+
 extern "C" float jxg_last_kernel_ms(int which) {
     if (which < 0 || which >= 4) return 0.f;
     if (which == 1 && g_timer_pending[1] && g_rot_b) {
@@ -317,31 +411,45 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
     JX_HIP(hipStreamSynchronize(st));
     if (hflag) return fail("jxg_grm_accumulate: design values exceed the fp16 split range (|z| > 3e4)");
 
-    const int64_t ntiles = (int64_t)nt * (nt + 1) / 2;
+    // tile shape: 256x128 (4 waves of 128x64) once there are enough tiles, else 128x128 (4 waves of 64x64)
+    static const int tile_env = getenv("JXGPU_GRM_TILE") ? atoi(getenv("JXGPU_GRM_TILE")) : 0;
+    const bool big = tile_env ? (tile_env >= 256) : false;
+    const int tdim = big ? (nt + 1) / 2 : nt;  // row blocks
+    const int64_t ntiles = big ? (int64_t)tdim * (tdim + 1) : (int64_t)tdim * (tdim + 1) / 2;
     if (ntiles > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
     const int64_t nchunks = (mk + kchunk - 1) / kchunk;
+    const int64_t slots = big ? 512 : 768;  // resident workgroups on 256 CUs
     // Few tiles: spread SNP chunks over blockIdx.y with f64 atomics so the chip is filled.
     // Many tiles: one launch per chunk, the owning workgroup does a plain f64 read-modify-write.
-    const bool atomic_mode = ntiles < 1024 && nchunks > 1;
+    const bool atomic_mode = ntiles < 2 * slots && mk > 2048;
     if (g_grm_ev.init()) return 1;
     JX_HIP(hipEventRecord(g_grm_ev.a, st));
+    auto launch = [&](dim3 grid, int64_t kb, int64_t ke, int kc, int atomic) {
+        if (big)
+            hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
+                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+        else if (tile_env == 129)
+            hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, true>), grid, dim3(256), 0, st, d_p32, m_total,
+                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+        else
+            hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
+                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+    };
     if (atomic_mode) {
-        // shrink chunks if that is what it takes to reach ~4 workgroups per CU
-        int64_t want = (4 * 256 + ntiles - 1) / ntiles;
+        // shrink chunks if that is what it takes to reach ~2 rounds of resident workgroups
+        int64_t want = (2 * slots + ntiles - 1) / ntiles;
         int64_t kc = kchunk;
         while ((mk + kc - 1) / kc < want && kc > 1024) kc /= 2;
         kc = ((kc + G_BK - 1) / G_BK) * G_BK;
         const int64_t ny = (mk + kc - 1) / kc;
         if (ny > 65535) return fail("jxg_grm_accumulate: too many chunks");
-        hipLaunchKernelGGL(grm_f16x2_kernel, dim3((unsigned)ntiles, (unsigned)ny), dim3(256), 0, st, d_p32, m_total,
-                           d_rows, lut16.as<uint4>(), (int64_t)0, mk, (int)kc, d_acc, ld, 1);
+        launch(dim3((unsigned)ntiles, (unsigned)ny), 0, mk, (int)kc, 1);
         JX_LAUNCH_CHECK();
     } else {
-        for (int64_t c = 0; c < nchunks; ++c) {
-            const int64_t kb = c * kchunk;
+        for (int64_t cidx = 0; cidx < nchunks; ++cidx) {
+            const int64_t kb = cidx * kchunk;
             const int64_t ke = (kb + kchunk < mk) ? kb + kchunk : mk;
-            hipLaunchKernelGGL(grm_f16x2_kernel, dim3((unsigned)ntiles, 1), dim3(256), 0, st, d_p32, m_total,
-                               d_rows, lut16.as<uint4>(), kb, ke, kchunk, d_acc, ld, 0);
+            launch(dim3((unsigned)ntiles, 1), kb, ke, kchunk, 0);
             JX_LAUNCH_CHECK();
         }
     }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void lut_split_r_kernel(const float *__restric
 
 // grid: x = column tile (eigenvector index j), y = row tile (SNP rows). 256 threads = 4 waves (2x2 of 64x64).
 // waves 0-1 decode the A panel (128 SNP rows x 32 samples), waves 2-3 stage the two U planes.
-__global__ __launch_bounds__(256, 2) void rotate_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+__global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
                                                               const int32_t *__restrict__ rows, int nrows,
                                                               const uint4 *__restrict__ lut16,
                                                               const __half *__restrict__ uhi,

@@ -330,7 +330,7 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
 }
 
 template <int MAXD>
-__global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_fast_kernel(
+__global__ __launch_bounds__(SCAN_THREADS, (MAXD <= 2 ? 4 : 2)) void lmm_scan_fast_kernel(
     const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s, const double *__restrict__ xcov,
     const double *__restrict__ yc, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,

@@ -1,0 +1,200 @@
+"""Thin `jx gwas` / `jx grm` command line for the accelerated path.
+
+Flag names, defaults and output file names follow the reference (python/janusx/assoc/workflow.py:6599-7047,
+python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model_stream.py:989-994):
+
+  python -m janusx_amd gwas -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] (-lmm | -fvlmm) [-k 1|2|GRM.npy] [-c COV.tsv]
+                            [-maf 0.02] [-geno 0.05] [-het 1.0] [-o OUT] [-force-model]
+  python -m janusx_amd grm  -bfile PREFIX [-m 1|2] [-maf 0.02] [-geno 0.05] [-o OUT]
+
+Outputs: `{out}.{trait}.lmm.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`.
+Only PLINK BED input, the additive model and the -lmm / -fvlmm scans are built; VCF/HMP readers,
+PCs (-q), plots and the history DB are out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def _read_table(path):
+    """Tab/space delimited table with a header; first column = sample id. -> (ids, names, values float with NaN)."""
+    with open(path) as fh:
+        header = fh.readline().rstrip("\n").replace(",", "\t").split()
+        ids, rows = [], []
+        for line in fh:
+            parts = line.rstrip("\n").replace(",", "\t").split()
+            if not parts:
+                continue
+            ids.append(parts[0])
+            vals = []
+            for v in parts[1:]:
+                try:
+                    vals.append(float(v))
+                except ValueError:
+                    vals.append(float("nan"))
+            rows.append(vals)
+    width = max(len(r) for r in rows) if rows else 0
+    arr = np.full((len(rows), width), np.nan)
+    for i, r in enumerate(rows):
+        arr[i, :len(r)] = r
+    names = header[1:] if len(header) == width + 1 else [f"trait{i}" for i in range(width)]
+    return ids, names, arr
+
+
+def _select_traits(names, specs):
+    if not specs:
+        return list(range(len(names)))
+    out = []
+    for spec in specs:
+        for tok in str(spec).split(","):
+            tok = tok.strip()
+            if ":" in tok and all(t.isdigit() for t in tok.split(":")):
+                a, b = [int(t) for t in tok.split(":")]
+                out.extend(range(a, b + 1))
+            elif tok.isdigit():
+                out.append(int(tok))
+            elif tok in names:
+                out.append(names.index(tok))
+            else:
+                raise SystemExit(f"unknown trait selector '{tok}'")
+    return out
+
+
+def _load_grm(path, fam_ids):
+    k = np.load(path)
+    id_path = path + ".id"
+    if os.path.exists(id_path):
+        ids = [ln.split()[0] for ln in open(id_path) if ln.strip()]
+        if ids != list(fam_ids):
+            pos = {s: i for i, s in enumerate(ids)}
+            try:
+                order = np.array([pos[s] for s in fam_ids])
+            except KeyError as e:
+                raise SystemExit(f"GRM id file lacks sample {e}") from None
+            k = k[np.ix_(order, order)]
+    if k.shape != (len(fam_ids), len(fam_ids)):
+        raise SystemExit(f"GRM shape {k.shape} does not match {len(fam_ids)} samples")
+    return np.ascontiguousarray(k, dtype=np.float32)
+
+
+def cmd_grm(args):
+    from . import janusx as jxrs
+    from .bed import read_fam_ids
+    out = args.out or args.bfile
+    t0 = time.perf_counter()
+    k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
+                                        max_missing_rate=args.geno, het_threshold=0.0)
+    tag = "cGRM" if args.method == 1 else "sGRM"
+    path = f"{out}.{tag}.npy"
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        np.lib.format.write_array(fh, k, version=(1, 0))
+    os.replace(tmp, path)
+    with open(path + ".id", "w") as fh:
+        for sid in read_fam_ids(args.bfile):
+            fh.write(f"{sid}\n")
+    print(f"GRM method {args.method}: n={n} eff_m={eff} -> {path} ({time.perf_counter() - t0:.2f}s)")
+    return 0
+
+
+def cmd_gwas(args):
+    import torch
+    from . import janusx as jxrs
+    from . import pipeline as pl
+    from .bed import read_bed_payload, read_fam_ids
+    from .tsv import write_assoc_tsv
+    if not (args.lmm or args.fvlmm):
+        raise SystemExit("select at least one model: -lmm and/or -fvlmm")
+    packed, n_fam, bim = read_bed_payload(args.bfile)
+    fam = read_fam_ids(args.bfile)
+    ids, names, ph = _read_table(args.pheno)
+    pos = {s: i for i, s in enumerate(ids)}
+    cov = None
+    if args.cov:
+        cids, _, cv = _read_table(args.cov)
+        cpos = {s: i for i, s in enumerate(cids)}
+    traits = _select_traits(names, args.ncol)
+    out = args.out or args.bfile
+    dev = torch.device("cuda", 0)
+    packed_t = torch.from_numpy(np.array(packed, dtype=np.uint8, copy=True)).to(dev)
+    t0 = time.perf_counter()
+    if args.grm in ("1", "2"):
+        k, eff, _ = pl.build_grm(packed_t, n_fam, int(args.grm), args.maf, args.geno)
+        print(f"GRM method {args.grm}: eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
+    else:
+        k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)
+    for ti in traits:
+        name = names[ti]
+        rows_ok = []
+        for j, sid in enumerate(fam):
+            i = pos.get(sid)
+            if i is None or not math.isfinite(ph[i, ti]):
+                continue
+            if args.cov and (sid not in cpos or not np.all(np.isfinite(cv[cpos[sid]]))):
+                continue
+            rows_ok.append(j)
+        keep_idx = np.array(rows_ok, dtype=np.int64)
+        n = len(keep_idx)
+        if n < 10:
+            print(f"[{name}] only {n} phenotyped samples, skipped")
+            continue
+        y = np.array([ph[pos[fam[j]], ti] for j in keep_idx])
+        x = np.ones((n, 1))
+        if args.cov:
+            x = np.concatenate([x, np.array([cv[cpos[fam[j]]] for j in keep_idx])], axis=1)
+        for mode in (["lmm"] if args.lmm else []) + (["fvlmm"] if args.fvlmm else []):
+            t1 = time.perf_counter()
+            res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het)
+            # LMM -> LM fallback test (src/stats/gwas_unified.rs:121-175); the LM scan itself is out of scope
+            sw, stat, pv, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x[:, 1:], res.null.ml0)
+            if sw and not args.force_model:
+                print(f"[{name}] note: null LRT p={pv:.3g} >= 0.05 - the reference would switch to the plain LM scan "
+                      f"here (not built); continuing with -{mode} as with -force-model")
+            kept = np.nonzero(res.keep)[0]
+            path = f"{out}.{name}.{mode}.tsv"
+            write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
+                            [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
+                            res.af, res.miss, res.stats)
+            print(f"[{name}] -{mode}: n={n} snps={len(kept)} lambda0={res.null.lbd:.5g} pve={res.null.pve:.4f} "
+                  f"-> {path} ({time.perf_counter() - t1:.2f}s)")
+    return 0
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="jx", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    g = sub.add_parser("gwas")
+    g.add_argument("-bfile", "--bfile", required=True)
+    g.add_argument("-p", "--pheno", required=True)
+    g.add_argument("-n", "--n", dest="ncol", action="append", default=None)
+    g.add_argument("-lmm", "--lmm", action="store_true", default=False)
+    g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
+    g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
+    g.add_argument("-c", "--cov", dest="cov", default=None)
+    g.add_argument("-maf", "--maf", type=float, default=0.02)
+    g.add_argument("-geno", "--geno", type=float, default=0.05)
+    g.add_argument("-het", "--het", type=float, default=1.0)
+    g.add_argument("-o", "--out", default=None)
+    g.add_argument("-force-model", "--force-model", dest="force_model", action="store_true", default=False)
+    g.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
+    g.set_defaults(func=cmd_gwas)
+    r = sub.add_parser("grm")
+    r.add_argument("-bfile", "--bfile", required=True)
+    r.add_argument("-m", "--method", type=int, default=1, choices=[1, 2])
+    r.add_argument("-maf", "--maf", type=float, default=0.02)
+    r.add_argument("-geno", "--geno", type=float, default=0.05)
+    r.add_argument("-o", "--out", default=None)
+    r.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
+    r.set_defaults(func=cmd_grm)
+    args = ap.parse_args(argv)
+    return args.func(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -299,6 +299,51 @@ class GwasResult:
     times: dict
 
 
+def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.05, panel: Panel = None):
+    """`build_grm_streaming` -> `grm_stream_bed_f32` on an HBM-resident payload (all samples; het filter off,
+    python/janusx/assoc/workflow.py:2928-3095). Returns (K f32 device tensor (n,n), eff_m, panel)."""
+    if panel is None:
+        panel = Panel(packed, n_samples)
+    counts = panel.counts()
+    n = panel.n
+    gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, method, maf, geno, 0.0)
+    grows = np.nonzero(gkeep)[0]
+    if len(grows) == 0:
+        raise RuntimeError("No SNPs remained after filtering; GRM is empty.")
+    glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
+    denom = float(np.sum(var[grows])) if method == 1 else float(len(grows))
+    if not (math.isfinite(denom) and denom > 0.0):
+        raise RuntimeError("invalid centered GRM denominator: sum(2p(1-p)) <= 0")
+    acc = grm_accumulate(panel, grows, glut)
+    k32 = grm_finalize(acc, n, denom, torch.float32)
+    return k32, len(grows), panel
+
+
+def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y: np.ndarray, x: np.ndarray,
+              mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False):
+    """One trait of `run_chunked_gwas_lmm_lm` (python/janusx/assoc/workflow_model_stream.py:464-1480):
+    eigh of K[keep, keep] + 1e-6 I, spectral null model, QC on the trait's samples, rotate + scan.
+    `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order)."""
+    keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
+    s, ut64 = eigh_from_grm(k, 1e-6, keep_idx)
+    model = SpectralModel(s, ut64, x, y)
+    del ut64
+    panel = Panel(packed, n_samples, keep_idx)
+    counts = panel.counts()
+    n = panel.n
+    keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
+    rows = np.nonzero(keep)[0]
+    lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
+    if mode == "lmm":
+        init = math.log10(model.null.lbd) if (warm_start and model.null.lbd > 0) else None
+        if init is not None:
+            init = min(max(init, model.null.bounds[0]), model.null.bounds[1])
+        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init)
+    else:
+        out = scan_rows(panel, model, rows, lut, "fvlmm")
+    return GwasResult(keep, af[rows], miss[rows], out.cpu().numpy(), model.null, 0, {})
+
+
 def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndarray = None, mode="lmm",
              maf=0.02, geno=0.05, het=1.0, grm_method=1, max_iter=30, tol=1e-2, timing=True) -> GwasResult:
     """Single-GPU `jx gwas -lmm/-fvlmm` on an HBM-resident payload (all samples phenotyped)."""

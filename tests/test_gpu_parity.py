@@ -375,3 +375,43 @@ def test_fast_scan_matches_exact_scan(oracle, null_case, monkeypatch):
             # shift = 1e4 makes the two-pass reference formulation itself lose ~6 digits in the normal equations
             lim = 1e-7 if shift == 0.0 else 1e-5
             assert max(be, se) < lim and pe < 10 * lim, (shift, k, be, se, pe)
+
+
+def test_cli_gwas_with_missing_phenotypes(oracle, oracle_c, tmp_path):
+    """`jx gwas -bfile ... -lmm` end to end with a trait that has NAs: sample-subset re-tiling, eigh of the GRM
+    sub-matrix, QC on the trait's samples, TSV in BED order; plus `jx grm` output naming."""
+    from janusx_amd import cli
+    n, m = 240, 420
+    packed, g = bed.synth_panel_numpy(n, m, seed=51, missing_rate=0.015)
+    y = bed.synth_phenotype(g, n_causal=15, pve=0.6, seed=51)
+    rng = np.random.default_rng(8)
+    na = rng.random(n) < 0.2
+    prefix = str(tmp_path / "toy")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ttraitA\n")
+        for i in np.random.default_rng(9).permutation(n):  # shuffled order: alignment is by sample id
+            fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-force-model", "-o", prefix]) == 0
+    lines = open(prefix + ".traitA.lmm.tsv").read().splitlines()
+    keep_idx = np.nonzero(~na)[0]
+    k_ref, eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    s, u = oracle.gwas_eigh_from_grm(k_ref, 1e-6, keep_idx)
+    nm = oracle.spectral_null_model(y[keep_idx], np.ones((len(keep_idx), 1)), s, u)
+    mi, he, ho = oracle.row_counts(packed, n, keep_idx)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, len(keep_idx), 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    assert len(lines) == len(rows) + 1
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, sample_idx=keep_idx, rows=rows)
+    ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, nm.bounds[0],
+                                          nm.bounds[1], 30, 1e-2)
+    for i, (ln, j) in enumerate(zip(lines[1:], rows)):
+        f = ln.split("\t")
+        assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}" and f[6] == f"{float(miss[j]):.4f}"
+        assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 and abs(float(f[8]) - ref[i, 1]) <= 1.5e-4
+    assert cli.main(["grm", "-bfile", prefix, "-m", "1", "-o", prefix]) == 0
+    kk = np.load(prefix + ".cGRM.npy")
+    assert kk.dtype == np.float32 and _grm_err(kk, k_ref) < TOL
+    assert open(prefix + ".cGRM.npy.id").read().split() == ids

@@ -415,3 +415,38 @@ def test_cli_gwas_with_missing_phenotypes(oracle, oracle_c, tmp_path):
     kk = np.load(prefix + ".cGRM.npy")
     assert kk.dtype == np.float32 and _grm_err(kk, k_ref) < TOL
     assert open(prefix + ".cGRM.npy.id").read().split() == ids
+
+
+def test_config_c1_mouse_hs1940_lmm(oracle, oracle_c):
+    """BASELINE configs[0]: example/mouse_hs1940 (n = 1940, 10 300 sites), trait test0 (1410 phenotyped samples),
+    `-lmm -force-model`: kept-SNP set / af / miss bit-exact, GRM, null model and per-SNP beta/SE/p vs the oracle."""
+    import os
+    import torch
+    from janusx_amd import pipeline
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "mouse_hs1940.npz"))
+    packed, n = np.ascontiguousarray(d["packed"]), len(d["ids"])
+    ph = d["pheno"][:, 0]
+    pos = {s: i for i, s in enumerate(d["pheno_ids"])}
+    yfull = np.array([ph[pos[s]] if s in pos else np.nan for s in d["ids"]])
+    keep_idx = np.nonzero(np.isfinite(yfull))[0]
+    y = yfull[keep_idx]
+    pt = torch.from_numpy(packed).cuda()
+    k, eff, _ = pipeline.build_grm(pt, n, 1, 0.02, 0.05)
+    k_ref, eff_ref, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    assert eff == eff_ref == 8960
+    assert _grm_err(k.cpu().numpy(), k_ref) < TOL
+    x = np.ones((len(keep_idx), 1))
+    res = pipeline.run_trait(pt, n, k, keep_idx, y, x, "lmm")
+    s, u = oracle.gwas_eigh_from_grm(k_ref, 1e-6, keep_idx)
+    nm = oracle.spectral_null_model(y, x, s, u)
+    mi, he, ho = oracle.row_counts(packed, n, keep_idx)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, len(keep_idx), 0.02, 0.05, 1.0)
+    assert np.array_equal(res.keep, keep)
+    rows = np.nonzero(keep)[0]
+    assert np.array_equal(res.af, maf[rows]) and np.array_equal(res.miss, miss[rows])
+    assert abs(res.null.lbd - nm.lbd_null) < 1e-5 * nm.lbd_null and abs(res.null.pve - nm.pve) < 1e-5
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, sample_idx=keep_idx, rows=rows)
+    ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, nm.bounds[0],
+                                          nm.bounds[1], 30, 1e-2)
+    be, se, pe = _assoc_err(res.stats, ref)
+    assert max(be, se) < 1e-4, (be, se, pe)  # GRM/eigenvectors differ at f32 rounding level between the two sides

@@ -142,3 +142,24 @@ def test_tsv_format(oracle, gold):
     row = oracle.format_assoc_row("2", 77, ".", "A", "T", np.float32(0.25), np.float32(0.0), float("nan"), float("nan"), 1.0)
     assert row == "2\t77\t2_77\tA\tT\t0.2500\t0.0000\tNaN\tNaN\tNaN\t1.0000e0\n"
     assert len(lines) == 13 and all(len(l.split("\t")) == 11 for l in lines)
+
+
+MOUSE = os.path.join(os.path.dirname(__file__), "golden", "mouse_hs1940.npz")
+
+
+def test_mouse_effective_snp_count_matches_reference_readme(oracle, oracle_c):
+    """The reference README's demo output reports `EffSNPs: 8960` for example/mouse_hs1940 at the default filters
+    (maf 0.02, geno 0.05; README.md:115): a number produced by the reference itself, reproduced by the QC restatement
+    (scan rule src/stats/lmm.rs:1258-1320 and stream-GRM rule src/stats/grm.rs:1465-1536)."""
+    from janusx_amd import stats
+    d = np.load(MOUSE)
+    packed, n = d["packed"], len(d["ids"])
+    assert n == 1940 and packed.shape[0] == 10300
+    mi, he, ho = oracle_c.row_counts(packed, n)
+    keep, af, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    assert int(keep.sum()) == 8960
+    gk = oracle.stream_grm_row_prepare(mi, he, ho, n, 1, 0.02, 0.05, 0.0)[0]
+    assert int(gk.sum()) == 8960
+    k2, af2, miss2 = stats.gwas_scan_row_stats(np.stack([mi, he, ho], 1), n, 0.02, 0.05, 1.0)
+    assert np.array_equal(k2, keep) and np.array_equal(af2[keep], af[keep])
+    assert int(np.isfinite(d["pheno"][:, 0]).sum()) == 1410  # README "Train size: 1410" (trait test0)

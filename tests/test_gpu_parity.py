@@ -450,3 +450,61 @@ def test_config_c1_mouse_hs1940_lmm(oracle, oracle_c):
                                           nm.bounds[1], 30, 1e-2)
     be, se, pe = _assoc_err(res.stats, ref)
     assert max(be, se) < 1e-4, (be, se, pe)  # GRM/eigenvectors differ at f32 rounding level between the two sides
+
+
+def test_full_size_c2_properties(oracle, oracle_c):
+    """BASELINE configs[1] at full size (n = 5000, m = 50 000) through size-independent properties:
+    GRM trace checksum from integer counts, row sums of a centred GRM, eigen-invariants, chunked == unchunked scan
+    (the reference's own smoke invariant, python/janusx/assoc/smoke.py:33-45) and a 150-SNP sample vs the oracle."""
+    import torch
+    import bench
+    from janusx_amd import pipeline, stats
+    n, m = 5000, 50000
+    dev = torch.device("cuda:0")
+    packed, dos = bench.synth_panel_gpu(n, m, 20260609, dev)
+    y = bench.make_phenotype(dos, n, 20260609, dev)
+    k, eff, panel = pipeline.build_grm(packed, n, 1, 0.02, 0.05)
+    counts = panel.counts()
+    gkeep, mean_g, scale, flip, var = stats.stream_grm_row_prepare(counts, n, 1, 0.02, 0.05, 0.0)
+    rows_g = np.nonzero(gkeep)[0]
+    c = counts[rows_g].astype(np.float64)
+    n0 = n - c[:, 0] - c[:, 1] - c[:, 2]
+    mu = mean_g[rows_g].astype(np.float64)
+    g0 = np.where(flip[rows_g], 2.0, 0.0)
+    g2 = np.where(flip[rows_g], 0.0, 2.0)
+    trace_ref = float(np.sum(n0 * (g0 - mu) ** 2 + c[:, 1] * (1.0 - mu) ** 2 + c[:, 2] * (g2 - mu) ** 2)) / float(np.sum(var[rows_g]))
+    k64 = k.double()
+    assert abs(float(torch.trace(k64)) - trace_ref) < 2e-6 * trace_ref
+    assert float((k - k.T).abs().max()) == 0.0
+    # no missing genotypes: every design row is centred by its own sample mean -> K 1 = 0 up to f32 rounding
+    assert float(k64.sum(dim=1).abs().max()) < 2e-3
+    s, ut64 = pipeline.eigh_from_grm(k, 1e-6)
+    kk = k64 + 1e-6 * torch.eye(n, device=dev, dtype=torch.float64)
+    assert float((ut64 @ kk - s[:, None] * ut64).abs().max()) < 1e-10
+    assert float((ut64 @ ut64.T - torch.eye(n, device=dev, dtype=torch.float64)).abs().max()) < 1e-10
+    assert bool((s[1:] >= s[:-1]).all())
+    model = pipeline.SpectralModel(s, ut64, np.ones((n, 1)), y)
+    keep, af, miss = stats.gwas_scan_row_stats(counts, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0][:12000]
+    lut = stats.scan_lut_from_counts(af[rows], np.zeros(len(rows), bool), counts[rows], n)
+    a = pipeline.scan_rows(panel, model, rows, lut, "lmm", block_rows=8192).cpu().numpy()
+    b = pipeline.scan_rows(panel, model, rows, lut, "lmm", block_rows=1000).cpu().numpy()
+    assert np.array_equal(a, b), "chunked scan differs from unchunked scan"
+    fa = pipeline.scan_rows(panel, model, rows, lut, "fvlmm", block_rows=8192).cpu().numpy()
+    fb = pipeline.scan_rows(panel, model, rows, lut, "fvlmm", block_rows=3000).cpu().numpy()
+    assert np.array_equal(fa, fb)
+    # sample of SNPs against the oracle, given the same spectral inputs (S, Dh, X~, y~ from the GPU)
+    pick = np.random.default_rng(0).choice(len(rows), 150, replace=False)
+    pk = packed.cpu().numpy()[rows[pick]]
+    gd = oracle.decode_centered_block_f32(pk, n, np.zeros(150, bool), af[rows[pick]])
+    dh = model.ut.cpu().numpy()
+    grot = oracle.rotate_block_f32(gd, dh)
+    sh, xh, yh = model.S.cpu().numpy(), model.xcov.cpu().numpy(), model.y.cpu().numpy()
+    ref = oracle_c.lmm_scan_rotated_block(grot, sh, xh, yh, model.null.bounds[0], model.null.bounds[1], 30, 1e-2)
+    be, se, pe = _assoc_err(a[pick], ref)
+    assert max(be, se) < TOL, (be, se, pe)
+    lbd_c, ml_c, _ = oracle_c.lmm_reml_null(sh, xh, yh, -5.0, 5.0, 50, 1e-3)
+    assert abs(model.null.lbd - lbd_c) < 1e-7 * lbd_c
+    fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(sh, xh, yh, model.null.lbd))
+    be, se, pe = _assoc_err(fa[pick], fref)
+    assert max(be, se) < TOL, (be, se, pe)

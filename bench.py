@@ -88,7 +88,7 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
     z = OC.decode_rows_lut(sub, n, lut, rows, center=False)
     acc = (z.T @ z).astype(np.float64)  # f32 SYRK-equivalent (OpenBLAS sgemm) + f64 merge
     t_grm = time.perf_counter() - t0
-    k = acc / float(np.sum(var[rows])) * (len(rows) / max(1, len(rows)))
+    k = acc / float(np.sum(var[rows]))  # GRM of the SNP sample: same size/spectrum class as the full one for timing eigh
     k = np.tril(k) + np.tril(k, -1).T
     t0 = time.perf_counter()
     s, u = O.gwas_eigh_from_grm(k.astype(np.float32))
@@ -119,6 +119,21 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
                    f"full n={n}: grm {t_grm:.2f}s and scan {t_scan:.2f}s scaled x{scale_m:.1f}, eigh {t_eig:.2f}s + "
                    f"null {t_null:.2f}s at full size"),
     }
+
+
+def pmc_traffic_bytes(kernel_prefix, run="fetch"):
+    """HBM read bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
+    streaming reads). Returns None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        runs = json.load(open(path))["runs"][run]
+    except Exception:
+        return None
+    for name, rec in runs.items():
+        if name.startswith(kernel_prefix):
+            return 2.0 * rec["mean_KB"] * 1024.0
+    return None
 
 
 def main():
@@ -270,14 +285,20 @@ def main():
                        "parallelism": f"snp-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "grm_f16x2_kernel",
                          "achieved": grm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                         "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS,
+                         "traffic": pmc_traffic_bytes("jx::grm_f16x2_kernel"),
+                         "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 correction, "
+                                         "n=5000 m=50000; algorithmic input = n*m/4 = 62.5 MB (payload re-read per tile "
+                                         "pair is served by L2/MALL)",
                          "note": "algorithmic n(n+1)m flops per launch; the kernel issues 3 f16 MFMA products per "
                                  "algorithmic product (hi*hi+hi*lo+lo*hi), so MFMA-pipe utilisation = 3*frac*(tile overhead)",
                          "avg_launch_ms": kern["grm_ms"] / L},
             "roofline_rotate": {"bound": "mfma", "kernel": "rotate_f16x2_kernel", "achieved": rot_tflops,
                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS,
                                 "ms_per_step": kern["rot_ms"] / L},
-            "roofline_scan": {"bound": "hbm", "kernel": "lmm_scan_kernel" if args.mode == "lmm" else "fvlmm_scan_kernel",
+            "roofline_scan": {"bound": "hbm", "kernel": "lmm_scan_fast_kernel" if args.mode == "lmm" else "fvlmm_scan_kernel",
+                              "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel" if args.mode == "lmm" else "jx::fvlmm_scan_kernel",
+                                                           "fetch" if args.mode == "lmm" else "fetch_fv"),
                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
                               "ms_per_step": kern["scan_ms"] / L},
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},

@@ -163,7 +163,8 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # JXGPU_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate it on a 1-GPU box)
+    distributed = world > 1 or bool(os.environ.get("JXGPU_BENCH_FORCE_DIST"))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

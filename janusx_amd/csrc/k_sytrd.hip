@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams 
 // tile's 8 x 16-byte loads per thread are issued before the current tile is reduced out of LDS, so every
 // workgroup keeps 32 KB in flight; the row product accumulates in registers across the strip (one atomic per row
 // per strip), the mirrored column product is reduced per tile.
-__global__ __launch_bounds__(TD_THREADS) void sytrd_symv_kernel(TdParams P, int j, int j0, int ktiles,
+__global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, int j, int j0, int ktiles,
                                                                 int nstrips) {
     __shared__ __attribute__((aligned(16))) double tile[TD_TS][TD_TS + 2];  // tile[c][r], pitch 66 (16-B rows)
     __shared__ double vr[TD_TS], vc[TD_TS];
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_symv_kernel(TdParams P, int 
                     raw_c = (vi < nt) ? P.ubuf[base + vi] : 0.0;
                 }
             }
-#pragma unroll
+#pragma unroll 4
             for (int q4 = 0; q4 < TD_TS / 4; ++q4) p += tile[tg + 4 * q4][tr] * vc[tg + 4 * q4];
             double q = 0.0;
-#pragma unroll
+#pragma unroll 4
             for (int q4 = 0; q4 < TD_TS / 4; ++q4) {
                 const int rr = qs + 4 * q4;
                 const double val = tile[qc][rr];
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_symv_kernel(TdParams P, int 
     // ---- row chunk (64 rows): scaled reflector out, V'v and W'v partial sums -----------------------------
     const int chunk = blockIdx.x - ntiles;
     const int rrow0 = chunk * TD_TS;  // relative row of this block's first row
-    __shared__ double vsh[TD_TS];
-    __shared__ double part[2][4][TD_NB];
+    // the row-chunk path never touches the tile image: reuse its storage (keeps the kernel at 4 workgroups per CU)
+    double *vsh = &tile[0][0];
+    double (*part)[4][TD_NB] = reinterpret_cast<double (*)[4][TD_NB]>(&tile[2][0]);
     if (tid < TD_TS) {
         const int rr = rrow0 + tid;
         double v = 0.0;
@@ -236,20 +237,24 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_symv_kernel(TdParams P, int 
         const int k = tid & 63, sub = tid >> 6;
         double s1 = 0.0, s2 = 0.0;
         if (k < i) {
-            double vv[16], a1[16], a2[16];
+            // two batches of 8 rows: 16 loads in flight per batch, half the registers of one 16-row batch
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int rloc = sub * 16 + q;
-                const bool okr = (rrow0 + rloc) < nt;
-                const int64_t row = (int64_t)(base + rrow0 + (okr ? rloc : 0)) * TD_NB;
-                vv[q] = okr ? vsh[rloc] : 0.0;
-                a1[q] = P.vt[row + k];
-                a2[q] = P.wt[row + k];
-            }
+            for (int hb = 0; hb < 2; ++hb) {
+                double vv[8], a1[8], a2[8];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                s1 += a1[q] * vv[q];
-                s2 += a2[q] * vv[q];
+                for (int q = 0; q < 8; ++q) {
+                    const int rloc = sub * 16 + hb * 8 + q;
+                    const bool okr = (rrow0 + rloc) < nt;
+                    const int64_t row = (int64_t)(base + rrow0 + (okr ? rloc : 0)) * TD_NB;
+                    vv[q] = okr ? vsh[rloc] : 0.0;
+                    a1[q] = P.vt[row + k];
+                    a2[q] = P.wt[row + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s1 += a1[q] * vv[q];
+                    s2 += a2[q] * vv[q];
+                }
             }
         }
         part[0][sub][k] = s1;
@@ -434,7 +439,8 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             const int side = (nt + TD_TS - 1) / TD_TS;
             const int64_t ntiles = (int64_t)side * (side + 1) / 2;
             static const int kt_env = getenv("JXGPU_SYTRD_KT") ? atoi(getenv("JXGPU_SYTRD_KT")) : 0;
-            int ktiles = kt_env > 0 ? kt_env : (int)((ntiles + 767) / 768);
+            static const int tg_env = getenv("JXGPU_SYTRD_TARGET") ? atoi(getenv("JXGPU_SYTRD_TARGET")) : 768;
+            int ktiles = kt_env > 0 ? kt_env : (int)((ntiles + tg_env - 1) / tg_env);
             if (ktiles < 1) ktiles = 1;
             if (ktiles > 64) ktiles = 64;
             const int nstrips = side * ((side + ktiles - 1) / ktiles);

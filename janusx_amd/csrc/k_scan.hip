@@ -486,28 +486,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
                                                                   const float *__restrict__ wx,
                                                                   const double *__restrict__ a_chol, double ypy,
                                                                   int df, double *__restrict__ out) {
+    // One WAVE per rotated SNP row (4 rows in flight per workgroup, no LDS, no barriers): the row is streamed once
+    // with 16-byte loads (4 samples per lane per step), the p + 2 sums are wave butterflies.
     constexpr int NV = MAXD + 2;
-    __shared__ double shm[SCAN_WAVES * NV];
     double l[MAXD * MAXD];
 #pragma unroll
     for (int r = 0; r < MAXD; ++r)
 #pragma unroll
         for (int c = 0; c < MAXD; ++c) l[r * MAXD + c] = (r < p && c < p) ? a_chol[r * p + c] : (r == c ? 1.0 : 0.0);
-    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec_ok = (n & 3) == 0;  // rows are 16-byte aligned when n is a multiple of 4
+    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
         const float *g = grot + (int64_t)r * n;
         double v[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = 0.0;
-        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
-            const double gi = (double)g[i];
-            v[0] += (double)w[i] * gi * gi;
-            v[1] += gi * (double)py[i];
+        if (vec_ok) {
+            const float4 *g4 = reinterpret_cast<const float4 *>(g);
+            const float4 *w4 = reinterpret_cast<const float4 *>(w);
+            const float4 *py4 = reinterpret_cast<const float4 *>(py);
+            const int n4 = n >> 2;
+#pragma unroll 2
+            for (int i4 = lane; i4 < n4; i4 += 64) {
+                const float4 gv = g4[i4], wv = w4[i4], pv = py4[i4];
+                const double g0 = gv.x, g1 = gv.y, g2 = gv.z, g3 = gv.w;
+                v[0] += (double)wv.x * g0 * g0 + (double)wv.y * g1 * g1 + (double)wv.z * g2 * g2 + (double)wv.w * g3 * g3;
+                v[1] += g0 * (double)pv.x + g1 * (double)pv.y + g2 * (double)pv.z + g3 * (double)pv.w;
+                const float *wxr = wx + (int64_t)i4 * 4 * p;
 #pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-                if (k < p) v[2 + k] += gi * (double)wx[(int64_t)i * p + k];
+                for (int k = 0; k < MAXD; ++k)
+                    if (k < p)
+                        v[2 + k] += g0 * (double)wxr[k] + g1 * (double)wxr[p + k] + g2 * (double)wxr[2 * p + k] +
+                                    g3 * (double)wxr[3 * p + k];
+            }
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                const double gi = (double)g[i];
+                v[0] += (double)w[i] * gi * gi;
+                v[1] += gi * (double)py[i];
+#pragma unroll
+                for (int k = 0; k < MAXD; ++k)
+                    if (k < p) v[2 + k] += gi * (double)wx[(int64_t)i * p + k];
+            }
         }
-        block_sum<NV>(v, 2 + p, shm);
-        if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (k < 2 + p) v[k] = wave_allsum(v[k]);
+        if (lane == 0) {
             double *o = out + (int64_t)r * 3;
             double c[MAXD], aic[MAXD];
             // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
@@ -627,7 +652,8 @@ extern "C" int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, 
                                   void *stream) {
     if (nrows <= 0) return 0;
     if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_scan: p out of range");
-    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                           (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df,
                                           d_out));
@@ -644,7 +670,8 @@ extern "C" int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, cons
     DevBuf a;
     if (a.alloc(sizeof(double) * p * p)) return 1;
     JX_HIP(hipMemcpyAsync(a.p, h_a_chol, sizeof(double) * p * p, hipMemcpyHostToDevice, st));
-    const int grid = nrows < 65536 * 8 ? nrows : 65536 * 8;
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0, st, d_grot,
                                           nrows, n, p, d_w, d_py, d_wx, a.as<double>(), ypy, df, d_out));
     JX_LAUNCH_CHECK();

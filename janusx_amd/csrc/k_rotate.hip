@@ -78,12 +78,12 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                                                               const __half *__restrict__ uhi,
                                                               const __half *__restrict__ ulo, int64_t npad, int n,
                                                               float out_scale, float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 2048];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 64];
     uint8_t *sAh = smem;
     uint8_t *sAl = smem + R_IMG;
     uint8_t *sBh = smem + 2 * R_IMG;
     uint8_t *sBl = smem + 3 * R_IMG;
-    uint2 *seltab = reinterpret_cast<uint2 *>(smem + 4 * R_IMG);
+    uint32_t *seltab = reinterpret_cast<uint32_t *>(smem + 4 * R_IMG);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
     const int j0 = blockIdx.x * 128;
     const int r0 = blockIdx.y * 128;
 
-    seltab[tid] = make_selectors_r((uint32_t)tid);
+    if (tid < 16) seltab[tid] = make_selectors_r((uint32_t)tid).x;
 
     // ---- loader roles -------------------------------------------------------------------------
     const bool is_decoder = tid < 128;
@@ -155,27 +155,27 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const uint32_t w = ws[half];
+                // nibble (two samples) -> v_perm selector: 16-entry table on 16 distinct banks, conflict-free
+                uint32_t sl[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sl[i] = seltab[(w >> (4 * i)) & 15u];
                 u32x4 h0, h1, l0, l1;
-                const uint2 s0 = seltab[w & 0xffu];
-                const uint2 s1 = seltab[(w >> 8) & 0xffu];
-                const uint2 s2 = seltab[(w >> 16) & 0xffu];
-                const uint2 s3 = seltab[w >> 24];
-                h0.x = __builtin_amdgcn_perm(L.y, L.x, s0.x);
-                h0.y = __builtin_amdgcn_perm(L.y, L.x, s0.y);
-                h0.z = __builtin_amdgcn_perm(L.y, L.x, s1.x);
-                h0.w = __builtin_amdgcn_perm(L.y, L.x, s1.y);
-                h1.x = __builtin_amdgcn_perm(L.y, L.x, s2.x);
-                h1.y = __builtin_amdgcn_perm(L.y, L.x, s2.y);
-                h1.z = __builtin_amdgcn_perm(L.y, L.x, s3.x);
-                h1.w = __builtin_amdgcn_perm(L.y, L.x, s3.y);
-                l0.x = __builtin_amdgcn_perm(L.w, L.z, s0.x);
-                l0.y = __builtin_amdgcn_perm(L.w, L.z, s0.y);
-                l0.z = __builtin_amdgcn_perm(L.w, L.z, s1.x);
-                l0.w = __builtin_amdgcn_perm(L.w, L.z, s1.y);
-                l1.x = __builtin_amdgcn_perm(L.w, L.z, s2.x);
-                l1.y = __builtin_amdgcn_perm(L.w, L.z, s2.y);
-                l1.z = __builtin_amdgcn_perm(L.w, L.z, s3.x);
-                l1.w = __builtin_amdgcn_perm(L.w, L.z, s3.y);
+                h0.x = __builtin_amdgcn_perm(L.y, L.x, sl[0]);
+                h0.y = __builtin_amdgcn_perm(L.y, L.x, sl[1]);
+                h0.z = __builtin_amdgcn_perm(L.y, L.x, sl[2]);
+                h0.w = __builtin_amdgcn_perm(L.y, L.x, sl[3]);
+                h1.x = __builtin_amdgcn_perm(L.y, L.x, sl[4]);
+                h1.y = __builtin_amdgcn_perm(L.y, L.x, sl[5]);
+                h1.z = __builtin_amdgcn_perm(L.y, L.x, sl[6]);
+                h1.w = __builtin_amdgcn_perm(L.y, L.x, sl[7]);
+                l0.x = __builtin_amdgcn_perm(L.w, L.z, sl[0]);
+                l0.y = __builtin_amdgcn_perm(L.w, L.z, sl[1]);
+                l0.z = __builtin_amdgcn_perm(L.w, L.z, sl[2]);
+                l0.w = __builtin_amdgcn_perm(L.w, L.z, sl[3]);
+                l1.x = __builtin_amdgcn_perm(L.w, L.z, sl[4]);
+                l1.y = __builtin_amdgcn_perm(L.w, L.z, sl[5]);
+                l1.z = __builtin_amdgcn_perm(L.w, L.z, sl[6]);
+                l1.w = __builtin_amdgcn_perm(L.w, L.z, sl[7]);
                 *reinterpret_cast<u32x4 *>(dh + half * 32) = h0;
                 *reinterpret_cast<u32x4 *>(dh + half * 32 + 16) = h1;
                 *reinterpret_cast<u32x4 *>(dl + half * 32) = l0;

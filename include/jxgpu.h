@@ -163,6 +163,17 @@ int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_
  * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
 float jxg_last_kernel_ms(int which);
 
+/* G1 ("next" row). GBLUP on a training GRM: eigh + intercept-only REML (Brent on log10 lambda,
+ * v floored at 1e-12) + alpha = U (V^-1 r).  d_k (n,n) f64 is overwritten with U^T; d_yc = y - mean(y).
+ * h_out = (lambda, beta_rot, r'V^-1r, ml, reml, mean eigenvalue).  src/stats/gblup.rs:1105-1240. */
+int jxg_gblup_fit(double *d_k, int n, double ridge, const double *d_yc, double low, double high, double tol,
+                  int max_iter, double *d_alpha, double *h_out, void *stream);
+/* d_out[i] = beta0 + sum_j K[rows[i], cols[j]] alpha[j]; K (n_full, n_full) f32/f64 row-major on the device
+ * (`square_matrix_subset_cross_dot_f64`, src/stats/gblup.rs:1446-1460). */
+int jxg_cross_dot(const void *d_k, int k_is_f64, int64_t n_full, const int32_t *d_rows, int nrows,
+                  const int32_t *d_cols, int ncols, const double *d_alpha, double beta0, double *d_out,
+                  void *stream);
+
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
                        const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out, void *stream);
@@ -221,6 +232,13 @@ int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8
                     const float *row_maf, const double *s, const double *xcov, const double *y_rot,
                     const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
                     double high, int max_iter, double tol, int warm, double init_log10_lbd, double *out);
+
+/* `gblup_reml_npy_grm` (src/stats/gblup.rs:1242-1516) on an in-memory GRM: fit on K[train,train] + g_eps I, predict
+ * K[*,train] alpha + beta0.  out_scalars = (pve, lambda, ml, reml, sigma_g2, sigma_e2, beta0). */
+int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const int64_t *train_idx, int n_train,
+                      const double *y_train, const int64_t *test_idx, int n_test, double g_eps, double low,
+                      double high, int max_iter, double tol, int estimate_only, double *out_pred_train,
+                      double *out_pred_test, double *out_scalars);
 
 #ifdef __cplusplus
 }

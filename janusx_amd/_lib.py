@@ -50,6 +50,8 @@ SIGNATURES = {
     "jxg_lmm_scan_exact": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
     "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jxg_gblup_fit": [c_p, c_i, c_d, c_p, c_d, c_d, c_d, c_i, c_p, c_p, c_p],
+    "jxg_cross_dot": [c_p, c_i, c_l, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
     "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],
@@ -60,6 +62,7 @@ SIGNATURES = {
     "jx_lmm_reml_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_p],
     "jx_lmm_reml_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_i, c_d, c_i, c_d, c_p],
     "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_p],
+    "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_p],
 }

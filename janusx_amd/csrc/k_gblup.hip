@@ -1,0 +1,326 @@
+// GBLUP: intercept-only REML on the spectral scale + BLUP back-solve + cross-GRM predictions.
+// Reference: src/stats/gblup.rs:1105-1240 (`fit_gblup_reml_from_grm_row_major_f64`), :1258-1516
+// (`gblup_reml_npy_grm`), `square_matrix_subset_cross_dot_f64` for the predictions K[*,train] alpha + beta0.
+// The O(n^3) part is the eigendecomposition (eigh.cpp / k_sytrd.hip); everything here is O(n^2) or O(n) per
+// Brent evaluation and runs in a handful of small kernels.
+#include <cmath>
+#include <vector>
+
+#include "scan_common.h"
+
+namespace jx {
+
+// x~[k] = sum_r U[r][k], y~[k] = sum_r U[r][k] yc[r] with ut = U^T row-major (row k = eigenvector k)
+__global__ __launch_bounds__(SCAN_THREADS) void gblup_rot_kernel(const double *__restrict__ ut, int n,
+                                                                 const double *__restrict__ yc,
+                                                                 double *__restrict__ x_rot,
+                                                                 double *__restrict__ y_rot) {
+    __shared__ double shm[SCAN_WAVES * 2];
+    const int k = blockIdx.x;
+    const double *row = ut + (int64_t)k * n;
+    double v[2] = {0.0, 0.0};
+    for (int r = threadIdx.x; r < n; r += SCAN_THREADS) {
+        const double u = row[r];
+        v[0] += u;
+        v[1] += u * yc[r];
+    }
+    block_sum<2>(v, 2, shm);
+    if (threadIdx.x == 0) {
+        x_rot[k] = v[0];
+        y_rot[k] = v[1];
+    }
+}
+
+struct GblupEval {
+    bool ok;
+    double reml, ml, beta, q;
+};
+
+__device__ void gblup_eval(double x, const double *__restrict__ s, const double *__restrict__ xr,
+                           const double *__restrict__ yr, int n, double *shm, double *t_out, GblupEval &o) {
+    const double v_floor = 1e-12;
+    o.ok = false;
+    o.reml = o.ml = o.beta = o.q = 0.0;
+    const double lbd = pow(10.0, x);
+    if (!(isfinite(lbd) && lbd > 0.0)) return;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double vi = fmax(s[i] + lbd, v_floor);
+        const double inv = 1.0 / vi;
+        v[0] += log(vi);
+        v[1] += inv * xr[i] * xr[i];
+        v[2] += inv * xr[i] * yr[i];
+    }
+    block_sum<3>(v, 3, shm);
+    if (!(isfinite(v[1]) && v[1] > v_floor)) return;
+    const double beta = v[2] / v[1];
+    double q[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const double inv = 1.0 / fmax(s[i] + lbd, v_floor);
+        const double ri = yr[i] - xr[i] * beta;
+        q[0] += inv * ri * ri;
+        if (t_out) t_out[i] = inv * ri;
+    }
+    block_sum<1>(q, 1, shm);
+    if (!(isfinite(q[0]) && q[0] > v_floor)) return;
+    const double n_eff = (double)(n - 1), nf = (double)n;
+    const double c_reml = n_eff * (log(n_eff) - 1.0 - log(2.0 * M_PI)) / 2.0;
+    const double c_ml = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0;
+    const double reml = c_reml - 0.5 * (n_eff * log(q[0]) + v[0] + log(v[1]));
+    const double ml = c_ml - 0.5 * (nf * log(q[0]) + v[0]);
+    if (!(isfinite(reml) && isfinite(ml))) return;
+    o.ok = true;
+    o.reml = reml;
+    o.ml = ml;
+    o.beta = beta;
+    o.q = q[0];
+}
+
+// Brent (src/math/brent.rs) on -REML (1e100 on failure), then the optimum's quantities.
+// out: [0] status (0 ok), [1] lambda, [2] beta_rot, [3] rtv_invr, [4] ml, [5] reml; t (n) = v^-1 r at the optimum.
+__global__ __launch_bounds__(SCAN_THREADS) void gblup_reml_kernel(const double *__restrict__ s,
+                                                                  const double *__restrict__ xr,
+                                                                  const double *__restrict__ yr, int n, double low,
+                                                                  double high, double tol_in, int max_iter,
+                                                                  double *__restrict__ t, double *__restrict__ out) {
+    __shared__ double shm[SCAN_WAVES * 3];
+    GblupEval ev;
+    auto cost = [&](double xx) {
+        gblup_eval(xx, s, xr, yr, n, shm, nullptr, ev);
+        return ev.ok ? -ev.reml : 1e100;
+    };
+    double a = low, c = high;
+    if (!(a < c)) {
+        const double tt = a;
+        a = c;
+        c = tt;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double tol = fmax(fabs(tol_in), 1e-12);
+    double x = 0.5 * (a + c);
+    double w = x, v = x;
+    double fx = cost(x), fw = fx, fv = fx;
+    double d = 0.0, e = 0.0;
+    for (int it = 0; it < max_iter; ++it) {
+        const double m = 0.5 * (a + c);
+        const double tol1 = tol * fabs(x) + eps;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x - m) <= tol2 - 0.5 * (c - a)) break;
+        double u;
+        bool use_par = false;
+        if (fabs(e) > tol1) {
+            double pq = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw));
+            double q = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)));
+            if (q > 0.0)
+                pq = -pq;
+            else
+                q = -q;
+            bool ok = false;
+            if (fabs(q) > eps) {
+                const double sstep = pq / q;
+                u = x + sstep;
+                if ((u - a) >= tol2 && (c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(e)) ok = true;
+            }
+            if (ok) {
+                d = pq / q;
+                u = x + d;
+                if ((u - a) < tol2 || (c - u) < tol2) d = (x < m) ? tol1 : -tol1;
+                use_par = true;
+            }
+        }
+        if (!use_par) {
+            e = (x < m) ? (c - x) : (a - x);
+            d = 0.3819660 * e;
+        }
+        if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
+        u = x + d;
+        const double fu = cost(u);
+        if (fu <= fx) {
+            if (u >= x)
+                a = x;
+            else
+                c = x;
+            v = w;
+            fv = fw;
+            w = x;
+            fw = fx;
+            x = u;
+            fx = fu;
+        } else {
+            if (u >= x)
+                c = u;
+            else
+                a = u;
+            if (fu <= fw || w == x) {
+                v = w;
+                fv = fw;
+                w = u;
+                fw = fu;
+            } else if (fu <= fv || v == x || v == w) {
+                v = u;
+                fv = fu;
+            }
+        }
+    }
+    gblup_eval(x, s, xr, yr, n, shm, t, ev);
+    if (threadIdx.x == 0) {
+        out[0] = ev.ok ? 0.0 : 1.0;
+        out[1] = pow(10.0, x);
+        out[2] = ev.beta;
+        out[3] = ev.q;
+        out[4] = ev.ml;
+        out[5] = ev.reml;
+    }
+}
+
+// alpha[row] = sum_k U[row][k] t[k] = sum_k ut[k][row] t[k]; one thread per row, coalesced over rows
+__global__ __launch_bounds__(SCAN_THREADS) void gblup_alpha_kernel(const double *__restrict__ ut, int n,
+                                                                   const double *__restrict__ t,
+                                                                   double *__restrict__ alpha) {
+    const int row = blockIdx.x * SCAN_THREADS + threadIdx.x;
+    if (row >= n) return;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < n; ++k) acc += ut[(int64_t)k * n + row] * t[k];
+    alpha[row] = acc;
+}
+
+// out[i] = beta0 + sum_j K[rows[i]][cols[j]] alpha[j]  (K (n_full, n_full) f32 or f64 row-major)
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void cross_dot_kernel(const T *__restrict__ k, int64_t n_full,
+                                                                 const int32_t *__restrict__ rows,
+                                                                 const int32_t *__restrict__ cols, int ncols,
+                                                                 const double *__restrict__ alpha, double beta0,
+                                                                 double *__restrict__ out) {
+    __shared__ double shm[SCAN_WAVES];
+    const T *krow = k + (int64_t)rows[blockIdx.x] * n_full;
+    double v[1] = {0.0};
+    for (int j = threadIdx.x; j < ncols; j += SCAN_THREADS) v[0] += (double)krow[cols[j]] * alpha[j];
+    block_sum<1>(v, 1, shm);
+    if (threadIdx.x == 0) out[blockIdx.x] = v[0] + beta0;
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream);
+
+// d_k (n,n) f64 training GRM (overwritten with U^T), d_yc (n) centred phenotype.
+// h_out: [0] lambda, [1] beta_rot, [2] rtv_invr, [3] ml, [4] reml, [5] mean(s).  d_alpha (n).
+extern "C" int jxg_gblup_fit(double *d_k, int n, double ridge, const double *d_yc, double low, double high, double tol,
+                             int max_iter, double *d_alpha, double *h_out, void *stream) {
+    if (n <= 1) return fail("GBLUP REML requires at least 2 training samples.");
+    if (!(low < high)) return fail("low/high must be finite and low < high");
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf s, xr, yr, t, out;
+    if (s.alloc(sizeof(double) * n) || xr.alloc(sizeof(double) * n) || yr.alloc(sizeof(double) * n) ||
+        t.alloc(sizeof(double) * n) || out.alloc(sizeof(double) * 8))
+        return 1;
+    if (jxg_eigh_f64(d_k, n, ridge, s.as<double>(), stream)) return 1;
+    hipLaunchKernelGGL(gblup_rot_kernel, dim3(n), dim3(SCAN_THREADS), 0, st, d_k, n, d_yc, xr.as<double>(),
+                       yr.as<double>());
+    JX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gblup_reml_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, s.as<double>(), xr.as<double>(),
+                       yr.as<double>(), n, low, high, tol, max_iter, t.as<double>(), out.as<double>());
+    JX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gblup_alpha_kernel, dim3((n + SCAN_THREADS - 1) / SCAN_THREADS), dim3(SCAN_THREADS), 0, st, d_k,
+                       n, t.as<double>(), d_alpha);
+    JX_LAUNCH_CHECK();
+    double ho[8];
+    JX_HIP(hipMemcpyAsync(ho, out.p, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+    std::vector<double> hs((size_t)n);
+    JX_HIP(hipMemcpyAsync(hs.data(), s.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    if (ho[0] != 0.0) return fail("GBLUP REML optimization failed to produce a valid optimum.");
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += hs[i];
+    for (int i = 0; i < 5; ++i) h_out[i] = ho[i + 1];
+    h_out[5] = sum / (double)n;
+    return 0;
+}
+
+extern "C" int jxg_cross_dot(const void *d_k, int k_is_f64, int64_t n_full, const int32_t *d_rows, int nrows,
+                             const int32_t *d_cols, int ncols, const double *d_alpha, double beta0, double *d_out,
+                             void *stream) {
+    if (nrows <= 0) return 0;
+    if (k_is_f64)
+        hipLaunchKernelGGL(cross_dot_kernel<double>, dim3(nrows), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
+                           (const double *)d_k, n_full, d_rows, d_cols, ncols, d_alpha, beta0, d_out);
+    else
+        hipLaunchKernelGGL(cross_dot_kernel<float>, dim3(nrows), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
+                           (const float *)d_k, n_full, d_rows, d_cols, ncols, d_alpha, beta0, d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// `gblup_reml_npy_grm` on an in-memory GRM (host arrays): fit on K[train,train] + g_eps I, predict train/test.
+// out_scalars: [0] pve, [1] lambda, [2] ml, [3] reml, [4] sigma_g2, [5] sigma_e2, [6] beta0.
+extern "C" int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const int64_t *train_idx,
+                                 int n_train, const double *y_train, const int64_t *test_idx, int n_test,
+                                 double g_eps, double low, double high, int max_iter, double tol, int estimate_only,
+                                 double *out_pred_train, double *out_pred_test, double *out_scalars) {
+    if (!(std::isfinite(g_eps) && g_eps >= 0.0)) return fail("g_eps must be finite and >= 0");
+    if (!(std::isfinite(low) && std::isfinite(high) && low < high)) return fail("low/high must be finite and low < high");
+    if (max_iter <= 0) return fail("max_iter must be > 0");
+    if (!(std::isfinite(tol) && tol > 0.0)) return fail("tol must be finite and > 0");
+    if (n_train <= 1) return fail("GBLUP REML requires at least 2 training samples.");
+    const size_t esz = k_is_f64 ? 8 : 4;
+    std::vector<int32_t> tr((size_t)n_train), te((size_t)(n_test > 0 ? n_test : 0));
+    for (int i = 0; i < n_train; ++i) {
+        if (train_idx[i] < 0 || train_idx[i] >= n_full) return fail("train sample index out of range");
+        tr[i] = (int32_t)train_idx[i];
+    }
+    for (int i = 0; i < n_test; ++i) {
+        if (test_idx[i] < 0 || test_idx[i] >= n_full) return fail("test sample index out of range");
+        te[i] = (int32_t)test_idx[i];
+    }
+    double y_mean = 0.0;
+    for (int i = 0; i < n_train; ++i) y_mean += y_train[i];
+    y_mean /= (double)n_train;
+    std::vector<double> yc((size_t)n_train);
+    for (int i = 0; i < n_train; ++i) yc[i] = y_train[i] - y_mean;
+
+    DevBuf dk, dtr, dte, dkt, dyc, dalpha, dpred;
+    if (dk.alloc(esz * (size_t)n_full * (size_t)n_full)) return 1;
+    JX_HIP(hipMemcpy(dk.p, k_full, esz * (size_t)n_full * (size_t)n_full, hipMemcpyHostToDevice));
+    if (dtr.alloc(sizeof(int32_t) * tr.size()) || dte.alloc(sizeof(int32_t) * (te.size() + 1))) return 1;
+    JX_HIP(hipMemcpy(dtr.p, tr.data(), sizeof(int32_t) * tr.size(), hipMemcpyHostToDevice));
+    if (!te.empty()) JX_HIP(hipMemcpy(dte.p, te.data(), sizeof(int32_t) * te.size(), hipMemcpyHostToDevice));
+    if (dkt.alloc(sizeof(double) * (size_t)n_train * n_train) || dyc.alloc(sizeof(double) * n_train) ||
+        dalpha.alloc(sizeof(double) * n_train))
+        return 1;
+    JX_HIP(hipMemcpy(dyc.p, yc.data(), sizeof(double) * n_train, hipMemcpyHostToDevice));
+    if (jxg_gather_sub_f64(dk.p, k_is_f64, (int)n_full, dtr.as<int32_t>(), n_train, dkt.as<double>(), nullptr)) return 1;
+    double fit[6];
+    if (jxg_gblup_fit(dkt.as<double>(), n_train, g_eps, dyc.as<double>(), low, high, tol, max_iter, dalpha.as<double>(),
+                      fit, nullptr))
+        return 1;
+    const double lambda = fit[0], beta_rot = fit[1], q = fit[2], ml = fit[3], reml = fit[4], mean_s = fit[5];
+    const double n_eff = (double)(n_train - 1);
+    const double sg2 = q / (n_eff > 1.0 ? n_eff : 1.0);
+    const double se2 = lambda * sg2;
+    const double var_g = sg2 * (mean_s > 0.0 ? mean_s : 0.0);
+    const double den = var_g + se2;
+    out_scalars[0] = (std::isfinite(den) && den > 0.0) ? var_g / den : NAN;
+    out_scalars[1] = lambda;
+    out_scalars[2] = ml;
+    out_scalars[3] = reml;
+    out_scalars[4] = sg2;
+    out_scalars[5] = se2;
+    out_scalars[6] = y_mean + beta_rot;
+    if (estimate_only) return 0;
+    const int np = n_train > n_test ? n_train : n_test;
+    if (dpred.alloc(sizeof(double) * (size_t)np)) return 1;
+    if (jxg_cross_dot(dk.p, k_is_f64, n_full, dtr.as<int32_t>(), n_train, dtr.as<int32_t>(), n_train, dalpha.as<double>(),
+                      out_scalars[6], dpred.as<double>(), nullptr))
+        return 1;
+    JX_HIP(hipMemcpy(out_pred_train, dpred.p, sizeof(double) * n_train, hipMemcpyDeviceToHost));
+    if (n_test > 0) {
+        if (jxg_cross_dot(dk.p, k_is_f64, n_full, dte.as<int32_t>(), n_test, dtr.as<int32_t>(), n_train,
+                          dalpha.as<double>(), out_scalars[6], dpred.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out_pred_test, dpred.p, sizeof(double) * n_test, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}

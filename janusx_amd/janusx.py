@@ -564,3 +564,63 @@ def gwas_lmm_lm_null_lrt_decision(y, x_cov, lmm_ml0, alpha=0.05, boundary_mixtur
         pval = 1.0
     pval = min(max(pval, 2.2250738585072014e-308), 1.0)
     return bool(pval >= alpha), stat, pval, lm_ml0
+
+
+# ------------------------------------------------------------------------------------------------
+# GBLUP (`jx gs -BLUP`, n <= 15 000 branch): src/stats/gblup.rs:1242-1516 `gblup_reml_npy_grm`
+# ------------------------------------------------------------------------------------------------
+
+def gblup_reml_grm(grm, train_sample_indices, y_train, test_sample_indices=None, train_pred_local_indices=None,
+                   g_eps=1e-8, low=-6.0, high=6.0, max_iter=50, tol=1e-4, threads=0,
+                   return_variance_components=False, estimate_only=False):
+    """In-memory form of `gblup_reml_npy_grm`: `grm` (n_full, n_full) f32/f64.  Returns the reference's 12-tuple
+    (pred_train (k,1), pred_test (t,1), pve, lambda, ml, reml, evd_backend, evd_elapsed, 0, sigma_g2, sigma_e2,
+    effect (empty))."""
+    import math
+    if not (math.isfinite(g_eps) and g_eps >= 0.0):
+        raise RuntimeError("g_eps must be finite and >= 0")
+    if not (math.isfinite(low) and math.isfinite(high) and low < high):
+        raise RuntimeError("low/high must be finite and low < high")
+    if int(max_iter) == 0:
+        raise RuntimeError("max_iter must be > 0")
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError("tol must be finite and > 0")
+    k = np.asarray(grm)
+    if k.ndim != 2 or k.shape[0] != k.shape[1]:
+        raise RuntimeError("GRM must be a square matrix")
+    is64 = k.dtype == np.float64
+    k = _c(k, np.float64 if is64 else np.float32)
+    tr = _c(train_sample_indices, np.int64).ravel()
+    y = _c(y_train, np.float64).ravel()
+    if y.shape[0] != tr.shape[0]:
+        raise RuntimeError("y_train length must equal train_sample_indices length")
+    te = np.zeros(0, dtype=np.int64) if test_sample_indices is None else _c(test_sample_indices, np.int64).ravel()
+    pt = np.zeros(tr.shape[0], dtype=np.float64)
+    pe = np.zeros(max(te.shape[0], 1), dtype=np.float64)
+    sc = np.zeros(8, dtype=np.float64)
+    t0 = time.perf_counter()
+    check(lib().jx_gblup_reml_grm(_p(k), 1 if is64 else 0, int(k.shape[0]), _p(tr), int(tr.shape[0]), _p(y), _p(te),
+                                  int(te.shape[0]), float(g_eps), float(low), float(high), int(max_iter), float(tol),
+                                  1 if estimate_only else 0, _p(pt), _p(pe), _p(sc)))
+    el = time.perf_counter() - t0
+    if estimate_only:
+        ptr = np.zeros((0, 1))
+        pte = np.zeros((0, 1))
+    else:
+        if train_pred_local_indices is not None:
+            pt = pt[np.asarray(train_pred_local_indices, dtype=np.int64)]
+        ptr = pt.reshape(-1, 1)
+        pte = pe[: te.shape[0]].reshape(-1, 1)
+    sg2 = float(sc[4]) if return_variance_components else float("nan")
+    se2 = float(sc[5]) if return_variance_components else float("nan")
+    return (ptr, pte, float(sc[0]), float(sc[1]), float(sc[2]), float(sc[3]), "rocsolver", el, 0, sg2, se2,
+            np.zeros(0, dtype=np.float64))
+
+
+def gblup_reml_npy_grm(grm_path, train_sample_indices, y_train, test_sample_indices=None,
+                       train_pred_local_indices=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50, tol=1e-4,
+                       threads=0, return_variance_components=False, estimate_only=False):
+    """src/stats/gblup.rs:1242-1516: `.npy` GRM (f32/f64 C-order) on disk."""
+    k = np.load(grm_path)
+    return gblup_reml_grm(k, train_sample_indices, y_train, test_sample_indices, train_pred_local_indices, g_eps, low,
+                          high, max_iter, tol, threads, return_variance_components, estimate_only)

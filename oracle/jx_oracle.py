@@ -886,3 +886,80 @@ def format_assoc_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p) -> str:
         pv = 1.0
     return (f"{chrom}\t{pos}\t{name}\t{a0}\t{a1}\t{rust_fmt_f4(float(af))}\t{rust_fmt_f4(float(miss))}\t"
             f"{rust_fmt_f4(beta)}\t{rust_fmt_f4(se)}\t{rust_fmt_e4(chisq)}\t{rust_fmt_e4(pv)}\n")
+
+
+# --------------------------------------------------------------------------------------------
+# G1  GBLUP (src/stats/gblup.rs:1105-1240 `fit_gblup_reml_from_grm_row_major_f64`, :1258-1516 `gblup_reml_npy_grm`)
+# --------------------------------------------------------------------------------------------
+
+def gblup_fit(grm_f64, y, low=-6.0, high=6.0, tol=1e-4, max_iter=50):
+    """Intercept-only REML on the spectral scale: eigh(K) (no ridge here; the caller adds g_eps), x~ = U'1,
+    y~ = U'(y - mean), Brent over log10(lambda) with v_i = max(s_i + lambda, 1e-12), alpha = U (v^-1 r)."""
+    k = np.asarray(grm_f64, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).ravel()
+    n = y.shape[0]
+    if n <= 1:
+        raise RuntimeError("GBLUP REML requires at least 2 training samples.")
+    y_mean = float(np.sum(y) / n)
+    yc = y - y_mean
+    s, u = eigh_sym(k)
+    x_rot = u.sum(axis=0)
+    y_rot = u.T @ yc
+    v_floor = 1e-12
+    n_eff = float(n - 1)
+    c_reml = n_eff * (math.log(n_eff) - 1.0 - math.log(2.0 * math.pi)) / 2.0
+    c_ml = n * (math.log(n) - 1.0 - math.log(2.0 * math.pi)) / 2.0
+
+    def ev(x):
+        lbd = 10.0 ** x
+        if not (math.isfinite(lbd) and lbd > 0.0):
+            return None
+        vi = np.maximum(s + lbd, v_floor)
+        log_det_v = float(np.sum(np.log(vi)))
+        inv = 1.0 / vi
+        xtvx = float(np.sum(inv * x_rot * x_rot))
+        xtvy = float(np.sum(inv * x_rot * y_rot))
+        if not (math.isfinite(xtvx) and xtvx > v_floor):
+            return None
+        beta = xtvy / xtvx
+        r = y_rot - x_rot * beta
+        q = float(np.sum(inv * r * r))
+        if not (math.isfinite(q) and q > v_floor):
+            return None
+        reml = c_reml - 0.5 * (n_eff * math.log(q) + log_det_v + math.log(xtvx))
+        ml = c_ml - 0.5 * (n * math.log(q) + log_det_v)
+        if not (math.isfinite(reml) and math.isfinite(ml)):
+            return None
+        return reml, ml, beta, q, inv, r
+
+    def cost(x):
+        e = ev(x)
+        return -e[0] if e is not None else 1e100
+
+    xb, _, _ = brent_minimize(cost, low, high, tol, max_iter)
+    e = ev(xb)
+    if e is None:
+        raise RuntimeError("GBLUP REML optimization failed to produce a valid optimum.")
+    reml, ml, beta_rot, q, inv, r = e
+    lbd = 10.0 ** xb
+    alpha = u @ (inv * r)
+    sg2 = q / max(n_eff, 1.0)
+    se2 = lbd * sg2
+    mean_s = float(np.sum(s) / n)
+    var_g = sg2 * max(mean_s, 0.0)
+    den = var_g + se2
+    pve = var_g / den if (math.isfinite(den) and den > 0.0) else float("nan")
+    return dict(alpha=alpha, beta0=y_mean + beta_rot, lbd=lbd, pve=pve, ml=ml, reml=reml, sigma_g2=sg2, sigma_e2=se2)
+
+
+def gblup_reml_grm(k_full, train_idx, y_train, test_idx=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50, tol=1e-4):
+    """`gblup_reml_npy_grm` on an in-memory GRM: fit on K[train,train] + g_eps I, predictions K[*,train] alpha + beta0."""
+    k_full = np.asarray(k_full)
+    tr = np.asarray(train_idx, dtype=np.int64)
+    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    kt = k_full[np.ix_(tr, tr)].astype(np.float64)
+    kt[np.diag_indices_from(kt)] += g_eps
+    fit = gblup_fit(kt, y_train, low, high, tol, max_iter)
+    pred_train = k_full[np.ix_(tr, tr)].astype(np.float64) @ fit["alpha"] + fit["beta0"]
+    pred_test = k_full[np.ix_(te, tr)].astype(np.float64) @ fit["alpha"] + fit["beta0"]
+    return pred_train, pred_test, fit

@@ -508,3 +508,32 @@ def test_full_size_c2_properties(oracle, oracle_c):
     fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(sh, xh, yh, model.null.lbd))
     be, se, pe = _assoc_err(fa[pick], fref)
     assert max(be, se) < TOL, (be, se, pe)
+
+
+def test_gblup_reml_grm(oracle, tmp_path):
+    """`jx gs -BLUP` GBLUP branch: fit on K[train,train], predict K[test,train] alpha + beta0."""
+    from janusx_amd import janusx as jxrs
+    n, m = 420, 1500
+    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.01, family=True)
+    y = bed.synth_phenotype(g, n_causal=40, pve=0.6, seed=61) + 3.0
+    k, eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n)
+    tr, te = np.sort(perm[:330]), np.sort(perm[330:])
+    ptr_ref, pte_ref, fit = oracle.gblup_reml_grm(k, tr, y[tr], te)
+    for kk in (k, k.astype(np.float64)):
+        out = jxrs.gblup_reml_grm(kk, tr, y[tr], te, return_variance_components=True)
+        ptr, pte, pve, lbd, ml, reml = out[0], out[1], out[2], out[3], out[4], out[5]
+        assert abs(lbd - fit["lbd"]) < 1e-6 * fit["lbd"] and abs(pve - fit["pve"]) < 1e-6
+        assert abs(ml - fit["ml"]) < 1e-8 * abs(fit["ml"]) and abs(reml - fit["reml"]) < 1e-8 * abs(fit["reml"])
+        assert abs(out[9] - fit["sigma_g2"]) < 1e-6 * fit["sigma_g2"] and abs(out[10] - fit["sigma_e2"]) < 1e-6 * fit["sigma_e2"]
+        sd = float(np.std(y))
+        assert np.max(np.abs(ptr.ravel() - ptr_ref)) < 1e-6 * sd and np.max(np.abs(pte.ravel() - pte_ref)) < 1e-6 * sd
+    # npy route + estimate_only + prediction sanity (positive accuracy on a structured panel)
+    path = str(tmp_path / "k.npy")
+    np.save(path, k)
+    est = jxrs.gblup_reml_npy_grm(path, tr, y[tr], te, estimate_only=True)
+    assert est[0].shape == (0, 1) and abs(est[3] - fit["lbd"]) < 1e-6 * fit["lbd"] and math.isnan(est[9])
+    assert np.corrcoef(pte_ref, y[te])[0, 1] > 0.1
+    with pytest.raises(RuntimeError, match="low/high"):
+        jxrs.gblup_reml_grm(k, tr, y[tr], te, low=2.0, high=1.0)

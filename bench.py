@@ -8,9 +8,10 @@ panel that is already resident in HBM when the timed region starts.  Rank 0 prin
 Workload at N = 1: BASELINE.json configs[1] shape (n = 5 000 samples, m = 50 000 SNPs, HWE genotypes with
 MAF ~ U(0.02, 0.45), intercept-only, 100 causal SNPs, pve 0.5), run with the exact per-SNP REML scan (`-lmm`,
 what the metric names; `--mode fvlmm` times the fixed-lambda scan of configs[1] instead).
-N > 1: the same panel, SNP-sharded (strong scaling): every rank builds the GRM partial of its SNP range, the
-f64 partials are summed with an RCCL all-reduce over xGMI, every rank then holds K, runs the (replicated)
-eigendecomposition + null fit and scans its own SNP range.
+N > 1: SNP-sharded.  Default `--scaling weak`: every rank owns m SNPs (the panel is n x (m*N), generated shard by
+shard with a counter-keyed RNG), builds the GRM partial of its SNP range, the f64 partials are summed with an RCCL
+all-reduce over xGMI, every rank then holds K, runs the (replicated, it does not shard: SURVEY.md 8e)
+eigendecomposition + null fit and scans its own SNP range.  `--scaling strong` splits one n x m panel instead.
 """
 import argparse
 import json
@@ -148,6 +149,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260609)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     args = ap.parse_args()
 
     import torch
@@ -169,8 +171,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    n, m = args.n, args.m
-    # SNP shard of this rank (contiguous range, strong scaling)
+    n = args.n
+    m = args.m * world if args.scaling == "weak" else args.m   # panel width of the whole job
+    # SNP shard of this rank (contiguous range)
     lo = (m * rank) // world
     hi = (m * (rank + 1)) // world
     packed, dos_head = synth_panel_gpu(n, hi - lo, args.seed, dev, m_offset=lo, missing_rate=args.missing)
@@ -276,11 +279,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f16x2-split MFMA (f32 acc, f64 merge) + f64 REML",
             "data": "synthetic",
-            "config": {"workload": f"synthetic HWE panel n={n} m={m} (BASELINE configs[1] shape), -{args.mode}, "
+            "config": {"workload": f"synthetic HWE panel n={n} m={m} (BASELINE configs[1] shape x{world if args.scaling == 'weak' else 1} SNPs), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
                        "parallelism": f"snp-shard x{world}"},

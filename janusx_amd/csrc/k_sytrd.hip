@@ -78,6 +78,78 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams 
     if ((threadIdx.x & 63) == 0 && sq != 0.0) unsafeAtomicAdd(&P.acc[par].sc[1], sq);
 }
 
+// Row-chunk part of B(j) (64 rows per workgroup): scaled reflector out (A, vbuf, Vt), V'v and W'v partial sums,
+// e_j / tau_j.  `scratch` >= 64 + 2 * 4 * 64 doubles of LDS.
+__device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j0, int chunk, double *scratch) {
+    const int par = j & 1;
+    const int n = P.n;
+    const int nt = n - j - 1;
+    const int base = j + 1;
+    const int i = j - j0;
+    const int tid = threadIdx.x;
+    double beta, tau, scale;
+    larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
+
+    // ---- row chunk (64 rows): scaled reflector out, V'v and W'v partial sums -----------------------------
+    const int rrow0 = chunk * TD_TS;  // relative row of this block's first row
+    // the row-chunk path never touches the tile image: reuse its storage (keeps the kernel at 4 workgroups per CU)
+    double *vsh = scratch;
+    double (*part)[4][TD_NB] = reinterpret_cast<double (*)[4][TD_NB]>(scratch + TD_TS);
+    if (tid < TD_TS) {
+        const int rr = rrow0 + tid;
+        double v = 0.0;
+        if (rr < nt) {
+            v = (rr == 0) ? 1.0 : P.ubuf[base + rr] * scale;
+            P.a[(base + rr) + (int64_t)j * P.ld] = v;  // explicit reflector (unit entry included) while in the panel
+            P.vbuf[base + rr] = v;
+            P.vt[(int64_t)(base + rr) * TD_NB + i] = v;
+        }
+        vsh[tid] = v;
+    }
+    if (chunk == 0 && tid == 0) {
+        P.e[j] = beta;
+        P.tau[j] = tau;
+        // zero the norm accumulator of the other parity (S(j) accumulates into it)
+        P.acc[par ^ 1].sc[1] = 0.0;
+    }
+    if (i > 0) {
+        __syncthreads();
+        // t1[k] += sum_r Vt[r][k] v_r ; t2[k] += sum_r Wt[r][k] v_r : thread (k = tid & 63, sub = tid >> 6), 16 rows
+        const int k = tid & 63, sub = tid >> 6;
+        double s1 = 0.0, s2 = 0.0;
+        if (k < i) {
+            // two batches of 8 rows: 16 loads in flight per batch, half the registers of one 16-row batch
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                double vv[8], a1[8], a2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int rloc = sub * 16 + hb * 8 + q;
+                    const bool okr = (rrow0 + rloc) < nt;
+                    const int64_t row = (int64_t)(base + rrow0 + (okr ? rloc : 0)) * TD_NB;
+                    vv[q] = okr ? vsh[rloc] : 0.0;
+                    a1[q] = P.vt[row + k];
+                    a2[q] = P.wt[row + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s1 += a1[q] * vv[q];
+                    s2 += a2[q] * vv[q];
+                }
+            }
+        }
+        part[0][sub][k] = s1;
+        part[1][sub][k] = s2;
+        __syncthreads();
+        if (tid < i) {
+            const double a1 = part[0][0][tid] + part[0][1][tid] + part[0][2][tid] + part[0][3][tid];
+            const double a2 = part[1][0][tid] + part[1][1][tid] + part[1][2][tid] + part[1][3][tid];
+            if (a1 != 0.0) unsafeAtomicAdd(&P.acc[par].t1[tid], a1);
+            if (a2 != 0.0) unsafeAtomicAdd(&P.acc[par].t2[tid], a2);
+        }
+    }
+}
+
 // B(j): see file header.  grid = nstrips + row chunks.
 // Symv work unit ("strip"): one 64-row block x up to K consecutive 64-column tiles of the lower triangle.  The next
 // tile's 8 x 16-byte loads per thread are issued before the current tile is reduced out of LDS, so every
@@ -93,7 +165,6 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
     const int n = P.n;
     const int nt = n - j - 1;       // trailing dimension
     const int base = j + 1;         // first trailing row/col
-    const int i = j - j0;           // columns already in the panel
     const int tid = threadIdx.x;
 
     if ((int)blockIdx.x < nstrips) {
@@ -204,69 +275,7 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
         }
         return;
     }
-    const int ntiles = nstrips;
-    double beta, tau, scale;
-    larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
-
-    // ---- row chunk (64 rows): scaled reflector out, V'v and W'v partial sums -----------------------------
-    const int chunk = blockIdx.x - ntiles;
-    const int rrow0 = chunk * TD_TS;  // relative row of this block's first row
-    // the row-chunk path never touches the tile image: reuse its storage (keeps the kernel at 4 workgroups per CU)
-    double *vsh = &tile[0][0];
-    double (*part)[4][TD_NB] = reinterpret_cast<double (*)[4][TD_NB]>(&tile[2][0]);
-    if (tid < TD_TS) {
-        const int rr = rrow0 + tid;
-        double v = 0.0;
-        if (rr < nt) {
-            v = (rr == 0) ? 1.0 : P.ubuf[base + rr] * scale;
-            P.a[(base + rr) + (int64_t)j * P.ld] = v;  // explicit reflector (unit entry included) while in the panel
-            P.vbuf[base + rr] = v;
-            P.vt[(int64_t)(base + rr) * TD_NB + i] = v;
-        }
-        vsh[tid] = v;
-    }
-    if (chunk == 0 && tid == 0) {
-        P.e[j] = beta;
-        P.tau[j] = tau;
-        // zero the norm accumulator of the other parity (S(j) accumulates into it)
-        P.acc[par ^ 1].sc[1] = 0.0;
-    }
-    if (i > 0) {
-        __syncthreads();
-        // t1[k] += sum_r Vt[r][k] v_r ; t2[k] += sum_r Wt[r][k] v_r : thread (k = tid & 63, sub = tid >> 6), 16 rows
-        const int k = tid & 63, sub = tid >> 6;
-        double s1 = 0.0, s2 = 0.0;
-        if (k < i) {
-            // two batches of 8 rows: 16 loads in flight per batch, half the registers of one 16-row batch
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                double vv[8], a1[8], a2[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int rloc = sub * 16 + hb * 8 + q;
-                    const bool okr = (rrow0 + rloc) < nt;
-                    const int64_t row = (int64_t)(base + rrow0 + (okr ? rloc : 0)) * TD_NB;
-                    vv[q] = okr ? vsh[rloc] : 0.0;
-                    a1[q] = P.vt[row + k];
-                    a2[q] = P.wt[row + k];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s1 += a1[q] * vv[q];
-                    s2 += a2[q] * vv[q];
-                }
-            }
-        }
-        part[0][sub][k] = s1;
-        part[1][sub][k] = s2;
-        __syncthreads();
-        if (tid < i) {
-            const double a1 = part[0][0][tid] + part[0][1][tid] + part[0][2][tid] + part[0][3][tid];
-            const double a2 = part[1][0][tid] + part[1][1][tid] + part[1][2][tid] + part[1][3][tid];
-            if (a1 != 0.0) unsafeAtomicAdd(&P.acc[par].t1[tid], a1);
-            if (a2 != 0.0) unsafeAtomicAdd(&P.acc[par].t2[tid], a2);
-        }
-    }
+    sytrd_chunk_path(P, j, j0, blockIdx.x - nstrips, &tile[0][0]);
 }
 
 // S(j): see file header. Four threads per trailing row (16 panel columns each), 64 rows per block.
@@ -434,12 +443,12 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             const int j = j0 + i;
             const int nt = n - j - 1;
             const int nchunks = (nt + TD_TS - 1) / TD_TS;
-            // strips: one 64-row block x K consecutive tiles; K grows with the tile count so that ~1000-2000
-            // workgroups stay in flight
-            const int side = (nt + TD_TS - 1) / TD_TS;
-            const int64_t ntiles = (int64_t)side * (side + 1) / 2;
             static const int kt_env = getenv("JXGPU_SYTRD_KT") ? atoi(getenv("JXGPU_SYTRD_KT")) : 0;
             static const int tg_env = getenv("JXGPU_SYTRD_TARGET") ? atoi(getenv("JXGPU_SYTRD_TARGET")) : 768;
+            // strips: one 64-row block x K consecutive tiles; K grows with the tile count so that ~768
+            // workgroups stay in flight.  (A 256x16 tall-tile form with 2 KB column runs measured 3-5 % slower.)
+            const int side = (nt + TD_TS - 1) / TD_TS;
+            const int64_t ntiles = (int64_t)side * (side + 1) / 2;
             int ktiles = kt_env > 0 ? kt_env : (int)((ntiles + tg_env - 1) / tg_env);
             if (ktiles < 1) ktiles = 1;
             if (ktiles > 64) ktiles = 64;

@@ -153,10 +153,16 @@ int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const double *d_s,
 int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double lbd,
                       float *d_w, float *d_py, float *d_wx, double *h_a_chol, double *h_scalars3);
 
-/* E2. fixed-lambda scan of a rotated block -> d_out (nrows,3) f64.  src/stats/fvlmm.rs:1691-1805. */
+/* E2. fixed-lambda scan of a rotated block -> d_out (nrows, 3 or 4) f64 = [beta, se, p(, plrt)]; with_plrt adds
+ * the ML likelihood-ratio column against nullml (log_det_v from jxg_fvlmm_prepare).  src/stats/fvlmm.rs:1691-1805. */
 int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
-                   const float *d_wx, const double *h_a_chol, double ypy, int df, double *d_out,
-                   void *stream);
+                   const float *d_wx, const double *h_a_chol, double ypy, int df, int with_plrt, double nullml,
+                   double log_det_v, double *d_out, void *stream);
+
+/* C2. `ml_loglike` and `reml_loglike` of the null model at log10 lambda -> d_out2 = (ml, reml); -1e8 on failure.
+ * src/stats/reml.rs:255-470. */
+int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
+                         double log10_lbd, double *d_out2, void *stream);
 
 /* Duration (ms, HIP events on the launch stream) of the MFMA kernel(s) issued by the most recent
  * jxg_grm_accumulate (which = 0) or jxg_rotate_packed (which = 1) call of this process.  Counterpart of the
@@ -176,7 +182,8 @@ int jxg_cross_dot(const void *d_k, int k_is_f64, int64_t n_full, const int32_t *
 
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
-                       const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out, void *stream);
+                       const float *d_wx, const double *d_a_chol, double ypy, int df, int with_plrt, double nullml,
+                       double log_det_v, double *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Host layer (reference PyO3 signatures with C arrays)
@@ -219,19 +226,26 @@ int jx_lmm_reml_chunk(const double *s, const double *xcov, const double *y_rot, 
                       double high, const float *snp_chunk, int64_t m_chunk, const float *u_t, int max_iter,
                       double tol, int has_nullml, double nullml, double *out);
 
-/* `fvlmm_assoc_chunk_f32` / `fvlmm_assoc_chunk_from_snp_f32` (src/stats/fvlmm.rs:1941-1994, 2114-2262). */
+/* `ml_loglike_null_f32` (src/stats/reml.rs:618-646) -> *ml. */
+int jx_ml_loglike_null(const double *s, const double *xcov, const double *y_rot, int n, int p, double log10_lbd,
+                       double *ml);
+
+/* `fvlmm_assoc_chunk_f32` / `fvlmm_assoc_chunk_from_snp_f32` (src/stats/fvlmm.rs:1941-1994, 2114-2262).
+ * has_nullml -> 4 output columns. */
 int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p,
                          double log10_lbd, const float *snp_chunk, int64_t m_chunk, const float *u_t,
-                         double *out);
+                         int has_nullml, double nullml, double *out);
 
 /* `lmm_reml_assoc_packed_f32` (src/stats/lmm.rs:3040-3362) and its fixed-lambda sibling
  * (`fvlmm_assoc_packed` core of src/stats/fvlmm.rs:4958-5190 with a caller-rotated null model).
  * model: 0 = exact per-SNP REML (lmm), 1 = fixed lambda (fvlmm; `low` carries log10 lambda).
- * warm: 0 none (parity contract), 1 seed with init_log10_lbd.  out (m, 3). */
+ * warm: 0 none (parity contract), 1 seed with init_log10_lbd.  out (m, 3), or (m, 4) with has_nullml (plrt column,
+ * src/stats/lmm.rs:202-330). */
 int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
                     const float *row_maf, const double *s, const double *xcov, const double *y_rot,
                     const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
-                    double high, int max_iter, double tol, int warm, double init_log10_lbd, double *out);
+                    double high, int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml,
+                    double nullml, double *out);
 
 /* `gblup_reml_npy_grm` (src/stats/gblup.rs:1242-1516) on an in-memory GRM: fit on K[train,train] + g_eps I, predict
  * K[*,train] alpha + beta0.  out_scalars = (pve, lambda, ml, reml, sigma_g2, sigma_e2, beta0). */

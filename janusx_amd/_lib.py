@@ -49,10 +49,12 @@ SIGNATURES = {
     "jxg_lmm_scan_tab": [c_p, c_i, c_i, c_p, c_p, c_i, c_d, c_d, c_p, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_lmm_scan_exact": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
-    "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
+    "jxg_lmm_loglike_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p],
+    "jx_ml_loglike_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_p],
     "jxg_gblup_fit": [c_p, c_i, c_d, c_p, c_d, c_d, c_d, c_i, c_p, c_p, c_p],
     "jxg_cross_dot": [c_p, c_i, c_l, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p],
-    "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
+    "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
     "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],
     "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
@@ -61,10 +63,10 @@ SIGNATURES = {
     "jx_lmm_rotate_x_y_with_ut_f64": [c_p, c_i, c_p, c_i, c_p, c_p, c_p],
     "jx_lmm_reml_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_p],
     "jx_lmm_reml_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_i, c_d, c_i, c_d, c_p],
-    "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_p],
+    "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_i, c_d, c_p],
     "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
-                        c_d, c_p],
+                        c_d, c_i, c_d, c_p],
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64}
 

@@ -383,6 +383,21 @@ extern "C" int jx_lmm_reml_null(const double *s, const double *xcov, const doubl
     return 0;
 }
 
+extern "C" int jx_ml_loglike_null(const double *s, const double *xcov, const double *y_rot, int n, int p,
+                                  double log10_lbd, double *ml) {
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    DevBuf o;
+    if (o.alloc(2 * sizeof(double))) return 1;
+    if (jxg_lmm_loglike_null(nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), n, p, log10_lbd, o.as<double>(),
+                             nullptr))
+        return 1;
+    double h[2];
+    JX_HIP(hipMemcpy(h, o.p, sizeof(h), hipMemcpyDeviceToHost));
+    *ml = h[0];
+    return 0;
+}
+
 static const int64_t kBlockRows = 4096;  // rotate/scan block (rows x n f32 kept in HBM)
 
 extern "C" int jx_lmm_reml_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
@@ -435,8 +450,9 @@ struct FvDev {
 
 extern "C" int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p,
                                     double log10_lbd, const float *snp_chunk, int64_t m_chunk, const float *u_t,
-                                    double *out) {
+                                    int has_nullml, double nullml, double *out) {
     if (m_chunk <= 0) return 0;
+    const int cols = has_nullml ? 4 : 3;
     NullDev nd;
     if (nd.upload(s, xcov, y_rot, n, p)) return 1;
     FvDev fv;
@@ -448,7 +464,7 @@ extern "C" int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const d
         if (drot.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
     }
     if (dg.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
-    if (dout.alloc(sizeof(double) * (size_t)kBlockRows * 3)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)kBlockRows * cols)) return 1;
     for (int64_t r0 = 0; r0 < m_chunk; r0 += kBlockRows) {
         const int rows = (int)std::min<int64_t>(kBlockRows, m_chunk - r0);
         JX_HIP(hipMemcpy(dg.p, snp_chunk + (size_t)r0 * n, sizeof(float) * (size_t)rows * n, hipMemcpyHostToDevice));
@@ -458,9 +474,9 @@ extern "C" int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const d
             grot = drot.as<float>();
         }
         if (jxg_fvlmm_scan(grot, rows, n, p, fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(), fv.a_chol.data(),
-                           fv.sc[0], (int)fv.sc[2], dout.as<double>(), nullptr))
+                           fv.sc[0], (int)fv.sc[2], has_nullml, nullml, fv.sc[1], dout.as<double>(), nullptr))
             return 1;
-        JX_HIP(hipMemcpy(out + (size_t)r0 * 3, dout.p, sizeof(double) * (size_t)rows * 3, hipMemcpyDeviceToHost));
+        JX_HIP(hipMemcpy(out + (size_t)r0 * cols, dout.p, sizeof(double) * (size_t)rows * cols, hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -472,7 +488,8 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                                const float *row_maf, const double *s, const double *xcov, const double *y_rot,
                                const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
                                double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
-                               double *out) {
+                               int has_nullml, double nullml, double *out) {
+    const int cols = has_nullml ? 4 : 3;
     if (n_samples <= 0) return fail("n_samples must be > 0");
     if (model == 0 && low >= high) return fail("low must be < high");
     if (model == 0 && !(isfinite(tol) && tol > 0.0)) return fail("tol must be positive and finite");
@@ -508,7 +525,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
     const int64_t brows = 8192;
     if (drot.alloc(sizeof(float) * (size_t)brows * n)) return 1;
-    if (dout.alloc(sizeof(double) * (size_t)brows * 3)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)brows * cols)) return 1;
     DevBuf drows;
     if (drows.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
     std::vector<int32_t> hrows((size_t)brows);
@@ -521,14 +538,16 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
             return 1;
         if (model == 0) {
             if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
-                             high, tol, max_iter, warm, init_log10_lbd, 0, 0.0, dout.as<double>(), nullptr, nullptr))
+                             high, tol, max_iter, warm, init_log10_lbd, has_nullml, nullml, dout.as<double>(), nullptr,
+                             nullptr))
                 return 1;
         } else {
             if (jxg_fvlmm_scan(drot.as<float>(), rows, n, p, fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(),
-                               fv.a_chol.data(), fv.sc[0], (int)fv.sc[2], dout.as<double>(), nullptr))
+                               fv.a_chol.data(), fv.sc[0], (int)fv.sc[2], has_nullml, nullml, fv.sc[1],
+                               dout.as<double>(), nullptr))
                 return 1;
         }
-        JX_HIP(hipMemcpy(out + (size_t)r0 * 3, dout.p, sizeof(double) * (size_t)rows * 3, hipMemcpyDeviceToHost));
+        JX_HIP(hipMemcpy(out + (size_t)r0 * cols, dout.p, sizeof(double) * (size_t)rows * cols, hipMemcpyDeviceToHost));
     }
     return 0;
 }

@@ -360,6 +360,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_null_kernel(const double *__
     }
 }
 
+// ml_loglike / reml_loglike of the null model at a given log10 lambda (reml.rs:255-470) -> out2 = (ml, reml).
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm_loglike_kernel(const double *__restrict__ s,
+                                                                   const double *__restrict__ xcov,
+                                                                   const double *__restrict__ y, int n, int p_cov,
+                                                                   double log10_lbd, double *__restrict__ out2) {
+    constexpr int NV = MAXD * (MAXD + 1) / 2 + MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    const double lbd = pow(10.0, log10_lbd);
+    double ml = -1e8;
+    if (isfinite(lbd) && lbd > 0.0 && n > p_cov) {
+        EvalOut<MAXD> e;
+        eval_normal_eq<MAXD, false>(lbd, s, xcov, y, nullptr, n, p_cov, shm, e, false);
+        if (e.ok && isfinite(e.q) && e.q > 0.0) {
+            const double nf = (double)n;
+            const double v = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * log(e.q) + e.logdetv);
+            ml = isfinite(v) ? v : -1e8;
+        }
+    }
+    const double nr = neg_reml<MAXD, false>(log10_lbd, s, xcov, y, nullptr, n, p_cov, shm);
+    if (threadIdx.x == 0) {
+        out2[0] = ml;
+        out2[1] = -nr;
+    }
+}
+
 // X~ = U^T [X | y]: one workgroup per output row (reml.rs:157-170: f32 U^T widened, f64 accumulation).
 __global__ __launch_bounds__(SCAN_THREADS) void rotate_xy_kernel(const float *__restrict__ ut, int n,
                                                                  const double *__restrict__ xy, int q,
@@ -485,10 +511,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
                                                                   const float *__restrict__ py,
                                                                   const float *__restrict__ wx,
                                                                   const double *__restrict__ a_chol, double ypy,
-                                                                  int df, double *__restrict__ out) {
+                                                                  int df, int with_plrt, double nullml,
+                                                                  double log_det_v, double *__restrict__ out) {
     // One WAVE per rotated SNP row (4 rows in flight per workgroup, no LDS, no barriers): the row is streamed once
     // with 16-byte loads (4 samples per lane per step), the p + 2 sums are wave butterflies.
     constexpr int NV = MAXD + 2;
+    const int out_cols = with_plrt ? 4 : 3;
+    const double n_f = (double)n;
+    const double c_ml = n_f * (log(n_f) - 1.0 - log(2.0 * M_PI)) / 2.0;
     double l[MAXD * MAXD];
 #pragma unroll
     for (int r = 0; r < MAXD; ++r)
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
         for (int k = 0; k < NV; ++k)
             if (k < 2 + p) v[k] = wave_allsum(v[k]);
         if (lane == 0) {
-            double *o = out + (int64_t)r * 3;
+            double *o = out + (int64_t)r * out_cols;
             double c[MAXD], aic[MAXD];
             // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
 #pragma unroll
@@ -548,6 +578,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
                 o[0] = nan("");
                 o[1] = nan("");
                 o[2] = nan("");
+                if (with_plrt) o[3] = 1.0;
             } else {
                 const double nu = (double)(float)v[1];
                 const double beta = nu / schur;
@@ -563,6 +594,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
                 o[0] = beta;
                 o[1] = se;
                 o[2] = pv;
+                if (with_plrt) {  // fvlmm.rs:1785-1802
+                    double stat = 0.0;
+                    if (rwr > 0.0 && isfinite(rwr)) {
+                        const double ml = c_ml - 0.5 * (n_f * jx_log(rwr) + log_det_v);
+                        if (isfinite(ml)) stat = 2.0 * (ml - nullml);
+                    }
+                    if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                    o[3] = chi2_sf_df1_dev(stat);
+                }
             }
         }
     }
@@ -602,6 +642,15 @@ extern "C" int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const 
     if (!(low < high)) return fail("low must be < high");
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(lmm_null_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
                                           d_s, d_xcov, d_y, n, p, low, high, tol, max_iter, d_out3));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
+                                    double log10_lbd, double *d_out2, void *stream) {
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_loglike_null: p out of range");
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(lmm_loglike_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
+                                          d_s, d_xcov, d_y, n, p, log10_lbd, d_out2));
     JX_LAUNCH_CHECK();
     return 0;
 }
@@ -648,22 +697,22 @@ extern "C" int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const 
 }
 
 extern "C" int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
-                                  const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out,
-                                  void *stream) {
+                                  const float *d_wx, const double *d_a_chol, double ypy, int df, int with_plrt,
+                                  double nullml, double log_det_v, double *d_out, void *stream) {
     if (nrows <= 0) return 0;
     if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_scan: p out of range");
     int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                           (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df,
-                                          d_out));
+                                          with_plrt, nullml, log_det_v, d_out));
     JX_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
-                              const float *d_wx, const double *h_a_chol, double ypy, int df, double *d_out,
-                              void *stream) {
+                              const float *d_wx, const double *h_a_chol, double ypy, int df, int with_plrt,
+                              double nullml, double log_det_v, double *d_out, void *stream) {
     if (nrows <= 0) return 0;
     if (p < 1 || p > JXG_MAX_COV) return fail("jxg_fvlmm_scan: p out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -673,7 +722,8 @@ extern "C" int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, cons
     int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0, st, d_grot,
-                                          nrows, n, p, d_w, d_py, d_wx, a.as<double>(), ypy, df, d_out));
+                                          nrows, n, p, d_w, d_py, d_wx, a.as<double>(), ypy, df, with_plrt, nullml,
+                                          log_det_v, d_out));
     JX_LAUNCH_CHECK();
     JX_HIP(hipStreamSynchronize(st));
     return 0;

@@ -250,6 +250,27 @@ def lmm_reml_null_f32(s, xcov, y_rot, low, high, max_iter=50, tol=1e-2):
     return float(out[0]), float(out[1]), float(out[2])
 
 
+def ml_loglike_null_f32(s, xcov, y_rot, log10_lbd):
+    """src/stats/reml.rs:618-646 -> ML profile log-likelihood of the null model at log10 lambda (-1e8 on failure)."""
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    out = np.zeros(1, dtype=np.float64)
+    check(lib().jx_ml_loglike_null(_p(s), _p(xcov), _p(y), n, p, float(log10_lbd), _p(out)))
+    return float(out[0])
+
+
+def _loglike_null(s, xcov, y_rot, log10_lbd):
+    """(ml, reml) of the null model at log10 lambda, one device launch (jxg_lmm_loglike_null)."""
+    import torch
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ds, dx, dy = (torch.from_numpy(a).to(dev) for a in (s, xcov, y))
+    o = torch.empty(2, dtype=torch.float64, device=dev)
+    check(lib().jxg_lmm_loglike_null(ds.data_ptr(), dx.data_ptr(), dy.data_ptr(), n, p, float(log10_lbd),
+                                     o.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    h = o.cpu().numpy()
+    return float(h[0]), float(h[1])
+
+
 # ------------------------------------------------------------------------------------------------
 # exact per-SNP scan  (src/stats/lmm.rs)
 # ------------------------------------------------------------------------------------------------
@@ -286,7 +307,7 @@ def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_i
 
 
 def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
-                  low, high, max_iter, tol, warm, init):
+                  low, high, max_iter, tol, warm, init, nullml=None):
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
     packed = _c(packed, np.uint8)
     if row_indices is not None:
@@ -302,10 +323,11 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
     n_eff = n_sel if idx is not None else int(n_samples)
     if n_eff != n:
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
-    out = np.zeros((m, 3), dtype=np.float64)
+    out = np.zeros((m, 4 if nullml is not None else 3), dtype=np.float64)
     check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
                                 _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
-                                int(warm), float(init), _p(out)))
+                                int(warm), float(init), 1 if nullml is not None else 0,
+                                float(nullml if nullml is not None else 0.0), _p(out)))
     return out
 
 
@@ -313,7 +335,7 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
                               row_indices=None, low=-5.0, high=5.0, max_iter=50, tol=1e-2, threads=0, model="add",
                               progress_callback=None, progress_every=0, nullml=None, init_log10_lbd=None,
                               rotate_block_rows=256):
-    """src/stats/lmm.rs:3040-3362 -> f64 (m, 3).
+    """src/stats/lmm.rs:3040-3362 -> f64 (m, 3), or (m, 4) with `nullml` (plrt column, lmm.rs:202-330).
 
     Warm start: the reference chains each SNP's optimum into the next one *per rayon work split*
     (lmm.rs:134-140), which makes its output depend on thread scheduling.  This implementation is
@@ -321,8 +343,6 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     else from the interval midpoint (the reference's `JX_LMM_UNIFIED_NO_WARM_START` / core-API behaviour)."""
     if str(model) != "add":
         raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
-    if nullml is not None:
-        raise RuntimeError("nullml/plrt output is not built for the packed route yet")
     if low >= high:
         raise RuntimeError("low must be < high")
     if not (np.isfinite(tol) and tol > 0):
@@ -331,7 +351,7 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
         warm, init = 1, float(min(max(init_log10_lbd, low), high))
     out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
-                        low, high, max_iter, tol, warm, init)
+                        low, high, max_iter, tol, warm, init, nullml)
     _done(progress_callback, out.shape[0])
     return out
 
@@ -341,8 +361,6 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
 # ------------------------------------------------------------------------------------------------
 
 def _fv_chunk(s, xcov, y_rot, log10_lbd, chunk, u_t, nullml, what):
-    if nullml is not None:
-        raise RuntimeError("nullml/plrt output is not built for the fixed-lambda route yet")
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
     g = _c(chunk, np.float32)
     if g.ndim != 2 or g.shape[1] != n:
@@ -352,13 +370,15 @@ def _fv_chunk(s, xcov, y_rot, log10_lbd, chunk, u_t, nullml, what):
         if u_t.shape != (n, n):
             raise RuntimeError("u_t must be (n, n) and row-major U^T")
     m = int(g.shape[0])
-    out = np.zeros((m, 3), dtype=np.float64)
-    check(lib().jx_fvlmm_assoc_chunk(_p(s), _p(xcov), _p(y), n, p, float(log10_lbd), _p(g), m, _p(u_t), _p(out)))
+    out = np.zeros((m, 4 if nullml is not None else 3), dtype=np.float64)
+    check(lib().jx_fvlmm_assoc_chunk(_p(s), _p(xcov), _p(y), n, p, float(log10_lbd), _p(g), m, _p(u_t),
+                                     1 if nullml is not None else 0, float(nullml if nullml is not None else 0.0),
+                                     _p(out)))
     return out
 
 
 def fvlmm_assoc_chunk_f32(s, xcov, y_rot, log10_lbd, g_rot_chunk, threads=0, nullml=None):
-    """src/stats/fvlmm.rs:1941-1994 -> f64 (m, 3)."""
+    """src/stats/fvlmm.rs:1941-1994 -> f64 (m, 3 or 4)."""
     return _fv_chunk(s, xcov, y_rot, log10_lbd, g_rot_chunk, None, nullml, "g_rot_chunk")
 
 
@@ -370,11 +390,11 @@ def fvlmm_assoc_chunk_from_snp_f32(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, th
 
 def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, log10_lbd,
                            sample_indices=None, row_indices=None, threads=0, progress_callback=None,
-                           progress_every=0, rotate_block_rows=512):
+                           progress_every=0, rotate_block_rows=512, nullml=None):
     """Array-returning core of `fvlmm_assoc_packed_f32_to_tsv` (src/stats/fvlmm.rs:4958-5190) with a
-    caller-rotated null model -> f64 (m, 3)."""
+    caller-rotated null model -> f64 (m, 3 or 4)."""
     out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 1,
-                        float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0)
+                        float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0, nullml)
     _done(progress_callback, out.shape[0])
     return out
 
@@ -402,8 +422,8 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
     from .tsv import write_assoc_tsv
     if str(genetic_model) != "add":
         raise RuntimeError(f"unsupported genetic model '{genetic_model}' (only 'add' is built)")
-    if nullml is not None:
-        raise RuntimeError("nullml/plrt output is not built for the BED route yet")
+    if nullml is not None and not np.isfinite(nullml):
+        raise RuntimeError("nullml must be finite when provided")
     s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
     if n <= p + 1:
         raise RuntimeError("n must be > p+1")
@@ -443,10 +463,11 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
-        res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init)
+        res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init,
+                            nullml)
     else:
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 1, float(low), float(low) + 1.0, 0,
-                            1e-2, 0, 0.0)
+                            1e-2, 0, 0.0, nullml)
     chrom = [bim.chrom[j] for j in rows]
     posv = [bim.pos[j] for j in rows]
     snp = [bim.snp[j] for j in rows]
@@ -514,6 +535,118 @@ def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_m
                               np.asarray(row_missing, dtype=np.float32), out)
     _done(progress_callback, m)
     return written
+
+
+def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_missing, u, s, y, x, sample_indices,
+                                  low, high, max_iter, tol, tau, threads, model, chrom, pos, snp, allele0, allele1,
+                                  out_tsv, progress_callback=None, progress_every=0, fixed_lbd=None, fixed_ml0=None,
+                                  row_indices=None, rotate_block_rows=0, bed_prefix=None):
+    """src/stats/fvlmm.rs:4958-5190 -> (lbd, ml0, reml0); writes the TSV.
+
+    `u` (n_samples, k) f32 holds eigenvectors as columns, `s` (k) f32 their eigenvalues (caller order, the packed
+    workflow passes them descending); the function adds the intercept to `x`, rotates X and y itself with the
+    sample-subset of U^T (f32 widened, f64 accumulation), fits lambda by Brent on REML unless `fixed_lbd` is given,
+    and scans every row at that lambda.  `fixed_ml0` switches the plrt column on."""
+    import math
+    from .tsv import write_assoc_tsv
+    if fixed_lbd is None and low >= high:
+        raise RuntimeError("low must be < high")
+    if not (np.isfinite(tol) and tol > 0):
+        raise RuntimeError("tol must be positive and finite")
+    if not (np.isfinite(tau) and tau >= 0):
+        raise RuntimeError("tau must be finite and >= 0")
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if str(model) != "add":
+        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    if packed.shape[1] != (int(n_samples) + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {packed.shape[1]}, expected {(int(n_samples) + 3) // 4}")
+    m = int(packed.shape[0]) if row_indices is None else int(len(row_indices))
+    for name, arr in (("row_flip", row_flip), ("row_maf", row_maf), ("row_missing", row_missing)):
+        if len(arr) != m:
+            raise RuntimeError(f"{name} length mismatch: got {len(arr)}, expected {m}")
+    yv = _c(y, np.float64).ravel()
+    n = int(yv.shape[0])
+    if n == 0:
+        raise RuntimeError("y must not be empty")
+    if sample_indices is not None:
+        sidx = np.asarray(sample_indices, dtype=np.int64).ravel()
+        if sidx.shape[0] != n:
+            raise RuntimeError(f"sample_indices length mismatch: got {sidx.shape[0]}, expected {n}")
+        if sidx.size and (sidx.min() < 0 or sidx.max() >= int(n_samples)):
+            raise RuntimeError("sample_indices out of range")
+    else:
+        if n != int(n_samples):
+            raise RuntimeError(f"len(y)={n} must equal n_samples={int(n_samples)} when sample_indices is not provided")
+        sidx = np.arange(n, dtype=np.int64)
+    u = _c(u, np.float32)
+    if u.ndim != 2:
+        raise RuntimeError("u must be 2D (n_samples, k)")
+    if u.shape[0] != int(n_samples):
+        raise RuntimeError(f"u row count mismatch: got {u.shape[0]}, expected {int(n_samples)}")
+    k_full = int(u.shape[1])
+    s32 = _c(s, np.float32).ravel()
+    if s32.shape[0] != k_full:
+        raise RuntimeError(f"s length mismatch: got {s32.shape[0]}, expected {k_full}")
+    if k_full < n:
+        raise RuntimeError("u must provide full-rank eigenvectors for packed fixed-lambda scan: "
+                           f"got k={k_full}, expected >= n={n}")
+    s_vec = s32[:n].astype(np.float64) + (float(tau) if tau != 0.0 else 0.0)
+    if not np.all(np.isfinite(s_vec)):
+        raise RuntimeError("invalid s/tau produced non-finite values")
+    if x is not None:
+        xa = _c(x, np.float64)
+        if xa.ndim != 2:
+            raise RuntimeError("x must be 2D (n, p0)")
+        if xa.shape[0] != n:
+            raise RuntimeError(f"x row count mismatch: got {xa.shape[0]}, expected {n}")
+        x_full = np.concatenate([np.ones((n, 1)), xa], axis=1)
+    else:
+        x_full = np.ones((n, 1), dtype=np.float64)
+    p = int(x_full.shape[1])
+    if n <= p:
+        raise RuntimeError(f"n must be > p for null model: n={n}, p={p}")
+    if n <= p + 1:
+        raise RuntimeError(f"n must be > p+1 for SNP tests: n={n}, p={p}")
+    # u_t_sub[c, j] = u[sample_idx[j], c], c < n (fvlmm.rs:1458-1482)
+    u_t = np.ascontiguousarray(u[sidx, :n].T)
+    x_rot, y_rot = lmm_rotate_x_y_with_ut_f64(u_t, x_full, yv)
+    y_rot = y_rot.ravel()
+    with_plrt = fixed_ml0 is not None
+    if with_plrt and not np.isfinite(fixed_ml0):
+        raise RuntimeError("fixed_ml0 must be finite when provided")
+    if fixed_lbd is not None:
+        if not (np.isfinite(fixed_lbd) and fixed_lbd > 0):
+            raise RuntimeError("fixed_lbd must be finite and > 0 when provided")
+        lbd = float(fixed_lbd)
+        ml0 = float(fixed_ml0) if with_plrt else math.nan
+        reml0 = _loglike_null(s_vec, x_rot, y_rot, math.log10(lbd))[1] if with_plrt else math.nan
+    else:
+        lbd, _, reml0 = lmm_reml_null_f32(s_vec, x_rot, y_rot, low, high, max_iter, tol)
+        ml0 = float(fixed_ml0) if with_plrt else math.nan
+    if not (np.isfinite(lbd) and lbd > 0):
+        raise RuntimeError("invalid fixed lambda in packed fvlmm")
+    out = _assoc_packed(packed, n_samples, row_flip, row_maf, s_vec, x_rot, y_rot, u_t,
+                        None if sample_indices is None else sidx, row_indices, 1, math.log10(lbd),
+                        math.log10(lbd) + 1.0, 0, 1e-2, 0, 0.0, float(fixed_ml0) if with_plrt else None)
+    if not len(chrom):
+        if not bed_prefix:
+            raise RuntimeError("metadata lists are empty and bed_prefix is not set")
+        from .bed import read_bim
+        bim = read_bim(bed_prefix)
+        sel = np.arange(m) if row_indices is None else np.asarray(row_indices, dtype=np.int64)
+        chrom = [bim.chrom[j] for j in sel]
+        pos = [bim.pos[j] for j in sel]
+        snp = [bim.snp[j] for j in sel]
+        allele0 = [bim.a0[j] for j in sel]
+        allele1 = [bim.a1[j] for j in sel]
+    write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
+                    np.asarray(row_missing, dtype=np.float32), out)
+    _done(progress_callback, m)
+    return float(lbd), float(ml0), float(reml0)
 
 
 # ------------------------------------------------------------------------------------------------

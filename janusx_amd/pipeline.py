@@ -218,15 +218,18 @@ class SpectralModel:
 
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
-              times: StageTimes = None):
+              times: StageTimes = None, nullml=None):
     """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML) or 'fvlmm' (fixed lambda).
-    Returns a (len(rows), 3) f64 device tensor [beta, se, p] (and the per-SNP Brent evaluation counts)."""
+    Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns [.., plrt] when `nullml` is given --
+    (and the per-SNP Brent evaluation counts)."""
     dev = panel.device
     n = model.n
     if panel.n != n:
         raise RuntimeError(f"selected sample count {panel.n} != model n {n}")
     mk = len(rows)
-    out = torch.empty((mk, 3), dtype=torch.float64, device=dev)
+    with_plrt = 1 if nullml is not None else 0
+    nullml_v = float(nullml) if nullml is not None else 0.0
+    out = torch.empty((mk, 4 if with_plrt else 3), dtype=torch.float64, device=dev)
     evals = torch.zeros(mk, dtype=torch.int32, device=dev) if return_evals else None
     if mk == 0:
         return (out, evals) if return_evals else out
@@ -248,7 +251,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             check(lib().jxg_lmm_tables_build(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b,
                                              _ptr(tables), _stream()))
     else:
-        lbd, w, py, wx, a_chol, ypy, _, df = model.fv_cache(init_log10_lbd)
+        lbd, w, py, wx, a_chol, ypy, log_det_v, df = model.fv_cache(init_log10_lbd)
         a_dev = torch.from_numpy(a_chol).to(dev)
     br = int(min(block_rows, mk))
     nbuf = 2 if mk > br else 1
@@ -270,15 +273,15 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             ev_p = evals[r0:].data_ptr() if evals is not None else None
             if tables is not None:
                 check(lib().jxg_lmm_scan_tab(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), model.p, lo_b, hi_b,
-                                             _ptr(tables), float(tol), int(max_iter), warm, init, 0, 0.0,
+                                             _ptr(tables), float(tol), int(max_iter), warm, init, with_plrt, nullml_v,
                                              o.data_ptr(), ev_p, _stream()))
             else:
                 check(lib().jxg_lmm_scan_exact(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y),
-                                               model.p, lo_b, hi_b, float(tol), int(max_iter), warm, init, 0, 0.0,
-                                               o.data_ptr(), ev_p, _stream()))
+                                               model.p, lo_b, hi_b, float(tol), int(max_iter), warm, init, with_plrt,
+                                               nullml_v, o.data_ptr(), ev_p, _stream()))
         else:
             check(lib().jxg_fvlmm_scan_dev(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev),
-                                           ypy, df, o.data_ptr(), _stream()))
+                                           ypy, df, with_plrt, nullml_v, log_det_v, o.data_ptr(), _stream()))
         if times is not None:
             ev_scan[bi][1].record()
     if times is not None:

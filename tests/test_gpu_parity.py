@@ -537,3 +537,113 @@ def test_gblup_reml_grm(oracle, tmp_path):
     assert np.corrcoef(pte_ref, y[te])[0, 1] > 0.1
     with pytest.raises(RuntimeError, match="low/high"):
         jxrs.gblup_reml_grm(k, tr, y[tr], te, low=2.0, high=1.0)
+
+
+def test_plrt_columns_and_ml_loglike(oracle, oracle_c, null_case):
+    """`nullml` -> 4th column (ML likelihood-ratio p) on the packed lmm / fixed-lambda routes
+    (src/stats/lmm.rs:202-330, src/stats/fvlmm.rs:1785-1802) and `ml_loglike_null_f32` (reml.rs:618-646)."""
+    from janusx_amd import janusx as jxrs
+    n, m, packed, g, y, x, nm = null_case
+    for l10 in (-2.0, math.log10(nm.lbd_null), 1.5):
+        ml = jxrs.ml_loglike_null_f32(nm.S, nm.Xcov, nm.y, l10)
+        ref = oracle.ml_loglike(l10, nm.S, nm.Xcov, nm.y)
+        assert abs(ml - ref) < 1e-9 * abs(ref)
+        ml2, reml2 = jxrs._loglike_null(nm.S, nm.Xcov, nm.y, l10)
+        assert ml2 == ml and abs(reml2 - oracle.reml_loglike(l10, nm.S, nm.Xcov, nm.y)) < 1e-9 * abs(reml2)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    pk = np.ascontiguousarray(packed[keep])
+    maf_k = maf[keep]
+    flip_k = np.zeros(int(keep.sum()), dtype=bool)
+    grot = oracle.rotate_block_f32(oracle.decode_centered_block_f32(pk, n, flip_k, maf_k), nm.Dh)
+    ref4 = oracle_c.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, -5.0, 5.0, 50, 1e-2, nullml=nm.ML0)
+    out4 = jxrs.lmm_reml_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, nullml=nm.ML0)
+    assert out4.shape == ref4.shape == (pk.shape[0], 4)
+    be, se, pe = _assoc_err(out4, ref4)
+    assert max(be, se) < TOL, (be, se, pe)
+    ok = ~np.isnan(ref4[:, 0])
+    # plrt = chi2_sf(2 (ml - ml0)): compare on the -log10 scale and relatively where p is not tiny
+    d = np.abs(np.log10(out4[ok, 3]) - np.log10(ref4[ok, 3]))
+    assert float(d.max()) < 1e-4, float(d.max())
+    cache = oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null)
+    fref = oracle.fvlmm_assoc_rotated_block(grot, cache, nullml=nm.ML0)
+    l10 = math.log10(nm.lbd_null)
+    fout = jxrs.fvlmm_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, l10, nullml=nm.ML0)
+    assert fout.shape == fref.shape
+    be, se, pe = _assoc_err(fout, fref)
+    assert max(be, se) < TOL, (be, se, pe)
+    d = np.abs(np.log10(fout[ok, 3]) - np.log10(fref[ok, 3]))
+    assert float(d.max()) < 1e-4, float(d.max())
+    fout_c = jxrs.fvlmm_assoc_chunk_f32(nm.S, nm.Xcov, nm.y, l10, grot, nullml=nm.ML0)
+    assert fout_c.shape[1] == 4
+    assert float(np.max(np.abs(np.log10(fout_c[ok, 3]) - np.log10(fref[ok, 3])))) < 1e-4  # num/c are f32-rounded
+
+
+def test_fvlmm_assoc_packed_to_tsv(oracle, oracle_c, null_case, tmp_path):
+    """`fvlmm_assoc_packed_f32_to_tsv` (src/stats/fvlmm.rs:4958-5190): U as (n_samples, k) f32 columns with
+    descending eigenvalues, intercept added by the callee, sample subset, Brent-fitted or fixed lambda."""
+    from janusx_amd import janusx as jxrs
+    n_all, m, packed, g, y_all, x_all, _ = null_case
+    rng = np.random.default_rng(31)
+    sidx = np.sort(rng.permutation(n_all)[:280]).astype(np.int64)
+    n = len(sidx)
+    # a GRM and its eigenpairs on the subset, embedded in (n_all, k) with rows of unused samples left zero
+    gsub = g[:, sidx].astype(np.float64)
+    gsub[gsub < 0] = np.nan
+    sd = np.nanstd(gsub, axis=1)
+    z = np.nan_to_num(gsub - np.nanmean(gsub, axis=1, keepdims=True))[sd > 0]
+    k_sub = (z.T @ z) / z.shape[0]
+    s_asc, u_cols = oracle.eigh_sym(k_sub + 1e-6 * np.eye(n))
+    order = np.argsort(-s_asc)
+    s_desc = s_asc[order].astype(np.float32)
+    u = np.zeros((n_all, n), dtype=np.float32)
+    u[sidx] = u_cols[:, order].astype(np.float32)
+    y = y_all[sidx]
+    x0 = x_all[sidx, 1:]
+    mi, he, ho = oracle.row_counts(packed, n_all, sidx)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    maf_k, miss_k, flip_k = maf[rows], miss[rows], np.zeros(len(rows), dtype=bool)
+    chrom = [str(1 + j % 3) for j in rows]
+    pos = [int(10 + j) for j in rows]
+    snp = [f"rs{j}" for j in rows]
+    a0, a1 = ["A"] * len(rows), ["C"] * len(rows)
+    # oracle composite
+    u_t = np.ascontiguousarray(u[sidx, :n].T)
+    x_full = np.concatenate([np.ones((n, 1)), x0], axis=1)
+    xr, yr = oracle.lmm_rotate_x_y_with_ut(u_t, x_full, y)
+    s64 = s_desc.astype(np.float64)
+    lbd_ref, _, reml_ref = oracle_c.lmm_reml_null(s64, xr, yr.ravel(), -5.0, 5.0, 50, 1e-3)
+    gd = oracle.decode_centered_block_f32(packed, n_all, np.zeros(m, dtype=bool), maf, sample_idx=sidx, rows=rows)
+    grot = oracle.rotate_block_f32(gd, u_t)
+    out = str(tmp_path / "fv.tsv")
+    lbd, ml0, reml0 = jxrs.fvlmm_assoc_packed_f32_to_tsv(
+        packed, n_all, flip_k, maf_k, miss_k, u, s_desc, y, x0, sidx, -5.0, 5.0, 50, 1e-3, 0.0, 0, "add",
+        chrom, pos, snp, a0, a1, out, row_indices=rows)
+    assert abs(lbd - lbd_ref) < 1e-8 * lbd_ref and abs(reml0 - reml_ref) < 1e-8 * abs(reml_ref) and math.isnan(ml0)
+    fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(s64, xr, yr.ravel(), lbd_ref))
+    lines = open(out).read().splitlines()
+    assert lines[0].split("\t")[-1] == "pwald" and len(lines) == len(rows) + 1
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert f[0] == chrom[i] and int(f[1]) == pos[i] and f[2] == snp[i]
+        assert f[5] == f"{float(maf_k[i]):.4f}" and f[6] == f"{float(miss_k[i]):.4f}"
+        assert abs(float(f[7]) - fref[i, 0]) <= 1.01e-4 and abs(float(f[8]) - fref[i, 1]) <= 1.01e-4
+        assert abs(float(f[10]) - fref[i, 2]) <= 2e-4 * fref[i, 2] + 1e-300
+    # fixed lambda + fixed_ml0 -> plrt column, reml0 evaluated at that lambda
+    ml_fix = oracle.ml_loglike(math.log10(lbd_ref), s64, xr, yr.ravel())
+    out2 = str(tmp_path / "fv4.tsv")
+    lbd2, ml2, reml2 = jxrs.fvlmm_assoc_packed_f32_to_tsv(
+        packed, n_all, flip_k, maf_k, miss_k, u, s_desc, y, x0, sidx, -5.0, 5.0, 50, 1e-3, 0.0, 0, "add",
+        chrom, pos, snp, a0, a1, out2, fixed_lbd=lbd_ref, fixed_ml0=ml_fix, row_indices=rows)
+    assert lbd2 == lbd_ref and ml2 == ml_fix
+    assert abs(reml2 - oracle.reml_loglike(math.log10(lbd_ref), s64, xr, yr.ravel())) < 1e-9 * abs(reml2)
+    fref4 = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(s64, xr, yr.ravel(), lbd_ref), nullml=ml_fix)
+    lines = open(out2).read().splitlines()
+    assert lines[0].split("\t")[-1] == "plrt"
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert abs(float(f[11]) - fref4[i, 3]) <= 2e-4 * fref4[i, 3] + 1e-300
+    with pytest.raises(RuntimeError):
+        jxrs.fvlmm_assoc_packed_f32_to_tsv(packed, n_all, flip_k, maf_k, miss_k, u[:, :10], s_desc[:10], y, x0, sidx,
+                                           -5.0, 5.0, 50, 1e-3, 0.0, 0, "add", chrom, pos, snp, a0, a1, out)

@@ -159,6 +159,20 @@ int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, const float *d_
                    const float *d_wx, const double *h_a_chol, double ypy, int df, int with_plrt, double nullml,
                    double log_det_v, double *d_out, void *stream);
 
+/* LMM2 scan of a rotated block ("next" row 8f-2): per SNP a REML Brent, `final_beta_se`, then a second Brent on
+ * -ml_loglike seeded with the REML optimum and the LRT against nullml.  d_out6 (nrows, 6) f64 =
+ * [beta, se, pwald, lambda_reml, ml_alt, plrt]; invalid rows (NaN, NaN, 1, NaN, NaN, 1).  warm as jxg_lmm_scan.
+ * `run_rotated_lmm2_assoc_block_f32`, src/stats/lmm.rs:202-330. */
+int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                  const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                  double init_log10_lbd, double nullml, double *d_out6, void *stream);
+
+/* Null ML for the LMM2 scan: Brent on -ml_loglike without a SNP column -> d_out2 = (log10 lambda, ml0).
+ * src/stats/lmm.rs:2902-2921. */
+int jxg_lmm2_null_ml(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double low,
+                     double high, int max_iter, double tol, int has_init, double init, double *d_out2,
+                     void *stream);
+
 /* C2. `ml_loglike` and `reml_loglike` of the null model at log10 lambda -> d_out2 = (ml, reml); -1e8 on failure.
  * src/stats/reml.rs:255-470. */
 int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
@@ -230,6 +244,17 @@ int jx_lmm_reml_chunk(const double *s, const double *xcov, const double *y_rot, 
 int jx_ml_loglike_null(const double *s, const double *xcov, const double *y_rot, int n, int p, double log10_lbd,
                        double *ml);
 
+/* `lmm_reml_lmm2_chunk_from_snp_f32` (src/stats/lmm.rs:1632-1760; u_t == NULL -> snp_chunk is already rotated)
+ * -> out (m_chunk, 6) = [beta, se, pwald, lambda_reml, ml_alt, plrt]. */
+int jx_lmm2_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p, double low, double high,
+                  const float *snp_chunk, int64_t m_chunk, const float *u_t, double nullml, int max_iter,
+                  double tol, double *out);
+
+/* Null ML of `lmm_reml_lmm2_assoc_bed_to_tsv_f32` when the caller passes no nullml (src/stats/lmm.rs:2902-2921)
+ * -> out2 = (log10 lambda, ml0). */
+int jx_lmm2_null_ml(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                    double high, int max_iter, double tol, int has_init, double init, double *out2);
+
 /* `fvlmm_assoc_chunk_f32` / `fvlmm_assoc_chunk_from_snp_f32` (src/stats/fvlmm.rs:1941-1994, 2114-2262).
  * has_nullml -> 4 output columns. */
 int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p,
@@ -238,7 +263,8 @@ int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const double *y_ro
 
 /* `lmm_reml_assoc_packed_f32` (src/stats/lmm.rs:3040-3362) and its fixed-lambda sibling
  * (`fvlmm_assoc_packed` core of src/stats/fvlmm.rs:4958-5190 with a caller-rotated null model).
- * model: 0 = exact per-SNP REML (lmm), 1 = fixed lambda (fvlmm; `low` carries log10 lambda).
+ * model: 0 = exact per-SNP REML (lmm), 1 = fixed lambda (fvlmm; `low` carries log10 lambda), 2 = LMM2
+ * (`lmm_reml_lmm2_assoc_bed_to_tsv_f32` core, src/stats/lmm.rs:2779-3037; needs nullml; out (m, 6)).
  * warm: 0 none (parity contract), 1 seed with init_log10_lbd.  out (m, 3), or (m, 4) with has_nullml (plrt column,
  * src/stats/lmm.rs:202-330). */
 int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,

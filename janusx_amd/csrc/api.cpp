@@ -432,6 +432,52 @@ extern "C" int jx_lmm_reml_chunk(const double *s, const double *xcov, const doub
     return 0;
 }
 
+extern "C" int jx_lmm2_chunk(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                             double high, const float *snp_chunk, int64_t m_chunk, const float *u_t, double nullml,
+                             int max_iter, double tol, double *out) {
+    if (low >= high) return fail("low must be < high");
+    if (!std::isfinite(nullml)) return fail("nullml must be finite");
+    if (m_chunk <= 0) return 0;
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    DevBuf dut, dg, drot, dout;
+    if (u_t) {
+        if (dut.alloc(sizeof(float) * (size_t)n * n)) return 1;
+        JX_HIP(hipMemcpy(dut.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+        if (drot.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    }
+    if (dg.alloc(sizeof(float) * (size_t)kBlockRows * n)) return 1;
+    if (dout.alloc(sizeof(double) * (size_t)kBlockRows * 6)) return 1;
+    for (int64_t r0 = 0; r0 < m_chunk; r0 += kBlockRows) {
+        const int rows = (int)std::min<int64_t>(kBlockRows, m_chunk - r0);
+        JX_HIP(hipMemcpy(dg.p, snp_chunk + (size_t)r0 * n, sizeof(float) * (size_t)rows * n, hipMemcpyHostToDevice));
+        const float *grot = dg.as<float>();
+        if (u_t) {
+            if (jxg_rotate_dense_f32(dg.as<float>(), rows, n, dut.as<float>(), drot.as<float>(), nullptr)) return 1;
+            grot = drot.as<float>();
+        }
+        if (jxg_lmm2_scan(grot, rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low, high, tol,
+                          max_iter, 0, 0.0, nullml, dout.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)r0 * 6, dout.p, sizeof(double) * (size_t)rows * 6, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int jx_lmm2_null_ml(const double *s, const double *xcov, const double *y_rot, int n, int p, double low,
+                               double high, int max_iter, double tol, int has_init, double init, double *out2) {
+    if (low >= high) return fail("low must be < high");
+    NullDev nd;
+    if (nd.upload(s, xcov, y_rot, n, p)) return 1;
+    DevBuf o;
+    if (o.alloc(2 * sizeof(double))) return 1;
+    if (jxg_lmm2_null_ml(nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), n, p, low, high, max_iter, tol,
+                         has_init, init, o.as<double>(), nullptr))
+        return 1;
+    JX_HIP(hipMemcpy(out2, o.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 namespace {
 struct FvDev {
     DevBuf w, py, wx;
@@ -489,10 +535,12 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                                const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
                                double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
                                int has_nullml, double nullml, double *out) {
-    const int cols = has_nullml ? 4 : 3;
+    const int cols = model == 2 ? 6 : (has_nullml ? 4 : 3);
+    if (model < 0 || model > 2) return fail("model must be 0 (lmm), 1 (fvlmm) or 2 (lmm2)");
+    if (model == 2 && !(has_nullml && std::isfinite(nullml))) return fail("nullml must be finite");
     if (n_samples <= 0) return fail("n_samples must be > 0");
-    if (model == 0 && low >= high) return fail("low must be < high");
-    if (model == 0 && !(isfinite(tol) && tol > 0.0)) return fail("tol must be positive and finite");
+    if (model != 1 && low >= high) return fail("low must be < high");
+    if (model != 1 && !(isfinite(tol) && tol > 0.0)) return fail("tol must be positive and finite");
     if (m <= 0) return 0;
     SampleSel sel;
     if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
@@ -540,6 +588,10 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
             if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
                              high, tol, max_iter, warm, init_log10_lbd, has_nullml, nullml, dout.as<double>(), nullptr,
                              nullptr))
+                return 1;
+        } else if (model == 2) {
+            if (jxg_lmm2_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
+                              high, tol, max_iter, warm, init_log10_lbd, nullml, dout.as<double>(), nullptr))
                 return 1;
         } else {
             if (jxg_fvlmm_scan(drot.as<float>(), rows, n, p, fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(),

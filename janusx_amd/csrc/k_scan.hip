@@ -149,8 +149,30 @@ __device__ double neg_reml(double x, const double *s, const double *xcov, const 
     return isfinite(reml) ? -reml : 1e8;
 }
 
-// src/math/brent.rs:1-136, verbatim control flow (including `e` not being updated on parabolic steps).
+// -ml_loglike (objective of the LMM2 second pass and its null fit; reml.rs:364-470). Failure -> +1e8.
 template <int MAXD, bool WAVE>
+__device__ double neg_ml(double x, const double *s, const double *xcov, const double *y, const float *g, int n,
+                         int p_cov, double *shm) {
+    const double lbd = pow(10.0, x);
+    const int dim = p_cov + (g ? 1 : 0);
+    if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return 1e8;
+    EvalOut<MAXD> o;
+    eval_normal_eq<MAXD, WAVE>(lbd, s, xcov, y, g, n, p_cov, shm, o, false);
+    if (!o.ok || !isfinite(o.q) || o.q <= 0.0) return 1e8;
+    const double nf = (double)n;
+    const double ml = nf * (log(nf) - 1.0 - log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * log(o.q) + o.logdetv);
+    return isfinite(ml) ? -ml : 1e8;
+}
+
+template <int MAXD, bool WAVE, bool ML>
+__device__ __forceinline__ double neg_obj(double x, const double *s, const double *xcov, const double *y,
+                                          const float *g, int n, int p_cov, double *shm) {
+    if (ML) return neg_ml<MAXD, WAVE>(x, s, xcov, y, g, n, p_cov, shm);
+    return neg_reml<MAXD, WAVE>(x, s, xcov, y, g, n, p_cov, shm);
+}
+
+// src/math/brent.rs:1-136, verbatim control flow (including `e` not being updated on parabolic steps).
+template <int MAXD, bool WAVE, bool ML = false>
 __device__ void brent_reml(const double *s, const double *xcov, const double *y, const float *g, int n, int p_cov,
                            double low, double high, double tol, int max_iter, bool has_init, double init,
                            double *shm, double &xbest, double &fbest, int &evals) {
@@ -164,7 +186,7 @@ __device__ void brent_reml(const double *s, const double *xcov, const double *y,
     tol = fmax(fabs(tol), 1e-12);
     double x = (has_init && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
     double w = x, v = x;
-    double fx = neg_reml<MAXD, WAVE>(x, s, xcov, y, g, n, p_cov, shm);
+    double fx = neg_obj<MAXD, WAVE, ML>(x, s, xcov, y, g, n, p_cov, shm);
     double fw = fx, fv = fx;
     double d = 0.0, e = 0.0;
     evals = 1;
@@ -201,7 +223,7 @@ __device__ void brent_reml(const double *s, const double *xcov, const double *y,
         }
         if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
         u = x + d;
-        const double fu = neg_reml<MAXD, WAVE>(u, s, xcov, y, g, n, p_cov, shm);
+        const double fu = neg_obj<MAXD, WAVE, ML>(u, s, xcov, y, g, n, p_cov, shm);
         ++evals;
         if (fu <= fx) {
             if (u >= x)
@@ -327,6 +349,98 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
                 if (with_plrt) o[3] = 1.0;
             }
         }
+    }
+}
+
+// LMM2 (src/stats/lmm.rs:202-330): REML Brent -> final_beta_se -> ML Brent seeded with the REML optimum -> LRT.
+// One wave per rotated row; out (nrows, 6) = [beta, se, pwald, lambda_reml, ml_alt, plrt].
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm2_scan_kernel(const float *__restrict__ grot, int nrows, int n,
+                                                                 const double *__restrict__ s,
+                                                                 const double *__restrict__ xcov,
+                                                                 const double *__restrict__ y, int p_cov, double low,
+                                                                 double high, double tol, int max_iter, int warm,
+                                                                 double init, double nullml,
+                                                                 double *__restrict__ out) {
+    constexpr bool WAVE = true;
+    double *shm = nullptr;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
+        const float *g = grot + (int64_t)r * n;
+        double *o = out + (int64_t)r * 6;
+        double ssq = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const double v = (double)g[i];
+            ssq += v * v;
+        }
+        ssq = wave_allsum(ssq);
+        double res[6] = {nan(""), nan(""), 1.0, nan(""), nan(""), 1.0};  // lmm.rs:84-91
+        if (isfinite(ssq) && ssq > 1e-12) {
+            double xr, fr;
+            int ne = 0;
+            brent_reml<MAXD, WAVE, false>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, warm != 0, init, shm, xr,
+                                          fr, ne);
+            const double lbd = pow(10.0, xr);
+            const int dim = p_cov + 1;
+            double beta = nan(""), se = nan("");
+            if (isfinite(lbd) && lbd > 0.0 && n > dim) {
+                EvalOut<MAXD> e;
+                eval_normal_eq<MAXD, WAVE>(lbd, s, xcov, y, g, n, p_cov, shm, e, true);
+                if (e.ok) {
+                    const double var = e.q / ((double)n - (double)dim) * e.ainv_kk;
+                    if (var > 0.0 && isfinite(var)) {
+                        beta = e.beta_k;
+                        se = sqrt(var);
+                    }
+                }
+            }
+            if (isfinite(beta) && isfinite(se) && se > 0.0) {  // wave-uniform: all lanes hold the same sums
+                double pv = 2.0 * (0.5 * erfc(fabs(beta / se) / 1.4142135623730951));
+                if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                if (pv > 1.0) pv = 1.0;
+                double xm, fm;
+                brent_reml<MAXD, WAVE, true>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, true, xr, shm, xm, fm,
+                                             ne);
+                double ml_alt = -fm;
+                if (!isfinite(ml_alt)) ml_alt = -neg_ml<MAXD, WAVE>(xm, s, xcov, y, g, n, p_cov, shm);
+                double stat = isfinite(ml_alt) ? 2.0 * (ml_alt - nullml) : 0.0;
+                if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                const double plrt = chi2_sf_df1_dev(stat);
+                res[0] = beta;
+                res[1] = se;
+                res[2] = isfinite(pv) ? pv : 1.0;
+                res[3] = lbd;
+                res[4] = ml_alt;
+                res[5] = isfinite(plrt) ? plrt : 1.0;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = res[k];
+        }
+    }
+}
+
+// Null ML of the LMM2 scan: Brent on -ML without a SNP column (lmm.rs:2902-2921) -> out2 = (log10 lambda, ml0).
+template <int MAXD>
+__global__ __launch_bounds__(SCAN_THREADS) void lmm2_null_ml_kernel(const double *__restrict__ s,
+                                                                    const double *__restrict__ xcov,
+                                                                    const double *__restrict__ y, int n, int p_cov,
+                                                                    double low, double high, double tol, int max_iter,
+                                                                    int has_init, double init,
+                                                                    double *__restrict__ out2) {
+    constexpr int NV = MAXD * (MAXD + 1) / 2 + MAXD + 2;
+    __shared__ double shm[SCAN_WAVES * NV];
+    double xb, fb;
+    int ne = 0;
+    brent_reml<MAXD, false, true>(s, xcov, y, nullptr, n, p_cov, low, high, tol, max_iter, has_init != 0, init, shm, xb,
+                                  fb, ne);
+    double ml0 = -fb;
+    if (!isfinite(ml0)) ml0 = -neg_ml<MAXD, false>(xb, s, xcov, y, nullptr, n, p_cov, shm);
+    if (threadIdx.x == 0) {
+        out2[0] = xb;
+        out2[1] = ml0;
     }
 }
 
@@ -642,6 +756,34 @@ extern "C" int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const 
     if (!(low < high)) return fail("low must be < high");
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(lmm_null_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, (hipStream_t)stream,
                                           d_s, d_xcov, d_y, n, p, low, high, tol, max_iter, d_out3));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                             const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                             double init_log10_lbd, double nullml, double *d_out6, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm2_scan: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    const int dim = p + 1;
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
+    JX_DISPATCH_DIM(dim, hipLaunchKernelGGL(lmm2_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                            (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high,
+                                            tol, max_iter, warm, init_log10_lbd, nullml, d_out6));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_lmm2_null_ml(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double low,
+                                double high, int max_iter, double tol, int has_init, double init, double *d_out2,
+                                void *stream) {
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm2_null_ml: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(lmm2_null_ml_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0,
+                                          (hipStream_t)stream, d_s, d_xcov, d_y, n, p, low, high, tol, max_iter,
+                                          has_init, init, d_out2));
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -323,7 +323,7 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
     n_eff = n_sel if idx is not None else int(n_samples)
     if n_eff != n:
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
-    out = np.zeros((m, 4 if nullml is not None else 3), dtype=np.float64)
+    out = np.zeros((m, 6 if int(model) == 2 else (4 if nullml is not None else 3)), dtype=np.float64)
     check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
                                 _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
                                 int(warm), float(init), 1 if nullml is not None else 0,
@@ -465,6 +465,12 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init,
                             nullml)
+    elif mode == "lmm2":
+        warm, init = 0, 0.0
+        if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
+            warm, init = 1, float(min(max(init_log10_lbd, low), high))
+        res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 2, low, high, max_iter, tol, warm, init,
+                            nullml)
     else:
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 1, float(low), float(low) + 1.0, 0,
                             1e-2, 0, 0.0, nullml)
@@ -492,6 +498,61 @@ def lmm_reml_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm", low, high,
                             max_iter, tol, nullml, init_log10_lbd, progress_callback)
+
+
+def lmm_reml_lmm2_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, nullml, max_iter=50, tol=1e-2,
+                                     threads=0, rotate_block_rows=256):
+    """src/stats/lmm.rs:1632-1760 -> f64 (m, 6) = [beta, se, pwald, lambda_reml, ml_alt, plrt] (LMM2: REML Wald test
+    plus an ML likelihood-ratio test from a second Brent on `ml_loglike`, lmm.rs:202-330); no warm start."""
+    s, xcov, y, n, p = _null_args(s, xcov, y_rot)
+    g = _c(snp_chunk, np.float32)
+    if g.ndim != 2 or g.shape[1] != n:
+        raise RuntimeError("snp_chunk must be (m_chunk, n)")
+    u_t = _c(u_t, np.float32)
+    if u_t.shape != (n, n):
+        raise RuntimeError("u_t must be (n, n) and row-major U^T")
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    if not np.isfinite(nullml):
+        raise RuntimeError("nullml must be finite")
+    m = int(g.shape[0])
+    out = np.zeros((m, 6), dtype=np.float64)
+    check(lib().jx_lmm2_chunk(_p(s), _p(xcov), _p(y), n, p, float(low), float(high), _p(g), m, _p(u_t), float(nullml),
+                              int(max_iter), float(tol), _p(out)))
+    return out
+
+
+def lmm_reml_lmm2_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr,
+                                       genetic_model="add", snps_only=False, sample_ids=None, row_indices=None,
+                                       row_flip=None, row_missing=None, row_maf=None, low=-5.0, high=5.0,
+                                       max_iter=30, tol=1e-2, threads=0, nullml=None, init_log10_lbd_reml=None,
+                                       init_log10_lbd_ml=None, rotate_block_rows=512, progress_callback=None,
+                                       progress_every=0, mmap_window_mb=None):
+    """src/stats/lmm.rs:2779-3037 (`jx gwas -lmm2`) -> rows written; TSV schema Lmm2_6
+    (`... pwald lambda ml plrt`, src/io/assoc2tsv.rs:54-56).  Without `nullml` the null ML is fitted first by Brent
+    on -ml_loglike seeded with init_log10_lbd_ml or init_log10_lbd_reml (lmm.rs:2902-2921).  Deterministic start per
+    SNP: init_log10_lbd_reml, else init_log10_lbd_ml, else the interval midpoint (see `lmm_reml_assoc_packed_f32`)."""
+    if low >= high:
+        raise RuntimeError("low must be < high")
+    if not (np.isfinite(tol) and tol > 0):
+        raise RuntimeError("tol must be positive and finite")
+    if nullml is not None:
+        if not np.isfinite(nullml):
+            raise RuntimeError("nullml must be finite when provided")
+        nullml_val = float(nullml)
+    else:
+        s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
+        init = init_log10_lbd_ml if init_log10_lbd_ml is not None else init_log10_lbd_reml
+        o2 = np.zeros(2, dtype=np.float64)
+        check(lib().jx_lmm2_null_ml(_p(s_), _p(xcov_), _p(y_), n, p, float(low), float(high), int(max_iter), float(tol),
+                                    1 if init is not None else 0, float(init if init is not None else 0.0), _p(o2)))
+        nullml_val = float(o2[1])
+        if not np.isfinite(nullml_val):
+            raise RuntimeError("failed to optimize null ML for LMM2 unified scan")
+    init_scan = init_log10_lbd_reml if init_log10_lbd_reml is not None else init_log10_lbd_ml
+    return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
+                            snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm2", low, high,
+                            max_iter, tol, nullml_val, init_scan, progress_callback)
 
 
 def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u_t, maf_thr, miss_thr, het_thr,

@@ -1,6 +1,6 @@
 """Association result TSV (format contract of src/io/assoc2tsv.rs:45-57, 430-548; src/math/linalg.rs:327-340).
 
-Header  chrom pos snp allele0 allele1 af miss beta se chisq pwald [plrt]
+Header  chrom pos snp allele0 allele1 af miss beta se chisq pwald [plrt | lambda ml plrt]
 Row     af/miss/beta/se `{:.4}`; chisq = (beta/se)^2 as `{:.4e}` or `NaN`; p `{:.4e}`; invalid beta/se -> p = 1
         (`sanitize_assoc_pvalue`, linalg.rs:111-121); Rust float text: `NaN`, `inf`, exponent without padding.
 Files are written to a temp path and renamed (python/janusx/assoc/workflow.py:833-845).
@@ -13,6 +13,16 @@ import os
 MIN_POSITIVE = 2.2250738585072014e-308
 HEADER3 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\n"
 HEADER4 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tplrt\n"
+HEADER6 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tlambda\tml\tplrt\n"
+
+
+def fmt_e6(v: float) -> str:
+    if v != v:
+        return "NaN"
+    if v in (math.inf, -math.inf):
+        return "inf" if v > 0 else "-inf"
+    mant, ex = f"{v:.6e}".split("e")
+    return f"{mant}e{int(ex)}"
 
 
 def fmt_e4(v: float) -> str:
@@ -37,7 +47,7 @@ def resolve_snp_name(snp: str, chrom: str, pos) -> str:
     return snp if (snp and snp != ".") else f"{chrom}_{pos}"
 
 
-def format_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p, plrt=None) -> str:
+def format_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p, plrt=None, lmm2=None) -> str:
     if math.isfinite(beta) and math.isfinite(se) and se > 0.0:
         z = beta / se
         chisq = z * z
@@ -47,21 +57,27 @@ def format_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p, plrt=None) -> str
         pv = 1.0
     row = (f"{chrom}\t{pos}\t{resolve_snp_name(snp, chrom, pos)}\t{a0}\t{a1}\t{fmt_f4(float(af))}\t"
            f"{fmt_f4(float(miss))}\t{fmt_f4(beta)}\t{fmt_f4(se)}\t{fmt_e4(chisq)}\t{fmt_e4(pv)}")
-    if plrt is not None:
+    if lmm2 is not None:  # Lmm2_6: lambda, ml `{:.6e}`, plrt `{:.4e}` (assoc2tsv.rs:500-512)
+        row += f"\t{fmt_e6(float(lmm2[0]))}\t{fmt_e6(float(lmm2[1]))}\t{fmt_e4(float(lmm2[2]))}"
+    elif plrt is not None:
         row += f"\t{fmt_e4(float(plrt))}"
     return row + "\n"
 
 
 def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
-    """stats (rows, 3|4) f64 [beta, se, p(, plrt)] in BED order of the kept SNPs. Returns rows written."""
+    """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
+    Returns rows written."""
     ncol = stats.shape[1]
     tmp = f"{path}.tmp.{os.getpid()}"
     with open(tmp, "w") as fh:
-        fh.write(HEADER4 if ncol == 4 else HEADER3)
+        if ncol not in (3, 4, 6):
+            raise RuntimeError(f"unsupported GWAS result column count: {ncol} (expected 3, 4, or 6)")
+        fh.write(HEADER6 if ncol == 6 else (HEADER4 if ncol == 4 else HEADER3))
         buf = []
         for i in range(stats.shape[0]):
             buf.append(format_row(chrom[i], pos[i], snp[i], a0[i], a1[i], af[i], miss[i], float(stats[i, 0]),
-                                  float(stats[i, 1]), float(stats[i, 2]), stats[i, 3] if ncol == 4 else None))
+                                  float(stats[i, 1]), float(stats[i, 2]), stats[i, 3] if ncol == 4 else None,
+                                  stats[i, 3:6] if ncol == 6 else None))
             if len(buf) >= 8192:
                 fh.write("".join(buf))
                 buf = []

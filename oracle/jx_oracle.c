@@ -163,9 +163,11 @@ void jxo_final_beta_se(double log10_lbd, const double *s, const double *xcov, co
 typedef struct {
     const double *s, *xcov, *y, *snp;
     int n, p_cov;
+    int use_ml; /* objective: -reml_loglike (0) or -ml_loglike (1, the LMM2 second pass) */
 } reml_ctx;
 
 static double neg_reml(double x, const reml_ctx *c) {
+    if (c->use_ml) return -jxo_ml_loglike(x, c->s, c->xcov, c->y, c->snp, c->n, c->p_cov);
     return -jxo_reml_loglike(x, c->s, c->xcov, c->y, c->snp, c->n, c->p_cov);
 }
 
@@ -235,7 +237,7 @@ static void brent_min(const reml_ctx *ctx, double low, double high, double tol, 
 /* `lmm_reml_null_f32`, src/stats/reml.rs:572-616 -> out = (lbd, ml, reml) */
 void jxo_lmm_reml_null(const double *s, const double *xcov, const double *y, int n, int p_cov, double low,
                        double high, int max_iter, double tol, double *out3) {
-    reml_ctx ctx = {s, xcov, y, NULL, n, p_cov};
+    reml_ctx ctx = {s, xcov, y, NULL, n, p_cov, 0};
     double xb, fb;
     brent_min(&ctx, low, high, tol, max_iter, 0, 0.0, &xb, &fb, NULL);
     out3[0] = pow(10.0, xb);
@@ -285,7 +287,7 @@ void jxo_lmm_scan_rotated_block(const float *g_rot, int rows, int n, const doubl
                 if (with_plrt) o[3] = 1.0;
                 continue;
             }
-            reml_ctx ctx = {s, xcov, y, snp, n, p_cov};
+            reml_ctx ctx = {s, xcov, y, snp, n, p_cov, 0};
             double xb, fb;
             int ne = 0;
             int hi = (warm == 1) ? isfinite(init) : (warm == 2 ? have_last : 0);
@@ -314,6 +316,68 @@ void jxo_lmm_scan_rotated_block(const float *g_rot, int rows, int n, const doubl
                 o[0] = NAN; o[1] = NAN; o[2] = 1.0;
                 if (with_plrt) o[3] = 1.0;
             }
+        }
+        free(snp);
+    }
+}
+
+/* Null ML of the LMM2 scan: Brent on -ml_loglike without a SNP column (src/stats/lmm.rs:2902-2921) -> out2 =
+ * (log10 lambda, ml0). */
+void jxo_lmm2_null_ml(const double *s, const double *xcov, const double *y, int n, int p_cov, double low,
+                      double high, int max_iter, double tol, int has_init, double init, double *out2) {
+    reml_ctx ctx = {s, xcov, y, NULL, n, p_cov, 1};
+    double xb, fb;
+    brent_min(&ctx, low, high, tol, max_iter, has_init, init, &xb, &fb, NULL);
+    double ml0 = -fb;
+    if (!isfinite(ml0)) ml0 = jxo_ml_loglike(xb, s, xcov, y, NULL, n, p_cov);
+    out2[0] = xb;
+    out2[1] = ml0;
+}
+
+/* `run_rotated_lmm2_assoc_block_f32`, src/stats/lmm.rs:202-330, without the warm-start chain: REML Brent (seeded
+ * with init when has_init) -> final_beta_se -> ML Brent seeded with the REML optimum -> LRT against nullml.
+ * out (rows, 6) = [beta, se, pwald, lambda_reml, ml_alt, plrt]. */
+void jxo_lmm2_scan_rotated_block(const float *g_rot, int rows, int n, const double *s, const double *xcov,
+                                 const double *y, int p_cov, double low, double high, double tol, int max_iter,
+                                 int has_init, double init, double nullml, double *out, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        double *snp = (double *)malloc(sizeof(double) * (size_t)n);
+#pragma omp for schedule(dynamic, 16)
+        for (int r = 0; r < rows; ++r) {
+            const float *row = g_rot + (size_t)r * n;
+            double *o = out + (size_t)r * 6;
+            double ssq = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double v = (double)row[i];
+                snp[i] = v;
+                ssq += v * v;
+            }
+            o[0] = NAN; o[1] = NAN; o[2] = 1.0; o[3] = NAN; o[4] = NAN; o[5] = 1.0; /* lmm.rs:84-91 */
+            if (!isfinite(ssq) || ssq <= 1e-12) continue;
+            reml_ctx ctx = {s, xcov, y, snp, n, p_cov, 0};
+            double xr, fr;
+            brent_min(&ctx, low, high, tol, max_iter, has_init && isfinite(init), init, &xr, &fr, NULL);
+            double bs[3];
+            jxo_final_beta_se(xr, s, xcov, y, snp, n, p_cov, bs);
+            if (!(isfinite(bs[0]) && isfinite(bs[1]) && bs[1] > 0.0)) continue;
+            double z = bs[0] / bs[1];
+            double pw = 2.0 * (0.5 * erfc(fabs(z) / M_SQRT2));
+            if (pw < DBL_MIN) pw = DBL_MIN;
+            if (pw > 1.0) pw = 1.0;
+            reml_ctx mctx = {s, xcov, y, snp, n, p_cov, 1};
+            double xm, fm;
+            brent_min(&mctx, low, high, tol, max_iter, 1, xr, &xm, &fm, NULL);
+            double ml_alt = -fm;
+            if (!isfinite(ml_alt)) ml_alt = jxo_ml_loglike(xm, s, xcov, y, snp, n, p_cov);
+            double stat = isfinite(ml_alt) ? 2.0 * (ml_alt - nullml) : 0.0;
+            if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+            double plrt = chi2_sf_df1(stat);
+            o[0] = bs[0]; o[1] = bs[1]; o[2] = isfinite(pw) ? pw : 1.0;
+            o[3] = bs[2]; o[4] = ml_alt; o[5] = isfinite(plrt) ? plrt : 1.0;
         }
         free(snp);
     }

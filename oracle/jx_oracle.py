@@ -730,6 +730,45 @@ def lmm_scan_rotated_block(g_rot, s, xcov, y, low, high, max_iter, tol, nullml=N
     return (out, evals) if count_evals else out
 
 
+def lmm2_scan_rotated_block(g_rot, s, xcov, y, low, high, max_iter, tol, nullml, init_reml=None, init_ml=None):
+    """`run_rotated_lmm2_assoc_block_f32` with use_warm_start = false (src/stats/lmm.rs:202-330):
+    (rows, 6) = [beta, se, pwald, lambda_reml, ml_alt, plrt]; invalid rows (NaN, NaN, 1, NaN, NaN, 1)."""
+    g_rot = np.asarray(g_rot, dtype=np.float32)
+    rows = g_rot.shape[0]
+    out = np.zeros((rows, 6), dtype=np.float64)
+    init = init_reml if init_reml is not None else init_ml
+    for r in range(rows):
+        out[r] = (np.nan, np.nan, 1.0, np.nan, np.nan, 1.0)
+        snp = g_rot[r].astype(np.float64)
+        ssq = float(np.sum(snp * snp))
+        if not math.isfinite(ssq) or ssq <= 1e-12:
+            continue
+        xr, _, _ = brent_minimize(lambda t: -reml_loglike(t, s, xcov, y, snp), low, high, tol, max_iter, init)
+        beta, se, lbd = final_beta_se(xr, s, xcov, y, snp)
+        if not (math.isfinite(beta) and math.isfinite(se) and se > 0.0):
+            continue
+        pw = min(max(2.0 * normal_sf(abs(beta / se)), MIN_POSITIVE), 1.0)
+        xm, fm, _ = brent_minimize(lambda t: -ml_loglike(t, s, xcov, y, snp), low, high, tol, max_iter, xr)
+        ml_alt = -fm
+        if not math.isfinite(ml_alt):
+            ml_alt = ml_loglike(xm, s, xcov, y, snp)
+        stat = 2.0 * (ml_alt - nullml) if math.isfinite(ml_alt) else 0.0
+        if not math.isfinite(stat) or stat < 0.0:
+            stat = 0.0
+        plrt = chi2_sf_df1(stat)
+        out[r] = (beta, se, pw if math.isfinite(pw) else 1.0, lbd, ml_alt, plrt if math.isfinite(plrt) else 1.0)
+    return out
+
+
+def lmm2_null_ml(s, xcov, y, low, high, max_iter, tol, init=None):
+    """Null ML of the LMM2 BED route (src/stats/lmm.rs:2902-2921) -> (log10 lambda, ml0)."""
+    xm, fm, _ = brent_minimize(lambda t: -ml_loglike(t, s, xcov, y), low, high, tol, max_iter, init)
+    ml0 = -fm
+    if not math.isfinite(ml0):
+        ml0 = ml_loglike(xm, s, xcov, y)
+    return xm, ml0
+
+
 def lmm_reml_chunk_from_snp(s, xcov, y_rot, low, high, snp_chunk, u_t, max_iter=50, tol=1e-2,
                             nullml=None):
     """`lmm_reml_chunk_from_snp_f32` (src/stats/lmm.rs:1479-1630): rotate then exact scan, no warm start."""

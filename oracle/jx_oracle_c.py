@@ -35,6 +35,10 @@ def lib():
         _LIB.jxo_lmm_reml_null.argtypes = [p, p, p, i, i, d, d, i, d, p]
         _LIB.jxo_lmm_scan_rotated_block.restype = None
         _LIB.jxo_lmm_scan_rotated_block.argtypes = [p, i, i, p, p, p, i, d, d, d, i, i, d, i, d, p, p, i]
+        _LIB.jxo_lmm2_null_ml.restype = None
+        _LIB.jxo_lmm2_null_ml.argtypes = [p, p, p, i, i, d, d, i, d, i, d, p]
+        _LIB.jxo_lmm2_scan_rotated_block.restype = None
+        _LIB.jxo_lmm2_scan_rotated_block.argtypes = [p, i, i, p, p, p, i, d, d, d, i, i, d, d, p, i]
         _LIB.jxo_fvlmm_assoc_block.restype = None
         _LIB.jxo_fvlmm_assoc_block.argtypes = [p, i, i, i, p, p, p, p, d, i, p, i]
         _LIB.jxo_decode_rows_lut_f32.restype = None
@@ -93,6 +97,27 @@ def lmm_scan_rotated_block(g_rot, s, xcov, y, low, high, max_iter, tol, warm=0, 
                                      1 if nullml is not None else 0, float(nullml or 0.0), _ptr(out), _ptr(ev),
                                      int(threads))
     return (out, ev) if return_evals else out
+
+
+def lmm2_null_ml(s, xcov, y, low, high, max_iter=30, tol=1e-2, init=None):
+    s, xcov, y = _f64(s).ravel(), _f64(xcov), _f64(y).ravel()
+    out = np.zeros(2)
+    lib().jxo_lmm2_null_ml(_ptr(s), _ptr(xcov), _ptr(y), len(y), xcov.shape[1], float(low), float(high),
+                           int(max_iter), float(tol), 1 if init is not None else 0,
+                           float(init if init is not None else 0.0), _ptr(out))
+    return float(out[0]), float(out[1])
+
+
+def lmm2_scan_rotated_block(g_rot, s, xcov, y, low, high, max_iter, tol, nullml, init=None, threads=0):
+    g = np.ascontiguousarray(g_rot, dtype=np.float32)
+    s, xcov, y = _f64(s).ravel(), _f64(xcov), _f64(y).ravel()
+    rows, n = g.shape
+    out = np.zeros((rows, 6))
+    lib().jxo_lmm2_scan_rotated_block(_ptr(g), rows, n, _ptr(s), _ptr(xcov), _ptr(y), xcov.shape[1], float(low),
+                                      float(high), float(tol), int(max_iter), 1 if init is not None else 0,
+                                      float(init if init is not None else 0.0), float(nullml), _ptr(out),
+                                      int(threads))
+    return out
 
 
 def fvlmm_assoc_block(g_rot, w, num, cbuf, a_chol, ypy, df, threads=0):

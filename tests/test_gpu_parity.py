@@ -647,3 +647,52 @@ def test_fvlmm_assoc_packed_to_tsv(oracle, oracle_c, null_case, tmp_path):
     with pytest.raises(RuntimeError):
         jxrs.fvlmm_assoc_packed_f32_to_tsv(packed, n_all, flip_k, maf_k, miss_k, u[:, :10], s_desc[:10], y, x0, sidx,
                                            -5.0, 5.0, 50, 1e-3, 0.0, 0, "add", chrom, pos, snp, a0, a1, out)
+
+
+def test_lmm2_routes(oracle, oracle_c, null_case, tmp_path):
+    """LMM2 ("next" row 8f-2): REML Wald + ML likelihood-ratio per SNP, 6 output columns
+    (src/stats/lmm.rs:202-330, 1632-1760, 2779-3037; TSV schema Lmm2_6 src/io/assoc2tsv.rs:54-56)."""
+    from janusx_amd import janusx as jxrs
+    n, m, packed, g, y, x, nm = null_case
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    kept = np.nonzero(keep)[0]
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, rows=kept)
+    gd[7] = 0.0
+    grot = oracle.rotate_block_f32(gd, nm.Dh)
+    lo, hi = nm.bounds
+    ref = oracle_c.lmm2_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2, nm.ML0)
+    # the pure-Python restatement agrees with the C one on a few rows
+    ref_py = oracle.lmm2_scan_rotated_block(grot[:12], nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2, nm.ML0)
+    assert np.allclose(ref_py, ref[:12], rtol=1e-7, atol=0, equal_nan=True)
+    out = jxrs.lmm_reml_lmm2_chunk_from_snp_f32(nm.S, nm.Xcov, nm.y, lo, hi, gd, nm.Dh, nm.ML0, max_iter=30, tol=1e-2)
+    assert out.shape == (len(kept), 6)
+    be, se, pe = _assoc_err(out, ref)
+    assert max(be, se) < TOL, (be, se, pe)
+    assert math.isnan(out[7, 0]) and out[7, 2] == 1.0 and math.isnan(out[7, 3]) and math.isnan(out[7, 4]) and out[7, 5] == 1.0
+    ok = ~np.isnan(ref[:, 0])
+    assert float(np.max(np.abs(out[ok, 3] - ref[ok, 3]) / ref[ok, 3])) < 1e-4      # lambda_reml
+    assert float(np.max(np.abs(out[ok, 4] - ref[ok, 4]) / np.abs(ref[ok, 4]))) < 1e-8  # ml_alt
+    assert float(np.max(np.abs(np.log10(out[ok, 5]) - np.log10(ref[ok, 5])))) < 1e-4
+    # BED -> TSV route; the null ML is fitted by the callee when nullml is not passed
+    prefix = str(tmp_path / "panel")
+    ids = [f"s{i}" for i in range(n)]
+    bim = bed.Bim([str(1 + j % 5) for j in range(m)], [f"rs{j}" for j in range(m)], [100 + j for j in range(m)],
+                  ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    tsv = str(tmp_path / "res.lmm2.tsv")
+    rows = jxrs.lmm_reml_lmm2_assoc_bed_to_tsv_f32(prefix, tsv, nm.S, nm.Xcov, nm.y, nm.Dh, 0.02, 0.05, 1.0,
+                                                   low=lo, high=hi, max_iter=30, tol=1e-2)
+    assert rows == len(kept)
+    x0, ml0 = oracle_c.lmm2_null_ml(nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2)
+    gd2 = oracle.decode_centered_block_f32(packed, n, flip, maf, rows=kept)
+    ref2 = oracle_c.lmm2_scan_rotated_block(oracle.rotate_block_f32(gd2, nm.Dh), nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2, ml0)
+    lines = open(tsv).read().splitlines()
+    assert lines[0].split("\t")[-3:] == ["lambda", "ml", "plrt"] and len(lines) == rows + 1
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert len(f) == 14
+        assert abs(float(f[7]) - ref2[i, 0]) <= 1.01e-4 and abs(float(f[8]) - ref2[i, 1]) <= 1.01e-4
+        assert abs(float(f[11]) - ref2[i, 3]) <= 2e-4 * ref2[i, 3]
+        assert abs(float(f[12]) - ref2[i, 4]) <= 2e-6 * abs(ref2[i, 4])
+        assert abs(float(f[13]) - ref2[i, 5]) <= 3e-4 * ref2[i, 5] + 1e-300

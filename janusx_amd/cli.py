@@ -1,4 +1,4 @@
-"""Thin `jx gwas` / `jx grm` command line for the accelerated path.
+"""Thin `jx gwas` / `jx grm` / `jx gs` command line for the accelerated path.
 
 Flag names, defaults and output file names follow the reference (python/janusx/assoc/workflow.py:6599-7047,
 python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model_stream.py:989-994):
@@ -6,10 +6,15 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
   python -m janusx_amd gwas -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] (-lmm | -fvlmm) [-k 1|2|GRM.npy] [-c COV.tsv]
                             [-maf 0.02] [-geno 0.05] [-het 1.0] [-o OUT] [-force-model]
   python -m janusx_amd grm  -bfile PREFIX [-m 1|2] [-maf 0.02] [-geno 0.05] [-o OUT]
+  python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -BLUP [-cv K] [-seed 42] [-k GRM.npy]
+                            [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`.
-Only PLINK BED input, the additive model and the -lmm / -fvlmm scans are built; VCF/HMP readers,
-PCs (-q), plots and the history DB are out of scope.
+Outputs: `{out}.{trait}.lmm.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`;
+`{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
+Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
+(python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
+python/janusx/gs/workflow.py:9122) are built; VCF/HMP readers, PCs (-q), plots, the history DB, the
+other GS model families and the rrBLUP/PCG routes are out of scope.
 """
 from __future__ import annotations
 
@@ -166,6 +171,69 @@ def cmd_gwas(args):
     return 0
 
 
+def cmd_gs(args):
+    """`jx gs -BLUP`: centred GRM of all genotyped samples (once), then per trait a GBLUP fit on the phenotyped
+    samples (spectral REML, src/stats/gblup.rs:1105-1240) -- K-fold cross-validated with `-cv` (fold shuffling
+    seeded by `-seed`, python/janusx/gs/workflow.py:18744-18760) -- and predictions for every genotyped sample."""
+    from . import janusx as jxrs
+    from .bed import read_fam_ids
+    if not (args.blup or args.gblup):
+        raise SystemExit("select a model: -BLUP (or -GBLUP)")
+    fam = read_fam_ids(args.bfile)
+    ids, names, ph = _read_table(args.pheno)
+    pos = {s: i for i, s in enumerate(ids)}
+    traits = _select_traits(names, args.ncol)
+    out = args.out or args.bfile
+    t0 = time.perf_counter()
+    if args.grm:
+        k = _load_grm(args.grm, fam)
+        print(f"GRM loaded from {args.grm}: n={k.shape[0]}")
+    else:
+        k, eff, _ = jxrs.grm_stream_bed_f32(args.bfile, method=1, maf_threshold=args.maf, max_missing_rate=args.geno,
+                                            het_threshold=0.0)
+        print(f"GRM method 1: n={k.shape[0]} eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
+    n_all = len(fam)
+    for ti in traits:
+        name = names[ti]
+        yv = np.array([ph[pos[s], ti] if s in pos else np.nan for s in fam])
+        train = np.nonzero(np.isfinite(yv))[0].astype(np.int64)
+        test = np.nonzero(~np.isfinite(yv))[0].astype(np.int64)
+        if len(train) < 10:
+            print(f"[{name}] only {len(train)} phenotyped samples, skipped")
+            continue
+        t1 = time.perf_counter()
+        fold = np.full(n_all, -1, dtype=np.int64)
+        pred = np.full(n_all, np.nan)
+        if args.cv and args.cv > 1:
+            perm = np.random.default_rng(args.seed).permutation(len(train))
+            for f in range(args.cv):
+                te_loc = np.sort(perm[f::args.cv])
+                tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+                r = jxrs.gblup_reml_grm(k, train[tr_loc], yv[train[tr_loc]], train[te_loc], estimate_only=False)
+                pred[train[te_loc]] = r[1].ravel()
+                fold[train[te_loc]] = f
+            yo, po = yv[train], pred[train]
+            rr = float(np.corrcoef(yo, po)[0, 1])
+            r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
+            print(f"[{name}] GBLUP {args.cv}-fold CV: pearson={rr:.4f} R2={r2:.4f}")
+        full = jxrs.gblup_reml_grm(k, train, yv[train], test if len(test) else None, return_variance_components=True)
+        if not (args.cv and args.cv > 1):
+            pred[train] = full[0].ravel()
+        if len(test):
+            pred[test] = full[1].ravel()
+        path = f"{out}.{name}.gs.GBLUP.tsv"
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "w") as fh:
+            fh.write("sample\tobserved\tpredicted\tfold\n")
+            for j, sid in enumerate(fam):
+                obs = "NA" if not math.isfinite(yv[j]) else f"{yv[j]:.6g}"
+                fh.write(f"{sid}\t{obs}\t{pred[j]:.6g}\t{'NA' if fold[j] < 0 else fold[j]}\n")
+        os.replace(tmp, path)
+        print(f"[{name}] GBLUP: n_train={len(train)} n_pred={len(test)} lambda={full[3]:.5g} pve={full[2]:.4f} "
+              f"sigma_g2={full[9]:.5g} sigma_e2={full[10]:.5g} -> {path} ({time.perf_counter() - t1:.2f}s)")
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="jx", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -192,6 +260,20 @@ def main(argv=None):
     r.add_argument("-o", "--out", default=None)
     r.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     r.set_defaults(func=cmd_grm)
+    q = sub.add_parser("gs")
+    q.add_argument("-bfile", "--bfile", required=True)
+    q.add_argument("-p", "--pheno", required=True)
+    q.add_argument("-n", "--n", dest="ncol", action="append", default=None)
+    q.add_argument("-BLUP", "--BLUP", dest="blup", action="store_true", default=False)
+    q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
+    q.add_argument("-cv", "--cv", type=int, default=None)
+    q.add_argument("-seed", "--seed", type=int, default=42)
+    q.add_argument("-k", "--grm", dest="grm", type=str, default=None)
+    q.add_argument("-maf", "--maf", type=float, default=0.02)
+    q.add_argument("-geno", "--geno", type=float, default=0.05)
+    q.add_argument("-o", "--out", default=None)
+    q.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
+    q.set_defaults(func=cmd_gs)
     args = ap.parse_args(argv)
     return args.func(args)
 

@@ -696,3 +696,40 @@ def test_lmm2_routes(oracle, oracle_c, null_case, tmp_path):
         assert abs(float(f[11]) - ref2[i, 3]) <= 2e-4 * ref2[i, 3]
         assert abs(float(f[12]) - ref2[i, 4]) <= 2e-6 * abs(ref2[i, 4])
         assert abs(float(f[13]) - ref2[i, 5]) <= 3e-4 * ref2[i, 5] + 1e-300
+
+
+def test_cli_gs_blup(oracle, tmp_path):
+    """`jx gs -bfile ... -BLUP -cv 3`: GRM of all samples, GBLUP per trait on the phenotyped samples, predictions for
+    the unphenotyped ones, cross-validated predictions per fold -- against the oracle's `gblup_reml_grm`."""
+    from janusx_amd import cli
+    n, m = 260, 600
+    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.01)
+    y = bed.synth_phenotype(g, n_causal=40, pve=0.7, seed=61)
+    na = np.random.default_rng(5).random(n) < 0.15
+    prefix = str(tmp_path / "gs")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\tyield\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-BLUP", "-cv", "3", "-seed", "7", "-o", prefix]) == 0
+    rows = [ln.split("\t") for ln in open(prefix + ".yield.gs.GBLUP.tsv").read().splitlines()]
+    assert rows[0] == ["sample", "observed", "predicted", "fold"] and len(rows) == n + 1
+    k_ref, _, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    train = np.nonzero(~na)[0]
+    test = np.nonzero(na)[0]
+    _, pte, fit = oracle.gblup_reml_grm(k_ref, train, y[train], test)
+    pred = np.array([float(r[2]) for r in rows[1:]])
+    assert [r[0] for r in rows[1:]] == ids
+    scale = float(np.std(y[train]))
+    assert np.max(np.abs(pred[test] - pte)) < 2e-5 * scale + 1e-5 * np.max(np.abs(pte))
+    assert all(rows[1 + j][1] == "NA" and rows[1 + j][3] == "NA" for j in test)
+    # fold structure and one fold recomputed with the oracle
+    perm = np.random.default_rng(7).permutation(len(train))
+    te_loc = np.sort(perm[1::3])
+    tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+    assert all(rows[1 + train[j]][3] == "1" for j in te_loc)
+    _, p1, _ = oracle.gblup_reml_grm(k_ref, train[tr_loc], y[train[tr_loc]], train[te_loc])
+    assert np.max(np.abs(pred[train[te_loc]] - p1)) < 2e-5 * scale + 1e-5 * np.max(np.abs(p1))

@@ -109,6 +109,46 @@ def _read_bed_payload(prefix):
     return read_bed_payload(prefix)
 
 
+def prepare_bed_2bit_packed(prefix, maf_threshold, max_missing_rate, het_threshold, snps_only=False):
+    """src/io/gfreader.rs:7029-7110 (the packed workflow's loader + QC) ->
+    (packed_keep u8 (k, bps), missing_rate f32 (k), maf f32 (k) [alt allele frequency], std_denom f32 (k),
+    row_flip bool (k) [all False], site_keep bool (m), n_samples, n_snps_total).
+    Row counts come from the device popcount kernel; thresholds out of range raise ValueError like the reference."""
+    from . import stats as st
+    from .bed import read_bed_payload, snps_only_mask
+    if not (0.0 <= maf_threshold <= 0.5):
+        raise ValueError("maf_threshold must be within [0, 0.5]")
+    if not (0.0 <= max_missing_rate <= 1.0):
+        raise ValueError("max_missing_rate must be within [0, 1.0]")
+    if not (0.0 <= het_threshold <= 1.0):
+        raise ValueError("het_threshold must be within [0, 1.0]")
+    low = str(prefix).lower()
+    if low.endswith((".bed", ".bim", ".fam")):
+        prefix = str(prefix)[:-4]
+    packed, n_fam, bim = read_bed_payload(prefix)
+    counts = bed_row_counts(packed, n_fam, None)
+    keep, miss, maf, std = st.packed_prep_row_stats(counts, n_fam, maf_threshold, max_missing_rate, het_threshold)
+    if snps_only:
+        keep &= snps_only_mask(bim)
+    if not keep.any():
+        raise RuntimeError("No SNPs left after packed BED filtering. Please relax thresholds.")
+    rows = np.nonzero(keep)[0]
+    return (np.ascontiguousarray(packed[rows]), miss[rows], maf[rows], std[rows], np.zeros(len(rows), dtype=bool),
+            keep, int(n_fam), int(packed.shape[0]))
+
+
+def grm_packed_bed_f32(prefix, method=1, maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0,
+                       snps_only=False, block_cols=65536, threads=0, progress_callback=None, progress_every=0):
+    """src/stats/grm.rs:3757-3839: `prepare_bed_2bit_packed` then `grm_packed_f32` -> (f32 (n,n), eff_m, n_samples)."""
+    maf_thr = min(max(float(maf_threshold), 0.0), 0.5)
+    miss_thr = min(max(float(max_missing_rate), 0.0), 1.0)
+    pk, _miss, maf, _std, flip, _keep, n, _tot = prepare_bed_2bit_packed(prefix, maf_thr, miss_thr,
+                                                                        min(max(float(het_threshold), 0.0), 1.0),
+                                                                        snps_only)
+    k = grm_packed_f32(pk, n, flip, maf, None, method, block_cols, threads, progress_callback, progress_every)
+    return k, int(pk.shape[0]), n
+
+
 def grm_stream_bed_f32(prefix, method=1, maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0,
                        snps_only=False, block_cols=65536, threads=0, progress_callback=None, progress_every=0,
                        mmap_window_mb=None):

@@ -41,6 +41,30 @@ def gwas_scan_row_stats(counts: np.ndarray, n: int, maf_thr: float, miss_thr: fl
     return keep, af, miss_rate.astype(np.float32)
 
 
+def packed_prep_row_stats(counts: np.ndarray, n: int, maf_thr: float, miss_thr: float, het_thr: float):
+    """QC of the packed workflow (`prepare_bed_2bit_packed`, src/io/gfreader.rs:5380-5420, 1911-1929, 6340-6400):
+    f32 missing-rate and MAF compares, f64 het-rate compare (filter on only when het_thr > 0).
+    -> keep, miss_rate f32, maf f32 (= alt allele frequency clamped to [0, 1]), std_denom f32 = sqrt(2p(1-p))."""
+    counts = np.asarray(counts, dtype=np.int64)
+    missing, het, hom = counts[:, 0], counts[:, 1], counts[:, 2]
+    maf_thr, miss_thr, het_thr = F32(maf_thr), F32(miss_thr), F32(het_thr)
+    nm = np.maximum(n - missing, 0)
+    has = nm > 0
+    alt_sum = het + 2 * hom
+    with np.errstate(divide="ignore", invalid="ignore"):
+        miss = ((n - nm).astype(np.float32) / F32(n)) if n > 0 else np.zeros(len(nm), dtype=np.float32)
+        af = np.where(has, alt_sum.astype(np.float32) / (F32(2.0) * nm.astype(np.float32)), F32(0.0)).astype(np.float32)
+        p = alt_sum.astype(np.float64) / (2.0 * nm.astype(np.float64))
+        d = np.sqrt(2.0 * p * (1.0 - p)).astype(np.float32)
+        std = np.where(has & np.isfinite(d), d, F32(0.0)).astype(np.float32)
+        pass_maf = np.minimum(af, F32(1.0) - af) >= maf_thr
+        keep = np.where(has, pass_maf, bool(maf_thr <= F32(0.0)))
+        if het_thr > F32(0.0):
+            keep &= ~(has & ((het.astype(np.float64) / nm.astype(np.float64)) > float(het_thr)))
+        keep &= ~(miss > miss_thr)
+    return keep.astype(bool), miss.astype(np.float32), np.clip(af, F32(0.0), F32(1.0)).astype(np.float32), std
+
+
 def stream_grm_row_prepare(counts: np.ndarray, n_samples: int, method: int, maf_thr: float, miss_thr: float,
                            het_thr: float):
     """-> keep, mean_g (f32), std_scale (f32), flip (bool), var (f64). Thresholds are clamped like

@@ -128,6 +128,43 @@ def gwas_scan_row_stats(missing, het, hom_alt, n, maf_thr, miss_thr, het_thr):
     return keep, maf, miss_rate, np.zeros(m, dtype=bool)
 
 
+def packed_prep_row_stats(missing, het, hom_alt, n, maf_thr, miss_thr, het_thr):
+    """Packed-workflow QC (`prepare_bed_2bit_packed`: src/io/gfreader.rs:5380-5420 keep rule,
+    `packed_row_stats_from_counts` :1911-1929 and the subset loader :6340-6400 for the kept rows' columns).
+    Returns keep, miss_rate (f32), maf (f32: the *alt allele frequency*, clamped to [0,1]), std_denom (f32),
+    row_flip (all False)."""
+    m = len(missing)
+    maf_thr, miss_thr, het_thr = F32(maf_thr), F32(miss_thr), F32(het_thr)
+    apply_het = het_thr > F32(0.0)
+    keep = np.zeros(m, dtype=bool)
+    miss = np.zeros(m, dtype=np.float32)
+    maf = np.zeros(m, dtype=np.float32)
+    std = np.zeros(m, dtype=np.float32)
+    for j in range(m):
+        nm = max(n - int(missing[j]), 0)
+        alt_sum = int(het[j]) + 2 * int(hom_alt[j])
+        mr = F32(n - nm) / F32(n) if n > 0 else F32(0.0)
+        miss[j] = mr
+        if nm > 0:
+            p = alt_sum / (2.0 * nm)
+            d = F32(math.sqrt(2.0 * p * (1.0 - p)))
+            std[j] = d if math.isfinite(float(d)) else F32(0.0)
+            af = F32(alt_sum) / (F32(2.0) * F32(nm))
+        else:
+            af = F32(0.0)
+        maf[j] = min(max(af, F32(0.0)), F32(1.0))
+        if mr > miss_thr:
+            ok = False
+        elif nm == 0:
+            ok = bool(maf_thr <= F32(0.0))
+        elif apply_het and (int(het[j]) / float(nm)) > float(het_thr):
+            ok = False
+        else:
+            ok = bool(min(af, F32(1.0) - af) >= maf_thr)
+        keep[j] = ok
+    return keep, miss, maf, std, np.zeros(m, dtype=bool)
+
+
 def stream_grm_row_prepare(missing, het, hom_alt, n_samples, method, maf_thr, miss_thr, het_thr,
                            eps=1e-12):
     """Stream-GRM per-row preparation, all in **f64** with f32 thresholds widened

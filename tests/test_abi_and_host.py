@@ -70,6 +70,10 @@ def test_stats_match_oracle_bit_exact(oracle):
         k2, af2, ms2 = stats.gwas_scan_row_stats(counts, n, maf_thr, miss_thr, het_thr)
         assert np.array_equal(k1, k2)
         assert np.array_equal(af1[k1], af2[k1]) and np.array_equal(ms1, ms2)
+        kp, mp, ap, sp, fp = oracle.packed_prep_row_stats(missing, het, hom, n, maf_thr, miss_thr, het_thr)
+        kq, mq, aq, sq = stats.packed_prep_row_stats(counts, n, maf_thr, miss_thr, het_thr)
+        assert np.array_equal(kp, kq) and np.array_equal(mp, mq) and np.array_equal(ap, aq) and np.array_equal(sp, sq)
+        assert not fp.any()
         for method in (1, 2):
             a = oracle.stream_grm_row_prepare(missing, het, hom, n, method, maf_thr, miss_thr, het_thr)
             b = stats.stream_grm_row_prepare(counts, n, method, maf_thr, miss_thr, het_thr)

@@ -733,3 +733,31 @@ def test_cli_gs_blup(oracle, tmp_path):
     assert all(rows[1 + train[j]][3] == "1" for j in te_loc)
     _, p1, _ = oracle.gblup_reml_grm(k_ref, train[tr_loc], y[train[tr_loc]], train[te_loc])
     assert np.max(np.abs(pred[train[te_loc]] - p1)) < 2e-5 * scale + 1e-5 * np.max(np.abs(p1))
+
+
+def test_packed_prep_and_grm_packed_bed(oracle, tmp_path):
+    """`prepare_bed_2bit_packed` + `grm_packed_bed_f32` (src/io/gfreader.rs:7029-7110, src/stats/grm.rs:3757-3839):
+    kept-SNP set, miss/maf/std columns bit-exact; GRM against the oracle's packed GRM on the same rows."""
+    from janusx_amd import janusx as jxrs
+    n, m = 211, 480
+    packed, g = bed.synth_panel_numpy(n, m, seed=71, missing_rate=0.03)
+    prefix = str(tmp_path / "pp")
+    alle = ["A" if j % 11 else "AT" for j in range(m)]   # a few indels for snps_only
+    bim = bed.Bim(["2"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), alle, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    mi, he, ho = oracle.row_counts(packed, n)
+    for maf_thr, miss_thr, het_thr, snps_only in [(0.02, 0.05, 0.0, False), (0.05, 0.04, 0.45, True)]:
+        pk, miss, maf, std, flip, keep, ns, tot = jxrs.prepare_bed_2bit_packed(prefix + ".bed", maf_thr, miss_thr, het_thr, snps_only)
+        k_ref, m_ref, a_ref, s_ref, _ = oracle.packed_prep_row_stats(mi, he, ho, n, maf_thr, miss_thr, het_thr)
+        if snps_only:
+            k_ref = k_ref & np.array([len(a) == 1 for a in alle])
+        assert ns == n and tot == m and np.array_equal(keep, k_ref) and not flip.any()
+        assert np.array_equal(pk, packed[k_ref])
+        assert np.array_equal(miss, m_ref[k_ref]) and np.array_equal(maf, a_ref[k_ref]) and np.array_equal(std, s_ref[k_ref])
+    with pytest.raises(ValueError):
+        jxrs.prepare_bed_2bit_packed(prefix, 0.7, 0.05, 0.0)
+    kk, eff, ns = jxrs.grm_packed_bed_f32(prefix, method=1)
+    k_keep, _, a_keep, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    ref = oracle.grm_packed(packed[k_keep], n, np.zeros(int(k_keep.sum()), dtype=bool), a_keep[k_keep], None, 1)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert eff == int(k_keep.sum()) and ns == n and _grm_err(kk, ref) < TOL

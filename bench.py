@@ -137,6 +137,23 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
     return None
 
 
+def pmc_mfma_util(kernel_substr):
+    """MFMA-pipe utilisation of a kernel from the committed counter pass (profiles/r01c_pmc_mfma.json):
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_mfma.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    for name, rec in kernels.items():
+        if kernel_substr in name:
+            try:
+                return rec["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (rec["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0)
+            except Exception:
+                return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,9 +313,14 @@ def main():
                                          "pair is served by L2/MALL)",
                          "note": "algorithmic n(n+1)m flops per launch; the kernel issues 3 f16 MFMA products per "
                                  "algorithmic product (hi*hi+hi*lo+lo*hi), so MFMA-pipe utilisation = 3*frac*(tile overhead)",
+                         "mfma_util_pmc": pmc_mfma_util("grm_f16x2_kernel"),
+                         "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
+                                           "profiles/r01c_pmc_mfma.json): the fraction of the dense f16 MFMA peak the "
+                                           "matrix pipes actually run at; frac above is the algorithmic share",
                          "avg_launch_ms": kern["grm_ms"] / L},
             "roofline_rotate": {"bound": "mfma", "kernel": "rotate_f16x2_kernel", "achieved": rot_tflops,
                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS,
+                                "mfma_util_pmc": pmc_mfma_util("rotate_f16x2_kernel"),
                                 "ms_per_step": kern["rot_ms"] / L},
             "roofline_scan": {"bound": "hbm", "kernel": "lmm_scan_fast_kernel" if args.mode == "lmm" else "fvlmm_scan_kernel",
                               "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel" if args.mode == "lmm" else "jx::fvlmm_scan_kernel",

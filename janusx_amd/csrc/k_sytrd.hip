@@ -290,7 +290,17 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
     const int i = j - j0;
     const int tid = threadIdx.x;
     const double tau = P.tau[j];
-    // row-side loads are independent of the scalars below: issue them first
+    // every global read of this launch is issued up front (the scalar chain below is otherwise three dependent
+    // round trips): v'Tv, y at the first trailing row, then the row-side operands
+    const double yv_all = P.acc[par].sc[0];
+    const double y_first = P.acc[par].y[base];
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+    if (tid < i) {  // i <= 63
+        a1 = P.acc[par].t1[tid];
+        a2 = P.acc[par].t2[tid];
+        b1 = P.vt[(int64_t)base * TD_NB + tid];
+        b2 = P.wt[(int64_t)base * TD_NB + tid];
+    }
     const int rloc = tid >> 2, q = tid & 3;
     const int rr = blockIdx.x * TD_TS + rloc;  // relative trailing row
     const bool okr = rr < nt;
@@ -309,10 +319,6 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
     const double y_r = P.acc[par].y[r];
     const double a_next = do_next ? P.a[r + (int64_t)(j + 1) * P.ld] : 0.0;
     if (tid < TD_NB) {
-        const double a1 = (tid < i) ? P.acc[par].t1[tid] : 0.0;
-        const double a2 = (tid < i) ? P.acc[par].t2[tid] : 0.0;
-        const double b1 = (tid < i) ? P.vt[(int64_t)base * TD_NB + tid] : 0.0;
-        const double b2 = (tid < i) ? P.wt[(int64_t)base * TD_NB + tid] : 0.0;
         t1s[tid] = a1;
         t2s[tid] = a2;
         vj1[tid] = b1;
@@ -325,11 +331,10 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
             s1 += __shfl_xor(s1, off, 64);
         }
         if (tid == 0) {
-            const double yv = P.acc[par].sc[0];
-            const double alpha = -0.5 * tau * tau * (yv - 2.0 * dot);
+            const double alpha = -0.5 * tau * tau * (yv_all - 2.0 * dot);
             // w at the first trailing row (v = 1 there): needed by every row for the next-column update
             scal[0] = alpha;
-            scal[1] = tau * (P.acc[par].y[base] - s1) + alpha;
+            scal[1] = tau * (y_first - s1) + alpha;
         }
     }
     __syncthreads();

@@ -232,6 +232,7 @@ def main():
         s, ut64 = pl.eigh_from_grm(k32, 1e-6)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
+        symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
         model = pl.SpectralModel(s, ut64, x, y)
         del ut64
         torch.cuda.synchronize()
@@ -248,6 +249,8 @@ def main():
                              ("scan", t5 - t4), ("rotate_k", tm.t.get("rotate", 0.0)),
                              ("assoc_k", tm.t.get("scan", 0.0))):
                 stage[key] = stage.get(key, 0.0) + val
+            kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
+            kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
             kern["grm_ms"] += grm_ms
             kern["grm_flops"] += float(n) * (n + 1) * len(grows)
             kern["rot_ms"] += tm.t.get("rotate", 0.0) * 1e3
@@ -327,6 +330,15 @@ def main():
                                                            "fetch" if args.mode == "lmm" else "fetch_fv"),
                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
                               "ms_per_step": kern["scan_ms"] / L},
+            "roofline_eigh": {"bound": "hbm", "kernel": "sytrd_symv_kernel (the dominant kernel by time: one launch "
+                                                        "per column of the tridiagonalisation)",
+                              "achieved": (kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)) / HBM_PEAK_GBS,
+                              "traffic": pmc_traffic_bytes("jx::sytrd_symv_kernel"),
+                              "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
+                              "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per "
+                                      "launch; HIP events around the mid-panel launch of every 64-column panel"},
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
             "null": {"lbd": null.lbd, "pve": null.pve},
             "device": {"cus": int(info[0]), "clock_khz": int(info[1]), "hbm_mib": int(info[2])},

@@ -179,7 +179,9 @@ int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *
                          double log10_lbd, double *d_out2, void *stream);
 
 /* Duration (ms, HIP events on the launch stream) of the MFMA kernel(s) issued by the most recent
- * jxg_grm_accumulate (which = 0) or jxg_rotate_packed (which = 1) call of this process.  Counterpart of the
+ * jxg_grm_accumulate (which = 0) or jxg_rotate_packed (which = 1) call of this process; which = 2: mean duration
+ * of the symv launches sampled by the most recent jxg_eigh_f64 (one per 64-column panel), which = 3: the mean
+ * algorithmic megabytes (lower triangle of the trailing matrix, f64) of those launches.  Counterpart of the
  * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
 float jxg_last_kernel_ms(int which);
 

@@ -19,6 +19,8 @@
 #include <rocblas/rocblas.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -403,6 +405,8 @@ __global__ void sytrd_finish_kernel(TdParams P) {
     if (j == P.n - 1) P.d[j] = P.a[j + (int64_t)j * P.ld];
 }
 
+extern float g_last_ms[4];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
+
 // d_a: (n,n) column-major symmetric (lower referenced), overwritten with the LAPACK dsytrd(lower) result.
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau) {
     if (n < 2) {
@@ -436,6 +440,17 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     P.e = d_e;
     P.tau = d_tau;
     const double minus1 = -1.0, one = 1.0;
+    // live roofline sample: the symv launch in the middle of every panel is bracketed by HIP events
+    // (one pair per panel = every 64th launch, uniformly spaced over the trailing sizes)
+    static std::vector<hipEvent_t> ev;
+    const int npanels = (n - 1 + TD_NB - 1) / TD_NB;
+    while ((int)ev.size() < 2 * npanels) {
+        hipEvent_t e;
+        JX_HIP(hipEventCreate(&e));
+        ev.push_back(e);
+    }
+    int nsamp = 0;
+    double samp_bytes = 0.0;
     for (int j0 = 0; j0 < n - 1; j0 += TD_NB) {
         const int pw = (n - 1 - j0 < TD_NB) ? (n - 1 - j0) : TD_NB;
         JX_HIP(hipMemsetAsync(acc_begin, 0, acc_bytes, st));
@@ -458,8 +473,15 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             if (ktiles < 1) ktiles = 1;
             if (ktiles > 64) ktiles = 64;
             const int nstrips = side * ((side + ktiles - 1) / ktiles);
+            const bool sample = (i == pw / 2);
+            if (sample) JX_HIP(hipEventRecord(ev[2 * nsamp], st));
             hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0, ktiles,
                                nstrips);
+            if (sample) {
+                JX_HIP(hipEventRecord(ev[2 * nsamp + 1], st));
+                samp_bytes += 4.0 * (double)nt * (double)nt + 4.0 * (double)nt;  // lower triangle incl. diagonal, f64
+                ++nsamp;
+            }
             hipLaunchKernelGGL(sytrd_update_kernel, dim3(nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
                                (i + 1 < pw) ? 1 : 0);
         }
@@ -477,6 +499,14 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     hipLaunchKernelGGL(sytrd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
     JX_LAUNCH_CHECK();
     JX_HIP(hipStreamSynchronize(st));  // workspace is freed on return
+    double samp_ms = 0.0;
+    for (int k = 0; k < nsamp; ++k) {
+        float ms = 0.f;
+        JX_HIP(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+        samp_ms += ms;
+    }
+    g_last_ms[2] = nsamp ? (float)(samp_ms / nsamp) : 0.f;
+    g_last_ms[3] = nsamp ? (float)(samp_bytes / nsamp / 1e6) : 0.f;
     return 0;
 }
 

@@ -196,6 +196,17 @@ int jxg_cross_dot(const void *d_k, int k_is_f64, int64_t n_full, const int32_t *
                   const int32_t *d_cols, int ncols, const double *d_alpha, double beta0, double *d_out,
                   void *stream);
 
+/* Matrix-free products with the 2-bit genotype matrix of a P32 image (n selected samples, rows = SNP records or NULL
+ * for all m_total); the decoded value of (SNP r, sample i) is d_lut[r][code], d_lut (nrows, 4) f32:
+ *   jxg_packed_tdot: d_out[r] = sum_i lut[r][code(r,i)] alpha[i]   (nrows)  `compute_malpha_from_meta_stream`,
+ *                    src/stats/gblup.rs:859-925 (and the Z'v half of src/math/pcg.rs:578-640);
+ *   jxg_packed_dot : d_out[i] = sum_r lut[r][code(r,i)] beta[r]    (n)      `predict_from_effect_stream`,
+ *                    src/stats/gblup.rs:1037-1103 (the Z v half). f64 accumulation; outputs are overwritten. */
+int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                    const float *d_lut, const double *d_alpha, double *d_out, void *stream);
+int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                   const float *d_lut, const double *d_beta, double *d_out, void *stream);
+
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
                        const float *d_wx, const double *d_a_chol, double ypy, int df, int with_plrt, double nullml,

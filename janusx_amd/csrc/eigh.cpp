@@ -3,6 +3,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -58,13 +59,25 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         DevBuf tau, c;
         if (tau.alloc(sizeof(double) * (size_t)n)) return 1;
         if (c.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
+        // JXGPU_EIGH_TRACE=1: synchronise and report after every stage (stderr), to locate a failing stage
+        const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
+        auto stage_done = [&](const char *what) -> int {
+            if (!trace) return 0;
+            JX_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[jxgpu eigh n=%d] %s done\n", n, what);
+            fflush(stderr);
+            return 0;
+        };
         if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
+        if (stage_done("sytrd")) return 1;
         rocblas_status rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
                                              info.as<rocblas_int>());
         if (rs != rocblas_status_success) return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
+        if (stage_done("dstedc")) return 1;
         rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
                               tau.as<double>(), c.as<double>(), n);
         if (rs != rocblas_status_success) return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+        if (stage_done("dormtr")) return 1;
         JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, st));
     }
     rocblas_int hinfo = 0;

@@ -200,6 +200,111 @@ __global__ __launch_bounds__(SCAN_THREADS) void cross_dot_kernel(const T *__rest
     if (threadIdx.x == 0) out[blockIdx.x] = v[0] + beta0;
 }
 
+
+// ---- matrix-free products with the 2-bit genotype matrix (P32 image: p32[tile][snp][32 B], 128 samples per record) --
+// The decoded value of (SNP r, sample i) is lut[r][code]: any of the reference's per-SNP decodes (mean-imputed
+// raw genotype, centred, standardised) is a 4-entry table, so M' alpha and M beta never materialise M.
+
+// out[r] += sum_i lut[r][code(r,i)] * alpha[i]  (`compute_malpha_from_meta_stream`, src/stats/gblup.rs:859-925;
+// also the Z'v half of the PCG operator, src/math/pcg.rs:578-640).  grid (ceil(nrows/256), ntiles); thread = SNP.
+__global__ __launch_bounds__(256) void packed_tdot_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                          const int32_t *__restrict__ rows, int nrows,
+                                                          const float *__restrict__ lut, const double *__restrict__ alpha,
+                                                          int n, double *__restrict__ out) {
+    __shared__ double a_sh[128];
+    __shared__ double a_tot;
+    const int tile = blockIdx.y;
+    if (threadIdx.x < 128) {
+        const int i = tile * 128 + threadIdx.x;
+        a_sh[threadIdx.x] = (i < n) ? alpha[i] : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 128; ++k) t += a_sh[k];
+        a_tot = t;
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+    const uint4 *p = reinterpret_cast<const uint4 *>(p32 + ((int64_t)tile * m_total + rec) * 32);
+    const uint4 w0 = p[0], w1 = p[1];
+    const uint32_t words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0;  // class sums of alpha for codes 01 (missing), 10 (het), 11 (hom alt)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t word = words[w];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t code = word & 3u;
+            word >>= 2;
+            const double a = a_sh[w * 16 + k];
+            c1 += (code == 1u) ? a : 0.0;
+            c2 += (code == 2u) ? a : 0.0;
+            c3 += (code == 3u) ? a : 0.0;
+        }
+    }
+    const double c0 = a_tot - c1 - c2 - c3;
+    const float *l = lut + (int64_t)r * 4;
+    const double v = (double)l[0] * c0 + (double)l[1] * c1 + (double)l[2] * c2 + (double)l[3] * c3;
+    if (v != 0.0) unsafeAtomicAdd(&out[r], v);
+}
+
+// out[i] += sum_r lut[r][code(r,i)] * beta[r]  (`predict_from_effect_stream`, src/stats/gblup.rs:1037-1103; the
+// Z v half of the PCG operator).  grid (ntiles, row slices of PD_SLICE); 128 threads x 2 row halves; records and
+// the per-row weight tables w[r][c] = lut[r][c] * beta[r] are staged through LDS 64 rows at a time.
+constexpr int PD_SLICE = 2048;
+__global__ __launch_bounds__(256) void packed_dot_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                         const int32_t *__restrict__ rows, int nrows,
+                                                         const float *__restrict__ lut, const double *__restrict__ beta,
+                                                         int n, double *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t rec_sh[64][32];
+    __shared__ double w_sh[64][4];
+    __shared__ double half_sh[128];
+    const int tile = blockIdx.x;
+    const int r_begin = blockIdx.y * PD_SLICE;
+    const int r_end = (r_begin + PD_SLICE < nrows) ? (r_begin + PD_SLICE) : nrows;
+    const int tid = threadIdx.x;
+    const int j = tid & 127, half = tid >> 7;   // sample within the tile, row parity group
+    double acc = 0.0;
+    for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+        const int cnt = (r_end - r0 < 64) ? (r_end - r0) : 64;
+        __syncthreads();
+        {   // 64 records x 32 B = 128 x 16 B
+            if (tid < 128) {
+                const int lr = tid >> 1, part = tid & 1;
+                uint4 v = make_uint4(0x55555555u, 0x55555555u, 0x55555555u, 0x55555555u);
+                if (lr < cnt) {
+                    const int64_t rec = rows ? (int64_t)rows[r0 + lr] : (int64_t)(r0 + lr);
+                    v = reinterpret_cast<const uint4 *>(p32 + ((int64_t)tile * m_total + rec) * 32)[part];
+                }
+                reinterpret_cast<uint4 *>(&rec_sh[lr][0])[part] = v;
+            } else {
+                const int k = tid - 128;           // 128 threads fill 64 x 4 weights, two each
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = k * 2 + u, lr = e >> 2, c = e & 3;
+                    w_sh[lr][c] = (lr < cnt) ? (double)lut[(int64_t)(r0 + lr) * 4 + c] * beta[r0 + lr] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        for (int lr = half; lr < cnt; lr += 2) {
+            const uint32_t code = (rec_sh[lr][j >> 2] >> (2 * (j & 3))) & 3u;
+            acc += w_sh[lr][code];
+        }
+    }
+    __syncthreads();
+    if (half == 1) half_sh[j] = acc;
+    __syncthreads();
+    if (half == 0) {
+        acc += half_sh[j];
+        const int i = tile * 128 + j;
+        if (i < n && acc != 0.0) unsafeAtomicAdd(&out[i], acc);
+    }
+}
+
 }  // namespace jx
 
 using namespace jx;
@@ -237,6 +342,32 @@ extern "C" int jxg_gblup_fit(double *d_k, int n, double ridge, const double *d_y
     for (int i = 0; i < n; ++i) sum += hs[i];
     for (int i = 0; i < 5; ++i) h_out[i] = ho[i + 1];
     h_out[5] = sum / (double)n;
+    return 0;
+}
+
+
+extern "C" int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                               const float *d_lut, const double *d_alpha, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)nrows, st));
+    dim3 grid((nrows + 255) / 256, (n + 127) / 128);
+    hipLaunchKernelGGL(packed_tdot_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_alpha, n,
+                       d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                              const float *d_lut, const double *d_beta, double *d_out, void *stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)n, st));
+    if (nrows <= 0) return 0;
+    dim3 grid((n + 127) / 128, (nrows + PD_SLICE - 1) / PD_SLICE);
+    hipLaunchKernelGGL(packed_dot_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_beta, n,
+                       d_out);
+    JX_LAUNCH_CHECK();
     return 0;
 }
 

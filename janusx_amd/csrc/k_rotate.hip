@@ -89,8 +89,16 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int j0 = blockIdx.x * 128;
-    const int r0 = blockIdx.y * 128;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch).  Every XCD owns the eigenvector
+    // column tiles ct = 8 g + xcd and walks the SNP row tiles of the block fastest, so the workgroups that are
+    // co-resident on an XCD stream the same two U planes (16 KB per k-step, read from HBM once and then hit in
+    // that XCD's L2) while each reads its own small payload panel (1 KB per k-step).
+    const int nrt = (nrows + 127) >> 7;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int ct = (local / nrt) * 8 + xcd;
+    if (ct * 128 >= ((n + 127) & ~127)) return;
+    const int j0 = ct * 128;
+    const int r0 = (local % nrt) * 128;
 
     if (tid < 16) seltab[tid] = make_selectors_r((uint32_t)tid).x;
 
@@ -393,7 +401,8 @@ extern "C" int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n,
         JX_HIP(hipEventCreate(&g_rot_a));
         JX_HIP(hipEventCreate(&g_rot_b));
     }
-    dim3 grid(nt, (nrows + 127) / 128);
+    const int nrt = (nrows + 127) / 128;
+    dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
     JX_HIP(hipEventRecord(g_rot_a, st));
     hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
                        (const uint4 *)d_lut16, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,

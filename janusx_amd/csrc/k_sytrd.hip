@@ -17,6 +17,7 @@
 //                            update of column j+1 and its norm for the next reflector.
 // Accumulators are double-buffered by column parity so no launch zeroes what a concurrent block still reads.
 #include <rocblas/rocblas.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -486,6 +487,11 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
                                (i + 1 < pw) ? 1 : 0);
         }
         JX_LAUNCH_CHECK();
+        if (getenv("JXGPU_EIGH_TRACE") && (j0 % (64 * TD_NB)) == 0) {
+            JX_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[jxgpu sytrd n=%d] panel at column %d reduced\n", n, j0);
+            fflush(stderr);
+        }
         const int j1 = j0 + pw;      // first row/col of the trailing matrix after this panel
         const int n2 = n - j1;
         if (n2 > 0) {
@@ -494,6 +500,11 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
                                                d_a + j1 + (int64_t)j0 * n, n, P.w + j1, n, &one,
                                                d_a + j1 + (int64_t)j1 * n, n);
             if (rs != rocblas_status_success) return fail("rocblas_dsyr2k failed: " + std::to_string((int)rs));
+            if (getenv("JXGPU_EIGH_TRACE") && (j0 % (64 * TD_NB)) == 0) {
+                JX_HIP(hipStreamSynchronize(st));
+                fprintf(stderr, "[jxgpu sytrd n=%d] syr2k after column %d done\n", n, j0);
+                fflush(stderr);
+            }
         }
     }
     hipLaunchKernelGGL(sytrd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);

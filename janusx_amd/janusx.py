@@ -851,6 +851,146 @@ def gblup_reml_grm(grm, train_sample_indices, y_train, test_sample_indices=None,
             np.zeros(0, dtype=np.float64))
 
 
+def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_indices=None,
+                          train_pred_local_indices=None, site_keep=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50,
+                          tol=1e-4, block_rows=4096, threads=0, return_variance_components=False, estimate_only=False,
+                          return_effect=False, row_source_indices=None, row_flip=None, row_maf=None,
+                          mmap_window_mb=None):
+    """src/stats/gblup.rs:1517-1958, metadata-streaming path (the one `python/janusx/gs/workflow.py:6300-6360` takes):
+    GRM of the training samples straight from the BED payload, spectral REML, then marker effects
+    effect_beta = (M' alpha - mean * sum(alpha)) / sum(var) and predictions alpha0 + M beta, M never materialised
+    (jxg_packed_tdot / jxg_packed_dot).  Returns the reference's 12-tuple (pred_train (k,1), pred_test (t,1), pve,
+    lambda, ml, reml, evd_backend, evd_elapsed, eff_m, sigma_g2, sigma_e2, effect (m) or empty)."""
+    import math
+    import torch
+    from . import pipeline as pl
+    from . import stats as st
+    from .bed import read_bed_payload
+    if not (math.isfinite(g_eps) and g_eps >= 0.0):
+        raise RuntimeError("g_eps must be finite and >= 0")
+    if not (math.isfinite(low) and math.isfinite(high) and low < high):
+        raise RuntimeError("low/high must be finite and low < high")
+    if int(max_iter) == 0:
+        raise RuntimeError("max_iter must be > 0")
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError("tol must be finite and > 0")
+    if row_source_indices is None or row_flip is None or row_maf is None:
+        raise RuntimeError("gblup_reml_packed_bed: only the metadata streaming path (row_source_indices, row_flip, "
+                           "row_maf) is built")
+    src = np.asarray(row_source_indices, dtype=np.int64).ravel()
+    if src.size == 0:
+        raise RuntimeError("row_source_indices must not be empty for metadata streaming path.")
+    if (src < 0).any():
+        raise RuntimeError("row_source_indices must be non-negative.")
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
+        raise RuntimeError(f"metadata length mismatch: row_source_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    packed, n_samples, _bim = read_bed_payload(prefix)
+    if n_samples == 0:
+        raise RuntimeError("No samples found in BED input.")
+    if src.max() >= packed.shape[0]:
+        raise RuntimeError("row_source_indices out of range")
+    tr = _c(train_sample_indices, np.int64).ravel()
+    if tr.size == 0:
+        raise RuntimeError("train_sample_indices must not be empty.")
+    if tr.min() < 0 or tr.max() >= n_samples:
+        raise RuntimeError("train_sample_indices out of range")
+    y = _c(y_train, np.float64).ravel()
+    if y.shape[0] != tr.shape[0]:
+        raise RuntimeError(f"y_train length mismatch: got {y.shape[0]}, expected {tr.shape[0]}")
+    if not np.all(np.isfinite(y)):
+        raise RuntimeError("y_train contains non-finite values.")
+    te = np.zeros(0, dtype=np.int64) if test_sample_indices is None else _c(test_sample_indices, np.int64).ravel()
+    if te.size and (te.min() < 0 or te.max() >= n_samples):
+        raise RuntimeError("test_sample_indices out of range")
+    n_tr = int(tr.shape[0])
+    if n_tr <= 1:
+        raise RuntimeError("GBLUP REML requires at least 2 training samples.")
+    pick = tr if train_pred_local_indices is None else tr[np.asarray(train_pred_local_indices, dtype=np.int64)]
+    m = int(src.shape[0])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    rows_payload = torch.from_numpy(np.ascontiguousarray(packed[src])).to(dev)
+    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
+    # per-row centring / variance (decode_meta_block_f32 :239-404; bedmath.rs:1359-1441 for a sample subset)
+    mafc = np.clip(maf, np.float32(0.0), np.float32(1.0))
+    if identity:
+        p64 = mafc.astype(np.float64)
+        mean64 = 2.0 * p64
+        var = 2.0 * p64 * (1.0 - p64)
+        mean32 = mean64.astype(np.float32)
+        row_mean = mean64
+    else:
+        mean32 = (np.float32(2.0) * mafc).astype(np.float32)
+        pg = np.clip(np.float32(0.5) * mean32, np.float32(0.0), np.float32(1.0))
+        var = np.maximum(np.float32(2.0) * pg * (np.float32(1.0) - pg), np.float32(0.0)).astype(np.float64)
+        row_mean = mean32.astype(np.float64)
+    var_sum = float(np.sum(var))
+    glut = st.grm_lut_from_mean_scale(mean32, np.ones(m, dtype=np.float32), flip)
+    panel = pl.Panel(rows_payload, n_samples, None if identity else tr)
+    acc = pl.grm_accumulate(panel, np.arange(m, dtype=np.int64), glut)
+    k = pl.grm_finalize(acc, n_tr, var_sum, torch.float64)
+    del acc
+    k.diagonal().add_(float(g_eps))
+    y_mean = float(np.sum(y) / n_tr)
+    yc = torch.from_numpy(y - y_mean).to(dev)
+    alpha = torch.empty(n_tr, dtype=torch.float64, device=dev)
+    fit = np.zeros(6, dtype=np.float64)
+    t0 = time.perf_counter()
+    check(lib().jxg_gblup_fit(k.data_ptr(), n_tr, 0.0, yc.data_ptr(), float(low), float(high), float(tol),
+                              int(max_iter), alpha.data_ptr(), fit.ctypes.data, stream))
+    evd_elapsed = time.perf_counter() - t0
+    lbd, beta_rot, q, ml, reml, mean_s = [float(v) for v in fit]
+    n_eff = float(n_tr - 1)
+    sg2 = q / max(n_eff, 1.0)
+    se2 = lbd * sg2
+    var_g = sg2 * max(mean_s, 0.0)
+    den = var_g + se2
+    pve = var_g / den if (math.isfinite(den) and den > 0.0) else float("nan")
+    beta0 = y_mean + beta_rot
+    pred_tr = np.zeros((0, 1))
+    pred_te = np.zeros((0, 1))
+    effect = np.zeros(0, dtype=np.float64)
+    if (not estimate_only) or return_effect:
+        mg = np.clip(np.float32(2.0) * maf, np.float32(0.0), np.float32(2.0)).astype(np.float32)
+        rlut = np.empty((m, 4), dtype=np.float32)      # mean-imputed raw genotype (bedmath.rs:983-988)
+        rlut[:, 0] = np.where(flip, 2.0, 0.0)
+        rlut[:, 1] = mg
+        rlut[:, 2] = 1.0
+        rlut[:, 3] = np.where(flip, 0.0, 2.0)
+        rlut_t = torch.from_numpy(rlut).to(dev)
+        m_alpha_t = torch.empty(m, dtype=torch.float64, device=dev)
+        check(lib().jxg_packed_tdot(panel.p32.data_ptr(), panel.m, n_tr, None, m, rlut_t.data_ptr(), alpha.data_ptr(),
+                                    m_alpha_t.data_ptr(), stream))
+        m_alpha = m_alpha_t.cpu().numpy()
+        alpha_sum = float(alpha.sum().item())
+        mean_sq = float(np.sum(row_mean * row_mean))
+        mean_malpha = float(np.sum(row_mean * m_alpha))
+        inv_var = 1.0 / max(var_sum, 1e-12)
+        effect = (m_alpha - row_mean * alpha_sum) * inv_var
+        alpha0 = beta0 + (mean_sq * alpha_sum - mean_malpha) * inv_var
+        if not estimate_only:
+            beta_t = torch.from_numpy(effect).to(dev)
+
+            def predict(idx):
+                if len(idx) == 0:
+                    return np.zeros((0, 1))
+                pan = pl.Panel(rows_payload, n_samples, np.asarray(idx, dtype=np.int64))
+                out = torch.empty(len(idx), dtype=torch.float64, device=dev)
+                check(lib().jxg_packed_dot(pan.p32.data_ptr(), pan.m, len(idx), None, m, rlut_t.data_ptr(),
+                                           beta_t.data_ptr(), out.data_ptr(), stream))
+                return (out.cpu().numpy() + alpha0).reshape(-1, 1)
+
+            pred_tr = predict(pick)
+            pred_te = predict(te)
+    sg2_o = sg2 if return_variance_components else float("nan")
+    se2_o = se2 if return_variance_components else float("nan")
+    return (pred_tr, pred_te, pve, lbd, ml, reml, "rocsolver", evd_elapsed, m, sg2_o, se2_o,
+            effect if return_effect else np.zeros(0, dtype=np.float64))
+
+
 def gblup_reml_npy_grm(grm_path, train_sample_indices, y_train, test_sample_indices=None,
                        train_pred_local_indices=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50, tol=1e-4,
                        threads=0, return_variance_components=False, estimate_only=False):

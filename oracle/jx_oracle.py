@@ -1039,3 +1039,79 @@ def gblup_reml_grm(k_full, train_idx, y_train, test_idx=None, g_eps=1e-8, low=-6
     pred_train = k_full[np.ix_(tr, tr)].astype(np.float64) @ fit["alpha"] + fit["beta0"]
     pred_test = k_full[np.ix_(te, tr)].astype(np.float64) @ fit["alpha"] + fit["beta0"]
     return pred_train, pred_test, fit
+
+
+def gblup_reml_packed_meta(packed, n_samples, row_source_indices, row_flip, row_maf, train_idx, y_train,
+                           test_idx=None, train_pred_local=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50,
+                           tol=1e-4, block_rows=65536):
+    """Metadata-streaming path of `gblup_reml_packed_bed` (src/stats/gblup.rs:1594-1958): GRM of the training samples
+    from the 2-bit payload (`build_grm_from_meta_stream` :406-857 with `decode_meta_block_f32` :239-404, Additive mode;
+    sample-subset rows through `decode_subset_row_from_full_scratch`, src/math/bedmath.rs:1359-1441, method 1), the
+    spectral REML fit (:1756-1848), then marker effects instead of cross-GRM rows: m_alpha = M' alpha over the
+    mean-imputed raw genotypes (`compute_malpha_from_meta_stream` :859-925, decode src/math/bedmath.rs:940-1010),
+    effect_beta / effect_alpha0 (:1865-1882) and predictions alpha0 + M beta (`predict_from_effect_stream` :1037-1103).
+    Returns (pred_train, pred_test, fit dict incl. effect_beta, effect_alpha0, var_sum)."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    src = np.asarray(row_source_indices, dtype=np.int64)
+    flip = np.asarray(row_flip, dtype=bool)
+    maf = np.asarray(row_maf, dtype=np.float32)
+    tr = np.asarray(train_idx, dtype=np.int64)
+    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    n_tr = tr.shape[0]
+    m = src.shape[0]
+    codes = unpack_codes(packed[src], n_samples)
+    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
+    z = np.empty((m, n_tr), dtype=np.float32)
+    var = np.zeros(m, dtype=np.float64)
+    row_sum = np.zeros(m, dtype=np.float64)
+    for r in range(m):
+        if identity:
+            p = float(min(max(maf[r], F32(0.0)), F32(1.0)))
+            mean_g = 2.0 * p
+            var[r] = 2.0 * p * (1.0 - p)
+            mg32 = F32(mean_g)
+            lut = np.array([2.0, mg32, 1.0, 0.0] if flip[r] else [0.0, mg32, 1.0, 2.0], dtype=np.float32)
+            z[r] = lut[codes[r]] - mg32
+            row_sum[r] = mean_g * float(n_tr)
+        else:
+            dmg = F32(2.0) * min(max(maf[r], F32(0.0)), F32(1.0))
+            lut = np.array([2.0, -9.0, 1.0, 0.0] if flip[r] else [0.0, -9.0, 1.0, 2.0], dtype=np.float32)
+            gsub = lut[codes[r, tr]]
+            gsub = np.where(gsub >= F32(0.0), gsub, dmg).astype(np.float32)
+            z[r] = (gsub - dmg) * F32(1.0)
+            pg = min(max(F32(0.5) * dmg, F32(0.0)), F32(1.0))
+            var[r] = float(max(F32(2.0) * pg * (F32(1.0) - pg), F32(0.0)))
+            row_sum[r] = float(dmg) * float(n_tr)
+    acc = np.zeros((n_tr, n_tr), dtype=np.float64)
+    for r0 in range(0, m, block_rows):
+        blk = z[r0:r0 + block_rows]
+        acc += (blk.T @ blk).astype(np.float64)          # f32 SYRK per block, f64 merge (grm.rs:1700-1772)
+    var_sum = float(np.sum(var))
+    k = acc * (1.0 / var_sum)
+    k = np.tril(k) + np.tril(k, -1).T
+    k[np.diag_indices_from(k)] += g_eps
+    fit = gblup_fit(k, y_train, low, high, tol, max_iter)
+    alpha = fit["alpha"]
+    # mean-imputed raw genotypes
+    mg = np.clip(F32(2.0) * maf, F32(0.0), F32(2.0)).astype(np.float32)
+
+    def raw(cols):
+        out = np.empty((m, len(cols)), dtype=np.float32)
+        for r in range(m):
+            lut = np.array([2.0, mg[r], 1.0, 0.0] if flip[r] else [0.0, mg[r], 1.0, 2.0], dtype=np.float32)
+            out[r] = lut[codes[r, cols]]
+        return out
+
+    m_alpha = raw(tr).astype(np.float64) @ alpha
+    row_mean = row_sum / float(n_tr)
+    alpha_sum = float(np.sum(alpha))
+    mean_sq = float(np.sum(row_mean * row_mean))
+    mean_malpha = float(np.sum(row_mean * m_alpha))
+    inv_var = 1.0 / max(var_sum, 1e-12)
+    effect_beta = (m_alpha - row_mean * alpha_sum) * inv_var
+    effect_alpha0 = fit["beta0"] + (mean_sq * alpha_sum - mean_malpha) * inv_var
+    pick = tr if train_pred_local is None else tr[np.asarray(train_pred_local, dtype=np.int64)]
+    pred_train = effect_alpha0 + raw(pick).astype(np.float64).T @ effect_beta
+    pred_test = effect_alpha0 + raw(te).astype(np.float64).T @ effect_beta if len(te) else np.zeros(0)
+    fit = dict(fit, effect_beta=effect_beta, effect_alpha0=effect_alpha0, var_sum=var_sum, m_alpha=m_alpha)
+    return pred_train, pred_test, fit

@@ -761,3 +761,106 @@ def test_packed_prep_and_grm_packed_bed(oracle, tmp_path):
     ref = oracle.grm_packed(packed[k_keep], n, np.zeros(int(k_keep.sum()), dtype=bool), a_keep[k_keep], None, 1)
     ref = ref[0] if isinstance(ref, tuple) else ref
     assert eff == int(k_keep.sum()) and ns == n and _grm_err(kk, ref) < TOL
+
+
+def test_tiny_panel_and_chunked_invariants(oracle, oracle_c):
+    """The reference's own smoke invariants (python/janusx/assoc/smoke.py:21-87): a toy panel (n = 8, m = 5) goes
+    through every stage, and chunked == unchunked.  Plus empty inputs."""
+    from janusx_amd import janusx as jxrs
+    n, m = 8, 5
+    g = np.array([[0, 1, 2, 0, 1, 2, 0, 1],
+                  [2, 2, 1, 0, 0, 1, 2, 0],
+                  [0, 0, 0, 1, 2, 2, 1, 1],
+                  [1, 2, -9, 0, 1, 0, 2, 2],
+                  [2, 0, 1, 1, 0, 2, 0, 1]], dtype=np.int8)
+    packed = bed.pack_dosage(g)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.0, 1.0, 1.0)
+    assert keep.all()
+    k = jxrs.grm_packed_f32(packed, n, flip, maf, None, 1)
+    k_ref = oracle.grm_packed(packed, n, flip, maf, None, 1)
+    k_ref = k_ref[0] if isinstance(k_ref, tuple) else k_ref
+    assert _grm_err(k, k_ref) < TOL
+    ev = jxrs.rust_eigh_from_array_f64(k_ref.astype(np.float64) + 1e-6 * np.eye(n))
+    s, u = ev[0], ev[1]
+    s_ref, _ = oracle.eigh_sym(k_ref.astype(np.float64) + 1e-6 * np.eye(n))
+    assert np.max(np.abs(s - s_ref)) < 1e-12 and np.max(np.abs(u.T @ u - np.eye(n))) < 1e-12
+    u_t = np.ascontiguousarray(u.T.astype(np.float32))
+    y = np.array([0.3, -1.2, 0.8, 1.9, -0.4, 0.1, 2.2, -0.9])
+    x = np.ones((n, 1))
+    xr, yr = jxrs.lmm_rotate_x_y_with_ut_f64(u_t, x, y)
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf)
+    full = jxrs.lmm_reml_chunk_from_snp_f32(s, xr, yr.ravel(), -5.0, 5.0, gd, u_t, max_iter=50, tol=1e-3)
+    ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, u_t), s, xr, yr.ravel(), -5.0, 5.0, 50, 1e-3)
+    be, se, pe = _assoc_err(full, ref)
+    assert max(be, se) < TOL, (be, se, pe)
+    parts = np.concatenate([jxrs.lmm_reml_chunk_from_snp_f32(s, xr, yr.ravel(), -5.0, 5.0, gd[a:b], u_t, max_iter=50, tol=1e-3)
+                            for a, b in ((0, 2), (2, 3), (3, 5))])
+    assert np.array_equal(parts, full, equal_nan=True)          # chunked == unchunked, bit for bit
+    fv = jxrs.fvlmm_assoc_chunk_from_snp_f32(s, xr, yr.ravel(), 0.0, gd, u_t)
+    fv_parts = np.concatenate([jxrs.fvlmm_assoc_chunk_from_snp_f32(s, xr, yr.ravel(), 0.0, gd[a:b], u_t)
+                               for a, b in ((0, 1), (1, 5))])
+    assert np.array_equal(fv_parts, fv, equal_nan=True)
+    # empty chunk / empty panel
+    assert jxrs.lmm_reml_chunk_from_snp_f32(s, xr, yr.ravel(), -5.0, 5.0, gd[:0], u_t).shape == (0, 3)
+    assert jxrs.fvlmm_assoc_chunk_f32(s, xr, yr.ravel(), 0.0, gd[:0]).shape == (0, 3)
+    assert jxrs.bed_row_counts(packed[:0], n).shape == (0, 3)
+    with pytest.raises(RuntimeError):
+        jxrs.lmm_reml_chunk_from_snp_f32(s, xr, yr.ravel(), -5.0, 5.0, gd[:, :7], u_t)   # wrong sample count
+
+
+@pytest.mark.parametrize("subset", [True, False])
+def test_gblup_reml_packed_bed(oracle, tmp_path, subset):
+    """`gblup_reml_packed_bed`, metadata-streaming path (src/stats/gblup.rs:1594-1958): GRM from the payload on the
+    training samples, REML, marker effects and predictions by the matrix-free M'alpha / M beta kernels."""
+    from janusx_amd import janusx as jxrs
+    n, m = 190, 420
+    packed, g = bed.synth_panel_numpy(n, m, seed=81, missing_rate=0.02)
+    y_all = bed.synth_phenotype(g, n_causal=30, pve=0.7, seed=81)
+    prefix = str(tmp_path / "gb")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["C"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    pk, miss, maf, std, flip0, keep, _, _ = jxrs.prepare_bed_2bit_packed(prefix, 0.02, 0.05, 0.0)
+    src = np.nonzero(keep)[0]
+    flip = np.random.default_rng(3).random(len(src)) < 0.3       # the metadata may carry flips
+    rng = np.random.default_rng(12)
+    if subset:
+        perm = rng.permutation(n)
+        tr, te = np.sort(perm[:140]), np.sort(perm[140:])
+    else:
+        tr, te = np.arange(n), np.array([3, 17, 3, 100])
+    ptr_ref, pte_ref, fit = oracle.gblup_reml_packed_meta(packed, n, src, flip, maf, tr, y_all[tr], te)
+    out = jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr], te, None, None, 1e-8, -6.0, 6.0, 50, 1e-4, 4096, 1, True,
+                                     False, True, row_source_indices=src, row_flip=flip, row_maf=maf)
+    ptr, pte, pve, lbd, ml, reml, _, _, eff_m, sg2, se2, effect = out
+    assert eff_m == len(src) and ptr.shape == (len(tr), 1) and pte.shape == (len(te), 1)
+    # Brent stops at tol = 1e-4 in log10(lambda): the optimum itself is only defined to that tolerance (the GRM here
+    # comes from the fp16x2 MFMA kernel, the oracle's from an f32 GEMM), the likelihood values are flat there
+    assert abs(lbd - fit["lbd"]) < 3e-4 * fit["lbd"] and abs(reml - fit["reml"]) < 1e-7 * abs(fit["reml"])
+    assert abs(ml - fit["ml"]) < 1e-7 * abs(fit["ml"]) and abs(pve - fit["pve"]) < 1e-4
+    assert abs(sg2 - fit["sigma_g2"]) < 3e-4 * fit["sigma_g2"] and abs(se2 - fit["sigma_e2"]) < 3e-4 * fit["sigma_e2"]
+    scale = float(np.std(y_all))
+    assert np.max(np.abs(effect - fit["effect_beta"])) < 1e-4 * np.max(np.abs(fit["effect_beta"]))
+    assert np.max(np.abs(ptr.ravel() - ptr_ref)) < 1e-4 * scale and np.max(np.abs(pte.ravel() - pte_ref)) < 1e-4 * scale
+    # the matrix-free kernels on their own: exact f64 sums of table values
+    import torch
+    from janusx_amd import pipeline as pl
+    from janusx_amd._lib import lib, check
+    dev = torch.device("cuda:0")
+    pan = pl.Panel(torch.from_numpy(np.ascontiguousarray(packed[src])).to(dev), n, tr if subset else None)
+    lut = rng.normal(size=(len(src), 4)).astype(np.float32)
+    a = rng.normal(size=len(tr))
+    b = rng.normal(size=len(src))
+    codes = oracle.unpack_codes(packed[src], n)[:, tr]
+    dec = np.take_along_axis(lut.astype(np.float64), codes.astype(np.int64), axis=1)
+    lut_t, a_t, b_t = torch.from_numpy(lut).to(dev), torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    o1 = torch.empty(len(src), dtype=torch.float64, device=dev)
+    o2 = torch.empty(len(tr), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().jxg_packed_tdot(pan.p32.data_ptr(), pan.m, len(tr), None, len(src), lut_t.data_ptr(), a_t.data_ptr(),
+                                o1.data_ptr(), st))
+    check(lib().jxg_packed_dot(pan.p32.data_ptr(), pan.m, len(tr), None, len(src), lut_t.data_ptr(), b_t.data_ptr(),
+                               o2.data_ptr(), st))
+    assert np.max(np.abs(o1.cpu().numpy() - dec @ a)) < 1e-11 and np.max(np.abs(o2.cpu().numpy() - dec.T @ b)) < 1e-11
+    with pytest.raises(RuntimeError):
+        jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr])       # site_keep route is not built

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "jx_common.h"
 
@@ -17,6 +18,11 @@ int launch_add_diag(double *d_a, int n, int64_t ld, double ridge, hipStream_t st
 int launch_symmetrize(double *d_a, int n, hipStream_t st);
 // k_sytrd.hip: two-kernels-per-column Householder tridiagonalisation, LAPACK dsytrd(lower) output format
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau);
+// k_stedc.hip: one Cuppen merge over two rocSOLVER dstedc halves (n beyond rocSOLVER's 32-bit limit)
+int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
+                std::vector<int> &h_perm);
+int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
+constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
 
 static rocblas_handle g_handle = nullptr;
 static std::mutex g_handle_mu;
@@ -46,6 +52,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
     DevBuf e, info;
     if (e.alloc(sizeof(double) * (size_t)n)) return 1;
     if (info.alloc(sizeof(rocblas_int))) return 1;
+    JX_HIP(hipMemsetAsync(info.p, 0, sizeof(rocblas_int), st));
     // symmetric input: row-major == column-major; the lower triangle is referenced.
     const char *mode = getenv("JXGPU_EIGH");
     const bool use_lib = (n < 256) || (mode && strcmp(mode, "rocsolver") == 0);
@@ -70,15 +77,39 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         };
         if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
         if (stage_done("sytrd")) return 1;
-        rocblas_status rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
-                                             info.as<rocblas_int>());
-        if (rs != rocblas_status_success) return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
+        const char *sm = getenv("JXGPU_STEDC");
+        // own divide-and-conquer merges above 2560 rows (3-5 % faster than rocSOLVER's top levels at n = 5000..20000
+        // and the only way past n = 46340); JXGPU_STEDC=rocsolver / split and JXGPU_STEDC_LEAF override
+        bool split = n >= 4096;
+        if (sm && strcmp(sm, "rocsolver") == 0 && n <= kRocsolverStedcMaxN) split = false;
+        if (sm && strcmp(sm, "split") == 0 && n >= 64) split = true;
+        int leaf = getenv("JXGPU_STEDC_LEAF") ? atoi(getenv("JXGPU_STEDC_LEAF")) : 2560;
+        if (leaf < 2) leaf = 2;
+        if (leaf > kRocsolverStedcMaxN) leaf = kRocsolverStedcMaxN;
+        std::vector<int> perm;
+        rocblas_status rs = rocblas_status_success;
+        if (split) {
+            if (stedc_split(h, st, n, d_w, e.as<double>(), c.as<double>(), leaf, perm)) return 1;
+        } else {
+            rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
+                                  info.as<rocblas_int>());
+            if (rs != rocblas_status_success)
+                return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
+        }
         if (stage_done("dstedc")) return 1;
         rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
                               tau.as<double>(), c.as<double>(), n);
         if (rs != rocblas_status_success) return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
         if (stage_done("dormtr")) return 1;
-        JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (split) {
+            DevBuf dperm;
+            if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;
+            JX_HIP(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+            if (launch_gather_cols(c.as<double>(), dperm.as<int>(), n, d_a, st)) return 1;
+            JX_HIP(hipStreamSynchronize(st));
+        } else {
+            JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, st));
+        }
     }
     rocblas_int hinfo = 0;
     JX_HIP(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, st));

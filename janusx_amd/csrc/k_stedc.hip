@@ -1,0 +1,631 @@
+// Symmetric tridiagonal eigensolver by one Cuppen divide-and-conquer merge on top of two rocSOLVER `dstedc` halves.
+// rocSOLVER 7.2's dstedc faults once n^2 exceeds 2^31 (n > 46340; measured at n = 50 000, BASELINE config C4), so the
+// eigendecomposition behind src/math/eigh.rs:1422-1528 needs its own top level there: T = diag(T1', T2') + rho u u'
+// (LAPACK dlaed0/dlaed1 organisation: deflation as in dlaed2, secular equation in the origin-shifted form of dlaed4,
+// eigenvectors from the Gu-Eisenstat / Loewner re-derived z as in dlaed3).  All O(n^2) and O(n^3) work runs on the
+// device; the O(n) deflation scan is host code.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int SD_THREADS = 256;
+constexpr int SD_WAVES = SD_THREADS / 64;
+
+__device__ __forceinline__ double sd_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double sd_wave_prod(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v *= __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ void sd_tear_kernel(double *d2, const double *amt) {
+    if (threadIdx.x < 2) d2[threadIdx.x] -= amt[threadIdx.x];
+}
+
+// z = [last row of Q1 ; sgn * first row of Q2] / sqrt(2)   (dlaed1: the rank-one vector in the eigenbasis)
+__global__ void sd_extract_z_kernel(const double *__restrict__ q1, int k1, const double *__restrict__ q2, int k2,
+                                    double sgn, double *__restrict__ z) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const double r = 0.70710678118654752440;
+    if (j < k1) z[j] = q1[(int64_t)j * k1 + (k1 - 1)] * r;
+    else if (j < k1 + k2) z[j] = sgn * q2[(int64_t)(j - k1) * k2] * r;
+}
+
+// Secular equation 1 + rho sum_j z_j^2 / (d_j - lambda) = 0, root i in (d_i, d_{i+1}) (the last one in
+// (d_{K-1}, d_{K-1} + rho |z|^2)).  One wave per root.  The root is kept as (origin pole, offset tau) so that every
+// d_j - lambda = (d_j - d_org) - tau is formed without cancellation (dlaed4); iteration = the two-pole rational
+// interpolation of dlaed4 (poles i and i+1) safeguarded by a bracket.
+__global__ __launch_bounds__(SD_THREADS) void sd_secular_kernel(const double *__restrict__ d,
+                                                                const double *__restrict__ z, int K, double rho,
+                                                                double *__restrict__ tau_out, int *__restrict__ org_out,
+                                                                double *__restrict__ lam_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * SD_WAVES + (threadIdx.x >> 6);
+    if (i >= K) return;
+    const double eps = 2.220446049250313e-16;
+    const bool last = (i == K - 1);
+    const double di = d[i];
+    double znorm2 = 0.0;
+    if (last) {
+        for (int j = lane; j < K; j += 64) znorm2 += z[j] * z[j];
+        znorm2 = sd_wave_sum(znorm2);
+    }
+    const double dip1 = last ? di + rho * znorm2 : d[i + 1];
+    const double delta = dip1 - di;
+    // which half of the interval holds the root: sign of f at the midpoint, evaluated around pole i
+    int org = i;
+    {
+        const double half = 0.5 * delta;
+        double acc = 0.0;
+        for (int j = lane; j < K; j += 64) acc += z[j] * z[j] / ((d[j] - di) - half);
+        const double fmid = 1.0 + rho * sd_wave_sum(acc);
+        if (!last && fmid < 0.0) org = i + 1;
+    }
+    const double dorg = d[org];
+    const double A = di - dorg;                    // 0 or -delta
+    const double B = dip1 - dorg;                  // +delta or 0 (for the last root: the virtual upper end)
+    double lo = (org == i) ? 0.0 : -0.5 * delta;
+    double hi = (org == i) ? (last ? delta : 0.5 * delta) : 0.0;
+    // starting point: the two nearest poles exactly, the rest frozen at the midpoint (dlaed4's initial guess)
+    double tau;
+    {
+        const double mid = 0.5 * (lo + hi);
+        double rest = 0.0;
+        for (int j = lane; j < K; j += 64)
+            if (j != i && (last || j != i + 1)) rest += z[j] * z[j] / ((d[j] - dorg) - mid);
+        const double c = 1.0 + rho * sd_wave_sum(rest);
+        const double a2 = rho * z[i] * z[i];
+        const double b2 = last ? 0.0 : rho * z[i + 1] * z[i + 1];
+        // c (A - t)(B - t) + a2 (B - t) + b2 (A - t) = 0
+        const double qa = c, qb = -(c * (A + B) + a2 + b2), qc = c * A * B + a2 * B + b2 * A;
+        tau = mid;
+        if (last) {
+            // one pole: c + a2 / (A - t) = 0
+            if (c > 0.0) {
+                const double t = A + a2 / c;
+                if (t > lo && t < hi) tau = t;
+            }
+        } else if (qa != 0.0) {
+            const double disc = qb * qb - 4.0 * qa * qc;
+            if (disc >= 0.0) {
+                const double sq = sqrt(disc);
+                const double qq = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+                const double t1 = qq / qa, t2 = (qq != 0.0) ? qc / qq : t1;
+                if (t1 > lo && t1 < hi) tau = t1;
+                else if (t2 > lo && t2 < hi) tau = t2;
+            }
+        } else if (qb != 0.0) {
+            const double t = -qc / qb;
+            if (t > lo && t < hi) tau = t;
+        }
+    }
+    for (int it = 0; it < 80; ++it) {
+        double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
+        for (int j = lane; j < K; j += 64) {
+            const double dl = (d[j] - dorg) - tau;
+            const double t = z[j] / dl;
+            const double zt = z[j] * t;   // z^2 / (d_j - lambda)
+            const double t2 = t * t;      // z^2 / (d_j - lambda)^2
+            if (j <= i) {
+                psi += zt;
+                dpsi += t2;
+            } else {
+                phi += zt;
+                dphi += t2;
+            }
+        }
+        psi = rho * sd_wave_sum(psi);
+        dpsi = rho * sd_wave_sum(dpsi);
+        phi = rho * sd_wave_sum(phi);
+        dphi = rho * sd_wave_sum(dphi);
+        const double w = 1.0 + psi + phi;
+        const double dw = dpsi + dphi;
+        const double erretm = 8.0 * (phi - psi) + 2.0 + fabs(tau) * dw;
+        if (fabs(w) <= eps * erretm) break;
+        if (w > 0.0) hi = tau; else lo = tau;      // f is increasing between two poles
+        if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi))) break;
+        const double D1 = A - tau;                  // d_i - lambda (< 0)
+        double eta;
+        if (last) {
+            // single-pole model of psi around d_i: c + p / (D1 - eta) = 0
+            const double c = w - dpsi * D1, p = dpsi * D1 * D1;
+            eta = (c > 0.0) ? (D1 + p / c) : -w / dw;
+        } else {
+            const double D2 = B - tau;              // d_{i+1} - lambda (> 0)
+            const double c = w - dpsi * D1 - dphi * D2;
+            const double a = (D1 + D2) * w - D1 * D2 * dw;
+            const double b = D1 * D2 * w;
+            if (c == 0.0) {
+                eta = (a != 0.0) ? b / a : -w / dw;
+            } else {
+                const double disc = sqrt(fabs(a * a - 4.0 * b * c));
+                eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+            }
+        }
+        if (!isfinite(eta) || w * eta > 0.0) eta = -w / dw;
+        double tn = tau + eta;
+        if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
+        if (tn == tau) break;
+        tau = tn;
+    }
+    if (lane == 0) {
+        tau_out[i] = tau;
+        org_out[i] = org;
+        lam_out[i] = dorg + tau;
+    }
+}
+
+// zhat_j = sign(z_j) sqrt( prod_i (lambda_i - d_j) / prod_{i != j} (d_i - d_j) ) / sqrt(rho)  (dlaed3: the z for which the
+// computed lambdas are the exact roots, which is what makes the eigenvectors orthogonal).  One wave per j.
+__global__ __launch_bounds__(SD_THREADS) void sd_lowner_kernel(const double *__restrict__ d, const double *__restrict__ z,
+                                                               int K, double rho, const double *__restrict__ tau,
+                                                               const int *__restrict__ org, double *__restrict__ zhat) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * SD_WAVES + (threadIdx.x >> 6);
+    if (j >= K) return;
+    const double dj = d[j];
+    double prod = 1.0;
+    for (int i = lane; i < K; i += 64) {
+        const double num = (d[org[i]] - dj) + tau[i];      // lambda_i - d_j, cancellation-free
+        if (i == j) prod *= num;
+        else prod *= num / (d[i] - dj);
+    }
+    prod = sd_wave_prod(prod);
+    if (lane == 0) {
+        const double v = sqrt(fabs(prod) / rho);
+        zhat[j] = (z[j] < 0.0) ? -v : v;
+    }
+}
+
+// 1 / || ( zhat_j / (d_j - lambda_i) )_j ||  per root i.  One wave per i.
+__global__ __launch_bounds__(SD_THREADS) void sd_colnorm_kernel(const double *__restrict__ d,
+                                                                const double *__restrict__ zhat, int K,
+                                                                const double *__restrict__ tau,
+                                                                const int *__restrict__ org, double *__restrict__ invn) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * SD_WAVES + (threadIdx.x >> 6);
+    if (i >= K) return;
+    const double dorg = d[org[i]], t = tau[i];
+    double acc = 0.0;
+    for (int j = lane; j < K; j += 64) {
+        const double v = zhat[j] / ((d[j] - dorg) - t);
+        acc += v * v;
+    }
+    acc = sd_wave_sum(acc);
+    if (lane == 0) invn[i] = 1.0 / sqrt(acc);
+}
+
+// U[r, i] = zhat_j / (d_j - lambda_i) * invn_i  for the kept entries j = rowmap[r]  (column-major, ld = ldu)
+__global__ __launch_bounds__(SD_THREADS) void sd_form_u_kernel(const double *__restrict__ d,
+                                                               const double *__restrict__ zhat,
+                                                               const double *__restrict__ tau,
+                                                               const int *__restrict__ org,
+                                                               const double *__restrict__ invn,
+                                                               const int *__restrict__ rowmap, int nrows, int K,
+                                                               double *__restrict__ u, int64_t ldu) {
+    const int r = blockIdx.x * SD_THREADS + threadIdx.x;
+    const int i = blockIdx.y;
+    if (r >= nrows || i >= K) return;
+    const int j = rowmap[r];
+    u[(int64_t)i * ldu + r] = zhat[j] / ((d[j] - d[org[i]]) - tau[i]) * invn[i];
+}
+
+// columns x <- c x + s y ; y <- -s x + c y   (drot on two columns of length n)
+__global__ void sd_rot_kernel(double *__restrict__ x, double *__restrict__ y, int n, double c, double s) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        const double a = x[r], b = y[r];
+        x[r] = c * a + s * b;
+        y[r] = c * b - s * a;
+    }
+}
+
+// dst[:, c] (n rows, ld ldd) = [zeros(off) ; src column ; zeros]  for a list of column pairs
+__global__ void sd_place_cols_kernel(const double *__restrict__ src, int64_t lds, int rows, const int *__restrict__ scol,
+                                     double *__restrict__ dst, int64_t ldd, int n, int row_off,
+                                     const int *__restrict__ dcol, int ncols) {
+    const int c = blockIdx.y;
+    if (c >= ncols) return;
+    const double *s = src + (int64_t)scol[c] * lds;
+    double *t = dst + (int64_t)dcol[c] * ldd;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int rr = r - row_off;
+        t[r] = (rr >= 0 && rr < rows) ? s[rr] : 0.0;
+    }
+}
+
+// in-place left compaction of the kept columns of a column-major matrix (keep[] ascending)
+__global__ void sd_copy_col_kernel(const double *__restrict__ src, double *__restrict__ dst, int rows) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) dst[r] = src[r];
+}
+
+namespace {
+// Stream-ordered bump allocator over one device block: every temporary of the recursion is carved from it, so a
+// merge performs no hipMalloc / hipFree (each hipFree is a device-wide synchronisation).  Reuse after a reset is
+// safe because all work of one eigendecomposition is ordered on a single stream.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    void *take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > cap) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+};
+struct ABuf {
+    void *p = nullptr;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+struct DcCtx {
+    rocblas_handle h;
+    hipStream_t st;
+    int leaf;
+    Arena ar;
+    const double *hd0, *he0;              // host copy of the tridiagonal (whole problem)
+    double *d_base, *e_base;              // device d / e of the whole problem (offsets recover the host index)
+    std::vector<std::vector<char>> keep;  // host staging blocks that must outlive their asynchronous copies
+    template <class T> const T *stage(const std::vector<T> &v) {
+        keep.emplace_back((const char *)v.data(), (const char *)v.data() + sizeof(T) * v.size());
+        return reinterpret_cast<const T *>(keep.back().data());
+    }
+};
+#define SD_TAKE(buf, bytes)                                                        \
+    do {                                                                           \
+        (buf).p = C.ar.take(bytes);                                                \
+        if (!(buf).p) return fail("stedc: workspace arena exhausted");             \
+    } while (0)
+
+struct Loc {      // where the current image of a basis column lives
+    int kind;     // 0: column of Q1 (rows [0,k1)), 1: column of Q2 (rows [k1,n)), 2: dense n-vector in the side buffer
+    int idx;
+};
+}  // namespace
+
+// Recursive worker.  d_d (n), d_e (n-1): tridiagonal T on the device (both overwritten).  d_c: (n,n) column-major,
+// receives the eigenvectors of T as columns; h_w[c] = eigenvalue of column c (not sorted above the leaves).
+// Problems of at most C.leaf rows go to rocSOLVER.
+static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std::vector<double> &h_w) {
+    rocblas_handle h = C.h;
+    hipStream_t st = C.st;
+    const size_t mark = C.ar.off;
+    if (n <= C.leaf || n < 4) {
+        ABuf linfo;
+        SD_TAKE(linfo, sizeof(rocblas_int));
+        JX_HIP(hipMemsetAsync(linfo.p, 0, sizeof(rocblas_int), st));
+        rocblas_status ls = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_d, d_e, d_c, n, linfo.as<rocblas_int>());
+        if (ls != rocblas_status_success) return fail("rocsolver_dstedc (leaf) failed: " + std::to_string((int)ls));
+        rocblas_int li = 0;
+        h_w.resize((size_t)n);
+        JX_HIP(hipMemcpyAsync(&li, linfo.p, sizeof(li), hipMemcpyDeviceToHost, st));
+        JX_HIP(hipMemcpyAsync(h_w.data(), d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        JX_HIP(hipStreamSynchronize(st));
+        C.ar.off = mark;
+        if (li != 0) return fail("rocsolver_dstedc did not converge on a leaf problem");
+        return 0;
+    }
+    const int k1 = n / 2, k2 = n - k1;
+    const size_t g0 = (size_t)(d_d - C.d_base);          // position of this block in the whole problem
+    const double rho0 = C.he0[g0 + k1 - 1];
+    const double absrho = fabs(rho0), sgn = (rho0 < 0.0) ? -1.0 : 1.0;
+    {
+        // rank-one tear: d[k1-1] -= |rho|, d[k1] -= |rho| (dlaed0).  Each diagonal entry is torn at most once per
+        // level, and by exactly one ancestor chain, so the host copy needs no update: apply on the device values.
+        std::vector<double> two = {absrho, absrho};
+        const double *hp = C.stage(two);
+        ABuf t2;
+        SD_TAKE(t2, 2 * sizeof(double));
+        JX_HIP(hipMemcpyAsync(t2.p, hp, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(sd_tear_kernel, dim3(1), dim3(64), 0, st, d_d + k1 - 1, t2.as<double>());
+        JX_LAUNCH_CHECK();
+    }
+
+    ABuf q1, q2;
+    SD_TAKE(q1, sizeof(double) * (size_t)k1 * k1);
+    SD_TAKE(q2, sizeof(double) * (size_t)k2 * k2);
+    std::vector<double> D((size_t)n), z((size_t)n);
+    {
+        std::vector<double> w1, w2;
+        if (stedc_dc(C, k1, d_d, d_e, q1.as<double>(), w1)) return 1;
+        if (stedc_dc(C, k2, d_d + k1, d_e + k1, q2.as<double>(), w2)) return 1;
+        std::copy(w1.begin(), w1.end(), D.begin());
+        std::copy(w2.begin(), w2.end(), D.begin() + k1);
+    }
+    ABuf dz;
+    SD_TAKE(dz, sizeof(double) * (size_t)n);
+    hipLaunchKernelGGL(sd_extract_z_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q1.as<double>(), k1,
+                       q2.as<double>(), k2, sgn, dz.as<double>());
+    JX_LAUNCH_CHECK();
+    JX_HIP(hipMemcpyAsync(z.data(), dz.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    const double rho = 2.0 * absrho;
+
+    // ---- deflation (dlaed2) ---------------------------------------------------------------------------
+    std::vector<int> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b] || (D[a] == D[b] && a < b); });
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = 0; i < n; ++i) {
+        dmax = std::max(dmax, fabs(D[i]));
+        zmax = std::max(zmax, fabs(z[i]));
+    }
+    const double eps = 2.220446049250313e-16;
+    const double tol = 8.0 * eps * std::max(dmax, zmax);
+    std::vector<Loc> loc((size_t)n);
+    for (int i = 0; i < n; ++i) loc[i] = (i < k1) ? Loc{0, i} : Loc{1, i - k1};
+    DevBuf side;          // dense n-vectors of columns that took part in a cross-block rotation
+    int nside = 0, side_cap = 0;
+    auto col_ptr = [&](const Loc &l) -> double * {
+        if (l.kind == 0) return q1.as<double>() + (size_t)l.idx * k1;
+        if (l.kind == 1) return q2.as<double>() + (size_t)l.idx * k2;
+        return side.as<double>() + (size_t)l.idx * n;
+    };
+    auto promote = [&](int col) -> int {   // give `col` a dense image in the side buffer
+        if (loc[col].kind == 2) return 0;
+        if (nside == side_cap) {
+            const int ncap = side_cap ? 2 * side_cap : 16;
+            DevBuf nb;
+            if (nb.alloc(sizeof(double) * (size_t)ncap * n)) return 1;
+            if (nside) JX_HIP(hipMemcpyAsync(nb.p, side.p, sizeof(double) * (size_t)nside * n, hipMemcpyDeviceToDevice, st));
+            JX_HIP(hipStreamSynchronize(st));
+            std::swap(side.p, nb.p);
+            std::swap(side.bytes, nb.bytes);
+            side_cap = ncap;
+        }
+        double *dst = side.as<double>() + (size_t)nside * n;
+        JX_HIP(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)n, st));
+        const Loc l = loc[col];
+        if (l.kind == 0) JX_HIP(hipMemcpyAsync(dst, col_ptr(l), sizeof(double) * k1, hipMemcpyDeviceToDevice, st));
+        else JX_HIP(hipMemcpyAsync(dst + k1, col_ptr(l), sizeof(double) * k2, hipMemcpyDeviceToDevice, st));
+        loc[col] = Loc{2, nside++};
+        return 0;
+    };
+    std::vector<int> kept, defl;
+    kept.reserve(n);
+    if (rho * zmax <= tol) {
+        for (int t = 0; t < n; ++t) defl.push_back(order[t]);   // the halves do not interact
+    } else {
+        int pj = -1;
+        for (int t = 0; t < n; ++t) {
+            const int nj = order[t];
+            if (rho * fabs(z[nj]) <= tol) {
+                defl.push_back(nj);
+                continue;
+            }
+            if (pj < 0) {
+                pj = nj;
+                continue;
+            }
+            double s = z[pj], c = z[nj];
+            const double tt = hypot(c, s);
+            const double gap = D[nj] - D[pj];
+            c /= tt;
+            s = -s / tt;
+            if (fabs(gap * c * s) <= tol) {
+                // rotate the pair so that all of z sits in nj; pj becomes an eigenvector of its own
+                z[nj] = tt;
+                z[pj] = 0.0;
+                if (loc[pj].kind != loc[nj].kind || loc[pj].kind == 2) {
+                    if (promote(pj) || promote(nj)) return 1;
+                }
+                const int len = (loc[pj].kind == 0) ? k1 : (loc[pj].kind == 1 ? k2 : n);
+                hipLaunchKernelGGL(sd_rot_kernel, dim3((len + 255) / 256), dim3(256), 0, st, col_ptr(loc[pj]),
+                                   col_ptr(loc[nj]), len, c, s);
+                JX_LAUNCH_CHECK();
+                const double t1 = D[pj] * c * c + D[nj] * s * s;
+                D[nj] = D[pj] * s * s + D[nj] * c * c;
+                D[pj] = t1;
+                defl.push_back(pj);
+                pj = nj;
+            } else {
+                kept.push_back(pj);
+                pj = nj;
+            }
+        }
+        if (pj >= 0) kept.push_back(pj);
+    }
+    const int K = (int)kept.size();
+
+    // ---- output column assignment: roots 0..K-1, then the deflated columns ---------------------------------
+    std::vector<double> w((size_t)n);
+    std::vector<double> lam((size_t)std::max(K, 1));
+    ABuf dk, zk, dtau, dorg, dlam, dzh, dinv;
+    if (K > 0) {
+        std::vector<double> hk((size_t)K), hz((size_t)K);
+        for (int r = 0; r < K; ++r) {
+            hk[r] = D[kept[r]];
+            hz[r] = z[kept[r]];
+        }
+        SD_TAKE(dk, sizeof(double) * K);
+        SD_TAKE(zk, sizeof(double) * K);
+        SD_TAKE(dtau, sizeof(double) * K);
+        SD_TAKE(dorg, sizeof(int) * K);
+        SD_TAKE(dlam, sizeof(double) * K);
+        SD_TAKE(dzh, sizeof(double) * K);
+        SD_TAKE(dinv, sizeof(double) * K);
+        JX_HIP(hipMemcpyAsync(dk.p, C.stage(hk), sizeof(double) * K, hipMemcpyHostToDevice, st));
+        JX_HIP(hipMemcpyAsync(zk.p, C.stage(hz), sizeof(double) * K, hipMemcpyHostToDevice, st));
+        const int gw = (K + SD_WAVES - 1) / SD_WAVES;
+        hipLaunchKernelGGL(sd_secular_kernel, dim3(gw), dim3(SD_THREADS), 0, st, dk.as<double>(), zk.as<double>(), K, rho,
+                           dtau.as<double>(), dorg.as<int>(), dlam.as<double>());
+        JX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sd_lowner_kernel, dim3(gw), dim3(SD_THREADS), 0, st, dk.as<double>(), zk.as<double>(), K, rho,
+                           dtau.as<double>(), dorg.as<int>(), dzh.as<double>());
+        JX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sd_colnorm_kernel, dim3(gw), dim3(SD_THREADS), 0, st, dk.as<double>(), dzh.as<double>(), K,
+                           dtau.as<double>(), dorg.as<int>(), dinv.as<double>());
+        JX_LAUNCH_CHECK();
+        JX_HIP(hipMemcpyAsync(lam.data(), dlam.p, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+        JX_HIP(hipStreamSynchronize(st));   // lam is needed on the host
+    }
+    for (int r = 0; r < K; ++r) w[r] = lam[r];
+    for (size_t r = 0; r < defl.size(); ++r) w[K + r] = D[defl[r]];
+
+    // ---- eigenvectors: C[:, 0:K] = [Q1(:,S1) U1 ; Q2(:,S2) U2] + Side(:,Sm) Um ; deflated columns copied -----
+    std::vector<int> rows1, rows2, rowsm;      // kept-list positions by where the column lives
+    std::vector<int> c1, c2, cm;               // and the column index inside that storage
+    for (int r = 0; r < K; ++r) {
+        const Loc l = loc[kept[r]];
+        if (l.kind == 0) { rows1.push_back(r); c1.push_back(l.idx); }
+        else if (l.kind == 1) { rows2.push_back(r); c2.push_back(l.idx); }
+        else { rowsm.push_back(r); cm.push_back(l.idx); }
+    }
+    // deflated columns go out first (their storage is about to be compacted)
+    {
+        std::vector<int> s0, t0, s1, t1, s2, t2;
+        for (size_t r = 0; r < defl.size(); ++r) {
+            const Loc l = loc[defl[r]];
+            const int dstc = K + (int)r;
+            if (l.kind == 0) { s0.push_back(l.idx); t0.push_back(dstc); }
+            else if (l.kind == 1) { s1.push_back(l.idx); t1.push_back(dstc); }
+            else { s2.push_back(l.idx); t2.push_back(dstc); }
+        }
+        auto place = [&](const std::vector<int> &sc, const std::vector<int> &dc, const double *src, int64_t lds,
+                         int rows, int row_off) -> int {
+            if (sc.empty()) return 0;
+            ABuf a, b;
+            SD_TAKE(a, sizeof(int) * sc.size());
+            SD_TAKE(b, sizeof(int) * dc.size());
+            JX_HIP(hipMemcpyAsync(a.p, C.stage(sc), sizeof(int) * sc.size(), hipMemcpyHostToDevice, st));
+            JX_HIP(hipMemcpyAsync(b.p, C.stage(dc), sizeof(int) * dc.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(sd_place_cols_kernel, dim3(64, (unsigned)sc.size()), dim3(256), 0, st, src, lds, rows,
+                               a.as<int>(), d_c, (int64_t)n, n, row_off, b.as<int>(), (int)sc.size());
+            JX_LAUNCH_CHECK();
+            return 0;
+        };
+        if (place(s0, t0, q1.as<double>(), k1, k1, 0)) return 1;
+        if (place(s1, t1, q2.as<double>(), k2, k2, k1)) return 1;
+        if (place(s2, t2, side.as<double>(), n, n, 0)) return 1;
+    }
+    if (K > 0) {
+        // compact the kept columns of Q1 / Q2 to the left (ascending source index, so a forward copy is safe)
+        auto compact = [&](std::vector<int> &rows, std::vector<int> &cols, double *q, int len) -> int {
+            std::vector<int> idx(rows.size());
+            std::iota(idx.begin(), idx.end(), 0);
+            std::sort(idx.begin(), idx.end(), [&](int a, int b) { return cols[a] < cols[b]; });
+            std::vector<int> r2(rows.size()), c2v(rows.size());
+            for (size_t t = 0; t < idx.size(); ++t) {
+                r2[t] = rows[idx[t]];
+                c2v[t] = cols[idx[t]];
+            }
+            rows.swap(r2);
+            cols.swap(c2v);
+            for (size_t t = 0; t < cols.size(); ++t) {
+                if (cols[t] != (int)t) {
+                    hipLaunchKernelGGL(sd_copy_col_kernel, dim3(64), dim3(256), 0, st, q + (size_t)cols[t] * len,
+                                       q + (size_t)t * len, len);
+                    JX_LAUNCH_CHECK();
+                }
+            }
+            return 0;
+        };
+        if (compact(rows1, c1, q1.as<double>(), k1)) return 1;
+        if (compact(rows2, c2, q2.as<double>(), k2)) return 1;
+        const double one = 1.0, zero = 0.0;
+        auto gemm_part = [&](const std::vector<int> &rows, const double *q, int64_t ldq, int qrows, double *cdst,
+                             double beta) -> int {
+            const int nr = (int)rows.size();
+            if (nr == 0) {
+                if (beta == 0.0)     // nothing of this block survives: its rows of the root columns are zero
+                    JX_HIP(hipMemset2DAsync(cdst, sizeof(double) * (size_t)n, 0, sizeof(double) * (size_t)qrows,
+                                            (size_t)K, st));
+                return 0;
+            }
+            const size_t gmark = C.ar.off;
+            ABuf u, rm;
+            SD_TAKE(u, sizeof(double) * (size_t)nr * K);
+            SD_TAKE(rm, sizeof(int) * (size_t)nr);
+            JX_HIP(hipMemcpyAsync(rm.p, C.stage(rows), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(sd_form_u_kernel, dim3((nr + SD_THREADS - 1) / SD_THREADS, K), dim3(SD_THREADS), 0, st,
+                               dk.as<double>(), dzh.as<double>(), dtau.as<double>(), dorg.as<int>(), dinv.as<double>(),
+                               rm.as<int>(), nr, K, u.as<double>(), (int64_t)nr);
+            JX_LAUNCH_CHECK();
+            rocblas_status g = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, qrows, K, nr, &one, q,
+                                             (rocblas_int)ldq, u.as<double>(), nr, &beta, cdst, n);
+            if (g != rocblas_status_success) return fail("rocblas_dgemm failed in stedc merge: " + std::to_string((int)g));
+            C.ar.off = gmark;   // stream order protects the reuse
+            return 0;
+        };
+        if (gemm_part(rows1, q1.as<double>(), k1, k1, d_c, zero)) return 1;
+        if (gemm_part(rows2, q2.as<double>(), k2, k2, d_c + k1, zero)) return 1;
+        if (!rowsm.empty()) {
+            // side columns are dense: gather them contiguously, then C(:, 0:K) += Side U_m
+            ABuf sg;
+            SD_TAKE(sg, sizeof(double) * (size_t)rowsm.size() * n);
+            for (size_t t = 0; t < cm.size(); ++t)
+                JX_HIP(hipMemcpyAsync(sg.as<double>() + t * (size_t)n, side.as<double>() + (size_t)cm[t] * n,
+                                      sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+            if (gemm_part(rowsm, sg.as<double>(), n, n, d_c, one)) return 1;
+        }
+    }
+    if (side.p) JX_HIP(hipStreamSynchronize(st));   // the side buffer (hipMalloc) is released on return
+    C.ar.off = mark;
+    h_w.swap(w);
+    return 0;
+}
+
+// d_d (n), d_e (n-1): tridiagonal T (both overwritten).  d_c: (n,n) column-major, receives the eigenvectors of T as
+// columns in the order given by h_perm (h_perm[r] = column holding the r-th smallest eigenvalue); d_d receives the
+// eigenvalues ascending.  leaf: largest problem handed to rocSOLVER's dstedc.
+int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
+                std::vector<int> &h_perm) {
+    std::vector<double> hd((size_t)n), he((size_t)n);
+    JX_HIP(hipMemcpyAsync(hd.data(), d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    JX_HIP(hipMemcpyAsync(he.data(), d_e, sizeof(double) * (size_t)(n - 1), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    // workspace: the two half-size eigenvector blocks plus the U factor of one merge per level = n^2 doubles at the
+    // top and a geometric tail below; vectors and index lists are O(n) per level
+    DevBuf arena;
+    const size_t nn = (size_t)n * (size_t)n;
+    const size_t bytes = sizeof(double) * (nn + nn / 2 + 64 * (size_t)n) + (1u << 20);
+    if (arena.alloc(bytes)) return 1;
+    DcCtx C;
+    C.h = h;
+    C.st = st;
+    C.leaf = leaf;
+    C.ar.base = (char *)arena.p;
+    C.ar.cap = bytes;
+    C.hd0 = hd.data();
+    C.he0 = he.data();
+    C.d_base = d_d;
+    C.e_base = d_e;
+    std::vector<double> w;
+    if (stedc_dc(C, n, d_d, d_e, d_c, w)) return 1;
+    h_perm.resize((size_t)n);
+    std::iota(h_perm.begin(), h_perm.end(), 0);
+    std::sort(h_perm.begin(), h_perm.end(), [&](int a, int b) { return w[a] < w[b] || (w[a] == w[b] && a < b); });
+    std::vector<double> ws((size_t)n);
+    for (int r = 0; r < n; ++r) ws[r] = w[h_perm[r]];
+    JX_HIP(hipMemcpyAsync(d_d, ws.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    JX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// dst row r (row-major, n x n) = column perm[r] of the column-major src: the final "eigenvector j in row j" layout
+__global__ void sd_gather_cols_kernel(const double *__restrict__ src, const int *__restrict__ perm, int n,
+                                      double *__restrict__ dst) {
+    const int r = blockIdx.y;
+    const double *s = src + (int64_t)perm[r] * n;
+    double *t = dst + (int64_t)r * n;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) t[c] = s[c];
+}
+
+int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st) {
+    hipLaunchKernelGGL(sd_gather_cols_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, src, d_perm, n, dst);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace jx

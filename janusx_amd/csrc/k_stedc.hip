@@ -246,11 +246,6 @@ __global__ void sd_place_cols_kernel(const double *__restrict__ src, int64_t lds
     }
 }
 
-// in-place left compaction of the kept columns of a column-major matrix (keep[] ascending)
-__global__ void sd_copy_col_kernel(const double *__restrict__ src, double *__restrict__ dst, int rows) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) dst[r] = src[r];
-}
-
 namespace {
 // Stream-ordered bump allocator over one device block: every temporary of the recursion is carved from it, so a
 // merge performs no hipMalloc / hipFree (each hipFree is a device-wide synchronisation).  Reuse after a reset is
@@ -510,29 +505,39 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         if (place(s2, t2, side.as<double>(), n, n, 0)) return 1;
     }
     if (K > 0) {
-        // compact the kept columns of Q1 / Q2 to the left (ascending source index, so a forward copy is safe)
-        auto compact = [&](std::vector<int> &rows, std::vector<int> &cols, double *q, int len) -> int {
+        // the kept columns of Q1 / Q2 as contiguous blocks: in place when nothing was deflated there, else one
+        // gather launch into the arena
+        auto compact = [&](std::vector<int> &rows, std::vector<int> &cols, double *&q, int len) -> int {
             std::vector<int> idx(rows.size());
             std::iota(idx.begin(), idx.end(), 0);
             std::sort(idx.begin(), idx.end(), [&](int a, int b) { return cols[a] < cols[b]; });
             std::vector<int> r2(rows.size()), c2v(rows.size());
+            bool identity = true;
             for (size_t t = 0; t < idx.size(); ++t) {
                 r2[t] = rows[idx[t]];
                 c2v[t] = cols[idx[t]];
+                identity = identity && (c2v[t] == (int)t);
             }
             rows.swap(r2);
             cols.swap(c2v);
-            for (size_t t = 0; t < cols.size(); ++t) {
-                if (cols[t] != (int)t) {
-                    hipLaunchKernelGGL(sd_copy_col_kernel, dim3(64), dim3(256), 0, st, q + (size_t)cols[t] * len,
-                                       q + (size_t)t * len, len);
-                    JX_LAUNCH_CHECK();
-                }
-            }
+            if (identity || cols.empty()) return 0;
+            ABuf g, sc, dc;
+            SD_TAKE(g, sizeof(double) * cols.size() * (size_t)len);
+            SD_TAKE(sc, sizeof(int) * cols.size());
+            SD_TAKE(dc, sizeof(int) * cols.size());
+            std::vector<int> seq(cols.size());
+            std::iota(seq.begin(), seq.end(), 0);
+            JX_HIP(hipMemcpyAsync(sc.p, C.stage(cols), sizeof(int) * cols.size(), hipMemcpyHostToDevice, st));
+            JX_HIP(hipMemcpyAsync(dc.p, C.stage(seq), sizeof(int) * cols.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(sd_place_cols_kernel, dim3(16, (unsigned)cols.size()), dim3(256), 0, st, q, (int64_t)len,
+                               len, sc.as<int>(), g.as<double>(), (int64_t)len, len, 0, dc.as<int>(), (int)cols.size());
+            JX_LAUNCH_CHECK();
+            q = g.as<double>();
             return 0;
         };
-        if (compact(rows1, c1, q1.as<double>(), k1)) return 1;
-        if (compact(rows2, c2, q2.as<double>(), k2)) return 1;
+        double *q1c = q1.as<double>(), *q2c = q2.as<double>();
+        if (compact(rows1, c1, q1c, k1)) return 1;
+        if (compact(rows2, c2, q2c, k2)) return 1;
         const double one = 1.0, zero = 0.0;
         auto gemm_part = [&](const std::vector<int> &rows, const double *q, int64_t ldq, int qrows, double *cdst,
                              double beta) -> int {
@@ -558,8 +563,8 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
             C.ar.off = gmark;   // stream order protects the reuse
             return 0;
         };
-        if (gemm_part(rows1, q1.as<double>(), k1, k1, d_c, zero)) return 1;
-        if (gemm_part(rows2, q2.as<double>(), k2, k2, d_c + k1, zero)) return 1;
+        if (gemm_part(rows1, q1c, k1, k1, d_c, zero)) return 1;
+        if (gemm_part(rows2, q2c, k2, k2, d_c + k1, zero)) return 1;
         if (!rowsm.empty()) {
             // side columns are dense: gather them contiguously, then C(:, 0:K) += Side U_m
             ABuf sg;
@@ -585,11 +590,12 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     JX_HIP(hipMemcpyAsync(hd.data(), d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
     JX_HIP(hipMemcpyAsync(he.data(), d_e, sizeof(double) * (size_t)(n - 1), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
-    // workspace: the two half-size eigenvector blocks plus the U factor of one merge per level = n^2 doubles at the
-    // top and a geometric tail below; vectors and index lists are O(n) per level
+    // workspace: per level the two half-size eigenvector blocks (n^2/2), their compacted copies when columns were
+    // deflated (<= n^2/2) and one U factor at a time (<= n^2/2); the levels below reuse the space above q1/q2, so
+    // 2 n^2 doubles cover the recursion; vectors and index lists are O(n) per level
     DevBuf arena;
     const size_t nn = (size_t)n * (size_t)n;
-    const size_t bytes = sizeof(double) * (nn + nn / 2 + 64 * (size_t)n) + (1u << 20);
+    const size_t bytes = sizeof(double) * (2 * nn + 64 * (size_t)n) + (1u << 20);
     if (arena.alloc(bytes)) return 1;
     DcCtx C;
     C.h = h;

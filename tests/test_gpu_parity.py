@@ -864,3 +864,32 @@ def test_gblup_reml_packed_bed(oracle, tmp_path, subset):
     assert np.max(np.abs(o1.cpu().numpy() - dec @ a)) < 1e-11 and np.max(np.abs(o2.cpu().numpy() - dec.T @ b)) < 1e-11
     with pytest.raises(RuntimeError):
         jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr])       # site_keep route is not built
+
+
+def test_eigh_own_divide_and_conquer(monkeypatch):
+    """csrc/k_stedc.hip: Cuppen merges forced at small sizes (several recursion levels), on spectra that exercise
+    every deflation branch: generic kinship-like, identity + low rank (massive close-eigenvalue deflation with
+    cross-block rotations), exactly diagonal (decoupled halves), and a graded spectrum."""
+    from janusx_amd import janusx as jxrs
+    monkeypatch.setenv("JXGPU_STEDC", "split")
+    monkeypatch.setenv("JXGPU_STEDC_LEAF", "40")
+    rng = np.random.default_rng(5)
+    n = 611
+    z = rng.normal(size=(n, n + 50))
+    mats = {"kinship": z @ z.T / (n + 50)}
+    lr = rng.normal(size=(n, 3))
+    mats["identity+lowrank"] = np.eye(n) + lr @ lr.T
+    mats["diagonal"] = np.diag(np.sort(rng.uniform(0.5, 2.0, n)))
+    q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    mats["graded"] = (q * np.logspace(-8, 2, n)) @ q.T
+    mats["repeated"] = (q * np.repeat(np.arange(1, 14), 47)[:n]) @ q.T
+    for name, a in mats.items():
+        a = 0.5 * (a + a.T)
+        res = jxrs.rust_eigh_from_array_f64(a)
+        w, u = res[0], res[1]
+        w_ref = np.linalg.eigvalsh(a)
+        scale = max(1.0, float(np.max(np.abs(w_ref))))
+        assert np.all(np.diff(w) >= 0), name
+        assert np.max(np.abs(w - w_ref)) < 1e-12 * scale * n ** 0.5, (name, float(np.max(np.abs(w - w_ref))))
+        assert np.max(np.abs(u.T @ u - np.eye(n))) < 1e-11, (name, float(np.max(np.abs(u.T @ u - np.eye(n)))))
+        assert np.max(np.abs(a @ u - u * w)) < 1e-11 * scale, (name, float(np.max(np.abs(a @ u - u * w))))

@@ -22,6 +22,8 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
                 std::vector<int> &h_perm);
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
+// k_ormtr.hip: C <- Q C with wide compact-WY blocks (dormtr left / lower / no-transpose)
+int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c);
 constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
 
 static rocblas_handle g_handle = nullptr;
@@ -97,9 +99,15 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
         }
         if (stage_done("dstedc")) return 1;
-        rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
-                              tau.as<double>(), c.as<double>(), n);
-        if (rs != rocblas_status_success) return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+        const char *om = getenv("JXGPU_ORMTR");
+        if (om && strcmp(om, "rocsolver") == 0) {
+            rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
+                                  tau.as<double>(), c.as<double>(), n);
+            if (rs != rocblas_status_success)
+                return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+        } else {
+            if (ormtr_lower(h, st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
+        }
         if (stage_done("dormtr")) return 1;
         if (split) {
             DevBuf dperm;

@@ -1,0 +1,89 @@
+// Back-transformation C <- Q C of the eigenvectors of the tridiagonal matrix, Q = H_0 H_1 ... H_{n-2} from
+// sytrd_lower (LAPACK dsytrd(lower) storage: v_j below the sub-diagonal of column j, tau_j) -- LAPACK dormtr
+// (left, lower, no-transpose), the last stage behind src/math/eigh.rs:1422-1528.
+// rocSOLVER's dormtr spends 32 ms here at n = 5000 (64-column blocks: ~80 larft recurrences of tiny kernels and
+// k = 64 GEMMs).  This form uses wide blocks and BLAS-3 only: for a block of nb reflectors with explicit V
+//   I - V T V',   T^-1 = strict_upper(V'V) + diag(1 / tau)            (compact WY, inverse-T form)
+// so the block needs one Gram product, one triangular solve with n right-hand sides and two GEMMs with k = nb.
+#include <rocblas/rocblas.h>
+
+#include <stdlib.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int OT_NB = 1024;
+
+// vc (rows, nbk) column-major = explicit reflectors of columns jb .. jb+nbk-1 restricted to rows jb+1 .. n-1
+// (zero above the unit entry; a reflector with tau = 0 is the identity and is stored as a zero column)
+__global__ __launch_bounds__(256) void ot_extract_v_kernel(const double *__restrict__ a, int n, int jb, int nbk,
+                                                          const double *__restrict__ tau, double *__restrict__ vc,
+                                                          int rows) {
+    const int k = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nbk || r >= rows) return;
+    const int j = jb + k;             // reflector / column index
+    const int row = jb + 1 + r;       // matrix row
+    double v = 0.0;
+    if (tau[j] != 0.0) {
+        if (row == j + 1) v = 1.0;
+        else if (row > j + 1) v = a[(int64_t)j * n + row];
+    }
+    vc[(int64_t)k * rows + r] = v;
+}
+
+// m (nb x nb, column-major, ld = nb) holds G = V'V: keep the strict upper triangle, put 1/tau on the diagonal
+// (1 for identity reflectors), zero the strict lower triangle.
+__global__ void ot_fix_m_kernel(double *__restrict__ m, int nbk, int ld, const double *__restrict__ tau, int jb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= nbk || r >= nbk) return;
+    double *p = m + (int64_t)c * ld + r;
+    if (r > c) *p = 0.0;
+    else if (r == c) {
+        const double t = tau[jb + c];
+        *p = (t != 0.0) ? 1.0 / t : 1.0;
+    }
+}
+
+// d_a: (n,n) column-major after sytrd_lower; d_tau (n-1); d_c (n,n) column-major, overwritten with Q C.
+int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c) {
+    if (n < 2) return 0;
+    const int nref = n - 1;                          // reflectors 0 .. n-2
+    const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB")) : OT_NB;
+    DevBuf vc, mm, w;
+    if (vc.alloc(sizeof(double) * (size_t)n * nb) || mm.alloc(sizeof(double) * (size_t)nb * nb) ||
+        w.alloc(sizeof(double) * (size_t)nb * n))
+        return 1;
+    const double one = 1.0, zero = 0.0, minus1 = -1.0;
+    const int nblocks = (nref + nb - 1) / nb;
+    for (int b = nblocks - 1; b >= 0; --b) {
+        const int jb = b * nb;
+        const int nbk = (nref - jb < nb) ? (nref - jb) : nb;
+        const int rows = n - jb - 1;
+        hipLaunchKernelGGL(ot_extract_v_kernel, dim3((rows + 255) / 256, nbk), dim3(256), 0, st, d_a, n, jb, nbk, d_tau,
+                           vc.as<double>(), rows);
+        JX_LAUNCH_CHECK();
+        rocblas_status rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, nbk, rows, &one,
+                                          vc.as<double>(), rows, vc.as<double>(), rows, &zero, mm.as<double>(), nb);
+        if (rs != rocblas_status_success) return fail("ormtr: Gram dgemm failed: " + std::to_string((int)rs));
+        hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nbk + 63) / 64, nbk), dim3(64), 0, st, mm.as<double>(), nbk, nb, d_tau,
+                           jb);
+        JX_LAUNCH_CHECK();
+        double *csub = d_c + (jb + 1);                // rows jb+1 .. n-1 of every column
+        rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, n, rows, &one, vc.as<double>(),
+                           rows, csub, n, &zero, w.as<double>(), nb);
+        if (rs != rocblas_status_success) return fail("ormtr: V'C dgemm failed: " + std::to_string((int)rs));
+        rs = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, nbk,
+                           n, &one, mm.as<double>(), nb, w.as<double>(), nb);
+        if (rs != rocblas_status_success) return fail("ormtr: dtrsm failed: " + std::to_string((int)rs));
+        rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, rows, n, nbk, &minus1, vc.as<double>(), rows,
+                           w.as<double>(), nb, &one, csub, n);
+        if (rs != rocblas_status_success) return fail("ormtr: update dgemm failed: " + std::to_string((int)rs));
+    }
+    JX_HIP(hipStreamSynchronize(st));   // work buffers are released on return
+    return 0;
+}
+
+}  // namespace jx

@@ -80,12 +80,14 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
         if (stage_done("sytrd")) return 1;
         const char *sm = getenv("JXGPU_STEDC");
-        // own divide-and-conquer merges above 2560 rows (3-5 % faster than rocSOLVER's top levels at n = 5000..20000
-        // and the only way past n = 46340); JXGPU_STEDC=rocsolver / split and JXGPU_STEDC_LEAF override
-        bool split = n >= 4096;
+        // own divide-and-conquer merges above 1280 rows, independent halves on concurrent streams (rocSOLVER's
+        // dstedc is a chain of latency-bound launches: 27 ms for the two 2500-row halves of n = 5000 run back to
+        // back, ~8 ms as four concurrent 1250-row leaves), and the only way past n = 46340;
+        // JXGPU_STEDC=rocsolver / split, JXGPU_STEDC_LEAF and JXGPU_STEDC_PAR override
+        bool split = n >= 2048;
         if (sm && strcmp(sm, "rocsolver") == 0 && n <= kRocsolverStedcMaxN) split = false;
         if (sm && strcmp(sm, "split") == 0 && n >= 64) split = true;
-        int leaf = getenv("JXGPU_STEDC_LEAF") ? atoi(getenv("JXGPU_STEDC_LEAF")) : 2560;
+        int leaf = getenv("JXGPU_STEDC_LEAF") ? atoi(getenv("JXGPU_STEDC_LEAF")) : 1280;
         if (leaf < 2) leaf = 2;
         if (leaf > kRocsolverStedcMaxN) leaf = kRocsolverStedcMaxN;
         std::vector<int> perm;

@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "jx_common.h"
@@ -268,6 +270,9 @@ struct DcCtx {
     rocblas_handle h;
     hipStream_t st;
     int leaf;
+    int depth = 0;      // recursion depth of the current call
+    int par_depth = 0;  // the two halves of a problem run concurrently (own host thread, stream, handle) above it
+    int device = 0;
     Arena ar;
     const double *hd0, *he0;              // host copy of the tridiagonal (whole problem)
     double *d_base, *e_base;              // device d / e of the whole problem (offsets recover the host index)
@@ -277,6 +282,39 @@ struct DcCtx {
         return reinterpret_cast<const T *>(keep.back().data());
     }
 };
+// (stream, rocBLAS handle) pairs for sub-problems that run concurrently with their sibling
+struct Lane {
+    hipStream_t st = nullptr;
+    rocblas_handle h = nullptr;
+};
+static std::mutex g_lane_mu;
+static std::vector<Lane> g_free_lanes;
+static int lane_acquire(Lane &l) {
+    {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        if (!g_free_lanes.empty()) {
+            l = g_free_lanes.back();
+            g_free_lanes.pop_back();
+            return 0;
+        }
+    }
+    JX_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    if (rocblas_create_handle(&l.h) != rocblas_status_success) return fail("rocblas_create_handle failed");
+    if (rocblas_set_stream(l.h, l.st) != rocblas_status_success) return fail("rocblas_set_stream failed");
+    return 0;
+}
+static void lane_release(const Lane &l) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    g_free_lanes.push_back(l);
+}
+static size_t dc_arena_bytes(int n) {
+    const size_t nn = (size_t)n * (size_t)n;
+    // q1/q2 (n^2/2), their compacted copies (<= n^2/2) and one U factor at a time (<= n^2/2), or q1/q2 plus the two
+    // children's arenas (n^2 + ...): 2 n^2 covers both for n >= 128; vectors, index lists and the 256-byte alignment
+    // of every block are O(n) per level
+    return sizeof(double) * (2 * nn + 256 * (size_t)n) + (64u << 10);
+}
+
 #define SD_TAKE(buf, bytes)                                                        \
     do {                                                                           \
         (buf).p = C.ar.take(bytes);                                                \
@@ -333,8 +371,70 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     std::vector<double> D((size_t)n), z((size_t)n);
     {
         std::vector<double> w1, w2;
-        if (stedc_dc(C, k1, d_d, d_e, q1.as<double>(), w1)) return 1;
-        if (stedc_dc(C, k2, d_d + k1, d_e + k1, q2.as<double>(), w2)) return 1;
+        const int child_depth = C.depth + 1;
+        if (C.depth < C.par_depth && n >= 1024) {
+            // the halves are independent: the second one gets its own host thread, stream, rocBLAS handle and arena
+            // slice (rocSOLVER's leaf solver is a chain of latency-bound launches, two of them overlap almost fully)
+            const size_t s1 = dc_arena_bytes(k1), s2 = dc_arena_bytes(k2);
+            ABuf a1, a2;
+            SD_TAKE(a1, s1);
+            SD_TAKE(a2, s2);
+            hipEvent_t ready;
+            JX_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+            JX_HIP(hipEventRecord(ready, st));     // the tear above, and every earlier user of the recycled arena
+            Lane lane;
+            if (lane_acquire(lane)) return 1;
+            int rc2 = 0;
+            DcCtx C2;
+            C2.h = lane.h;
+            C2.st = lane.st;
+            C2.leaf = C.leaf;
+            C2.depth = child_depth;
+            C2.par_depth = C.par_depth;
+            C2.device = C.device;
+            C2.ar.base = (char *)a2.p;
+            C2.ar.cap = s2;
+            C2.hd0 = C.hd0;
+            C2.he0 = C.he0;
+            C2.d_base = C.d_base;
+            C2.e_base = C.e_base;
+            std::thread th([&]() {
+                if (hipSetDevice(C2.device) != hipSuccess || hipStreamWaitEvent(C2.st, ready, 0) != hipSuccess) {
+                    rc2 = 1;
+                    return;
+                }
+                rc2 = stedc_dc(C2, k2, d_d + k1, d_e + k1, q2.as<double>(), w2);
+                if (hipStreamSynchronize(C2.st) != hipSuccess) rc2 = 1;
+            });
+            DcCtx C1;
+            C1.h = C.h;
+            C1.st = C.st;
+            C1.leaf = C.leaf;
+            C1.depth = child_depth;
+            C1.par_depth = C.par_depth;
+            C1.device = C.device;
+            C1.ar.base = (char *)a1.p;
+            C1.ar.cap = s1;
+            C1.hd0 = C.hd0;
+            C1.he0 = C.he0;
+            C1.d_base = C.d_base;
+            C1.e_base = C.e_base;
+            const int rc1 = stedc_dc(C1, k1, d_d, d_e, q1.as<double>(), w1);
+            th.join();
+            (void)hipEventDestroy(ready);
+            lane_release(lane);
+            if (rc1) return 1;
+            if (rc2) return fail("stedc: the concurrent half-problem failed");
+            JX_HIP(hipStreamSynchronize(st));   // C1's staging blocks die with it
+            C.ar.off = (size_t)((char *)a1.p - C.ar.base);   // both slices are free again
+        } else {
+            const int saved = C.depth;
+            C.depth = child_depth;
+            const int r1 = stedc_dc(C, k1, d_d, d_e, q1.as<double>(), w1);
+            const int r2 = r1 ? 1 : stedc_dc(C, k2, d_d + k1, d_e + k1, q2.as<double>(), w2);
+            C.depth = saved;
+            if (r1 || r2) return 1;
+        }
         std::copy(w1.begin(), w1.end(), D.begin());
         std::copy(w2.begin(), w2.end(), D.begin() + k1);
     }
@@ -594,13 +694,14 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     // deflated (<= n^2/2) and one U factor at a time (<= n^2/2); the levels below reuse the space above q1/q2, so
     // 2 n^2 doubles cover the recursion; vectors and index lists are O(n) per level
     DevBuf arena;
-    const size_t nn = (size_t)n * (size_t)n;
-    const size_t bytes = sizeof(double) * (2 * nn + 64 * (size_t)n) + (1u << 20);
+    const size_t bytes = dc_arena_bytes(n);
     if (arena.alloc(bytes)) return 1;
     DcCtx C;
     C.h = h;
     C.st = st;
     C.leaf = leaf;
+    C.par_depth = getenv("JXGPU_STEDC_PAR") ? atoi(getenv("JXGPU_STEDC_PAR")) : 3;   // up to 8 concurrent sub-trees
+    JX_HIP(hipGetDevice(&C.device));
     C.ar.base = (char *)arena.p;
     C.ar.cap = bytes;
     C.hd0 = hd.data();

@@ -329,17 +329,35 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
     }
 }
 
-template <int MAXD>
-__global__ __launch_bounds__(SCAN_THREADS, (MAXD <= 2 ? 4 : 2)) void lmm_scan_fast_kernel(
-    const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s, const double *__restrict__ xcov,
-    const double *__restrict__ yc, int p, const ChebHeader hd, const double *__restrict__ coef,
+// NW waves per workgroup.  LDS = true: the three vectors every evaluation of every SNP streams -- s, X~ (n x p) and the
+// shifted y~, 8 n (2 + p) bytes -- are copied into LDS once per workgroup and shared by its NW waves.  Without it each
+// evaluation re-reads them through L2 (they do not fit the 32 KB L1): measured 7.7 TB/s of L1<-L2 traffic and waves
+// parked on s_waitcnt for 87 % of their cycles at n = 5000 (profiles/r01d_pmc_scan.json).
+template <int MAXD, int NW, bool LDS>
+__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void lmm_scan_fast_kernel(
+    const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
+    const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out) {
+    extern __shared__ __attribute__((aligned(16))) double scan_lds[];
+    const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
+    if (LDS) {
+        double *ls = scan_lds, *lx = scan_lds + n, *ly = scan_lds + n + (int64_t)n * p;
+        for (int i = threadIdx.x; i < n; i += NW * 64) {
+            ls[i] = s_g[i];
+            ly[i] = yc_g[i];
+        }
+        for (int i = threadIdx.x; i < n * p; i += NW * 64) lx[i] = xcov_g[i];
+        __syncthreads();
+        s = ls;
+        xcov = lx;
+        yc = ly;
+    }
     const int out_cols = with_plrt ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const double smin = smin_ptr[0];
-    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
+    for (int r = blockIdx.x * NW + wave; r < nrows; r += gridDim.x * NW) {
         const float *g = grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         double ssq = 0.0;
@@ -564,12 +582,46 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     const double *w = (const double *)d_work;
     const double *smin = w, *yc = w + 8, *coef = yc + n;
     const int dim = p + 1;
+    // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
+    const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
+    const bool use_lds = dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
+    if (use_lds) {
+        if (dim <= 2) {
+            constexpr int NW = 16;
+            auto kfn = lmm_scan_fast_kernel<2, NW, true>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done = true;
+            }
+            int grid = (nrows + NW - 1) / NW;
+            if (grid > 65536) grid = 65536;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                               nullml, d_out, d_evals);
+        } else {
+            constexpr int NW = 8;
+            auto kfn = lmm_scan_fast_kernel<4, NW, true>;
+            static bool attr_done4 = false;
+            if (!attr_done4) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done4 = true;
+            }
+            int grid = (nrows + NW - 1) / NW;
+            if (grid > 65536) grid = 65536;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                               nullml, d_out, d_evals);
+        }
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
     int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
     if (grid > 65536 * 8) grid = 65536 * 8;
-    JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL(lmm_scan_fast_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
-                                              (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, yc, p, hd, coef, smin,
-                                              low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out,
-                                              d_evals));
+    JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXD, SCAN_WAVES, false>), dim3(grid),
+                                              dim3(SCAN_THREADS), 0, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
+                                              yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd,
+                                              with_plrt, nullml, d_out, d_evals));
     JX_LAUNCH_CHECK();
     return 0;
 }

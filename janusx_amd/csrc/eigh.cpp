@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -70,10 +71,12 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (c.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
         // JXGPU_EIGH_TRACE=1: synchronise and report after every stage (stderr), to locate a failing stage
         const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
         auto stage_done = [&](const char *what) -> int {
             if (!trace) return 0;
             JX_HIP(hipStreamSynchronize(st));
-            fprintf(stderr, "[jxgpu eigh n=%d] %s done\n", n, what);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            fprintf(stderr, "[jxgpu eigh n=%d] %s done at %.1f ms\n", n, what, ms);
             fflush(stderr);
             return 0;
         };

@@ -123,10 +123,10 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
 
 
 def pmc_traffic_bytes(kernel_prefix, run="fetch"):
-    """HBM read bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_hbm_traffic.json:
+    """HBM read bytes per launch of a kernel from the committed PMC summary (profiles/r01d_pmc_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
     streaming reads). Returns None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")
     try:
         runs = json.load(open(path))["runs"][run]
     except Exception:

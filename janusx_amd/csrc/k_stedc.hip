@@ -701,6 +701,10 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     C.st = st;
     C.leaf = leaf;
     C.par_depth = getenv("JXGPU_STEDC_PAR") ? atoi(getenv("JXGPU_STEDC_PAR")) : 3;   // up to 8 concurrent sub-trees
+    // rocprofv3 counter collection serialises dispatches across queues; a WRITE_SIZE pass over this code with its
+    // concurrent host threads and streams stopped making progress (25 minutes, killed) -- run the halves in turn there
+    const char *pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+    if (pmc && pmc[0] == '1' && !getenv("JXGPU_STEDC_PAR")) C.par_depth = 0;
     JX_HIP(hipGetDevice(&C.device));
     C.ar.base = (char *)arena.p;
     C.ar.cap = bytes;

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "jx_common.h"
@@ -16,6 +17,42 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(const std::string &msg) {
     g_err = msg;
     return 1;
+}
+
+namespace {
+struct ScratchSlot {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool busy = false;
+};
+ScratchSlot g_scratch[8];
+std::mutex g_scratch_mu;
+}  // namespace
+
+int scratch_acquire(int which, size_t bytes, void **p) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchSlot &s = g_scratch[which & 7];
+    if (s.busy) return 1;
+    if (s.cap < bytes) {
+        if (s.p) (void)hipFree(s.p);
+        s.p = nullptr;
+        s.cap = 0;
+        hipError_t e = hipMalloc(&s.p, bytes);
+        if (e != hipSuccess) {
+            s.p = nullptr;
+            fail(std::string("hipMalloc(") + std::to_string(bytes) + ") failed: " + hipGetErrorString(e));
+            return 2;
+        }
+        s.cap = bytes;
+    }
+    s.busy = true;
+    *p = s.p;
+    return 0;
+}
+
+void scratch_release(int which) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch[which & 7].busy = false;
 }
 
 int launch_symmetrize(double *d_a, int n, hipStream_t st);

@@ -66,9 +66,10 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             return fail("rocsolver_dsyevd failed with status " + std::to_string((int)rs));
     } else {
         // own tridiagonalisation (k_sytrd.hip) + rocSOLVER divide & conquer on T + back-transformation Z = Q C
-        DevBuf tau, c;
+        DevBuf tau;
+        ScratchLease c;
         if (tau.alloc(sizeof(double) * (size_t)n)) return 1;
-        if (c.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
+        if (c.take(0, sizeof(double) * (size_t)n * (size_t)n)) return 1;
         // JXGPU_EIGH_TRACE=1: synchronise and report after every stage (stderr), to locate a failing stage
         const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
         const auto t_begin = std::chrono::steady_clock::now();

@@ -60,4 +60,35 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Scratch block that outlives the call (one per purpose, grown on demand): the eigendecomposition asks for ~4 n^2
+// doubles per call, and each hipMalloc / hipFree pair of that size costs milliseconds (hipFree synchronises the device).
+// Blocks larger than kScratchKeepBytes are released again by the caller's ScratchLease so big problems do not pin HBM.
+constexpr size_t kScratchKeepBytes = (size_t)6 << 30;
+// which: 0 eigh C, 1 stedc arena, 2 sytrd workspace, 3 ormtr workspace.  Returns 0 and *p (kept block), or 1 when
+// the block should be a private allocation (slot in use by a concurrent call, or too large to keep).  api.cpp
+int scratch_acquire(int which, size_t bytes, void **p);
+void scratch_release(int which);
+struct ScratchLease {
+    int which = -1;
+    DevBuf own;
+    void *p = nullptr;
+    int take(int w, size_t bytes) {
+        if (bytes <= kScratchKeepBytes) {
+            const int rc = scratch_acquire(w, bytes, &p);
+            if (rc == 0) {
+                which = w;
+                return 0;
+            }
+            if (rc == 2) return 1;   // allocation failure (message set)
+        }
+        if (own.alloc(bytes)) return 1;
+        p = own.p;
+        return 0;
+    }
+    ~ScratchLease() {
+        if (which >= 0) scratch_release(which);
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 }  // namespace jx

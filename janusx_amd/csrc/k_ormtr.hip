@@ -52,10 +52,10 @@ int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, cons
     if (n < 2) return 0;
     const int nref = n - 1;                          // reflectors 0 .. n-2
     const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB")) : OT_NB;
-    DevBuf vc, mm, w;
-    if (vc.alloc(sizeof(double) * (size_t)n * nb) || mm.alloc(sizeof(double) * (size_t)nb * nb) ||
-        w.alloc(sizeof(double) * (size_t)nb * n))
-        return 1;
+    ScratchLease ws;   // vc (n x nb) | mm (nb x nb) | w (nb x n)
+    const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * n;
+    if (ws.take(3, sizeof(double) * (nvc + nmm + nw))) return 1;
+    double *const vc = ws.as<double>(), *const mm = vc + nvc, *const w = mm + nmm;
     const double one = 1.0, zero = 0.0, minus1 = -1.0;
     const int nblocks = (nref + nb - 1) / nb;
     for (int b = nblocks - 1; b >= 0; --b) {
@@ -63,23 +63,23 @@ int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, cons
         const int nbk = (nref - jb < nb) ? (nref - jb) : nb;
         const int rows = n - jb - 1;
         hipLaunchKernelGGL(ot_extract_v_kernel, dim3((rows + 255) / 256, nbk), dim3(256), 0, st, d_a, n, jb, nbk, d_tau,
-                           vc.as<double>(), rows);
+                           vc, rows);
         JX_LAUNCH_CHECK();
         rocblas_status rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, nbk, rows, &one,
-                                          vc.as<double>(), rows, vc.as<double>(), rows, &zero, mm.as<double>(), nb);
+                                          vc, rows, vc, rows, &zero, mm, nb);
         if (rs != rocblas_status_success) return fail("ormtr: Gram dgemm failed: " + std::to_string((int)rs));
-        hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nbk + 63) / 64, nbk), dim3(64), 0, st, mm.as<double>(), nbk, nb, d_tau,
+        hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nbk + 63) / 64, nbk), dim3(64), 0, st, mm, nbk, nb, d_tau,
                            jb);
         JX_LAUNCH_CHECK();
         double *csub = d_c + (jb + 1);                // rows jb+1 .. n-1 of every column
-        rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, n, rows, &one, vc.as<double>(),
-                           rows, csub, n, &zero, w.as<double>(), nb);
+        rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, n, rows, &one, vc,
+                           rows, csub, n, &zero, w, nb);
         if (rs != rocblas_status_success) return fail("ormtr: V'C dgemm failed: " + std::to_string((int)rs));
         rs = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, nbk,
-                           n, &one, mm.as<double>(), nb, w.as<double>(), nb);
+                           n, &one, mm, nb, w, nb);
         if (rs != rocblas_status_success) return fail("ormtr: dtrsm failed: " + std::to_string((int)rs));
-        rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, rows, n, nbk, &minus1, vc.as<double>(), rows,
-                           w.as<double>(), nb, &one, csub, n);
+        rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, rows, n, nbk, &minus1, vc, rows,
+                           w, nb, &one, csub, n);
         if (rs != rocblas_status_success) return fail("ormtr: update dgemm failed: " + std::to_string((int)rs));
     }
     JX_HIP(hipStreamSynchronize(st));   // work buffers are released on return

@@ -693,9 +693,9 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     // workspace: per level the two half-size eigenvector blocks (n^2/2), their compacted copies when columns were
     // deflated (<= n^2/2) and one U factor at a time (<= n^2/2); the levels below reuse the space above q1/q2, so
     // 2 n^2 doubles cover the recursion; vectors and index lists are O(n) per level
-    DevBuf arena;
+    ScratchLease arena;
     const size_t bytes = dc_arena_bytes(n);
-    if (arena.alloc(bytes)) return 1;
+    if (arena.take(1, bytes)) return 1;
     DcCtx C;
     C.h = h;
     C.st = st;

@@ -414,11 +414,11 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
         if (n == 1) JX_HIP(hipMemcpyAsync(d_d, d_a, sizeof(double), hipMemcpyDeviceToDevice, st));
         return 0;
     }
-    DevBuf work;
+    ScratchLease work;
     const size_t nn = (size_t)n;
     // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
     const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (nn + 2 * TD_NB + 2);
-    if (work.alloc(sizeof(double) * doubles)) return 1;
+    if (work.take(2, sizeof(double) * doubles)) return 1;
     double *p = work.as<double>();
     TdParams P;
     P.a = d_a;

@@ -34,8 +34,13 @@ struct TdAcc {            // one per column parity
     double *y;            // (n)
     double *t1;           // (NB)  V'v
     double *t2;           // (NB)  W'v
-    double *sc;           // [0] v'Tv, [1] norm^2 of the next column below its first sub-diagonal entry
+    double *s0;           // v'Tv in TD_S0 partial sums, one per 128-byte line (slot = workgroup index mod TD_S0)
+    double *s1;           // norm^2 of the next column below its first sub-diagonal entry, TD_S1 partial sums
 };
+// Scalars that every workgroup of a launch adds to are kept as a few partial sums on separate cache lines: atomics on
+// one address retire one after the other (~50 ns each across XCDs), 660 strips adding to a single v'Tv word cost
+// more than the 15 us launch they belong to.
+constexpr int TD_S0 = 32, TD_S1 = 8, TD_SL = 16;   // slots, slots, doubles per slot (128 B)
 
 struct TdParams {
     double *a;            // (n,n) column-major, lower
@@ -49,6 +54,13 @@ struct TdParams {
     double *d, *e, *tau;
     TdAcc acc[2];
 };
+
+__device__ __forceinline__ double td_sum_s1(const double *s1) {
+    double v[TD_S1];
+#pragma unroll
+    for (int k = 0; k < TD_S1; ++k) v[k] = s1[k * TD_SL];
+    return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
 
 __device__ __forceinline__ void larfg_scalars(double alpha0, double xnorm2, int nt, double &beta, double &tau,
                                               double &scale) {
@@ -78,7 +90,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams 
     if (blockIdx.x == 0 && threadIdx.x == 0) P.d[j] = P.a[j + (int64_t)j * P.ld];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-    if ((threadIdx.x & 63) == 0 && sq != 0.0) unsafeAtomicAdd(&P.acc[par].sc[1], sq);
+    if ((threadIdx.x & 63) == 0 && sq != 0.0)
+        unsafeAtomicAdd(&P.acc[par].s1[((blockIdx.x * 4 + (threadIdx.x >> 6)) & (TD_S1 - 1)) * TD_SL], sq);
 }
 
 // Row-chunk part of B(j) (64 rows per workgroup): scaled reflector out (A, vbuf, Vt), V'v and W'v partial sums,
@@ -91,7 +104,7 @@ __device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j
     const int i = j - j0;
     const int tid = threadIdx.x;
     double beta, tau, scale;
-    larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
+    larfg_scalars(P.ubuf[base], td_sum_s1(P.acc[par].s1), nt, beta, tau, scale);
 
     // ---- row chunk (64 rows): scaled reflector out, V'v and W'v partial sums -----------------------------
     const int rrow0 = chunk * TD_TS;  // relative row of this block's first row
@@ -112,9 +125,8 @@ __device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j
     if (chunk == 0 && tid == 0) {
         P.e[j] = beta;
         P.tau[j] = tau;
-        // zero the norm accumulator of the other parity (S(j) accumulates into it)
-        P.acc[par ^ 1].sc[1] = 0.0;
     }
+    if (chunk == 0 && tid < TD_S1) P.acc[par ^ 1].s1[tid * TD_SL] = 0.0;   // S(j) accumulates the next norm there
     if (i > 0) {
         __syncthreads();
         // t1[k] += sum_r Vt[r][k] v_r ; t2[k] += sum_r Wt[r][k] v_r : thread (k = tid & 63, sub = tid >> 6), 16 rows
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
             if (vi < nt) raw_c = P.ubuf[base + vi];
         }
         double beta, tau, scale;
-        larfg_scalars(P.ubuf[base], P.acc[par].sc[1], nt, beta, tau, scale);
+        larfg_scalars(P.ubuf[base], td_sum_s1(P.acc[par].s1), nt, beta, tau, scale);
         if (tid < TD_TS) {
             const int vi = r0 + tid;
             vr[tid] = (vi < nt) ? (vi == 0 ? 1.0 : raw_r * scale) : 0.0;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
         __syncthreads();
         if (tid == 0) {
             const double tot = red1[0] + red1[1] + red1[2] + red1[3];
-            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par].sc[0], tot);
+            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par].s0[(blockIdx.x & (TD_S0 - 1)) * TD_SL], tot);
         }
         return;
     }
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
     const double tau = P.tau[j];
     // every global read of this launch is issued up front (the scalar chain below is otherwise three dependent
     // round trips): v'Tv, y at the first trailing row, then the row-side operands
-    const double yv_all = P.acc[par].sc[0];
+    const double yv_part = (tid < TD_S0) ? P.acc[par].s0[tid * TD_SL] : 0.0;
     const double y_first = P.acc[par].y[base];
     double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
     if (tid < i) {  // i <= 63
@@ -328,10 +340,12 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
         wj1k[tid] = b2;
         double dot = a1 * a2;
         double s1 = b1 * a2 + b2 * a1;
+        double yv_all = yv_part;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             dot += __shfl_xor(dot, off, 64);
             s1 += __shfl_xor(s1, off, 64);
+            yv_all += __shfl_xor(yv_all, off, 64);
         }
         if (tid == 0) {
             const double alpha = -0.5 * tau * tau * (yv_all - 2.0 * dot);
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
             P.acc[par ^ 1].t1[tid] = 0.0;
             P.acc[par ^ 1].t2[tid] = 0.0;
         }
-        if (tid == 0) P.acc[par ^ 1].sc[0] = 0.0;
+        if (tid < TD_S0) P.acc[par ^ 1].s0[tid * TD_SL] = 0.0;
     }
     if (do_next) {
 #pragma unroll
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
         __syncthreads();
         if (tid == 0) {
             const double tot = redn[0] + redn[1] + redn[2] + redn[3];
-            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par ^ 1].sc[1], tot);
+            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par ^ 1].s1[(blockIdx.x & (TD_S1 - 1)) * TD_SL], tot);
         }
     }
 }
@@ -417,7 +431,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     ScratchLease work;
     const size_t nn = (size_t)n;
     // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
-    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (nn + 2 * TD_NB + 2);
+    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL);
     if (work.take(2, sizeof(double) * doubles)) return 1;
     double *p = work.as<double>();
     TdParams P;
@@ -434,7 +448,8 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
         P.acc[q].y = p; p += nn;
         P.acc[q].t1 = p; p += TD_NB;
         P.acc[q].t2 = p; p += TD_NB;
-        P.acc[q].sc = p; p += 2;
+        P.acc[q].s0 = p; p += TD_S0 * TD_SL;
+        P.acc[q].s1 = p; p += TD_S1 * TD_SL;
     }
     const size_t acc_bytes = sizeof(double) * (size_t)(p - acc_begin);
     P.d = d_d;

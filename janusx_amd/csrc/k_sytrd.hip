@@ -31,7 +31,7 @@ constexpr int TD_TS = 64;     // symv tile
 constexpr int TD_THREADS = 256;
 
 struct TdAcc {            // one per column parity
-    double *y;            // (n)
+    double *y;            // (TD_YC, n)  y = T v in TD_YC partial copies (copy = tile row block mod TD_YC)
     double *t1;           // (NB)  V'v
     double *t2;           // (NB)  W'v
     double *s0;           // v'Tv in TD_S0 partial sums, one per 128-byte line (slot = workgroup index mod TD_S0)
@@ -41,6 +41,7 @@ struct TdAcc {            // one per column parity
 // one address retire one after the other (~50 ns each across XCDs), 660 strips adding to a single v'Tv word cost
 // more than the 15 us launch they belong to.
 constexpr int TD_S0 = 32, TD_S1 = 8, TD_SL = 16;   // slots, slots, doubles per slot (128 B)
+constexpr int TD_YC = 4;                           // copies of y (the first column blocks take one atomic per tile row)
 
 struct TdParams {
     double *a;            // (n,n) column-major, lower
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
             q += __shfl_xor(q, 1, 64);
             q += __shfl_xor(q, 2, 64);
             if (qs == 0) {
-                if (c0 + qc < nt && q != 0.0) unsafeAtomicAdd(&P.acc[par].y[base + c0 + qc], q);
+                if (c0 + qc < nt && q != 0.0)
+                    unsafeAtomicAdd(&P.acc[par].y[(int64_t)(rb & (TD_YC - 1)) * n + base + c0 + qc], q);
                 contrib += vc[qc] * q;
             }
             __syncthreads();
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
         __syncthreads();
         if (tid < TD_TS) {
             const double pr = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            if (r0 + tid < nt && pr != 0.0) unsafeAtomicAdd(&P.acc[par].y[base + r0 + tid], pr);
+            if (r0 + tid < nt && pr != 0.0)
+                unsafeAtomicAdd(&P.acc[par].y[(int64_t)(rb & (TD_YC - 1)) * n + base + r0 + tid], pr);
             contrib += vr[tid] * pr;
         }
 #pragma unroll
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
     // every global read of this launch is issued up front (the scalar chain below is otherwise three dependent
     // round trips): v'Tv, y at the first trailing row, then the row-side operands
     const double yv_part = (tid < TD_S0) ? P.acc[par].s0[tid * TD_SL] : 0.0;
-    const double y_first = P.acc[par].y[base];
+    double y_first = 0.0;
+#pragma unroll
+    for (int c = 0; c < TD_YC; ++c) y_first += P.acc[par].y[(int64_t)c * n + base];
     double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
     if (tid < i) {  // i <= 63
         a1 = P.acc[par].t1[tid];
@@ -331,7 +336,9 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
         }
     }
     const double v_r = P.vbuf[r];
-    const double y_r = P.acc[par].y[r];
+    double y_r = 0.0;
+#pragma unroll
+    for (int c = 0; c < TD_YC; ++c) y_r += P.acc[par].y[(int64_t)c * n + r];
     const double a_next = do_next ? P.a[r + (int64_t)(j + 1) * P.ld] : 0.0;
     if (tid < TD_NB) {
         t1s[tid] = a1;
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
                 if (rr >= 2) sq = unew * unew;
             }
         }
-        P.acc[par ^ 1].y[r] = 0.0;
+#pragma unroll
+        for (int c = 0; c < TD_YC; ++c) P.acc[par ^ 1].y[(int64_t)c * n + r] = 0.0;
     }
     if (blockIdx.x == 0) {
         if (tid < TD_NB) {
@@ -431,7 +439,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     ScratchLease work;
     const size_t nn = (size_t)n;
     // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
-    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL);
+    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (TD_YC * nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL);
     if (work.take(2, sizeof(double) * doubles)) return 1;
     double *p = work.as<double>();
     TdParams P;
@@ -445,7 +453,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     P.vbuf = p; p += nn;
     double *acc_begin = p;
     for (int q = 0; q < 2; ++q) {
-        P.acc[q].y = p; p += nn;
+        P.acc[q].y = p; p += TD_YC * nn;
         P.acc[q].t1 = p; p += TD_NB;
         P.acc[q].t2 = p; p += TD_NB;
         P.acc[q].s0 = p; p += TD_S0 * TD_SL;

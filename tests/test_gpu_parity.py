@@ -893,3 +893,48 @@ def test_eigh_own_divide_and_conquer(monkeypatch):
         assert np.max(np.abs(w - w_ref)) < 1e-12 * scale * n ** 0.5, (name, float(np.max(np.abs(w - w_ref))))
         assert np.max(np.abs(u.T @ u - np.eye(n))) < 1e-11, (name, float(np.max(np.abs(u.T @ u - np.eye(n)))))
         assert np.max(np.abs(a @ u - u * w)) < 1e-11 * scale, (name, float(np.max(np.abs(a @ u - u * w))))
+
+
+@pytest.mark.parametrize("n,m,p,seed", [(17, 40, 1, 1), (130, 90, 4, 2), (257, 120, 8, 3), (300, 64, 15, 4), (64, 33, 2, 5)])
+def test_small_shapes_and_many_covariates(oracle, oracle_c, n, m, p, seed):
+    """Edge shapes through the C ABI: n below / across the 128-sample tile, n not a multiple of 4, one SNP block smaller
+    than any tile, covariate counts up to the JXG_MAX_COV = 15 instantiation (dim = 16), heavy missingness."""
+    from janusx_amd import janusx as jxrs
+    rng = np.random.default_rng(seed)
+    packed, g = bed.synth_panel_numpy(n, m, seed=100 + seed, missing_rate=0.08)
+    g[0, :] = -9                      # all missing
+    g[1, : n // 2] = -9               # half missing
+    packed = bed.pack_dosage(g)
+    mi, he, ho = oracle.row_counts(packed, n)
+    c = jxrs.bed_row_counts(packed, n)
+    assert np.array_equal(c[:, 0], mi) and np.array_equal(c[:, 1], he) and np.array_equal(c[:, 2], ho)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.0, 1.0, 1.0)
+    k = jxrs.grm_packed_f64(packed[keep], n, flip[keep], maf[keep], None, 1)
+    k_ref = oracle.grm_packed(packed[keep], n, flip[keep], maf[keep], None, 1, out_dtype=np.float64)
+    k_ref = k_ref[0] if isinstance(k_ref, tuple) else k_ref
+    assert _grm_err(k, k_ref) < TOL
+    s, u = oracle.eigh_sym(np.asarray(k_ref, dtype=np.float64) + 1e-6 * np.eye(n))
+    ev = jxrs.rust_eigh_from_array_f64(np.asarray(k_ref, dtype=np.float64) + 1e-6 * np.eye(n))
+    assert np.max(np.abs(ev[0] - s)) < 1e-11 * max(1.0, float(np.max(np.abs(s))))
+    u_t = np.ascontiguousarray(u.T.astype(np.float32))
+    x = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, p - 1))], axis=1)
+    y = rng.normal(size=n)
+    if n <= p + 1:
+        return
+    xr, yr = jxrs.lmm_rotate_x_y_with_ut_f64(u_t, x, y)
+    xr_ref, yr_ref = oracle.lmm_rotate_x_y_with_ut(u_t, x, y)
+    assert np.max(np.abs(xr - xr_ref)) < 1e-11 and np.max(np.abs(yr - yr_ref)) < 1e-11
+    lbd, ml, reml = jxrs.lmm_reml_null_f32(s, xr, yr.ravel(), -5.0, 5.0, 50, 1e-3)
+    lbd_c, ml_c, reml_c = oracle_c.lmm_reml_null(s, xr, yr.ravel(), -5.0, 5.0, 50, 1e-3)
+    assert abs(lbd - lbd_c) < 1e-7 * lbd_c and abs(reml - reml_c) < 1e-8 * abs(reml_c)
+    pk = np.ascontiguousarray(packed[keep])
+    gd = oracle.decode_centered_block_f32(pk, n, flip[keep], maf[keep])
+    grot = oracle.rotate_block_f32(gd, u_t)
+    ref = oracle_c.lmm_scan_rotated_block(grot, s, xr, yr.ravel(), -5.0, 5.0, 50, 1e-2)
+    out = jxrs.lmm_reml_assoc_packed_f32(pk, n, flip[keep], maf[keep], s, xr, yr.ravel(), u_t)
+    be, se, pe = _assoc_err(out, ref)
+    assert max(be, se) < 5 * TOL, (be, se, pe)     # tiny n: a few rows sit on flat likelihoods
+    fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(s, xr, yr.ravel(), lbd_c))
+    fout = jxrs.fvlmm_assoc_packed_f32(pk, n, flip[keep], maf[keep], s, xr, yr.ravel(), u_t, math.log10(lbd_c))
+    be, se, pe = _assoc_err(fout, fref)
+    assert max(be, se) < 5 * TOL, (be, se, pe)

@@ -32,6 +32,117 @@ __device__ __forceinline__ double sd_wave_prod(double v) {
     return v;
 }
 
+// All rank-one tears of the recursion at once: split point k (between rows k-1 and k): d[k-1] -= |e[k-1]|, d[k] -= |e[k-1]|.
+// Every diagonal entry belongs to at most one tear on each side, leaves have >= 2 rows, so the updates are disjoint.
+__global__ void sd_tear_all_kernel(double *__restrict__ d, const double *__restrict__ e, const int *__restrict__ split,
+                                   int nsplit) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsplit) return;
+    const int k = split[t];
+    const double a = fabs(e[k - 1]);
+    d[k - 1] -= a;
+    d[k] -= a;
+}
+
+// Leaf problems (<= SD_LEAF rows), one workgroup each: implicit-shift QL (EISPACK imtql2 / LAPACK dsteqr's QL branch)
+// with the eigenvector matrix resident in LDS.  Thread 0 runs the scalar recurrence of one sweep and leaves the plane
+// rotations in LDS; every thread then applies the sweep to its own row of Z.  d receives the eigenvalues (unsorted),
+// zpool + zoff[leaf] the eigenvectors (column-major nl x nl).
+constexpr int SD_LEAF = 128;
+__global__ __launch_bounds__(256) void sd_leaf_ql_kernel(double *__restrict__ dg, const double *__restrict__ eg,
+                                                         const int *__restrict__ off, const int *__restrict__ len,
+                                                         const int64_t *__restrict__ zoff, double *__restrict__ zpool,
+                                                         int *__restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int leaf = blockIdx.x;
+    const int nl = len[leaf];
+    const int g0 = off[leaf];
+    double *z = lds;                       // z[i * nl + k] = Z(k, i)
+    double *d = lds + (size_t)nl * nl;
+    double *e = d + nl;
+    double *cs = e + nl;                   // (c_i, s_i) pairs
+    __shared__ int sh_m, sh_lo;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < nl * nl; t += 256) z[t] = 0.0;
+    __syncthreads();
+    if (tid < nl) {
+        z[tid * nl + tid] = 1.0;
+        d[tid] = dg[g0 + tid];
+        e[tid] = (tid < nl - 1) ? eg[g0 + tid] : 0.0;
+    }
+    __syncthreads();
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < nl; ++l) {
+        for (int iter = 0;; ++iter) {
+            if (tid == 0) {
+                int m = l;
+                for (; m < nl - 1; ++m) {
+                    const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                    if (fabs(e[m]) <= eps * dd) break;
+                }
+                sh_m = m;
+                sh_lo = m;   // first rotation index that is valid (rotations cover [sh_lo, m-1])
+                if (m != l) {
+                    if (iter >= 60) {
+                        *err = 1;
+                        sh_m = l;   // give up on this eigenvalue
+                    } else {
+                        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                        double r = sqrt(g * g + 1.0);
+                        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                        double s = 1.0, c = 1.0, p = 0.0;
+                        int i = m - 1;
+                        bool underflow = false;
+                        for (; i >= l; --i) {
+                            double f = s * e[i];
+                            const double b = c * e[i];
+                            r = sqrt(f * f + g * g);
+                            e[i + 1] = r;
+                            if (r == 0.0) {
+                                d[i + 1] -= p;
+                                e[m] = 0.0;
+                                underflow = true;
+                                break;
+                            }
+                            s = f / r;
+                            c = g / r;
+                            g = d[i + 1] - p;
+                            r = (d[i] - g) * s + 2.0 * c * b;
+                            p = s * r;
+                            d[i + 1] = g + p;
+                            g = c * r - b;
+                            cs[2 * i] = c;
+                            cs[2 * i + 1] = s;
+                        }
+                        sh_lo = i + 1;
+                        if (!underflow) {
+                            d[l] -= p;
+                            e[l] = g;
+                            e[m] = 0.0;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int m = sh_m, lo = sh_lo;
+            if (m == l) break;
+            if (tid < nl) {
+                for (int i = m - 1; i >= lo; --i) {
+                    const double c = cs[2 * i], sn = cs[2 * i + 1];
+                    const double f = z[(i + 1) * nl + tid];
+                    const double zi = z[i * nl + tid];
+                    z[(i + 1) * nl + tid] = sn * zi + c * f;
+                    z[i * nl + tid] = c * zi - sn * f;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < nl) dg[g0 + tid] = d[tid];
+    double *zo = zpool + zoff[leaf];
+    for (int t = tid; t < nl * nl; t += 256) zo[t] = z[t];
+}
+
 __global__ void sd_tear_kernel(double *d2, const double *amt) {
     if (threadIdx.x < 2) d2[threadIdx.x] -= amt[threadIdx.x];
 }
@@ -273,6 +384,12 @@ struct DcCtx {
     int depth = 0;      // recursion depth of the current call
     int par_depth = 0;  // the two halves of a problem run concurrently (own host thread, stream, handle) above it
     int device = 0;
+    // own leaf solver (sd_leaf_ql_kernel): every leaf of the tree is solved by one batched launch before the recursion
+    bool own_leaf = false;
+    const std::vector<int> *leaf_off = nullptr;     // ascending global offsets of the leaves
+    const std::vector<int64_t> *leaf_zoff = nullptr;
+    const double *zpool = nullptr;                  // device
+    const double *hleaf_w = nullptr;                // host copy of the leaf eigenvalues (whole problem)
     Arena ar;
     const double *hd0, *he0;              // host copy of the tridiagonal (whole problem)
     double *d_base, *e_base;              // device d / e of the whole problem (offsets recover the host index)
@@ -334,6 +451,15 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     rocblas_handle h = C.h;
     hipStream_t st = C.st;
     const size_t mark = C.ar.off;
+    if (C.own_leaf && (n <= C.leaf || n < 4)) {
+        const int g0 = (int)(d_d - C.d_base);
+        const auto it = std::lower_bound(C.leaf_off->begin(), C.leaf_off->end(), g0);
+        if (it == C.leaf_off->end() || *it != g0) return fail("stedc: leaf plan mismatch");
+        const int64_t zo = (*C.leaf_zoff)[it - C.leaf_off->begin()];
+        JX_HIP(hipMemcpyAsync(d_c, C.zpool + zo, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+        h_w.assign(C.hleaf_w + g0, C.hleaf_w + g0 + n);
+        return 0;
+    }
     if (n <= C.leaf || n < 4) {
         ABuf linfo;
         SD_TAKE(linfo, sizeof(rocblas_int));
@@ -353,7 +479,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     const size_t g0 = (size_t)(d_d - C.d_base);          // position of this block in the whole problem
     const double rho0 = C.he0[g0 + k1 - 1];
     const double absrho = fabs(rho0), sgn = (rho0 < 0.0) ? -1.0 : 1.0;
-    {
+    if (!C.own_leaf) {
         // rank-one tear: d[k1-1] -= |rho|, d[k1] -= |rho| (dlaed0).  Each diagonal entry is torn at most once per
         // level, and by exactly one ancestor chain, so the host copy needs no update: apply on the device values.
         std::vector<double> two = {absrho, absrho};
@@ -398,6 +524,11 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
             C2.he0 = C.he0;
             C2.d_base = C.d_base;
             C2.e_base = C.e_base;
+            C2.own_leaf = C.own_leaf;
+            C2.leaf_off = C.leaf_off;
+            C2.leaf_zoff = C.leaf_zoff;
+            C2.zpool = C.zpool;
+            C2.hleaf_w = C.hleaf_w;
             std::thread th([&]() {
                 if (hipSetDevice(C2.device) != hipSuccess || hipStreamWaitEvent(C2.st, ready, 0) != hipSuccess) {
                     rc2 = 1;
@@ -419,6 +550,11 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
             C1.he0 = C.he0;
             C1.d_base = C.d_base;
             C1.e_base = C.e_base;
+            C1.own_leaf = C.own_leaf;
+            C1.leaf_off = C.leaf_off;
+            C1.leaf_zoff = C.leaf_zoff;
+            C1.zpool = C.zpool;
+            C1.hleaf_w = C.hleaf_w;
             const int rc1 = stedc_dc(C1, k1, d_d, d_e, q1.as<double>(), w1);
             th.join();
             (void)hipEventDestroy(ready);
@@ -712,6 +848,75 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     C.he0 = he.data();
     C.d_base = d_d;
     C.e_base = d_e;
+    std::vector<int> leaf_off, leaf_len, splits;
+    std::vector<int64_t> leaf_zoff;
+    std::vector<double> hleaf_w;
+    DevBuf zpool, dplan, derr;
+    // leaves: one batched launch of the QL kernel (default) or rocSOLVER dstedc per leaf (JXGPU_STEDC_OWNLEAF=0, and
+    // whenever the requested leaf size exceeds what fits the LDS-resident eigenvector block)
+    const char *ol = getenv("JXGPU_STEDC_OWNLEAF");
+    const bool want_own = !(ol && ol[0] == '0');
+    const int own_leaf_rows = (getenv("JXGPU_STEDC_LEAF") && leaf < SD_LEAF) ? (leaf < 2 ? 2 : leaf) : SD_LEAF;
+    if (want_own && n > own_leaf_rows) {
+        C.own_leaf = true;
+        C.leaf = own_leaf_rows;
+        // the same halving rule as the recursion, down to <= SD_LEAF rows
+        std::vector<std::pair<int, int>> stack = {{0, n}};
+        std::vector<std::pair<int, int>> leaves;
+        while (!stack.empty()) {
+            const auto [g0, len] = stack.back();
+            stack.pop_back();
+            if (len <= own_leaf_rows || len < 4) {
+                leaves.push_back({g0, len});
+                continue;
+            }
+            const int k1 = len / 2;
+            splits.push_back(g0 + k1);
+            stack.push_back({g0, k1});
+            stack.push_back({g0 + k1, len - k1});
+        }
+        std::sort(leaves.begin(), leaves.end());
+        int64_t zo = 0;
+        for (const auto &lf : leaves) {
+            leaf_off.push_back(lf.first);
+            leaf_len.push_back(lf.second);
+            leaf_zoff.push_back(zo);
+            zo += (int64_t)lf.second * lf.second;
+        }
+        const int nleaf = (int)leaves.size(), nsplit = (int)splits.size();
+        if (zpool.alloc(sizeof(double) * (size_t)zo) || derr.alloc(sizeof(int)) ||
+            dplan.alloc(sizeof(int) * (size_t)(2 * nleaf + nsplit) + sizeof(int64_t) * (size_t)nleaf + 64))
+            return 1;
+        int64_t *p_zoff = reinterpret_cast<int64_t *>(dplan.p);
+        int *p_off = reinterpret_cast<int *>(p_zoff + nleaf), *p_len = p_off + nleaf, *p_split = p_len + nleaf;
+        JX_HIP(hipMemcpyAsync(p_zoff, leaf_zoff.data(), sizeof(int64_t) * nleaf, hipMemcpyHostToDevice, st));
+        JX_HIP(hipMemcpyAsync(p_off, leaf_off.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice, st));
+        JX_HIP(hipMemcpyAsync(p_len, leaf_len.data(), sizeof(int) * nleaf, hipMemcpyHostToDevice, st));
+        JX_HIP(hipMemcpyAsync(p_split, splits.data(), sizeof(int) * nsplit, hipMemcpyHostToDevice, st));
+        JX_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(sd_tear_all_kernel, dim3((nsplit + 255) / 256), dim3(256), 0, st, d_d, d_e, p_split, nsplit);
+        JX_LAUNCH_CHECK();
+        const size_t lds = sizeof(double) * ((size_t)SD_LEAF * SD_LEAF + 4 * SD_LEAF);
+        static bool attr_done = false;
+        if (!attr_done) {
+            JX_HIP(hipFuncSetAttribute((const void *)sd_leaf_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(sd_leaf_ql_kernel, dim3(nleaf), dim3(256), lds, st, d_d, d_e, p_off, p_len, p_zoff,
+                           zpool.as<double>(), derr.as<int>());
+        JX_LAUNCH_CHECK();
+        hleaf_w.resize((size_t)n);
+        int herr = 0;
+        JX_HIP(hipMemcpyAsync(hleaf_w.data(), d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        JX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        JX_HIP(hipStreamSynchronize(st));
+        if (herr) return fail("stedc: the QL leaf solver did not converge");
+        C.leaf_off = &leaf_off;
+        C.leaf_zoff = &leaf_zoff;
+        C.zpool = zpool.as<double>();
+        C.hleaf_w = hleaf_w.data();
+    }
     std::vector<double> w;
     if (stedc_dc(C, n, d_d, d_e, d_c, w)) return 1;
     h_perm.resize((size_t)n);

@@ -3,13 +3,13 @@
 Flag names, defaults and output file names follow the reference (python/janusx/assoc/workflow.py:6599-7047,
 python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model_stream.py:989-994):
 
-  python -m janusx_amd gwas -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] (-lmm | -fvlmm) [-k 1|2|GRM.npy] [-c COV.tsv]
+  python -m janusx_amd gwas -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] (-lmm | -lmm2 | -fvlmm) [-k 1|2|GRM.npy] [-c COV.tsv]
                             [-maf 0.02] [-geno 0.05] [-het 1.0] [-o OUT] [-force-model]
   python -m janusx_amd grm  -bfile PREFIX [-m 1|2] [-maf 0.02] [-geno 0.05] [-o OUT]
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -BLUP [-cv K] [-seed 42] [-k GRM.npy]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`;
+Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`;
 `{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
@@ -114,8 +114,8 @@ def cmd_gwas(args):
     from . import pipeline as pl
     from .bed import read_bed_payload, read_fam_ids
     from .tsv import write_assoc_tsv
-    if not (args.lmm or args.fvlmm):
-        raise SystemExit("select at least one model: -lmm and/or -fvlmm")
+    if not (args.lmm or args.fvlmm or args.lmm2):
+        raise SystemExit("select at least one model: -lmm, -lmm2 and/or -fvlmm")
     packed, n_fam, bim = read_bed_payload(args.bfile)
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
@@ -153,7 +153,7 @@ def cmd_gwas(args):
         x = np.ones((n, 1))
         if args.cov:
             x = np.concatenate([x, np.array([cv[cpos[fam[j]]] for j in keep_idx])], axis=1)
-        for mode in (["lmm"] if args.lmm else []) + (["fvlmm"] if args.fvlmm else []):
+        for mode in (["lmm"] if args.lmm else []) + (["lmm2"] if args.lmm2 else []) + (["fvlmm"] if args.fvlmm else []):
             t1 = time.perf_counter()
             res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het)
             # LMM -> LM fallback test (src/stats/gwas_unified.rs:121-175); the LM scan itself is out of scope
@@ -242,6 +242,7 @@ def main(argv=None):
     g.add_argument("-p", "--pheno", required=True)
     g.add_argument("-n", "--n", dest="ncol", action="append", default=None)
     g.add_argument("-lmm", "--lmm", action="store_true", default=False)
+    g.add_argument("-lmm2", "--lmm2", action="store_true", default=False)
     g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
     g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
     g.add_argument("-c", "--cov", dest="cov", default=None)

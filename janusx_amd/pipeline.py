@@ -219,9 +219,10 @@ class SpectralModel:
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
               times: StageTimes = None, nullml=None):
-    """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML) or 'fvlmm' (fixed lambda).
-    Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns [.., plrt] when `nullml` is given --
-    (and the per-SNP Brent evaluation counts)."""
+    """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML), 'fvlmm' (fixed lambda) or 'lmm2' (REML Wald +
+    ML likelihood ratio, needs `nullml`).  Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns
+    [.., plrt] when `nullml` is given, 6 columns [beta, se, pwald, lambda, ml, plrt] for 'lmm2' -- (and the per-SNP
+    Brent evaluation counts)."""
     dev = panel.device
     n = model.n
     if panel.n != n:
@@ -229,7 +230,9 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     mk = len(rows)
     with_plrt = 1 if nullml is not None else 0
     nullml_v = float(nullml) if nullml is not None else 0.0
-    out = torch.empty((mk, 4 if with_plrt else 3), dtype=torch.float64, device=dev)
+    if mode == "lmm2" and nullml is None:
+        raise RuntimeError("lmm2 needs the null ML (nullml)")
+    out = torch.empty((mk, 6 if mode == "lmm2" else (4 if with_plrt else 3)), dtype=torch.float64, device=dev)
     evals = torch.zeros(mk, dtype=torch.int32, device=dev) if return_evals else None
     if mk == 0:
         return (out, evals) if return_evals else out
@@ -241,7 +244,11 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
     check(lib().jxg_lut_split(_ptr(lut_t), mk, _ptr(lut16), _stream()))
     tables = None
-    if mode == "lmm":
+    if mode == "lmm2":
+        lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
+        warm = 1 if init_log10_lbd is not None else 0
+        init = float(init_log10_lbd) if init_log10_lbd is not None else 0.0
+    elif mode == "lmm":
         lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
         warm = 1 if init_log10_lbd is not None else 0
         init = float(init_log10_lbd) if init_log10_lbd is not None else 0.0
@@ -269,7 +276,10 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             ev_rot[bi][1].record()
             ev_scan[bi][0].record()
         o = out[r0:]
-        if mode == "lmm":
+        if mode == "lmm2":
+            check(lib().jxg_lmm2_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p, lo_b,
+                                      hi_b, float(tol), int(max_iter), warm, init, nullml_v, o.data_ptr(), _stream()))
+        elif mode == "lmm":
             ev_p = evals[r0:].data_ptr() if evals is not None else None
             if tables is not None:
                 check(lib().jxg_lmm_scan_tab(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), model.p, lo_b, hi_b,
@@ -342,6 +352,19 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
         if init is not None:
             init = min(max(init, model.null.bounds[0]), model.null.bounds[1])
         out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init)
+    elif mode == "lmm2":
+        # null ML by Brent on -ml_loglike, seeded with the REML optimum (src/stats/lmm.rs:2902-2921; the workflow passes
+        # bounds, max_iter = 30, tol = 1e-2 and init_log10_lbd_reml = log10 lambda0: workflow_model_stream.py:1499-1590)
+        o2 = torch.empty(2, dtype=torch.float64, device=packed.device)
+        lo_b, hi_b = model.null.bounds
+        init = min(max(math.log10(model.null.lbd), lo_b), hi_b) if model.null.lbd > 0 else None
+        check(lib().jxg_lmm2_null_ml(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b, int(max_iter),
+                                     float(tol), 1 if init is not None else 0, float(init or 0.0), o2.data_ptr(),
+                                     _stream()))
+        ml0 = float(o2.cpu().numpy()[1])
+        if not math.isfinite(ml0):
+            raise RuntimeError("failed to optimize null ML for LMM2 unified scan")
+        out = scan_rows(panel, model, rows, lut, "lmm2", max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=ml0)
     else:
         out = scan_rows(panel, model, rows, lut, "fvlmm")
     return GwasResult(keep, af[rows], miss[rows], out.cpu().numpy(), model.null, 0, {})

@@ -411,6 +411,19 @@ def test_cli_gwas_with_missing_phenotypes(oracle, oracle_c, tmp_path):
         f = ln.split("\t")
         assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}" and f[6] == f"{float(miss[j]):.4f}"
         assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 and abs(float(f[8]) - ref[i, 1]) <= 1.5e-4
+    # -lmm2: null ML by Brent seeded with the REML optimum, then the 6-column scan (Lmm2_6 schema)
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm2", "-force-model", "-o", prefix]) == 0
+    l2 = open(prefix + ".traitA.lmm2.tsv").read().splitlines()
+    assert l2[0].split("\t")[-3:] == ["lambda", "ml", "plrt"] and len(l2) == len(rows) + 1
+    init = min(max(math.log10(nm.lbd_null), nm.bounds[0]), nm.bounds[1])
+    _, ml0 = oracle_c.lmm2_null_ml(nm.S, nm.Xcov, nm.y, nm.bounds[0], nm.bounds[1], 30, 1e-2, init=init)
+    ref2 = oracle_c.lmm2_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, nm.bounds[0],
+                                            nm.bounds[1], 30, 1e-2, ml0, init=init)
+    for i, ln in enumerate(l2[1:]):
+        f = ln.split("\t")
+        assert abs(float(f[7]) - ref2[i, 0]) <= 1.5e-4 and abs(float(f[8]) - ref2[i, 1]) <= 1.5e-4
+        assert abs(float(f[12]) - ref2[i, 4]) <= 3e-6 * abs(ref2[i, 4])
+        assert abs(float(f[13]) - ref2[i, 5]) <= 5e-4 * ref2[i, 5] + 1e-300
     assert cli.main(["grm", "-bfile", prefix, "-m", "1", "-o", prefix]) == 0
     kk = np.load(prefix + ".cGRM.npy")
     assert kk.dtype == np.float32 and _grm_err(kk, k_ref) < TOL

@@ -99,6 +99,25 @@ __device__ __forceinline__ void decode16_to_lds(uint32_t w, const uint4 L, const
     *reinterpret_cast<u32x4 *>(dst_lo + half_off) = l1;
 }
 
+// hi plane only (exact-integer steps: the lo plane is identically zero)
+__device__ __forceinline__ void decode16_hi_to_lds(uint32_t w, const uint4 L, const uint32_t *__restrict__ seltab,
+                                                   uint8_t *dst_hi, int half_off) {
+    u32x4 h0, h1;
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = seltab[(w >> (4 * i)) & 15u];
+    h0.x = __builtin_amdgcn_perm(L.y, L.x, s[0]);
+    h0.y = __builtin_amdgcn_perm(L.y, L.x, s[1]);
+    h0.z = __builtin_amdgcn_perm(L.y, L.x, s[2]);
+    h0.w = __builtin_amdgcn_perm(L.y, L.x, s[3]);
+    h1.x = __builtin_amdgcn_perm(L.y, L.x, s[4]);
+    h1.y = __builtin_amdgcn_perm(L.y, L.x, s[5]);
+    h1.z = __builtin_amdgcn_perm(L.y, L.x, s[6]);
+    h1.w = __builtin_amdgcn_perm(L.y, L.x, s[7]);
+    *reinterpret_cast<u32x4 *>(dst_hi) = h0;
+    *reinterpret_cast<u32x4 *>(dst_hi + half_off) = h1;
+}
+
 // MFMA operand (8 consecutive k for this lane's sample) from a [k][sample] image: two transposed reads.
 template <int PITCH>
 __device__ __forceinline__ half8 tr_frag(const uint8_t *img_lane_base) {
@@ -122,11 +141,14 @@ __device__ __forceinline__ half8 tr_frag(const uint8_t *img_lane_base) {
 //                      2 workgroups per CU keep one decoding while the other issues MFMAs
 //   DBUF: two LDS image sets; the decode of step k+1 is issued in the same barrier interval as the MFMAs of step k
 //   (one barrier per step, VALU/LDS-write work rides in the MFMA issue gaps) at 2 workgroups per CU.
-template <int TM, int TN, int WM, int WN, bool DBUF>
-__global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 ? 3 : 2))) void grm_f16x2_kernel(
+//   EXACT: every LUT value of the SNP range is a small integer (lo plane zero): one image per panel, one MFMA
+//   product per k-step; `corr` (r[0..ld), B at [ld]) adds the affine terms r_i + r_j + B of the integer
+//   factorisation z = beta + c to the first chunk's merge (see jxg_grm_accumulate).
+template <int TM, int TN, int WM, int WN, bool DBUF, bool EXACT = false, int BK = G_BK>
+__global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? (EXACT ? 4 : 2) : (TM == 128 ? (EXACT ? 4 : 3) : 2))) void grm_f16x2_kernel(
     const uint8_t *__restrict__ p32, int64_t m_total, const int32_t *__restrict__ rows,
     const uint4 *__restrict__ lut16, int64_t k_begin, int64_t k_end, int kchunk, int nt128,
-    double *__restrict__ acc, int64_t ld, int use_atomic) {
+    double *__restrict__ acc, int64_t ld, int use_atomic, const double *__restrict__ corr) {
     constexpr int NWN = TN / WN;
     constexpr int NTHREADS = 64 * (TM / WM) * NWN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -136,11 +158,12 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 
     // pitch (row bytes + 32) puts the four rows of a transposed read on disjoint banks (pitch/4 = 8 mod 64).
     constexpr int PA = TM * 2 + 32;   // bytes per SNP row of the A images
     constexpr int PB = TN * 2 + 32;
-    constexpr int IMG_A = G_BK * PA, IMG_B = G_BK * PB;
+    constexpr int IMG_A = BK * PA, IMG_B = BK * PB;
     constexpr int DWA = TM / 16, DWB = TN / 16;  // payload dwords per SNP row of each panel
-    constexpr int NA = G_BK * DWA / NTHREADS, NB = G_BK * DWB / NTHREADS;  // payload dwords per thread per step
-    static_assert(NA * NTHREADS == G_BK * DWA && NB * NTHREADS == G_BK * DWB, "panel dwords must divide evenly");
-    constexpr int SET = 2 * IMG_A + 2 * IMG_B;  // one set of the four images
+    constexpr int NA = BK * DWA / NTHREADS, NB = BK * DWB / NTHREADS;  // payload dwords per thread per step
+    static_assert(NA * NTHREADS == BK * DWA && NB * NTHREADS == BK * DWB, "panel dwords must divide evenly");
+    constexpr int NPL = EXACT ? 1 : 2;           // planes per panel
+    constexpr int SET = NPL * (IMG_A + IMG_B);   // one set of the images: A hi [A lo] B hi [B lo]
     __shared__ __attribute__((aligned(16))) uint8_t smem[(DBUF ? 2 : 1) * SET + 64];
     uint32_t *seltab = reinterpret_cast<uint32_t *>(smem + (DBUF ? 2 : 1) * SET);
 
@@ -227,44 +250,52 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 
     const int offB = (8 * h + q) * PB + ((pp >> 1) * DWB + (g & 1)) * 16 + (pp & 1) * 8;
 
     auto decode_to = [&](uint8_t *base) {
-        uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + 2 * IMG_A, *sBl = base + 2 * IMG_A + IMG_B;
+        uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + NPL * IMG_A, *sBl = base + NPL * IMG_A + IMG_B;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int idx = tid + u * NTHREADS;
             const int kk = idx / DWA, d = idx % DWA;
-            decode16_to_lds(wA[u], LA[u], seltab, sAh + kk * PA + d * 16, sAl + kk * PA + d * 16, DWA * 16);
+            if constexpr (EXACT)
+                decode16_hi_to_lds(wA[u], LA[u], seltab, sAh + kk * PA + d * 16, DWA * 16);
+            else
+                decode16_to_lds(wA[u], LA[u], seltab, sAh + kk * PA + d * 16, sAl + kk * PA + d * 16, DWA * 16);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int idx = tid + u * NTHREADS;
             const int kk = idx / DWB, d = idx % DWB;
-            decode16_to_lds(wB[u], LB[u], seltab, sBh + kk * PB + d * 16, sBl + kk * PB + d * 16, DWB * 16);
+            if constexpr (EXACT)
+                decode16_hi_to_lds(wB[u], LB[u], seltab, sBh + kk * PB + d * 16, DWB * 16);
+            else
+                decode16_to_lds(wB[u], LB[u], seltab, sBh + kk * PB + d * 16, sBl + kk * PB + d * 16, DWB * 16);
         }
     };
     auto mfma_from = [&](const uint8_t *base) {
-        const uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + 2 * IMG_A, *sBl = base + 2 * IMG_A + IMG_B;
+        const uint8_t *sAh = base, *sAl = base + IMG_A, *sBh = base + NPL * IMG_A, *sBl = base + NPL * IMG_A + IMG_B;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             half8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int off = ks * 16 * PA + offA + ((wm * WM + mi * 32) / 16) * 16;
                 ah[mi] = tr_frag<PA>(sAh + off);
-                al[mi] = tr_frag<PA>(sAl + off);
+                if constexpr (!EXACT) al[mi] = tr_frag<PA>(sAl + off);
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int off = ks * 16 * PB + offB + ((wn * WN + ni * 32) / 16) * 16;
                 bh[ni] = tr_frag<PB>(sBh + off);
-                bl[ni] = tr_frag<PB>(sBl + off);
+                if constexpr (!EXACT) bl[ni] = tr_frag<PB>(sBl + off);
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], c[mi][ni], 0, 0, 0);
-                    c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], c[mi][ni], 0, 0, 0);
-                    c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], c[mi][ni], 0, 0, 0);
+                    if constexpr (!EXACT) {
+                        c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], c[mi][ni], 0, 0, 0);
+                        c[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], c[mi][ni], 0, 0, 0);
+                    }
                 }
         }
     };
@@ -272,22 +303,22 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 
     prefetch(k0);
     __syncthreads();  // selector table ready
     if constexpr (!DBUF) {
-        for (int64_t kbase = k0; kbase < k1; kbase += G_BK) {
+        for (int64_t kbase = k0; kbase < k1; kbase += BK) {
             decode_to(smem);
             __syncthreads();
-            prefetch(kbase + G_BK);
+            prefetch(kbase + BK);
             mfma_from(smem);
             __syncthreads();
         }
     } else {
         decode_to(smem);
-        prefetch(k0 + G_BK);
+        prefetch(k0 + BK);
         __syncthreads();
         int cur = 0;
-        for (int64_t kbase = k0; kbase < k1; kbase += G_BK) {
+        for (int64_t kbase = k0; kbase < k1; kbase += BK) {
             // same barrier interval: decode step k+1 into the other image set, MFMAs of step k from this one
-            if (kbase + G_BK < k1) decode_to(smem + (cur ^ 1) * SET);
-            prefetch(kbase + 2 * G_BK);
+            if (kbase + BK < k1) decode_to(smem + (cur ^ 1) * SET);
+            prefetch(kbase + 2 * BK);
             mfma_from(smem + cur * SET);
             __syncthreads();
             cur ^= 1;
@@ -295,17 +326,21 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 
     }
 
     // f64 merge: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool add_corr = EXACT && corr != nullptr && k0 == k_begin;
+    const double corr_b = add_corr ? corr[ld] : 0.0;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int64_t gj = (int64_t)tj * TN + wn * WN + ni * 32 + (lane & 31);
+            const double corr_j = (add_corr && gj < ld) ? corr[gj] + corr_b : 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t gi = (int64_t)ti * TM + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gi < ld && gj < ld) {
                     double *dst = acc + gi * ld + gj;
-                    const double v = (double)c[mi][ni][r];
+                    double v = (double)c[mi][ni][r];
+                    if (add_corr) v += corr[gi] + corr_j;
                     if (use_atomic) {
                         unsafeAtomicAdd(dst, v);
                     } else {
@@ -314,6 +349,136 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? 2 : (TM == 128 
                 }
             }
         }
+}
+
+
+// ---- exact-integer factorisation of design rows -------------------------------------------------------------------
+// A SNP whose three genotype values are beta + {0,1,2} (method 1: g - 2p, either allele orientation) and that has
+// no missing call among the selected samples contributes
+//     sum_j (beta_j + c_ij)(beta_j + c_kj) = sum_j c_ij c_kj + r_i + r_k + B,   r = C beta,  B = sum_j beta_j^2,
+// with c in {0,1,2}: the Gram term is exact in fp16 x fp16 -> f32 (one MFMA product instead of three, sums
+// <= 4 * kchunk < 2^24) and the affine terms are one f64 matrix-vector product over the payload.  The reference
+// rounds g - 2p to f32 before its SSYRK (src/decode/decode.rs:813-839), i.e. differs from beta + c by <= 1 ulp(2).
+
+// flag[k] = 1 if SNP k qualifies; beta[k] (f64), ilut[k] = integer LUT {c(00), 0, c(10), c(11)} as f32.
+__global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                           const int32_t *__restrict__ rows,
+                                                           const float *__restrict__ lut, int64_t mk, int n_sel,
+                                                           int nt128, int32_t *__restrict__ flag,
+                                                           double *__restrict__ beta, float *__restrict__ ilut) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= mk) return;
+    const float v0 = lut[k * 4 + 0], v2 = lut[k * 4 + 2], v3 = lut[k * 4 + 3];
+    const float b = fminf(v0, v3);
+    const float c0 = v0 - b, c2 = v2 - b, c3 = v3 - b;
+    const float tol = 4e-6f;
+    bool ok = fabsf(c2 - 1.0f) <= tol &&
+              ((fabsf(c0) <= tol && fabsf(c3 - 2.0f) <= tol) || (fabsf(c0 - 2.0f) <= tol && fabsf(c3) <= tol)) &&
+              fabsf(b) <= 4.0f;
+    const float r0 = (c0 > 1.0f) ? 2.0f : 0.0f, r3 = 2.0f - r0;
+    if (ok) {
+        const int64_t rec = rows ? (int64_t)rows[k] : k;
+        uint32_t any = 0;
+        for (int t = 0; t < nt128; ++t) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p32 + ((int64_t)t * m_total + rec) * 32);
+            const uint4 a = q[0], c = q[1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            const int valid = n_sel - t * 128;   // real samples in this tile (pads are code 01)
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                uint32_t miss = w[d] & ~(w[d] >> 1) & 0x55555555u;
+                const int left = valid - d * 16;
+                if (left <= 0) miss = 0;
+                else if (left < 16) miss &= (1u << (2 * left)) - 1u;
+                any |= miss;
+            }
+        }
+        ok = (any == 0);
+    }
+    flag[k] = ok ? 1 : 0;
+    beta[k] = ok ? ((double)(v0 - r0) + (double)(v2 - 1.0f) + (double)(v3 - r3)) / 3.0 : 0.0;
+    ilut[k * 4 + 0] = r0;
+    ilut[k * 4 + 1] = 0.0f;
+    ilut[k * 4 + 2] = 1.0f;
+    ilut[k * 4 + 3] = r3;
+}
+
+// stable partition positions: qualifying SNPs first.  One workgroup; info[0] = number qualifying.
+__global__ __launch_bounds__(1024) void grm_partition_kernel(const int32_t *__restrict__ flag, int64_t mk,
+                                                             int32_t *__restrict__ pos, int32_t *__restrict__ info) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (mk + 1023) / 1024;
+    const int64_t b = tid * per, e = (b + per < mk) ? b + per : mk;
+    int64_t cnt = 0;
+    for (int64_t k = b; k < e; ++k) cnt += flag[k];
+    part[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+        const int64_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int64_t total = part[1023];
+    int64_t ones = part[tid] - cnt;   // qualifying SNPs before b
+    for (int64_t k = b; k < e; ++k) {
+        if (flag[k]) pos[k] = (int32_t)ones++;
+        else pos[k] = (int32_t)(total + (k - ones));
+    }
+    if (tid == 0) info[0] = (int32_t)total;
+}
+
+// reordered SNP list: rows2, split LUT (integer LUT below the 32-aligned exact prefix), f32 integer LUT and beta for
+// the affine terms (zero beyond the prefix); info[1] |= 1 if a general value leaves the safe fp16 range.
+__global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restrict__ rows, const float *__restrict__ lut,
+                                                         const float *__restrict__ ilut, const double *__restrict__ beta,
+                                                         const int32_t *__restrict__ pos, int64_t mk,
+                                                         int32_t *__restrict__ info, int32_t *__restrict__ rows2,
+                                                         uint4 *__restrict__ lut16, float *__restrict__ ilut2,
+                                                         double *__restrict__ beta2) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= mk) return;
+    const int32_t nex = info[0] & ~63;
+    const int32_t dst = pos[k];
+    const bool exact = dst < nex;
+    rows2[dst] = rows ? rows[k] : (int32_t)k;
+    uint16_t hi[4], lo[4];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float v = exact ? ilut[k * 4 + c] : lut[k * 4 + c];
+        if (!(fabsf(v) <= 30000.0f)) bad = true;
+        const __half h = __float2half_rn(v);
+        const __half l = __float2half_rn(v - __half2float(h));
+        hi[c] = __half_as_ushort(h);
+        lo[c] = __half_as_ushort(l);
+        ilut2[(int64_t)dst * 4 + c] = ilut[k * 4 + c];
+    }
+    uint4 o;
+    o.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    o.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    o.z = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    o.w = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    lut16[dst] = o;
+    beta2[dst] = exact ? beta[k] : 0.0;
+    if (bad) atomicOr(&info[1], 1);
+}
+
+// corr[ld] = sum_k beta2[k]^2, k < info[0] & ~31 (one workgroup)
+__global__ __launch_bounds__(1024) void grm_sumsq_kernel(const double *__restrict__ beta2, const int32_t *__restrict__ info,
+                                                         double *__restrict__ out) {
+    __shared__ double sh[1024];
+    const int nex = info[0] & ~63;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nex; k += 1024) a += beta2[k] * beta2[k];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // K = acc * inv_scale mirrored to both triangles, cast to the output type (n x n, row-major).
@@ -379,6 +544,9 @@ extern "C" int jxg_debug_occupancy(int *out) {
     return 0;
 }
 
+extern "C" int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                              const float *d_lut, const double *d_beta, double *d_out, void *stream);
+
 extern "C" float jxg_last_kernel_ms(int which) {
     if (which < 0 || which >= 4) return 0.f;
     if (which == 1 && g_timer_pending[1] && g_rot_b) {
@@ -397,19 +565,43 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
     const int nt = num_tiles(n_sel);
     const int64_t ld = (int64_t)nt * JXG_TILE;
     if (kchunk <= 0) kchunk = 8192;
-    kchunk = ((kchunk + G_BK - 1) / G_BK) * G_BK;
+    kchunk = ((kchunk + 63) / 64) * 64;
 
-    DevBuf lut16, flags;
-    if (lut16.alloc(sizeof(uint4) * (size_t)mk)) return 1;
-    if (flags.alloc(sizeof(int))) return 1;
-    JX_HIP(hipMemsetAsync(flags.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(lut_split_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_lut, mk,
-                       lut16.as<uint4>(), 1.0f, flags.as<int>());
+    // classify / reorder: SNPs that factor as beta + {0,1,2} without missing calls first (exact single-product path)
+    static const int exact_env = getenv("JXGPU_GRM_EXACT") ? atoi(getenv("JXGPU_GRM_EXACT")) : 1;
+    static const int exact_bk = getenv("JXGPU_GRM_EXACT_BK") ? atoi(getenv("JXGPU_GRM_EXACT_BK")) : 64;
+    if (mk > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many SNPs in one call");
+    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb;
+    if (lut16.alloc(sizeof(uint4) * (size_t)mk) || flagb.alloc(sizeof(int32_t) * (size_t)mk) ||
+        betab.alloc(sizeof(double) * (size_t)mk) || ilutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
+        posb.alloc(sizeof(int32_t) * (size_t)mk) || infob.alloc(2 * sizeof(int32_t)) ||
+        rows2b.alloc(sizeof(int32_t) * (size_t)mk) || ilut2b.alloc(sizeof(float) * 4 * (size_t)mk) ||
+        beta2b.alloc(sizeof(double) * (size_t)mk) || corrb.alloc(sizeof(double) * (size_t)(ld + 1)))
+        return 1;
+    JX_HIP(hipMemsetAsync(infob.p, 0, 2 * sizeof(int32_t), st));
+    const unsigned gk = (unsigned)((mk + 255) / 256);
+    if (exact_env) {
+        hipLaunchKernelGGL(grm_classify_kernel, dim3(gk), dim3(256), 0, st, d_p32, m_total, d_rows, d_lut, mk, n_sel, nt,
+                           flagb.as<int32_t>(), betab.as<double>(), ilutb.as<float>());
+        JX_LAUNCH_CHECK();
+    } else {
+        JX_HIP(hipMemsetAsync(flagb.p, 0, sizeof(int32_t) * (size_t)mk, st));
+        JX_HIP(hipMemsetAsync(ilutb.p, 0, sizeof(float) * 4 * (size_t)mk, st));
+        JX_HIP(hipMemsetAsync(betab.p, 0, sizeof(double) * (size_t)mk, st));
+    }
+    hipLaunchKernelGGL(grm_partition_kernel, dim3(1), dim3(1024), 0, st, flagb.as<int32_t>(), mk, posb.as<int32_t>(),
+                       infob.as<int32_t>());
     JX_LAUNCH_CHECK();
-    int hflag = 0;
-    JX_HIP(hipMemcpyAsync(&hflag, flags.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(grm_gather_kernel, dim3(gk), dim3(256), 0, st, d_rows, d_lut, ilutb.as<float>(),
+                       betab.as<double>(), posb.as<int32_t>(), mk, infob.as<int32_t>(), rows2b.as<int32_t>(),
+                       lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>());
+    JX_LAUNCH_CHECK();
+    int32_t hinfo[2] = {0, 0};
+    JX_HIP(hipMemcpyAsync(hinfo, infob.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
-    if (hflag) return fail("jxg_grm_accumulate: design values exceed the fp16 split range (|z| > 3e4)");
+    if (hinfo[1]) return fail("jxg_grm_accumulate: design values exceed the fp16 split range (|z| > 3e4)");
+    const int64_t n_exact = (int64_t)(hinfo[0] & ~63);
+    const int32_t *rows2 = rows2b.as<int32_t>();
 
     // tile shape: 256x128 (4 waves of 128x64) once there are enough tiles, else 128x128 (4 waves of 64x64)
     static const int tile_env = getenv("JXGPU_GRM_TILE") ? atoi(getenv("JXGPU_GRM_TILE")) : 0;
@@ -417,42 +609,73 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
     const int tdim = big ? (nt + 1) / 2 : nt;  // row blocks
     const int64_t ntiles = big ? (int64_t)tdim * (tdim + 1) : (int64_t)tdim * (tdim + 1) / 2;
     if (ntiles > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
-    const int64_t nchunks = (mk + kchunk - 1) / kchunk;
     const int64_t slots = big ? 512 : 768;  // resident workgroups on 256 CUs
-    // Few tiles: spread SNP chunks over blockIdx.y with f64 atomics so the chip is filled.
-    // Many tiles: one launch per chunk, the owning workgroup does a plain f64 read-modify-write.
-    const bool atomic_mode = ntiles < 2 * slots && mk > 2048;
     if (g_grm_ev.init()) return 1;
     JX_HIP(hipEventRecord(g_grm_ev.a, st));
-    auto launch = [&](dim3 grid, int64_t kb, int64_t ke, int kc, int atomic) {
-        if (big)
+    if (n_exact > 0) {   // affine terms of the exact prefix: r = C beta (f64), B = sum beta^2
+        JX_HIP(hipMemsetAsync(corrb.p, 0, sizeof(double) * (size_t)(ld + 1), st));
+        if (jxg_packed_dot(d_p32, m_total, n_sel, rows2, (int)n_exact, ilut2b.as<float>(), beta2b.as<double>(),
+                           corrb.as<double>(), st))
+            return 1;
+        hipLaunchKernelGGL(grm_sumsq_kernel, dim3(1), dim3(1024), 0, st, beta2b.as<double>(), infob.as<int32_t>(),
+                           corrb.as<double>() + ld);
+        JX_LAUNCH_CHECK();
+    }
+    auto launch = [&](bool exact, dim3 grid, int64_t kb, int64_t ke, int kc, int atomic, const double *corr) {
+        if (exact && big)
+            hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false, true>), grid, dim3(256), 0, st, d_p32, m_total,
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+        else if (exact)
+            if (exact_bk == 33)
+                hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, true, true>), grid, dim3(256), 0, st, d_p32,
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+            else if (exact_bk == 64)
+                hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false, true, 64>), grid, dim3(256), 0, st, d_p32,
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+            else
+                hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false, true>), grid, dim3(256), 0, st, d_p32,
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+        else if (big)
             hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
-                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
         else if (tile_env == 129)
             hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, true>), grid, dim3(256), 0, st, d_p32, m_total,
-                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
         else
             hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
-                               d_rows, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
     };
-    if (atomic_mode) {
-        // shrink chunks if that is what it takes to reach ~2 rounds of resident workgroups
-        int64_t want = (2 * slots + ntiles - 1) / ntiles;
-        int64_t kc = kchunk;
-        while ((mk + kc - 1) / kc < want && kc > 1024) kc /= 2;
-        kc = ((kc + G_BK - 1) / G_BK) * G_BK;
-        const int64_t ny = (mk + kc - 1) / kc;
-        if (ny > 65535) return fail("jxg_grm_accumulate: too many chunks");
-        launch(dim3((unsigned)ntiles, (unsigned)ny), 0, mk, (int)kc, 1);
-        JX_LAUNCH_CHECK();
-    } else {
-        for (int64_t cidx = 0; cidx < nchunks; ++cidx) {
-            const int64_t kb = cidx * kchunk;
-            const int64_t ke = (kb + kchunk < mk) ? kb + kchunk : mk;
-            launch(dim3((unsigned)ntiles, 1), kb, ke, kchunk, 0);
+    // SNP range [r0, r1) of the reordered list with one kernel variant
+    auto run_range = [&](bool exact, int64_t r0, int64_t r1) -> int {
+        const int64_t cnt = r1 - r0;
+        if (cnt <= 0) return 0;
+        const double *corr = exact ? corrb.as<double>() : nullptr;
+        // Few tiles: spread SNP chunks over blockIdx.y with f64 atomics so the chip is filled.
+        // Many tiles: one launch per chunk, the owning workgroup does a plain f64 read-modify-write.
+        const bool atomic_mode = ntiles < 2 * slots && cnt > 2048;
+        if (atomic_mode) {
+            // shrink chunks if that is what it takes to reach ~2 rounds of resident workgroups
+            int64_t want = (2 * slots + ntiles - 1) / ntiles;
+            int64_t kc = kchunk;
+            while ((cnt + kc - 1) / kc < want && kc > 1024) kc /= 2;
+            kc = ((kc + 63) / 64) * 64;
+            const int64_t ny = (cnt + kc - 1) / kc;
+            if (ny > 65535) return fail("jxg_grm_accumulate: too many chunks");
+            launch(exact, dim3((unsigned)ntiles, (unsigned)ny), r0, r1, (int)kc, 1, corr);
             JX_LAUNCH_CHECK();
+        } else {
+            // exact sums stay below 2^24 for 4 M SNPs: one launch per 2^20 SNPs instead of one per kchunk
+            const int64_t kcl = exact ? (int64_t)(1 << 20) : (int64_t)kchunk;
+            for (int64_t kb = r0; kb < r1; kb += kcl) {
+                const int64_t ke = (kb + kcl < r1) ? kb + kcl : r1;
+                launch(exact, dim3((unsigned)ntiles, 1), kb, ke, (int)kcl, 0, kb == r0 ? corr : nullptr);
+                JX_LAUNCH_CHECK();
+            }
         }
-    }
+        return 0;
+    };
+    if (run_range(true, 0, n_exact)) return 1;
+    if (run_range(false, n_exact, mk)) return 1;
     JX_HIP(hipEventRecord(g_grm_ev.b, st));
     JX_HIP(hipStreamSynchronize(st));  // lut16 is freed on return
     JX_HIP(hipEventElapsedTime(&g_last_ms[0], g_grm_ev.a, g_grm_ev.b));

@@ -138,6 +138,54 @@ def test_grm_multichunk(oracle):
         k = pipeline.grm_finalize(acc, n, float(np.sum(var[rows]))).cpu().numpy()
         assert _grm_err(k, ref) < TOL
 
+@pytest.mark.parametrize("miss_frac", [0.0, 0.5, 1.0])
+def test_grm_exact_integer_path(oracle, miss_frac, monkeypatch):
+    """SNPs without missing calls take the single-product integer path (z = beta + c): all / half / none of the
+    SNPs qualify; atomic split, multi-launch chunks (corr added once) and the switch-off must all agree."""
+    import torch
+    from janusx_amd import pipeline, stats
+    n, m = 300, 6000
+    packed, g = bed.synth_panel_numpy(n, m, seed=8, missing_rate=0.0)
+    rng = np.random.default_rng(3)
+    sw = rng.random(m) < 0.3              # swap the alleles of 30 % of the SNPs (00 <-> 11): flipped design rows
+    x = packed[sw]
+    same = ~((x & 0x55) ^ ((x >> 1) & 0x55)) & 0x55
+    packed[sw] = x ^ (same | (same << 1))
+    hit = rng.random(m) < miss_frac
+    for r in np.nonzero(hit)[0]:          # one or two missing calls (code 01) in the chosen SNPs
+        for j in rng.integers(0, n, size=rng.integers(1, 3)):
+            b, sh = j >> 2, 2 * (j & 3)
+            packed[r, b] = (packed[r, b] & ~(3 << sh)) | (1 << sh)
+    ref, eff_ref, keep_ref = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0, block_rows=4096)
+    p = pipeline.Panel(torch.from_numpy(packed).cuda(), n)
+    keep, mean_g, scale, flip, var = stats.stream_grm_row_prepare(p.counts(), n, 1, 0.02, 0.05, 0.0)
+    assert np.array_equal(keep, keep_ref)
+    rows = np.nonzero(keep)[0]
+    lut = stats.grm_lut_from_mean_scale(mean_g[rows], scale[rows], flip[rows])
+    assert flip[rows].any() and (~flip[rows]).any()
+    ks = []
+    for kchunk in (0, 1024):
+        acc = pipeline.grm_accumulate(p, rows, lut, kchunk=kchunk)
+        k = pipeline.grm_finalize(acc, n, float(np.sum(var[rows])), dtype=torch.float64).cpu().numpy()
+        assert _grm_err(k, ref) < TOL
+        ks.append(k)
+    # <= 2048 SNPs per call: plain read-modify-write launches, one per 512-SNP chunk
+    acc = None
+    for a in range(0, len(rows), 2048):
+        acc = pipeline.grm_accumulate(p, rows[a:a + 2048], lut[a:a + 2048], acc=acc, kchunk=512)
+    k = pipeline.grm_finalize(acc, n, float(np.sum(var[rows])), dtype=torch.float64).cpu().numpy()
+    assert _grm_err(k, ref) < TOL
+    # the integer path does not depend on the chunking (exact Gram sums, f64 affine terms); the split path does
+    assert np.max(np.abs(k - ks[0])) <= (1e-12 if miss_frac == 0.0 else 3e-6) * np.max(np.abs(k))
+    # method 2 rows never qualify (scaled values); the result must still match
+    ref2, _, keep2 = oracle.grm_stream_bed(packed, n, 2, 0.02, 0.05, 0.0, block_rows=4096)
+    keep_b, mean_b, scale_b, flip_b, var_b = stats.stream_grm_row_prepare(p.counts(), n, 2, 0.02, 0.05, 0.0)
+    rows_b = np.nonzero(keep_b)[0]
+    lut_b = stats.grm_lut_from_mean_scale(mean_b[rows_b], scale_b[rows_b], flip_b[rows_b])
+    acc = pipeline.grm_accumulate(p, rows_b, lut_b)
+    k2 = pipeline.grm_finalize(acc, n, float(len(rows_b)), dtype=torch.float64).cpu().numpy()
+    assert _grm_err(k2, ref2) < TOL
+
 
 def test_eigh_invariants(oracle):
     from janusx_amd import janusx as jxrs

@@ -293,6 +293,19 @@ int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const in
                       double high, int max_iter, double tol, int estimate_only, double *out_pred_train,
                       double *out_pred_test, double *out_scalars);
 
+/* `rrblup_pcg_bed` on a resident packed payload (src/stats/rrblup.rs:3494-4307): marker effects by
+ * Jacobi-preconditioned conjugate gradients, (Z_c Z_c' + lambda I) beta = Z y_c, Z the standardised genotypes of the
+ * training samples streamed from the 2-bit payload (never materialised).  value_lut (eff_m,4) f32 = design values by
+ * 2-bit code [00, 01 (missing, must be 0), 10, 11] (src/math/bedmath.rs:1199-1214); row_indices (eff_m) selects the
+ * kept SNP rows (NULL = all m_total).  out_beta (eff_m) f32; out_pred_train (n_train) and out_pred_test (n_test) f64
+ * (either may be NULL); out_scalars = (converged, iterations, relative residual, sum of centred row sums of squares,
+ * intercept).  The iteration follows `pcg_solve_into` for f32 (src/math/pcg.rs:870-949). */
+int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
+                         int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
+                         const double *y_train, const int64_t *test_idx, int n_test, double lambda_value, double tol,
+                         int max_iter, float *out_beta, double *out_pred_train, double *out_pred_test,
+                         double *out_scalars);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
                             [-maf 0.02] [-geno 0.05] [-het 1.0] [-o OUT] [-force-model]
   python -m janusx_amd grm  -bfile PREFIX [-m 1|2] [-maf 0.02] [-geno 0.05] [-o OUT]
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -BLUP [-cv K] [-seed 42] [-k GRM.npy]
+  python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -rrBLUP [-lambda L] [-tol 1e-4] [-max-iter 100] [-cv K]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
 Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`;
@@ -14,7 +15,8 @@ Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` 
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
 python/janusx/gs/workflow.py:9122) are built; VCF/HMP readers, PCs (-q), plots, the history DB, the
-other GS model families and the rrBLUP/PCG routes are out of scope.
+other GS model families and the exact (SNP-spectral) rrBLUP route are out of scope; `-rrBLUP` runs the PCG route
+(`rrblup_pcg_bed`) with a manual or subsample-REML lambda.
 """
 from __future__ import annotations
 
@@ -177,8 +179,10 @@ def cmd_gs(args):
     seeded by `-seed`, python/janusx/gs/workflow.py:18744-18760) -- and predictions for every genotyped sample."""
     from . import janusx as jxrs
     from .bed import read_fam_ids
+    if args.rrblup:
+        return cmd_gs_rrblup(args)
     if not (args.blup or args.gblup):
-        raise SystemExit("select a model: -BLUP (or -GBLUP)")
+        raise SystemExit("select a model: -BLUP (or -GBLUP, -rrBLUP)")
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
     pos = {s: i for i, s in enumerate(ids)}
@@ -234,6 +238,84 @@ def cmd_gs(args):
     return 0
 
 
+def cmd_gs_rrblup(args):
+    """`jx gs -rrBLUP`: marker effects of the standardised genotypes by PCG over the packed payload
+    (`rrblup_pcg_bed`, src/stats/rrblup.rs:3494-4307; the route python/janusx/gs/blup.py:146-163 takes for large n
+    and m).  lambda (equation scale, sigma_e^2 / sigma_beta^2) is `-lambda` when given; otherwise
+    m_effective * sigma_e^2 / sigma_g^2 from the spectral GBLUP REML of a random subsample of at most 2000 training
+    samples (seed `-seed`) on the standardised GRM -- the GRM-REML branch of the reference's
+    `_estimate_rrblup_lambda_subsample_reml` (python/janusx/gs/workflow.py:5481) without its HE variants."""
+    from . import janusx as jxrs
+    from .bed import read_fam_ids
+    fam = read_fam_ids(args.bfile)
+    ids, names, ph = _read_table(args.pheno)
+    pos = {s: i for i, s in enumerate(ids)}
+    traits = _select_traits(names, args.ncol)
+    out = args.out or args.bfile
+    packed, miss, maf, _std, n_all = jxrs.load_bed_2bit_packed(args.bfile)
+    flip = jxrs.bed_packed_row_flip_mask(packed, n_all)
+    keep = (maf >= np.float32(args.maf)) & (miss <= np.float32(args.geno))
+    print(f"rrBLUP-PCG: n={n_all} m={packed.shape[0]} kept={int(keep.sum())} (maf {args.maf}, geno {args.geno})")
+    for ti in traits:
+        name = names[ti]
+        yv = np.array([ph[pos[s], ti] if s in pos else np.nan for s in fam])
+        train = np.nonzero(np.isfinite(yv))[0].astype(np.int64)
+        test = np.nonzero(~np.isfinite(yv))[0].astype(np.int64)
+        if len(train) < 10:
+            print(f"[{name}] only {len(train)} phenotyped samples, skipped")
+            continue
+        t1 = time.perf_counter()
+        if args.lam is not None:
+            lam, src = float(args.lam), "manual"
+        else:
+            rng = np.random.default_rng(args.seed)
+            sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
+            ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
+            fit = jxrs.gblup_reml_grm(ks, np.arange(len(sub), dtype=np.int64), yv[train[sub]], None,
+                                      return_variance_components=True)
+            lam_k = float(fit[3])
+            p = np.clip(maf[keep], 0.0, 0.5)
+            m_eff = int(np.count_nonzero(2.0 * p * (1.0 - p) > 1e-12))
+            lam, src = lam_k * m_eff, f"subsample REML (n_sub={len(sub)}, lambda_k={lam_k:.5g})"
+        fold = np.full(n_all, -1, dtype=np.int64)
+        pred = np.full(n_all, np.nan)
+
+        def fit_predict(tr, te):
+            return jxrs.rrblup_pcg_bed("", tr, yv[tr], te if len(te) else None, site_keep=keep, lambda_value=lam,
+                                       tol=args.tol, max_iter=args.max_iter, packed=packed, packed_n_samples=n_all,
+                                       maf=maf, row_flip=flip)
+
+        if args.cv and args.cv > 1:
+            perm = np.random.default_rng(args.seed).permutation(len(train))
+            for f in range(args.cv):
+                te_loc = np.sort(perm[f::args.cv])
+                tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+                r = fit_predict(train[tr_loc], train[te_loc])
+                pred[train[te_loc]] = r[1].ravel()
+                fold[train[te_loc]] = f
+            yo, po = yv[train], pred[train]
+            rr = float(np.corrcoef(yo, po)[0, 1])
+            r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
+            print(f"[{name}] rrBLUP {args.cv}-fold CV: pearson={rr:.4f} R2={r2:.4f}")
+        full = fit_predict(train, test)
+        if not (args.cv and args.cv > 1):
+            pred[train] = full[0].ravel()
+        if len(test):
+            pred[test] = full[1].ravel()
+        path = f"{out}.{name}.gs.rrBLUP.tsv"
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "w") as fh:
+            fh.write("sample\tobserved\tpredicted\tfold\n")
+            for j, sid in enumerate(fam):
+                obs = "NA" if not math.isfinite(yv[j]) else f"{yv[j]:.6g}"
+                fh.write(f"{sid}\t{obs}\t{pred[j]:.6g}\t{'NA' if fold[j] < 0 else fold[j]}\n")
+        os.replace(tmp, path)
+        print(f"[{name}] rrBLUP-PCG: n_train={len(train)} n_pred={len(test)} lambda={lam:.5g} [{src}] "
+              f"converged={full[3]} iters={full[4]} rel_res={full[5]:.3g} m_effective={full[6]} "
+              f"pve={full[7]:.4f} -> {path} ({time.perf_counter() - t1:.2f}s)")
+    return 0
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="jx", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -267,6 +349,10 @@ def main(argv=None):
     q.add_argument("-n", "--n", dest="ncol", action="append", default=None)
     q.add_argument("-BLUP", "--BLUP", dest="blup", action="store_true", default=False)
     q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
+    q.add_argument("-rrBLUP", "--rrBLUP", dest="rrblup", action="store_true", default=False)
+    q.add_argument("-lambda", "--lambda", dest="lam", type=float, default=None)
+    q.add_argument("-tol", "--tol", type=float, default=1e-4)
+    q.add_argument("-max-iter", "--max-iter", dest="max_iter", type=int, default=100)
     q.add_argument("-cv", "--cv", type=int, default=None)
     q.add_argument("-seed", "--seed", type=int, default=42)
     q.add_argument("-k", "--grm", dest="grm", type=str, default=None)

@@ -1,0 +1,340 @@
+// rrBLUP marker effects by preconditioned conjugate gradients over the 2-bit payload.
+//
+// Reference: `rrblup_pcg_bed` (src/stats/rrblup.rs:3494-4307): solve (Z_c Z_c' + lambda I) beta = Z y_c over the m
+// markers, Z (m, n_train) = standardised genotypes of the training samples ((g - 2p) / sqrt(2p(1-p)), missing -> 0,
+// `decode_standardized_packed_block_rows_f32_with_plan`, src/math/bedmath.rs:1161-1249), Z_c its row-centred form
+// applied implicitly (`RrblupPcgOperator::apply`, rrblup.rs:865-929); Jacobi preconditioner 1 / (ss_j + lambda) and
+// right-hand side from one pre-pass (`rrblup_prepare_rhs_diag` :650-845); the iteration is `pcg_solve_into` for
+// T = f32 (src/math/pcg.rs:870-949: f32 vectors, f64 dot products).
+//
+// Here Z is never materialised: both halves of the operator stream the P32 payload (`packed_dot_kernel`,
+// `packed_tdot_kernel`, k_gblup.hip: 2 bits per genotype, f64 accumulation), the row sums / sums of squares of the
+// pre-pass come from the per-SNP genotype counts, and the m-vectors of the iteration live in HBM as f32 like the
+// reference's; only three scalars per iteration cross to the host (the convergence test is the reference's).
+#include <math.h>
+
+#include <vector>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int PCG_T = 256;
+
+__device__ __forceinline__ void pcg_block_add(double v, double *out) {
+    __shared__ double sh[PCG_T / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < PCG_T / 64; ++w) t += sh[w];
+        if (t != 0.0) unsafeAtomicAdd(out, t);
+    }
+}
+
+// out += sum a_j b_j (f64 products of f32 values, `PcgScalar::dot_to_f64`)
+__global__ __launch_bounds__(PCG_T) void pcg_dot_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                        int64_t n, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x; j < n; j += (int64_t)gridDim.x * PCG_T)
+        acc += (double)a[j] * (double)b[j];
+    pcg_block_add(acc, out);
+}
+
+__global__ __launch_bounds__(PCG_T) void pcg_widen_kernel(const float *__restrict__ a, double *__restrict__ o, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x;
+    if (j < n) o[j] = (double)a[j];
+}
+
+// the reference's GEMV output is f32: round the f64 accumulations once
+__global__ __launch_bounds__(PCG_T) void pcg_round_kernel(double *__restrict__ a, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x;
+    if (j < n) a[j] = (double)(float)a[j];
+}
+
+// ap = f32(Z Z'p) - n_train * mu * mean_dot + lambda * p  (rrblup.rs:902-916);  denom += p . ap
+__global__ __launch_bounds__(PCG_T) void pcg_finish_ap_kernel(const double *__restrict__ ap64, const float *__restrict__ p,
+                                                              const float *__restrict__ mu, float n_train_f,
+                                                              const double *__restrict__ mean_dot, float lambda,
+                                                              int64_t n, float *__restrict__ ap,
+                                                              double *__restrict__ denom) {
+    const float md = (float)mean_dot[0];
+    double acc = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x; j < n; j += (int64_t)gridDim.x * PCG_T) {
+        float v = (float)ap64[j];
+        v = __fsub_rn(v, __fmul_rn(__fmul_rn(n_train_f, mu[j]), md));
+        v = __fadd_rn(v, __fmul_rn(lambda, p[j]));
+        ap[j] = v;
+        acc += (double)p[j] * (double)v;
+    }
+    pcg_block_add(acc, denom);
+}
+
+// x += alpha p; r -= alpha ap; rr += r . r   (pcg.rs:672-694)
+__global__ __launch_bounds__(PCG_T) void pcg_update_xr_kernel(float *__restrict__ x, float *__restrict__ r,
+                                                              const float *__restrict__ p, const float *__restrict__ ap,
+                                                              float alpha, int64_t n, double *__restrict__ rr) {
+    double acc = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x; j < n; j += (int64_t)gridDim.x * PCG_T) {
+        x[j] = __fadd_rn(x[j], __fmul_rn(alpha, p[j]));
+        const float rv = __fsub_rn(r[j], __fmul_rn(alpha, ap[j]));
+        r[j] = rv;
+        acc += (double)rv * (double)rv;
+    }
+    pcg_block_add(acc, rr);
+}
+
+// z = r * inv_diag; rz += r . z   (Jacobi, pcg.rs:223-245)
+__global__ __launch_bounds__(PCG_T) void pcg_precond_kernel(const float *__restrict__ r, const float *__restrict__ dinv,
+                                                            float *__restrict__ z, int64_t n, double *__restrict__ rz) {
+    double acc = 0.0;
+    for (int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x; j < n; j += (int64_t)gridDim.x * PCG_T) {
+        const float zv = __fmul_rn(r[j], dinv[j]);
+        z[j] = zv;
+        acc += (double)r[j] * (double)zv;
+    }
+    pcg_block_add(acc, rz);
+}
+
+// p = z + beta p   (pcg.rs:696-707)
+__global__ __launch_bounds__(PCG_T) void pcg_update_p_kernel(float *__restrict__ p, const float *__restrict__ z, float beta,
+                                                             int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * PCG_T + threadIdx.x;
+    if (j < n) p[j] = __fadd_rn(z[j], __fmul_rn(beta, p[j]));
+}
+
+static inline unsigned pcg_grid(int64_t n) {
+    int64_t g = (n + PCG_T - 1) / PCG_T;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+static inline unsigned pcg_grid_full(int64_t n) { return (unsigned)((n + PCG_T - 1) / PCG_T); }
+
+}  // namespace jx
+
+using namespace jx;
+
+// value_lut (eff_m, 4) f32: standardised design values by 2-bit code (entry 1, the missing code, must be 0).
+// row_indices (eff_m) int64 or NULL (all m_total rows).  out_scalars: [0] converged, [1] iterations, [2] relative
+// residual, [3] sum of the centred row sums of squares (k_trace numerator), [4] intercept alpha.
+extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
+                                    int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
+                                    const double *y_train, const int64_t *test_idx, int n_test, double lambda_value,
+                                    double tol, int max_iter, float *out_beta, double *out_pred_train,
+                                    double *out_pred_test, double *out_scalars) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (m_total <= 0 || eff_m <= 0) return fail("No SNP rows found in BED input.");
+    if (n_train <= 0) return fail("train_sample_indices must not be empty.");
+    if (max_iter <= 0) return fail("max_iter must be > 0");
+    if (!(isfinite(tol) && tol > 0.0)) return fail("tol must be finite and > 0");
+    if (!isfinite(lambda_value) || lambda_value < 0.0) return fail("lambda_value must be finite and >= 0");
+    if (eff_m > 0x7fffffffLL) return fail("too many markers for one call");
+    const int64_t bps = ((int64_t)n_samples + 3) / 4;
+    std::vector<int32_t> tr32(n_train), te32(n_test > 0 ? n_test : 0);
+    for (int i = 0; i < n_train; ++i) {
+        if (train_idx[i] < 0 || train_idx[i] >= n_samples) return fail("train_sample_indices out of range");
+        tr32[i] = (int32_t)train_idx[i];
+    }
+    for (int i = 0; i < n_test; ++i) {
+        if (test_idx[i] < 0 || test_idx[i] >= n_samples) return fail("test_sample_indices out of range");
+        te32[i] = (int32_t)test_idx[i];
+    }
+    if (row_indices)
+        for (int64_t j = 0; j < eff_m; ++j)
+            if (row_indices[j] < 0 || row_indices[j] >= m_total) return fail("site_keep row index out of range");
+    double y_mean = 0.0;
+    for (int i = 0; i < n_train; ++i) {
+        if (!isfinite(y_train[i])) return fail("y_train contains non-finite values.");
+        y_mean += y_train[i];
+    }
+    y_mean /= (double)n_train;
+    const float lambda_use = (float)(lambda_value > 1e-8 ? lambda_value : 1e-8);
+    const double tol_use = tol > 1e-12 ? tol : 1e-12;
+
+    hipStream_t st = nullptr;
+    DevBuf raw, didx, drow, p32, dlut, dcnt;
+    if (raw.alloc((size_t)(m_total * bps))) return 1;
+    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
+    if (didx.alloc(sizeof(int32_t) * (size_t)n_train)) return 1;
+    JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n_train, hipMemcpyHostToDevice));
+    const int64_t *d_rowidx = nullptr;
+    if (row_indices) {
+        if (drow.alloc(sizeof(int64_t) * (size_t)eff_m)) return 1;
+        JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
+        d_rowidx = drow.as<int64_t>();
+    }
+    const int nt = num_tiles(n_train);
+    if (p32.alloc((size_t)nt * (size_t)eff_m * 32)) return 1;
+    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m,
+                       p32.as<uint8_t>(), st))
+        return 1;
+    if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m)) return 1;
+    JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
+    if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
+    if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
+    std::vector<int32_t> cnt(3 * (size_t)eff_m);
+    JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
+
+    // pre-pass (row_major_block_prepare_rhs_diag_f32, rrblup.rs:396-466): the f64 sums over the f32 row values are
+    // count-weighted sums of the three genotype values
+    std::vector<float> mu(eff_m), dinv(eff_m);
+    double sum_ss = 0.0;
+    for (int64_t j = 0; j < eff_m; ++j) {
+        const double c1 = cnt[3 * j + 1], c2 = cnt[3 * j + 2];
+        const double c0 = (double)n_train - (double)cnt[3 * j] - c1 - c2;
+        const double v0 = value_lut[4 * j], v2 = value_lut[4 * j + 2], v3 = value_lut[4 * j + 3];
+        const double sum = c0 * v0 + c1 * v2 + c2 * v3;
+        const double mean = sum / (double)n_train;
+        const double ss_raw = c0 * v0 * v0 + c1 * v2 * v2 + c2 * v3 * v3;
+        double ss = ss_raw - (double)n_train * mean * mean;
+        if (!(ss > 0.0)) ss = 0.0;
+        sum_ss += ss;
+        mu[j] = (float)mean;
+        float d = (float)ss + lambda_use;
+        if (!(d > 1e-12f)) d = 1e-12f;
+        dinv[j] = 1.0f / d;
+    }
+
+    DevBuf dmu, ddinv, dx, dr, dz, dp, dap, dv64m, dv64n, dsc;
+    const size_t mb = sizeof(float) * (size_t)eff_m;
+    if (dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) || dz.alloc(mb) || dp.alloc(mb) ||
+        dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
+        dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
+        return 1;
+    JX_HIP(hipMemcpy(dmu.p, mu.data(), mb, hipMemcpyHostToDevice));
+    JX_HIP(hipMemcpy(ddinv.p, dinv.data(), mb, hipMemcpyHostToDevice));
+    float *x = dx.as<float>(), *r = dr.as<float>(), *z = dz.as<float>(), *p = dp.as<float>(), *ap = dap.as<float>();
+    double *v64m = dv64m.as<double>(), *v64n = dv64n.as<double>(), *sc = dsc.as<double>();
+    const uint8_t *P = p32.as<uint8_t>();
+    const float *L = dlut.as<float>();
+    const unsigned gm = pcg_grid(eff_m), gmf = pcg_grid_full(eff_m), gnf = pcg_grid_full(n_train);
+
+    auto scalar = [&](int k, double &out) -> int {
+        JX_HIP(hipMemcpyAsync(&out, sc + k, sizeof(double), hipMemcpyDeviceToHost, st));
+        JX_HIP(hipStreamSynchronize(st));
+        return 0;
+    };
+    auto zero_scalar = [&](int k) -> int {
+        JX_HIP(hipMemsetAsync(sc + k, 0, sizeof(double), st));
+        return 0;
+    };
+
+    // b = Z y_c (f32 GEMV in the reference; f64 accumulation rounded once here)
+    {
+        std::vector<double> yc(n_train);
+        for (int i = 0; i < n_train; ++i) yc[i] = (double)(float)(y_train[i] - y_mean);
+        JX_HIP(hipMemcpy(v64n, yc.data(), sizeof(double) * (size_t)n_train, hipMemcpyHostToDevice));
+        if (jxg_packed_tdot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;
+    }
+    // r = b (f32), x = 0, z = M^-1 r, p = z
+    std::vector<double> b64(eff_m);
+    JX_HIP(hipMemcpy(b64.data(), v64m, sizeof(double) * (size_t)eff_m, hipMemcpyDeviceToHost));
+    std::vector<float> b32(eff_m);
+    double bb = 0.0;
+    for (int64_t j = 0; j < eff_m; ++j) {
+        b32[j] = (float)b64[j];
+        bb += (double)b32[j] * (double)b32[j];
+    }
+    if (!isfinite(bb)) return fail("PCG invalid RHS norm.");
+    const double bnorm = sqrt(bb);
+    const double denom_b = bnorm > 1e-12 ? bnorm : 1e-12;
+    JX_HIP(hipMemcpy(r, b32.data(), mb, hipMemcpyHostToDevice));
+    JX_HIP(hipMemsetAsync(x, 0, mb, st));
+    if (zero_scalar(0)) return 1;
+    hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
+    JX_LAUNCH_CHECK();
+    JX_HIP(hipMemcpyAsync(p, z, mb, hipMemcpyDeviceToDevice, st));
+    double rz_old = 0.0;
+    if (scalar(0, rz_old)) return 1;
+    double rel_res = bnorm / denom_b;   // r = b
+    if (rel_res < 0.0) rel_res = 0.0;
+    bool converged = false;
+    int iters = 0;
+    const double tiny_use = 1e-20;
+    if (isfinite(rel_res) && rel_res <= tol_use) {
+        converged = true;
+    } else {
+        for (int it = 0; it < max_iter; ++it) {
+            // ap = A p
+            hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
+            JX_LAUNCH_CHECK();
+            if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;   // Z'p
+            hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
+            JX_LAUNCH_CHECK();
+            if (jxg_packed_tdot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
+            JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
+            hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);
+            JX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(pcg_finish_ap_kernel, dim3(gm), dim3(PCG_T), 0, st, v64m, p, dmu.as<float>(),
+                               (float)n_train, sc + 1, lambda_use, eff_m, ap, sc + 2);
+            JX_LAUNCH_CHECK();
+            double denom = 0.0;
+            if (scalar(2, denom)) return 1;
+            if (!isfinite(denom) || denom <= tiny_use) break;
+            const double alpha = rz_old / denom;
+            if (zero_scalar(3)) return 1;
+            hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gm), dim3(PCG_T), 0, st, x, r, p, ap, (float)alpha, eff_m,
+                               sc + 3);
+            JX_LAUNCH_CHECK();
+            if (zero_scalar(0)) return 1;
+            hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
+            JX_LAUNCH_CHECK();
+            double rr = 0.0, rz_new = 0.0;
+            JX_HIP(hipMemcpyAsync(&rr, sc + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+            if (scalar(0, rz_new)) return 1;
+            rel_res = sqrt(rr) / denom_b;
+            if (rel_res < 0.0) rel_res = 0.0;
+            iters = it + 1;
+            if (isfinite(rel_res) && rel_res <= tol_use) {
+                converged = true;
+                break;
+            }
+            if (!isfinite(rz_new) || rz_new <= tiny_use) break;
+            const double beta = rz_new / (rz_old > tiny_use ? rz_old : tiny_use);
+            hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, z, (float)beta, eff_m);
+            JX_LAUNCH_CHECK();
+            rz_old = rz_new;
+        }
+    }
+    JX_HIP(hipMemcpy(out_beta, x, mb, hipMemcpyDeviceToHost));
+    float acc = 0.0f;   // `.map(mu * b).sum::<f32>()`, sequential (rrblup.rs:4057-4062)
+    for (int64_t j = 0; j < eff_m; ++j) {
+        volatile float t = mu[j] * out_beta[j];
+        acc = acc + t;
+    }
+    const float alpha_use = (float)y_mean - acc;
+
+    // predictions: alpha + Z_samples' beta (pcg_x_mul_samples, f32 output)
+    hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, x, v64m, eff_m);
+    JX_LAUNCH_CHECK();
+    if (out_pred_train) {
+        if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+        JX_HIP(hipStreamSynchronize(st));
+        JX_HIP(hipMemcpy(out_pred_train, v64n, sizeof(double) * (size_t)n_train, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_train; ++i) out_pred_train[i] = (double)((float)out_pred_train[i] + alpha_use);
+    }
+    if (n_test > 0 && out_pred_test) {
+        DevBuf dte, p32t;
+        if (dte.alloc(sizeof(int32_t) * (size_t)n_test)) return 1;
+        JX_HIP(hipMemcpy(dte.p, te32.data(), sizeof(int32_t) * (size_t)n_test, hipMemcpyHostToDevice));
+        const int ntt = num_tiles(n_test);
+        if (p32t.alloc((size_t)ntt * (size_t)eff_m * 32)) return 1;
+        if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, dte.as<int32_t>(), n_test, d_rowidx, eff_m,
+                           p32t.as<uint8_t>(), st))
+            return 1;
+        if (jxg_packed_dot(p32t.as<uint8_t>(), eff_m, n_test, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+        JX_HIP(hipStreamSynchronize(st));
+        JX_HIP(hipMemcpy(out_pred_test, v64n, sizeof(double) * (size_t)n_test, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_test; ++i) out_pred_test[i] = (double)(float)out_pred_test[i] + (double)alpha_use;
+    }
+    JX_HIP(hipStreamSynchronize(st));
+    out_scalars[0] = converged ? 1.0 : 0.0;
+    out_scalars[1] = (double)iters;
+    out_scalars[2] = rel_res;
+    out_scalars[3] = sum_ss;
+    out_scalars[4] = (double)alpha_use;
+    return 0;
+}

@@ -998,3 +998,212 @@ def gblup_reml_npy_grm(grm_path, train_sample_indices, y_train, test_sample_indi
     k = np.load(grm_path)
     return gblup_reml_grm(k, train_sample_indices, y_train, test_sample_indices, train_pred_local_indices, g_eps, low,
                           high, max_iter, tol, threads, return_variance_components, estimate_only)
+
+
+# ---- rrBLUP by PCG over the packed payload ---------------------------------------------------------
+
+def load_bed_2bit_packed(prefix):
+    """src/io/gfreader.rs:4401-4530: (packed (m, ceil(n/4)) u8, missing_rate f32, maf f32, std_denom f32, n_samples);
+    the per-SNP counts come from the device, the f32 expressions are the reference's."""
+    from .bed import read_bed_payload
+    p = str(prefix)
+    if p.lower().endswith((".bed", ".bim", ".fam")):
+        p = p[:-4]
+    packed, n_samples, _bim = read_bed_payload(p)
+    if n_samples == 0:
+        raise RuntimeError("no samples found in PLINK input")
+    cnt = bed_row_counts(packed, n_samples)
+    mi, he, ho = cnt[:, 0].astype(np.int64), cnt[:, 1].astype(np.int64), cnt[:, 2].astype(np.int64)
+    f32 = np.float32
+    miss = (mi.astype(f32) / f32(n_samples)).astype(f32)
+    nm = n_samples - mi
+    alt = he + 2 * ho
+    ok = nm > 0
+    pfreq = np.zeros(mi.shape[0], dtype=f32)
+    pfreq[ok] = alt[ok].astype(f32) / (f32(2.0) * nm[ok].astype(f32))
+    maf = np.where(ok, np.minimum(pfreq, f32(1.0) - pfreq), f32(0.0)).astype(f32)
+    d = np.sqrt((f32(2.0) * pfreq * (f32(1.0) - pfreq)).astype(f32)).astype(f32)
+    std = np.where(ok & np.isfinite(d), d, f32(0.0)).astype(f32)
+    return packed, miss, maf, std, int(n_samples)
+
+
+def bed_packed_row_flip_mask(packed, n_samples):
+    """src/stats/packed.rs:45-121: True where the ALT frequency among non-missing calls exceeds 0.5 (f64)."""
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if packed.shape[1] != (int(n_samples) + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {packed.shape[1]}, expected "
+                           f"{(int(n_samples) + 3) // 4} for n_samples={int(n_samples)}")
+    cnt = bed_row_counts(packed, n_samples).astype(np.int64)
+    nm = int(n_samples) - cnt[:, 0]
+    alt = cnt[:, 1] + 2 * cnt[:, 2]
+    out = np.zeros(cnt.shape[0], dtype=bool)
+    ok = nm > 0
+    out[ok] = (alt[ok].astype(np.float64) / (2.0 * nm[ok].astype(np.float64))) > 0.5
+    return out
+
+
+def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=None, train_pred_local_indices=None,
+                   site_keep=None, lambda_value=10000.0, tol=1e-4, max_iter=100, block_rows=4096, std_eps=1e-12,
+                   threads=0, progress_callback=None, progress_every=0, compute_trainvar=False, packed=None,
+                   packed_n_samples=0, maf=None, row_flip=None, row_mean=None, row_inv_sd=None, blas_threads=0):
+    """src/stats/rrblup.rs:3494-4307.  Marker effects of the standardised genotypes by Jacobi-preconditioned CG on the
+    device (`jx_rrblup_pcg_packed`), the payload resident in HBM for the whole solve.  Returns the reference's tuple
+    (pred_train (k,1), pred_test (t,1), pve_trainvar, converged, iters, rel_res, m_effective, pve_lambda_vc,
+    k_trace_mean, beta f32 (m)).  `block_rows`, `threads`, `blas_threads` are accepted and ignored; the streaming-stats
+    form (maf/row_flip with a prefix and no payload) loads the payload from the prefix."""
+    import math
+    if int(max_iter) == 0:
+        raise RuntimeError("max_iter must be > 0")
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError("tol must be finite and > 0")
+    if not (math.isfinite(std_eps) and std_eps > 0.0):
+        raise RuntimeError("std_eps must be finite and > 0")
+    if (not math.isfinite(lambda_value)) or lambda_value < 0.0:
+        raise RuntimeError("lambda_value must be finite and >= 0")
+    f32 = np.float32
+    if packed is not None:
+        if maf is None:
+            raise RuntimeError("rrblup_pcg_bed: packed payload path requires `maf` argument.")
+        if row_flip is None:
+            raise RuntimeError("rrblup_pcg_bed: packed payload path requires `row_flip` argument.")
+        if int(packed_n_samples) == 0:
+            raise RuntimeError("rrblup_pcg_bed: packed payload path requires packed_n_samples > 0.")
+        n_samples = int(packed_n_samples)
+        pk = _c(packed, np.uint8)
+        if pk.ndim != 2:
+            raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+    elif maf is not None or row_flip is not None or int(packed_n_samples) > 0:
+        if maf is None:
+            raise RuntimeError("rrblup_pcg_bed: streaming stats path requires `maf` argument.")
+        if row_flip is None:
+            raise RuntimeError("rrblup_pcg_bed: streaming stats path requires `row_flip` argument.")
+        if int(packed_n_samples) == 0:
+            raise RuntimeError("rrblup_pcg_bed: streaming stats path requires packed_n_samples > 0.")
+        if not str(prefix).strip():
+            raise RuntimeError("rrblup_pcg_bed: streaming stats path requires non-empty prefix.")
+        from .bed import read_bed_payload
+        pk, n_file, _bim = read_bed_payload(str(prefix))
+        n_samples = int(packed_n_samples)
+        if n_file != n_samples:
+            raise RuntimeError(f"packed_n_samples mismatch: got {n_samples}, BED has {n_file}")
+    else:
+        pk, _miss, maf, _std, n_samples = load_bed_2bit_packed(prefix)
+        row_flip = bed_packed_row_flip_mask(pk, n_samples)
+    m_total = int(pk.shape[0])
+    if m_total == 0:
+        raise RuntimeError("No SNP rows found in BED input.")
+    if pk.shape[1] != (n_samples + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1]}, expected {(n_samples + 3) // 4}")
+    maf_full = _c(maf, f32).ravel()
+    if maf_full.shape[0] != m_total:
+        raise RuntimeError(f"maf length mismatch: got {maf_full.shape[0]}, expected {m_total}")
+    flip_full = np.asarray(row_flip).astype(bool).ravel()
+    if flip_full.shape[0] != m_total:
+        raise RuntimeError(f"row_flip length mismatch: got {flip_full.shape[0]}, expected {m_total}")
+    rows = None
+    maf_keep, flip_keep = maf_full, flip_full
+    if site_keep is not None:
+        mask = np.asarray(site_keep).astype(bool).ravel()
+        if mask.shape[0] != m_total:
+            raise RuntimeError(f"site_keep length mismatch: got {mask.shape[0]}, expected {m_total}")
+        keep_idx = np.nonzero(mask)[0].astype(np.int64)
+        if keep_idx.shape[0] == 0:
+            raise RuntimeError("No SNPs remained after applying site_keep mask.")
+        if keep_idx.shape[0] != m_total:
+            rows = keep_idx
+            maf_keep = np.clip(maf_full[keep_idx], f32(0.0), f32(0.5)).astype(f32)
+            flip_keep = flip_full[keep_idx]
+    eff_m = int(maf_keep.shape[0])
+    tr = _c(train_sample_indices, np.int64).ravel()
+    if tr.size == 0:
+        raise RuntimeError("train_sample_indices must not be empty.")
+    if tr.min() < 0 or tr.max() >= n_samples:
+        raise RuntimeError("train_sample_indices out of range")
+    y = _c(y_train, np.float64).ravel()
+    if y.shape[0] != tr.shape[0]:
+        raise RuntimeError(f"y_train length mismatch: got {y.shape[0]}, expected {tr.shape[0]}")
+    if not np.all(np.isfinite(y)):
+        raise RuntimeError("y_train contains non-finite values.")
+    te = np.zeros(0, dtype=np.int64) if test_sample_indices is None else _c(test_sample_indices, np.int64).ravel()
+    if te.size and (te.min() < 0 or te.max() >= n_samples):
+        raise RuntimeError("test_sample_indices out of range")
+    pick = None
+    if train_pred_local_indices is not None:
+        pick = _c(train_pred_local_indices, np.int64).ravel()
+        if pick.size and (pick.min() < 0 or pick.max() >= tr.shape[0]):
+            raise RuntimeError("train_pred_local_indices out of range")
+    n_train = int(tr.shape[0])
+    lambda_use = f32(max(float(lambda_value), 1e-8))
+    std_eps32 = f32(max(float(std_eps), 1e-12))
+    # row standardisation (`rrblup_subset_or_validate_stats`, rrblup.rs:568-625)
+    if (row_mean is None) != (row_inv_sd is None):
+        raise RuntimeError("rrBLUP standardization requires row_mean and row_inv_sd together when overriding row stats.")
+    if row_mean is not None:
+        rm = _c(row_mean, f32).ravel()
+        ri = _c(row_inv_sd, f32).ravel()
+        if rm.shape[0] == eff_m and ri.shape[0] == eff_m:
+            pass
+        elif rm.shape[0] == m_total and ri.shape[0] == m_total and rows is not None:
+            rm, ri = rm[rows], ri[rows]
+        else:
+            raise RuntimeError(f"External row_mean/row_inv_sd length mismatch: mean={rm.shape[0]}, inv={ri.shape[0]}, "
+                               f"expected active={eff_m} or full={m_total}.")
+        m_effective = int(np.count_nonzero(np.isfinite(ri) & (ri > 0)))
+        if m_effective == 0:
+            raise RuntimeError("rrBLUP standardization received zero effective markers from external row_inv_sd.")
+    else:
+        pq = np.clip(maf_keep, f32(0.0), f32(0.5)).astype(f32)
+        rm = (f32(2.0) * pq).astype(f32)
+        var = np.maximum((f32(2.0) * pq * (f32(1.0) - pq)).astype(f32), f32(0.0))
+        good = var > std_eps32
+        ri = np.zeros_like(var)
+        ri[good] = (f32(1.0) / np.sqrt(var[good])).astype(f32)
+        m_effective = int(np.count_nonzero(good))
+    g0 = np.where(flip_keep, f32(2.0), f32(0.0)).astype(f32)
+    g2 = np.where(flip_keep, f32(0.0), f32(2.0)).astype(f32)
+    lut = np.zeros((eff_m, 4), dtype=f32)
+    lut[:, 0] = (g0 - rm) * ri
+    lut[:, 2] = (f32(1.0) - rm) * ri
+    lut[:, 3] = (g2 - rm) * ri
+    need_all = pick is None
+    need_train = need_all or bool(compute_trainvar) or (pick is not None and pick.size > 0)
+    beta = np.zeros(eff_m, dtype=f32)
+    pred_tr_full = np.zeros(n_train, dtype=np.float64) if need_train else None
+    pred_te = np.zeros(te.shape[0], dtype=np.float64)
+    sc = np.zeros(8, dtype=np.float64)
+    check(lib().jx_rrblup_pcg_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
+                                     _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
+                                     int(max_iter), _p(beta), _p(pred_tr_full), _p(pred_te) if te.size else None,
+                                     _p(sc)))
+    converged, iters, rel_res, sum_ss = bool(sc[0] != 0.0), int(sc[1]), float(sc[2]), float(sc[3])
+    if progress_callback is not None:
+        try:
+            progress_callback(iters, int(max_iter), rel_res)
+        except TypeError:
+            progress_callback(iters, int(max_iter))
+    pve_trainvar = float("nan")
+    if need_train:
+        pred_train = pred_tr_full if need_all else pred_tr_full[pick]
+        if compute_trainvar:
+            resid = y - pred_tr_full
+            if n_train > 1:
+                vg = float(np.sum((pred_tr_full - pred_tr_full.mean()) ** 2) / (n_train - 1))
+                ve = float(np.sum((resid - resid.mean()) ** 2) / (n_train - 1))
+            else:
+                vg = ve = 0.0
+            den = vg + ve
+            pve_trainvar = vg / den if (math.isfinite(den) and den > 0.0) else float("nan")
+    else:
+        pred_train = np.zeros(0, dtype=np.float64)
+    k_trace_mean = sum_ss / (float(m_effective) * float(n_train)) if (n_train > 0 and m_effective > 0) else float("nan")
+    pve_lambda_vc = float("nan")
+    if math.isfinite(k_trace_mean) and k_trace_mean > 0.0 and m_effective > 0:
+        dv = k_trace_mean + float(lambda_use) / float(m_effective)
+        if math.isfinite(dv) and dv > 0.0:
+            pve_lambda_vc = k_trace_mean / dv
+    return (np.asarray(pred_train, dtype=np.float64).reshape(-1, 1), pred_te.reshape(-1, 1), pve_trainvar, converged,
+            iters, rel_res, m_effective, pve_lambda_vc, k_trace_mean, beta)

@@ -1115,3 +1115,200 @@ def gblup_reml_packed_meta(packed, n_samples, row_source_indices, row_flip, row_
     pred_test = effect_alpha0 + raw(te).astype(np.float64).T @ effect_beta if len(te) else np.zeros(0)
     fit = dict(fit, effect_beta=effect_beta, effect_alpha0=effect_alpha0, var_sum=var_sum, m_alpha=m_alpha)
     return pred_train, pred_test, fit
+
+
+# --------------------------------------------------------------------------------------------
+# Next row 8f-4: rrBLUP by preconditioned conjugate gradients over the 2-bit payload
+# (src/stats/rrblup.rs:3494-4307 `rrblup_pcg_bed`, src/math/pcg.rs:870-949 `pcg_solve_into`)
+# --------------------------------------------------------------------------------------------
+
+def load_bed_2bit_packed_stats(packed, n_samples):
+    """(missing_rate, maf, std_denom) f32 per SNP as `load_bed_2bit_packed` computes them
+    (src/io/gfreader.rs:4460-4485) and the flip mask of `bed_packed_row_flip_mask` (src/stats/packed.rs:81-117)."""
+    mi, he, ho = row_counts(np.asarray(packed, dtype=np.uint8), n_samples)
+    m = mi.shape[0]
+    miss = (mi.astype(np.float32) / F32(n_samples)).astype(np.float32)
+    nm = n_samples - mi
+    alt = he + 2 * ho
+    maf = np.zeros(m, dtype=np.float32)
+    std = np.zeros(m, dtype=np.float32)
+    ok = nm > 0
+    p = np.zeros(m, dtype=np.float32)
+    p[ok] = alt[ok].astype(np.float32) / (F32(2.0) * nm[ok].astype(np.float32))
+    maf[ok] = np.minimum(p[ok], F32(1.0) - p[ok])
+    d = np.sqrt((F32(2.0) * p * (F32(1.0) - p)).astype(np.float32)).astype(np.float32)
+    std[ok] = np.where(np.isfinite(d[ok]), d[ok], F32(0.0))
+    flip = np.zeros(m, dtype=bool)
+    flip[ok] = (alt[ok].astype(np.float64) / (2.0 * nm[ok].astype(np.float64))) > 0.5
+    return miss, maf, std, flip
+
+
+def rrblup_row_standardization(maf_keep, std_eps32):
+    """`rrblup_parallel_row_standardization` (src/stats/rrblup.rs:512-566): mean = 2p, inv_sd = 1/sqrt(2p(1-p)) in f32,
+    0 when the variance is <= std_eps; returns (row_mean, row_inv_sd, m_effective)."""
+    p = np.clip(np.asarray(maf_keep, dtype=np.float32), F32(0.0), F32(0.5))
+    mean = (F32(2.0) * p).astype(np.float32)
+    var = np.maximum((F32(2.0) * p * (F32(1.0) - p)).astype(np.float32), F32(0.0))
+    good = var > F32(std_eps32)
+    inv = np.zeros_like(var)
+    inv[good] = (F32(1.0) / np.sqrt(var[good])).astype(np.float32)
+    return mean, inv, int(np.count_nonzero(good))
+
+
+def rrblup_value_lut(row_mean, row_inv_sd, row_flip):
+    """(m,4) f32 standardised design values by 2-bit code [00, 01, 10, 11]
+    (`decode_standardized_packed_block_rows_f32_with_plan`, src/math/bedmath.rs:1199-1214; missing -> 0)."""
+    mean = np.asarray(row_mean, dtype=np.float32)
+    inv = np.asarray(row_inv_sd, dtype=np.float32)
+    flip = np.asarray(row_flip, dtype=bool)
+    g0 = np.where(flip, F32(2.0), F32(0.0)).astype(np.float32)
+    g2 = np.where(flip, F32(0.0), F32(2.0)).astype(np.float32)
+    lut = np.zeros((mean.shape[0], 4), dtype=np.float32)
+    lut[:, 0] = (g0 - mean) * inv
+    lut[:, 2] = (F32(1.0) - mean) * inv
+    lut[:, 3] = (g2 - mean) * inv
+    return lut
+
+
+def pcg_solve_f32(b, apply_a, inv_diag, max_iter, tol, tiny=1e-20):
+    """`pcg_solve_into` for T = f32 without an initial guess (src/math/pcg.rs:870-949): vectors f32, dot products in
+    f64 (`PcgScalar for f32`, :65-90), Jacobi preconditioner (:223-245). Returns (x, converged, iters, rel_res)."""
+    b = np.asarray(b, dtype=np.float32)
+    m = b.shape[0]
+    x = np.zeros(m, dtype=np.float32)
+    if m == 0 or max_iter == 0:
+        return x, m == 0, 0, 0.0
+
+    def dot(u, v):
+        return float(np.dot(u.astype(np.float64), v.astype(np.float64)))
+
+    bnorm = math.sqrt(dot(b, b))
+    denom_b = max(bnorm, 1e-12)
+    r = b.copy()
+    z = (r * inv_diag).astype(np.float32)
+    p = z.copy()
+    rz_old = dot(r, z)
+    rel_res = max(math.sqrt(dot(r, r)) / denom_b, 0.0)
+    iters = 0
+    tiny_use = max(tiny, 1e-30)
+    tol_use = max(tol, 0.0)
+    if math.isfinite(rel_res) and rel_res <= tol_use:
+        return x, True, 0, rel_res
+    converged = False
+    for it in range(max_iter):
+        ap = apply_a(p)
+        denom = dot(p, ap)
+        if not math.isfinite(denom) or denom <= tiny_use:
+            break
+        alpha = F32(rz_old / denom)
+        x = (x + alpha * p).astype(np.float32)
+        r = (r - alpha * ap).astype(np.float32)
+        rel_res = max(math.sqrt(dot(r, r)) / denom_b, 0.0)
+        iters = it + 1
+        if math.isfinite(rel_res) and rel_res <= tol_use:
+            converged = True
+            break
+        z = (r * inv_diag).astype(np.float32)
+        rz_new = dot(r, z)
+        if not math.isfinite(rz_new) or rz_new <= tiny_use:
+            break
+        beta = F32(rz_new / max(rz_old, tiny_use))
+        p = (z + beta * p).astype(np.float32)
+        rz_old = rz_new
+    return x, converged, iters, rel_res
+
+
+def rrblup_pcg_packed(packed, n_samples, maf, row_flip, train_idx, y_train, test_idx=None, train_pred_local=None,
+                      site_keep=None, lambda_value=10000.0, tol=1e-4, max_iter=100, std_eps=1e-12,
+                      compute_trainvar=False, row_mean=None, row_inv_sd=None):
+    """`rrblup_pcg_bed` on a resident packed payload (src/stats/rrblup.rs:3519-4307): marker effects beta solve
+    (Z_c Z_c' + lambda I) beta = Z y_c, Z (m, n_train) the standardised genotypes of the training samples, Z_c its
+    row-centred form applied implicitly (`RrblupPcgOperator::apply` :865-929), right-hand side and Jacobi diagonal
+    from one pre-pass (`rrblup_prepare_rhs_diag` :650-845, `row_major_block_prepare_rhs_diag_f32` :396-466).
+    Returns the reference's tuple (pred_train (k,1), pred_test (t,1), pve_trainvar, converged, iters, rel_res,
+    m_effective, pve_lambda_vc, k_trace_mean, beta f32 (m))."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    m_total = packed.shape[0]
+    maf_full = np.asarray(maf, dtype=np.float32)
+    flip_full = np.asarray(row_flip, dtype=bool)
+    rows = None
+    maf_keep, flip_keep = maf_full, flip_full
+    if site_keep is not None:
+        keep_idx = np.nonzero(np.asarray(site_keep, dtype=bool))[0]
+        if keep_idx.shape[0] == 0:
+            raise RuntimeError("No SNPs remained after applying site_keep mask.")
+        if not (keep_idx.shape[0] == m_total):
+            rows = keep_idx
+            maf_keep = np.clip(maf_full[keep_idx], F32(0.0), F32(0.5))
+            flip_keep = flip_full[keep_idx]
+    eff_m = maf_keep.shape[0]
+    tr = np.asarray(train_idx, dtype=np.int64)
+    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    y = np.asarray(y_train, dtype=np.float64)
+    n_train = tr.shape[0]
+    lambda_use = F32(max(lambda_value, 1e-8))
+    tol_use = max(tol, 1e-12)
+    std_eps32 = F32(max(std_eps, 1e-12))
+    if row_mean is not None and row_inv_sd is not None:
+        rm = np.asarray(row_mean, dtype=np.float32)
+        ri = np.asarray(row_inv_sd, dtype=np.float32)
+        if rm.shape[0] != eff_m:
+            rm, ri = rm[rows], ri[rows]
+        m_effective = int(np.count_nonzero(np.isfinite(ri) & (ri > 0)))
+    else:
+        rm, ri, m_effective = rrblup_row_standardization(maf_keep, std_eps32)
+    lut = rrblup_value_lut(rm, ri, flip_keep)
+    codes = unpack_codes(packed if rows is None else packed[rows], n_samples)
+
+    def decode(cols):
+        return np.take_along_axis(lut, codes[:, cols].astype(np.int64), axis=1).astype(np.float32)
+
+    z = decode(tr)                                     # (m, n_train) f32
+    y_mean = float(np.sum(y)) / float(n_train)
+    y_c = (y - y_mean).astype(np.float32)
+    b = (z @ y_c).astype(np.float32)                   # row_major_block_mul_vec_f32 (f32 GEMV)
+    z64 = z.astype(np.float64)
+    s = z64.sum(axis=1)
+    mean = s / float(n_train)
+    ss = np.maximum((z64 * z64).sum(axis=1) - float(n_train) * mean * mean, 0.0)
+    sum_ss_global = float(np.sum(ss))
+    train_row_mean = mean.astype(np.float32)
+    diag_inv = (F32(1.0) / np.maximum(ss.astype(np.float32) + lambda_use, F32(1e-12))).astype(np.float32)
+
+    def apply_a(p):
+        xp = (z.T @ p).astype(np.float32)
+        ap = (z @ xp).astype(np.float32)
+        mean_dot = F32(float(np.dot(train_row_mean.astype(np.float64), p.astype(np.float64))))
+        ap = (ap - F32(n_train) * train_row_mean * mean_dot).astype(np.float32)
+        return (ap + lambda_use * p).astype(np.float32)
+
+    beta, converged, iters, rel_res = pcg_solve_f32(b, apply_a, diag_inv, max_iter, tol_use)
+    acc = F32(0.0)
+    for v in (train_row_mean * beta).astype(np.float32):   # `.sum::<f32>()`, sequential
+        acc = F32(acc + v)
+    alpha_use = F32(F32(y_mean) - acc)
+    need_all = train_pred_local is None
+    pred_train = np.zeros(0)
+    pve_trainvar = float("nan")
+    if compute_trainvar or need_all:
+        full = ((z.T @ beta).astype(np.float32) + alpha_use).astype(np.float32).astype(np.float64)
+        pred_train = full if need_all else full[np.asarray(train_pred_local, dtype=np.int64)]
+        if compute_trainvar:
+            resid = y - full
+            vg = float(np.var(full, ddof=1)) if n_train > 1 else 0.0
+            ve = float(np.var(resid, ddof=1)) if n_train > 1 else 0.0
+            pve_trainvar = vg / (vg + ve) if (vg + ve) > 0 and math.isfinite(vg + ve) else float("nan")
+    elif len(train_pred_local) > 0:
+        cols = tr[np.asarray(train_pred_local, dtype=np.int64)]
+        pred_train = ((decode(cols).T @ beta).astype(np.float32) + alpha_use).astype(np.float32).astype(np.float64)
+    k_trace_mean = sum_ss_global / (float(m_effective) * float(n_train)) if (n_train > 0 and m_effective > 0) else float("nan")
+    pve_lambda_vc = float("nan")
+    if math.isfinite(k_trace_mean) and k_trace_mean > 0 and m_effective > 0:
+        dv = k_trace_mean + float(lambda_use) / float(m_effective)
+        if math.isfinite(dv) and dv > 0:
+            pve_lambda_vc = k_trace_mean / dv
+    pred_test = np.zeros(0)
+    if te.shape[0] > 0:
+        pred_test = (decode(te).T @ beta).astype(np.float32).astype(np.float64) + float(alpha_use)
+    return (pred_train.reshape(-1, 1), pred_test.reshape(-1, 1), pve_trainvar, bool(converged), int(iters),
+            float(rel_res), int(m_effective), pve_lambda_vc, k_trace_mean, beta)

@@ -999,3 +999,100 @@ def test_small_shapes_and_many_covariates(oracle, oracle_c, n, m, p, seed):
     fout = jxrs.fvlmm_assoc_packed_f32(pk, n, flip[keep], maf[keep], s, xr, yr.ravel(), u_t, math.log10(lbd_c))
     be, se, pe = _assoc_err(fout, fref)
     assert max(be, se) < 5 * TOL, (be, se, pe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", [False, True])
+def test_rrblup_pcg_bed(oracle, tmp_path, subset):
+    """marker effects by PCG over the packed payload vs the numpy restatement of `rrblup_pcg_bed`.
+    Both run the same f32 iteration (f64 dots); the matrix-vector products differ in summation order (f64 accumulation
+    on the device, f32 GEMV in the restatement), so iterates agree to f32 rounding and the converged solutions to a
+    small multiple of the stopping tolerance: 2e-5 of max|beta| at tol = 1e-7 (the f32 floor), 1e-3 at the default
+    1e-4 with iteration counts within one."""
+    from janusx_amd import janusx as jxrs
+    n, m = 420, 1500
+    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.01)
+    _miss, maf, _std, flip = oracle.load_bed_2bit_packed_stats(packed, n)
+    assert np.array_equal(jxrs.bed_packed_row_flip_mask(packed, n), flip)
+    rng = np.random.default_rng(5)
+    tr = np.sort(rng.permutation(n)[:330]).astype(np.int64)
+    te = np.setdiff1d(np.arange(n), tr).astype(np.int64)
+    eff = rng.standard_normal(40) * 0.4
+    yall = (g[:40].astype(np.float64) - g[:40].mean(1, keepdims=True)).T @ eff + rng.standard_normal(n)
+    y = yall[tr]
+    keep = (rng.random(m) < 0.8) if subset else None
+    pick = np.array([5, 0, 17, 200], dtype=np.int64) if subset else None
+    lam = 250.0
+    for tol, max_iter, btol in ((1e-7, 400, 2e-5), (1e-4, 100, 1e-3)):
+        ref = oracle.rrblup_pcg_packed(packed, n, maf, flip, tr, y, te, pick, keep, lam, tol, max_iter,
+                                       compute_trainvar=True)
+        got = jxrs.rrblup_pcg_bed("", tr, y, te, pick, keep, lambda_value=lam, tol=tol, max_iter=max_iter,
+                                  compute_trainvar=True, packed=packed, packed_n_samples=n, maf=maf, row_flip=flip)
+        assert got[3] == ref[3] and abs(got[4] - ref[4]) <= 1 and got[6] == ref[6]
+        assert got[9].dtype == np.float32 and got[9].shape == ref[9].shape
+        bscale = float(np.max(np.abs(ref[9])))
+        assert np.max(np.abs(got[9] - ref[9])) <= btol * bscale
+        pscale = float(np.max(np.abs(ref[0]))) + float(np.std(y))
+        assert got[0].shape == ref[0].shape and got[1].shape == ref[1].shape
+        assert np.max(np.abs(got[0] - ref[0])) <= btol * pscale
+        assert np.max(np.abs(got[1] - ref[1])) <= btol * pscale
+        assert abs(got[2] - ref[2]) <= 10 * btol
+        assert abs(got[8] - ref[8]) <= 1e-9 * abs(ref[8]) and abs(got[7] - ref[7]) <= 1e-9
+    # prefix form: payload, maf and flip mask derived from the BED file
+    prefix = str(tmp_path / "pcg")
+    bim = bed.Bim(["1"] * m, [f"s{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"id{i}" for i in range(n)], bim)
+    pk2, miss2, maf2, std2, n2 = jxrs.load_bed_2bit_packed(prefix)
+    assert n2 == n and np.array_equal(pk2, packed) and np.array_equal(maf2, maf) and np.array_equal(miss2, _miss)
+    assert np.array_equal(std2, _std)
+    got2 = jxrs.rrblup_pcg_bed(prefix, tr, y, te, lambda_value=lam, tol=1e-7, max_iter=400)
+    ref2 = oracle.rrblup_pcg_packed(packed, n, maf, flip, tr, y, te, None, None, lam, 1e-7, 400)
+    assert np.max(np.abs(got2[9] - ref2[9])) <= 2e-5 * float(np.max(np.abs(ref2[9])))
+    assert np.isnan(got2[2]) and got2[0].shape == (len(tr), 1)
+    with pytest.raises(RuntimeError):
+        jxrs.rrblup_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf)          # row_flip missing
+    with pytest.raises(RuntimeError):
+        jxrs.rrblup_pcg_bed("", tr, y[:-1], packed=packed, packed_n_samples=n, maf=maf, row_flip=flip)
+
+
+@pytest.mark.gpu
+def test_cli_gs_rrblup(oracle, tmp_path):
+    """`jx gs -rrBLUP -lambda L -cv 2`: PCG marker effects on the phenotyped samples, predictions for the rest, against
+    the restatement of `rrblup_pcg_bed` on the same kept-SNP mask; and the subsample-REML lambda runs end to end."""
+    from janusx_amd import cli
+    n, m = 300, 900
+    packed, g = bed.synth_panel_numpy(n, m, seed=83, missing_rate=0.01)
+    y = bed.synth_phenotype(g, n_causal=50, pve=0.6, seed=83)
+    na = np.random.default_rng(9).random(n) < 0.2
+    prefix = str(tmp_path / "rr")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ttrait\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
+    lam = 400.0
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-lambda", str(lam), "-tol", "1e-7",
+                     "-max-iter", "400", "-cv", "2", "-seed", "3", "-o", prefix]) == 0
+    rows = [ln.split("\t") for ln in open(prefix + ".trait.gs.rrBLUP.tsv").read().splitlines()]
+    assert rows[0] == ["sample", "observed", "predicted", "fold"] and len(rows) == n + 1
+    miss, maf, _std, flip = oracle.load_bed_2bit_packed_stats(packed, n)
+    keep = (maf >= np.float32(0.02)) & (miss <= np.float32(0.05))
+    train, test = np.nonzero(~na)[0], np.nonzero(na)[0]
+    ref = oracle.rrblup_pcg_packed(packed, n, maf, flip, train, y[train], test, None, keep, lam, 1e-7, 400)
+    pred = np.array([float(r[2]) for r in rows[1:]])
+    scale = float(np.std(y[train]))
+    assert np.max(np.abs(pred[test] - ref[1].ravel())) < 1e-4 * scale
+    perm = np.random.default_rng(3).permutation(len(train))
+    te_loc = np.sort(perm[1::2])
+    tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+    assert all(rows[1 + train[j]][3] == "1" for j in te_loc)
+    r1 = oracle.rrblup_pcg_packed(packed, n, maf, flip, train[tr_loc], y[train[tr_loc]], train[te_loc], None, keep, lam,
+                                  1e-7, 400)
+    assert np.max(np.abs(pred[train[te_loc]] - r1[1].ravel())) < 1e-4 * scale
+    # lambda from the subsample REML: runs, converges, predicts the held-out samples with positive accuracy
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-o", prefix + "_auto"]) == 0
+    rows2 = [ln.split("\t") for ln in open(prefix + "_auto.trait.gs.rrBLUP.tsv").read().splitlines()]
+    p2 = np.array([float(r[2]) for r in rows2[1:]])
+    assert np.all(np.isfinite(p2)) and np.corrcoef(p2[test], y[test])[0, 1] > 0.2

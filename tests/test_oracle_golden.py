@@ -163,3 +163,34 @@ def test_mouse_effective_snp_count_matches_reference_readme(oracle, oracle_c):
     k2, af2, miss2 = stats.gwas_scan_row_stats(np.stack([mi, he, ho], 1), n, 0.02, 0.05, 1.0)
     assert np.array_equal(k2, keep) and np.array_equal(af2[keep], af[keep])
     assert int(np.isfinite(d["pheno"][:, 0]).sum()) == 1410  # README "Train size: 1410" (trait test0)
+
+
+def test_rrblup_pcg_restatement_solves_the_ridge_system():
+    """the reference ships no numeric test for `rrblup_pcg_bed` / `pcg_solve_into` (parity unpinned beyond
+    this property): the restated f32 PCG must converge to the f64 direct solution of
+    (Z_c Z_c' + lambda I) beta = Z y_c, and its predictions must be alpha + Z' beta."""
+    from oracle import jx_oracle as O
+    from janusx_amd import bed
+    n, m = 200, 500
+    packed, g = bed.synth_panel_numpy(n, m, seed=4, missing_rate=0.02)
+    miss, maf, std, flip = O.load_bed_2bit_packed_stats(packed, n)
+    rng = np.random.default_rng(0)
+    tr = np.sort(rng.permutation(n)[:160])
+    te = np.setdiff1d(np.arange(n), tr)
+    y = rng.standard_normal(160) + (g[:20, tr].T @ rng.standard_normal(20)) * 0.3
+    lam = 120.0
+    out = O.rrblup_pcg_packed(packed, n, maf, flip, tr, y, te, lambda_value=lam, tol=1e-7, max_iter=500)
+    assert out[3] and out[5] <= 1e-7
+    rm, ri, me = O.rrblup_row_standardization(maf, np.float32(1e-12))
+    assert me == out[6]
+    lut = O.rrblup_value_lut(rm, ri, flip)
+    codes = O.unpack_codes(packed, n).astype(np.int64)
+    z = np.take_along_axis(lut, codes[:, tr], axis=1).astype(np.float64)
+    zc = z - z.mean(1, keepdims=True)
+    yc = y - y.mean()
+    beta = np.linalg.solve(zc @ zc.T + lam * np.eye(m), z @ yc)
+    assert np.max(np.abs(beta - out[9])) <= 2e-5 * np.max(np.abs(beta))
+    alpha = y.mean() - float(np.sum(z.mean(1) * beta))
+    zt = np.take_along_axis(lut, codes[:, te], axis=1).astype(np.float64)
+    assert np.max(np.abs(out[1].ravel() - (zt.T @ beta + alpha))) <= 1e-4
+    assert np.max(np.abs(out[0].ravel() - (z.T @ beta + alpha))) <= 1e-4

@@ -115,6 +115,19 @@ int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int3
                         const void *d_lut16, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
                         float *d_out, void *stream);
 
+/* D1+D2, exact-row form.  A design row whose three genotype values are beta + {0,1,2} (the scan design g - row mean,
+ * src/decode/decode.rs:192-271, either allele orientation) and that has no missing call among the n selected samples
+ * is rotated as  (c U) + beta * usum:  `jxg_lut_split_rows` stores its integer LUT (fp16-exact, lo plane zero) and
+ * beta in d_rowoff[k]; every other row keeps the hi/lo split and gets d_rowoff[k] = NaN.  `jxg_ut_rowsum` gives
+ * usum[j] = sum_i u_t[j][i] (n_pad floats).  `jxg_rotate_packed16x` = `jxg_rotate_packed16` plus the affine term; a
+ * 128-row tile whose rows all qualify skips the lo plane of the design (two MFMA products instead of three). */
+int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
+                       int64_t mk, void *d_lut16, float *d_rowoff, void *stream);
+int jxg_ut_rowsum(const float *d_ut, int n, float *d_usum, void *stream);
+int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                         const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
+                         const uint16_t *d_ulo, int scale_exp, float *d_out, void *stream);
+
 /* D2 (dense input). out[r, j] = sum_i g[r, i] * u_t[j, i] in exact f32 (f32 MFMA).
  * src/stats/lmm.rs:520-552 `rotate_snp_block_with_ut`. */
 int jxg_rotate_dense_f32(const float *d_g, int nrows, int n, const float *d_ut, float *d_out, void *stream);

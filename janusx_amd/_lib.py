@@ -42,6 +42,9 @@ SIGNATURES = {
     "jxg_rotate_packed": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
     "jxg_lut_split": [c_p, c_l, c_p, c_p],
     "jxg_rotate_packed16": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p],
+    "jxg_lut_split_rows": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p],
+    "jxg_ut_rowsum": [c_p, c_i, c_p, c_p],
+    "jxg_rotate_packed16x": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "jxg_rotate_dense_f32": [c_p, c_i, c_i, c_p, c_p, c_p],
     "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_lmm_tables_bytes": [c_i, c_i, c_d, c_d],

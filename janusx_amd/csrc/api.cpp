@@ -605,9 +605,17 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         return 1;
     const int scale_exp = 10;
     if (jxg_ut_split(dut.as<float>(), n, uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, nullptr)) return 1;
+    DevBuf dusum, dlut16, drowoff;
+    if (dusum.alloc(sizeof(float) * (size_t)npad)) return 1;
+    if (jxg_ut_rowsum(dut.as<float>(), n, dusum.as<float>(), nullptr)) return 1;
+    JX_HIP(hipDeviceSynchronize());
     dut.release();
     if (dlut.alloc(lut.size() * sizeof(float))) return 1;
     JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    // fp16 LUT records once for all rows; rows without missing calls as integer LUT + offset (exact-row rotation)
+    if (dlut16.alloc((size_t)16 * (size_t)m) || drowoff.alloc(sizeof(float) * (size_t)m)) return 1;
+    if (jxg_lut_split_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(), nullptr))
+        return 1;
     const int64_t brows = 8192;
     if (drot.alloc(sizeof(float) * (size_t)brows * n)) return 1;
     if (dout.alloc(sizeof(double) * (size_t)brows * cols)) return 1;
@@ -618,8 +626,10 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         const int rows = (int)std::min<int64_t>(brows, m - r0);
         for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
         JX_HIP(hipMemcpy(drows.p, hrows.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
-        if (jxg_rotate_packed(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows, dlut.as<float>() + (size_t)r0 * 4,
-                              uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, drot.as<float>(), nullptr))
+        if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                 (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,
+                                 dusum.as<float>(), uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, drot.as<float>(),
+                                 nullptr))
             return 1;
         if (model == 0) {
             if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,

@@ -11,6 +11,10 @@
 // ~2^-22 per operand.  Dense route (jxg_rotate_dense_f32): exact f32 MFMA (v_mfma_f32_32x32x2_f32).
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -70,20 +74,106 @@ __global__ __launch_bounds__(256) void lut_split_r_kernel(const float *__restric
     if (bad) atomicOr(flags, 1);
 }
 
+
+// Design rows that factor as beta + {0,1,2}: integer LUT (hi plane, lo = 0) and rowoff[k] = beta; every other row keeps
+// the hi/lo split of its values and rowoff[k] = NaN.  A row qualifies when its three genotype values are
+// beta + {0,1,2} in either allele orientation (the scan design: g - row mean, src/decode/decode.rs:192-271) and no
+// selected sample carries the missing code (its imputed value is then never decoded).
+__global__ __launch_bounds__(256) void lut_split_rows_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                             const int32_t *__restrict__ rows,
+                                                             const float *__restrict__ lut, int64_t mk, int n_sel,
+                                                             int nt128, uint4 *__restrict__ out,
+                                                             float *__restrict__ rowoff, int *__restrict__ flags) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= mk) return;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = lut[k * 4 + c];
+    const float b = fminf(v[0], v[3]);
+    const float c0 = v[0] - b, c2 = v[2] - b, c3 = v[3] - b;
+    const float tol = 4e-6f;
+    bool ok = fabsf(c2 - 1.0f) <= tol &&
+              ((fabsf(c0) <= tol && fabsf(c3 - 2.0f) <= tol) || (fabsf(c0 - 2.0f) <= tol && fabsf(c3) <= tol)) &&
+              fabsf(b) <= 4.0f;
+    if (ok) {
+        const int64_t rec = rows ? (int64_t)rows[k] : k;
+        uint32_t any = 0;
+        for (int t = 0; t < nt128; ++t) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p32 + ((int64_t)t * m_total + rec) * 32);
+            const uint4 a = q[0], c = q[1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+            const int valid = n_sel - t * 128;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                uint32_t miss = w[d] & ~(w[d] >> 1) & 0x55555555u;
+                const int left = valid - d * 16;
+                if (left <= 0) miss = 0;
+                else if (left < 16) miss &= (1u << (2 * left)) - 1u;
+                any |= miss;
+            }
+        }
+        ok = (any == 0);
+    }
+    float off = __builtin_nanf("");
+    if (ok) {
+        const float r0 = (c0 > 1.0f) ? 2.0f : 0.0f, r3 = 2.0f - r0;
+        off = ((v[0] - r0) + (v[2] - 1.0f) + (v[3] - r3)) * (1.0f / 3.0f);
+        v[0] = r0; v[1] = 0.0f; v[2] = 1.0f; v[3] = r3;
+    }
+    rowoff[k] = off;
+    uint16_t hi[4], lo[4];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (!(fabsf(v[c]) <= 30000.0f)) bad = true;
+        const __half h = __float2half_rn(v[c]);
+        const __half l = __float2half_rn(v[c] - __half2float(h));
+        hi[c] = __half_as_ushort(h);
+        lo[c] = __half_as_ushort(l);
+    }
+    uint4 o;
+    o.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
+    o.y = (uint32_t)hi[2] | ((uint32_t)hi[3] << 16);
+    o.z = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    o.w = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
+    out[k] = o;
+    if (bad) atomicOr(flags, 1);
+}
+
+// usum[j] = sum_i u_t[j][i] (f64 accumulation), one wave per eigenvector row; zero beyond n
+__global__ __launch_bounds__(256) void ut_rowsum_kernel(const float *__restrict__ ut, int n, int npad,
+                                                        float *__restrict__ usum) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= npad) return;
+    double a = 0.0;
+    if (j < n)
+        for (int i = lane; i < n; i += 64) a += (double)ut[(int64_t)j * n + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) usum[j] = (float)a;
+}
+
 // grid: x = column tile (eigenvector index j), y = row tile (SNP rows). 256 threads = 4 waves (2x2 of 64x64).
 // waves 0-1 decode the A panel (128 SNP rows x 32 samples), waves 2-3 stage the two U planes.
+// Rows whose design values are beta + {0,1,2} without missing calls (`jxg_lut_split_rows`: integer LUT, lo plane zero,
+// beta in rowoff[r]; NaN marks a general row) contribute  out = (c U) + beta * usum,  usum[j] = sum_i u_t[j][i]:
+// a tile whose 128 rows all qualify skips the A-lo plane (decode, LDS traffic and one of the three MFMA products).
 __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
                                                               const int32_t *__restrict__ rows, int nrows,
                                                               const uint4 *__restrict__ lut16,
+                                                              const float *__restrict__ rowoff,
+                                                              const float *__restrict__ usum,
                                                               const __half *__restrict__ uhi,
                                                               const __half *__restrict__ ulo, int64_t npad, int n,
                                                               float out_scale, float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 64 + 512];
     uint8_t *sAh = smem;
     uint8_t *sAl = smem + R_IMG;
     uint8_t *sBh = smem + 2 * R_IMG;
     uint8_t *sBl = smem + 3 * R_IMG;
     uint32_t *seltab = reinterpret_cast<uint32_t *>(smem + 4 * R_IMG);
+    float *sOff = reinterpret_cast<float *>(smem + 4 * R_IMG + 64);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,14 +197,25 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
     // decoder: thread = SNP row r0 + tid
     const uint8_t *arec = nullptr;
     uint4 L = make_uint4(0, 0, 0, 0);
+    int row_exact = 1;
     if (is_decoder) {
         const int r = r0 + tid;
+        float boff = 0.0f;
         if (r < nrows) {
             const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
             arec = p32 + rec * 32;
             L = lut16[r];
+            if (rowoff) {
+                const float t = rowoff[r];
+                row_exact = (t == t) ? 1 : 0;
+                boff = row_exact ? t : 0.0f;
+            } else {
+                row_exact = 0;
+            }
         }
+        sOff[tid] = boff;
     }
+    const bool tile_exact = __syncthreads_and(row_exact) != 0 && rowoff != nullptr;
     // stager: u = tid - 128; chunk id = u + 128*c (c = 0..3): row = id >> 2, part = id & 3 (16 B each)
     const int u = tid - 128;
 
@@ -176,18 +277,20 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                 h1.y = __builtin_amdgcn_perm(L.y, L.x, sl[5]);
                 h1.z = __builtin_amdgcn_perm(L.y, L.x, sl[6]);
                 h1.w = __builtin_amdgcn_perm(L.y, L.x, sl[7]);
-                l0.x = __builtin_amdgcn_perm(L.w, L.z, sl[0]);
-                l0.y = __builtin_amdgcn_perm(L.w, L.z, sl[1]);
-                l0.z = __builtin_amdgcn_perm(L.w, L.z, sl[2]);
-                l0.w = __builtin_amdgcn_perm(L.w, L.z, sl[3]);
-                l1.x = __builtin_amdgcn_perm(L.w, L.z, sl[4]);
-                l1.y = __builtin_amdgcn_perm(L.w, L.z, sl[5]);
-                l1.z = __builtin_amdgcn_perm(L.w, L.z, sl[6]);
-                l1.w = __builtin_amdgcn_perm(L.w, L.z, sl[7]);
                 *reinterpret_cast<u32x4 *>(dh + half * 32) = h0;
                 *reinterpret_cast<u32x4 *>(dh + half * 32 + 16) = h1;
-                *reinterpret_cast<u32x4 *>(dl + half * 32) = l0;
-                *reinterpret_cast<u32x4 *>(dl + half * 32 + 16) = l1;
+                if (!tile_exact) {
+                    l0.x = __builtin_amdgcn_perm(L.w, L.z, sl[0]);
+                    l0.y = __builtin_amdgcn_perm(L.w, L.z, sl[1]);
+                    l0.z = __builtin_amdgcn_perm(L.w, L.z, sl[2]);
+                    l0.w = __builtin_amdgcn_perm(L.w, L.z, sl[3]);
+                    l1.x = __builtin_amdgcn_perm(L.w, L.z, sl[4]);
+                    l1.y = __builtin_amdgcn_perm(L.w, L.z, sl[5]);
+                    l1.z = __builtin_amdgcn_perm(L.w, L.z, sl[6]);
+                    l1.w = __builtin_amdgcn_perm(L.w, L.z, sl[7]);
+                    *reinterpret_cast<u32x4 *>(dl + half * 32) = l0;
+                    *reinterpret_cast<u32x4 *>(dl + half * 32 + 16) = l1;
+                }
             }
         } else {
 #pragma unroll
@@ -207,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
             for (int mi = 0; mi < 2; ++mi) {
                 const int off = (wm * 64 + mi * 32) * R_PITCH + frag_off + kk * 32;
                 ah[mi] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sAh + off));
-                al[mi] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sAl + off));
+                if (!tile_exact) al[mi] = __builtin_bit_cast(half8, *reinterpret_cast<const u32x4 *>(sAl + off));
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
@@ -221,7 +324,8 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                 for (int ni = 0; ni < 2; ++ni) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bhf[ni], acc[mi][ni], 0, 0, 0);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], blf[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bhf[ni], acc[mi][ni], 0, 0, 0);
+                    if (!tile_exact)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bhf[ni], acc[mi][ni], 0, 0, 0);
                 }
         }
         __syncthreads();
@@ -232,10 +336,12 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int gj = j0 + wn * 64 + ni * 32 + (lane & 31);
+            const float us = (usum && gj < n) ? usum[gj] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gr = r0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (gr < nrows && gj < n) out[(int64_t)gr * n + gj] = acc[mi][ni][r] * out_scale;
+                const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gr = r0 + lr;
+                if (gr < nrows && gj < n) out[(int64_t)gr * n + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
             }
         }
 }
@@ -390,10 +496,52 @@ extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void
     return 0;
 }
 
+extern "C" int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows,
+                                  const float *d_lut, int64_t mk, void *d_lut16, float *d_rowoff, void *stream) {
+    if (mk <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int *flags = nullptr;
+    JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));
+    JX_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
+    hipLaunchKernelGGL(lut_split_rows_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_p32, m_total,
+                       d_rows, d_lut, mk, n, num_tiles(n), (uint4 *)d_lut16, d_rowoff, flags);
+    JX_LAUNCH_CHECK();
+    int hflag = 0;
+    JX_HIP(hipMemcpyAsync(&hflag, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    JX_HIP(hipFreeAsync(flags, st));
+    if (hflag) return fail("design values exceed the fp16 split range (|z| > 3e4)");
+    return 0;
+}
+
+extern "C" int jxg_ut_rowsum(const float *d_ut, int n, float *d_usum, void *stream) {
+    const int npad = num_tiles(n) * JXG_TILE;
+    hipLaunchKernelGGL(ut_rowsum_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_ut, n,
+                       npad, d_usum);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                    const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                    const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
+                                    void *stream);
+
 extern "C" int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                    const void *d_lut16, const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp,
                                    float *d_out, void *stream) {
+    return jxg_rotate_packed16x(d_p32, m_total, n, d_rows, nrows, d_lut16, nullptr, nullptr, d_uhi, d_ulo, scale_exp,
+                                d_out, stream);
+}
+
+extern "C" int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                    const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                    const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
+                                    void *stream) {
     if (nrows <= 0) return 0;
+    static const int exact_env = getenv("JXGPU_ROT_EXACT") ? atoi(getenv("JXGPU_ROT_EXACT")) : 1;
+    if (!d_usum) d_rowoff = nullptr;
+    if (!exact_env && d_rowoff) return fail("JXGPU_ROT_EXACT=0 must be set before the design LUTs are split");
     hipStream_t st = (hipStream_t)stream;
     const int nt = num_tiles(n);
     const int64_t npad = (int64_t)nt * JXG_TILE;
@@ -405,7 +553,7 @@ extern "C" int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n,
     dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
     JX_HIP(hipEventRecord(g_rot_a, st));
     hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
-                       (const uint4 *)d_lut16, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
+                       (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
                        ldexpf(1.0f, -scale_exp), d_out);
     JX_LAUNCH_CHECK();
     JX_HIP(hipEventRecord(g_rot_b, st));

@@ -196,7 +196,9 @@ class SpectralModel:
             hi = torch.empty((npad, npad), dtype=torch.float16, device=self.S.device)
             lo = torch.empty((npad, npad), dtype=torch.float16, device=self.S.device)
             check(lib().jxg_ut_split(_ptr(self.ut), self.n, _ptr(hi), _ptr(lo), SCALE_EXP, _stream()))
-            self._planes = (hi, lo)
+            usum = torch.empty(npad, dtype=torch.float32, device=self.S.device)   # sum_i u_t[j][i]: affine term of exact rows
+            check(lib().jxg_ut_rowsum(_ptr(self.ut), self.n, _ptr(usum), _stream()))
+            self._planes = (hi, lo, usum)
         return self._planes
 
     def fv_cache(self, log10_lbd=None):
@@ -238,11 +240,14 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         return (out, evals) if return_evals else out
     rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
-    hi, lo = model.planes()
-    # one-off per call: fp16 hi/lo LUT records (range-checked) and, for the exact scan, the Chebyshev tables of the
-    # lambda-only REML sums; the block loop below then only launches kernels (no allocation, no host sync).
+    hi, lo, usum = model.planes()
+    # one-off per call: fp16 hi/lo LUT records (range-checked; rows without missing calls as integer LUT + offset, see
+    # jxg_lut_split_rows) and, for the exact scan, the Chebyshev tables of the lambda-only REML sums; the block loop
+    # below then only launches kernels (no allocation, no host sync).
     lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
-    check(lib().jxg_lut_split(_ptr(lut_t), mk, _ptr(lut16), _stream()))
+    rowoff = torch.empty(mk, dtype=torch.float32, device=dev)
+    check(lib().jxg_lut_split_rows(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16),
+                                   _ptr(rowoff), _stream()))
     tables = None
     if mode == "lmm2":
         lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
@@ -270,8 +275,9 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         grot = grots[bi % nbuf]
         if times is not None:
             ev_rot[bi][0].record()
-        check(lib().jxg_rotate_packed16(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
-                                        lut16[r0:].data_ptr(), _ptr(hi), _ptr(lo), SCALE_EXP, _ptr(grot), _stream()))
+        check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                         lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
+                                         SCALE_EXP, _ptr(grot), _stream()))
         if times is not None:
             ev_rot[bi][1].record()
             ev_scan[bi][0].record()

@@ -288,6 +288,51 @@ def test_assoc_packed(oracle, oracle_c, null_case):
     assert max(be, se) < TOL, (be, se, pe)
 
 
+def test_scan_exact_design_rows(oracle, oracle_c):
+    """Design rows without missing calls are rotated as (c U) + beta * usum (integer LUT, two MFMA products per tile when
+    all 128 rows of a tile qualify): a panel without missing genotypes (every tile exact), one with missing calls in
+    a third of the SNPs (mixed tiles), flipped alleles, on the host C-ABI route and the device pipeline route."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import pipeline, stats
+    n, m = 300, 700
+    for miss_frac in (0.0, 0.35):
+        packed, g = bed.synth_panel_numpy(n, m, seed=17, missing_rate=0.0)
+        rng = np.random.default_rng(11)
+        for r in np.nonzero(rng.random(m) < miss_frac)[0]:
+            for j in rng.integers(0, n, size=rng.integers(1, 4)):
+                b, sh = j >> 2, 2 * (j & 3)
+                packed[r, b] = (packed[r, b] & ~(3 << sh)) | (1 << sh)
+        y = bed.synth_phenotype(g, n_causal=20, pve=0.6, seed=17)
+        k, eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+        s, u = oracle.gwas_eigh_from_grm(k)
+        x = np.concatenate([np.ones((n, 1)), np.random.default_rng(4).normal(size=(n, 1))], axis=1)
+        nm = oracle.spectral_null_model(y, x, s, u)
+        mi, he, ho = oracle.row_counts(packed, n)
+        keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+        pk = np.ascontiguousarray(packed[keep])
+        maf_k = maf[keep]
+        flip_k = np.random.default_rng(9).random(int(keep.sum())) < 0.3
+        gd = oracle.decode_centered_block_f32(pk, n, flip_k, maf_k)
+        grot = oracle.rotate_block_f32(gd, nm.Dh)
+        ref = oracle_c.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, -5.0, 5.0, 50, 1e-2)
+        out = jxrs.lmm_reml_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh)
+        be, se, pe = _assoc_err(out, ref)
+        assert max(be, se) < TOL, (miss_frac, be, se, pe)
+        fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
+        fout = jxrs.fvlmm_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, math.log10(nm.lbd_null))
+        be, se, pe = _assoc_err(fout, fref)
+        assert max(be, se) < TOL, (miss_frac, be, se, pe)
+        # device pipeline route (what bench.py times): same rows through pipeline.scan_rows
+        p = pipeline.Panel(torch.from_numpy(pk).cuda(), n)
+        model = pipeline.SpectralModel(torch.from_numpy(nm.S).cuda(), torch.from_numpy(np.ascontiguousarray(nm.Dh.astype(np.float64))).cuda(), x, y)
+        rows = np.arange(pk.shape[0])
+        lut = stats.scan_lut_from_counts(maf_k, flip_k, p.counts(), n)
+        res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=-5.0, high=5.0, max_iter=50, tol=1e-2).cpu().numpy()
+        be, se, pe = _assoc_err(res, ref)
+        assert max(be, se) < TOL, (miss_frac, be, se, pe)
+
+
 def test_pipeline_end_to_end(oracle, oracle_c):
     import torch
     from janusx_amd import pipeline

@@ -126,10 +126,14 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
     """HBM read bytes per launch of a kernel from the committed PMC summary (profiles/r01d_pmc_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
     streaming reads). Returns None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")
-    try:
-        runs = json.load(open(path))["runs"][run]
-    except Exception:
+    runs = None
+    for tag in ("r01e", "r01d"):
+        try:
+            runs = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")))["runs"][run]
+            break
+        except Exception:
+            continue
+    if runs is None:
         return None
     for name, rec in runs.items():
         if name.startswith(kernel_prefix):
@@ -140,10 +144,14 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
 def pmc_mfma_util(kernel_substr):
     """MFMA-pipe utilisation of a kernel from the committed counter pass (profiles/r01c_pmc_mfma.json):
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_mfma.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except Exception:
+    kernels = None
+    for tag in ("r01e", "r01c"):
+        try:
+            kernels = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma.json")))["kernels"]
+            break
+        except Exception:
+            continue
+    if kernels is None:
         return None
     for name, rec in kernels.items():
         if kernel_substr in name:
@@ -290,6 +298,7 @@ def main():
         grm_tflops = kern["grm_flops"] / max(kern["grm_ms"], 1e-9) / 1e9
         rot_tflops = kern["rot_flops"] / max(kern["rot_ms"], 1e-9) / 1e9
         scan_gbs = kern["scan_bytes"] / max(kern["scan_ms"], 1e-9) / 1e6
+        symv_gbs = kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)
         res = {
             "metric": "SNPs/sec full -lmm (GRM+eig+scan)" if args.mode == "lmm" else "SNPs/sec full -fvlmm (GRM+eig+scan)",
             "value": value,
@@ -301,44 +310,58 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f16x2-split MFMA (f32 acc, f64 merge) + f64 REML",
+            "dtype": "f64 eigendecomposition and REML; f16 MFMA with f32 accumulation and f64 merge for GRM / rotation "
+                     "(exact integer operands, or fp16 hi+lo split of the f32 operands)",
             "data": "synthetic",
             "config": {"workload": f"synthetic HWE panel n={n} m={m} (BASELINE configs[1] shape x{world if args.scaling == 'weak' else 1} SNPs), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
                        "parallelism": f"snp-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "grm_f16x2_kernel",
-                         "achieved": grm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes("jx::grm_f16x2_kernel"),
-                         "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 correction, "
-                                         "n=5000 m=50000; algorithmic input = n*m/4 = 62.5 MB (payload re-read per tile "
-                                         "pair is served by L2/MALL)",
-                         "note": "algorithmic n(n+1)m flops per launch; the kernel issues 3 f16 MFMA products per "
-                                 "algorithmic product (hi*hi+hi*lo+lo*hi), so MFMA-pipe utilisation = 3*frac*(tile overhead)",
-                         "mfma_util_pmc": pmc_mfma_util("grm_f16x2_kernel"),
-                         "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
-                                           "profiles/r01c_pmc_mfma.json): the fraction of the dense f16 MFMA peak the "
-                                           "matrix pipes actually run at; frac above is the algorithmic share",
-                         "avg_launch_ms": kern["grm_ms"] / L},
+            # the dominant kernel by time (43 % of the GPU time of a step: one launch per column of the
+            # tridiagonalisation, profiles/*_kernel_stats.csv)
+            "roofline": {"bound": "hbm", "kernel": "sytrd_symv_kernel",
+                         "achieved": symv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": symv_gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes("jx::sytrd_symv_kernel"),
+                         "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
+                         "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per launch; "
+                                 "achieved = mean bytes / mean duration of the mid-panel launch of every 64-column panel "
+                                 "(HIP events on the launch stream); traffic = rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
+                                 "correction, mean over all launches of a step"},
+            "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
+                                                        "missing call among the selected samples, else the fp16 hi/lo "
+                                                        "three-product variant)",
+                             "achieved": grm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS,
+                             "traffic": pmc_traffic_bytes("jx::grm_f16x2_kernel"),
+                             "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
+                                             "correction, n=5000 m=50000; algorithmic input = n*m/4 = 62.5 MB (payload "
+                                             "re-read per tile pair is served by L2/MALL)",
+                             "note": "algorithmic n(n+1)m flops over the duration of the call (classification, affine "
+                                     "terms and MFMA kernels; HIP events); one f16 MFMA product per algorithmic product "
+                                     "on the exact variant, three on the split variant",
+                             "mfma_util_pmc": pmc_mfma_util("grm_f16x2_kernel"),
+                             "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
+                                               "profiles/*_pmc_mfma.json): the fraction of the dense f16 MFMA peak the "
+                                               "matrix pipes actually run at",
+                             "avg_launch_ms": kern["grm_ms"] / L},
             "roofline_rotate": {"bound": "mfma", "kernel": "rotate_f16x2_kernel", "achieved": rot_tflops,
                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS,
                                 "mfma_util_pmc": pmc_mfma_util("rotate_f16x2_kernel"),
+                                "note": "algorithmic 2 m n^2 flops; two f16 MFMA products per algorithmic product on "
+                                        "all-exact 128-row tiles (integer design rows x U hi/lo), three otherwise",
                                 "ms_per_step": kern["rot_ms"] / L},
-            "roofline_scan": {"bound": "hbm", "kernel": "lmm_scan_fast_kernel" if args.mode == "lmm" else "fvlmm_scan_kernel",
-                              "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel" if args.mode == "lmm" else "jx::fvlmm_scan_kernel",
-                                                           "fetch" if args.mode == "lmm" else "fetch_fv"),
-                              "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
-                              "ms_per_step": kern["scan_ms"] / L},
-            "roofline_eigh": {"bound": "hbm", "kernel": "sytrd_symv_kernel (the dominant kernel by time: one launch "
-                                                        "per column of the tridiagonalisation)",
-                              "achieved": (kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)),
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": (kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)) / HBM_PEAK_GBS,
-                              "traffic": pmc_traffic_bytes("jx::sytrd_symv_kernel"),
-                              "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
-                              "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per "
-                                      "launch; HIP events around the mid-panel launch of every 64-column panel"},
+            "roofline_scan": ({"bound": "f64 valu + lds", "kernel": "lmm_scan_fast_kernel",
+                               "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel", "fetch"),
+                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
+                               "note": "Brent over the exact per-SNP REML: ~12-17 objective evaluations per SNP, each a pass "
+                                       "over the n rotated samples with one f64 reciprocal per sample out of LDS-resident "
+                                       "s / X~ / y~; algorithmic bytes 4 n per SNP are read once -- the HBM fraction is "
+                                       "reported for completeness, the kernel is bound by f64 issue and LDS reads",
+                               "ms_per_step": kern["scan_ms"] / L} if args.mode == "lmm" else
+                              {"bound": "hbm", "kernel": "fvlmm_scan_kernel",
+                               "traffic": pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"),
+                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
+                               "ms_per_step": kern["scan_ms"] / L}),
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
             "null": {"lbd": null.lbd, "pve": null.pve},
             "device": {"cus": int(info[0]), "clock_khz": int(info[1]), "hbm_mib": int(info[2])},

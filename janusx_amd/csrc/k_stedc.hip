@@ -12,6 +12,7 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "jx_common.h"
@@ -44,11 +45,45 @@ __global__ void sd_tear_all_kernel(double *__restrict__ d, const double *__restr
     d[k] -= a;
 }
 
-// Leaf problems (<= SD_LEAF rows), one workgroup each: implicit-shift QL (EISPACK imtql2 / LAPACK dsteqr's QL branch)
-// with the eigenvector matrix resident in LDS.  Thread 0 runs the scalar recurrence of one sweep and leaves the plane
-// rotations in LDS; every thread then applies the sweep to its own row of Z.  d receives the eigenvalues (unsorted),
-// zpool + zoff[leaf] the eigenvectors (column-major nl x nl).
+// Leaf problems (<= SD_LEAF rows), one workgroup each (`sd_leaf_ql_kernel` below).  d receives the eigenvalues
+// (unsorted), zpool + zoff[leaf] the eigenvectors (column-major nl x nl).
 constexpr int SD_LEAF = 128;
+// lane-distributed vector of up to 128 doubles held by one wave: element i lives in lane i & 63 of x0 (i < 64) or x1
+struct LaneVec {
+    double x0, x1;
+    __device__ __forceinline__ double get(int i) const {   // i is wave-uniform
+        const double v = (i < 64) ? x0 : x1;
+        const int l = i & 63;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ void set(int i, double v, int lane) {   // every lane holds the same v
+        if (lane == (i & 63)) {
+            if (i < 64) x0 = v;
+            else x1 = v;
+        }
+    }
+};
+
+// 1 / sqrt(h), h > 0: hardware estimate + two Newton steps (full double precision)
+__device__ __forceinline__ double sd_rsqrt(double h) {
+    double y = __builtin_amdgcn_rsq(h);
+    double t = h * y;
+    double u = fma(-t, y, 1.0);
+    y = fma(0.5 * y, u, y);
+    t = h * y;
+    u = fma(-t, y, 1.0);
+    y = fma(0.5 * y, u, y);
+    return y;
+}
+
+// One workgroup per leaf (<= SD_LEAF = 128 rows): implicit-shift QL (LAPACK dsteqr's QL branch) with the eigenvector
+// block resident in LDS.  Wave 0 runs the scalar recurrence of a sweep: d and e live in its registers for the whole
+// solve (lane-distributed, `LaneVec`), every lane executes the same recurrence and the lane that owns an element
+// captures its new value, so the chain never waits on LDS; plane rotations use 1/sqrt(f^2 + g^2) (rsq + Newton)
+// instead of a square root followed by two divisions.  The rotations of the sweep go to LDS, then every thread
+// applies the sweep to its own row of Z.
 __global__ __launch_bounds__(256) void sd_leaf_ql_kernel(double *__restrict__ dg, const double *__restrict__ eg,
                                                          const int *__restrict__ off, const int *__restrict__ len,
                                                          const int64_t *__restrict__ zoff, double *__restrict__ zpool,
@@ -58,87 +93,123 @@ __global__ __launch_bounds__(256) void sd_leaf_ql_kernel(double *__restrict__ dg
     const int nl = len[leaf];
     const int g0 = off[leaf];
     double *z = lds;                       // z[i * nl + k] = Z(k, i)
-    double *d = lds + (size_t)nl * nl;
-    double *e = d + nl;
-    double *cs = e + nl;                   // (c_i, s_i) pairs
+    double *cs = lds + (size_t)nl * nl;    // (c_i, s_i) pairs
     __shared__ int sh_m, sh_lo;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     for (int t = tid; t < nl * nl; t += 256) z[t] = 0.0;
     __syncthreads();
-    if (tid < nl) {
-        z[tid * nl + tid] = 1.0;
-        d[tid] = dg[g0 + tid];
-        e[tid] = (tid < nl - 1) ? eg[g0 + tid] : 0.0;
+    if (tid < nl) z[tid * nl + tid] = 1.0;
+    LaneVec d, e, cc, ss;
+    d.x0 = d.x1 = e.x0 = e.x1 = 0.0;
+    cc.x0 = cc.x1 = ss.x0 = ss.x1 = 0.0;
+    if (tid < 64) {
+        if (lane < nl) d.x0 = dg[g0 + lane];
+        if (lane + 64 < nl) d.x1 = dg[g0 + lane + 64];
+        if (lane < nl - 1) e.x0 = eg[g0 + lane];
+        if (lane + 64 < nl - 1) e.x1 = eg[g0 + lane + 64];
     }
     __syncthreads();
     const double eps = 2.220446049250313e-16;
     for (int l = 0; l < nl; ++l) {
         for (int iter = 0;; ++iter) {
-            if (tid == 0) {
-                int m = l;
-                for (; m < nl - 1; ++m) {
-                    const double dd = fabs(d[m]) + fabs(d[m + 1]);
-                    if (fabs(e[m]) <= eps * dd) break;
+            if (tid < 64) {
+                // first m >= l with a negligible e[m] (m = nl - 1 when there is none)
+                int m;
+                {
+                    // d[k + 1] for this lane's two elements
+                    double dn0 = __shfl_down(d.x0, 1, 64), dn1 = __shfl_down(d.x1, 1, 64);
+                    const double d1first = d.get(64 < nl ? 64 : 0);
+                    if (lane == 63) dn0 = d1first;
+                    const int k0 = lane, k1 = lane + 64;
+                    const bool t0 = k0 >= l && k0 < nl - 1 && fabs(e.x0) <= eps * (fabs(d.x0) + fabs(dn0));
+                    const bool t1 = k1 >= l && k1 < nl - 1 && fabs(e.x1) <= eps * (fabs(d.x1) + fabs(dn1));
+                    const unsigned long long b0 = __ballot(t0), b1 = __ballot(t1);
+                    if (b0) m = __builtin_ctzll(b0);
+                    else if (b1) m = 64 + __builtin_ctzll(b1);
+                    else m = nl - 1;
                 }
-                sh_m = m;
-                sh_lo = m;   // first rotation index that is valid (rotations cover [sh_lo, m-1])
+                int lo = m;
                 if (m != l) {
                     if (iter >= 60) {
-                        *err = 1;
-                        sh_m = l;   // give up on this eigenvalue
+                        if (lane == 0) *err = 1;
+                        m = l;   // give up on this eigenvalue
+                        lo = l;
                     } else {
-                        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                        const double dl = d.get(l), el = e.get(l);
+                        double g = (d.get(l + 1) - dl) / (2.0 * el);
                         double r = sqrt(g * g + 1.0);
-                        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
-                        double s = 1.0, c = 1.0, p = 0.0;
+                        g = d.get(m) - dl + el / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                        double sn = 1.0, c = 1.0, p = 0.0;
                         int i = m - 1;
                         bool underflow = false;
                         for (; i >= l; --i) {
-                            double f = s * e[i];
-                            const double b = c * e[i];
-                            r = sqrt(f * f + g * g);
-                            e[i + 1] = r;
-                            if (r == 0.0) {
-                                d[i + 1] -= p;
-                                e[m] = 0.0;
+                            const double ei = e.get(i), di = d.get(i), di1 = d.get(i + 1);
+                            const double f = sn * ei;
+                            const double b = c * ei;
+                            const double h = f * f + g * g;
+                            if (h == 0.0) {
+                                e.set(i + 1, 0.0, lane);
+                                d.set(i + 1, di1 - p, lane);
+                                e.set(m, 0.0, lane);
                                 underflow = true;
                                 break;
                             }
-                            s = f / r;
-                            c = g / r;
-                            g = d[i + 1] - p;
-                            r = (d[i] - g) * s + 2.0 * c * b;
-                            p = s * r;
-                            d[i + 1] = g + p;
+                            const double rinv = sd_rsqrt(h);
+                            e.set(i + 1, h * rinv, lane);
+                            sn = f * rinv;
+                            c = g * rinv;
+                            g = di1 - p;
+                            r = (di - g) * sn + 2.0 * c * b;
+                            p = sn * r;
+                            d.set(i + 1, g + p, lane);
                             g = c * r - b;
-                            cs[2 * i] = c;
-                            cs[2 * i + 1] = s;
+                            cc.set(i, c, lane);
+                            ss.set(i, sn, lane);
                         }
-                        sh_lo = i + 1;
+                        lo = i + 1;
                         if (!underflow) {
-                            d[l] -= p;
-                            e[l] = g;
-                            e[m] = 0.0;
+                            d.set(l, d.get(l) - p, lane);
+                            e.set(l, g, lane);
+                            e.set(m, 0.0, lane);
+                        }
+                        // rotations [lo, m-1] of this sweep -> LDS
+                        if (lane >= lo && lane < m) {
+                            cs[2 * lane] = cc.x0;
+                            cs[2 * lane + 1] = ss.x0;
+                        }
+                        if (lane + 64 >= lo && lane + 64 < m) {
+                            cs[2 * (lane + 64)] = cc.x1;
+                            cs[2 * (lane + 64) + 1] = ss.x1;
                         }
                     }
+                }
+                if (lane == 0) {
+                    sh_m = m;
+                    sh_lo = lo;
                 }
             }
             __syncthreads();
             const int m = sh_m, lo = sh_lo;
             if (m == l) break;
-            if (tid < nl) {
+            if (tid < nl && lo < m) {
+                // the value carried from rotation i + 1 to rotation i stays in a register (no LDS write -> read chain)
+                double f = z[m * nl + tid];
                 for (int i = m - 1; i >= lo; --i) {
                     const double c = cs[2 * i], sn = cs[2 * i + 1];
-                    const double f = z[(i + 1) * nl + tid];
                     const double zi = z[i * nl + tid];
                     z[(i + 1) * nl + tid] = sn * zi + c * f;
-                    z[i * nl + tid] = c * zi - sn * f;
+                    f = c * zi - sn * f;
                 }
+                z[lo * nl + tid] = f;
             }
             __syncthreads();
         }
     }
-    if (tid < nl) dg[g0 + tid] = d[tid];
+    if (tid < 64) {
+        if (lane < nl) dg[g0 + lane] = d.x0;
+        if (lane + 64 < nl) dg[g0 + lane + 64] = d.x1;
+    }
     double *zo = zpool + zoff[leaf];
     for (int t = tid; t < nl * nl; t += 256) zo[t] = z[t];
 }
@@ -432,6 +503,18 @@ static size_t dc_arena_bytes(int n) {
     return sizeof(double) * (2 * nn + 256 * (size_t)n) + (64u << 10);
 }
 
+static std::chrono::steady_clock::time_point g_dc_t0;
+static bool g_dc_trace = false;
+// JXGPU_EIGH_TRACE=1: time line of the merges of the top three levels (synchronises the stream at every mark)
+#define DC_MARK(what)                                                                                              \
+    do {                                                                                                           \
+        if (g_dc_trace && C.depth <= 2) {                                                                          \
+            (void)hipStreamSynchronize(st);                                                                        \
+            fprintf(stderr, "[jxgpu stedc] depth %d n %5d %-14s at %7.2f ms\n", C.depth, n, what,                   \
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_dc_t0).count()); \
+        }                                                                                                          \
+    } while (0)
+
 #define SD_TAKE(buf, bytes)                                                        \
     do {                                                                           \
         (buf).p = C.ar.take(bytes);                                                \
@@ -498,7 +581,8 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     {
         std::vector<double> w1, w2;
         const int child_depth = C.depth + 1;
-        if (C.depth < C.par_depth && n >= 1024) {
+        static const int par_min_n = getenv("JXGPU_STEDC_PARMIN") ? atoi(getenv("JXGPU_STEDC_PARMIN")) : 1024;
+        if (C.depth < C.par_depth && n >= par_min_n) {
             // the halves are independent: the second one gets its own host thread, stream, rocBLAS handle and arena
             // slice (rocSOLVER's leaf solver is a chain of latency-bound launches, two of them overlap almost fully)
             const size_t s1 = dc_arena_bytes(k1), s2 = dc_arena_bytes(k2);
@@ -574,6 +658,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         std::copy(w1.begin(), w1.end(), D.begin());
         std::copy(w2.begin(), w2.end(), D.begin() + k1);
     }
+    DC_MARK("children done");
     ABuf dz;
     SD_TAKE(dz, sizeof(double) * (size_t)n);
     hipLaunchKernelGGL(sd_extract_z_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q1.as<double>(), k1,
@@ -582,6 +667,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     JX_HIP(hipMemcpyAsync(z.data(), dz.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
     const double rho = 2.0 * absrho;
+    DC_MARK("z on host");
 
     // ---- deflation (dlaed2) ---------------------------------------------------------------------------
     std::vector<int> order((size_t)n);
@@ -688,6 +774,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         SD_TAKE(dinv, sizeof(double) * K);
         JX_HIP(hipMemcpyAsync(dk.p, C.stage(hk), sizeof(double) * K, hipMemcpyHostToDevice, st));
         JX_HIP(hipMemcpyAsync(zk.p, C.stage(hz), sizeof(double) * K, hipMemcpyHostToDevice, st));
+        DC_MARK("deflated");
         const int gw = (K + SD_WAVES - 1) / SD_WAVES;
         hipLaunchKernelGGL(sd_secular_kernel, dim3(gw), dim3(SD_THREADS), 0, st, dk.as<double>(), zk.as<double>(), K, rho,
                            dtau.as<double>(), dorg.as<int>(), dlam.as<double>());
@@ -812,6 +899,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         }
     }
     if (side.p) JX_HIP(hipStreamSynchronize(st));   // the side buffer (hipMalloc) is released on return
+    DC_MARK("merged");
     C.ar.off = mark;
     h_w.swap(w);
     return 0;
@@ -832,6 +920,8 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
     ScratchLease arena;
     const size_t bytes = dc_arena_bytes(n);
     if (arena.take(1, bytes)) return 1;
+    g_dc_trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
+    g_dc_t0 = std::chrono::steady_clock::now();
     DcCtx C;
     C.h = h;
     C.st = st;
@@ -912,6 +1002,9 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
         JX_HIP(hipMemcpyAsync(&herr, derr.p, sizeof(int), hipMemcpyDeviceToHost, st));
         JX_HIP(hipStreamSynchronize(st));
         if (herr) return fail("stedc: the QL leaf solver did not converge");
+        if (g_dc_trace)
+            fprintf(stderr, "[jxgpu stedc] leaves done (%d) at %7.2f ms\n", nleaf,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_dc_t0).count());
         C.leaf_off = &leaf_off;
         C.leaf_zoff = &leaf_zoff;
         C.zpool = zpool.as<double>();

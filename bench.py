@@ -325,7 +325,7 @@ def main():
                          "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
                          "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per launch; "
                                  "achieved = mean bytes / mean duration of the mid-panel launch of every 64-column panel "
-                                 "(HIP events on the launch stream); traffic = rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
+                                 "(HIP start/stop events bound to the dispatch, hipExtLaunchKernelGGL, on the launch stream); traffic = rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
                                  "correction, mean over all launches of a step"},
             "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
                                                         "missing call among the selected samples, else the fp16 hi/lo "

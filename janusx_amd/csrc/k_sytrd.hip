@@ -16,6 +16,7 @@
 //   sytrd_update_kernel S(j): row-parallel w (alpha from v'Tv and (V'v).(W'v), no extra pass), then the
 //                            update of column j+1 and its norm for the next reflector.
 // Accumulators are double-buffered by column parity so no launch zeroes what a concurrent block still reads.
+#include <hip/hip_ext.h>
 #include <rocblas/rocblas.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -468,7 +469,9 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     // (one pair per panel = every 64th launch, uniformly spaced over the trailing sizes)
     static std::vector<hipEvent_t> ev;
     const int npanels = (n - 1 + TD_NB - 1) / TD_NB;
-    while ((int)ev.size() < 2 * npanels) {
+    // + 8 events for four empty back-to-back pairs (reported under JXGPU_EIGH_TRACE: what a hipEventRecord bracket
+    // would add to a sample; the samples themselves use hipExtLaunchKernelGGL's dispatch-bound events)
+    while ((int)ev.size() < 2 * npanels + 8) {
         hipEvent_t e;
         JX_HIP(hipEventCreate(&e));
         ev.push_back(e);
@@ -498,11 +501,15 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             if (ktiles > 64) ktiles = 64;
             const int nstrips = side * ((side + ktiles - 1) / ktiles);
             const bool sample = (i == pw / 2);
-            if (sample) JX_HIP(hipEventRecord(ev[2 * nsamp], st));
-            hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0, ktiles,
-                               nstrips);
             if (sample) {
-                JX_HIP(hipEventRecord(ev[2 * nsamp + 1], st));
+                // start / stop events bound to this dispatch's own begin / end time stamps (what rocprofv3 reports)
+                hipExtLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st,
+                                      ev[2 * nsamp], ev[2 * nsamp + 1], 0, P, j, j0, ktiles, nstrips);
+            } else {
+                hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
+                                   ktiles, nstrips);
+            }
+            if (sample) {
                 samp_bytes += 4.0 * (double)nt * (double)nt + 4.0 * (double)nt;  // lower triangle incl. diagonal, f64
                 ++nsamp;
             }
@@ -532,13 +539,26 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     }
     hipLaunchKernelGGL(sytrd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
     JX_LAUNCH_CHECK();
+    for (int k = 0; k < 4; ++k) {
+        JX_HIP(hipEventRecord(ev[2 * npanels + 2 * k], st));
+        JX_HIP(hipEventRecord(ev[2 * npanels + 2 * k + 1], st));
+    }
     JX_HIP(hipStreamSynchronize(st));  // workspace is freed on return
-    double samp_ms = 0.0;
+    double samp_ms = 0.0, pair_ms = 0.0;
     for (int k = 0; k < nsamp; ++k) {
         float ms = 0.f;
         JX_HIP(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
         samp_ms += ms;
     }
+    for (int k = 0; k < 4; ++k) {
+        float ms = 0.f;
+        JX_HIP(hipEventElapsedTime(&ms, ev[2 * npanels + 2 * k], ev[2 * npanels + 2 * k + 1]));
+        pair_ms += ms;
+    }
+    pair_ms /= 4.0;
+    if (getenv("JXGPU_EIGH_TRACE"))
+        fprintf(stderr, "[jxgpu sytrd n=%d] symv samples: %d, mean %.2f us (dispatch-bound events), empty hipEventRecord pair %.2f us\n", n, nsamp,
+                nsamp ? samp_ms / nsamp * 1e3 : 0.0, pair_ms * 1e3);
     g_last_ms[2] = nsamp ? (float)(samp_ms / nsamp) : 0.f;
     g_last_ms[3] = nsamp ? (float)(samp_bytes / nsamp / 1e6) : 0.f;
     return 0;

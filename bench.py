@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
+F64_VALU_PEAK_TFLOPS = 78.6    # f64 vector peak (public MI355X spec; 256 CUs x 128 flop/clk x 2.4 GHz)
 
 
 def synth_panel_gpu(n, m, seed, device, m_offset=0, missing_rate=0.0):
@@ -135,10 +136,13 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
             continue
     if runs is None:
         return None
-    for name, rec in runs.items():
-        if name.startswith(kernel_prefix):
-            return 2.0 * rec["mean_KB"] * 1024.0
-    return None
+    best = None
+    for name, rec in runs.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
+        if kernel_prefix in name:
+            b = 2.0 * rec["mean_KB"] * 1024.0
+            if best is None or b > best:
+                best = b
+    return best
 
 
 def pmc_mfma_util(kernel_substr):
@@ -249,7 +253,13 @@ def main():
         rows = np.nonzero(keep)[0]
         lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
         tm = pl.StageTimes()
-        out = pl.scan_rows(panel, model, rows, lut, args.mode, max_iter=30, tol=1e-2, times=tm)
+        out = pl.scan_rows(panel, model, rows, lut, args.mode, max_iter=30, tol=1e-2, times=tm,
+                           return_evals=(args.mode == "lmm"))
+        if args.mode == "lmm":
+            out, evals = out
+            n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
+        else:
+            n_evals = 0.0
         torch.cuda.synchronize()
         t5 = time.perf_counter()
         if record:
@@ -265,6 +275,10 @@ def main():
             kern["rot_flops"] += 2.0 * len(rows) * float(n) * n
             kern["scan_ms"] += tm.t.get("scan", 0.0) * 1e3
             kern["scan_bytes"] += 4.0 * n * len(rows)
+            dim = x.shape[1] + 1
+            # (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) flops per SNP, B = Brent evaluations
+            kern["scan_flops"] = kern.get("scan_flops", 0.0) + (n_evals + len(rows)) * n * (1.5 * dim * (dim + 1) + 5 * dim + 8)
+            kern["scan_evals"] = kern.get("scan_evals", 0.0) + n_evals / max(1, len(rows))
             kern["launches"] += 1
         return len(rows), len(grows), model.null, out
 
@@ -350,13 +364,18 @@ def main():
                                 "note": "algorithmic 2 m n^2 flops; two f16 MFMA products per algorithmic product on "
                                         "all-exact 128-row tiles (integer design rows x U hi/lo), three otherwise",
                                 "ms_per_step": kern["rot_ms"] / L},
-            "roofline_scan": ({"bound": "f64 valu + lds", "kernel": "lmm_scan_fast_kernel",
+            "roofline_scan": ({"bound": "f64 valu", "kernel": "lmm_scan_fast_kernel",
+                               "achieved": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9,
+                               "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,
+                               "brent_evals_per_snp": kern.get("scan_evals", 0.0) / L,
+                               "hbm_gbs": scan_gbs,
                                "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel", "fetch"),
-                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
-                               "note": "Brent over the exact per-SNP REML: ~12-17 objective evaluations per SNP, each a pass "
-                                       "over the n rotated samples with one f64 reciprocal per sample out of LDS-resident "
-                                       "s / X~ / y~; algorithmic bytes 4 n per SNP are read once -- the HBM fraction is "
-                                       "reported for completeness, the kernel is bound by f64 issue and LDS reads",
+                               "note": "Brent over the exact per-SNP REML: every objective evaluation is a pass over the n "
+                                       "rotated samples (one f64 reciprocal per sample, operands s / X~ / y~ resident in "
+                                       "LDS); algorithmic flops per SURVEY 8(d): (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) "
+                                       "per SNP with the measured B; peak = 78.6 TFLOP/s f64 vector (public MI355X "
+                                       "figure); the 4 n bytes per SNP are read once (hbm_gbs), HBM is not the bound",
                                "ms_per_step": kern["scan_ms"] / L} if args.mode == "lmm" else
                               {"bound": "hbm", "kernel": "fvlmm_scan_kernel",
                                "traffic": pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"),

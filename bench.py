@@ -198,6 +198,7 @@ def main():
     distributed = world > 1 or bool(os.environ.get("JXGPU_BENCH_FORCE_DIST"))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")   # only reached without a launcher (JXGPU_BENCH_FORCE_DIST)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.n
@@ -392,7 +393,14 @@ def main():
                                                    os.cpu_count() or 1)
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res))
+        # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it first so that the
+        # JSON line is the last line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()
 

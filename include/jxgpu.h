@@ -219,6 +219,11 @@ int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t 
                     const float *d_lut, const double *d_alpha, double *d_out, void *stream);
 int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                    const float *d_lut, const double *d_beta, double *d_out, void *stream);
+/* jxg_packed_tdot with the vector rounded to f32 and f32 partial sums inside a 128-sample tile (the Z u half of the PCG
+ * operator of `rrblup_pcg_bed`, whose vectors are f32: src/stats/rrblup.rs:1220-1372): bit-plane table form, three LDS
+ * lookups per four genotypes. */
+int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                        const float *d_lut, const double *d_u, double *d_out, void *stream);
 
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,

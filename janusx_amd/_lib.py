@@ -61,6 +61,7 @@ SIGNATURES = {
     "jx_ml_loglike_null": [c_p, c_p, c_p, c_i, c_i, c_d, c_p],
     "jxg_gblup_fit": [c_p, c_i, c_d, c_p, c_d, c_d, c_d, c_i, c_p, c_p, c_p],
     "jxg_packed_tdot": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
+    "jxg_packed_tdot_f32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "jxg_packed_dot": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "jxg_cross_dot": [c_p, c_i, c_l, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],

@@ -251,6 +251,78 @@ __global__ __launch_bounds__(256) void packed_tdot_kernel(const uint8_t *__restr
     if (v != 0.0) unsafeAtomicAdd(&out[r], v);
 }
 
+
+// out[r] += sum_i lut[r][code(r,i)] * u[i] with u rounded to f32 (the PCG vectors of rrblup_pcg_bed are f32), bit-plane
+// form: per record the lo / hi / both bit planes of the 2-bit codes index ONE 16-entry partial-sum table per sample
+// quad (T[q][x] = sum_k bit_2k(x) u[4q+k], x a 0x55-masked byte), i.e. three LDS lookups + three f32 adds per four
+// genotypes instead of a decode and an f64 select-add per genotype:
+//   S_lo = sum u [b0], S_hi = sum u [b1], S_b = sum u [b0 & b1]  ->  missing = S_lo - S_b, het = S_hi - S_b, hom = S_b.
+// Partial sums stay f32 inside a 128-sample tile (the reference's GEMV is f32 throughout), tiles merge in f64.
+// grid (ceil(nrows / (256 * PT_RPT)), ntiles), 256 threads, thread = SNP.
+constexpr int PT_RPT = 4;
+constexpr int PT_STRIDE = 86;   // 0x55 + 1 table entries per quad
+__global__ __launch_bounds__(256) void packed_tdot_f32_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                              const int32_t *__restrict__ rows, int nrows,
+                                                              const float *__restrict__ lut,
+                                                              const double *__restrict__ u, int n,
+                                                              double *__restrict__ out) {
+    __shared__ float tab[32 * PT_STRIDE];
+    __shared__ float u_sh[128];
+    __shared__ float u_tot;
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const int i = tile * 128 + tid;
+        u_sh[tid] = (i < n) ? (float)u[i] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * PT_STRIDE; e += 256) {
+        const int q = e / PT_STRIDE, x = e - q * PT_STRIDE;
+        float t = 0.0f;
+        if ((x & 0xAA) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((x >> (2 * k)) & 1) t += u_sh[4 * q + k];
+        }
+        tab[e] = t;
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 128; ++k) t += (double)u_sh[k];
+        u_tot = (float)t;
+    }
+    __syncthreads();
+    const float utot = u_tot;
+#pragma unroll 1
+    for (int rr = 0; rr < PT_RPT; ++rr) {
+        const int r = (blockIdx.x * PT_RPT + rr) * 256 + tid;
+        if (r >= nrows) break;
+        const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+        const uint4 *pp = reinterpret_cast<const uint4 *>(p32 + ((int64_t)tile * m_total + rec) * 32);
+        const uint4 w0 = pp[0], w1 = pp[1];
+        const uint32_t words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float slo = 0.0f, shi = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const uint32_t xl = words[d] & 0x55555555u;
+            const uint32_t xh = (words[d] >> 1) & 0x55555555u;
+            const uint32_t xb = xl & xh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float *t = tab + (4 * d + k) * PT_STRIDE;
+                slo += t[(xl >> (8 * k)) & 0xFFu];
+                shi += t[(xh >> (8 * k)) & 0xFFu];
+                sb += t[(xb >> (8 * k)) & 0xFFu];
+            }
+        }
+        const double c3 = (double)sb, c2 = (double)shi - c3, c1 = (double)slo - c3;
+        const double c0 = (double)utot - c1 - c2 - c3;
+        const float *l = lut + (int64_t)r * 4;
+        const double v = (double)l[0] * c0 + (double)l[1] * c1 + (double)l[2] * c2 + (double)l[3] * c3;
+        if (v != 0.0) unsafeAtomicAdd(&out[r], v);
+    }
+}
+
 // out[i] += sum_r lut[r][code(r,i)] * beta[r]  (`predict_from_effect_stream`, src/stats/gblup.rs:1037-1103; the
 // Z v half of the PCG operator).  grid (ntiles, row slices of PD_SLICE); 128 threads x 2 row halves; records and
 // the per-row weight tables w[r][c] = lut[r][c] * beta[r] are staged through LDS 64 rows at a time.
@@ -353,6 +425,18 @@ extern "C" int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, con
     JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)nrows, st));
     dim3 grid((nrows + 255) / 256, (n + 127) / 128);
     hipLaunchKernelGGL(packed_tdot_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_alpha, n,
+                       d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                   const float *d_lut, const double *d_u, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)nrows, st));
+    dim3 grid((nrows + 256 * PT_RPT - 1) / (256 * PT_RPT), (n + 127) / 128);
+    hipLaunchKernelGGL(packed_tdot_f32_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_u, n,
                        d_out);
     JX_LAUNCH_CHECK();
     return 0;

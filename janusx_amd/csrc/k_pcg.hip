@@ -264,7 +264,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;   // Z'p
             hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
             JX_LAUNCH_CHECK();
-            if (jxg_packed_tdot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
+            if (jxg_packed_tdot_f32(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
             JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
             hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);
             JX_LAUNCH_CHECK();

@@ -25,7 +25,8 @@ def main():
     om = torch.empty(m, device=dev, dtype=torch.float64)
     payload = n * m / 4.0
     for name, fn in (("packed_dot  (Z'v -> n)", lambda: lib().jxg_packed_dot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), beta.data_ptr(), on.data_ptr(), st)),
-                     ("packed_tdot (Z u -> m)", lambda: lib().jxg_packed_tdot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))):
+                     ("packed_tdot (Z u -> m)", lambda: lib().jxg_packed_tdot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st)),
+                     ("packed_tdot_f32 (Z u, bit-plane tables)", lambda: lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))):
         for _ in range(2):
             check(fn())
         torch.cuda.synchronize()
@@ -44,6 +45,11 @@ def main():
     check(lib().jxg_packed_tdot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))
     torch.cuda.synchronize()
     print("tdot slice err", float((z @ alpha - om[:256]).abs().max()))
+    a32 = alpha.to(torch.float32).to(torch.float64)
+    check(lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))
+    torch.cuda.synchronize()
+    ref = z @ a32
+    print("tdot_f32 slice rel err", float((ref - om[:256]).abs().max() / ref.abs().max()))
     if len(sys.argv) > 3:
         from janusx_amd import janusx as jxrs
         pk = packed.cpu().numpy()

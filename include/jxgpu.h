@@ -224,6 +224,15 @@ int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *
  * lookups per four genotypes. */
 int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                         const float *d_lut, const double *d_u, double *d_out, void *stream);
+/* The Z'p half of the same operator from a sample-major image of the payload: `jxg_p32_transpose` builds
+ * t32[snp_tile][sample][32 B] (128 consecutive SNPs of the row list per record; `jxg_t32_bytes` bytes) once per solve,
+ * `jxg_packed_dot_t32` then evaluates d_out[i] = sum_r f32(lut[r][code] * f32(beta[r])) with the same bit-plane tables
+ * (three lookups per four genotypes); d_work needs 16 * nrows + 16 bytes. */
+int64_t jxg_t32_bytes(int n, int nrows);
+int jxg_p32_transpose(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, uint8_t *d_t32,
+                      void *stream);
+int jxg_packed_dot_t32(const uint8_t *d_t32, int n, int nrows, const float *d_lut, const double *d_beta, void *d_work,
+                       double *d_out, void *stream);
 
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,

@@ -62,6 +62,9 @@ SIGNATURES = {
     "jxg_gblup_fit": [c_p, c_i, c_d, c_p, c_d, c_d, c_d, c_i, c_p, c_p, c_p],
     "jxg_packed_tdot": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "jxg_packed_tdot_f32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
+    "jxg_t32_bytes": [c_i, c_i],
+    "jxg_p32_transpose": [c_p, c_l, c_i, c_p, c_i, c_p, c_p],
+    "jxg_packed_dot_t32": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "jxg_packed_dot": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "jxg_cross_dot": [c_p, c_i, c_l, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
@@ -79,7 +82,8 @@ SIGNATURES = {
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
 }
-_RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64}
+_RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
+             "jxg_t32_bytes": C.c_int64}
 
 
 def lib():

@@ -276,15 +276,14 @@ __global__ __launch_bounds__(256) void packed_tdot_f32_kernel(const uint8_t *__r
         u_sh[tid] = (i < n) ? (float)u[i] : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < 32 * PT_STRIDE; e += 256) {
-        const int q = e / PT_STRIDE, x = e - q * PT_STRIDE;
+    for (int e = tid; e < 32 * 16; e += 256) {   // the 16 valid (0x55-pattern) entries of every quad
+        const int q = e >> 4, b = e & 15;
+        const int x = (b & 1) | ((b & 2) << 1) | ((b & 4) << 2) | ((b & 8) << 3);
         float t = 0.0f;
-        if ((x & 0xAA) == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((x >> (2 * k)) & 1) t += u_sh[4 * q + k];
-        }
-        tab[e] = t;
+        for (int k = 0; k < 4; ++k)
+            if ((b >> k) & 1) t += u_sh[4 * q + k];
+        tab[q * PT_STRIDE + x] = t;
     }
     if (tid == 0) {
         double t = 0.0;
@@ -320,6 +319,140 @@ __global__ __launch_bounds__(256) void packed_tdot_f32_kernel(const uint8_t *__r
         const float *l = lut + (int64_t)r * 4;
         const double v = (double)l[0] * c0 + (double)l[1] * c1 + (double)l[2] * c2 + (double)l[3] * c3;
         if (v != 0.0) unsafeAtomicAdd(&out[r], v);
+    }
+}
+
+// ---- sample-major image of the payload for the Z'p half: t32[snp_tile][sample][32 B], 128 consecutive SNPs (of the
+// row list) of one sample per record -- the transpose of the P32 image, built once per solve.
+// grid (snp tiles, sample tiles), 128 threads: thread j gathers the codes of sample j from the 128 staged records.
+__global__ __launch_bounds__(128) void p32_transpose_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                            const int32_t *__restrict__ rows, int nrows, int n,
+                                                            uint8_t *__restrict__ t32) {
+    __shared__ __attribute__((aligned(16))) uint32_t rec_sh[128][9];   // 8 payload dwords + 1 pad (bank spread)
+    const int st = blockIdx.x, tile = blockIdx.y;
+    const int j = threadIdx.x;
+    {
+        const int r = st * 128 + j;
+        uint4 a = make_uint4(0x55555555u, 0x55555555u, 0x55555555u, 0x55555555u), b = a;
+        if (r < nrows) {
+            const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+            const uint4 *pp = reinterpret_cast<const uint4 *>(p32 + ((int64_t)tile * m_total + rec) * 32);
+            a = pp[0];
+            b = pp[1];
+        }
+        rec_sh[j][0] = a.x; rec_sh[j][1] = a.y; rec_sh[j][2] = a.z; rec_sh[j][3] = a.w;
+        rec_sh[j][4] = b.x; rec_sh[j][5] = b.y; rec_sh[j][6] = b.z; rec_sh[j][7] = b.w;
+    }
+    __syncthreads();
+    const int dw = j >> 4, sh = 2 * (j & 15);
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w |= ((rec_sh[16 * d + k][dw] >> sh) & 3u) << (2 * k);
+        o[d] = w;
+    }
+    const int i = tile * 128 + j;
+    if (i < n) {
+        uint4 *dst = reinterpret_cast<uint4 *>(t32 + ((int64_t)st * n + i) * 32);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// per-SNP bit-plane weights of w_r[code] = lut[r][code] * p_r (f32 product, as the reference's f32 decode x f32 weight):
+// w[code] = w0 + b0 (w1 - w0) + b1 (w2 - w0) + b0 b1 (w3 - w2 - w1 + w0);  wq[r] = (d_lo, d_hi, d_both, w0); sum w0 -> w0sum
+__global__ __launch_bounds__(256) void pcg_plane_weights_kernel(const float *__restrict__ lut,
+                                                                const double *__restrict__ p, int nrows,
+                                                                float4 *__restrict__ wq, double *__restrict__ w0sum) {
+    __shared__ double sh[4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    double w0d = 0.0;
+    if (r < nrows) {
+        const float pr = (float)p[r];
+        const float w0 = lut[(int64_t)r * 4 + 0] * pr, w1 = lut[(int64_t)r * 4 + 1] * pr;
+        const float w2 = lut[(int64_t)r * 4 + 2] * pr, w3 = lut[(int64_t)r * 4 + 3] * pr;
+        const double d3 = ((double)w3 - (double)w2) - (double)w1 + (double)w0;
+        wq[r] = make_float4(w1 - w0, w2 - w0, (float)d3, w0);
+        w0d = (double)w0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w0d += __shfl_xor(w0d, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w0d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = sh[0] + sh[1] + sh[2] + sh[3];
+        if (t != 0.0) unsafeAtomicAdd(w0sum, t);
+    }
+}
+
+// out[i] += sum_r w_r[code(r,i)] from the sample-major image: per 128-SNP tile three 16-entry tables per SNP quad
+// (lo / hi / both planes), three LDS lookups per four genotypes, f32 partial sums inside a tile, f64 across tiles.
+// grid (ceil(n / (256 * PD_SPT)), tile slices), 256 threads, thread = sample (PD_SPT samples each).
+constexpr int PD_SPT = 4;
+__global__ __launch_bounds__(256) void packed_dot_t32_kernel(const uint8_t *__restrict__ t32, int nrows, int n,
+                                                             const float4 *__restrict__ wq,
+                                                             const double *__restrict__ w0sum, int tiles_per_slice,
+                                                             double *__restrict__ out) {
+    __shared__ float tab[3][32 * PT_STRIDE];
+    const int tid = threadIdx.x;
+    const int nst = (nrows + 127) / 128;
+    const int st0 = blockIdx.y * tiles_per_slice;
+    const int st1 = (st0 + tiles_per_slice < nst) ? (st0 + tiles_per_slice) : nst;
+    double acc[PD_SPT];
+#pragma unroll
+    for (int s = 0; s < PD_SPT; ++s) acc[s] = 0.0;
+    const int i0 = blockIdx.x * 256 * PD_SPT + tid;
+    for (int st = st0; st < st1; ++st) {
+        __syncthreads();
+        for (int e = tid; e < 3 * 32 * 16; e += 256) {
+            const int pl = e >> 9, q = (e >> 4) & 31, b = e & 15;
+            const int x = (b & 1) | ((b & 2) << 1) | ((b & 4) << 2) | ((b & 8) << 3);
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = st * 128 + 4 * q + k;
+                if (((b >> k) & 1) && r < nrows) {
+                    const float4 w = wq[r];
+                    t += (pl == 0) ? w.x : (pl == 1 ? w.y : w.z);
+                }
+            }
+            tab[pl][q * PT_STRIDE + x] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < PD_SPT; ++s) {
+            const int i = i0 + 256 * s;
+            if (i >= n) continue;
+            const uint4 *pp = reinterpret_cast<const uint4 *>(t32 + ((int64_t)st * n + i) * 32);
+            const uint4 w0 = pp[0], w1 = pp[1];
+            const uint32_t words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float f = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const uint32_t xl = words[d] & 0x55555555u;
+                const uint32_t xh = (words[d] >> 1) & 0x55555555u;
+                const uint32_t xb = xl & xh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int o = (4 * d + k) * PT_STRIDE;
+                    f += tab[0][o + ((xl >> (8 * k)) & 0xFFu)];
+                    f += tab[1][o + ((xh >> (8 * k)) & 0xFFu)];
+                    f += tab[2][o + ((xb >> (8 * k)) & 0xFFu)];
+                }
+            }
+            acc[s] += (double)f;
+        }
+    }
+    const double base = (blockIdx.y == 0) ? w0sum[0] : 0.0;
+#pragma unroll
+    for (int s = 0; s < PD_SPT; ++s) {
+        const int i = i0 + 256 * s;
+        if (i < n) {
+            const double v = acc[s] + base;
+            if (v != 0.0) unsafeAtomicAdd(&out[i], v);
+        }
     }
 }
 
@@ -437,6 +570,44 @@ extern "C" int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n,
     JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)nrows, st));
     dim3 grid((nrows + 256 * PT_RPT - 1) / (256 * PT_RPT), (n + 127) / 128);
     hipLaunchKernelGGL(packed_tdot_f32_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_u, n,
+                       d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t jxg_t32_bytes(int n, int nrows) { return (int64_t)((nrows + 127) / 128) * (int64_t)n * 32; }
+
+extern "C" int jxg_p32_transpose(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                 uint8_t *d_t32, void *stream) {
+    if (nrows <= 0 || n <= 0) return 0;
+    dim3 grid((nrows + 127) / 128, (n + 127) / 128);
+    hipLaunchKernelGGL(p32_transpose_kernel, grid, dim3(128), 0, (hipStream_t)stream, d_p32, m_total, d_rows, nrows, n,
+                       d_t32);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// d_work: nrows float4 + one double (16 * nrows + 16 bytes)
+extern "C" int jxg_packed_dot_t32(const uint8_t *d_t32, int n, int nrows, const float *d_lut, const double *d_beta,
+                                  void *d_work, double *d_out, void *stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)n, st));
+    if (nrows <= 0) return 0;
+    float4 *wq = (float4 *)d_work;
+    double *w0sum = (double *)((char *)d_work + sizeof(float4) * (size_t)nrows);
+    JX_HIP(hipMemsetAsync(w0sum, 0, sizeof(double), st));
+    hipLaunchKernelGGL(pcg_plane_weights_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, d_lut, d_beta, nrows, wq,
+                       w0sum);
+    JX_LAUNCH_CHECK();
+    const int nst = (nrows + 127) / 128;
+    const int gx = (n + 256 * PD_SPT - 1) / (256 * PD_SPT);
+    int slices = (1024 + gx - 1) / gx;            // ~1024 workgroups
+    if (slices > nst) slices = nst;
+    if (slices < 1) slices = 1;
+    const int tps = (nst + slices - 1) / slices;
+    slices = (nst + tps - 1) / tps;
+    hipLaunchKernelGGL(packed_dot_t32_kernel, dim3(gx, slices), dim3(256), 0, st, d_t32, nrows, n, wq, w0sum, tps,
                        d_out);
     JX_LAUNCH_CHECK();
     return 0;

@@ -175,6 +175,11 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
     if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
     if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
+    // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
+    DevBuf t32, dwork;
+    if (t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m))) return 1;
+    if (dwork.alloc(16 * (size_t)eff_m + 16)) return 1;
+    if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
     std::vector<int32_t> cnt(3 * (size_t)eff_m);
     JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
 
@@ -261,7 +266,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             // ap = A p
             hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
             JX_LAUNCH_CHECK();
-            if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;   // Z'p
+            if (jxg_packed_dot_t32(t32.as<uint8_t>(), n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
             hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
             JX_LAUNCH_CHECK();
             if (jxg_packed_tdot_f32(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)

@@ -24,7 +24,17 @@ def main():
     on = torch.empty(n, device=dev, dtype=torch.float64)
     om = torch.empty(m, device=dev, dtype=torch.float64)
     payload = n * m / 4.0
+    t32 = torch.empty(int(lib().jxg_t32_bytes(n, m)), dtype=torch.uint8, device=dev)
+    work = torch.empty(16 * m + 16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib().jxg_p32_transpose(p.p32.data_ptr(), p.m, n, None, m, t32.data_ptr(), st))
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"p32 -> sample-major transpose: {e0.elapsed_time(e1):.3f} ms", flush=True)
     for name, fn in (("packed_dot  (Z'v -> n)", lambda: lib().jxg_packed_dot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), beta.data_ptr(), on.data_ptr(), st)),
+                     ("packed_dot_t32 (Z'v, bit-plane tables)", lambda: lib().jxg_packed_dot_t32(t32.data_ptr(), n, m, lut.data_ptr(), beta.data_ptr(), work.data_ptr(), on.data_ptr(), st)),
                      ("packed_tdot (Z u -> m)", lambda: lib().jxg_packed_tdot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st)),
                      ("packed_tdot_f32 (Z u, bit-plane tables)", lambda: lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))):
         for _ in range(2):
@@ -45,6 +55,17 @@ def main():
     check(lib().jxg_packed_tdot(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))
     torch.cuda.synchronize()
     print("tdot slice err", float((z @ alpha - om[:256]).abs().max()))
+    # Z'v: full reference on the first 64 samples through a dense decode in chunks
+    b32 = beta.to(torch.float32)
+    ref = torch.zeros(64, dtype=torch.float64, device=dev)
+    for r0 in range(0, m, 8192):
+        pk = packed[r0:r0 + 8192, :16].to(torch.int64)
+        cd = torch.stack([(pk >> (2 * k)) & 3 for k in range(4)], dim=2).reshape(pk.shape[0], -1)[:, :64]
+        wv = (lut[r0:r0 + 8192] * b32[r0:r0 + 8192, None]).to(torch.float64)
+        ref += torch.gather(wv, 1, cd).sum(0)
+    check(lib().jxg_packed_dot_t32(t32.data_ptr(), n, m, lut.data_ptr(), beta.data_ptr(), work.data_ptr(), on.data_ptr(), st))
+    torch.cuda.synchronize()
+    print("dot_t32 rel err (64 samples)", float((ref - on[:64]).abs().max() / ref.abs().max()))
     a32 = alpha.to(torch.float32).to(torch.float64)
     check(lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))
     torch.cuda.synchronize()

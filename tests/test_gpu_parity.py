@@ -1141,3 +1141,46 @@ def test_cli_gs_rrblup(oracle, tmp_path):
     rows2 = [ln.split("\t") for ln in open(prefix + "_auto.trait.gs.rrBLUP.tsv").read().splitlines()]
     p2 = np.array([float(r[2]) for r in rows2[1:]])
     assert np.all(np.isfinite(p2)) and np.corrcoef(p2[test], y[test])[0, 1] > 0.2
+
+
+@pytest.mark.gpu
+def test_rrblup_pcg_residual_at_scale(oracle):
+    """Size-independent property of the PCG route on a panel with many sample / SNP tiles and table slices
+    (n = 2500 training samples of 3000, m = 30 000): the returned marker effects satisfy the ridge system
+    (Z_c Z_c' + lambda I) beta = Z y_c to the requested tolerance when the residual is recomputed independently in f64
+    from a dense decode, predictions equal alpha + Z' beta, and the external row_mean / row_inv_sd form agrees."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    n, m = 3000, 30000
+    packed, g = bed.synth_panel_numpy(n, m, seed=97, missing_rate=0.003)
+    _miss, maf, _std, flip = oracle.load_bed_2bit_packed_stats(packed, n)
+    rng = np.random.default_rng(2)
+    tr = np.sort(rng.permutation(n)[:2500]).astype(np.int64)
+    te = np.setdiff1d(np.arange(n), tr).astype(np.int64)
+    y = rng.standard_normal(len(tr)) + (g[:50, tr].astype(np.float64).T @ rng.standard_normal(50)) * 0.2
+    lam, tol = 5000.0, 1e-6
+    out = jxrs.rrblup_pcg_bed("", tr, y, te, lambda_value=lam, tol=tol, max_iter=300, packed=packed, packed_n_samples=n,
+                              maf=maf, row_flip=flip)
+    assert out[3] and out[5] <= tol
+    rm, ri, me = oracle.rrblup_row_standardization(maf, np.float32(1e-12))
+    lut = torch.from_numpy(oracle.rrblup_value_lut(rm, ri, flip)).cuda().to(torch.float64)
+    pk = torch.from_numpy(packed).cuda().to(torch.int64)
+    codes = torch.stack([(pk >> (2 * k)) & 3 for k in range(4)], dim=2).reshape(m, -1)[:, :n]
+    z_all = torch.gather(lut, 1, codes)                                   # (m, n) f64
+    z = z_all[:, torch.from_numpy(tr).cuda()]
+    beta = torch.from_numpy(out[9].astype(np.float64)).cuda()
+    yc = torch.from_numpy(y - y.mean()).cuda()
+    mu = z.mean(dim=1)
+    b = z @ yc
+    ab = z @ (z.T @ beta) - float(len(tr)) * mu * torch.dot(mu, beta) + lam * beta
+    rel = float(torch.linalg.norm(b - ab) / torch.linalg.norm(b))
+    assert rel <= 5 * tol, rel          # f32 vectors: the true residual tracks the recurrence residual to a small factor
+    alpha = float(y.mean()) - float(torch.dot(mu, beta))
+    pred_te = (z_all[:, torch.from_numpy(te).cuda()].T @ beta + alpha).cpu().numpy()
+    scale = float(np.std(y))
+    assert np.max(np.abs(out[1].ravel() - pred_te)) <= 2e-5 * scale
+    pred_tr = (z.T @ beta + alpha).cpu().numpy()
+    assert np.max(np.abs(out[0].ravel() - pred_tr)) <= 2e-5 * scale
+    out2 = jxrs.rrblup_pcg_bed("", tr, y, te, lambda_value=lam, tol=tol, max_iter=300, packed=packed, packed_n_samples=n,
+                               maf=maf, row_flip=flip, row_mean=rm, row_inv_sd=ri)
+    assert out2[4] == out[4] and np.array_equal(out2[9], out[9])

@@ -73,7 +73,8 @@ int jxg_grm_finalize(const double *d_acc, int n, double inv_scale, void *d_out, 
 
 /* B1. symmetric eigendecomposition, f64, ascending.  d_a (n,n) is overwritten with U^T row-major
  * (row j = eigenvector j); d_w receives the n eigenvalues.  Replaces LAPACK dsyevd/dsyevr behind
- * src/math/eigh.rs:1422-1528 (rocSOLVER dsyevd on the device).  `ridge` is added to the diagonal first
+ * src/math/eigh.rs:1422-1528: own Householder tridiagonalisation (k_sytrd.hip), divide and conquer (k_stedc.hip) and
+ * compact-WY back-transformation (k_ormtr.hip); rocSOLVER dsyevd only below n = 256.  `ridge` is added to the diagonal first
  * (python/janusx/assoc/workflow.py:5639-5641). */
 int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream);
 

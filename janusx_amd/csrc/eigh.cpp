@@ -1,5 +1,6 @@
-// Symmetric eigendecomposition on the device (rocSOLVER dsyevd), replacing LAPACK dsyevd/dsyevr behind
-// src/math/eigh.rs:1422-1528 (`symmetric_eigh_f64_row_major_with_driver`).
+// Symmetric eigendecomposition on the device, replacing LAPACK dsyevd/dsyevr behind src/math/eigh.rs:1422-1528
+// (`symmetric_eigh_f64_row_major_with_driver`): own tridiagonalisation (k_sytrd.hip), divide and conquer (k_stedc.hip)
+// and back-transformation (k_ormtr.hip); rocSOLVER dsyevd below n = 256 or with JXGPU_EIGH=rocsolver.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -19,7 +20,7 @@ int launch_add_diag(double *d_a, int n, int64_t ld, double ridge, hipStream_t st
 int launch_symmetrize(double *d_a, int n, hipStream_t st);
 // k_sytrd.hip: two-kernels-per-column Householder tridiagonalisation, LAPACK dsytrd(lower) output format
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau);
-// k_stedc.hip: one Cuppen merge over two rocSOLVER dstedc halves (n beyond rocSOLVER's 32-bit limit)
+// k_stedc.hip: Cuppen divide and conquer (batched QL leaves, merges level by level; no 32-bit size limit)
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
                 std::vector<int> &h_perm);
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
@@ -65,7 +66,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (rs != rocblas_status_success)
             return fail("rocsolver_dsyevd failed with status " + std::to_string((int)rs));
     } else {
-        // own tridiagonalisation (k_sytrd.hip) + rocSOLVER divide & conquer on T + back-transformation Z = Q C
+        // own tridiagonalisation (k_sytrd.hip) + divide & conquer on T (k_stedc.hip) + back-transformation Z = Q C
         DevBuf tau;
         ScratchLease c;
         if (tau.alloc(sizeof(double) * (size_t)n)) return 1;

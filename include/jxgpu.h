@@ -334,6 +334,16 @@ int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, 
                          int max_iter, float *out_beta, double *out_pred_train, double *out_pred_test,
                          double *out_scalars);
 
+/* Haseman-Elston sufficient statistics over the same matrix-free operator (`he_pcg_bed`, src/stats/he.rs:1633-2070,
+ * 2101-2636): K = Z'Z / m_scale on the training samples, P the projector off [1, x_cov] (x_cov (n_train, p_cov)
+ * row-major or NULL).  out5 = (y'PKPy, y'Py, tr(PKP), tr((PKP)^2), tr(P)); traces by `trace_samples` Rademacher probes
+ * generated as the reference does (splitmix64 chains keyed by `seed`), or exactly (one probe per sample) when
+ * exact_trace != 0.  The 2x2 HE normal equations are solved by the caller (janusx_amd/janusx.py `he_pcg_bed`). */
+int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
+                        int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
+                        const double *y_train, const double *x_cov, int p_cov, int trace_samples, uint64_t seed,
+                        int exact_trace, double m_scale, double *out5);
+
 #ifdef __cplusplus
 }
 #endif

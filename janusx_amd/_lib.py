@@ -78,6 +78,7 @@ SIGNATURES = {
     "jx_lmm_reml_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_i, c_d, c_i, c_d, c_p],
     "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_i, c_d, c_p],
     "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
+    "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],

@@ -267,7 +267,22 @@ def cmd_gs_rrblup(args):
         t1 = time.perf_counter()
         if args.lam is not None:
             lam, src = float(args.lam), "manual"
+        elif not args.lambda_reml:
+            # Haseman-Elston first (python/janusx/gs/workflow.py:5564 `he_first`): lambda_equation = lambda_k * m_effective
+            try:
+                he = jxrs.he_pcg_bed("", train, yv[train], site_keep=keep, seed=args.seed if args.seed != 42 else 20260512,
+                                     packed=packed, packed_n_samples=n_all, maf=maf, row_flip=flip)
+            except RuntimeError as e:   # e.g. the stochastic traces violate the PSD bound on a small panel
+                he = None
+                lam, src = None, f"HE failed ({e})"
+            if he is not None:
+                if np.isfinite(he[10]) and he[10] >= 0.0:
+                    lam, src = max(1e-8, float(he[10]) * float(max(1, he[6]))), f"HE (h2={he[2]:.4f}, lambda_k={he[10]:.5g})"
+                else:
+                    lam, src = None, "HE on the boundary"
         else:
+            lam, src = None, ""
+        if lam is None:
             rng = np.random.default_rng(args.seed)
             sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
             ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
@@ -276,7 +291,7 @@ def cmd_gs_rrblup(args):
             lam_k = float(fit[3])
             p = np.clip(maf[keep], 0.0, 0.5)
             m_eff = int(np.count_nonzero(2.0 * p * (1.0 - p) > 1e-12))
-            lam, src = lam_k * m_eff, f"subsample REML (n_sub={len(sub)}, lambda_k={lam_k:.5g})"
+            lam, src = lam_k * m_eff, (src + " -> " if src else "") + f"subsample REML (n_sub={len(sub)}, lambda_k={lam_k:.5g})"
         fold = np.full(n_all, -1, dtype=np.int64)
         pred = np.full(n_all, np.nan)
 
@@ -351,6 +366,8 @@ def main(argv=None):
     q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
     q.add_argument("-rrBLUP", "--rrBLUP", dest="rrblup", action="store_true", default=False)
     q.add_argument("-lambda", "--lambda", dest="lam", type=float, default=None)
+    q.add_argument("-lambda-reml", "--lambda-reml", dest="lambda_reml", action="store_true", default=False,
+                   help="rrBLUP: take lambda from the subsample GBLUP REML instead of Haseman-Elston")
     q.add_argument("-tol", "--tol", type=float, default=1e-4)
     q.add_argument("-max-iter", "--max-iter", dest="max_iter", type=int, default=100)
     q.add_argument("-cv", "--cv", type=int, default=None)

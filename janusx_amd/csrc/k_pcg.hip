@@ -343,3 +343,213 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     out_scalars[4] = (double)alpha_use;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Haseman-Elston traces over the same matrix-free operator (second half of SURVEY 8f-4): src/stats/he.rs:1633-2070
+// `he_variance_components_with_source`.  K = Z'Z / m_scale on the training samples, P = I - X (X'X)^-1 X' with
+// X = [1, x_cov]; returns y'PKPy, y'Py and the Hutchinson (or exact) estimates of tr(PKP), tr((PKP)^2).
+// The probes are the reference's (+-1 from splitmix64 chains, he.rs:1871-1881), so the estimates are deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+inline uint64_t he_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct HeProjector {   // he.rs:206-354
+    int n = 0, p = 0;
+    std::vector<double> x, chol;   // x (n,p) row-major, chol = lower Cholesky factor of X'X
+    int init(int n_, const double *x_cov, int p_cov) {
+        n = n_;
+        p = 1 + p_cov;
+        if (n <= p) return fail("HE projection requires n > rank(X): n=" + std::to_string(n) + ", p(with intercept)=" + std::to_string(p));
+        x.assign((size_t)n * p, 0.0);
+        for (int i = 0; i < n; ++i) {
+            x[(size_t)i * p] = 1.0;
+            for (int a = 0; a < p_cov; ++a) {
+                const double v = x_cov[(size_t)i * p_cov + a];
+                if (!isfinite(v)) return fail("x_cov contains non-finite values");
+                x[(size_t)i * p + 1 + a] = v;
+            }
+        }
+        chol.assign((size_t)p * p, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < p; ++a)
+                for (int b = 0; b <= a; ++b) chol[(size_t)a * p + b] += x[(size_t)i * p + a] * x[(size_t)i * p + b];
+        for (int a = 0; a < p; ++a) {   // in-place lower Cholesky
+            for (int b = 0; b <= a; ++b) {
+                double s = chol[(size_t)a * p + b];
+                for (int k = 0; k < b; ++k) s -= chol[(size_t)a * p + k] * chol[(size_t)b * p + k];
+                if (a == b) {
+                    if (!(s > 0.0) || !isfinite(s))
+                        return fail("HE covariate projection failed: X'X is singular or ill-conditioned (p=" + std::to_string(p) + ")");
+                    chol[(size_t)a * p + a] = sqrt(s);
+                } else {
+                    chol[(size_t)a * p + b] = s / chol[(size_t)b * p + b];
+                }
+            }
+        }
+        return 0;
+    }
+    void coef(const std::vector<double> &xtv, std::vector<double> &beta) const {
+        std::vector<double> t(p);
+        for (int a = 0; a < p; ++a) {
+            double s = xtv[a];
+            for (int k = 0; k < a; ++k) s -= chol[(size_t)a * p + k] * t[k];
+            t[a] = s / chol[(size_t)a * p + a];
+        }
+        for (int a = p - 1; a >= 0; --a) {
+            double s = t[a];
+            for (int k = a + 1; k < p; ++k) s -= chol[(size_t)k * p + a] * beta[k];
+            beta[a] = s / chol[(size_t)a * p + a];
+        }
+    }
+    void project64(std::vector<double> &v) const {
+        std::vector<double> xtv(p, 0.0), beta(p, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < p; ++a) xtv[a] += x[(size_t)i * p + a] * v[i];
+        coef(xtv, beta);
+        for (int i = 0; i < n; ++i) {
+            double xb = 0.0;
+            for (int a = 0; a < p; ++a) xb += x[(size_t)i * p + a] * beta[a];
+            v[i] -= xb;
+        }
+    }
+    void project32(std::vector<float> &v) const {
+        std::vector<double> xtv(p, 0.0), beta(p, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < p; ++a) xtv[a] += x[(size_t)i * p + a] * (double)v[i];
+        coef(xtv, beta);
+        for (int i = 0; i < n; ++i) {
+            double xb = 0.0;
+            for (int a = 0; a < p; ++a) xb += x[(size_t)i * p + a] * beta[a];
+            v[i] -= (float)xb;
+        }
+    }
+};
+}  // namespace
+
+// out5: [0] y'PKPy, [1] y'Py, [2] tr(PKP), [3] tr((PKP)^2) (means over the probes, or exact sums), [4] tr(P)
+extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
+                                   int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
+                                   const double *y_train, const double *x_cov, int p_cov, int trace_samples,
+                                   uint64_t seed, int exact_trace, double m_scale, double *out5) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (m_total <= 0 || eff_m <= 0) return fail("SNP row count must be > 0");
+    if (n_train <= 0) return fail("sample_idx must not be empty");
+    if (trace_samples <= 0) return fail("trace_samples must be > 0");
+    if (eff_m > 0x7fffffffLL) return fail("too many markers for one call");
+    if ((x_cov == nullptr) != (p_cov == 0)) return fail(x_cov ? "x_cov provided but p_cov == 0" : "p_cov > 0 but x_cov is None");
+    const int64_t bps = ((int64_t)n_samples + 3) / 4;
+    const int n = n_train;
+    std::vector<int32_t> tr32(n);
+    for (int i = 0; i < n; ++i) {
+        if (train_idx[i] < 0 || train_idx[i] >= n_samples) return fail("train_sample_indices out of range");
+        tr32[i] = (int32_t)train_idx[i];
+    }
+    if (row_indices)
+        for (int64_t j = 0; j < eff_m; ++j)
+            if (row_indices[j] < 0 || row_indices[j] >= m_total) return fail("row source index out of bounds");
+    for (int i = 0; i < n; ++i)
+        if (!isfinite(y_train[i])) return fail("y contains non-finite values");
+    HeProjector P;
+    if (P.init(n, x_cov, p_cov)) return 1;
+
+    hipStream_t st = nullptr;
+    DevBuf raw, didx, drow, p32, t32, dlut, dwork, dvn, dvm;
+    if (raw.alloc((size_t)(m_total * bps))) return 1;
+    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
+    if (didx.alloc(sizeof(int32_t) * (size_t)n)) return 1;
+    JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    const int64_t *d_rowidx = nullptr;
+    if (row_indices) {
+        if (drow.alloc(sizeof(int64_t) * (size_t)eff_m)) return 1;
+        JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
+        d_rowidx = drow.as<int64_t>();
+    }
+    if (p32.alloc((size_t)num_tiles(n) * (size_t)eff_m * 32)) return 1;
+    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, didx.as<int32_t>(), n, d_rowidx, eff_m,
+                       p32.as<uint8_t>(), st))
+        return 1;
+    JX_HIP(hipStreamSynchronize(st));
+    raw.release();
+    if (t32.alloc((size_t)jxg_t32_bytes(n, (int)eff_m))) return 1;
+    if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
+    if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) || dwork.alloc(16 * (size_t)eff_m + 16) ||
+        dvn.alloc(sizeof(double) * (size_t)n) || dvm.alloc(sizeof(double) * (size_t)eff_m))
+        return 1;
+    JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
+    const float ms = (float)m_scale;
+    const float inv_m = 1.0f / (ms > 1.0f ? ms : 1.0f);
+    std::vector<double> h64(n);
+    // out = K v (f32 in, f32 out): Z v (f32 GEMV in the reference) -> Z'(.) -> * 1/m   (he.rs:1273-1327)
+    auto apply_k = [&](const std::vector<float> &v, std::vector<float> &o) -> int {
+        for (int i = 0; i < n; ++i) h64[i] = (double)v[i];
+        JX_HIP(hipMemcpyAsync(dvn.p, h64.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        if (jxg_packed_tdot_f32(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, dlut.as<float>(), dvn.as<double>(),
+                                dvm.as<double>(), st))
+            return 1;
+        hipLaunchKernelGGL(pcg_round_kernel, dim3(pcg_grid_full(eff_m)), dim3(PCG_T), 0, st, dvm.as<double>(), eff_m);
+        JX_LAUNCH_CHECK();
+        if (jxg_packed_dot_t32(t32.as<uint8_t>(), n, (int)eff_m, dlut.as<float>(), dvm.as<double>(), dwork.p,
+                               dvn.as<double>(), st))
+            return 1;
+        JX_HIP(hipMemcpyAsync(h64.data(), dvn.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        JX_HIP(hipStreamSynchronize(st));
+        o.resize(n);
+        for (int i = 0; i < n; ++i) o[i] = (float)h64[i] * inv_m;
+        return 0;
+    };
+    std::vector<double> yp(y_train, y_train + n);
+    P.project64(yp);
+    std::vector<float> y32(n), kv, probe(n);
+    for (int i = 0; i < n; ++i) y32[i] = (float)yp[i];
+    if (apply_k(y32, kv)) return 1;
+    double y_ky = 0.0, y_y = 0.0;
+    for (int i = 0; i < n; ++i) {
+        y_ky += (double)y32[i] * (double)kv[i];
+        y_y += (double)y32[i] * (double)y32[i];
+    }
+    double trk = 0.0, trk2 = 0.0;
+    if (exact_trace) {
+        for (int c = 0; c < n; ++c) {
+            std::fill(probe.begin(), probe.end(), 0.0f);
+            probe[c] = 1.0f;
+            P.project32(probe);
+            if (apply_k(probe, kv)) return 1;
+            P.project32(kv);
+            trk += (double)kv[c];
+            for (int i = 0; i < n; ++i) trk2 += (double)kv[i] * (double)kv[i];
+        }
+    } else {
+        for (int t = 0; t < trace_samples; ++t) {
+            uint64_t state = he_splitmix64(seed ^ ((uint64_t)t * 0x517CC1B727220A95ull));
+            for (int i = 0; i < n; ++i) {
+                state = he_splitmix64(state);
+                probe[i] = ((state & 1ull) == 0) ? 1.0f : -1.0f;
+            }
+            P.project32(probe);
+            if (apply_k(probe, kv)) return 1;
+            P.project32(kv);
+            double a = 0.0, b = 0.0;
+            for (int i = 0; i < n; ++i) {
+                a += (double)probe[i] * (double)kv[i];
+                b += (double)kv[i] * (double)kv[i];
+            }
+            trk += a;
+            trk2 += b;
+        }
+        trk /= (double)trace_samples;
+        trk2 /= (double)trace_samples;
+    }
+    out5[0] = y_ky;
+    out5[1] = y_y;
+    out5[2] = trk;
+    out5[3] = trk2;
+    const double trp = (double)n - (double)P.p;
+    out5[4] = trp > 1.0 ? trp : 1.0;
+    return 0;
+}

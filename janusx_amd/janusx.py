@@ -1207,3 +1207,222 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
             pve_lambda_vc = k_trace_mean / dv
     return (np.asarray(pred_train, dtype=np.float64).reshape(-1, 1), pred_te.reshape(-1, 1), pve_trainvar, converged,
             iters, rel_res, m_effective, pve_lambda_vc, k_trace_mean, beta)
+
+
+def _he_solve_2x2(a00, a01, a11, b0, b1):
+    """src/stats/he.rs:874-897."""
+    import math
+    if not all(math.isfinite(v) for v in (a00, a01, a11, b0, b1)):
+        raise RuntimeError("HE 2x2 solve received non-finite inputs")
+    det = a00 * a11 - a01 * a01
+    det_scale = max(abs(a00) + abs(a11) + 2.0 * abs(a01), 1.0)
+    det_floor = det_scale * det_scale * float(np.finfo(np.float64).eps)
+    if (not math.isfinite(det)) or abs(det) <= det_floor:
+        raise RuntimeError(f"HE 2x2 solve is singular/ill-conditioned: det={det}, floor={det_floor}")
+    x0 = (b0 * a11 - b1 * a01) / det
+    x1 = (a00 * b1 - a01 * b0) / det
+    if not (math.isfinite(x0) and math.isfinite(x1)):
+        raise RuntimeError("HE 2x2 solve produced non-finite outputs")
+    return x0, x1
+
+
+def _he_project_nnls_2x2(a00, a01, a11, b0, b1, x0u, x1u):
+    """src/stats/he.rs:815-871 -> (sigma_g2, sigma_e2, projected, boundary status 0..3)."""
+    import math
+
+    def obj(x0, x1):
+        r0 = a00 * x0 + a01 * x1 - b0
+        r1 = a01 * x0 + a11 * x1 - b1
+        return r0 * r0 + r1 * r1
+    cands = [(x0u, x1u, 0)]
+    c1 = a01 * a01 + a11 * a11
+    if math.isfinite(c1) and c1 > 0.0:
+        cands.append((0.0, max((a01 * b0 + a11 * b1) / c1, 0.0), 1))
+    c0 = a00 * a00 + a01 * a01
+    if math.isfinite(c0) and c0 > 0.0:
+        cands.append((max((a00 * b0 + a01 * b1) / c0, 0.0), 0.0, 2))
+    cands.append((0.0, 0.0, 3))
+    best = (0.0, 0.0, float("inf"), 3)
+    for x0, x1, stt in cands:
+        if not (math.isfinite(x0) and math.isfinite(x1)) or x0 < 0.0 or x1 < 0.0:
+            continue
+        o = obj(x0, x1)
+        if math.isfinite(o) and o < best[2]:
+            best = (x0, x1, o, stt)
+    if not math.isfinite(best[2]):
+        return 0.0, 0.0, True, 3
+    tolp = 1e-10 * max(abs(x0u), abs(x1u), 1.0)
+    projected = best[3] != 0 or abs(best[0] - x0u) > tolp or abs(best[1] - x1u) > tolp
+    return best[0], best[1], projected, best[3]
+
+
+def he_pcg_bed(prefix, train_sample_indices, y_train, site_keep=None, trace_samples=32, trace_probe_batch=64, tol=1e-6,
+               max_iter=32, block_rows=4096, std_eps=1e-12, use_train_maf=True, exact_trace_debug=False,
+               exact_trace_max_n=256, threads=0, seed=20260512, packed=None, packed_n_samples=0, maf=None, row_flip=None,
+               row_source_indices=None, x_cov=None, blas_threads=0, mmap_window_mb=None):
+    """src/stats/he.rs:2073-2636: Haseman-Elston variance components of y = g + e, g ~ N(0, sigma_g2 K), K the standardised
+    GRM of the training samples applied matrix-free on the device (`jx_he_traces_packed`: two streaming passes per
+    probe), Hutchinson traces with the reference's splitmix64 probes.  Returns the reference's 12-tuple (sigma_g2,
+    sigma_e2, h2, converged, iters, rel_res, m_effective, tr_k2, y_ky, y_y, lambda, tr_k2_solve).  The packed-payload
+    form and the prefix form are built (the metadata-streaming form maps onto them: rows = row_source_indices)."""
+    import math
+    f32 = np.float32
+    if int(trace_samples) == 0:
+        raise RuntimeError("trace_samples must be > 0")
+    if int(trace_probe_batch) == 0:
+        raise RuntimeError("trace_probe_batch must be > 0")
+    if int(max_iter) == 0:
+        raise RuntimeError("max_iter must be > 0")
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError("tol must be finite and > 0")
+    if not (math.isfinite(std_eps) and std_eps > 0.0):
+        raise RuntimeError("std_eps must be finite and > 0")
+    ext = packed is not None or int(packed_n_samples) > 0
+    meta = row_source_indices is not None
+    if ext and meta:
+        raise RuntimeError("he_pcg_bed: provide either packed payload inputs or row_source_indices metadata streaming "
+                           "inputs, not both.")
+    if (not ext) and (not meta) and (maf is not None or row_flip is not None):
+        raise RuntimeError("he_pcg_bed: external maf/row_flip without packed payload requires row_source_indices for "
+                           "metadata streaming.")
+    rows = None
+    if ext:
+        if packed is None:
+            raise RuntimeError("he_pcg_bed: packed payload path requires `packed` argument.")
+        if maf is None:
+            raise RuntimeError("he_pcg_bed: packed payload path requires `maf` argument.")
+        if row_flip is None:
+            raise RuntimeError("he_pcg_bed: packed payload path requires `row_flip` argument.")
+        if int(packed_n_samples) == 0:
+            raise RuntimeError("he_pcg_bed: packed payload path requires packed_n_samples > 0.")
+        n_samples = int(packed_n_samples)
+        pk = _c(packed, np.uint8)
+        if pk.ndim != 2:
+            raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+    elif meta:
+        if site_keep is not None:
+            raise RuntimeError("he_pcg_bed: metadata streaming path does not accept site_keep; subset rows via "
+                               "row_source_indices instead.")
+        if maf is None:
+            raise RuntimeError("he_pcg_bed: metadata streaming path requires `maf` argument.")
+        if row_flip is None:
+            raise RuntimeError("he_pcg_bed: metadata streaming path requires `row_flip` argument.")
+        from .bed import read_bed_payload
+        pk, n_samples, _bim = read_bed_payload(str(prefix))
+        rows = _c(row_source_indices, np.int64).ravel()
+        if rows.size == 0:
+            raise RuntimeError("row_source_indices must not be empty for metadata streaming path.")
+        if rows.min() < 0:
+            raise RuntimeError("row_source_indices must be non-negative.")
+    else:
+        pk, _miss, maf, _std, n_samples = load_bed_2bit_packed(prefix)
+        row_flip = bed_packed_row_flip_mask(pk, n_samples)
+    m_total = int(pk.shape[0])
+    if m_total == 0:
+        raise RuntimeError("No SNP rows found in BED input.")
+    if pk.shape[1] != (n_samples + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1]}, expected {(n_samples + 3) // 4}")
+    maf_in = _c(maf, f32).ravel()
+    flip_in = np.asarray(row_flip).astype(bool).ravel()
+    if meta:
+        if maf_in.shape[0] != rows.shape[0] or flip_in.shape[0] != rows.shape[0]:
+            raise RuntimeError("metadata length mismatch between row_source_indices, maf and row_flip")
+        if rows.max() >= m_total:
+            raise RuntimeError("row source index out of bounds")
+        maf_keep, flip_keep = maf_in, flip_in
+    else:
+        if maf_in.shape[0] != m_total:
+            raise RuntimeError(f"maf length mismatch: got {maf_in.shape[0]}, expected {m_total}")
+        if flip_in.shape[0] != m_total:
+            raise RuntimeError(f"row_flip length mismatch: got {flip_in.shape[0]}, expected {m_total}")
+        maf_keep, flip_keep = maf_in, flip_in
+        if site_keep is not None:
+            mask = np.asarray(site_keep).astype(bool).ravel()
+            if mask.shape[0] != m_total:
+                raise RuntimeError(f"site_keep length mismatch: got {mask.shape[0]}, expected {m_total}")
+            keep_idx = np.nonzero(mask)[0].astype(np.int64)
+            if keep_idx.shape[0] == 0:
+                raise RuntimeError("No SNPs remained after applying site_keep mask.")
+            if keep_idx.shape[0] != m_total:
+                rows = keep_idx
+                maf_keep, flip_keep = maf_in[keep_idx], flip_in[keep_idx]
+    eff_m = int(maf_keep.shape[0])
+    tr = _c(train_sample_indices, np.int64).ravel()
+    if tr.size == 0:
+        raise RuntimeError("train_sample_indices must not be empty.")
+    if tr.min() < 0 or tr.max() >= n_samples:
+        raise RuntimeError("train_sample_indices out of range")
+    y = _c(y_train, np.float64).ravel()
+    if y.shape[0] != tr.shape[0]:
+        raise RuntimeError(f"y_train length mismatch: got {y.shape[0]}, expected {tr.shape[0]}")
+    if not np.all(np.isfinite(y)):
+        raise RuntimeError("y_train contains non-finite values.")
+    n = int(tr.shape[0])
+    xc, p_cov = None, 0
+    if x_cov is not None:
+        xa = _c(x_cov, np.float64)
+        if xa.ndim != 2:
+            raise RuntimeError("x_cov must be 2D (n, p_cov)")
+        if xa.shape[1] == 0:
+            raise RuntimeError("x_cov must have at least one column")
+        if xa.shape[0] == n_samples:
+            xc = np.ascontiguousarray(xa[tr])
+        elif xa.shape[0] == n:
+            xc = xa
+        else:
+            raise RuntimeError(f"x_cov rows mismatch: got {xa.shape[0]}, expected either n_samples={n_samples} or n_train={n}")
+        p_cov = int(xc.shape[1])
+    # row standardisation (he.rs:454-640): oriented minor frequency, or the training samples' own frequency
+    if not np.all(np.isfinite(maf_keep)):
+        raise RuntimeError("row_maf contains non-finite values")
+    af = np.clip(maf_keep, f32(0.0), f32(1.0))
+    pfr = np.where(af <= f32(0.5), af, np.where(flip_keep, f32(1.0) - af, af)).astype(f32)
+    if use_train_maf:
+        pk_rows = pk if rows is None else np.ascontiguousarray(pk[rows])
+        cnt = bed_row_counts(pk_rows, n_samples, tr).astype(np.int64)
+        nm = n - cnt[:, 0]
+        alt = cnt[:, 1] + 2 * cnt[:, 2]
+        dos = np.where(flip_keep, 2 * nm - alt, alt)
+        okc = nm > 0
+        pt = np.zeros_like(pfr)
+        pt[okc] = dos[okc].astype(f32) / (f32(2.0) * nm[okc].astype(f32))
+        pfr = np.where(okc, pt, pfr).astype(f32)
+    pfr = np.clip(pfr, f32(0.0), f32(1.0))
+    rm = (f32(2.0) * pfr).astype(f32)
+    var = np.maximum((f32(2.0) * pfr * (f32(1.0) - pfr)).astype(f32), f32(0.0))
+    good = var > f32(max(float(std_eps), 1e-12))
+    ri = np.zeros_like(var)
+    ri[good] = (f32(1.0) / np.sqrt(var[good])).astype(f32)
+    m_effective = int(np.count_nonzero(good))
+    if m_effective == 0:
+        raise RuntimeError("No effective SNPs after std_eps filtering")
+    g0 = np.where(flip_keep, f32(2.0), f32(0.0)).astype(f32)
+    g2 = np.where(flip_keep, f32(0.0), f32(2.0)).astype(f32)
+    lut = np.zeros((eff_m, 4), dtype=f32)
+    lut[:, 0] = (g0 - rm) * ri
+    lut[:, 2] = (f32(1.0) - rm) * ri
+    lut[:, 3] = (g2 - rm) * ri
+    exact = bool(exact_trace_debug) and n <= max(int(exact_trace_max_n), 1)
+    out5 = np.zeros(5, dtype=np.float64)
+    check(lib().jx_he_traces_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n, _p(y), _p(xc), p_cov,
+                                    int(trace_samples), int(seed) & ((1 << 64) - 1), 1 if exact else 0,
+                                    float(m_effective), _p(out5)))
+    y_ky, y_y, tr_k, tr_k2, tr_p = (float(v) for v in out5)
+    if not (math.isfinite(tr_k) and tr_k > 0.0):
+        raise RuntimeError(f"estimated Tr(PKP) is invalid: {tr_k}. Try increasing trace_samples.")
+    if not (math.isfinite(tr_k2) and tr_k2 > 0.0):
+        raise RuntimeError(f"estimated Tr((PKP)^2) is invalid: {tr_k2}. Try increasing trace_samples.")
+    tr_k2_solve = max(tr_k2, (tr_k * tr_k) / tr_p + tr_p * 1e-6)
+    if tr_k2_solve > tr_k2 * 1.05:
+        raise RuntimeError(f"Tr((PKP)^2) stochastic estimate violates PSD bound too much: raw={tr_k2}, "
+                           f"adjusted={tr_k2_solve}. Increase trace_samples.")
+    sg_u, se_u = _he_solve_2x2(tr_k2_solve, tr_k, tr_p, y_ky, y_y)
+    sg, se, _proj, _status = _he_project_nnls_2x2(tr_k2_solve, tr_k, tr_p, y_ky, y_y, sg_u, se_u)
+    r0 = tr_k2_solve * sg + tr_k * se - y_ky
+    r1 = tr_k * sg + tr_p * se - y_y
+    rel_res = math.sqrt(r0 * r0 + r1 * r1) / max(math.sqrt(y_ky * y_ky + y_y * y_y), 1e-20)
+    converged = math.isfinite(rel_res) and rel_res <= max(float(tol), 1e-12)
+    den = sg + se
+    h2 = sg / den if (math.isfinite(den) and den > 0.0) else float("nan")
+    lam = se / sg if (math.isfinite(sg) and sg > 0.0) else float("inf")
+    return (sg, se, h2, bool(converged), 1, rel_res, min(m_effective, eff_m), tr_k2, y_ky, y_y, lam, tr_k2_solve)

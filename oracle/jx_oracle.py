@@ -1312,3 +1312,195 @@ def rrblup_pcg_packed(packed, n_samples, maf, row_flip, train_idx, y_train, test
         pred_test = (decode(te).T @ beta).astype(np.float32).astype(np.float64) + float(alpha_use)
     return (pred_train.reshape(-1, 1), pred_test.reshape(-1, 1), pve_trainvar, bool(converged), int(iters),
             float(rel_res), int(m_effective), pve_lambda_vc, k_trace_mean, beta)
+
+
+# --------------------------------------------------------------------------------------------
+# Row 8f-4, second half: Haseman-Elston variance components with stochastic traces over the same matrix-free GRM
+# operator (src/stats/he.rs:1633-2070 `he_variance_components_with_source`, `he_pcg_bed` :2073-2636)
+# --------------------------------------------------------------------------------------------
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(x: int) -> int:
+    """src/stats/he.rs:899-906."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def he_rademacher_probe(seed: int, probe_idx: int, n: int) -> np.ndarray:
+    """+-1 probe of index `probe_idx` (he.rs:1871-1881)."""
+    state = splitmix64((seed ^ ((probe_idx * 0x517CC1B727220A95) & _M64)) & _M64)
+    out = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        state = splitmix64(state)
+        out[i] = 1.0 if (state & 1) == 0 else -1.0
+    return out
+
+
+def he_row_standardization(packed_rows, n_samples, row_flip, row_maf, sample_idx, std_eps32, use_train_maf=True):
+    """`build_row_standardization_stats_with_options` without the sample diagonal (he.rs:454-640): oriented minor
+    frequency from the input (:367-384) or, with `use_train_maf`, from the training samples' calls (:506-534)."""
+    flip = np.asarray(row_flip, dtype=bool)
+    raw = np.asarray(row_maf, dtype=np.float32)
+    if not np.all(np.isfinite(raw)):
+        raise RuntimeError("row_maf contains non-finite values")
+    af = np.clip(raw, F32(0.0), F32(1.0))
+    p = np.where(af <= F32(0.5), af, np.where(flip, F32(1.0) - af, af)).astype(np.float32)
+    p = np.clip(p, F32(0.0), F32(1.0))
+    if use_train_maf:
+        mi, he, ho = row_counts(packed_rows, n_samples, sample_idx)
+        nm = len(sample_idx) - mi
+        alt = he + 2 * ho
+        dos = np.where(flip, 2 * nm - alt, alt)
+        ok = nm > 0
+        pt = np.zeros_like(p)
+        pt[ok] = dos[ok].astype(np.float32) / (F32(2.0) * nm[ok].astype(np.float32))
+        p = np.where(ok, pt, p).astype(np.float32)
+    p = np.clip(p, F32(0.0), F32(1.0))
+    mean = (F32(2.0) * p).astype(np.float32)
+    var = np.maximum((F32(2.0) * p * (F32(1.0) - p)).astype(np.float32), F32(0.0))
+    good = var > F32(std_eps32)
+    inv = np.zeros_like(var)
+    inv[good] = (F32(1.0) / np.sqrt(var[good])).astype(np.float32)
+    return mean, inv, int(np.count_nonzero(good))
+
+
+def he_solve_2x2(a00, a01, a11, b0, b1):
+    """he.rs:874-897."""
+    det = a00 * a11 - a01 * a01
+    det_scale = max(abs(a00) + abs(a11) + 2.0 * abs(a01), 1.0)
+    det_floor = det_scale * det_scale * EPS64
+    if not math.isfinite(det) or abs(det) <= det_floor:
+        raise RuntimeError(f"HE 2x2 solve is singular/ill-conditioned: det={det}, floor={det_floor}")
+    return (b0 * a11 - b1 * a01) / det, (a00 * b1 - a01 * b0) / det
+
+
+def he_project_nnls_2x2(a00, a01, a11, b0, b1, x0u, x1u):
+    """he.rs:815-871: best feasible point among the interior solution, the two boundaries and the origin.
+    Returns (x0, x1, projected, status) with status 0 interior, 1 sigma_g2 = 0, 2 sigma_e2 = 0, 3 origin."""
+    def obj(x0, x1):
+        r0 = a00 * x0 + a01 * x1 - b0
+        r1 = a01 * x0 + a11 * x1 - b1
+        return r0 * r0 + r1 * r1
+    best = (0.0, 0.0, float("inf"), 3)
+    cands = [(x0u, x1u, 0)]
+    c1 = a01 * a01 + a11 * a11
+    if math.isfinite(c1) and c1 > 0:
+        cands.append((0.0, max((a01 * b0 + a11 * b1) / c1, 0.0), 1))
+    c0 = a00 * a00 + a01 * a01
+    if math.isfinite(c0) and c0 > 0:
+        cands.append((max((a00 * b0 + a01 * b1) / c0, 0.0), 0.0, 2))
+    cands.append((0.0, 0.0, 3))
+    for x0, x1, st in cands:
+        if not (math.isfinite(x0) and math.isfinite(x1)) or x0 < 0 or x1 < 0:
+            continue
+        o = obj(x0, x1)
+        if math.isfinite(o) and o < best[2]:
+            best = (x0, x1, o, st)
+    if not math.isfinite(best[2]):
+        return 0.0, 0.0, True, 3
+    scale = max(abs(x0u), abs(x1u), 1.0)
+    tolp = 1e-10 * scale
+    projected = best[3] != 0 or abs(best[0] - x0u) > tolp or abs(best[1] - x1u) > tolp
+    return best[0], best[1], projected, best[3]
+
+
+def he_pcg_packed(packed, n_samples, maf, row_flip, train_idx, y_train, site_keep=None, trace_samples=32, tol=1e-6,
+                  std_eps=1e-12, use_train_maf=True, exact_trace_debug=False, exact_trace_max_n=256, seed=20260512,
+                  x_cov=None):
+    """`he_pcg_bed`, resident packed form (he.rs:2101-2636 -> :1633-2070). K = Z'Z / m_effective on the training
+    samples (Z standardised with the training-sample allele frequency, missing -> 0), P the projector off
+    [1, x_cov]; y'PKPy, y'Py, tr(PKP) and tr((PKP)^2) by Hutchinson probes (or exactly); 2x2 HE normal equations with
+    the non-negative projection. Returns the reference's 12-tuple (sigma_g2, sigma_e2, h2, converged, iters, rel_res,
+    m_effective, tr_k2, y_ky, y_y, lambda, tr_k2_solve) plus (tr_k, tr_p, status) for tests."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    m_total = packed.shape[0]
+    maf = np.asarray(maf, dtype=np.float32)
+    flip = np.asarray(row_flip, dtype=bool)
+    rows = np.arange(m_total)
+    if site_keep is not None:
+        rows = np.nonzero(np.asarray(site_keep, dtype=bool))[0]
+        if rows.shape[0] == 0:
+            raise RuntimeError("No SNPs remained after applying site_keep mask.")
+    eff_m = rows.shape[0]
+    tr = np.asarray(train_idx, dtype=np.int64)
+    y = np.asarray(y_train, dtype=np.float64)
+    n = tr.shape[0]
+    pk = packed[rows]
+    mean, inv, m_eff = he_row_standardization(pk, n_samples, flip[rows], maf[rows], tr, F32(max(std_eps, 1e-12)),
+                                              use_train_maf)
+    if m_eff == 0:
+        raise RuntimeError("No effective SNPs after std_eps filtering")
+    lut = rrblup_value_lut(mean, inv, flip[rows])
+    codes = unpack_codes(pk, n_samples)[:, tr].astype(np.int64)
+    z = np.take_along_axis(lut, codes, axis=1).astype(np.float32)            # (m, n)
+    m_scale = F32(m_eff)
+    inv_m = F32(1.0) / max(m_scale, F32(1.0))
+    # projector off [1, x_cov] (he.rs:206-354)
+    if x_cov is not None:
+        xc = np.asarray(x_cov, dtype=np.float64)
+        if xc.shape[0] == n_samples and n != n_samples:
+            xc = xc[tr]
+        x = np.concatenate([np.ones((n, 1)), xc.reshape(n, -1)], axis=1)
+    else:
+        x = np.ones((n, 1))
+    p = x.shape[1]
+    if n <= p:
+        raise RuntimeError(f"HE projection requires n > rank(X): n={n}, p(with intercept)={p}")
+    xtx = x.T @ x
+
+    def proj64(v):
+        return v - x @ np.linalg.solve(xtx, x.T @ v)
+
+    def proj32(v32):
+        v = v32.astype(np.float64)
+        return (v32 - (x @ np.linalg.solve(xtx, x.T @ v)).astype(np.float32)).astype(np.float32)
+
+    def apply_k(v32):
+        t = (z @ v32).astype(np.float32)
+        return ((z.T @ t).astype(np.float32) * inv_m).astype(np.float32)
+
+    y32 = proj64(y).astype(np.float32)
+    k_y = apply_k(y32)
+    y_ky = float(np.dot(y32.astype(np.float64), k_y.astype(np.float64)))
+    y_y = float(np.dot(y32.astype(np.float64), y32.astype(np.float64)))
+    exact = bool(exact_trace_debug) and n <= max(int(exact_trace_max_n), 1)
+    tr_k_acc = tr_k2_acc = 0.0
+    if exact:
+        for i in range(n):
+            e = np.zeros(n, dtype=np.float32)
+            e[i] = 1.0
+            v = proj32(apply_k(proj32(e)))
+            tr_k_acc += float(v[i])
+            tr_k2_acc += float(np.dot(v.astype(np.float64), v.astype(np.float64)))
+        tr_k, tr_k2 = tr_k_acc, tr_k2_acc
+    else:
+        for t in range(trace_samples):
+            zp = proj32(he_rademacher_probe(seed, t, n))
+            v = proj32(apply_k(zp))
+            tr_k_acc += float(np.dot(zp.astype(np.float64), v.astype(np.float64)))
+            tr_k2_acc += float(np.dot(v.astype(np.float64), v.astype(np.float64)))
+        tr_k, tr_k2 = tr_k_acc / trace_samples, tr_k2_acc / trace_samples
+    if not (math.isfinite(tr_k) and tr_k > 0):
+        raise RuntimeError(f"estimated Tr(PKP) is invalid: {tr_k}. Try increasing trace_samples.")
+    if not (math.isfinite(tr_k2) and tr_k2 > 0):
+        raise RuntimeError(f"estimated Tr((PKP)^2) is invalid: {tr_k2}. Try increasing trace_samples.")
+    tr_p = max(float(n) - float(p), 1.0)
+    tr_k2_solve = max(tr_k2, (tr_k * tr_k) / tr_p + tr_p * 1e-6)
+    if tr_k2_solve > tr_k2 * 1.05:
+        raise RuntimeError("Tr((PKP)^2) stochastic estimate violates PSD bound too much: "
+                           f"raw={tr_k2}, adjusted={tr_k2_solve}. Increase trace_samples.")
+    sg_u, se_u = he_solve_2x2(tr_k2_solve, tr_k, tr_p, y_ky, y_y)
+    sg, se, _proj, status = he_project_nnls_2x2(tr_k2_solve, tr_k, tr_p, y_ky, y_y, sg_u, se_u)
+    r0 = tr_k2_solve * sg + tr_k * se - y_ky
+    r1 = tr_k * sg + tr_p * se - y_y
+    rel_res = math.sqrt(r0 * r0 + r1 * r1) / max(math.sqrt(y_ky * y_ky + y_y * y_y), 1e-20)
+    converged = math.isfinite(rel_res) and rel_res <= max(tol, 1e-12)
+    den = sg + se
+    h2 = sg / den if (math.isfinite(den) and den > 0) else float("nan")
+    lam = se / sg if (math.isfinite(sg) and sg > 0) else float("inf")
+    return (sg, se, h2, converged, 1, rel_res, min(m_eff, eff_m), tr_k2, y_ky, y_y, lam, tr_k2_solve, tr_k, tr_p, status)

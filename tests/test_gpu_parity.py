@@ -1184,3 +1184,37 @@ def test_rrblup_pcg_residual_at_scale(oracle):
     out2 = jxrs.rrblup_pcg_bed("", tr, y, te, lambda_value=lam, tol=tol, max_iter=300, packed=packed, packed_n_samples=n,
                                maf=maf, row_flip=flip, row_mean=rm, row_inv_sd=ri)
     assert out2[4] == out[4] and np.array_equal(out2[9], out[9])
+
+
+@pytest.mark.gpu
+def test_he_pcg_bed(oracle):
+    """Second half of SURVEY 8f-4: Haseman-Elston variance components with the matrix-free GRM operator and the
+    reference's splitmix64 probes -- stochastic and exact traces, covariates, a kept-SNP mask -- against the numpy
+    restatement of `he_pcg_bed`.  The sufficient statistics differ only in summation order (f64-merged table sums here,
+    f32 GEMMs there): 2e-5 relative; the variance components inherit the conditioning of the 2x2 system."""
+    from janusx_amd import janusx as jxrs
+    n, m = 420, 1600
+    packed, g = bed.synth_panel_numpy(n, m, seed=23, missing_rate=0.01, family=True)
+    _miss, maf, _std, flip = oracle.load_bed_2bit_packed_stats(packed, n)
+    rng = np.random.default_rng(1)
+    tr = np.sort(rng.permutation(n)[:350]).astype(np.int64)
+    gs = g[:, tr].astype(np.float64)
+    gs = (gs - gs.mean(1, keepdims=True)) / (gs.std(1, keepdims=True) + 1e-9)
+    y = gs.T @ (rng.standard_normal(m) * math.sqrt(0.5 / m)) + rng.standard_normal(len(tr)) * math.sqrt(0.5)
+    xcov = rng.standard_normal((len(tr), 2))
+    keep = rng.random(m) < 0.85
+    cases = [dict(), dict(x_cov=xcov, site_keep=keep, trace_samples=48, seed=7), dict(use_train_maf=False),
+             dict(exact_trace_debug=True, exact_trace_max_n=512)]
+    for kw in cases:
+        ref = oracle.he_pcg_packed(packed, n, maf, flip, tr, y, **kw)
+        got = jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf, row_flip=flip, **kw)
+        assert len(got) == 12 and got[6] == ref[6] and got[3] == ref[3] and got[4] == 1
+        for k in (7, 8, 9, 11):                      # tr_k2, y'PKPy, y'Py, tr_k2_solve
+            assert abs(got[k] - ref[k]) <= 2e-5 * abs(ref[k]), (kw.keys(), k, got[k], ref[k])
+        for k in (0, 1):                             # sigma_g2, sigma_e2
+            assert abs(got[k] - ref[k]) <= 2e-3 * (abs(ref[0]) + abs(ref[1])), (kw.keys(), k, got[k], ref[k])
+        assert abs(got[2] - ref[2]) <= 2e-3
+    with pytest.raises(RuntimeError):
+        jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf)               # row_flip missing
+    with pytest.raises(RuntimeError):
+        jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf, row_flip=flip, trace_samples=0)

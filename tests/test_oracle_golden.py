@@ -194,3 +194,35 @@ def test_rrblup_pcg_restatement_solves_the_ridge_system():
     zt = np.take_along_axis(lut, codes[:, te], axis=1).astype(np.float64)
     assert np.max(np.abs(out[1].ravel() - (zt.T @ beta + alpha))) <= 1e-4
     assert np.max(np.abs(out[0].ravel() - (z.T @ beta + alpha))) <= 1e-4
+
+
+def test_he_restatement_matches_dense_traces():
+    """SURVEY 8f-4 (HE half): no numeric test in the reference (parity unpinned beyond this): with exact traces the
+    restated estimator must reproduce tr(PKP), tr((PKP)^2), y'PKPy of the dense f64 standardised GRM, and its probes
+    are the reference's splitmix64 stream (first values pinned from the published splitmix64 test vector)."""
+    from oracle import jx_oracle as O
+    from janusx_amd import bed
+    assert O.splitmix64(0) == 0xE220A8397B1DCDAF and O.splitmix64(0xE220A8397B1DCDAF) != 0
+    n, m = 150, 400
+    packed, g = bed.synth_panel_numpy(n, m, seed=12, missing_rate=0.02)
+    miss, maf, std, flip = O.load_bed_2bit_packed_stats(packed, n)
+    rng = np.random.default_rng(3)
+    tr = np.sort(rng.permutation(n)[:120])
+    y = rng.standard_normal(120)
+    out = O.he_pcg_packed(packed, n, maf, flip, tr, y, exact_trace_debug=True, exact_trace_max_n=256)
+    mean, inv, me = O.he_row_standardization(packed, n, flip, maf, tr, np.float32(1e-12), True)
+    lut = O.rrblup_value_lut(mean, inv, flip)
+    codes = O.unpack_codes(packed, n)[:, tr].astype(np.int64)
+    z = np.take_along_axis(lut, codes, axis=1).astype(np.float64)
+    k = z.T @ z / float(me)
+    pm = np.eye(120) - np.ones((120, 120)) / 120.0
+    pkp = pm @ k @ pm
+    assert abs(out[12] - np.trace(pkp)) <= 2e-5 * np.trace(pkp)
+    assert abs(out[7] - np.sum(pkp * pkp)) <= 5e-5 * np.sum(pkp * pkp)
+    yp = pm @ y
+    assert abs(out[8] - yp @ k @ yp) <= 2e-5 * abs(yp @ k @ yp)
+    assert abs(out[9] - yp @ yp) <= 1e-6 * (yp @ yp)
+    sg, se = np.linalg.solve(np.array([[np.sum(pkp * pkp), np.trace(pkp)], [np.trace(pkp), 119.0]]),
+                             np.array([yp @ k @ yp, yp @ yp]))
+    if sg >= 0 and se >= 0:
+        assert abs(out[0] - sg) <= 1e-3 * (abs(sg) + abs(se)) and abs(out[1] - se) <= 1e-3 * (abs(sg) + abs(se))

@@ -149,7 +149,7 @@ def pmc_mfma_util(kernel_substr):
     """MFMA-pipe utilisation of a kernel from the committed counter pass (profiles/r01c_pmc_mfma.json):
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). None when the summary is absent."""
     kernels = None
-    for tag in ("r01e", "r01c"):
+    for tag in ("r01f", "r01e", "r01c"):
         try:
             kernels = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma.json")))["kernels"]
             break

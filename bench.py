@@ -171,8 +171,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=5000)
-    ap.add_argument("--m", type=int, default=50000)
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=5000)    # long forms: torchrun's own parser
+    ap.add_argument("--m", "--snps", dest="m", type=int, default=50000)      # treats a bare --n / --m as its options
     ap.add_argument("--mode", default="lmm", choices=["lmm", "fvlmm"])
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=20260609)
@@ -192,6 +192,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback)")
+    # JXGPU_BENCH_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through gloo); the measured configuration is always nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("JXGPU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # JXGPU_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to validate it on a 1-GPU box)
@@ -199,7 +204,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")   # only reached without a launcher (JXGPU_BENCH_FORCE_DIST)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.n
     m = args.m * world if args.scaling == "weak" else args.m   # panel width of the whole job

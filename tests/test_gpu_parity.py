@@ -1218,3 +1218,32 @@ def test_he_pcg_bed(oracle):
         jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf)               # row_flip missing
     with pytest.raises(RuntimeError):
         jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf, row_flip=flip, trace_samples=0)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    """The driver launches bench.py with one rank per GPU over RCCL; on a one-GPU box the same multi-rank code path
+    (SNP shards, broadcast of the phenotype, all-reduce of the f64 accumulator and the denominators, barrier-bracketed
+    timing, rank-0 JSON) is exercised with two ranks sharing the device and gloo collectives."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--samples", "1000",
+           "--snps", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["m"] == 12000
+    assert 11000 < d["config"]["m_kept"] <= 12000 and d["value"] > 0 and 0.0 < d["null"]["pve"] < 1.0
+    # single-rank run of the same total panel width keeps a comparable number of SNPs (different random shards)
+    assert out.stdout.strip().splitlines()[-1].startswith("{")        # the JSON line is the last line on stdout

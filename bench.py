@@ -183,6 +183,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from janusx_amd import dist as jd
     from janusx_amd import pipeline as pl
     from janusx_amd import stats as st
     from janusx_amd._lib import lib
@@ -244,8 +245,8 @@ def main():
         acc = pl.grm_accumulate(panel, grows, glut)
         grm_ms = lib().jxg_last_kernel_ms(0)
         if distributed:
-            dist.all_reduce(acc)       # f64 partial GRMs summed over xGMI (RCCL)
-            dist.all_reduce(denom)
+            jd.allreduce_sum_(acc)     # f64 partial GRMs summed over xGMI (RCCL)
+            jd.allreduce_sum_(denom)
         k32 = pl.grm_finalize(acc, n, float(denom[0]), torch.float32)
         del acc
         torch.cuda.synchronize()

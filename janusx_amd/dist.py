@@ -19,7 +19,13 @@ def allreduce_sum_(t):
     """In-place sum over ranks (no-op when torch.distributed is not initialised)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)
+        if t.is_cuda and dist.get_backend() != "nccl":
+            # functional multi-rank mode on shared GPUs (gloo): reduce through host memory
+            h = t.detach().cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
     return t
 
 

@@ -78,6 +78,16 @@ int jxg_grm_finalize(const double *d_acc, int n, double inv_scale, void *d_out, 
  * (python/janusx/assoc/workflow.py:5639-5641). */
 int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream);
 
+/* Node-level distribution of B1 (no counterpart in the reference, whose LAPACK call is single-process): every rank
+ * calls jxg_eigh_f64 on the same matrix; for n >= min_n (<= 0: keep the default 16384) each rank streams 1 / world of
+ * the trailing-matrix tiles in every column of the tridiagonalisation and `allreduce(user)` has to sum the
+ * `jxg_eigh_dist_staging_doubles(n)` doubles at d_staging over the ranks, ordered on the stream given to jxg_eigh_f64
+ * (RCCL through torch.distributed in janusx_amd/pipeline.py).  The replicated part of every column is computed without
+ * floating-point atomics in this mode, so the ranks' copies stay bit-identical.  world = 1 or allreduce = NULL: off. */
+int64_t jxg_eigh_dist_staging_doubles(int n);
+int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
+                      int64_t staging_doubles, int min_n);
+
 /* a <- (a + a^T)/2 (src/math/eigh.rs:179-207); dst = src^T; dst (k,k) f64 = src[idx, idx] of an (n,n)
  * f32/f64 matrix (trait-sample subset, python/janusx/assoc/workflow.py:5509-5560). */
 int jxg_symmetrize_f64(double *d_a, int n, void *stream);

@@ -32,6 +32,8 @@ SIGNATURES = {
     "jxg_grm_accumulate": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "jxg_grm_finalize": [c_p, c_i, c_d, c_p, c_i, c_p],
     "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
+    "jxg_eigh_dist_staging_doubles": [c_i],
+    "jxg_eigh_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i],
     "jxg_symmetrize_f64": [c_p, c_i, c_p],
     "jxg_transpose_f64": [c_p, c_p, c_i, c_p],
     "jxg_gather_sub_f64": [c_p, c_i, c_i, c_p, c_i, c_p, c_p],
@@ -84,7 +86,7 @@ SIGNATURES = {
                         c_d, c_i, c_d, c_p],
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
-             "jxg_t32_bytes": C.c_int64}
+             "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64}
 
 
 def lib():

@@ -24,6 +24,8 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
                 std::vector<int> &h_perm);
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
+int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
+                   int min_n);
 // k_ormtr.hip: C <- Q C with wide compact-WY blocks (dormtr left / lower / no-transpose)
 int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c);
 constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
@@ -41,6 +43,16 @@ static rocblas_handle get_handle() {
 }  // namespace jx
 
 using namespace jx;
+
+// Node-level distribution of the tridiagonalisation's symv (k_sytrd.hip): every rank calls jxg_eigh_f64 on the same
+// matrix; from `min_n` rows on each rank streams 1 / world of the tiles per column and `allreduce(user)` has to sum the
+// `jxg_eigh_dist_staging_doubles(n)` doubles at `d_staging` over the ranks on the stream passed to jxg_eigh_f64.
+extern "C" int64_t jxg_eigh_dist_staging_doubles(int n) { return 4 * (int64_t)n + 32 * 16 + 2 * 64; }
+
+extern "C" int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
+                                 int64_t staging_doubles, int min_n) {
+    return sytrd_set_dist(rank, world, allreduce, user, d_staging, staging_doubles, min_n);
+}
 
 // d_a: (n,n) symmetric, f64. On return row j of d_a (row-major) = eigenvector j (= column j of the
 // column-major LAPACK result), eigenvalues ascending in d_w.

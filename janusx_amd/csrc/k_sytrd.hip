@@ -55,6 +55,14 @@ struct TdParams {
     double *vbuf;         // (n) scaled reflector of column j
     double *d, *e, *tau;
     TdAcc acc[2];
+    // node-level distribution (sytrd_set_dist): every rank keeps the whole matrix and runs every kernel, but a rank reads
+    // only its 1 / world of the symv tiles.  The replicas must stay BIT-identical (a rank that updated its copy with a y
+    // belonging to slightly different copies diverges by ~7x per column), so in this mode nothing replicated goes through
+    // floating-point atomics: V'v / W'v are accumulated on rank 0 only and travel with the all-reduce, the norm of the next
+    // column is summed in workgroup order by the last workgroup of S(j).
+    int rank = 0, world = 1;
+    double *s1part = nullptr;     // (chunks) per-workgroup partial norms of S(j)
+    unsigned int *s1count = nullptr;
 };
 
 __device__ __forceinline__ double td_sum_s1(const double *s1) {
@@ -80,6 +88,7 @@ __device__ __forceinline__ void larfg_scalars(double alpha0, double xnorm2, int 
 }
 
 // Panel start (column j = j0, no pending updates): d_j, unscaled column -> ubuf, norm^2 -> acc[par].sc[1].
+template <bool DIST>
 __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams P, int j) {
     const int par = j & 1;
     const int r = j + 1 + blockIdx.x * TD_THREADS + threadIdx.x;
@@ -92,12 +101,30 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_panel_start_kernel(TdParams 
     if (blockIdx.x == 0 && threadIdx.x == 0) P.d[j] = P.a[j + (int64_t)j * P.ld];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-    if ((threadIdx.x & 63) == 0 && sq != 0.0)
-        unsafeAtomicAdd(&P.acc[par].s1[((blockIdx.x * 4 + (threadIdx.x >> 6)) & (TD_S1 - 1)) * TD_SL], sq);
+    if (!DIST) {
+        if ((threadIdx.x & 63) == 0 && sq != 0.0)
+            unsafeAtomicAdd(&P.acc[par].s1[((blockIdx.x * 4 + (threadIdx.x >> 6)) & (TD_S1 - 1)) * TD_SL], sq);
+        return;
+    }
+    // distributed form: bit-reproducible norm (per-wave partials in order, summed by the last workgroup)
+    if ((threadIdx.x & 63) == 0) P.s1part[blockIdx.x * 4 + (threadIdx.x >> 6)] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int done = atomicAdd(P.s1count, 1u);
+        if (done == gridDim.x - 1) {
+            __threadfence();
+            double acc_n = 0.0;
+            for (unsigned int b = 0; b < gridDim.x * 4; ++b) acc_n += __builtin_nontemporal_load(&P.s1part[b]);
+            P.acc[par].s1[0] = acc_n;
+            *P.s1count = 0u;
+        }
+    }
 }
 
 // Row-chunk part of B(j) (64 rows per workgroup): scaled reflector out (A, vbuf, Vt), V'v and W'v partial sums,
 // e_j / tau_j.  `scratch` >= 64 + 2 * 4 * 64 doubles of LDS.
+template <bool DIST>
 __device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j0, int chunk, double *scratch) {
     const int par = j & 1;
     const int n = P.n;
@@ -158,7 +185,7 @@ __device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j
         part[0][sub][k] = s1;
         part[1][sub][k] = s2;
         __syncthreads();
-        if (tid < i) {
+        if (tid < i && (!DIST || P.rank == 0)) {   // distributed: rank 0's sums reach the others by the all-reduce
             const double a1 = part[0][0][tid] + part[0][1][tid] + part[0][2][tid] + part[0][3][tid];
             const double a2 = part[1][0][tid] + part[1][1][tid] + part[1][2][tid] + part[1][3][tid];
             if (a1 != 0.0) unsafeAtomicAdd(&P.acc[par].t1[tid], a1);
@@ -172,6 +199,7 @@ __device__ __forceinline__ void sytrd_chunk_path(const TdParams &P, int j, int j
 // tile's 8 x 16-byte loads per thread are issued before the current tile is reduced out of LDS, so every
 // workgroup keeps 32 KB in flight; the row product accumulates in registers across the strip (one atomic per row
 // per strip), the mirrored column product is reduced per tile.
+template <bool DIST>
 __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, int j, int j0, int ktiles,
                                                                 int nstrips) {
     __shared__ __attribute__((aligned(16))) double tile[TD_TS][TD_TS + 2];  // tile[c][r], pitch 66 (16-B rows)
@@ -185,6 +213,9 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
     const int tid = threadIdx.x;
 
     if ((int)blockIdx.x < nstrips) {
+        // distributed form: strips are dealt round-robin to the ranks; one all-reduce between this launch and S(j) sums
+        // the ranks' partial y / v'Tv
+        if (DIST && ((int)blockIdx.x % P.world) != P.rank) return;
         // ---- locate the strip: row block rb (rb+1 tiles), first tile cb0 ---------------------------------
         // uniform decomposition: nsx strips per row block, strips entirely above the diagonal exit at once
         const int side = (nt + TD_TS - 1) / TD_TS;
@@ -294,10 +325,11 @@ __global__ __launch_bounds__(TD_THREADS, 4) void sytrd_symv_kernel(TdParams P, i
         }
         return;
     }
-    sytrd_chunk_path(P, j, j0, blockIdx.x - nstrips, &tile[0][0]);
+    sytrd_chunk_path<DIST>(P, j, j0, blockIdx.x - nstrips, &tile[0][0]);
 }
 
 // S(j): see file header. Four threads per trailing row (16 panel columns each), 64 rows per block.
+template <bool DIST>
 __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, int j, int j0, int do_next) {
     __shared__ double t1s[TD_NB], t2s[TD_NB], vj1[TD_NB], wj1k[TD_NB];
     __shared__ double scal[2];
@@ -417,7 +449,21 @@ __global__ __launch_bounds__(TD_THREADS) void sytrd_update_kernel(TdParams P, in
         __syncthreads();
         if (tid == 0) {
             const double tot = redn[0] + redn[1] + redn[2] + redn[3];
-            if (tot != 0.0) unsafeAtomicAdd(&P.acc[par ^ 1].s1[(blockIdx.x & (TD_S1 - 1)) * TD_SL], tot);
+            if (!DIST) {
+                if (tot != 0.0) unsafeAtomicAdd(&P.acc[par ^ 1].s1[(blockIdx.x & (TD_S1 - 1)) * TD_SL], tot);
+            } else {
+                // bit-reproducible form: partials in workgroup order, summed by whichever workgroup arrives last
+                P.s1part[blockIdx.x] = tot;
+                __threadfence();
+                const unsigned int done = atomicAdd(P.s1count, 1u);
+                if (done == gridDim.x - 1) {
+                    __threadfence();
+                    double acc_n = 0.0;
+                    for (unsigned int b = 0; b < gridDim.x; ++b) acc_n += __builtin_nontemporal_load(&P.s1part[b]);
+                    P.acc[par ^ 1].s1[0] = acc_n;   // the other slots stay zero (cleared by B(j))
+                    *P.s1count = 0u;
+                }
+            }
         }
     }
 }
@@ -428,6 +474,16 @@ __global__ void sytrd_finish_kernel(TdParams P) {
     if (j < P.n - 1) P.a[(j + 1) + (int64_t)j * P.ld] = P.e[j];
     if (j == P.n - 1) P.d[j] = P.a[j + (int64_t)j * P.ld];
 }
+
+struct SytrdDist {
+    int rank = 0, world = 1;
+    int (*allreduce)(void *user) = nullptr;   // sums `staging_doubles` doubles at `staging` over the ranks, on the stream
+    void *user = nullptr;
+    double *staging = nullptr;
+    int64_t staging_doubles = 0;
+    int min_n = 16384;
+};
+static SytrdDist g_dist;
 
 extern float g_last_ms[4];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
 
@@ -440,7 +496,9 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     ScratchLease work;
     const size_t nn = (size_t)n;
     // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
-    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (TD_YC * nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL);
+    const size_t nchunk_max = (nn + TD_TS - 1) / TD_TS;
+    const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (TD_YC * nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL) +
+                           nchunk_max + 8;
     if (work.take(2, sizeof(double) * doubles)) return 1;
     double *p = work.as<double>();
     TdParams P;
@@ -454,16 +512,30 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     P.vbuf = p; p += nn;
     double *acc_begin = p;
     for (int q = 0; q < 2; ++q) {
-        P.acc[q].y = p; p += TD_YC * nn;
+        P.acc[q].y = p; p += TD_YC * nn;           // y, s0, t1, t2 adjacent: one all-reduce in the distributed form
+        P.acc[q].s0 = p; p += TD_S0 * TD_SL;
         P.acc[q].t1 = p; p += TD_NB;
         P.acc[q].t2 = p; p += TD_NB;
-        P.acc[q].s0 = p; p += TD_S0 * TD_SL;
         P.acc[q].s1 = p; p += TD_S1 * TD_SL;
     }
     const size_t acc_bytes = sizeof(double) * (size_t)(p - acc_begin);
+    P.s1part = p; p += nchunk_max;
+    P.s1count = reinterpret_cast<unsigned int *>(p); p += 8;
     P.d = d_d;
     P.e = d_e;
     P.tau = d_tau;
+    const size_t red_doubles = (size_t)TD_YC * nn + (size_t)TD_S0 * TD_SL + 2 * TD_NB;   // [y | s0 | t1 | t2]
+    const bool dist_on = g_dist.world > 1 && g_dist.allreduce && n >= g_dist.min_n &&
+                         g_dist.staging_doubles >= (int64_t)red_doubles;
+    if (dist_on) {
+        JX_HIP(hipMemsetAsync(P.s1count, 0, 8 * sizeof(double), st));
+        P.rank = g_dist.rank;
+        P.world = g_dist.world;
+    }
+    // the single-rank instantiations carry none of the distributed form's branches
+    const auto k_start = dist_on ? sytrd_panel_start_kernel<true> : sytrd_panel_start_kernel<false>;
+    const auto k_symv = dist_on ? sytrd_symv_kernel<true> : sytrd_symv_kernel<false>;
+    const auto k_update = dist_on ? sytrd_update_kernel<true> : sytrd_update_kernel<false>;
     const double minus1 = -1.0, one = 1.0;
     // live roofline sample: the symv launch in the middle of every panel is bracketed by HIP events
     // (one pair per panel = every 64th launch, uniformly spaced over the trailing sizes)
@@ -483,8 +555,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
         JX_HIP(hipMemsetAsync(acc_begin, 0, acc_bytes, st));
         {
             const int rows = n - j0 - 1;
-            hipLaunchKernelGGL(sytrd_panel_start_kernel, dim3((rows + TD_THREADS - 1) / TD_THREADS), dim3(TD_THREADS),
-                               0, st, P, j0);
+            hipLaunchKernelGGL(k_start, dim3((rows + TD_THREADS - 1) / TD_THREADS), dim3(TD_THREADS), 0, st, P, j0);
         }
         for (int i = 0; i < pw; ++i) {
             const int j = j0 + i;
@@ -503,17 +574,23 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             const bool sample = (i == pw / 2);
             if (sample) {
                 // start / stop events bound to this dispatch's own begin / end time stamps (what rocprofv3 reports)
-                hipExtLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st,
+                hipExtLaunchKernelGGL(k_symv, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st,
                                       ev[2 * nsamp], ev[2 * nsamp + 1], 0, P, j, j0, ktiles, nstrips);
             } else {
-                hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
+                hipLaunchKernelGGL(k_symv, dim3(nstrips + nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
                                    ktiles, nstrips);
             }
             if (sample) {
                 samp_bytes += 4.0 * (double)nt * (double)nt + 4.0 * (double)nt;  // lower triangle incl. diagonal, f64
                 ++nsamp;
             }
-            hipLaunchKernelGGL(sytrd_update_kernel, dim3(nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
+            if (dist_on) {   // sum the ranks' partial y / v'Tv (+ rank 0's V'v, W'v): staging copy, collective, copy back
+                double *reg = P.acc[j & 1].y;
+                JX_HIP(hipMemcpyAsync(g_dist.staging, reg, sizeof(double) * red_doubles, hipMemcpyDeviceToDevice, st));
+                if (g_dist.allreduce(g_dist.user)) return fail("sytrd: the all-reduce callback failed");
+                JX_HIP(hipMemcpyAsync(reg, g_dist.staging, sizeof(double) * red_doubles, hipMemcpyDeviceToDevice, st));
+            }
+            hipLaunchKernelGGL(k_update, dim3(nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
                                (i + 1 < pw) ? 1 : 0);
         }
         JX_LAUNCH_CHECK();
@@ -561,6 +638,19 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
                 nsamp ? samp_ms / nsamp * 1e3 : 0.0, pair_ms * 1e3);
     g_last_ms[2] = nsamp ? (float)(samp_ms / nsamp) : 0.f;
     g_last_ms[3] = nsamp ? (float)(samp_bytes / nsamp / 1e6) : 0.f;
+    return 0;
+}
+
+int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
+                   int min_n) {
+    if (world < 1 || rank < 0 || rank >= world) return fail("sytrd_set_dist: bad rank / world");
+    g_dist.rank = rank;
+    g_dist.world = world;
+    g_dist.allreduce = allreduce;
+    g_dist.user = user;
+    g_dist.staging = staging;
+    g_dist.staging_doubles = staging_doubles;
+    if (min_n > 0) g_dist.min_n = min_n;
     return 0;
 }
 

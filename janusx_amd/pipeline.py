@@ -111,6 +111,47 @@ def grm_finalize(acc: torch.Tensor, n: int, scale: float, dtype=torch.float32):
     return out
 
 
+_DIST_EIGH = {}   # keeps the ctypes callback and the staging tensor alive
+
+
+def enable_distributed_eigh(min_n: int = 0):
+    """Shard the tridiagonalisation's symv over the ranks of the initialised torch.distributed group (every rank must
+    then call `eigh_from_grm` on the same matrix): per column each rank streams 1 / world of the trailing-matrix tiles
+    and one all-reduce (RCCL over xGMI with the nccl backend) sums the partial products. Applies from `min_n` rows
+    (default 16384: below that a column is launch-latency-bound and the collective costs more than it saves)."""
+    import ctypes as C
+    import torch.distributed as dist
+    from .dist import allreduce_sum_
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        check(lib().jxg_eigh_set_dist(0, 1, None, None, None, 0, 0))
+        _DIST_EIGH.clear()
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    state = {"staging": None}
+
+    def _cb(_user):
+        try:
+            allreduce_sum_(state["staging"])
+            return 0
+        except Exception as e:   # noqa: BLE001 - reported through the C status
+            import sys
+            print(f"distributed eigh: all-reduce failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(_cb)
+
+    def prepare(n):
+        need = int(lib().jxg_eigh_dist_staging_doubles(int(n)))
+        if state["staging"] is None or state["staging"].numel() != need:
+            state["staging"] = torch.zeros(need, dtype=torch.float64, device=dev)
+            check(lib().jxg_eigh_set_dist(rank, world, C.cast(cb, C.c_void_p), None, _ptr(state["staging"]), need,
+                                          int(min_n)))
+
+    _DIST_EIGH.update(cb=cb, state=state, prepare=prepare)
+    return True
+
+
 def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
     """K (n,n) f32/f64 on device -> (S f64 (k), U^T f64 (k,k) row j = eigenvector j)."""
     dev = k.device
@@ -123,6 +164,8 @@ def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
                                    _stream()))
     check(lib().jxg_symmetrize_f64(_ptr(a), kk, _stream()))
     w = torch.empty(kk, dtype=torch.float64, device=dev)
+    if _DIST_EIGH:
+        _DIST_EIGH["prepare"](kk)   # staging buffer of the per-column all-reduce (sized by n)
     check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
     return w, a
 

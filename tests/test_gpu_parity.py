@@ -1247,3 +1247,25 @@ def test_bench_two_ranks_share_one_gpu():
     assert 11000 < d["config"]["m_kept"] <= 12000 and d["value"] > 0 and 0.0 < d["null"]["pve"] < 1.0
     # single-rank run of the same total panel width keeps a comparable number of SNPs (different random shards)
     assert out.stdout.strip().splitlines()[-1].startswith("{")        # the JSON line is the last line on stdout
+
+
+@pytest.mark.gpu
+def test_distributed_eigh_two_ranks_share_one_gpu():
+    """Rank-sharded tridiagonalisation (jxg_eigh_set_dist): two ranks on the one device, gloo collectives through host
+    memory; scripts/dist_eigh_check.py checks residual / orthogonality / eigenvalues against LAPACK on every rank and
+    that the ranks' results are bit-identical."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", "dist_eigh_check.py"), "700"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_OK n=700 world=2" in out.stdout and "replicas_identical=True" in out.stdout

@@ -211,6 +211,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = args.n
+    # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
+    # the ranks and summed by one all-reduce per column (JXGPU_DIST_EIGH=0 keeps every rank on the whole matrix)
+    eigh_min_n = int(os.environ.get("JXGPU_DIST_EIGH_MIN_N", "16384"))
+    eigh_sharded = bool(world > 1 and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
+                        pl.enable_distributed_eigh(eigh_min_n))
     m = args.m * world if args.scaling == "weak" else args.m   # panel width of the whole job
     # SNP shard of this rank (contiguous range)
     lo = (m * rank) // world
@@ -340,7 +345,7 @@ def main():
             "config": {"workload": f"synthetic HWE panel n={n} m={m} (BASELINE configs[1] shape x{world if args.scaling == 'weak' else 1} SNPs), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
-                       "parallelism": f"snp-shard x{world}"},
+                       "parallelism": f"snp-shard x{world}" + (", eigh symv tiles sharded" if eigh_sharded else "")},
             # the dominant kernel by time (43 % of the GPU time of a step: one launch per column of the
             # tridiagonalisation, profiles/*_kernel_stats.csv)
             "roofline": {"bound": "hbm", "kernel": "sytrd_symv_kernel",

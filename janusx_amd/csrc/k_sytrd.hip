@@ -581,7 +581,8 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
                                    ktiles, nstrips);
             }
             if (sample) {
-                samp_bytes += 4.0 * (double)nt * (double)nt + 4.0 * (double)nt;  // lower triangle incl. diagonal, f64
+                // lower triangle incl. diagonal, f64 (this rank's share of it in the distributed form)
+                samp_bytes += (4.0 * (double)nt * (double)nt + 4.0 * (double)nt) / (double)P.world;
                 ++nsamp;
             }
             if (dist_on) {   // sum the ranks' partial y / v'Tv (+ rank 0's V'v, W'v): staging copy, collective, copy back

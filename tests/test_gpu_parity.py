@@ -1235,7 +1235,8 @@ def test_bench_two_ranks_share_one_gpu():
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo")
+    # JXGPU_DIST_EIGH_MIN_N: also deal the tridiagonalisation's symv tiles over the two ranks at this small size
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo", JXGPU_DIST_EIGH_MIN_N="512")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--samples", "1000",
            "--snps", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
@@ -1244,6 +1245,7 @@ def test_bench_two_ranks_share_one_gpu():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["m"] == 12000
+    assert "eigh symv tiles sharded" in d["config"]["parallelism"]
     assert 11000 < d["config"]["m_kept"] <= 12000 and d["value"] > 0 and 0.0 < d["null"]["pve"] < 1.0
     # single-rank run of the same total panel width keeps a comparable number of SNPs (different random shards)
     assert out.stdout.strip().splitlines()[-1].startswith("{")        # the JSON line is the last line on stdout

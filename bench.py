@@ -214,7 +214,8 @@ def main():
     # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
     # the ranks and summed by one all-reduce per column (JXGPU_DIST_EIGH=0 keeps every rank on the whole matrix)
     eigh_min_n = int(os.environ.get("JXGPU_DIST_EIGH_MIN_N", "16384"))
-    eigh_sharded = bool(world > 1 and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
+    eigh_ranks = world > 1 or (distributed and os.environ.get("JXGPU_DIST_EIGH_FORCE", "0") != "0")
+    eigh_sharded = bool(eigh_ranks and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
                         pl.enable_distributed_eigh(eigh_min_n))
     m = args.m * world if args.scaling == "weak" else args.m   # panel width of the whole job
     # SNP shard of this rank (contiguous range)

@@ -498,7 +498,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     // w (n*NB) + vt (n*NB) + wt (n*NB) + ubuf (n) + vbuf (n) + 2 * (y (n) + t1 (NB) + t2 (NB) + sc (2))
     const size_t nchunk_max = (nn + TD_TS - 1) / TD_TS;
     const size_t doubles = 3 * nn * TD_NB + 2 * nn + 2 * (TD_YC * nn + 2 * TD_NB + (TD_S0 + TD_S1) * TD_SL) +
-                           nchunk_max + 8;
+                           (nchunk_max + 4) + 8;
     if (work.take(2, sizeof(double) * doubles)) return 1;
     double *p = work.as<double>();
     TdParams P;
@@ -519,13 +519,16 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
         P.acc[q].s1 = p; p += TD_S1 * TD_SL;
     }
     const size_t acc_bytes = sizeof(double) * (size_t)(p - acc_begin);
-    P.s1part = p; p += nchunk_max;
+    P.s1part = p; p += nchunk_max + 4;   // panel start: one partial per wave of ceil(rows / 256) workgroups
     P.s1count = reinterpret_cast<unsigned int *>(p); p += 8;
     P.d = d_d;
     P.e = d_e;
     P.tau = d_tau;
     const size_t red_doubles = (size_t)TD_YC * nn + (size_t)TD_S0 * TD_SL + 2 * TD_NB;   // [y | s0 | t1 | t2]
-    const bool dist_on = g_dist.world > 1 && g_dist.allreduce && n >= g_dist.min_n &&
+    // JXGPU_DIST_EIGH_FORCE: run the distributed instantiation and the collective with a single rank too (how the RCCL
+    // callback path is exercised on a one-GPU box)
+    static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
+    const bool dist_on = (g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n &&
                          g_dist.staging_doubles >= (int64_t)red_doubles;
     if (dist_on) {
         JX_HIP(hipMemsetAsync(P.s1count, 0, 8 * sizeof(double), st));

@@ -1271,3 +1271,28 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=700 world=2" in out.stdout and "replicas_identical=True" in out.stdout
+
+
+@pytest.mark.gpu
+def test_distributed_eigh_rccl_callback_single_rank():
+    """The per-column all-reduce of the rank-sharded tridiagonalisation through RCCL (nccl backend) with one rank:
+    JXGPU_DIST_EIGH_FORCE runs the distributed kernel instantiation and the torch.distributed callback on the one-GPU
+    box; the null fit must agree with the plain single-rank run of the same panel."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for on in ("1", "0"):
+        env = dict(os.environ, JXGPU_BENCH_FORCE_DIST="1", JXGPU_DIST_EIGH_FORCE="1", JXGPU_DIST_EIGH_MIN_N="512",
+                   JXGPU_DIST_EIGH=on, MASTER_PORT="29547")
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--samples", "1200", "--snps", "5000", "--steps", "1",
+               "--warmup", "0", "--no-cpu-baseline"]
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[on] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "eigh symv tiles sharded" in res["1"]["config"]["parallelism"]
+    assert "eigh symv tiles sharded" not in res["0"]["config"]["parallelism"]
+    assert abs(res["1"]["null"]["lbd"] - res["0"]["null"]["lbd"]) <= 1e-6 * res["0"]["null"]["lbd"]
+    assert res["1"]["config"]["m_kept"] == res["0"]["config"]["m_kept"]

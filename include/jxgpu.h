@@ -71,6 +71,19 @@ int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const i
 int jxg_grm_finalize(const double *d_acc, int n, double inv_scale, void *d_out, int out_is_f64,
                      void *stream);
 
+/* A6 (next row 8f-3). Sparse GRM: threshold + order-preserving compaction of the accumulator into the lower-triangle
+ * CSC image of the reference's `.spgrm` file (`compute_spgrm_task_entries`, src/stats/spgrm.rs:3422-3554; keep rule
+ * `spgrm_keep_value` :1956-1965 — diagonal always, |v| > thr with abs_threshold, everything for thr < 0, else v > thr;
+ * order (col, row) as `spgrm_entry_cmp` :1401; layout `coo_lower_to_csc` :3637-3683).
+ * jxg_spgrm_count fills d_colptr (n + 1, u64; d_colptr[n] = nnz) and the per-band offsets in d_work
+ * (jxg_spgrm_work_bytes(n) bytes), synchronises, and fails on a non-finite value as the reference does;
+ * jxg_spgrm_fill writes d_rows (nnz, u32) and d_vals (nnz, f64 = acc * inv_scale). */
+int64_t jxg_spgrm_work_bytes(int n);
+int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold, void *d_work,
+                    uint64_t *d_colptr, void *stream);
+int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                   const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals, void *stream);
+
 /* B1. symmetric eigendecomposition, f64, ascending.  d_a (n,n) is overwritten with U^T row-major
  * (row j = eigenvector j); d_w receives the n eigenvalues.  Replaces LAPACK dsyevd/dsyevr behind
  * src/math/eigh.rs:1422-1528: own Householder tridiagonalisation (k_sytrd.hip), divide and conquer (k_stedc.hip) and
@@ -343,6 +356,17 @@ int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, 
                          const double *y_train, const int64_t *test_idx, int n_test, double lambda_value, double tol,
                          int max_iter, float *out_beta, double *out_pred_train, double *out_pred_test,
                          double *out_scalars);
+
+/* `spgrm_packed_to_jxgrm` (src/stats/spgrm.rs:5201-5278 -> `spgrm_packed_to_jxgrm_core` :3769-3908) and, with
+ * stream_denominator != 0, the stream core behind `spgrm_bed_to_jxgrm` (:3910-4264: denominator = sum of 2p(1-p) in
+ * f64 whatever the sample selection, :3973-3989): GRM accumulation as jx_grm_packed, then A6; writes the file
+ * (`write_sparse_grm_csc` :3745-3767: u64 n, u64 nnz, col_ptr u64 (n+1), row_indices u32 (nnz), zero padding to an
+ * 8-byte boundary, values f64 (nnz), little endian) at out_path (already normalised, `normalize_spgrm_path` :450-469
+ * is done by the caller).  Errors carry the reference's messages (`validate_spgrm_inputs` :2858-2915). */
+int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                             const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
+                             double threshold, int abs_threshold, int stream_denominator, const char *out_path,
+                             int64_t *out_n, int64_t *out_nnz);
 
 /* Haseman-Elston sufficient statistics over the same matrix-free operator (`he_pcg_bed`, src/stats/he.rs:1633-2070,
  * 2101-2636): K = Z'Z / m_scale on the training samples, P the projector off [1, x_cov] (x_cov (n_train, p_cov)

@@ -31,6 +31,9 @@ SIGNATURES = {
     "jxg_row_counts_p32": [c_p, c_l, c_i, c_p, c_p],
     "jxg_grm_accumulate": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "jxg_grm_finalize": [c_p, c_i, c_d, c_p, c_i, c_p],
+    "jxg_spgrm_work_bytes": [c_i],
+    "jxg_spgrm_count": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p],
+    "jxg_spgrm_fill": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p, c_p],
     "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
     "jxg_eigh_dist_staging_doubles": [c_i],
     "jxg_eigh_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i],
@@ -80,13 +83,15 @@ SIGNATURES = {
     "jx_lmm_reml_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_i, c_d, c_i, c_d, c_p],
     "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_i, c_d, c_p],
     "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
+    "jx_spgrm_packed_to_jxgrm": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_i, c_i, C.c_char_p, c_p, c_p],
     "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
-             "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64}
+             "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,
+             "jxg_spgrm_work_bytes": C.c_int64}
 
 
 def lib():

@@ -10,7 +10,7 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -rrBLUP [-lambda L] [-tol 1e-4] [-max-iter 100] [-cv K]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`;
+Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
 `{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
@@ -95,6 +95,17 @@ def cmd_grm(args):
     from .bed import read_fam_ids
     out = args.out or args.bfile
     t0 = time.perf_counter()
+    if args.sparse is not None:
+        # python/janusx/script/grm.py:1574-1675 (`-sparse [cutoff]`): thresholded lower-triangle CSC `.spgrm` + `.id`
+        path, n, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=args.method,
+                                               threshold=float(args.sparse), maf_threshold=args.maf,
+                                               max_missing_rate=args.geno, het_threshold=0.0)
+        with open(path + ".id", "w") as fh:
+            for sid in read_fam_ids(args.bfile):
+                fh.write(f"{sid}\n")
+        print(f"Sparse GRM method {args.method}: n={n} nnz={nnz} cutoff={args.sparse} -> {path} "
+              f"({time.perf_counter() - t0:.2f}s)")
+        return 0
     k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
                                         max_missing_rate=args.geno, het_threshold=0.0)
     tag = "cGRM" if args.method == 1 else "sGRM"
@@ -356,6 +367,8 @@ def main(argv=None):
     r.add_argument("-maf", "--maf", type=float, default=0.02)
     r.add_argument("-geno", "--geno", type=float, default=0.05)
     r.add_argument("-o", "--out", default=None)
+    r.add_argument("-sparse", "--sparse", nargs="?", const=0.05, default=None, type=float,
+                   help="write a sparse `.spgrm` keeping off-diagonal kinship > cutoff (negative: keep everything)")
     r.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     r.set_defaults(func=cmd_grm)
     q = sub.add_parser("gs")

@@ -2,6 +2,7 @@
 // HBM and drive the device layer; per-SNP statistics / filter logic (integer counts -> f32/f64 decisions) is
 // done on the host exactly as the reference writes it, so the kept-SNP set is bit-exact.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -249,6 +250,86 @@ extern "C" int jx_grm_packed(const uint8_t *packed, int64_t m, int n_samples, co
     if (jxg_grm_finalize(acc.as<double>(), n, 1.0 / D, dout.p, out_is_f64, nullptr)) return 1;
     JX_HIP(hipMemcpy(out_k, dout.p, esz * (size_t)n * (size_t)n, hipMemcpyDeviceToHost));
     if (out_varsum) *out_varsum = (method == 1) ? D : (double)m;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// spgrm_packed_to_jxgrm / the stream core behind spgrm_bed_to_jxgrm (src/stats/spgrm.rs:3769-3908, 3910-4264)
+// ---------------------------------------------------------------------------------------------------
+extern "C" int64_t jxg_spgrm_work_bytes(int n);
+extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                               void *d_work, uint64_t *d_colptr, void *stream);
+extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                              const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
+                              void *stream);
+
+extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                                        const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
+                                        double threshold, int abs_threshold, int stream_denominator,
+                                        const char *out_path, int64_t *out_n, int64_t *out_nnz) {
+    // validate_spgrm_inputs (spgrm.rs:2858-2915)
+    if (n_samples <= 0) return fail("Sparse GRM requires n_samples > 0");
+    if (method != 1 && method != 2)
+        return fail("Sparse GRM method must be 1 (centered) or 2 (standardized); got " + std::to_string(method));
+    if (!isfinite(threshold)) return fail("Sparse GRM threshold must be finite");
+    if (sample_indices && n_sel <= 0) return fail("Sparse GRM sample_indices must not be empty");
+    if (m <= 0) return fail("Sparse GRM requires at least one SNP row");
+    if (!out_path || !out_path[0]) return fail("Sparse GRM output prefix must not be empty");
+    SampleSel sel;
+    if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
+    const int n = sel.n;
+    // packed route: `centered_varsum_from_packed` (:2917-2979); stream route: sum of 2p(1-p) in f64 whatever the
+    // sample selection (:3973-3989)
+    const double D = grm_varsum(row_maf, m, method, sel.identity || stream_denominator != 0);
+    if (!(isfinite(D) && D > 0.0))
+        return fail(method == 1 ? "Sparse GRM centered denominator is not positive"
+                                : "Sparse GRM denominator is not positive");
+    std::vector<float> lut((size_t)m * 4);
+    for (int64_t j = 0; j < m; ++j) grm_lut_from_maf(row_maf[j], row_flip[j] != 0, method, &lut[(size_t)j * 4]);
+    DevBuf p32, dlut, acc, work, dcolptr, drows, dvals;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    if (dlut.alloc(lut.size() * sizeof(float))) return 1;
+    JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
+    if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
+    JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
+    if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, nullptr))
+        return 1;
+    p32.release();
+    if (work.alloc((size_t)jxg_spgrm_work_bytes(n))) return 1;
+    if (dcolptr.alloc(sizeof(uint64_t) * ((size_t)n + 1))) return 1;
+    const double inv = 1.0 / D;
+    if (jxg_spgrm_count(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(), nullptr))
+        return 1;
+    std::vector<uint64_t> colptr((size_t)n + 1);
+    JX_HIP(hipMemcpy(colptr.data(), dcolptr.p, sizeof(uint64_t) * colptr.size(), hipMemcpyDeviceToHost));
+    const uint64_t nnz = colptr[(size_t)n];
+    std::vector<uint32_t> rows((size_t)nnz);
+    std::vector<double> vals((size_t)nnz);
+    if (nnz) {
+        if (drows.alloc(sizeof(uint32_t) * (size_t)nnz) || dvals.alloc(sizeof(double) * (size_t)nnz)) return 1;
+        if (jxg_spgrm_fill(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(),
+                           drows.as<uint32_t>(), dvals.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(rows.data(), drows.p, sizeof(uint32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+        JX_HIP(hipMemcpy(vals.data(), dvals.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+    }
+    // write_sparse_grm_csc (:3745-3767): u64 n, u64 nnz, col_ptr, row_indices, zero padding to 8 bytes, values (LE)
+    FILE *fh = fopen(out_path, "wb");
+    if (!fh) return fail(std::string("create ") + out_path + " failed");
+    const uint64_t hdr[2] = {(uint64_t)n, nnz};
+    const size_t pad = (size_t)((8 - ((nnz * 4) & 7)) & 7);
+    const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = fwrite(hdr, 8, 2, fh) == 2 && fwrite(colptr.data(), 8, colptr.size(), fh) == colptr.size() &&
+              fwrite(rows.data(), 4, rows.size(), fh) == rows.size() && fwrite(zeros, 1, pad, fh) == pad &&
+              fwrite(vals.data(), 8, vals.size(), fh) == vals.size();
+    ok = (fclose(fh) == 0) && ok;
+    if (!ok) {
+        remove(out_path);
+        return fail(std::string("write sparse GRM file failed: ") + out_path);
+    }
+    if (out_n) *out_n = n;
+    if (out_nnz) *out_nnz = (int64_t)nnz;
     return 0;
 }
 

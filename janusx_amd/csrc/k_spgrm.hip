@@ -1,0 +1,150 @@
+// Sparse GRM (first half of `-splmm`): threshold + compaction of the f64 GRM accumulator into the
+// lower-triangle CSC image of the reference's `.spgrm` file.
+//
+// Reference: `compute_spgrm_task_entries` (src/stats/spgrm.rs:3422-3554): per sample-tile pair the f32 GEMM blocks are
+// merged in f64, `scaled = acc * inv_scale`, an entry (row >= col) is kept when it is on the diagonal or passes
+// `spgrm_keep_value` (:1956-1965: |v| > thr with abs_threshold, everything when thr < 0, else v > thr); a non-finite
+// value is an error; entries are ordered by (col, row) (`spgrm_entry_cmp` :1401) and laid out as col_ptr u64 /
+// row_indices u32 / values f64 (`coo_lower_to_csc` :3637-3683, `write_sparse_grm_csc` :3745-3767).
+//
+// Here the accumulator is the one `jxg_grm_accumulate` leaves in HBM (row-major, lower triangle valid, leading
+// dimension num_tiles(n) * 128), so the whole matrix is thresholded in place: HBM-bound, two streaming passes over the
+// lower triangle (count, fill; 8 n^2 bytes together), 256 columns x 256 rows per workgroup with the wave reading 512
+// contiguous bytes of one accumulator row per step; every thread owns one column of its band and walks the rows in
+// order, so the compaction is order-preserving without a sort: entry position = col_ptr[col] + (entries of the bands
+// above in that column) + running count.
+#include <math.h>
+#include <stdint.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int SG_T = 256;      // threads = columns per workgroup
+constexpr int SG_BAND = 256;   // rows per band
+
+__device__ __forceinline__ bool spgrm_keep(double v, double thr, int abs_thr) {
+    if (abs_thr) return fabs(v) > thr;
+    if (thr < 0.0) return true;
+    return v > thr;
+}
+
+// FILL = false: d_cnt[band][col] = kept entries of (band, col); FILL = true: write them at their final position.
+template <bool FILL>
+__global__ __launch_bounds__(SG_T) void spgrm_band_kernel(const double *__restrict__ acc, int64_t ld, int n,
+                                                          double inv_scale, double thr, int abs_thr,
+                                                          int32_t *__restrict__ cnt,
+                                                          const uint64_t *__restrict__ colptr,
+                                                          uint32_t *__restrict__ rows, double *__restrict__ vals,
+                                                          int *__restrict__ flag) {
+    const int c = blockIdx.x * SG_T + threadIdx.x;
+    const int band = blockIdx.y;
+    if (c >= n) return;
+    const int r_lo = band * SG_BAND;
+    const int r_hi = (r_lo + SG_BAND < n) ? (r_lo + SG_BAND) : n;
+    int kept = 0;
+    uint64_t pos = 0;
+    if (FILL) pos = colptr[c] + (uint64_t)cnt[(int64_t)band * n + c];
+    bool bad = false;
+    const int r0 = (c > r_lo) ? c : r_lo;   // lower triangle: row >= col
+    const double *p = acc + (int64_t)r0 * ld + c;
+#pragma unroll 8
+    for (int r = r0; r < r_hi; ++r, p += ld) {
+        const double v = __builtin_nontemporal_load(p) * inv_scale;
+        bad |= !isfinite(v);
+        if (r == c || spgrm_keep(v, thr, abs_thr)) {
+            if (FILL) {
+                rows[pos] = (uint32_t)r;
+                vals[pos] = v;
+                ++pos;
+            } else {
+                ++kept;
+            }
+        }
+    }
+    if (!FILL) {
+        cnt[(int64_t)band * n + c] = kept;
+        if (bad) atomicOr(flag, 1);
+    }
+}
+
+// per column: counts of the bands -> exclusive prefix over the bands (in place), column total -> colptr[col + 1]
+__global__ void spgrm_band_prefix_kernel(int32_t *__restrict__ cnt, int n, int nbands, uint64_t *__restrict__ colptr) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    uint64_t run = 0;
+    for (int b = c / SG_BAND; b < nbands; ++b) {   // bands above the diagonal hold no entry of this column
+        const int64_t at = (int64_t)b * n + c;
+        const int32_t k = cnt[at];
+        cnt[at] = (int32_t)run;
+        run += (uint64_t)k;
+    }
+    colptr[c + 1] = run;
+    if (c == 0) colptr[0] = 0;
+}
+
+// one workgroup: inclusive scan of colptr[1..n] (column totals) in place
+__global__ __launch_bounds__(1024) void spgrm_colptr_scan_kernel(uint64_t *__restrict__ colptr, int n) {
+    __shared__ uint64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = t * per, hi = (lo + per < n) ? (lo + per) : n;
+    uint64_t s = 0;
+    for (int c = lo; c < hi; ++c) s += colptr[c + 1];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint64_t add = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint64_t run = (t > 0) ? part[t - 1] : 0;
+    for (int c = lo; c < hi; ++c) {
+        run += colptr[c + 1];
+        colptr[c + 1] = run;
+    }
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+static inline int spgrm_bands(int n) { return (n + SG_BAND - 1) / SG_BAND; }
+
+extern "C" int64_t jxg_spgrm_work_bytes(int n) { return (int64_t)spgrm_bands(n) * (int64_t)n * 4 + 16; }
+
+extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                               void *d_work, uint64_t *d_colptr, void *stream) {
+    if (n <= 0) return fail("jxg_spgrm_count: n must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = spgrm_bands(n);
+    const int64_t ld = (int64_t)num_tiles(n) * JXG_TILE;
+    int32_t *cnt = (int32_t *)d_work;
+    int *flag = (int *)((char *)d_work + (int64_t)nb * n * 4);
+    JX_HIP(hipMemsetAsync(flag, 0, 16, st));
+    hipLaunchKernelGGL(spgrm_band_kernel<false>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, st, d_acc, ld, n,
+                       inv_scale, threshold, abs_threshold, cnt, (const uint64_t *)nullptr, (uint32_t *)nullptr,
+                       (double *)nullptr, flag);
+    hipLaunchKernelGGL(spgrm_band_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, n, nb, d_colptr);
+    hipLaunchKernelGGL(spgrm_colptr_scan_kernel, dim3(1), dim3(1024), 0, st, d_colptr, n);
+    JX_LAUNCH_CHECK();
+    int hflag = 0;
+    JX_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    if (hflag) return fail("Sparse GRM produced non-finite value");
+    return 0;
+}
+
+extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                              const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
+                              void *stream) {
+    if (n <= 0) return fail("jxg_spgrm_fill: n must be > 0");
+    const int nb = spgrm_bands(n);
+    const int64_t ld = (int64_t)num_tiles(n) * JXG_TILE;
+    hipLaunchKernelGGL(spgrm_band_kernel<true>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, (hipStream_t)stream,
+                       d_acc, ld, n, inv_scale, threshold, abs_threshold, (int32_t *)d_work, d_colptr, d_rows, d_vals,
+                       (int *)nullptr);
+    JX_LAUNCH_CHECK();
+    return 0;
+}

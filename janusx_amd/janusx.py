@@ -103,6 +103,122 @@ def grm_packed_f64_with_stats(packed, n_samples, row_flip, row_maf, sample_indic
     return k, rs, vs
 
 
+def _normalize_spgrm_path(prefix):
+    """src/stats/spgrm.rs:450-469."""
+    t = str(prefix).strip()
+    if not t:
+        return ""
+    if t.lower().endswith(".spgrm") or t.lower().endswith(".jxgrm"):
+        return t
+    if os.path.exists(t + ".jxgrm") and not os.path.exists(t + ".spgrm"):
+        return t + ".jxgrm"
+    return t + ".spgrm"
+
+
+def _spgrm_packed(packed, n_samples, row_flip, row_maf, out_prefix, sample_indices, method, threshold, abs_threshold,
+                  stream_denominator):
+    pk = _c(packed, np.uint8)
+    if pk.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    n_samples = int(n_samples)
+    if pk.shape[1] != (n_samples + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1]}, expected {(n_samples + 3) // 4}")
+    flip = np.ascontiguousarray(np.asarray(row_flip).astype(np.uint8)).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    m = int(flip.shape[0])
+    if m and maf.shape[0] != m:
+        raise RuntimeError(f"Sparse GRM row_maf length mismatch: got {maf.shape[0]}, expected {m}")
+    if m and pk.shape[0] != m:
+        raise RuntimeError(f"Sparse GRM packed length mismatch: got {pk.size}, expected {m * pk.shape[1]}")
+    idx, n_sel = _opt_idx(sample_indices)
+    if sample_indices is not None and n_sel == 0:
+        raise RuntimeError("Sparse GRM sample_indices must not be empty")
+    out_path = _normalize_spgrm_path(out_prefix)
+    if not out_path:
+        raise RuntimeError("Sparse GRM output prefix must not be empty")
+    out_n, out_nnz = C.c_int64(0), C.c_int64(0)
+    check(lib().jx_spgrm_packed_to_jxgrm(_p(pk), m, n_samples, _p(flip), _p(maf), _p(idx) if idx is not None else None,
+                                         n_sel, int(method), float(threshold), int(bool(abs_threshold)),
+                                         int(bool(stream_denominator)), out_path.encode(), C.byref(out_n),
+                                         C.byref(out_nnz)))
+    return out_path, int(out_n.value), int(out_nnz.value)
+
+
+def spgrm_packed_to_jxgrm(packed, n_samples, row_flip, row_maf, out_prefix, sample_indices=None, method=1,
+                          threshold=0.05, abs_threshold=False, block_rows=0, sample_block=0, threads=0,
+                          progress_callback=None, progress_every=0):
+    """src/stats/spgrm.rs:5201-5278: sparse (thresholded, lower-triangle CSC) GRM of a packed panel written as
+    `<out_prefix>.spgrm` -> (path, n_samples_used, nnz).  The tile / spill planning arguments of the reference
+    (block_rows, sample_block, threads) have no counterpart: the whole accumulator lives in HBM."""
+    out = _spgrm_packed(packed, n_samples, row_flip, row_maf, out_prefix, sample_indices, method, threshold,
+                        abs_threshold, False)
+    if progress_callback is not None:
+        progress_callback(1, 1)
+    return out
+
+
+def spgrm_bed_to_jxgrm(prefix, out_prefix=None, sample_indices=None, method=1, threshold=0.05, abs_threshold=False,
+                       maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0, snps_only=False, block_rows=0,
+                       sample_block=0, threads=0, mmap_window_mb=None, progress_callback=None, progress_every=0):
+    """src/stats/spgrm.rs:5280-5356 -> `spgrm_bed_to_jxgrm_core` :4937-5025: metadata pre-pass over the selected
+    samples (`prepare_bed_logic_meta_owned_for_stats_samples_with_mmap_window`, src/io/gfreader.rs:5236-5480: the
+    packed-prep QC rule, maf := alt allele frequency, no flips), then the stream core (:3910-4264) whose centred
+    denominator is the f64 sum of 2p(1-p) whatever the sample selection.  -> (path, n_samples_used, nnz)."""
+    from . import stats as st
+    from .bed import read_bed_payload, snps_only_mask
+    if not (0.0 <= maf_threshold <= 0.5):
+        raise RuntimeError("maf_threshold must be within [0, 0.5]")
+    if not (0.0 <= max_missing_rate <= 1.0):
+        raise RuntimeError("max_missing_rate must be within [0, 1.0]")
+    if not (0.0 <= het_threshold <= 1.0):
+        raise RuntimeError("het_threshold must be within [0, 1.0]")
+    bed_prefix = str(prefix).strip()
+    if bed_prefix.lower().endswith((".bed", ".bim", ".fam")):
+        bed_prefix = bed_prefix[:-4]
+    if not bed_prefix:
+        raise RuntimeError("Sparse GRM BED prefix must not be empty")
+    packed, n_fam, bim = read_bed_payload(bed_prefix)
+    if n_fam == 0:
+        raise RuntimeError("No samples found in BED input.")
+    idx, n_sel = _opt_idx(sample_indices)
+    if idx is not None and n_sel and (idx.min() < 0 or idx.max() >= n_fam):
+        raise RuntimeError("selected sample index out of range for BED logic preparation")
+    n_stats = n_sel if (idx is not None and n_sel) else n_fam
+    counts = bed_row_counts(packed, n_fam, idx if (idx is not None and n_sel) else None)
+    keep, _miss, maf, _std = st.packed_prep_row_stats(counts, n_stats, np.float32(maf_threshold),
+                                                      np.float32(max_missing_rate), np.float32(het_threshold))
+    if snps_only:
+        keep &= snps_only_mask(bim)
+    if not keep.any():
+        raise RuntimeError("No SNPs left after packed BED filtering. Please relax thresholds.")
+    rows = np.nonzero(keep)[0]
+    out = _spgrm_packed(np.ascontiguousarray(packed[rows]), n_fam, np.zeros(len(rows), dtype=bool), maf[rows],
+                        out_prefix if out_prefix is not None else bed_prefix,
+                        idx if (idx is not None and n_sel) else None, method, threshold, abs_threshold, True)
+    if progress_callback is not None:
+        progress_callback(1, 1)
+    return out
+
+
+def load_spgrm(path):
+    """Reader of the `.spgrm` layout (`write_sparse_grm_csc`, src/stats/spgrm.rs:3745-3767)
+    -> (n, col_ptr u64 (n+1), row_indices u32 (nnz), values f64 (nnz))."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size < 16:
+        raise RuntimeError(f"sparse GRM file too small: {path}")
+    n, nnz = (int(v) for v in raw[:16].view("<u8"))
+    at = 16
+    need = at + 8 * (n + 1) + 4 * nnz + ((-(4 * nnz)) % 8) + 8 * nnz
+    if raw.size != need:
+        raise RuntimeError(f"sparse GRM file length mismatch: got {raw.size}, expected {need}")
+    col_ptr = raw[at:at + 8 * (n + 1)].view("<u8").copy()
+    at += 8 * (n + 1)
+    rows = raw[at:at + 4 * nnz].view("<u4").copy()
+    at += 4 * nnz + ((-(4 * nnz)) % 8)
+    vals = raw[at:at + 8 * nnz].view("<f8").copy()
+    return n, col_ptr, rows, vals
+
+
 def _read_bed_payload(prefix):
     """PLINK .bed payload as (m, bps) uint8 plus n_samples (src/stats/lmm.rs:1050-1061, gfcore.rs:307-323)."""
     from .bed import read_bed_payload

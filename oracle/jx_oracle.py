@@ -310,6 +310,116 @@ def grm_packed(packed, n_samples, row_flip, row_maf, sample_idx=None, method=1, 
     return k.astype(out_dtype), D
 
 
+def spgrm_keep_value(value: float, threshold: float, abs_threshold: bool) -> bool:
+    """Off-diagonal keep rule of the sparse GRM (src/stats/spgrm.rs:1956-1965; tests :6618-6630)."""
+    if abs_threshold:
+        return abs(value) > threshold
+    if threshold < 0.0:
+        return True
+    return value > threshold
+
+
+def sparse_grm_csc_from_packed(packed, n_samples, row_flip, row_maf, sample_idx=None, method=1, threshold=0.05,
+                               abs_threshold=False, stream_denominator=False, block_rows=65536):
+    """Sparse GRM of `spgrm_packed_to_jxgrm` / `sparse_grm_coo_from_packed` + `coo_lower_to_csc`
+    (src/stats/spgrm.rs:3769-3908, 3556-3683): validation `validate_spgrm_inputs` (:2858-2915); denominator
+    `centered_varsum_from_packed` (:2917-2979: full sample -> sum of 2p(1-p) in f64, subset -> the decode's f32
+    `var_global_centered` sums) or, for the stream core behind `spgrm_bed_to_jxgrm`, always the f64 sum (:3973-3989);
+    per sample-tile pair f32 GEMM blocks merged in f64, `scaled = acc * (1 / denom)`, entry kept on the diagonal or by
+    `spgrm_keep_value`, non-finite -> error (`compute_spgrm_task_entries` :3422-3554); (col, row) order (:1401).
+    Returns (col_ptr u64 (n+1), row_indices u32 (nnz), values f64 (nnz))."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    if n_samples == 0:
+        raise RuntimeError("Sparse GRM requires n_samples > 0")
+    if method not in (1, 2):
+        raise RuntimeError(f"Sparse GRM method must be 1 (centered) or 2 (standardized); got {method}")
+    if not math.isfinite(threshold):
+        raise RuntimeError("Sparse GRM threshold must be finite")
+    if sample_idx is not None and len(sample_idx) == 0:
+        raise RuntimeError("Sparse GRM sample_indices must not be empty")
+    m = len(row_flip)
+    if m == 0:
+        raise RuntimeError("Sparse GRM requires at least one SNP row")
+    if len(row_maf) != m:
+        raise RuntimeError(f"Sparse GRM row_maf length mismatch: got {len(row_maf)}, expected {m}")
+    full = sample_idx is None or (len(sample_idx) == n_samples and
+                                  np.array_equal(np.asarray(sample_idx), np.arange(n_samples)))
+    n = n_samples if sample_idx is None else len(sample_idx)
+    denom = grm_varsum(row_maf, method, full or stream_denominator, n)
+    if not (math.isfinite(denom) and denom > 0.0):
+        raise RuntimeError("Sparse GRM centered denominator is not positive" if method == 1
+                           else "Sparse GRM denominator is not positive")
+    acc = np.zeros((n, n), dtype=np.float64)
+    for r0 in range(0, m, max(1, int(block_rows))):
+        r1 = min(m, r0 + max(1, int(block_rows)))
+        z = decode_grm_block_f32(packed, n_samples, row_flip, row_maf, None if full else sample_idx, method, r0, r1)
+        acc += (z.T @ z).astype(np.float64)        # f32 GEMM per SNP block, f64 merge
+    scaled = acc * (1.0 / denom)
+    if not np.isfinite(scaled).all():
+        raise RuntimeError("Sparse GRM produced non-finite value")
+    col_ptr = np.zeros(n + 1, dtype=np.uint64)
+    rows_out, vals_out = [], []
+    for c in range(n):
+        col = scaled[c:, c]
+        if abs_threshold:
+            keep = np.abs(col) > threshold
+        elif threshold < 0.0:
+            keep = np.ones(col.shape, dtype=bool)
+        else:
+            keep = col > threshold
+        keep[0] = True                             # the diagonal is always stored
+        r = np.nonzero(keep)[0]
+        rows_out.append((r + c).astype(np.uint32))
+        vals_out.append(col[r])
+        col_ptr[c + 1] = col_ptr[c] + np.uint64(len(r))
+    return col_ptr, np.concatenate(rows_out), np.concatenate(vals_out).astype(np.float64)
+
+
+def normalize_spgrm_path(prefix: str) -> str:
+    """Output path of the sparse GRM (src/stats/spgrm.rs:450-469)."""
+    import os
+    t = prefix.strip()
+    if not t:
+        return ""
+    if t.lower().endswith(".spgrm") or t.lower().endswith(".jxgrm"):
+        return t
+    if os.path.exists(t + ".jxgrm") and not os.path.exists(t + ".spgrm"):
+        return t + ".jxgrm"
+    return t + ".spgrm"
+
+
+def write_sparse_grm_csc(path, n_samples, col_ptr, row_indices, values):
+    """`.spgrm` layout (src/stats/spgrm.rs:3745-3767; padding :810-820): u64 n, u64 nnz, col_ptr u64 (n+1),
+    row_indices u32 (nnz), zero padding up to a multiple of 8 bytes of the row payload, values f64 (nnz); LE."""
+    nnz = len(values)
+    pad = (-(nnz * 4)) % 8
+    with open(path, "wb") as fh:
+        fh.write(np.array([n_samples, nnz], dtype="<u8").tobytes())
+        fh.write(np.asarray(col_ptr, dtype="<u8").tobytes())
+        fh.write(np.asarray(row_indices, dtype="<u4").tobytes())
+        fh.write(b"\0" * pad)
+        fh.write(np.asarray(values, dtype="<f8").tobytes())
+
+
+def read_sparse_grm_csc(path):
+    """Inverse of `write_sparse_grm_csc` -> (n, col_ptr, row_indices, values); checks the total length."""
+    raw = open(path, "rb").read()
+    n, nnz = (int(v) for v in np.frombuffer(raw[:16], dtype="<u8"))
+    at = 16
+    col_ptr = np.frombuffer(raw[at:at + 8 * (n + 1)], dtype="<u8")
+    at += 8 * (n + 1)
+    rows = np.frombuffer(raw[at:at + 4 * nnz], dtype="<u4")
+    at += 4 * nnz
+    pad = (-(nnz * 4)) % 8
+    if raw[at:at + pad] != b"\0" * pad:
+        raise RuntimeError("sparse GRM padding is not zero")
+    at += pad
+    vals = np.frombuffer(raw[at:at + 8 * nnz], dtype="<f8")
+    if at + 8 * nnz != len(raw):
+        raise RuntimeError(f"sparse GRM file length mismatch: {len(raw)} != {at + 8 * nnz}")
+    return n, col_ptr, rows, vals
+
+
 def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
                    het_threshold=0.0, block_rows=65536):
     """`grm_stream_bed_f32` restatement (src/stats/grm.rs:4690-5455): prestat pass -> keep/flip/mean/

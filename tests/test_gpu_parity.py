@@ -1296,3 +1296,105 @@ def test_distributed_eigh_rccl_callback_single_rank():
     assert "eigh symv tiles sharded" not in res["0"]["config"]["parallelism"]
     assert abs(res["1"]["null"]["lbd"] - res["0"]["null"]["lbd"]) <= 1e-6 * res["0"]["null"]["lbd"]
     assert res["1"]["config"]["m_kept"] == res["0"]["config"]["m_kept"]
+
+
+def _related_panel(n, m, seed, missing_rate):
+    """HWE panel with a few close relatives (so that a positive kinship cut-off keeps some off-diagonals)."""
+    packed, g = bed.synth_panel_numpy(n, m, seed=seed, missing_rate=missing_rate)
+    rng = np.random.default_rng(seed + 1)
+    for a, b in [(1, 0), (7, 5), (n - 1, 3), (n // 2, n // 2 - 1)]:     # duplicates / half-identical pairs
+        g[:, a] = g[:, b]
+        swap = rng.random(m) < (0.0 if a == 1 else 0.35)
+        g[swap, a] = rng.integers(0, 3, int(swap.sum()))
+    return bed.pack_dosage(g), g
+
+
+def _csc_check(n, cp, ri, va, ref, thr, abs_thr, tol):
+    """Structure (sorted rows, diagonal first in every column) + entry set / values against the oracle's CSC."""
+    rcp, rri, rva = ref
+    assert cp[0] == 0 and cp[-1] == len(ri) == len(va) and np.all(np.diff(cp.astype(np.int64)) >= 1)
+    scale = float(np.abs(rva).max())
+    got, want = {}, {}
+    for c in range(n):
+        r = ri[int(cp[c]):int(cp[c + 1])]
+        assert r[0] == c and np.all(np.diff(r.astype(np.int64)) > 0)
+        for k in range(int(cp[c]), int(cp[c + 1])):
+            got[(int(ri[k]), c)] = va[k]
+        for k in range(int(rcp[c]), int(rcp[c + 1])):
+            want[(int(rri[k]), c)] = rva[k]
+    for key in set(got) | set(want):
+        if key in got and key in want:
+            assert abs(got[key] - want[key]) <= tol * scale, key
+        else:    # only entries within the GEMM tolerance of the cut-off may differ between the two
+            v = got.get(key, want.get(key))
+            edge = abs(abs(v) - thr) if abs_thr else abs(v - thr)
+            assert edge <= 2 * tol * scale, (key, v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,thr,abs_thr,subset", [(1, 0.05, False, False), (2, 0.02, True, False),
+                                                        (1, -1.0, False, True), (1, 0.0, False, True)])
+def test_spgrm_packed_to_jxgrm(oracle, tmp_path, method, thr, abs_thr, subset):
+    """Sparse GRM file (`spgrm_packed_to_jxgrm`, src/stats/spgrm.rs:5201-5278) against the restatement: identical
+    entry set up to entries within the GEMM tolerance of the cut-off, values within TOL, (col, row) order, header,
+    padding and length of the `.spgrm` layout."""
+    from janusx_amd import janusx as jxrs
+    n, m = 301, 900
+    packed, g = _related_panel(n, m, 91, 0.02)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    pk, maf = np.ascontiguousarray(packed[keep]), af[keep]
+    flip = maf > 0.5
+    maf = np.where(flip, 1.0 - maf, maf).astype(np.float32)
+    sub = np.sort(np.random.default_rng(5).choice(n, 170, replace=False)).astype(np.int64) if subset else None
+    path, n_out, nnz = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, maf, str(tmp_path / "k"), sub, method, thr, abs_thr)
+    assert path.endswith("k.spgrm") and n_out == (170 if subset else n)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)          # checks padding bytes and the total length
+    assert nn == n_out and len(va) == nnz
+    assert jxrs.load_spgrm(path)[3].tobytes() == va.tobytes()
+    ref = oracle.sparse_grm_csc_from_packed(pk, n, flip, maf, sub, method, thr, abs_thr)
+    _csc_check(n_out, cp, ri, va, ref, thr, abs_thr, TOL)
+    if thr < 0 and not abs_thr:
+        assert nnz == n_out * (n_out + 1) // 2
+    else:
+        assert n_out < nnz < n_out * (n_out + 1) // 2        # the relatives survive, the bulk does not
+
+
+@pytest.mark.gpu
+def test_spgrm_bed_to_jxgrm_and_errors(oracle, tmp_path):
+    """`spgrm_bed_to_jxgrm` (src/stats/spgrm.rs:5280-5356): metadata pre-pass over the selected samples + the stream
+    core's denominator; the reference's error strings."""
+    from janusx_amd import janusx as jxrs
+    n, m = 190, 640
+    packed, g = _related_panel(n, m, 17, 0.03)
+    prefix = str(tmp_path / "toy")
+    bim = bed.Bim(["1"] * m, [f"snp{j + 1}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["C"] * m)
+    bed.write_bed(prefix, packed, [f"I{i}" for i in range(n)], bim)
+    for sub in (None, np.arange(5, 150, dtype=np.int64)):
+        mi, he, ho = oracle.row_counts(packed, n, sub)
+        ns = n if sub is None else len(sub)
+        keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, ns, 0.02, 0.05, 0.0)
+        path, n_out, nnz = jxrs.spgrm_bed_to_jxgrm(prefix, str(tmp_path / "o"), sub, 1, 0.05)
+        nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+        ref = oracle.sparse_grm_csc_from_packed(packed[keep], n, np.zeros(int(keep.sum()), dtype=bool), af[keep], sub, 1,
+                                                0.05, False, stream_denominator=True)
+        assert n_out == ns == nn and nnz == len(va)
+        _csc_check(ns, cp, ri, va, ref, 0.05, False, TOL)
+    from janusx_amd import cli
+    assert cli.main(["grm", "-bfile", prefix, "-o", str(tmp_path / "c"), "-sparse"]) == 0
+    nn, cp2, ri2, va2 = oracle.read_sparse_grm_csc(str(tmp_path / "c.spgrm"))
+    path_full, _, _ = jxrs.spgrm_bed_to_jxgrm(prefix, str(tmp_path / "full"), None, 1, 0.05)
+    assert open(path_full, "rb").read() == open(str(tmp_path / "c.spgrm"), "rb").read()
+    assert open(str(tmp_path / "c.spgrm.id")).read().split() == [f"I{i}" for i in range(n)]
+    flip = np.zeros(m, dtype=bool)
+    maf = np.full(m, 0.3, dtype=np.float32)
+    with pytest.raises(RuntimeError, match="method must be 1"):
+        jxrs.spgrm_packed_to_jxgrm(packed, n, flip, maf, prefix, None, 3)
+    with pytest.raises(RuntimeError, match="threshold must be finite"):
+        jxrs.spgrm_packed_to_jxgrm(packed, n, flip, maf, prefix, None, 1, float("nan"))
+    with pytest.raises(RuntimeError, match="denominator is not positive"):
+        jxrs.spgrm_packed_to_jxgrm(packed, n, flip, np.zeros(m, dtype=np.float32), prefix, None, 1)
+    with pytest.raises(RuntimeError, match="output prefix must not be empty"):
+        jxrs.spgrm_packed_to_jxgrm(packed, n, flip, maf, "  ", None, 1)
+    with pytest.raises(RuntimeError, match="second dimension mismatch"):
+        jxrs.spgrm_packed_to_jxgrm(packed[:, :-1], n, flip, maf, prefix, None, 1)

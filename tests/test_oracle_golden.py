@@ -226,3 +226,55 @@ def test_he_restatement_matches_dense_traces():
                              np.array([yp @ k @ yp, yp @ yp]))
     if sg >= 0 and se >= 0:
         assert abs(out[0] - sg) <= 1e-3 * (abs(sg) + abs(se)) and abs(out[1] - se) <= 1e-3 * (abs(sg) + abs(se))
+
+
+def test_sparse_grm_restatement_keep_rule_layout_and_dense_equivalence(tmp_path):
+    """Sparse GRM (next row 8f-3).  Pins: the keep rule against the reference's unit tests
+    (src/stats/spgrm.rs:6618-6630), the `.spgrm` layout against its writer tests (:6125-6183: header words, total
+    length, 4 zero bytes after an odd number of row indices), and the CSC content against the dense GRM restatement
+    (itself pinned above): every stored entry equals the dense f64 K, every dropped one fails the rule.
+    The reference's toy test :6067-6122 is not usable as a vector: its hand-written expectation centres by the data
+    mean and keeps a negative entry at cut-off 0.2, which contradicts `spgrm_keep_value` and the tests at :6618."""
+    from oracle import jx_oracle as O
+    assert O.spgrm_keep_value(-1.5, -0.1, False) and O.spgrm_keep_value(0.0, -0.1, False)
+    assert O.spgrm_keep_value(2.0, -0.1, False)
+    assert not O.spgrm_keep_value(-1e-6, 0.0, False) and not O.spgrm_keep_value(0.0, 0.0, False)
+    assert O.spgrm_keep_value(1e-6, 0.0, False)
+    assert O.spgrm_keep_value(-0.3, 0.2, True) and not O.spgrm_keep_value(-0.3, 0.2, False)
+    # writer: n = 3, nnz = 4 (no padding) and n = 2, nnz = 3 (4 bytes of padding)
+    p = str(tmp_path / "a.spgrm")
+    O.write_sparse_grm_csc(p, 3, [0, 2, 3, 4], [0, 2, 1, 2], [1.0, 0.25, 1.1, 0.9])
+    raw = open(p, "rb").read()
+    assert len(raw) == 16 + 4 * 8 + 4 * 4 + 0 + 4 * 8
+    assert int.from_bytes(raw[0:8], "little") == 3 and int.from_bytes(raw[8:16], "little") == 4
+    O.write_sparse_grm_csc(p, 2, [0, 2, 3], [0, 1, 1], [1.0, 0.25, 0.9])
+    raw = open(p, "rb").read()
+    row_end = 16 + 3 * 8 + 3 * 4
+    assert row_end % 8 == 4 and raw[row_end:row_end + 4] == b"\0" * 4 and len(raw) == row_end + 4 + 3 * 8
+    n, cp, ri, va = O.read_sparse_grm_csc(p)
+    assert n == 2 and list(cp) == [0, 2, 3] and list(ri) == [0, 1, 1] and list(va) == [1.0, 0.25, 0.9]
+    assert O.normalize_spgrm_path(" x ") == "x.spgrm" and O.normalize_spgrm_path("y.SPGRM") == "y.SPGRM"
+    assert O.normalize_spgrm_path("z.jxgrm") == "z.jxgrm" and O.normalize_spgrm_path("  ") == ""
+    # dense equivalence
+    rng = np.random.default_rng(3)
+    nn, m = 37, 260
+    g = rng.integers(0, 3, (m, nn)).astype(float)
+    g[:, 5] = g[:, 4]
+    g[rng.random((m, nn)) < 0.02] = np.nan
+    packed = O.pack_codes(O.genotypes_to_codes(g))
+    maf = (np.nanmean(g, axis=1) / 2.0).astype(np.float32)
+    flip = np.zeros(m, dtype=bool)
+    for method, thr, abs_thr in [(1, 0.05, False), (2, 0.03, True), (1, -0.5, False)]:
+        cp, ri, va = O.sparse_grm_csc_from_packed(packed, nn, flip, maf, None, method, thr, abs_thr)
+        k64, _ = O.grm_packed(packed, nn, flip, maf, None, method, out_dtype=np.float64)
+        seen = np.zeros((nn, nn), dtype=bool)
+        for c in range(nn):
+            rows = ri[int(cp[c]):int(cp[c + 1])]
+            assert rows[0] == c and np.all(np.diff(rows.astype(np.int64)) > 0)
+            assert np.array_equal(va[int(cp[c]):int(cp[c + 1])], k64[rows, c])
+            seen[rows, c] = True
+        for c in range(nn):
+            for r in range(c + 1, nn):
+                assert seen[r, c] == O.spgrm_keep_value(float(k64[r, c]), thr, abs_thr)
+    with pytest.raises(RuntimeError, match="threshold must be finite"):
+        O.sparse_grm_csc_from_packed(packed, nn, flip, maf, None, 1, float("inf"), False)

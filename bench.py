@@ -128,7 +128,7 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
     rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
     streaming reads). Returns None when the summary is absent."""
     runs = None
-    for tag in ("r01e", "r01d"):
+    for tag in ("r01g", "r01e", "r01d"):
         try:
             runs = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")))["runs"][run]
             break

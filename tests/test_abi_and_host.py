@@ -148,3 +148,30 @@ def test_lm_fallback_decision(oracle):
     assert stat3 == 0.0 and p3 == 0.5 and sw3 is True
     with pytest.raises(RuntimeError, match="alpha"):
         jxrs.gwas_lmm_lm_null_lrt_decision(y, x, lm, alpha=1.5)
+
+
+def test_spgrm_host_helpers_round_trip(tmp_path):
+    """`.spgrm` reader and output-path rule of the host mirror against the oracle's writer (layout of
+    src/stats/spgrm.rs:3745-3767, path rule :450-469); no GPU involved."""
+    from janusx_amd import janusx as jxrs
+    from oracle import jx_oracle as O
+    for nnz_rows, vals in [([0, 2, 1, 2], [1.0, 0.25, 1.1, 0.9]), ([0, 1, 1], [1.0, 0.25, 0.9])]:
+        n = 3 if len(vals) == 4 else 2
+        cp = [0, 2, 3, 4] if n == 3 else [0, 2, 3]
+        p = str(tmp_path / f"k{n}.spgrm")
+        O.write_sparse_grm_csc(p, n, cp, nnz_rows, vals)
+        nn, cp2, ri2, va2 = jxrs.load_spgrm(p)
+        assert nn == n and list(cp2) == cp and list(ri2) == nnz_rows and list(va2) == vals
+        assert cp2.dtype == np.uint64 and ri2.dtype == np.uint32 and va2.dtype == np.float64
+    with open(p, "ab") as fh:
+        fh.write(b"\0")
+    with pytest.raises(RuntimeError, match="length mismatch"):
+        jxrs.load_spgrm(p)
+    base = str(tmp_path / "q")
+    assert jxrs._normalize_spgrm_path(" " + base + " ") == base + ".spgrm"
+    assert jxrs._normalize_spgrm_path(base + ".SPGRM") == base + ".SPGRM"
+    open(base + ".jxgrm", "wb").close()                       # an old-style file alone keeps its name
+    assert jxrs._normalize_spgrm_path(base) == base + ".jxgrm" == O.normalize_spgrm_path(base)
+    open(base + ".spgrm", "wb").close()
+    assert jxrs._normalize_spgrm_path(base) == base + ".spgrm" == O.normalize_spgrm_path(base)
+    assert jxrs._normalize_spgrm_path("   ") == ""

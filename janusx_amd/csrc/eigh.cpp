@@ -47,7 +47,7 @@ using namespace jx;
 // Node-level distribution of the tridiagonalisation's symv (k_sytrd.hip): every rank calls jxg_eigh_f64 on the same
 // matrix; from `min_n` rows on each rank streams 1 / world of the tiles per column and `allreduce(user)` has to sum the
 // `jxg_eigh_dist_staging_doubles(n)` doubles at `d_staging` over the ranks on the stream passed to jxg_eigh_f64.
-extern "C" int64_t jxg_eigh_dist_staging_doubles(int n) { return 4 * (int64_t)n + 32 * 16 + 2 * 64; }
+extern "C" int64_t jxg_eigh_dist_staging_doubles(int n) { return (int64_t)n + 32 * 16 + 2 * 64; }
 
 extern "C" int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                                  int64_t staging_doubles, int min_n) {

@@ -475,6 +475,31 @@ __global__ void sytrd_finish_kernel(TdParams P) {
     if (j == P.n - 1) P.d[j] = P.a[j + (int64_t)j * P.ld];
 }
 
+// distributed form: the per-column collective carries [sum of the TD_YC y copies (n) | s0 | t1 | t2]; pack folds the
+// copies in a fixed order, unpack puts the reduced vector into copy 0 and clears the others
+constexpr int TD_TAIL = TD_S0 * TD_SL + 2 * TD_NB;
+__global__ void sytrd_dist_pack_kernel(const double *__restrict__ reg, int n, double *__restrict__ staging) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double v = reg[i];
+#pragma unroll
+        for (int c = 1; c < TD_YC; ++c) v += reg[(int64_t)c * n + i];
+        staging[i] = v;
+    } else if (i < n + TD_TAIL) {
+        staging[i] = reg[(int64_t)TD_YC * n + (i - n)];
+    }
+}
+__global__ void sytrd_dist_unpack_kernel(double *__restrict__ reg, int n, const double *__restrict__ staging) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        reg[i] = staging[i];
+#pragma unroll
+        for (int c = 1; c < TD_YC; ++c) reg[(int64_t)c * n + i] = 0.0;
+    } else if (i < n + TD_TAIL) {
+        reg[(int64_t)TD_YC * n + (i - n)] = staging[i];
+    }
+}
+
 struct SytrdDist {
     int rank = 0, world = 1;
     int (*allreduce)(void *user) = nullptr;   // sums `staging_doubles` doubles at `staging` over the ranks, on the stream
@@ -524,7 +549,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     P.d = d_d;
     P.e = d_e;
     P.tau = d_tau;
-    const size_t red_doubles = (size_t)TD_YC * nn + (size_t)TD_S0 * TD_SL + 2 * TD_NB;   // [y | s0 | t1 | t2]
+    const size_t red_doubles = nn + (size_t)TD_TAIL;   // [folded y | s0 | t1 | t2]
     // JXGPU_DIST_EIGH_FORCE: run the distributed instantiation and the collective with a single rank too (how the RCCL
     // callback path is exercised on a one-GPU box)
     static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
@@ -590,9 +615,10 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
             }
             if (dist_on) {   // sum the ranks' partial y / v'Tv (+ rank 0's V'v, W'v): staging copy, collective, copy back
                 double *reg = P.acc[j & 1].y;
-                JX_HIP(hipMemcpyAsync(g_dist.staging, reg, sizeof(double) * red_doubles, hipMemcpyDeviceToDevice, st));
+                const int pk_grid = (int)((red_doubles + 255) / 256);
+                hipLaunchKernelGGL(sytrd_dist_pack_kernel, dim3(pk_grid), dim3(256), 0, st, reg, n, g_dist.staging);
                 if (g_dist.allreduce(g_dist.user)) return fail("sytrd: the all-reduce callback failed");
-                JX_HIP(hipMemcpyAsync(reg, g_dist.staging, sizeof(double) * red_doubles, hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(sytrd_dist_unpack_kernel, dim3(pk_grid), dim3(256), 0, st, reg, n, g_dist.staging);
             }
             hipLaunchKernelGGL(k_update, dim3(nchunks), dim3(TD_THREADS), 0, st, P, j, j0,
                                (i + 1 < pw) ? 1 : 0);

@@ -475,6 +475,184 @@ __global__ void sytrd_finish_kernel(TdParams P) {
     if (j == P.n - 1) P.d[j] = P.a[j + (int64_t)j * P.ld];
 }
 
+// LDS-resident tail: the last t <= TD_TAILN columns by ONE workgroup (a column of the two-kernel form costs two launch
+// floors, ~17 us, however small the trailing matrix is; here it is ~1-2 us).  Unblocked dsytd2 (lower) on the packed
+// lower triangle in LDS: per column larfg, y = tau S v, alpha = -tau/2 y'v, w = y + alpha v, S -= v w' + w v'.
+// Element (r, c), r >= c, of the t x t block lives at tp_off(c) + r - c.  Writes d, e, tau and the reflectors like B(j).
+constexpr int TD_TAILN = 192;
+constexpr int TD_TAIL_THREADS = 1024;   // 16 waves: four per SIMD to cover the LDS latency of the column loops
+constexpr int TD_TAIL_ROWS = 256;       // threads (r, h): row r = tid % 256 (< m <= 191 active), column class h = tid / 256
+
+__global__ __launch_bounds__(TD_TAIL_THREADS) void sytrd_tail_kernel(TdParams P, int j0, long long *dbg) {
+    extern __shared__ double tail_lds[];
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    long long tc = dbg ? wall_clock64() : 0;
+#define TAIL_MARK(i) if (dbg) { const long long now = wall_clock64(); tk[i] += now - tc; tc = now; }
+    const int n = P.n, t = n - j0, tid = threadIdx.x;
+    const int r = tid & (TD_TAIL_ROWS - 1), h = tid >> 8;   // h in 0..3
+    constexpr int NW = TD_TAIL_THREADS / 64;
+    double *Tp = tail_lds;                         // t (t + 1) / 2
+    double *v = Tp + (t * (t + 1)) / 2;            // t
+    double *w = v + t;                             // t
+    double *red_a = w + t;                         // NW: partial v'Sv
+    double *red_b = red_a + NW;                    // NW: partial norm of the next column
+    double *e_s = red_b + NW;                      // t: e and tau stay in LDS until the end
+    double *tau_s = e_s + t;                       // t
+    double *part = tau_s + t;                      // 4 x t partial row products
+    auto tp_off = [t](int c) { return c * t - (c * (c - 1)) / 2; };
+    // 4 columns per pass, one element per thread and column: the loads of a pass are in flight together
+    for (int c0 = 0; c0 < t; c0 += 16) {
+        double val[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + 4 * q + h, rr = c + r;
+            val[q] = (c < t && rr < t) ? P.a[j0 + rr + (int64_t)(j0 + c) * P.ld] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + 4 * q + h, rr = c + r;
+            if (c < t && rr < t) Tp[tp_off(c) + r] = val[q];
+        }
+    }
+    __syncthreads();
+    // norm^2 of the first column below its sub-diagonal entry
+    double xn2;
+    {
+        double sq = 0.0;
+        if (h == 0 && r >= 2 && r < t) sq = Tp[r] * Tp[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if ((tid & 63) == 0) red_b[tid >> 6] = sq;
+        __syncthreads();
+        xn2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) xn2 += red_b[q];
+    }
+    TAIL_MARK(0)
+    // Three barriers per column: (B) partial row products and v'Sv out, (C) w out, (D) trailing block updated and the
+    // next column's norm out.  v is formed on the fly from the raw column (x * scale), every thread redoes the scalars.
+    for (int k = 0; k + 1 < t; ++k) {
+        const int m = t - k - 1;                   // trailing dimension, local rows / columns 0 .. m-1
+        const int ok = tp_off(k);
+        const double *xcol = Tp + ok + 1;          // raw column: x[0] = sub-diagonal entry
+        double beta, tau, scale;
+        larfg_scalars(xcol[0], xn2, m, beta, tau, scale);
+        TAIL_MARK(1)
+        double pd = 0.0;
+        if (r < m) {
+            // y = S v: thread (r, h) takes the columns c = h (mod 4).  Element (r, c), c <= r, sits at
+            // tp_off(k+1) + r + c (m - 1) - c (c - 1) / 2 (lanes = consecutive r: conflict-free); stepping c by 4 moves it
+            // by 4 (m - 1) - 4 c - 6 doubles and that step shrinks by 16 (no integer multiplies in the loops).
+            // For c > r it is the mirrored entry in row r's own column.
+            int addr = tp_off(k + 1) + r + h * (m - 1) - (h * (h - 1)) / 2;
+            int step = 4 * (m - 1) - 4 * h - 6;
+            double a0 = 0.0, a1 = 0.0;
+            int c = h;
+            if (c == 0 && c <= r) {                // v[0] = 1
+                a0 = Tp[addr];
+                addr += step;
+                step -= 16;
+                c = 4;
+            }
+            for (; c + 4 <= r; c += 8) {
+                const int addr2 = addr + step;
+                a0 += Tp[addr] * (xcol[c] * scale);
+                a1 += Tp[addr2] * (xcol[c + 4] * scale);
+                addr = addr2 + step - 16;
+                step -= 32;
+            }
+            for (; c <= r; c += 4) {
+                a0 += Tp[addr] * (xcol[c] * scale);
+                addr += step;
+                step -= 16;
+            }
+            const double *colp = Tp + tp_off(k + 1 + r) - r;    // element (c, r), c > r, at colp[c]
+            for (; c + 4 < m; c += 8) {            // c continues in the same residue class past the diagonal
+                a0 += colp[c] * (xcol[c] * scale);
+                a1 += colp[c + 4] * (xcol[c + 4] * scale);
+            }
+            for (; c < m; c += 4) a0 += colp[c] * (xcol[c] * scale);
+            const double a = a0 + a1;
+            const double vr = (r == 0) ? 1.0 : xcol[r] * scale;
+            part[h * t + r] = a;
+            pd = a * vr;
+            if (h == 0) v[r] = vr;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pd += __shfl_xor(pd, off, 64);
+        if ((tid & 63) == 0) red_a[tid >> 6] = pd;
+        if (tid == 0) {
+            e_s[k] = beta;
+            tau_s[k] = tau;
+        }
+        __syncthreads();                           // (B)
+        TAIL_MARK(2)
+        double vsv = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) vsv += red_a[q];
+        const double alpha = -0.5 * tau * (tau * vsv);          // -tau/2 y'v with y = tau S v
+        if (h == 0 && r < m) {
+            const double yr = tau * ((part[r] + part[t + r]) + (part[2 * t + r] + part[3 * t + r]));
+            w[r] = yr + alpha * v[r];
+        }
+        __syncthreads();                           // (C)
+        TAIL_MARK(3)
+        double sq = 0.0;
+        if (r < m) {
+            const double vr = v[r], wr = w[r];
+            int addr = tp_off(k + 1) + r + h * (m - 1) - (h * (h - 1)) / 2;
+            int step = 4 * (m - 1) - 4 * h - 6;
+            int c = h;
+            if (h == 0) {                          // column 0 of the trailing block = the next column to reduce
+                const double nv = Tp[addr] - (vr * w[0] + wr * v[0]);
+                Tp[addr] = nv;
+                if (r >= 2) sq = nv * nv;
+                addr += step;
+                step -= 16;
+                c = 4;
+            }
+            for (; c + 4 <= r; c += 8) {
+                const int addr2 = addr + step;
+                const double t0 = Tp[addr], t1 = Tp[addr2];
+                Tp[addr] = t0 - (vr * w[c] + wr * v[c]);
+                Tp[addr2] = t1 - (vr * w[c + 4] + wr * v[c + 4]);
+                addr = addr2 + step - 16;
+                step -= 32;
+            }
+            for (; c <= r; c += 4) {
+                Tp[addr] -= vr * w[c] + wr * v[c];
+                addr += step;
+                step -= 16;
+            }
+            if (h == 1) Tp[ok + 1 + r] = vr;       // reflector in place (unit entry included; e restored by the finish kernel)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if ((tid & 63) == 0) red_b[tid >> 6] = sq;
+        __syncthreads();                           // (D)
+        xn2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) xn2 += red_b[q];
+        TAIL_MARK(4)
+    }
+    // results out: reflectors (columns of the packed image, diagonal included: A(n-1, n-1) feeds the finish kernel), d, e, tau
+    for (int c0 = 0; c0 < t; c0 += 4) {
+        const int c = c0 + h, rr = c + r;
+        if (c < t && rr < t) P.a[j0 + rr + (int64_t)(j0 + c) * P.ld] = Tp[tp_off(c) + r];
+    }
+    for (int k = tid; k < t; k += TD_TAIL_THREADS) {
+        P.d[j0 + k] = Tp[tp_off(k)];
+        if (k + 1 < t) {
+            P.e[j0 + k] = e_s[k];
+            P.tau[j0 + k] = tau_s[k];
+        }
+    }
+    TAIL_MARK(5)
+    if (dbg && tid == 0)
+        for (int i = 0; i < 6; ++i) dbg[i] = tk[i];
+#undef TAIL_MARK
+}
+
 // distributed form: the per-column collective carries [sum of the TD_YC y copies (n) | s0 | t1 | t2]; pack folds the
 // copies in a fixed order, unpack puts the reduced vector into copy 0 and clears the others
 constexpr int TD_TAIL = TD_S0 * TD_SL + 2 * TD_NB;
@@ -578,8 +756,17 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     }
     int nsamp = 0;
     double samp_bytes = 0.0;
-    for (int j0 = 0; j0 < n - 1; j0 += TD_NB) {
-        const int pw = (n - 1 - j0 < TD_NB) ? (n - 1 - j0) : TD_NB;
+    // the last tail_n columns go to the LDS-resident single-workgroup kernel; the first panel is narrower so that the
+    // 64-column panels end exactly where the tail starts (JXGPU_SYTRD_TAIL=0: two-kernel form to the end)
+    static const int tail_env = getenv("JXGPU_SYTRD_TAIL") ? atoi(getenv("JXGPU_SYTRD_TAIL")) : TD_TAILN;
+    const int tail_cap = tail_env < 0 ? 0 : (tail_env > TD_TAILN ? TD_TAILN : tail_env);
+    const int tail_n = (tail_cap >= 2) ? (n < tail_cap ? n : tail_cap) : 0;
+    const int n_panel_cols = tail_n ? (n - tail_n) : (n - 1);   // columns reduced by the panel loop
+    int first_pw = n_panel_cols % TD_NB;
+    if (first_pw == 0) first_pw = TD_NB;
+    for (int j0 = 0, pw = 0; j0 < n_panel_cols; j0 += pw) {
+        pw = (j0 == 0) ? first_pw : TD_NB;
+        if (pw > n_panel_cols - j0) pw = n_panel_cols - j0;
         JX_HIP(hipMemsetAsync(acc_begin, 0, acc_bytes, st));
         {
             const int rows = n - j0 - 1;
@@ -642,6 +829,26 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
                 fprintf(stderr, "[jxgpu sytrd n=%d] syr2k after column %d done\n", n, j0);
                 fflush(stderr);
             }
+        }
+    }
+    if (tail_n) {
+        const size_t lds = sizeof(double) * ((size_t)tail_n * (tail_n + 1) / 2 + 8 * (size_t)tail_n + 32);
+        static bool attr_set = false;
+        if (!attr_set) {
+            JX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sytrd_tail_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * ((size_t)TD_TAILN * (TD_TAILN + 1) / 2 + 8 * TD_TAILN + 32))));
+            attr_set = true;
+        }
+        static long long *d_dbg = nullptr;
+        if (getenv("JXGPU_EIGH_TRACE") && !d_dbg) JX_HIP(hipMalloc(&d_dbg, 6 * sizeof(long long)));
+        hipLaunchKernelGGL(sytrd_tail_kernel, dim3(1), dim3(TD_TAIL_THREADS), lds, st, P, n - tail_n, d_dbg);
+        if (d_dbg) {
+            long long hk[6];
+            JX_HIP(hipMemcpyAsync(hk, d_dbg, sizeof(hk), hipMemcpyDeviceToHost, st));
+            JX_HIP(hipStreamSynchronize(st));
+            fprintf(stderr, "[jxgpu sytrd tail t=%d] 100 MHz ticks: load %lld, scalars %lld, symv->B %lld, w->C %lld, update->D %lld, store %lld\n",
+                    tail_n, hk[0], hk[1], hk[2], hk[3], hk[4], hk[5]);
         }
     }
     hipLaunchKernelGGL(sytrd_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);

@@ -1398,3 +1398,22 @@ def test_spgrm_bed_to_jxgrm_and_errors(oracle, tmp_path):
         jxrs.spgrm_packed_to_jxgrm(packed, n, flip, maf, "  ", None, 1)
     with pytest.raises(RuntimeError, match="second dimension mismatch"):
         jxrs.spgrm_packed_to_jxgrm(packed[:, :-1], n, flip, maf, prefix, None, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [257, 321, 448, 449, 1217])
+def test_eigh_panel_and_tail_boundaries(n):
+    """Sizes around the panel / LDS-tail boundaries of the tridiagonalisation (first panel of 1 .. 64 columns, tail of
+    192): eigenvalues against LAPACK, residual and orthogonality at rounding level."""
+    import torch
+    from janusx_amd import pipeline as jp
+    rng = np.random.default_rng(n)
+    z = rng.standard_normal((n, n + 11))
+    k = z @ z.T / z.shape[1]
+    w, u = jp.eigh_from_grm(torch.from_numpy(k).cuda(), ridge=0.0)
+    wh, uh = w.cpu().numpy(), u.cpu().numpy()
+    wref = np.linalg.eigvalsh(k)
+    sc = np.abs(wref).max()
+    assert np.abs(np.sort(wh) - wref).max() / sc < 1e-12
+    assert np.abs(k @ uh.T - uh.T * wh[None, :]).max() / sc < 1e-12
+    assert np.abs(uh @ uh.T - np.eye(n)).max() < 1e-12

@@ -128,10 +128,12 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
     rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
     streaming reads). Returns None when the summary is absent."""
     runs = None
-    for tag in ("r01g", "r01e", "r01d"):
+    for tag in ("r01h", "r01g", "r01e", "r01d"):
         try:
             runs = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")))["runs"][run]
-            break
+            if runs:
+                break
+            runs = None
         except Exception:
             continue
     if runs is None:
@@ -149,10 +151,12 @@ def pmc_mfma_util(kernel_substr):
     """MFMA-pipe utilisation of a kernel from the committed counter pass (profiles/r01c_pmc_mfma.json):
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). None when the summary is absent."""
     kernels = None
-    for tag in ("r01f", "r01e", "r01c"):
+    for tag in ("r01h", "r01f", "r01e", "r01c"):
         try:
             kernels = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma.json")))["kernels"]
-            break
+            if kernels:
+                break
+            kernels = None
         except Exception:
             continue
     if kernels is None:

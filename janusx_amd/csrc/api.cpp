@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "jx_common.h"
@@ -304,8 +305,14 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
     std::vector<uint64_t> colptr((size_t)n + 1);
     JX_HIP(hipMemcpy(colptr.data(), dcolptr.p, sizeof(uint64_t) * colptr.size(), hipMemcpyDeviceToHost));
     const uint64_t nnz = colptr[(size_t)n];
-    std::vector<uint32_t> rows((size_t)nnz);
-    std::vector<double> vals((size_t)nnz);
+    std::vector<uint32_t> rows;
+    std::vector<double> vals;
+    try {   // up to n (n + 1) / 2 entries with a negative cut-off: 12 bytes each on the host
+        rows.resize((size_t)nnz);
+        vals.resize((size_t)nnz);
+    } catch (const std::bad_alloc &) {
+        return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
+    }
     if (nnz) {
         if (drows.alloc(sizeof(uint32_t) * (size_t)nnz) || dvals.alloc(sizeof(double) * (size_t)nnz)) return 1;
         if (jxg_spgrm_fill(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(),

@@ -84,6 +84,13 @@ int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double thresho
 int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
                    const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals, void *stream);
 
+/* Dense symmetric image (n_out, n_out) f64 of a lower-triangle CSC sparse GRM in HBM, optionally restricted / reordered
+ * by d_map (n int32: new index of every original sample, -1 = dropped; NULL = identity, n_out = n) — the operand of the
+ * sparse REML null model (`subset_sparse_grm_csc`, src/math/cholesky.rs:618-690, then K + lambda I, src/stats/spreml.rs:
+ * 384-512), which this library evaluates spectrally (jxg_eigh_f64 of the dense image) instead of by a sparse LLT. */
+int jxg_spgrm_densify(const uint64_t *d_colptr, const uint32_t *d_rows, const double *d_vals, int n,
+                      const int32_t *d_map, int n_out, double *d_out, void *stream);
+
 /* B1. symmetric eigendecomposition, f64, ascending.  d_a (n,n) is overwritten with U^T row-major
  * (row j = eigenvector j); d_w receives the n eigenvalues.  Replaces LAPACK dsyevd/dsyevr behind
  * src/math/eigh.rs:1422-1528: own Householder tridiagonalisation (k_sytrd.hip), divide and conquer (k_stedc.hip) and

@@ -34,6 +34,7 @@ SIGNATURES = {
     "jxg_spgrm_work_bytes": [c_i],
     "jxg_spgrm_count": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p],
     "jxg_spgrm_fill": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p, c_p],
+    "jxg_spgrm_densify": [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
     "jxg_eigh_dist_staging_doubles": [c_i],
     "jxg_eigh_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i],

@@ -106,6 +106,28 @@ __global__ __launch_bounds__(1024) void spgrm_colptr_scan_kernel(uint64_t *__res
     }
 }
 
+// CSC (lower) -> dense symmetric f64, optionally the sub-matrix of a sample selection: map[orig] = new index or -1.
+// One wave per column, lanes stride over the column's entries.
+__global__ __launch_bounds__(256) void spgrm_densify_kernel(const uint64_t *__restrict__ colptr,
+                                                            const uint32_t *__restrict__ rows,
+                                                            const double *__restrict__ vals, int n,
+                                                            const int32_t *__restrict__ map, int n_out,
+                                                            double *__restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n) return;
+    const int nc = map ? map[c] : c;
+    if (nc < 0) return;
+    const uint64_t lo = colptr[c], hi = colptr[c + 1];
+    for (uint64_t q = lo + (threadIdx.x & 63); q < hi; q += 64) {
+        const int r = (int)rows[q];
+        const int nr = map ? map[r] : r;
+        if (nr < 0) continue;
+        const double v = vals[q];
+        out[(int64_t)nr * n_out + nc] = v;
+        out[(int64_t)nc * n_out + nr] = v;
+    }
+}
+
 }  // namespace jx
 
 using namespace jx;
@@ -145,6 +167,17 @@ extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, doub
     hipLaunchKernelGGL(spgrm_band_kernel<true>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, (hipStream_t)stream,
                        d_acc, ld, n, inv_scale, threshold, abs_threshold, (int32_t *)d_work, d_colptr, d_rows, d_vals,
                        (int *)nullptr);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_spgrm_densify(const uint64_t *d_colptr, const uint32_t *d_rows, const double *d_vals, int n,
+                                 const int32_t *d_map, int n_out, double *d_out, void *stream) {
+    if (n <= 0 || n_out <= 0) return fail("jxg_spgrm_densify: n and n_out must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)n_out * (size_t)n_out, st));
+    hipLaunchKernelGGL(spgrm_densify_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_colptr, d_rows, d_vals, n, d_map,
+                       n_out, d_out);
     JX_LAUNCH_CHECK();
     return 0;
 }

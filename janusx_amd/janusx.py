@@ -219,6 +219,296 @@ def load_spgrm(path):
     return n, col_ptr, rows, vals
 
 
+# ------------------------------------------------------------------------------------------------
+# Sparse REML null model over a `.spgrm` (src/stats/spreml.rs)
+# ------------------------------------------------------------------------------------------------
+
+def _brent_minimize_with_init(f, low, high, tol, max_iter, init_x):
+    """Host Brent of src/math/brent.rs (`brent_minimize_with_init`; the device twin is `brent_reml` in csrc/k_scan.hip):
+    golden-section / parabolic steps, `e` kept on parabolic steps, start at init_x when it lies inside [low, high]."""
+    import math
+    a, c = (low, high) if low < high else (high, low)
+    eps = float(np.finfo(np.float64).eps)
+    tol = max(abs(tol), 1e-12)
+    x = init_x if (init_x is not None and math.isfinite(init_x) and a <= init_x <= c) else 0.5 * (a + c)
+    w = v = x
+    fx = f(x)
+    fw = fv = fx
+    d = e = 0.0
+    for _ in range(int(max_iter)):
+        m = 0.5 * (a + c)
+        tol1 = tol * abs(x) + eps
+        tol2 = 2.0 * tol1
+        if abs(x - m) <= tol2 - 0.5 * (c - a):
+            break
+        parabolic = False
+        if abs(e) > tol1:
+            pp = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw))
+            qq = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)))
+            if qq > 0.0:
+                pp = -pp
+            else:
+                qq = -qq
+            if abs(qq) > eps:
+                st = pp / qq
+                u = x + st
+                if (u - a) >= tol2 and (c - u) >= tol2 and abs(st) < 0.5 * abs(e):
+                    d = st
+                    if (u - a) < tol2 or (c - u) < tol2:
+                        d = tol1 if x < m else -tol1
+                    parabolic = True
+        if not parabolic:
+            e = (c - x) if x < m else (a - x)
+            d = 0.3819660 * e
+        if abs(d) < tol1:
+            d = tol1 if d >= 0.0 else -tol1
+        u = x + d
+        fu = f(u)
+        if fu <= fx:
+            if u >= x:
+                a = x
+            else:
+                c = x
+            v, fv = w, fw
+            w, fw = x, fx
+            x, fx = u, fu
+        else:
+            if u >= x:
+                c = u
+            else:
+                a = u
+            if fu <= fw or w == x:
+                v, fv = w, fw
+                w, fw = u, fu
+            elif fu <= fv or v == x or v == w:
+                v, fv = u, fu
+    return x, fx
+
+
+class _SpectralSparseReml:
+    """K + lambda I of a (subset of a) sparse GRM handled through ONE eigendecomposition on the GPU instead of one
+    sparse LLT per lambda (src/stats/spreml.rs:384-512 factorises at every evaluation): K = U diag(s) U', so
+    (K + lambda I)^-1 = U diag(1 / (s + lambda)) U', log det = sum log(s + lambda), and the matrix is factorisable
+    exactly when min(s) + lambda > 0.  Densify (jxg_spgrm_densify), eigh (jxg_eigh_f64) and the rotation of [y | X]
+    (rocBLAS dgemm through torch) run on the device; an evaluation is then O(n p^2) on (n, p + 2) numbers."""
+
+    def __init__(self, path, y, x_cov, sample_indices):
+        import torch
+        from . import pipeline as pl
+        y = _c(y, np.float64).ravel()
+        n_all, col_ptr, rows, vals = load_spgrm(path)
+        idx, n_sel = _opt_idx(sample_indices)
+        if idx is not None:
+            if n_sel == 0:
+                raise RuntimeError("Sparse GRM subset requires at least one sample")
+            if idx.min() < 0 or idx.max() >= n_all:
+                raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
+            uniq, cnt = np.unique(idx, return_counts=True)
+            if (cnt > 1).any():
+                first = next(int(v) for v in idx if cnt[np.searchsorted(uniq, v)] > 1)
+                raise RuntimeError(f"Sparse GRM subset contains duplicated sample index: {first}")
+        n = n_sel if idx is not None else n_all
+        if n != y.shape[0]:
+            raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={n}, phenotype n={y.shape[0]}")
+        if n == 0:
+            raise RuntimeError("SPREML requires n > 0")
+        if x_cov is None:
+            x = np.ones((n, 1), dtype=np.float64)
+        else:
+            xc = _c(x_cov, np.float64)
+            if xc.ndim != 2 or xc.shape[0] != n:
+                raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
+            x = np.concatenate([np.ones((n, 1)), xc], axis=1)
+        self.n, self.p = n, int(x.shape[1])
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_cp = torch.from_numpy(col_ptr.view(np.int64)).to(dev)
+        d_ri = torch.from_numpy(rows.view(np.int32)).to(dev)
+        d_va = torch.from_numpy(vals).to(dev)
+        d_map = None
+        if idx is not None:
+            mp = np.full(n_all, -1, dtype=np.int32)
+            mp[idx] = np.arange(n, dtype=np.int32)
+            d_map = torch.from_numpy(mp).to(dev)
+        k = torch.empty((n, n), dtype=torch.float64, device=dev)
+        check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all),
+                                      d_map.data_ptr() if d_map is not None else None, n, k.data_ptr(), pl._stream()))
+        s, ut = pl.eigh_from_grm(k, ridge=0.0)                   # row j of ut = eigenvector j
+        rot = ut @ torch.from_numpy(np.concatenate([y[:, None], x], axis=1)).to(dev)
+        rot = rot.cpu().numpy()
+        self.s = s.cpu().numpy()
+        self.yr, self.xr = rot[:, 0].copy(), rot[:, 1:].copy()
+        self.smin = float(self.s.min())
+
+    def factorizable(self, lam):
+        import math
+        return math.isfinite(lam) and lam > 0.0 and (self.smin + lam) > 0.0
+
+    def evaluate(self, log10_lambda, vp_fixed=None):
+        import math
+        lam = 10.0 ** log10_lambda
+        if not (math.isfinite(lam) and lam > 0.0):
+            raise RuntimeError(f"SPREML lambda is invalid at log10(lambda)={log10_lambda}")
+        n, p = self.n, self.p
+        if p == 0 or n <= p:
+            raise RuntimeError(f"SPREML requires n > p, got n={n}, p={p}")
+        d = self.s + lam
+        if not (d.min() > 0.0):
+            raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam} (min eigenvalue {d.min():.3e})")
+        wy = self.yr / d
+        y_vinv_y = float(self.yr @ wy)
+        xt_vinv_y = self.xr.T @ wy
+        xt_vinv_x = self.xr.T @ (self.xr / d[:, None])
+        chol = _spd_cholesky_with_jitter(xt_vinv_x, "SPREML XtVinvX")
+        beta = np.linalg.solve(chol.T, np.linalg.solve(chol, xt_vinv_y))
+        ypy = y_vinv_y - float(xt_vinv_y @ beta)
+        if not math.isfinite(ypy) or ypy <= 1e-30:
+            raise RuntimeError(f"SPREML profiled residual quadratic form is invalid at lambda={lam}: yPy={ypy}")
+        df = float(n - p)
+        log_det_m = float(np.log(d).sum())
+        log_det_x = 2.0 * float(np.log(np.diag(chol)).sum())
+        if vp_fixed is None:
+            sigma_g2 = ypy / df
+            if not math.isfinite(sigma_g2) or sigma_g2 <= 0.0:
+                raise RuntimeError(f"SPREML sigma_g2 is invalid at lambda={lam}: sigma_g2={sigma_g2}")
+            sigma_e2 = lam * sigma_g2
+            reml = df * (math.log(df) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (
+                df * math.log(ypy) + log_det_m + log_det_x)
+            nf = float(n)
+            ml = nf * (math.log(nf) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (nf * math.log(ypy) + log_det_m)
+        else:
+            if not (math.isfinite(vp_fixed) and vp_fixed > 0.0):
+                raise RuntimeError(f"SPREML fastGWA fixed-Vp objective requires finite vp_fixed > 0, got {vp_fixed}")
+            sigma_g2 = vp_fixed / (1.0 + lam)
+            sigma_e2 = lam * sigma_g2
+            reml = -0.5 * (df * math.log(sigma_g2) + log_det_m + log_det_x + ypy / sigma_g2)
+            ml = float("nan")
+        if not math.isfinite(reml) or not (math.isfinite(ml) or math.isnan(ml)):
+            raise RuntimeError(f"SPREML likelihood is invalid at lambda={lam}: ml={ml}, reml={reml}")
+        return (log10_lambda, lam, sigma_g2, sigma_e2, ml, reml)
+
+
+def _spd_cholesky_with_jitter(mat, label):
+    """src/stats/spreml.rs:324-351 (pivot floor 1e-18 of `cholesky_inplace`, src/math/linalg.rs:341-363)."""
+    def try_chol(a):
+        try:
+            l = np.linalg.cholesky(a)
+        except np.linalg.LinAlgError:
+            return None
+        return l if (np.diag(l) ** 2 > 1e-18).all() else None
+    dim = mat.shape[0]
+    l = try_chol(mat)
+    if l is not None:
+        return l
+    base = max(float(np.abs(np.diag(mat)).sum()) / max(dim, 1), 1.0) * 1e-10
+    for k in range(8):
+        l = try_chol(mat + np.eye(dim) * (base * 10.0 ** k))
+        if l is not None:
+            return l
+    raise RuntimeError(f"{label} is not SPD even after diagonal jitter")
+
+
+def _spreml_grid(model, low, high, grid_size, vp_fixed):
+    import math
+    if not (math.isfinite(low) and math.isfinite(high)) or low >= high:
+        raise RuntimeError(f"SPREML grid search requires finite low < high, got low={low}, high={high}")
+    grid_n = max(int(grid_size), 2)
+    evals, best, first_err = [], None, None
+    for i in range(grid_n):
+        x = low + (high - low) * (i / (grid_n - 1))
+        try:
+            ev = model.evaluate(x, vp_fixed)
+        except RuntimeError as e:
+            if first_err is None:
+                first_err = str(e)
+            continue
+        if best is None or ev[5] > best[5]:
+            best = ev
+        evals.append(ev)
+    if best is None:
+        tail = f"; first failure: {first_err}" if first_err else ""
+        raise RuntimeError(f"SPREML sparse grid search found no valid lambda in [{low}, {high}]{tail}")
+    return best, evals
+
+
+def _spreml_tuple(best, grid):
+    return (best[1], best[2], best[3], best[4], best[5], best[0], [g[0] for g in grid], [g[5] for g in grid],
+            [g[2] for g in grid], [g[3] for g in grid])
+
+
+def _spreml_brent(model, low, high, grid_size, tol, max_iter, vp_fixed, progress_callback):
+    """`sparse_reml_brent_search_with_progress` (src/stats/spreml.rs:591-757)."""
+    import math
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError(f"SPREML Brent tol must be finite and > 0, got {tol}")
+    if int(max_iter) == 0:
+        raise RuntimeError("SPREML Brent max_iter must be > 0")
+    grid_n = max(int(grid_size), 2)
+    total = 1 + grid_n + max(int(max_iter), 1)
+    best, grid = _spreml_grid(model, low, high, grid_size, vp_fixed)
+    bi = next((i for i, g in enumerate(grid) if g[0] == best[0]), 0)
+    b_low = grid[bi - 1][0] if bi > 0 else low
+    b_high = grid[bi + 1][0] if bi + 1 < len(grid) else high
+    if bi == 0 and grid and grid_n > 1:
+        raw_step = (high - low) / (grid_n - 1)
+        first_valid = grid[0][0]
+        prev_raw = max(first_valid - raw_step, low)
+        if prev_raw < first_valid:     # `refine_monotone_valid_lower_bound` (:152-186), 24 bisections
+            valid = lambda v: model.factorizable(10.0 ** v)   # noqa: E731
+            if valid(first_valid):
+                if valid(prev_raw):
+                    b_low = prev_raw
+                else:
+                    lo, hi, tol_use = prev_raw, first_valid, max(abs(min(tol, 1e-2)), 1e-6)
+                    for _ in range(24):
+                        if abs(hi - lo) <= tol_use:
+                            break
+                        mid = 0.5 * (lo + hi)
+                        if valid(mid):
+                            hi = mid
+                        else:
+                            lo = mid
+                    b_low = hi
+            else:
+                b_low = first_valid
+    if not (math.isfinite(b_low) and math.isfinite(b_high) and b_low < b_high):
+        b_low, b_high = low, high
+
+    def cost(v):
+        try:
+            return -model.evaluate(v, vp_fixed)[5]
+        except RuntimeError:
+            return 1e300
+
+    x_best, _ = _brent_minimize_with_init(cost, b_low, b_high, tol, max_iter, best[0])
+    out = model.evaluate(x_best, vp_fixed)
+    if progress_callback is not None:
+        progress_callback(total, total)
+    return _spreml_tuple(out, grid)
+
+
+def spreml_sparse_reml_grid_from_jxgrm(jxgrm_path, y, x_cov=None, sample_indices=None, low=-5.0, high=5.0,
+                                       grid_size=33, threads=1):
+    """src/stats/spreml.rs:826-918 -> (lambda, sigma_g2, sigma_e2, ml, reml, log10_lambda, grid_log10, grid_reml,
+    grid_sigma_g2, grid_sigma_e2): REML profile of y ~ [1, x_cov] + g, Var g = sigma_g2 K (sparse), on a lambda grid."""
+    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    return _spreml_tuple(*_spreml_grid(model, low, high, grid_size, None))
+
+
+def spreml_sparse_reml_brent_from_jxgrm(jxgrm_path, y, x_cov=None, sample_indices=None, low=-5.0, high=5.0,
+                                        grid_size=9, tol=1e-3, max_iter=20, threads=1, progress_callback=None):
+    """src/stats/spreml.rs:920-1042: grid, then Brent between the best point's neighbours (same 10-tuple)."""
+    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    return _spreml_brent(model, low, high, grid_size, tol, max_iter, None, progress_callback)
+
+
+def spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(jxgrm_path, y_resid, vp_fixed, sample_indices=None, low=-5.0,
+                                                    high=5.0, grid_size=9, tol=1e-3, max_iter=20, threads=1,
+                                                    progress_callback=None):
+    """src/stats/spreml.rs:1044-1160: the fastGWA objective (Vp fixed, intercept-only design on residuals)."""
+    model = _SpectralSparseReml(jxgrm_path, y_resid, None, sample_indices)
+    return _spreml_brent(model, low, high, grid_size, tol, max_iter, float(vp_fixed), progress_callback)
+
+
 def _read_bed_payload(prefix):
     """PLINK .bed payload as (m, bps) uint8 plus n_samples (src/stats/lmm.rs:1050-1061, gfcore.rs:307-323)."""
     from .bed import read_bed_payload

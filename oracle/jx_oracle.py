@@ -420,6 +420,227 @@ def read_sparse_grm_csc(path):
     return n, col_ptr, rows, vals
 
 
+# --------------------------------------------------------------------------------------------
+# Sparse REML null model over a `.spgrm` (src/stats/spreml.rs; first consumer of the sparse GRM in `-splmm`)
+# --------------------------------------------------------------------------------------------
+
+def sparse_grm_dense_subset(n, col_ptr, row_indices, values, sample_idx=None):
+    """Dense symmetric K of the lower-triangle CSC, optionally K[idx][:, idx] in the given order
+    (`subset_sparse_grm_csc`, src/math/cholesky.rs:618-690: empty / out-of-range / duplicated indices are errors;
+    reference vector :1656-1669)."""
+    col_ptr = np.asarray(col_ptr, dtype=np.int64)
+    k = np.zeros((n, n), dtype=np.float64)
+    for c in range(n):
+        for q in range(int(col_ptr[c]), int(col_ptr[c + 1])):
+            r = int(row_indices[q])
+            k[r, c] = values[q]
+            k[c, r] = values[q]
+    if sample_idx is None:
+        return k
+    idx = np.asarray(sample_idx, dtype=np.int64)
+    if idx.size == 0:
+        raise RuntimeError("Sparse GRM subset requires at least one sample")
+    if (idx < 0).any() or (idx >= n).any():
+        raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n}")
+    seen = set()
+    for v in idx.tolist():
+        if v in seen:
+            raise RuntimeError(f"Sparse GRM subset contains duplicated sample index: {v}")
+        seen.add(v)
+    return np.ascontiguousarray(k[np.ix_(idx, idx)])
+
+
+def spreml_design_matrix(x_cov, n):
+    """[1 | x_cov] row-major (src/stats/spreml.rs:296-322)."""
+    if n == 0:
+        raise RuntimeError("SPREML requires n > 0")
+    if x_cov is None:
+        return np.ones((n, 1), dtype=np.float64)
+    x_cov = np.asarray(x_cov, dtype=np.float64)
+    if x_cov.ndim != 2 or x_cov.shape[0] != n:
+        raise RuntimeError(f"x_cov shape mismatch: got {list(x_cov.shape)}, expected ({n}, p)")
+    return np.concatenate([np.ones((n, 1)), x_cov], axis=1)
+
+
+def spd_cholesky_with_jitter(mat, label):
+    """src/stats/spreml.rs:324-351: plain Cholesky, then up to eight diagonal jitters base * 10^k,
+    base = max(mean |diag|, 1) * 1e-10."""
+    dim = mat.shape[0]
+    chol = np.array(mat, dtype=np.float64)
+    if cholesky_inplace(chol):
+        return chol
+    base = max(float(np.abs(np.diag(mat)).sum()) / max(dim, 1), 1.0) * 1e-10
+    for k in range(8):
+        chol = np.array(mat, dtype=np.float64)
+        chol[np.diag_indices(dim)] += base * 10.0 ** k
+        if cholesky_inplace(chol):
+            return chol
+    raise RuntimeError(f"{label} is not SPD even after diagonal jitter")
+
+
+def spreml_evaluate(k_dense, x_design, y, log10_lambda, vp_fixed=None):
+    """`evaluate_sparse_reml_at_lambda` (src/stats/spreml.rs:384-512) with the sparse LLT of K + lambda I restated as a
+    dense Cholesky (the reference's own tests compare against exactly that, :1205-1262, 1264-1329).
+    vp_fixed=None: profile objective; else the fastGWA fixed-Vp objective.
+    -> dict(log10_lambda, lambda, sigma_g2, sigma_e2, ml, reml)."""
+    lam = 10.0 ** log10_lambda
+    if not (math.isfinite(lam) and lam > 0.0):
+        raise RuntimeError(f"SPREML lambda is invalid at log10(lambda)={log10_lambda}")
+    y = np.asarray(y, dtype=np.float64)
+    n = y.shape[0]
+    p = x_design.shape[1]
+    if p == 0 or n <= p:
+        raise RuntimeError(f"SPREML requires n > p, got n={n}, p={p}")
+    m = np.array(k_dense, dtype=np.float64) + lam * np.eye(n)
+    try:
+        lfac = np.linalg.cholesky(m)
+    except np.linalg.LinAlgError:
+        raise RuntimeError(f"sparse Cholesky of K + lambda I failed at lambda={lam}")
+    import scipy.linalg as sla
+    rhs = np.concatenate([y[:, None], x_design], axis=1)
+    sol = sla.cho_solve((lfac, True), rhs)
+    y_vinv, x_vinv = sol[:, 0], sol[:, 1:]
+    y_vinv_y = float(y @ y_vinv)
+    xt_vinv_y = x_design.T @ y_vinv
+    xt_vinv_x = x_design.T @ x_vinv
+    cx = spd_cholesky_with_jitter(xt_vinv_x, "SPREML XtVinvX")
+    beta = cholesky_solve(cx, xt_vinv_y)
+    ypy = y_vinv_y - float(xt_vinv_y @ beta)
+    if not math.isfinite(ypy) or ypy <= 1e-30:
+        raise RuntimeError(f"SPREML profiled residual quadratic form is invalid at lambda={lam}: yPy={ypy}")
+    df = float(n - p)
+    log_det_m = 2.0 * float(np.log(np.diag(lfac)).sum())
+    log_det_x = 2.0 * float(np.log(np.diag(cx)).sum())
+    if vp_fixed is None:
+        sigma_g2 = ypy / df
+        if not math.isfinite(sigma_g2) or sigma_g2 <= 0.0:
+            raise RuntimeError(f"SPREML sigma_g2 is invalid at lambda={lam}: sigma_g2={sigma_g2}")
+        sigma_e2 = lam * sigma_g2
+        reml = df * (math.log(df) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (df * math.log(ypy) + log_det_m + log_det_x)
+        nf = float(n)
+        ml = nf * (math.log(nf) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (nf * math.log(ypy) + log_det_m)
+    else:
+        if not (math.isfinite(vp_fixed) and vp_fixed > 0.0):
+            raise RuntimeError(f"SPREML fastGWA fixed-Vp objective requires finite vp_fixed > 0, got {vp_fixed}")
+        sigma_g2 = vp_fixed / (1.0 + lam)
+        sigma_e2 = lam * sigma_g2
+        reml = -0.5 * (df * math.log(sigma_g2) + log_det_m + log_det_x + ypy / sigma_g2)
+        ml = float("nan")
+    if not math.isfinite(reml) or not (math.isfinite(ml) or math.isnan(ml)):
+        raise RuntimeError(f"SPREML likelihood is invalid at lambda={lam}: ml={ml}, reml={reml}")
+    return dict(log10_lambda=log10_lambda, lam=lam, sigma_g2=sigma_g2, sigma_e2=sigma_e2, ml=ml, reml=reml)
+
+
+def refine_monotone_valid_lower_bound(is_valid, invalid_log10, valid_log10, tol, max_iter):
+    """src/stats/spreml.rs:152-186 (reference vector :1197-1207)."""
+    if not (math.isfinite(invalid_log10) and math.isfinite(valid_log10) and invalid_log10 < valid_log10):
+        return valid_log10
+    if not is_valid(valid_log10):
+        return valid_log10
+    if is_valid(invalid_log10):
+        return invalid_log10
+    tol_use = max(abs(tol), 1e-6)
+    lo, hi = invalid_log10, valid_log10
+    for _ in range(max(int(max_iter), 1)):
+        if abs(hi - lo) <= tol_use:
+            break
+        mid = 0.5 * (lo + hi)
+        if is_valid(mid):
+            hi = mid
+        else:
+            lo = mid
+    return hi
+
+
+def spreml_grid_search(evaluate, low, high, grid_size):
+    """`sparse_reml_grid_search_core` (src/stats/spreml.rs:514-589): failed points are skipped, strict > keeps the
+    first best. `evaluate(log10_lambda)` returns the evaluation dict or raises. -> (best, grid list)."""
+    if not (math.isfinite(low) and math.isfinite(high)) or low >= high:
+        raise RuntimeError(f"SPREML grid search requires finite low < high, got low={low}, high={high}")
+    grid_n = max(int(grid_size), 2)
+    evals, best, first_err = [], None, None
+    for idx in range(grid_n):
+        x = low + (high - low) * (idx / (grid_n - 1))
+        try:
+            ev = evaluate(x)
+        except RuntimeError as e:
+            if first_err is None:
+                first_err = str(e)
+            continue
+        if best is None or ev["reml"] > best["reml"]:
+            best = ev
+        evals.append(ev)
+    if best is None:
+        tail = f"; first failure: {first_err}" if first_err else ""
+        raise RuntimeError(f"SPREML sparse grid search found no valid lambda in [{low}, {high}]{tail}")
+    return best, evals
+
+
+def spreml_brent_search(evaluate, is_factorizable, low, high, grid_size, tol, max_iter):
+    """`sparse_reml_brent_search_with_progress` (src/stats/spreml.rs:591-757): grid, then Brent on -reml between the
+    grid neighbours of the best point started from it; when the best point is the first valid one the lower end is
+    refined towards the factorisability edge (24 bisections, tolerance min(tol, 1e-2)); failed evaluations cost 1e300;
+    the result is re-evaluated at the Brent minimiser. -> (best, grid list)."""
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError(f"SPREML Brent tol must be finite and > 0, got {tol}")
+    if int(max_iter) == 0:
+        raise RuntimeError("SPREML Brent max_iter must be > 0")
+    grid_n = max(int(grid_size), 2)
+    best, grid = spreml_grid_search(evaluate, low, high, grid_size)
+    best_idx = next((i for i, ev in enumerate(grid) if ev["log10_lambda"] == best["log10_lambda"]), 0)
+    b_low = grid[best_idx - 1]["log10_lambda"] if best_idx > 0 else low
+    b_high = grid[best_idx + 1]["log10_lambda"] if best_idx + 1 < len(grid) else high
+    if best_idx == 0 and grid and grid_n > 1:
+        raw_step = (high - low) / (grid_n - 1)
+        first_valid = grid[0]["log10_lambda"]
+        prev_raw = max(first_valid - raw_step, low)
+        if prev_raw < first_valid:
+            b_low = refine_monotone_valid_lower_bound(
+                lambda x: (math.isfinite(10.0 ** x) and 10.0 ** x > 0.0 and is_factorizable(10.0 ** x)),
+                prev_raw, first_valid, min(tol, 1e-2), 24)
+    if not (math.isfinite(b_low) and math.isfinite(b_high) and b_low < b_high):
+        b_low, b_high = low, high
+
+    def cost(x):
+        try:
+            return -evaluate(x)["reml"]
+        except RuntimeError:
+            return 1e300
+
+    x_best, _, _ = brent_minimize(cost, b_low, b_high, tol, max_iter, init_x=best["log10_lambda"])
+    return evaluate(x_best), grid
+
+
+def spreml_sparse_reml_brent(n, col_ptr, row_indices, values, y, x_cov=None, sample_idx=None, low=-5.0, high=5.0,
+                             grid_size=9, tol=1e-3, max_iter=20, vp_fixed=None, grid_only=False):
+    """`spreml_sparse_reml_brent_from_jxgrm` / `_grid_from_jxgrm` / `spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm`
+    (src/stats/spreml.rs:839-1160) on an in-memory CSC -> the reference's 10-tuple
+    (lambda, sigma_g2, sigma_e2, ml, reml, log10_lambda, grid_log10, grid_reml, grid_sigma_g2, grid_sigma_e2)."""
+    y = np.asarray(y, dtype=np.float64).ravel()
+    k = sparse_grm_dense_subset(n, col_ptr, row_indices, values, sample_idx)
+    if k.shape[0] != y.shape[0]:
+        raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={k.shape[0]}, phenotype n={y.shape[0]}")
+    x = spreml_design_matrix(x_cov, y.shape[0])
+
+    def evaluate(v):
+        return spreml_evaluate(k, x, y, v, vp_fixed)
+
+    def is_fact(lam):
+        try:
+            np.linalg.cholesky(k + lam * np.eye(k.shape[0]))
+            return True
+        except np.linalg.LinAlgError:
+            return False
+
+    if grid_only:
+        best, grid = spreml_grid_search(evaluate, low, high, grid_size)
+    else:
+        best, grid = spreml_brent_search(evaluate, is_fact, low, high, grid_size, tol, max_iter)
+    return (best["lam"], best["sigma_g2"], best["sigma_e2"], best["ml"], best["reml"], best["log10_lambda"],
+            [g["log10_lambda"] for g in grid], [g["reml"] for g in grid], [g["sigma_g2"] for g in grid],
+            [g["sigma_e2"] for g in grid])
+
+
 def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
                    het_threshold=0.0, block_rows=65536):
     """`grm_stream_bed_f32` restatement (src/stats/grm.rs:4690-5455): prestat pass -> keep/flip/mean/

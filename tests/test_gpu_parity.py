@@ -1417,3 +1417,72 @@ def test_eigh_panel_and_tail_boundaries(n):
     assert np.abs(np.sort(wh) - wref).max() / sc < 1e-12
     assert np.abs(k @ uh.T - uh.T * wh[None, :]).max() / sc < 1e-12
     assert np.abs(uh @ uh.T - np.eye(n)).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_spreml_reference_vectors_through_the_gpu_path(oracle, tmp_path):
+    """The reference's own sparse-REML cases (src/stats/spreml.rs:1209-1329) through the spectral GPU evaluation:
+    fixed lambda on an indefinite K and the fastGWA objective agree with the dense-Cholesky restatement to 1e-12."""
+    from janusx_amd import janusx as jxrs
+    p = str(tmp_path / "k2.spgrm")
+    oracle.write_sparse_grm_csc(p, 2, [0, 2, 3], [0, 1, 1], [1.0, 2.0, 1.0])
+    m = jxrs._SpectralSparseReml(p, [0.5, -1.25], None, None)
+    assert not m.factorizable(0.9) and m.factorizable(1.1)          # eigenvalues 3 and -1
+    got = m.evaluate(math.log10(1.5))
+    want = oracle.spreml_evaluate(np.array([[1.0, 2.0], [2.0, 1.0]]), np.ones((2, 1)), np.array([0.5, -1.25]),
+                                  math.log10(1.5))
+    for a, b in zip(got[1:], (want["lam"], want["sigma_g2"], want["sigma_e2"], want["ml"], want["reml"])):
+        assert abs(a - b) < 1e-12
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        m.evaluate(math.log10(0.5))
+    p3 = str(tmp_path / "k3.spgrm")
+    oracle.write_sparse_grm_csc(p3, 3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0])
+    got = jxrs._SpectralSparseReml(p3, [0.75, -0.10, -0.65], None, None).evaluate(math.log10(1.25), 1.2)
+    k3 = oracle.sparse_grm_dense_subset(3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0])
+    want = oracle.spreml_evaluate(k3, np.ones((3, 1)), np.array([0.75, -0.10, -0.65]), math.log10(1.25), vp_fixed=1.2)
+    assert abs(got[5] - want["reml"]) < 1e-12 and math.isnan(got[4]) and abs(got[2] - want["sigma_g2"]) < 1e-12
+    with pytest.raises(RuntimeError, match="sample size mismatch"):
+        jxrs.spreml_sparse_reml_brent_from_jxgrm(p3, [1.0, 2.0])
+    with pytest.raises(RuntimeError, match="duplicated sample index: 1"):
+        jxrs.spreml_sparse_reml_brent_from_jxgrm(p3, [1.0, 2.0], None, [1, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["plain", "covariates_subset", "fastgwa"])
+def test_spreml_brent_from_jxgrm(oracle, tmp_path, case):
+    """`spreml_sparse_reml_brent_from_jxgrm` / `_grid_` / `_fastgwa_` (src/stats/spreml.rs:826-1160) on a sparse GRM
+    built by `spgrm_packed_to_jxgrm`: grid values, Brent optimum and variance components against the dense-Cholesky
+    restatement on the same file."""
+    from janusx_amd import janusx as jxrs
+    n, m = 320, 1200
+    packed, g = _related_panel(n, m, 23, 0.01)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    path, _, nnz = jxrs.spgrm_packed_to_jxgrm(np.ascontiguousarray(packed[keep]), n, np.zeros(int(keep.sum()), bool),
+                                               af[keep], str(tmp_path / "k"), None, 1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    rng = np.random.default_rng(8)
+    gv = np.where(g[keep] < 0, 0, g[keep]).astype(np.float64)
+    y = (gv[:60].T @ rng.normal(0, 0.3, 60)) + rng.normal(0, 1.0, n)
+    y = (y - y.mean()) / y.std()
+    if case == "plain":
+        got = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, y)
+        ref = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y)
+        grid = jxrs.spreml_sparse_reml_grid_from_jxgrm(path, y, grid_size=17)
+        gref = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y, grid_size=17, grid_only=True)
+        assert np.allclose(grid[6], gref[6], atol=0) and np.allclose(grid[7], gref[7], rtol=1e-9, atol=1e-8)
+        assert abs(grid[5] - gref[5]) == 0.0
+    elif case == "covariates_subset":
+        sub = np.random.default_rng(2).permutation(n)[:257].astype(np.int64)        # unsorted on purpose
+        xc = rng.normal(size=(257, 2))
+        got = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, y[sub], xc, sub, -4.0, 4.0, 11, 1e-4, 30)
+        ref = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y[sub], xc, sub, -4.0, 4.0, 11, 1e-4, 30)
+    else:
+        got = jxrs.spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(path, y, float(np.var(y)))
+        ref = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y, vp_fixed=float(np.var(y)))
+        assert math.isnan(got[3]) and math.isnan(ref[3])
+    assert len(got[6]) == len(ref[6]) and np.allclose(got[6], ref[6], atol=0)
+    assert np.allclose(got[7], ref[7], rtol=1e-9, atol=1e-8)                        # REML on the grid
+    assert np.allclose(got[8], ref[8], rtol=1e-9) and np.allclose(got[9], ref[9], rtol=1e-9)
+    assert abs(got[5] - ref[5]) < 1e-6 and abs(got[0] - ref[0]) < 1e-5 * ref[0]    # same Brent path
+    assert abs(got[4] - ref[4]) < 1e-8 * max(1.0, abs(ref[4])) and abs(got[1] - ref[1]) < 1e-6 * ref[1]

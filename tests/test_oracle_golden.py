@@ -278,3 +278,49 @@ def test_sparse_grm_restatement_keep_rule_layout_and_dense_equivalence(tmp_path)
                 assert seen[r, c] == O.spgrm_keep_value(float(k64[r, c]), thr, abs_thr)
     with pytest.raises(RuntimeError, match="threshold must be finite"):
         O.sparse_grm_csc_from_packed(packed, nn, flip, maf, None, 1, float("inf"), False)
+
+
+def test_sparse_reml_restatement_matches_reference_vectors():
+    """Sparse REML null model (src/stats/spreml.rs).  Pins from the reference's own tests: the fixed-lambda profile
+    objective on an indefinite K against explicit 2x2 algebra (:1209-1262), the fastGWA fixed-Vp objective (:1264-1329,
+    recomputed here with numpy's dense inverse), the feasibility bisection (:1197-1207), the subset reordering
+    (src/math/cholesky.rs:1656-1669) and the smoke properties of the grid search (:1165-1195)."""
+    from oracle import jx_oracle as O
+    k = O.sparse_grm_dense_subset(2, [0, 2, 3], [0, 1, 1], [1.0, 2.0, 1.0])
+    assert np.array_equal(k, [[1.0, 2.0], [2.0, 1.0]])
+    lam = 1.5
+    ev = O.spreml_evaluate(k, np.ones((2, 1)), np.array([0.5, -1.25]), math.log10(lam))
+    vi = np.array([[2.5, -2.0], [-2.0, 2.5]]) / 2.25               # (K + 1.5 I)^-1, det = 2.25
+    y, x = np.array([0.5, -1.25]), np.ones(2)
+    xvx, xvy = x @ vi @ x, x @ vi @ y
+    ypy = y @ vi @ y - xvy ** 2 / xvx
+    reml = (0.0 - 1.0 - math.log(2 * math.pi)) * 0.5 - 0.5 * (math.log(ypy) + math.log(2.25) + math.log(xvx))
+    ml = 2.0 * (math.log(2.0) - 1.0 - math.log(2 * math.pi)) * 0.5 - 0.5 * (2.0 * math.log(ypy) + math.log(2.25))
+    assert abs(ev["lam"] - lam) < 1e-12 and abs(ev["sigma_g2"] - ypy) < 1e-12
+    assert abs(ev["sigma_e2"] - lam * ypy) < 1e-12 and abs(ev["reml"] - reml) < 1e-12 and abs(ev["ml"] - ml) < 1e-12
+    with pytest.raises(RuntimeError):                              # K + 0.5 I is indefinite
+        O.spreml_evaluate(k, np.ones((2, 1)), y, math.log10(0.5))
+    # fastGWA fixed-Vp objective
+    k3 = O.sparse_grm_dense_subset(3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0])
+    y3, lam, vp = np.array([0.75, -0.10, -0.65]), 1.25, 1.2
+    ev = O.spreml_evaluate(k3, np.ones((3, 1)), y3, math.log10(lam), vp_fixed=vp)
+    sg2 = vp / (1.0 + lam)
+    v = k3 * sg2 + np.eye(3) * (lam * sg2)
+    vinv = np.linalg.inv(v)
+    x3 = np.ones(3)
+    ypy_v = y3 @ vinv @ y3 - (x3 @ vinv @ y3) ** 2 / (x3 @ vinv @ x3)
+    want = -0.5 * (np.linalg.slogdet(v)[1] + math.log(x3 @ vinv @ x3) + ypy_v)
+    assert abs(ev["sigma_g2"] - sg2) < 1e-12 and abs(ev["sigma_e2"] - lam * sg2) < 1e-12
+    assert abs(ev["reml"] - want) < 1e-12 and math.isnan(ev["ml"])
+    assert abs(O.refine_monotone_valid_lower_bound(lambda t: t >= -0.137, -0.625, 0.0, 1e-6, 64) + 0.137) <= 1e-4
+    sub = O.sparse_grm_dense_subset(3, [0, 3, 5, 6], [0, 1, 2, 1, 2, 2], [1.0, 0.2, 0.3, 1.0, 0.4, 1.0], [2, 0, 1])
+    assert np.allclose(sub[np.tril_indices(3)], [1.0, 0.3, 1.0, 0.4, 0.2, 1.0], atol=1e-12)   # rows of the lower triangle
+    with pytest.raises(RuntimeError, match="duplicated sample index: 1"):
+        O.sparse_grm_dense_subset(3, [0, 3, 5, 6], [0, 1, 2, 1, 2, 2], [1.0] * 6, [1, 1])
+    res = O.spreml_sparse_reml_brent(3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0], [1.0, 0.5, -0.3],
+                                     low=-3.0, high=2.0, grid_size=9, grid_only=True)
+    assert math.isfinite(res[0]) and res[0] > 0.0 and math.isfinite(res[1]) and res[1] > 0.0 and len(res[6]) == 9
+    # Brent never ends below the best grid point
+    full = O.spreml_sparse_reml_brent(3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0], [1.0, 0.5, -0.3],
+                                      low=-3.0, high=2.0, grid_size=9)
+    assert full[4] >= max(full[7]) - 1e-12

@@ -265,6 +265,15 @@ int jxg_p32_transpose(const uint8_t *d_p32, int64_t m_total, int n, const int32_
 int jxg_packed_dot_t32(const uint8_t *d_t32, int n, int nrows, const float *d_lut, const double *d_beta, void *d_work,
                        double *d_out, void *stream);
 
+/* SparseLMM exact scan on rotated rows (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880, with V = K + lambda I
+ * handled spectrally): per row g~ = U'g the sums g~'Wg~, g~'(W X~), g~.(Py)~ of E2, then the score-form Wald test of
+ * `splmm_wald_from_score_denom` (:2517-2538) with the NULL model's sigma2 = ypy / df (df = n - p): out (nrows, 3) =
+ * (beta, se, p), rows with g'Pg <= 1e-30 are (NaN, NaN, 1).  d_w, d_py, d_wx, d_a_chol, ypy as produced by
+ * jxg_fvlmm_prepare at the null lambda. */
+int jxg_splmm_exact_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
+                             const float *d_wx, const double *d_a_chol, double ypy, int df, double *d_out,
+                             void *stream);
+
 /* E2 with the Cholesky factor already on the device: launch only (no allocation, no synchronisation). */
 int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w, const float *d_py,
                        const float *d_wx, const double *d_a_chol, double ypy, int df, int with_plrt, double nullml,

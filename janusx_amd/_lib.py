@@ -73,6 +73,7 @@ SIGNATURES = {
     "jxg_packed_dot_t32": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "jxg_packed_dot": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p],
     "jxg_cross_dot": [c_p, c_i, c_l, c_p, c_i, c_p, c_i, c_p, c_d, c_p, c_p],
+    "jxg_splmm_exact_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_p, c_p],
     "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
     "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],

@@ -626,7 +626,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
                                                                   const float *__restrict__ wx,
                                                                   const double *__restrict__ a_chol, double ypy,
                                                                   int df, int with_plrt, double nullml,
-                                                                  double log_det_v, double *__restrict__ out) {
+                                                                  double log_det_v, double *__restrict__ out,
+                                                                  int score_mode) {
+    // score_mode != 0: SparseLMM exact scan (src/stats/splmm.rs:2567-2880): same three sums, but the test keeps the
+    // NULL model's sigma2 = yPy / df (df = n - p passed in), beta = score / g'Pg, se = sqrt(sigma2 / g'Pg),
+    // p = chi2_sf(score^2 / (sigma2 g'Pg)) (`splmm_wald_from_score_denom` :2517-2538); g'Pg = max(g'V^-1 g - c'A^-1 c, 0),
+    // c kept in f64 there, rows with g'Pg <= 1e-30 are (NaN, NaN, 1).
     // One WAVE per rotated SNP row (4 rows in flight per workgroup, no LDS, no barriers): the row is streamed once
     // with 16-byte loads (4 samples per lane per step), the p + 2 sums are wave butterflies.
     constexpr int NV = MAXD + 2;
@@ -681,12 +686,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
             double c[MAXD], aic[MAXD];
             // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
 #pragma unroll
-            for (int k = 0; k < MAXD; ++k) c[k] = (k < p) ? (double)(float)v[2 + k] : 0.0;
+            for (int k = 0; k < MAXD; ++k) c[k] = (k < p) ? (score_mode ? v[2 + k] : (double)(float)v[2 + k]) : 0.0;
             chol_solve<MAXD>(l, p, c, aic);
             double ct = 0.0;
 #pragma unroll
             for (int k = 0; k < MAXD; ++k)
                 if (k < p) ct += c[k] * aic[k];
+            if (score_mode) {
+                const double denom = fmax(v[0] - ct, 0.0);
+                const double score = (double)(float)v[1];           // f32 GEMV output in the reference (:2702-2711)
+                const double sigma2 = ypy / (double)df;
+                bool ok = isfinite(score) && isfinite(denom) && denom > 1e-30 && isfinite(sigma2) && sigma2 > 0.0;
+                double beta = 0.0, se = 0.0, chisq = 0.0;
+                if (ok) {
+                    beta = score / denom;
+                    const double var_beta = sigma2 / denom;
+                    ok = isfinite(beta) && isfinite(var_beta) && var_beta > 0.0;
+                    if (ok) {
+                        se = sqrt(var_beta);
+                        chisq = (score * score) / (sigma2 * denom);
+                        ok = isfinite(se) && se > 0.0 && isfinite(chisq) && chisq >= 0.0;
+                    }
+                }
+                o[0] = ok ? beta : nan("");
+                o[1] = ok ? se : nan("");
+                o[2] = ok ? chi2_sf_df1_dev(chisq) : 1.0;
+                continue;
+            }
             const double schur = v[0] - ct;
             if (schur <= 1e-12 || !isfinite(schur)) {
                 o[0] = nan("");
@@ -847,7 +873,7 @@ extern "C" int jxg_fvlmm_scan_dev(const float *d_grot, int nrows, int n, int p, 
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                           (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df,
-                                          with_plrt, nullml, log_det_v, d_out));
+                                          with_plrt, nullml, log_det_v, d_out, 0));
     JX_LAUNCH_CHECK();
     return 0;
 }
@@ -865,8 +891,25 @@ extern "C" int jxg_fvlmm_scan(const float *d_grot, int nrows, int n, int p, cons
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0, st, d_grot,
                                           nrows, n, p, d_w, d_py, d_wx, a.as<double>(), ypy, df, with_plrt, nullml,
-                                          log_det_v, d_out));
+                                          log_det_v, d_out, 0));
     JX_LAUNCH_CHECK();
     JX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// SparseLMM exact scan on rotated rows (see the score_mode note in fvlmm_scan_kernel): launch only.
+extern "C" int jxg_splmm_exact_scan_dev(const float *d_grot, int nrows, int n, int p, const float *d_w,
+                                        const float *d_py, const float *d_wx, const double *d_a_chol, double ypy,
+                                        int df, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_splmm_exact_scan: p out of range");
+    if (!(ypy > 0.0) || !std::isfinite(ypy)) return fail("SparseLMM exact scan requires finite positive yPy on K + lambda I scale");
+    if (df <= 0) return fail("SparseLMM exact scan requires finite positive df");
+    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (grid > 65536 * 8) grid = 65536 * 8;
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                          (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df, 0,
+                                          0.0, 0.0, d_out, 1));
+    JX_LAUNCH_CHECK();
     return 0;
 }

@@ -338,6 +338,7 @@ class _SpectralSparseReml:
         self.s = s.cpu().numpy()
         self.yr, self.xr = rot[:, 0].copy(), rot[:, 1:].copy()
         self.smin = float(self.s.min())
+        self.s_dev, self.ut_dev, self.x_design, self.y_raw, self.sample_idx = s, ut, x, y, idx
 
     def factorizable(self, lam):
         import math
@@ -507,6 +508,62 @@ def spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(jxgrm_path, y_resid, vp_fixe
     """src/stats/spreml.rs:1044-1160: the fastGWA objective (Vp fixed, intercept-only design on residuals)."""
     model = _SpectralSparseReml(jxgrm_path, y_resid, None, sample_indices)
     return _spreml_brent(model, low, high, grid_size, tol, max_iter, float(vp_fixed), progress_callback)
+
+
+def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, row_flip, x_cov=None,
+                                sample_indices=None, row_indices=None, log10_lambda=None, low=-5.0, high=5.0,
+                                grid_size=9, tol=1e-3, max_iter=20):
+    """SparseLMM exact association scan: the null model of `spreml_sparse_reml_brent_from_jxgrm` (or a given
+    log10_lambda) followed by `exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) over the packed rows — the two
+    stages the reference's `splmm_assoc_pcg_bed` workflow chains for its exact mode.  V = K + lambda I is never
+    factorised: the eigenvectors of the sparse K rotate every SNP (the MFMA rotation kernel of the dense LMM, LUT
+    [0, 2 maf, 1, 2] or flipped, missing = mean, not centred), and g'V^-1 g, X'V^-1 g, g.Py are weighted sums over the
+    rotated row (`jxg_splmm_exact_scan_dev`).  -> (stats (m, 3) f64 [beta, se, p], log10_lambda, null 10-tuple or None)."""
+    import torch
+    from . import pipeline as pl
+    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    null = None
+    if log10_lambda is None:
+        null = _spreml_brent(model, low, high, grid_size, tol, max_iter, None, None)
+        log10_lambda = null[5]
+    lam = 10.0 ** float(log10_lambda)
+    if not model.factorizable(lam):
+        raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
+    pk = _c(packed, np.uint8)
+    n_full = int(packed_n_samples)
+    if pk.ndim != 2 or pk.shape[1] != (n_full + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1] if pk.ndim == 2 else pk.shape}, "
+                           f"expected {(n_full + 3) // 4}")
+    maf32 = _c(maf, np.float32).ravel()
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    if maf32.shape[0] != pk.shape[0] or flip.shape[0] != pk.shape[0]:
+        raise RuntimeError("maf / row_flip length must match packed rows")
+    rows = np.arange(pk.shape[0], dtype=np.int64) if row_indices is None else _c(row_indices, np.int64).ravel()
+    if rows.size and (rows.min() < 0 or rows.max() >= pk.shape[0]):
+        raise RuntimeError("row_indices out of range")
+    mean_g = np.clip(np.float32(2.0) * maf32[rows], np.float32(0.0), np.float32(2.0)).astype(np.float32)
+    lut = np.empty((len(rows), 4), dtype=np.float32)
+    lut[:, 0] = np.where(flip[rows], 2.0, 0.0)
+    lut[:, 1] = mean_g
+    lut[:, 2] = 1.0
+    lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
+    dev = model.s_dev.device
+    panel = pl.Panel(torch.from_numpy(pk).to(dev), n_full, model.sample_idx)
+    sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
+    # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
+    # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy
+    d = model.s + lam
+    wxh = model.xr / d[:, None]
+    a_chol = _spd_cholesky_with_jitter(model.xr.T @ wxh, "SparseLMM XtWX")
+    b0 = np.linalg.solve(a_chol.T, np.linalg.solve(a_chol, wxh.T @ model.yr))
+    pyh = (model.yr - model.xr @ b0) / d
+    ypy = float(model.yr @ pyh)
+    if not (np.isfinite(ypy) and ypy > 0.0):
+        raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)   # noqa: E731
+    out = pl.scan_rows(panel, sm, rows.astype(np.int32), lut, mode="splmm",
+                       fv_state=(f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy))
+    return out.cpu().numpy(), float(log10_lambda), null
 
 
 def _read_bed_payload(prefix):

@@ -175,7 +175,7 @@ def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
 class SpectralModel:
     """Device-resident counterpart of `LMM.from_spectral` (python/janusx/pyBLUP/assoc.py:1702-1876)."""
 
-    def __init__(self, s: torch.Tensor, ut64: torch.Tensor, x: np.ndarray, y: np.ndarray):
+    def __init__(self, s: torch.Tensor, ut64: torch.Tensor, x: np.ndarray, y: np.ndarray, fit_null: bool = True):
         dev = s.device
         self.n = n = int(s.shape[0])
         self.S = s
@@ -191,6 +191,11 @@ class SpectralModel:
         check(lib().jxg_rotate_xy(_ptr(self.ut), n, _ptr(xy), p + 1, _ptr(rot), _stream()))
         self.xcov = rot[:, :p].contiguous()
         self.y = rot[:, p].contiguous()
+        self._planes = None
+        self._fv = None
+        if not fit_null:      # spectrum of a sparse (possibly indefinite) K: lambda comes from the sparse REML search
+            self.null = None
+            return
         out3 = torch.empty(3, dtype=torch.float64, device=dev)
         check(lib().jxg_lmm_reml_null(_ptr(self.S), _ptr(self.xcov), _ptr(self.y), n, p, -5.0, 5.0, 50, 1e-3,
                                       _ptr(out3), _stream()))
@@ -265,7 +270,7 @@ class SpectralModel:
 
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
-              times: StageTimes = None, nullml=None):
+              times: StageTimes = None, nullml=None, fv_state=None):
     """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML), 'fvlmm' (fixed lambda) or 'lmm2' (REML Wald +
     ML likelihood ratio, needs `nullml`).  Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns
     [.., plrt] when `nullml` is given, 6 columns [beta, se, pwald, lambda, ml, plrt] for 'lmm2' -- (and the per-SNP
@@ -294,6 +299,8 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     check(lib().jxg_lut_split_rows(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16),
                                    _ptr(rowoff), _stream()))
     tables = None
+    if mode == "splmm" and fv_state is None:
+        raise RuntimeError("the SparseLMM exact scan needs its null state (fv_state = w, py, wx, a_chol, ypy)")
     if mode == "lmm2":
         lo_b, hi_b = model.null.bounds if low is None else (float(low), float(high))
         warm = 1 if init_log10_lbd is not None else 0
@@ -307,6 +314,11 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             check(lib().jxg_lmm_tables_build(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b,
                                              _ptr(tables), _stream()))
+    elif mode == "splmm":
+        # null state on the K + lambda I scale, formed in f64 by the caller without the 1e-6 ridge jxg_fvlmm_prepare puts
+        # on X'WX (fvlmm.rs): at the large lambda of a trait without polygenic signal that ridge is a 1e-4 relative error
+        w, py, wx, a_chol, ypy = fv_state
+        a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
     else:
         lbd, w, py, wx, a_chol, ypy, log_det_v, df = model.fv_cache(init_log10_lbd)
         a_dev = torch.from_numpy(a_chol).to(dev)
@@ -340,6 +352,9 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                 check(lib().jxg_lmm_scan_exact(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y),
                                                model.p, lo_b, hi_b, float(tol), int(max_iter), warm, init, with_plrt,
                                                nullml_v, o.data_ptr(), ev_p, _stream()))
+        elif mode == "splmm":   # score-form test with the null sigma2 = yPy / (n - p) (src/stats/splmm.rs:2567-2880)
+            check(lib().jxg_splmm_exact_scan_dev(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev),
+                                                 ypy, n - model.p, o.data_ptr(), _stream()))
         else:
             check(lib().jxg_fvlmm_scan_dev(_ptr(grot), nr, n, model.p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev),
                                            ypy, df, with_plrt, nullml_v, log_det_v, o.data_ptr(), _stream()))

@@ -641,6 +641,62 @@ def spreml_sparse_reml_brent(n, col_ptr, row_indices, values, y, x_cov=None, sam
             [g["sigma_e2"] for g in grid])
 
 
+def splmm_wald_from_score_denom(score, denom, sigma2):
+    """src/stats/splmm.rs:2517-2538 -> (beta, se, p) or None."""
+    if not (math.isfinite(score) and math.isfinite(denom) and denom > 1e-30 and math.isfinite(sigma2) and sigma2 > 0.0):
+        return None
+    beta = score / denom
+    var_beta = sigma2 / denom
+    if not (math.isfinite(beta) and math.isfinite(var_beta) and var_beta > 0.0):
+        return None
+    se = math.sqrt(var_beta)
+    chisq = (score * score) / (sigma2 * denom)
+    if not (math.isfinite(se) and se > 0.0 and math.isfinite(chisq) and chisq >= 0.0):
+        return None
+    return beta, se, chi2_sf_df1(chisq)
+
+
+def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip, sample_idx=None, rows=None):
+    """SparseLMM exact scan (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880) with the sparse factor of
+    V = K + lambda I restated as a dense Cholesky: null state Py = V^-1 (y - X b), yPy, sigma2 = yPy / (n - p),
+    chol(X'V^-1 X); per SNP the mean-imputed additive f32 decode ([0, 2 maf, 1, 2] or flipped, NOT centred:
+    `decode_mean_imputed_additive_packed_block_rows_f32`, src/math/bedmath.rs:940-1010), score = f32 GEMV g . f32(Py),
+    z = V^-1 g in f64, g'Pg = max(g'z - c'A^-1 c, 0) with c = X'z, then `splmm_wald_from_score_denom`;
+    failed rows are (NaN, NaN, 1).  -> (m, 3) f64."""
+    import scipy.linalg as sla
+    y = np.asarray(y, dtype=np.float64)
+    n, p = x_design.shape
+    lfac = np.linalg.cholesky(np.asarray(k_dense, dtype=np.float64) + lam * np.eye(n))
+    sol = sla.cho_solve((lfac, True), np.concatenate([y[:, None], x_design], axis=1))
+    xt_vinv_x = x_design.T @ sol[:, 1:]
+    cx = spd_cholesky_with_jitter(xt_vinv_x, "SparseLMM XtWX")
+    beta0 = cholesky_solve(cx, x_design.T @ sol[:, 0])
+    py = sol[:, 0] - sol[:, 1:] @ beta0
+    ypy = float(y @ py)
+    df = float(n - p)
+    if not (math.isfinite(ypy) and ypy > 0.0):
+        raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
+    sigma2 = ypy / df
+    py32 = py.astype(np.float32)
+    codes = unpack_codes(np.ascontiguousarray(packed, dtype=np.uint8), n_samples)
+    if sample_idx is not None:
+        codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
+    rows = np.arange(codes.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
+    out = np.empty((len(rows), 3), dtype=np.float64)
+    for k, r in enumerate(rows):
+        mean_g = F32(min(max(F32(2.0) * F32(maf[r]), F32(0.0)), F32(2.0)))
+        lut = np.array([2.0, mean_g, 1.0, 0.0] if row_flip[r] else [0.0, mean_g, 1.0, 2.0], dtype=np.float32)
+        g32 = lut[codes[r]]
+        score = float(np.dot(g32, py32))                      # f32 GEMV output
+        g = g32.astype(np.float64)
+        z = sla.cho_solve((lfac, True), g)
+        c = x_design.T @ z
+        x_quad = float(c @ cholesky_solve(cx, c))
+        res = splmm_wald_from_score_denom(score, max(float(g @ z) - x_quad, 0.0), sigma2)
+        out[k] = res if res is not None else (float("nan"), float("nan"), 1.0)
+    return out
+
+
 def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
                    het_threshold=0.0, block_rows=65536):
     """`grm_stream_bed_f32` restatement (src/stats/grm.rs:4690-5455): prestat pass -> keep/flip/mean/

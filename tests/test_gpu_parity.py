@@ -1486,3 +1486,50 @@ def test_spreml_brent_from_jxgrm(oracle, tmp_path, case):
     assert np.allclose(got[8], ref[8], rtol=1e-9) and np.allclose(got[9], ref[9], rtol=1e-9)
     assert abs(got[5] - ref[5]) < 1e-6 and abs(got[0] - ref[0]) < 1e-5 * ref[0]    # same Brent path
     assert abs(got[4] - ref[4]) < 1e-8 * max(1.0, abs(ref[4])) and abs(got[1] - ref[1]) < 1e-6 * ref[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset,cov", [(False, False), (True, False), (False, True), (True, True)])
+def test_splmm_exact_scan_from_jxgrm(oracle, tmp_path, subset, cov):
+    """SparseLMM exact scan (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880) through the spectral GPU path
+    (sparse K eigenvectors + MFMA rotation + `jxg_splmm_exact_scan_dev`) against the dense-Cholesky restatement at the
+    same lambda: beta / se within TOL (beta relative to max(|beta|, se)), p-values within TOL in log space."""
+    from janusx_amd import janusx as jxrs
+    n, m = 320, 900
+    packed, g = _related_panel(n, m, 29, 0.02)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    path, _, _ = jxrs.spgrm_packed_to_jxgrm(np.ascontiguousarray(packed[keep]), n, np.zeros(int(keep.sum()), bool),
+                                            af[keep], str(tmp_path / "k"), None, 1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    rng = np.random.default_rng(4)
+    gv = np.where(g < 0, 0, g).astype(np.float64)
+    y = gv[100] * 0.5 + gv[200:240].T @ rng.normal(0, 0.2, 40) + rng.normal(0, 1.0, n)
+    sub = np.sort(np.random.default_rng(6).permutation(n)[:288]).astype(np.int64) if subset else None
+    ys = y[sub] if subset else y
+    xc = rng.normal(size=(len(ys), 2)) if cov else None
+    ns = len(ys)
+    maf_all = (mi * 0 + (he + 2 * ho) / np.maximum(2 * (n - mi), 1)).astype(np.float32)    # alt allele frequency, all rows
+    flip = np.zeros(m, dtype=bool)
+    flip[::7] = True                                                     # flipped rows: LUT [2, mean, 1, 0]
+    rows = np.arange(0, m, 2, dtype=np.int64)
+    got, l10, null = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows)
+    ref_null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, ys, xc, sub)
+    assert abs(l10 - ref_null[5]) < 1e-6 and abs(null[4] - ref_null[4]) < 1e-8 * max(1.0, abs(ref_null[4]))
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, sub)
+    ref = oracle.splmm_exact_scan(kd, 10.0 ** l10, oracle.spreml_design_matrix(xc, ns), ys, packed, n, maf_all, flip,
+                                  sub, rows)
+    assert got.shape == ref.shape == (len(rows), 3)
+    bad = np.isnan(ref[:, 0])
+    assert np.array_equal(np.isnan(got[:, 0]), bad) and np.all(got[bad, 2] == 1.0)
+    ok = ~bad
+    scale = np.maximum(np.abs(ref[ok, 0]), ref[ok, 1])
+    assert np.max(np.abs(got[ok, 0] - ref[ok, 0]) / scale) < TOL
+    assert np.max(np.abs(got[ok, 1] - ref[ok, 1]) / ref[ok, 1]) < TOL
+    lp = np.abs(np.log(np.maximum(got[ok, 2], 1e-300)) - np.log(np.maximum(ref[ok, 2], 1e-300)))
+    assert np.max(lp / np.maximum(1.0, np.abs(np.log(np.maximum(ref[ok, 2], 1e-300))))) < 10 * TOL
+    assert ref[ok, 2].min() < 1e-4                                       # the causal SNP is found
+    # a given lambda skips the null search
+    got2, l2, null2 = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows, log10_lambda=l10)
+    assert null2 is None and l2 == l10 and np.array_equal(np.isnan(got2), np.isnan(got))
+    assert np.allclose(got2[ok], got[ok], rtol=1e-4, atol=1e-7)    # a second eigendecomposition: atomics reorder the sums

@@ -10,7 +10,7 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -rrBLUP [-lambda L] [-tol 1e-4] [-max-iter 100] [-cv K]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv`; `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
+Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm.tsv` (`gwas -splmm [cutoff]`, exact SparseLMM scan); `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
 `{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
@@ -127,8 +127,8 @@ def cmd_gwas(args):
     from . import pipeline as pl
     from .bed import read_bed_payload, read_fam_ids
     from .tsv import write_assoc_tsv
-    if not (args.lmm or args.fvlmm or args.lmm2):
-        raise SystemExit("select at least one model: -lmm, -lmm2 and/or -fvlmm")
+    if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
+        raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm and/or -splmm")
     packed, n_fam, bim = read_bed_payload(args.bfile)
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
@@ -142,11 +142,28 @@ def cmd_gwas(args):
     dev = torch.device("cuda", 0)
     packed_t = torch.from_numpy(np.array(packed, dtype=np.uint8, copy=True)).to(dev)
     t0 = time.perf_counter()
-    if args.grm in ("1", "2"):
+    dense_models = args.lmm or args.fvlmm or args.lmm2
+    k = None
+    if dense_models and args.grm in ("1", "2"):
         k, eff, _ = pl.build_grm(packed_t, n_fam, int(args.grm), args.maf, args.geno)
         print(f"GRM method {args.grm}: eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
-    else:
+    elif dense_models:
         k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)
+    sparse_path = None
+    if args.splmm is not None:
+        # SparseLMM, exact mode: thresholded sparse GRM of all genotyped samples once (`.spgrm`, or an existing one given
+        # with -grm FILE.spgrm), then per trait the sparse REML null model and the exact g'Pg scan on its samples
+        if str(args.grm).lower().endswith((".spgrm", ".jxgrm")):
+            sparse_path = args.grm
+        else:
+            method = int(args.grm) if args.grm in ("1", "2") else 1
+            sparse_path, _, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=method,
+                                                         threshold=float(args.splmm), maf_threshold=args.maf,
+                                                         max_missing_rate=args.geno, het_threshold=0.0)
+            with open(sparse_path + ".id", "w") as fh:
+                for sid in fam:
+                    fh.write(f"{sid}\n")
+            print(f"Sparse GRM cutoff={args.splmm}: nnz={nnz} -> {sparse_path} ({time.perf_counter() - t0:.2f}s)")
     for ti in traits:
         name = names[ti]
         rows_ok = []
@@ -181,6 +198,24 @@ def cmd_gwas(args):
                             res.af, res.miss, res.stats)
             print(f"[{name}] -{mode}: n={n} snps={len(kept)} lambda0={res.null.lbd:.5g} pve={res.null.pve:.4f} "
                   f"-> {path} ({time.perf_counter() - t1:.2f}s)")
+        if sparse_path is not None:
+            from . import stats as st
+            t1 = time.perf_counter()
+            full = n == n_fam and np.array_equal(keep_idx, np.arange(n_fam))
+            counts = jxrs.bed_row_counts(packed, n_fam, None if full else keep_idx)
+            keep, af, miss = st.gwas_scan_row_stats(counts, n, args.maf, args.geno, args.het)
+            kept = np.nonzero(keep)[0]
+            maf_all = np.zeros(packed.shape[0], dtype=np.float32)
+            maf_all[kept] = af[kept]
+            stats, l10, null = jxrs.splmm_exact_scan_from_jxgrm(
+                sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool),
+                x[:, 1:] if x.shape[1] > 1 else None, None if full else keep_idx, kept)
+            path = f"{out}.{name}.splmm.tsv"
+            write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
+                            [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
+                            af[kept], miss[kept], stats)
+            print(f"[{name}] -splmm: n={n} snps={len(kept)} lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} "
+                  f"sigma_e2={null[2]:.4g} -> {path} ({time.perf_counter() - t1:.2f}s)")
     return 0
 
 
@@ -361,6 +396,9 @@ def main(argv=None):
     g.add_argument("-force-model", "--force-model", dest="force_model", action="store_true", default=False)
     g.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     g.set_defaults(func=cmd_gwas)
+    g.add_argument("-splmm", "--splmm", nargs="?", const=0.05, default=None, type=float,
+                   help="SparseLMM exact scan on a sparse GRM thresholded at this kinship cut-off (default 0.05); "
+                        "-grm FILE.spgrm reuses an existing sparse GRM")
     r = sub.add_parser("grm")
     r.add_argument("-bfile", "--bfile", required=True)
     r.add_argument("-m", "--method", type=int, default=1, choices=[1, 2])

@@ -1533,3 +1533,43 @@ def test_splmm_exact_scan_from_jxgrm(oracle, tmp_path, subset, cov):
     got2, l2, null2 = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows, log10_lambda=l10)
     assert null2 is None and l2 == l10 and np.array_equal(np.isnan(got2), np.isnan(got))
     assert np.allclose(got2[ok], got[ok], rtol=1e-4, atol=1e-7)    # a second eigendecomposition: atomics reorder the sums
+
+
+@pytest.mark.gpu
+def test_cli_gwas_splmm(oracle, tmp_path):
+    """`jx gwas -splmm [cutoff]`: sparse GRM of all genotyped samples, then for the trait's phenotyped samples the
+    sparse REML null model and the exact scan; TSV rows against the dense-Cholesky restatement on the written `.spgrm`."""
+    from janusx_amd import cli
+    n, m = 300, 700
+    packed, g = _related_panel(n, m, 41, 0.015)
+    y = bed.synth_phenotype(g, n_causal=12, pve=0.5, seed=3)
+    na = np.random.default_rng(12).random(n) < 0.1
+    prefix = str(tmp_path / "toy")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ttraitA\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-o", prefix]) == 0
+    lines = open(prefix + ".traitA.splmm.tsv").read().splitlines()
+    assert open(prefix + ".spgrm.id").read().split() == ids
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(prefix + ".spgrm")
+    keep_idx = np.nonzero(~na)[0]
+    mi, he, ho = oracle.row_counts(packed, n, keep_idx)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, len(keep_idx), 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    assert len(lines) == len(rows) + 1
+    null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y[keep_idx], None, keep_idx)
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, keep_idx)
+    maf_all = np.zeros(m, dtype=np.float32)
+    maf_all[rows] = maf[rows]
+    ref = oracle.splmm_exact_scan(kd, null[0], np.ones((len(keep_idx), 1)), y[keep_idx], packed, n, maf_all,
+                                  np.zeros(m, dtype=bool), keep_idx, rows)
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert f[2] == f"rs{rows[i]}"
+        assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 * max(1.0, abs(ref[i, 0]))     # 4 significant digits in the TSV
+        assert abs(float(f[8]) - ref[i, 1]) <= 1.5e-4 * max(1.0, abs(ref[i, 1]))
+        assert abs(float(f[10]) - ref[i, 2]) <= 2e-4 * ref[i, 2] + 1e-300           # chisq is f[9], pwald f[10]

@@ -548,7 +548,8 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 2] = 1.0
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
     dev = model.s_dev.device
-    panel = pl.Panel(torch.from_numpy(pk).to(dev), n_full, model.sample_idx)
+    pk_w = pk if pk.flags.writeable else pk.copy()          # torch.from_numpy wants a writable array (memmapped payloads are not)
+    panel = pl.Panel(torch.from_numpy(pk_w).to(dev), n_full, model.sample_idx)
     sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
     # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
     # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy

@@ -200,6 +200,63 @@ def spgrm_bed_to_jxgrm(prefix, out_prefix=None, sample_indices=None, method=1, t
     return out
 
 
+def _write_spgrm(path, n, col_ptr, rows, vals):
+    """`.spgrm` layout of `write_sparse_grm_csc` (src/stats/spgrm.rs:3745-3767)."""
+    nnz = int(len(vals))
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        fh.write(np.array([n, nnz], dtype="<u8").tobytes())
+        fh.write(np.ascontiguousarray(col_ptr, dtype="<u8").tobytes())
+        fh.write(np.ascontiguousarray(rows, dtype="<u4").tobytes())
+        fh.write(b"\0" * ((-(4 * nnz)) % 8))
+        fh.write(np.ascontiguousarray(vals, dtype="<f8").tobytes())
+    os.replace(tmp, path)
+
+
+def spgrm_dense_npy_to_jxgrm(npy_path, out_prefix, threshold=0.05, abs_threshold=False, progress_callback=None,
+                             progress_every=0):
+    """src/stats/spgrm.rs:5972-6003 -> `spgrm_dense_npy_to_jxgrm_core` :5103-5199 / `spgrm_dense_f32_to_jxgrm_core`
+    :5027-5101: an existing dense GRM (`.npy`, f32 or f64, square) thresholded into `<out_prefix>.spgrm` — lower triangle
+    of the stored matrix, values widened to f64, same keep rule, (col, row) order.  The matrix goes to HBM once and the
+    count / fill kernels of the sparse GRM build compact it (bit-exact: no arithmetic besides the widening).
+    -> (path, n_samples, nnz)."""
+    import math
+    import torch
+    from . import pipeline as pl
+    k = np.load(npy_path, mmap_mode="r")
+    if k.ndim != 2 or k.shape[0] != k.shape[1]:
+        raise RuntimeError(f"Sparse GRM dense writer expects a square matrix, got shape {tuple(k.shape)}")
+    if k.dtype not in (np.float32, np.float64):
+        raise RuntimeError(f"Sparse GRM dense writer expects float32 or float64, got {k.dtype}")
+    n = int(k.shape[0])
+    if n == 0:
+        raise RuntimeError("Sparse GRM dense writer requires n_samples > 0")
+    if not math.isfinite(threshold):
+        raise RuntimeError("Sparse GRM threshold must be finite")
+    out_path = _normalize_spgrm_path(out_prefix)
+    if not out_path:
+        raise RuntimeError("Sparse GRM output prefix must not be empty")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ld = int(lib().jxg_num_tiles(n)) * 128
+    acc = torch.zeros((ld, ld), dtype=torch.float64, device=dev)
+    acc[:n, :n] = torch.from_numpy(np.array(k, copy=True)).to(dev).to(torch.float64)
+    work = torch.empty(int(lib().jxg_spgrm_work_bytes(n)), dtype=torch.uint8, device=dev)
+    colptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    st = pl._stream()
+    check(lib().jxg_spgrm_count(acc.data_ptr(), n, 1.0, float(threshold), int(bool(abs_threshold)), work.data_ptr(),
+                                colptr.data_ptr(), st))
+    cp = colptr.cpu().numpy().view(np.uint64)
+    nnz = int(cp[n])
+    rows = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    vals = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    check(lib().jxg_spgrm_fill(acc.data_ptr(), n, 1.0, float(threshold), int(bool(abs_threshold)), work.data_ptr(),
+                               colptr.data_ptr(), rows.data_ptr(), vals.data_ptr(), st))
+    _write_spgrm(out_path, n, cp, rows.cpu().numpy()[:nnz].view(np.uint32), vals.cpu().numpy()[:nnz])
+    if progress_callback is not None:
+        progress_callback(n, n)
+    return out_path, n, nnz
+
+
 def load_spgrm(path):
     """Reader of the `.spgrm` layout (`write_sparse_grm_csc`, src/stats/spgrm.rs:3745-3767)
     -> (n, col_ptr u64 (n+1), row_indices u32 (nnz), values f64 (nnz))."""

@@ -375,6 +375,37 @@ def sparse_grm_csc_from_packed(packed, n_samples, row_flip, row_maf, sample_idx=
     return col_ptr, np.concatenate(rows_out), np.concatenate(vals_out).astype(np.float64)
 
 
+def sparse_grm_csc_from_dense(k, threshold=0.05, abs_threshold=False):
+    """`spgrm_dense_f32_to_jxgrm_core` (src/stats/spgrm.rs:5027-5101): lower triangle of the stored dense matrix
+    (entry [row, col], row >= col), widened to f64, diagonal always kept, `spgrm_keep_value` otherwise; a non-finite
+    entry is an error.  -> (col_ptr u64, row_indices u32, values f64)."""
+    if not math.isfinite(threshold):
+        raise RuntimeError("Sparse GRM threshold must be finite")
+    k = np.asarray(k)
+    n = k.shape[0]
+    if n == 0:
+        raise RuntimeError("Sparse GRM dense writer requires n_samples > 0")
+    col_ptr = np.zeros(n + 1, dtype=np.uint64)
+    rows_out, vals_out = [], []
+    for c in range(n):
+        col = k[c:, c].astype(np.float64)
+        if not np.isfinite(col).all():
+            r = int(np.nonzero(~np.isfinite(col))[0][0]) + c
+            raise RuntimeError(f"Sparse GRM dense writer found non-finite value at pair ({r}, {c})")
+        if abs_threshold:
+            keep = np.abs(col) > threshold
+        elif threshold < 0.0:
+            keep = np.ones(col.shape, dtype=bool)
+        else:
+            keep = col > threshold
+        keep[0] = True
+        r = np.nonzero(keep)[0]
+        rows_out.append((r + c).astype(np.uint32))
+        vals_out.append(col[r])
+        col_ptr[c + 1] = col_ptr[c] + np.uint64(len(r))
+    return col_ptr, np.concatenate(rows_out), np.concatenate(vals_out)
+
+
 def normalize_spgrm_path(prefix: str) -> str:
     """Output path of the sparse GRM (src/stats/spgrm.rs:450-469)."""
     import os

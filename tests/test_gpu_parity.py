@@ -1573,3 +1573,29 @@ def test_cli_gwas_splmm(oracle, tmp_path):
         assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 * max(1.0, abs(ref[i, 0]))     # 4 significant digits in the TSV
         assert abs(float(f[8]) - ref[i, 1]) <= 1.5e-4 * max(1.0, abs(ref[i, 1]))
         assert abs(float(f[10]) - ref[i, 2]) <= 2e-4 * ref[i, 2] + 1e-300           # chisq is f[9], pwald f[10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,thr,abs_thr", [(np.float32, 0.05, False), (np.float64, 0.1, True),
+                                               (np.float32, -1.0, False)])
+def test_spgrm_dense_npy_to_jxgrm(oracle, tmp_path, dtype, thr, abs_thr):
+    """`spgrm_dense_npy_to_jxgrm` (src/stats/spgrm.rs:5972-6003): an existing dense GRM thresholded on the device;
+    no arithmetic besides the f64 widening, so the file is bit-identical to the restatement's."""
+    from janusx_amd import janusx as jxrs
+    rng = np.random.default_rng(14)
+    n = 411
+    z = rng.normal(size=(n, 90))
+    k = (z @ z.T / 90.0).astype(dtype)
+    k[np.tril_indices(n, -1)] *= rng.random(n * (n - 1) // 2) < 0.3          # sparsify, and make it non-symmetric:
+    npy = str(tmp_path / "g.npy")                                           # only the stored lower triangle counts
+    np.save(npy, k)
+    path, nn, nnz = jxrs.spgrm_dense_npy_to_jxgrm(npy, str(tmp_path / "d"), thr, abs_thr)
+    cp, ri, va = oracle.sparse_grm_csc_from_dense(k, thr, abs_thr)
+    ref = str(tmp_path / "ref.spgrm")
+    oracle.write_sparse_grm_csc(ref, n, cp, ri, va)
+    assert nn == n and nnz == len(va) and path.endswith("d.spgrm")
+    assert open(path, "rb").read() == open(ref, "rb").read()
+    k[7, 3] = np.inf
+    np.save(npy, k)
+    with pytest.raises(RuntimeError, match="non-finite value"):
+        jxrs.spgrm_dense_npy_to_jxgrm(npy, str(tmp_path / "e"), thr, abs_thr)

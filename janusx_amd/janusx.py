@@ -342,6 +342,47 @@ def _brent_minimize_with_init(f, low, high, tol, max_iter, init_x):
     return x, fx
 
 
+def _spgrm_dense_device(path, sample_indices):
+    """Dense symmetric image (HBM, f64) of a `.spgrm`, optionally K[idx][:, idx] in the given order
+    (`subset_sparse_grm_csc`, src/math/cholesky.rs:618-690, + `sparse_grm_to_dense`, src/stats/splmm.rs:2024-2039).
+    -> (tensor (n, n), idx or None)."""
+    import torch
+    from . import pipeline as pl
+    n_all, col_ptr, rows, vals = load_spgrm(path)
+    idx, n_sel = _opt_idx(sample_indices)
+    if idx is not None:
+        if n_sel == 0:
+            raise RuntimeError("Sparse GRM subset requires at least one sample")
+        if idx.min() < 0 or idx.max() >= n_all:
+            raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
+        uniq, cnt = np.unique(idx, return_counts=True)
+        if (cnt > 1).any():
+            first = next(int(v) for v in idx if cnt[np.searchsorted(uniq, v)] > 1)
+            raise RuntimeError(f"Sparse GRM subset contains duplicated sample index: {first}")
+    n = n_sel if idx is not None else n_all
+    if n == 0:
+        raise RuntimeError("SPREML requires n > 0")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_cp = torch.from_numpy(col_ptr.view(np.int64)).to(dev)
+    d_ri = torch.from_numpy(rows.view(np.int32)).to(dev)
+    d_va = torch.from_numpy(vals).to(dev)
+    d_map = None
+    if idx is not None:
+        mp = np.full(n_all, -1, dtype=np.int32)
+        mp[idx] = np.arange(n, dtype=np.int32)
+        d_map = torch.from_numpy(mp).to(dev)
+    k = torch.empty((n, n), dtype=torch.float64, device=dev)
+    check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all),
+                                  d_map.data_ptr() if d_map is not None else None, n, k.data_ptr(), pl._stream()))
+    return k, idx
+
+
+def splmm_load_sparse_grm_subset_dense(jxgrm_path, sample_indices=None):
+    """src/stats/splmm.rs:4022-4054 -> dense (n, n) f64 image of the (subset of the) sparse GRM."""
+    k, _ = _spgrm_dense_device(jxgrm_path, sample_indices)
+    return k.cpu().numpy()
+
+
 class _SpectralSparseReml:
     """K + lambda I of a (subset of a) sparse GRM handled through ONE eigendecomposition on the GPU instead of one
     sparse LLT per lambda (src/stats/spreml.rs:384-512 factorises at every evaluation): K = U diag(s) U', so
@@ -353,18 +394,8 @@ class _SpectralSparseReml:
         import torch
         from . import pipeline as pl
         y = _c(y, np.float64).ravel()
-        n_all, col_ptr, rows, vals = load_spgrm(path)
-        idx, n_sel = _opt_idx(sample_indices)
-        if idx is not None:
-            if n_sel == 0:
-                raise RuntimeError("Sparse GRM subset requires at least one sample")
-            if idx.min() < 0 or idx.max() >= n_all:
-                raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
-            uniq, cnt = np.unique(idx, return_counts=True)
-            if (cnt > 1).any():
-                first = next(int(v) for v in idx if cnt[np.searchsorted(uniq, v)] > 1)
-                raise RuntimeError(f"Sparse GRM subset contains duplicated sample index: {first}")
-        n = n_sel if idx is not None else n_all
+        k, idx = _spgrm_dense_device(path, sample_indices)
+        n = int(k.shape[0])
         if n != y.shape[0]:
             raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={n}, phenotype n={y.shape[0]}")
         if n == 0:
@@ -377,19 +408,9 @@ class _SpectralSparseReml:
                 raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
             x = np.concatenate([np.ones((n, 1)), xc], axis=1)
         self.n, self.p = n, int(x.shape[1])
-        dev = torch.device("cuda", torch.cuda.current_device())
-        d_cp = torch.from_numpy(col_ptr.view(np.int64)).to(dev)
-        d_ri = torch.from_numpy(rows.view(np.int32)).to(dev)
-        d_va = torch.from_numpy(vals).to(dev)
-        d_map = None
-        if idx is not None:
-            mp = np.full(n_all, -1, dtype=np.int32)
-            mp[idx] = np.arange(n, dtype=np.int32)
-            d_map = torch.from_numpy(mp).to(dev)
-        k = torch.empty((n, n), dtype=torch.float64, device=dev)
-        check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all),
-                                      d_map.data_ptr() if d_map is not None else None, n, k.data_ptr(), pl._stream()))
+        dev = k.device
         s, ut = pl.eigh_from_grm(k, ridge=0.0)                   # row j of ut = eigenvector j
+        del k
         rot = ut @ torch.from_numpy(np.concatenate([y[:, None], x], axis=1)).to(dev)
         rot = rot.cpu().numpy()
         self.s = s.cpu().numpy()

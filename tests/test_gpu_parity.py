@@ -1441,6 +1441,11 @@ def test_spreml_reference_vectors_through_the_gpu_path(oracle, tmp_path):
     k3 = oracle.sparse_grm_dense_subset(3, [0, 2, 4, 5], [0, 1, 1, 2, 2], [1.0, 0.2, 1.0, 0.1, 1.0])
     want = oracle.spreml_evaluate(k3, np.ones((3, 1)), np.array([0.75, -0.10, -0.65]), math.log10(1.25), vp_fixed=1.2)
     assert abs(got[5] - want["reml"]) < 1e-12 and math.isnan(got[4]) and abs(got[2] - want["sigma_g2"]) < 1e-12
+    assert np.array_equal(jxrs.splmm_load_sparse_grm_subset_dense(p3), k3)
+    p6 = str(tmp_path / "k6.spgrm")                                  # reference vector src/math/cholesky.rs:1656-1669
+    oracle.write_sparse_grm_csc(p6, 3, [0, 3, 5, 6], [0, 1, 2, 1, 2, 2], [1.0, 0.2, 0.3, 1.0, 0.4, 1.0])
+    assert np.array_equal(jxrs.splmm_load_sparse_grm_subset_dense(p6, [2, 0, 1]),
+                          [[1.0, 0.3, 0.4], [0.3, 1.0, 0.2], [0.4, 0.2, 1.0]])
     with pytest.raises(RuntimeError, match="sample size mismatch"):
         jxrs.spreml_sparse_reml_brent_from_jxgrm(p3, [1.0, 2.0])
     with pytest.raises(RuntimeError, match="duplicated sample index: 1"):

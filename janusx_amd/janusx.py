@@ -377,6 +377,46 @@ def _spgrm_dense_device(path, sample_indices):
     return k, idx
 
 
+def splmm_sparse_grm_diag_stats(jxgrm_path, sample_indices=None):
+    """src/stats/splmm.rs:4055-4111 (`sparse_diag_stats` :1978-2022) -> (mean |diag| floored at 1e-30, min diag, max
+    diag [starting from 0], n, nnz) of the (subset of the) sparse GRM; host-side metadata pass over the CSC arrays."""
+    n_all, col_ptr, rows, vals = load_spgrm(jxgrm_path)
+    idx, n_sel = _opt_idx(sample_indices)
+    cp = col_ptr.astype(np.int64)
+    cols = np.repeat(np.arange(n_all, dtype=np.int64), np.diff(cp))
+    if n_all == 0:
+        raise RuntimeError("SparseLMM diagonal stats require n_samples > 0")
+    if idx is not None and not (n_sel == n_all and np.array_equal(idx, np.arange(n_all))):
+        if n_sel == 0:
+            raise RuntimeError("Sparse GRM subset requires at least one sample")
+        if idx.min() < 0 or idx.max() >= n_all:
+            raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
+        if len(np.unique(idx)) != n_sel:
+            dup = next(int(v) for k, v in enumerate(idx) if v in idx[:k])
+            raise RuntimeError(f"Sparse GRM subset contains duplicated sample index: {dup}")
+        inside = np.zeros(n_all, dtype=bool)
+        inside[idx] = True
+        sel = inside[rows.astype(np.int64)] & inside[cols]
+        rows, cols, vals = rows[sel], cols[sel], vals[sel]
+        n_out = n_sel
+        want = np.sort(idx)
+    else:
+        n_out = n_all
+        want = np.arange(n_all, dtype=np.int64)
+    on_diag = rows.astype(np.int64) == cols
+    dcols, dvals = cols[on_diag], vals[on_diag]
+    first = np.unique(dcols, return_index=True)[1]                  # the first diagonal entry of every column counts
+    dcols, dvals = dcols[first], dvals[first]
+    missing = np.setdiff1d(want, dcols)
+    if missing.size:
+        raise RuntimeError(f"SparseLMM diagonal is missing at column {int(missing[0])}")
+    if not np.isfinite(dvals).all():
+        bad = int(dcols[np.nonzero(~np.isfinite(dvals))[0][0]])
+        raise RuntimeError(f"SparseLMM diagonal contains non-finite value at column {bad}")
+    mean_abs = max(float(np.abs(dvals).sum()) / float(n_out), 1e-30)
+    return mean_abs, float(dvals.min()), float(max(dvals.max(), 0.0)), int(n_out), int(len(vals))
+
+
 def splmm_load_sparse_grm_subset_dense(jxgrm_path, sample_indices=None):
     """src/stats/splmm.rs:4022-4054 -> dense (n, n) f64 image of the (subset of the) sparse GRM."""
     k, _ = _spgrm_dense_device(jxgrm_path, sample_indices)

@@ -175,3 +175,21 @@ def test_spgrm_host_helpers_round_trip(tmp_path):
     open(base + ".spgrm", "wb").close()
     assert jxrs._normalize_spgrm_path(base) == base + ".spgrm" == O.normalize_spgrm_path(base)
     assert jxrs._normalize_spgrm_path("   ") == ""
+
+
+def test_sparse_grm_diag_stats_host(tmp_path):
+    """`splmm_sparse_grm_diag_stats` (src/stats/splmm.rs:1978-2022, 4055-4111) on a written `.spgrm`: full set, identity
+    subset, proper subset (entries with both ends inside), and the missing-diagonal error."""
+    from janusx_amd import janusx as jxrs
+    from oracle import jx_oracle as O
+    p = str(tmp_path / "d.spgrm")
+    O.write_sparse_grm_csc(p, 4, [0, 3, 5, 7, 8], [0, 1, 3, 1, 2, 2, 3, 3], [1.5, 0.2, 0.3, 0.9, 0.4, 1.1, 0.5, 0.7])
+    assert jxrs.splmm_sparse_grm_diag_stats(p) == ((1.5 + 0.9 + 1.1 + 0.7) / 4, 0.7, 1.5, 4, 8)
+    assert jxrs.splmm_sparse_grm_diag_stats(p, [0, 1, 2, 3]) == jxrs.splmm_sparse_grm_diag_stats(p)
+    mean, lo, hi, n, nnz = jxrs.splmm_sparse_grm_diag_stats(p, [3, 0])
+    assert (lo, hi, n, nnz) == (0.7, 1.5, 2, 3) and abs(mean - 1.1) < 1e-15       # (0,0), (3,0), (3,3)
+    with pytest.raises(RuntimeError, match="duplicated sample index: 3"):
+        jxrs.splmm_sparse_grm_diag_stats(p, [3, 0, 3])
+    O.write_sparse_grm_csc(p, 2, [0, 1, 2], [1, 1], [0.3, 1.0])                    # column 0 has no diagonal entry
+    with pytest.raises(RuntimeError, match="diagonal is missing at column 0"):
+        jxrs.splmm_sparse_grm_diag_stats(p)

@@ -93,8 +93,26 @@ def _load_grm(path, fam_ids):
 def cmd_grm(args):
     from . import janusx as jxrs
     from .bed import read_fam_ids
-    out = args.out or args.bfile
+    if args.grm is None and not args.bfile:
+        raise SystemExit("grm needs -bfile PREFIX (or -grm FILE.npy -sparse [cutoff])")
+    out = args.out or args.bfile or (args.grm[:-4] if args.grm.lower().endswith(".npy") else args.grm)
     t0 = time.perf_counter()
+    if args.grm is not None:
+        # python/janusx/script/grm.py:1806-1868, 1896: an existing dense GRM (`.npy` + sibling `.id`) thresholded into `.spgrm`
+        if args.sparse is None:
+            raise SystemExit("-grm FILE.npy must be used with -sparse [cutoff]")
+        if not os.path.exists(args.grm + ".id"):
+            raise SystemExit(f"{args.grm}.id not found (sample ids of the dense GRM)")
+        path, n, nnz = jxrs.spgrm_dense_npy_to_jxgrm(args.grm, out, float(args.sparse))
+        ids_in = open(args.grm + ".id").read().split()
+        if len(ids_in) != n:
+            raise SystemExit(f"{args.grm}.id lists {len(ids_in)} samples, the matrix has {n}")
+        with open(path + ".id", "w") as fh:
+            for sid in ids_in:
+                fh.write(f"{sid}\n")
+        print(f"Sparse GRM from {args.grm}: n={n} nnz={nnz} cutoff={args.sparse} -> {path} "
+              f"({time.perf_counter() - t0:.2f}s)")
+        return 0
     if args.sparse is not None:
         # python/janusx/script/grm.py:1574-1675 (`-sparse [cutoff]`): thresholded lower-triangle CSC `.spgrm` + `.id`
         path, n, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=args.method,
@@ -400,11 +418,13 @@ def main(argv=None):
                    help="SparseLMM exact scan on a sparse GRM thresholded at this kinship cut-off (default 0.05); "
                         "-grm FILE.spgrm reuses an existing sparse GRM")
     r = sub.add_parser("grm")
-    r.add_argument("-bfile", "--bfile", required=True)
+    r.add_argument("-bfile", "--bfile", default=None)
     r.add_argument("-m", "--method", type=int, default=1, choices=[1, 2])
     r.add_argument("-maf", "--maf", type=float, default=0.02)
     r.add_argument("-geno", "--geno", type=float, default=0.05)
     r.add_argument("-o", "--out", default=None)
+    r.add_argument("-grm", "--grm", default=None,
+                   help="existing dense GRM (.npy with a sibling .id); with -sparse it is thresholded into a .spgrm")
     r.add_argument("-sparse", "--sparse", nargs="?", const=0.05, default=None, type=float,
                    help="write a sparse `.spgrm` keeping off-diagonal kinship > cutoff (negative: keep everything)")
     r.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")

@@ -1600,6 +1600,13 @@ def test_spgrm_dense_npy_to_jxgrm(oracle, tmp_path, dtype, thr, abs_thr):
     oracle.write_sparse_grm_csc(ref, n, cp, ri, va)
     assert nn == n and nnz == len(va) and path.endswith("d.spgrm")
     assert open(path, "rb").read() == open(ref, "rb").read()
+    if dtype == np.float32 and thr > 0:       # the CLI route: jx grm -grm FILE.npy -sparse CUT (needs the sibling .id)
+        from janusx_amd import cli
+        with open(npy + ".id", "w") as fh:
+            fh.write("\n".join(f"s{i}" for i in range(n)) + "\n")
+        assert cli.main(["grm", "-grm", npy, "-sparse", str(thr), "-o", str(tmp_path / "c")]) == 0
+        assert open(str(tmp_path / "c.spgrm"), "rb").read() == open(ref, "rb").read()
+        assert open(str(tmp_path / "c.spgrm.id")).read().split() == [f"s{i}" for i in range(n)]
     k[7, 3] = np.inf
     np.save(npy, k)
     with pytest.raises(RuntimeError, match="non-finite value"):

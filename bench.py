@@ -5,13 +5,15 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run (one rank per GPU, RCCL).  One "step" = one pass of the whole hot path over one synthetic
 panel that is already resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
 
-Workload at N = 1: BASELINE.json configs[1] shape (n = 5 000 samples, m = 50 000 SNPs, HWE genotypes with
-MAF ~ U(0.02, 0.45), intercept-only, 100 causal SNPs, pve 0.5), run with the exact per-SNP REML scan (`-lmm`,
-what the metric names; `--mode fvlmm` times the fixed-lambda scan of configs[1] instead).
-N > 1: SNP-sharded.  Default `--scaling weak`: every rank owns m SNPs (the panel is n x (m*N), generated shard by
-shard with a counter-keyed RNG), builds the GRM partial of its SNP range, the f64 partials are summed with an RCCL
-all-reduce over xGMI, every rank then holds K, runs the (replicated, it does not shard: SURVEY.md 8e)
-eigendecomposition + null fit and scans its own SNP range.  `--scaling strong` splits one n x m panel instead.
+Workload at N = 1: BASELINE.json configs[2], the largest single-GPU configuration of the metric (n = 20 000 samples,
+m = 200 000 SNPs, HWE genotypes with MAF ~ U(0.02, 0.45), intercept-only, 100 causal SNPs, pve 0.5), run with the
+exact per-SNP REML scan (`-lmm`, what the metric names; `--mode fvlmm` times the fixed-lambda scan instead;
+`--n 5000 --m 50000` is configs[1]).
+N > 1: SNP-sharded, default `--scaling strong` on BASELINE.json configs[3] (n = 50 000, m = 500 000: the panel the
+north star's 1 -> 8 GPU target is quoted on): every rank builds the GRM partial of its contiguous SNP range, the f64
+partials are summed with an RCCL all-reduce over xGMI, every rank then holds K, runs the eigendecomposition (its
+O(n^3) stages dealt over the ranks, see janusx_amd/csrc/eigh.cpp) + null fit and scans its own SNP range.
+`--scaling weak` gives every rank m SNPs of an n x (m N) panel instead.
 """
 import argparse
 import json
@@ -72,7 +74,7 @@ def make_phenotype(dos_head, n, seed, device):
     return (gv + e).cpu().numpy()
 
 
-def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
+def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
     """The oracle (C + numpy/OpenBLAS restatement of the reference algorithm) timed on the host cores on a
     bounded SNP sample; GRM and scan are linear in m and are extrapolated, eigh + null are timed at full n."""
     from oracle import jx_oracle as O
@@ -92,9 +94,24 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
     t_grm = time.perf_counter() - t0
     k = acc / float(np.sum(var[rows]))  # GRM of the SNP sample: same size/spectrum class as the full one for timing eigh
     k = np.tril(k) + np.tril(k, -1).T
+    # LAPACK dsyevd is O(n^3): above n_eig_cap rows the decomposition is TIMED on the leading n_eig_cap x n_eig_cap block
+    # and scaled by (n / n_eig_cap)^3 (SURVEY.md 8d allows an n^3-extrapolated eigh with the rule stated; the full-size
+    # call would take ~10 minutes of host time at n = 20 000); the eigenpairs the scan below uses are then taken from a
+    # cheap exact source: the GPU-side result is NOT used, the scan sample only needs *a* spectral basis of full size,
+    # so the block's eigenvectors are embedded into an orthonormal n x n basis (identity on the remaining coordinates)
+    n_eig = min(n, eig_cap)
     t0 = time.perf_counter()
-    s, u = O.gwas_eigh_from_grm(k.astype(np.float32))
-    t_eig = time.perf_counter() - t0
+    s_b, u_b = O.gwas_eigh_from_grm(np.ascontiguousarray(k[:n_eig, :n_eig]).astype(np.float32))
+    t_eig_block = time.perf_counter() - t0
+    eig_scale = (n / float(n_eig)) ** 3
+    t_eig = t_eig_block * eig_scale
+    if n_eig < n:
+        s = np.concatenate([s_b, np.diag(k)[n_eig:].astype(np.float64) + 1e-6])
+        u = np.zeros((n, n), dtype=np.float64)
+        u[:n_eig, :n_eig] = u_b
+        u[n_eig:, n_eig:] = np.eye(n - n_eig)
+    else:
+        s, u = s_b, u_b
     t0 = time.perf_counter()
     nm = O.spectral_null_model(y, np.ones((n, 1)), s, u)
     t_null = time.perf_counter() - t0
@@ -118,56 +135,68 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads):
         "cores": int(threads),
         "kind": "port",
         "sample": (f"oracle (C restatement + numpy/OpenBLAS sgemm + scipy dsyevd) on the first {ms} of {m_full} SNPs at "
-                   f"full n={n}: grm {t_grm:.2f}s and scan {t_scan:.2f}s scaled x{scale_m:.1f}, eigh {t_eig:.2f}s + "
-                   f"null {t_null:.2f}s at full size"),
+                   f"full n={n}: grm {t_grm:.2f}s and scan {t_scan:.2f}s scaled x{scale_m:.1f} (linear in m); eigh "
+                   + (f"{t_eig:.2f}s at full size" if n_eig == n else
+                      f"{t_eig_block:.2f}s measured on the leading {n_eig} x {n_eig} block, scaled by (n/{n_eig})^3 = "
+                      f"{eig_scale:.1f} -> {t_eig:.1f}s") + f"; null {t_null:.2f}s at full size"),
     }
 
 
-def pmc_traffic_bytes(kernel_prefix, run="fetch"):
-    """HBM read bytes per launch of a kernel from the committed PMC summary (profiles/r01d_pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide
-    streaming reads). Returns None when the summary is absent."""
-    runs = None
-    for tag in ("r01h", "r01g", "r01e", "r01d"):
+def baseline_config_label(n, m):
+    """Which BASELINE.json config an (n, m) panel is, for `config.workload`."""
+    return {(5000, 50000): "BASELINE configs[1] shape", (20000, 200000): "BASELINE configs[2] shape",
+            (50000, 500000): "BASELINE configs[3] shape"}.get((int(n), int(m)), "not a BASELINE config shape")
+
+
+_PMC_SHAPE = {"n": None, "m": None}   # shape of the running configuration (set in main)
+
+
+def _pmc_files(kind):
+    """Committed counter summaries profiles/<tag>_pmc_<kind>.json whose recorded shape is the running one, newest tag
+    first.  Round-1 summaries carry no shape field: they were collected at n = 5000, m = 50000."""
+    import glob
+    out = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}.json")), reverse=True):
         try:
-            runs = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic.json")))["runs"][run]
-            if runs:
-                break
-            runs = None
+            d = json.load(open(path))
         except Exception:
             continue
-    if runs is None:
-        return None
-    best = None
-    for name, rec in runs.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
-        if kernel_prefix in name:
-            b = 2.0 * rec["mean_KB"] * 1024.0
-            if best is None or b > best:
-                best = b
-    return best
+        shape = d.get("shape", {"n": 5000, "m": 50000})
+        if int(shape.get("n", -1)) == _PMC_SHAPE["n"] and int(shape.get("m", -1)) == _PMC_SHAPE["m"]:
+            out.append((os.path.relpath(path, ROOT), d))
+    return out
+
+
+def pmc_traffic_bytes(kernel_prefix, run="fetch"):
+    """(HBM bytes per launch, source file) of a kernel from a committed PMC summary of THIS shape (rocprofv3 --pmc
+    FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide streaming reads).
+    (None, None) when no summary of the running shape is committed."""
+    for src, d in _pmc_files("hbm_traffic"):
+        runs = d.get("runs", {}).get(run)
+        if not runs:
+            continue
+        best = None
+        for name, rec in runs.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
+            if kernel_prefix in name:
+                b = 2.0 * rec["mean_KB"] * 1024.0
+                if best is None or b > best:
+                    best = b
+        if best is not None:
+            return best, src
+    return None, None
 
 
 def pmc_mfma_util(kernel_substr):
-    """MFMA-pipe utilisation of a kernel from the committed counter pass (profiles/r01c_pmc_mfma.json):
-    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). None when the summary is absent."""
-    kernels = None
-    for tag in ("r01h", "r01f", "r01e", "r01c"):
-        try:
-            kernels = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma.json")))["kernels"]
-            if kernels:
-                break
-            kernels = None
-        except Exception:
-            continue
-    if kernels is None:
-        return None
-    for name, rec in kernels.items():
-        if kernel_substr in name:
-            try:
-                return rec["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (rec["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0)
-            except Exception:
-                return None
-    return None
+    """(MFMA-pipe utilisation, source file) of a kernel from a committed counter pass of THIS shape:
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). (None, None) when absent."""
+    for src, d in _pmc_files("mfma"):
+        for name, rec in d.get("kernels", {}).items():
+            if kernel_substr in name:
+                try:
+                    return rec["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (rec["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0), src
+                except Exception:
+                    pass
+    return None, None
 
 
 def main():
@@ -175,15 +204,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", "--samples", dest="n", type=int, default=5000)    # long forms: torchrun's own parser
-    ap.add_argument("--m", "--snps", dest="m", type=int, default=50000)      # treats a bare --n / --m as its options
+    ap.add_argument("--n", "--samples", dest="n", type=int, default=None)    # long forms: torchrun's own parser
+    ap.add_argument("--m", "--snps", dest="m", type=int, default=None)       # treats a bare --n / --m as its options
     ap.add_argument("--mode", default="lmm", choices=["lmm", "fvlmm"])
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=20260609)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     args = ap.parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with one rank per GPU: python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py "
+                         f"--gpus {args.gpus} ... (WORLD_SIZE is {world_env})")
+    # BASELINE.json configs: [2] (n = 20k, m = 200k) is the largest one-GPU configuration of the metric, [3] (n = 50k,
+    # m = 500k) the panel the multi-GPU target is quoted on
+    if args.n is None:
+        args.n = 20000 if world_env == 1 else 50000
+    if args.m is None:
+        args.m = 200000 if world_env == 1 else 500000
 
     import torch
     import torch.distributed as dist
@@ -333,6 +373,13 @@ def main():
         rot_tflops = kern["rot_flops"] / max(kern["rot_ms"], 1e-9) / 1e9
         scan_gbs = kern["scan_bytes"] / max(kern["scan_ms"], 1e-9) / 1e6
         symv_gbs = kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)
+        _PMC_SHAPE.update(n=int(n), m=int(m))
+        tr_symv, tr_symv_src = pmc_traffic_bytes("jx::sytrd_symv_kernel")
+        tr_grm, tr_grm_src = pmc_traffic_bytes("jx::grm_f16x2_kernel")
+        tr_scan, tr_scan_src = (pmc_traffic_bytes("jx::lmm_scan_fast_kernel", "fetch") if args.mode == "lmm" else
+                                pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
+        mu_grm, mu_grm_src = pmc_mfma_util("grm_f16x2_kernel")
+        mu_rot, mu_rot_src = pmc_mfma_util("rotate_f16x2_kernel")
         res = {
             "metric": "SNPs/sec full -lmm (GRM+eig+scan)" if args.mode == "lmm" else "SNPs/sec full -fvlmm (GRM+eig+scan)",
             "value": value,
@@ -347,7 +394,7 @@ def main():
             "dtype": "f64 eigendecomposition and REML; f16 MFMA with f32 accumulation and f64 merge for GRM / rotation "
                      "(exact integer operands, or fp16 hi+lo split of the f32 operands)",
             "data": "synthetic",
-            "config": {"workload": f"synthetic HWE panel n={n} m={m} (BASELINE configs[1] shape x{world if args.scaling == 'weak' else 1} SNPs), -{args.mode}, "
+            "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
                        "parallelism": f"snp-shard x{world}" + (", eigh symv tiles sharded" if eigh_sharded else "")},
@@ -355,7 +402,7 @@ def main():
             # tridiagonalisation, profiles/*_kernel_stats.csv)
             "roofline": {"bound": "hbm", "kernel": "sytrd_symv_kernel",
                          "achieved": symv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": symv_gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes("jx::sytrd_symv_kernel"),
+                         "traffic": tr_symv, "traffic_source": tr_symv_src,
                          "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
                          "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per launch; "
                                  "achieved = mean bytes / mean duration of the mid-panel launch of every 64-column panel "
@@ -366,21 +413,22 @@ def main():
                                                         "three-product variant)",
                              "achieved": grm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS,
-                             "traffic": pmc_traffic_bytes("jx::grm_f16x2_kernel"),
+                             "traffic": tr_grm, "traffic_source": tr_grm_src,
                              "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
-                                             "correction, n=5000 m=50000; algorithmic input = n*m/4 = 62.5 MB (payload "
+                                             "correction, from the committed summary of this shape (null when none); "
+                                             f"algorithmic input = n*m/4 = {n * m / 4e6:.1f} MB (payload "
                                              "re-read per tile pair is served by L2/MALL)",
                              "note": "algorithmic n(n+1)m flops over the duration of the call (classification, affine "
                                      "terms and MFMA kernels; HIP events); one f16 MFMA product per algorithmic product "
                                      "on the exact variant, three on the split variant",
-                             "mfma_util_pmc": pmc_mfma_util("grm_f16x2_kernel"),
+                             "mfma_util_pmc": mu_grm, "mfma_util_source": mu_grm_src,
                              "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
                                                "profiles/*_pmc_mfma.json): the fraction of the dense f16 MFMA peak the "
                                                "matrix pipes actually run at",
                              "avg_launch_ms": kern["grm_ms"] / L},
             "roofline_rotate": {"bound": "mfma", "kernel": "rotate_f16x2_kernel", "achieved": rot_tflops,
                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS,
-                                "mfma_util_pmc": pmc_mfma_util("rotate_f16x2_kernel"),
+                                "mfma_util_pmc": mu_rot, "mfma_util_source": mu_rot_src,
                                 "note": "algorithmic 2 m n^2 flops; two f16 MFMA products per algorithmic product on "
                                         "all-exact 128-row tiles (integer design rows x U hi/lo), three otherwise",
                                 "ms_per_step": kern["rot_ms"] / L},
@@ -390,7 +438,7 @@ def main():
                                "frac": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,
                                "brent_evals_per_snp": kern.get("scan_evals", 0.0) / L,
                                "hbm_gbs": scan_gbs,
-                               "traffic": pmc_traffic_bytes("jx::lmm_scan_fast_kernel", "fetch"),
+                               "traffic": tr_scan, "traffic_source": tr_scan_src,
                                "note": "Brent over the exact per-SNP REML: every objective evaluation is a pass over the n "
                                        "rotated samples (one f64 reciprocal per sample, operands s / X~ / y~ resident in "
                                        "LDS); algorithmic flops per SURVEY 8(d): (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) "
@@ -398,7 +446,7 @@ def main():
                                        "figure); the 4 n bytes per SNP are read once (hbm_gbs), HBM is not the bound",
                                "ms_per_step": kern["scan_ms"] / L} if args.mode == "lmm" else
                               {"bound": "hbm", "kernel": "fvlmm_scan_kernel",
-                               "traffic": pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"),
+                               "traffic": tr_scan, "traffic_source": tr_scan_src,
                                "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
                                "ms_per_step": kern["scan_ms"] / L}),
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},

@@ -401,8 +401,9 @@ def test_pipeline_end_to_end(oracle, oracle_c):
         else:
             ref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
         be, se, pe = _assoc_err(res.stats, ref)
-        # end-to-end: GRM (f32) and eigenvectors come from different f32/f64 summation orders on the two sides
-        assert max(be, se, pe) < 1e-4, (mode, be, se, pe)
+        # end-to-end: GRM (f32) and eigenvectors come from different f32/f64 summation orders on the two sides; measured
+        # 1.9e-6 / 1.8e-7 / 2.2e-6 (gpurun_out/parity_maxima.json, round 2), so the north star's 1e-5 holds end to end
+        assert max(be, se, pe) < TOL, (mode, be, se, pe)
 
 
 def test_golden_fixture_gpu():
@@ -596,7 +597,8 @@ def test_config_c1_mouse_hs1940_lmm(oracle, oracle_c):
     ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, nm.bounds[0],
                                           nm.bounds[1], 30, 1e-2)
     be, se, pe = _assoc_err(res.stats, ref)
-    assert max(be, se, pe) < 1e-4, (be, se, pe)  # GRM/eigenvectors differ at f32 rounding level between the two sides
+    # GRM / eigenvectors differ at f32 rounding level between the two sides; measured 5.8e-6 / 1.8e-7 / 6.6e-6 (round 2)
+    assert max(be, se, pe) < TOL, (be, se, pe)
 
 
 def _full_size_properties(oracle, oracle_c, n, m, missing, scan_cap):
@@ -1334,7 +1336,7 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo", JXGPU_DIST_EIGH_MIN_N="512")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--samples", "1000",
-           "--snps", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+           "--snps", "6000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--scaling", "weak"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]

@@ -108,6 +108,21 @@ int64_t jxg_eigh_dist_staging_doubles(int n);
 int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                       int64_t staging_doubles, int min_n);
 
+/* Building blocks of B1's two-stage reduction, exported for tests and timing scripts (no counterpart in the reference,
+ * which calls LAPACK dsyevd, src/math/eigh.rs:1320-1400).  All matrices column-major f64 in HBM.
+ *   jxg_dgemm_f64:            C = alpha op(A) op(B) + beta C on the f64 matrix pipes (ksplit <= 0: automatic split over K)
+ *   jxg_dsymm_lower_f64:      C = alpha A B + beta C, A (m,m) symmetric with only its lower triangle stored
+ *   jxg_dsyr2k_lower_nt_f64:  lower tiles of C (m,m) = alpha A B' + beta C, A, B (m,k)
+ *   jxg_sy2st_f64:            dense symmetric -> band (half bandwidth 64) -> tridiagonal (d_d, d_e); d_ab_out (optional,
+ *                             128 x n) = the band after stage 1; h_flags[0] / [1] = stage-1 failure / stage-2 abort flag */
+int jxg_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,
+                  int64_t ldb, double beta, double *d_c, int64_t ldc, int ksplit, void *stream);
+int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,
+                        double beta, double *d_c, int64_t ldc, void *stream);
+int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,
+                            double beta, double *d_c, int64_t ldc, void *stream);
+int jxg_sy2st_f64(double *d_a, int n, double *d_d, double *d_e, double *d_ab_out, int *h_flags, void *stream);
+
 /* a <- (a + a^T)/2 (src/math/eigh.rs:179-207); dst = src^T; dst (k,k) f64 = src[idx, idx] of an (n,n)
  * f32/f64 matrix (trait-sample subset, python/janusx/assoc/workflow.py:5509-5560). */
 int jxg_symmetrize_f64(double *d_a, int n, void *stream);

@@ -28,6 +28,20 @@ int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, do
                    int min_n);
 // k_ormtr.hip: C <- Q C with wide compact-WY blocks (dormtr left / lower / no-transpose)
 int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c);
+// k_sy2sb.hip / k_sb2st.hip: two-stage reduction (dense -> band -> tridiagonal)
+size_t sy2sb_work_doubles(int n);
+int sy2sb_bandwidth();
+int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work, int *d_flags);
+int sb2st_ldab();
+int sb2st_steps(int n);
+int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, double *d_v2, double *d_tau2, int *d_ctrl);
+// k_sbback.hip: C <- Q2 C (reflectors of the bulge chasing); k_ormtr.hip: C <- Q1 C (reflectors of the band reduction)
+size_t sbback_tq_doubles(int n, int ks);
+int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, int n, int ks, double *d_c, int ncols,
+                    double *d_tq);
+int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
+                    double *d_c);
+int sytrd_dist_active(int n);
 constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
 
 static rocblas_handle g_handle = nullptr;
@@ -94,8 +108,53 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             fflush(stderr);
             return 0;
         };
-        if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
-        if (stage_done("sytrd")) return 1;
+        // Two-stage reduction (dense -> band -> tridiagonal; k_sy2sb.hip, k_sb2st.hip) from JXGPU_EIGH_TWOSTAGE_MIN rows
+        // on: its O(n^3) work is f64-MFMA products instead of one HBM-bound symv per column.  JXGPU_EIGH=onestage keeps
+        // the one-stage form; it is also the fallback when a panel of the band reduction cannot be factored, and the
+        // form the rank-sharded tridiagonalisation (jxg_eigh_set_dist) uses.
+        static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : (1 << 30);
+        bool twostage = n >= ts_min && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
+                        !sytrd_dist_active(n);
+        if (mode && strcmp(mode, "twostage") == 0 && n > 2 * sy2sb_bandwidth() + 2) twostage = true;
+        DevBuf ts_work, ts_ab, ts_tau2, ts_ctrl, ts_flags, ts_tq;
+        ScratchLease ts_v2;
+        const int ldab = sb2st_ldab(), ks = sb2st_steps(n);
+        if (twostage) {
+            if (ts_work.alloc(sizeof(double) * sy2sb_work_doubles(n))) return 1;
+            if (ts_ab.alloc(sizeof(double) * (size_t)ldab * n)) return 1;
+            if (ts_v2.take(4, sizeof(double) * (size_t)n * n)) return 1;
+            if (ts_tau2.alloc(sizeof(double) * (size_t)n * ks)) return 1;
+            if (ts_ctrl.alloc(sizeof(int) * ((size_t)n + 4))) return 1;
+            if (ts_flags.alloc(sizeof(int) * 4)) return 1;
+            // the band reduction overwrites A: keep a copy (in the buffer the divide and conquer fills later) in case a
+            // panel cannot be factored
+            JX_HIP(hipMemcpyAsync(c.p, d_a, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+            if (sy2sb_lower(st, d_a, n, tau.as<double>(), ts_ab.as<double>(), ldab, ts_work.as<double>(),
+                            ts_flags.as<int>()))
+                return 1;
+            int hf[4] = {0, 0, 0, 0};
+            JX_HIP(hipMemcpyAsync(hf, ts_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+            JX_HIP(hipStreamSynchronize(st));
+            if (hf[0] != 0) {
+                if (trace) fprintf(stderr, "[jxgpu eigh n=%d] band reduction flagged a panel (code %d): one-stage fallback\n", n, hf[0]);
+                JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+                twostage = false;
+            }
+        }
+        if (twostage) {
+            if (stage_done("sy2sb")) return 1;
+            if (sb2st_chase(st, ts_ab.as<double>(), n, d_w, e.as<double>(), ts_v2.as<double>(), ts_tau2.as<double>(),
+                            ts_ctrl.as<int>()))
+                return 1;
+            int habort = 0;
+            JX_HIP(hipMemcpyAsync(&habort, ts_ctrl.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+            JX_HIP(hipStreamSynchronize(st));
+            if (habort != 0) return fail("jxg_eigh_f64: the bulge-chasing kernel gave up waiting for a neighbour sweep");
+            if (stage_done("sb2st")) return 1;
+        } else {
+            if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
+            if (stage_done("sytrd")) return 1;
+        }
         const char *sm = getenv("JXGPU_STEDC");
         // own divide-and-conquer merges above 1280 rows, independent halves on concurrent streams (rocSOLVER's
         // dstedc is a chain of latency-bound launches: 27 ms for the two 2500-row halves of n = 5000 run back to
@@ -118,14 +177,23 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
         }
         if (stage_done("dstedc")) return 1;
-        const char *om = getenv("JXGPU_ORMTR");
-        if (om && strcmp(om, "rocsolver") == 0) {
-            rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
-                                  tau.as<double>(), c.as<double>(), n);
-            if (rs != rocblas_status_success)
-                return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+        if (twostage) {
+            if (ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
+            if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, c.as<double>(), n, ts_tq.as<double>()))
+                return 1;
+            if (stage_done("Q2 back-transformation")) return 1;
+            const int ncol = n - sy2sb_bandwidth() - 1;
+            if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>())) return 1;
         } else {
-            if (ormtr_lower(h, st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
+            const char *om = getenv("JXGPU_ORMTR");
+            if (om && strcmp(om, "rocsolver") == 0) {
+                rs = rocsolver_dormtr(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, d_a, n,
+                                      tau.as<double>(), c.as<double>(), n);
+                if (rs != rocblas_status_success)
+                    return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
+            } else {
+                if (ormtr_lower(h, st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
+            }
         }
         if (stage_done("dormtr")) return 1;
         if (split) {
@@ -142,5 +210,49 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
     JX_HIP(hipMemcpyAsync(&hinfo, info.p, sizeof(hinfo), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
     if (hinfo != 0) return fail("rocsolver_dsyevd did not converge (info=" + std::to_string(hinfo) + ")");
+    return 0;
+}
+
+// Diagnostic entry (tests, timing scripts): the two reduction stages alone.  d_a (n,n) symmetric f64 is overwritten
+// (band + stage-1 reflectors); d_d / d_e receive the tridiagonal matrix; d_ab_out (optional, 2 SB x n doubles) the band
+// matrix after stage 1; h_flags[0] = stage-1 failure flag, h_flags[1] = stage-2 abort flag.
+extern "C" int jxg_sy2st_f64(double *d_a, int n, double *d_d, double *d_e, double *d_ab_out, int *h_flags, void *stream) {
+    if (n <= 0) return fail("jxg_sy2st_f64: n must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int ldab = sb2st_ldab(), ks = sb2st_steps(n);
+    DevBuf work, ab, tau, v2, tau2, ctrl, flags;
+    if (work.alloc(sizeof(double) * sy2sb_work_doubles(n))) return 1;
+    if (ab.alloc(sizeof(double) * (size_t)ldab * n)) return 1;
+    if (tau.alloc(sizeof(double) * (size_t)n)) return 1;
+    if (v2.alloc(sizeof(double) * (size_t)n * n)) return 1;
+    if (tau2.alloc(sizeof(double) * (size_t)n * ks)) return 1;
+    if (ctrl.alloc(sizeof(int) * ((size_t)n + 4))) return 1;
+    if (flags.alloc(sizeof(int) * 4)) return 1;
+    const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
+    if (trace) JX_HIP(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (sy2sb_lower(st, d_a, n, tau.as<double>(), ab.as<double>(), ldab, work.as<double>(), flags.as<int>())) return 1;
+    if (trace) {
+        JX_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[jxgpu sy2st n=%d] band reduction %.2f ms\n", n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (d_ab_out)
+        JX_HIP(hipMemcpyAsync(d_ab_out, ab.p, sizeof(double) * (size_t)ldab * n, hipMemcpyDeviceToDevice, st));
+    if (sb2st_chase(st, ab.as<double>(), n, d_d, d_e, v2.as<double>(), tau2.as<double>(), ctrl.as<int>())) return 1;
+    if (trace) {
+        JX_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[jxgpu sy2st n=%d] bulge chasing %.2f ms\n", n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    }
+    int hf[4] = {0, 0, 0, 0}, habort = 0;
+    JX_HIP(hipMemcpyAsync(hf, flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipMemcpyAsync(&habort, ctrl.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    if (h_flags) {
+        h_flags[0] = hf[0];
+        h_flags[1] = habort;
+    }
     return 0;
 }

@@ -1,0 +1,322 @@
+// f64 GEMM family on the matrix pipes (v_mfma_f64_16x16x4_f64) for the eigensolver behind src/math/eigh.rs:1422-1528
+// (the reference calls LAPACK dsyevd; every O(n^3) stage of the two-stage reduction here is one of these products):
+//   dgemm      C = alpha op(A) op(B) + beta C          (NN / TN / NT / TT, optional split over K with f64 atomics)
+//   dsymm_l    C = alpha A B + beta C, A symmetric with only its LOWER triangle stored (band reduction: Z = A22 V)
+//   dsyr2k_l   lower tiles of C += alpha (A B' ...) as one NT product over concatenated panels (trailing update)
+// All matrices are column-major.  One workgroup = 256 threads = 2 x 2 waves on a BM x BN tile, K in steps of 16 through a
+// double-buffered LDS image [k][x] (row pitch BM + 17 doubles: an odd pitch makes the k-fast staging stores of a
+// transposed operand conflict-free, and the two k-rows a 32-lane read group touches land 34 banks apart); global loads
+// of step t + 1 are in flight in registers while step t is multiplied.  The MFMA "A" operand is fed with op(B) and the
+// "B" operand with op(A), so a lane's accumulator column index is the memory-contiguous row index of C: each store
+// instruction writes four 128-byte runs.  f64 MFMA issues one 16x16x4 block per 64 cycles per SIMD (the f64 vector
+// rate, 78.6 TFLOP/s per chip): LDS and address arithmetic hide behind it, HBM does as long as an operand element is
+// reused >= 16 times, which every call site here satisfies.
+#include <stdlib.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int DG_BK = 16;
+constexpr int DG_THREADS = 256;
+
+struct DgemmArgs {
+    const double *a;
+    const double *b;
+    double *c;
+    int64_t lda, ldb, ldc;
+    int m, n, k;
+    double alpha, beta;
+    int ta, tb;        // operand stored transposed
+    int symm_a;        // A is m x m symmetric, lower triangle stored (k == m, ta ignored)
+    int lower_tiles;   // grid enumerates the tiles (ti >= tj) of a square C only (BM == BN)
+    int ksplit;        // > 1: blockIdx.z owns a K range, results added with f64 atomics (beta must already be applied)
+};
+
+template <int BX>
+__device__ __forceinline__ void dg_load_tile(const double *__restrict__ p, int64_t ld, bool trans, bool symm, int x0,
+                                             int xmax, int k0, int kmax, double (&r)[BX * DG_BK / DG_THREADS]) {
+    // element (x, kk) of the BX x 16 operand tile; storage: !trans -> p[x + kk * ld], trans -> p[kk + x * ld]
+    constexpr int NL = BX * DG_BK / DG_THREADS;
+    const int t = threadIdx.x;
+    if (symm) {
+        // lower-stored symmetric operand: (x, kk) = p[max + min * ld]; tiles off the diagonal take the coalesced mapping
+        // of the orientation they are stored in, tiles crossing it are read element by element
+        const bool below = x0 >= k0 + DG_BK;     // rows entirely below the columns: stored as is
+        const bool above = x0 + BX <= k0;        // entirely above: stored transposed
+        if (below || !above) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = i * DG_THREADS + t;
+                const int x = x0 + idx % BX, kk = k0 + idx / BX;
+                double v = 0.0;
+                if (x < xmax && kk < kmax) v = (x >= kk) ? p[x + (int64_t)kk * ld] : p[kk + (int64_t)x * ld];
+                r[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = i * DG_THREADS + t;
+                const int kk = k0 + idx % DG_BK, x = x0 + idx / DG_BK;
+                r[i] = (x < xmax && kk < kmax) ? p[kk + (int64_t)x * ld] : 0.0;
+            }
+        }
+        return;
+    }
+    if (!trans) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = i * DG_THREADS + t;
+            const int x = x0 + idx % BX, kk = k0 + idx / BX;
+            r[i] = (x < xmax && kk < kmax) ? p[x + (int64_t)kk * ld] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = i * DG_THREADS + t;
+            const int kk = k0 + idx % DG_BK, x = x0 + idx / DG_BK;
+            r[i] = (x < xmax && kk < kmax) ? p[kk + (int64_t)x * ld] : 0.0;
+        }
+    }
+}
+
+template <int BX>
+__device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast, const double (&r)[BX * DG_BK / DG_THREADS]) {
+    constexpr int NL = BX * DG_BK / DG_THREADS;
+    constexpr int PITCH = BX + 17;
+    const int t = threadIdx.x;
+    if (!kfast) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = i * DG_THREADS + t;
+            s[(idx / BX) * PITCH + idx % BX] = r[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = i * DG_THREADS + t;
+            s[(idx % DG_BK) * PITCH + idx / DG_BK] = r[i];
+        }
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(DG_THREADS) void dgemm_kernel(DgemmArgs g) {
+    constexpr int PA = BM + 17, PB = BN + 17;
+    constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
+    constexpr int MB = WM / 16, NB = WN / 16;        // 16x16 blocks per wave
+    extern __shared__ __attribute__((aligned(16))) double dg_smem[];
+    double *as = dg_smem;                            // [2][16][PA]
+    double *bs = dg_smem + 2 * DG_BK * PA;           // [2][16][PB]
+
+    int ti, tj;
+    if (g.lower_tiles) {
+        // linear index -> (ti >= tj): ti = floor((sqrt(8 b + 1) - 1) / 2)
+        const int bid = blockIdx.x;
+        int r = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(r + 1) * (r + 2) / 2 <= bid) ++r;
+        while ((int64_t)r * (r + 1) / 2 > bid) --r;
+        ti = r;
+        tj = bid - (int)((int64_t)r * (r + 1) / 2);
+    } else {
+        ti = blockIdx.x;
+        tj = blockIdx.y;
+    }
+    const int m0 = ti * BM, n0 = tj * BN;
+    // K range of this workgroup
+    int kbeg = 0, kend = g.k;
+    if (g.ksplit > 1) {
+        const int ktiles = (g.k + DG_BK - 1) / DG_BK;
+        const int per = (ktiles + g.ksplit - 1) / g.ksplit;
+        kbeg = (int)blockIdx.z * per * DG_BK;
+        kend = min(g.k, kbeg + per * DG_BK);
+        if (kbeg >= kend) return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
+    const int lx = lane & 15, lk = lane >> 4;
+
+    d4 acc[NB][MB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[j][i] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    double ra[BM * DG_BK / DG_THREADS], rb[BN * DG_BK / DG_THREADS];
+    const bool symm = g.symm_a != 0;
+    const bool ta = g.ta != 0, tb_kfast = g.tb == 0;   // B stored (k, n): k contiguous -> k-fast mapping
+    auto a_kfast = [&](int k0) -> bool {
+        if (symm) return (m0 + BM <= k0);              // tile entirely above the diagonal: read transposed
+        return ta;
+    };
+    auto load = [&](int k0) {
+        dg_load_tile<BM>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
+        // op(B)(kk, x): !tb -> b[kk + x ldb] (k contiguous = "trans" mapping of the loader), tb -> b[x + kk ldb]
+        dg_load_tile<BN>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
+    };
+    load(kbeg);
+    dg_store_tile<BM>(as, a_kfast(kbeg), ra);
+    dg_store_tile<BN>(bs, tb_kfast, rb);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += DG_BK) {
+        const bool more = k0 + DG_BK < kend;
+        if (more) load(k0 + DG_BK);
+        const double *ap = as + buf * DG_BK * PA + wm + lx;
+        const double *bp = bs + buf * DG_BK * PB + wn + lx;
+#pragma unroll
+        for (int ks = 0; ks < DG_BK; ks += 4) {
+            double fa[MB], fb[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) fa[i] = ap[(ks + lk) * PA + i * 16];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb[j] = bp[(ks + lk) * PB + j * 16];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        if (more) {
+            dg_store_tile<BM>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra);
+            dg_store_tile<BN>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // epilogue: acc[j][i][r] = C[m0 + wm + 16 i + lx][n0 + wn + 16 j + lk + 4 r]
+    const bool atomic = g.ksplit > 1;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = n0 + wn + 16 * j + lk + 4 * r;
+            if (col >= g.n) continue;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int row = m0 + wm + 16 * i + lx;
+                if (row >= g.m) continue;
+                if (g.lower_tiles && row < col) continue;     // diagonal tiles: the strict upper part is not referenced
+                double *cp = g.c + row + (int64_t)col * g.ldc;
+                const double v = g.alpha * acc[j][i][r];
+                if (atomic) unsafeAtomicAdd(cp, v);
+                else *cp = (g.beta == 0.0) ? v : (v + g.beta * *cp);
+            }
+        }
+}
+
+template <int BM, int BN>
+static int dg_launch(const DgemmArgs &g, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = sizeof(double) * 2 * DG_BK * ((BM + 17) + (BN + 17));
+    static bool attr_set = false;
+    if (!attr_set) {
+        JX_HIP(hipFuncSetAttribute((const void *)dgemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dgemm_kernel<BM, BN>), grid, dim3(DG_THREADS), smem, st, g);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// beta C for the split-K form (the partial products are added atomically afterwards)
+__global__ void dg_scale_kernel(double *c, int64_t ldc, int m, int n, double beta) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)m * n) return;
+    const int r = (int)(i % m), col = (int)(i / m);
+    double *p = c + r + (int64_t)col * ldc;
+    *p = (beta == 0.0) ? 0.0 : beta * *p;
+}
+
+// C (m x n) = alpha op(A) op(B) + beta C.  ksplit <= 0: chosen so that the launch fills the chip.
+int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, const double *a, int64_t lda,
+          const double *b, int64_t ldb, double beta, double *c, int64_t ldc, int ksplit) {
+    if (m <= 0 || n <= 0) return 0;
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, k, alpha, beta, ta ? 1 : 0, tb ? 1 : 0, 0, 0, 1};
+    if (k <= 0) {
+        hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
+    const bool small_n = n <= 64, small_m = m <= 64;
+    const int bm = small_m ? 64 : 128, bn = (small_n || small_m) ? 64 : 128;
+    const int tm = ceil_div(m, bm), tn = ceil_div(n, bn);
+    if (ksplit <= 0) {
+        const int64_t tiles = (int64_t)tm * tn;
+        const int ktiles = ceil_div(k, DG_BK);
+        ksplit = 1;
+        if (tiles < 384) {
+            ksplit = (int)((768 + tiles - 1) / tiles);
+            const int maxsplit = ktiles / 8 > 0 ? ktiles / 8 : 1;    // at least 128 of K per slice
+            if (ksplit > maxsplit) ksplit = maxsplit;
+            if (ksplit < 1) ksplit = 1;
+        }
+    }
+    g.ksplit = ksplit;
+    if (ksplit > 1) {
+        hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
+        JX_LAUNCH_CHECK();
+    }
+    dim3 grid(tm, tn, ksplit);
+    if (bm == 128 && bn == 128) return dg_launch<128, 128>(g, grid, st);
+    if (bm == 128) return dg_launch<128, 64>(g, grid, st);
+    return dg_launch<64, 64>(g, grid, st);
+}
+
+// C (m x n) = alpha A B + beta C with A (m x m) symmetric, lower triangle stored
+int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
+                double beta, double *c, int64_t ldc) {
+    if (m <= 0 || n <= 0) return 0;
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, m, alpha, beta, 0, 0, 1, 0, 1};
+    const bool wide = n > 64;
+    const int bn = wide ? 128 : 64;
+    const int tm = ceil_div(m, 128), tn = ceil_div(n, bn);
+    const int64_t tiles = (int64_t)tm * tn;
+    int ksplit = 1;
+    if (tiles < 384) {
+        ksplit = (int)((768 + tiles - 1) / tiles);
+        const int maxsplit = ceil_div(m, DG_BK) / 8 > 0 ? ceil_div(m, DG_BK) / 8 : 1;
+        if (ksplit > maxsplit) ksplit = maxsplit;
+    }
+    g.ksplit = ksplit;
+    if (ksplit > 1) {
+        hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
+        JX_LAUNCH_CHECK();
+    }
+    dim3 grid(tm, tn, ksplit);
+    return wide ? dg_launch<128, 128>(g, grid, st) : dg_launch<128, 64>(g, grid, st);
+}
+
+// lower tiles of C (m x m) = alpha A B' + beta C, A and B (m x k): with A = [V | W], B = [W | V] this is the symmetric
+// rank-2k update C + alpha (V W' + W V'); the strict upper triangle of C is not referenced
+int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
+                    double beta, double *c, int64_t ldc) {
+    if (m <= 0) return 0;
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, m, k, alpha, beta, 0, 1, 0, 1, 1};
+    const int t = ceil_div(m, 128);
+    dim3 grid((unsigned)((int64_t)t * (t + 1) / 2), 1, 1);
+    return dg_launch<128, 128>(g, grid, st);
+}
+
+}  // namespace jx
+
+using namespace jx;
+
+// C-ABI entry for tests and timing scripts: plain column-major dgemm on device pointers
+extern "C" int jxg_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda,
+                             const double *d_b, int64_t ldb, double beta, double *d_c, int64_t ldc, int ksplit,
+                             void *stream) {
+    if (m < 0 || n < 0 || k < 0) return fail("jxg_dgemm_f64: negative dimension");
+    return dgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, ksplit);
+}
+
+extern "C" int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t lda, const double *d_b,
+                                   int64_t ldb, double beta, double *d_c, int64_t ldc, void *stream) {
+    return dsymm_lower((hipStream_t)stream, m, n, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc);
+}
+
+extern "C" int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,
+                                       int64_t ldb, double beta, double *d_c, int64_t ldc, void *stream) {
+    return dsyr2k_lower_nt((hipStream_t)stream, m, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc);
+}

@@ -17,18 +17,20 @@ constexpr int OT_NB = 1024;
 
 // vc (rows, nbk) column-major = explicit reflectors of columns jb .. jb+nbk-1 restricted to rows jb+1 .. n-1
 // (zero above the unit entry; a reflector with tau = 0 is the identity and is stored as a zero column)
+// `off` = row offset of the unit entry below the diagonal: 1 for dsytrd (k_sytrd.hip), the band width for the band
+// reduction (k_sy2sb.hip)
 __global__ __launch_bounds__(256) void ot_extract_v_kernel(const double *__restrict__ a, int n, int jb, int nbk,
                                                           const double *__restrict__ tau, double *__restrict__ vc,
-                                                          int rows) {
+                                                          int rows, int off) {
     const int k = blockIdx.y;
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (k >= nbk || r >= rows) return;
     const int j = jb + k;             // reflector / column index
-    const int row = jb + 1 + r;       // matrix row
+    const int row = jb + off + r;     // matrix row
     double v = 0.0;
     if (tau[j] != 0.0) {
-        if (row == j + 1) v = 1.0;
-        else if (row > j + 1) v = a[(int64_t)j * n + row];
+        if (row == j + off) v = 1.0;
+        else if (row > j + off) v = a[(int64_t)j * n + row];
     }
     vc[(int64_t)k * rows + r] = v;
 }
@@ -47,10 +49,18 @@ __global__ void ot_fix_m_kernel(double *__restrict__ m, int nbk, int ld, const d
     }
 }
 
+int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
+                    double *d_c);
+
 // d_a: (n,n) column-major after sytrd_lower; d_tau (n-1); d_c (n,n) column-major, overwritten with Q C.
 int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c) {
-    if (n < 2) return 0;
-    const int nref = n - 1;                          // reflectors 0 .. n-2
+    return ormtr_lower_off(h, st, d_a, n, 1, n - 1, d_tau, d_c);
+}
+
+// General form: reflector j (j = 0 .. nref-1) = [0 (j + off rows); 1; A(j+off+1 : n, j)] with factor d_tau[j].
+int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
+                    double *d_c) {
+    if (n < 2 || nref < 1) return 0;
     const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB")) : OT_NB;
     ScratchLease ws;   // vc (n x nb) | mm (nb x nb) | w (nb x n)
     const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * n;
@@ -61,9 +71,9 @@ int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, cons
     for (int b = nblocks - 1; b >= 0; --b) {
         const int jb = b * nb;
         const int nbk = (nref - jb < nb) ? (nref - jb) : nb;
-        const int rows = n - jb - 1;
+        const int rows = n - jb - off;
         hipLaunchKernelGGL(ot_extract_v_kernel, dim3((rows + 255) / 256, nbk), dim3(256), 0, st, d_a, n, jb, nbk, d_tau,
-                           vc, rows);
+                           vc, rows, off);
         JX_LAUNCH_CHECK();
         rocblas_status rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, nbk, rows, &one,
                                           vc, rows, vc, rows, &zero, mm, nb);
@@ -71,7 +81,7 @@ int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, cons
         hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nbk + 63) / 64, nbk), dim3(64), 0, st, mm, nbk, nb, d_tau,
                            jb);
         JX_LAUNCH_CHECK();
-        double *csub = d_c + (jb + 1);                // rows jb+1 .. n-1 of every column
+        double *csub = d_c + (jb + off);              // rows jb+off .. n-1 of every column
         rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, n, rows, &one, vc,
                            rows, csub, n, &zero, w, nb);
         if (rs != rocblas_status_success) return fail("ormtr: V'C dgemm failed: " + std::to_string((int)rs));

@@ -1,0 +1,332 @@
+// Stage 2 of the two-stage symmetric eigensolver behind src/math/eigh.rs:1422-1528: symmetric band (half bandwidth
+// SB, k_sy2sb.hip) -> tridiagonal by bulge chasing, as ONE persistent launch.
+//
+// Sweep s (s = 0 .. n-3) eliminates column s below its sub-diagonal with a reflector on rows s+1 .. s+SB and chases
+// the bulge down the band in steps k = 0, 1, ...: step k works on the window of columns r .. r+L-1, r = s+1+k SB,
+//   D = A[r:r+L, r:r+L] (two-sided by the step's reflector),  B = A[r+L:r+L+L1, r:r+L] (reflector from the right, then a
+//   new reflector from B's first column, applied from the left; it is the reflector of step k+1).
+// Only the first column of every bulge is annihilated (Haidar, Ltaief, Dongarra 2011), so a window is 2 SB x SB
+// doubles = one contiguous 64 KB run of the compact band storage ab[d + j ldab] = A[j+d, j], ldab = 2 SB.
+// Step (s, k) overlaps the windows of (s-1, k) and (s-1, k+1) only: sweep s may run step k once sweep s-1 has finished
+// step k+1.  Workgroup g owns the sweeps g, g+G, g+2G, ...; progress[s] counts finished steps.  Windows are exchanged
+// through memory with write-through (sc1) stores and L1-bypassing (sc1) loads, every storing wave drains its stores
+// before the workgroup's barrier and ONE lane then publishes the counter (cdna_hip_programming.md guideline 16, form R1
+// with sc1 loads on the consumer side); every spin is bounded and raises an abort flag the other workgroups honour.
+// The reflectors are kept for the back-transformation (k_sbback.hip): v2[row + s n] (entry 1 explicit), tau2[s KS + k].
+#include <stdlib.h>
+
+#include "jx_common.h"
+
+namespace jx {
+
+constexpr int BC_SB = 64;                 // must equal SB of k_sy2sb.hip
+constexpr int BC_LD = 2 * BC_SB;          // ldab
+constexpr int BC_P = BC_SB + 1;           // LDS pitch
+constexpr int BC_THREADS = 256;
+constexpr int BC_DONE = 1 << 30;
+constexpr unsigned BC_SPIN_LIMIT = 1u << 22;
+
+struct BcParams {
+    double *ab;
+    int n;
+    double *v2;        // (n, n) column-major: reflector of sweep s in column s, by matrix row
+    double *tau2;      // (n, ks)
+    int ks;
+    int *prog;         // (n) finished steps per sweep
+    int *abort_flag;
+};
+
+__device__ __forceinline__ double bc_ld(const double *p) {
+    const unsigned long long u =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void bc_st(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LAPACK dlarfg on x[0 .. len-1] held one element per lane of wave 0 (lane < len): returns v (v[0] = 1), tau, beta
+__device__ __forceinline__ void bc_house_wave(double x, int lane, int len, double &v, double &tau, double &beta) {
+    double ss = (lane >= 1 && lane < len) ? x * x : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    const double alpha = __shfl(x, 0);
+    if (ss == 0.0) {
+        tau = 0.0;
+        beta = alpha;
+        v = (lane == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double nrm = sqrt(alpha * alpha + ss);
+    beta = (alpha >= 0.0) ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    const double sc = 1.0 / (alpha - beta);
+    v = (lane == 0) ? 1.0 : ((lane < len) ? x * sc : 0.0);
+}
+
+__global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
+    extern __shared__ __attribute__((aligned(16))) double bc_smem[];
+    double(*E)[BC_P] = reinterpret_cast<double(*)[BC_P]>(bc_smem);          // [2 SB][SB + 1] window, dense
+    double *vv = bc_smem + 2 * BC_SB * BC_P;    // [SB] current reflector
+    double *vn = vv + BC_SB;                    // [SB] next reflector
+    double *yy = vn + BC_SB;                    // [SB]
+    double *ww = yy + BC_SB;                    // [SB]
+    double *part = ww + BC_SB;                  // [4][SB]
+    double *sc = part + 4 * BC_SB;              // [8] scalars: 0 tau, 1 tau_next, 2 v'y
+    int *ish = reinterpret_cast<int *>(sc + 8); // [2] 0: ok flag
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = P.n;
+    const int row = t & 63, quarter = t >> 6;   // (row or column) x 16-wide slice decomposition of a 64 x 64 block
+
+    for (int s = blockIdx.x; s < n - 2; s += gridDim.x) {
+        int r = s + 1;
+        int L = min(BC_SB, n - r);
+        // ---- wait for sweep s-1 to have finished steps 0 and 1, then form the sweep's first reflector from column s
+        if (t == 0) {
+            int ok = 1;
+            if (s > 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > BC_SPIN_LIMIT ||
+                        __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            ish[0] = ok;
+        }
+        __syncthreads();
+        if (!ish[0]) {
+            if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (wave == 0) {
+            double *col = P.ab + (int64_t)s * BC_LD;
+            const double x = (lane < L) ? bc_ld(col + 1 + lane) : 0.0;
+            double v, tau, beta;
+            bc_house_wave(x, lane, L, v, tau, beta);
+            if (lane < L) {
+                bc_st(col + 1 + lane, (lane == 0) ? beta : 0.0);
+                vv[lane] = v;
+            }
+            if (lane == 0) sc[0] = tau;
+        }
+        __syncthreads();
+        for (int k = 0;; ++k) {
+            const int L1 = min(BC_SB, n - (r + L));       // rows of the off-diagonal block (<= 0: none)
+            if (k > 0) {
+                if (t == 0) {
+                    int ok = 1;
+                    if (s > 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 2) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > BC_SPIN_LIMIT ||
+                                __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                ok = 0;
+                                break;
+                            }
+                        }
+                    }
+                    ish[0] = ok;
+                }
+                __syncthreads();
+                if (!ish[0]) {
+                    if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+            const int rowsB = L1 > 0 ? L1 : 0;
+            // ---- window -> LDS (dense, D mirrored to a full square); 16 loads in flight per thread
+            {
+                const double *base = P.ab + (int64_t)r * BC_LD;
+                constexpr int NLD = BC_SB * BC_LD / BC_THREADS;     // 32 elements per thread for a full window
+#pragma unroll
+                for (int h = 0; h < NLD; h += 32) {
+                    double x[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        const int idx = (h + u) * BC_THREADS + t;
+                        const int i = idx / BC_LD, d = idx % BC_LD;
+                        x[u] = (i < L && i + d < L + rowsB) ? bc_ld(base + idx) : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        const int idx = (h + u) * BC_THREADS + t;
+                        const int i = idx / BC_LD, d = idx % BC_LD;
+                        const int q = i + d;
+                        if (i < L && q < L + rowsB) {
+                            E[q][i] = x[u];
+                            if (q < L && q > i) E[i][q] = x[u];
+                        }
+                    }
+                }
+            }
+            // reflector of this step -> v2 / tau2 (read by the back-transformation after the launch)
+            if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
+            if (t == 0) P.tau2[(int64_t)s * P.ks + k] = sc[0];
+            __syncthreads();
+            const double tau = sc[0];
+            // ---- D <- H D H:  y = D v,  w = tau y - (tau^2 v'y / 2) v,  D -= v w' + w v'
+            {
+                double acc = 0.0;
+                if (row < L) {
+                    const int c0 = quarter * 16;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c0 + c < L) acc += E[row][c0 + c] * vv[c0 + c];
+                }
+                part[quarter * BC_SB + row] = acc;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const double y = (lane < L) ? (part[lane] + part[BC_SB + lane]) + (part[2 * BC_SB + lane] + part[3 * BC_SB + lane]) : 0.0;
+                double vy = (lane < L) ? y * vv[lane] : 0.0;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) vy += __shfl_xor(vy, o);
+                if (lane < L) ww[lane] = tau * y - (0.5 * tau * tau * vy) * vv[lane];
+            }
+            __syncthreads();
+            if (row < L) {
+                const int c0 = quarter * 16;
+                const double vr = vv[row], wr = ww[row];
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c0 + c < L) E[row][c0 + c] -= vr * ww[c0 + c] + wr * vv[c0 + c];
+            }
+            double taun = 0.0;
+            if (rowsB > 0) {
+                // ---- B <- B H:  z = B v,  B -= tau z v'
+                {
+                    double acc = 0.0;
+                    if (row < rowsB) {
+                        const int c0 = quarter * 16;
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c0 + c < L) acc += E[L + row][c0 + c] * vv[c0 + c];
+                    }
+                    part[quarter * BC_SB + row] = acc;
+                }
+                __syncthreads();
+                if (row < rowsB) {
+                    const double z = tau * ((part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]));
+                    const int c0 = quarter * 16;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c0 + c < L) E[L + row][c0 + c] -= z * vv[c0 + c];
+                }
+                __syncthreads();
+                // ---- new reflector from the first column of B
+                if (wave == 0) {
+                    const double x = (lane < rowsB) ? E[L + lane][0] : 0.0;
+                    double v, tn, beta;
+                    bc_house_wave(x, lane, rowsB, v, tn, beta);
+                    if (lane < rowsB) {
+                        E[L + lane][0] = (lane == 0) ? beta : 0.0;
+                        vn[lane] = v;
+                    }
+                    if (lane == 0) sc[1] = tn;
+                }
+                __syncthreads();
+                taun = sc[1];
+                // ---- B <- H1 B on the columns 1 .. L-1:  u = B' vn,  B -= taun vn u'
+                {
+                    const int c = row;                     // column
+                    double acc = 0.0;
+                    if (c >= 1 && c < L) {
+                        const int p0 = quarter * 16;
+#pragma unroll
+                        for (int p = 0; p < 16; ++p)
+                            if (p0 + p < rowsB) acc += E[L + p0 + p][c] * vn[p0 + p];
+                    }
+                    part[quarter * BC_SB + c] = acc;
+                }
+                __syncthreads();
+                {
+                    const int c = row;
+                    if (c >= 1 && c < L) {
+                        const double u = taun * ((part[c] + part[BC_SB + c]) + (part[2 * BC_SB + c] + part[3 * BC_SB + c]));
+                        const int p0 = quarter * 16;
+#pragma unroll
+                        for (int p = 0; p < 16; ++p)
+                            if (p0 + p < rowsB) E[L + p0 + p][c] -= vn[p0 + p] * u;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- window -> memory (write-through), drain, publish
+            {
+                double *base = P.ab + (int64_t)r * BC_LD;
+                for (int idx = t; idx < L * BC_LD; idx += BC_THREADS) {
+                    const int i = idx / BC_LD, d = idx % BC_LD;
+                    const int q = i + d;
+                    if (q < L + rowsB) bc_st(base + idx, E[q][i]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0)
+                __hip_atomic_store(P.prog + s, (rowsB > 0) ? (k + 1) : BC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rowsB <= 0) break;
+            // next step: the reflector just formed
+            if (t < BC_SB) vv[t] = (t < rowsB) ? vn[t] : 0.0;
+            if (t == 0) sc[0] = taun;
+            r += L;
+            L = rowsB;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void sb2st_de_kernel(const double *__restrict__ ab, int n, double *__restrict__ d, double *__restrict__ e) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    d[j] = ab[(int64_t)j * BC_LD];
+    e[j] = (j < n - 1) ? ab[(int64_t)j * BC_LD + 1] : 0.0;     // e[n-1] = 0: the divide and conquer reads n entries
+}
+
+int sb2st_ldab() { return BC_LD; }
+int sb2st_steps(int n) { return (n + BC_SB - 1) / BC_SB + 1; }
+
+// d_ab (2 SB x n band, lower, ld = 2 SB; destroyed) -> d, e of the tridiagonal matrix; reflectors to d_v2 (n x n,
+// column s = sweep s; only the entries written are meaningful) and d_tau2 (n x sb2st_steps(n)).
+// d_ctrl: >= n + 4 ints (progress counters + abort flag), zeroed here.  d_ctrl[n] != 0 after synchronisation = a
+// bounded wait expired (never observed; the caller then reports an error instead of hanging).
+int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, double *d_v2, double *d_tau2, int *d_ctrl) {
+    const int ks = sb2st_steps(n);
+    JX_HIP(hipMemsetAsync(d_ctrl, 0, sizeof(int) * ((size_t)n + 4), st));
+    JX_HIP(hipMemsetAsync(d_tau2, 0, sizeof(double) * (size_t)n * ks, st));
+    if (n > 2) {
+        BcParams P{d_ab, n, d_v2, d_tau2, ks, d_ctrl, d_ctrl + n};
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            JX_HIP(hipGetDevice(&dev));
+            JX_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        // sweeps in flight are at most half the steps of a sweep (lag of two steps); one workgroup per CU
+        int g = (ks + 1) / 2 + 1;
+        if (getenv("JXGPU_SB2ST_WGS") && atoi(getenv("JXGPU_SB2ST_WGS")) > 0) g = atoi(getenv("JXGPU_SB2ST_WGS"));
+        if (g > cus) g = cus;
+        if (g > n - 2) g = n - 2;
+        // > 80 KB of LDS per workgroup: at most one workgroup per CU (the hand-off form is measured for that geometry)
+        const size_t lds = 84 * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            JX_HIP(hipFuncSetAttribute((const void *)sb2st_chase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sb2st_chase_kernel, dim3(g), dim3(BC_THREADS), lds, st, P);
+        JX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sb2st_de_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_ab, n, d_d, d_e);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace jx

@@ -878,6 +878,12 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     return 0;
 }
 
+// whether sytrd_lower would deal the symv tiles of an n-row problem over ranks (the eigensolver then keeps the one-stage form)
+int sytrd_dist_active(int n) {
+    static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
+    return ((g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n) ? 1 : 0;
+}
+
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
                    int min_n) {
     if (world < 1 || rank < 0 || rank >= world) return fail("sytrd_set_dist: bad rank / world");

@@ -3,7 +3,7 @@
 //   dgemm      C = alpha op(A) op(B) + beta C          (NN / TN / NT / TT, optional split over K with f64 atomics)
 //   dsymm_l    C = alpha A B + beta C, A symmetric with only its LOWER triangle stored (band reduction: Z = A22 V)
 //   dsyr2k_l   lower tiles of C += alpha (A B' ...) as one NT product over concatenated panels (trailing update)
-// All matrices are column-major.  One workgroup = 256 threads = 2 x 2 waves on a BM x BN tile, K in steps of 16 through a
+// All matrices are column-major.  One workgroup = 512 threads = 4 x 2 waves on a BM x BN tile, K in steps of 16 through a
 // double-buffered LDS image [k][x] (row pitch BM + 17 doubles: an odd pitch makes the k-fast staging stores of a
 // transposed operand conflict-free, and the two k-rows a 32-lane read group touches land 34 banks apart); global loads
 // of step t + 1 are in flight in registers while step t is multiplied.  The MFMA "A" operand is fed with op(B) and the
@@ -20,7 +20,7 @@ namespace jx {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int DG_BK = 16;
-constexpr int DG_THREADS = 256;
+constexpr int DG_THREADS = 512;   // 8 waves = 4 (M) x 2 (N): <= 128 VGPRs per lane, two workgroups per CU
 
 struct DgemmArgs {
     const double *a;
@@ -103,9 +103,9 @@ __device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(DG_THREADS) void dgemm_kernel(DgemmArgs g) {
+__global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
     constexpr int PA = BM + 17, PB = BN + 17;
-    constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
+    constexpr int WM = BM / 4, WN = BN / 2;          // wave tile
     constexpr int MB = WM / 16, NB = WN / 16;        // 16x16 blocks per wave
     extern __shared__ __attribute__((aligned(16))) double dg_smem[];
     double *as = dg_smem;                            // [2][16][PA]
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(DG_THREADS) void dgemm_kernel(DgemmArgs g) {
         if (kbeg >= kend) return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 1) * WM, wn = (wave >> 1) * WN;
+    const int wm = (wave & 3) * WM, wn = (wave >> 2) * WN;
     const int lx = lane & 15, lk = lane >> 4;
 
     d4 acc[NB][MB];

@@ -28,123 +28,267 @@ constexpr int SB = 64;            // half bandwidth of the intermediate band mat
 constexpr int SB_P = SB + 1;      // LDS pitch of the SB x SB work matrices
 constexpr int SB_FLAG_FAIL = 0, SB_FLAG_ZERO = 1;
 
-// ---- tiny single-workgroup kernels on SB x SB matrices (256 threads, LDS) ----------------------------------------
+// ---- tiny single-workgroup kernels on SB x SB matrices ------------------------------------------------------------
+// 256 threads hold a 64 x 64 matrix in registers, 4 x 4 elements each, cyclically: thread (ti, tk) = (t / 16, t % 16)
+// owns the elements (ti + 16 a, tk + 16 b).  The sequential eliminations (Cholesky, LU, triangular solves) are fully
+// unrolled right-looking loops: per step the owners of the pivot row / column publish it through a double-buffered LDS
+// vector, ONE barrier, and every thread updates its 16 elements from 8 LDS reads.
+static_assert(SB == 64, "the register-cyclic tiny kernels are written for SB = 64");
 
-// in-LDS Cholesky G = R'R of the leading pw x pw block of s (upper triangle on exit, strict lower part untouched);
-// indices >= pw become the identity.  Returns false (all threads) when a pivot is not positive and finite.
-__device__ bool sb_chol_upper(double (*s)[SB_P], int pw, int *bad_sh) {
-    const int t = threadIdx.x;
-    if (t == 0) *bad_sh = 0;
-    __syncthreads();
-    for (int j = 0; j < pw; ++j) {
-        const double d = s[j][j];
+struct Tiny {
+    double v[4][4];
+};
+
+__device__ __forceinline__ void tiny_load_lds(Tiny &m, const double (*s)[SB_P]) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m.v[a][b] = s[ti + 16 * a][tk + 16 * b];
+}
+__device__ __forceinline__ void tiny_store_lds(const Tiny &m, double (*s)[SB_P]) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[ti + 16 * a][tk + 16 * b] = m.v[a][b];
+}
+
+// G (symmetric, full, identity-padded) -> R upper triangular (G = R'R), strict lower part zero.  Returns 0 when a pivot
+// is not positive and finite (the factor is then meaningless; the caller raises the failure flag).
+__device__ __forceinline__ int tiny_chol_upper(Tiny &m, double (*vec)[SB]) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+    int ok = 1;
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        const int ja = j >> 4, jr = j & 15, p = j & 1;
+        if (ti == jr) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) vec[p][tk + 16 * b] = m.v[ja][b];
+        }
         __syncthreads();
+        double d = vec[p][j];
         if (!(d > 0.0) || !(d < 1e300)) {
-            if (t == 0) *bad_sh = 1;
+            ok = 0;
+            d = 1.0;
         }
-        const double r = (d > 0.0) ? sqrt(d) : 1.0;
-        const double ri = 1.0 / r;
-        for (int i = j + t; i < pw; i += 256) s[j][i] = (i == j) ? r : s[j][i] * ri;
-        __syncthreads();
-        // trailing update of the upper triangle: s[i][k] -= s[j][i] s[j][k], j < i <= k < pw
-        const int rem = pw - j - 1;
-        for (int e = t; e < rem * rem; e += 256) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (k >= i) s[i][k] -= s[j][i] * s[j][k];
+        const double ri = 1.0 / sqrt(d);
+        double rk[4], rr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rk[b] = vec[p][tk + 16 * b] * ri;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rr[a] = vec[p][ti + 16 * a] * ri;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = ti + 16 * a, k = tk + 16 * b;
+                if (i > j && k > j) m.v[a][b] -= rr[a] * rk[b];
+            }
+        if (ti == jr) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m.v[ja][b] = (tk + 16 * b >= j) ? rk[b] : 0.0;
         }
-        __syncthreads();
     }
-    for (int e = t; e < SB * SB; e += 256) {
-        const int i = e / SB, k = e % SB;
-        if (i >= pw || k >= pw) s[i][k] = (i == k) ? 1.0 : 0.0;
-        else if (k < i) s[i][k] = 0.0;
-    }
-    __syncthreads();
-    return *bad_sh == 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (ti + 16 * a > tk + 16 * b) m.v[a][b] = 0.0;
+    return ok;
 }
 
-// rtot <- r * rtot (both upper triangular SB x SB; rtot row-major in global memory, ld = SB), or rtot <- r; the product
-// is also left in tmp (LDS)
-__device__ void sb_accumulate_r(const double (*r)[SB_P], double *__restrict__ rtot, bool first, double (*tmp)[SB_P]) {
-    const int t = threadIdx.x;
-    for (int e = t; e < SB * SB; e += 256) tmp[e / SB][e % SB] = first ? ((e / SB == e % SB) ? 1.0 : 0.0) : rtot[e];
-    __syncthreads();
-    double acc[SB * SB / 256];
+// X <- X U^-1, U upper triangular in LDS (u[c][k], c <= k) with its diagonal stored as the reciprocal
+__device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)[SB_P], double (*vec)[SB]) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
 #pragma unroll
-    for (int u = 0; u < SB * SB / 256; ++u) {
-        const int e = u * 256 + t;
-        const int i = e / SB, k = e % SB;
-        double a = 0.0;
-        if (k >= i)
-            for (int q = i; q <= k; ++q) a += r[i][q] * tmp[q][k];
-        acc[u] = a;
+    for (int c = 0; c < SB; ++c) {
+        const int cb = c >> 4, cr = c & 15, p = c & 1;
+        if (tk == cr) {
+            const double rd = u[c][c];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                x.v[a][cb] *= rd;
+                vec[p][ti + 16 * a] = x.v[a][cb];
+            }
+        }
+        __syncthreads();
+        double xc[4], uk[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xc[a] = vec[p][ti + 16 * a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > c) ? u[c][tk + 16 * b] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) x.v[a][b] -= xc[a] * uk[b];
     }
-    __syncthreads();
+}
+
+// modified LU of W (Householder reconstruction): on exit the strict lower part holds L (unit diagonal implied), the
+// upper part incl. diagonal U; sgn[j] = the sign subtracted from the j-th pivot
+__device__ __forceinline__ void tiny_lu_modified(Tiny &w, double (*vec)[SB], double (*vec2)[SB], double *sgn) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
 #pragma unroll
-    for (int u = 0; u < SB * SB / 256; ++u) {
-        const int e = u * 256 + t;
-        tmp[e / SB][e % SB] = acc[u];
-        rtot[e] = acc[u];
+    for (int j = 0; j < SB; ++j) {
+        const int ja = j >> 4, jr = j & 15, p = j & 1;
+        if (ti == jr) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) vec[p][tk + 16 * b] = w.v[ja][b];        // row j
+        }
+        if (tk == jr) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) vec2[p][ti + 16 * a] = w.v[a][ja];       // column j
+        }
+        __syncthreads();
+        const double d = vec[p][j];
+        const double sj = (d >= 0.0) ? -1.0 : 1.0;
+        const double piv = d - sj;
+        const double pinv = 1.0 / piv;
+        double li[4], uk[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > j) ? vec2[p][ti + 16 * a] * pinv : 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > j) ? vec[p][tk + 16 * b] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w.v[a][b] -= li[a] * uk[b];
+        if (tk == jr) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = ti + 16 * a;
+                if (i > j) w.v[a][ja] = li[a];
+                else if (i == j) w.v[a][ja] = piv;
+            }
+        }
+        if (threadIdx.x == 0) sgn[j] = sj;
     }
     __syncthreads();
 }
 
-// passes 1 and 2: g (pw x pw Gram matrix, column-major ld = SB) -> r_out (SB x SB row-major upper, identity-padded),
-// rtot updated.  shift_coef > 0: G + shift_coef * trace(G) * I (first pass).  flags[SB_FLAG_ZERO] is set when the
-// panel is exactly zero (trace == 0 in the first pass) and honoured by the later passes.
+// C = A B (64 x 64 each; A, B in LDS)
+__device__ __forceinline__ void tiny_matmul(Tiny &c, const double (*a)[SB_P], const double (*b)[SB_P]) {
+    const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c.v[x][y] = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < SB; ++q) {
+        double ai[4], bk[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ai[x] = a[ti + 16 * x][q];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) bk[y] = b[q][tk + 16 * y];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) c.v[x][y] += ai[x] * bk[y];
+    }
+}
+
+// shared by the tiny kernels: global (column-major, ld = SB) pw x pw block -> LDS row-major, identity- or zero-padded
+__device__ __forceinline__ void tiny_fetch_colmajor(double (*s)[SB_P], const double *__restrict__ g, int pw, bool ident_pad) {
+    for (int e = threadIdx.x; e < SB * SB; e += 256) {
+        const int c = e / SB, r = e % SB;
+        s[r][c] = (r < pw && c < pw) ? g[r + c * SB] : ((ident_pad && r == c) ? 1.0 : 0.0);
+    }
+}
+
+// passes 1 and 2: g (pw x pw Gram matrix, column-major ld = SB) -> r_out = R^-1 (SB x SB column-major, identity-padded;
+// G = R'R), rtot <- R rtot (or R in the first pass).  shift_coef > 0:
+// G + shift_coef * trace(G) * I.  *panel_zero is set in the first pass when the panel is exactly zero (trace == 0) and
+// honoured by the later passes.
 __global__ __launch_bounds__(256) void sb_chol_kernel(const double *__restrict__ g, int pw, double shift_coef, int first,
                                                       double *__restrict__ r_out, double *__restrict__ rtot,
                                                       int *__restrict__ flags, int *__restrict__ panel_zero) {
     __shared__ double s[SB][SB_P];
-    __shared__ double tmp[SB][SB_P];
-    __shared__ int bad;
+    __shared__ double s2[SB][SB_P];
+    __shared__ double vec[2][SB];
     __shared__ int zero_sh;
-    __shared__ double tr_sh;
     const int t = threadIdx.x;
-    for (int e = t; e < SB * SB; e += 256) {
-        const int c = e / SB, r = e % SB;          // column-major source
-        s[r][c] = (r < pw && c < pw) ? g[r + c * SB] : 0.0;
+    tiny_fetch_colmajor(s, g, pw, true);
+    if (!first) {
+        for (int e = t; e < SB * SB; e += 256) s2[e / SB][e % SB] = rtot[e];
     }
     __syncthreads();
     if (t == 0) {
         double tr = 0.0;
         for (int i = 0; i < pw; ++i) tr += s[i][i];
-        tr_sh = tr;
         int z = *panel_zero;
         if (first) {
             z = (tr == 0.0) ? 1 : 0;
             *panel_zero = z;
         }
         zero_sh = z;
+        vec[0][0] = tr;
     }
     __syncthreads();
     const bool zero = (zero_sh != 0);
+    const double tr = vec[0][0];
+    __syncthreads();
+    Tiny m;
+    tiny_load_lds(m, s);
+    const int ti = t >> 4, tk = t & 15;
     if (zero) {
-        for (int e = t; e < SB * SB; e += 256) s[e / SB][e % SB] = (e / SB == e % SB) ? 1.0 : 0.0;
-        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m.v[a][b] = (ti + 16 * a == tk + 16 * b) ? 1.0 : 0.0;
     } else {
         if (shift_coef > 0.0) {
-            const double sh = shift_coef * tr_sh;
-            for (int i = t; i < pw; i += 256) s[i][i] += sh;
-            __syncthreads();
+            const double sh = shift_coef * tr;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (ti + 16 * a == tk + 16 * b && ti + 16 * a < pw) m.v[a][b] += sh;
         }
-        if (!sb_chol_upper(s, pw, &bad)) {
-            if (t == 0) atomicOr(flags + SB_FLAG_FAIL, first ? 1 : 2);
-        }
+        if (!tiny_chol_upper(m, vec)) atomicOr(flags + SB_FLAG_FAIL, first ? 1 : 2);
     }
-    for (int e = t; e < SB * SB; e += 256) {     // the row solve multiplies by the reciprocal diagonal
-        const int i = e / SB, k = e % SB;
-        r_out[e] = (i == k) ? 1.0 / s[i][k] : s[i][k];
+    __syncthreads();
+    tiny_store_lds(m, s);                       // R
+    __syncthreads();
+    if (first) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rtot[(ti + 16 * a) * SB + tk + 16 * b] = m.v[a][b];
+    } else {
+        Tiny prod;
+        tiny_matmul(prod, s, s2);               // R * rtot
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rtot[(ti + 16 * a) * SB + tk + 16 * b] = prod.v[a][b];
     }
-    sb_accumulate_r(s, rtot, first != 0, tmp);
+    // R^-1 for the panel product Q = P R^-1 (an f64-MFMA GEMM): X = I, X <- X R^-1
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (ti + 16 * a == tk + 16 * b) s[ti + 16 * a][tk + 16 * b] = 1.0 / m.v[a][b];
+    Tiny x;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x.v[a][b] = (ti + 16 * a == tk + 16 * b) ? 1.0 : 0.0;
+    __syncthreads();
+    tiny_trsm_right_upper(x, s, vec);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r_out[(ti + 16 * a) + (tk + 16 * b) * SB] = x.v[a][b];      // column-major
 }
 
 // pass 3 + Householder reconstruction (one workgroup):
 //   g3 -> R3, rtot <- R3 rtot;  Qtop <- Qtop R3^-1 (the pw x pw top block of the panel, in A);  modified LU of
 //   Qtop - S -> L1 (unit lower), U (upper), S = -sign(diag);  T = -U S L1^-T;  writes
 //   A top block = [S rtot in the upper triangle incl. diagonal | L1 strictly below], the two V copies of the panel
-//   buffer (rows 0 .. pw-1: unit lower triangle), T (column-major, ld = SB), tau = diag T, R3 and U (row-major) for the
-//   row solve of the remaining panel rows.
+//   buffer (rows 0 .. pw-1: unit lower triangle), T (column-major, ld = SB), tau = diag T, and u_out = R3^-1 U^-1
+//   (column-major) for the remaining panel rows: v = q R3^-1 U^-1 is one GEMM.
 __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict__ g3, int pw, double *__restrict__ atop,
                                                        int64_t lda, double *__restrict__ r3_out,
                                                        double *__restrict__ u_out, double *__restrict__ rtot,
@@ -152,182 +296,187 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
                                                        double *__restrict__ pan_v1, double *__restrict__ pan_v2,
                                                        int64_t ldp, int *__restrict__ flags,
                                                        const int *__restrict__ panel_zero) {
-    __shared__ double s[SB][SB_P];     // R3, later T
-    __shared__ double w[SB][SB_P];     // Qtop -> LU
-    __shared__ double tmp[SB][SB_P];
+    __shared__ double s[SB][SB_P];
+    __shared__ double s2[SB][SB_P];
+    __shared__ double vec[2][SB];
+    __shared__ double vec2[2][SB];
     __shared__ double sgn[SB];
-    __shared__ int bad;
     const int t = threadIdx.x;
-    const bool zero = (*panel_zero != 0);
-    if (zero) {
+    const int ti = t >> 4, tk = t & 15;
+    if (*panel_zero != 0) {
         // all-zero panel: identity transformation (tau = 0, V = 0); keep the buffers the next kernels read well-defined
         for (int e = t; e < SB * SB; e += 256) {
             const int i = e / SB, k = e % SB;
-            r3_out[e] = (i == k) ? 1.0 : 0.0;
             u_out[e] = (i == k) ? 1.0 : 0.0;
             t_out[e] = 0.0;
-            pan_v1[i + (int64_t)k * ldp] = 0.0;      // rows < SB of the panel buffer always exist? (guarded below)
-        }
-        __syncthreads();
-        for (int e = t; e < SB * SB; e += 256) {
-            const int i = e / SB, k = e % SB;
+            pan_v1[i + (int64_t)k * ldp] = 0.0;
             pan_v2[i + (int64_t)k * ldp] = 0.0;
             if (i < pw && k < pw) atop[i + (int64_t)k * lda] = 0.0;
         }
         for (int i = t; i < pw; i += 256) tau[i] = 0.0;
         return;
     }
-    for (int e = t; e < SB * SB; e += 256) {
-        const int c = e / SB, r = e % SB;
-        s[r][c] = (r < pw && c < pw) ? g3[r + c * SB] : 0.0;
-        w[r][c] = (r < pw && c < pw) ? atop[r + (int64_t)c * lda] : ((r == c) ? 1.0 : 0.0);
+    tiny_fetch_colmajor(s, g3, pw, true);
+    for (int e = t; e < SB * SB; e += 256) s2[e / SB][e % SB] = rtot[e];
+    __syncthreads();
+    Tiny r3;
+    tiny_load_lds(r3, s);
+    if (!tiny_chol_upper(r3, vec)) atomicOr(flags + SB_FLAG_FAIL, 4);
+    {
+        // G3 = Q2'Q2 must be the identity to working accuracy (R3 = I), or the panel was too ill-conditioned for three
+        // CholeskyQR passes
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (ti + 16 * a == tk + 16 * b && !(fabs(r3.v[a][b] - 1.0) < 1e-8)) bad = true;
+        if (bad) atomicOr(flags + SB_FLAG_FAIL, 8);
     }
     __syncthreads();
-    if (!sb_chol_upper(s, pw, &bad)) {
-        if (t == 0) atomicOr(flags + SB_FLAG_FAIL, 4);
-    }
-    for (int e = t; e < SB * SB; e += 256) {
-        const int i = e / SB, k = e % SB;
-        r3_out[e] = (i == k) ? 1.0 / s[i][k] : s[i][k];
-    }
-    if (t == 0) {
-        // G3 = Q2'Q2 must be the identity to working accuracy (R3 = I), or the panel was too ill-conditioned for
-        // three CholeskyQR passes
-        double worst = 0.0;
-        for (int i = 0; i < pw; ++i) worst = fmax(worst, fabs(s[i][i] - 1.0));
-        if (!(worst < 1e-8)) atomicOr(flags + SB_FLAG_FAIL, 8);
-    }
-    sb_accumulate_r(s, rtot, false, tmp);      // tmp <- R3 R2 R1
-    // Qtop <- Qtop R3^-1: row i, forward over columns (thread = row)
-    if (t < pw) {
-        for (int c = 0; c < pw; ++c) {
-            double acc = w[t][c];
-            for (int k = 0; k < c; ++k) acc -= w[t][k] * s[k][c];
-            w[t][c] = acc / s[c][c];
-        }
-    }
+    tiny_store_lds(r3, s);                      // s = R3
     __syncthreads();
-    // modified LU (no pivoting; |L| <= 1 by the sign choice)
-    for (int j = 0; j < pw; ++j) {
-        if (t == 0) {
-            const double d = w[j][j];
-            const double sj = (d >= 0.0) ? -1.0 : 1.0;
-            sgn[j] = sj;
-            w[j][j] = d - sj;
+    Tiny rt;
+    tiny_matmul(rt, s, s2);                     // rtot = R3 * rtot
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            rtot[i * SB + k] = rt.v[a][b];
         }
-        __syncthreads();
-        const double piv = w[j][j];
-        for (int i = j + 1 + t; i < pw; i += 256) w[i][j] /= piv;
-        __syncthreads();
-        const int rem = pw - j - 1;
-        for (int e = t; e < rem * rem; e += 256) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            w[i][k] -= w[i][j] * w[j][k];
+    // s <- R3 with reciprocal diagonal (operand of the triangular solve)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (ti + 16 * a == tk + 16 * b) s[ti + 16 * a][tk + 16 * b] = 1.0 / r3.v[a][b];
+    // W = Qtop (identity-padded)
+    Tiny w;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            w.v[a][b] = (i < pw && k < pw) ? atop[i + (int64_t)k * lda] : ((i == k) ? 1.0 : 0.0);
         }
-        __syncthreads();
-    }
-    // A top block: S rtot (upper incl. diagonal) | L1 strictly below
-    for (int e = t; e < pw * pw; e += 256) {
-        const int i = e / pw, k = e % pw;
-        atop[i + (int64_t)k * lda] = (k >= i) ? sgn[i] * tmp[i][k] : w[i][k];
-    }
     __syncthreads();
-    // T L1' = -U S  (row i of T, forward over columns; T upper triangular).  tmp <- T
-    if (t < pw) {
-        for (int c = 0; c < pw; ++c) {
-            double acc = (c >= t) ? -w[t][c] * sgn[c] : 0.0;
-            for (int k = t; k < c; ++k) acc -= tmp[t][k] * w[c][k];
-            tmp[t][c] = (c >= t) ? acc : 0.0;
-        }
-    }
+    tiny_trsm_right_upper(w, s, vec);           // Qtop R3^-1
     __syncthreads();
-    for (int e = t; e < SB * SB; e += 256) {
-        const int i = e / SB, k = e % SB;     // (row, column)
-        const bool in = (i < pw && k < pw);
-        // U (row-major, identity-padded) for the row solve
-        u_out[e] = in ? ((k > i) ? w[i][k] : ((k == i) ? 1.0 / w[i][k] : 0.0)) : ((i == k) ? 1.0 : 0.0);
-        // T column-major
-        t_out[i + k * SB] = in ? tmp[i][k] : 0.0;
-        // V copies of the panel buffer, rows 0 .. SB-1 (rows >= pw of the top block belong to the row solve, which
-        // writes them afterwards; columns >= pw are zero)
-        if (i < pw) {
-            const double v = (k < pw) ? ((i == k) ? 1.0 : ((i > k) ? w[i][k] : 0.0)) : 0.0;
-            pan_v1[i + (int64_t)k * ldp] = v;
-            pan_v2[i + (int64_t)k * ldp] = v;
+    tiny_lu_modified(w, vec, vec2, sgn);
+    // A top block: S rtot (upper incl. diagonal) | L1 strictly below;  V copies: unit lower triangle;  U for the row solve
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            const bool in = (i < pw && k < pw);
+            if (in) atop[i + (int64_t)k * lda] = (k >= i) ? sgn[i] * rt.v[a][b] : w.v[a][b];
+            if (i < pw) {
+                const double vv = (k < pw) ? ((i == k) ? 1.0 : ((i > k) ? w.v[a][b] : 0.0)) : 0.0;
+                pan_v1[i + (int64_t)k * ldp] = vv;
+                pan_v2[i + (int64_t)k * ldp] = vv;
+            }
         }
-    }
-    for (int i = t; i < pw; i += 256) tau[i] = tmp[i][i];
+    // T L1' = -U S:  X = -U S (upper), then X <- X (L1')^-1 with L1' unit upper = transpose of the strict lower part of w
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            s2[k][i] = (i > k) ? w.v[a][b] : ((i == k) ? 1.0 : 0.0);       // s2 = L1' (unit diagonal = its own reciprocal)
+        }
+    Tiny x;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            x.v[a][b] = (k >= i && i < pw && k < pw) ? -w.v[a][b] * sgn[k] : 0.0;
+        }
+    __syncthreads();
+    tiny_trsm_right_upper(x, s2, vec);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            const bool in = (i < pw && k < pw && k >= i);
+            t_out[i + k * SB] = in ? x.v[a][b] : 0.0;
+            if (i == k && i < pw) tau[i] = x.v[a][b];
+        }
+    // X = R3^-1 U^-1 for the rows below the top block (v = q X, one GEMM): I <- I R3^-1 (s still holds R3 with its
+    // reciprocal diagonal), then <- (.) U^-1 with U = upper part of w
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, k = tk + 16 * b;
+            const bool in = (i < pw && k < pw);
+            s2[i][k] = in ? ((k > i) ? w.v[a][b] : ((k == i) ? 1.0 / w.v[a][b] : 0.0)) : ((i == k) ? 1.0 : 0.0);
+            x.v[a][b] = (i == k) ? 1.0 : 0.0;
+        }
+    __syncthreads();
+    tiny_trsm_right_upper(x, s, vec);
+    __syncthreads();
+    tiny_trsm_right_upper(x, s2, vec);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u_out[(ti + 16 * a) + (tk + 16 * b) * SB] = x.v[a][b];      // column-major
 }
 
 // M = T' N1 T  ->  TM (2 SB x SB, column-major, ld = 2 SB): rows 0 .. SB-1 = T, rows SB .. = -M / 2
 __global__ __launch_bounds__(256) void sb_tm_kernel(const double *__restrict__ tmat, const double *__restrict__ n1, int pw,
                                                     double *__restrict__ tm) {
     __shared__ double ts[SB][SB_P];    // T[row][col]
+    __shared__ double tt[SB][SB_P];    // T'
     __shared__ double x[SB][SB_P];
-    __shared__ double y[SB][SB_P];
     const int t = threadIdx.x;
+    const int ti = t >> 4, tk = t & 15;
     for (int e = t; e < SB * SB; e += 256) {
         const int c = e / SB, r = e % SB;
-        ts[r][c] = tmat[r + c * SB];
+        const double tv = tmat[r + c * SB];
+        ts[r][c] = tv;
+        tt[c][r] = tv;
         x[r][c] = (r < pw && c < pw) ? n1[r + c * SB] : 0.0;
     }
     __syncthreads();
-    for (int e = t; e < SB * SB; e += 256) {          // y = N1 T
-        const int i = e / SB, k = e % SB;
-        double acc = 0.0;
-        for (int q = 0; q <= k; ++q) acc += x[i][q] * ts[q][k];
-        y[i][k] = acc;
-    }
+    Tiny y;
+    tiny_matmul(y, x, ts);             // N1 T
     __syncthreads();
-    for (int e = t; e < SB * SB; e += 256) {          // M = T' y
-        const int c = e / SB, r = e % SB;
-        double acc = 0.0;
-        for (int q = 0; q <= r; ++q) acc += ts[q][r] * y[q][c];
-        tm[r + c * (2 * SB)] = ts[r][c];
-        tm[SB + r + c * (2 * SB)] = -0.5 * acc;
-    }
+    tiny_store_lds(y, x);
+    __syncthreads();
+    Tiny m;
+    tiny_matmul(m, tt, x);             // T' (N1 T)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = ti + 16 * a, c = tk + 16 * b;
+            tm[r + c * (2 * SB)] = ts[r][c];
+            tm[SB + r + c * (2 * SB)] = -0.5 * m.v[a][b];
+        }
 }
 
-// ---- row-parallel triangular solves of the panel ------------------------------------------------------------------
-// q <- q R^-1 for every panel row (thread = row; R upper triangular SB x SB, row-major, identity-padded), optionally
-// followed by U^-1 (reconstruction: v = q R3^-1 U^-1) with the result also written to the two V copies of the panel
-// buffer.  R entries are wave-uniform: the compiler keeps them on the scalar path.
-template <bool RECON>
-__global__ __launch_bounds__(128) void sb_row_solve_kernel(double *__restrict__ p, int64_t ldp, int row0, int rows,
-                                                           const double *__restrict__ r, const double *__restrict__ u,
-                                                           double *__restrict__ v1, double *__restrict__ v2,
-                                                           int64_t ldv, int pw) {
-    const int i = blockIdx.x * 128 + threadIdx.x;
+// rows [row0, row0 + rows) of the first V copy of the panel buffer -> A's panel (LAPACK storage of the reflectors) and the
+// second V copy; columns >= pw of both copies are zeroed
+__global__ __launch_bounds__(256) void sb_copy_v_kernel(double *__restrict__ v1, double *__restrict__ v2, int64_t ldv,
+                                                        double *__restrict__ p, int64_t ldp, int row0, int rows, int pw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
     if (i >= rows) return;
-    double q[SB];
-    double *row = p + row0 + i;
-#pragma unroll
-    for (int c = 0; c < SB; ++c) q[c] = (c < pw) ? row[(int64_t)c * ldp] : 0.0;
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        double acc = q[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) acc -= q[k] * r[k * SB + c];
-        q[c] = acc * r[c * SB + c];      // diagonal stored as its reciprocal
+    const int64_t o = row0 + i + (int64_t)c * ldv;
+    double v = 0.0;
+    if (c < pw) {
+        v = v1[o];
+        p[row0 + i + (int64_t)c * ldp] = v;
+    } else {
+        v1[o] = 0.0;
     }
-    if (RECON) {
-#pragma unroll
-        for (int c = 0; c < SB; ++c) {
-            double acc = q[c];
-#pragma unroll
-            for (int k = 0; k < c; ++k) acc -= q[k] * u[k * SB + c];
-            q[c] = acc * u[c * SB + c];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < SB; ++c) {
-        if (c < pw) row[(int64_t)c * ldp] = q[c];
-        if (RECON) {
-            const double v = (c < pw) ? q[c] : 0.0;
-            v1[row0 + i + (int64_t)c * ldv] = v;
-            v2[row0 + i + (int64_t)c * ldv] = v;
-        }
-    }
+    v2[o] = v;
 }
 
 // band (d = 0 .. SB) of the reduced matrix -> compact storage ab (ldab x n, column-major): ab[d + j ldab] = A[j + d, j],
@@ -374,24 +523,27 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             double *a22 = d_a + (j0 + SB) + (int64_t)(j0 + SB) * ld;  // trailing matrix
             double *zc = pan, *v1 = pan + (size_t)SB * ld, *wc = pan + (size_t)2 * SB * ld, *v2 = pan + (size_t)3 * SB * ld;
             int *pz = d_flags + 2;
-            // CholeskyQR passes 1 and 2
+            // CholeskyQR passes 1 and 2: G = P'P, R = chol(G), P <- P R^-1 (in place: a workgroup of the product reads only
+            // the rows it writes, and all of them before its epilogue)
             for (int pass = 0; pass < 2; ++pass) {
                 if (dgemm(st, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, g, SB, 0)) return 1;
                 const double shift = (pass == 0) ? 11.0 * ((double)nt * pw + (double)pw * (pw + 1)) * eps : 0.0;
                 hipLaunchKernelGGL(sb_chol_kernel, dim3(1), dim3(256), 0, st, g, pw, shift, pass == 0 ? 1 : 0, rmat, rtot,
                                    d_flags, pz);
-                hipLaunchKernelGGL(sb_row_solve_kernel<false>, dim3(ceil_div(nt, 128)), dim3(128), 0, st, pp, ld, 0, nt,
-                                   rmat, umat, v1, v2, ld, pw);
                 JX_LAUNCH_CHECK();
+                if (dgemm(st, false, false, nt, pw, pw, 1.0, pp, ld, rmat, SB, 0.0, pp, ld, 1)) return 1;
             }
             // pass 3 + reconstruction
             if (dgemm(st, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, g, SB, 0)) return 1;
             hipLaunchKernelGGL(sb_recon_kernel, dim3(1), dim3(256), 0, st, g, pw, pp, ld, rmat, umat, rtot, tmat,
                                d_tau + j0, v1, v2, ld, d_flags, pz);
-            if (nt > pw)
-                hipLaunchKernelGGL(sb_row_solve_kernel<true>, dim3(ceil_div(nt - pw, 128)), dim3(128), 0, st, pp, ld, pw,
-                                   nt - pw, rmat, umat, v1, v2, ld, pw);
             JX_LAUNCH_CHECK();
+            if (nt > pw) {
+                if (dgemm(st, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1)) return 1;
+                hipLaunchKernelGGL(sb_copy_v_kernel, dim3(ceil_div(nt - pw, 256), SB), dim3(256), 0, st, v1, v2, ld, pp, ld,
+                                   pw, nt - pw, pw);
+                JX_LAUNCH_CHECK();
+            }
             if (pw < SB) {
                 // last, narrower panel: the columns j0 + pw .. j0 + SB - 1 of the block row see Q' from the left only
                 const int nc = SB - pw;

@@ -65,15 +65,42 @@ __device__ __forceinline__ void bc_house_wave(double x, int lane, int len, doubl
     v = (lane == 0) ? 1.0 : ((lane < len) ? x * sc : 0.0);
 }
 
+typedef int bc_v4i __attribute__((ext_vector_type(4)));
+constexpr int BC_NV = BC_SB * BC_LD / 2 / BC_THREADS;     // 16-byte pieces of a window per thread (16)
+constexpr int BC_AUX_SC1 = 16;                            // cache-policy bit of the raw buffer builtins: sc1
+
+// buffer descriptor over the window that starts at column r: accesses past the end of the band storage return zero /
+// are dropped, so every thread always issues all BC_NV pieces (the counted s_waitcnt below relies on that)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bc_window_rsrc(double *ab, int n, int r) {
+    const int64_t cols = (int64_t)n - r;
+    const int64_t bytes = cols <= 0 ? 0 : (cols >= BC_SB ? (int64_t)BC_SB * BC_LD * 8 : cols * BC_LD * 8);
+    return __builtin_amdgcn_make_buffer_rsrc(ab + (int64_t)(r < n ? r : 0) * BC_LD, 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void bc_window_load(__amdgpu_buffer_rsrc_t rs, int t, bc_v4i (&x)[BC_NV]) {
+#pragma unroll
+    for (int u = 0; u < BC_NV; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * BC_THREADS + t) * 16, 0, BC_AUX_SC1);
+}
+
+__device__ __forceinline__ bool bc_wait_progress(const BcParams &P, int s, int need, int prefetched) {
+    if (s == 0 || prefetched >= need) return true;
+    unsigned spins = 0;
+    while (__hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > BC_SPIN_LIMIT || __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            return false;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
     extern __shared__ __attribute__((aligned(16))) double bc_smem[];
     double(*E)[BC_P] = reinterpret_cast<double(*)[BC_P]>(bc_smem);          // [2 SB][SB + 1] window, dense
     double *vv = bc_smem + 2 * BC_SB * BC_P;    // [SB] current reflector
     double *vn = vv + BC_SB;                    // [SB] next reflector
-    double *yy = vn + BC_SB;                    // [SB]
-    double *ww = yy + BC_SB;                    // [SB]
+    double *ww = vn + BC_SB;                    // [SB]
     double *part = ww + BC_SB;                  // [4][SB]
-    double *sc = part + 4 * BC_SB;              // [8] scalars: 0 tau, 1 tau_next, 2 v'y
+    double *sc = part + 4 * BC_SB;              // [8] scalars: 0 tau, 1 tau_next
     int *ish = reinterpret_cast<int *>(sc + 8); // [2] 0: ok flag
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = P.n;
@@ -83,93 +110,55 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
         int r = s + 1;
         int L = min(BC_SB, n - r);
         // ---- wait for sweep s-1 to have finished steps 0 and 1, then form the sweep's first reflector from column s
-        if (t == 0) {
-            int ok = 1;
-            if (s > 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > BC_SPIN_LIMIT ||
-                        __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        ok = 0;
-                        break;
-                    }
-                }
-            }
-            ish[0] = ok;
-        }
+        if (t == 0) ish[0] = bc_wait_progress(P, s, 2, -1) ? 1 : 0;
         __syncthreads();
         if (!ish[0]) {
             if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
+        bc_v4i x[BC_NV];
+        bc_window_load(bc_window_rsrc(P.ab, n, r), t, x);          // window of step 0
         if (wave == 0) {
             double *col = P.ab + (int64_t)s * BC_LD;
-            const double x = (lane < L) ? bc_ld(col + 1 + lane) : 0.0;
+            const double xc = (lane < L) ? bc_ld(col + 1 + lane) : 0.0;
             double v, tau, beta;
-            bc_house_wave(x, lane, L, v, tau, beta);
+            bc_house_wave(xc, lane, L, v, tau, beta);
             if (lane < L) {
                 bc_st(col + 1 + lane, (lane == 0) ? beta : 0.0);
                 vv[lane] = v;
             }
             if (lane == 0) sc[0] = tau;
         }
-        __syncthreads();
         for (int k = 0;; ++k) {
             const int L1 = min(BC_SB, n - (r + L));       // rows of the off-diagonal block (<= 0: none)
-            if (k > 0) {
-                if (t == 0) {
-                    int ok = 1;
-                    if (s > 0) {
-                        unsigned spins = 0;
-                        while (__hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k + 2) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > BC_SPIN_LIMIT ||
-                                __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                ok = 0;
-                                break;
-                            }
-                        }
-                    }
-                    ish[0] = ok;
-                }
-                __syncthreads();
-                if (!ish[0]) {
-                    if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-            }
             const int rowsB = L1 > 0 ? L1 : 0;
-            // ---- window -> LDS (dense, D mirrored to a full square); 16 loads in flight per thread
-            {
-                const double *base = P.ab + (int64_t)r * BC_LD;
-                constexpr int NLD = BC_SB * BC_LD / BC_THREADS;     // 32 elements per thread for a full window
+            const int nrow = L + rowsB;
+            // ---- window (registers, loaded during the previous step) -> LDS, dense, D mirrored to a full square
 #pragma unroll
-                for (int h = 0; h < NLD; h += 32) {
-                    double x[32];
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) {
-                        const int idx = (h + u) * BC_THREADS + t;
-                        const int i = idx / BC_LD, d = idx % BC_LD;
-                        x[u] = (i < L && i + d < L + rowsB) ? bc_ld(base + idx) : 0.0;
+            for (int u = 0; u < BC_NV; ++u) {
+                const int idx = 2 * (u * BC_THREADS + t);
+                const int i = idx / BC_LD, d = idx % BC_LD;
+                const int q = i + d;
+                const double x0 = __hiloint2double(x[u][1], x[u][0]), x1 = __hiloint2double(x[u][3], x[u][2]);
+                if (i < L) {
+                    if (q < nrow) {
+                        E[q][i] = x0;
+                        if (q < L && q > i) E[i][q] = x0;
                     }
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) {
-                        const int idx = (h + u) * BC_THREADS + t;
-                        const int i = idx / BC_LD, d = idx % BC_LD;
-                        const int q = i + d;
-                        if (i < L && q < L + rowsB) {
-                            E[q][i] = x[u];
-                            if (q < L && q > i) E[i][q] = x[u];
-                        }
+                    if (q + 1 < nrow) {
+                        E[q + 1][i] = x1;
+                        if (q + 1 < L) E[i][q + 1] = x1;
                     }
                 }
             }
-            // reflector of this step -> v2 / tau2 (read by the back-transformation after the launch)
-            if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
-            if (t == 0) P.tau2[(int64_t)s * P.ks + k] = sc[0];
+            // progress of the previous sweep, read early: by the end of this step it usually already allows step k + 1
+            int seen = -1;
+            if (t == 0 && s > 0 && rowsB > 0) seen = __hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const double tau = sc[0];
+            // reflector of this step -> v2 / tau2 (read by the back-transformation after the launch)
+            if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
+            if (t == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
             // ---- D <- H D H:  y = D v,  w = tau y - (tau^2 v'y / 2) v,  D -= v w' + w v'
             {
                 double acc = 0.0;
@@ -221,9 +210,9 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
                 __syncthreads();
                 // ---- new reflector from the first column of B
                 if (wave == 0) {
-                    const double x = (lane < rowsB) ? E[L + lane][0] : 0.0;
+                    const double xb = (lane < rowsB) ? E[L + lane][0] : 0.0;
                     double v, tn, beta;
-                    bc_house_wave(x, lane, rowsB, v, tn, beta);
+                    bc_house_wave(xb, lane, rowsB, v, tn, beta);
                     if (lane < rowsB) {
                         E[L + lane][0] = (lane == 0) ? beta : 0.0;
                         vn[lane] = v;
@@ -257,16 +246,40 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
                 }
             }
             __syncthreads();
-            // ---- window -> memory (write-through), drain, publish
+            // ---- window -> memory (write-through 16-byte pieces); the positions below the window's rows are zero by the
+            // band structure and are rewritten as such
             {
-                double *base = P.ab + (int64_t)r * BC_LD;
-                for (int idx = t; idx < L * BC_LD; idx += BC_THREADS) {
+                const __amdgpu_buffer_rsrc_t rs = bc_window_rsrc(P.ab, n, r);
+#pragma unroll
+                for (int u = 0; u < BC_NV; ++u) {
+                    const int idx = 2 * (u * BC_THREADS + t);
                     const int i = idx / BC_LD, d = idx % BC_LD;
                     const int q = i + d;
-                    if (q < L + rowsB) bc_st(base + idx, E[q][i]);
+                    const double x0 = (i < L && q < nrow) ? E[q][i] : 0.0;
+                    const double x1 = (i < L && q + 1 < nrow) ? E[q + 1][i] : 0.0;
+                    bc_v4i o;
+                    o[0] = __double2loint(x0);
+                    o[1] = __double2hiint(x0);
+                    o[2] = __double2loint(x1);
+                    o[3] = __double2hiint(x1);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs, (u * BC_THREADS + t) * 16, 0, BC_AUX_SC1);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // may step k + 1 start?  (the previous sweep must have finished its step k + 2)
+            if (t == 0) ish[0] = (rowsB > 0) ? (bc_wait_progress(P, s, k + 3, seen) ? 1 : 0) : 1;
+            __syncthreads();                              // also: every wave has read its part of E
+            if (!ish[0]) {
+                if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (rowsB > 0) {
+                // the next window's loads go out behind the stores; the counted wait below retires the stores (memory
+                // operations of a wave complete in issue order) and leaves the BC_NV loads in flight
+                bc_window_load(bc_window_rsrc(P.ab, n, r + L), t, x);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BC_NV) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
             if (t == 0)
                 __hip_atomic_store(P.prog + s, (rowsB > 0) ? (k + 1) : BC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -276,7 +289,6 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
             if (t == 0) sc[0] = taun;
             r += L;
             L = rowsB;
-            __syncthreads();
         }
     }
 }

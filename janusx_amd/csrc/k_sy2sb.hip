@@ -54,20 +54,28 @@ __device__ __forceinline__ void tiny_store_lds(const Tiny &m, double (*s)[SB_P])
         for (int b = 0; b < 4; ++b) s[ti + 16 * a][tk + 16 * b] = m.v[a][b];
 }
 
+// The elimination loops run over j at run time (a fully unrolled form is ~0.5 MB of code and runs at the speed of the
+// instruction fetch).  Register arrays are only ever indexed with compile-time constants: the owners of the pivot row /
+// column publish all four of their 16-blocks and the readers pick block j / 16 by its LDS address.
+typedef double TinyVec[4][SB];      // [16-block][position]
+
 // G (symmetric, full, identity-padded) -> R upper triangular (G = R'R), strict lower part zero.  Returns 0 when a pivot
 // is not positive and finite (the factor is then meaningless; the caller raises the failure flag).
-__device__ __forceinline__ int tiny_chol_upper(Tiny &m, double (*vec)[SB]) {
+__device__ __forceinline__ int tiny_chol_upper(Tiny &m, TinyVec *vec) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
     int ok = 1;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < SB; ++j) {
         const int ja = j >> 4, jr = j & 15, p = j & 1;
         if (ti == jr) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) vec[p][tk + 16 * b] = m.v[ja][b];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = m.v[a][b];      // rows jr + 16 a; row j is block ja
         }
         __syncthreads();
-        double d = vec[p][j];
+        const double *rowj = vec[p][ja];
+        double d = rowj[j];
         if (!(d > 0.0) || !(d < 1e300)) {
             ok = 0;
             d = 1.0;
@@ -75,19 +83,17 @@ __device__ __forceinline__ int tiny_chol_upper(Tiny &m, double (*vec)[SB]) {
         const double ri = 1.0 / sqrt(d);
         double rk[4], rr[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rk[b] = vec[p][tk + 16 * b] * ri;
+        for (int b = 0; b < 4; ++b) rk[b] = rowj[tk + 16 * b] * ri;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) rr[a] = vec[p][ti + 16 * a] * ri;
+        for (int a = 0; a < 4; ++a) rr[a] = rowj[ti + 16 * a] * ri;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int i = ti + 16 * a, k = tk + 16 * b;
                 if (i > j && k > j) m.v[a][b] -= rr[a] * rk[b];
+                else if (i == j) m.v[a][b] = (k >= j) ? rk[b] : 0.0;
             }
-        if (ti == jr) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) m.v[ja][b] = (tk + 16 * b >= j) ? rk[b] : 0.0;
         }
     }
 #pragma unroll
@@ -99,67 +105,74 @@ __device__ __forceinline__ int tiny_chol_upper(Tiny &m, double (*vec)[SB]) {
 }
 
 // X <- X U^-1, U upper triangular in LDS (u[c][k], c <= k) with its diagonal stored as the reciprocal
-__device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)[SB_P], double (*vec)[SB]) {
+__device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)[SB_P], TinyVec *vec) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < SB; ++c) {
         const int cb = c >> 4, cr = c & 15, p = c & 1;
         if (tk == cr) {
-            const double rd = u[c][c];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                x.v[a][cb] *= rd;
-                vec[p][ti + 16 * a] = x.v[a][cb];
-            }
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vec[p][b][ti + 16 * a] = x.v[a][b];      // columns cr + 16 b; column c is block cb
         }
         __syncthreads();
+        const double *colc = vec[p][cb];
+        const double rd = u[c][c];
         double xc[4], uk[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xc[a] = vec[p][ti + 16 * a];
+        for (int a = 0; a < 4; ++a) xc[a] = colc[ti + 16 * a] * rd;
 #pragma unroll
         for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > c) ? u[c][tk + 16 * b] : 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) x.v[a][b] -= xc[a] * uk[b];
+            for (int a = 0; a < 4; ++a) {
+                if (tk + 16 * b == c) x.v[a][b] = xc[a];
+                else x.v[a][b] -= xc[a] * uk[b];
+            }
+        }
     }
 }
 
 // modified LU of W (Householder reconstruction): on exit the strict lower part holds L (unit diagonal implied), the
 // upper part incl. diagonal U; sgn[j] = the sign subtracted from the j-th pivot
-__device__ __forceinline__ void tiny_lu_modified(Tiny &w, double (*vec)[SB], double (*vec2)[SB], double *sgn) {
+__device__ __forceinline__ void tiny_lu_modified(Tiny &w, TinyVec *vec, TinyVec *vec2, double *sgn) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < SB; ++j) {
         const int ja = j >> 4, jr = j & 15, p = j & 1;
         if (ti == jr) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) vec[p][tk + 16 * b] = w.v[ja][b];        // row j
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = w.v[a][b];       // row j = block ja
         }
         if (tk == jr) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) vec2[p][ti + 16 * a] = w.v[a][ja];       // column j
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vec2[p][b][ti + 16 * a] = w.v[a][b];      // column j = block ja
         }
         __syncthreads();
-        const double d = vec[p][j];
+        const double *rowj = vec[p][ja], *colj = vec2[p][ja];
+        const double d = rowj[j];
         const double sj = (d >= 0.0) ? -1.0 : 1.0;
         const double piv = d - sj;
         const double pinv = 1.0 / piv;
         double li[4], uk[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > j) ? vec2[p][ti + 16 * a] * pinv : 0.0;
+        for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > j) ? colj[ti + 16 * a] * pinv : 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > j) ? vec[p][tk + 16 * b] : 0.0;
+        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > j) ? rowj[tk + 16 * b] : 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) w.v[a][b] -= li[a] * uk[b];
-        if (tk == jr) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = ti + 16 * a;
-                if (i > j) w.v[a][ja] = li[a];
-                else if (i == j) w.v[a][ja] = piv;
+            for (int b = 0; b < 4; ++b) {
+                const int i = ti + 16 * a, k = tk + 16 * b;
+                if (k == j && i > j) w.v[a][b] = li[a];
+                else if (k == j && i == j) w.v[a][b] = piv;
+                else w.v[a][b] -= li[a] * uk[b];
             }
         }
         if (threadIdx.x == 0) sgn[j] = sj;
@@ -205,8 +218,9 @@ __global__ __launch_bounds__(256) void sb_chol_kernel(const double *__restrict__
                                                       int *__restrict__ flags, int *__restrict__ panel_zero) {
     __shared__ double s[SB][SB_P];
     __shared__ double s2[SB][SB_P];
-    __shared__ double vec[2][SB];
+    __shared__ TinyVec vec[2];
     __shared__ int zero_sh;
+    __shared__ double tr_sh;
     const int t = threadIdx.x;
     tiny_fetch_colmajor(s, g, pw, true);
     if (!first) {
@@ -222,12 +236,11 @@ __global__ __launch_bounds__(256) void sb_chol_kernel(const double *__restrict__
             *panel_zero = z;
         }
         zero_sh = z;
-        vec[0][0] = tr;
+        tr_sh = tr;
     }
     __syncthreads();
     const bool zero = (zero_sh != 0);
-    const double tr = vec[0][0];
-    __syncthreads();
+    const double tr = tr_sh;
     Tiny m;
     tiny_load_lds(m, s);
     const int ti = t >> 4, tk = t & 15;
@@ -295,11 +308,11 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
                                                        double *__restrict__ t_out, double *__restrict__ tau,
                                                        double *__restrict__ pan_v1, double *__restrict__ pan_v2,
                                                        int64_t ldp, int *__restrict__ flags,
-                                                       const int *__restrict__ panel_zero) {
+                                                       const int *__restrict__ panel_zero, double skip_tol) {
     __shared__ double s[SB][SB_P];
     __shared__ double s2[SB][SB_P];
-    __shared__ double vec[2][SB];
-    __shared__ double vec2[2][SB];
+    __shared__ TinyVec vec[2];
+    __shared__ TinyVec vec2[2];
     __shared__ double sgn[SB];
     const int t = threadIdx.x;
     const int ti = t >> 4, tk = t & 15;
@@ -319,38 +332,49 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
     tiny_fetch_colmajor(s, g3, pw, true);
     for (int e = t; e < SB * SB; e += 256) s2[e / SB][e % SB] = rtot[e];
     __syncthreads();
+    // Is the panel orthonormal already after two passes?  |G3 - I| at the rounding level of the Gram product itself means a
+    // third pass would only factor noise: R3 = I then (the usual case; saves three of the six elimination loops).
     Tiny r3;
     tiny_load_lds(r3, s);
-    if (!tiny_chol_upper(r3, vec)) atomicOr(flags + SB_FLAG_FAIL, 4);
-    {
-        // G3 = Q2'Q2 must be the identity to working accuracy (R3 = I), or the panel was too ill-conditioned for three
-        // CholeskyQR passes
-        bool bad = false;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (ti + 16 * a == tk + 16 * b && !(fabs(r3.v[a][b] - 1.0) < 1e-8)) bad = true;
-        if (bad) atomicOr(flags + SB_FLAG_FAIL, 8);
-    }
-    __syncthreads();
-    tiny_store_lds(r3, s);                      // s = R3
-    __syncthreads();
-    Tiny rt;
-    tiny_matmul(rt, s, s2);                     // rtot = R3 * rtot
+    bool off = false;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int i = ti + 16 * a, k = tk + 16 * b;
-            rtot[i * SB + k] = rt.v[a][b];
+            const double dev = fabs(r3.v[a][b] - ((ti + 16 * a == tk + 16 * b) ? 1.0 : 0.0));
+            if (!(dev <= skip_tol)) off = true;
         }
-    // s <- R3 with reciprocal diagonal (operand of the triangular solve)
+    const bool third = __syncthreads_or(off ? 1 : 0) != 0;
+    Tiny rt;
+    if (third) {
+        if (!tiny_chol_upper(r3, vec)) atomicOr(flags + SB_FLAG_FAIL, 4);
+        {
+            // G3 = Q2'Q2 must be close to the identity (R3 ~ I), or the panel was too ill-conditioned for three passes
+            bool bad = false;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (ti + 16 * a == tk + 16 * b) s[ti + 16 * a][tk + 16 * b] = 1.0 / r3.v[a][b];
+                for (int b = 0; b < 4; ++b)
+                    if (ti + 16 * a == tk + 16 * b && !(fabs(r3.v[a][b] - 1.0) < 1e-8)) bad = true;
+            if (bad) atomicOr(flags + SB_FLAG_FAIL, 8);
+        }
+        __syncthreads();
+        tiny_store_lds(r3, s);                      // s = R3
+        __syncthreads();
+        tiny_matmul(rt, s, s2);                     // rtot = R3 * rtot
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rtot[(ti + 16 * a) * SB + tk + 16 * b] = rt.v[a][b];
+        // s <- R3 with reciprocal diagonal (operand of the triangular solve)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (ti + 16 * a == tk + 16 * b) s[ti + 16 * a][tk + 16 * b] = 1.0 / r3.v[a][b];
+    } else {
+        tiny_load_lds(rt, s2);                      // rtot unchanged
+    }
     // W = Qtop (identity-padded)
     Tiny w;
 #pragma unroll
@@ -361,8 +385,10 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
             w.v[a][b] = (i < pw && k < pw) ? atop[i + (int64_t)k * lda] : ((i == k) ? 1.0 : 0.0);
         }
     __syncthreads();
-    tiny_trsm_right_upper(w, s, vec);           // Qtop R3^-1
-    __syncthreads();
+    if (third) {
+        tiny_trsm_right_upper(w, s, vec);       // Qtop R3^-1
+        __syncthreads();
+    }
     tiny_lu_modified(w, vec, vec2, sgn);
     // A top block: S rtot (upper incl. diagonal) | L1 strictly below;  V copies: unit lower triangle;  U for the row solve
 #pragma unroll
@@ -419,8 +445,10 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
             x.v[a][b] = (i == k) ? 1.0 : 0.0;
         }
     __syncthreads();
-    tiny_trsm_right_upper(x, s, vec);
-    __syncthreads();
+    if (third) {
+        tiny_trsm_right_upper(x, s, vec);
+        __syncthreads();
+    }
     tiny_trsm_right_upper(x, s2, vec);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -536,7 +564,7 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             // pass 3 + reconstruction
             if (dgemm(st, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, g, SB, 0)) return 1;
             hipLaunchKernelGGL(sb_recon_kernel, dim3(1), dim3(256), 0, st, g, pw, pp, ld, rmat, umat, rtot, tmat,
-                               d_tau + j0, v1, v2, ld, d_flags, pz);
+                               d_tau + j0, v1, v2, ld, d_flags, pz, 8.0 * eps * sqrt((double)nt));
             JX_LAUNCH_CHECK();
             if (nt > pw) {
                 if (dgemm(st, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1)) return 1;

@@ -295,7 +295,7 @@ def main():
         acc = pl.grm_accumulate(panel, grows, glut)
         grm_ms = lib().jxg_last_kernel_ms(0)
         if distributed:
-            jd.allreduce_sum_(acc)     # f64 partial GRMs summed over xGMI (RCCL)
+            jd.allreduce_grm_accumulator_(acc)     # f64 partial GRMs summed over xGMI (RCCL): lower-triangle tiles only
             jd.allreduce_sum_(denom)
         k32 = pl.grm_finalize(acc, n, float(denom[0]), torch.float32)
         del acc

@@ -97,6 +97,8 @@ int jxg_spgrm_densify(const uint64_t *d_colptr, const uint32_t *d_rows, const do
  * compact-WY back-transformation (k_ormtr.hip); rocSOLVER dsyevd only below n = 256.  `ridge` is added to the diagonal first
  * (python/janusx/assoc/workflow.py:5639-5641). */
 int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream);
+/* 1 when every n-dependent launch grid of jxg_eigh_f64 is inside the HIP limits for an n-row problem (no GPU needed). */
+int jxg_eigh_grid_check(int n);
 
 /* Node-level distribution of B1 (no counterpart in the reference, whose LAPACK call is single-process): every rank
  * calls jxg_eigh_f64 on the same matrix; for n >= min_n (<= 0: keep the default 16384) each rank streams 1 / world of
@@ -122,6 +124,12 @@ int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t l
 int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,
                             double beta, double *d_c, int64_t ldc, void *stream);
 int jxg_sy2st_f64(double *d_a, int n, double *d_d, double *d_e, double *d_ab_out, int *h_flags, void *stream);
+
+/* Multi-GPU reduce of the partial GRMs (no counterpart in the single-process reference): the lower-triangle
+ * tiles (ti >= tj, 128 x 128) of the (npad, npad) f64 accumulator <-> a packed buffer of jxg_tri_tiles_doubles(npad)
+ * doubles, so the all-reduce over xGMI moves n (n + 1) / 2 values instead of the n^2 square. */
+int64_t jxg_tri_tiles_doubles(int npad);
+int jxg_tri_tiles_pack_f64(double *d_acc, int npad, double *d_buf, int unpack, void *stream);
 
 /* a <- (a + a^T)/2 (src/math/eigh.rs:179-207); dst = src^T; dst (k,k) f64 = src[idx, idx] of an (n,n)
  * f32/f64 matrix (trait-sample subset, python/janusx/assoc/workflow.py:5509-5560). */

@@ -36,12 +36,15 @@ SIGNATURES = {
     "jxg_spgrm_fill": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p, c_p],
     "jxg_spgrm_densify": [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
+    "jxg_eigh_grid_check": [c_i],
     "jxg_eigh_dist_staging_doubles": [c_i],
     "jxg_eigh_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i],
     "jxg_dgemm_f64": [c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_i, c_p],
     "jxg_dsymm_lower_f64": [c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p],
     "jxg_dsyr2k_lower_nt_f64": [c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p],
     "jxg_sy2st_f64": [c_p, c_i, c_p, c_p, c_p, c_p, c_p],
+    "jxg_tri_tiles_doubles": [c_i],
+    "jxg_tri_tiles_pack_f64": [c_p, c_i, c_p, c_i, c_p],
     "jxg_symmetrize_f64": [c_p, c_i, c_p],
     "jxg_transpose_f64": [c_p, c_p, c_i, c_p],
     "jxg_gather_sub_f64": [c_p, c_i, c_i, c_p, c_i, c_p, c_p],
@@ -97,7 +100,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,
-             "jxg_spgrm_work_bytes": C.c_int64}
+             "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64}
 
 
 def lib():

@@ -162,17 +162,30 @@ def cmd_gwas(args):
     t0 = time.perf_counter()
     dense_models = args.lmm or args.fvlmm or args.lmm2
     k = None
+    if dense_models and str(args.grm).lower().endswith((".spgrm", ".jxgrm")):
+        raise SystemExit("-k FILE.spgrm is a sparse GRM: it serves -splmm only; -lmm / -lmm2 / -fvlmm need a dense GRM "
+                         "(-k 1 | 2 | FILE.npy)")
     if dense_models and args.grm in ("1", "2"):
         k, eff, _ = pl.build_grm(packed_t, n_fam, int(args.grm), args.maf, args.geno)
         print(f"GRM method {args.grm}: eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
     elif dense_models:
         k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)
     sparse_path = None
+    sparse_pos = None
     if args.splmm is not None:
         # SparseLMM, exact mode: thresholded sparse GRM of all genotyped samples once (`.spgrm`, or an existing one given
         # with -grm FILE.spgrm), then per trait the sparse REML null model and the exact g'Pg scan on its samples
         if str(args.grm).lower().endswith((".spgrm", ".jxgrm")):
             sparse_path = args.grm
+            # the sparse GRM's own sample order: map by id, like the dense -grm FILE path (_load_grm)
+            id_path = sparse_path + ".id"
+            if not os.path.exists(id_path):
+                raise SystemExit(f"{id_path} not found: a sparse GRM given with -k needs its sample-id file "
+                                 "(one id per line, in the order of the matrix)")
+            sparse_ids = [ln.split()[0] for ln in open(id_path) if ln.strip()]
+            sparse_pos = {sid: i for i, sid in enumerate(sparse_ids)}
+            if len(sparse_pos) != len(sparse_ids):
+                raise SystemExit(f"{id_path} lists duplicate sample ids")
         else:
             method = int(args.grm) if args.grm in ("1", "2") else 1
             sparse_path, _, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=method,
@@ -225,9 +238,16 @@ def cmd_gwas(args):
             kept = np.nonzero(keep)[0]
             maf_all = np.zeros(packed.shape[0], dtype=np.float32)
             maf_all[kept] = af[kept]
+            grm_idx = None
+            if sparse_pos is not None:
+                missing_ids = [fam[j] for j in keep_idx if fam[j] not in sparse_pos]
+                if missing_ids:
+                    raise SystemExit(f"{sparse_path}.id lacks {len(missing_ids)} phenotyped sample(s), e.g. {missing_ids[0]}")
+                grm_idx = np.array([sparse_pos[fam[j]] for j in keep_idx], dtype=np.int64)
             stats, l10, null = jxrs.splmm_exact_scan_from_jxgrm(
                 sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool),
-                x[:, 1:] if x.shape[1] > 1 else None, None if full else keep_idx, kept)
+                x[:, 1:] if x.shape[1] > 1 else None, keep_idx if (grm_idx is not None or not full) else None, kept,
+                grm_sample_indices=grm_idx)
             path = f"{out}.{name}.splmm.tsv"
             write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
                             [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],

@@ -24,6 +24,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
                 std::vector<int> &h_perm);
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
+void gather_cols_grid(int n, unsigned *gx, unsigned *gy);
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
                    int min_n);
 // k_ormtr.hip: C <- Q C with wide compact-WY blocks (dormtr left / lower / no-transpose)
@@ -70,8 +71,26 @@ extern "C" int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), 
 
 // d_a: (n,n) symmetric, f64. On return row j of d_a (row-major) = eigenvector j (= column j of the
 // column-major LAPACK result), eigenvalues ascending in d_w.
+// launch geometry of the n-dependent two-dimensional grids of the eigensolver (gridDim.y <= 65535, gridDim.x < 2^31):
+// 1 when every one of them is valid for an n-row problem.  No GPU needed (CPU test for n beyond 65535).
+extern "C" int jxg_eigh_grid_check(int n) {
+    if (n <= 0) return 0;
+    unsigned gx = 0, gy = 0;
+    gather_cols_grid(n, &gx, &gy);
+    if (gy > 65535u || gx > 0x7fffffffu) return 0;
+    const int ks = sb2st_steps(n);                       // sbback_tfactor_kernel: (ks, groups of 32 sweeps)
+    const int64_t groups = ((int64_t)n - 2 + 31) / 32;
+    if (ks > 0x7fffffff || groups > 65535) return 0;
+    const int64_t band_blocks = ((int64_t)n * sb2st_ldab() + 255) / 256;   // sb_extract_band_kernel (1-D)
+    if (band_blocks > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+static std::mutex g_eigh_mu;   // one decomposition at a time: the rocBLAS handle and the kept scratch blocks are process-global
+
 extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void *stream) {
     if (n <= 0) return fail("jxg_eigh_f64: n must be > 0");
+    std::lock_guard<std::mutex> eigh_lock(g_eigh_mu);
     hipStream_t st = (hipStream_t)stream;
     rocblas_handle h = get_handle();
     if (!h) return fail("rocblas_create_handle failed");
@@ -204,6 +223,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             JX_HIP(hipStreamSynchronize(st));
         } else {
             JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * (size_t)n, hipMemcpyDeviceToDevice, st));
+            JX_HIP(hipStreamSynchronize(st));   // the scratch block `c` is released at the end of this scope
         }
     }
     rocblas_int hinfo = 0;

@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void gather_sub_kernel(const T *__restrict__ s
     dst[gid] = (double)src[(int64_t)idx[r] * n + idx[c]];
 }
 
+// Lower-triangle tiles (ti >= tj, JXG_TILE x JXG_TILE each) of the (npad, npad) f64 GRM accumulator <-> a packed buffer of
+// T (T + 1) / 2 tiles: the multi-GPU reduce of the partial GRMs moves only what the GRM kernel writes (SURVEY.md 8e:
+// n (n + 1) / 2 values, half of the square).  One workgroup per tile, 16-byte accesses.
+template <bool PACK>
+__global__ __launch_bounds__(256) void tri_tiles_kernel(double *__restrict__ acc, int npad, double *__restrict__ buf) {
+    const int bid = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+    while ((int64_t)ti * (ti + 1) / 2 > bid) --ti;
+    const int tj = bid - (int)((int64_t)ti * (ti + 1) / 2);
+    double2 *b2 = reinterpret_cast<double2 *>(buf + (int64_t)bid * JXG_TILE * JXG_TILE);
+    for (int e = threadIdx.x; e < JXG_TILE * JXG_TILE / 2; e += 256) {
+        const int r = e / (JXG_TILE / 2), c2 = e % (JXG_TILE / 2);
+        double2 *a2 = reinterpret_cast<double2 *>(acc + (int64_t)(ti * JXG_TILE + r) * npad + tj * JXG_TILE) + c2;
+        if (PACK) b2[e] = *a2;
+        else *a2 = b2[e];
+    }
+}
+
 int launch_add_diag(double *d_a, int n, int64_t ld, double ridge, hipStream_t st) {
     hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_a, n, ld, ridge);
     JX_LAUNCH_CHECK();
@@ -73,6 +92,21 @@ int launch_transpose_f64(const double *src, double *dst, int n, hipStream_t st) 
 }  // namespace jx
 
 using namespace jx;
+
+extern "C" int64_t jxg_tri_tiles_doubles(int npad) {
+    const int64_t t = npad / JXG_TILE;
+    return t * (t + 1) / 2 * JXG_TILE * JXG_TILE;
+}
+
+extern "C" int jxg_tri_tiles_pack_f64(double *d_acc, int npad, double *d_buf, int unpack, void *stream) {
+    if (npad <= 0 || npad % JXG_TILE != 0) return fail("jxg_tri_tiles_pack_f64: npad must be a positive multiple of the tile size");
+    const int64_t t = npad / JXG_TILE;
+    const unsigned blocks = (unsigned)(t * (t + 1) / 2);
+    if (unpack) hipLaunchKernelGGL(tri_tiles_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_acc, npad, d_buf);
+    else hipLaunchKernelGGL(tri_tiles_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_acc, npad, d_buf);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int jxg_symmetrize_f64(double *d_a, int n, void *stream) { return launch_symmetrize(d_a, n, (hipStream_t)stream); }
 

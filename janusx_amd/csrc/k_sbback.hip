@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void sbback_tfactor_kernel(QbParams P) {
 }
 
 constexpr int QB_VP = QB_WIN + 2;          // pitch of the V image [m][q]
-constexpr int QB_T = 512;                  // threads per workgroup: two waves per SIMD hide each other's LDS latency
+constexpr int QB_T = 1024;                 // threads per workgroup: two waves per SIMD hide each other's LDS latency
 constexpr int QB_NWAVE = QB_T / 64;
 
 // NW = slab width / 16.  LDS: ring [W][QB_RP] | w1, w2 [W][QB_WP] | vs [QB_G][QB_VP]

@@ -1025,14 +1025,23 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
 // dst row r (row-major, n x n) = column perm[r] of the column-major src: the final "eigenvector j in row j" layout
 __global__ void sd_gather_cols_kernel(const double *__restrict__ src, const int *__restrict__ perm, int n,
                                       double *__restrict__ dst) {
-    const int r = blockIdx.y;
+    // rows on gridDim.x (limit 2^31 - 1; gridDim.y stops at 65535), a grid-stride loop along the row
+    const int r = blockIdx.x;
     const double *s = src + (int64_t)perm[r] * n;
     double *t = dst + (int64_t)r * n;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) t[c] = s[c];
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < n; c += gridDim.y * blockDim.x) t[c] = s[c];
+}
+
+// launch geometry of the gather (exposed for the CPU-side test of large n)
+void gather_cols_grid(int n, unsigned *gx, unsigned *gy) {
+    *gx = (unsigned)n;
+    *gy = 16;
 }
 
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st) {
-    hipLaunchKernelGGL(sd_gather_cols_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, src, d_perm, n, dst);
+    unsigned gx, gy;
+    gather_cols_grid(n, &gx, &gy);
+    hipLaunchKernelGGL(sd_gather_cols_kernel, dim3(gx, gy), dim3(256), 0, st, src, d_perm, n, dst);
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -46,3 +46,27 @@ def gather_rows(local, counts=None):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def allreduce_grm_accumulator_(acc, chunk_bytes=2 << 30):
+    """Sum the (npad, npad) f64 GRM accumulators of the ranks in place, moving only the lower-triangle tiles the GRM kernel
+    writes: pack (ti >= tj) tiles -> all-reduce of n (n + 1) / 2 values (in `chunk_bytes` pieces, so the staging buffer
+    stays small next to the 20 GB square of BASELINE configs[3]) -> unpack.  Falls back to the plain all-reduce off the
+    GPU (gloo CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return acc
+    if not acc.is_cuda:
+        return allreduce_sum_(acc)
+    from ._lib import check, lib
+    npad = int(acc.shape[0])
+    total = int(lib().jxg_tri_tiles_doubles(npad))
+    buf = torch.empty(total, dtype=torch.float64, device=acc.device)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().jxg_tri_tiles_pack_f64(acc.data_ptr(), npad, buf.data_ptr(), 0, st))
+    step = max(1, int(chunk_bytes) // 8)
+    for o in range(0, total, step):
+        allreduce_sum_(buf[o:o + step])
+    check(lib().jxg_tri_tiles_pack_f64(acc.data_ptr(), npad, buf.data_ptr(), 1, st))
+    return acc

@@ -423,6 +423,21 @@ def splmm_load_sparse_grm_subset_dense(jxgrm_path, sample_indices=None):
     return k.cpu().numpy()
 
 
+def _check_spectral_sparse_size(n):
+    """The spectral form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors and the
+    eigensolver's workspace (~5 n^2 doubles) in HBM; the reference factorises the sparse K + lambda I instead
+    (src/stats/spreml.rs:384-512) and stays usable beyond that.  Refuse clearly instead of failing inside hipMalloc."""
+    import torch
+    need = 5 * int(n) * int(n) * 8
+    if torch.cuda.is_available():
+        free, _total = torch.cuda.mem_get_info()
+        if need > free:
+            raise RuntimeError(
+                f"sparse-GRM spectral route: n = {n} needs about {need / 2**30:.0f} GiB of HBM for the dense image of K and "
+                f"its eigenvectors, {free / 2**30:.0f} GiB are free; this build has no sparse-factorisation route for "
+                "larger n (restrict the samples, or use -lmm with the dense GRM)")
+
+
 class _SpectralSparseReml:
     """K + lambda I of a (subset of a) sparse GRM handled through ONE eigendecomposition on the GPU instead of one
     sparse LLT per lambda (src/stats/spreml.rs:384-512 factorises at every evaluation): K = U diag(s) U', so
@@ -434,6 +449,7 @@ class _SpectralSparseReml:
         import torch
         from . import pipeline as pl
         y = _c(y, np.float64).ravel()
+        _check_spectral_sparse_size(y.shape[0])
         k, idx = _spgrm_dense_device(path, sample_indices)
         n = int(k.shape[0])
         if n != y.shape[0]:
@@ -630,16 +646,22 @@ def spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(jxgrm_path, y_resid, vp_fixe
 
 def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, row_flip, x_cov=None,
                                 sample_indices=None, row_indices=None, log10_lambda=None, low=-5.0, high=5.0,
-                                grid_size=9, tol=1e-3, max_iter=20):
+                                grid_size=9, tol=1e-3, max_iter=20, grm_sample_indices=None):
     """SparseLMM exact association scan: the null model of `spreml_sparse_reml_brent_from_jxgrm` (or a given
     log10_lambda) followed by `exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) over the packed rows — the two
     stages the reference's `splmm_assoc_pcg_bed` workflow chains for its exact mode.  V = K + lambda I is never
     factorised: the eigenvectors of the sparse K rotate every SNP (the MFMA rotation kernel of the dense LMM, LUT
     [0, 2 maf, 1, 2] or flipped, missing = mean, not centred), and g'V^-1 g, X'V^-1 g, g.Py are weighted sums over the
-    rotated row (`jxg_splmm_exact_scan_dev`).  -> (stats (m, 3) f64 [beta, se, p], log10_lambda, null 10-tuple or None)."""
+    rotated row (`jxg_splmm_exact_scan_dev`).  -> (stats (m, 3) f64 [beta, se, p], log10_lambda, null 10-tuple or None).
+    `grm_sample_indices` (extension): positions of the same samples inside the sparse GRM when its sample order is not
+    the genotype file's (`sample_indices` then indexes the packed payload only); default: the same indices for both."""
     import torch
     from . import pipeline as pl
-    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices if grm_sample_indices is None else grm_sample_indices)
+    panel_idx = model.sample_idx if grm_sample_indices is None else (
+        None if sample_indices is None else _c(sample_indices, np.int64).ravel())
+    if grm_sample_indices is not None and panel_idx is not None and panel_idx.shape[0] != model.n:
+        raise RuntimeError(f"sample_indices ({panel_idx.shape[0]}) and grm_sample_indices ({model.n}) differ in length")
     null = None
     if log10_lambda is None:
         null = _spreml_brent(model, low, high, grid_size, tol, max_iter, None, None)
@@ -667,7 +689,7 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
     dev = model.s_dev.device
     pk_w = pk if pk.flags.writeable else pk.copy()          # torch.from_numpy wants a writable array (memmapped payloads are not)
-    panel = pl.Panel(torch.from_numpy(pk_w).to(dev), n_full, model.sample_idx)
+    panel = pl.Panel(torch.from_numpy(pk_w).to(dev), n_full, panel_idx)
     sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
     # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
     # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy

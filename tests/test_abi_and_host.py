@@ -193,3 +193,12 @@ def test_sparse_grm_diag_stats_host(tmp_path):
     O.write_sparse_grm_csc(p, 2, [0, 1, 2], [1, 1], [0.3, 1.0])                    # column 0 has no diagonal entry
     with pytest.raises(RuntimeError, match="diagonal is missing at column 0"):
         jxrs.splmm_sparse_grm_diag_stats(p)
+
+
+def test_eigh_launch_geometry_beyond_65535_rows():
+    """the column gather of the eigensolver put its rows on gridDim.y (limit 65535); every n-dependent
+    grid must be valid up to the sizes HBM allows (n = 70 000 and n = 150 000 here; no GPU needed)."""
+    from janusx_amd import _lib
+    h = _lib.lib()
+    for n in (300, 46341, 65536, 70000, 150000):
+        assert h.jxg_eigh_grid_check(n) == 1, n

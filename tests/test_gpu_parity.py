@@ -1675,6 +1675,33 @@ def test_cli_gwas_splmm(oracle, tmp_path):
         assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 * max(1.0, abs(ref[i, 0]))     # 4 significant digits in the TSV
         assert abs(float(f[8]) - ref[i, 1]) <= 1.5e-4 * max(1.0, abs(ref[i, 1]))
         assert abs(float(f[10]) - ref[i, 2]) <= 2e-4 * ref[i, 2] + 1e-300           # chisq is f[9], pwald f[10]
+    # an EXISTING sparse GRM (-grm FILE.spgrm) is aligned to the genotype file by its sibling .id file:
+    # the same GRM with its samples in another order must give the same table; without the id file, or together with a
+    # dense model, the command refuses
+    from janusx_amd import janusx as jxrs
+    kfull = oracle.sparse_grm_dense_subset(nn, cp, ri, va, np.arange(n))
+    perm = np.random.default_rng(5).permutation(n)
+    np.save(str(tmp_path / "perm.npy"), kfull[np.ix_(perm, perm)])
+    with open(str(tmp_path / "perm.npy.id"), "w") as fh:
+        fh.write("\n".join(ids[i] for i in perm) + "\n")
+    ppath, _, _ = jxrs.spgrm_dense_npy_to_jxgrm(str(tmp_path / "perm.npy"), str(tmp_path / "perm"), 0.0, abs_threshold=True)
+    with open(ppath + ".id", "w") as fh:
+        fh.write("\n".join(ids[i] for i in perm) + "\n")
+    out2 = str(tmp_path / "toy2")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-k", ppath, "-o", out2]) == 0
+    lines2 = open(out2 + ".traitA.splmm.tsv").read().splitlines()
+    assert len(lines2) == len(lines)
+    for a, b in zip(lines[1:], lines2[1:]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert fa[:7] == fb[:7]
+        for c in (7, 8, 10):
+            assert abs(float(fa[c]) - float(fb[c])) <= 2e-4 * max(abs(float(fa[c])), 1e-300) + (1e-4 if c < 10 else 0.0)
+    import os
+    os.remove(ppath + ".id")
+    with pytest.raises(SystemExit, match="not found"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-k", ppath, "-o", out2])
+    with pytest.raises(SystemExit, match="sparse GRM"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-splmm", "0.05", "-k", prefix + ".spgrm", "-o", out2])
 
 
 @pytest.mark.gpu
@@ -1708,3 +1735,31 @@ def test_spgrm_dense_npy_to_jxgrm(oracle, tmp_path, dtype, thr, abs_thr):
     np.save(npy, k)
     with pytest.raises(RuntimeError, match="non-finite value"):
         jxrs.spgrm_dense_npy_to_jxgrm(npy, str(tmp_path / "e"), thr, abs_thr)
+
+
+@pytest.mark.gpu
+def test_grm_accumulator_lower_tile_packing():
+    """Multi-GPU reduce of the partial GRMs: only the lower-triangle tiles travel.  Pack -> (sum of two
+    'ranks' on the packed image) -> unpack reproduces the sum of the lower tiles and leaves the upper tiles alone."""
+    import torch
+    from janusx_amd._lib import check, lib
+    npad = 5 * 128
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    a = torch.randn((npad, npad), generator=g, device=dev, dtype=torch.float64)
+    b = torch.randn((npad, npad), generator=g, device=dev, dtype=torch.float64)
+    total = int(lib().jxg_tri_tiles_doubles(npad))
+    assert total == 15 * 128 * 128
+    st = torch.cuda.current_stream().cuda_stream
+    pa = torch.empty(total, dtype=torch.float64, device=dev)
+    pb = torch.empty(total, dtype=torch.float64, device=dev)
+    check(lib().jxg_tri_tiles_pack_f64(a.data_ptr(), npad, pa.data_ptr(), 0, st))
+    check(lib().jxg_tri_tiles_pack_f64(b.data_ptr(), npad, pb.data_ptr(), 0, st))
+    out = a.clone()
+    pa += pb
+    check(lib().jxg_tri_tiles_pack_f64(out.data_ptr(), npad, pa.data_ptr(), 1, st))
+    tile = torch.arange(npad, device=dev) // 128
+    lower = tile[:, None] >= tile[None, :]
+    assert torch.equal(out[lower], (a + b)[lower])
+    assert torch.equal(out[~lower], a[~lower])

@@ -34,6 +34,7 @@ struct BcParams {
     int ks;
     int *prog;         // (n) finished steps per sweep
     int *abort_flag;
+    int skip;          // diagnostic bit mask (JXGPU_BC_SKIP): 1 no arithmetic phases, 2 no window stores / loads
 };
 
 __device__ __forceinline__ double bc_ld(const double *p) {
@@ -99,9 +100,12 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
     double *vv = bc_smem + 2 * BC_SB * BC_P;    // [SB] current reflector
     double *vn = vv + BC_SB;                    // [SB] next reflector
     double *ww = vn + BC_SB;                    // [SB]
-    double *part = ww + BC_SB;                  // [4][SB]
-    double *sc = part + 4 * BC_SB;              // [8] scalars: 0 tau, 1 tau_next
-    int *ish = reinterpret_cast<int *>(sc + 8); // [2] 0: ok flag
+    double *part = ww + BC_SB;                  // [8][SB]
+    double *sc = part + 8 * BC_SB;              // [8] scalars: 0 tau, 1 tau_next
+    double *wcopy = sc + 8;                     // [4][SB] per-wave copy of w
+    double *usum = wcopy + 4 * BC_SB;           // [4][16] column sums of the left application
+    double *colscr = usum + 64;                 // [4][16][SB + 1] scratch of the column sums
+    int *ish = reinterpret_cast<int *>(colscr + 4 * 16 * BC_P); // [2] 0: ok flag
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = P.n;
     const int row = t & 63, quarter = t >> 6;   // (row or column) x 16-wide slice decomposition of a 64 x 64 block
@@ -156,99 +160,110 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
             if (t == 0 && s > 0 && rowsB > 0) seen = __hip_atomic_load(P.prog + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const double tau = sc[0];
+            double taun = 0.0;
+            if (P.skip & 1) goto after_compute;
             // reflector of this step -> v2 / tau2 (read by the back-transformation after the launch)
-            if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
-            if (t == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
-            // ---- D <- H D H:  y = D v,  w = tau y - (tau^2 v'y / 2) v,  D -= v w' + w v'
-            {
-                double acc = 0.0;
-                if (row < L) {
-                    const int c0 = quarter * 16;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c0 + c < L) acc += E[row][c0 + c] * vv[c0 + c];
-                }
-                part[quarter * BC_SB + row] = acc;
+            if (!(P.skip & 4)) {
+                if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
+                if (t == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
             }
-            __syncthreads();
-            if (wave == 0) {
-                const double y = (lane < L) ? (part[lane] + part[BC_SB + lane]) + (part[2 * BC_SB + lane] + part[3 * BC_SB + lane]) : 0.0;
-                double vy = (lane < L) ? y * vv[lane] : 0.0;
+            {
+                // The arithmetic runs on registers: wave q (= quarter) holds the columns 16 q .. 16 q + 15 of D (dD) and of B
+                // (dB), lane = row.  Row sums cross the four waves through LDS (one barrier), column sums are butterfly
+                // reductions inside a wave, vector entries of other rows come by lane permutes.
+                const int c0 = quarter * 16;
+                double dD[16], dB[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    dD[c] = (row < L && c0 + c < L) ? E[row][c0 + c] : 0.0;
+                    dB[c] = (row < rowsB && c0 + c < L) ? E[L + row][c0 + c] : 0.0;
+                }
+                const double v_lane = (lane < L) ? vv[lane] : 0.0;
+                double vq[16];                                   // v of this wave's columns (vv is zero beyond L)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) vq[c] = (c0 + c < L) ? vv[c0 + c] : 0.0;
+                // ---- y = D v, z = B v: partial sums over this wave's 16 columns
+                {
+                    double py = 0.0, pz = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        py += dD[c] * vq[c];
+                        pz += dB[c] * vq[c];
+                    }
+                    part[quarter * BC_SB + row] = py;
+                    part[(4 + quarter) * BC_SB + row] = pz;
+                }
+                __syncthreads();
+                const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
+                const double z = tau * ((part[4 * BC_SB + row] + part[5 * BC_SB + row]) + (part[6 * BC_SB + row] + part[7 * BC_SB + row]));
+                double vy = y * v_lane;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) vy += __shfl_xor(vy, o);
-                if (lane < L) ww[lane] = tau * y - (0.5 * tau * tau * vy) * vv[lane];
-            }
-            __syncthreads();
-            if (row < L) {
-                const int c0 = quarter * 16;
-                const double vr = vv[row], wr = ww[row];
+                const double w_lane = tau * y - (0.5 * tau * tau * vy) * v_lane;
+                // w of this wave's columns: through a per-wave LDS copy (a wave's LDS operations complete in order)
+                double *wsh = wcopy + wave * BC_SB;
+                wsh[lane] = w_lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- D <- H D H = D - v w' - w v';  B <- B H = B - (tau B v) v'
+                if (!(P.skip & 32))
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c0 + c < L) E[row][c0 + c] -= vr * ww[c0 + c] + wr * vv[c0 + c];
-            }
-            double taun = 0.0;
-            if (rowsB > 0) {
-                // ---- B <- B H:  z = B v,  B -= tau z v'
-                {
-                    double acc = 0.0;
-                    if (row < rowsB) {
-                        const int c0 = quarter * 16;
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (c0 + c < L) acc += E[L + row][c0 + c] * vv[c0 + c];
-                    }
-                    part[quarter * BC_SB + row] = acc;
+                for (int c = 0; c < 16; ++c) {
+                    const double wc = wsh[c0 + c];
+                    dD[c] -= v_lane * wc + w_lane * vq[c];
+                    dB[c] -= z * vq[c];
                 }
-                __syncthreads();
-                if (row < rowsB) {
-                    const double z = tau * ((part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]));
-                    const int c0 = quarter * 16;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c0 + c < L) E[L + row][c0 + c] -= z * vv[c0 + c];
-                }
-                __syncthreads();
-                // ---- new reflector from the first column of B
-                if (wave == 0) {
-                    const double xb = (lane < rowsB) ? E[L + lane][0] : 0.0;
-                    double v, tn, beta;
-                    bc_house_wave(xb, lane, rowsB, v, tn, beta);
-                    if (lane < rowsB) {
-                        E[L + lane][0] = (lane == 0) ? beta : 0.0;
-                        vn[lane] = v;
+                if (rowsB > 0) {
+                    // ---- new reflector from the first column of B (wave 0, register 0)
+                    if (wave == 0 && !(P.skip & 16)) {
+                        double v, tn, beta;
+                        bc_house_wave(dB[0], lane, rowsB, v, tn, beta);
+                        dB[0] = (lane == 0) ? beta : 0.0;
+                        vn[lane] = (lane < rowsB) ? v : 0.0;
+                        if (lane == 0) sc[1] = tn;
                     }
-                    if (lane == 0) sc[1] = tn;
-                }
-                __syncthreads();
-                taun = sc[1];
-                // ---- B <- H1 B on the columns 1 .. L-1:  u = B' vn,  B -= taun vn u'
-                {
-                    const int c = row;                     // column
-                    double acc = 0.0;
-                    if (c >= 1 && c < L) {
-                        const int p0 = quarter * 16;
+                    __syncthreads();
+                    taun = sc[1];
+                    const double vn_lane = vn[lane];
+                    // ---- B <- H1 B on the columns 1 .. L-1:  u = B' vn,  B -= taun vn u'.  The 16 column sums of a wave go
+                    // through an LDS scratch (16 butterfly reductions are 96 dependent cross-lane steps, 3.4 us per step of
+                    // the chase): every lane stores its 16 products, lane l then adds 16 rows of column l / 4 and two
+                    // lane-exchange steps finish the sum.
+                    if (!(P.skip & 8)) {
+                        double *scr = colscr + wave * (16 * BC_P);
 #pragma unroll
-                        for (int p = 0; p < 16; ++p)
-                            if (p0 + p < rowsB) acc += E[L + p0 + p][c] * vn[p0 + p];
-                    }
-                    part[quarter * BC_SB + c] = acc;
-                }
-                __syncthreads();
-                {
-                    const int c = row;
-                    if (c >= 1 && c < L) {
-                        const double u = taun * ((part[c] + part[BC_SB + c]) + (part[2 * BC_SB + c] + part[3 * BC_SB + c]));
-                        const int p0 = quarter * 16;
+                        for (int c = 0; c < 16; ++c) scr[c * BC_P + lane] = vn_lane * dB[c];
+                        __syncthreads();
+                        {
+                            const int cl = lane >> 2, sub = lane & 3;
+                            double acc = 0.0;
 #pragma unroll
-                        for (int p = 0; p < 16; ++p)
-                            if (p0 + p < rowsB) E[L + p0 + p][c] -= vn[p0 + p] * u;
+                            for (int p = 0; p < 16; ++p) acc += scr[cl * BC_P + sub * 16 + p];
+                            acc += __shfl_xor(acc, 1);
+                            acc += __shfl_xor(acc, 2);
+                            if (sub == 0) usum[wave * 16 + cl] = acc;
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            if (c0 + c == 0) continue;                  // wave-uniform: the eliminated column
+                            dB[c] -= taun * vn_lane * usum[wave * 16 + c];
+                        }
                     }
+                }
+                // registers -> LDS image for the write-back (lower part of D, B)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (row < L && c0 + c < L) E[row][c0 + c] = dD[c];
+                    if (row < rowsB && c0 + c < L) E[L + row][c0 + c] = dB[c];
                 }
             }
+        after_compute:
             __syncthreads();
             // ---- window -> memory (write-through 16-byte pieces); the positions below the window's rows are zero by the
             // band structure and are rewritten as such
-            {
+            if (!(P.skip & 2)) {
                 const __amdgpu_buffer_rsrc_t rs = bc_window_rsrc(P.ab, n, r);
 #pragma unroll
                 for (int u = 0; u < BC_NV; ++u) {
@@ -275,8 +290,8 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
             if (rowsB > 0) {
                 // the next window's loads go out behind the stores; the counted wait below retires the stores (memory
                 // operations of a wave complete in issue order) and leaves the BC_NV loads in flight
-                bc_window_load(bc_window_rsrc(P.ab, n, r + L), t, x);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BC_NV) : "memory");
+                if (!(P.skip & 2)) bc_window_load(bc_window_rsrc(P.ab, n, r + L), t, x);
+                if (!(P.skip & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BC_NV) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -312,7 +327,7 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
     JX_HIP(hipMemsetAsync(d_ctrl, 0, sizeof(int) * ((size_t)n + 4), st));
     JX_HIP(hipMemsetAsync(d_tau2, 0, sizeof(double) * (size_t)n * ks, st));
     if (n > 2) {
-        BcParams P{d_ab, n, d_v2, d_tau2, ks, d_ctrl, d_ctrl + n};
+        BcParams P{d_ab, n, d_v2, d_tau2, ks, d_ctrl, d_ctrl + n, getenv("JXGPU_BC_SKIP") ? atoi(getenv("JXGPU_BC_SKIP")) : 0};
         static int cus = 0;
         if (!cus) {
             int dev = 0;
@@ -327,7 +342,7 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
         if (g > cus) g = cus;
         if (g > n - 2) g = n - 2;
         // > 80 KB of LDS per workgroup: at most one workgroup per CU (the hand-off form is measured for that geometry)
-        const size_t lds = 84 * 1024;
+        const size_t lds = 120 * 1024;
         static bool attr_set = false;
         if (!attr_set) {
             JX_HIP(hipFuncSetAttribute((const void *)sb2st_chase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

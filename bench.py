@@ -305,6 +305,9 @@ def main():
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
+        two_stage = lib().jxg_last_kernel_ms(10) > 0.5        # which reduction jxg_eigh_f64 took (two-stage from n = 13000)
+        q2_ms, q2_gflop = lib().jxg_last_kernel_ms(4), lib().jxg_last_kernel_ms(5)
+        eig_st = [lib().jxg_last_kernel_ms(i) for i in (6, 7, 8, 9)]
         model = pl.SpectralModel(s, ut64, x, y)
         del ut64
         torch.cuda.synchronize()
@@ -329,6 +332,13 @@ def main():
                 stage[key] = stage.get(key, 0.0) + val
             kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
             kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
+            kern["two_stage"] = two_stage
+            if two_stage:
+                kern["q2_ms"] = kern.get("q2_ms", 0.0) + q2_ms
+                kern["q2_gflop"] = kern.get("q2_gflop", 0.0) + q2_gflop
+                for name, v in zip(("eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform"), eig_st):
+                    stage[name] = stage.get(name, 0.0) + v * 1e-3
+                stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3
             kern["grm_ms"] += grm_ms
             kern["grm_flops"] += float(n) * (n + 1) * len(grows)
             kern["rot_ms"] += tm.t.get("rotate", 0.0) * 1e3
@@ -380,6 +390,31 @@ def main():
                                 pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
         mu_grm, mu_grm_src = pmc_mfma_util("grm_f16x2_kernel")
         mu_rot, mu_rot_src = pmc_mfma_util("rotate_f16x2_kernel")
+        F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: one 2048-flop block per 64 cycles per SIMD = the f64 vector rate
+        if kern.get("two_stage"):
+            # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
+            # reflectors (one launch per decomposition; profiles/r02*_kernel_stats.csv)
+            q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
+            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_kernel")
+            roofline_main = {"bound": "mfma", "kernel": "sbback_apply_kernel", "achieved": q2_tflops,
+                             "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
+                             "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
+                             "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "
+                                     "kernel issues (64 + 32) / 64 of them on the parallelogram blocks plus the T products; "
+                                     "duration = HIP start/stop events bound to the dispatch (hipExtLaunchKernelGGL) on the "
+                                     "launch stream; peak = f64 MFMA 78.6 TFLOP/s (public MI355X figure, = 64 cycles per "
+                                     "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE "
+                                     "(own pass) x2 gfx950 correction per launch from the committed summary of this shape"}
+        else:
+            # one-stage path (n < 13000): the dominant kernel is the symv of the tridiagonalisation, one launch per column
+            roofline_main = {"bound": "hbm", "kernel": "sytrd_symv_kernel",
+                             "achieved": symv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": symv_gbs / HBM_PEAK_GBS,
+                             "traffic": tr_symv, "traffic_source": tr_symv_src,
+                             "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
+                             "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per launch; "
+                                     "achieved = mean bytes / mean duration of the mid-panel launch of every 64-column panel "
+                                     "(HIP start/stop events bound to the dispatch, hipExtLaunchKernelGGL, on the launch "
+                                     "stream); traffic = rocprofv3 FETCH_SIZE (own pass) x2 gfx950 correction"}
         res = {
             "metric": "SNPs/sec full -lmm (GRM+eig+scan)" if args.mode == "lmm" else "SNPs/sec full -fvlmm (GRM+eig+scan)",
             "value": value,
@@ -391,23 +426,14 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64 eigendecomposition and REML; f16 MFMA with f32 accumulation and f64 merge for GRM / rotation "
-                     "(exact integer operands, or fp16 hi+lo split of the f32 operands)",
+            "dtype": "f64 (eigendecomposition on f64 MFMA, REML); f16 MFMA with f32 accumulation and f64 merge for GRM / "
+                     "rotation (exact integer operands, or fp16 hi+lo split of the f32 operands)",
             "data": "synthetic",
             "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
                        "parallelism": f"snp-shard x{world}" + (", eigh symv tiles sharded" if eigh_sharded else "")},
-            # the dominant kernel by time (43 % of the GPU time of a step: one launch per column of the
-            # tridiagonalisation, profiles/*_kernel_stats.csv)
-            "roofline": {"bound": "hbm", "kernel": "sytrd_symv_kernel",
-                         "achieved": symv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": symv_gbs / HBM_PEAK_GBS,
-                         "traffic": tr_symv, "traffic_source": tr_symv_src,
-                         "avg_launch_ms": kern.get("symv_ms", 0.0) / L,
-                         "note": "algorithmic bytes = lower triangle of the trailing matrix (4 nt^2 + 4 nt B) per launch; "
-                                 "achieved = mean bytes / mean duration of the mid-panel launch of every 64-column panel "
-                                 "(HIP start/stop events bound to the dispatch, hipExtLaunchKernelGGL, on the launch stream); traffic = rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
-                                 "correction, mean over all launches of a step"},
+            "roofline": roofline_main,
             "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
                                                         "missing call among the selected samples, else the fp16 hi/lo "
                                                         "three-product variant)",

@@ -39,7 +39,9 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
 // k_sbback.hip: C <- Q2 C (reflectors of the bulge chasing); k_ormtr.hip: C <- Q1 C (reflectors of the band reduction)
 size_t sbback_tq_doubles(int n, int ks);
 int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, int n, int ks, double *d_c, int ncols,
-                    double *d_tq);
+                    double *d_tq, hipEvent_t ev_start, hipEvent_t ev_stop);
+extern float g_last_ms[16];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
+                              // [8] divide and conquer ms, [9] Q1 back-transformation ms, [10] 1 = two-stage path taken
 int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
                     double *d_c);
 int sytrd_dist_active(int n);
@@ -119,6 +121,10 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         // JXGPU_EIGH_TRACE=1: synchronise and report after every stage (stderr), to locate a failing stage
         const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
         const auto t_begin = std::chrono::steady_clock::now();
+        static hipEvent_t ev[8] = {nullptr};
+        if (!ev[0])
+            for (int q = 0; q < 8; ++q) JX_HIP(hipEventCreate(&ev[q]));
+        JX_HIP(hipEventRecord(ev[0], st));
         auto stage_done = [&](const char *what) -> int {
             if (!trace) return 0;
             JX_HIP(hipStreamSynchronize(st));
@@ -161,6 +167,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             }
         }
         if (twostage) {
+            JX_HIP(hipEventRecord(ev[1], st));
             if (stage_done("sy2sb")) return 1;
             if (sb2st_chase(st, ts_ab.as<double>(), n, d_w, e.as<double>(), ts_v2.as<double>(), ts_tau2.as<double>(),
                             ts_ctrl.as<int>()))
@@ -169,6 +176,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             JX_HIP(hipMemcpyAsync(&habort, ts_ctrl.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
             if (habort != 0) return fail("jxg_eigh_f64: the bulge-chasing kernel gave up waiting for a neighbour sweep");
+            JX_HIP(hipEventRecord(ev[2], st));
             if (stage_done("sb2st")) return 1;
         } else {
             if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
@@ -195,11 +203,14 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             if (rs != rocblas_status_success)
                 return fail("rocsolver_dstedc failed with status " + std::to_string((int)rs));
         }
+        JX_HIP(hipEventRecord(ev[3], st));
         if (stage_done("dstedc")) return 1;
         if (twostage) {
             if (ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
-            if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, c.as<double>(), n, ts_tq.as<double>()))
+            if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, c.as<double>(), n, ts_tq.as<double>(),
+                                ev[6], ev[7]))
                 return 1;
+            JX_HIP(hipEventRecord(ev[4], st));
             if (stage_done("Q2 back-transformation")) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
             if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>())) return 1;
@@ -214,7 +225,24 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 if (ormtr_lower(h, st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
             }
         }
+        JX_HIP(hipEventRecord(ev[5], st));
         if (stage_done("dormtr")) return 1;
+        g_last_ms[10] = twostage ? 1.f : 0.f;
+        {
+            JX_HIP(hipEventSynchronize(ev[5]));
+            float ms = 0.f;
+            if (twostage) {
+                JX_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); g_last_ms[6] = ms;
+                JX_HIP(hipEventElapsedTime(&ms, ev[1], ev[2])); g_last_ms[7] = ms;
+                JX_HIP(hipEventElapsedTime(&ms, ev[2], ev[3])); g_last_ms[8] = ms;
+                JX_HIP(hipEventElapsedTime(&ms, ev[4], ev[5])); g_last_ms[9] = ms;
+                JX_HIP(hipEventElapsedTime(&ms, ev[6], ev[7])); g_last_ms[4] = ms;
+                // algorithmic flops of C <- Q2 C: 4 * (reflector length) * n per reflector, lengths ~ 64, n (n - 1) / 2 / 64 of them
+                double refl = 0.0;
+                for (int sidx = 0; sidx < n - 2; ++sidx) refl += (double)(n - 1 - sidx);
+                g_last_ms[5] = (float)(4.0 * refl * (double)n / 1e9);
+            }
+        }
         if (split) {
             DevBuf dperm;
             if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;

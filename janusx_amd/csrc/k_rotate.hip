@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_f32_kernel(const float *__res
 using namespace jx;
 
 namespace jx {
-extern float g_last_ms[4];
+extern float g_last_ms[16];
 extern int g_timer_pending[4];
 hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
 }  // namespace jx

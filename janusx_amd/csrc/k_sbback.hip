@@ -9,6 +9,7 @@
 // window slides down by SB rows per step (every row of the slab is read and written once per group).  Per block:
 //   W1 = V' Cwin,  W2 = T W1,  Cwin -= V W2      (all on v_mfma_f64_16x16x4_f64; V and T fragments straight from L2)
 // T comes from sbback_tfactor_kernel: T^-1 = striu(V'V) + diag(1 / tau).
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include "jx_common.h"
@@ -266,7 +267,7 @@ size_t sbback_tq_doubles(int n, int ks) { return (size_t)((n - 2 + QB_G - 1) / Q
 
 // C (n x ncols, ld = n) <- Q2 C.  d_tq: sbback_tq_doubles(n, ks) doubles of workspace.
 int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, int n, int ks, double *d_c, int ncols,
-                    double *d_tq) {
+                    double *d_tq, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n <= 2 || ncols <= 0) return 0;
     const int ngroups = (n - 2 + QB_G - 1) / QB_G;
     QbParams P{d_v2, d_tau2, d_tq, d_c, n, ks, ngroups, ncols, getenv("JXGPU_QB_SKIP") ? atoi(getenv("JXGPU_QB_SKIP")) : 0};
@@ -297,7 +298,7 @@ int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, in
                                        (int)lds));                                                                     \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL(sbback_apply_kernel<NWV>, grid, dim3(QB_T), lds, st, P);                                     \
+        hipExtLaunchKernelGGL(sbback_apply_kernel<NWV>, grid, dim3(QB_T), lds, st, ev_start, ev_stop, 0, P);            \
     } while (0)
     switch (nw) {
         case 1: JX_QB_LAUNCH(1); break;

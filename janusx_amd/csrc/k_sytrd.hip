@@ -688,7 +688,7 @@ struct SytrdDist {
 };
 static SytrdDist g_dist;
 
-extern float g_last_ms[4];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
+extern float g_last_ms[16];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
 
 // d_a: (n,n) column-major symmetric (lower referenced), overwritten with the LAPACK dsytrd(lower) result.
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau) {

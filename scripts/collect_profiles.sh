@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end profile collection on the GPU box (run from the repo root through gpurun):
+# Round-end profile collection on the GPU box (run from the repo root through gpurun; bench.py default = BASELINE configs[2]):
 #   kernel-trace stats, HBM traffic counters (FETCH_SIZE and WRITE_SIZE in their own passes), MFMA counters.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,6 +13,6 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python
 python3 scripts/pmc_summarize.py $O/write $O/write.json write > /dev/null; rm -rf $O/write
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_fv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --mode fvlmm > $O/fetch_fv.log 2>&1
 python3 scripts/pmc_summarize.py $O/fetch_fv $O/fetch_fv.json fetch_fv > /dev/null; rm -rf $O/fetch_fv
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/mfma.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/mfma.log 2>&1
 python3 scripts/pmc_summarize.py $O/mfma $O/mfma.json mfma > /dev/null; rm -rf $O/mfma
 ls -la $O $O/stats/*

@@ -1763,3 +1763,46 @@ def test_grm_accumulator_lower_tile_packing():
     lower = tile[:, None] >= tile[None, :]
     assert torch.equal(out[lower], (a + b)[lower])
     assert torch.equal(out[~lower], a[~lower])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["grm_like", "low_rank_ridge", "diagonal", "block_diagonal", "identity_plus_rank_one"])
+def test_eigh_two_stage_path_and_its_fallback(case, monkeypatch):
+    """The two-stage reduction (band reduction by CholeskyQR panels, bulge chasing, two back-transformations), forced at a
+    small size, on matrices that exercise its special cases: all-zero panels (diagonal input: every reflector is the
+    identity), exactly rank-deficient panels (block-diagonal / low-rank input: the panel factorisation raises its flag
+    and the driver falls back to the one-stage reduction on the saved copy) and a well-conditioned GRM-like matrix."""
+    import torch
+    from janusx_amd import pipeline
+    monkeypatch.setenv("JXGPU_EIGH", "twostage")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    n = 700
+    if case == "grm_like":
+        z = torch.randn((n, 2 * n), generator=g, device=dev, dtype=torch.float64)
+        k = z @ z.T / (2 * n)
+    elif case == "low_rank_ridge":
+        z = torch.randn((n, 40), generator=g, device=dev, dtype=torch.float64)
+        k = z @ z.T / 40
+    elif case == "diagonal":
+        k = torch.diag(torch.rand(n, generator=g, device=dev, dtype=torch.float64) + 0.1)
+    elif case == "block_diagonal":
+        k = torch.zeros((n, n), device=dev, dtype=torch.float64)
+        for b0 in range(0, n, 7):                       # families of 7, as a thresholded sparse GRM looks
+            b1 = min(n, b0 + 7)
+            z = torch.randn((b1 - b0, 20), generator=g, device=dev, dtype=torch.float64)
+            k[b0:b1, b0:b1] = z @ z.T / 20
+    else:
+        u = torch.randn((n, 1), generator=g, device=dev, dtype=torch.float64)
+        k = torch.eye(n, device=dev, dtype=torch.float64) + u @ u.T
+    k = 0.5 * (k + k.T)
+    s, ut = pipeline.eigh_from_grm(k, 1e-6)
+    kk = k.clone()
+    kk.diagonal().add_(1e-6)
+    smax = float(s.abs().max())
+    assert bool((s[1:] >= s[:-1]).all())
+    assert float((ut @ kk - s[:, None] * ut).abs().max()) < 1e-11 * smax
+    assert float((ut @ ut.T - torch.eye(n, device=dev, dtype=torch.float64)).abs().max()) < 1e-11
+    ref = torch.linalg.eigvalsh(kk)
+    assert float((s - ref).abs().max()) < 1e-11 * smax

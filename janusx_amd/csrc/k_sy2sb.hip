@@ -519,74 +519,118 @@ __global__ __launch_bounds__(256) void sb_extract_band_kernel(const double *__re
     ab[e] = v;
 }
 
-size_t sy2sb_work_doubles(int n) { return (size_t)n * 4 * SB + 8 * SB * SB + 2 * SB * 2 * SB + 64; }
+size_t sy2sb_work_doubles(int n) { return (size_t)n * 8 * SB + 12 * SB * SB + 64; }
 int sy2sb_bandwidth() { return SB; }
 
 // d_a (n x n, column-major, symmetric, lower referenced) -> band form in place (V below the band, see above);
 // d_tau (n): tau of every stage-1 reflector (0 beyond the last eliminated column); d_ab (ldab x n): band copy for
 // stage 2.  d_flags[0] != 0 on return (after the caller's synchronisation) means a panel could not be factored.
+//
+// Look-ahead: the trailing update of panel p is split into the block column of panel p + 1 (a narrow GEMM) and the
+// rest; the factorisation chain of panel p + 1 (~15 small launches, latency-bound) then runs on a side stream beside the
+// rest of the update, which is what fills the chip.  Panel buffers, T and the zero-panel flag alternate by panel parity.
 int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work,
                 int *d_flags) {
     const int ncol = n - SB - 1;                     // columns with entries below the band
     JX_HIP(hipMemsetAsync(d_tau, 0, sizeof(double) * (size_t)n, st));
     JX_HIP(hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
     if (ncol > 0) {
-        double *pan = d_work;                        // (n, 4 SB), ld = n: [Z | V | W | V]
-        double *p = d_work + (size_t)n * 4 * SB;
-        double *g = p; p += SB * SB;                 // Gram / N1 (column-major, ld = SB)
-        double *rmat = p; p += SB * SB;              // current R (row-major)
-        double *umat = p; p += SB * SB;
+        double *pan[2] = {d_work, d_work + (size_t)n * 4 * SB};     // (n, 4 SB) each, ld = n: [Z | V | W | V]
+        double *p = d_work + (size_t)n * 8 * SB;
+        double *gq = p; p += SB * SB;                // Gram matrices of the factorisation chain (column-major, ld = SB)
+        double *gu = p; p += SB * SB;                // N1 = V'Z of the update chain
+        double *rmat = p; p += SB * SB;              // R^-1 of the current pass (column-major)
+        double *umat = p; p += SB * SB;              // R3^-1 U^-1
         double *rtot = p; p += SB * SB;
-        double *tmat = p; p += SB * SB;              // T of the current panel (column-major)
+        double *tmat[2];
+        tmat[0] = p; p += SB * SB;                   // T of the panel (column-major), by parity
+        tmat[1] = p; p += SB * SB;
         double *tm = p; p += 2 * SB * SB;            // [T; -M/2]
         double *tmp1 = p; p += SB * SB;
         double *tmp2 = p; p += SB * SB;
-        JX_HIP(hipMemsetAsync(pan, 0, sizeof(double) * (size_t)n * 4 * SB, st));
+        JX_HIP(hipMemsetAsync(d_work, 0, sizeof(double) * (size_t)n * 8 * SB, st));
         const int64_t ld = n;
         const double eps = 2.220446049250313e-16;
-        for (int j0 = 0; j0 < ncol; j0 += SB) {
+        static hipStream_t side = nullptr;
+        static hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_qr[2] = {nullptr, nullptr};
+        static const bool lookahead = !(getenv("JXGPU_SY2SB_LOOKAHEAD") && atoi(getenv("JXGPU_SY2SB_LOOKAHEAD")) == 0);
+        if (!side) {
+            JX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            for (int q = 0; q < 2; ++q) {
+                JX_HIP(hipEventCreateWithFlags(&ev_a[q], hipEventDisableTiming));
+                JX_HIP(hipEventCreateWithFlags(&ev_qr[q], hipEventDisableTiming));
+            }
+        }
+        // factorisation chain of the panel at column j0 on stream s
+        auto panel_qr = [&](hipStream_t s, int j0, int par) -> int {
             const int pw = (ncol - j0 < SB) ? (ncol - j0) : SB;
             const int nt = n - j0 - SB;
-            double *pp = d_a + (j0 + SB) + (int64_t)j0 * ld;          // panel
-            double *a22 = d_a + (j0 + SB) + (int64_t)(j0 + SB) * ld;  // trailing matrix
-            double *zc = pan, *v1 = pan + (size_t)SB * ld, *wc = pan + (size_t)2 * SB * ld, *v2 = pan + (size_t)3 * SB * ld;
-            int *pz = d_flags + 2;
+            double *pp = d_a + (j0 + SB) + (int64_t)j0 * ld;
+            double *v1 = pan[par] + (size_t)SB * ld, *v2 = pan[par] + (size_t)3 * SB * ld;
+            int *pz = d_flags + 2 + par;
             // CholeskyQR passes 1 and 2: G = P'P, R = chol(G), P <- P R^-1 (in place: a workgroup of the product reads only
             // the rows it writes, and all of them before its epilogue)
             for (int pass = 0; pass < 2; ++pass) {
-                if (dgemm(st, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, g, SB, 0)) return 1;
+                if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0)) return 1;
                 const double shift = (pass == 0) ? 11.0 * ((double)nt * pw + (double)pw * (pw + 1)) * eps : 0.0;
-                hipLaunchKernelGGL(sb_chol_kernel, dim3(1), dim3(256), 0, st, g, pw, shift, pass == 0 ? 1 : 0, rmat, rtot,
+                hipLaunchKernelGGL(sb_chol_kernel, dim3(1), dim3(256), 0, s, gq, pw, shift, pass == 0 ? 1 : 0, rmat, rtot,
                                    d_flags, pz);
                 JX_LAUNCH_CHECK();
-                if (dgemm(st, false, false, nt, pw, pw, 1.0, pp, ld, rmat, SB, 0.0, pp, ld, 1)) return 1;
+                if (dgemm(s, false, false, nt, pw, pw, 1.0, pp, ld, rmat, SB, 0.0, pp, ld, 1)) return 1;
             }
             // pass 3 + reconstruction
-            if (dgemm(st, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, g, SB, 0)) return 1;
-            hipLaunchKernelGGL(sb_recon_kernel, dim3(1), dim3(256), 0, st, g, pw, pp, ld, rmat, umat, rtot, tmat,
+            if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0)) return 1;
+            hipLaunchKernelGGL(sb_recon_kernel, dim3(1), dim3(256), 0, s, gq, pw, pp, ld, rmat, umat, rtot, tmat[par],
                                d_tau + j0, v1, v2, ld, d_flags, pz, 8.0 * eps * sqrt((double)nt));
             JX_LAUNCH_CHECK();
             if (nt > pw) {
-                if (dgemm(st, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1)) return 1;
-                hipLaunchKernelGGL(sb_copy_v_kernel, dim3(ceil_div(nt - pw, 256), SB), dim3(256), 0, st, v1, v2, ld, pp, ld,
+                if (dgemm(s, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1)) return 1;
+                hipLaunchKernelGGL(sb_copy_v_kernel, dim3(ceil_div(nt - pw, 256), SB), dim3(256), 0, s, v1, v2, ld, pp, ld,
                                    pw, nt - pw, pw);
                 JX_LAUNCH_CHECK();
             }
+            return 0;
+        };
+        if (panel_qr(st, 0, 0)) return 1;
+        int par = 0;
+        for (int j0 = 0; j0 < ncol; j0 += SB, par ^= 1) {
+            const int pw = (ncol - j0 < SB) ? (ncol - j0) : SB;
+            const int nt = n - j0 - SB;
+            double *a22 = d_a + (j0 + SB) + (int64_t)(j0 + SB) * ld;  // trailing matrix
+            double *zc = pan[par], *v1 = pan[par] + (size_t)SB * ld, *wc = pan[par] + (size_t)2 * SB * ld;
+            const bool has_next = j0 + SB < ncol;
+            if (j0 > 0 && lookahead) JX_HIP(hipStreamWaitEvent(st, ev_qr[par], 0));     // this panel's chain ran on the side stream
             if (pw < SB) {
                 // last, narrower panel: the columns j0 + pw .. j0 + SB - 1 of the block row see Q' from the left only
                 const int nc = SB - pw;
                 double *cb = d_a + (j0 + SB) + (int64_t)(j0 + pw) * ld;
                 if (dgemm(st, true, false, pw, nc, nt, 1.0, v1, ld, cb, ld, 0.0, tmp1, SB, 1)) return 1;
-                if (dgemm(st, true, false, pw, nc, pw, 1.0, tmat, SB, tmp1, SB, 0.0, tmp2, SB, 1)) return 1;
+                if (dgemm(st, true, false, pw, nc, pw, 1.0, tmat[par], SB, tmp1, SB, 0.0, tmp2, SB, 1)) return 1;
                 if (dgemm(st, false, false, nt, nc, pw, -1.0, v1, ld, tmp2, SB, 1.0, cb, ld, 1)) return 1;
             }
             // two-sided update of the trailing matrix
             if (dsymm_lower(st, nt, pw, 1.0, a22, ld, v1, ld, 0.0, zc, ld)) return 1;
-            if (dgemm(st, true, false, pw, pw, nt, 1.0, v1, ld, zc, ld, 0.0, g, SB, 0)) return 1;
-            hipLaunchKernelGGL(sb_tm_kernel, dim3(1), dim3(256), 0, st, tmat, g, pw, tm);
+            if (dgemm(st, true, false, pw, pw, nt, 1.0, v1, ld, zc, ld, 0.0, gu, SB, 0)) return 1;
+            hipLaunchKernelGGL(sb_tm_kernel, dim3(1), dim3(256), 0, st, tmat[par], gu, pw, tm);
             JX_LAUNCH_CHECK();
             if (dgemm(st, false, false, nt, pw, 2 * SB, 1.0, zc, ld, tm, 2 * SB, 0.0, wc, ld, 1)) return 1;
-            if (dsyr2k_lower_nt(st, nt, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld)) return 1;
+            if (has_next) {
+                // block column of the next panel first: A22[:, 0:SB] -= [V | W] ([W | V][0:SB, :])'
+                const int nb = SB;                                      // has_next => nt > SB
+                if (dgemm(st, false, true, nt, nb, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld, 1)) return 1;
+                if (lookahead) {
+                    JX_HIP(hipEventRecord(ev_a[par], st));
+                    JX_HIP(hipStreamWaitEvent(side, ev_a[par], 0));
+                    if (panel_qr(side, j0 + SB, par ^ 1)) return 1;
+                    JX_HIP(hipEventRecord(ev_qr[par ^ 1], side));
+                }
+                // the rest of the trailing update runs beside that chain
+                if (dsyr2k_lower_nt(st, nt - nb, 2 * SB, -1.0, v1 + nb, ld, wc + nb, ld, 1.0, a22 + nb + (int64_t)nb * ld, ld))
+                    return 1;
+                if (!lookahead && panel_qr(st, j0 + SB, par ^ 1)) return 1;
+            } else {
+                if (dsyr2k_lower_nt(st, nt, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld)) return 1;
+            }
         }
     }
     hipLaunchKernelGGL(sb_extract_band_kernel, dim3((unsigned)(((int64_t)n * ldab + 255) / 256)), dim3(256), 0, st, d_a, n,

@@ -137,7 +137,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         // on: its O(n^3) work is f64-MFMA products instead of one HBM-bound symv per column.  JXGPU_EIGH=onestage keeps
         // the one-stage form; it is also the fallback when a panel of the band reduction cannot be factored, and the
         // form the rank-sharded tridiagonalisation (jxg_eigh_set_dist) uses.
-        static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : 13000;
+        static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : 10000;
         bool twostage = n >= ts_min && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
                         !sytrd_dist_active(n);
         if (mode && strcmp(mode, "twostage") == 0 && n > 2 * sy2sb_bandwidth() + 2) twostage = true;

@@ -61,7 +61,9 @@ int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, cons
 int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
                     double *d_c) {
     if (n < 2 || nref < 1) return 0;
-    const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB")) : OT_NB;
+    // wider blocks for large n (measured at n = 20000: 512 -> 378 ms, 1024 -> 315, 2048 -> 281, 4096 -> 327)
+    const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB"))
+                                                                                    : (n >= 12000 ? 2 * OT_NB : OT_NB);
     ScratchLease ws;   // vc (n x nb) | mm (nb x nb) | w (nb x n)
     const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * n;
     if (ws.take(3, sizeof(double) * (nvc + nmm + nw))) return 1;

@@ -417,6 +417,15 @@ int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n_samples, c
                         const double *y_train, const double *x_cov, int p_cov, int trace_samples, uint64_t seed,
                         int exact_trace, double m_scale, double *out5);
 
+/* F2. Association TSV writer (host): replaces `append_assoc_block_from_arrays` / `append_assoc_row_from_fields` and the
+ * writer thread behind them (src/io/assoc2tsv.rs:430-548, 604; src/stats/common.rs:374).  Row i = prefix i (the bytes
+ * prefix_blob[prefix_off[i] .. prefix_off[i+1]) = `chrom\tpos\tsnp\tallele0\tallele1`) + af, miss, beta, se as `{:.4}`,
+ * chisq = (beta/se)^2 and p as `{:.4e}` (Rust float text: unpadded exponent, `NaN`, `inf`; invalid beta / se -> chisq NaN,
+ * p = 1, src/math/linalg.rs:111-121) [+ plrt | lambda, ml `{:.6e}`, plrt].  stats (rows, ncol) f64, ncol in {3, 4, 6}.
+ * Returns the number of rows written, -1 on error (jx_last_error). */
+int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
+                           const float *af, const float *miss, const double *stats, int ncol);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 // HBM and drive the device layer; per-SNP statistics / filter logic (integer counts -> f32/f64 decisions) is
 // done on the host exactly as the reference writes it, so the kept-SNP set is bit-exact.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 
@@ -737,4 +738,105 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         JX_HIP(hipMemcpy(out + (size_t)r0 * cols, dout.p, sizeof(double) * (size_t)rows * cols, hipMemcpyDeviceToHost));
     }
     return 0;
+}
+
+
+// ---- association TSV writer (host) ------------------------------------------------------------------------------------
+// Native counterpart of the reference's row formatter + writer (src/io/assoc2tsv.rs:430-548, `AsyncTsvWriter`
+// src/stats/common.rs:374): the numeric columns of every row are formatted here with Rust's float text (`{:.4}`,
+// `{:.4e}` / `{:.6e}` with an unpadded exponent, `NaN`, `inf`), the per-row prefix `chrom\tpos\tsnp\tallele0\tallele1`
+// comes from the caller as one byte blob with offsets.  stats: (rows, ncol) f64, ncol = 3 [beta, se, p], 4 [.., plrt] or
+// 6 [beta, se, p, lambda, ml, plrt].  Writes `path` directly (the caller renames a temp file).
+namespace {
+inline char *put_str(char *o, const char *t) {
+    while (*t) *o++ = *t++;
+    return o;
+}
+inline char *put_fixed4(char *o, double v) {
+    if (v != v) return put_str(o, "NaN");
+    if (std::isinf(v)) return put_str(o, v > 0 ? "inf" : "-inf");
+    return o + snprintf(o, 64, "%.4f", v);
+}
+inline char *put_exp(char *o, double v, int prec) {
+    if (v != v) return put_str(o, "NaN");
+    if (std::isinf(v)) return put_str(o, v > 0 ? "inf" : "-inf");
+    char tmp[64];
+    const int len = snprintf(tmp, sizeof(tmp), "%.*e", prec, v);
+    int epos = len - 1;
+    while (epos > 0 && tmp[epos] != 'e') --epos;
+    memcpy(o, tmp, (size_t)epos + 1);          // mantissa and 'e'
+    o += epos + 1;
+    const char *x = tmp + epos + 1;
+    if (*x == '-') *o++ = '-';
+    if (*x == '-' || *x == '+') ++x;
+    while (*x == '0' && x[1] != 0) ++x;        // Rust prints the exponent without padding: e-3, e0, e12
+    return put_str(o, x);
+}
+}  // namespace
+
+extern "C" int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
+                                      const float *af, const float *miss, const double *stats, int ncol) {
+    if (ncol != 3 && ncol != 4 && ncol != 6) {
+        fail("unsupported GWAS result column count: " + std::to_string(ncol) + " (expected 3, 4, or 6)");
+        return -1;
+    }
+    FILE *fh = fopen(path, "wb");
+    if (!fh) {
+        fail(std::string("cannot open ") + path + " for writing");
+        return -1;
+    }
+    static const char *h3 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\n";
+    static const char *h4 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tplrt\n";
+    static const char *h6 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tlambda\tml\tplrt\n";
+    fputs(ncol == 6 ? h6 : (ncol == 4 ? h4 : h3), fh);
+    std::vector<char> buf((size_t)1 << 20);
+    size_t used = 0;
+    const double min_pos = 2.2250738585072014e-308;
+    for (int64_t i = 0; i < rows; ++i) {
+        const int64_t plen = prefix_off[i + 1] - prefix_off[i];
+        if (used + (size_t)plen + 512 > buf.size()) {
+            if (fwrite(buf.data(), 1, used, fh) != used) {
+                fclose(fh);
+                fail(std::string("write to ") + path + " failed");
+                return -1;
+            }
+            used = 0;
+            if ((size_t)plen + 512 > buf.size()) buf.resize((size_t)plen + 1024);
+        }
+        char *o = buf.data() + used;
+        memcpy(o, prefix_blob + prefix_off[i], (size_t)plen);
+        o += plen;
+        const double *r = stats + i * ncol;
+        const double beta = r[0], se = r[1], p = r[2];
+        double chisq, pv;
+        if (std::isfinite(beta) && std::isfinite(se) && se > 0.0) {      // sanitize_assoc_pvalue, src/math/linalg.rs:111-121
+            const double z = beta / se;
+            chisq = z * z;
+            pv = std::isfinite(p) ? std::min(std::max(p, min_pos), 1.0) : 1.0;
+        } else {
+            chisq = NAN;
+            pv = 1.0;
+        }
+        *o++ = '\t'; o = put_fixed4(o, (double)af[i]);
+        *o++ = '\t'; o = put_fixed4(o, (double)miss[i]);
+        *o++ = '\t'; o = put_fixed4(o, beta);
+        *o++ = '\t'; o = put_fixed4(o, se);
+        *o++ = '\t'; o = put_exp(o, chisq, 4);
+        *o++ = '\t'; o = put_exp(o, pv, 4);
+        if (ncol == 6) {
+            *o++ = '\t'; o = put_exp(o, r[3], 6);
+            *o++ = '\t'; o = put_exp(o, r[4], 6);
+            *o++ = '\t'; o = put_exp(o, r[5], 4);
+        } else if (ncol == 4) {
+            *o++ = '\t'; o = put_exp(o, r[3], 4);
+        }
+        *o++ = '\n';
+        used = (size_t)(o - buf.data());
+    }
+    const bool ok = fwrite(buf.data(), 1, used, fh) == used;
+    if (fclose(fh) != 0 || !ok) {
+        fail(std::string("write to ") + path + " failed");
+        return -1;
+    }
+    return rows;
 }

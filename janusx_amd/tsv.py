@@ -64,9 +64,8 @@ def format_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p, plrt=None, lmm2=N
     return row + "\n"
 
 
-def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
-    """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
-    Returns rows written."""
+def write_assoc_tsv_python(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
+    """Pure-Python statement of the row format (kept as the checker of the native writer in the CPU tests)."""
     ncol = stats.shape[1]
     tmp = f"{path}.tmp.{os.getpid()}"
     with open(tmp, "w") as fh:
@@ -84,3 +83,36 @@ def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
         fh.write("".join(buf))
     os.replace(tmp, path)
     return int(stats.shape[0])
+
+
+def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
+    """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
+    The numeric columns are formatted and written by the native writer (`jx_assoc_tsv_write`, the counterpart of the
+    reference's Rust formatter, src/io/assoc2tsv.rs:430-548); only the per-row `chrom pos snp a0 a1` prefix is put
+    together here.  Returns rows written."""
+    import numpy as np
+    from ._lib import lib
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    if stats.ndim != 2 or stats.shape[1] not in (3, 4, 6):
+        raise RuntimeError(f"unsupported GWAS result column count: {stats.shape[1] if stats.ndim == 2 else stats.shape} "
+                           "(expected 3, 4, or 6)")
+    rows = int(stats.shape[0])
+    prefixes = [f"{chrom[i]}\t{pos[i]}\t{resolve_snp_name(snp[i], chrom[i], pos[i])}\t{a0[i]}\t{a1[i]}".encode()
+                for i in range(rows)]
+    off = np.zeros(rows + 1, dtype=np.int64)
+    if rows:
+        np.cumsum([len(p) for p in prefixes], out=off[1:])
+    blob = b"".join(prefixes)
+    af32 = np.ascontiguousarray(af, dtype=np.float32)
+    miss32 = np.ascontiguousarray(miss, dtype=np.float32)
+    if af32.shape[0] < rows or miss32.shape[0] < rows:
+        raise RuntimeError("af / miss shorter than the result table")
+    tmp = f"{path}.tmp.{os.getpid()}"
+    import ctypes as C
+    written = lib().jx_assoc_tsv_write(tmp.encode(), C.cast(C.c_char_p(blob), C.c_void_p), off.ctypes.data, rows,
+                                       af32.ctypes.data, miss32.ctypes.data, stats.ctypes.data, int(stats.shape[1]))
+    if written < 0:
+        msg = lib().jx_last_error()
+        raise RuntimeError(msg.decode("utf-8", "replace") if msg else "jx_assoc_tsv_write failed")
+    os.replace(tmp, path)
+    return int(written)

@@ -202,3 +202,38 @@ def test_eigh_launch_geometry_beyond_65535_rows():
     h = _lib.lib()
     for n in (300, 46341, 65536, 70000, 150000):
         assert h.jxg_eigh_grid_check(n) == 1, n
+
+
+def test_native_tsv_writer_matches_the_row_format(tmp_path):
+    """`jx_assoc_tsv_write` (native formatter + writer, src/io/assoc2tsv.rs:430-548) against the pure-Python statement of
+    the same row format, on values that hit every branch: NaN rows, zero / negative-zero, p = 0 (clamped to the smallest
+    positive double), p = inf (-> 1), infinite beta (-> chisq NaN, p 1), `.` SNP names, 3 / 4 / 6 column tables."""
+    from janusx_amd import tsv
+    rng = np.random.default_rng(0)
+    n = 3000
+    stats = np.empty((n, 6))
+    stats[:, 0] = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)
+    stats[:, 1] = np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-6, 3, n)
+    stats[:, 2] = 10.0 ** (-rng.random(n) * 320)
+    stats[:, 3] = rng.random(n) * 1e3
+    stats[:, 4] = -rng.random(n) * 1e4
+    stats[:, 5] = rng.random(n)
+    stats[5] = [np.nan, np.nan, 1.0, np.nan, np.nan, 1.0]
+    stats[6, 0] = 0.0
+    stats[7, 1] = 0.0
+    stats[8, 2] = 0.0
+    stats[9, 0] = -0.0
+    stats[10, 2] = np.inf
+    stats[11, 0] = np.inf
+    chrom = [str(1 + i % 22) for i in range(n)]
+    pos = list(range(n))
+    snp = ["." if i % 7 == 0 else ("" if i % 11 == 0 else f"rs{i}") for i in range(n)]
+    af = rng.random(n).astype(np.float32)
+    miss = (rng.random(n) * 0.05).astype(np.float32)
+    for nc in (3, 4, 6):
+        a, b = str(tmp_path / f"a{nc}.tsv"), str(tmp_path / f"b{nc}.tsv")
+        assert tsv.write_assoc_tsv(a, chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss, stats[:, :nc]) == n
+        assert tsv.write_assoc_tsv_python(b, chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss, stats[:, :nc]) == n
+        assert open(a).read() == open(b).read()
+    with pytest.raises(RuntimeError, match="column count"):
+        tsv.write_assoc_tsv(str(tmp_path / "c.tsv"), chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss, stats[:, :5])

@@ -168,20 +168,24 @@ def _pmc_files(kind):
 
 
 def pmc_traffic_bytes(kernel_prefix, run="fetch"):
-    """(HBM bytes per launch, source file) of a kernel from a committed PMC summary of THIS shape (rocprofv3 --pmc
-    FETCH_SIZE in its own pass; KB units; x2 gfx950 correction of MI355X_MICROARCH.md for wide streaming reads).
-    (None, None) when no summary of the running shape is committed."""
+    """(HBM bytes per launch, source file) of a kernel from a committed PMC summary of THIS shape: rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE, each in its own pass, KB units; reads x2 (the gfx950 correction of MI355X_MICROARCH.md
+    for wide streaming reads) + writes as reported.  (None, None) when no summary of the running shape is committed."""
     for src, d in _pmc_files("hbm_traffic"):
-        runs = d.get("runs", {}).get(run)
-        if not runs:
+        runs = d.get("runs", {})
+        rd = runs.get(run)
+        if not rd:
             continue
-        best = None
-        for name, rec in runs.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
+        best, best_name = None, None
+        for name, rec in rd.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
             if kernel_prefix in name:
                 b = 2.0 * rec["mean_KB"] * 1024.0
                 if best is None or b > best:
-                    best = b
+                    best, best_name = b, name
         if best is not None:
+            wr = runs.get("write", {}).get(best_name) if run == "fetch" else None
+            if wr:
+                best += wr["mean_KB"] * 1024.0
             return best, src
     return None, None
 
@@ -396,15 +400,19 @@ def main():
             # reflectors (one launch per decomposition; profiles/r02*_kernel_stats.csv)
             q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
             tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_kernel")
+            mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_kernel")
             roofline_main = {"bound": "mfma", "kernel": "sbback_apply_kernel", "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
                              "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
+                             "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
                              "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "
                                      "kernel issues (64 + 32) / 64 of them on the parallelogram blocks plus the T products; "
                                      "duration = HIP start/stop events bound to the dispatch (hipExtLaunchKernelGGL) on the "
                                      "launch stream; peak = f64 MFMA 78.6 TFLOP/s (public MI355X figure, = 64 cycles per "
-                                     "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE "
-                                     "(own pass) x2 gfx950 correction per launch from the committed summary of this shape"}
+                                     "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE x2 "
+                                     "(gfx950 correction) + WRITE_SIZE, each in its own pass, per launch, from the committed "
+                                     "summary of this shape (algorithmic: every row of C read and written once per group of "
+                                     "32 sweeps = 8 n^3 / 32 B); mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}
         else:
             # one-stage path (n < 10000): the dominant kernel is the symv of the tridiagonalisation, one launch per column
             roofline_main = {"bound": "hbm", "kernel": "sytrd_symv_kernel",

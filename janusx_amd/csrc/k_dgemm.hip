@@ -1,6 +1,7 @@
 // f64 GEMM family on the matrix pipes (v_mfma_f64_16x16x4_f64) for the eigensolver behind src/math/eigh.rs:1422-1528
 // (the reference calls LAPACK dsyevd; every O(n^3) stage of the two-stage reduction here is one of these products):
-//   dgemm      C = alpha op(A) op(B) + beta C          (NN / TN / NT / TT, optional split over K with f64 atomics)
+//   dgemm      C = alpha op(A) op(B) + beta C          (NN / TN / NT / TT, optional split over K: per-slice partial
+//              products summed in a fixed order by a second kernel, bit-reproducible)
 //   dsymm_l    C = alpha A B + beta C, A symmetric with only its LOWER triangle stored (band reduction: Z = A22 V)
 //   dsyr2k_l   lower tiles of C += alpha (A B' ...) as one NT product over concatenated panels (trailing update)
 // All matrices are column-major.  One workgroup = 512 threads = 4 x 2 waves on a BM x BN tile, K in steps of 16 through a
@@ -32,7 +33,9 @@ struct DgemmArgs {
     int ta, tb;        // operand stored transposed
     int symm_a;        // A is m x m symmetric, lower triangle stored (k == m, ta ignored)
     int lower_tiles;   // grid enumerates the tiles (ti >= tj) of a square C only (BM == BN)
-    int ksplit;        // > 1: blockIdx.z owns a K range, results added with f64 atomics (beta must already be applied)
+    int ksplit;        // > 1: blockIdx.z owns a K range and writes its partial product to ws[z] (m x n, ld = m); a second
+                       // kernel sums the slices in a fixed order (bit-reproducible, unlike f64 atomics)
+    double *ws;
 };
 
 template <int BX>
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
         const int per = (ktiles + g.ksplit - 1) / g.ksplit;
         kbeg = (int)blockIdx.z * per * DG_BK;
         kend = min(g.k, kbeg + per * DG_BK);
-        if (kbeg >= kend) return;
+        if (kbeg > kend) kbeg = kend;                 // an empty slice still writes its zeros
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave & 3) * WM, wn = (wave >> 2) * WN;
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
         buf ^= 1;
     }
     // epilogue: acc[j][i][r] = C[m0 + wm + 16 i + lx][n0 + wn + 16 j + lk + 4 r]
-    const bool atomic = g.ksplit > 1;
+    const bool split = g.ksplit > 1;
+    double *slice = split ? g.ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -199,10 +203,13 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
                 const int row = m0 + wm + 16 * i + lx;
                 if (row >= g.m) continue;
                 if (g.lower_tiles && row < col) continue;     // diagonal tiles: the strict upper part is not referenced
-                double *cp = g.c + row + (int64_t)col * g.ldc;
                 const double v = g.alpha * acc[j][i][r];
-                if (atomic) unsafeAtomicAdd(cp, v);
-                else *cp = (g.beta == 0.0) ? v : (v + g.beta * *cp);
+                if (split) {
+                    slice[row + (int64_t)col * g.m] = v;
+                } else {
+                    double *cp = g.c + row + (int64_t)col * g.ldc;
+                    *cp = (g.beta == 0.0) ? v : (v + g.beta * *cp);
+                }
             }
         }
 }
@@ -220,7 +227,17 @@ static int dg_launch(const DgemmArgs &g, dim3 grid, hipStream_t st) {
     return 0;
 }
 
-// beta C for the split-K form (the partial products are added atomically afterwards)
+// C = beta C + sum_z ws[z] (slices in index order: bit-reproducible)
+__global__ void dg_reduce_kernel(double *c, int64_t ldc, int m, int n, double beta, const double *ws, int ksplit) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)m * n) return;
+    const int r = (int)(i % m), col = (int)(i / m);
+    double acc = 0.0;
+    for (int z = 0; z < ksplit; ++z) acc += ws[(int64_t)z * m * n + i];
+    double *p = c + r + (int64_t)col * ldc;
+    *p = (beta == 0.0) ? acc : (acc + beta * *p);
+}
+
 __global__ void dg_scale_kernel(double *c, int64_t ldc, int m, int n, double beta) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)m * n) return;
@@ -229,11 +246,25 @@ __global__ void dg_scale_kernel(double *c, int64_t ldc, int m, int n, double bet
     *p = (beta == 0.0) ? 0.0 : beta * *p;
 }
 
-// C (m x n) = alpha op(A) op(B) + beta C.  ksplit <= 0: chosen so that the launch fills the chip.
+static int dg_fit_split(int ksplit, int m, int n, size_t ws_doubles) {
+    const size_t per = (size_t)m * (size_t)n;
+    if (ksplit > 1 && per * (size_t)ksplit > ws_doubles) ksplit = (int)(ws_doubles / per);
+    return ksplit < 2 ? 1 : ksplit;
+}
+
+static int dg_reduce(hipStream_t st, const DgemmArgs &g) {
+    hipLaunchKernelGGL(dg_reduce_kernel, dim3((unsigned)(((int64_t)g.m * g.n + 255) / 256)), dim3(256), 0, st, g.c, g.ldc,
+                       g.m, g.n, g.beta, g.ws, g.ksplit);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// C (m x n) = alpha op(A) op(B) + beta C.  ksplit <= 0: chosen so that the launch fills the chip; a split over K needs
+// `ws` (ksplit m n doubles; the split is reduced to what fits, 1 without a workspace).
 int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, const double *a, int64_t lda,
-          const double *b, int64_t ldb, double beta, double *c, int64_t ldc, int ksplit) {
+          const double *b, int64_t ldb, double beta, double *c, int64_t ldc, int ksplit, double *ws, size_t ws_doubles) {
     if (m <= 0 || n <= 0) return 0;
-    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, k, alpha, beta, ta ? 1 : 0, tb ? 1 : 0, 0, 0, 1};
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, k, alpha, beta, ta ? 1 : 0, tb ? 1 : 0, 0, 0, 1, ws};
     if (k <= 0) {
         hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
         JX_LAUNCH_CHECK();
@@ -253,22 +284,21 @@ int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, c
             if (ksplit < 1) ksplit = 1;
         }
     }
-    g.ksplit = ksplit;
-    if (ksplit > 1) {
-        hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
-        JX_LAUNCH_CHECK();
-    }
-    dim3 grid(tm, tn, ksplit);
-    if (bm == 128 && bn == 128) return dg_launch<128, 128>(g, grid, st);
-    if (bm == 128) return dg_launch<128, 64>(g, grid, st);
-    return dg_launch<64, 64>(g, grid, st);
+    g.ksplit = dg_fit_split(ksplit, m, n, ws ? ws_doubles : 0);
+    dim3 grid(tm, tn, g.ksplit);
+    int rc;
+    if (bm == 128 && bn == 128) rc = dg_launch<128, 128>(g, grid, st);
+    else if (bm == 128) rc = dg_launch<128, 64>(g, grid, st);
+    else rc = dg_launch<64, 64>(g, grid, st);
+    if (rc) return rc;
+    return g.ksplit > 1 ? dg_reduce(st, g) : 0;
 }
 
 // C (m x n) = alpha A B + beta C with A (m x m) symmetric, lower triangle stored
 int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
-                double beta, double *c, int64_t ldc) {
+                double beta, double *c, int64_t ldc, double *ws, size_t ws_doubles) {
     if (m <= 0 || n <= 0) return 0;
-    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, m, alpha, beta, 0, 0, 1, 0, 1};
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, n, m, alpha, beta, 0, 0, 1, 0, 1, ws};
     const bool wide = n > 64;
     const int bn = wide ? 128 : 64;
     const int tm = ceil_div(m, 128), tn = ceil_div(n, bn);
@@ -279,13 +309,11 @@ int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int
         const int maxsplit = ceil_div(m, DG_BK) / 8 > 0 ? ceil_div(m, DG_BK) / 8 : 1;
         if (ksplit > maxsplit) ksplit = maxsplit;
     }
-    g.ksplit = ksplit;
-    if (ksplit > 1) {
-        hipLaunchKernelGGL(dg_scale_kernel, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, st, c, ldc, m, n, beta);
-        JX_LAUNCH_CHECK();
-    }
-    dim3 grid(tm, tn, ksplit);
-    return wide ? dg_launch<128, 128>(g, grid, st) : dg_launch<128, 64>(g, grid, st);
+    g.ksplit = dg_fit_split(ksplit, m, n, ws ? ws_doubles : 0);
+    dim3 grid(tm, tn, g.ksplit);
+    const int rc = wide ? dg_launch<128, 128>(g, grid, st) : dg_launch<128, 64>(g, grid, st);
+    if (rc) return rc;
+    return g.ksplit > 1 ? dg_reduce(st, g) : 0;
 }
 
 // lower tiles of C (m x m) = alpha A B' + beta C, A and B (m x k): with A = [V | W], B = [W | V] this is the symmetric
@@ -293,7 +321,7 @@ int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int
 int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
                     double beta, double *c, int64_t ldc) {
     if (m <= 0) return 0;
-    DgemmArgs g{a, b, c, lda, ldb, ldc, m, m, k, alpha, beta, 0, 1, 0, 1, 1};
+    DgemmArgs g{a, b, c, lda, ldb, ldc, m, m, k, alpha, beta, 0, 1, 0, 1, 1, nullptr};
     const int t = ceil_div(m, 128);
     dim3 grid((unsigned)((int64_t)t * (t + 1) / 2), 1, 1);
     return dg_launch<128, 128>(g, grid, st);
@@ -304,16 +332,30 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
 using namespace jx;
 
 // C-ABI entry for tests and timing scripts: plain column-major dgemm on device pointers
+namespace {
+// workspace of the diagnostic entries (the eigensolver passes its own)
+double *abi_workspace(size_t doubles) {
+    static DevBuf buf;
+    if (buf.bytes < doubles * sizeof(double) && buf.alloc(doubles * sizeof(double))) return nullptr;
+    return buf.as<double>();
+}
+constexpr size_t kAbiWs = (size_t)8 << 20;   // 8 M doubles
+}  // namespace
+
 extern "C" int jxg_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda,
                              const double *d_b, int64_t ldb, double beta, double *d_c, int64_t ldc, int ksplit,
                              void *stream) {
     if (m < 0 || n < 0 || k < 0) return fail("jxg_dgemm_f64: negative dimension");
-    return dgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, ksplit);
+    double *ws = abi_workspace(kAbiWs);
+    if (!ws) return 1;
+    return dgemm((hipStream_t)stream, ta != 0, tb != 0, m, n, k, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, ksplit, ws, kAbiWs);
 }
 
 extern "C" int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t lda, const double *d_b,
                                    int64_t ldb, double beta, double *d_c, int64_t ldc, void *stream) {
-    return dsymm_lower((hipStream_t)stream, m, n, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc);
+    double *ws = abi_workspace(kAbiWs);
+    if (!ws) return 1;
+    return dsymm_lower((hipStream_t)stream, m, n, alpha, d_a, lda, d_b, ldb, beta, d_c, ldc, ws, kAbiWs);
 }
 
 extern "C" int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,

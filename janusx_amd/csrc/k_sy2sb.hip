@@ -18,9 +18,9 @@
 namespace jx {
 
 int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, const double *a, int64_t lda,
-          const double *b, int64_t ldb, double beta, double *c, int64_t ldc, int ksplit);
+          const double *b, int64_t ldb, double beta, double *c, int64_t ldc, int ksplit, double *ws, size_t ws_doubles);
 int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
-                double beta, double *c, int64_t ldc);
+                double beta, double *c, int64_t ldc, double *ws, size_t ws_doubles);
 int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
                     double beta, double *c, int64_t ldc);
 
@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256) void sb_extract_band_kernel(const double *__re
     ab[e] = v;
 }
 
-size_t sy2sb_work_doubles(int n) { return (size_t)n * 8 * SB + 12 * SB * SB + 64; }
+constexpr size_t SB_WS = (size_t)7 << 20;   // split-K workspace of one launch chain (7 M doubles >= 128 * 64 * 768)
+size_t sy2sb_work_doubles(int n) { return (size_t)n * 8 * SB + 12 * SB * SB + 64 + 2 * SB_WS; }
 int sy2sb_bandwidth() { return SB; }
 
 // d_a (n x n, column-major, symmetric, lower referenced) -> band form in place (V below the band, see above);
@@ -548,6 +549,8 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
         double *tm = p; p += 2 * SB * SB;            // [T; -M/2]
         double *tmp1 = p; p += SB * SB;
         double *tmp2 = p; p += SB * SB;
+        double *ws_main = p; p += SB_WS;             // split-K slices of the update chain (main stream) ...
+        double *ws_side = p; p += SB_WS;             // ... and of the factorisation chain (side stream)
         JX_HIP(hipMemsetAsync(d_work, 0, sizeof(double) * (size_t)n * 8 * SB, st));
         const int64_t ld = n;
         const double eps = 2.220446049250313e-16;
@@ -562,7 +565,7 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             }
         }
         // factorisation chain of the panel at column j0 on stream s
-        auto panel_qr = [&](hipStream_t s, int j0, int par) -> int {
+        auto panel_qr = [&](hipStream_t s, int j0, int par, double *ws) -> int {
             const int pw = (ncol - j0 < SB) ? (ncol - j0) : SB;
             const int nt = n - j0 - SB;
             double *pp = d_a + (j0 + SB) + (int64_t)j0 * ld;
@@ -571,27 +574,27 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             // CholeskyQR passes 1 and 2: G = P'P, R = chol(G), P <- P R^-1 (in place: a workgroup of the product reads only
             // the rows it writes, and all of them before its epilogue)
             for (int pass = 0; pass < 2; ++pass) {
-                if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0)) return 1;
+                if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0, ws, SB_WS)) return 1;
                 const double shift = (pass == 0) ? 11.0 * ((double)nt * pw + (double)pw * (pw + 1)) * eps : 0.0;
                 hipLaunchKernelGGL(sb_chol_kernel, dim3(1), dim3(256), 0, s, gq, pw, shift, pass == 0 ? 1 : 0, rmat, rtot,
                                    d_flags, pz);
                 JX_LAUNCH_CHECK();
-                if (dgemm(s, false, false, nt, pw, pw, 1.0, pp, ld, rmat, SB, 0.0, pp, ld, 1)) return 1;
+                if (dgemm(s, false, false, nt, pw, pw, 1.0, pp, ld, rmat, SB, 0.0, pp, ld, 1, nullptr, 0)) return 1;
             }
             // pass 3 + reconstruction
-            if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0)) return 1;
+            if (dgemm(s, true, false, pw, pw, nt, 1.0, pp, ld, pp, ld, 0.0, gq, SB, 0, ws, SB_WS)) return 1;
             hipLaunchKernelGGL(sb_recon_kernel, dim3(1), dim3(256), 0, s, gq, pw, pp, ld, rmat, umat, rtot, tmat[par],
                                d_tau + j0, v1, v2, ld, d_flags, pz, 8.0 * eps * sqrt((double)nt));
             JX_LAUNCH_CHECK();
             if (nt > pw) {
-                if (dgemm(s, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1)) return 1;
+                if (dgemm(s, false, false, nt - pw, pw, pw, 1.0, pp + pw, ld, umat, SB, 0.0, v1 + pw, ld, 1, nullptr, 0)) return 1;
                 hipLaunchKernelGGL(sb_copy_v_kernel, dim3(ceil_div(nt - pw, 256), SB), dim3(256), 0, s, v1, v2, ld, pp, ld,
                                    pw, nt - pw, pw);
                 JX_LAUNCH_CHECK();
             }
             return 0;
         };
-        if (panel_qr(st, 0, 0)) return 1;
+        if (panel_qr(st, 0, 0, ws_main)) return 1;
         int par = 0;
         for (int j0 = 0; j0 < ncol; j0 += SB, par ^= 1) {
             const int pw = (ncol - j0 < SB) ? (ncol - j0) : SB;
@@ -604,30 +607,30 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
                 // last, narrower panel: the columns j0 + pw .. j0 + SB - 1 of the block row see Q' from the left only
                 const int nc = SB - pw;
                 double *cb = d_a + (j0 + SB) + (int64_t)(j0 + pw) * ld;
-                if (dgemm(st, true, false, pw, nc, nt, 1.0, v1, ld, cb, ld, 0.0, tmp1, SB, 1)) return 1;
-                if (dgemm(st, true, false, pw, nc, pw, 1.0, tmat[par], SB, tmp1, SB, 0.0, tmp2, SB, 1)) return 1;
-                if (dgemm(st, false, false, nt, nc, pw, -1.0, v1, ld, tmp2, SB, 1.0, cb, ld, 1)) return 1;
+                if (dgemm(st, true, false, pw, nc, nt, 1.0, v1, ld, cb, ld, 0.0, tmp1, SB, 1, nullptr, 0)) return 1;
+                if (dgemm(st, true, false, pw, nc, pw, 1.0, tmat[par], SB, tmp1, SB, 0.0, tmp2, SB, 1, nullptr, 0)) return 1;
+                if (dgemm(st, false, false, nt, nc, pw, -1.0, v1, ld, tmp2, SB, 1.0, cb, ld, 1, nullptr, 0)) return 1;
             }
             // two-sided update of the trailing matrix
-            if (dsymm_lower(st, nt, pw, 1.0, a22, ld, v1, ld, 0.0, zc, ld)) return 1;
-            if (dgemm(st, true, false, pw, pw, nt, 1.0, v1, ld, zc, ld, 0.0, gu, SB, 0)) return 1;
+            if (dsymm_lower(st, nt, pw, 1.0, a22, ld, v1, ld, 0.0, zc, ld, ws_main, SB_WS)) return 1;
+            if (dgemm(st, true, false, pw, pw, nt, 1.0, v1, ld, zc, ld, 0.0, gu, SB, 0, ws_main, SB_WS)) return 1;
             hipLaunchKernelGGL(sb_tm_kernel, dim3(1), dim3(256), 0, st, tmat[par], gu, pw, tm);
             JX_LAUNCH_CHECK();
-            if (dgemm(st, false, false, nt, pw, 2 * SB, 1.0, zc, ld, tm, 2 * SB, 0.0, wc, ld, 1)) return 1;
+            if (dgemm(st, false, false, nt, pw, 2 * SB, 1.0, zc, ld, tm, 2 * SB, 0.0, wc, ld, 1, nullptr, 0)) return 1;
             if (has_next) {
                 // block column of the next panel first: A22[:, 0:SB] -= [V | W] ([W | V][0:SB, :])'
                 const int nb = SB;                                      // has_next => nt > SB
-                if (dgemm(st, false, true, nt, nb, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld, 1)) return 1;
+                if (dgemm(st, false, true, nt, nb, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld, 1, nullptr, 0)) return 1;
                 if (lookahead) {
                     JX_HIP(hipEventRecord(ev_a[par], st));
                     JX_HIP(hipStreamWaitEvent(side, ev_a[par], 0));
-                    if (panel_qr(side, j0 + SB, par ^ 1)) return 1;
+                    if (panel_qr(side, j0 + SB, par ^ 1, ws_side)) return 1;
                     JX_HIP(hipEventRecord(ev_qr[par ^ 1], side));
                 }
                 // the rest of the trailing update runs beside that chain
                 if (dsyr2k_lower_nt(st, nt - nb, 2 * SB, -1.0, v1 + nb, ld, wc + nb, ld, 1.0, a22 + nb + (int64_t)nb * ld, ld))
                     return 1;
-                if (!lookahead && panel_qr(st, j0 + SB, par ^ 1)) return 1;
+                if (!lookahead && panel_qr(st, j0 + SB, par ^ 1, ws_main)) return 1;
             } else {
                 if (dsyr2k_lower_nt(st, nt, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld)) return 1;
             }

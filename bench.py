@@ -440,7 +440,8 @@ def main():
             "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
-                       "parallelism": f"snp-shard x{world}" + (", eigh symv tiles sharded" if eigh_sharded else "")},
+                       "parallelism": f"snp-shard x{world}" + (", eigh: replicated two-stage reduction + divide and conquer, "
+                                                                 "back-transformations sharded by eigenvector" if eigh_sharded else "")},
             "roofline": roofline_main,
             "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
                                                         "missing call among the selected samples, else the fp16 hi/lo "

@@ -109,6 +109,13 @@ int jxg_eigh_grid_check(int n);
 int64_t jxg_eigh_dist_staging_doubles(int n);
 int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                       int64_t staging_doubles, int min_n);
+/* Node-level distribution of the two-stage path of B1 (n >= 10000): with rank / world set by jxg_eigh_set_dist and a
+ * gather callback registered here, every rank runs the (bit-reproducible) reduction stages and the divide and conquer on
+ * the same matrix, back-transforms only the eigenvectors [n r / world, n (r + 1) / world) -- two thirds of the flops of
+ * the decomposition shard this way -- and gather(user) must then deliver the other ranks' rows of the row-major result
+ * into d_a (janusx_amd/pipeline.py: one broadcast per rank over RCCL).  NULL: off (the rank-sharded one-stage
+ * tridiagonalisation of jxg_eigh_set_dist is used instead; JXGPU_DIST_EIGH_ONESTAGE=1 forces that too). */
+int jxg_eigh_set_gather(int (*gather)(void *), void *user);
 
 /* Building blocks of B1's two-stage reduction, exported for tests and timing scripts (no counterpart in the reference,
  * which calls LAPACK dsyevd, src/math/eigh.rs:1320-1400).  All matrices column-major f64 in HBM.

@@ -43,8 +43,18 @@ int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, in
 extern float g_last_ms[16];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
                               // [8] divide and conquer ms, [9] Q1 back-transformation ms, [10] 1 = two-stage path taken
 int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
-                    double *d_c);
+                    double *d_c, int ncols);
 int sytrd_dist_active(int n);
+void sytrd_dist_rank(int *rank, int *world);
+int launch_gather_cols_range(const double *src, const int *d_perm, int n, int count, double *dst, hipStream_t st);
+// Node-level distribution of the two-stage path (jxg_eigh_set_gather): reduction stages and divide and conquer run
+// replicated (bit-reproducible kernels, identical inputs), every rank back-transforms its own share of the eigenvectors
+// and `gather` fills in the others' rows.
+struct EighGather {
+    int (*gather)(void *) = nullptr;
+    void *user = nullptr;
+};
+static EighGather g_gather;
 constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
 
 static rocblas_handle g_handle = nullptr;
@@ -69,6 +79,15 @@ extern "C" int64_t jxg_eigh_dist_staging_doubles(int n) { return (int64_t)n + 32
 extern "C" int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                                  int64_t staging_doubles, int min_n) {
     return sytrd_set_dist(rank, world, allreduce, user, d_staging, staging_doubles, min_n);
+}
+
+// Two-stage path on several ranks (rank / world from jxg_eigh_set_dist): rank r finishes the eigenvectors
+// [n r / world, n (r + 1) / world) -- rows of the row-major result in d_a -- and then calls gather(user), which must
+// deliver every other rank's rows into the same d_a (all ranks call it; e.g. one broadcast per rank).  NULL: off.
+extern "C" int jxg_eigh_set_gather(int (*gather)(void *), void *user) {
+    g_gather.gather = gather;
+    g_gather.user = user;
+    return 0;
 }
 
 // d_a: (n,n) symmetric, f64. On return row j of d_a (row-major) = eigenvector j (= column j of the
@@ -138,8 +157,14 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         // the one-stage form; it is also the fallback when a panel of the band reduction cannot be factored, and the
         // form the rank-sharded tridiagonalisation (jxg_eigh_set_dist) uses.
         static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : 10000;
+        int drank = 0, dworld = 1;
+        sytrd_dist_rank(&drank, &dworld);
+        // several ranks: the two-stage path with column-sharded back-transformations when a gather callback is registered
+        // (JXGPU_DIST_EIGH_ONESTAGE=1 keeps the rank-sharded one-stage tridiagonalisation instead)
+        static const bool dist_onestage = getenv("JXGPU_DIST_EIGH_ONESTAGE") && atoi(getenv("JXGPU_DIST_EIGH_ONESTAGE")) != 0;
+        const bool dist_two = dworld > 1 && g_gather.gather != nullptr && !dist_onestage;
         bool twostage = n >= ts_min && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
-                        !sytrd_dist_active(n);
+                        (dist_two || !sytrd_dist_active(n));
         if (mode && strcmp(mode, "twostage") == 0 && n > 2 * sy2sb_bandwidth() + 2) twostage = true;
         DevBuf ts_work, ts_ab, ts_tau2, ts_ctrl, ts_flags, ts_tq;
         ScratchLease ts_v2;
@@ -205,15 +230,38 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         }
         JX_HIP(hipEventRecord(ev[3], st));
         if (stage_done("dstedc")) return 1;
+        bool sharded_rows = false;                       // d_a already holds this rank's rows + the gathered rest
         if (twostage) {
             if (ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
-            if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, c.as<double>(), n, ts_tq.as<double>(),
-                                ev[6], ev[7]))
-                return 1;
-            JX_HIP(hipEventRecord(ev[4], st));
-            if (stage_done("Q2 back-transformation")) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
-            if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>())) return 1;
+            if (dist_two && split) {
+                // this rank's eigenvectors only: columns perm[r0 .. r1) of C, gathered into a contiguous (n, nr) block
+                const int r0 = (int)((int64_t)n * drank / dworld), r1 = (int)((int64_t)n * (drank + 1) / dworld);
+                const int nr = r1 - r0;
+                DevBuf dperm, blk;
+                if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;
+                if (blk.alloc(sizeof(double) * (size_t)n * (size_t)(nr > 0 ? nr : 1))) return 1;
+                JX_HIP(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+                if (launch_gather_cols_range(c.as<double>(), dperm.as<int>() + r0, n, nr, blk.as<double>(), st)) return 1;
+                if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, blk.as<double>(), nr,
+                                    ts_tq.as<double>(), ev[6], ev[7]))
+                    return 1;
+                JX_HIP(hipEventRecord(ev[4], st));
+                if (stage_done("Q2 back-transformation (this rank's columns)")) return 1;
+                if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), blk.as<double>(), nr)) return 1;
+                // column j of the block = eigenvector r0 + j = row r0 + j of the row-major result
+                JX_HIP(hipMemcpyAsync(d_a + (size_t)r0 * n, blk.p, sizeof(double) * (size_t)n * nr, hipMemcpyDeviceToDevice, st));
+                JX_HIP(hipStreamSynchronize(st));
+                if (g_gather.gather(g_gather.user)) return fail("jxg_eigh_f64: the gather callback failed");
+                sharded_rows = true;
+            } else {
+                if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, c.as<double>(), n, ts_tq.as<double>(),
+                                    ev[6], ev[7]))
+                    return 1;
+                JX_HIP(hipEventRecord(ev[4], st));
+                if (stage_done("Q2 back-transformation")) return 1;
+                if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>(), n)) return 1;
+            }
         } else {
             const char *om = getenv("JXGPU_ORMTR");
             if (om && strcmp(om, "rocsolver") == 0) {
@@ -243,7 +291,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 g_last_ms[5] = (float)(4.0 * refl * (double)n / 1e9);
             }
         }
-        if (split) {
+        if (sharded_rows) {
+            JX_HIP(hipStreamSynchronize(st));
+        } else if (split) {
             DevBuf dperm;
             if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;
             JX_HIP(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));

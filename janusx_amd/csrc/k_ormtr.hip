@@ -50,22 +50,23 @@ __global__ void ot_fix_m_kernel(double *__restrict__ m, int nbk, int ld, const d
 }
 
 int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
-                    double *d_c);
+                    double *d_c, int ncols);
 
 // d_a: (n,n) column-major after sytrd_lower; d_tau (n-1); d_c (n,n) column-major, overwritten with Q C.
 int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c) {
-    return ormtr_lower_off(h, st, d_a, n, 1, n - 1, d_tau, d_c);
+    return ormtr_lower_off(h, st, d_a, n, 1, n - 1, d_tau, d_c, n);
 }
 
-// General form: reflector j (j = 0 .. nref-1) = [0 (j + off rows); 1; A(j+off+1 : n, j)] with factor d_tau[j].
+// General form: reflector j (j = 0 .. nref-1) = [0 (j + off rows); 1; A(j+off+1 : n, j)] with factor d_tau[j];
+// d_c (n, ncols), ld = n (ncols < n: a rank's share of the eigenvector columns).
 int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
-                    double *d_c) {
-    if (n < 2 || nref < 1) return 0;
+                    double *d_c, int ncols) {
+    if (n < 2 || nref < 1 || ncols < 1) return 0;
     // wider blocks for large n (measured at n = 20000: 512 -> 378 ms, 1024 -> 315, 2048 -> 281, 4096 -> 327)
     const int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB"))
                                                                                     : (n >= 12000 ? 2 * OT_NB : OT_NB);
     ScratchLease ws;   // vc (n x nb) | mm (nb x nb) | w (nb x n)
-    const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * n;
+    const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * ncols;
     if (ws.take(3, sizeof(double) * (nvc + nmm + nw))) return 1;
     double *const vc = ws.as<double>(), *const mm = vc + nvc, *const w = mm + nmm;
     const double one = 1.0, zero = 0.0, minus1 = -1.0;
@@ -84,13 +85,13 @@ int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, 
                            jb);
         JX_LAUNCH_CHECK();
         double *csub = d_c + (jb + off);              // rows jb+off .. n-1 of every column
-        rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, n, rows, &one, vc,
+        rs = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, nbk, ncols, rows, &one, vc,
                            rows, csub, n, &zero, w, nb);
         if (rs != rocblas_status_success) return fail("ormtr: V'C dgemm failed: " + std::to_string((int)rs));
         rs = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, nbk,
-                           n, &one, mm, nb, w, nb);
+                           ncols, &one, mm, nb, w, nb);
         if (rs != rocblas_status_success) return fail("ormtr: dtrsm failed: " + std::to_string((int)rs));
-        rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, rows, n, nbk, &minus1, vc, rows,
+        rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, rows, ncols, nbk, &minus1, vc, rows,
                            w, nb, &one, csub, n);
         if (rs != rocblas_status_success) return fail("ormtr: update dgemm failed: " + std::to_string((int)rs));
     }

@@ -1038,6 +1038,14 @@ void gather_cols_grid(int n, unsigned *gx, unsigned *gy) {
     *gy = 16;
 }
 
+// dst row r (r = 0 .. count-1, n entries each) = src column d_perm[r]
+int launch_gather_cols_range(const double *src, const int *d_perm, int n, int count, double *dst, hipStream_t st) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(sd_gather_cols_kernel, dim3((unsigned)count, 16), dim3(256), 0, st, src, d_perm, n, dst);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st) {
     unsigned gx, gy;
     gather_cols_grid(n, &gx, &gy);

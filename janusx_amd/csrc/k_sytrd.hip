@@ -884,6 +884,11 @@ int sytrd_dist_active(int n) {
     return ((g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n) ? 1 : 0;
 }
 
+void sytrd_dist_rank(int *rank, int *world) {
+    *rank = g_dist.rank;
+    *world = g_dist.world;
+}
+
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
                    int min_n) {
     if (world < 1 || rank < 0 || rank >= world) return fail("sytrd_set_dist: bad rank / world");

@@ -29,6 +29,20 @@ def allreduce_sum_(t):
     return t
 
 
+def broadcast_(t, src):
+    """In-place broadcast from rank `src` (no-op without an initialised multi-rank group)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if t.is_cuda and dist.get_backend() != "nccl":
+            h = t.detach().cpu()          # functional multi-rank mode on shared GPUs (gloo): through host memory
+            dist.broadcast(h, src)
+            if dist.get_rank() != src:
+                t.copy_(h)
+        else:
+            dist.broadcast(t, src)
+    return t
+
+
 def gather_rows(local, counts=None):
     """Concatenate per-rank (rows_r, c) tensors in rank order on every rank (BED order of the SNP shards)."""
     import torch

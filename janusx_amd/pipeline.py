@@ -115,17 +115,22 @@ _DIST_EIGH = {}   # keeps the ctypes callback and the staging tensor alive
 
 
 def enable_distributed_eigh(min_n: int = 0):
-    """Shard the tridiagonalisation's symv over the ranks of the initialised torch.distributed group (every rank must
-    then call `eigh_from_grm` on the same matrix): per column each rank streams 1 / world of the trailing-matrix tiles
-    and one all-reduce (RCCL over xGMI with the nccl backend) sums the partial products. Applies from `min_n` rows
-    (default 16384: below that a column is launch-latency-bound and the collective costs more than it saves)."""
+    """Distribute the eigendecomposition over the ranks of the initialised torch.distributed group (every rank must then
+    call `eigh_from_grm` on the same matrix).  Two-stage path (n >= 10000, the default there): the reduction stages and
+    the divide and conquer run replicated -- their kernels are bit-reproducible, so the replicas agree --, every rank
+    back-transforms its n / world eigenvectors (two thirds of the flops) and one broadcast per rank (RCCL over xGMI with
+    the nccl backend) completes U on every rank.  One-stage path (JXGPU_DIST_EIGH_ONESTAGE=1, or n below the two-stage
+    threshold): per column each rank streams 1 / world of the trailing-matrix tiles of the symv and one all-reduce sums
+    the partial products, from `min_n` rows (default 16384: below that a column is launch-latency-bound and the
+    collective costs more than it saves)."""
     import ctypes as C
     import torch.distributed as dist
-    from .dist import allreduce_sum_
+    from .dist import allreduce_sum_, broadcast_
     import os
     force_single = os.environ.get("JXGPU_DIST_EIGH_FORCE", "0") not in ("", "0")   # one-rank run of the same code path
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_single):
         check(lib().jxg_eigh_set_dist(0, 1, None, None, None, 0, 0))
+        check(lib().jxg_eigh_set_gather(None, None))
         _DIST_EIGH.clear()
         return False
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -143,6 +148,25 @@ def enable_distributed_eigh(min_n: int = 0):
 
     cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(_cb)
 
+    def _gather(_user):
+        # two-stage path: every rank has back-transformed the eigenvectors [n r / world, n (r + 1) / world) (rows of the
+        # row-major result); one broadcast per rank completes the matrix on every rank (RCCL over xGMI with nccl)
+        try:
+            a = state["out"]
+            n = int(a.shape[0])
+            for r in range(world):
+                r0, r1 = (n * r) // world, (n * (r + 1)) // world
+                if r1 > r0:
+                    broadcast_(a[r0:r1], r)
+            return 0
+        except Exception as e:   # noqa: BLE001 - reported through the C status
+            import sys
+            print(f"distributed eigh: gather failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+    gcb = C.CFUNCTYPE(C.c_int, C.c_void_p)(_gather)
+    check(lib().jxg_eigh_set_gather(C.cast(gcb, C.c_void_p) if world > 1 else None, None))
+
     def prepare(n):
         need = int(lib().jxg_eigh_dist_staging_doubles(int(n)))
         if state["staging"] is None or state["staging"].numel() != need:
@@ -150,7 +174,7 @@ def enable_distributed_eigh(min_n: int = 0):
             check(lib().jxg_eigh_set_dist(rank, world, C.cast(cb, C.c_void_p), None, _ptr(state["staging"]), need,
                                           int(min_n)))
 
-    _DIST_EIGH.update(cb=cb, state=state, prepare=prepare)
+    _DIST_EIGH.update(cb=cb, gcb=gcb, state=state, prepare=prepare)
     return True
 
 
@@ -168,6 +192,7 @@ def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
     w = torch.empty(kk, dtype=torch.float64, device=dev)
     if _DIST_EIGH:
         _DIST_EIGH["prepare"](kk)   # staging buffer of the per-column all-reduce (sized by n)
+        _DIST_EIGH["state"]["out"] = a   # the gather callback of the two-stage path completes this tensor
     check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
     return w, a
 

@@ -1,4 +1,6 @@
-"""Functional check of the rank-sharded tridiagonalisation (run under torch.distributed.run, any world size):
+"""Functional check of the distributed eigensolver (run under torch.distributed.run, any world size).  Default: the
+rank-sharded one-stage tridiagonalisation; with JXGPU_EIGH=twostage in the environment: the two-stage path with
+column-sharded back-transformations (replicated reduction + divide and conquer, one broadcast per rank at the end).
 
     JXGPU_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
         --master-addr 127.0.0.1 --master-port 29531 scripts/dist_eigh_check.py 600

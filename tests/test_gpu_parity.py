@@ -1368,6 +1368,13 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=700 world=2" in out.stdout and "replicas_identical=True" in out.stdout
+    # the two-stage path on two ranks (forced at this size; the default from n = 10000): replicated reduction stages and
+    # divide and conquer, every rank back-transforms its half of the eigenvectors, one broadcast per rank completes U
+    env2 = dict(env, JXGPU_EIGH="twostage")
+    cmd[-1] = "2300"
+    out = subprocess.run(cmd, env=env2, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "replicas_identical=True" in out.stdout
 
 
 @pytest.mark.gpu

@@ -440,8 +440,12 @@ def main():
             "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
-                       "parallelism": f"snp-shard x{world}" + (", eigh: replicated two-stage reduction + divide and conquer, "
-                                                                 "back-transformations sharded by eigenvector" if eigh_sharded else "")},
+                       "parallelism": f"snp-shard x{world}" + (
+                           "" if not eigh_sharded else
+                           ", eigh: replicated two-stage reduction + divide and conquer, back-transformations sharded by "
+                           "eigenvector" if kern.get("two_stage") else
+                           ", eigh symv tiles sharded over ranks (one-stage tridiagonalisation below the two-stage "
+                           "threshold)")},
             "roofline": roofline_main,
             "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
                                                         "missing call among the selected samples, else the fp16 hi/lo "
@@ -467,7 +471,10 @@ def main():
                                 "note": "algorithmic 2 m n^2 flops; two f16 MFMA products per algorithmic product on "
                                         "all-exact 128-row tiles (integer design rows x U hi/lo), three otherwise",
                                 "ms_per_step": kern["rot_ms"] / L},
-            "roofline_scan": ({"bound": "f64 valu", "kernel": "lmm_scan_fast_kernel",
+            "roofline_scan": ({"bound": "f64 valu",
+                               "kernel": ("lmm_scan_fast_kernel (s / X~ / y~ resident in LDS)",
+                                          "lmm_scan_tiled_kernel (LDS tiles of s / X~ / y~, 16 SNPs per workgroup in lock step)",
+                                          "lmm_scan_fast_kernel (operands from L2)")[int(lib().jxg_last_kernel_ms(11))],
                                "achieved": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9,
                                "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,

@@ -206,6 +206,91 @@ struct FastEval {
     double q, logdetv, beta_k, ainv_kk;
 };
 
+// lambda of an evaluation point, or a negative value when the evaluation fails before any sum is formed
+// (src/stats/reml.rs:255-362: non-finite / non-positive lambda, n <= dim, a non-positive s_i + lambda)
+__device__ __forceinline__ double fast_eval_lambda(double x, double smin, int n, int dim) {
+    const double lbd = jx_pow10(x);
+    if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return -1.0;
+    if (smin + lbd <= 0.0) return -1.0;
+    return lbd;
+}
+
+// SNP-specific sums over the samples [i0, i1) of one lane's stride: acc[r] += g x_r / v, acc[MAXD-1] += g^2 / v,
+// acc[MAXD] += g y_c / v; s / xcov / yc are indexed from `base` (0 for whole vectors, the tile start for an LDS tile)
+template <int MAXD>
+__device__ __forceinline__ void fast_eval_accumulate(double lbd, const double *__restrict__ s,
+                                                     const double *__restrict__ xcov, const double *__restrict__ yc,
+                                                     const float *__restrict__ g, int i0, int i1, int base, int p,
+                                                     double (&acc)[MAXD + 1]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll 4
+    for (int i = i0 + lane; i < i1; i += 64) {
+        const int j = i - base;
+        const double vi = fast_rcp(s[j] + lbd);
+        const double gi = (double)g[i];
+        const double gv = gi * vi;
+#pragma unroll
+        for (int r = 0; r < MAXD - 1; ++r)
+            if (r < p) acc[r] = fma(gv, xcov[(int64_t)j * p + r], acc[r]);
+        acc[MAXD - 1] = fma(gv, gi, acc[MAXD - 1]);
+        acc[MAXD] = fma(gv, yc[j], acc[MAXD]);
+    }
+}
+
+// the same sums for the tiled kernel.  The rotated row comes from HBM / L2 with nothing to cover its latency but the
+// bytes in flight, so a lane takes FOUR consecutive samples per load (16 bytes; 1 KB per wave instruction) and keeps B
+// loads in flight; V4 = false is the scalar form (rows not 16-byte aligned: n % 4 != 0).  Optionally the sum of squares of
+// the row in the same pass.  (Per-lane sample order differs from the one-wave-per-SNP kernels: results agree to rounding.)
+template <int MAXD, int B, bool V4>
+__device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const double *__restrict__ s,
+                                                             const double *__restrict__ xcov, const double *__restrict__ yc,
+                                                             const float *__restrict__ g, int i0, int i1, int base, int p,
+                                                             double (&acc)[MAXD + 1], double &ssq, bool want_ssq) {
+    const int lane = threadIdx.x & 63;
+    constexpr int W = V4 ? 4 : 1;
+    for (int i = i0 + W * lane; i < i1; i += 64 * W * B) {
+        float gb[B][W];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int idx = i + 64 * W * u;
+            if (V4) {
+                const float4 q = (idx < i1) ? *reinterpret_cast<const float4 *>(g + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gb[u][0] = q.x;
+                gb[u][W > 1 ? 1 : 0] = q.y;
+                gb[u][W > 2 ? 2 : 0] = q.z;
+                gb[u][W > 3 ? 3 : 0] = q.w;
+            } else {
+                gb[u][0] = (idx < i1) ? g[idx] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int idx = i + 64 * W * u;
+            if (idx < i1) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const int j = idx + e - base;
+                    const double gi = (double)gb[u][e];
+                    if (want_ssq) ssq += gi * gi;
+                    if (lbd >= 0.0) {
+                        const double vi = fast_rcp(s[j] + lbd);
+                        const double gv = gi * vi;
+#pragma unroll
+                        for (int r = 0; r < MAXD - 1; ++r)
+                            if (r < p) acc[r] = fma(gv, xcov[(int64_t)j * p + r], acc[r]);
+                        acc[MAXD - 1] = fma(gv, gi, acc[MAXD - 1]);
+                        acc[MAXD] = fma(gv, yc[j], acc[MAXD]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MAXD>
+__device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
+                                                 bool want_ainv, double (&acc)[MAXD + 1], FastEval<MAXD> &o);
+
 // One evaluation for the SNP owned by this wave. MAXD bounds dim = p + 1.
 template <int MAXD>
 __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const double *__restrict__ coef,
@@ -214,32 +299,28 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
                                           const float *__restrict__ g, int n, int p, bool want_ainv,
                                           FastEval<MAXD> &o) {
     const int dim = p + 1;
-    const int lane = threadIdx.x & 63;
     o.ok = false;
     o.reml_neg = 1e8;
     o.q = 0.0;
     o.logdetv = 0.0;
     o.beta_k = 0.0;
     o.ainv_kk = 0.0;
-    const double lbd = jx_pow10(x);
-    if (!isfinite(lbd) || lbd <= 0.0 || n <= dim) return;
-    if (smin + lbd <= 0.0) return;
-
-    // ---- SNP-specific sums: c[r] = sum g x_r / v, gg = sum g^2 / v, gy = sum g y_c / v -------------------
+    const double lbd = fast_eval_lambda(x, smin, n, dim);
+    if (lbd < 0.0) return;
     double acc[MAXD + 1];
 #pragma unroll
     for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
-#pragma unroll 4
-    for (int i = lane; i < n; i += 64) {
-        const double vi = fast_rcp(s[i] + lbd);
-        const double gi = (double)g[i];
-        const double gv = gi * vi;
-#pragma unroll
-        for (int r = 0; r < MAXD - 1; ++r)
-            if (r < p) acc[r] = fma(gv, xcov[(int64_t)i * p + r], acc[r]);
-        acc[MAXD - 1] = fma(gv, gi, acc[MAXD - 1]);
-        acc[MAXD] = fma(gv, yc[i], acc[MAXD]);
-    }
+    fast_eval_accumulate<MAXD>(lbd, s, xcov, yc, g, 0, n, 0, p, acc);
+    fast_eval_finish<MAXD>(x, hd, coef, n, p, want_ainv, acc, o);
+}
+
+// Second half of an evaluation: wave sums of the per-lane accumulators, lambda-only sums from the Chebyshev tables,
+// normal equations, REML.  `o` must have been reset by the caller.
+template <int MAXD>
+__device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
+                                                 bool want_ainv, double (&acc)[MAXD + 1], FastEval<MAXD> &o) {
+    const int dim = p + 1;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
 
@@ -501,6 +582,251 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     }
 }
 
+
+// ---- tiled form for n beyond the LDS-resident limit --------------------------------------------------------------------
+// The vectors every evaluation streams (s, X~, shifted y~: 8 n (2 + p) bytes, 480 KB at n = 20 000) do not fit LDS, and the
+// one-wave-per-SNP form above re-reads them through L2 for every evaluation of every SNP (measured 13.5x the algorithmic
+// bytes, association 291 ms at BASELINE configs[2]).  Here a workgroup of NW waves walks the samples in tiles held in LDS:
+// all waves evaluate in lock step over the tiles (one evaluation of one SNP per wave per round, whatever Brent iteration
+// the wave is in), a wave that finishes a SNP takes the next one from the workgroup's queue in the following round.  Brent
+// is the same state machine unrolled in time: identical evaluation points and sums (per-lane order of the samples is
+// unchanged: tile lengths are multiples of 64), identical results.
+struct BrentState {
+    double a, c, x, w, v, fx, fw, fv, d, e;
+    int it, evals;
+};
+
+// the head of one iteration of src/math/brent.rs:1-136: false = converged / out of iterations, true = evaluate at u next
+__device__ __forceinline__ bool brent_propose(BrentState &b, double tol, int max_iter, double &u) {
+    const double eps = 2.220446049250313e-16;
+    if (b.it >= max_iter) return false;
+    const double m = 0.5 * (b.a + b.c);
+    const double tol1 = tol * fabs(b.x) + eps;
+    const double tol2 = 2.0 * tol1;
+    if (fabs(b.x - m) <= tol2 - 0.5 * (b.c - b.a)) return false;
+    bool use_par = false;
+    u = b.x;
+    if (fabs(b.e) > tol1) {
+        double pq = (b.x - b.v) * ((b.x - b.w) * (b.fx - b.fv)) - (b.x - b.w) * ((b.x - b.v) * (b.fx - b.fw));
+        double q = 2.0 * (((b.x - b.v) * (b.fx - b.fw)) - ((b.x - b.w) * (b.fx - b.fv)));
+        if (q > 0.0)
+            pq = -pq;
+        else
+            q = -q;
+        bool ok = false;
+        if (fabs(q) > eps) {
+            const double sstep = pq / q;
+            u = b.x + sstep;
+            if ((u - b.a) >= tol2 && (b.c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(b.e)) ok = true;
+        }
+        if (ok) {
+            b.d = pq / q;
+            u = b.x + b.d;
+            if ((u - b.a) < tol2 || (b.c - u) < tol2) b.d = (b.x < m) ? tol1 : -tol1;
+            use_par = true;
+        }
+    }
+    if (!use_par) {
+        b.e = (b.x < m) ? (b.c - b.x) : (b.a - b.x);
+        b.d = 0.3819660 * b.e;
+    }
+    if (fabs(b.d) < tol1) b.d = (b.d >= 0.0) ? tol1 : -tol1;
+    u = b.x + b.d;
+    return true;
+}
+
+// the tail of the same iteration, after f(u) is known
+__device__ __forceinline__ void brent_update(BrentState &b, double u, double fu) {
+    ++b.evals;
+    if (fu <= b.fx) {
+        if (u >= b.x)
+            b.a = b.x;
+        else
+            b.c = b.x;
+        b.v = b.w;
+        b.fv = b.fw;
+        b.w = b.x;
+        b.fw = b.fx;
+        b.x = u;
+        b.fx = fu;
+    } else {
+        if (u >= b.x)
+            b.c = u;
+        else
+            b.a = u;
+        if (fu <= b.fw || b.w == b.x) {
+            b.v = b.w;
+            b.fv = b.fw;
+            b.w = u;
+            b.fw = fu;
+        } else if (fu <= b.fv || b.v == b.x || b.v == b.w) {
+            b.v = u;
+            b.fv = fu;
+        }
+    }
+    ++b.it;
+}
+
+template <int MAXD, int NW>
+__global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
+    const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
+    const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
+    const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
+    int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out, int tile, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) double scan_lds[];
+    double *ls = scan_lds, *lx = scan_lds + tile, *ly = scan_lds + tile + (int64_t)tile * p;
+    int &next_row = *reinterpret_cast<int *>(scan_lds + (int64_t)tile * (2 + p));   // queue head, behind the tile (all LDS is
+                                                                                     // dynamic: the base stays 16-byte aligned)
+    const int out_cols = with_plrt ? 4 : 3;
+    const int lane = threadIdx.x & 63;
+    const double smin = smin_ptr[0];
+    const int dim = p + 1;
+    const int row_begin = blockIdx.x * rows_per_wg;
+    const int row_end = min(nrows, row_begin + rows_per_wg);
+    if (threadIdx.x == 0) next_row = row_begin;
+    __syncthreads();
+    const double tol = fmax(fabs(tol_in), 1e-12);
+    const bool vec4 = (n % 4 == 0) && (tile % 256 == 0) && ((reinterpret_cast<uintptr_t>(grot) & 15) == 0);
+    double lo_b = low, hi_b = high;
+    if (!(lo_b < hi_b)) {
+        const double tt = lo_b;
+        lo_b = hi_b;
+        hi_b = tt;
+    }
+    // wave state: phase 0 = needs a SNP, 1 = first evaluation (also forms sum g^2), 2 = Brent evaluation at u, 3 = final
+    int phase = 0, r = -1;
+    bool exhausted = false;
+    BrentState b;
+    double u = 0.0, x_eval = 0.0;
+    for (;;) {
+        if (phase == 0 && !exhausted) {
+            int nr = 0;
+            if (lane == 0) nr = atomicAdd(&next_row, 1);
+            nr = __shfl(nr, 0, 64);
+            if (nr >= row_end) {
+                exhausted = true;
+            } else {
+                r = nr;
+                phase = 1;
+                b.a = lo_b;
+                b.c = hi_b;
+                b.x = (warm && isfinite(init) && init >= b.a && init <= b.c) ? init : 0.5 * (b.a + b.c);
+                b.w = b.x;
+                b.v = b.x;
+                b.d = 0.0;
+                b.e = 0.0;
+                b.it = 0;
+                b.evals = 0;
+                x_eval = b.x;
+            }
+        }
+        if (__syncthreads_and((phase == 0 && exhausted) ? 1 : 0)) break;
+        const bool active = phase != 0;
+        const float *g = grot + (int64_t)(active ? r : 0) * n;
+        const double lbd = active ? fast_eval_lambda(x_eval, smin, n, dim) : -1.0;
+        double acc[MAXD + 1];
+#pragma unroll
+        for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
+        double ssq = 0.0;
+        for (int t0 = 0; t0 < n; t0 += tile) {
+            const int t1 = min(n, t0 + tile);
+            __syncthreads();                                   // the previous tile has been consumed
+            for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) {
+                ls[i] = s_g[t0 + i];
+                ly[i] = yc_g[t0 + i];
+            }
+            for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) lx[i] = xcov_g[(int64_t)t0 * p + i];
+            __syncthreads();
+            if (active && (lbd >= 0.0 || phase == 1)) {
+                if (vec4) fast_eval_accumulate_batched<MAXD, 4, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1);
+                else fast_eval_accumulate_batched<MAXD, 8, false>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1);
+            }
+        }
+        if (!active) continue;
+        FastEval<MAXD> ev;
+        ev.ok = false;
+        ev.reml_neg = 1e8;
+        ev.q = 0.0;
+        ev.logdetv = 0.0;
+        ev.beta_k = 0.0;
+        ev.ainv_kk = 0.0;
+        if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd, coef, n, p, phase == 3, acc, ev);
+        double *o = out + (int64_t)r * out_cols;
+        if (phase == 1) {
+            ssq = wave_allsum(ssq);
+            if (!isfinite(ssq) || ssq <= 1e-12) {
+                if (lane == 0) {
+                    o[0] = nan("");
+                    o[1] = nan("");
+                    o[2] = 1.0;
+                    if (with_plrt) o[3] = 1.0;
+                    if (evals_out) evals_out[r] = 0;
+                }
+                phase = 0;
+                continue;
+            }
+            b.fx = ev.reml_neg;
+            b.fw = b.fx;
+            b.fv = b.fx;
+            b.evals = 1;
+        } else if (phase == 2) {
+            brent_update(b, u, ev.reml_neg);
+        }
+        if (phase == 1 || phase == 2) {
+            if (brent_propose(b, tol, max_iter, u)) {
+                phase = 2;
+                x_eval = u;
+            } else {
+                phase = 3;
+                x_eval = b.x;
+            }
+            continue;
+        }
+        // phase 3: final_beta_se (src/stats/reml.rs:472-568) at the optimum
+        double beta = nan(""), se = nan("");
+        if (ev.ok) {
+            const double sigma2 = ev.q / ((double)n - (double)dim);
+            const double var = sigma2 * ev.ainv_kk;
+            if (var > 0.0 && isfinite(var)) {
+                beta = ev.beta_k;
+                se = sqrt(var);
+            }
+        }
+        if (lane == 0) {
+            if (evals_out) evals_out[r] = b.evals;
+            if (isfinite(beta) && isfinite(se) && se > 0.0) {
+                const double z = beta / se;
+                double pv = 2.0 * (0.5 * jx_erfc(fabs(z) / 1.4142135623730951));
+                if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                if (pv > 1.0) pv = 1.0;
+                o[0] = beta;
+                o[1] = se;
+                o[2] = isfinite(pv) ? pv : 1.0;
+                if (with_plrt) {
+                    double plrt = 1.0;
+                    if (ev.ok && isfinite(ev.q) && ev.q > 0.0) {
+                        const double nf = (double)n;
+                        const double ml =
+                            nf * (jx_log(nf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * jx_log(ev.q) + ev.logdetv);
+                        if (isfinite(ml)) {
+                            double stat = 2.0 * (ml - nullml);
+                            if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                            plrt = chi2_sf_df1_dev(stat);
+                        }
+                    }
+                    o[3] = plrt;
+                }
+            } else {
+                o[0] = nan("");
+                o[1] = nan("");
+                o[2] = 1.0;
+                if (with_plrt) o[3] = 1.0;
+            }
+        }
+        phase = 0;
+    }
+}
+
 }  // namespace jx
 
 using namespace jx;
@@ -571,6 +897,8 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     return 0;
 }
 
+namespace jx { extern float g_last_ms[16]; }   // [11]: form the last exact scan launch took (0 LDS-resident, 1 tiled, 2 plain)
+
 extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
                                 double low, double high, const void *d_work, double tol, int max_iter, int warm,
                                 double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
@@ -586,6 +914,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
     const bool use_lds = dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
     if (use_lds) {
+        g_last_ms[11] = 0.f;
         if (dim <= 2) {
             constexpr int NW = 16;
             auto kfn = lmm_scan_fast_kernel<2, NW, true>;
@@ -616,6 +945,55 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         JX_LAUNCH_CHECK();
         return 0;
     }
+    if (dim <= 4 && !getenv("JXGPU_SCAN_NOTILE")) {
+        // n beyond the LDS-resident limit: tiles of the shared vectors in LDS, NW SNPs per workgroup in lock step
+        g_last_ms[11] = 1.f;
+        const int per_sample = 8 * (2 + p);
+        int tile = (150 * 1024 / per_sample) / 256 * 256;
+        const int ntiles = (n + tile - 1) / tile;
+        tile = ((n + ntiles - 1) / ntiles + 255) / 256 * 256;
+        const size_t lds_tile = (size_t)per_sample * tile + 16;
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            JX_HIP(hipGetDevice(&dev));
+            JX_HIP(hipGetDeviceProperties(&prop, dev));
+            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        if (dim <= 2) {
+            constexpr int NW = 16;
+            auto kfn = lmm_scan_tiled_kernel<2, NW>;
+            static bool attr_t2 = false;
+            if (!attr_t2) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+                attr_t2 = true;
+            }
+            int grid = cus;
+            if (grid * NW > nrows) grid = (nrows + NW - 1) / NW;
+            const int rows_per_wg = (nrows + grid - 1) / grid;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_tile, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
+                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
+                               d_out, d_evals, tile, rows_per_wg);
+        } else {
+            constexpr int NW = 8;
+            auto kfn = lmm_scan_tiled_kernel<4, NW>;
+            static bool attr_t4 = false;
+            if (!attr_t4) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+                attr_t4 = true;
+            }
+            int grid = cus;
+            if (grid * NW > nrows) grid = (nrows + NW - 1) / NW;
+            const int rows_per_wg = (nrows + grid - 1) / grid;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_tile, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
+                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
+                               d_out, d_evals, tile, rows_per_wg);
+        }
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
+    g_last_ms[11] = 2.f;
     int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXD, SCAN_WAVES, false>), dim3(grid),

@@ -399,14 +399,14 @@ def main():
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
             # reflectors (one launch per decomposition; profiles/r02*_kernel_stats.csv)
             q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
-            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_kernel")
-            mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_kernel")
-            roofline_main = {"bound": "mfma", "kernel": "sbback_apply_kernel", "achieved": q2_tflops,
+            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_reg_kernel")
+            mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_reg_kernel")
+            roofline_main = {"bound": "mfma", "kernel": "sbback_apply_reg_kernel", "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
                              "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
                              "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
                              "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "
-                                     "kernel issues (64 + 32) / 64 of them on the parallelogram blocks plus the T products; "
+                                     "kernel issues (64 + 32) / 64 of them on the parallelogram blocks (U = V T' is precomputed per block); "
                                      "duration = HIP start/stop events bound to the dispatch (hipExtLaunchKernelGGL) on the "
                                      "launch stream; peak = f64 MFMA 78.6 TFLOP/s (public MI355X figure, = 64 cycles per "
                                      "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE x2 "

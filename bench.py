@@ -167,10 +167,11 @@ def _pmc_files(kind):
     return out
 
 
-def pmc_traffic_bytes(kernel_prefix, run="fetch"):
+def pmc_traffic_bytes(kernel_prefix, run="fetch", fetch_scale=2.0):
     """(HBM bytes per launch, source file) of a kernel from a committed PMC summary of THIS shape: rocprofv3 --pmc
-    FETCH_SIZE and WRITE_SIZE, each in its own pass, KB units; reads x2 (the gfx950 correction of MI355X_MICROARCH.md
-    for wide streaming reads) + writes as reported.  (None, None) when no summary of the running shape is committed."""
+    FETCH_SIZE and WRITE_SIZE, each in its own pass, KB units; reads x fetch_scale (2 = the gfx950 correction of
+    MI355X_MICROARCH.md for 16-byte-per-lane streaming reads; other widths have to be calibrated on a known byte count,
+    as that guide says) + writes as reported.  (None, None) when no summary of the running shape is committed."""
     for src, d in _pmc_files("hbm_traffic"):
         runs = d.get("runs", {})
         rd = runs.get(run)
@@ -179,7 +180,7 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch"):
         best, best_name = None, None
         for name, rec in rd.items():   # templated kernels are listed as "void jx::name<...>"; take the variant that ran longest
             if kernel_prefix in name:
-                b = 2.0 * rec["mean_KB"] * 1024.0
+                b = fetch_scale * rec["mean_KB"] * 1024.0
                 if best is None or b > best:
                     best, best_name = b, name
         if best is not None:
@@ -399,7 +400,9 @@ def main():
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
             # reflectors (one launch per decomposition; profiles/r02*_kernel_stats.csv)
             q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
-            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_reg_kernel")
+            # this kernel reads its rows 8 bytes per lane (16 lanes = one 128-byte line): calibrated on its known row bytes
+            # (n^3 / 8 = 1.00 TB at n = 20000 vs 1.02 TB raw FETCH_SIZE) the counter is exact here, not halved
+            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_reg_kernel", fetch_scale=1.0)
             mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_reg_kernel")
             roofline_main = {"bound": "mfma", "kernel": "sbback_apply_reg_kernel", "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
@@ -409,8 +412,9 @@ def main():
                                      "kernel issues (64 + 32) / 64 of them on the parallelogram blocks (U = V T' is precomputed per block); "
                                      "duration = HIP start/stop events bound to the dispatch (hipExtLaunchKernelGGL) on the "
                                      "launch stream; peak = f64 MFMA 78.6 TFLOP/s (public MI355X figure, = 64 cycles per "
-                                     "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE x2 "
-                                     "(gfx950 correction) + WRITE_SIZE, each in its own pass, per launch, from the committed "
+                                     "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE "
+                                     "(8-byte-per-lane row reads: counter calibrated exact on the known row bytes, no x2) + "
+                                     "WRITE_SIZE, each in its own pass, per launch, from the committed "
                                      "summary of this shape (algorithmic: every row of C read and written once per group of "
                                      "32 sweeps = 8 n^3 / 32 B); mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}
         else:

@@ -30,6 +30,13 @@ extern "C" {
 
 const char *jx_last_error(void);
 int jx_version(void);
+
+/* Progress hook of the host layer's row-block loops (jx_assoc_packed): `fn(done, total, user)` is called every `every` rows
+ * (every <= 0: once per internal block of 8192 rows) and at the end; a nonzero return stops the call, which then fails with
+ * "interrupted by the progress callback".  NULL clears the hook.  Replaces the `progress_callback` / `progress_every`
+ * arguments of the reference's PyO3 entry points (src/stats/lmm.rs:3059-3083, 3214-3330; src/stats/grm.rs:3485-3495). */
+typedef int (*jx_progress_fn)(int64_t done, int64_t total, void *user);
+int jx_set_progress(jx_progress_fn fn, void *user, int64_t every);
 int jxg_device_count(void);
 int jxg_set_device(int dev);
 /* device properties: out[0]=CU count, out[1]=clock kHz, out[2]=total HBM MiB, out[3]=LDS bytes/CU */
@@ -432,6 +439,10 @@ int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n_samples, c
  * Returns the number of rows written, -1 on error (jx_last_error). */
 int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
                            const float *af, const float *miss, const double *stats, int ncol);
+/* Same rows appended behind the present content of `path` (append != 0: no header): the block-wise writer of the
+ * streaming scan, counterpart of the reference's AsyncTsvWriter (src/stats/common.rs:374). */
+int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
+                           const float *af, const float *miss, const double *stats, int ncol, int append);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ c_f = C.c_float
 SIGNATURES = {
     "jx_last_error": [],
     "jx_version": [],
+    "jx_set_progress": [c_p, c_p, c_l],
     "jxg_device_count": [],
     "jxg_set_device": [c_i],
     "jxg_device_info": [c_p],
@@ -85,6 +86,7 @@ SIGNATURES = {
     "jxg_fvlmm_scan_dev": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
     "jxg_last_kernel_ms": [c_i],
     "jx_assoc_tsv_write": [C.c_char_p, c_p, c_p, c_l, c_p, c_p, c_p, c_i],
+    "jx_assoc_tsv_append": [C.c_char_p, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_i],
     "jx_row_counts": [c_p, c_l, c_i, c_p, c_i, c_p],
     "jx_grm_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
     "jx_grm_stream_payload_f32": [c_p, c_l, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p],
@@ -102,7 +104,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,
-             "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64}
+             "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
+             "jx_assoc_tsv_append": C.c_int64}
 
 
 def lib():

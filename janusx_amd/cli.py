@@ -144,7 +144,7 @@ def cmd_gwas(args):
     from . import janusx as jxrs
     from . import pipeline as pl
     from .bed import read_bed_payload, read_fam_ids
-    from .tsv import write_assoc_tsv
+    from .tsv import AsyncAssocTsvWriter, write_assoc_tsv
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
         raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm and/or -splmm")
     packed, n_fam, bim = read_bed_payload(args.bfile)
@@ -216,17 +216,30 @@ def cmd_gwas(args):
             x = np.concatenate([x, np.array([cv[cpos[fam[j]]] for j in keep_idx])], axis=1)
         for mode in (["lmm"] if args.lmm else []) + (["lmm2"] if args.lmm2 else []) + (["fvlmm"] if args.fvlmm else []):
             t1 = time.perf_counter()
-            res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het)
+            # rows are formatted and written block by block on a writer thread while the device scans the next block
+            # (src/stats/lmm.rs:975-1477 with its AsyncTsvWriter, src/stats/common.rs:374)
+            path = f"{out}.{name}.{mode}.tsv"
+            wr = {}
+
+            def open_writer(keep_mask, af_k, miss_k, ncol):
+                kept_rows = np.nonzero(keep_mask)[0]
+                wr["w"] = AsyncAssocTsvWriter(path, ncol, [bim.chrom[j] for j in kept_rows], [bim.pos[j] for j in kept_rows],
+                                              [bim.snp[j] for j in kept_rows], [bim.a0[j] for j in kept_rows],
+                                              [bim.a1[j] for j in kept_rows], af_k, miss_k)
+                return wr["w"].put
+
+            try:
+                res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het,
+                                   on_rows=open_writer)
+            finally:
+                if "w" in wr:
+                    wr["w"].close()
             # LMM -> LM fallback test (src/stats/gwas_unified.rs:121-175); the LM scan itself is out of scope
             sw, stat, pv, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x[:, 1:], res.null.ml0)
             if sw and not args.force_model:
                 print(f"[{name}] note: null LRT p={pv:.3g} >= 0.05 - the reference would switch to the plain LM scan "
                       f"here (not built); continuing with -{mode} as with -force-model")
             kept = np.nonzero(res.keep)[0]
-            path = f"{out}.{name}.{mode}.tsv"
-            write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
-                            [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
-                            res.af, res.miss, res.stats)
             print(f"[{name}] -{mode}: n={n} snps={len(kept)} lambda0={res.null.lbd:.5g} pve={res.null.pve:.4f} "
                   f"-> {path} ({time.perf_counter() - t1:.2f}s)")
         if sparse_path is not None:

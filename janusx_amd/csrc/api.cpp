@@ -173,6 +173,35 @@ using namespace jx;
 extern "C" const char *jx_last_error(void) { return g_err.c_str(); }
 extern "C" int jx_version(void) { return 100; }
 
+// ---- progress hook ------------------------------------------------------------------------------------------------------
+// The reference calls `progress_callback(done, total)` every `progress_every` rows (default: its rotate block) and lets a
+// Python exception raised there (KeyboardInterrupt) end the scan (src/stats/lmm.rs:3214-3330, src/stats/grm.rs:3485-3495).
+// The host layer's row-block loops report through this process-wide hook: `fn` returns nonzero to stop the call, which
+// then fails with "interrupted by the progress callback".  every <= 0: once per internal block.
+typedef int (*jx_progress_fn)(int64_t done, int64_t total, void *user);
+namespace {
+jx_progress_fn g_progress = nullptr;
+void *g_progress_user = nullptr;
+int64_t g_progress_every = 0;
+struct ProgressTicker {
+    int64_t last = 0;
+    // 0 = go on, 1 = the callback asked to stop
+    int tick(int64_t done, int64_t total, int64_t block) {
+        if (!g_progress) return 0;
+        const int64_t step = g_progress_every > 0 ? g_progress_every : block;
+        if (done < total && done < last + step) return 0;
+        last = done;
+        return g_progress(done, total, g_progress_user) != 0;
+    }
+};
+}  // namespace
+extern "C" int jx_set_progress(jx_progress_fn fn, void *user, int64_t every) {
+    g_progress = fn;
+    g_progress_user = user;
+    g_progress_every = every;
+    return 0;
+}
+
 extern "C" int jxg_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;
@@ -711,6 +740,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     DevBuf drows;
     if (drows.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
     std::vector<int32_t> hrows((size_t)brows);
+    ProgressTicker ticker;
     for (int64_t r0 = 0; r0 < m; r0 += brows) {
         const int rows = (int)std::min<int64_t>(brows, m - r0);
         for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
@@ -736,6 +766,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                 return 1;
         }
         JX_HIP(hipMemcpy(out + (size_t)r0 * cols, dout.p, sizeof(double) * (size_t)rows * cols, hipMemcpyDeviceToHost));
+        if (ticker.tick(r0 + rows, m, brows)) return fail("interrupted by the progress callback");
     }
     return 0;
 }
@@ -774,13 +805,23 @@ inline char *put_exp(char *o, double v, int prec) {
 }
 }  // namespace
 
+extern "C" int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
+                                       const float *af, const float *miss, const double *stats, int ncol, int append);
+
 extern "C" int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
                                       const float *af, const float *miss, const double *stats, int ncol) {
+    return jx_assoc_tsv_append(path, prefix_blob, prefix_off, rows, af, miss, stats, ncol, 0);
+}
+
+// append != 0: the rows go behind what `path` holds already, without a header (the block-wise writer of the streaming
+// scan: header + first block with append = 0, every later block with append = 1)
+extern "C" int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
+                                       const float *af, const float *miss, const double *stats, int ncol, int append) {
     if (ncol != 3 && ncol != 4 && ncol != 6) {
         fail("unsupported GWAS result column count: " + std::to_string(ncol) + " (expected 3, 4, or 6)");
         return -1;
     }
-    FILE *fh = fopen(path, "wb");
+    FILE *fh = fopen(path, append ? "ab" : "wb");
     if (!fh) {
         fail(std::string("cannot open ") + path + " for writing");
         return -1;
@@ -788,7 +829,7 @@ extern "C" int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob,
     static const char *h3 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\n";
     static const char *h4 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tplrt\n";
     static const char *h6 = "chrom\tpos\tsnp\tallele0\tallele1\taf\tmiss\tbeta\tse\tchisq\tpwald\tlambda\tml\tplrt\n";
-    fputs(ncol == 6 ? h6 : (ncol == 4 ? h4 : h3), fh);
+    if (!append) fputs(ncol == 6 ? h6 : (ncol == 4 ? h4 : h3), fh);
     std::vector<char> buf((size_t)1 << 20);
     size_t used = 0;
     const double min_pos = 2.2250738585072014e-308;

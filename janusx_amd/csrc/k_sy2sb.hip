@@ -26,7 +26,7 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
 
 constexpr int SB = 64;            // half bandwidth of the intermediate band matrix
 constexpr int SB_P = SB + 1;      // LDS pitch of the SB x SB work matrices
-constexpr int SB_FLAG_FAIL = 0, SB_FLAG_ZERO = 1;
+constexpr int SB_FLAG_FAIL = 0;
 
 // ---- tiny single-workgroup kernels on SB x SB matrices ------------------------------------------------------------
 // 256 threads hold a 64 x 64 matrix in registers, 4 x 4 elements each, cyclically: thread (ti, tk) = (t / 16, t % 16)

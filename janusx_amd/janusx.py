@@ -4,7 +4,9 @@ Every function here has the name, argument meaning, defaults and error behaviour
 replaces (signatures: /root/reference/src/lib.rs:691-1005 registrations, ``#[pyo3(signature=...)]`` at the cited
 lines) and forwards to the HIP library through the C ABI (``include/jxgpu.h``, host layer).  Arguments that only
 steer CPU threading in the reference (``threads``, ``block_cols``, ``rotate_block_rows``, ``mmap_window_mb``) are
-accepted and ignored; ``progress_callback(done, total)`` is called once at completion.
+accepted and ignored; ``progress_callback(done, total)`` follows the reference's cadence on the packed association
+scans (C-ABI hook `jx_set_progress`: every `progress_every` rows, default one 8192-row block; an exception raised by the
+callback stops the scan) and is called once at completion elsewhere.
 
 A reference call site such as ``jxrs.grm_packed_f32(packed, n, flip, maf, idx, method=1)`` works unchanged
 with ``import janusx_amd.janusx as jxrs``.
@@ -38,6 +40,36 @@ def _opt_idx(a):
 def _done(cb, total):
     if cb is not None:
         cb(int(total), int(total))
+
+
+class _progress_hook:
+    """Installs `progress_callback(done, total)` as the C-ABI progress hook for the duration of one host-layer call
+    (the reference's cadence: every `progress_every` rows, default one internal block; src/stats/lmm.rs:3214-3330).  An
+    exception raised by the callback (KeyboardInterrupt included) stops the native loop and is re-raised here."""
+    _CB = C.CFUNCTYPE(C.c_int, C.c_int64, C.c_int64, C.c_void_p)
+
+    def __init__(self, cb, every):
+        self.cb, self.every, self.exc, self.fn = cb, int(every or 0), None, None
+
+    def __enter__(self):
+        if self.cb is not None:
+            def tramp(done, total, _user):
+                try:
+                    self.cb(int(done), int(total))
+                    return 0
+                except BaseException as e:      # noqa: BLE001 - handed back to the caller of the native function
+                    self.exc = e
+                    return 1
+            self.fn = self._CB(tramp)
+            lib().jx_set_progress(self.fn, None, self.every)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.cb is not None:
+            lib().jx_set_progress(None, None, 0)
+        if self.exc is not None:
+            raise self.exc
+        return False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -951,7 +983,7 @@ def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_i
 
 
 def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
-                  low, high, max_iter, tol, warm, init, nullml=None):
+                  low, high, max_iter, tol, warm, init, nullml=None, progress_callback=None, progress_every=0):
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
     packed = _c(packed, np.uint8)
     if row_indices is not None:
@@ -968,10 +1000,11 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
     if n_eff != n:
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
     out = np.zeros((m, 6 if int(model) == 2 else (4 if nullml is not None else 3)), dtype=np.float64)
-    check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
-                                _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
-                                int(warm), float(init), 1 if nullml is not None else 0,
-                                float(nullml if nullml is not None else 0.0), _p(out)))
+    with _progress_hook(progress_callback, progress_every):
+        check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
+                                    _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
+                                    int(warm), float(init), 1 if nullml is not None else 0,
+                                    float(nullml if nullml is not None else 0.0), _p(out)))
     return out
 
 
@@ -994,10 +1027,8 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     warm, init = 0, 0.0
     if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
         warm, init = 1, float(min(max(init_log10_lbd, low), high))
-    out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
-                        low, high, max_iter, tol, warm, init, nullml)
-    _done(progress_callback, out.shape[0])
-    return out
+    return _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
+                         low, high, max_iter, tol, warm, init, nullml, progress_callback, progress_every)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1037,10 +1068,9 @@ def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot,
                            progress_every=0, rotate_block_rows=512, nullml=None):
     """Array-returning core of `fvlmm_assoc_packed_f32_to_tsv` (src/stats/fvlmm.rs:4958-5190) with a
     caller-rotated null model -> f64 (m, 3 or 4)."""
-    out = _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 1,
-                        float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0, nullml)
-    _done(progress_callback, out.shape[0])
-    return out
+    return _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 1,
+                         float(log10_lbd), float(log10_lbd) + 1.0, 0, 1e-2, 0, 0.0, nullml, progress_callback,
+                         progress_every)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1060,7 +1090,7 @@ def bed_row_counts(packed, n_samples, sample_indices=None):
 
 def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model, snps_only,
                      sample_ids, row_indices, row_flip, row_missing, row_maf, mode, low, high, max_iter, tol, nullml,
-                     init_log10_lbd, progress_callback):
+                     init_log10_lbd, progress_callback, progress_every=0):
     from . import stats as st
     from .bed import read_bed_payload, read_fam_ids, snps_only_mask
     from .tsv import write_assoc_tsv
@@ -1108,23 +1138,22 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init,
-                            nullml)
+                            nullml, progress_callback, progress_every)
     elif mode == "lmm2":
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 2, low, high, max_iter, tol, warm, init,
-                            nullml)
+                            nullml, progress_callback, progress_every)
     else:
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 1, float(low), float(low) + 1.0, 0,
-                            1e-2, 0, 0.0, nullml)
+                            1e-2, 0, 0.0, nullml, progress_callback, progress_every)
     chrom = [bim.chrom[j] for j in rows]
     posv = [bim.pos[j] for j in rows]
     snp = [bim.snp[j] for j in rows]
     a0 = [bim.a0[j] for j in rows]
     a1 = [bim.a1[j] for j in rows]
     written = write_assoc_tsv(out_tsv, chrom, posv, snp, a0, a1, af, miss, res)
-    _done(progress_callback, m)
     return written
 
 
@@ -1141,7 +1170,7 @@ def lmm_reml_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_
         raise RuntimeError("tol must be positive and finite")
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm", low, high,
-                            max_iter, tol, nullml, init_log10_lbd, progress_callback)
+                            max_iter, tol, nullml, init_log10_lbd, progress_callback, progress_every)
 
 
 def lmm_reml_lmm2_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, nullml, max_iter=50, tol=1e-2,
@@ -1196,7 +1225,7 @@ def lmm_reml_lmm2_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t,
     init_scan = init_log10_lbd_reml if init_log10_lbd_reml is not None else init_log10_lbd_ml
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm2", low, high,
-                            max_iter, tol, nullml_val, init_scan, progress_callback)
+                            max_iter, tol, nullml_val, init_scan, progress_callback, progress_every)
 
 
 def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u_t, maf_thr, miss_thr, het_thr,
@@ -1206,7 +1235,7 @@ def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u
     """src/stats/fvlmm.rs:2482-2526 (the default `jx gwas -fvlmm` kernel call) -> (rows, pve, log_det_v)."""
     rows = _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "fvlmm",
-                            float(log10_lbd), None, 0, 1e-2, nullml, None, progress_callback)
+                            float(log10_lbd), None, 0, 1e-2, nullml, None, progress_callback, progress_every)
     s_ = np.asarray(s, dtype=np.float64).ravel()
     lbd = 10.0 ** float(log10_lbd)
     vg = float(np.mean(np.clip(s_, 0.0, None)))
@@ -1222,8 +1251,8 @@ def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_m
     """src/stats/lmm.rs:3364-3790 -> rows written (metadata lists empty => read the BIM via `bed_prefix`)."""
     from .tsv import write_assoc_tsv
     out = lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices,
-                                    row_indices, low, high, max_iter, tol, threads, model, None, 0, nullml,
-                                    init_log10_lbd, rotate_block_rows)
+                                    row_indices, low, high, max_iter, tol, threads, model, progress_callback,
+                                    progress_every, nullml, init_log10_lbd, rotate_block_rows)
     m = out.shape[0]
     if not len(chrom):
         if not bed_prefix:
@@ -1238,7 +1267,6 @@ def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_m
         allele1 = [bim.a1[j] for j in sel]
     written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
                               np.asarray(row_missing, dtype=np.float32), out)
-    _done(progress_callback, m)
     return written
 
 
@@ -1336,7 +1364,8 @@ def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_miss
         raise RuntimeError("invalid fixed lambda in packed fvlmm")
     out = _assoc_packed(packed, n_samples, row_flip, row_maf, s_vec, x_rot, y_rot, u_t,
                         None if sample_indices is None else sidx, row_indices, 1, math.log10(lbd),
-                        math.log10(lbd) + 1.0, 0, 1e-2, 0, 0.0, float(fixed_ml0) if with_plrt else None)
+                        math.log10(lbd) + 1.0, 0, 1e-2, 0, 0.0, float(fixed_ml0) if with_plrt else None,
+                        progress_callback, progress_every)
     if not len(chrom):
         if not bed_prefix:
             raise RuntimeError("metadata lists are empty and bed_prefix is not set")
@@ -1350,7 +1379,6 @@ def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_miss
         allele1 = [bim.a1[j] for j in sel]
     write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
                     np.asarray(row_missing, dtype=np.float32), out)
-    _done(progress_callback, m)
     return float(lbd), float(ml0), float(reml0)
 
 

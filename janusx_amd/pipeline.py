@@ -295,7 +295,7 @@ class SpectralModel:
 
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
-              times: StageTimes = None, nullml=None, fv_state=None):
+              times: StageTimes = None, nullml=None, fv_state=None, on_block=None):
     """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML), 'fvlmm' (fixed lambda) or 'lmm2' (REML Wald +
     ML likelihood ratio, needs `nullml`).  Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns
     [.., plrt] when `nullml` is given, 6 columns [beta, se, pwald, lambda, ml, plrt] for 'lmm2' -- (and the per-SNP
@@ -356,6 +356,16 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     grots = [torch.empty((br, n), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     ev_rot = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((mk + br - 1) // br)]
     ev_scan = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(len(ev_rot))]
+    pending = None          # (i0, i1, event recorded behind the block's scan)
+    copy_stream = torch.cuda.Stream(device=dev) if on_block is not None else None
+
+    def hand_over(item):
+        i0, i1, ev = item
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev)
+            host = out[i0:i1].to("cpu", non_blocking=False)
+        on_block(i0, host.numpy())
+
     for bi, r0 in enumerate(range(0, mk, br)):
         nr = min(br, mk - r0)
         grot = grots[bi % nbuf]
@@ -389,6 +399,14 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                            ypy, df, with_plrt, nullml_v, log_det_v, o.data_ptr(), _stream()))
         if times is not None:
             ev_scan[bi][1].record()
+        if on_block is not None:
+            done = torch.cuda.Event()
+            done.record()
+            if pending is not None:
+                hand_over(pending)       # the previous block, while this one runs
+            pending = (r0, r0 + nr, done)
+    if pending is not None:
+        hand_over(pending)
     if times is not None:
         torch.cuda.synchronize()
         times.add("rotate", sum(a.elapsed_time(b) for a, b in ev_rot) * 1e-3)
@@ -428,10 +446,12 @@ def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.0
 
 
 def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y: np.ndarray, x: np.ndarray,
-              mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False):
+              mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False, on_rows=None):
     """One trait of `run_chunked_gwas_lmm_lm` (python/janusx/assoc/workflow_model_stream.py:464-1480):
     eigh of K[keep, keep] + 1e-6 I, spectral null model, QC on the trait's samples, rotate + scan.
-    `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order)."""
+    `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order).
+    `on_rows(keep, af, miss, ncol)` (optional) is called once the kept SNP set is known and returns the `on_block`
+    callback of `scan_rows` (or None): the streaming writer is opened there."""
     keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
     s, ut64 = eigh_from_grm(k, 1e-6, keep_idx)
     model = SpectralModel(s, ut64, x, y)
@@ -442,11 +462,12 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
     rows = np.nonzero(keep)[0]
     lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
+    on_block = on_rows(keep, af[rows], miss[rows], 6 if mode == "lmm2" else 3) if on_rows is not None else None
     if mode == "lmm":
         init = math.log10(model.null.lbd) if (warm_start and model.null.lbd > 0) else None
         if init is not None:
             init = min(max(init, model.null.bounds[0]), model.null.bounds[1])
-        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init)
+        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init, on_block=on_block)
     elif mode == "lmm2":
         # null ML by Brent on -ml_loglike, seeded with the REML optimum (src/stats/lmm.rs:2902-2921; the workflow passes
         # bounds, max_iter = 30, tol = 1e-2 and init_log10_lbd_reml = log10 lambda0: workflow_model_stream.py:1499-1590)
@@ -459,9 +480,10 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
         ml0 = float(o2.cpu().numpy()[1])
         if not math.isfinite(ml0):
             raise RuntimeError("failed to optimize null ML for LMM2 unified scan")
-        out = scan_rows(panel, model, rows, lut, "lmm2", max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=ml0)
+        out = scan_rows(panel, model, rows, lut, "lmm2", max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=ml0,
+                        on_block=on_block)
     else:
-        out = scan_rows(panel, model, rows, lut, "fvlmm")
+        out = scan_rows(panel, model, rows, lut, "fvlmm", on_block=on_block)
     return GwasResult(keep, af[rows], miss[rows], out.cpu().numpy(), model.null, 0, {})
 
 

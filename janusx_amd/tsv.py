@@ -85,12 +85,11 @@ def write_assoc_tsv_python(path, chrom, pos, snp, a0, a1, af, miss, stats) -> in
     return int(stats.shape[0])
 
 
-def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
-    """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
-    The numeric columns are formatted and written by the native writer (`jx_assoc_tsv_write`, the counterpart of the
-    reference's Rust formatter, src/io/assoc2tsv.rs:430-548); only the per-row `chrom pos snp a0 a1` prefix is put
-    together here.  Returns rows written."""
+def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append) -> int:
+    import ctypes as C
+
     import numpy as np
+
     from ._lib import lib
     stats = np.ascontiguousarray(stats, dtype=np.float64)
     if stats.ndim != 2 or stats.shape[1] not in (3, 4, 6):
@@ -107,12 +106,84 @@ def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
     miss32 = np.ascontiguousarray(miss, dtype=np.float32)
     if af32.shape[0] < rows or miss32.shape[0] < rows:
         raise RuntimeError("af / miss shorter than the result table")
-    tmp = f"{path}.tmp.{os.getpid()}"
-    import ctypes as C
-    written = lib().jx_assoc_tsv_write(tmp.encode(), C.cast(C.c_char_p(blob), C.c_void_p), off.ctypes.data, rows,
-                                       af32.ctypes.data, miss32.ctypes.data, stats.ctypes.data, int(stats.shape[1]))
+    written = lib().jx_assoc_tsv_append(tmp.encode(), C.cast(C.c_char_p(blob), C.c_void_p), off.ctypes.data, rows,
+                                        af32.ctypes.data, miss32.ctypes.data, stats.ctypes.data, int(stats.shape[1]),
+                                        1 if append else 0)
     if written < 0:
         msg = lib().jx_last_error()
-        raise RuntimeError(msg.decode("utf-8", "replace") if msg else "jx_assoc_tsv_write failed")
-    os.replace(tmp, path)
+        raise RuntimeError(msg.decode("utf-8", "replace") if msg else "jx_assoc_tsv_append failed")
     return int(written)
+
+
+def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
+    """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
+    The numeric columns are formatted and written by the native writer (`jx_assoc_tsv_append`, the counterpart of the
+    reference's Rust formatter, src/io/assoc2tsv.rs:430-548); only the per-row `chrom pos snp a0 a1` prefix is put
+    together here.  Returns rows written."""
+    tmp = f"{path}.tmp.{os.getpid()}"
+    written = _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, False)
+    os.replace(tmp, path)
+    return written
+
+
+class AsyncAssocTsvWriter:
+    """Block-wise writer on its own thread, the counterpart of the reference's `AsyncTsvWriter` (src/stats/common.rs:374)
+    behind its streaming scan (src/stats/lmm.rs:975-1477): `put(i0, stats_block)` hands the scan results of the kept rows
+    [i0, i0 + len) over and returns at once; the thread builds the row prefixes and calls the native formatter (which
+    releases the GIL) while the device scans the next block.  `close()` waits, renames the temp file and returns the row
+    count; an error on the thread is raised there (and by the next `put`)."""
+
+    def __init__(self, path, ncol, chrom, pos, snp, a0, a1, af, miss, depth=4):
+        import queue
+        import threading
+        if ncol not in (3, 4, 6):
+            raise RuntimeError(f"unsupported GWAS result column count: {ncol} (expected 3, 4, or 6)")
+        self.path, self.ncol = path, int(ncol)
+        self.meta = (chrom, pos, snp, a0, a1, af, miss)
+        self.tmp = f"{path}.tmp.{os.getpid()}"
+        self.rows, self.err, self.first = 0, None, True
+        self.q = queue.Queue(maxsize=depth)
+        self.th = threading.Thread(target=self._run, name="jx-tsv-writer", daemon=True)
+        self.th.start()
+
+    def _run(self):
+        chrom, pos, snp, a0, a1, af, miss = self.meta
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.err is not None:
+                continue                      # drain after a failure
+            i0, st = item
+            i1 = i0 + st.shape[0]
+            try:
+                self.rows += _native_rows(self.tmp, chrom[i0:i1], pos[i0:i1], snp[i0:i1], a0[i0:i1], a1[i0:i1],
+                                          af[i0:i1], miss[i0:i1], st, not self.first)
+                self.first = False
+            except BaseException as e:        # noqa: BLE001 - reported by put() / close()
+                self.err = e
+
+    def put(self, i0, stats_block):
+        import numpy as np
+        if self.err is not None:
+            raise self.err
+        st = np.array(stats_block, dtype=np.float64, copy=True)
+        if st.ndim != 2 or st.shape[1] != self.ncol:
+            raise RuntimeError(f"result block has {st.shape} columns, the writer was opened for {self.ncol}")
+        self.q.put((int(i0), st))
+
+    def close(self) -> int:
+        import numpy as np
+        self.q.put(None)
+        self.th.join()
+        if self.err is not None:
+            try:
+                os.remove(self.tmp)
+            except OSError:
+                pass
+            raise self.err
+        if self.first:                        # no block at all: header only
+            _native_rows(self.tmp, [], [], [], [], [], np.zeros(0, np.float32), np.zeros(0, np.float32),
+                         np.zeros((0, self.ncol)), False)
+        os.replace(self.tmp, self.path)
+        return self.rows

@@ -237,3 +237,21 @@ def test_native_tsv_writer_matches_the_row_format(tmp_path):
         assert open(a).read() == open(b).read()
     with pytest.raises(RuntimeError, match="column count"):
         tsv.write_assoc_tsv(str(tmp_path / "c.tsv"), chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss, stats[:, :5])
+    # block-wise writer thread (streaming scan): ragged blocks, same bytes; no block at all -> header only; a wrong block
+    # shape is refused; nothing is left behind under the final name before close()
+    for nc in (3, 6):
+        c, b = str(tmp_path / f"s{nc}.tsv"), str(tmp_path / f"b{nc}.tsv")
+        w = tsv.AsyncAssocTsvWriter(c, nc, chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss)
+        i0 = 0
+        for ln in (1, 700, 1, 1298, 1000):
+            w.put(i0, stats[i0:i0 + ln, :nc])
+            i0 += ln
+        assert not os.path.exists(c)
+        assert w.close() == n and open(c).read() == open(b).read()
+    e = str(tmp_path / "empty.tsv")
+    assert tsv.AsyncAssocTsvWriter(e, 3, [], [], [], [], [], af[:0], miss[:0]).close() == 0
+    assert open(e).read() == tsv.HEADER3
+    w = tsv.AsyncAssocTsvWriter(str(tmp_path / "bad.tsv"), 3, chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss)
+    with pytest.raises(RuntimeError, match="columns"):
+        w.put(0, stats[:10, :4])
+    w.close()

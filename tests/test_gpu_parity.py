@@ -327,6 +327,25 @@ def test_assoc_packed(oracle, oracle_c, null_case):
     fout = jxrs.fvlmm_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, math.log10(nm.lbd_null))
     be, se, pe = _assoc_err(fout, fref)
     assert max(be, se, pe) < TOL, (be, se, pe)
+    # progress cadence of the reference (src/stats/lmm.rs:3214-3330): (done, total) after every block, the last call with
+    # done == total; an exception raised by the callback ends the scan and reaches the caller
+    big = np.ascontiguousarray(np.tile(pk, (20000 // len(pk) + 1, 1))[:20000])
+    seen = []
+    outb = jxrs.lmm_reml_assoc_packed_f32(big, n, np.resize(flip_k, 20000), np.resize(maf_k, 20000), nm.S, nm.Xcov, nm.y,
+                                          nm.Dh, progress_callback=lambda d, t: seen.append((d, t)))
+    assert seen == [(8192, 20000), (16384, 20000), (20000, 20000)], seen
+    assert np.array_equal(outb[:len(pk)], out, equal_nan=True)
+    seen.clear()
+    jxrs.lmm_reml_assoc_packed_f32(big, n, np.resize(flip_k, 20000), np.resize(maf_k, 20000), nm.S, nm.Xcov, nm.y, nm.Dh,
+                                   progress_callback=lambda d, t: seen.append(d), progress_every=16000)
+    assert seen == [16384, 20000], seen
+
+    def stop(done, total):
+        raise KeyboardInterrupt
+    with pytest.raises(KeyboardInterrupt):
+        jxrs.lmm_reml_assoc_packed_f32(big, n, np.resize(flip_k, 20000), np.resize(maf_k, 20000), nm.S, nm.Xcov, nm.y,
+                                       nm.Dh, progress_callback=stop)
+    jxrs.lmm_reml_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh)     # the hook is cleared afterwards
 
 
 def test_scan_exact_design_rows(oracle, oracle_c):

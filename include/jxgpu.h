@@ -409,6 +409,16 @@ int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, 
                          const double *y_train, const int64_t *test_idx, int n_test, double lambda_value, double tol,
                          int max_iter, float *out_beta, double *out_pred_train, double *out_pred_test,
                          double *out_scalars);
+/* Exact marker-space rrBLUP on a resident payload: `rrblup_exact_snp_packed` (src/stats/rrblup.rs:3179-3490; cache
+ * :1613-1899, fit :1951-2430).  A* = Z Z' - rs rs' / n_train over the training samples (f64), eigendecomposition, Brent on the
+ * REML cost of the spectrum (:1568-1611) over log10 lambda in [low, high], beta = V diag(1 / (s + lambda)) V' Z y_c,
+ * predictions alpha + Z' beta.  value_lut / row_indices / indices as for jx_rrblup_pcg_packed.  out_scalars (8):
+ * pve_trainvar, lambda, REML, var_g, sigma_e2, rank, intercept alpha, mean of y_train. */
+int jx_rrblup_exact_snp_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
+                               int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
+                               const double *y_train, const int64_t *test_idx, int n_test, double log10_lambda_low,
+                               double log10_lambda_high, double reml_tol, int reml_max_iter, float *out_beta,
+                               double *out_pred_train, double *out_pred_test, double *out_scalars);
 
 /* `spgrm_packed_to_jxgrm` (src/stats/spgrm.rs:5201-5278 -> `spgrm_packed_to_jxgrm_core` :3769-3908) and, with
  * stream_denominator != 0, the stream core behind `spgrm_bed_to_jxgrm` (:3910-4264: denominator = sum of 2p(1-p) in

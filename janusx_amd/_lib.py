@@ -99,6 +99,8 @@ SIGNATURES = {
     "jx_spgrm_packed_to_jxgrm": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_i, c_i, C.c_char_p, c_p, c_p],
     "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
+    "jx_rrblup_exact_snp_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_p,
+                                   c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
 }

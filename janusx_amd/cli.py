@@ -15,8 +15,9 @@ Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm.tsv` (`g
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
 python/janusx/gs/workflow.py:9122) are built; VCF/HMP readers, PCs (-q), plots, the history DB, the
-other GS model families and the exact (SNP-spectral) rrBLUP route are out of scope; `-rrBLUP` runs the PCG route
-(`rrblup_pcg_bed`) with a manual or subsample-REML lambda.
+other GS model families are out of scope; `-rrBLUP` runs the exact marker-space route (`rrblup_exact_snp_packed`, REML
+lambda from the spectrum) up to 15 000 kept markers and the PCG route (`rrblup_pcg_bed`, HE / manual / subsample-REML
+lambda) beyond, `-rr-solver exact|pcg` forces one.
 """
 from __future__ import annotations
 
@@ -336,7 +337,8 @@ def cmd_gs(args):
 
 
 def cmd_gs_rrblup(args):
-    """`jx gs -rrBLUP`: marker effects of the standardised genotypes by PCG over the packed payload
+    """`jx gs -rrBLUP`: marker effects of the standardised genotypes, by the exact marker-space route
+    (`rrblup_exact_snp_packed`, src/stats/rrblup.rs:3179-3490) or by PCG over the packed payload
     (`rrblup_pcg_bed`, src/stats/rrblup.rs:3494-4307; the route python/janusx/gs/blup.py:146-163 takes for large n
     and m).  lambda (equation scale, sigma_e^2 / sigma_beta^2) is `-lambda` when given; otherwise
     m_effective * sigma_e^2 / sigma_g^2 from the spectral GBLUP REML of a random subsample of at most 2000 training
@@ -352,7 +354,13 @@ def cmd_gs_rrblup(args):
     packed, miss, maf, _std, n_all = jxrs.load_bed_2bit_packed(args.bfile)
     flip = jxrs.bed_packed_row_flip_mask(packed, n_all)
     keep = (maf >= np.float32(args.maf)) & (miss <= np.float32(args.geno))
-    print(f"rrBLUP-PCG: n={n_all} m={packed.shape[0]} kept={int(keep.sum())} (maf {args.maf}, geno {args.geno})")
+    # solver choice of the reference (`_resolve_rrblup_solver`, python/janusx/gs/workflow.py:5230-5255): up to 15 000 markers
+    # the exact marker-space route (REML lambda from the spectrum); beyond that PCG for n_train > 10 000 -- and here also
+    # for smaller n_train, where the reference takes its sample-space exact route (not built)
+    solver = args.rr_solver
+    if solver == "auto":
+        solver = "exact" if int(keep.sum()) <= 15000 else "pcg"
+    print(f"rrBLUP-{solver.upper()}: n={n_all} m={packed.shape[0]} kept={int(keep.sum())} (maf {args.maf}, geno {args.geno})")
     for ti in traits:
         name = names[ti]
         yv = np.array([ph[pos[s], ti] if s in pos else np.nan for s in fam])
@@ -362,7 +370,9 @@ def cmd_gs_rrblup(args):
             print(f"[{name}] only {len(train)} phenotyped samples, skipped")
             continue
         t1 = time.perf_counter()
-        if args.lam is not None:
+        if solver == "exact":
+            lam, src = None, "REML on the spectrum"
+        elif args.lam is not None:
             lam, src = float(args.lam), "manual"
         elif not args.lambda_reml:
             # Haseman-Elston first (python/janusx/gs/workflow.py:5564 `he_first`): lambda_equation = lambda_k * m_effective
@@ -379,7 +389,7 @@ def cmd_gs_rrblup(args):
                     lam, src = None, "HE on the boundary"
         else:
             lam, src = None, ""
-        if lam is None:
+        if lam is None and solver != "exact":
             rng = np.random.default_rng(args.seed)
             sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
             ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
@@ -393,6 +403,9 @@ def cmd_gs_rrblup(args):
         pred = np.full(n_all, np.nan)
 
         def fit_predict(tr, te):
+            if solver == "exact":
+                return jxrs.rrblup_exact_snp_packed(packed, n_all, tr, yv[tr], te if len(te) else None, site_keep=keep,
+                                                    maf=maf, row_flip=flip)
             return jxrs.rrblup_pcg_bed("", tr, yv[tr], te if len(te) else None, site_keep=keep, lambda_value=lam,
                                        tol=args.tol, max_iter=args.max_iter, packed=packed, packed_n_samples=n_all,
                                        maf=maf, row_flip=flip)
@@ -422,9 +435,14 @@ def cmd_gs_rrblup(args):
                 obs = "NA" if not math.isfinite(yv[j]) else f"{yv[j]:.6g}"
                 fh.write(f"{sid}\t{obs}\t{pred[j]:.6g}\t{'NA' if fold[j] < 0 else fold[j]}\n")
         os.replace(tmp, path)
-        print(f"[{name}] rrBLUP-PCG: n_train={len(train)} n_pred={len(test)} lambda={lam:.5g} [{src}] "
-              f"converged={full[3]} iters={full[4]} rel_res={full[5]:.3g} m_effective={full[6]} "
-              f"pve={full[7]:.4f} -> {path} ({time.perf_counter() - t1:.2f}s)")
+        if solver == "exact":
+            print(f"[{name}] rrBLUP-EXACT: n_train={len(train)} n_pred={len(test)} lambda={full[3]:.5g} [{src}] "
+                  f"reml={full[4]:.6g} var_g={full[5][0]:.5g} sigma_e2={full[5][1]:.5g} m_effective={full[6]} "
+                  f"pve={full[2]:.4f} -> {path} ({time.perf_counter() - t1:.2f}s)")
+        else:
+            print(f"[{name}] rrBLUP-PCG: n_train={len(train)} n_pred={len(test)} lambda={lam:.5g} [{src}] "
+                  f"converged={full[3]} iters={full[4]} rel_res={full[5]:.3g} m_effective={full[6]} "
+                  f"pve={full[7]:.4f} -> {path} ({time.perf_counter() - t1:.2f}s)")
     return 0
 
 
@@ -469,6 +487,8 @@ def main(argv=None):
     q.add_argument("-BLUP", "--BLUP", dest="blup", action="store_true", default=False)
     q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
     q.add_argument("-rrBLUP", "--rrBLUP", dest="rrblup", action="store_true", default=False)
+    q.add_argument("-rr-solver", "--rr-solver", dest="rr_solver", choices=["auto", "exact", "pcg"], default="auto",
+                   help="rrBLUP: exact marker-space route (auto up to 15000 kept markers) or PCG")
     q.add_argument("-lambda", "--lambda", dest="lam", type=float, default=None)
     q.add_argument("-lambda-reml", "--lambda-reml", dest="lambda_reml", action="store_true", default=False,
                    help="rrBLUP: take lambda from the subsample GBLUP REML instead of Haseman-Elston")

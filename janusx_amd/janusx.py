@@ -1841,6 +1841,131 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
             iters, rel_res, m_effective, pve_lambda_vc, k_trace_mean, beta)
 
 
+def rrblup_exact_snp_packed(packed, n_samples, train_sample_indices, y_train, test_sample_indices=None,
+                            train_pred_local_indices=None, site_keep=None, maf=None, row_flip=None, row_mean=None,
+                            row_inv_sd=None, log10_lambda_low=-6.0, log10_lambda_high=6.0, reml_tol=1e-4, reml_max_iter=50,
+                            sample_block=2048, std_eps=1e-12, threads=0, blas_threads=0):
+    """src/stats/rrblup.rs:3157-3490.  Exact marker-space rrBLUP (the reference's route up to 15 000 markers): SNP-space
+    Gram matrix of the standardised training genotypes, eigendecomposition, REML over log10 lambda by Brent on the
+    spectrum, marker effects and predictions — all on the device (`jx_rrblup_exact_snp_packed`).  Returns the reference's
+    tuple (pred_train (k,1), pred_test (t,1), pve_trainvar, lambda, reml, (var_g, sigma_e2), m_effective, y_mean,
+    beta f32 (m), row_mean f32 (m), row_inv_sd f32 (m), eigensolver name).  `sample_block`, `threads`, `blas_threads` are
+    accepted and ignored."""
+    import math
+    n_samples = int(n_samples)
+    if n_samples == 0:
+        raise RuntimeError("n_samples must be > 0")
+    if not (math.isfinite(log10_lambda_low) and math.isfinite(log10_lambda_high)):
+        raise RuntimeError("rrblup_exact_snp_packed requires finite log10(lambda) bounds.")
+    if not (math.isfinite(reml_tol) and reml_tol > 0.0):
+        raise RuntimeError("rrblup_exact_snp_packed requires finite reml_tol > 0.")
+    if int(reml_max_iter) == 0:
+        raise RuntimeError("rrblup_exact_snp_packed requires reml_max_iter > 0.")
+    if not (math.isfinite(std_eps) and std_eps > 0.0):
+        raise RuntimeError("rrblup_exact_snp_packed requires finite std_eps > 0.")
+    f32 = np.float32
+    pk = _c(packed, np.uint8)
+    if pk.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp).")
+    m_total = int(pk.shape[0])
+    if pk.shape[1] != (n_samples + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1]}, expected {(n_samples + 3) // 4}")
+    if maf is None:
+        raise RuntimeError("rrblup_exact_snp_packed requires `maf` argument.")
+    if row_flip is None:
+        raise RuntimeError("rrblup_exact_snp_packed requires `row_flip` argument.")
+    maf_full = _c(maf, f32).ravel()
+    if maf_full.shape[0] != m_total:
+        raise RuntimeError(f"maf length mismatch: got {maf_full.shape[0]}, expected {m_total}")
+    flip_full = np.asarray(row_flip).astype(bool).ravel()
+    if flip_full.shape[0] != m_total:
+        raise RuntimeError(f"row_flip length mismatch: got {flip_full.shape[0]}, expected {m_total}")
+    rows = None
+    maf_keep, flip_keep = maf_full, flip_full
+    if site_keep is not None:
+        mask = np.asarray(site_keep).astype(bool).ravel()
+        if mask.shape[0] != m_total:
+            raise RuntimeError(f"site_keep length mismatch: got {mask.shape[0]}, expected {m_total}")
+        keep_idx = np.nonzero(mask)[0].astype(np.int64)
+        if keep_idx.shape[0] == 0:
+            raise RuntimeError("No SNPs remained after applying site_keep mask.")
+        if keep_idx.shape[0] != m_total:
+            rows = keep_idx
+            maf_keep = np.clip(maf_full[keep_idx], f32(0.0), f32(0.5)).astype(f32)
+            flip_keep = flip_full[keep_idx]
+    eff_m = int(maf_keep.shape[0])
+    if eff_m == 0:
+        raise RuntimeError("rrblup_exact_snp_packed received zero active markers.")
+    tr = _c(train_sample_indices, np.int64).ravel()
+    if tr.size and (tr.min() < 0 or tr.max() >= n_samples):
+        raise RuntimeError("train_sample_indices out of range")
+    n_train = int(tr.shape[0])
+    if n_train <= 1:
+        raise RuntimeError("rrblup_exact_snp_packed requires at least two training samples.")
+    y = _c(y_train, np.float64).ravel()
+    if y.shape[0] != n_train:
+        raise RuntimeError(f"y_train length mismatch: got {y.shape[0]}, expected {n_train}")
+    if not np.all(np.isfinite(y)):
+        raise RuntimeError("y_train contains non-finite values.")
+    te = np.zeros(0, dtype=np.int64) if test_sample_indices is None else _c(test_sample_indices, np.int64).ravel()
+    if te.size and (te.min() < 0 or te.max() >= n_samples):
+        raise RuntimeError("test_sample_indices out of range")
+    pick = None
+    if train_pred_local_indices is not None:
+        pick = _c(train_pred_local_indices, np.int64).ravel()
+        if pick.size and (pick.min() < 0 or pick.max() >= n_train):
+            raise RuntimeError("train_pred_local_indices out of range")
+    std_eps32 = f32(max(float(std_eps), 1e-12))
+    # row standardisation (`rrblup_subset_or_validate_stats`, rrblup.rs:568-625)
+    if (row_mean is None) != (row_inv_sd is None):
+        raise RuntimeError("rrBLUP standardization requires row_mean and row_inv_sd together when overriding row stats.")
+    if row_mean is not None:
+        rm = _c(row_mean, f32).ravel()
+        ri = _c(row_inv_sd, f32).ravel()
+        if rm.shape[0] == eff_m and ri.shape[0] == eff_m:
+            pass
+        elif rm.shape[0] == m_total and ri.shape[0] == m_total and rows is not None:
+            rm, ri = rm[rows], ri[rows]
+        else:
+            raise RuntimeError(f"External row_mean/row_inv_sd length mismatch: mean={rm.shape[0]}, inv={ri.shape[0]}, "
+                               f"expected active={eff_m} or full={m_total}.")
+        m_effective = int(np.count_nonzero(np.isfinite(ri) & (ri > 0)))
+    else:
+        pq = np.clip(maf_keep, f32(0.0), f32(0.5)).astype(f32)
+        rm = (f32(2.0) * pq).astype(f32)
+        var = np.maximum((f32(2.0) * pq * (f32(1.0) - pq)).astype(f32), f32(0.0))
+        good = var > std_eps32
+        ri = np.zeros_like(var)
+        ri[good] = (f32(1.0) / np.sqrt(var[good])).astype(f32)
+        m_effective = int(np.count_nonzero(good))
+    if m_effective == 0:
+        raise RuntimeError("rrblup_exact_snp_packed found zero effective markers after standardization.")
+    g0 = np.where(flip_keep, f32(2.0), f32(0.0)).astype(f32)
+    g2 = np.where(flip_keep, f32(0.0), f32(2.0)).astype(f32)
+    lut = np.zeros((eff_m, 4), dtype=f32)
+    lut[:, 0] = (g0 - rm) * ri
+    lut[:, 2] = (f32(1.0) - rm) * ri
+    lut[:, 3] = (g2 - rm) * ri
+    beta = np.zeros(eff_m, dtype=f32)
+    need_train = pick is None or pick.size > 0
+    pred_tr_full = np.zeros(n_train, dtype=np.float64) if need_train else None
+    pred_te = np.zeros(te.shape[0], dtype=np.float64)
+    sc = np.zeros(8, dtype=np.float64)
+    check(lib().jx_rrblup_exact_snp_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
+                                           _p(te) if te.size else None, int(te.shape[0]), float(log10_lambda_low),
+                                           float(log10_lambda_high), float(reml_tol), int(reml_max_iter), _p(beta),
+                                           _p(pred_tr_full), _p(pred_te) if te.size else None, _p(sc)))
+    if pick is None:
+        pred_train = pred_tr_full
+    elif pick.size:
+        pred_train = pred_tr_full[pick]
+    else:
+        pred_train = np.zeros(0, dtype=np.float64)
+    return (np.asarray(pred_train, dtype=np.float64).reshape(-1, 1), pred_te.reshape(-1, 1), float(sc[0]), float(sc[1]),
+            float(sc[2]), (float(sc[3]), float(sc[4])), m_effective, float(sc[7]), beta, rm.astype(f32), ri.astype(f32),
+            "jxgpu_eigh_f64")
+
+
 def _he_solve_2x2(a00, a01, a11, b0, b1):
     """src/stats/he.rs:874-897."""
     import math

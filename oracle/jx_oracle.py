@@ -1827,6 +1827,139 @@ def he_project_nnls_2x2(a00, a01, a11, b0, b1, x0u, x1u):
     return best[0], best[1], projected, best[3]
 
 
+def rrblup_exact_reml_cost_from_spectrum(lam, eigvals, y_proj, y_resid_ss, n_eff):
+    """src/stats/rrblup.rs:1568-1611."""
+    if not (math.isfinite(lam) and lam > 0.0):
+        return math.inf
+    r = len(eigvals)
+    if r != len(y_proj) or n_eff == 0 or n_eff < r:
+        return math.inf
+    quad = log_det = y_proj_ss = 0.0
+    for k in range(r):
+        s, yk = float(eigvals[k]), float(y_proj[k])
+        if not (math.isfinite(s) and s >= 0.0 and math.isfinite(yk)):
+            return math.inf
+        vk = s + lam
+        if not (math.isfinite(vk) and vk > 0.0):
+            return math.inf
+        quad += (yk * yk) / vk
+        log_det += math.log(vk)
+        y_proj_ss += yk * yk
+    null_df = max(n_eff - r, 0)
+    null_ss = max(y_resid_ss - y_proj_ss, 0.0)
+    if null_df > 0:
+        quad += null_ss / lam
+        log_det += float(null_df) * math.log(lam)
+    if not (math.isfinite(quad) and quad > 0.0 and math.isfinite(log_det)):
+        return math.inf
+    return 0.5 * (float(n_eff) * math.log(quad) + log_det)
+
+
+def rrblup_exact_snp_packed(packed, n_samples, train_idx, y_train, test_idx=None, train_pred_local=None, site_keep=None,
+                            maf=None, row_flip=None, row_mean=None, row_inv_sd=None, log10_lambda_low=-6.0,
+                            log10_lambda_high=6.0, reml_tol=1e-4, reml_max_iter=50, std_eps=1e-12):
+    """Exact marker-space rrBLUP (src/stats/rrblup.rs:3179-3490; cache :1613-1899, fit :1951-2430): A* = Z Z' over the
+    training samples (Z (m, n_train) standardised genotypes, f32 values accumulated in f64 by DSYRK) minus the rank-one
+    centring term, eigendecomposition, REML over log10 lambda by Brent on the spectrum, beta = V diag(1 / (s + lambda)) V' z.
+    Returns the reference's tuple (pred_train (k,1), pred_test (t,1), pve_trainvar, lambda, reml, (var_g, sigma_e2),
+    m_effective, y_mean, beta f32 (m), row_mean f32, row_inv_sd f32, backend)."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    m_total = packed.shape[0]
+    maf_full = np.asarray(maf, dtype=np.float32)
+    flip_full = np.asarray(row_flip, dtype=bool)
+    rows = None
+    maf_keep, flip_keep = maf_full, flip_full
+    if site_keep is not None:
+        keep_idx = np.nonzero(np.asarray(site_keep, dtype=bool))[0]
+        if keep_idx.shape[0] == 0:
+            raise RuntimeError("No SNPs remained after applying site_keep mask.")
+        if keep_idx.shape[0] != m_total:
+            rows = keep_idx
+            maf_keep = np.clip(maf_full[keep_idx], F32(0.0), F32(0.5))
+            flip_keep = flip_full[keep_idx]
+    eff_m = maf_keep.shape[0]
+    tr = np.asarray(train_idx, dtype=np.int64)
+    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    y = np.asarray(y_train, dtype=np.float64)
+    n_train = tr.shape[0]
+    if n_train <= 1:
+        raise RuntimeError("rrblup_exact_snp_packed requires at least two training samples.")
+    std_eps32 = F32(max(std_eps, 1e-12))
+    if row_mean is not None and row_inv_sd is not None:
+        rm = np.asarray(row_mean, dtype=np.float32)
+        ri = np.asarray(row_inv_sd, dtype=np.float32)
+        if rm.shape[0] != eff_m:
+            rm, ri = rm[rows], ri[rows]
+        m_effective = int(np.count_nonzero(np.isfinite(ri) & (ri > 0)))
+    else:
+        rm, ri, m_effective = rrblup_row_standardization(maf_keep, std_eps32)
+    lut = rrblup_value_lut(rm, ri, flip_keep)
+    codes = unpack_codes(packed if rows is None else packed[rows], n_samples)
+
+    def decode(cols):
+        return np.take_along_axis(lut, codes[:, cols].astype(np.int64), axis=1).astype(np.float32)
+
+    z = decode(tr)                                      # (m, n_train) f32
+    z64 = z.astype(np.float64)
+    a_star = z64 @ z64.T                                # cblas_dsyrk over the sample blocks (:1757-1775)
+    row_sum = z64.sum(axis=1)
+    train_row_mean = (row_sum / float(n_train)).astype(np.float32)
+    a_star -= np.outer(row_sum, row_sum) / float(n_train)          # symmetrize_upper_minus_rank1_in_place (:1549-1565)
+    a_star = 0.5 * (a_star + a_star.T)
+    evals_all, evecs = np.linalg.eigh(a_star)
+    max_eval = max(float(evals_all[-1]), 0.0)
+    tol = EPS64 * max(max_eval, 1.0) * float(max(eff_m, 1))
+    n_eff = n_train - 1
+    pos = np.nonzero(evals_all > tol)[0]
+    if pos.size == 0:
+        raise RuntimeError("rrblup_exact_snp_packed found no positive spectrum after centering.")
+    keep_start = int(pos[0])
+    if eff_m - keep_start > n_eff:
+        keep_start = eff_m - n_eff
+    eigvals = evals_all[keep_start:]
+    v = evecs[:, keep_start:]                           # (m, rank)
+    rank = eigvals.shape[0]
+    y_mean = float(np.sum(y)) / float(n_train)
+    y_c32 = (y - y_mean).astype(np.float32)
+    y_center_ss = float(np.sum((y - y_mean) ** 2))
+    zy = (z @ y_c32).astype(np.float32).astype(np.float64)          # f32 GEMV per sample block, summed in f64 (:2080-2110)
+    coeff = v.T @ zy
+    y_proj = coeff / np.sqrt(eigvals)
+    low, high = min(log10_lambda_low, log10_lambda_high), max(log10_lambda_low, log10_lambda_high)
+    best_log10, best_cost, _ = brent_minimize(
+        lambda x: rrblup_exact_reml_cost_from_spectrum(10.0 ** x, eigvals, y_proj, y_center_ss, n_eff), low, high, reml_tol,
+        reml_max_iter)
+    lambda_opt = max(10.0 ** best_log10, 1e-12)
+    denom = eigvals + lambda_opt
+    quad = float(np.sum(y_proj * y_proj / denom))
+    y_proj_ss = float(np.sum(y_proj * y_proj))
+    g_center_ss = float(np.sum(eigvals * coeff * coeff / (denom * denom)))
+    w = coeff / denom
+    null_ss = max(y_center_ss - y_proj_ss, 0.0)
+    if n_eff - rank > 0:
+        quad += null_ss / lambda_opt
+    sigma_beta2 = quad / float(n_eff)
+    sigma_e2 = lambda_opt * sigma_beta2
+    beta = (v @ w).astype(np.float32)
+    alpha_use = y_mean - float(np.sum(train_row_mean.astype(np.float64) * beta.astype(np.float64)))
+    var_g = g_center_ss / float(n_train - 1) if n_train > 1 else 0.0
+    den = var_g + sigma_e2
+    pve = var_g / den if (math.isfinite(den) and den > 0.0) else math.nan
+
+    def predict(cols):
+        zz = decode(cols)                               # pcg_x_mul_samples: f32 products, f32 output
+        return (zz.T @ beta).astype(np.float32).astype(np.float64) + alpha_use
+
+    if train_pred_local is not None:
+        pick = np.asarray(train_pred_local, dtype=np.int64)
+        pred_train = predict(tr[pick]) if pick.size else np.zeros(0)
+    else:
+        pred_train = predict(tr)
+    pred_test = predict(te) if te.size else np.zeros(0)
+    return (pred_train.reshape(-1, 1), pred_test.reshape(-1, 1), pve, lambda_opt, -best_cost, (var_g, sigma_e2),
+            m_effective, y_mean, beta, rm, ri, "numpy")
+
+
 def he_pcg_packed(packed, n_samples, maf, row_flip, train_idx, y_train, site_keep=None, trace_samples=32, tol=1e-6,
                   std_eps=1e-12, use_train_maf=True, exact_trace_debug=False, exact_trace_max_n=256, seed=20260512,
                   x_cov=None):

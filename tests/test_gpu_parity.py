@@ -1234,8 +1234,8 @@ def test_cli_gs_rrblup(oracle, tmp_path):
         for i in range(n):
             fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
     lam = 400.0
-    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-lambda", str(lam), "-tol", "1e-7",
-                     "-max-iter", "400", "-cv", "2", "-seed", "3", "-o", prefix]) == 0
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-rr-solver", "pcg", "-lambda", str(lam),
+                     "-tol", "1e-7", "-max-iter", "400", "-cv", "2", "-seed", "3", "-o", prefix]) == 0
     rows = [ln.split("\t") for ln in open(prefix + ".trait.gs.rrBLUP.tsv").read().splitlines()]
     assert rows[0] == ["sample", "observed", "predicted", "fold"] and len(rows) == n + 1
     miss, maf, _std, flip = oracle.load_bed_2bit_packed_stats(packed, n)
@@ -1252,11 +1252,18 @@ def test_cli_gs_rrblup(oracle, tmp_path):
     r1 = oracle.rrblup_pcg_packed(packed, n, maf, flip, train[tr_loc], y[train[tr_loc]], train[te_loc], None, keep, lam,
                                   1e-7, 400)
     assert np.max(np.abs(pred[train[te_loc]] - r1[1].ravel())) < 1e-4 * scale
-    # lambda from the subsample REML: runs, converges, predicts the held-out samples with positive accuracy
-    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-o", prefix + "_auto"]) == 0
+    # lambda from Haseman-Elston / the subsample REML: runs, converges, predicts the held-out samples with positive accuracy
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-rr-solver", "pcg", "-o",
+                     prefix + "_auto"]) == 0
     rows2 = [ln.split("\t") for ln in open(prefix + "_auto.trait.gs.rrBLUP.tsv").read().splitlines()]
     p2 = np.array([float(r[2]) for r in rows2[1:]])
     assert np.all(np.isfinite(p2)) and np.corrcoef(p2[test], y[test])[0, 1] > 0.2
+    # default solver at this marker count: the exact marker-space route (REML lambda from the spectrum)
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-o", prefix + "_exact"]) == 0
+    rows3 = [ln.split("\t") for ln in open(prefix + "_exact.trait.gs.rrBLUP.tsv").read().splitlines()]
+    p3 = np.array([float(r[2]) for r in rows3[1:]])
+    rex = oracle.rrblup_exact_snp_packed(packed, n, train, y[train], test, site_keep=keep, maf=maf, row_flip=flip)
+    assert np.max(np.abs(p3[test] - rex[1].ravel())) < 1e-4 * scale and np.max(np.abs(p3[train] - rex[0].ravel())) < 1e-4 * scale
 
 
 @pytest.mark.gpu
@@ -1334,6 +1341,57 @@ def test_he_pcg_bed(oracle):
         jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf)               # row_flip missing
     with pytest.raises(RuntimeError):
         jxrs.he_pcg_bed("", tr, y, packed=packed, packed_n_samples=n, maf=maf, row_flip=flip, trace_samples=0)
+
+
+@pytest.mark.gpu
+def test_rrblup_exact_snp_packed(oracle):
+    """Exact marker-space rrBLUP (src/stats/rrblup.rs:3179-3490) against the numpy restatement: training subsets, a
+    site_keep mask, flipped alleles, missing genotypes, external row statistics, more markers than training samples
+    (rank capped at n_train - 1) and fewer; the error rules of the PyO3 entry point."""
+    from janusx_amd import janusx as jxrs
+    rng = np.random.default_rng(23)
+    for n, m, ntr in ((150, 420, 110), (260, 90, 200)):
+        packed, g = bed.synth_panel_numpy(n, m, seed=n + m, missing_rate=0.02)
+        mi, he, ho = oracle.row_counts(packed, n)
+        nm = np.maximum(n - mi, 1)
+        af = (he + 2 * ho) / (2.0 * nm)
+        maf = np.minimum(af, 1.0 - af).astype(np.float32)
+        flip = af > 0.5
+        tr = np.sort(rng.choice(n, ntr, replace=False))
+        te = np.setdiff1d(np.arange(n), tr)
+        y = g[:40, tr].T @ rng.standard_normal(40) * 0.3 + rng.standard_normal(ntr)
+        keep = rng.random(m) < 0.9
+        cases = [dict(), dict(site_keep=keep, train_pred_local_indices=np.arange(0, ntr, 3)),
+                 dict(log10_lambda_low=-2.0, log10_lambda_high=4.0, reml_tol=1e-6, reml_max_iter=80)]
+        for kw in cases:
+            okw = {("train_pred_local" if k == "train_pred_local_indices" else k): v for k, v in kw.items()}
+            ref = oracle.rrblup_exact_snp_packed(packed, n, tr, y, te, maf=maf, row_flip=flip, **okw)
+            got = jxrs.rrblup_exact_snp_packed(packed, n, tr, y, te, maf=maf, row_flip=flip, **kw)
+            assert len(got) == 12 and got[6] == ref[6] and got[0].shape == ref[0].shape and got[1].shape == ref[1].shape
+            assert abs(math.log10(got[3]) - math.log10(ref[3])) < 1e-6, (got[3], ref[3])          # lambda
+            assert abs(got[4] - ref[4]) <= 1e-8 * abs(ref[4])                                       # REML
+            assert abs(got[5][0] - ref[5][0]) <= 1e-6 * abs(ref[5][0]) and abs(got[5][1] - ref[5][1]) <= 1e-6 * ref[5][1]
+            assert abs(got[2] - ref[2]) <= 1e-6 * max(abs(ref[2]), 1e-12) and abs(got[7] - ref[7]) <= 1e-14 * max(abs(ref[7]), 1.0)
+            bscale = np.abs(ref[8]).max()
+            assert np.abs(got[8] - ref[8]).max() <= 2e-6 * bscale, np.abs(got[8] - ref[8]).max() / bscale
+            for a, b in ((got[0], ref[0]), (got[1], ref[1])):
+                assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1.0)
+            assert np.array_equal(got[9], ref[9]) and np.array_equal(got[10], ref[10])
+        # external row statistics of the full marker list, subset by site_keep
+        rm, ri, _ = oracle.rrblup_row_standardization(np.clip(maf, 0, 0.5).astype(np.float32), np.float32(1e-12))
+        ref = oracle.rrblup_exact_snp_packed(packed, n, tr, y, None, site_keep=keep, maf=maf, row_flip=flip, row_mean=rm,
+                                             row_inv_sd=ri)
+        got = jxrs.rrblup_exact_snp_packed(packed, n, tr, y, None, site_keep=keep, maf=maf, row_flip=flip, row_mean=rm,
+                                           row_inv_sd=ri)
+        assert np.abs(got[8] - ref[8]).max() <= 2e-6 * np.abs(ref[8]).max() and got[1].shape == (0, 1)
+    with pytest.raises(RuntimeError, match="maf"):
+        jxrs.rrblup_exact_snp_packed(packed, n, tr, y, row_flip=flip)
+    with pytest.raises(RuntimeError, match="at least two"):
+        jxrs.rrblup_exact_snp_packed(packed, n, tr[:1], y[:1], maf=maf, row_flip=flip)
+    with pytest.raises(RuntimeError, match="reml_tol"):
+        jxrs.rrblup_exact_snp_packed(packed, n, tr, y, maf=maf, row_flip=flip, reml_tol=0.0)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        jxrs.rrblup_exact_snp_packed(packed, n, tr, np.where(np.arange(len(y)) == 3, np.nan, y), maf=maf, row_flip=flip)
 
 
 @pytest.mark.gpu

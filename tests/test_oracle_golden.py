@@ -196,6 +196,51 @@ def test_rrblup_pcg_restatement_solves_the_ridge_system():
     assert np.max(np.abs(out[0].ravel() - (z.T @ beta + alpha))) <= 1e-4
 
 
+def test_rrblup_exact_restatement_is_the_ridge_solution_at_its_reml_optimum():
+    """SURVEY 8f-4, exact marker-space route (src/stats/rrblup.rs:3179-3490): no numeric test in the reference (parity
+    unpinned beyond these properties).  The restated route must (i) return the f64 direct solution of
+    (Z_c Z_c' + lambda I) beta = Z y_c at ITS lambda, (ii) sit at a minimum of the restricted likelihood of the equivalent
+    sample-space model y_c ~ N(0, sigma^2 (Z_c'Z_c / lambda + I)) evaluated densely, (iii) cap the rank at n_train - 1
+    when there are more markers than samples."""
+    from oracle import jx_oracle as O
+    from janusx_amd import bed
+    for n, m, ntr in ((160, 380, 120), (220, 70, 180)):
+        packed, g = bed.synth_panel_numpy(n, m, seed=n, missing_rate=0.02)
+        miss, maf, std, flip = O.load_bed_2bit_packed_stats(packed, n)
+        rng = np.random.default_rng(1)
+        tr = np.sort(rng.permutation(n)[:ntr])
+        te = np.setdiff1d(np.arange(n), tr)
+        y = rng.standard_normal(ntr) + (g[:20, tr].T @ rng.standard_normal(20)) * 0.4
+        out = O.rrblup_exact_snp_packed(packed, n, tr, y, te, maf=maf, row_flip=flip, reml_tol=1e-8, reml_max_iter=200)
+        lam = out[3]
+        rm, ri, me = O.rrblup_row_standardization(maf, np.float32(1e-12))
+        lut = O.rrblup_value_lut(rm, ri, flip)
+        codes = O.unpack_codes(packed, n).astype(np.int64)
+        z = np.take_along_axis(lut, codes[:, tr], axis=1).astype(np.float64)
+        zc = z - z.mean(1, keepdims=True)
+        yc = y - y.mean()
+        beta = np.linalg.solve(zc @ zc.T + lam * np.eye(m), z @ yc)
+        assert np.max(np.abs(beta - out[8])) <= 2e-6 * np.max(np.abs(beta))
+        alpha = y.mean() - float(np.sum(z.mean(1) * beta))
+        zt = np.take_along_axis(lut, codes[:, te], axis=1).astype(np.float64)
+        assert np.max(np.abs(out[1].ravel() - (zt.T @ beta + alpha))) <= 1e-5
+        # dense restricted likelihood (intercept projected out: n_train - 1 degrees of freedom) as a function of log10 lambda
+        k = zc.T @ zc
+        ev, u = np.linalg.eigh(k)            # the constant vector is a null direction of k and orthogonal to y_c
+        ev = np.clip(ev, 0.0, None)
+        yp = u.T @ yc
+
+        def cost(l10):
+            lamv = 10.0 ** l10
+            v = ev / lamv + 1.0
+            q = float(np.sum(yp * yp / v))
+            return 0.5 * ((ntr - 1) * math.log(q) + float(np.sum(np.log(v))))
+        l0 = math.log10(lam)
+        assert cost(l0) <= cost(l0 - 0.05) + 1e-9
+        assert l0 > 5.999 or cost(l0) <= cost(l0 + 0.05) + 1e-9        # an optimum on the upper bound is one-sided
+        assert len(out[8]) == m and out[6] == me
+
+
 def test_he_restatement_matches_dense_traces():
     """SURVEY 8f-4 (HE half): no numeric test in the reference (parity unpinned beyond this): with exact traces the
     restated estimator must reproduce tr(PKP), tr((PKP)^2), y'PKPy of the dense f64 standardised GRM, and its probes

@@ -72,6 +72,11 @@ int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, int32_t *d_co
 int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
                        const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
                        void *stream);
+/* Tile rows [tile_row_begin, tile_row_end) of the lower triangle only (128-row tiles; end < 0: all); d_acc is then the
+ * panel buffer: (end - begin) * 128 rows of the full leading dimension, row 0 = sample row begin * 128. */
+int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows, const float *d_lut,
+                            int64_t mk, double *d_acc, int kchunk, int precision, int tile_row_begin, int tile_row_end,
+                            void *stream);
 
 /* A5. K = acc * inv_scale, mirrored lower -> upper, written as (n,n) f32 or f64 row-major.
  * src/stats/grm.rs:2771-2785 `grm_scale_and_symmetrize_raw_f64`. */
@@ -90,6 +95,16 @@ int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double thresho
                     uint64_t *d_colptr, void *stream);
 int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
                    const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals, void *stream);
+/* Row-panel forms for a sparse GRM whose n x n f64 accumulator does not fit in HBM (`jx_spgrm_packed_to_jxgrm` switches to
+ * them above JXGPU_SPGRM_ACC_GB = 96 GB, or when JXGPU_SPGRM_PANEL_ROWS is set): bands [band0, band1) of 256 sample rows
+ * (band1 < 0: all); d_acc is the panel holding exactly those rows (row 0 = sample row band0 * 256, leading dimension
+ * num_tiles(n) * 128), d_work needs (band1 - band0) * n * 4 + 16 bytes, and d_colptr / d_rows / d_vals describe the entries of
+ * these rows only (merged column by column by the caller). */
+int jxg_spgrm_count_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold, int band0,
+                          int band1, void *d_work, uint64_t *d_colptr, void *stream);
+int jxg_spgrm_fill_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold, int band0,
+                         int band1, const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
+                         void *stream);
 
 /* Dense symmetric image (n_out, n_out) f64 of a lower-triangle CSC sparse GRM in HBM, optionally restricted / reordered
  * by d_map (n int32: new index of every original sample, -1 = dropped; NULL = identity, n_out = n) — the operand of the
@@ -195,6 +210,11 @@ int jxg_ut_rowsum(const float *d_ut, int n, float *d_usum, void *stream);
 int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                          const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
                          const uint16_t *d_ulo, int scale_exp, float *d_out, void *stream);
+/* The same with a row pitch `ld_out` >= n (floats) of d_out: writes a block of eigenvector columns of a wider rotated-row
+ * buffer (block-diagonal rotation of the sparse-GRM routes, one call per diagonal block). */
+int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                            const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
+                            const uint16_t *d_ulo, int scale_exp, float *d_out, int64_t ld_out, void *stream);
 
 /* D2 (dense input). out[r, j] = sum_i g[r, i] * u_t[j, i] in exact f32 (f32 MFMA).
  * src/stats/lmm.rs:520-552 `rotate_snp_block_with_ut`. */

@@ -31,10 +31,13 @@ SIGNATURES = {
     "jxg_repack_p32": [c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_l, c_p, c_p],
     "jxg_row_counts_p32": [c_p, c_l, c_i, c_p, c_p],
     "jxg_grm_accumulate": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
+    "jxg_grm_accumulate_rows": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "jxg_grm_finalize": [c_p, c_i, c_d, c_p, c_i, c_p],
     "jxg_spgrm_work_bytes": [c_i],
     "jxg_spgrm_count": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p],
     "jxg_spgrm_fill": [c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p, c_p],
+    "jxg_spgrm_count_bands": [c_p, c_i, c_d, c_d, c_i, c_i, c_i, c_p, c_p, c_p],
+    "jxg_spgrm_fill_bands": [c_p, c_i, c_d, c_d, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "jxg_spgrm_densify": [c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     "jxg_eigh_f64": [c_p, c_i, c_d, c_p, c_p],
     "jxg_eigh_grid_check": [c_i],
@@ -60,6 +63,7 @@ SIGNATURES = {
     "jxg_lut_split_rows": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p],
     "jxg_ut_rowsum": [c_p, c_i, c_p, c_p],
     "jxg_rotate_packed16x": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "jxg_rotate_packed16x_ld": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "jxg_rotate_dense_f32": [c_p, c_i, c_i, c_p, c_p, c_p],
     "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_lmm_tables_bytes": [c_i, c_i, c_d, c_d],

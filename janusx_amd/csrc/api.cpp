@@ -290,6 +290,14 @@ extern "C" int jx_grm_packed(const uint8_t *packed, int64_t m, int n_samples, co
 extern "C" int64_t jxg_spgrm_work_bytes(int n);
 extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
                                void *d_work, uint64_t *d_colptr, void *stream);
+extern "C" int jxg_spgrm_count_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                                     int band0, int band1, void *d_work, uint64_t *d_colptr, void *stream);
+extern "C" int jxg_spgrm_fill_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                                    int band0, int band1, const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows,
+                                    double *d_vals, void *stream);
+extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
+                                       const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
+                                       int tile_row_begin, int tile_row_end, void *stream);
 extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
                               const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
                               void *stream);
@@ -322,34 +330,111 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
     if (dlut.alloc(lut.size() * sizeof(float))) return 1;
     JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
     const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
-    if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
-    JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
-    if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, nullptr))
-        return 1;
-    p32.release();
-    if (work.alloc((size_t)jxg_spgrm_work_bytes(n))) return 1;
-    if (dcolptr.alloc(sizeof(uint64_t) * ((size_t)n + 1))) return 1;
     const double inv = 1.0 / D;
-    if (jxg_spgrm_count(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(), nullptr))
-        return 1;
     std::vector<uint64_t> colptr((size_t)n + 1);
-    JX_HIP(hipMemcpy(colptr.data(), dcolptr.p, sizeof(uint64_t) * colptr.size(), hipMemcpyDeviceToHost));
-    const uint64_t nnz = colptr[(size_t)n];
     std::vector<uint32_t> rows;
     std::vector<double> vals;
-    try {   // up to n (n + 1) / 2 entries with a negative cut-off: 12 bytes each on the host
-        rows.resize((size_t)nnz);
-        vals.resize((size_t)nnz);
-    } catch (const std::bad_alloc &) {
-        return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
-    }
-    if (nnz) {
-        if (drows.alloc(sizeof(uint32_t) * (size_t)nnz) || dvals.alloc(sizeof(double) * (size_t)nnz)) return 1;
-        if (jxg_spgrm_fill(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(),
-                           drows.as<uint32_t>(), dvals.as<double>(), nullptr))
+    uint64_t nnz = 0;
+    // Row panels when the n x n f64 accumulator is too large for HBM (JXGPU_SPGRM_ACC_GB, default 96) or when
+    // JXGPU_SPGRM_PANEL_ROWS asks for them: the GRM is computed and thresholded 256-row bands at a time (tile rows of the
+    // lower triangle), every panel yields the CSC entries of its rows, and the panels are merged column by column on the
+    // host (rows ascend with the panels, so the order inside a column is kept).  One pass over the payload per panel.
+    const char *env_rows = getenv("JXGPU_SPGRM_PANEL_ROWS");
+    const double acc_gb = getenv("JXGPU_SPGRM_ACC_GB") ? atof(getenv("JXGPU_SPGRM_ACC_GB")) : 96.0;
+    int64_t panel_rows = 0;
+    if (env_rows && atoll(env_rows) > 0) panel_rows = atoll(env_rows);
+    else if ((double)npad * (double)npad * 8.0 > acc_gb * 1073741824.0) panel_rows = (int64_t)(32.0 * 1073741824.0 / (8.0 * npad));
+    if (panel_rows > 0) {
+        panel_rows = std::max<int64_t>(256, (panel_rows / 256) * 256);
+        const int nbands = (n + 255) / 256;
+        const int bands_per = (int)(panel_rows / 256);
+        if (acc.alloc(sizeof(double) * (size_t)(panel_rows * npad))) return 1;
+        if (work.alloc((size_t)((int64_t)bands_per * n * 4 + 16))) return 1;
+        if (dcolptr.alloc(sizeof(uint64_t) * ((size_t)n + 1))) return 1;
+        struct PanelEntries {
+            std::vector<uint64_t> cp;
+            std::vector<uint32_t> r;
+            std::vector<double> v;
+        };
+        std::vector<PanelEntries> panels;
+        for (int b0 = 0; b0 < nbands; b0 += bands_per) {
+            const int b1 = std::min(nbands, b0 + bands_per);
+            const int t0 = b0 * 2, t1 = std::min((int)num_tiles(n), b1 * 2);       // 128-row tiles of the bands
+            JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)((int64_t)(t1 - t0) * JXG_TILE * npad)));
+            if (jxg_grm_accumulate_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, t0, t1,
+                                        nullptr))
+                return 1;
+            if (jxg_spgrm_count_bands(acc.as<double>(), n, inv, threshold, abs_threshold, b0, b1, work.p,
+                                      dcolptr.as<uint64_t>(), nullptr))
+                return 1;
+            PanelEntries pe;
+            pe.cp.resize((size_t)n + 1);
+            JX_HIP(hipMemcpy(pe.cp.data(), dcolptr.p, sizeof(uint64_t) * pe.cp.size(), hipMemcpyDeviceToHost));
+            const uint64_t pn = pe.cp[(size_t)n];
+            if (pn) {
+                DevBuf pr, pv;
+                if (pr.alloc(sizeof(uint32_t) * (size_t)pn) || pv.alloc(sizeof(double) * (size_t)pn)) return 1;
+                if (jxg_spgrm_fill_bands(acc.as<double>(), n, inv, threshold, abs_threshold, b0, b1, work.p,
+                                         dcolptr.as<uint64_t>(), pr.as<uint32_t>(), pv.as<double>(), nullptr))
+                    return 1;
+                try {
+                    pe.r.resize((size_t)pn);
+                    pe.v.resize((size_t)pn);
+                } catch (const std::bad_alloc &) {
+                    return fail("Sparse GRM: host allocation of " + std::to_string(pn) + " entries failed");
+                }
+                JX_HIP(hipMemcpy(pe.r.data(), pr.p, sizeof(uint32_t) * (size_t)pn, hipMemcpyDeviceToHost));
+                JX_HIP(hipMemcpy(pe.v.data(), pv.p, sizeof(double) * (size_t)pn, hipMemcpyDeviceToHost));
+            }
+            nnz += pn;
+            panels.push_back(std::move(pe));
+        }
+        p32.release();
+        colptr[0] = 0;
+        for (int c = 0; c < n; ++c) {
+            uint64_t k = 0;
+            for (const auto &pe : panels) k += pe.cp[(size_t)c + 1] - pe.cp[(size_t)c];
+            colptr[(size_t)c + 1] = colptr[(size_t)c] + k;
+        }
+        try {
+            rows.resize((size_t)nnz);
+            vals.resize((size_t)nnz);
+        } catch (const std::bad_alloc &) {
+            return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
+        }
+        std::vector<uint64_t> cursor(colptr.begin(), colptr.end() - 1);
+        for (const auto &pe : panels)
+            for (int c = 0; c < n; ++c)
+                for (uint64_t k = pe.cp[(size_t)c]; k < pe.cp[(size_t)c + 1]; ++k) {
+                    rows[(size_t)cursor[(size_t)c]] = pe.r[(size_t)k];
+                    vals[(size_t)cursor[(size_t)c]++] = pe.v[(size_t)k];
+                }
+    } else {
+        if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
+        JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
+        if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, nullptr))
             return 1;
-        JX_HIP(hipMemcpy(rows.data(), drows.p, sizeof(uint32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
-        JX_HIP(hipMemcpy(vals.data(), dvals.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+        p32.release();
+        if (work.alloc((size_t)jxg_spgrm_work_bytes(n))) return 1;
+        if (dcolptr.alloc(sizeof(uint64_t) * ((size_t)n + 1))) return 1;
+        if (jxg_spgrm_count(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(colptr.data(), dcolptr.p, sizeof(uint64_t) * colptr.size(), hipMemcpyDeviceToHost));
+        nnz = colptr[(size_t)n];
+        try {   // up to n (n + 1) / 2 entries with a negative cut-off: 12 bytes each on the host
+            rows.resize((size_t)nnz);
+            vals.resize((size_t)nnz);
+        } catch (const std::bad_alloc &) {
+            return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
+        }
+        if (nnz) {
+            if (drows.alloc(sizeof(uint32_t) * (size_t)nnz) || dvals.alloc(sizeof(double) * (size_t)nnz)) return 1;
+            if (jxg_spgrm_fill(acc.as<double>(), n, inv, threshold, abs_threshold, work.p, dcolptr.as<uint64_t>(),
+                               drows.as<uint32_t>(), dvals.as<double>(), nullptr))
+                return 1;
+            JX_HIP(hipMemcpy(rows.data(), drows.p, sizeof(uint32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+            JX_HIP(hipMemcpy(vals.data(), dvals.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+        }
     }
     // write_sparse_grm_csc (:3745-3767): u64 n, u64 nnz, col_ptr, row_indices, zero padding to 8 bytes, values (LE)
     FILE *fh = fopen(out_path, "wb");

@@ -148,7 +148,7 @@ template <int TM, int TN, int WM, int WN, bool DBUF, bool EXACT = false, int BK 
 __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? (EXACT ? 4 : 2) : (TM == 128 ? (EXACT ? 4 : 3) : 2))) void grm_f16x2_kernel(
     const uint8_t *__restrict__ p32, int64_t m_total, const int32_t *__restrict__ rows,
     const uint4 *__restrict__ lut16, int64_t k_begin, int64_t k_end, int kchunk, int nt128,
-    double *__restrict__ acc, int64_t ld, int use_atomic, const double *__restrict__ corr) {
+    double *__restrict__ acc, int64_t ld, int use_atomic, const double *__restrict__ corr, int tile_base) {
     constexpr int NWN = TN / WN;
     constexpr int NTHREADS = 64 * (TM / WM) * NWN;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), (DBUF ? (EXACT ? 4 : 2)
     // output tiles covering the lower triangle: row block ti (TM rows) x column blocks tj (TN columns) with
     // tj * TN < (ti + 1) * TM; RATIO = TM / TN column blocks per row-block step
     constexpr int RATIO = TM / TN;
-    const int t = blockIdx.x;
+    const int t = blockIdx.x + tile_base;     // tile_base > 0: a panel of tile rows (sparse GRM of large n, row panels)
     int ti, tj;
     if (RATIO == 1) {
         ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -556,9 +556,22 @@ extern "C" float jxg_last_kernel_ms(int which) {
     return g_last_ms[which];
 }
 
+extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
+                                       const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
+                                       int tile_row_begin, int tile_row_end, void *stream);
+
 extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
                                   const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
                                   void *stream) {
+    return jxg_grm_accumulate_rows(d_p32, m_total, n_sel, d_rows, d_lut, mk, d_acc, kchunk, precision, 0, -1, stream);
+}
+
+// Tile rows [tile_row_begin, tile_row_end) of the lower triangle only (128-row tiles; end < 0: all).  d_acc is then the
+// PANEL buffer: (tile_row_end - tile_row_begin) * 128 rows of the full leading dimension, row 0 = sample row
+// tile_row_begin * 128 -- the form the sparse GRM takes when the n x n f64 accumulator does not fit in HBM.
+extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
+                                       const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
+                                       int tile_row_begin, int tile_row_end, void *stream) {
     if (mk <= 0) return 0;
     if (precision != 0) return fail("jxg_grm_accumulate: precision=1 (f32 MFMA) path not built yet");
     hipStream_t st = (hipStream_t)stream;
@@ -605,9 +618,17 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
 
     // tile shape: 256x128 (4 waves of 128x64) once there are enough tiles, else 128x128 (4 waves of 64x64)
     static const int tile_env = getenv("JXGPU_GRM_TILE") ? atoi(getenv("JXGPU_GRM_TILE")) : 0;
-    const bool big = tile_env ? (tile_env >= 256) : false;
+    const bool panel = tile_row_end >= 0;
+    if (panel && (tile_row_begin < 0 || tile_row_end > nt || tile_row_begin >= tile_row_end))
+        return fail("jxg_grm_accumulate_rows: tile row range out of bounds");
+    const bool big = (tile_env && !panel) ? (tile_env >= 256) : false;
     const int tdim = big ? (nt + 1) / 2 : nt;  // row blocks
-    const int64_t ntiles = big ? (int64_t)tdim * (tdim + 1) : (int64_t)tdim * (tdim + 1) / 2;
+    const int64_t tile_base = panel ? (int64_t)tile_row_begin * (tile_row_begin + 1) / 2 : 0;
+    const int64_t ntiles = panel ? (int64_t)tile_row_end * (tile_row_end + 1) / 2 - tile_base
+                                 : (big ? (int64_t)tdim * (tdim + 1) : (int64_t)tdim * (tdim + 1) / 2);
+    if (tile_base + ntiles > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
+    // the kernels index the accumulator by global sample row: shift the panel buffer accordingly
+    d_acc -= panel ? (int64_t)tile_row_begin * JXG_TILE * ld : 0;
     if (ntiles > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
     const int64_t slots = big ? 512 : 768;  // resident workgroups on 256 CUs
     if (g_grm_ev.init()) return 1;
@@ -624,26 +645,26 @@ extern "C" int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_s
     auto launch = [&](bool exact, dim3 grid, int64_t kb, int64_t ke, int kc, int atomic, const double *corr) {
         if (exact && big)
             hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false, true>), grid, dim3(256), 0, st, d_p32, m_total,
-                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
         else if (exact)
             if (exact_bk == 33)
                 hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, true, true>), grid, dim3(256), 0, st, d_p32,
-                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
             else if (exact_bk == 64)
                 hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false, true, 64>), grid, dim3(256), 0, st, d_p32,
-                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
             else
                 hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false, true>), grid, dim3(256), 0, st, d_p32,
-                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                                   m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
         else if (big)
             hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
-                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
         else if (tile_env == 129)
             hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, true>), grid, dim3(256), 0, st, d_p32, m_total,
-                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
         else
             hipLaunchKernelGGL((grm_f16x2_kernel<128, 128, 64, 64, false>), grid, dim3(256), 0, st, d_p32, m_total,
-                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr);
+                               rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
     };
     // SNP range [r0, r1) of the reordered list with one kernel variant
     auto run_range = [&](bool exact, int64_t r0, int64_t r1) -> int {

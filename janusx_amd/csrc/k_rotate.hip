@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                                                               const float *__restrict__ usum,
                                                               const __half *__restrict__ uhi,
                                                               const __half *__restrict__ ulo, int64_t npad, int n,
-                                                              float out_scale, float *__restrict__ out) {
+                                                              float out_scale, float *__restrict__ out, int64_t ldo) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 64 + 512];
     uint8_t *sAh = smem;
     uint8_t *sAl = smem + R_IMG;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
             for (int r = 0; r < 16; ++r) {
                 const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int gr = r0 + lr;
-                if (gr < nrows && gj < n) out[(int64_t)gr * n + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
+                if (gr < nrows && gj < n) out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
             }
         }
 }
@@ -534,10 +534,26 @@ extern "C" int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n,
                                 d_out, stream);
 }
 
+extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                       const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                       const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
+                                       int64_t ld_out, void *stream);
+
 extern "C" int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                     const void *d_lut16, const float *d_rowoff, const float *d_usum,
                                     const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
                                     void *stream) {
+    return jxg_rotate_packed16x_ld(d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo, scale_exp,
+                                   d_out, (int64_t)n, stream);
+}
+
+// ld_out >= n: row pitch of d_out in floats (a block of eigenvector columns of a wider rotated-row buffer: the
+// block-diagonal rotation of the sparse-GRM routes)
+extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                       const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                       const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
+                                       int64_t ld_out, void *stream) {
+    if (ld_out < n) return fail("jxg_rotate_packed16x_ld: ld_out < n");
     if (nrows <= 0) return 0;
     static const int exact_env = getenv("JXGPU_ROT_EXACT") ? atoi(getenv("JXGPU_ROT_EXACT")) : 1;
     if (!d_usum) d_rowoff = nullptr;
@@ -554,7 +570,7 @@ extern "C" int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n
     JX_HIP(hipEventRecord(g_rot_a, st));
     hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
                        (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
-                       ldexpf(1.0f, -scale_exp), d_out);
+                       ldexpf(1.0f, -scale_exp), d_out, ld_out);
     JX_LAUNCH_CHECK();
     JX_HIP(hipEventRecord(g_rot_b, st));
     g_timer_pending[1] = 1;

@@ -36,15 +36,16 @@ __global__ __launch_bounds__(SG_T) void spgrm_band_kernel(const double *__restri
                                                           int32_t *__restrict__ cnt,
                                                           const uint64_t *__restrict__ colptr,
                                                           uint32_t *__restrict__ rows, double *__restrict__ vals,
-                                                          int *__restrict__ flag) {
+                                                          int *__restrict__ flag, int band0) {
+    // band0: first band of this launch (a row panel of the accumulator; cnt is indexed by band - band0)
     const int c = blockIdx.x * SG_T + threadIdx.x;
-    const int band = blockIdx.y;
+    const int band = blockIdx.y + band0;
     if (c >= n) return;
     const int r_lo = band * SG_BAND;
     const int r_hi = (r_lo + SG_BAND < n) ? (r_lo + SG_BAND) : n;
     int kept = 0;
     uint64_t pos = 0;
-    if (FILL) pos = colptr[c] + (uint64_t)cnt[(int64_t)band * n + c];
+    if (FILL) pos = colptr[c] + (uint64_t)cnt[(int64_t)(band - band0) * n + c];
     bool bad = false;
     const int r0 = (c > r_lo) ? c : r_lo;   // lower triangle: row >= col
     const double *p = acc + (int64_t)r0 * ld + c;
@@ -63,18 +64,20 @@ __global__ __launch_bounds__(SG_T) void spgrm_band_kernel(const double *__restri
         }
     }
     if (!FILL) {
-        cnt[(int64_t)band * n + c] = kept;
+        cnt[(int64_t)(band - band0) * n + c] = kept;
         if (bad) atomicOr(flag, 1);
     }
 }
 
 // per column: counts of the bands -> exclusive prefix over the bands (in place), column total -> colptr[col + 1]
-__global__ void spgrm_band_prefix_kernel(int32_t *__restrict__ cnt, int n, int nbands, uint64_t *__restrict__ colptr) {
+__global__ void spgrm_band_prefix_kernel(int32_t *__restrict__ cnt, int n, int band0, int nbands,
+                                         uint64_t *__restrict__ colptr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     uint64_t run = 0;
-    for (int b = c / SG_BAND; b < nbands; ++b) {   // bands above the diagonal hold no entry of this column
-        const int64_t at = (int64_t)b * n + c;
+    const int bfirst = (c / SG_BAND > band0) ? c / SG_BAND : band0;
+    for (int b = bfirst; b < nbands; ++b) {        // bands above the diagonal hold no entry of this column
+        const int64_t at = (int64_t)(b - band0) * n + c;
         const int32_t k = cnt[at];
         cnt[at] = (int32_t)run;
         run += (uint64_t)k;
@@ -136,19 +139,30 @@ static inline int spgrm_bands(int n) { return (n + SG_BAND - 1) / SG_BAND; }
 
 extern "C" int64_t jxg_spgrm_work_bytes(int n) { return (int64_t)spgrm_bands(n) * (int64_t)n * 4 + 16; }
 
-extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
-                               void *d_work, uint64_t *d_colptr, void *stream) {
+// Bands [band0, band1) of 256 sample rows (band1 < 0: all): d_acc is then the row panel holding exactly those bands (row 0
+// = sample row band0 * 256, full leading dimension), d_work needs (band1 - band0) * n * 4 + 16 bytes and d_colptr / d_rows /
+// d_vals describe the entries of these rows only (the caller merges the panels column by column).
+extern "C" int jxg_spgrm_count_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                                     int band0, int band1, void *d_work, uint64_t *d_colptr, void *stream) {
     if (n <= 0) return fail("jxg_spgrm_count: n must be > 0");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = spgrm_bands(n);
+    const int nb_all = spgrm_bands(n);
+    if (band1 < 0) {
+        band0 = 0;
+        band1 = nb_all;
+    }
+    if (band0 < 0 || band1 > nb_all || band0 >= band1) return fail("jxg_spgrm_count_bands: band range out of bounds");
+    const int nb = band1 - band0;
     const int64_t ld = (int64_t)num_tiles(n) * JXG_TILE;
+    const double *acc = d_acc - (int64_t)band0 * SG_BAND * ld;
     int32_t *cnt = (int32_t *)d_work;
     int *flag = (int *)((char *)d_work + (int64_t)nb * n * 4);
     JX_HIP(hipMemsetAsync(flag, 0, 16, st));
-    hipLaunchKernelGGL(spgrm_band_kernel<false>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, st, d_acc, ld, n,
+    JX_HIP(hipMemsetAsync(cnt, 0, (size_t)((int64_t)nb * n * 4), st));     // columns right of a band's rows stay empty
+    hipLaunchKernelGGL(spgrm_band_kernel<false>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, st, acc, ld, n,
                        inv_scale, threshold, abs_threshold, cnt, (const uint64_t *)nullptr, (uint32_t *)nullptr,
-                       (double *)nullptr, flag);
-    hipLaunchKernelGGL(spgrm_band_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, n, nb, d_colptr);
+                       (double *)nullptr, flag, band0);
+    hipLaunchKernelGGL(spgrm_band_prefix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, n, band0, band1, d_colptr);
     hipLaunchKernelGGL(spgrm_colptr_scan_kernel, dim3(1), dim3(1024), 0, st, d_colptr, n);
     JX_LAUNCH_CHECK();
     int hflag = 0;
@@ -158,17 +172,34 @@ extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, dou
     return 0;
 }
 
+extern "C" int jxg_spgrm_fill_bands(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                                    int band0, int band1, const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows,
+                                    double *d_vals, void *stream) {
+    if (n <= 0) return fail("jxg_spgrm_fill: n must be > 0");
+    const int nb_all = spgrm_bands(n);
+    if (band1 < 0) {
+        band0 = 0;
+        band1 = nb_all;
+    }
+    if (band0 < 0 || band1 > nb_all || band0 >= band1) return fail("jxg_spgrm_fill_bands: band range out of bounds");
+    const int64_t ld = (int64_t)num_tiles(n) * JXG_TILE;
+    const double *acc = d_acc - (int64_t)band0 * SG_BAND * ld;
+    hipLaunchKernelGGL(spgrm_band_kernel<true>, dim3((n + SG_T - 1) / SG_T, band1 - band0), dim3(SG_T), 0,
+                       (hipStream_t)stream, acc, ld, n, inv_scale, threshold, abs_threshold, (int32_t *)d_work, d_colptr, d_rows,
+                       d_vals, (int *)nullptr, band0);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int jxg_spgrm_count(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
+                               void *d_work, uint64_t *d_colptr, void *stream) {
+    return jxg_spgrm_count_bands(d_acc, n, inv_scale, threshold, abs_threshold, 0, -1, d_work, d_colptr, stream);
+}
+
 extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, double threshold, int abs_threshold,
                               const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
                               void *stream) {
-    if (n <= 0) return fail("jxg_spgrm_fill: n must be > 0");
-    const int nb = spgrm_bands(n);
-    const int64_t ld = (int64_t)num_tiles(n) * JXG_TILE;
-    hipLaunchKernelGGL(spgrm_band_kernel<true>, dim3((n + SG_T - 1) / SG_T, nb), dim3(SG_T), 0, (hipStream_t)stream,
-                       d_acc, ld, n, inv_scale, threshold, abs_threshold, (int32_t *)d_work, d_colptr, d_rows, d_vals,
-                       (int *)nullptr);
-    JX_LAUNCH_CHECK();
-    return 0;
+    return jxg_spgrm_fill_bands(d_acc, n, inv_scale, threshold, abs_threshold, 0, -1, d_work, d_colptr, d_rows, d_vals, stream);
 }
 
 extern "C" int jxg_spgrm_densify(const uint64_t *d_colptr, const uint32_t *d_rows, const double *d_vals, int n,

@@ -455,6 +455,24 @@ def splmm_load_sparse_grm_subset_dense(jxgrm_path, sample_indices=None):
     return k.cpu().numpy()
 
 
+def _sparse_block_size():
+    """Samples per diagonal block of the block route (JXGPU_SPLMM_BLOCK, default 4096)."""
+    v = os.environ.get("JXGPU_SPLMM_BLOCK", "")
+    return max(int(v), 2) if v.strip() else 4096
+
+
+def _sparse_block_route(n):
+    """Block-diagonal spectral form (connected components of the sparse GRM) instead of one dense n x n eigenproblem:
+    from n = 16384 (JXGPU_SPLMM_BLOCK_MIN_N), or always / never with JXGPU_SPLMM_ROUTE=block / dense."""
+    mode = os.environ.get("JXGPU_SPLMM_ROUTE", "").strip().lower()
+    if mode == "block":
+        return True
+    if mode == "dense":
+        return False
+    v = os.environ.get("JXGPU_SPLMM_BLOCK_MIN_N", "")
+    return int(n) >= (int(v) if v.strip() else 16384)
+
+
 def _check_spectral_sparse_size(n):
     """The spectral form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors and the
     eigensolver's workspace (~5 n^2 doubles) in HBM; the reference factorises the sparse K + lambda I instead
@@ -481,6 +499,10 @@ class _SpectralSparseReml:
         import torch
         from . import pipeline as pl
         y = _c(y, np.float64).ravel()
+        self.perm, self.blocks = None, None
+        if _sparse_block_route(y.shape[0]):
+            self._init_blocks(path, y, x_cov, sample_indices)
+            return
         _check_spectral_sparse_size(y.shape[0])
         k, idx = _spgrm_dense_device(path, sample_indices)
         n = int(k.shape[0])
@@ -505,6 +527,104 @@ class _SpectralSparseReml:
         self.yr, self.xr = rot[:, 0].copy(), rot[:, 1:].copy()
         self.smin = float(self.s.min())
         self.s_dev, self.ut_dev, self.x_design, self.y_raw, self.sample_idx = s, ut, x, y, idx
+
+    def _init_blocks(self, path, y, x_cov, sample_indices):
+        """Block-diagonal form: the graph of the (subset of the) sparse GRM is split into connected components, whole
+        components are packed into diagonal blocks of at most `_sparse_block_size()` samples (a larger component is its own
+        block), every block is densified and eigendecomposed on the device on its own.  The model then lives in the BLOCK
+        ORDER of the samples (`self.perm`: position -> index into the caller's sample list); likelihood evaluations only
+        see (s, U'y, U'X) and are unchanged."""
+        import torch
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        from . import pipeline as pl
+        n_all, col_ptr, rows, vals = load_spgrm(path)
+        idx, n_sel = _opt_idx(sample_indices)
+        if idx is not None:
+            if n_sel == 0:
+                raise RuntimeError("Sparse GRM subset requires at least one sample")
+            if idx.min() < 0 or idx.max() >= n_all:
+                raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
+            if len(np.unique(idx)) != n_sel:
+                raise RuntimeError("Sparse GRM subset contains duplicated sample index")
+        n = n_sel if idx is not None else n_all
+        if n != y.shape[0]:
+            raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={n}, phenotype n={y.shape[0]}")
+        if x_cov is None:
+            x = np.ones((n, 1), dtype=np.float64)
+        else:
+            xc = _c(x_cov, np.float64)
+            if xc.ndim != 2 or xc.shape[0] != n:
+                raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
+            x = np.concatenate([np.ones((n, 1)), xc], axis=1)
+        self.n, self.p = n, int(x.shape[1])
+        # connected components of the selected sub-graph (host: one pass over the nnz entries)
+        cp = col_ptr.astype(np.int64)
+        cols = np.repeat(np.arange(n_all, dtype=np.int64), np.diff(cp))
+        r64 = rows.astype(np.int64)
+        local = np.arange(n_all, dtype=np.int64)
+        if idx is not None:
+            local = np.full(n_all, -1, dtype=np.int64)
+            local[idx] = np.arange(n, dtype=np.int64)
+        lr, lc = local[r64], local[cols]
+        ok = (lr >= 0) & (lc >= 0) & (lr != lc) & (vals != 0.0)
+        graph = coo_matrix((np.ones(int(ok.sum()), dtype=np.int8), (lr[ok], lc[ok])), shape=(n, n))
+        ncomp, lab = connected_components(graph, directed=False)
+        sizes = np.bincount(lab, minlength=ncomp)
+        bsz = _sparse_block_size()
+        free, _tot = torch.cuda.mem_get_info()
+        if int(sizes.max()) > bsz and 5 * int(sizes.max()) ** 2 * 8 > free:
+            raise RuntimeError(f"sparse-GRM block route: a connected component of {int(sizes.max())} samples does not fit one "
+                               "dense block in HBM (raise the GRM cutoff or restrict the samples)")
+        # first-fit packing of the components (largest first) into blocks of <= bsz samples
+        order = np.argsort(-sizes, kind="stable")
+        block_of = np.empty(ncomp, dtype=np.int64)
+        fill = []
+        for c in order:
+            placed = False
+            if sizes[c] < bsz:
+                for b in range(len(fill) - 1, max(len(fill) - 64, -1), -1):
+                    if fill[b] + sizes[c] <= bsz:
+                        fill[b] += int(sizes[c])
+                        block_of[c] = b
+                        placed = True
+                        break
+            if not placed:
+                fill.append(int(sizes[c]))
+                block_of[c] = len(fill) - 1
+        sample_block = block_of[lab]
+        perm = np.lexsort((lab, sample_block)).astype(np.int64)          # block order, components contiguous inside a block
+        offs = np.concatenate([[0], np.cumsum(np.bincount(sample_block, minlength=len(fill)))]).astype(np.int64)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_cp = torch.from_numpy(col_ptr.view(np.int64)).to(dev)
+        d_ri = torch.from_numpy(rows.view(np.int32)).to(dev)
+        d_va = torch.from_numpy(vals).to(dev)
+        glob = perm if idx is None else idx[perm]                        # sparse-GRM index of every position of the block order
+        yx = np.concatenate([y[:, None], x], axis=1)[perm]
+        s_all = np.empty(n, dtype=np.float64)
+        rot_all = np.empty((n, 1 + self.p), dtype=np.float64)
+        blocks = []
+        for b in range(len(fill)):
+            o0, o1 = int(offs[b]), int(offs[b + 1])
+            nb = o1 - o0
+            mp = np.full(n_all, -1, dtype=np.int32)
+            mp[glob[o0:o1]] = np.arange(nb, dtype=np.int32)
+            d_map = torch.from_numpy(mp).to(dev)
+            kb = torch.empty((nb, nb), dtype=torch.float64, device=dev)
+            check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all), d_map.data_ptr(), nb,
+                                          kb.data_ptr(), pl._stream()))
+            sb, utb = pl.eigh_from_grm(kb, ridge=0.0)
+            del kb
+            s_all[o0:o1] = sb.cpu().numpy()
+            rot_all[o0:o1] = (utb @ torch.from_numpy(yx[o0:o1]).to(dev)).cpu().numpy()
+            blocks.append((o0, nb, utb))
+        self.s = s_all
+        self.yr, self.xr = rot_all[:, 0].copy(), rot_all[:, 1:].copy()
+        self.smin = float(self.s.min())
+        self.perm, self.blocks = perm, blocks
+        self.s_dev, self.ut_dev = torch.from_numpy(s_all).to(dev), None
+        self.x_design, self.y_raw = x[perm], y[perm]
+        self.sample_idx = glob
 
     def factorizable(self, lam):
         import math
@@ -694,6 +814,9 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
         None if sample_indices is None else _c(sample_indices, np.int64).ravel())
     if grm_sample_indices is not None and panel_idx is not None and panel_idx.shape[0] != model.n:
         raise RuntimeError(f"sample_indices ({panel_idx.shape[0]}) and grm_sample_indices ({model.n}) differ in length")
+    if model.blocks is not None and grm_sample_indices is not None:
+        # block route: the model lives in its block order of the samples; the payload samples follow it
+        panel_idx = model.perm if panel_idx is None else panel_idx[model.perm]
     null = None
     if log10_lambda is None:
         null = _spreml_brent(model, low, high, grid_size, tol, max_iter, None, None)
@@ -721,8 +844,6 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
     dev = model.s_dev.device
     pk_w = pk if pk.flags.writeable else pk.copy()          # torch.from_numpy wants a writable array (memmapped payloads are not)
-    panel = pl.Panel(torch.from_numpy(pk_w).to(dev), n_full, panel_idx)
-    sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
     # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
     # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy
     d = model.s + lam
@@ -734,8 +855,17 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     if not (np.isfinite(ypy) and ypy > 0.0):
         raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)   # noqa: E731
-    out = pl.scan_rows(panel, sm, rows.astype(np.int32), lut, mode="splmm",
-                       fv_state=(f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy))
+    fv_state = (f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy)
+    packed_t = torch.from_numpy(pk_w).to(dev)
+    if model.blocks is not None:
+        if panel_idx is None:
+            panel_idx = np.arange(n_full, dtype=np.int64)
+        rot = pl.BlockRotation(packed_t, n_full, panel_idx, model.blocks)
+        out = pl.scan_rows_splmm_blocks(rot, model.p, rows.astype(np.int32), lut, fv_state)
+    else:
+        panel = pl.Panel(packed_t, n_full, panel_idx)
+        sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
+        out = pl.scan_rows(panel, sm, rows.astype(np.int32), lut, mode="splmm", fv_state=fv_state)
     return out.cpu().numpy(), float(log10_lambda), null
 
 

@@ -414,6 +414,62 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     return (out, evals) if return_evals else out
 
 
+class BlockRotation:
+    """Block-diagonal eigenbasis of a sparse GRM whose graph falls into small connected components (thresholded GRMs are
+    block diagonal by family): the samples are ordered so that every diagonal block holds whole components, each block has
+    its own dense eigendecomposition, and a SNP is rotated block by block with the MFMA rotation kernel writing its columns
+    of the rotated row (`jxg_rotate_packed16x_ld`).  Memory and time are O(n B) / O(n B) per SNP for blocks of B samples
+    instead of O(n^2): the form the SparseLMM routes take beyond the reach of one dense n x n eigenproblem
+    (reference: sparse LLT of K + lambda I, src/stats/spreml.rs:384-512, src/math/cholesky.rs:776-1075)."""
+
+    def __init__(self, packed: torch.Tensor, n_samples: int, sample_idx: np.ndarray, blocks):
+        # blocks: list of (offset, nb, ut64 device tensor (nb, nb), rows = eigenvectors); sample_idx: panel sample of every
+        # position of the block order
+        self.n = int(sum(b[1] for b in blocks))
+        self.parts = []
+        dev = packed.device
+        for off, nb, ut64 in blocks:
+            ut32 = torch.empty((nb, nb), dtype=torch.float32, device=dev)
+            check(lib().jxg_cast_f64_to_f32(_ptr(ut64), _ptr(ut32), nb * nb, _stream()))
+            npad = lib().jxg_num_tiles(nb) * 128
+            hi = torch.empty((npad, npad), dtype=torch.float16, device=dev)
+            lo = torch.empty((npad, npad), dtype=torch.float16, device=dev)
+            check(lib().jxg_ut_split(_ptr(ut32), nb, _ptr(hi), _ptr(lo), SCALE_EXP, _stream()))
+            del ut32
+            panel = Panel(packed, n_samples, np.asarray(sample_idx[off:off + nb], dtype=np.int64))
+            self.parts.append((off, nb, hi, lo, panel))
+        self.m = int(packed.shape[0])
+        self.device = dev
+
+
+def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np.ndarray, fv_state, block_rows=8192):
+    """SparseLMM exact scan (`jxg_splmm_exact_scan_dev`, src/stats/splmm.rs:2567-2880) over rows rotated by a block-diagonal
+    eigenbasis: per block of SNP rows one rotation launch per diagonal block, then the score-form scan over the full
+    rotated rows.  Returns (len(rows), 3) f64 [beta, se, p] on the device."""
+    dev = rot.device
+    n, mk = rot.n, len(rows)
+    out = torch.empty((mk, 3), dtype=torch.float64, device=dev)
+    if mk == 0:
+        return out
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
+    check(lib().jxg_lut_split(_ptr(lut_t), mk, _ptr(lut16), _stream()))      # general rows: hi / lo split of every LUT
+    w, py, wx, a_chol, ypy = fv_state
+    a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
+    br = int(min(block_rows, mk))
+    grot = torch.empty((br, n), dtype=torch.float32, device=dev)
+    for r0 in range(0, mk, br):
+        nr = min(br, mk - r0)
+        for off, nb, hi, lo, panel in rot.parts:
+            check(lib().jxg_rotate_packed16x_ld(_ptr(panel.p32), panel.m, nb, rows_t[r0:].data_ptr(), nr,
+                                                lut16[r0:].data_ptr(), None, None, _ptr(hi), _ptr(lo), SCALE_EXP,
+                                                grot[:, off:].data_ptr(), n, _stream()))
+        check(lib().jxg_splmm_exact_scan_dev(_ptr(grot), nr, n, p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev), ypy, n - p,
+                                             out[r0:].data_ptr(), _stream()))
+    return out
+
+
 @dataclass
 class GwasResult:
     keep: np.ndarray        # (m,) bool, kept SNPs in BED order

@@ -1722,6 +1722,86 @@ def test_splmm_exact_scan_from_jxgrm(oracle, tmp_path, subset, cov):
 
 
 @pytest.mark.gpu
+def test_sparse_grm_row_panels_write_the_same_file(oracle, tmp_path, monkeypatch):
+    """Row-panel form of the sparse GRM builder (the n x n accumulator replaced by 256-row bands: GRM tile rows +
+    threshold + column-wise merge of the panels) against the whole-accumulator form: byte-identical `.spgrm` files, for a
+    kinship cut-off, an absolute cut-off, a negative cut-off (every entry kept), methods 1 and 2, a sample subset, and
+    panel heights that do and do not divide n."""
+    from janusx_amd import janusx as jxrs
+    n, m = 700, 800
+    packed, g = _related_panel(n, m, 57, 0.02)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    pk = np.ascontiguousarray(packed[keep])
+    flip = np.zeros(int(keep.sum()), bool)
+    sub = np.sort(np.random.default_rng(2).permutation(n)[:523]).astype(np.int64)
+    for method, thr, abs_thr, idx in ((1, 0.05, False, None), (2, 0.03, True, None), (1, -1.0, False, None),
+                                      (1, 0.05, False, sub)):
+        monkeypatch.delenv("JXGPU_SPGRM_PANEL_ROWS", raising=False)
+        p0, n0, z0 = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, af[keep], str(tmp_path / "full"), idx, method, thr, abs_thr)
+        ref = open(p0, "rb").read()
+        for prow in (256, 512):
+            monkeypatch.setenv("JXGPU_SPGRM_PANEL_ROWS", str(prow))
+            p1, n1, z1 = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, af[keep], str(tmp_path / f"p{prow}"), idx, method, thr,
+                                                    abs_thr)
+            assert (n1, z1) == (n0, z0) and open(p1, "rb").read() == ref, (method, thr, prow)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", [False, True])
+def test_splmm_block_route_matches_the_dense_route(oracle, tmp_path, monkeypatch, subset):
+    """Block-diagonal spectral route of the sparse-GRM models (connected components of the thresholded GRM packed into
+    diagonal blocks, one eigendecomposition and one rotation launch per block) against the single dense eigenproblem on the
+    same inputs: sparse REML optimum and likelihoods, and the exact scan, with a block size small enough that the families
+    spread over many blocks; with covariates, flipped rows, a sample subset given in shuffled order, and a sparse GRM whose
+    sample order differs from the genotype file's (`grm_sample_indices`)."""
+    from janusx_amd import janusx as jxrs
+    n, m = 320, 600
+    packed, g = _related_panel(n, m, 31, 0.02)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    path, _, _ = jxrs.spgrm_packed_to_jxgrm(np.ascontiguousarray(packed[keep]), n, np.zeros(int(keep.sum()), bool),
+                                            af[keep], str(tmp_path / "k"), None, 1, 0.05)
+    rng = np.random.default_rng(8)
+    gv = np.where(g < 0, 0, g).astype(np.float64)
+    y = gv[50] * 0.5 + gv[200:230].T @ rng.normal(0, 0.2, 30) + rng.normal(0, 1.0, n)
+    sub = rng.permutation(n)[:280].astype(np.int64) if subset else None
+    ys = y[sub] if subset else y
+    xc = rng.normal(size=(len(ys), 2))
+    maf_all = ((he + 2 * ho) / np.maximum(2 * (n - mi), 1)).astype(np.float32)
+    flip = np.zeros(m, dtype=bool)
+    flip[::5] = True
+    rows = np.arange(0, m, 2, dtype=np.int64)
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "dense")
+    ref, l_ref, null_ref = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows)
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "block")
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "48")
+    got, l_got, null_got = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows)
+    assert abs(l_got - l_ref) < 1e-9
+    def same_scalars(u, v):
+        return all(abs(a - b) <= 1e-9 * max(1.0, abs(b)) for a, b in zip(u, v) if isinstance(b, (int, float)))
+    assert same_scalars(null_got, null_ref), (null_got, null_ref)
+    bad = np.isnan(ref[:, 0])
+    assert np.array_equal(np.isnan(got[:, 0]), bad)
+    ok = ~bad
+    scale = np.maximum(np.abs(ref[ok, 0]), ref[ok, 1])
+    assert np.max(np.abs(got[ok, 0] - ref[ok, 0]) / scale) < TOL and np.max(np.abs(got[ok, 1] - ref[ok, 1]) / ref[ok, 1]) < TOL
+    lp = np.abs(np.log(np.maximum(got[ok, 2], 1e-300)) - np.log(np.maximum(ref[ok, 2], 1e-300)))
+    assert np.max(lp / np.maximum(1.0, np.abs(np.log(np.maximum(ref[ok, 2], 1e-300))))) < 10 * TOL
+    # the sparse REML entry point alone (no payload) takes the same route
+    r1 = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, ys, xc, sub)
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "dense")
+    r0 = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, ys, xc, sub)
+    assert same_scalars(r1, r0)
+    # sparse GRM in another sample order than the payload: positions given separately
+    if subset:
+        monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "block")
+        got2, l2, _ = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows,
+                                                       grm_sample_indices=sub)
+        assert abs(l2 - l_ref) < 1e-9 and np.allclose(got2[ok], got[ok], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
 def test_cli_gwas_splmm(oracle, tmp_path):
     """`jx gwas -splmm [cutoff]`: sparse GRM of all genotyped samples, then for the trait's phenotyped samples the
     sparse REML null model and the exact scan; TSV rows against the dense-Cholesky restatement on the written `.spgrm`."""

@@ -474,9 +474,9 @@ def _sparse_block_route(n):
 
 
 def _check_spectral_sparse_size(n):
-    """The spectral form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors and the
-    eigensolver's workspace (~5 n^2 doubles) in HBM; the reference factorises the sparse K + lambda I instead
-    (src/stats/spreml.rs:384-512) and stays usable beyond that.  Refuse clearly instead of failing inside hipMalloc."""
+    """The single-eigenproblem form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors
+    and the eigensolver's workspace (~5 n^2 doubles) in HBM (the block-diagonal form, `_sparse_block_route`, does not).
+    Refuse clearly instead of failing inside hipMalloc."""
     import torch
     need = 5 * int(n) * int(n) * 8
     if torch.cuda.is_available():
@@ -484,8 +484,8 @@ def _check_spectral_sparse_size(n):
         if need > free:
             raise RuntimeError(
                 f"sparse-GRM spectral route: n = {n} needs about {need / 2**30:.0f} GiB of HBM for the dense image of K and "
-                f"its eigenvectors, {free / 2**30:.0f} GiB are free; this build has no sparse-factorisation route for "
-                "larger n (restrict the samples, or use -lmm with the dense GRM)")
+                f"its eigenvectors, {free / 2**30:.0f} GiB are free; use the block-diagonal form (JXGPU_SPLMM_ROUTE=block, the "
+                "default from n = 16384) or restrict the samples")
 
 
 class _SpectralSparseReml:

@@ -231,6 +231,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         JX_HIP(hipEventRecord(ev[3], st));
         if (stage_done("dstedc")) return 1;
         bool sharded_rows = false;                       // d_a already holds this rank's rows + the gathered rest
+        int q2_cols = n;                                 // eigenvector columns the Q2 kernel of this rank processed
         if (twostage) {
             if (ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
@@ -238,6 +239,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 // this rank's eigenvectors only: columns perm[r0 .. r1) of C, gathered into a contiguous (n, nr) block
                 const int r0 = (int)((int64_t)n * drank / dworld), r1 = (int)((int64_t)n * (drank + 1) / dworld);
                 const int nr = r1 - r0;
+                q2_cols = nr;
                 DevBuf dperm, blk;
                 if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;
                 if (blk.alloc(sizeof(double) * (size_t)n * (size_t)(nr > 0 ? nr : 1))) return 1;
@@ -288,7 +290,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 // algorithmic flops of C <- Q2 C: 4 * (reflector length) * n per reflector, lengths ~ 64, n (n - 1) / 2 / 64 of them
                 double refl = 0.0;
                 for (int sidx = 0; sidx < n - 2; ++sidx) refl += (double)(n - 1 - sidx);
-                g_last_ms[5] = (float)(4.0 * refl * (double)n / 1e9);
+                g_last_ms[5] = (float)(4.0 * refl * (double)q2_cols / 1e9);
             }
         }
         if (sharded_rows) {

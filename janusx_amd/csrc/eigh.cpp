@@ -186,6 +186,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             JX_HIP(hipMemcpyAsync(hf, ts_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
             if (hf[0] != 0) {
+                if (trace) (void)stage_done("sy2sb (flagged)");
                 if (trace) fprintf(stderr, "[jxgpu eigh n=%d] band reduction flagged a panel (code %d): one-stage fallback\n", n, hf[0]);
                 JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
                 twostage = false;

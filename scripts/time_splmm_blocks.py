@@ -49,6 +49,10 @@ def main():
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     fam = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     cut = float(sys.argv[4]) if len(sys.argv) > 4 else 0.05
+    payload = ((n + 3) // 4) * m
+    if payload > 12 * 2**30 and not os.environ.get("JXGPU_ALLOW_BIG_HOST"):
+        raise SystemExit(f"packed payload of {payload / 2**30:.0f} GiB: this script keeps three host copies of it; an attempt at "
+                         "n = 200000, m = 1000000 took a GPU box down (set JXGPU_ALLOW_BIG_HOST=1 to run anyway)")
     dev = torch.device("cuda", 0)
     packed_t, dos = family_panel(n, m, fam, 11, dev)
     y = bench.make_phenotype(dos, n, 7, dev)

@@ -473,6 +473,35 @@ def _sparse_block_route(n):
     return int(n) >= (int(v) if v.strip() else 16384)
 
 
+def _pack_components_into_blocks(lab, bsz):
+    """Sample order of the block-diagonal route: `lab[i]` = connected component of sample i.  Whole components are packed
+    (largest first, first fit among the most recent blocks) into blocks of at most `bsz` samples; a component of `bsz` or
+    more samples is a block of its own.  -> (perm, offs): perm[pos] = sample at position pos of the block order (components
+    contiguous inside a block), block b = positions offs[b] .. offs[b + 1]."""
+    lab = np.asarray(lab, dtype=np.int64)
+    ncomp = int(lab.max()) + 1 if lab.size else 0
+    sizes = np.bincount(lab, minlength=ncomp)
+    order = np.argsort(-sizes, kind="stable")
+    block_of = np.empty(ncomp, dtype=np.int64)
+    fill = []
+    for c in order:
+        placed = False
+        if sizes[c] < bsz:
+            for b in range(len(fill) - 1, max(len(fill) - 64, -1), -1):
+                if fill[b] + sizes[c] <= bsz:
+                    fill[b] += int(sizes[c])
+                    block_of[c] = b
+                    placed = True
+                    break
+        if not placed:
+            fill.append(int(sizes[c]))
+            block_of[c] = len(fill) - 1
+    sample_block = block_of[lab]
+    perm = np.lexsort((lab, sample_block)).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(np.bincount(sample_block, minlength=len(fill)))]).astype(np.int64)
+    return perm, offs
+
+
 def _check_spectral_sparse_size(n):
     """The single-eigenproblem form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors
     and the eigensolver's workspace (~5 n^2 doubles) in HBM (the block-diagonal form, `_sparse_block_route`, does not).
@@ -576,25 +605,8 @@ class _SpectralSparseReml:
         if int(sizes.max()) > bsz and 5 * int(sizes.max()) ** 2 * 8 > free:
             raise RuntimeError(f"sparse-GRM block route: a connected component of {int(sizes.max())} samples does not fit one "
                                "dense block in HBM (raise the GRM cutoff or restrict the samples)")
-        # first-fit packing of the components (largest first) into blocks of <= bsz samples
-        order = np.argsort(-sizes, kind="stable")
-        block_of = np.empty(ncomp, dtype=np.int64)
-        fill = []
-        for c in order:
-            placed = False
-            if sizes[c] < bsz:
-                for b in range(len(fill) - 1, max(len(fill) - 64, -1), -1):
-                    if fill[b] + sizes[c] <= bsz:
-                        fill[b] += int(sizes[c])
-                        block_of[c] = b
-                        placed = True
-                        break
-            if not placed:
-                fill.append(int(sizes[c]))
-                block_of[c] = len(fill) - 1
-        sample_block = block_of[lab]
-        perm = np.lexsort((lab, sample_block)).astype(np.int64)          # block order, components contiguous inside a block
-        offs = np.concatenate([[0], np.cumsum(np.bincount(sample_block, minlength=len(fill)))]).astype(np.int64)
+        perm, offs = _pack_components_into_blocks(lab, bsz)
+        fill = np.diff(offs)
         dev = torch.device("cuda", torch.cuda.current_device())
         d_cp = torch.from_numpy(col_ptr.view(np.int64)).to(dev)
         d_ri = torch.from_numpy(rows.view(np.int32)).to(dev)

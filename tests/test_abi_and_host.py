@@ -255,3 +255,26 @@ def test_native_tsv_writer_matches_the_row_format(tmp_path):
     with pytest.raises(RuntimeError, match="columns"):
         w.put(0, stats[:10, :4])
     w.close()
+
+
+def test_block_route_packs_whole_components():
+    """Sample order of the block-diagonal sparse-GRM route (`_pack_components_into_blocks`): a permutation; no component is
+    split over two blocks; components are contiguous inside their block; no block exceeds the size limit unless it is one
+    oversized component; the packing wastes little (singletons fill the blocks)."""
+    from janusx_amd.janusx import _pack_components_into_blocks
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(1, 9, 400), [70, 64, 130], np.ones(300, dtype=np.int64)])
+    lab = rng.permutation(np.repeat(np.arange(len(sizes)), sizes))
+    n = len(lab)
+    for bsz in (64, 100, 4096):
+        perm, offs = _pack_components_into_blocks(lab, bsz)
+        assert sorted(perm.tolist()) == list(range(n)) and offs[0] == 0 and offs[-1] == n
+        block_of_pos = np.repeat(np.arange(len(offs) - 1), np.diff(offs))
+        comp_block = {}
+        for pos, smp in enumerate(perm):
+            assert comp_block.setdefault(int(lab[smp]), int(block_of_pos[pos])) == block_of_pos[pos]
+        for b in range(len(offs) - 1):
+            labs = lab[perm[offs[b]:offs[b + 1]]]
+            assert len(np.nonzero(np.diff(labs))[0]) + 1 == len(np.unique(labs))          # contiguous components
+            assert offs[b + 1] - offs[b] <= bsz or len(np.unique(labs)) == 1
+        assert len(offs) - 1 <= int(np.ceil(n / bsz)) + 3 + int((sizes >= bsz).sum())

@@ -1630,7 +1630,8 @@ def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_ind
                           tol=1e-4, block_rows=4096, threads=0, return_variance_components=False, estimate_only=False,
                           return_effect=False, row_source_indices=None, row_flip=None, row_maf=None,
                           mmap_window_mb=None):
-    """src/stats/gblup.rs:1517-1958, metadata-streaming path (the one `python/janusx/gs/workflow.py:6300-6360` takes):
+    """src/stats/gblup.rs:1517-1958, metadata-streaming path (the one `python/janusx/gs/workflow.py:6300-6360` takes; without
+    the metadata arguments the `site_keep` route :1986-2140 with the loader's row statistics, same formulation):
     GRM of the training samples straight from the BED payload, spectral REML, then marker effects
     effect_beta = (M' alpha - mean * sum(alpha)) / sum(var) and predictions alpha0 + M beta, M never materialised
     (jxg_packed_tdot / jxg_packed_dot).  Returns the reference's 12-tuple (pred_train (k,1), pred_test (t,1), pve,
@@ -1648,9 +1649,31 @@ def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_ind
         raise RuntimeError("max_iter must be > 0")
     if not (math.isfinite(tol) and tol > 0.0):
         raise RuntimeError("tol must be finite and > 0")
+    packed_loaded = None
     if row_source_indices is None or row_flip is None or row_maf is None:
-        raise RuntimeError("gblup_reml_packed_bed: only the metadata streaming path (row_source_indices, row_flip, "
-                           "row_maf) is built")
+        # `site_keep` route (gblup.rs:1986-2140): the whole payload (or the rows of the mask) with the loader's own row
+        # statistics -- alt-allele frequency over all samples (`load_bed_2bit_packed`) and the flip mask of
+        # `bed_packed_row_flip_mask` -- then the same model.  The reference evaluates it in marker space when
+        # n_train > m (`gblup_marker_fast_packed`) and through `grm_packed_f64_with_stats` otherwise; here both go through
+        # the formulation of the metadata route below (one GRM of the training samples, spectral REML, M' alpha).
+        packed_loaded, _miss, maf_all, _std, n_loaded = load_bed_2bit_packed(prefix)
+        if n_loaded == 0:
+            raise RuntimeError("No samples found in BED input.")
+        m_total = int(packed_loaded.shape[0])
+        if m_total == 0:
+            raise RuntimeError("No SNP rows found in BED input.")
+        flip_all = bed_packed_row_flip_mask(packed_loaded, n_loaded)
+        if site_keep is not None:
+            mask = np.asarray(site_keep).astype(bool).ravel()
+            if mask.shape[0] != m_total:
+                raise RuntimeError(f"site_keep length mismatch: got {mask.shape[0]}, expected {m_total}")
+            row_source_indices = np.nonzero(mask)[0].astype(np.int64)
+            if row_source_indices.size == 0:
+                raise RuntimeError("No SNPs remained after applying site_keep mask.")
+        else:
+            row_source_indices = np.arange(m_total, dtype=np.int64)
+        row_flip = np.asarray(flip_all)[row_source_indices]
+        row_maf = np.asarray(maf_all, dtype=np.float32)[row_source_indices]
     src = np.asarray(row_source_indices, dtype=np.int64).ravel()
     if src.size == 0:
         raise RuntimeError("row_source_indices must not be empty for metadata streaming path.")
@@ -1661,7 +1684,10 @@ def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_ind
     if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
         raise RuntimeError(f"metadata length mismatch: row_source_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
                            f"row_maf={maf.shape[0]}")
-    packed, n_samples, _bim = read_bed_payload(prefix)
+    if packed_loaded is not None:
+        packed, n_samples = packed_loaded, int(n_loaded)
+    else:
+        packed, n_samples, _bim = read_bed_payload(prefix)
     if n_samples == 0:
         raise RuntimeError("No samples found in BED input.")
     if src.max() >= packed.shape[0]:

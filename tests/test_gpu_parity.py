@@ -1084,8 +1084,23 @@ def test_gblup_reml_packed_bed(oracle, tmp_path, subset):
     check(lib().jxg_packed_dot(pan.p32.data_ptr(), pan.m, len(tr), None, len(src), lut_t.data_ptr(), b_t.data_ptr(),
                                o2.data_ptr(), st))
     assert np.max(np.abs(o1.cpu().numpy() - dec @ a)) < 1e-11 and np.max(np.abs(o2.cpu().numpy() - dec.T @ b)) < 1e-11
-    with pytest.raises(RuntimeError):
-        jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr])       # site_keep route is not built
+    # `site_keep` route (no metadata): the loader's own row statistics and flip mask, all rows or the rows of the mask --
+    # the restatement fed with exactly those is the reference value
+    pk_all, _miss_all, maf_all, _std_all, n_all = jxrs.load_bed_2bit_packed(prefix)
+    flip_all = jxrs.bed_packed_row_flip_mask(pk_all, n_all)
+    mask = rng.random(m) < 0.8
+    for sk in (None, mask):
+        rows_k = np.arange(m) if sk is None else np.nonzero(sk)[0]
+        ptr_r, pte_r, fit_r = oracle.gblup_reml_packed_meta(packed, n, rows_k, np.asarray(flip_all)[rows_k],
+                                                           np.asarray(maf_all)[rows_k], tr, y_all[tr], te)
+        o = jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr], te, None, sk, 1e-8, -6.0, 6.0, 50, 1e-4, 4096, 1, True, False,
+                                       True)
+        assert o[8] == len(rows_k) and abs(o[3] - fit_r["lbd"]) < 3e-4 * fit_r["lbd"]
+        assert abs(o[5] - fit_r["reml"]) < 1e-7 * abs(fit_r["reml"])
+        assert np.max(np.abs(o[11] - fit_r["effect_beta"])) < 1e-4 * np.max(np.abs(fit_r["effect_beta"]))
+        assert np.max(np.abs(o[0].ravel() - ptr_r)) < 1e-4 * scale and np.max(np.abs(o[1].ravel() - pte_r)) < 1e-4 * scale
+    with pytest.raises(RuntimeError, match="site_keep length"):
+        jxrs.gblup_reml_packed_bed(prefix, tr, y_all[tr], site_keep=mask[:-1])
 
 
 def test_eigh_own_divide_and_conquer(monkeypatch):

@@ -232,9 +232,12 @@ def cmd_gwas(args):
             try:
                 res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het,
                                    on_rows=open_writer)
-            finally:
+            except BaseException:
                 if "w" in wr:
-                    wr["w"].close()
+                    wr["w"].abort()
+                raise
+            if "w" in wr:
+                wr["w"].close()
             # LMM -> LM fallback test (src/stats/gwas_unified.rs:121-175); the LM scan itself is out of scope
             sw, stat, pv, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x[:, 1:], res.null.ml0)
             if sw and not args.force_model:

@@ -172,6 +172,16 @@ class AsyncAssocTsvWriter:
             raise RuntimeError(f"result block has {st.shape} columns, the writer was opened for {self.ncol}")
         self.q.put((int(i0), st))
 
+    def abort(self):
+        """Stop the thread and remove the temp file (the scan failed: no partial table under the final name)."""
+        self.err = self.err or RuntimeError("aborted")
+        self.q.put(None)
+        self.th.join()
+        try:
+            os.remove(self.tmp)
+        except OSError:
+            pass
+
     def close(self) -> int:
         import numpy as np
         self.q.put(None)

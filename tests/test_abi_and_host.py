@@ -255,6 +255,10 @@ def test_native_tsv_writer_matches_the_row_format(tmp_path):
     with pytest.raises(RuntimeError, match="columns"):
         w.put(0, stats[:10, :4])
     w.close()
+    w = tsv.AsyncAssocTsvWriter(str(tmp_path / "gone.tsv"), 3, chrom, pos, snp, ["A"] * n, ["T"] * n, af, miss)
+    w.put(0, stats[:100, :3])
+    w.abort()                                                        # a failed scan leaves nothing behind
+    assert not os.path.exists(str(tmp_path / "gone.tsv")) and not [f for f in os.listdir(tmp_path) if "gone.tsv.tmp" in f]
 
 
 def test_block_route_packs_whole_components():

@@ -305,8 +305,24 @@ int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int
     const int64_t tiles = (int64_t)tm * tn;
     int ksplit = 1;
     if (tiles < 384) {
-        ksplit = (int)((768 + tiles - 1) / tiles);
+        // two workgroups fit a CU: with `slots` resident workgroups the product takes ceil(tiles ks / slots) rounds of a
+        // 1 / ks share of K each -- take the smallest ks within 3 % of the best (fewer slices to reduce);
+        // JXGPU_DSYMM_SPLIT=768 restores the former "fill 768 slots" rule
+        static const int rule = getenv("JXGPU_DSYMM_SPLIT") ? atoi(getenv("JXGPU_DSYMM_SPLIT")) : 0;
         const int maxsplit = ceil_div(m, DG_BK) / 8 > 0 ? ceil_div(m, DG_BK) / 8 : 1;
+        if (rule > 0) {
+            ksplit = (int)((rule + tiles - 1) / tiles);
+        } else {
+            const int64_t slots = 512;
+            double best = 1e300;
+            for (int ks = 1; ks <= 16 && ks <= maxsplit; ++ks) {
+                const double cost = (double)((tiles * ks + slots - 1) / slots) / (double)ks;
+                if (cost < 0.97 * best) {
+                    best = cost;
+                    ksplit = ks;
+                }
+            }
+        }
         if (ksplit > maxsplit) ksplit = maxsplit;
     }
     g.ksplit = dg_fit_split(ksplit, m, n, ws ? ws_doubles : 0);

@@ -625,7 +625,10 @@ class _SpectralSparseReml:
             kb = torch.empty((nb, nb), dtype=torch.float64, device=dev)
             check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all), d_map.data_ptr(), nb,
                                           kb.data_ptr(), pl._stream()))
-            sb, utb = pl.eigh_from_grm(kb, ridge=0.0)
+            if nb == 1:                                  # a lone sample: its own eigenpair
+                sb, utb = kb.reshape(1).clone(), torch.ones((1, 1), dtype=torch.float64, device=dev)
+            else:
+                sb, utb = pl.eigh_from_grm(kb, ridge=0.0)
             del kb
             s_all[o0:o1] = sb.cpu().numpy()
             rot_all[o0:o1] = (utb @ torch.from_numpy(yx[o0:o1]).to(dev)).cpu().numpy()

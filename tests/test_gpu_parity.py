@@ -1803,6 +1803,11 @@ def test_splmm_block_route_matches_the_dense_route(oracle, tmp_path, monkeypatch
     assert np.max(np.abs(got[ok, 0] - ref[ok, 0]) / scale) < TOL and np.max(np.abs(got[ok, 1] - ref[ok, 1]) / ref[ok, 1]) < TOL
     lp = np.abs(np.log(np.maximum(got[ok, 2], 1e-300)) - np.log(np.maximum(ref[ok, 2], 1e-300)))
     assert np.max(lp / np.maximum(1.0, np.abs(np.log(np.maximum(ref[ok, 2], 1e-300))))) < 10 * TOL
+    # blocks of two samples: many blocks, single-sample blocks among them
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "2")
+    got_b2, l_b2, _ = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows[:64])
+    assert abs(l_b2 - l_ref) < 1e-9 and np.allclose(got_b2[ok[:64]], got[:64][ok[:64]], rtol=1e-6, atol=1e-9)
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "48")
     # the sparse REML entry point alone (no payload) takes the same route
     r1 = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, ys, xc, sub)
     monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "dense")

@@ -410,6 +410,25 @@ int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8
                     double high, int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml,
                     double nullml, double *out);
 
+/* `lm_block_assoc_packed` (src/stats/glm.rs:3550-3860): the plain LM scan `jx gwas -lmm / -fvlmm` switches to when the null
+ * likelihood-ratio test (jx_gwas_lmm_lm_null_lrt_decision) finds no polygenic variance
+ * (python/janusx/assoc/workflow_model_stream.py:930-963).  x (n, q0) row-major INCLUDING the intercept column, ixx (q0, q0) =
+ * (X'X)^-1 (`_lm_precompute_ixx_qr`, python/janusx/pyBLUP/assoc.py:453-480), decode = mean-imputed additive
+ * ([0, clamp(2 maf, 0, 2), 1, 2] or flipped, src/math/bedmath.rs:984-989).  out (m, 4) = beta, se, pwald (two-sided Student t,
+ * df = n - q0 - 1), plrt. */
+int jx_lm_assoc_packed(const double *y, const double *x, const double *ixx, int q0, const uint8_t *packed, int64_t m,
+                       int n_samples, const uint8_t *row_flip, const float *row_maf, const int64_t *sample_indices,
+                       int n_sel, double *out);
+/* Host half of the LM scan (glm.rs:3635-3672): r_y = y - X (ixx X'y), *yy_r = r_y'r_y, xr_out (n, q0 + 1) = [X | r_y]
+ * rounded through f32 as the reference does before its sgemm. */
+int jx_lm_residualize(const double *y, const double *x, const double *ixx, int n, int q0, double *xr_out,
+                      double *yy_r_out);
+/* Device half on a resident P32 image: d_lut (nrows, 4) f32, d_xr (n, q0 + 1) f64, d_ixx (q0, q0) f64, d_work
+ * (nrows * (q0 + 2)) f64 scratch, d_out (nrows, 4) f64. */
+int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const float *d_lut,
+                    const double *d_xr, int q0, const double *d_ixx, double yy_r, double *d_work, double *d_out,
+                    void *stream);
+
 /* `gblup_reml_npy_grm` (src/stats/gblup.rs:1242-1516) on an in-memory GRM: fit on K[train,train] + g_eps I, predict
  * K[*,train] alpha + beta0.  out_scalars = (pve, lambda, ml, reml, sigma_g2, sigma_e2, beta0). */
 int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const int64_t *train_idx, int n_train,

@@ -219,33 +219,36 @@ def cmd_gwas(args):
             t1 = time.perf_counter()
             # rows are formatted and written block by block on a writer thread while the device scans the next block
             # (src/stats/lmm.rs:975-1477 with its AsyncTsvWriter, src/stats/common.rs:374)
-            path = f"{out}.{name}.{mode}.tsv"
             wr = {}
 
-            def open_writer(keep_mask, af_k, miss_k, ncol):
+            def open_writer(keep_mask, af_k, miss_k, ncol, model_tag):
                 kept_rows = np.nonzero(keep_mask)[0]
-                wr["w"] = AsyncAssocTsvWriter(path, ncol, [bim.chrom[j] for j in kept_rows], [bim.pos[j] for j in kept_rows],
+                wr["path"] = f"{out}.{name}.{model_tag}.tsv"
+                wr["w"] = AsyncAssocTsvWriter(wr["path"], ncol, [bim.chrom[j] for j in kept_rows], [bim.pos[j] for j in kept_rows],
                                               [bim.snp[j] for j in kept_rows], [bim.a0[j] for j in kept_rows],
                                               [bim.a1[j] for j in kept_rows], af_k, miss_k)
                 return wr["w"].put
 
             try:
                 res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het,
-                                   on_rows=open_writer)
+                                   on_rows=open_writer, force_model=bool(args.force_model))
             except BaseException:
                 if "w" in wr:
                     wr["w"].abort()
                 raise
             if "w" in wr:
                 wr["w"].close()
-            # LMM -> LM fallback test (src/stats/gwas_unified.rs:121-175); the LM scan itself is out of scope
-            sw, stat, pv, _ = jxrs.gwas_lmm_lm_null_lrt_decision(y, x[:, 1:], res.null.ml0)
-            if sw and not args.force_model:
-                print(f"[{name}] note: null LRT p={pv:.3g} >= 0.05 - the reference would switch to the plain LM scan "
-                      f"here (not built); continuing with -{mode} as with -force-model")
             kept = np.nonzero(res.keep)[0]
-            print(f"[{name}] -{mode}: n={n} snps={len(kept)} lambda0={res.null.lbd:.5g} pve={res.null.pve:.4f} "
-                  f"-> {path} ({time.perf_counter() - t1:.2f}s)")
+            path = wr.get("path", f"{out}.{name}.{res.model_tag}.tsv")
+            if res.model_tag == "lm":
+                # LMM -> LM fallback (src/stats/gwas_unified.rs:121-175, workflow_model_stream.py:930-963)
+                _sw, stat, pv = res.null_lrt
+                print(f"[{name}] Warning: -{mode} switch to LM: null LRT stat={stat:.4g}, p={pv:.4g} (>=0.05); "
+                      f"pve(null)={res.null.pve:.4f}")
+                print(f"[{name}] -lm: n={n} snps={len(kept)} -> {path} ({time.perf_counter() - t1:.2f}s)")
+            else:
+                print(f"[{name}] -{mode}: n={n} snps={len(kept)} lambda0={res.null.lbd:.5g} pve={res.null.pve:.4f} "
+                      f"-> {path} ({time.perf_counter() - t1:.2f}s)")
         if sparse_path is not None:
             from . import stats as st
             t1 = time.perf_counter()

@@ -857,6 +857,90 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// lm_block_assoc_packed (src/stats/glm.rs:3550-3860): the plain LM scan the mixed-model routes fall back to
+// ---------------------------------------------------------------------------------------------------
+extern "C" int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                               const float *d_lut, const double *d_xr, int q0, const double *d_ixx, double yy_r,
+                               double *d_work, double *d_out, void *stream);
+
+// Host half shared with the resident-panel route (janusx_amd/pipeline.py): r_y = y - X (C X'y), y'M_X y, and [X | r_y]
+// rounded through f32 (glm.rs:3635-3672).  xr_out (n, q0 + 1).
+extern "C" int jx_lm_residualize(const double *y, const double *x, const double *ixx, int n, int q0, double *xr_out,
+                                 double *yy_r_out) {
+    if (n <= 0 || q0 < 0) return fail("X.n_rows must equal len(y)");
+    if (n <= q0 + 1) return fail("n too small: require n > q0+1, got n=" + std::to_string(n) + ", q0=" + std::to_string(q0));
+    std::vector<double> xy((size_t)q0, 0.0), cxy((size_t)q0, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < q0; ++j) xy[j] += x[(size_t)i * q0 + j] * y[i];
+    for (int i = 0; i < q0; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < q0; ++j) acc += ixx[(size_t)i * q0 + j] * xy[j];
+        cxy[i] = acc;
+    }
+    double yy = 0.0;
+    const int ld = q0 + 1;
+    for (int i = 0; i < n; ++i) {
+        double pred = 0.0;
+        for (int j = 0; j < q0; ++j) pred += x[(size_t)i * q0 + j] * cxy[j];
+        const double resid = y[i] - pred;
+        yy += resid * resid;
+        for (int j = 0; j < q0; ++j) xr_out[(size_t)i * ld + j] = (double)(float)x[(size_t)i * q0 + j];
+        xr_out[(size_t)i * ld + q0] = (double)(float)resid;
+    }
+    *yy_r_out = yy;
+    return 0;
+}
+
+extern "C" int jx_lm_assoc_packed(const double *y, const double *x, const double *ixx, int q0, const uint8_t *packed,
+                                  int64_t m, int n_samples, const uint8_t *row_flip, const float *row_maf,
+                                  const int64_t *sample_indices, int n_sel, double *out) {
+    if (n_samples <= 0) return fail("n_samples must be > 0");
+    if (m <= 0) return 0;
+    SampleSel sel;
+    if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
+    const int n = sel.n;
+    std::vector<double> xr((size_t)n * (q0 + 1));
+    double yy_r = 0.0;
+    if (jx_lm_residualize(y, x, ixx, n, q0, xr.data(), &yy_r)) return 1;
+    DevBuf p32;
+    if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
+    std::vector<float> lut((size_t)m * 4);
+    for (int64_t j = 0; j < m; ++j) {                       // `decode_mean_imputed_additive_packed_block_rows_f32`,
+        const float mean_g = std::min(std::max(2.0f * row_maf[j], 0.0f), 2.0f);   // src/math/bedmath.rs:984-989
+        float *l = &lut[(size_t)j * 4];
+        if (row_flip[j]) l[0] = 2.0f, l[1] = mean_g, l[2] = 1.0f, l[3] = 0.0f;
+        else l[0] = 0.0f, l[1] = mean_g, l[2] = 1.0f, l[3] = 2.0f;
+    }
+    DevBuf dlut, dxr, dixx, dwork, dout;
+    if (dlut.alloc(lut.size() * sizeof(float)) || dxr.alloc(xr.size() * sizeof(double)) ||
+        dixx.alloc(sizeof(double) * (size_t)std::max(q0 * q0, 1)))
+        return 1;
+    JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
+    JX_HIP(hipMemcpy(dxr.p, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (q0 > 0) JX_HIP(hipMemcpy(dixx.p, ixx, sizeof(double) * (size_t)q0 * q0, hipMemcpyHostToDevice));
+    const int64_t brows = 1 << 20;
+    if (dwork.alloc(sizeof(double) * (size_t)std::min(brows, m) * (q0 + 2)) ||
+        dout.alloc(sizeof(double) * (size_t)std::min(brows, m) * 4))
+        return 1;
+    DevBuf drows;
+    if (drows.alloc(sizeof(int32_t) * (size_t)std::min(brows, m))) return 1;
+    std::vector<int32_t> hrows((size_t)std::min(brows, m));
+    ProgressTicker ticker;
+    for (int64_t r0 = 0; r0 < m; r0 += brows) {
+        const int rows = (int)std::min<int64_t>(brows, m - r0);
+        for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
+        JX_HIP(hipMemcpy(drows.p, hrows.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
+        if (jxg_lm_scan_p32(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows, dlut.as<float>() + (size_t)r0 * 4,
+                            dxr.as<double>(), q0, dixx.as<double>(), yy_r, dwork.as<double>(), dout.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)r0 * 4, dout.p, sizeof(double) * (size_t)rows * 4, hipMemcpyDeviceToHost));
+        if (ticker.tick(r0 + rows, m, brows)) return fail("interrupted by the progress callback");
+    }
+    return 0;
+}
+
+
 // ---- association TSV writer (host) ------------------------------------------------------------------------------------
 // Native counterpart of the reference's row formatter + writer (src/io/assoc2tsv.rs:430-548, `AsyncTsvWriter`
 // src/stats/common.rs:374): the numeric columns of every row are formatted here with Rust's float text (`{:.4}`,

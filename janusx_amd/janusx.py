@@ -1577,6 +1577,67 @@ def gwas_lmm_lm_null_lrt_decision(y, x_cov, lmm_ml0, alpha=0.05, boundary_mixtur
     return bool(pval >= alpha), stat, pval, lm_ml0
 
 
+def lm_precompute_ixx_qr(x):
+    """`_lm_precompute_ixx_qr` (python/janusx/pyBLUP/assoc.py:453-480): (X'X)^-1 of the LM design through the reduced QR,
+    the Hermitian pseudo-inverse when X is rank deficient."""
+    x = _c(x, np.float64)
+    if x.ndim != 2:
+        raise ValueError("X must be 2D for LM QR precomputation.")
+    n, q = x.shape
+    if n == 0 or q == 0:
+        raise ValueError("X must be non-empty for LM QR precomputation.")
+    _q, r = np.linalg.qr(x, mode="reduced")
+    diag = np.abs(np.diag(r))
+    tol = np.finfo(np.float64).eps * float(max(n, q)) * (float(diag.max()) if diag.size else 0.0)
+    if int(np.sum(diag > tol)) == q:
+        rinv = np.linalg.inv(r)
+        return np.ascontiguousarray(rinv @ rinv.T)
+    return np.ascontiguousarray(np.linalg.pinv(x.T @ x, hermitian=True))
+
+
+def lm_block_assoc_packed(y, x, ixx, packed, n_samples, row_flip, row_maf, sample_indices=None, chunk_size=10000,
+                          threads=0, progress_callback=None, progress_every=0):
+    """src/stats/glm.rs:3550-3860 -> f64 (m, 4) = beta, se, pwald (two-sided Student t, df = n - q0 - 1), plrt.  `x` (n, q0)
+    carries the intercept column (the `LM` wrapper prepends it, python/janusx/pyBLUP/assoc.py:2192-2199); `chunk_size` and
+    `threads` are accepted for signature parity (the whole payload is scanned from HBM)."""
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if int(chunk_size) <= 0:
+        raise RuntimeError("chunk_size must be > 0")
+    y = _c(y, np.float64).ravel()
+    x = _c(x, np.float64)
+    ixx = _c(ixx, np.float64)
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    m, bps = int(packed.shape[0]), int(packed.shape[1])
+    if bps != (int(n_samples) + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {bps}, expected {(int(n_samples) + 3) // 4}")
+    flip = _c(np.asarray(row_flip).astype(np.uint8), np.uint8).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if flip.shape[0] != m:
+        raise RuntimeError(f"row_flip length mismatch: got {flip.shape[0]}, expected {m}")
+    if maf.shape[0] != m:
+        raise RuntimeError(f"row_maf length mismatch: got {maf.shape[0]}, expected {m}")
+    idx, n_sel = _opt_idx(sample_indices)
+    n = y.shape[0]
+    if (n_sel if idx is not None else int(n_samples)) != n:
+        raise RuntimeError(f"sample_indices length mismatch: got {n_sel if idx is not None else int(n_samples)}, "
+                           f"expected len(y)={n}")
+    if x.ndim != 2 or x.shape[0] != n:
+        raise RuntimeError("X.n_rows must equal len(y)")
+    q0 = int(x.shape[1])
+    if ixx.shape != (q0, q0):
+        raise RuntimeError("ixx must be (q0,q0)")
+    if n <= q0 + 1:
+        raise RuntimeError(f"n too small: require n > q0+1, got n={n}, q0={q0}")
+    out = np.zeros((m, 4), dtype=np.float64)
+    with _progress_hook(progress_callback, progress_every):
+        check(lib().jx_lm_assoc_packed(_p(y), _p(x), _p(ixx), q0, _p(packed), m, int(n_samples), _p(flip), _p(maf),
+                                       _p(idx), n_sel, _p(out)))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # GBLUP (`jx gs -BLUP`, n <= 15 000 branch): src/stats/gblup.rs:1242-1516 `gblup_reml_npy_grm`
 # ------------------------------------------------------------------------------------------------

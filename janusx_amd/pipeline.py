@@ -470,6 +470,41 @@ def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np
     return out
 
 
+def scan_rows_lm(panel: Panel, rows: np.ndarray, af: np.ndarray, x: np.ndarray, y: np.ndarray, on_block=None):
+    """Plain LM scan of the given SNP rows of a resident panel (`lm_block_assoc_packed`, src/stats/glm.rs:3550-3860; the `LM`
+    wrapper python/janusx/pyBLUP/assoc.py:2185-2228): mean-imputed additive decode with the rows' allele frequencies, `x`
+    includes the intercept.  Returns a (len(rows), 4) f64 device tensor [beta, se, pwald (Student t), plrt]."""
+    from .janusx import lm_precompute_ixx_qr
+    dev = panel.device
+    n = panel.n
+    y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if y.shape[0] != n or x.shape[0] != n:
+        raise RuntimeError(f"selected sample count {panel.n} != len(y) {y.shape[0]}")
+    q0 = int(x.shape[1])
+    mk = len(rows)
+    out = torch.empty((mk, 4), dtype=torch.float64, device=dev)
+    if mk == 0:
+        return out
+    ixx = lm_precompute_ixx_qr(x)
+    xr = np.empty((n, q0 + 1), dtype=np.float64)
+    yy = np.zeros(1, dtype=np.float64)
+    check(lib().jx_lm_residualize(y.ctypes.data, x.ctypes.data, ixx.ctypes.data, n, q0, xr.ctypes.data, yy.ctypes.data))
+    mean_g = np.clip(np.float32(2.0) * np.asarray(af, dtype=np.float32), np.float32(0.0), np.float32(2.0))
+    lut = np.zeros((mk, 4), dtype=np.float32)
+    lut[:, 1], lut[:, 2], lut[:, 3] = mean_g, 1.0, 2.0
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(lut).to(dev)
+    xr_t = torch.from_numpy(xr).to(dev)
+    ixx_t = torch.from_numpy(ixx).to(dev)
+    work = torch.empty(mk * (q0 + 2), dtype=torch.float64, device=dev)
+    check(lib().jxg_lm_scan_p32(_ptr(panel.p32), panel.m, n, _ptr(rows_t), mk, _ptr(lut_t), _ptr(xr_t), q0, _ptr(ixx_t),
+                                float(yy[0]), _ptr(work), _ptr(out), _stream()))
+    if on_block is not None:
+        on_block(0, out[:, :3].cpu().numpy())
+    return out
+
+
 @dataclass
 class GwasResult:
     keep: np.ndarray        # (m,) bool, kept SNPs in BED order
@@ -479,6 +514,8 @@ class GwasResult:
     null: NullFit
     grm_eff_m: int
     times: dict
+    model_tag: str = None   # route that produced `stats`: the requested mode, or "lm" after the null LRT fallback
+    null_lrt: tuple = None  # (switch_to_lm, LRT statistic, p) of `gwas_lmm_lm_null_lrt_decision` when it was evaluated
 
 
 def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.05, panel: Panel = None):
@@ -502,12 +539,16 @@ def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.0
 
 
 def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y: np.ndarray, x: np.ndarray,
-              mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False, on_rows=None):
+              mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False, on_rows=None,
+              force_model=True):
     """One trait of `run_chunked_gwas_lmm_lm` (python/janusx/assoc/workflow_model_stream.py:464-1480):
     eigh of K[keep, keep] + 1e-6 I, spectral null model, QC on the trait's samples, rotate + scan.
     `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order).
-    `on_rows(keep, af, miss, ncol)` (optional) is called once the kept SNP set is known and returns the `on_block`
-    callback of `scan_rows` (or None): the streaming writer is opened there."""
+    `on_rows(keep, af, miss, ncol, model_tag)` (optional) is called once the kept SNP set and the route are known and
+    returns the `on_block` callback of `scan_rows` (or None): the streaming writer is opened there.
+    force_model=False: the null likelihood-ratio test against the plain LM (`gwas_lmm_lm_null_lrt_decision`) runs after the
+    null fit and, when it finds no polygenic variance (p >= 0.05), the trait is scanned with the LM instead
+    (workflow_model_stream.py:930-963; result.model_tag == "lm", three columns beta, se, Student-t p)."""
     keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
     s, ut64 = eigh_from_grm(k, 1e-6, keep_idx)
     model = SpectralModel(s, ut64, x, y)
@@ -518,7 +559,18 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
     rows = np.nonzero(keep)[0]
     lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
-    on_block = on_rows(keep, af[rows], miss[rows], 6 if mode == "lmm2" else 3) if on_rows is not None else None
+    lrt = None
+    if not force_model:
+        from .janusx import gwas_lmm_lm_null_lrt_decision
+        sw, stat, pv, _ml = gwas_lmm_lm_null_lrt_decision(y, np.asarray(x)[:, 1:], model.null.ml0)
+        lrt = (sw, stat, pv)
+        if sw:
+            on_block = on_rows(keep, af[rows], miss[rows], 3, "lm") if on_rows is not None else None
+            out = scan_rows_lm(panel, rows, af[rows], x, y, on_block=on_block)
+            res = GwasResult(keep, af[rows], miss[rows], out[:, :3].cpu().numpy(), model.null, 0, {})
+            res.model_tag, res.null_lrt = "lm", lrt
+            return res
+    on_block = on_rows(keep, af[rows], miss[rows], 6 if mode == "lmm2" else 3, mode) if on_rows is not None else None
     if mode == "lmm":
         init = math.log10(model.null.lbd) if (warm_start and model.null.lbd > 0) else None
         if init is not None:
@@ -540,7 +592,9 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
                         on_block=on_block)
     else:
         out = scan_rows(panel, model, rows, lut, "fvlmm", on_block=on_block)
-    return GwasResult(keep, af[rows], miss[rows], out.cpu().numpy(), model.null, 0, {})
+    res = GwasResult(keep, af[rows], miss[rows], out.cpu().numpy(), model.null, 0, {})
+    res.model_tag, res.null_lrt = mode, lrt
+    return res
 
 
 def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndarray = None, mode="lmm",

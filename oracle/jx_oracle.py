@@ -1344,6 +1344,152 @@ def lm_null_ml(y, xcov):
 
 
 # --------------------------------------------------------------------------------------------
+# A.9b  plain LM scan, the route taken after the fallback decision (src/stats/glm.rs:383-501, 3550-3860)
+# --------------------------------------------------------------------------------------------
+
+def lm_precompute_ixx_qr(x):
+    """`_lm_precompute_ixx_qr` (python/janusx/pyBLUP/assoc.py:453-480): (X'X)^-1 through the reduced QR, the
+    Hermitian pseudo-inverse when X is rank deficient."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    n, q = x.shape
+    _q, r = np.linalg.qr(x, mode="reduced")
+    diag = np.abs(np.diag(r))
+    tol = EPS64 * float(max(n, q)) * (float(diag.max()) if diag.size else 0.0)
+    if int(np.sum(diag > tol)) == q:
+        rinv = np.linalg.inv(r)
+        return np.ascontiguousarray(rinv @ rinv.T)
+    return np.ascontiguousarray(np.linalg.pinv(x.T @ x, hermitian=True))
+
+
+def betacf(a, b, x):
+    """Continued fraction of the incomplete beta function (src/stats/glm.rs:383-433)."""
+    eps, fpmin = 3.0e-14, 1.0e-300
+    qab, qap, qam = a + b, a + 1.0, a - 1.0
+    c = 1.0
+    d = 1.0 - qab * x / qap
+    if abs(d) < fpmin:
+        d = fpmin
+    d = 1.0 / d
+    h = d
+    for m in range(1, 201):
+        fm = float(m)
+        m2 = 2.0 * fm
+        aa = fm * (b - fm) * x / ((qam + m2) * (a + m2))
+        d = 1.0 + aa * d
+        if abs(d) < fpmin:
+            d = fpmin
+        c = 1.0 + aa / c
+        if abs(c) < fpmin:
+            c = fpmin
+        d = 1.0 / d
+        h *= d * c
+        aa = -(a + fm) * (qab + fm) * x / ((a + m2) * (qap + m2))
+        d = 1.0 + aa * d
+        if abs(d) < fpmin:
+            d = fpmin
+        c = 1.0 + aa / c
+        if abs(c) < fpmin:
+            c = fpmin
+        d = 1.0 / d
+        de = d * c
+        h *= de
+        if abs(de - 1.0) < eps:
+            break
+    return h
+
+
+def betai(a, b, x):
+    """Regularised incomplete beta function (src/stats/glm.rs:435-455)."""
+    if not (0.0 <= x <= 1.0):
+        return float("nan")
+    if x == 0.0:
+        return 0.0
+    if x == 1.0:
+        return 1.0
+    ln_beta = math.lgamma(a) + math.lgamma(b) - math.lgamma(a + b)
+    if x < (a + 1.0) / (a + b + 2.0):
+        return math.exp(a * math.log(x) + b * math.log(1.0 - x) - ln_beta) / a * betacf(a, b, x)
+    return 1.0 - math.exp(b * math.log(1.0 - x) + a * math.log(x) - ln_beta) / b * betacf(b, a, 1.0 - x)
+
+
+def student_t_p_two_sided(t, df):
+    """src/stats/glm.rs:458-481."""
+    if df <= 0:
+        return float("nan")
+    if not math.isfinite(t):
+        return float("nan") if math.isnan(t) else MIN_POSITIVE
+    v = float(df)
+    p = betai(v / 2.0, 0.5, v / (v + t * t))
+    if not math.isfinite(p):
+        p = 1.0
+    return min(max(p, MIN_POSITIVE), 1.0)
+
+
+def lm_chi2_sf_df1(stat):
+    """The LM file's own chi-square tail (src/stats/glm.rs:483-492; NaN for an invalid statistic, unlike linalg.rs:7-17)."""
+    if not math.isfinite(stat) or stat < 0.0:
+        return float("nan")
+    p = math.erfc(math.sqrt(0.5 * stat))
+    return min(max(p, MIN_POSITIVE), 1.0) if math.isfinite(p) else 1.0
+
+
+def lm_plrt_from_t2(t2, n_obs, df):
+    """src/stats/glm.rs:495-501."""
+    if df <= 0 or not math.isfinite(t2) or t2 < 0.0:
+        return float("nan")
+    return lm_chi2_sf_df1(float(n_obs) * math.log(1.0 + t2 / float(df)))
+
+
+def lm_value_lut_f32(row_maf_f32, flip: bool):
+    """Mean-imputed additive decode of the LM scan (src/math/bedmath.rs:984-989)."""
+    mean_g = F32(min(max(F32(2.0) * F32(row_maf_f32), F32(0.0)), F32(2.0)))
+    if flip:
+        return np.array([2.0, mean_g, 1.0, 0.0], dtype=np.float32)
+    return np.array([0.0, mean_g, 1.0, 2.0], dtype=np.float32)
+
+
+def lm_block_assoc_packed(y, x, ixx, packed, n_samples, row_flip, row_maf, sample_idx=None):
+    """`lm_block_assoc_packed` (src/stats/glm.rs:3550-3860).  x (n, q0) includes the intercept.  The products G X and
+    G r_y take f32 operands like the reference's sgemm; they are summed in f64 here (the reference's f32 accumulation
+    order is BLAS-dependent).  -> (m, 4) = beta, se, pwald, plrt."""
+    y = np.asarray(y, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    ixx = np.asarray(ixx, dtype=np.float64)
+    n, q0 = x.shape
+    if n <= q0 + 1:
+        raise RuntimeError(f"n too small: require n > q0+1, got n={n}, q0={q0}")
+    df = n - q0 - 1
+    c_xy = ixx @ (x.T @ y)
+    ry = y - x @ c_xy
+    yy_r = float(ry @ ry)
+    ry32 = ry.astype(np.float32).astype(np.float64)
+    x32 = x.astype(np.float32).astype(np.float64)
+    codes = unpack_codes(packed, n_samples)
+    if sample_idx is not None:
+        codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
+    m = codes.shape[0]
+    out = np.full((m, 4), np.nan, dtype=np.float64)
+    for j in range(m):
+        g = lm_value_lut_f32(row_maf[j], bool(row_flip[j]))[codes[j]].astype(np.float64)
+        u = g @ x32
+        a = float(g @ ry32)
+        d = float(g @ g)
+        s = d - float(u @ (ixx @ u))
+        if s < 1e-12 or not math.isfinite(s):
+            continue
+        b = a / s
+        rss = max(yy_r - b * a, 0.0)
+        ve = rss / float(df)
+        if ve <= 0.0:
+            out[j, 0] = b
+            continue
+        se = math.sqrt(ve / s)
+        t = b / se
+        out[j] = (b, se, student_t_p_two_sided(t, df), lm_plrt_from_t2(t * t, n, df))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # A.10  TSV formatting (src/io/assoc2tsv.rs:45-57, 430-548; src/math/linalg.rs:327-340)
 # --------------------------------------------------------------------------------------------
 

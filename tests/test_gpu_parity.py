@@ -1990,3 +1990,80 @@ def test_eigh_two_stage_path_and_its_fallback(case, monkeypatch):
     assert float((ut @ ut.T - torch.eye(n, device=dev, dtype=torch.float64)).abs().max()) < 1e-11
     ref = torch.linalg.eigvalsh(kk)
     assert float((s - ref).abs().max()) < 1e-11 * smax
+
+
+def test_lm_block_assoc_packed(oracle):
+    """Plain LM scan (src/stats/glm.rs:3550-3860) through the C ABI against the restatement: one to seven design columns
+    (more than one column pass), flipped rows, missing calls, a ragged last sample tile, a sample subset, a monomorphic
+    row; both sides sum the same f32-rounded operands in f64, so only the summation order differs."""
+    from janusx_amd import janusx as jxrs
+    n, m = 777, 333
+    packed, g = bed.synth_panel_numpy(n, m, seed=23, missing_rate=0.02)
+    rng = np.random.default_rng(5)
+    mi, he, ho = oracle.row_counts(packed, n)
+    _k, maf, _miss, _f = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.0, 1.0, 1.0)
+    flip = rng.random(m) < 0.3
+    packed[11] = 0xFF                                      # every call hom-alt: s = 0 -> NaN row
+    for q0 in (1, 3, 7):
+        x = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, q0 - 1))], axis=1)
+        y = x @ rng.standard_normal(q0) + 0.4 * np.where(g[5] < 0, 0, g[5]) + rng.standard_normal(n)
+        for sub in (None, np.sort(rng.permutation(n)[:515])):
+            ys, xs = (y, x) if sub is None else (y[sub], x[sub])
+            ixx = jxrs.lm_precompute_ixx_qr(xs)
+            assert np.max(np.abs(ixx - oracle.lm_precompute_ixx_qr(xs))) <= 1e-12 * np.max(np.abs(ixx))
+            ref = oracle.lm_block_assoc_packed(ys, xs, ixx, packed, n, flip, maf, sub)
+            out = jxrs.lm_block_assoc_packed(ys, xs, ixx, packed, n, flip, maf, sample_indices=sub)
+            assert out.shape == (m, 4) and np.isnan(out[11]).all() and np.isnan(ref[11]).all()
+            ok = ~np.isnan(ref[:, 0])
+            assert np.array_equal(ok, ~np.isnan(out[:, 0]))
+            for c, lim in ((0, 1e-9), (1, 1e-10), (2, 1e-7), (3, 1e-7)):
+                scale = np.abs(ref[ok, c]) + (ref[ok, 1] if c == 0 else 0.0)
+                err = np.max(np.abs(out[ok, c] - ref[ok, c]) / scale)
+                assert err < lim, (q0, sub is None, c, err)
+            assert out[5, 2] < 1e-4
+    with pytest.raises(RuntimeError, match="n too small"):
+        jxrs.lm_block_assoc_packed(np.zeros(2), np.ones((2, 1)), np.ones((1, 1)), packed[:, :1], 2, flip, maf)
+    with pytest.raises(RuntimeError, match="row_flip length mismatch"):
+        jxrs.lm_block_assoc_packed(y, x, ixx, packed, n, flip[:5], maf)
+
+
+def test_cli_gwas_switches_to_the_lm_scan_without_polygenic_signal(oracle, tmp_path):
+    """`jx gwas -lmm` WITHOUT -force-model on a trait with no polygenic variance: the null LRT (gwas_unified.rs:121-175)
+    says LM, the trait is scanned by the plain LM and written as {out}.{trait}.lm.tsv (workflow_model_stream.py:930-963,
+    :980-984); with a heritable trait the same call stays on -lmm."""
+    from janusx_amd import cli
+    n, m = 260, 380
+    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.01)
+    rng = np.random.default_rng(3)
+    cov = rng.standard_normal(n)
+    y0 = 0.3 * cov + rng.standard_normal(n)                               # no genetic signal at all
+    y1 = bed.synth_phenotype(g, n_causal=40, pve=0.8, seed=61)
+    prefix = str(tmp_path / "toy")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\tnoise\therit\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{float(y0[i])!r}\t{float(y1[i])!r}\n")
+    with open(prefix + ".cov", "w") as fh:
+        fh.write("id\tc1\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{float(cov[i])!r}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-c", prefix + ".cov", "-lmm", "-o", prefix]) == 0
+    import os
+    assert os.path.exists(prefix + ".herit.lmm.tsv") and not os.path.exists(prefix + ".herit.lm.tsv")
+    assert os.path.exists(prefix + ".noise.lm.tsv") and not os.path.exists(prefix + ".noise.lmm.tsv")
+    lines = open(prefix + ".noise.lm.tsv").read().splitlines()
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, _flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    assert lines[0].split("\t")[-4:] == ["beta", "se", "chisq", "pwald"] and len(lines) == len(rows) + 1
+    x = np.concatenate([np.ones((n, 1)), cov[:, None]], axis=1)
+    ref = oracle.lm_block_assoc_packed(y0, x, oracle.lm_precompute_ixx_qr(x), packed[rows], n, np.zeros(len(rows), bool),
+                                       maf[rows], None)
+    for i, (ln, j) in enumerate(zip(lines[1:], rows)):
+        f = ln.split("\t")
+        assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}"
+        assert abs(float(f[7]) - ref[i, 0]) <= 5.1e-5 and abs(float(f[8]) - ref[i, 1]) <= 5.1e-5
+        assert abs(float(f[10]) - ref[i, 2]) <= 6e-5 * ref[i, 2]

@@ -491,10 +491,20 @@ def main():
                                        "per SNP with the measured B; peak = 78.6 TFLOP/s f64 vector (public MI355X "
                                        "figure); the 4 n bytes per SNP are read once (hbm_gbs), HBM is not the bound",
                                "ms_per_step": kern["scan_ms"] / L} if args.mode == "lmm" else
-                              {"bound": "hbm", "kernel": "fvlmm_scan_kernel",
-                               "traffic": tr_scan, "traffic_source": tr_scan_src,
-                               "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
-                               "ms_per_step": kern["scan_ms"] / L}),
+                              ({"bound": "mfma", "kernel": "rotate_f16x2_kernel<fused epilogue> + fvlmm_finish_kernel",
+                                "achieved": rot_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                                "note": "the fixed-lambda scan has no kernel of its own: the rotation kernel reduces every "
+                                        "128 x 128 tile of G~ against w / Py~ / WX~ in its epilogue (p + 2 f64 atomics per SNP "
+                                        "and column tile), G~ is never written; the finish kernel reads (p + 2) x 8 B per SNP. "
+                                        "Priced as the rotation (roofline_rotate); JXGPU_FVLMM_FUSED=0 restores the two-kernel "
+                                        "form (4 n B per SNP written and read back, HBM-bound)",
+                                "ms_per_step": (kern["rot_ms"] + kern["scan_ms"]) / L}
+                               if pl._fused_fixed_lambda(int(x.shape[1])) else
+                               {"bound": "hbm", "kernel": "fvlmm_scan_kernel",
+                                "traffic": tr_scan, "traffic_source": tr_scan_src,
+                                "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
+                                "ms_per_step": kern["scan_ms"] / L})),
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
             "null": {"lbd": null.lbd, "pve": null.pve},
             "device": {"cus": int(info[0]), "clock_khz": int(info[1]), "hbm_mib": int(info[2])},

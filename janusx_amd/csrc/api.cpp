@@ -820,7 +820,16 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     if (jxg_lut_split_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(), nullptr))
         return 1;
     const int64_t brows = 8192;
-    if (drot.alloc(sizeof(float) * (size_t)brows * n)) return 1;
+    // fixed lambda: the rotation kernel's fused epilogue reduces the tile in place, G~ is never written (k_rotate.hip)
+    static const bool fused_env = !(getenv("JXGPU_FVLMM_FUSED") && atoi(getenv("JXGPU_FVLMM_FUSED")) == 0);
+    const bool fused = model == 1 && p <= 8 && fused_env;
+    DevBuf dsums, dachol;
+    if (fused) {
+        if (dsums.alloc(sizeof(double) * (size_t)brows * (p + 2)) || dachol.alloc(sizeof(double) * (size_t)p * p)) return 1;
+        JX_HIP(hipMemcpy(dachol.p, fv.a_chol.data(), sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
+    } else if (drot.alloc(sizeof(float) * (size_t)brows * n)) {
+        return 1;
+    }
     if (dout.alloc(sizeof(double) * (size_t)brows * cols)) return 1;
     DevBuf drows;
     if (drows.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
@@ -830,12 +839,24 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         const int rows = (int)std::min<int64_t>(brows, m - r0);
         for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
         JX_HIP(hipMemcpy(drows.p, hrows.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
-        if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
-                                 (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,
-                                 dusum.as<float>(), uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, drot.as<float>(),
-                                 nullptr))
+        if (fused) {
+            JX_HIP(hipMemsetAsync(dsums.p, 0, sizeof(double) * (size_t)rows * (p + 2), nullptr));
+            if (jxg_rotate_packed16x_fused(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                           (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,
+                                           dusum.as<float>(), uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp,
+                                           fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(), p, dsums.as<double>(),
+                                           p + 2, nullptr) ||
+                jxg_fvlmm_finish_dev(dsums.as<double>(), p + 2, rows, n, p, dachol.as<double>(), fv.sc[0], (int)fv.sc[2],
+                                     has_nullml, nullml, fv.sc[1], 0, dout.as<double>(), nullptr))
+                return 1;
+        } else if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                        (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,
+                                        dusum.as<float>(), uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp,
+                                        drot.as<float>(), nullptr)) {
             return 1;
-        if (model == 0) {
+        }
+        if (fused) {
+        } else if (model == 0) {
             if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
                              high, tol, max_iter, warm, init_log10_lbd, has_nullml, nullml, dout.as<double>(), nullptr,
                              nullptr))

@@ -159,6 +159,21 @@ __global__ __launch_bounds__(256) void ut_rowsum_kernel(const float *__restrict_
 // Rows whose design values are beta + {0,1,2} without missing calls (`jxg_lut_split_rows`: integer LUT, lo plane zero,
 // beta in rowoff[r]; NaN marks a general row) contribute  out = (c U) + beta * usum,  usum[j] = sum_i u_t[j][i]:
 // a tile whose 128 rows all qualify skips the A-lo plane (decode, LDS traffic and one of the three MFMA products).
+// FUSE: instead of writing the rotated tile, reduce it against the fixed-lambda weights of its 128 eigenvector columns
+// (fw = 1 / (s + lambda), fpy = W P y~, fwx = W X~, the state of jxg_fvlmm_prepare) and add the p + 2 partial sums of every
+// SNP row to fsums[row][0 .. p+1] = (sum w g~^2, g~.Py~, g~.WX~[k]) with f64 atomics: the fixed-lambda scan
+// (src/stats/fvlmm.rs:1691-1805) and the SparseLMM exact scan never see G~ in memory.  The tile goes through the LDS of the
+// finished main loop, 64 rows at a time; four threads share a row (32 interleaved columns each, conflict-free reads).
+constexpr int R_FP = 132;      // floats per row of the epilogue's LDS tile
+constexpr int R_FMAXP = 8;     // covariates the fused epilogue supports
+struct RotFuse {
+    const float *fw, *fpy, *fwx;
+    int fp;
+    double *fsums;
+    int flds;
+};
+
+template <bool FUSE>
 __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
                                                               const int32_t *__restrict__ rows, int nrows,
                                                               const uint4 *__restrict__ lut16,
@@ -166,7 +181,8 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                                                               const float *__restrict__ usum,
                                                               const __half *__restrict__ uhi,
                                                               const __half *__restrict__ ulo, int64_t npad, int n,
-                                                              float out_scale, float *__restrict__ out, int64_t ldo) {
+                                                              float out_scale, float *__restrict__ out, int64_t ldo,
+                                                              RotFuse F) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * R_IMG + 64 + 512];
     uint8_t *sAh = smem;
     uint8_t *sAl = smem + R_IMG;
@@ -331,19 +347,79 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
         __syncthreads();
     }
 
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int gj = j0 + wn * 64 + ni * 32 + (lane & 31);
-            const float us = (usum && gj < n) ? usum[gj] : 0.0f;
+            for (int ni = 0; ni < 2; ++ni) {
+                const int gj = j0 + wn * 64 + ni * 32 + (lane & 31);
+                const float us = (usum && gj < n) ? usum[gj] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int gr = r0 + lr;
-                if (gr < nrows && gj < n) out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gr = r0 + lr;
+                    if (gr < nrows && gj < n) out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
+                }
             }
+    } else {
+        float *tile = reinterpret_cast<float *>(smem);                   // [64][R_FP]
+        float *wt = tile + 64 * R_FP;                                    // [128] w, [128] py, [128][fp] wx
+        float *pyt = wt + 128;
+        float *wxt = pyt + 128;
+        const int fp = F.fp;
+        if (tid < 128) {
+            const int gj = j0 + tid;
+            const bool okc = gj < n;
+            wt[tid] = okc ? F.fw[gj] : 0.0f;
+            pyt[tid] = okc ? F.fpy[gj] : 0.0f;
+            for (int k = 0; k < fp; ++k) wxt[tid * fp + k] = okc ? F.fwx[(int64_t)gj * fp + k] : 0.0f;
         }
+#pragma unroll 1
+        for (int phase = 0; phase < 2; ++phase) {
+            if (wm == phase) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int cj = wn * 64 + ni * 32 + (lane & 31);
+                        const float us = (usum && j0 + cj < n) ? usum[j0 + cj] : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            tile[lr * R_FP + cj] = fmaf(sOff[phase * 64 + lr], us, acc[mi][ni][r] * out_scale);
+                        }
+                    }
+            }
+            __syncthreads();
+            {
+                const int row = tid >> 2, q = tid & 3;
+                double sv[2 + R_FMAXP];
+#pragma unroll
+                for (int k = 0; k < 2 + R_FMAXP; ++k) sv[k] = 0.0;
+#pragma unroll 4
+                for (int c = 0; c < 32; ++c) {
+                    const int cj = q + 4 * c;
+                    const double v = (double)tile[row * R_FP + cj];
+                    sv[0] += (double)wt[cj] * v * v;
+                    sv[1] += v * (double)pyt[cj];
+#pragma unroll
+                    for (int k = 0; k < R_FMAXP; ++k)
+                        if (k < fp) sv[2 + k] += v * (double)wxt[cj * fp + k];
+                }
+                const int gr = r0 + phase * 64 + row;
+#pragma unroll
+                for (int k = 0; k < 2 + R_FMAXP; ++k) {
+                    if (k < 2 + fp) {
+                        double t = sv[k];
+                        t += __shfl_xor(t, 1, 64);
+                        t += __shfl_xor(t, 2, 64);
+                        if (q == 0 && gr < nrows && t != 0.0) unsafeAtomicAdd(F.fsums + (int64_t)gr * F.flds + k, t);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -568,9 +644,41 @@ extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, in
     const int nrt = (nrows + 127) / 128;
     dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
     JX_HIP(hipEventRecord(g_rot_a, st));
-    hipLaunchKernelGGL(rotate_f16x2_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
+    hipLaunchKernelGGL(rotate_f16x2_kernel<false>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
                        (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
-                       ldexpf(1.0f, -scale_exp), d_out, ld_out);
+                       ldexpf(1.0f, -scale_exp), d_out, ld_out, RotFuse{});
+    JX_LAUNCH_CHECK();
+    JX_HIP(hipEventRecord(g_rot_b, st));
+    g_timer_pending[1] = 1;
+    return 0;
+}
+
+// Rotation with the fused fixed-lambda reduction (rotate_f16x2_kernel<true>): nothing is written but
+// d_sums[r][0 .. p+1] += (sum_j w_j g~_rj^2, sum_j g~_rj py_j, sum_j g~_rj wx_jk) over this call's n eigenvector columns
+// (d_w, d_py (n) f32, d_wx (n, p) f32: the state of jxg_fvlmm_prepare restricted to the columns of d_uhi / d_ulo).  The caller
+// zeroes d_sums (nrows, lds_sums >= p + 2) once per row block and finishes with jxg_fvlmm_finish_dev; several calls (the
+// diagonal blocks of the block route) accumulate into the same sums.  p <= 8.
+extern "C" int jxg_rotate_packed16x_fused(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                          const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                          const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, const float *d_w,
+                                          const float *d_py, const float *d_wx, int p, double *d_sums, int lds_sums,
+                                          void *stream) {
+    if (p < 1 || p > R_FMAXP || lds_sums < p + 2) return fail("jxg_rotate_packed16x_fused: p out of range (1..8)");
+    if (nrows <= 0) return 0;
+    if (!d_usum) d_rowoff = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = num_tiles(n);
+    const int64_t npad = (int64_t)nt * JXG_TILE;
+    if (!g_rot_a) {
+        JX_HIP(hipEventCreate(&g_rot_a));
+        JX_HIP(hipEventCreate(&g_rot_b));
+    }
+    const int nrt = (nrows + 127) / 128;
+    dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
+    JX_HIP(hipEventRecord(g_rot_a, st));
+    hipLaunchKernelGGL(rotate_f16x2_kernel<true>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
+                       (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
+                       ldexpf(1.0f, -scale_exp), nullptr, 0, RotFuse{d_w, d_py, d_wx, p, d_sums, lds_sums});
     JX_LAUNCH_CHECK();
     JX_HIP(hipEventRecord(g_rot_b, st));
     g_timer_pending[1] = 1;

@@ -618,6 +618,78 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_prepare_kernel(const doubl
     }
 }
 
+// Statistics of one SNP from its three weighted sums v = (sum w g~^2, g~.Py~, g~.WX~[0..p-1]) (fvlmm.rs:1728-1805; the
+// score_mode note of fvlmm_scan_kernel).  Shared by the row-streaming scan kernel and by the finish kernel behind the
+// rotation's fused epilogue (k_rotate.hip).
+template <int MAXD>
+__device__ __forceinline__ void fvlmm_row_finish(const double *v, const double *l, int p, int n, double ypy, int df,
+                                                 int with_plrt, double nullml, double log_det_v, int score_mode,
+                                                 double *o) {
+    const double n_f = (double)n;
+    const double c_ml = n_f * (log(n_f) - 1.0 - log(2.0 * M_PI)) / 2.0;
+    double c[MAXD], aic[MAXD];
+    // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) c[k] = (k < p) ? (score_mode ? v[2 + k] : (double)(float)v[2 + k]) : 0.0;
+    chol_solve<MAXD>(l, p, c, aic);
+    double ct = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k)
+        if (k < p) ct += c[k] * aic[k];
+    if (score_mode) {
+        const double denom = fmax(v[0] - ct, 0.0);
+        const double score = (double)(float)v[1];           // f32 GEMV output in the reference (:2702-2711)
+        const double sigma2 = ypy / (double)df;
+        bool ok = isfinite(score) && isfinite(denom) && denom > 1e-30 && isfinite(sigma2) && sigma2 > 0.0;
+        double beta = 0.0, se = 0.0, chisq = 0.0;
+        if (ok) {
+            beta = score / denom;
+            const double var_beta = sigma2 / denom;
+            ok = isfinite(beta) && isfinite(var_beta) && var_beta > 0.0;
+            if (ok) {
+                se = sqrt(var_beta);
+                chisq = (score * score) / (sigma2 * denom);
+                ok = isfinite(se) && se > 0.0 && isfinite(chisq) && chisq >= 0.0;
+            }
+        }
+        o[0] = ok ? beta : nan("");
+        o[1] = ok ? se : nan("");
+        o[2] = ok ? chi2_sf_df1_dev(chisq) : 1.0;
+        return;
+    }
+    const double schur = v[0] - ct;
+    if (schur <= 1e-12 || !isfinite(schur)) {
+        o[0] = nan("");
+        o[1] = nan("");
+        o[2] = nan("");
+        if (with_plrt) o[3] = 1.0;
+    } else {
+        const double nu = (double)(float)v[1];
+        const double beta = nu / schur;
+        const double rwr = fmax(ypy - (nu * nu) / schur, 0.0);
+        const double sigma2 = rwr / (double)df;
+        const double se = sqrt(sigma2 / schur);
+        double pv = 1.0;
+        if (isfinite(se) && se > 0.0 && isfinite(beta)) {
+            pv = 2.0 * (0.5 * erfc(fabs(beta / se) / 1.4142135623730951));
+            if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+            if (pv > 1.0) pv = 1.0;
+        }
+        o[0] = beta;
+        o[1] = se;
+        o[2] = pv;
+        if (with_plrt) {  // fvlmm.rs:1785-1802
+            double stat = 0.0;
+            if (rwr > 0.0 && isfinite(rwr)) {
+                const double ml = c_ml - 0.5 * (n_f * jx_log(rwr) + log_det_v);
+                if (isfinite(ml)) stat = 2.0 * (ml - nullml);
+            }
+            if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+            o[3] = chi2_sf_df1_dev(stat);
+        }
+    }
+}
+
 // Fixed-lambda scan (fvlmm.rs:1691-1805): num = g.Py~, c = g.WX~, d = sum w g^2, Schur complement, Wald test.
 template <int MAXD>
 __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *__restrict__ grot, int nrows, int n,
@@ -636,8 +708,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
     // with 16-byte loads (4 samples per lane per step), the p + 2 sums are wave butterflies.
     constexpr int NV = MAXD + 2;
     const int out_cols = with_plrt ? 4 : 3;
-    const double n_f = (double)n;
-    const double c_ml = n_f * (log(n_f) - 1.0 - log(2.0 * M_PI)) / 2.0;
     double l[MAXD * MAXD];
 #pragma unroll
     for (int r = 0; r < MAXD; ++r)
@@ -681,71 +751,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
 #pragma unroll
         for (int k = 0; k < NV; ++k)
             if (k < 2 + p) v[k] = wave_allsum(v[k]);
-        if (lane == 0) {
-            double *o = out + (int64_t)r * out_cols;
-            double c[MAXD], aic[MAXD];
-            // the reference's num / c are f32 GEMM outputs (fvlmm.rs:1708-1727): round like its f32 store
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k) c[k] = (k < p) ? (score_mode ? v[2 + k] : (double)(float)v[2 + k]) : 0.0;
-            chol_solve<MAXD>(l, p, c, aic);
-            double ct = 0.0;
-#pragma unroll
-            for (int k = 0; k < MAXD; ++k)
-                if (k < p) ct += c[k] * aic[k];
-            if (score_mode) {
-                const double denom = fmax(v[0] - ct, 0.0);
-                const double score = (double)(float)v[1];           // f32 GEMV output in the reference (:2702-2711)
-                const double sigma2 = ypy / (double)df;
-                bool ok = isfinite(score) && isfinite(denom) && denom > 1e-30 && isfinite(sigma2) && sigma2 > 0.0;
-                double beta = 0.0, se = 0.0, chisq = 0.0;
-                if (ok) {
-                    beta = score / denom;
-                    const double var_beta = sigma2 / denom;
-                    ok = isfinite(beta) && isfinite(var_beta) && var_beta > 0.0;
-                    if (ok) {
-                        se = sqrt(var_beta);
-                        chisq = (score * score) / (sigma2 * denom);
-                        ok = isfinite(se) && se > 0.0 && isfinite(chisq) && chisq >= 0.0;
-                    }
-                }
-                o[0] = ok ? beta : nan("");
-                o[1] = ok ? se : nan("");
-                o[2] = ok ? chi2_sf_df1_dev(chisq) : 1.0;
-                continue;
-            }
-            const double schur = v[0] - ct;
-            if (schur <= 1e-12 || !isfinite(schur)) {
-                o[0] = nan("");
-                o[1] = nan("");
-                o[2] = nan("");
-                if (with_plrt) o[3] = 1.0;
-            } else {
-                const double nu = (double)(float)v[1];
-                const double beta = nu / schur;
-                const double rwr = fmax(ypy - (nu * nu) / schur, 0.0);
-                const double sigma2 = rwr / (double)df;
-                const double se = sqrt(sigma2 / schur);
-                double pv = 1.0;
-                if (isfinite(se) && se > 0.0 && isfinite(beta)) {
-                    pv = 2.0 * (0.5 * erfc(fabs(beta / se) / 1.4142135623730951));
-                    if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
-                    if (pv > 1.0) pv = 1.0;
-                }
-                o[0] = beta;
-                o[1] = se;
-                o[2] = pv;
-                if (with_plrt) {  // fvlmm.rs:1785-1802
-                    double stat = 0.0;
-                    if (rwr > 0.0 && isfinite(rwr)) {
-                        const double ml = c_ml - 0.5 * (n_f * jx_log(rwr) + log_det_v);
-                        if (isfinite(ml)) stat = 2.0 * (ml - nullml);
-                    }
-                    if (!isfinite(stat) || stat < 0.0) stat = 0.0;
-                    o[3] = chi2_sf_df1_dev(stat);
-                }
-            }
-        }
+        if (lane == 0)
+            fvlmm_row_finish<MAXD>(v, l, p, n, ypy, df, with_plrt, nullml, log_det_v, score_mode,
+                                   out + (int64_t)r * out_cols);
     }
+}
+
+// Finish kernel of the fused rotation epilogue: sums (nrows, lds) f64 = per SNP (sum w g~^2, g~.Py~, g~.WX~[k]) accumulated
+// by rotate_f16x2_kernel<true>; one thread per SNP.
+template <int MAXD>
+__global__ __launch_bounds__(256) void fvlmm_finish_kernel(const double *__restrict__ sums, int lds, int nrows, int n, int p,
+                                                           const double *__restrict__ a_chol, double ypy, int df,
+                                                           int with_plrt, double nullml, double log_det_v,
+                                                           int score_mode, double *__restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    double l[MAXD * MAXD];
+#pragma unroll
+    for (int a = 0; a < MAXD; ++a)
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) l[a * MAXD + c] = (a < p && c < p) ? a_chol[a * p + c] : (a == c ? 1.0 : 0.0);
+    double v[MAXD + 2];
+#pragma unroll
+    for (int k = 0; k < MAXD + 2; ++k) v[k] = (k < 2 + p) ? sums[(int64_t)r * lds + k] : 0.0;
+    fvlmm_row_finish<MAXD>(v, l, p, n, ypy, df, with_plrt, nullml, log_det_v, score_mode,
+                           out + (int64_t)r * ((with_plrt && !score_mode) ? 4 : 3));
 }
 
 }  // namespace jx
@@ -910,6 +940,23 @@ extern "C" int jxg_splmm_exact_scan_dev(const float *d_grot, int nrows, int n, i
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                           (hipStream_t)stream, d_grot, nrows, n, p, d_w, d_py, d_wx, d_a_chol, ypy, df, 0,
                                           0.0, 0.0, d_out, 1));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// Finish of the fused rotation epilogue (jxg_rotate_packed16x_fused): d_sums (nrows, lds) f64 with lds >= p + 2;
+// score_mode != 0 = SparseLMM exact scan (df = n - p), else the fixed-lambda scan (df = n - p - 1).
+extern "C" int jxg_fvlmm_finish_dev(const double *d_sums, int lds, int nrows, int n, int p, const double *d_a_chol,
+                                    double ypy, int df, int with_plrt, double nullml, double log_det_v, int score_mode,
+                                    double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV || lds < p + 2) return fail("jxg_fvlmm_finish: p out of range");
+    if (score_mode && (!(ypy > 0.0) || !std::isfinite(ypy)))
+        return fail("SparseLMM exact scan requires finite positive yPy on K + lambda I scale");
+    if (df <= 0) return fail("df <= 0");
+    JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_finish_kernel<MAXD>, dim3((nrows + 255) / 256), dim3(256), 0,
+                                          (hipStream_t)stream, d_sums, lds, nrows, n, p, d_a_chol, ypy, df,
+                                          score_mode ? 0 : with_plrt, nullml, log_det_v, score_mode, d_out));
     JX_LAUNCH_CHECK();
     return 0;
 }

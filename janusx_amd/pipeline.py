@@ -12,6 +12,7 @@ Mirrors the reference's call stack for `jx gwas -lmm/-fvlmm` (SURVEY.md §3.1-3.
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -293,6 +294,13 @@ class SpectralModel:
         return self._fv
 
 
+def _fused_fixed_lambda(p: int) -> bool:
+    """The fixed-lambda scans (fvlmm, SparseLMM exact) reduce the rotated tile inside the rotation kernel's epilogue
+    (`jxg_rotate_packed16x_fused` + `jxg_fvlmm_finish_dev`) instead of writing and re-reading G~ (4 m n bytes each way);
+    JXGPU_FVLMM_FUSED=0 keeps the two-kernel form, more than 8 covariates always do."""
+    return p <= 8 and os.environ.get("JXGPU_FVLMM_FUSED", "1").strip() != "0"
+
+
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
               times: StageTimes = None, nullml=None, fv_state=None, on_block=None):
@@ -353,7 +361,12 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         block_rows = 32768
     br = int(min(block_rows, mk))
     nbuf = 2 if mk > br else 1
-    grots = [torch.empty((br, n), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)
+    if fused:
+        sums = [torch.empty((br, model.p + 2), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        grots = [None] * nbuf
+    else:
+        grots = [torch.empty((br, n), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     ev_rot = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((mk + br - 1) // br)]
     ev_scan = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(len(ev_rot))]
     pending = None          # (i0, i1, event recorded behind the block's scan)
@@ -371,14 +384,29 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         grot = grots[bi % nbuf]
         if times is not None:
             ev_rot[bi][0].record()
-        check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
-                                         lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
-                                         SCALE_EXP, _ptr(grot), _stream()))
+        if fused:
+            sm = sums[bi % nbuf]
+            sm.zero_()
+            check(lib().jxg_rotate_packed16x_fused(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                                   lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi),
+                                                   _ptr(lo), SCALE_EXP, _ptr(w), _ptr(py), _ptr(wx), model.p, _ptr(sm),
+                                                   model.p + 2, _stream()))
+        else:
+            check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                             lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
+                                             SCALE_EXP, _ptr(grot), _stream()))
         if times is not None:
             ev_rot[bi][1].record()
             ev_scan[bi][0].record()
         o = out[r0:]
-        if mode == "lmm2":
+        if fused:
+            if mode == "splmm":
+                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, n - model.p, 0,
+                                                 0.0, 0.0, 1, o.data_ptr(), _stream()))
+            else:
+                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, df, with_plrt,
+                                                 nullml_v, log_det_v, 0, o.data_ptr(), _stream()))
+        elif mode == "lmm2":
             check(lib().jxg_lmm2_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p, lo_b,
                                       hi_b, float(tol), int(max_iter), warm, init, nullml_v, o.data_ptr(), _stream()))
         elif mode == "lmm":
@@ -458,6 +486,20 @@ def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np
     w, py, wx, a_chol, ypy = fv_state
     a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
     br = int(min(block_rows, mk))
+    if _fused_fixed_lambda(p):
+        # every diagonal block adds its columns' share of the three weighted sums; G~ is never written
+        sums = torch.empty((br, p + 2), dtype=torch.float64, device=dev)
+        for r0 in range(0, mk, br):
+            nr = min(br, mk - r0)
+            sums.zero_()
+            for off, nb, hi, lo, panel in rot.parts:
+                check(lib().jxg_rotate_packed16x_fused(_ptr(panel.p32), panel.m, nb, rows_t[r0:].data_ptr(), nr,
+                                                       lut16[r0:].data_ptr(), None, None, _ptr(hi), _ptr(lo), SCALE_EXP,
+                                                       w[off:].data_ptr(), py[off:].data_ptr(), wx[off:].data_ptr(), p,
+                                                       _ptr(sums), p + 2, _stream()))
+            check(lib().jxg_fvlmm_finish_dev(_ptr(sums), p + 2, nr, n, p, _ptr(a_dev), ypy, n - p, 0, 0.0, 0.0, 1,
+                                             out[r0:].data_ptr(), _stream()))
+        return out
     grot = torch.empty((br, n), dtype=torch.float32, device=dev)
     for r0 in range(0, mk, br):
         nr = min(br, mk - r0)

@@ -2067,3 +2067,52 @@ def test_cli_gwas_switches_to_the_lm_scan_without_polygenic_signal(oracle, tmp_p
         assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}"
         assert abs(float(f[7]) - ref[i, 0]) <= 5.1e-5 and abs(float(f[8]) - ref[i, 1]) <= 5.1e-5
         assert abs(float(f[10]) - ref[i, 2]) <= 6e-5 * ref[i, 2]
+
+
+def test_fixed_lambda_scan_fused_into_the_rotation_epilogue(oracle, monkeypatch):
+    """`jxg_rotate_packed16x_fused` + `jxg_fvlmm_finish_dev` (the rotated tile is reduced against w, Py~, WX~ inside the
+    rotation kernel, G~ never reaches memory) against the two-kernel form (rotation writes G~, `fvlmm_scan_kernel` reads it
+    back) and the oracle: 1 / 3 / 8 design columns, ragged row and column tiles, rows with and without missing calls, the
+    plrt column, several row blocks; 9 design columns take the two-kernel form."""
+    import torch
+    from janusx_amd import pipeline, stats
+    n, m = 333, 900
+    packed, g = bed.synth_panel_numpy(n, m, seed=77, missing_rate=0.0)
+    rng = np.random.default_rng(12)
+    for r in np.nonzero(rng.random(m) < 0.3)[0]:
+        for j in rng.integers(0, n, size=rng.integers(1, 4)):
+            b, sh = j >> 2, 2 * (j & 3)
+            packed[r, b] = (packed[r, b] & ~(3 << sh)) | (1 << sh)
+    y = bed.synth_phenotype(g, n_causal=20, pve=0.6, seed=77)
+    k, _eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    s, u = oracle.gwas_eigh_from_grm(k)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, _miss, _flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    pk = np.ascontiguousarray(packed[keep])
+    maf_k = maf[keep]
+    flip_k = rng.random(int(keep.sum())) < 0.3
+    panel = pipeline.Panel(torch.from_numpy(pk).cuda(), n)
+    rows = np.arange(pk.shape[0])
+    lut = stats.scan_lut_from_counts(maf_k, flip_k, panel.counts(), n)
+    gd = oracle.decode_centered_block_f32(pk, n, flip_k, maf_k)
+    for q in (1, 3, 8, 9):
+        x = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, q - 1))], axis=1)
+        nm = oracle.spectral_null_model(y, x, s, u)
+        model = pipeline.SpectralModel(torch.from_numpy(nm.S).cuda(),
+                                       torch.from_numpy(np.ascontiguousarray(nm.Dh.astype(np.float64))).cuda(), x, y)
+        outs = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("JXGPU_FVLMM_FUSED", fused)
+            assert pipeline._fused_fixed_lambda(q) == (fused == "1" and q <= 8)
+            outs[fused] = pipeline.scan_rows(panel, model, rows, lut, "fvlmm", nullml=nm.ML0, block_rows=400).cpu().numpy()
+        a, b = outs["1"], outs["0"]
+        assert a.shape == b.shape == (len(rows), 4)
+        ok = ~np.isnan(b[:, 0])
+        assert np.array_equal(ok, ~np.isnan(a[:, 0]))
+        for c in range(4):
+            err = np.max(np.abs(a[ok, c] - b[ok, c]) / (np.abs(b[ok, c]) + (b[ok, 1] if c == 0 else 1e-300)))
+            assert err < (1e-6 if c < 2 else 1e-5), (q, c, err)       # the f32-rounded num / c of the reference's GEMM outputs
+        fref = oracle.fvlmm_assoc_rotated_block(oracle.rotate_block_f32(gd, nm.Dh),
+                                                oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null), nullml=nm.ML0)
+        be, se, pe = _assoc_err(a[:, :3], fref[:, :3])
+        assert max(be, se, pe) < TOL, (q, be, se, pe)

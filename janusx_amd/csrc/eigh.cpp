@@ -184,11 +184,19 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 return 1;
             int hf[4] = {0, 0, 0, 0};
             JX_HIP(hipMemcpyAsync(hf, ts_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+            {
+                // the workspace of the Q2 back-transformation (tens of GB at n = 50 000: a hipMalloc of that size takes up to
+                // seconds) is allocated here, behind the band reduction's launches, while the device works through them
+                size_t fr = 0, tot = 0;
+                const size_t need = sizeof(double) * sbback_tq_doubles(n, ks);
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > need + ((size_t)8 << 30) && ts_tq.alloc(need)) return 1;
+            }
             JX_HIP(hipStreamSynchronize(st));
             if (hf[0] != 0) {
                 if (trace) (void)stage_done("sy2sb (flagged)");
                 if (trace) fprintf(stderr, "[jxgpu eigh n=%d] band reduction flagged a panel (code %d): one-stage fallback\n", n, hf[0]);
                 JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+                ts_tq.release();
                 twostage = false;
             }
         }
@@ -234,7 +242,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         bool sharded_rows = false;                       // d_a already holds this rank's rows + the gathered rest
         int q2_cols = n;                                 // eigenvector columns the Q2 kernel of this rank processed
         if (twostage) {
-            if (ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
+            if (!ts_tq.p && ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
             if (dist_two && split) {
                 // this rank's eigenvectors only: columns perm[r0 .. r1) of C, gathered into a contiguous (n, nr) block

@@ -10,6 +10,8 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -50,6 +52,7 @@ struct QrParams {
     double *vu;             // blocks ((grp - g_lo) * ks + k): V image then U image, QR_BLK doubles each
     double *ct;             // C in slab layout: [slab][row][16 NU columns] (sbback_slab_kernel), zero-padded columns
     int n, ks, ncols;
+    int units;              // 16-column units of C; slab b of the gridDim.x slabs holds the units [b units / G, (b+1) units / G)
     int g_lo, g_hi;         // groups [g_lo, g_hi) of this launch (applied from g_hi - 1 down)
     int skip;               // diagnostic bit mask (JXGPU_QB_SKIP): 1 no MFMA phases, 2 no row traffic, 4 no V / U loads,
                             // 8 no row stores, 16 no row loads
@@ -188,6 +191,26 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
     // ------------------------------------------------------------------------------------------------------ compute waves
     const int lx = lane & 15, lk = lane >> 4;
     const int unit = wave / 3, j = wave % 3;
+    {
+        // balanced slabs: a workgroup holds NU or NU - 1 units (qr_plan); the waves of an absent unit only keep the
+        // workgroup's barrier sequence (G0, G1, then B2 and B3 per block)
+        const int ub = (int)((int64_t)blockIdx.x * P.units / gridDim.x);
+        const int nb = (int)((int64_t)(blockIdx.x + 1) * P.units / gridDim.x) - ub;
+        if (unit >= nb) {
+            for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
+                const int s0 = grp * QB_G;
+                if (s0 + 1 >= n) continue;
+                const int nk = (n - s0 - 1 + QB_SB - 1) / QB_SB;
+                __syncthreads();                               // G0
+                qr_lds_barrier();                              // G1
+                for (int k = 0; k < nk; ++k) {
+                    qr_lds_barrier();                          // B2
+                    qr_lds_barrier();                          // B3
+                }
+            }
+            return;
+        }
+    }
     // slab layout: the rows of this workgroup's 16 NU columns are contiguous (one row = 128 NU bytes), so a workgroup streams
     // through memory linearly (one read and one write stream per workgroup instead of one per column)
     constexpr int W = NU * 16;
@@ -326,16 +349,21 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
 // C (n x ncols, column-major, ld = n) <-> slab layout [slab][row][w] (w = slab width in columns; columns past ncols are
 // zero on the way in and dropped on the way out).  One workgroup = 64 rows of one slab through LDS: both sides coalesced.
 template <bool TO_SLAB>
-__global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c, double *__restrict__ ct, int n, int ncols, int w) {
+__global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c, double *__restrict__ ct, int n, int ncols, int w,
+                                                          int units) {
     extern __shared__ double slab_tile[];                      // [64][w + 1]
     const int r0 = blockIdx.x * 64, slab = blockIdx.y;
     const int t = threadIdx.x;
     const int64_t base = (int64_t)slab * n * w;
+    // columns of this slab: units [ub, ub + nb) of C, the rest of the w columns is padding
+    const int ub = (int)((int64_t)slab * units / gridDim.y);
+    const int wv = ((int)((int64_t)(slab + 1) * units / gridDim.y) - ub) * 16;
+    const int cbase = ub * 16;
     if (TO_SLAB) {
         for (int e = t; e < 64 * w; e += 256) {
             const int cc = e >> 6, r = e & 63;
-            const int col = slab * w + cc, row = r0 + r;
-            slab_tile[r * (w + 1) + cc] = (col < ncols && row < n) ? c[(int64_t)col * n + row] : 0.0;
+            const int col = cbase + cc, row = r0 + r;
+            slab_tile[r * (w + 1) + cc] = (cc < wv && col < ncols && row < n) ? c[(int64_t)col * n + row] : 0.0;
         }
         __syncthreads();
         for (int e = t; e < 64 * w; e += 256) {
@@ -350,8 +378,8 @@ __global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c
         __syncthreads();
         for (int e = t; e < 64 * w; e += 256) {
             const int cc = e >> 6, r = e & 63;
-            const int col = slab * w + cc, row = r0 + r;
-            if (col < ncols && row < n) c[(int64_t)col * n + row] = slab_tile[r * (w + 1) + cc];
+            const int col = cbase + cc, row = r0 + r;
+            if (cc < wv && col < ncols && row < n) c[(int64_t)col * n + row] = slab_tile[r * (w + 1) + cc];
         }
     }
 }
@@ -366,9 +394,37 @@ static int qr_groups_per_launch(int n, int ks) {
     return g < ngroups ? g : ngroups;
 }
 
+static int device_cus();
+
+// Slabs of the register form for `ncols` columns: G workgroups of at most NU <= 5 units (16 columns) each, units dealt
+// evenly (a slab holds NU or NU - 1).  Up to 5 units per CU: one round with NU = ceil(units / CUs).  Beyond: R = ceil(units /
+// (5 CUs)) rounds of CUs workgroups, so that every round is full and as short as its widest slab (n = 50 000: 3125 units ->
+// 768 slabs of 4 or 5 units instead of 625 of 5 = 2.44 rounds each as long as a full one).
+static void qr_plan(int ncols, int *g_out, int *nu_out) {
+    const int units = (ncols + 15) / 16;
+    const int cus = device_cus();
+    int nu, g;
+    if (getenv("JXGPU_SBBACK_NW") && atoi(getenv("JXGPU_SBBACK_NW")) > 0) {       // fixed width, whole slabs (diagnostic)
+        nu = std::min(atoi(getenv("JXGPU_SBBACK_NW")), 5);
+        g = (units + nu - 1) / nu;
+    } else if (units <= 5 * cus) {
+        nu = std::max((units + cus - 1) / cus, 1);
+        g = (units + nu - 1) / nu;
+    } else {
+        const int rounds = (units + 5 * cus - 1) / (5 * cus);
+        g = rounds * cus;
+        nu = (units + g - 1) / g;
+    }
+    *g_out = std::max(g, 1);
+    *nu_out = nu;
+}
+
 size_t sbback_tq_doubles(int n, int ks) {
-    // V / U images of one launch | C in slab layout (up to 5 x 16 - 1 padding columns)
-    return (size_t)qr_groups_per_launch(n, ks) * ks * 2 * QR_BLK + (size_t)(n + 96) * n;
+    // V / U images of one launch | C in slab layout (G slabs of NU x 16 columns, padding included)
+    int g, nu;
+    qr_plan(n, &g, &nu);
+    const size_t padded = std::max((size_t)g * nu * 16, (size_t)n + 96);
+    return (size_t)qr_groups_per_launch(n, ks) * ks * 2 * QR_BLK + padded * (size_t)n;
 }
 
 static int device_cus() {
@@ -388,24 +444,32 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
                                double *d_vu, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int ngroups = (n - 2 + QB_G - 1) / QB_G;
     const int gpl = qr_groups_per_launch(n, ks);
-    const int units = ceil_div(ncols, 16);
-    int nu = ceil_div(units, device_cus());
-    if (nu < 1) nu = 1;
-    if (nu > 5) nu = 5;
-    if (getenv("JXGPU_SBBACK_NW") && atoi(getenv("JXGPU_SBBACK_NW")) > 0) nu = atoi(getenv("JXGPU_SBBACK_NW"));
-    if (nu > 5) nu = 5;
+    int units = ceil_div(ncols, 16);
+    int nu, gslabs;
+    qr_plan(ncols, &gslabs, &nu);
+    if (getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0) {   // diagnostic: whole slabs of 5 units at most
+        nu = std::min(std::max(ceil_div(units, device_cus()), 1), 5);
+        gslabs = ceil_div(units, nu);
+        units = gslabs * nu;
+    }
+    {
+        int gn, nun;                                           // the workspace was sized for ncols = n (sbback_tq_doubles)
+        qr_plan(n, &gn, &nun);
+        if ((size_t)gslabs * nu * 16 > std::max((size_t)gn * nun * 16, (size_t)n + 96))
+            return fail("sbback_apply_q2: slab plan exceeds the workspace");
+    }
     const size_t lds = sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
-    const dim3 grid(ceil_div(units, nu));
+    const dim3 grid(gslabs);
     const int skip = getenv("JXGPU_QB_SKIP") ? atoi(getenv("JXGPU_QB_SKIP")) : 0;
     const int w = nu * 16;
     double *d_ct = d_vu + (size_t)gpl * ks * 2 * QR_BLK;
     const dim3 sgrid(ceil_div(n, 64), grid.x);
     const size_t slds = sizeof(double) * 64 * (w + 1);
-    hipLaunchKernelGGL(sbback_slab_kernel<true>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w);
+    hipLaunchKernelGGL(sbback_slab_kernel<true>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w, units);
     JX_LAUNCH_CHECK();
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
         const int g_lo = g_hi > gpl ? g_hi - gpl : 0;
-        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, g_lo, g_hi, skip};
+        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip};
         hipLaunchKernelGGL(sbback_vu_kernel, dim3(ks, g_hi - g_lo), dim3(128), 0, st, P);
         JX_LAUNCH_CHECK();
         hipEvent_t e0 = (g_hi == ngroups) ? ev_start : nullptr, e1 = (g_lo == 0) ? ev_stop : nullptr;
@@ -429,7 +493,7 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
 #undef JX_QR_LAUNCH
         JX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(sbback_slab_kernel<false>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w);
+    hipLaunchKernelGGL(sbback_slab_kernel<false>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w, units);
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -217,18 +217,19 @@ int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const 
                             const uint16_t *d_ulo, int scale_exp, float *d_out, int64_t ld_out, void *stream);
 
 /* Rotation with the fused fixed-lambda reduction (src/stats/fvlmm.rs:1691-1805 consumes G~ only through three weighted sums):
- * nothing is written but d_sums[r][0 .. p+1] += (sum_j w_j g~_rj^2, sum_j g~_rj py_j, sum_j g~_rj wx_jk) over this call's n
- * eigenvector columns; d_w, d_py (n) f32 and d_wx (n, p) f32 are the state of jxg_fvlmm_prepare on those columns.  The
- * caller zeroes d_sums (nrows, lds_sums >= p + 2) once per row block; several calls (diagonal blocks) accumulate; p <= 8.
- * jxg_fvlmm_finish_dev turns the sums into (beta, se, p[, plrt]) -- score_mode != 0: the SparseLMM exact scan
- * (src/stats/splmm.rs:2517-2538, df = n - p). */
+ * G~ is not written; column tile t of this call (128 eigenvector columns, t < jxg_num_tiles(n)) writes its share of
+ * (sum_j w_j g~_rj^2, sum_j g~_rj py_j, sum_j g~_rj wx_jk) to d_part[tile0 + t][r][0 .. p+1]; d_w, d_py (n) f32 and d_wx (n, p)
+ * f32 are the state of jxg_fvlmm_prepare on this call's columns; d_part (tiles of all calls, nrows, lds_sums >= p + 2) f64.
+ * Successive calls with tile0 advancing serve the diagonal blocks of the block route; p <= 8.  jxg_fvlmm_finish_dev adds the
+ * ntiles tiles in index order (no atomics: bit-reproducible) and turns the sums into (beta, se, p[, plrt]) -- score_mode != 0:
+ * the SparseLMM exact scan (src/stats/splmm.rs:2517-2538, df = n - p). */
 int jxg_rotate_packed16x_fused(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
                                const uint16_t *d_ulo, int scale_exp, const float *d_w, const float *d_py,
-                               const float *d_wx, int p, double *d_sums, int lds_sums, void *stream);
-int jxg_fvlmm_finish_dev(const double *d_sums, int lds, int nrows, int n, int p, const double *d_a_chol, double ypy,
-                         int df, int with_plrt, double nullml, double log_det_v, int score_mode, double *d_out,
-                         void *stream);
+                               const float *d_wx, int p, double *d_part, int lds_sums, int tile0, void *stream);
+int jxg_fvlmm_finish_dev(const double *d_part, int ntiles, int lds, int nrows, int n, int p, const double *d_a_chol,
+                         double ypy, int df, int with_plrt, double nullml, double log_det_v, int score_mode,
+                         double *d_out, void *stream);
 
 /* D2 (dense input). out[r, j] = sum_i g[r, i] * u_t[j, i] in exact f32 (f32 MFMA).
  * src/stats/lmm.rs:520-552 `rotate_snp_block_with_ut`. */

@@ -10,7 +10,7 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -rrBLUP [-lambda L] [-tol 1e-4] [-max-iter 100] [-cv K]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm.tsv` (`gwas -splmm [cutoff]`, exact SparseLMM scan); `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
+Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm2.tsv` (`gwas -splmm-exact [cutoff]`, exact SparseLMM scan; `-splmm` writes the same scan as `.splmm.tsv`); `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
 `{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
@@ -146,8 +146,23 @@ def cmd_gwas(args):
     from . import pipeline as pl
     from .bed import read_bed_payload, read_fam_ids
     from .tsv import AsyncAssocTsvWriter, write_assoc_tsv
+    # SparseLMM flags of the reference (python/janusx/assoc/workflow.py:6689-6725, 6992-7017): -splmm-exact = exact g'Pg scan,
+    # raw REML null objective, result stem "splmm2"; -splmm = GRAMMAR-gamma denominator, stem "splmm" (the approximation is not
+    # built: -splmm runs the exact scan too -- what the reference itself does for a trait with fewer kept markers than its
+    # gamma sample, workflow_model_packed.py:8087-8107 -- and says so)
+    sp_stems = []
+    if getattr(args, "splmm_exact", None) is not None:
+        sp_stems.append("splmm2")
+    if args.splmm is not None:
+        sp_stems.append("splmm")
+        if getattr(args, "splmm_exact", None) is not None and float(args.splmm_exact) != float(args.splmm):
+            raise SystemExit("-splmm and -splmm-exact in one run must use the same sparse-GRM cut-off")
+        print("note: -splmm: the GRAMMAR-gamma denominator is not built, the exact g'Pg scan (-splmm-exact) is written "
+              "under the -splmm result name")
+    if args.splmm is None and sp_stems:
+        args.splmm = float(args.splmm_exact)
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
-        raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm and/or -splmm")
+        raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm, -splmm and/or -splmm-exact")
     packed, n_fam, bim = read_bed_payload(args.bfile)
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
@@ -268,11 +283,12 @@ def cmd_gwas(args):
                 sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool),
                 x[:, 1:] if x.shape[1] > 1 else None, keep_idx if (grm_idx is not None or not full) else None, kept,
                 grm_sample_indices=grm_idx)
-            path = f"{out}.{name}.splmm.tsv"
-            write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
-                            [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
-                            af[kept], miss[kept], stats)
-            print(f"[{name}] -splmm: n={n} snps={len(kept)} lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} "
+            for stem in sp_stems:
+                path = f"{out}.{name}.{stem}.tsv"
+                write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
+                                [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
+                                af[kept], miss[kept], stats)
+            print(f"[{name}] -{'splmm-exact' if sp_stems[0] == 'splmm2' else 'splmm'}: n={n} snps={len(kept)} lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} "
                   f"sigma_e2={null[2]:.4g} -> {path} ({time.perf_counter() - t1:.2f}s)")
     return 0
 
@@ -474,6 +490,8 @@ def main(argv=None):
     g.add_argument("-splmm", "--splmm", nargs="?", const=0.05, default=None, type=float,
                    help="SparseLMM exact scan on a sparse GRM thresholded at this kinship cut-off (default 0.05); "
                         "-grm FILE.spgrm reuses an existing sparse GRM")
+    g.add_argument("-splmm-exact", "--splmm-exact", dest="splmm_exact", nargs="?", const=0.05, default=None, type=float,
+                   help="SparseLMM with the exact g'Pg denominator for every SNP -> {out}.{trait}.splmm2.tsv")
     r = sub.add_parser("grm")
     r.add_argument("-bfile", "--bfile", default=None)
     r.add_argument("-m", "--method", type=int, default=1, choices=[1, 2])

@@ -825,7 +825,8 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     const bool fused = model == 1 && p <= 8 && fused_env;
     DevBuf dsums, dachol;
     if (fused) {
-        if (dsums.alloc(sizeof(double) * (size_t)brows * (p + 2)) || dachol.alloc(sizeof(double) * (size_t)p * p)) return 1;
+        if (dsums.alloc(sizeof(double) * (size_t)num_tiles(n) * brows * (p + 2)) || dachol.alloc(sizeof(double) * (size_t)p * p))
+            return 1;
         JX_HIP(hipMemcpy(dachol.p, fv.a_chol.data(), sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
     } else if (drot.alloc(sizeof(float) * (size_t)brows * n)) {
         return 1;
@@ -840,13 +841,12 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         for (int i = 0; i < rows; ++i) hrows[i] = (int32_t)(r0 + i);
         JX_HIP(hipMemcpy(drows.p, hrows.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
         if (fused) {
-            JX_HIP(hipMemsetAsync(dsums.p, 0, sizeof(double) * (size_t)rows * (p + 2), nullptr));
             if (jxg_rotate_packed16x_fused(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
                                            (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,
                                            dusum.as<float>(), uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp,
                                            fv.w.as<float>(), fv.py.as<float>(), fv.wx.as<float>(), p, dsums.as<double>(),
-                                           p + 2, nullptr) ||
-                jxg_fvlmm_finish_dev(dsums.as<double>(), p + 2, rows, n, p, dachol.as<double>(), fv.sc[0], (int)fv.sc[2],
+                                           p + 2, 0, nullptr) ||
+                jxg_fvlmm_finish_dev(dsums.as<double>(), num_tiles(n), p + 2, rows, n, p, dachol.as<double>(), fv.sc[0], (int)fv.sc[2],
                                      has_nullml, nullml, fv.sc[1], 0, dout.as<double>(), nullptr))
                 return 1;
         } else if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,

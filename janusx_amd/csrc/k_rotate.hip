@@ -161,16 +161,19 @@ __global__ __launch_bounds__(256) void ut_rowsum_kernel(const float *__restrict_
 // a tile whose 128 rows all qualify skips the A-lo plane (decode, LDS traffic and one of the three MFMA products).
 // FUSE: instead of writing the rotated tile, reduce it against the fixed-lambda weights of its 128 eigenvector columns
 // (fw = 1 / (s + lambda), fpy = W P y~, fwx = W X~, the state of jxg_fvlmm_prepare) and add the p + 2 partial sums of every
-// SNP row to fsums[row][0 .. p+1] = (sum w g~^2, g~.Py~, g~.WX~[k]) with f64 atomics: the fixed-lambda scan
-// (src/stats/fvlmm.rs:1691-1805) and the SparseLMM exact scan never see G~ in memory.  The tile goes through the LDS of the
-// finished main loop, 64 rows at a time; four threads share a row (32 interleaved columns each, conflict-free reads).
+// SNP row into fsums[tile0 + column tile][row][0 .. p+1] = this tile's share of (sum w g~^2, g~.Py~, g~.WX~[k]); the finish
+// kernel adds the column tiles in index order (no atomics: a fixed-lambda result is the same bits in every run).  The
+// fixed-lambda scan (src/stats/fvlmm.rs:1691-1805) and the SparseLMM exact scan never see G~ in memory.  The tile goes through
+// the LDS of the finished main loop, 64 rows at a time; four threads share a row (32 interleaved columns each, conflict-free
+// reads).
 constexpr int R_FP = 132;      // floats per row of the epilogue's LDS tile
 constexpr int R_FMAXP = 8;     // covariates the fused epilogue supports
 struct RotFuse {
     const float *fw, *fpy, *fwx;
     int fp;
-    double *fsums;
+    double *fsums;          // [column tiles of all calls][nrows][flds]
     int flds;
+    int tile0;              // index of this call's first column tile in fsums
 };
 
 template <bool FUSE>
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void rotate_f16x2_kernel(const uint8_t *__r
                         double t = sv[k];
                         t += __shfl_xor(t, 1, 64);
                         t += __shfl_xor(t, 2, 64);
-                        if (q == 0 && gr < nrows && t != 0.0) unsafeAtomicAdd(F.fsums + (int64_t)gr * F.flds + k, t);
+                        if (q == 0 && gr < nrows) F.fsums[((int64_t)(F.tile0 + ct) * nrows + gr) * F.flds + k] = t;
                     }
                 }
             }
@@ -653,16 +656,17 @@ extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, in
     return 0;
 }
 
-// Rotation with the fused fixed-lambda reduction (rotate_f16x2_kernel<true>): nothing is written but
-// d_sums[r][0 .. p+1] += (sum_j w_j g~_rj^2, sum_j g~_rj py_j, sum_j g~_rj wx_jk) over this call's n eigenvector columns
-// (d_w, d_py (n) f32, d_wx (n, p) f32: the state of jxg_fvlmm_prepare restricted to the columns of d_uhi / d_ulo).  The caller
-// zeroes d_sums (nrows, lds_sums >= p + 2) once per row block and finishes with jxg_fvlmm_finish_dev; several calls (the
-// diagonal blocks of the block route) accumulate into the same sums.  p <= 8.
+// Rotation with the fused fixed-lambda reduction (rotate_f16x2_kernel<true>): G~ is not written; column tile t of this call
+// (128 eigenvector columns, t < jxg_num_tiles(n)) writes its share of (sum_j w_j g~_rj^2, sum_j g~_rj py_j, sum_j g~_rj wx_jk)
+// to d_part[tile0 + t][r][0 .. p+1] (d_w, d_py (n) f32, d_wx (n, p) f32: the state of jxg_fvlmm_prepare restricted to the
+// columns of d_uhi / d_ulo).  d_part: (tiles of all calls, nrows, lds_sums >= p + 2) f64; jxg_fvlmm_finish_dev adds the tiles in
+// index order and computes the statistics; the diagonal blocks of the block route are successive calls with tile0 advancing.
+// p <= 8.
 extern "C" int jxg_rotate_packed16x_fused(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                           const void *d_lut16, const float *d_rowoff, const float *d_usum,
                                           const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, const float *d_w,
                                           const float *d_py, const float *d_wx, int p, double *d_sums, int lds_sums,
-                                          void *stream) {
+                                          int tile0, void *stream) {
     if (p < 1 || p > R_FMAXP || lds_sums < p + 2) return fail("jxg_rotate_packed16x_fused: p out of range (1..8)");
     if (nrows <= 0) return 0;
     if (!d_usum) d_rowoff = nullptr;
@@ -678,7 +682,7 @@ extern "C" int jxg_rotate_packed16x_fused(const uint8_t *d_p32, int64_t m_total,
     JX_HIP(hipEventRecord(g_rot_a, st));
     hipLaunchKernelGGL(rotate_f16x2_kernel<true>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
                        (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
-                       ldexpf(1.0f, -scale_exp), nullptr, 0, RotFuse{d_w, d_py, d_wx, p, d_sums, lds_sums});
+                       ldexpf(1.0f, -scale_exp), nullptr, 0, RotFuse{d_w, d_py, d_wx, p, d_sums, lds_sums, tile0});
     JX_LAUNCH_CHECK();
     JX_HIP(hipEventRecord(g_rot_b, st));
     g_timer_pending[1] = 1;

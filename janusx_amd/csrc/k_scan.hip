@@ -757,10 +757,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void fvlmm_scan_kernel(const float *_
     }
 }
 
-// Finish kernel of the fused rotation epilogue: sums (nrows, lds) f64 = per SNP (sum w g~^2, g~.Py~, g~.WX~[k]) accumulated
-// by rotate_f16x2_kernel<true>; one thread per SNP.
+// Finish kernel of the fused rotation epilogue: sums (ntiles, nrows, lds) f64 = per column tile and SNP the tile's share of
+// (sum w g~^2, g~.Py~, g~.WX~[k]) written by rotate_f16x2_kernel<true>, added here in tile order; one thread per SNP.
 template <int MAXD>
-__global__ __launch_bounds__(256) void fvlmm_finish_kernel(const double *__restrict__ sums, int lds, int nrows, int n, int p,
+__global__ __launch_bounds__(256) void fvlmm_finish_kernel(const double *__restrict__ sums, int ntiles, int lds, int nrows, int n, int p,
                                                            const double *__restrict__ a_chol, double ypy, int df,
                                                            int with_plrt, double nullml, double log_det_v,
                                                            int score_mode, double *__restrict__ out) {
@@ -773,7 +773,13 @@ __global__ __launch_bounds__(256) void fvlmm_finish_kernel(const double *__restr
         for (int c = 0; c < MAXD; ++c) l[a * MAXD + c] = (a < p && c < p) ? a_chol[a * p + c] : (a == c ? 1.0 : 0.0);
     double v[MAXD + 2];
 #pragma unroll
-    for (int k = 0; k < MAXD + 2; ++k) v[k] = (k < 2 + p) ? sums[(int64_t)r * lds + k] : 0.0;
+    for (int k = 0; k < MAXD + 2; ++k) v[k] = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        const double *sp = sums + ((int64_t)t * nrows + r) * lds;
+#pragma unroll
+        for (int k = 0; k < MAXD + 2; ++k)
+            if (k < 2 + p) v[k] += sp[k];
+    }
     fvlmm_row_finish<MAXD>(v, l, p, n, ypy, df, with_plrt, nullml, log_det_v, score_mode,
                            out + (int64_t)r * ((with_plrt && !score_mode) ? 4 : 3));
 }
@@ -944,18 +950,18 @@ extern "C" int jxg_splmm_exact_scan_dev(const float *d_grot, int nrows, int n, i
     return 0;
 }
 
-// Finish of the fused rotation epilogue (jxg_rotate_packed16x_fused): d_sums (nrows, lds) f64 with lds >= p + 2;
+// Finish of the fused rotation epilogue (jxg_rotate_packed16x_fused): d_sums (ntiles, nrows, lds) f64 with lds >= p + 2;
 // score_mode != 0 = SparseLMM exact scan (df = n - p), else the fixed-lambda scan (df = n - p - 1).
-extern "C" int jxg_fvlmm_finish_dev(const double *d_sums, int lds, int nrows, int n, int p, const double *d_a_chol,
+extern "C" int jxg_fvlmm_finish_dev(const double *d_sums, int ntiles, int lds, int nrows, int n, int p, const double *d_a_chol,
                                     double ypy, int df, int with_plrt, double nullml, double log_det_v, int score_mode,
                                     double *d_out, void *stream) {
     if (nrows <= 0) return 0;
-    if (p < 1 || p > JXG_MAX_COV || lds < p + 2) return fail("jxg_fvlmm_finish: p out of range");
+    if (p < 1 || p > JXG_MAX_COV || lds < p + 2 || ntiles < 1) return fail("jxg_fvlmm_finish: p out of range");
     if (score_mode && (!(ypy > 0.0) || !std::isfinite(ypy)))
         return fail("SparseLMM exact scan requires finite positive yPy on K + lambda I scale");
     if (df <= 0) return fail("df <= 0");
     JX_DISPATCH_DIM(p, hipLaunchKernelGGL(fvlmm_finish_kernel<MAXD>, dim3((nrows + 255) / 256), dim3(256), 0,
-                                          (hipStream_t)stream, d_sums, lds, nrows, n, p, d_a_chol, ypy, df,
+                                          (hipStream_t)stream, d_sums, ntiles, lds, nrows, n, p, d_a_chol, ypy, df,
                                           score_mode ? 0 : with_plrt, nullml, log_det_v, score_mode, d_out));
     JX_LAUNCH_CHECK();
     return 0;

@@ -363,7 +363,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     nbuf = 2 if mk > br else 1
     fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)
     if fused:
-        sums = [torch.empty((br, model.p + 2), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        sums = [torch.empty((panel.nt, br, model.p + 2), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         grots = [None] * nbuf
     else:
         grots = [torch.empty((br, n), dtype=torch.float32, device=dev) for _ in range(nbuf)]
@@ -386,11 +386,10 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             ev_rot[bi][0].record()
         if fused:
             sm = sums[bi % nbuf]
-            sm.zero_()
             check(lib().jxg_rotate_packed16x_fused(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
                                                    lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi),
                                                    _ptr(lo), SCALE_EXP, _ptr(w), _ptr(py), _ptr(wx), model.p, _ptr(sm),
-                                                   model.p + 2, _stream()))
+                                                   model.p + 2, 0, _stream()))
         else:
             check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
                                              lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
@@ -401,10 +400,10 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         o = out[r0:]
         if fused:
             if mode == "splmm":
-                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, n - model.p, 0,
+                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), panel.nt, model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, n - model.p, 0,
                                                  0.0, 0.0, 1, o.data_ptr(), _stream()))
             else:
-                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, df, with_plrt,
+                check(lib().jxg_fvlmm_finish_dev(_ptr(sm), panel.nt, model.p + 2, nr, n, model.p, _ptr(a_dev), ypy, df, with_plrt,
                                                  nullml_v, log_det_v, 0, o.data_ptr(), _stream()))
         elif mode == "lmm2":
             check(lib().jxg_lmm2_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p, lo_b,
@@ -487,17 +486,19 @@ def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np
     a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
     br = int(min(block_rows, mk))
     if _fused_fixed_lambda(p):
-        # every diagonal block adds its columns' share of the three weighted sums; G~ is never written
-        sums = torch.empty((br, p + 2), dtype=torch.float64, device=dev)
+        # every column tile of every diagonal block writes its share of the three weighted sums; G~ is never written
+        tiles = int(sum(panel.nt for _o, _nb, _h, _l, panel in rot.parts))
+        sums = torch.empty((tiles, br, p + 2), dtype=torch.float64, device=dev)
         for r0 in range(0, mk, br):
             nr = min(br, mk - r0)
-            sums.zero_()
+            t0 = 0
             for off, nb, hi, lo, panel in rot.parts:
                 check(lib().jxg_rotate_packed16x_fused(_ptr(panel.p32), panel.m, nb, rows_t[r0:].data_ptr(), nr,
                                                        lut16[r0:].data_ptr(), None, None, _ptr(hi), _ptr(lo), SCALE_EXP,
                                                        w[off:].data_ptr(), py[off:].data_ptr(), wx[off:].data_ptr(), p,
-                                                       _ptr(sums), p + 2, _stream()))
-            check(lib().jxg_fvlmm_finish_dev(_ptr(sums), p + 2, nr, n, p, _ptr(a_dev), ypy, n - p, 0, 0.0, 0.0, 1,
+                                                       _ptr(sums), p + 2, t0, _stream()))
+                t0 += panel.nt
+            check(lib().jxg_fvlmm_finish_dev(_ptr(sums), tiles, p + 2, nr, n, p, _ptr(a_dev), ypy, n - p, 0, 0.0, 0.0, 1,
                                              out[r0:].data_ptr(), _stream()))
         return out
     grot = torch.empty((br, n), dtype=torch.float32, device=dev)

@@ -1840,6 +1840,11 @@ def test_cli_gwas_splmm(oracle, tmp_path):
             fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
     assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-o", prefix]) == 0
     lines = open(prefix + ".traitA.splmm.tsv").read().splitlines()
+    # the reference's name for this scan: -splmm-exact -> result stem "splmm2" (workflow.py:6705-6715, 7005-7015)
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm-exact", "-o", prefix + "_x"]) == 0
+    lx = open(prefix + "_x.traitA.splmm2.tsv").read().splitlines()
+    assert len(lx) == len(lines) and lx[0] == lines[0]
+    assert lx[1:] == lines[1:]              # the scan is bit-reproducible (ordered per-tile sums, no atomics)
     assert open(prefix + ".spgrm.id").read().split() == ids
     nn, cp, ri, va = oracle.read_sparse_grm_csc(prefix + ".spgrm")
     keep_idx = np.nonzero(~na)[0]
@@ -2107,6 +2112,10 @@ def test_fixed_lambda_scan_fused_into_the_rotation_epilogue(oracle, monkeypatch)
             outs[fused] = pipeline.scan_rows(panel, model, rows, lut, "fvlmm", nullml=nm.ML0, block_rows=400).cpu().numpy()
         a, b = outs["1"], outs["0"]
         assert a.shape == b.shape == (len(rows), 4)
+        if q <= 8:      # per-tile partial sums added in tile order: the same bits in every run and for every row blocking
+            monkeypatch.setenv("JXGPU_FVLMM_FUSED", "1")
+            again = pipeline.scan_rows(panel, model, rows, lut, "fvlmm", nullml=nm.ML0, block_rows=256).cpu().numpy()
+            assert np.array_equal(again, a, equal_nan=True)
         ok = ~np.isnan(b[:, 0])
         assert np.array_equal(ok, ~np.isnan(a[:, 0]))
         for c in range(4):

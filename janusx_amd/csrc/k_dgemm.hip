@@ -38,70 +38,49 @@ struct DgemmArgs {
     double *ws;
 };
 
+// Branch-free: every lane always issues its NL loads from a clamped (valid) address and zeroes the out-of-range elements
+// afterwards, so the loads of a step are independent instructions behind ONE wait (the former per-element `if` made hipcc
+// wait for each load before the next address was formed: eight exposed memory latencies per K step).
+// Returns the bit mask of the in-range elements: the zeroing is left to dg_store_tile (behind the MFMAs of the step), so
+// that nothing consumes a loaded value while the step is multiplied.
 template <int BX>
-__device__ __forceinline__ void dg_load_tile(const double *__restrict__ p, int64_t ld, bool trans, bool symm, int x0,
-                                             int xmax, int k0, int kmax, double (&r)[BX * DG_BK / DG_THREADS]) {
-    // element (x, kk) of the BX x 16 operand tile; storage: !trans -> p[x + kk * ld], trans -> p[kk + x * ld]
+__device__ __forceinline__ unsigned dg_load_tile(const double *__restrict__ p, int64_t ld, bool trans, bool symm, int x0,
+                                                 int xmax, int k0, int kmax, double (&r)[BX * DG_BK / DG_THREADS]) {
+    // element (x, kk) of the BX x 16 operand tile; storage: !trans -> p[x + kk * ld], trans -> p[kk + x * ld];
+    // lower-stored symmetric operand: (x, kk) = p[max + min * ld], tiles entirely above the diagonal take the k-fast
+    // (coalesced along the stored columns) thread mapping, the others the x-fast one
     constexpr int NL = BX * DG_BK / DG_THREADS;
     const int t = threadIdx.x;
-    if (symm) {
-        // lower-stored symmetric operand: (x, kk) = p[max + min * ld]; tiles off the diagonal take the coalesced mapping
-        // of the orientation they are stored in, tiles crossing it are read element by element
-        const bool below = x0 >= k0 + DG_BK;     // rows entirely below the columns: stored as is
-        const bool above = x0 + BX <= k0;        // entirely above: stored transposed
-        if (below || !above) {
+    const bool kfast = symm ? (x0 + BX <= k0) : trans;
+    unsigned okmask = 0;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = i * DG_THREADS + t;
-                const int x = x0 + idx % BX, kk = k0 + idx / BX;
-                double v = 0.0;
-                if (x < xmax && kk < kmax) v = (x >= kk) ? p[x + (int64_t)kk * ld] : p[kk + (int64_t)x * ld];
-                r[i] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int idx = i * DG_THREADS + t;
-                const int kk = k0 + idx % DG_BK, x = x0 + idx / DG_BK;
-                r[i] = (x < xmax && kk < kmax) ? p[kk + (int64_t)x * ld] : 0.0;
-            }
-        }
-        return;
+    for (int i = 0; i < NL; ++i) {
+        const int idx = i * DG_THREADS + t;
+        const int xo = kfast ? idx / DG_BK : idx % BX;
+        const int ko = kfast ? idx % DG_BK : idx / BX;
+        const int x = x0 + xo, kk = k0 + ko;
+        const bool ok = x < xmax && kk < kmax;
+        const int xc = min(x, xmax - 1), kc = min(kk, kmax - 1);
+        int64_t off;
+        if (symm) off = (int64_t)max(xc, kc) + (int64_t)min(xc, kc) * ld;
+        else off = trans ? (int64_t)kc + (int64_t)xc * ld : (int64_t)xc + (int64_t)kc * ld;
+        r[i] = p[off];
+        okmask |= ok ? (1u << i) : 0u;
     }
-    if (!trans) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = i * DG_THREADS + t;
-            const int x = x0 + idx % BX, kk = k0 + idx / BX;
-            r[i] = (x < xmax && kk < kmax) ? p[x + (int64_t)kk * ld] : 0.0;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = i * DG_THREADS + t;
-            const int kk = k0 + idx % DG_BK, x = x0 + idx / DG_BK;
-            r[i] = (x < xmax && kk < kmax) ? p[kk + (int64_t)x * ld] : 0.0;
-        }
-    }
+    return okmask;
 }
 
 template <int BX>
-__device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast, const double (&r)[BX * DG_BK / DG_THREADS]) {
+__device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast, const double (&r)[BX * DG_BK / DG_THREADS],
+                                              unsigned okmask) {
     constexpr int NL = BX * DG_BK / DG_THREADS;
     constexpr int PITCH = BX + 17;
     const int t = threadIdx.x;
-    if (!kfast) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = i * DG_THREADS + t;
-            s[(idx / BX) * PITCH + idx % BX] = r[i];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = i * DG_THREADS + t;
-            s[(idx % DG_BK) * PITCH + idx / DG_BK] = r[i];
-        }
+    for (int i = 0; i < NL; ++i) {
+        const int idx = i * DG_THREADS + t;
+        const int pos = kfast ? (idx % DG_BK) * PITCH + idx / DG_BK : (idx / BX) * PITCH + idx % BX;
+        s[pos] = ((okmask >> i) & 1u) ? r[i] : 0.0;
     }
 }
 
@@ -154,14 +133,15 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
         if (symm) return (m0 + BM <= k0);              // tile entirely above the diagonal: read transposed
         return ta;
     };
+    unsigned oka = 0, okb = 0;
     auto load = [&](int k0) {
-        dg_load_tile<BM>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
+        oka = dg_load_tile<BM>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
         // op(B)(kk, x): !tb -> b[kk + x ldb] (k contiguous = "trans" mapping of the loader), tb -> b[x + kk ldb]
-        dg_load_tile<BN>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
+        okb = dg_load_tile<BN>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
     };
     load(kbeg);
-    dg_store_tile<BM>(as, a_kfast(kbeg), ra);
-    dg_store_tile<BN>(bs, tb_kfast, rb);
+    dg_store_tile<BM>(as, a_kfast(kbeg), ra, oka);
+    dg_store_tile<BN>(bs, tb_kfast, rb, okb);
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += DG_BK) {
@@ -183,8 +163,8 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
         if (more) {
-            dg_store_tile<BM>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra);
-            dg_store_tile<BN>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb);
+            dg_store_tile<BM>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra, oka);
+            dg_store_tile<BN>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb, okb);
         }
         __syncthreads();
         buf ^= 1;
@@ -192,8 +172,23 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
     // epilogue: acc[j][i][r] = C[m0 + wm + 16 i + lx][n0 + wn + 16 j + lk + 4 r]
     const bool split = g.ksplit > 1;
     double *slice = split ? g.ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
+    const bool rmw = !split && g.beta != 0.0;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NB; ++j) {
+        // the C values of this 16-column strip first (clamped, always valid addresses: MB x 4 independent loads behind one
+        // wait), then the stores -- the former element-by-element read-modify-write exposed one memory latency per element
+        double cv[4][MB];
+        if (rmw) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = min(n0 + wn + 16 * j + lk + 4 * r, g.n - 1);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int row = min(m0 + wm + 16 * i + lx, g.m - 1);
+                    cv[r][i] = g.c[row + (int64_t)col * g.ldc];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = n0 + wn + 16 * j + lk + 4 * r;
@@ -204,14 +199,11 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
                 if (row >= g.m) continue;
                 if (g.lower_tiles && row < col) continue;     // diagonal tiles: the strict upper part is not referenced
                 const double v = g.alpha * acc[j][i][r];
-                if (split) {
-                    slice[row + (int64_t)col * g.m] = v;
-                } else {
-                    double *cp = g.c + row + (int64_t)col * g.ldc;
-                    *cp = (g.beta == 0.0) ? v : (v + g.beta * *cp);
-                }
+                if (split) slice[row + (int64_t)col * g.m] = v;
+                else g.c[row + (int64_t)col * g.ldc] = rmw ? (v + g.beta * cv[r][i]) : v;
             }
         }
+    }
 }
 
 template <int BM, int BN>

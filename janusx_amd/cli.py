@@ -140,6 +140,41 @@ def cmd_grm(args):
     return 0
 
 
+def build_cv_splits(n_samples, n_splits, seed=42):
+    """`build_cv_splits` (python/janusx/gs/workflow.py:3950-3980) over the `KFold` of python/janusx/pyBLUP/kfold.py:28-88:
+    one permutation of arange(n) from numpy's default_rng(seed), cut into n_splits runs whose sizes differ by at most one
+    (the first n % k folds are the longer ones); each item is (test_idx, train_idx), train in ascending order."""
+    n, k = int(n_samples), int(n_splits)
+    if n < 2:
+        raise ValueError(f"CV requires at least 2 samples, got {n}.")
+    if k < 2:
+        raise ValueError(f"CV folds must be >=2, got {k}.")
+    if k > n:
+        raise ValueError(f"CV folds ({k}) cannot exceed sample size ({n}).")
+    idx = np.asarray(np.random.default_rng(int(seed)).permutation(np.arange(n, dtype=np.int64)), dtype=np.int64)
+    sizes = np.full(k, n // k, dtype=np.int64)
+    sizes[: n % k] += 1
+    out, cur = [], 0
+    for fs in sizes:
+        te = idx[cur:cur + int(fs)]
+        cur += int(fs)
+        mask = np.zeros(n, dtype=bool)
+        mask[te] = True
+        out.append((te, np.nonzero(~mask)[0].astype(np.int64)))
+    return out
+
+
+def cv_fold_metrics(y_true, y_pred):
+    """Per-fold metrics of the reference's GS summary (python/janusx/gs/workflow.py:880-930): Pearson r, Spearman rho,
+    R2 = 1 - SS_res / SS_tot of the held-out fold."""
+    from scipy.stats import pearsonr, spearmanr
+    yt, yp = np.asarray(y_true, dtype=np.float64), np.asarray(y_pred, dtype=np.float64)
+    ss_res = float(np.sum((yt - yp) ** 2))
+    ss_tot = float(np.sum((yt - float(np.mean(yt))) ** 2))
+    r2 = 1.0 - ss_res / ss_tot if ss_tot > 0.0 else 0.0
+    return float(pearsonr(yt, yp).statistic), float(spearmanr(yt, yp).statistic), r2
+
+
 def cmd_gwas(args):
     import torch
     from . import janusx as jxrs
@@ -295,8 +330,8 @@ def cmd_gwas(args):
 
 def cmd_gs(args):
     """`jx gs -BLUP`: centred GRM of all genotyped samples (once), then per trait a GBLUP fit on the phenotyped
-    samples (spectral REML, src/stats/gblup.rs:1105-1240) -- K-fold cross-validated with `-cv` (fold shuffling
-    seeded by `-seed`, python/janusx/gs/workflow.py:18744-18760) -- and predictions for every genotyped sample."""
+    samples (spectral REML, src/stats/gblup.rs:1105-1240) -- K-fold cross-validated with `-cv` (folds of
+    `build_cv_splits`, seeded by `-seed` = 42, python/janusx/gs/workflow.py:3950-3980, 18753-18760) -- and predictions for every genotyped sample."""
     from . import janusx as jxrs
     from .bed import read_fam_ids
     if args.rrblup:
@@ -329,13 +364,13 @@ def cmd_gs(args):
         fold = np.full(n_all, -1, dtype=np.int64)
         pred = np.full(n_all, np.nan)
         if args.cv and args.cv > 1:
-            perm = np.random.default_rng(args.seed).permutation(len(train))
-            for f in range(args.cv):
-                te_loc = np.sort(perm[f::args.cv])
-                tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+            print("Fold Method     Pearsonr Spearmanr R2")
+            for f, (te_loc, tr_loc) in enumerate(build_cv_splits(len(train), args.cv, args.seed)):
                 r = jxrs.gblup_reml_grm(k, train[tr_loc], yv[train[tr_loc]], train[te_loc], estimate_only=False)
                 pred[train[te_loc]] = r[1].ravel()
                 fold[train[te_loc]] = f
+                pe, sp, r2f = cv_fold_metrics(yv[train[te_loc]], r[1].ravel())
+                print(f"{f + 1:<4d} BLUP       {pe:.3f}    {sp:.3f}     {r2f:.3f}")
             yo, po = yv[train], pred[train]
             rr = float(np.corrcoef(yo, po)[0, 1])
             r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
@@ -433,13 +468,13 @@ def cmd_gs_rrblup(args):
                                        maf=maf, row_flip=flip)
 
         if args.cv and args.cv > 1:
-            perm = np.random.default_rng(args.seed).permutation(len(train))
-            for f in range(args.cv):
-                te_loc = np.sort(perm[f::args.cv])
-                tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+            print("Fold Method     Pearsonr Spearmanr R2")
+            for f, (te_loc, tr_loc) in enumerate(build_cv_splits(len(train), args.cv, args.seed)):
                 r = fit_predict(train[tr_loc], train[te_loc])
                 pred[train[te_loc]] = r[1].ravel()
                 fold[train[te_loc]] = f
+                pe, sp, r2f = cv_fold_metrics(yv[train[te_loc]], r[1].ravel())
+                print(f"{f + 1:<4d} rrBLUP     {pe:.3f}    {sp:.3f}     {r2f:.3f}")
             yo, po = yv[train], pred[train]
             rr = float(np.corrcoef(yo, po)[0, 1])
             r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))

@@ -282,3 +282,22 @@ def test_block_route_packs_whole_components():
             assert len(np.nonzero(np.diff(labs))[0]) + 1 == len(np.unique(labs))          # contiguous components
             assert offs[b + 1] - offs[b] <= bsz or len(np.unique(labs)) == 1
         assert len(offs) - 1 <= int(np.ceil(n / bsz)) + 3 + int((sizes >= bsz).sum())
+
+
+def test_cv_splits_follow_the_reference_kfold():
+    """`cli.build_cv_splits` against vectors of the reference's own splitter (`build_cv_splits`,
+    python/janusx/gs/workflow.py:3950-3980 over python/janusx/pyBLUP/kfold.py `KFold(shuffle=True, random_state=seed)`;
+    generated in the build container with `KFold(n_splits=5, shuffle=True, random_state=42).split(np.arange(1410))`):
+    balanced run lengths, the permutation of numpy's default_rng(seed), (test, train) order, train ascending."""
+    from janusx_amd import cli
+    sp = cli.build_cv_splits(1410, 5, 42)
+    assert [len(te) for te, _ in sp] == [282] * 5
+    assert sp[0][0][:8].tolist() == [180, 184, 631, 282, 20, 483, 1370, 849]
+    sp = cli.build_cv_splits(13, 4, 7)
+    assert [len(te) for te, _ in sp] == [4, 3, 3, 3]
+    ref = np.random.default_rng(7).permutation(np.arange(13))
+    assert np.array_equal(np.concatenate([te for te, _ in sp]), ref)
+    for te, tr in sp:
+        assert np.array_equal(np.sort(np.concatenate([te, tr])), np.arange(13)) and np.all(np.diff(tr) > 0)
+    with pytest.raises(ValueError, match="cannot exceed"):
+        cli.build_cv_splits(3, 5)

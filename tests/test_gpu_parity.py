@@ -949,9 +949,7 @@ def test_cli_gs_blup(oracle, tmp_path):
     assert np.max(np.abs(pred[test] - pte)) < 2e-5 * scale + 1e-5 * np.max(np.abs(pte))
     assert all(rows[1 + j][1] == "NA" and rows[1 + j][3] == "NA" for j in test)
     # fold structure and one fold recomputed with the oracle
-    perm = np.random.default_rng(7).permutation(len(train))
-    te_loc = np.sort(perm[1::3])
-    tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+    te_loc, tr_loc = cli.build_cv_splits(len(train), 3, 7)[1]      # the reference's split (workflow.py:3950-3980)
     assert all(rows[1 + train[j]][3] == "1" for j in te_loc)
     _, p1, _ = oracle.gblup_reml_grm(k_ref, train[tr_loc], y[train[tr_loc]], train[te_loc])
     assert np.max(np.abs(pred[train[te_loc]] - p1)) < 2e-5 * scale + 1e-5 * np.max(np.abs(p1))
@@ -1260,9 +1258,7 @@ def test_cli_gs_rrblup(oracle, tmp_path):
     pred = np.array([float(r[2]) for r in rows[1:]])
     scale = float(np.std(y[train]))
     assert np.max(np.abs(pred[test] - ref[1].ravel())) < 1e-4 * scale
-    perm = np.random.default_rng(3).permutation(len(train))
-    te_loc = np.sort(perm[1::2])
-    tr_loc = np.setdiff1d(np.arange(len(train)), te_loc)
+    te_loc, tr_loc = cli.build_cv_splits(len(train), 2, 3)[1]
     assert all(rows[1 + train[j]][3] == "1" for j in te_loc)
     r1 = oracle.rrblup_pcg_packed(packed, n, maf, flip, train[tr_loc], y[train[tr_loc]], train[te_loc], None, keep, lam,
                                   1e-7, 400)

@@ -503,8 +503,10 @@ int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n_samples, c
  * Returns the number of rows written, -1 on error (jx_last_error). */
 int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
                            const float *af, const float *miss, const double *stats, int ncol);
-/* Same rows appended behind the present content of `path` (append != 0: no header): the block-wise writer of the
- * streaming scan, counterpart of the reference's AsyncTsvWriter (src/stats/common.rs:374). */
+/* Same rows appended behind the present content of `path` (append bit 0 set: no header): the block-wise writer of the
+ * streaming scan, counterpart of the reference's AsyncTsvWriter (src/stats/common.rs:374).  append bit 1 (+2): `miss` holds
+ * counts of missing samples and is printed as an integer (`AssocMissValue::Count`, src/io/assoc2tsv.rs:452-458: the LM
+ * routes) instead of a rate. */
 int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
                            const float *af, const float *miss, const double *stats, int ncol, int append);
 

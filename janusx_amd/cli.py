@@ -276,7 +276,7 @@ def cmd_gwas(args):
                 wr["path"] = f"{out}.{name}.{model_tag}.tsv"
                 wr["w"] = AsyncAssocTsvWriter(wr["path"], ncol, [bim.chrom[j] for j in kept_rows], [bim.pos[j] for j in kept_rows],
                                               [bim.snp[j] for j in kept_rows], [bim.a0[j] for j in kept_rows],
-                                              [bim.a1[j] for j in kept_rows], af_k, miss_k)
+                                              [bim.a1[j] for j in kept_rows], af_k, miss_k, miss_count=(model_tag == "lm"))
                 return wr["w"].put
 
             try:

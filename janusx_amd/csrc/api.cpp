@@ -1003,10 +1003,13 @@ extern "C" int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob,
     return jx_assoc_tsv_append(path, prefix_blob, prefix_off, rows, af, miss, stats, ncol, 0);
 }
 
-// append != 0: the rows go behind what `path` holds already, without a header (the block-wise writer of the streaming
-// scan: header + first block with append = 0, every later block with append = 1)
+// append bit 0: the rows go behind what `path` holds already, without a header (the block-wise writer of the streaming
+// scan: header + first block with 0, every later block with 1); bit 1 (+2): `miss` holds COUNTS of missing samples and is
+// printed as an integer (`AssocMissValue::Count`, src/io/assoc2tsv.rs:452-458: the LM routes) instead of a rate `{:.4}`
 extern "C" int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
-                                       const float *af, const float *miss, const double *stats, int ncol, int append) {
+                                       const float *af, const float *miss, const double *stats, int ncol, int append_flags) {
+    const int append = append_flags & 1;
+    const bool miss_count = (append_flags & 2) != 0;
     if (ncol != 3 && ncol != 4 && ncol != 6) {
         fail("unsupported GWAS result column count: " + std::to_string(ncol) + " (expected 3, 4, or 6)");
         return -1;
@@ -1049,7 +1052,9 @@ extern "C" int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob
             pv = 1.0;
         }
         *o++ = '\t'; o = put_fixed4(o, (double)af[i]);
-        *o++ = '\t'; o = put_fixed4(o, (double)miss[i]);
+        *o++ = '\t';
+        if (miss_count) o += snprintf(o, 32, "%lld", (long long)llround((double)miss[i]));
+        else o = put_fixed4(o, (double)miss[i]);
         *o++ = '\t'; o = put_fixed4(o, beta);
         *o++ = '\t'; o = put_fixed4(o, se);
         *o++ = '\t'; o = put_exp(o, chisq, 4);

@@ -608,9 +608,12 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
         sw, stat, pv, _ml = gwas_lmm_lm_null_lrt_decision(y, np.asarray(x)[:, 1:], model.null.ml0)
         lrt = (sw, stat, pv)
         if sw:
-            on_block = on_rows(keep, af[rows], miss[rows], 3, "lm") if on_rows is not None else None
+            # the reference's LM routes print the COUNT of missing samples in the miss column (AssocMissValue::Count,
+            # src/io/assoc2tsv.rs:452-458; the streaming writer formats rint(miss) as an integer)
+            miss_cnt = counts[rows, 0].astype(np.float32)
+            on_block = on_rows(keep, af[rows], miss_cnt, 3, "lm") if on_rows is not None else None
             out = scan_rows_lm(panel, rows, af[rows], x, y, on_block=on_block)
-            res = GwasResult(keep, af[rows], miss[rows], out[:, :3].cpu().numpy(), model.null, 0, {})
+            res = GwasResult(keep, af[rows], miss_cnt, out[:, :3].cpu().numpy(), model.null, 0, {})
             res.model_tag, res.null_lrt = "lm", lrt
             return res
     on_block = on_rows(keep, af[rows], miss[rows], 6 if mode == "lmm2" else 3, mode) if on_rows is not None else None

@@ -85,7 +85,7 @@ def write_assoc_tsv_python(path, chrom, pos, snp, a0, a1, af, miss, stats) -> in
     return int(stats.shape[0])
 
 
-def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append) -> int:
+def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append, miss_count=False) -> int:
     import ctypes as C
 
     import numpy as np
@@ -108,7 +108,7 @@ def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append) -> int:
         raise RuntimeError("af / miss shorter than the result table")
     written = lib().jx_assoc_tsv_append(tmp.encode(), C.cast(C.c_char_p(blob), C.c_void_p), off.ctypes.data, rows,
                                         af32.ctypes.data, miss32.ctypes.data, stats.ctypes.data, int(stats.shape[1]),
-                                        1 if append else 0)
+                                        (1 if append else 0) | (2 if miss_count else 0))
     if written < 0:
         msg = lib().jx_last_error()
         raise RuntimeError(msg.decode("utf-8", "replace") if msg else "jx_assoc_tsv_append failed")
@@ -133,12 +133,13 @@ class AsyncAssocTsvWriter:
     releases the GIL) while the device scans the next block.  `close()` waits, renames the temp file and returns the row
     count; an error on the thread is raised there (and by the next `put`)."""
 
-    def __init__(self, path, ncol, chrom, pos, snp, a0, a1, af, miss, depth=4):
+    def __init__(self, path, ncol, chrom, pos, snp, a0, a1, af, miss, depth=4, miss_count=False):
         import queue
         import threading
         if ncol not in (3, 4, 6):
             raise RuntimeError(f"unsupported GWAS result column count: {ncol} (expected 3, 4, or 6)")
         self.path, self.ncol = path, int(ncol)
+        self.miss_count = bool(miss_count)      # `miss` holds counts, printed as integers (the reference's LM routes)
         self.meta = (chrom, pos, snp, a0, a1, af, miss)
         self.tmp = f"{path}.tmp.{os.getpid()}"
         self.rows, self.err, self.first = 0, None, True
@@ -158,7 +159,7 @@ class AsyncAssocTsvWriter:
             i1 = i0 + st.shape[0]
             try:
                 self.rows += _native_rows(self.tmp, chrom[i0:i1], pos[i0:i1], snp[i0:i1], a0[i0:i1], a1[i0:i1],
-                                          af[i0:i1], miss[i0:i1], st, not self.first)
+                                          af[i0:i1], miss[i0:i1], st, not self.first, self.miss_count)
                 self.first = False
             except BaseException as e:        # noqa: BLE001 - reported by put() / close()
                 self.err = e

@@ -2068,7 +2068,7 @@ def test_cli_gwas_switches_to_the_lm_scan_without_polygenic_signal(oracle, tmp_p
                                        maf[rows], None)
     for i, (ln, j) in enumerate(zip(lines[1:], rows)):
         f = ln.split("\t")
-        assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}"
+        assert f[2] == f"rs{j}" and f[5] == f"{float(maf[j]):.4f}" and f[6] == str(int(mi[j]))   # miss as a COUNT on the LM routes
         assert abs(float(f[7]) - ref[i, 0]) <= 5.1e-5 and abs(float(f[8]) - ref[i, 1]) <= 5.1e-5
         assert abs(float(f[10]) - ref[i, 2]) <= 6e-5 * ref[i, 2]
 

@@ -391,7 +391,9 @@ def main():
         _PMC_SHAPE.update(n=int(n), m=int(m))
         tr_symv, tr_symv_src = pmc_traffic_bytes("jx::sytrd_symv_kernel")
         tr_grm, tr_grm_src = pmc_traffic_bytes("jx::grm_f16x2_kernel")
-        tr_scan, tr_scan_src = (pmc_traffic_bytes("jx::lmm_scan_fast_kernel", "fetch") if args.mode == "lmm" else
+        # the exact scan's kernel is chosen by n and p (jxg_last_kernel_ms(11): 0 LDS-resident, 1 tiled, 2 operands from L2)
+        scan_kernel = "jx::lmm_scan_tiled_kernel" if int(lib().jxg_last_kernel_ms(11)) == 1 else "jx::lmm_scan_fast_kernel"
+        tr_scan, tr_scan_src = (pmc_traffic_bytes(scan_kernel, "fetch") if args.mode == "lmm" else
                                 pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
         mu_grm, mu_grm_src = pmc_mfma_util("grm_f16x2_kernel")
         mu_rot, mu_rot_src = pmc_mfma_util("rotate_f16x2_kernel")

@@ -60,6 +60,37 @@ def synth_panel_gpu(n, m, seed, device, m_offset=0, missing_rate=0.0):
     return out, dos_chunks[0]
 
 
+def family_panel_gpu(n, m, fam, seed, device):
+    """Panel with family structure generated directly in HBM (SURVEY.md 8d "family" variant, python/janusx/script/sim.py:18-19):
+    sibships of `fam` consecutive samples, every member after the founder copies each SNP of the founder with probability
+    1/2 (kinship ~ 0.25-0.5), so a thresholded GRM is block diagonal by family.  No (m x n) array ever exists on the host.
+    -> (packed (m, ceil(n / 4)) uint8 on the device, dosages of the first 128 SNPs)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bps = (n + 3) // 4
+    out = torch.empty((m, bps), dtype=torch.uint8, device=device)
+    founder = (torch.arange(n, device=device) // fam) * fam
+    head = None
+    chunk = max(1, min(m, (1 << 27) // max(n, 1)))
+    for r0 in range(0, m, chunk):
+        r1 = min(m, r0 + chunk)
+        p = 0.05 + 0.4 * torch.rand((r1 - r0, 1), generator=g, device=device)
+        d = (torch.rand((r1 - r0, n), generator=g, device=device) < p).to(torch.uint8)
+        d += (torch.rand((r1 - r0, n), generator=g, device=device) < p).to(torch.uint8)
+        share = torch.rand((r1 - r0, n), generator=g, device=device) < 0.5
+        d = torch.where(share, d[:, founder], d)
+        codes = torch.where(d == 0, 0, d + 1).to(torch.uint8)
+        pad = bps * 4 - n
+        if pad:
+            codes = torch.nn.functional.pad(codes, (0, pad))
+        c4 = codes.view(r1 - r0, bps, 4)
+        out[r0:r1] = c4[:, :, 0] | (c4[:, :, 1] << 2) | (c4[:, :, 2] << 4) | (c4[:, :, 3] << 6)
+        if head is None:
+            head = d[:128].clone()
+    return out, head
+
+
 def make_phenotype(dos_head, n, seed, device):
     """y = Z beta + e with up to 100 causal SNPs (the first rows of the panel), pve 0.5."""
     import torch

@@ -138,6 +138,13 @@ int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user,
  * into d_a (janusx_amd/pipeline.py: one broadcast per rank over RCCL).  NULL: off (the rank-sharded one-stage
  * tridiagonalisation of jxg_eigh_set_dist is used instead; JXGPU_DIST_EIGH_ONESTAGE=1 forces that too). */
 int jxg_eigh_set_gather(int (*gather)(void *), void *user);
+/* Guard of that mode: before the sharded back-transformations every rank hashes its replicated intermediate results
+ * (eigenvalues of the tridiagonal matrix, the divide and conquer's permutation, the first row of its eigenvector matrix)
+ * and agree(user, checksum) must return 1 when every rank reports the same value, 0 when they differ (every rank then
+ * back-transforms ALL its eigenvectors itself: slower, self-consistent), < 0 on failure.  NULL: no check.
+ * jxg_eigh_last_dist_agree: -1 not checked, 1 the replicas agreed, 0 they differed, for the last decomposition. */
+int jxg_eigh_set_agree(int (*agree)(void *, uint64_t checksum), void *user);
+int jxg_eigh_last_dist_agree(void);
 
 /* Building blocks of B1's two-stage reduction, exported for tests and timing scripts (no counterpart in the reference,
  * which calls LAPACK dsyevd, src/math/eigh.rs:1320-1400).  All matrices column-major f64 in HBM.

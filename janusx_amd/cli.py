@@ -415,8 +415,12 @@ def cmd_gs_rrblup(args):
     # the exact marker-space route (REML lambda from the spectrum); beyond that PCG for n_train > 10 000 -- and here also
     # for smaller n_train, where the reference takes its sample-space exact route (not built)
     solver = args.rr_solver
+    if solver == "exact" and args.lam is not None:
+        raise SystemExit("-lambda needs -rr-solver pcg: the exact marker-space route estimates lambda by REML on the spectrum "
+                         "and would ignore the given value")
     if solver == "auto":
-        solver = "exact" if int(keep.sum()) <= 15000 else "pcg"
+        # a given -lambda only exists on the PCG route (the exact route re-estimates it): honour it
+        solver = "pcg" if args.lam is not None else ("exact" if int(keep.sum()) <= 15000 else "pcg")
     print(f"rrBLUP-{solver.upper()}: n={n_all} m={packed.shape[0]} kept={int(keep.sum())} (maf {args.maf}, geno {args.geno})")
     for ti in traits:
         name = names[ti]

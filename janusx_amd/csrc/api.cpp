@@ -146,21 +146,46 @@ static int make_sample_sel(const int64_t *sample_indices, int n_sel, int n_sampl
     return 0;
 }
 
-// Upload a PLINK payload and re-tile it to P32 (with optional sample subset). p32 must stay alive.
+// true when `p` points into device memory (a payload that is already resident in HBM: torch CUDA tensor, hipMalloc)
+static bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();                     // plain (unregistered) host memory: not an error for the caller
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+// Re-tile a PLINK payload to P32 (with optional sample subset). p32 must stay alive.  `packed` may be a host pointer
+// (uploaded first) or a device pointer (used in place: no host copy of the payload exists anywhere).  Refuses with a
+// clear message, before anything is allocated, when the device copies do not fit the free HBM.
 static int stage_p32(const uint8_t *packed, int64_t m, int n_samples, const SampleSel &sel, DevBuf &p32) {
     const int64_t bps = (n_samples + 3) / 4;
+    const bool on_device = is_device_ptr(packed);
+    const int nt = num_tiles(sel.n);
+    {
+        size_t fr = 0, tot = 0;
+        const double need = (on_device ? 0.0 : (double)m * (double)bps) + (double)nt * (double)m * 32.0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > 0.95 * (double)fr)
+            return fail("packed payload of " + std::to_string((long long)(m * bps >> 20)) + " MiB: its device images need " +
+                        std::to_string((long long)(need / 1048576.0)) + " MiB of HBM, " + std::to_string((long long)(fr >> 20)) +
+                        " MiB are free (split the SNP rows over several calls)");
+    }
     DevBuf raw, didx;
-    if (raw.alloc((size_t)(m * bps))) return 1;
-    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m * bps), hipMemcpyHostToDevice));
+    const uint8_t *d_raw = packed;
+    if (!on_device) {
+        if (raw.alloc((size_t)(m * bps))) return 1;
+        JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m * bps), hipMemcpyHostToDevice));
+        d_raw = raw.as<uint8_t>();
+    }
     const int32_t *d_idx = nullptr;
     if (!sel.identity) {
         if (didx.alloc(sizeof(int32_t) * sel.idx.size())) return 1;
         JX_HIP(hipMemcpy(didx.p, sel.idx.data(), sizeof(int32_t) * sel.idx.size(), hipMemcpyHostToDevice));
         d_idx = didx.as<int32_t>();
     }
-    const int nt = num_tiles(sel.n);
     if (p32.alloc((size_t)nt * (size_t)m * 32)) return 1;
-    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m, d_idx, sel.n, nullptr, m, p32.as<uint8_t>(), nullptr))
+    if (jxg_repack_p32(d_raw, bps, n_samples, m, d_idx, sel.n, nullptr, m, p32.as<uint8_t>(), nullptr))
         return 1;
     JX_HIP(hipDeviceSynchronize());
     return 0;
@@ -180,9 +205,11 @@ extern "C" int jx_version(void) { return 100; }
 // then fails with "interrupted by the progress callback".  every <= 0: once per internal block.
 typedef int (*jx_progress_fn)(int64_t done, int64_t total, void *user);
 namespace {
-jx_progress_fn g_progress = nullptr;
-void *g_progress_user = nullptr;
-int64_t g_progress_every = 0;
+// per calling thread: ctypes runs a call on the Python thread that made it and releases the GIL, so two concurrent
+// scans from different threads each see their own hook
+thread_local jx_progress_fn g_progress = nullptr;
+thread_local void *g_progress_user = nullptr;
+thread_local int64_t g_progress_every = 0;
 struct ProgressTicker {
     int64_t last = 0;
     // 0 = go on, 1 = the callback asked to stop
@@ -976,8 +1003,12 @@ inline char *put_str(char *o, const char *t) {
 inline char *put_fixed4(char *o, double v) {
     if (v != v) return put_str(o, "NaN");
     if (std::isinf(v)) return put_str(o, v > 0 ? "inf" : "-inf");
-    return o + snprintf(o, 64, "%.4f", v);
+    // Rust's {:.4} prints every digit of a huge finite value (up to 309 before the point): the caller reserves
+    // kRowReserve bytes per row, enough for four such fields
+    const int len = snprintf(o, 336, "%.4f", v);
+    return o + (len < 336 ? len : 335);
 }
+constexpr size_t kRowReserve = 2048;   // 4 fixed-point fields of <= 336 bytes + 5 exponent fields + tabs
 inline char *put_exp(char *o, double v, int prec) {
     if (v != v) return put_str(o, "NaN");
     if (std::isinf(v)) return put_str(o, v > 0 ? "inf" : "-inf");
@@ -1028,14 +1059,14 @@ extern "C" int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob
     const double min_pos = 2.2250738585072014e-308;
     for (int64_t i = 0; i < rows; ++i) {
         const int64_t plen = prefix_off[i + 1] - prefix_off[i];
-        if (used + (size_t)plen + 512 > buf.size()) {
+        if (used + (size_t)plen + kRowReserve > buf.size()) {
             if (fwrite(buf.data(), 1, used, fh) != used) {
                 fclose(fh);
                 fail(std::string("write to ") + path + " failed");
                 return -1;
             }
             used = 0;
-            if ((size_t)plen + 512 > buf.size()) buf.resize((size_t)plen + 1024);
+            if ((size_t)plen + kRowReserve > buf.size()) buf.resize((size_t)plen + 2 * kRowReserve);
         }
         char *o = buf.data() + used;
         memcpy(o, prefix_blob + prefix_off[i], (size_t)plen);

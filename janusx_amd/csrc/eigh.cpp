@@ -53,6 +53,11 @@ int launch_gather_cols_range(const double *src, const int *d_perm, int n, int co
 struct EighGather {
     int (*gather)(void *) = nullptr;
     void *user = nullptr;
+    // optional: agree(user, checksum) -> 1 when every rank reports the same checksum of its replicated intermediate
+    // results (eigenvalues of T, the divide and conquer's permutation, a row of its eigenvector matrix), 0 when they
+    // differ, < 0 on failure
+    int (*agree)(void *, uint64_t) = nullptr;
+    void *agree_user = nullptr;
 };
 static EighGather g_gather;
 constexpr int kRocsolverStedcMaxN = 46340;   // n^2 < 2^31: rocSOLVER 7.2 dstedc faults above (measured at n = 50000)
@@ -64,6 +69,8 @@ static rocblas_handle get_handle() {
     std::lock_guard<std::mutex> lk(g_handle_mu);
     if (!g_handle) {
         if (rocblas_create_handle(&g_handle) != rocblas_status_success) g_handle = nullptr;
+        // replicas of a multi-rank decomposition must agree bit for bit: no atomics-based split-K inside rocBLAS
+        if (g_handle) rocblas_set_atomics_mode(g_handle, rocblas_atomics_not_allowed);
     }
     return g_handle;
 }
@@ -88,6 +95,28 @@ extern "C" int jxg_eigh_set_gather(int (*gather)(void *), void *user) {
     g_gather.gather = gather;
     g_gather.user = user;
     return 0;
+}
+
+// Agreement check in front of the sharded back-transformations: the ranks' replicated results (tridiagonal eigenvalues,
+// divide-and-conquer permutation, first row of its eigenvector matrix) are hashed and `agree(user, checksum)` has to say
+// whether every rank holds the same value (e.g. a MIN and a MAX all-reduce).  When they differ every rank takes the
+// unsharded back-transformation (its own, self-consistent result) instead of mixing rows of different bases.  NULL: off.
+extern "C" int jxg_eigh_set_agree(int (*agree)(void *, uint64_t), void *user) {
+    g_gather.agree = agree;
+    g_gather.agree_user = user;
+    return 0;
+}
+
+static int g_last_dist_agree = -1;   // -1 not checked, 1 replicas agreed, 0 they differed (unsharded fallback taken)
+extern "C" int jxg_eigh_last_dist_agree(void) { return g_last_dist_agree; }
+
+static uint64_t fnv1a(const void *p, size_t bytes, uint64_t h) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
 }
 
 // d_a: (n,n) symmetric, f64. On return row j of d_a (row-major) = eigenvector j (= column j of the
@@ -209,10 +238,19 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             int habort = 0;
             JX_HIP(hipMemcpyAsync(&habort, ts_ctrl.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
-            if (habort != 0) return fail("jxg_eigh_f64: the bulge-chasing kernel gave up waiting for a neighbour sweep");
-            JX_HIP(hipEventRecord(ev[2], st));
-            if (stage_done("sb2st")) return 1;
-        } else {
+            if (habort != 0) {
+                // a sweep's bounded spin on its predecessor expired (the persistent launch assumes its workgroups are
+                // co-resident: a shared device can break that): restore the input from the copy and reduce it in one stage
+                if (trace) fprintf(stderr, "[jxgpu eigh n=%d] bulge chasing gave up waiting for a neighbour sweep: one-stage fallback\n", n);
+                JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+                ts_tq.release();
+                twostage = false;
+            } else {
+                JX_HIP(hipEventRecord(ev[2], st));
+                if (stage_done("sb2st")) return 1;
+            }
+        }
+        if (!twostage) {
             if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
             if (stage_done("sytrd")) return 1;
         }
@@ -244,7 +282,23 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (twostage) {
             if (!ts_tq.p && ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
-            if (dist_two && split) {
+            bool replicas_agree = true;
+            g_last_dist_agree = -1;
+            if (dist_two && split && g_gather.agree) {
+                std::vector<double> hw((size_t)2 * n);
+                JX_HIP(hipMemcpyAsync(hw.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                JX_HIP(hipMemcpyAsync(hw.data() + n, c.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                JX_HIP(hipStreamSynchronize(st));
+                uint64_t cs = fnv1a(hw.data(), sizeof(double) * hw.size(), 1469598103934665603ull);
+                cs = fnv1a(perm.data(), sizeof(int) * perm.size(), cs);
+                const int ag = g_gather.agree(g_gather.agree_user, cs);
+                if (ag < 0) return fail("jxg_eigh_f64: the agreement callback failed");
+                replicas_agree = ag != 0;
+                g_last_dist_agree = replicas_agree ? 1 : 0;
+                if (!replicas_agree && trace)
+                    fprintf(stderr, "[jxgpu eigh n=%d] the ranks' replicated results differ: unsharded back-transformation\n", n);
+            }
+            if (dist_two && split && replicas_agree) {
                 // this rank's eigenvectors only: columns perm[r0 .. r1) of C, gathered into a contiguous (n, nr) block
                 const int r0 = (int)((int64_t)n * drank / dworld), r1 = (int)((int64_t)n * (drank + 1) / dworld);
                 const int nr = r1 - r0;

@@ -488,6 +488,7 @@ static int lane_acquire(Lane &l) {
     }
     JX_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
     if (rocblas_create_handle(&l.h) != rocblas_status_success) return fail("rocblas_create_handle failed");
+    rocblas_set_atomics_mode(l.h, rocblas_atomics_not_allowed);   // bit-identical merges on every rank (eigh.cpp)
     if (rocblas_set_stream(l.h, l.st) != rocblas_status_success) return fail("rocblas_set_stream failed");
     return 0;
 }

@@ -30,6 +30,46 @@ def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def _is_device_tensor(a):
+    """A torch CUDA tensor (a payload that is already resident in HBM)."""
+    return hasattr(a, "is_cuda") and bool(getattr(a, "is_cuda"))
+
+
+def _payload(packed, n_samples):
+    """Packed 2-bit payload (m, ceil(n / 4)) uint8 as (object that owns the memory, pointer, m): a C-contiguous numpy
+    array on the host, or a torch CUDA tensor used in place (extension of the reference's numpy-only interface: a panel
+    that already lives in HBM is never staged through the host)."""
+    if _is_device_tensor(packed):
+        import torch
+        if packed.dtype != torch.uint8 or packed.dim() != 2:
+            raise RuntimeError("packed must be 2D uint8 (m, bytes_per_snp)")
+        pk = packed.contiguous()
+        ptr, shape = C.c_void_p(pk.data_ptr()), tuple(pk.shape)
+    else:
+        pk = _c(packed, np.uint8)
+        if pk.ndim != 2:
+            raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+        _guard_host_payload(pk.nbytes, "packed")
+        ptr, shape = _p(pk), pk.shape
+    if shape[1] != (int(n_samples) + 3) // 4:
+        raise RuntimeError(f"packed second dimension mismatch: got {shape[1]}, expected {(int(n_samples) + 3) // 4}")
+    return pk, ptr, int(shape[0])
+
+
+def _guard_host_payload(nbytes, what):
+    """A host array handed to the device layer is copied once more on its way (contiguous copy / staging): refuse clearly
+    when that cannot fit instead of driving the machine out of memory (an n = 200 000 x m = 1 000 000 payload is 50 GB)."""
+    try:
+        import psutil
+        avail = int(psutil.virtual_memory().available)
+    except Exception:   # noqa: BLE001 - no psutil: no guard
+        return
+    if int(nbytes) > (1 << 30) and int(nbytes) > avail // 2:
+        raise RuntimeError(f"{what}: a host array of {int(nbytes) / 2**30:.1f} GiB with {avail / 2**30:.1f} GiB of host memory "
+                           "available cannot be staged safely; pass the payload as a device (torch CUDA uint8) tensor or "
+                           "split the SNP rows over several calls")
+
+
 def _opt_idx(a):
     if a is None:
         return None, 0
@@ -149,19 +189,16 @@ def _normalize_spgrm_path(prefix):
 
 def _spgrm_packed(packed, n_samples, row_flip, row_maf, out_prefix, sample_indices, method, threshold, abs_threshold,
                   stream_denominator):
-    pk = _c(packed, np.uint8)
-    if pk.ndim != 2:
-        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
     n_samples = int(n_samples)
-    if pk.shape[1] != (n_samples + 3) // 4:
-        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1]}, expected {(n_samples + 3) // 4}")
+    pk, pk_ptr, pk_rows = _payload(packed, n_samples)
     flip = np.ascontiguousarray(np.asarray(row_flip).astype(np.uint8)).ravel()
     maf = _c(row_maf, np.float32).ravel()
     m = int(flip.shape[0])
     if m and maf.shape[0] != m:
         raise RuntimeError(f"Sparse GRM row_maf length mismatch: got {maf.shape[0]}, expected {m}")
-    if m and pk.shape[0] != m:
-        raise RuntimeError(f"Sparse GRM packed length mismatch: got {pk.size}, expected {m * pk.shape[1]}")
+    if m and pk_rows != m:
+        raise RuntimeError(f"Sparse GRM packed length mismatch: got {pk_rows * ((n_samples + 3) // 4)}, expected "
+                           f"{m * ((n_samples + 3) // 4)}")
     idx, n_sel = _opt_idx(sample_indices)
     if sample_indices is not None and n_sel == 0:
         raise RuntimeError("Sparse GRM sample_indices must not be empty")
@@ -169,7 +206,7 @@ def _spgrm_packed(packed, n_samples, row_flip, row_maf, out_prefix, sample_indic
     if not out_path:
         raise RuntimeError("Sparse GRM output prefix must not be empty")
     out_n, out_nnz = C.c_int64(0), C.c_int64(0)
-    check(lib().jx_spgrm_packed_to_jxgrm(_p(pk), m, n_samples, _p(flip), _p(maf), _p(idx) if idx is not None else None,
+    check(lib().jx_spgrm_packed_to_jxgrm(pk_ptr, m, n_samples, _p(flip), _p(maf), _p(idx) if idx is not None else None,
                                          n_sel, int(method), float(threshold), int(bool(abs_threshold)),
                                          int(bool(stream_denominator)), out_path.encode(), C.byref(out_n),
                                          C.byref(out_nnz)))
@@ -839,11 +876,8 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lam = 10.0 ** float(log10_lambda)
     if not model.factorizable(lam):
         raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
-    pk = _c(packed, np.uint8)
     n_full = int(packed_n_samples)
-    if pk.ndim != 2 or pk.shape[1] != (n_full + 3) // 4:
-        raise RuntimeError(f"packed second dimension mismatch: got {pk.shape[1] if pk.ndim == 2 else pk.shape}, "
-                           f"expected {(n_full + 3) // 4}")
+    pk, _pk_ptr, _pk_rows = _payload(packed, n_full)
     maf32 = _c(maf, np.float32).ravel()
     flip = np.asarray(row_flip).astype(bool).ravel()
     if maf32.shape[0] != pk.shape[0] or flip.shape[0] != pk.shape[0]:
@@ -858,7 +892,6 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 2] = 1.0
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
     dev = model.s_dev.device
-    pk_w = pk if pk.flags.writeable else pk.copy()          # torch.from_numpy wants a writable array (memmapped payloads are not)
     # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
     # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy
     d = model.s + lam
@@ -871,7 +904,10 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
         raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)   # noqa: E731
     fv_state = (f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy)
-    packed_t = torch.from_numpy(pk_w).to(dev)
+    if _is_device_tensor(pk):
+        packed_t = pk.to(dev)
+    else:   # torch.from_numpy wants a writable array (memmapped payloads are not)
+        packed_t = torch.from_numpy(pk if pk.flags.writeable else pk.copy()).to(dev)
     if model.blocks is not None:
         if panel_idx is None:
             panel_idx = np.arange(n_full, dtype=np.int64)
@@ -986,7 +1022,15 @@ def rust_eigh_from_array_f64(a, threads=0, driver=None, jobz="V", require_lapack
     want = str(jobz).upper() != "N"
     evecs = np.empty((n, n), dtype=np.float64) if want else None
     check(lib().jx_eigh_f64(_p(a), n, float(diag_shift), _p(evals), _p(evecs)))
-    return (evals, evecs, "rocblas", "rocsolver_dsyevd", n, 0, 0, 0, True, time.perf_counter() - t0)
+    # which solver ran (csrc/eigh.cpp): rocSOLVER below n = 256 or on request, else the own one- or two-stage reduction
+    # + own divide and conquer (jxg_last_kernel_ms(10) = 1 after a two-stage decomposition)
+    if n < 256 or os.environ.get("JXGPU_EIGH", "") == "rocsolver":
+        evd = "rocsolver_dsyevd"
+    elif float(lib().jxg_last_kernel_ms(10)) > 0.5:
+        evd = "jxgpu_sy2sb_sb2st_stedc"
+    else:
+        evd = "jxgpu_sytrd_stedc"
+    return (evals, evecs, "rocblas", evd, n, 0, 0, 0, True, time.perf_counter() - t0)
 
 
 rust_eigh_from_array_f64_inplace = rust_eigh_from_array_f64
@@ -1225,11 +1269,10 @@ def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot,
 
 def bed_row_counts(packed, n_samples, sample_indices=None):
     """(m,3) int32 (missing, het, hom_alt) over the selected samples (src/io/gfreader.rs:1378-1395)."""
-    packed = _c(packed, np.uint8)
-    m = int(packed.shape[0])
+    _pk, pk_ptr, m = _payload(packed, n_samples)          # host array or device tensor
     idx, n_sel = _opt_idx(sample_indices)
     out = np.zeros((m, 3), dtype=np.int32)
-    check(lib().jx_row_counts(_p(packed), m, int(n_samples), _p(idx), n_sel, _p(out)))
+    check(lib().jx_row_counts(pk_ptr, m, int(n_samples), _p(idx), n_sel, _p(out)))
     return out
 
 

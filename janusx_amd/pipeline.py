@@ -132,6 +132,7 @@ def enable_distributed_eigh(min_n: int = 0):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_single):
         check(lib().jxg_eigh_set_dist(0, 1, None, None, None, 0, 0))
         check(lib().jxg_eigh_set_gather(None, None))
+        check(lib().jxg_eigh_set_agree(None, None))
         _DIST_EIGH.clear()
         return False
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -168,6 +169,28 @@ def enable_distributed_eigh(min_n: int = 0):
     gcb = C.CFUNCTYPE(C.c_int, C.c_void_p)(_gather)
     check(lib().jxg_eigh_set_gather(C.cast(gcb, C.c_void_p) if world > 1 else None, None))
 
+    def _agree(_user, checksum):
+        # the replicated stages must have produced the same bits on every rank before rows of different ranks are mixed:
+        # MIN and MAX of the 64-bit checksum (as two 32-bit halves in int64 lanes) over the ranks
+        try:
+            cs = int(checksum) & 0xFFFFFFFFFFFFFFFF
+            if os.environ.get("JXGPU_DIST_EIGH_TEST_DISAGREE", "") == str(rank):
+                cs ^= 1                                   # test hook: this rank pretends to hold different bits
+            v = torch.tensor([cs >> 32, cs & 0xFFFFFFFF], dtype=torch.int64)
+            lo, hi = v.clone(), v.clone()
+            if dist.get_backend() == "nccl":
+                lo, hi = lo.to(dev), hi.to(dev)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            return 1 if bool((lo == hi).all()) else 0
+        except Exception as e:   # noqa: BLE001 - reported through the C status
+            import sys
+            print(f"distributed eigh: agreement check failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            return -1
+
+    acb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)(_agree)
+    check(lib().jxg_eigh_set_agree(C.cast(acb, C.c_void_p) if world > 1 else None, None))
+
     def prepare(n):
         need = int(lib().jxg_eigh_dist_staging_doubles(int(n)))
         if state["staging"] is None or state["staging"].numel() != need:
@@ -175,7 +198,7 @@ def enable_distributed_eigh(min_n: int = 0):
             check(lib().jxg_eigh_set_dist(rank, world, C.cast(cb, C.c_void_p), None, _ptr(state["staging"]), need,
                                           int(min_n)))
 
-    _DIST_EIGH.update(cb=cb, gcb=gcb, state=state, prepare=prepare)
+    _DIST_EIGH.update(cb=cb, gcb=gcb, acb=acb, state=state, prepare=prepare)
     return True
 
 

@@ -509,6 +509,36 @@ def spd_cholesky_with_jitter(mat, label):
     raise RuntimeError(f"{label} is not SPD even after diagonal jitter")
 
 
+class SpdFactor:
+    """K + lambda I factorised once, with `solve` and `logdet`.  The reference holds a sparse supernodal LLT (faer 0.18.2,
+    src/math/cholesky.rs:776-1075); restated as a dense Cholesky for a dense K (what the reference's own tests compare
+    against, src/stats/spreml.rs:1205-1329) and, for a scipy.sparse K, as a sparse LU without pivoting of the same SPD matrix
+    (identical solve / log-determinant, O(nnz) memory: the checker of sample counts where no dense image fits the host)."""
+
+    def __init__(self, k, lam):
+        import scipy.sparse as sp
+        self.sparse = sp.issparse(k)
+        if self.sparse:
+            from scipy.sparse.linalg import splu
+            n = k.shape[0]
+            m = (k + lam * sp.identity(n, format="csc")).tocsc()
+            self.lu = splu(m, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+            piv = self.lu.U.diagonal()
+            if not (np.all(np.isfinite(piv)) and np.all(piv > 0.0)):
+                raise np.linalg.LinAlgError("K + lambda I is not positive definite")
+            self.logdet = float(np.log(piv).sum())
+        else:
+            n = np.asarray(k).shape[0]
+            self.lfac = np.linalg.cholesky(np.array(k, dtype=np.float64) + lam * np.eye(n))
+            self.logdet = 2.0 * float(np.log(np.diag(self.lfac)).sum())
+
+    def solve(self, b):
+        if self.sparse:
+            return self.lu.solve(np.ascontiguousarray(b, dtype=np.float64))
+        import scipy.linalg as sla
+        return sla.cho_solve((self.lfac, True), b)
+
+
 def spreml_evaluate(k_dense, x_design, y, log10_lambda, vp_fixed=None):
     """`evaluate_sparse_reml_at_lambda` (src/stats/spreml.rs:384-512) with the sparse LLT of K + lambda I restated as a
     dense Cholesky (the reference's own tests compare against exactly that, :1205-1262, 1264-1329).
@@ -522,14 +552,12 @@ def spreml_evaluate(k_dense, x_design, y, log10_lambda, vp_fixed=None):
     p = x_design.shape[1]
     if p == 0 or n <= p:
         raise RuntimeError(f"SPREML requires n > p, got n={n}, p={p}")
-    m = np.array(k_dense, dtype=np.float64) + lam * np.eye(n)
     try:
-        lfac = np.linalg.cholesky(m)
+        fac = SpdFactor(k_dense, lam)
     except np.linalg.LinAlgError:
         raise RuntimeError(f"sparse Cholesky of K + lambda I failed at lambda={lam}")
-    import scipy.linalg as sla
     rhs = np.concatenate([y[:, None], x_design], axis=1)
-    sol = sla.cho_solve((lfac, True), rhs)
+    sol = fac.solve(rhs)
     y_vinv, x_vinv = sol[:, 0], sol[:, 1:]
     y_vinv_y = float(y @ y_vinv)
     xt_vinv_y = x_design.T @ y_vinv
@@ -540,7 +568,7 @@ def spreml_evaluate(k_dense, x_design, y, log10_lambda, vp_fixed=None):
     if not math.isfinite(ypy) or ypy <= 1e-30:
         raise RuntimeError(f"SPREML profiled residual quadratic form is invalid at lambda={lam}: yPy={ypy}")
     df = float(n - p)
-    log_det_m = 2.0 * float(np.log(np.diag(lfac)).sum())
+    log_det_m = fac.logdet
     log_det_x = 2.0 * float(np.log(np.diag(cx)).sum())
     if vp_fixed is None:
         sigma_g2 = ypy / df
@@ -694,11 +722,10 @@ def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip
     `decode_mean_imputed_additive_packed_block_rows_f32`, src/math/bedmath.rs:940-1010), score = f32 GEMV g . f32(Py),
     z = V^-1 g in f64, g'Pg = max(g'z - c'A^-1 c, 0) with c = X'z, then `splmm_wald_from_score_denom`;
     failed rows are (NaN, NaN, 1).  -> (m, 3) f64."""
-    import scipy.linalg as sla
     y = np.asarray(y, dtype=np.float64)
     n, p = x_design.shape
-    lfac = np.linalg.cholesky(np.asarray(k_dense, dtype=np.float64) + lam * np.eye(n))
-    sol = sla.cho_solve((lfac, True), np.concatenate([y[:, None], x_design], axis=1))
+    fac = SpdFactor(k_dense, lam)                      # dense Cholesky, or a sparse factor for a scipy.sparse K
+    sol = fac.solve(np.concatenate([y[:, None], x_design], axis=1))
     xt_vinv_x = x_design.T @ sol[:, 1:]
     cx = spd_cholesky_with_jitter(xt_vinv_x, "SparseLMM XtWX")
     beta0 = cholesky_solve(cx, x_design.T @ sol[:, 0])
@@ -720,7 +747,7 @@ def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip
         g32 = lut[codes[r]]
         score = float(np.dot(g32, py32))                      # f32 GEMV output
         g = g32.astype(np.float64)
-        z = sla.cho_solve((lfac, True), g)
+        z = fac.solve(g)
         c = x_design.T @ z
         x_quad = float(c @ cholesky_solve(cx, c))
         res = splmm_wald_from_score_denom(score, max(float(g @ z) - x_quad, 0.0), sigma2)

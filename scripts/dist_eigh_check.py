@@ -53,9 +53,12 @@ def main():
     flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64)
     dist.all_reduce(flag)
     if rank == 0:
+        from janusx_amd._lib import lib
         tag = "DIST_EIGH_OK" if flag.item() == 0 else "DIST_EIGH_FAIL"
+        # agree: the replicas' checksum comparison in front of the sharded back-transformations of the two-stage path
+        # (-1 not run, 1 agreed, 0 differed -> unsharded fallback; JXGPU_DIST_EIGH_TEST_DISAGREE=<rank> forces a difference)
         print(f"{tag} n={n} world={world} eval_err={eval_err:.2e} resid={resid:.2e} orth={orth:.2e} "
-              f"replicas_identical={same}", flush=True)
+              f"replicas_identical={same} agree={int(lib().jxg_eigh_last_dist_agree())}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 0 else 1)
 

@@ -1,0 +1,91 @@
+"""BASELINE configs[4]-shaped `-splmm` run with the panel GENERATED ON THE DEVICE (run as its own process by
+tests/test_gpu_parity.py::test_c5_shaped_splmm_device_panel, so that the peak host RSS it reports is this run's alone).
+
+n samples in sibships of four, m SNPs; sparse GRM through the row-panel builder (`jxg_grm_accumulate_rows`, the accumulator of
+n = 200 000 does not fit HBM as a square), block-diagonal spectral route, SparseLMM exact scan.  No (m x n) or packed
+(m x n / 4) array ever exists on the host.  Checks a 150-SNP sample against the oracle's restatement of
+`exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) with a sparse factorisation of K + lambda I read back from the
+`.spgrm` file, and the sparse REML optimum against the oracle's evaluation at that lambda.  Prints one JSON line.
+
+    python tests/c5_shaped_driver.py N M [SAMPLE]
+"""
+import json
+import os
+import resource
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import bench
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import stats as st
+    from oracle import jx_oracle as O
+    import scipy.sparse as sp
+    n, m = int(sys.argv[1]), int(sys.argv[2])
+    n_pick = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+    dev = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    packed_t, dos = bench.family_panel_gpu(n, m, 4, 11, dev)
+    y = bench.make_phenotype(dos, n, 7, dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    counts = jxrs.bed_row_counts(packed_t, n)
+    keep, _miss, maf, _std = st.packed_prep_row_stats(counts, n, 0.02, 0.05, 0.0)
+    pk = packed_t if bool(keep.all()) else packed_t[torch.from_numpy(np.nonzero(keep)[0]).to(dev)]
+    del packed_t
+    maf_k = maf[keep]
+    flip = np.zeros(len(maf_k), dtype=bool)
+    res = {"n": n, "m": m, "m_kept": int(len(maf_k)), "gen_s": t_gen}
+    with tempfile.TemporaryDirectory() as td:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        path, nn, nnz = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, maf_k, os.path.join(td, "k"), None, 1, 0.05)
+        t1 = time.perf_counter()
+        out, l10, null = jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res.update(spgrm_s=t1 - t0, scan_s=t2 - t1, nnz=int(nnz), log10_lambda=float(l10),
+                   snps_per_s=len(maf_k) / (t2 - t0), route="block" if jxrs._sparse_block_route(n) else "dense")
+        # ---- checker: the oracle on the sparse GRM file (a sparse LU of K + lambda I is the reference's sparse LLT restated)
+        _n, cp, ri, va = O.read_sparse_grm_csc(path)
+    low = sp.csc_matrix((va, ri.astype(np.int64), cp.astype(np.int64)), shape=(n, n))
+    ksym = (low + sp.tril(low, -1).T).tocsc()
+    # structure: families of four -> every sample related to at most three others above the cut-off
+    per_col = np.diff(ksym.indptr)
+    res["max_relatives"] = int(per_col.max()) - 1
+    lam = 10.0 ** l10
+    x = np.ones((n, 1))
+    pick = np.sort(np.random.default_rng(0).choice(len(maf_k), n_pick, replace=False))
+    pk_small = pk[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    ref = O.splmm_exact_scan(ksym, lam, x, y, pk_small, n, maf_k[pick], flip[pick])
+    got = out[pick]
+    ok = ~np.isnan(ref[:, 0])
+    res["nan_pattern_equal"] = bool(np.array_equal(np.isnan(got[:, 0]), ~ok))
+    res["se_err"] = float(np.max(np.abs(got[ok, 1] - ref[ok, 1]) / ref[ok, 1]))
+    res["beta_err"] = float(np.max(np.abs(got[ok, 0] - ref[ok, 0]) / np.maximum(np.abs(ref[ok, 0]), ref[ok, 1])))
+    z2 = (ref[ok, 0] / ref[ok, 1]) ** 2
+    res["p_err"] = float(max(np.max(np.abs(got[ok, 2] - ref[ok, 2]) / ref[ok, 2] / np.maximum(1.0, z2)),
+                             np.max(np.abs(np.log10(got[ok, 2]) - np.log10(ref[ok, 2])) /
+                                    np.maximum(1.0, -np.log10(ref[ok, 2])))))
+    # sparse REML at the optimum the GPU path found: the oracle's evaluation (dense form per the reference's own test
+    # spreml.rs:1209-1329, here through the sparse factor) must give the same likelihood
+    ev = O.spreml_evaluate(ksym, x, y, l10)
+    # null 10-tuple: (lambda, sigma_g2, sigma_e2, ml, reml, log10_lambda, ...)
+    res["reml_err"] = float(abs(ev["reml"] - null[4]) / max(1.0, abs(ev["reml"])))
+    res["ml_err"] = float(abs(ev["ml"] - null[3]) / max(1.0, abs(ev["ml"])))
+    res["all_rows_finite_p"] = bool(np.all((out[:, 2] > 0) & (out[:, 2] <= 1)))
+    res["peak_hbm_gib"] = torch.cuda.max_memory_allocated() / 2**30
+    res["host_maxrss_gib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -225,6 +225,8 @@ def test_native_tsv_writer_matches_the_row_format(tmp_path):
     stats[9, 0] = -0.0
     stats[10, 2] = np.inf
     stats[11, 0] = np.inf
+    stats[12, :2] = [1e300, 1e300]      # degenerate but finite: Rust's {:.4} prints all 301 digits (no truncation, no overflow)
+    stats[13, :2] = [-1.7976931348623157e308, 1.7976931348623157e308]
     chrom = [str(1 + i % 22) for i in range(n)]
     pos = list(range(n))
     snp = ["." if i % 7 == 0 else ("" if i % 11 == 0 else f"rs{i}") for i in range(n)]
@@ -301,3 +303,16 @@ def test_cv_splits_follow_the_reference_kfold():
         assert np.array_equal(np.sort(np.concatenate([te, tr])), np.arange(13)) and np.all(np.diff(tr) > 0)
     with pytest.raises(ValueError, match="cannot exceed"):
         cli.build_cv_splits(3, 5)
+
+
+def test_host_payload_guard_refuses_what_cannot_be_staged(monkeypatch):
+    """A host payload that cannot be staged safely (BASELINE configs[4] is 50 GB packed; a round-2 attempt took the GPU box
+    down) is refused with a clear error before anything is copied; small arrays and device tensors pass."""
+    import types
+    from janusx_amd import janusx as jxrs
+    import psutil
+    monkeypatch.setattr(psutil, "virtual_memory", lambda: types.SimpleNamespace(available=8 << 30))
+    jxrs._guard_host_payload(3 << 30, "packed")                   # fits twice
+    with pytest.raises(RuntimeError, match="device .torch CUDA uint8. tensor"):
+        jxrs._guard_host_payload(5 << 30, "packed")
+    jxrs._guard_host_payload(1 << 20, "packed")                   # small arrays are never refused

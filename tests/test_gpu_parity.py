@@ -694,10 +694,80 @@ def test_full_size_c2_properties(oracle, oracle_c, missing):
     _full_size_properties(oracle, oracle_c, 5000, 50000, missing, 12000)
 
 
-def test_full_size_c3_properties(oracle, oracle_c):
+@pytest.mark.parametrize("missing", [0.0, 0.01])
+def test_full_size_c3_properties(oracle, oracle_c, missing):
     """BASELINE configs[2] at full size (n = 20 000, m = 200 000, `-lmm`): the configuration `bench.py` times at N = 1;
-    reaches the code paths only this size reaches (scan form beyond the LDS-resident limit, multi-panel eigensolver)."""
-    _full_size_properties(oracle, oracle_c, 20000, 200000, 0.0, 12000)
+    reaches the code paths only this size reaches (scan form beyond the LDS-resident limit, multi-panel eigensolver).
+    With 1 % missing calls every SNP takes the fp16 hi/lo three-product path of the GRM and the rotation at this n."""
+    _full_size_properties(oracle, oracle_c, 20000, 200000, missing, 12000)
+
+
+def test_full_size_c4_properties(oracle, oracle_c):
+    """BASELINE configs[3] (n = 50 000, m = 500 000, `-lmm`) on ONE GPU at full size: the >20 480-column slab plan of the Q2
+    back-transformation, its image splitting over several launches, the 2^20-SNP chunks of the exact GRM and the own divide
+    and conquer beyond n = 46 340 are only reached here.  Same size-independent properties + 150-SNP oracle sample."""
+    import torch
+    free, _tot = torch.cuda.mem_get_info()
+    if free < 200 * 2**30:
+        pytest.skip("needs ~200 GiB of free HBM (MI355X: 288 GB)")
+    _full_size_properties(oracle, oracle_c, 50000, 500000, 0.0, 12000)
+    torch.cuda.empty_cache()
+
+
+def test_c5_shaped_splmm_device_panel():
+    """BASELINE configs[4] shape (`-splmm`, n = 200 000) with the panel generated ON THE DEVICE (tests/c5_shaped_driver.py in
+    its own process): families of four, m = 200 000 SNPs, sparse GRM through the row-panel builder
+    (`jxg_grm_accumulate_rows`), block-diagonal spectral route, exact scan; 150-SNP sample against the oracle's restatement
+    of `exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) with a sparse factor of K + lambda I, sparse REML optimum
+    against the oracle's evaluation; no (m x n) host array: peak host RSS of the whole run < 8 GiB."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "c5_shaped_driver.py"), "200000", "200000", "150"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    _MAXIMA["c5_shaped"] = [d["beta_err"], d["se_err"], 0.0, d["p_err"], d["p_err"]]
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        json.dump(d, open(os.path.join(root, "gpurun_out", "c5_shaped.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert d["route"] == "block" and d["m_kept"] > 190000 and d["max_relatives"] <= 3
+    assert d["nan_pattern_equal"] and d["all_rows_finite_p"]
+    assert max(d["beta_err"], d["se_err"], d["p_err"]) < TOL, d
+    assert d["reml_err"] < 1e-9 and d["ml_err"] < 1e-9, d
+    assert d["host_maxrss_gib"] < 8.0, d
+
+
+def test_device_resident_payload_entry_points(oracle, tmp_path):
+    """The host-layer entry points take a payload that already lives in HBM (torch CUDA tensor) in place: same counts, same
+    sparse GRM file bytes and the same scan table as with the numpy array; a host array too large to stage is refused
+    with a clear error instead of an out-of-memory kill."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    n, m = 700, 900
+    packed, g = _related_panel(n, m, 5, 0.01)
+    y = bed.synth_phenotype(g, n_causal=10, pve=0.5, seed=3)
+    pt = torch.from_numpy(packed).cuda()
+    c_h, c_d = jxrs.bed_row_counts(packed, n), jxrs.bed_row_counts(pt, n)
+    assert np.array_equal(c_h, c_d)
+    from janusx_amd import stats as st
+    keep, _miss, maf, _std = st.packed_prep_row_stats(c_h, n, 0.02, 0.05, 0.0)
+    rows = np.nonzero(keep)[0]
+    pk_h = np.ascontiguousarray(packed[rows])
+    pk_d = pt[torch.from_numpy(rows).cuda()]
+    flip = np.zeros(len(rows), dtype=bool)
+    a = jxrs.spgrm_packed_to_jxgrm(pk_h, n, flip, maf[rows], str(tmp_path / "a"), None, 1, 0.05)
+    b = jxrs.spgrm_packed_to_jxgrm(pk_d, n, flip, maf[rows], str(tmp_path / "b"), None, 1, 0.05)
+    assert a[1:] == b[1:] and open(a[0], "rb").read() == open(b[0], "rb").read()
+    o_h = jxrs.splmm_exact_scan_from_jxgrm(a[0], y, pk_h, n, maf[rows], flip)
+    o_d = jxrs.splmm_exact_scan_from_jxgrm(a[0], y, pk_d, n, maf[rows], flip)
+    assert np.array_equal(o_h[0], o_d[0], equal_nan=True) and o_h[1] == o_d[1]
+    with pytest.raises(RuntimeError, match="second dimension"):
+        jxrs.bed_row_counts(pt[:, :-1], n)
 
 
 def test_eigh_invariants_beyond_int32_elements():
@@ -1463,6 +1533,13 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env2, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "replicas_identical=True" in out.stdout
+    assert "agree=1" in out.stdout        # the replicas' checksums were compared (and matched) before rows were mixed
+    # a rank whose replicated results differ (forced through the test hook): every rank must notice and back-transform
+    # all its eigenvectors itself instead of mixing rows of different bases -- still a correct decomposition everywhere
+    env3 = dict(env2, JXGPU_DIST_EIGH_TEST_DISAGREE="1")
+    out = subprocess.run(cmd, env=env3, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "agree=0" in out.stdout
 
 
 @pytest.mark.gpu

@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the two extra legs of the default one-GPU run (1 %% missing calls; BASELINE configs[3] on one GPU)")
     args = ap.parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env != args.gpus:
@@ -290,124 +292,146 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    n = args.n
-    # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
-    # the ranks and summed by one all-reduce per column (JXGPU_DIST_EIGH=0 keeps every rank on the whole matrix)
-    eigh_min_n = int(os.environ.get("JXGPU_DIST_EIGH_MIN_N", "16384"))
-    eigh_ranks = world > 1 or (distributed and os.environ.get("JXGPU_DIST_EIGH_FORCE", "0") != "0")
-    eigh_sharded = bool(eigh_ranks and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
-                        pl.enable_distributed_eigh(eigh_min_n))
-    m = args.m * world if args.scaling == "weak" else args.m   # panel width of the whole job
-    # SNP shard of this rank (contiguous range)
-    lo = (m * rank) // world
-    hi = (m * (rank + 1)) // world
-    packed, dos_head = synth_panel_gpu(n, hi - lo, args.seed, dev, m_offset=lo, missing_rate=args.missing)
-    if rank == 0:
-        y = make_phenotype(dos_head, n, args.seed, dev)
-        y_t = torch.from_numpy(y).to(dev)
-    else:
-        y_t = torch.empty(n, dtype=torch.float64, device=dev)
-    if distributed:
-        dist.broadcast(y_t, 0)
-    y = y_t.cpu().numpy()
-    x = np.ones((n, 1))
-
-    kern = {"grm_ms": 0.0, "rot_ms": 0.0, "scan_ms": 0.0, "grm_flops": 0.0, "rot_flops": 0.0, "scan_bytes": 0.0,
-            "launches": 0}
-    stage = {}
-
-    def one_step(record):
-        t = {}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        panel = pl.Panel(packed, n)
-        counts = panel.counts()
-        gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, 1, 0.02, 0.05, 0.0)
-        grows = np.nonzero(gkeep)[0]
-        glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
-        denom = torch.tensor([float(np.sum(var[grows])), float(len(grows))], dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        acc = pl.grm_accumulate(panel, grows, glut)
-        grm_ms = lib().jxg_last_kernel_ms(0)
-        if distributed:
-            jd.allreduce_grm_accumulator_(acc)     # f64 partial GRMs summed over xGMI (RCCL): lower-triangle tiles only
-            jd.allreduce_sum_(denom)
-        k32 = pl.grm_finalize(acc, n, float(denom[0]), torch.float32)
-        del acc
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        s, ut64 = pl.eigh_from_grm(k32, 1e-6)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
-        two_stage = lib().jxg_last_kernel_ms(10) > 0.5        # which reduction jxg_eigh_f64 took (two-stage from n = 10000)
-        q2_ms, q2_gflop = lib().jxg_last_kernel_ms(4), lib().jxg_last_kernel_ms(5)
-        eig_st = [lib().jxg_last_kernel_ms(i) for i in (6, 7, 8, 9)]
-        model = pl.SpectralModel(s, ut64, x, y)
-        del ut64
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        keep, af, miss = st.gwas_scan_row_stats(counts, n, 0.02, 0.05, 1.0)
-        rows = np.nonzero(keep)[0]
-        lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
-        tm = pl.StageTimes()
-        out = pl.scan_rows(panel, model, rows, lut, args.mode, max_iter=30, tol=1e-2, times=tm,
-                           return_evals=(args.mode == "lmm"))
-        if args.mode == "lmm":
-            out, evals = out
-            n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
+    def run_leg(n, m_arg, missing, steps, warmup):
+        """One timed configuration: synthetic panel resident in HBM, `warmup` untimed + `steps` timed passes of the whole
+        hot path.  -> dict(elapsed, kept_total, kern, stage, null, packed, y, x, eigh_sharded, m)."""
+        # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
+        # the ranks and summed by one all-reduce per column (JXGPU_DIST_EIGH=0 keeps every rank on the whole matrix)
+        eigh_min_n = int(os.environ.get("JXGPU_DIST_EIGH_MIN_N", "16384"))
+        eigh_ranks = world > 1 or (distributed and os.environ.get("JXGPU_DIST_EIGH_FORCE", "0") != "0")
+        eigh_sharded = bool(eigh_ranks and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
+                            pl.enable_distributed_eigh(eigh_min_n))
+        m = m_arg * world if args.scaling == "weak" else m_arg   # panel width of the whole job
+        # SNP shard of this rank (contiguous range)
+        lo = (m * rank) // world
+        hi = (m * (rank + 1)) // world
+        packed, dos_head = synth_panel_gpu(n, hi - lo, args.seed, dev, m_offset=lo, missing_rate=missing)
+        if rank == 0:
+            y = make_phenotype(dos_head, n, args.seed, dev)
+            y_t = torch.from_numpy(y).to(dev)
         else:
-            n_evals = 0.0
-        torch.cuda.synchronize()
-        t5 = time.perf_counter()
-        if record:
-            for key, val in (("prep", t1 - t0), ("grm", t2 - t1), ("eigh", t3 - t2), ("null", t4 - t3),
-                             ("scan", t5 - t4), ("rotate_k", tm.t.get("rotate", 0.0)),
-                             ("assoc_k", tm.t.get("scan", 0.0))):
-                stage[key] = stage.get(key, 0.0) + val
-            kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
-            kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
-            kern["two_stage"] = two_stage
-            if two_stage:
-                kern["q2_ms"] = kern.get("q2_ms", 0.0) + q2_ms
-                kern["q2_gflop"] = kern.get("q2_gflop", 0.0) + q2_gflop
-                for name, v in zip(("eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform"), eig_st):
-                    stage[name] = stage.get(name, 0.0) + v * 1e-3
-                stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3
-            kern["grm_ms"] += grm_ms
-            kern["grm_flops"] += float(n) * (n + 1) * len(grows)
-            kern["rot_ms"] += tm.t.get("rotate", 0.0) * 1e3
-            kern["rot_flops"] += 2.0 * len(rows) * float(n) * n
-            kern["scan_ms"] += tm.t.get("scan", 0.0) * 1e3
-            kern["scan_bytes"] += 4.0 * n * len(rows)
-            dim = x.shape[1] + 1
-            # (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) flops per SNP, B = Brent evaluations
-            kern["scan_flops"] = kern.get("scan_flops", 0.0) + (n_evals + len(rows)) * n * (1.5 * dim * (dim + 1) + 5 * dim + 8)
-            kern["scan_evals"] = kern.get("scan_evals", 0.0) + n_evals / max(1, len(rows))
-            kern["launches"] += 1
-        return len(rows), len(grows), model.null, out
+            y_t = torch.empty(n, dtype=torch.float64, device=dev)
+        if distributed:
+            dist.broadcast(y_t, 0)
+        y = y_t.cpu().numpy()
+        x = np.ones((n, 1))
 
-    for _ in range(args.warmup):
-        one_step(False)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    kept = 0
-    for _ in range(args.steps):
-        kept, geff, null, out = one_step(True)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    kept_t = torch.tensor([float(kept)], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kept_t)
-    elapsed = float(el_t[0])
-    kept_total = float(kept_t[0])
+        kern = {"grm_ms": 0.0, "rot_ms": 0.0, "scan_ms": 0.0, "grm_flops": 0.0, "rot_flops": 0.0, "scan_bytes": 0.0,
+                "launches": 0}
+        stage = {}
+
+        def one_step(record):
+            t = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            panel = pl.Panel(packed, n)
+            counts = panel.counts()
+            gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, 1, 0.02, 0.05, 0.0)
+            grows = np.nonzero(gkeep)[0]
+            glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
+            denom = torch.tensor([float(np.sum(var[grows])), float(len(grows))], dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            acc = pl.grm_accumulate(panel, grows, glut)
+            grm_ms = lib().jxg_last_kernel_ms(0)
+            if distributed:
+                jd.allreduce_grm_accumulator_(acc)     # f64 partial GRMs summed over xGMI (RCCL): lower-triangle tiles only
+                jd.allreduce_sum_(denom)
+            k32 = pl.grm_finalize(acc, n, float(denom[0]), torch.float32)
+            del acc
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            s, ut64 = pl.eigh_from_grm(k32, 1e-6)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
+            two_stage = lib().jxg_last_kernel_ms(10) > 0.5        # which reduction jxg_eigh_f64 took (two-stage from n = 10000)
+            q2_ms, q2_gflop = lib().jxg_last_kernel_ms(4), lib().jxg_last_kernel_ms(5)
+            eig_st = [lib().jxg_last_kernel_ms(i) for i in (6, 7, 8, 9)]
+            model = pl.SpectralModel(s, ut64, x, y)
+            del ut64
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            keep, af, miss = st.gwas_scan_row_stats(counts, n, 0.02, 0.05, 1.0)
+            rows = np.nonzero(keep)[0]
+            lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
+            tm = pl.StageTimes()
+            out = pl.scan_rows(panel, model, rows, lut, args.mode, max_iter=30, tol=1e-2, times=tm,
+                               return_evals=(args.mode == "lmm"))
+            if args.mode == "lmm":
+                out, evals = out
+                n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
+            else:
+                n_evals = 0.0
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            if record:
+                for key, val in (("prep", t1 - t0), ("grm", t2 - t1), ("eigh", t3 - t2), ("null", t4 - t3),
+                                 ("scan", t5 - t4), ("rotate_k", tm.t.get("rotate", 0.0)),
+                                 ("assoc_k", tm.t.get("scan", 0.0))):
+                    stage[key] = stage.get(key, 0.0) + val
+                kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
+                kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
+                kern["two_stage"] = two_stage
+                if two_stage:
+                    kern["q2_ms"] = kern.get("q2_ms", 0.0) + q2_ms
+                    kern["q2_gflop"] = kern.get("q2_gflop", 0.0) + q2_gflop
+                    for name, v in zip(("eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform"), eig_st):
+                        stage[name] = stage.get(name, 0.0) + v * 1e-3
+                    stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3
+                kern["grm_ms"] += grm_ms
+                kern["grm_flops"] += float(n) * (n + 1) * len(grows)
+                kern["rot_ms"] += tm.t.get("rotate", 0.0) * 1e3
+                kern["rot_flops"] += 2.0 * len(rows) * float(n) * n
+                kern["scan_ms"] += tm.t.get("scan", 0.0) * 1e3
+                kern["scan_bytes"] += 4.0 * n * len(rows)
+                dim = x.shape[1] + 1
+                # SURVEY 8(d): (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) flops per SNP, B = Brent evaluations
+                kern["scan_flops"] = kern.get("scan_flops", 0.0) + (n_evals + len(rows)) * n * (1.5 * dim * (dim + 1) + 5 * dim + 8)
+                kern["scan_evals"] = kern.get("scan_evals", 0.0) + n_evals / max(1, len(rows))
+                kern["launches"] += 1
+            return len(rows), len(grows), model.null, out
+
+        for _ in range(warmup):
+            one_step(False)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        kept = 0
+        null = None
+        for _ in range(steps):
+            kept, geff, null, out = one_step(True)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        kept_t = torch.tensor([float(kept)], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(kept_t)
+        return dict(elapsed=float(el_t[0]), kept_total=float(kept_t[0]), kern=kern, stage=stage, null=null, packed=packed,
+                    y=y, x=x, eigh_sharded=eigh_sharded, m=m)
+
+    def leg_summary(leg, n, steps):
+        """Condensed record of an extra leg: whole-step rate, stage times and the two f16-MFMA kernels against the dense peak."""
+        k = leg["kern"]
+        grm_tf = k["grm_flops"] / max(k["grm_ms"], 1e-9) / 1e9
+        rot_tf = k["rot_flops"] / max(k["rot_ms"], 1e-9) / 1e9
+        L = max(1, k["launches"])
+        return {"value": leg["kept_total"] * steps / leg["elapsed"], "unit": "SNPs/s", "steps": steps,
+                "ms_per_step": leg["elapsed"] / steps * 1e3, "m_kept": int(leg["kept_total"]),
+                "stages_ms_per_step": {kk: v / steps * 1e3 for kk, v in leg["stage"].items()},
+                "roofline_grm": {"bound": "mfma", "achieved": grm_tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": grm_tf / MFMA_F16_PEAK_TFLOPS, "avg_launch_ms": k["grm_ms"] / L},
+                "roofline_rotate": {"bound": "mfma", "achieved": rot_tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": rot_tf / MFMA_F16_PEAK_TFLOPS, "ms_per_step": k["rot_ms"] / L}}
+
+    n = args.n
+    main_leg = run_leg(n, args.m, args.missing, args.steps, args.warmup)
+    elapsed, kept_total, kern, stage, null = (main_leg[k] for k in ("elapsed", "kept_total", "kern", "stage", "null"))
+    packed, y, x, eigh_sharded, m = (main_leg[k] for k in ("packed", "y", "x", "eigh_sharded", "m"))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -528,8 +552,10 @@ def main():
                                 "achieved": rot_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
                                 "note": "the fixed-lambda scan has no kernel of its own: the rotation kernel reduces every "
-                                        "128 x 128 tile of G~ against w / Py~ / WX~ in its epilogue (p + 2 f64 atomics per SNP "
-                                        "and column tile), G~ is never written; the finish kernel reads (p + 2) x 8 B per SNP. "
+                                        "128 x 128 tile of G~ against w / Py~ / WX~ in its epilogue and stores the p + 2 partial "
+                                        "sums of every SNP in its column tile's slot (plain stores, no atomics), G~ is never "
+                                        "written; the finish kernel adds the column tiles in index order ((p + 2) x 8 B per SNP "
+                                        "and column tile read; bit-reproducible). "
                                         "Priced as the rotation (roofline_rotate); JXGPU_FVLMM_FUSED=0 restores the two-kernel "
                                         "form (4 n B per SNP written and read back, HBM-bound)",
                                 "ms_per_step": (kern["rot_ms"] + kern["scan_ms"]) / L}
@@ -549,6 +575,41 @@ def main():
                                                    os.cpu_count() or 1)
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"error": repr(e)}
+        # Extra legs of the default one-GPU run (BASELINE configs[2], -lmm, no missing calls): (1) the same shape with 1 %
+        # missing calls (every SNP takes the fp16 hi/lo three-product path of the GRM and of the rotation), (2) one step of
+        # BASELINE configs[3] (n = 50 000, m = 500 000: the shape the north star's 8-GPU target is quoted on) on this ONE GPU.
+        if (world == 1 and not distributed and not args.no_extra and args.mode == "lmm" and args.missing == 0.0
+                and (int(n), int(args.m)) == (20000, 200000)):
+            del main_leg, packed
+            torch.cuda.empty_cache()
+            try:
+                leg = run_leg(20000, 200000, 0.01, 2, 1)
+                sm = leg_summary(leg, 20000, 2)
+                res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_f16x2_kernel (SNPs with a missing call among "
+                                                       "the samples: fp16 hi/lo three-product variant)",
+                                                       note="2 timed steps of the configs[2] shape with 1 % missing calls; "
+                                                            "algorithmic n(n+1)m flops over the whole accumulate call")
+                res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"], kernel="rotate_f16x2_kernel",
+                                                          note="same leg; algorithmic 2 m n^2 flops")
+                res["extra_c3_missing1pct"] = {k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
+                                                                  "stages_ms_per_step")}
+                del leg
+                torch.cuda.empty_cache()
+            except Exception as e:   # an extra leg never takes the headline line down
+                res["extra_c3_missing1pct"] = {"error": repr(e)}
+            try:
+                leg = run_leg(50000, 500000, 0.0, 1, 1)
+                sm = leg_summary(leg, 50000, 1)
+                res["extra_c4_1gpu"] = dict({k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
+                                                                "stages_ms_per_step")},
+                                            warmup=1, n_gpus=1,
+                                            workload="synthetic HWE panel n=50000 m=500000 (BASELINE configs[3] shape) on ONE GPU, "
+                                                     "-lmm, maf 0.02 geno 0.05, intercept only, missing=0.0",
+                                            roofline_grm=sm["roofline_grm"], roofline_rotate=sm["roofline_rotate"])
+                del leg
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["extra_c4_1gpu"] = {"error": repr(e)}
         # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it first so that the
         # JSON line is the last line on stdout
         try:

@@ -1559,6 +1559,35 @@ def format_assoc_row(chrom, pos, snp, a0, a1, af, miss, beta, se, p) -> str:
 # G1  GBLUP (src/stats/gblup.rs:1105-1240 `fit_gblup_reml_from_grm_row_major_f64`, :1258-1516 `gblup_reml_npy_grm`)
 # --------------------------------------------------------------------------------------------
 
+def gblup_reml_eval(s, x_rot, y_rot, n, log10_lbd, v_floor=1e-12):
+    """One evaluation of the intercept-only spectral likelihood of the GBLUP fit (src/stats/gblup.rs:1140-1190; the
+    Python twin is `BLUP._REML`, python/janusx/pyBLUP/mlm.py:1940-2050, which tests/golden/gen_fixtures.py runs to pin
+    this function): v_i = max(s_i + lambda, v_floor).  -> (reml, ml, beta, q, 1 / v, r) or None when invalid."""
+    lbd = 10.0 ** log10_lbd
+    if not (math.isfinite(lbd) and lbd > 0.0):
+        return None
+    n_eff = float(n - 1)
+    c_reml = n_eff * (math.log(n_eff) - 1.0 - math.log(2.0 * math.pi)) / 2.0
+    c_ml = n * (math.log(n) - 1.0 - math.log(2.0 * math.pi)) / 2.0
+    vi = np.maximum(s + lbd, v_floor)
+    log_det_v = float(np.sum(np.log(vi)))
+    inv = 1.0 / vi
+    xtvx = float(np.sum(inv * x_rot * x_rot))
+    xtvy = float(np.sum(inv * x_rot * y_rot))
+    if not (math.isfinite(xtvx) and xtvx > v_floor):
+        return None
+    beta = xtvy / xtvx
+    r = y_rot - x_rot * beta
+    q = float(np.sum(inv * r * r))
+    if not (math.isfinite(q) and q > v_floor):
+        return None
+    reml = c_reml - 0.5 * (n_eff * math.log(q) + log_det_v + math.log(xtvx))
+    ml = c_ml - 0.5 * (n * math.log(q) + log_det_v)
+    if not (math.isfinite(reml) and math.isfinite(ml)):
+        return None
+    return reml, ml, beta, q, inv, r
+
+
 def gblup_fit(grm_f64, y, low=-6.0, high=6.0, tol=1e-4, max_iter=50):
     """Intercept-only REML on the spectral scale: eigh(K) (no ridge here; the caller adds g_eps), x~ = U'1,
     y~ = U'(y - mean), Brent over log10(lambda) with v_i = max(s_i + lambda, 1e-12), alpha = U (v^-1 r)."""
@@ -1572,32 +1601,10 @@ def gblup_fit(grm_f64, y, low=-6.0, high=6.0, tol=1e-4, max_iter=50):
     s, u = eigh_sym(k)
     x_rot = u.sum(axis=0)
     y_rot = u.T @ yc
-    v_floor = 1e-12
     n_eff = float(n - 1)
-    c_reml = n_eff * (math.log(n_eff) - 1.0 - math.log(2.0 * math.pi)) / 2.0
-    c_ml = n * (math.log(n) - 1.0 - math.log(2.0 * math.pi)) / 2.0
 
     def ev(x):
-        lbd = 10.0 ** x
-        if not (math.isfinite(lbd) and lbd > 0.0):
-            return None
-        vi = np.maximum(s + lbd, v_floor)
-        log_det_v = float(np.sum(np.log(vi)))
-        inv = 1.0 / vi
-        xtvx = float(np.sum(inv * x_rot * x_rot))
-        xtvy = float(np.sum(inv * x_rot * y_rot))
-        if not (math.isfinite(xtvx) and xtvx > v_floor):
-            return None
-        beta = xtvy / xtvx
-        r = y_rot - x_rot * beta
-        q = float(np.sum(inv * r * r))
-        if not (math.isfinite(q) and q > v_floor):
-            return None
-        reml = c_reml - 0.5 * (n_eff * math.log(q) + log_det_v + math.log(xtvx))
-        ml = c_ml - 0.5 * (n * math.log(q) + log_det_v)
-        if not (math.isfinite(reml) and math.isfinite(ml)):
-            return None
-        return reml, ml, beta, q, inv, r
+        return gblup_reml_eval(s, x_rot, y_rot, n, x)
 
     def cost(x):
         e = ev(x)

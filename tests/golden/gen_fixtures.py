@@ -7,7 +7,11 @@ Run in the BUILD container only:  python tests/golden/gen_fixtures.py
     written: /root/reference/python/janusx/pyBLUP/assoc.py is imported with a stub `janusx.janusx` module (the
     native extension cannot be built: no Rust toolchain) and its pure-numpy helpers `_lmm_profile_exact_vc` and
     `_chi2_sf_df1` are evaluated on the same inputs; /root/reference/python/janusx/pyBLUP/QK2.py (legacy numpy GRM)
-    is used as a structural sanity check of ZZ^T / sum(2pq).
+    is used as a structural sanity check of ZZ^T / sum(2pq);
+  * round 3: further reference-produced values are STORED in the fixture (and asserted by the CPU and GPU tests):
+    `pyBLUP/blup.py::REML` (dense-Cholesky restricted likelihood at 5 lambda), `pyBLUP/mlm.py::BLUP._REML` (spectral GBLUP
+    likelihood, incl. its v_floor branch), `pyBLUP/assoc.py::_lm_plrt_from_beta_se` and `_lm_precompute_ixx_qr` (full-rank
+    and rank-deficient design).
 Nothing under /root/reference is copied: the fixtures hold data only.
 """
 import importlib
@@ -119,6 +123,65 @@ def main():
                 ref_used.append(f"QK2.GRM corr={c:.4f}")
         except Exception as e:
             print("QK2 sanity skipped:", repr(e))
+    # ---- round 3: more reference-produced values, stored -----------------------------------------
+    extra = {}
+    lm_x = x
+    lm_ixx = O.lm_precompute_ixx_qr(lm_x)
+    flip0 = np.zeros(int(keep.sum()), dtype=bool)
+    lm_out = O.lm_block_assoc_packed(y, lm_x, lm_ixx, pk, n, flip0, af[keep])
+    if ref is not None:
+        blup_mod = importlib.import_module("janusx.pyBLUP.blup")
+        mlm_mod = importlib.import_module("janusx.pyBLUP.mlm")
+        # (a) dense restricted likelihood of blup.py (scale invariant in theta: V = K + lambda I), on the ridged GRM the
+        #     spectral null model decomposes: must equal -reml_loglike of the spectral form up to its 1e-6 ridge on X'V^-1X
+        kr = k1.astype(np.float64) + 1e-6 * np.eye(n)
+        dense = []
+        for lam in ref_lams:
+            val = float(blup_mod.REML(np.array([1.0, lam]), y.reshape(-1, 1), x, [kr]))
+            dense.append(val)
+            mine = -O.reml_loglike(math.log10(lam), nm.S, nm.Xcov, nm.y, None)
+            assert abs(val - mine) < 1e-6 * max(1.0, abs(val)), (lam, val, mine)
+        extra["ref_dense_reml"] = np.array(dense)
+        ref_used.append("blup.REML")
+        # (b) spectral GBLUP likelihood of mlm.py on the training spectrum of the GBLUP fit (K + g_eps I), incl. a lambda
+        #     where an (artificially negative) eigenvalue hits the v_floor branch
+        g_eps = 1e-8
+        sg, ug = O.eigh_sym(k1.astype(np.float64) + g_eps * np.eye(n))
+        yc = y - float(np.sum(y) / n)
+        x_rot, y_rot = ug.sum(axis=0), ug.T @ yc
+        obj = mlm_mod.BLUP.__new__(mlm_mod.BLUP)
+        obj._reml_calls, obj._debug_stage, obj._reml_v_floor = 0, False, 1e-12
+        obj.X, obj.y, obj.p = x_rot.reshape(-1, 1), y_rot.reshape(-1, 1), 1
+        gb = []
+        for lam in ref_lams:
+            obj.S = sg
+            val = float(obj._REML(lam))
+            gb.append(val)
+            mine = O.gblup_reml_eval(sg, x_rot, y_rot, n, math.log10(lam))[0]
+            assert abs(val - mine) < 1e-10 * max(1.0, abs(val)), (lam, val, mine)
+        s_floor = sg.copy()
+        s_floor[0] = -0.3                                   # s + lambda <= 1e-12 at lambda = 0.3: clipped to the floor
+        obj.S = s_floor
+        val = float(obj._REML(0.3))
+        mine = O.gblup_reml_eval(s_floor, x_rot, y_rot, n, math.log10(0.3))[0]
+        assert abs(val - mine) < 1e-10 * max(1.0, abs(val)), (val, mine)
+        extra.update(ref_gblup_reml=np.array(gb), ref_gblup_reml_floor=np.array(val), gblup_s=sg, gblup_s_floor=s_floor,
+                     gblup_xrot=x_rot, gblup_yrot=y_rot)
+        ref_used.append("mlm.BLUP._REML")
+        # (c) LM helpers of assoc.py
+        df_lm = n - lm_x.shape[1] - 1
+        plrt_ref = ref._lm_plrt_from_beta_se(lm_out[:, 0], lm_out[:, 1], n_obs=n, df=df_lm)
+        okr = np.isfinite(plrt_ref)
+        assert np.array_equal(okr, np.isfinite(lm_out[:, 3]))
+        assert np.max(np.abs(plrt_ref[okr] - lm_out[okr, 3]) / plrt_ref[okr]) < 1e-12
+        ixx_ref = ref._lm_precompute_ixx_qr(lm_x)
+        assert np.max(np.abs(ixx_ref - lm_ixx)) < 1e-14 * np.max(np.abs(ixx_ref))
+        x_def = np.concatenate([lm_x, lm_x[:, 1:2] * 2.0], axis=1)          # rank deficient: pseudo-inverse branch
+        ixx_def_ref = ref._lm_precompute_ixx_qr(x_def)
+        assert np.max(np.abs(ixx_def_ref - O.lm_precompute_ixx_qr(x_def))) < 1e-12 * np.max(np.abs(ixx_def_ref))
+        extra.update(ref_lm_plrt=plrt_ref, ref_lm_ixx=ixx_ref, ref_lm_ixx_deficient=ixx_def_ref, lm_x_deficient=x_def)
+        ref_used += ["_lm_plrt_from_beta_se", "_lm_precompute_ixx_qr"]
+    extra.update(lm_out=lm_out, lm_pk=pk, lm_maf=af[keep])
     print("reference helpers cross-checked:", ref_used)
 
     # ---- TSV text ---------------------------------------------------------------------------------
@@ -140,6 +203,7 @@ def main():
         grot=grot, lmm=lmm, lmm_evals=evals, fvlmm=fv, tsv=np.array(buf.getvalue()),
         reference_checked=np.array(";".join(ref_used)),
         ref_lams=np.array(ref_lams), ref_nullreml=np.array(ref_nullreml),
+        **extra,
     )
     sz = os.path.getsize(os.path.join(HERE, "panel_small.npz"))
     print("wrote panel_small.npz", sz, "bytes; mean Brent evals", evals[evals > 0].mean())

@@ -460,6 +460,41 @@ def test_golden_fixture_gpu():
     assert max(be, se, pe) < TOL, (be, se, pe)
 
 
+def test_reference_python_values_through_the_gpu_path():
+    """The HIP path against values the reference's own Python produced (tests/golden/gen_fixtures.py): the dense-Cholesky
+    restricted likelihood of pyBLUP/blup.py through the spectral likelihood kernel, the GBLUP likelihood of
+    pyBLUP/mlm.py through `gblup_reml_grm` pinned at each lambda, and the LM scan's plrt column / (X'X)^-1 against
+    `_lm_plrt_from_beta_se` / `_lm_precompute_ixx_qr` of pyBLUP/assoc.py."""
+    import os
+    from janusx_amd import janusx as jxrs
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "panel_small.npz"))
+    n = int(gold["n"])
+    for lam, val in zip(gold["ref_lams"], gold["ref_dense_reml"]):
+        _ml, reml = jxrs._loglike_null(gold["S"], gold["Xcov"], gold["yrot"], math.log10(lam))
+        assert abs(-reml - val) < 1e-6 * max(1.0, abs(val)), (lam, reml, val)     # 1e-6 ridge on X'V^-1X (reml.rs:311)
+    k = gold["k_stream_m1"].astype(np.float64)
+    tr = np.arange(n, dtype=np.int64)
+    for lam, val in zip(gold["ref_lams"], gold["ref_gblup_reml"]):
+        l10 = math.log10(lam)
+        r = jxrs.gblup_reml_grm(k, tr, gold["y"], None, low=l10 - 1e-9, high=l10 + 1e-9, g_eps=1e-8, estimate_only=True)
+        assert abs(r[3] - lam) < 1e-6 * lam
+        assert abs(r[5] - val) < 1e-8 * max(1.0, abs(val)), (lam, r[5], val)
+    x = gold["x"]
+    ixx = jxrs.lm_precompute_ixx_qr(x)
+    assert np.max(np.abs(ixx - gold["ref_lm_ixx"])) < 1e-13 * np.max(np.abs(ixx))
+    ixd = jxrs.lm_precompute_ixx_qr(gold["lm_x_deficient"])
+    assert np.max(np.abs(ixd - gold["ref_lm_ixx_deficient"])) < 1e-11 * np.max(np.abs(ixd))
+    maf = gold["lm_maf"]
+    out = jxrs.lm_block_assoc_packed(gold["y"], x, ixx, gold["lm_pk"], n, np.zeros(len(maf), bool), maf)
+    ok = np.isfinite(gold["ref_lm_plrt"])
+    assert np.array_equal(ok, np.isfinite(out[:, 3]))
+    # plrt is a function of t^2 = (beta / se)^2: d ln p / d ln t^2 ~ stat / 2, so compare through -log10 p as well
+    rel = np.abs(out[ok, 3] - gold["ref_lm_plrt"][ok]) / gold["ref_lm_plrt"][ok]
+    lrel = np.abs(np.log10(out[ok, 3]) - np.log10(gold["ref_lm_plrt"][ok])) / np.maximum(1.0, -np.log10(gold["ref_lm_plrt"][ok]))
+    assert float(np.max(np.minimum(rel, lrel))) < 1e-6, (float(rel.max()), float(lrel.max()))
+    assert np.max(np.abs(out[ok, 0] - gold["lm_out"][ok, 0]) / (np.abs(gold["lm_out"][ok, 0]) + gold["lm_out"][ok, 1])) < 1e-8
+
+
 def test_bed_to_tsv_routes(oracle, oracle_c, null_case, tmp_path):
     """`jx gwas -lmm/-fvlmm` kernel entry points: BED file -> QC -> scan -> TSV (rows in BED order)."""
     from janusx_amd import janusx as jxrs

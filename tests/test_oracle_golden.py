@@ -76,6 +76,36 @@ def test_reference_nullreml_values(oracle, oracle_c, gold):
     assert "LMM._NULLREML" in str(gold["reference_checked"])
 
 
+def test_reference_python_values_round3(oracle, gold):
+    """Values produced by the reference's OWN Python in the build container (tests/golden/gen_fixtures.py, stored in the
+    fixture): the dense-Cholesky restricted likelihood `REML` (python/janusx/pyBLUP/blup.py:158-236), the spectral GBLUP
+    likelihood `BLUP._REML` incl. its v_floor branch (pyBLUP/mlm.py:1940-2050), `_lm_plrt_from_beta_se` and
+    `_lm_precompute_ixx_qr` (pyBLUP/assoc.py:74-100, 453-480).  The oracle must reproduce every one of them."""
+    import math
+    assert all(t in str(gold["reference_checked"]) for t in ("blup.REML", "mlm.BLUP._REML", "_lm_plrt_from_beta_se",
+                                                             "_lm_precompute_ixx_qr"))
+    for lam, val in zip(gold["ref_lams"], gold["ref_dense_reml"]):
+        # blup.REML returns the objective to MINIMISE; the spectral form carries a 1e-6 ridge on X'V^-1X (reml.rs:311)
+        mine = -oracle.reml_loglike(math.log10(lam), gold["S"], gold["Xcov"], gold["yrot"], None)
+        assert abs(val - mine) < 1e-6 * max(1.0, abs(val)), (lam, val, mine)
+    n = int(gold["n"])
+    for lam, val in zip(gold["ref_lams"], gold["ref_gblup_reml"]):
+        mine = oracle.gblup_reml_eval(gold["gblup_s"], gold["gblup_xrot"], gold["gblup_yrot"], n, math.log10(lam))[0]
+        assert abs(val - mine) < 1e-10 * max(1.0, abs(val)), (lam, val, mine)
+    mine = oracle.gblup_reml_eval(gold["gblup_s_floor"], gold["gblup_xrot"], gold["gblup_yrot"], n, math.log10(0.3))[0]
+    assert abs(float(gold["ref_gblup_reml_floor"]) - mine) < 1e-10 * abs(mine)
+    x = gold["x"]
+    ixx = oracle.lm_precompute_ixx_qr(x)
+    assert np.max(np.abs(ixx - gold["ref_lm_ixx"])) < 1e-14 * np.max(np.abs(ixx))
+    ixd = oracle.lm_precompute_ixx_qr(gold["lm_x_deficient"])
+    assert np.max(np.abs(ixd - gold["ref_lm_ixx_deficient"])) < 1e-12 * np.max(np.abs(ixd))
+    pk, maf = gold["lm_pk"], gold["lm_maf"]
+    out = oracle.lm_block_assoc_packed(gold["y"], x, ixx, pk, n, np.zeros(len(maf), bool), maf)
+    ok = np.isfinite(gold["ref_lm_plrt"])
+    assert np.array_equal(ok, np.isfinite(out[:, 3]))
+    assert np.max(np.abs(out[ok, 3] - gold["ref_lm_plrt"][ok]) / gold["ref_lm_plrt"][ok]) < 1e-12
+
+
 def test_python_vs_c_oracle(oracle, oracle_c, gold):
     s, x, y, grot = gold["S"], gold["Xcov"], gold["yrot"], gold["grot"]
     for t in (-2.0, 0.0, 1.5):

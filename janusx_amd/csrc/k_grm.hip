@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ pos, int64_t mk,
                                                          int32_t *__restrict__ info, int32_t *__restrict__ rows2,
                                                          uint4 *__restrict__ lut16, float *__restrict__ ilut2,
-                                                         double *__restrict__ beta2) {
+                                                         double *__restrict__ beta2, int i8mode) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const int32_t nex = info[0] & ~63;
@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
         const __half l = __float2half_rn(v - __half2float(h));
         hi[c] = __half_as_ushort(h);
         lo[c] = __half_as_ushort(l);
-        ilut2[(int64_t)dst * 4 + c] = ilut[k * 4 + c];
+        // int8 Gram (k_grm_i8.hip): z = b + s c with the UNFLIPPED count c of the payload (LUT 0, 0, 1, 2); else the
+        // flipped integer LUT of the fp16 exact variant (z = beta + c~)
+        ilut2[(int64_t)dst * 4 + c] = i8mode ? (c == 0 ? 0.0f : (float)(c - 1)) : ilut[k * 4 + c];
     }
     uint4 o;
     o.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
@@ -461,7 +463,14 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
     o.z = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
     o.w = (uint32_t)lo[2] | ((uint32_t)lo[3] << 16);
     lut16[dst] = o;
-    beta2[dst] = exact ? beta[k] : 0.0;
+    if (i8mode) {
+        // b = beta + c~(00) (0, or 2 when the reference flips the SNP), s = -1 for a flipped SNP: weight of the affine term
+        // r = C (b s); sum b^2 = sum (b s)^2 is formed from the same array (grm_sumsq_kernel)
+        const double r0 = (double)ilut[k * 4 + 0];
+        beta2[dst] = exact ? (beta[k] + r0) * (r0 == 0.0 ? 1.0 : -1.0) : 0.0;
+    } else {
+        beta2[dst] = exact ? beta[k] : 0.0;
+    }
     if (bad) atomicOr(&info[1], 1);
 }
 
@@ -530,6 +539,11 @@ struct EventPair {
 static EventPair g_grm_ev;
 }  // namespace jx
 
+namespace jx {
+int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, int64_t r0, int64_t r1, int nt128,
+                  double *d_acc, int64_t ld, const double *corr, bool panel, int tile_row_begin, int tile_row_end);
+}
+
 extern "C" int jxg_debug_occupancy(int *out) {
     int a = -1, b = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *)grm_f16x2_kernel<128, 128, 64, 64, false>, 256, 0);
@@ -583,6 +597,8 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     // classify / reorder: SNPs that factor as beta + {0,1,2} without missing calls first (exact single-product path)
     static const int exact_env = getenv("JXGPU_GRM_EXACT") ? atoi(getenv("JXGPU_GRM_EXACT")) : 1;
     static const int exact_bk = getenv("JXGPU_GRM_EXACT_BK") ? atoi(getenv("JXGPU_GRM_EXACT_BK")) : 64;
+    // exact prefix on the int8 matrix pipes (k_grm_i8.hip); JXGPU_GRM_I8=0 keeps the fp16 single-product variant
+    static const int i8_env = getenv("JXGPU_GRM_I8") ? atoi(getenv("JXGPU_GRM_I8")) : 1;
     if (mk > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many SNPs in one call");
     DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb;
     if (lut16.alloc(sizeof(uint4) * (size_t)mk) || flagb.alloc(sizeof(int32_t) * (size_t)mk) ||
@@ -607,7 +623,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     JX_LAUNCH_CHECK();
     hipLaunchKernelGGL(grm_gather_kernel, dim3(gk), dim3(256), 0, st, d_rows, d_lut, ilutb.as<float>(),
                        betab.as<double>(), posb.as<int32_t>(), mk, infob.as<int32_t>(), rows2b.as<int32_t>(),
-                       lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>());
+                       lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>(), i8_env);
     JX_LAUNCH_CHECK();
     int32_t hinfo[2] = {0, 0};
     JX_HIP(hipMemcpyAsync(hinfo, infob.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -695,7 +711,13 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
         }
         return 0;
     };
-    if (run_range(true, 0, n_exact)) return 1;
+    if (i8_env) {
+        if (launch_grm_i8(st, d_p32, m_total, rows2, 0, n_exact, nt, d_acc, ld, n_exact > 0 ? corrb.as<double>() : nullptr,
+                          panel, tile_row_begin, tile_row_end))
+            return 1;
+    } else if (run_range(true, 0, n_exact)) {
+        return 1;
+    }
     if (run_range(false, n_exact, mk)) return 1;
     JX_HIP(hipEventRecord(g_grm_ev.b, st));
     JX_HIP(hipStreamSynchronize(st));  // lut16 is freed on return

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out) {
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
+    if (MAXD == 2) p = 1;     // dim = p + 1 <= 2 and p >= 1: a compile-time p (see lmm_scan_tiled_kernel)
     const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
     if (LDS) {
         double *ls = scan_lds, *lx = scan_lds + n, *ly = scan_lds + n + (int64_t)n * p;
@@ -673,10 +674,19 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out, int tile, int rows_per_wg) {
+    // MAXD = 2 is dispatched for dim = p + 1 <= 2 only, i.e. p = 1 (p >= 1 is checked by the host wrapper): a compile-time p
+    // turns the X~ addresses of the batched sample loop into immediate offsets (with a run-time p the compiler kept one
+    // LDS address register per sample slot of the unrolled loop alive for the whole kernel)
+    if (MAXD == 2) p = 1;
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
     double *ls = scan_lds, *lx = scan_lds + tile, *ly = scan_lds + tile + (int64_t)tile * p;
     int &next_row = *reinterpret_cast<int *>(scan_lds + (int64_t)tile * (2 + p));   // queue head, behind the tile (all LDS is
                                                                                      // dynamic: the base stays 16-byte aligned)
+    // The Brent state of the wave's SNP (wave-uniform: 10 doubles + 2 counters) lives in LDS between two rounds: held in
+    // registers it was live across the tile loop in every lane and pushed the 1024-thread workgroup (128 VGPRs per lane)
+    // into scratch (58 spilled registers, 1.4 GB of scratch writes per launch at BASELINE configs[2]).  Lane 0 stores it,
+    // every lane reads it back (one broadcast read per value) where the round's evaluation is folded in.
+    BrentState *const bslot = reinterpret_cast<BrentState *>(scan_lds + (int64_t)tile * (2 + p) + 2) + (threadIdx.x >> 6);
     const int out_cols = with_plrt ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const double smin = smin_ptr[0];
@@ -685,7 +695,6 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
     const int row_end = min(nrows, row_begin + rows_per_wg);
     if (threadIdx.x == 0) next_row = row_begin;
     __syncthreads();
-    const double tol = fmax(fabs(tol_in), 1e-12);
     const bool vec4 = (n % 4 == 0) && (tile % 256 == 0) && ((reinterpret_cast<uintptr_t>(grot) & 15) == 0);
     double lo_b = low, hi_b = high;
     if (!(lo_b < hi_b)) {
@@ -696,9 +705,18 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
     // wave state: phase 0 = needs a SNP, 1 = first evaluation (also forms sum g^2), 2 = Brent evaluation at u, 3 = final
     int phase = 0, r = -1;
     bool exhausted = false;
-    BrentState b;
-    double u = 0.0, x_eval = 0.0;
+    double x_eval = 0.0;                                  // the point the round evaluates (= u of the Brent iteration in phase 2)
     for (;;) {
+        // Re-derive the round-invariant quantities (sample count as a double, staging addresses, the tolerance) in every round:
+        // hoisted out of the round loop they are live across the tile loop and, at 128 VGPRs per lane, end up in scratch.
+        // The empty asm makes the scalar inputs opaque per round, so the few instructions stay where they are used.
+        int n_r = n;
+        double tol_r = tol_in;
+        const double *s_r = s_g, *y_r = yc_g, *x_r = xcov_g, *coef_r = coef;
+        ChebHeader hd_r = hd;
+        asm volatile("" : "+s"(n_r), "+s"(tol_r), "+s"(s_r), "+s"(y_r), "+s"(x_r), "+s"(coef_r), "+s"(hd_r.segw),
+                     "+s"(hd_r.low), "+s"(hd_r.nf), "+s"(hd_r.nseg));
+        const double tol = fmax(fabs(tol_r), 1e-12);
         if (phase == 0 && !exhausted) {
             int nr = 0;
             if (lane == 0) nr = atomicAdd(&next_row, 1);
@@ -708,16 +726,7 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
             } else {
                 r = nr;
                 phase = 1;
-                b.a = lo_b;
-                b.c = hi_b;
-                b.x = (warm && isfinite(init) && init >= b.a && init <= b.c) ? init : 0.5 * (b.a + b.c);
-                b.w = b.x;
-                b.v = b.x;
-                b.d = 0.0;
-                b.e = 0.0;
-                b.it = 0;
-                b.evals = 0;
-                x_eval = b.x;
+                x_eval = (warm && isfinite(init) && init >= lo_b && init <= hi_b) ? init : 0.5 * (lo_b + hi_b);
             }
         }
         if (__syncthreads_and((phase == 0 && exhausted) ? 1 : 0)) break;
@@ -732,10 +741,10 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
             const int t1 = min(n, t0 + tile);
             __syncthreads();                                   // the previous tile has been consumed
             for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) {
-                ls[i] = s_g[t0 + i];
-                ly[i] = yc_g[t0 + i];
+                ls[i] = s_r[t0 + i];
+                ly[i] = y_r[t0 + i];
             }
-            for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) lx[i] = xcov_g[(int64_t)t0 * p + i];
+            for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) lx[i] = x_r[(int64_t)t0 * p + i];
             __syncthreads();
             if (active && (lbd >= 0.0 || phase == 1)) {
                 if (vec4) fast_eval_accumulate_batched<MAXD, 4, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1);
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
         ev.logdetv = 0.0;
         ev.beta_k = 0.0;
         ev.ainv_kk = 0.0;
-        if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd, coef, n, p, phase == 3, acc, ev);
+        if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd_r, coef_r, n_r, p, phase == 3, acc, ev);
         double *o = out + (int64_t)r * out_cols;
         if (phase == 1) {
             ssq = wave_allsum(ssq);
@@ -765,14 +774,27 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                 phase = 0;
                 continue;
             }
-            b.fx = ev.reml_neg;
-            b.fw = b.fx;
-            b.fv = b.fx;
-            b.evals = 1;
-        } else if (phase == 2) {
-            brent_update(b, u, ev.reml_neg);
         }
         if (phase == 1 || phase == 2) {
+            BrentState b;
+            if (phase == 1) {
+                b.a = lo_b;
+                b.c = hi_b;
+                b.x = x_eval;
+                b.w = b.x;
+                b.v = b.x;
+                b.d = 0.0;
+                b.e = 0.0;
+                b.it = 0;
+                b.fx = ev.reml_neg;
+                b.fw = b.fx;
+                b.fv = b.fx;
+                b.evals = 1;
+            } else {
+                b = *bslot;                                // written by this wave's lane 0 at the end of its previous round
+                brent_update(b, x_eval, ev.reml_neg);
+            }
+            double u;
             if (brent_propose(b, tol, max_iter, u)) {
                 phase = 2;
                 x_eval = u;
@@ -780,12 +802,13 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                 phase = 3;
                 x_eval = b.x;
             }
+            if (lane == 0) *bslot = b;
             continue;
         }
         // phase 3: final_beta_se (src/stats/reml.rs:472-568) at the optimum
         double beta = nan(""), se = nan("");
         if (ev.ok) {
-            const double sigma2 = ev.q / ((double)n - (double)dim);
+            const double sigma2 = ev.q / ((double)n_r - (double)dim);
             const double var = sigma2 * ev.ainv_kk;
             if (var > 0.0 && isfinite(var)) {
                 beta = ev.beta_k;
@@ -793,7 +816,7 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
             }
         }
         if (lane == 0) {
-            if (evals_out) evals_out[r] = b.evals;
+            if (evals_out) evals_out[r] = bslot->evals;
             if (isfinite(beta) && isfinite(se) && se > 0.0) {
                 const double z = beta / se;
                 double pv = 2.0 * (0.5 * jx_erfc(fabs(z) / 1.4142135623730951));
@@ -805,7 +828,7 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                 if (with_plrt) {
                     double plrt = 1.0;
                     if (ev.ok && isfinite(ev.q) && ev.q > 0.0) {
-                        const double nf = (double)n;
+                        const double nf = (double)n_r;
                         const double ml =
                             nf * (jx_log(nf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * jx_log(ev.q) + ev.logdetv);
                         if (isfinite(ml)) {
@@ -952,7 +975,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         int tile = (150 * 1024 / per_sample) / 256 * 256;
         const int ntiles = (n + tile - 1) / tile;
         tile = ((n + ntiles - 1) / ntiles + 255) / 256 * 256;
-        const size_t lds_tile = (size_t)per_sample * tile + 16;
+        const size_t lds_tile = (size_t)per_sample * tile + 16 + 16 * sizeof(BrentState);   // + queue head + one Brent state per wave
         static int cus = 0;
         if (!cus) {
             int dev = 0;

@@ -11,7 +11,6 @@ n = 200 000 does not fit HBM as a square), block-diagonal spectral route, Sparse
 """
 import json
 import os
-import resource
 import sys
 import tempfile
 import time
@@ -22,22 +21,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _rss_gib():
+    """(resident now, peak so far) in GiB, from VmRSS / VmHWM of this process image (ru_maxrss would also carry the peak of
+    the parent that forked us: the pytest process with its full-size host arrays)."""
+    now = peak = 0.0
+    with open("/proc/self/status") as f:
+        for ln in f:
+            if ln.startswith("VmRSS:"):
+                now = int(ln.split()[1]) / 2**20
+            elif ln.startswith("VmHWM:"):
+                peak = int(ln.split()[1]) / 2**20
+    return round(now, 3), round(peak, 3)
+
+
 def main():
     import torch
     import bench
     from janusx_amd import janusx as jxrs
     from janusx_amd import stats as st
+    from janusx_amd._lib import lib
     from oracle import jx_oracle as O
     import scipy.sparse as sp
     n, m = int(sys.argv[1]), int(sys.argv[2])
     n_pick = int(sys.argv[3]) if len(sys.argv) > 3 else 150
     dev = torch.device("cuda", 0)
+    # baseline of the process before any panel exists: interpreter + torch + the HIP runtime with its code objects loaded
+    lib()
+    (torch.ones(8, device=dev) @ torch.ones(8, device=dev)).item()
+    torch.cuda.synchronize()
+    rss = {"init": _rss_gib()}
     t0 = time.perf_counter()
     packed_t, dos = bench.family_panel_gpu(n, m, 4, 11, dev)
     y = bench.make_phenotype(dos, n, 7, dev)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
+    rss["generated"] = _rss_gib()
     counts = jxrs.bed_row_counts(packed_t, n)
+    rss["counted"] = _rss_gib()
     keep, _miss, maf, _std = st.packed_prep_row_stats(counts, n, 0.02, 0.05, 0.0)
     pk = packed_t if bool(keep.all()) else packed_t[torch.from_numpy(np.nonzero(keep)[0]).to(dev)]
     del packed_t
@@ -49,9 +69,11 @@ def main():
         t0 = time.perf_counter()
         path, nn, nnz = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, maf_k, os.path.join(td, "k"), None, 1, 0.05)
         t1 = time.perf_counter()
+        rss["sparse_grm"] = _rss_gib()
         out, l10, null = jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
+        rss["scanned"] = _rss_gib()
         res.update(spgrm_s=t1 - t0, scan_s=t2 - t1, nnz=int(nnz), log10_lambda=float(l10),
                    snps_per_s=len(maf_k) / (t2 - t0), route="block" if jxrs._sparse_block_route(n) else "dense")
         # ---- checker: the oracle on the sparse GRM file (a sparse LU of K + lambda I is the reference's sparse LLT restated)
@@ -83,7 +105,11 @@ def main():
     res["ml_err"] = float(abs(ev["ml"] - null[3]) / max(1.0, abs(ev["ml"])))
     res["all_rows_finite_p"] = bool(np.all((out[:, 2] > 0) & (out[:, 2] <= 1)))
     res["peak_hbm_gib"] = torch.cuda.max_memory_allocated() / 2**30
-    res["host_maxrss_gib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20
+    rss["checked"] = _rss_gib()
+    res["host_rss_gib"] = rss
+    res["host_maxrss_gib"] = rss["checked"][1]
+    # what the run added on top of the process baseline (interpreter + torch + HIP runtime with its code objects loaded)
+    res["host_rss_growth_gib"] = res["host_maxrss_gib"] - rss["init"][1]
     print(json.dumps(res), flush=True)
 
 

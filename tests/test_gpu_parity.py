@@ -754,7 +754,8 @@ def test_c5_shaped_splmm_device_panel():
     its own process): families of four, m = 200 000 SNPs, sparse GRM through the row-panel builder
     (`jxg_grm_accumulate_rows`), block-diagonal spectral route, exact scan; 150-SNP sample against the oracle's restatement
     of `exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) with a sparse factor of K + lambda I, sparse REML optimum
-    against the oracle's evaluation; no (m x n) host array: peak host RSS of the whole run < 8 GiB."""
+    against the oracle's evaluation; no (m x n) host array (the packed payload alone is 10 GB, its dosages 40 GB): the host RSS
+    the run adds on top of the process baseline (interpreter + torch + HIP runtime, recorded) stays < 8 GiB."""
     import json
     import os
     import subprocess
@@ -774,7 +775,7 @@ def test_c5_shaped_splmm_device_panel():
     assert d["nan_pattern_equal"] and d["all_rows_finite_p"]
     assert max(d["beta_err"], d["se_err"], d["p_err"]) < TOL, d
     assert d["reml_err"] < 1e-9 and d["ml_err"] < 1e-9, d
-    assert d["host_maxrss_gib"] < 8.0, d
+    assert d["host_maxrss_gib"] < 8.0 and d["host_rss_growth_gib"] < 4.0, d
 
 
 def test_device_resident_payload_entry_points(oracle, tmp_path):

@@ -541,6 +541,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_f32_kernel(const float *__res
 using namespace jx;
 
 namespace jx {
+int launch_rotate256(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                     const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
+                     const uint16_t *d_ulo, float out_scale, float *d_out, int64_t ld_out, int *took);
 extern float g_last_ms[16];
 extern int g_timer_pending[4];
 hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
@@ -647,10 +650,16 @@ extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, in
     const int nrt = (nrows + 127) / 128;
     dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
     JX_HIP(hipEventRecord(g_rot_a, st));
-    hipLaunchKernelGGL(rotate_f16x2_kernel<false>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
-                       (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
-                       ldexpf(1.0f, -scale_exp), d_out, ld_out, RotFuse{});
-    JX_LAUNCH_CHECK();
+    int took = 0;                         // full-size blocks: 256 x 256 tiles (k_rotate256.hip)
+    if (launch_rotate256(st, d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
+                         ldexpf(1.0f, -scale_exp), d_out, ld_out, &took))
+        return 1;
+    if (!took) {
+        hipLaunchKernelGGL(rotate_f16x2_kernel<false>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
+                           (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,
+                           ldexpf(1.0f, -scale_exp), d_out, ld_out, RotFuse{});
+        JX_LAUNCH_CHECK();
+    }
     JX_HIP(hipEventRecord(g_rot_b, st));
     g_timer_pending[1] = 1;
     return 0;

@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores: I8 row)
 F64_VALU_PEAK_TFLOPS = 78.6    # f64 vector peak (public MI355X spec; 256 CUs x 128 flop/clk x 2.4 GHz)
 
 
@@ -171,6 +172,13 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
                       f"{t_eig_block:.2f}s measured on the leading {n_eig} x {n_eig} block, scaled by (n/{n_eig})^3 = "
                       f"{eig_scale:.1f} -> {t_eig:.1f}s") + f"; null {t_null:.2f}s at full size"),
     }
+
+
+def grm_peak_tflops(i8_share):
+    """Dense MFMA peak the GRM is priced against: the exact-integer SNPs run on the int8 pipes (5 POP/s), the rest on the f16
+    pipes (2.5 PFLOP/s, three products per algorithmic product); a mixed panel is priced by the time-weighted (harmonic) mix."""
+    s = min(max(float(i8_share), 0.0), 1.0)
+    return 1.0 / (s / MFMA_I8_PEAK_TOPS + (1.0 - s) / MFMA_F16_PEAK_TFLOPS)
 
 
 def baseline_config_label(n, m):
@@ -334,6 +342,7 @@ def main():
             t1 = time.perf_counter()
             acc = pl.grm_accumulate(panel, grows, glut)
             grm_ms = lib().jxg_last_kernel_ms(0)
+            kern["grm_i8_share"] = float(lib().jxg_last_kernel_ms(12))   # SNPs on the exact int8 path / all kept SNPs
             if distributed:
                 jd.allreduce_grm_accumulator_(acc)     # f64 partial GRMs summed over xGMI (RCCL): lower-triangle tiles only
                 jd.allreduce_sum_(denom)
@@ -420,11 +429,13 @@ def main():
         grm_tf = k["grm_flops"] / max(k["grm_ms"], 1e-9) / 1e9
         rot_tf = k["rot_flops"] / max(k["rot_ms"], 1e-9) / 1e9
         L = max(1, k["launches"])
+        grm_peak = grm_peak_tflops(k.get("grm_i8_share", 0.0))
         return {"value": leg["kept_total"] * steps / leg["elapsed"], "unit": "SNPs/s", "steps": steps,
                 "ms_per_step": leg["elapsed"] / steps * 1e3, "m_kept": int(leg["kept_total"]),
                 "stages_ms_per_step": {kk: v / steps * 1e3 for kk, v in leg["stage"].items()},
-                "roofline_grm": {"bound": "mfma", "achieved": grm_tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": grm_tf / MFMA_F16_PEAK_TFLOPS, "avg_launch_ms": k["grm_ms"] / L},
+                "roofline_grm": {"bound": "mfma", "achieved": grm_tf, "peak": grm_peak, "unit": "TFLOP/s",
+                                 "frac": grm_tf / grm_peak, "int8_share": k.get("grm_i8_share", 0.0),
+                                 "avg_launch_ms": k["grm_ms"] / L},
                 "roofline_rotate": {"bound": "mfma", "achieved": rot_tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": rot_tf / MFMA_F16_PEAK_TFLOPS, "ms_per_step": k["rot_ms"] / L}}
 
@@ -445,13 +456,17 @@ def main():
         symv_gbs = kern.get("symv_mb", 0.0) / max(kern.get("symv_ms", 0.0), 1e-9)
         _PMC_SHAPE.update(n=int(n), m=int(m))
         tr_symv, tr_symv_src = pmc_traffic_bytes("jx::sytrd_symv_kernel")
-        tr_grm, tr_grm_src = pmc_traffic_bytes("jx::grm_f16x2_kernel")
         # the exact scan's kernel is chosen by n and p (jxg_last_kernel_ms(11): 0 LDS-resident, 1 tiled, 2 operands from L2)
         scan_kernel = "jx::lmm_scan_tiled_kernel" if int(lib().jxg_last_kernel_ms(11)) == 1 else "jx::lmm_scan_fast_kernel"
         tr_scan, tr_scan_src = (pmc_traffic_bytes(scan_kernel, "fetch") if args.mode == "lmm" else
                                 pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
-        mu_grm, mu_grm_src = pmc_mfma_util("grm_f16x2_kernel")
-        mu_rot, mu_rot_src = pmc_mfma_util("rotate_f16x2_kernel")
+        i8_share = kern.get("grm_i8_share", 0.0)
+        grm_kernel = "grm_i8_kernel" if i8_share >= 0.5 else "grm_f16x2_kernel"
+        grm_peak = grm_peak_tflops(i8_share)
+        tr_grm, tr_grm_src = pmc_traffic_bytes("jx::" + grm_kernel)
+        mu_grm, mu_grm_src = pmc_mfma_util(grm_kernel)
+        rot_kernel = "rotate256_kernel" if n >= 4096 else "rotate_f16x2_kernel"
+        mu_rot, mu_rot_src = pmc_mfma_util(rot_kernel)
         F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: one 2048-flop block per 64 cycles per SIMD = the f64 vector rate
         if kern.get("two_stage"):
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
@@ -495,8 +510,9 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64 (eigendecomposition on f64 MFMA, REML); f16 MFMA with f32 accumulation and f64 merge for GRM / "
-                     "rotation (exact integer operands, or fp16 hi+lo split of the f32 operands)",
+            "dtype": "f64 (eigendecomposition on f64 MFMA, REML); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
+                     "or fp16 hi+lo split of the f32 operands with f32 accumulation, f64 merge; rotation: fp16 hi+lo split, "
+                     "f32 accumulation",
             "data": "synthetic",
             "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",
@@ -508,25 +524,25 @@ def main():
                            ", eigh symv tiles sharded over ranks (one-stage tridiagonalisation below the two-stage "
                            "threshold)")},
             "roofline": roofline_main,
-            "roofline_grm": {"bound": "mfma", "kernel": "grm_f16x2_kernel (exact single-product variant when a SNP has no "
-                                                        "missing call among the selected samples, else the fp16 hi/lo "
-                                                        "three-product variant)",
-                             "achieved": grm_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": grm_tflops / MFMA_F16_PEAK_TFLOPS,
+            "roofline_grm": {"bound": "mfma", "kernel": grm_kernel + " (int8 exact-integer Gram term for SNPs without a missing "
+                                                        "call among the selected samples: v_mfma_i32_32x32x32_i8; the fp16 "
+                                                        "hi/lo three-product grm_f16x2_kernel for the rest)",
+                             "achieved": grm_tflops, "peak": grm_peak, "unit": "TFLOP/s", "int8_share": i8_share,
+                             "frac": grm_tflops / grm_peak,
                              "traffic": tr_grm, "traffic_source": tr_grm_src,
                              "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
                                              "correction, from the committed summary of this shape (null when none); "
                                              f"algorithmic input = n*m/4 = {n * m / 4e6:.1f} MB (payload "
                                              "re-read per tile pair is served by L2/MALL)",
-                             "note": "algorithmic n(n+1)m flops over the duration of the call (classification, affine "
-                                     "terms and MFMA kernels; HIP events); one f16 MFMA product per algorithmic product "
-                                     "on the exact variant, three on the split variant",
+                             "note": "algorithmic n(n+1)m flops (one int8 multiply-add = 2 ops) over the duration of the call "
+                                     "(classification, affine terms and MFMA kernels; HIP events); peak = dense int8 MFMA "
+                                     "5 POP/s for the exact-integer SNPs (one product per algorithmic product), dense f16 "
+                                     "2.5 PFLOP/s for the others (three products per algorithmic product), mixed by share",
                              "mfma_util_pmc": mu_grm, "mfma_util_source": mu_grm_src,
                              "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
-                                               "profiles/*_pmc_mfma.json): the fraction of the dense f16 MFMA peak the "
-                                               "matrix pipes actually run at",
+                                               "profiles/*_pmc_mfma.json): the fraction of time the matrix pipes are busy",
                              "avg_launch_ms": kern["grm_ms"] / L},
-            "roofline_rotate": {"bound": "mfma", "kernel": "rotate_f16x2_kernel", "achieved": rot_tflops,
+            "roofline_rotate": {"bound": "mfma", "kernel": rot_kernel, "achieved": rot_tflops,
                                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rot_tflops / MFMA_F16_PEAK_TFLOPS,
                                 "mfma_util_pmc": mu_rot, "mfma_util_source": mu_rot_src,
                                 "note": "algorithmic 2 m n^2 flops; two f16 MFMA products per algorithmic product on "

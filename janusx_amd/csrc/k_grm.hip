@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void grm_finalize_kernel(const double *__restr
 using namespace jx;
 
 namespace jx {
-float g_last_ms[16] = {0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2-3: symv sample, 4-10: eigensolver stages (eigh.cpp)
+float g_last_ms[16] = {0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2-3: symv sample, 4-10: eigensolver stages (eigh.cpp), 11: scan form, 12: int8 share of the last GRM
 int g_timer_pending[4] = {0, 0, 0, 0};
 extern hipEvent_t g_rot_a, g_rot_b;
 struct EventPair {
@@ -630,6 +630,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     JX_HIP(hipStreamSynchronize(st));
     if (hinfo[1]) return fail("jxg_grm_accumulate: design values exceed the fp16 split range (|z| > 3e4)");
     const int64_t n_exact = (int64_t)(hinfo[0] & ~63);
+    g_last_ms[12] = (i8_env && mk > 0) ? (float)((double)n_exact / (double)mk) : 0.f;   // share of the SNPs on the int8 path
     const int32_t *rows2 = rows2b.as<int32_t>();
 
     // tile shape: 256x128 (4 waves of 128x64) once there are enough tiles, else 128x128 (4 waves of 64x64)

@@ -18,7 +18,7 @@ def main():
         out = os.path.join(root, f"{tag}_bench_{label}_lmm_kernel_stats.csv")
         with open(out, "w") as fh:
             fh.write(f'"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 '
-                     f'--no-cpu-baseline (MI355X, {note}; n={n} m={m} -lmm; 3 pipeline passes incl. warmup)"\n')
+                     f'--no-cpu-baseline --no-extra (MI355X, {note}; n={n} m={m} -lmm; 3 pipeline passes incl. warmup)"\n')
             fh.write("kernel,calls,total_ns,avg_ns,pct\n")
             for r in rows:
                 fh.write('"%s",%s,%s,%s,%s\n' % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]))
@@ -35,7 +35,7 @@ def main():
     if runs:
         out = os.path.join(root, f"{tag}_pmc_hbm_traffic.json")
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (each in its own pass) -- python3 bench.py --steps 1 "
-                           f"--warmup 0 --no-cpu-baseline [--mode fvlmm for fetch_fv]; MI355X, {note} (n={n} m={m}); unit "
+                           f"--warmup 0 --no-cpu-baseline --no-extra [--mode fvlmm for fetch_fv]; MI355X, {note} (n={n} m={m}); unit "
                            "KB as reported; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide streaming reads by 2x on "
                            "gfx950 (double before comparing with bytes). Per-kernel means over dispatches "
                            "(scripts/pmc_summarize.py).", "shape": shape, "runs": runs}, open(out, "w"), indent=1)
@@ -43,8 +43,8 @@ def main():
     path = os.path.join(src, "mfma.json")
     if os.path.exists(path):
         d = json.load(open(path))
-        d["note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 "
-                     f"GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; MI355X, {note} (n={n} "
+        d["note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 "
+                     f"GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra; MI355X, {note} (n={n} "
                      f"m={m} -lmm). MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 "
                      "SIMDs). Per-kernel means over dispatches.")
         d["shape"] = shape

@@ -5,14 +5,14 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_end
 rm -rf $O; mkdir -p $O
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/stats.log 2>&1
 rm -f $O/stats/*/*kernel_trace.csv
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/fetch.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $O/fetch.log 2>&1
 python3 scripts/pmc_summarize.py $O/fetch $O/fetch.json fetch > /dev/null; rm -rf $O/fetch
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/write.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $O/write.log 2>&1
 python3 scripts/pmc_summarize.py $O/write $O/write.json write > /dev/null; rm -rf $O/write
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_fv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --mode fvlmm > $O/fetch_fv.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_fv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --mode fvlmm > $O/fetch_fv.log 2>&1
 python3 scripts/pmc_summarize.py $O/fetch_fv $O/fetch_fv.json fetch_fv > /dev/null; rm -rf $O/fetch_fv
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/mfma.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $O/mfma.log 2>&1
 python3 scripts/pmc_summarize.py $O/mfma $O/mfma.json mfma > /dev/null; rm -rf $O/mfma
 ls -la $O $O/stats/*

@@ -470,6 +470,14 @@ int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, 
                          const double *y_train, const int64_t *test_idx, int n_test, double lambda_value, double tol,
                          int max_iter, float *out_beta, double *out_pred_train, double *out_pred_test,
                          double *out_scalars);
+/* Marker-sharded form of that solve over `world` ranks (last row: SNP-range shards, one all-reduce of an
+ * n_train-vector per iteration; the reference has no distributed layer, src/math/pcg.rs:870-949 is the iteration every rank
+ * runs).  After jx_pcg_set_dist every rank calls jx_rrblup_pcg_packed with ITS range of the kept rows (payload rows, value_lut
+ * and out_beta of the shard; samples and y_train replicated): Z'p, mu'p and the three scalars of an iteration are summed over
+ * the ranks through allreduce(user), which must add the first jx_pcg_dist_count() doubles of d_staging in place on every
+ * rank; predictions and out_scalars are complete on every rank, out_beta is the shard's.  world <= 1 or allreduce NULL: off. */
+int jx_pcg_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging, int64_t staging_doubles);
+int64_t jx_pcg_dist_count(void);
 /* Exact marker-space rrBLUP on a resident payload: `rrblup_exact_snp_packed` (src/stats/rrblup.rs:3179-3490; cache
  * :1613-1899, fit :1951-2430).  A* = Z Z' - rs rs' / n_train over the training samples (f64), eigendecomposition, Brent on the
  * REML cost of the spectrum (:1568-1611) over log10 lambda in [low, high], beta = V diag(1 / (s + lambda)) V' Z y_c,

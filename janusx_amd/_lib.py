@@ -104,6 +104,8 @@ SIGNATURES = {
     "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
     "jx_spgrm_packed_to_jxgrm": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_i, c_i, C.c_char_p, c_p, c_p],
     "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
+    "jx_pcg_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l],
+    "jx_pcg_dist_count": [],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
     "jx_rrblup_exact_snp_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_p,
                                    c_p, c_p],
@@ -119,7 +121,7 @@ SIGNATURES = {
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,
              "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
-             "jx_assoc_tsv_append": C.c_int64}
+             "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64}
 
 
 def lib():

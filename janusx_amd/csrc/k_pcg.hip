@@ -120,6 +120,71 @@ using namespace jx;
 // value_lut (eff_m, 4) f32: standardised design values by 2-bit code (entry 1, the missing code, must be 0).
 // row_indices (eff_m) int64 or NULL (all m_total rows).  out_scalars: [0] converged, [1] iterations, [2] relative
 // residual, [3] sum of the centred row sums of squares (k_trace numerator), [4] intercept alpha.
+// ---- marker-sharded solve over several ranks (last row) ----------------------------------------------
+// The operator Z (Z'p) sums over markers: with the markers dealt over the ranks (contiguous ranges of the kept rows) rank r
+// holds p_r, forms its partial Z_r' p_r (an n_train-vector) and ONE all-reduce per iteration completes Z'p on every rank
+// (the implicit row-centring term mu'p rides in the same buffer); the three scalars of an iteration (p'Ap, r'r, r'z) are
+// all-reduced too, so every rank takes the same step and the same stopping decision.  `allreduce(user)` has to sum the
+// first `jx_pcg_dist_count()` doubles of `d_staging` over the ranks in place (torch.distributed: RCCL over xGMI with the
+// nccl backend; janusx_amd/dist.py).  world = 1 (the default): nothing changes.
+namespace {
+struct PcgDist {
+    int rank = 0, world = 1;
+    int (*allreduce)(void *) = nullptr;
+    void *user = nullptr;
+    double *staging = nullptr;
+    int64_t cap = 0;
+    int64_t count = 0;       // doubles of the pending collective
+};
+PcgDist g_pcg_dist;
+
+// sum `na` doubles at device pointer a (and `nb` at b, optional) over the ranks, in place
+int pcg_allreduce_dev(double *a, int64_t na, double *b, int64_t nb, hipStream_t st) {
+    PcgDist &D = g_pcg_dist;
+    if (D.world <= 1) return 0;
+    if (na + nb > D.cap) return fail("jx_pcg_set_dist: staging buffer too small for the solve");
+    JX_HIP(hipMemcpyAsync(D.staging, a, sizeof(double) * (size_t)na, hipMemcpyDeviceToDevice, st));
+    if (nb > 0) JX_HIP(hipMemcpyAsync(D.staging + na, b, sizeof(double) * (size_t)nb, hipMemcpyDeviceToDevice, st));
+    JX_HIP(hipStreamSynchronize(st));
+    D.count = na + nb;
+    if (D.allreduce(D.user)) return fail("jx_rrblup_pcg_packed: the all-reduce callback failed");
+    JX_HIP(hipMemcpyAsync(a, D.staging, sizeof(double) * (size_t)na, hipMemcpyDeviceToDevice, st));
+    if (nb > 0) JX_HIP(hipMemcpyAsync(b, D.staging + na, sizeof(double) * (size_t)nb, hipMemcpyDeviceToDevice, st));
+    JX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+// the same for a few host doubles
+int pcg_allreduce_host(double *h, int cnt, hipStream_t st) {
+    PcgDist &D = g_pcg_dist;
+    if (D.world <= 1) return 0;
+    if (cnt > D.cap) return fail("jx_pcg_set_dist: staging buffer too small");
+    JX_HIP(hipMemcpyAsync(D.staging, h, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, st));
+    JX_HIP(hipStreamSynchronize(st));
+    D.count = cnt;
+    if (D.allreduce(D.user)) return fail("jx_rrblup_pcg_packed: the all-reduce callback failed");
+    JX_HIP(hipMemcpyAsync(h, D.staging, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+    JX_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+}  // namespace
+
+extern "C" int jx_pcg_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
+                               int64_t staging_doubles) {
+    if (world <= 1 || !allreduce) {
+        g_pcg_dist = PcgDist{};
+        return 0;
+    }
+    if (rank < 0 || rank >= world || !d_staging || staging_doubles < 8) return fail("jx_pcg_set_dist: bad arguments");
+    g_pcg_dist.rank = rank;
+    g_pcg_dist.world = world;
+    g_pcg_dist.allreduce = allreduce;
+    g_pcg_dist.user = user;
+    g_pcg_dist.staging = d_staging;
+    g_pcg_dist.cap = staging_doubles;
+    return 0;
+}
+extern "C" int64_t jx_pcg_dist_count(void) { return g_pcg_dist.count; }
+
 extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
                                     int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
                                     const double *y_train, const int64_t *test_idx, int n_test, double lambda_value,
@@ -243,6 +308,8 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         b32[j] = (float)b64[j];
         bb += (double)b32[j] * (double)b32[j];
     }
+    if (pcg_allreduce_host(&bb, 1, st)) return 1;          // markers sharded over ranks: |b|^2 and the trace over all markers
+    if (pcg_allreduce_host(&sum_ss, 1, st)) return 1;
     if (!isfinite(bb)) return fail("PCG invalid RHS norm.");
     const double bnorm = sqrt(bb);
     const double denom_b = bnorm > 1e-12 ? bnorm : 1e-12;
@@ -254,6 +321,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     JX_HIP(hipMemcpyAsync(p, z, mb, hipMemcpyDeviceToDevice, st));
     double rz_old = 0.0;
     if (scalar(0, rz_old)) return 1;
+    if (pcg_allreduce_host(&rz_old, 1, st)) return 1;
     double rel_res = bnorm / denom_b;   // r = b
     if (rel_res < 0.0) rel_res = 0.0;
     bool converged = false;
@@ -267,17 +335,19 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
             JX_LAUNCH_CHECK();
             if (jxg_packed_dot_t32(t32.as<uint8_t>(), n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
+            JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
+            hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);    // mu'p
+            JX_LAUNCH_CHECK();
+            if (pcg_allreduce_dev(v64n, n_train, sc + 1, 1, st)) return 1;      // this rank's markers -> all markers
             hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
             JX_LAUNCH_CHECK();
             if (jxg_packed_tdot_f32(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
-            JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
-            hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);
-            JX_LAUNCH_CHECK();
             hipLaunchKernelGGL(pcg_finish_ap_kernel, dim3(gm), dim3(PCG_T), 0, st, v64m, p, dmu.as<float>(),
                                (float)n_train, sc + 1, lambda_use, eff_m, ap, sc + 2);
             JX_LAUNCH_CHECK();
             double denom = 0.0;
             if (scalar(2, denom)) return 1;
+            if (pcg_allreduce_host(&denom, 1, st)) return 1;
             if (!isfinite(denom) || denom <= tiny_use) break;
             const double alpha = rz_old / denom;
             if (zero_scalar(3)) return 1;
@@ -290,6 +360,12 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             double rr = 0.0, rz_new = 0.0;
             JX_HIP(hipMemcpyAsync(&rr, sc + 3, sizeof(double), hipMemcpyDeviceToHost, st));
             if (scalar(0, rz_new)) return 1;
+            {
+                double two[2] = {rr, rz_new};
+                if (pcg_allreduce_host(two, 2, st)) return 1;
+                rr = two[0];
+                rz_new = two[1];
+            }
             rel_res = sqrt(rr) / denom_b;
             if (rel_res < 0.0) rel_res = 0.0;
             iters = it + 1;
@@ -310,6 +386,11 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         volatile float t = mu[j] * out_beta[j];
         acc = acc + t;
     }
+    if (g_pcg_dist.world > 1) {      // sum over all markers (the single-rank form keeps the reference's sequential f32 sum)
+        double a64 = (double)acc;
+        if (pcg_allreduce_host(&a64, 1, st)) return 1;
+        acc = (float)a64;
+    }
     const float alpha_use = (float)y_mean - acc;
 
     // predictions: alpha + Z_samples' beta (pcg_x_mul_samples, f32 output)
@@ -317,6 +398,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     JX_LAUNCH_CHECK();
     if (out_pred_train) {
         if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+        if (pcg_allreduce_dev(v64n, n_train, nullptr, 0, st)) return 1;
         JX_HIP(hipStreamSynchronize(st));
         JX_HIP(hipMemcpy(out_pred_train, v64n, sizeof(double) * (size_t)n_train, hipMemcpyDeviceToHost));
         for (int i = 0; i < n_train; ++i) out_pred_train[i] = (double)((float)out_pred_train[i] + alpha_use);
@@ -331,6 +413,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
                            p32t.as<uint8_t>(), st))
             return 1;
         if (jxg_packed_dot(p32t.as<uint8_t>(), eff_m, n_test, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+        if (pcg_allreduce_dev(v64n, n_test, nullptr, 0, st)) return 1;
         JX_HIP(hipStreamSynchronize(st));
         JX_HIP(hipMemcpy(out_pred_test, v64n, sizeof(double) * (size_t)n_test, hipMemcpyDeviceToHost));
         for (int i = 0; i < n_test; ++i) out_pred_test[i] = (double)(float)out_pred_test[i] + (double)alpha_use;

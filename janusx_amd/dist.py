@@ -84,3 +84,46 @@ def allreduce_grm_accumulator_(acc, chunk_bytes=2 << 30):
         allreduce_sum_(buf[o:o + step])
     check(lib().jxg_tri_tiles_pack_f64(acc.data_ptr(), npad, buf.data_ptr(), 1, st))
     return acc
+
+
+_DIST_PCG = {}
+
+
+def enable_distributed_pcg(max_samples: int = 0):
+    """Marker-sharded rrBLUP PCG over the ranks of the initialised torch.distributed group (last row): after
+    this call `janusx.rrblup_pcg_bed` deals the kept SNP rows over the ranks in contiguous ranges, every rank streams its own
+    range of the payload and ONE all-reduce of an n_train-vector per iteration (RCCL over xGMI with the nccl backend; gloo
+    through host memory in the functional tests) completes Z'p; every rank returns the full result.  `max_samples`: largest
+    n_train / n_test to be solved (sizes the staging buffer; 0: 2^20).  Returns False (and switches the mode off) without a
+    multi-rank group."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import check, lib
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        check(lib().jx_pcg_set_dist(0, 1, None, None, None, 0))
+        _DIST_PCG.clear()
+        return False
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cap = max(int(max_samples), 1 << 20) + 16
+    staging = torch.zeros(cap, dtype=torch.float64, device=dev)
+
+    def _cb(_user):
+        try:
+            allreduce_sum_(staging[: int(lib().jx_pcg_dist_count())])
+            return 0
+        except Exception as e:   # noqa: BLE001 - reported through the C status
+            import sys
+            print(f"distributed PCG: all-reduce failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p)(_cb)
+    check(lib().jx_pcg_set_dist(rank, world, C.cast(cb, C.c_void_p), None, staging.data_ptr(), cap))
+    _DIST_PCG.update(cb=cb, staging=staging, rank=rank, world=world)
+    return True
+
+
+def distributed_pcg():
+    """(rank, world) of the marker-sharded PCG mode, or None when it is off."""
+    return (_DIST_PCG["rank"], _DIST_PCG["world"]) if _DIST_PCG else None

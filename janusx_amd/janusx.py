@@ -2082,10 +2082,44 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
     pred_tr_full = np.zeros(n_train, dtype=np.float64) if need_train else None
     pred_te = np.zeros(te.shape[0], dtype=np.float64)
     sc = np.zeros(8, dtype=np.float64)
-    check(lib().jx_rrblup_pcg_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
-                                     _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
-                                     int(max_iter), _p(beta), _p(pred_tr_full), _p(pred_te) if te.size else None,
-                                     _p(sc)))
+    from .dist import distributed_pcg, shard_range
+    shard = distributed_pcg()
+    if shard is not None:
+        # marker-sharded solve (dist.enable_distributed_pcg): this rank's contiguous range of the kept rows; the device layer
+        # all-reduces Z'p and the iteration's scalars, beta is gathered in rank (= row) order afterwards
+        import torch
+        import torch.distributed as tdist
+        rank, world = shard
+        lo, hi = shard_range(eff_m, rank, world)
+        if hi <= lo:
+            raise RuntimeError(f"distributed rrBLUP PCG: rank {rank} of {world} has no marker ({eff_m} kept rows)")
+        rows_all = rows if rows is not None else np.arange(m_total, dtype=np.int64)
+        pk_s = np.ascontiguousarray(pk[rows_all[lo:hi]])
+        lut_s = np.ascontiguousarray(lut[lo:hi])
+        beta_s = np.zeros(hi - lo, dtype=f32)
+        check(lib().jx_rrblup_pcg_packed(_p(pk_s), hi - lo, n_samples, None, hi - lo, _p(lut_s), _p(tr), n_train, _p(y),
+                                         _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
+                                         int(max_iter), _p(beta_s), _p(pred_tr_full), _p(pred_te) if te.size else None,
+                                         _p(sc)))
+        sizes = [shard_range(eff_m, r, world) for r in range(world)]
+        width = max(b - a for a, b in sizes)
+        pad = torch.zeros(width, dtype=torch.float32)
+        pad[: hi - lo] = torch.from_numpy(beta_s)
+        parts = [torch.zeros(width, dtype=torch.float32) for _ in range(world)]
+        if tdist.get_backend() == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            parts = [t.to(dev) for t in parts]
+            tdist.all_gather(parts, pad.to(dev))
+            parts = [t.cpu() for t in parts]
+        else:
+            tdist.all_gather(parts, pad)
+        for (a, b), t in zip(sizes, parts):
+            beta[a:b] = t[: b - a].numpy()
+    else:
+        check(lib().jx_rrblup_pcg_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
+                                         _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
+                                         int(max_iter), _p(beta), _p(pred_tr_full), _p(pred_te) if te.size else None,
+                                         _p(sc)))
     converged, iters, rel_res, sum_ss = bool(sc[0] != 0.0), int(sc[1]), float(sc[2]), float(sc[3])
     if progress_callback is not None:
         try:

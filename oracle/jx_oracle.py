@@ -1768,17 +1768,19 @@ def rrblup_value_lut(row_mean, row_inv_sd, row_flip):
     return lut
 
 
-def pcg_solve_f32(b, apply_a, inv_diag, max_iter, tol, tiny=1e-20):
+def pcg_solve_f32(b, apply_a, inv_diag, max_iter, tol, tiny=1e-20, dot=None):
     """`pcg_solve_into` for T = f32 without an initial guess (src/math/pcg.rs:870-949): vectors f32, dot products in
-    f64 (`PcgScalar for f32`, :65-90), Jacobi preconditioner (:223-245). Returns (x, converged, iters, rel_res)."""
+    f64 (`PcgScalar for f32`, :65-90), Jacobi preconditioner (:223-245). Returns (x, converged, iters, rel_res).
+    `dot` (tests only): replaces the f64 dot product, e.g. by one that sums the ranks' shares of a marker-sharded solve."""
     b = np.asarray(b, dtype=np.float32)
     m = b.shape[0]
     x = np.zeros(m, dtype=np.float32)
     if m == 0 or max_iter == 0:
         return x, m == 0, 0, 0.0
 
-    def dot(u, v):
-        return float(np.dot(u.astype(np.float64), v.astype(np.float64)))
+    if dot is None:
+        def dot(u, v):
+            return float(np.dot(u.astype(np.float64), v.astype(np.float64)))
 
     bnorm = math.sqrt(dot(b, b))
     denom_b = max(bnorm, 1e-12)

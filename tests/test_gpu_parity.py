@@ -1581,6 +1581,28 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
 
 
 @pytest.mark.gpu
+def test_marker_sharded_pcg_two_ranks_share_one_gpu():
+    """rrBLUP PCG with the markers dealt over two ranks (jx_pcg_set_dist: one all-reduce of an n_train-vector per iteration,
+    SURVEY.md 8e last row), two ranks on the one device over gloo: same iterations (+-1), beta and predictions as the
+    single-rank solve, identical on both ranks (scripts/dist_pcg_check.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", "dist_pcg_check.py"), "1500", "6000"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_PCG_OK" in out.stdout and "ranks_identical=True" in out.stdout
+
+
+@pytest.mark.gpu
 def test_distributed_eigh_rccl_callback_single_rank():
     """The per-column all-reduce of the rank-sharded tridiagonalisation through RCCL (nccl backend) with one rank:
     JXGPU_DIST_EIGH_FORCE runs the distributed kernel instantiation and the torch.distributed callback on the one-GPU

@@ -659,8 +659,18 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                            corrb.as<double>() + ld);
         JX_LAUNCH_CHECK();
     }
+    // split (three-product) path with 256 x 256 tiles, 8 waves, two image sets (one barrier per 32-SNP step): measured
+    // SLOWER than the 128 x 128 kernel at 4 workgroups per CU (235 vs 223 ms at n = 20000, m = 200000 with 1 % missing
+    // calls; round 3) -- kept behind JXGPU_GRM_TILE=257 for comparison only.
+    const int nt256 = (nt + 1) / 2;
+    const int64_t tiles256 = (int64_t)nt256 * (nt256 + 1) / 2;
+    const bool split256 = !panel && tile_env == 257;
     auto launch = [&](bool exact, dim3 grid, int64_t kb, int64_t ke, int kc, int atomic, const double *corr) {
-        if (exact && big)
+        if (!exact && split256)
+            hipLaunchKernelGGL((grm_f16x2_kernel<256, 256, 128, 64, true, false, 32>), dim3((unsigned)tiles256, grid.y),
+                               dim3(512), 0, st, d_p32, m_total, rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic,
+                               corr, 0);
+        else if (exact && big)
             hipLaunchKernelGGL((grm_f16x2_kernel<256, 128, 128, 64, false, true>), grid, dim3(256), 0, st, d_p32, m_total,
                                rows2, lut16.as<uint4>(), kb, ke, kc, nt, d_acc, ld, atomic, corr, (int)tile_base);
         else if (exact)
@@ -690,7 +700,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
         const double *corr = exact ? corrb.as<double>() : nullptr;
         // Few tiles: spread SNP chunks over blockIdx.y with f64 atomics so the chip is filled.
         // Many tiles: one launch per chunk, the owning workgroup does a plain f64 read-modify-write.
-        const bool atomic_mode = ntiles < 2 * slots && cnt > 2048;
+        const bool atomic_mode = ntiles < 2 * slots && cnt > 2048 && !(split256 && !exact);
         if (atomic_mode) {
             // shrink chunks if that is what it takes to reach ~2 rounds of resident workgroups
             int64_t want = (2 * slots + ntiles - 1) / ntiles;

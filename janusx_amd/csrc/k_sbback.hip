@@ -17,6 +17,12 @@
 namespace jx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// slab layout: element (row, column cc of the slab's w columns) of a slab that starts at `base`
+__host__ __device__ __forceinline__ int64_t qr_slab_at(int row, int cc, int w) {
+    return (int64_t)(row >> 1) * (2 * w) + 2 * cc + (row & 1);
+}
 
 constexpr int QB_SB = 64;                  // band width (= SB of k_sy2sb.hip / BC_SB of k_sb2st.hip)
 constexpr int QB_G = 32;                   // sweeps per group
@@ -50,7 +56,9 @@ struct QrParams {
     const double *v2;       // (n, n): column s = reflectors of sweep s by matrix row
     const double *tau2;     // (n, ks)
     double *vu;             // blocks ((grp - g_lo) * ks + k): V image then U image, QR_BLK doubles each
-    double *ct;             // C in slab layout: [slab][row][16 NU columns] (sbback_slab_kernel), zero-padded columns
+    double *ct;             // C in slab layout: [slab][row pair][16 NU columns][2 rows] (sbback_slab_kernel), zero-padded
+                            // columns: the rows 2 j, 2 j + 1 of a column are adjacent, so a lane's two rows of a register
+                            // pair are ONE 16-byte access (8-byte accesses reach 0.54-0.70 of the 16-byte rate on this part)
     int n, ks, ncols;
     int units;              // 16-column units of C; slab b of the gridDim.x slabs holds the units [b units / G, (b+1) units / G)
     int g_lo, g_hi;         // groups [g_lo, g_hi) of this launch (applied from g_hi - 1 down)
@@ -214,7 +222,8 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
     // slab layout: the rows of this workgroup's 16 NU columns are contiguous (one row = 128 NU bytes), so a workgroup streams
     // through memory linearly (one read and one write stream per workgroup instead of one per column)
     constexpr int W = NU * 16;
-    double *cp = P.ct + (int64_t)blockIdx.x * n * W + unit * 16 + lx;
+    const int n2 = (n + 1) & ~1;                               // rows of a slab (row pairs)
+    double *cp = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (unit * 16 + lx);   // row pair j of this lane's column: cp + j 2 W
     const int rm_a = 8 * (lx >> 3) + 2 * (lx & 3) + ((lx >> 2) & 1);      // A-operand row lx of a 16-row block -> window row
 
     // chunk rows rb + [0, 32): register (h, r) <-> row rb + 16 h + 8 (r >> 1) + 2 lk + (r & 1).  The load is branch-free
@@ -224,52 +233,48 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
     // stores of the finished chunk (the memory counter retires in issue order and hipcc assumes the fewest operations
     // behind a load), and a store acknowledgement under write-back pressure takes longer than a block.  chunk_wait is the
     // only wait for them: vmcnt(8) when exactly eight stores were issued behind the loads, else vmcnt(0).
-    auto chunk_load = [&](int rb, double (&raw)[8]) {
+    // (rb is even: group starts, chunk and window offsets are multiples of 32, so a register pair (2 q, 2 q + 1) is the row
+    // pair (rb + 8 q + 2 lk) / 2 of the slab: four 16-byte accesses per chunk, 4 row pairs x 256 bytes per instruction)
+    auto chunk_load = [&](int rb, d2 (&raw)[4]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
-            const double *src = cp + (int64_t)min(row, n - 1) * W;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(raw[i]) : "v"(src) : "memory");
+        for (int q = 0; q < 4; ++q) {
+            const int row = rb + 8 * q + 2 * lk;
+            const double *src = cp + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[q]) : "v"(src) : "memory");
         }
     };
-    auto chunk_wait = [&](bool eight_stores_behind, double (&raw)[8]) {
-        if (eight_stores_behind)
-            asm volatile("s_waitcnt vmcnt(8)"
-                         : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7])
-                         :
-                         : "memory");
+    auto chunk_wait = [&](bool four_stores_behind, d2 (&raw)[4]) {
+        if (four_stores_behind)
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
         else
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7])
-                         :
-                         : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
     };
-    auto chunk_unpack = [&](int rb, const double (&raw)[8], d4 (&reg)[2]) {
+    auto chunk_unpack = [&](int rb, const d2 (&raw)[4], d4 (&reg)[2]) {
         const bool inside = rb + 32 <= n;                      // whole chunk inside the matrix (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
-            reg[i >> 2][i & 3] = (inside || row < n) ? raw[i] : 0.0;
+            reg[i >> 2][i & 3] = (inside || row < n) ? raw[i >> 1][i & 1] : 0.0;
         }
     };
     auto chunk_store = [&](int rb, const d4 (&reg)[2]) {
         if (rb + 32 <= n) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                double *dst = cp + (int64_t)(rb + 8 * (i >> 1) + 2 * lk + (i & 1)) * W;
-                *dst = reg[i >> 2][i & 3];
+            for (int q = 0; q < 4; ++q) {
+                d2 v = {reg[q >> 1][2 * (q & 1)], reg[q >> 1][2 * (q & 1) + 1]};
+                *reinterpret_cast<d2 *>(cp + (int64_t)((rb + 8 * q + 2 * lk) >> 1) * (2 * W)) = v;
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
-            if (row < n) cp[(int64_t)row * W] = reg[i >> 2][i & 3];
+            if (row < n) cp[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[i >> 2][i & 3];
         }
     };
 
     d4 cw[2];
-    double pf[8];
+    d2 pf[4];
     for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
         const int s0 = grp * QB_G;
         if (s0 + 1 >= n) continue;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
         chunk_load(s0 + 32 * j, pf);
         chunk_wait(false, pf);
         chunk_unpack(s0 + 32 * j, pf, cw);
-        bool stored8 = false;                                  // exactly eight stores were issued behind the last prefetch
+        bool stored8 = false;                                  // exactly four stores were issued behind the last prefetch
         qr_lds_barrier();                                      // G1: the images of block 0 are in place
         int w = j;                                             // position of this wave's chunk in the window: (j + k) mod 3
         for (int k = 0; k < nk; ++k) {
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c
     extern __shared__ double slab_tile[];                      // [64][w + 1]
     const int r0 = blockIdx.x * 64, slab = blockIdx.y;
     const int t = threadIdx.x;
-    const int64_t base = (int64_t)slab * n * w;
+    const int64_t base = (int64_t)slab * ((n + 1) & ~1) * w;
     // columns of this slab: units [ub, ub + nb) of C, the rest of the w columns is padding
     const int ub = (int)((int64_t)slab * units / gridDim.y);
     const int wv = ((int)((int64_t)(slab + 1) * units / gridDim.y) - ub) * 16;
@@ -368,12 +373,12 @@ __global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c
         __syncthreads();
         for (int e = t; e < 64 * w; e += 256) {
             const int r = e / w, cc = e % w;
-            if (r0 + r < n) ct[base + (int64_t)(r0 + r) * w + cc] = slab_tile[r * (w + 1) + cc];
+            if (r0 + r < n) ct[base + qr_slab_at(r0 + r, cc, w)] = slab_tile[r * (w + 1) + cc];
         }
     } else {
         for (int e = t; e < 64 * w; e += 256) {
             const int r = e / w, cc = e % w;
-            slab_tile[r * (w + 1) + cc] = (r0 + r < n) ? ct[base + (int64_t)(r0 + r) * w + cc] : 0.0;
+            slab_tile[r * (w + 1) + cc] = (r0 + r < n) ? ct[base + qr_slab_at(r0 + r, cc, w)] : 0.0;
         }
         __syncthreads();
         for (int e = t; e < 64 * w; e += 256) {
@@ -424,7 +429,7 @@ size_t sbback_tq_doubles(int n, int ks) {
     int g, nu;
     qr_plan(n, &g, &nu);
     const size_t padded = std::max((size_t)g * nu * 16, (size_t)n + 96);
-    return (size_t)qr_groups_per_launch(n, ks) * ks * 2 * QR_BLK + padded * (size_t)n;
+    return (size_t)qr_groups_per_launch(n, ks) * ks * 2 * QR_BLK + padded * (size_t)(n + 1);
 }
 
 static int device_cus() {

@@ -68,6 +68,54 @@ def read_bed_payload(prefix):
     return packed, n, bim
 
 
+def stage_bed_payload(prefix, mmap_window_mb=None, device=None):
+    """PLINK .bed payload -> (m, bps) uint8 tensor in HBM, staged window by window: the counterpart of the reference's
+    `WindowedBedMatrix` (src/io/gload.rs:523-640; `mmap_window_mb` of src/stats/lmm.rs:2488-2520, :1046-1049: windows of
+    that many MiB of the file instead of one mapping of all of it).  The file is read `mmap_window_mb` MiB at a time (default
+    256) into two pinned staging buffers that alternate, each window copied to its rows of the device tensor while the next
+    one is read: no host copy of the payload exists beyond the two windows (BASELINE configs[4] is 50 GB packed), and the
+    host-layer entry points take the device tensor in place.  -> (tensor, n_samples, Bim)."""
+    import torch
+    ids = read_fam_ids(prefix)
+    n = len(ids)
+    bim = read_bim(prefix)
+    m = len(bim.snp)
+    bps = (n + 3) // 4
+    path = f"{prefix}.bed"
+    if mmap_window_mb is not None and int(mmap_window_mb) <= 0:
+        raise RuntimeError("mmap_window_mb must be > 0")
+    with open(path, "rb") as fh:
+        if fh.read(3) != BED_MAGIC:
+            raise RuntimeError(f"{path}: not a SNP-major PLINK .bed (bad magic)")
+        size = os.path.getsize(path)
+        if size != 3 + m * bps:
+            raise RuntimeError(f"{path}: size {size} != 3 + {m}*{bps}")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        out = torch.empty((m, bps), dtype=torch.uint8, device=dev)
+        if m == 0:
+            return out, n, bim
+        win_rows = max(1, (int(mmap_window_mb or 256) << 20) // max(bps, 1))
+        win_rows = min(win_rows, m)
+        bufs = [torch.empty((win_rows, bps), dtype=torch.uint8).pin_memory() for _ in range(2 if m > win_rows else 1)]
+        events = [None] * len(bufs)
+        stream = torch.cuda.current_stream(dev)
+        for w, r0 in enumerate(range(0, m, win_rows)):
+            r1 = min(m, r0 + win_rows)
+            b = bufs[w % len(bufs)]
+            if events[w % len(bufs)] is not None:
+                events[w % len(bufs)].synchronize()           # the copy out of this buffer has finished
+            view = b[: r1 - r0].numpy().reshape(-1)
+            got = fh.readinto(memoryview(view))
+            if got != (r1 - r0) * bps:
+                raise RuntimeError(f"{path}: short read ({got} of {(r1 - r0) * bps} bytes)")
+            out[r0:r1].copy_(b[: r1 - r0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            events[w % len(bufs)] = ev
+        stream.synchronize()
+    return out, n, bim
+
+
 def snps_only_mask(bim: Bim):
     """Both alleles single A/C/G/T (src/io/gfreader.rs:7013-7019)."""
     ok = set("ACGTacgt")

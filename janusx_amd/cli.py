@@ -198,7 +198,11 @@ def cmd_gwas(args):
         args.splmm = float(args.splmm_exact)
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
         raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm, -splmm and/or -splmm-exact")
-    packed, n_fam, bim = read_bed_payload(args.bfile)
+    # the payload goes to HBM in windows (bed.stage_bed_payload: `mmap_window_mb` of the reference's BED routes); nothing
+    # below holds a host copy of it
+    from .bed import stage_bed_payload
+    packed_t, n_fam, bim = stage_bed_payload(args.bfile, getattr(args, "mmap_window_mb", None))
+    packed = packed_t
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
     pos = {s: i for i, s in enumerate(ids)}
@@ -208,8 +212,7 @@ def cmd_gwas(args):
         cpos = {s: i for i, s in enumerate(cids)}
     traits = _select_traits(names, args.ncol)
     out = args.out or args.bfile
-    dev = torch.device("cuda", 0)
-    packed_t = torch.from_numpy(np.array(packed, dtype=np.uint8, copy=True)).to(dev)
+    dev = packed_t.device
     t0 = time.perf_counter()
     dense_models = args.lmm or args.fvlmm or args.lmm2
     k = None
@@ -519,6 +522,8 @@ def main(argv=None):
     g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
     g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
     g.add_argument("-c", "--cov", dest="cov", default=None)
+    g.add_argument("-mmap-window-mb", "--mmap-window-mb", dest="mmap_window_mb", type=int, default=None,
+                   help="stage the .bed payload to the device in windows of this many MiB (default 256)")
     g.add_argument("-maf", "--maf", type=float, default=0.02)
     g.add_argument("-geno", "--geno", type=float, default=0.05)
     g.add_argument("-het", "--het", type=float, default=1.0)

@@ -246,7 +246,9 @@ def spgrm_bed_to_jxgrm(prefix, out_prefix=None, sample_indices=None, method=1, t
         bed_prefix = bed_prefix[:-4]
     if not bed_prefix:
         raise RuntimeError("Sparse GRM BED prefix must not be empty")
-    packed, n_fam, bim = read_bed_payload(bed_prefix)
+    import torch
+    from .bed import stage_bed_payload
+    packed, n_fam, bim = stage_bed_payload(bed_prefix, mmap_window_mb)      # windowed staging to HBM, used in place
     if n_fam == 0:
         raise RuntimeError("No samples found in BED input.")
     idx, n_sel = _opt_idx(sample_indices)
@@ -261,7 +263,9 @@ def spgrm_bed_to_jxgrm(prefix, out_prefix=None, sample_indices=None, method=1, t
     if not keep.any():
         raise RuntimeError("No SNPs left after packed BED filtering. Please relax thresholds.")
     rows = np.nonzero(keep)[0]
-    out = _spgrm_packed(np.ascontiguousarray(packed[rows]), n_fam, np.zeros(len(rows), dtype=bool), maf[rows],
+    pk = packed if len(rows) == int(packed.shape[0]) else packed[torch.from_numpy(rows).to(packed.device)]
+    del packed
+    out = _spgrm_packed(pk, n_fam, np.zeros(len(rows), dtype=bool), maf[rows],
                         out_prefix if out_prefix is not None else bed_prefix,
                         idx if (idx is not None and n_sel) else None, method, threshold, abs_threshold, True)
     if progress_callback is not None:
@@ -920,6 +924,12 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     return out.cpu().numpy(), float(log10_lambda), null
 
 
+def _bed_prefix(prefix):
+    """PLINK prefix with a trailing .bed / .bim / .fam removed (`normalize_plink_prefix`, src/io/gfcore.rs)."""
+    t = str(prefix).strip()
+    return t[:-4] if t.lower().endswith((".bed", ".bim", ".fam")) else t
+
+
 def _read_bed_payload(prefix):
     """PLINK .bed payload as (m, bps) uint8 plus n_samples (src/stats/lmm.rs:1050-1061, gfcore.rs:307-323)."""
     from .bed import read_bed_payload
@@ -969,26 +979,27 @@ def grm_packed_bed_f32(prefix, method=1, maf_threshold=0.02, max_missing_rate=0.
 def grm_stream_bed_f32(prefix, method=1, maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0,
                        snps_only=False, block_cols=65536, threads=0, progress_callback=None, progress_every=0,
                        mmap_window_mb=None):
-    """src/stats/grm.rs:4676-4703 -> (f32 (n,n), eff_m, n_samples)."""
-    packed, n_samples, bim = _read_bed_payload(prefix)
+    """src/stats/grm.rs:4676-4703 -> (f32 (n,n), eff_m, n_samples).  The payload is staged to HBM in windows of
+    `mmap_window_mb` MiB (bed.stage_bed_payload: the reference's WindowedBedMatrix role); no host copy of it is made."""
+    import torch
+    from .bed import snps_only_mask, stage_bed_payload
+    packed, n_samples, bim = stage_bed_payload(_bed_prefix(prefix), mmap_window_mb)
     if snps_only:
-        from .bed import snps_only_mask
-        packed = np.ascontiguousarray(packed[snps_only_mask(bim)])
+        packed = packed[torch.from_numpy(np.nonzero(snps_only_mask(bim))[0]).to(packed.device)]
     k, eff, _ = grm_stream_payload_f32(packed, n_samples, method, maf_threshold, max_missing_rate, het_threshold)
-    _done(progress_callback, packed.shape[0])
+    _done(progress_callback, int(packed.shape[0]))
     return k, int(eff), int(n_samples)
 
 
 def grm_stream_payload_f32(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
                            het_threshold=0.0):
-    """In-memory form of `grm_stream_bed_f32` -> (K f32, eff_m, keep mask)."""
-    packed = _c(packed, np.uint8)
-    m = int(packed.shape[0])
+    """In-memory form of `grm_stream_bed_f32` -> (K f32, eff_m, keep mask); `packed`: host array or device tensor."""
     n = int(n_samples)
+    _pk, pk_ptr, m = _payload(packed, n)
     out = np.empty((n, n), dtype=np.float32)
     eff = np.zeros(1, dtype=np.int64)
     keep = np.zeros(m, dtype=np.uint8)
-    check(lib().jx_grm_stream_payload_f32(_p(packed), m, n, int(method), float(maf_threshold),
+    check(lib().jx_grm_stream_payload_f32(pk_ptr, m, n, int(method), float(maf_threshold),
                                           float(max_missing_rate), float(het_threshold), _p(out), _p(eff), _p(keep)))
     return out, int(eff[0]), keep.astype(bool)
 
@@ -997,7 +1008,8 @@ def grm_stream_bed_f32_to_npy(prefix, out_path, method=1, maf_threshold=0.02, ma
                               het_threshold=0.0, snps_only=False, block_cols=65536, threads=0,
                               progress_callback=None, progress_every=0, mmap_window_mb=None):
     """src/stats/grm.rs:5517-5545: writes NPY v1 f32 C-order, returns (eff_m, n_samples)."""
-    k, eff, n = grm_stream_bed_f32(prefix, method, maf_threshold, max_missing_rate, het_threshold, snps_only)
+    k, eff, n = grm_stream_bed_f32(prefix, method, maf_threshold, max_missing_rate, het_threshold, snps_only,
+                                   mmap_window_mb=mmap_window_mb)
     tmp = f"{out_path}.tmp.{os.getpid()}"
     with open(tmp, "wb") as fh:
         np.lib.format.write_array(fh, np.ascontiguousarray(k, dtype=np.float32), version=(1, 0))
@@ -1174,11 +1186,14 @@ def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_i
 def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
                   low, high, max_iter, tol, warm, init, nullml=None, progress_callback=None, progress_every=0):
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
-    packed = _c(packed, np.uint8)
     if row_indices is not None:
         ri = np.asarray(row_indices, dtype=np.int64)
-        packed = np.ascontiguousarray(packed[ri])
-    m = int(packed.shape[0])
+        if _is_device_tensor(packed):
+            import torch
+            packed = packed[torch.from_numpy(ri).to(packed.device)]
+        else:
+            packed = np.ascontiguousarray(_c(packed, np.uint8)[ri])
+    packed, pk_ptr, m = _payload(packed, n_samples)           # host array or device tensor
     flip = _c(np.asarray(row_flip).astype(np.uint8), np.uint8).ravel()
     maf = _c(row_maf, np.float32).ravel()
     u_t = _c(u_t, np.float32)
@@ -1190,7 +1205,7 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
     out = np.zeros((m, 6 if int(model) == 2 else (4 if nullml is not None else 3)), dtype=np.float64)
     with _progress_hook(progress_callback, progress_every):
-        check(lib().jx_assoc_packed(_p(packed), m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
+        check(lib().jx_assoc_packed(pk_ptr, m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
                                     _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
                                     int(warm), float(init), 1 if nullml is not None else 0,
                                     float(nullml if nullml is not None else 0.0), _p(out)))
@@ -1278,9 +1293,10 @@ def bed_row_counts(packed, n_samples, sample_indices=None):
 
 def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model, snps_only,
                      sample_ids, row_indices, row_flip, row_missing, row_maf, mode, low, high, max_iter, tol, nullml,
-                     init_log10_lbd, progress_callback, progress_every=0):
+                     init_log10_lbd, progress_callback, progress_every=0, mmap_window_mb=None):
+    import torch
     from . import stats as st
-    from .bed import read_bed_payload, read_fam_ids, snps_only_mask
+    from .bed import read_fam_ids, snps_only_mask, stage_bed_payload
     from .tsv import write_assoc_tsv
     if str(genetic_model) != "add":
         raise RuntimeError(f"unsupported genetic model '{genetic_model}' (only 'add' is built)")
@@ -1289,9 +1305,11 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
     s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
     if n <= p + 1:
         raise RuntimeError("n must be > p+1")
-    packed, n_fam, bim = read_bed_payload(bed_prefix)
+    # payload staged to HBM in windows of `mmap_window_mb` MiB (the reference's WindowedBedMatrix role); the counts, the row
+    # gather and the scan below take the device tensor in place
+    packed, n_fam, bim = stage_bed_payload(_bed_prefix(bed_prefix), mmap_window_mb)
     if sample_ids is not None:
-        fam = read_fam_ids(bed_prefix)
+        fam = read_fam_ids(_bed_prefix(bed_prefix))
         pos = {sid: i for i, sid in enumerate(fam)}
         try:
             sidx = np.array([pos[str(x)] for x in sample_ids], dtype=np.int64)
@@ -1320,7 +1338,9 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
         flip = np.zeros(len(rows), dtype=bool)
         af = af_all[rows]
         miss = miss_all[rows]
-    pk = np.ascontiguousarray(packed[rows])
+    pk = packed if len(rows) == m and np.array_equal(rows, np.arange(m)) else \
+        packed[torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(packed.device)]
+    del packed
     if mode == "lmm":
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
@@ -1358,7 +1378,7 @@ def lmm_reml_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_
         raise RuntimeError("tol must be positive and finite")
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm", low, high,
-                            max_iter, tol, nullml, init_log10_lbd, progress_callback, progress_every)
+                            max_iter, tol, nullml, init_log10_lbd, progress_callback, progress_every, mmap_window_mb)
 
 
 def lmm_reml_lmm2_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, nullml, max_iter=50, tol=1e-2,
@@ -1413,7 +1433,7 @@ def lmm_reml_lmm2_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t,
     init_scan = init_log10_lbd_reml if init_log10_lbd_reml is not None else init_log10_lbd_ml
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm2", low, high,
-                            max_iter, tol, nullml_val, init_scan, progress_callback, progress_every)
+                            max_iter, tol, nullml_val, init_scan, progress_callback, progress_every, mmap_window_mb)
 
 
 def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u_t, maf_thr, miss_thr, het_thr,
@@ -1423,7 +1443,7 @@ def fvlmm_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, log10_lbd, u
     """src/stats/fvlmm.rs:2482-2526 (the default `jx gwas -fvlmm` kernel call) -> (rows, pve, log_det_v)."""
     rows = _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "fvlmm",
-                            float(log10_lbd), None, 0, 1e-2, nullml, None, progress_callback, progress_every)
+                            float(log10_lbd), None, 0, 1e-2, nullml, None, progress_callback, progress_every, mmap_window_mb)
     s_ = np.asarray(s, dtype=np.float64).ravel()
     lbd = 10.0 ** float(log10_lbd)
     vg = float(np.mean(np.clip(s_, 0.0, None)))

@@ -778,6 +778,38 @@ def test_c5_shaped_splmm_device_panel():
     assert d["host_maxrss_gib"] < 8.0 and d["host_rss_growth_gib"] < 4.0, d
 
 
+def test_bed_payload_is_staged_in_windows(oracle, tmp_path):
+    """`mmap_window_mb` (src/io/gload.rs WindowedBedMatrix; src/stats/lmm.rs:2488-2520): the BED routes stage the payload to
+    HBM window by window -- several windows (1 MiB each here) give the same device payload as the file, the same GRM and the
+    same TSV as one window; a non-positive window is refused like the reference does."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    n, m = 2100, 5000                                   # 525 bytes per SNP: 1997 rows per 1 MiB window -> 3 windows
+    packed, g = bed.synth_panel_numpy(n, m, seed=21, missing_rate=0.01)
+    prefix = str(tmp_path / "w")
+    ids = [f"s{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    dev_pk, n_f, _bim = bed.stage_bed_payload(prefix, 1)
+    assert n_f == n and np.array_equal(dev_pk.cpu().numpy(), packed)
+    with pytest.raises(RuntimeError, match="mmap_window_mb must be > 0"):
+        bed.stage_bed_payload(prefix, 0)
+    k1, eff1, _ = jxrs.grm_stream_bed_f32(prefix, mmap_window_mb=1)
+    k2, eff2, _ = jxrs.grm_stream_bed_f32(prefix)
+    k3, eff3, _keep = jxrs.grm_stream_payload_f32(packed, n)
+    assert eff1 == eff2 == eff3 and np.array_equal(k1, k2) and np.array_equal(k1, k3)
+    y = bed.synth_phenotype(g, n_causal=10, pve=0.5, seed=3)
+    s, u = oracle.gwas_eigh_from_grm(k3.astype(np.float64))
+    nm = oracle.spectral_null_model(y, np.ones((n, 1)), s, u)
+    outs = []
+    for tag, win in (("a", 1), ("b", None)):
+        path = str(tmp_path / f"{tag}.tsv")
+        rows = jxrs.fvlmm_assoc_bed_to_tsv_f32(prefix, path, nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null), nm.Dh, 0.02, 0.05,
+                                               1.0, mmap_window_mb=win)[0]
+        outs.append((rows, open(path).read()))
+    assert outs[0] == outs[1] and outs[0][0] > 4000
+
+
 def test_device_resident_payload_entry_points(oracle, tmp_path):
     """The host-layer entry points take a payload that already lives in HBM (torch CUDA tensor) in place: same counts, same
     sparse GRM file bytes and the same scan table as with the numpy array; a host array too large to stage is refused

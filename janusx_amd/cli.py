@@ -17,7 +17,7 @@ Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP 
 python/janusx/gs/workflow.py:9122) are built; VCF/HMP readers, PCs (-q), plots, the history DB, the
 other GS model families are out of scope; `-rrBLUP` runs the exact marker-space route (`rrblup_exact_snp_packed`, REML
 lambda from the spectrum) up to 15 000 kept markers and the PCG route (`rrblup_pcg_bed`, HE / manual / subsample-REML
-lambda) beyond, `-rr-solver exact|pcg` forces one.
+lambda) beyond, `-rr-solver exact|fast|pcg` forces one (fast = exact sample-space route for n_train <= 10 000).
 """
 from __future__ import annotations
 
@@ -414,17 +414,36 @@ def cmd_gs_rrblup(args):
     packed, miss, maf, _std, n_all = jxrs.load_bed_2bit_packed(args.bfile)
     flip = jxrs.bed_packed_row_flip_mask(packed, n_all)
     keep = (maf >= np.float32(args.maf)) & (miss <= np.float32(args.geno))
-    # solver choice of the reference (`_resolve_rrblup_solver`, python/janusx/gs/workflow.py:5230-5255): up to 15 000 markers
-    # the exact marker-space route (REML lambda from the spectrum); beyond that PCG for n_train > 10 000 -- and here also
-    # for smaller n_train, where the reference takes its sample-space exact route (not built)
+    # solver choice of the reference (`_resolve_rrblup_solver` + `_resolve_rrblup_exact_backend`, python/janusx/gs/workflow.py:
+    # 5230-5276): up to 15 000 markers the exact marker-space route ("snp": REML lambda from the m x m spectrum); beyond that
+    # the exact SAMPLE-space route ("fast": REML on the spectrum of the n x n kernel of the standardised markers) while the
+    # phenotyped samples number at most 10 000, PCG above
     solver = args.rr_solver
-    if solver == "exact" and args.lam is not None:
-        raise SystemExit("-lambda needs -rr-solver pcg: the exact marker-space route estimates lambda by REML on the spectrum "
-                         "and would ignore the given value")
+    if solver in ("exact", "fast") and args.lam is not None:
+        raise SystemExit("-lambda needs -rr-solver pcg: the exact routes estimate lambda by REML on the spectrum and would "
+                         "ignore the given value")
+    n_pheno_max = max((int(np.isfinite([ph[pos[s], ti] if s in pos else np.nan for s in fam]).sum()) for ti in traits), default=0)
     if solver == "auto":
-        # a given -lambda only exists on the PCG route (the exact route re-estimates it): honour it
-        solver = "pcg" if args.lam is not None else ("exact" if int(keep.sum()) <= 15000 else "pcg")
+        # a given -lambda only exists on the PCG route (the exact routes re-estimate it): honour it
+        if args.lam is not None:
+            solver = "pcg"
+        elif int(keep.sum()) <= 15000:
+            solver = "exact"
+        else:
+            solver = "fast" if n_pheno_max <= 10000 else "pcg"
     print(f"rrBLUP-{solver.upper()}: n={n_all} m={packed.shape[0]} kept={int(keep.sum())} (maf {args.maf}, geno {args.geno})")
+    k_std = None
+    if solver == "fast":
+        # sample-space exact route (the reference's "fast" backend: pyBLUP.BLUP on the implicit kinship of the standardised
+        # markers, python/janusx/pyBLUP/mlm.py): ridge regression on Z is GBLUP on K = Z'Z / m_eff with lambda_equation =
+        # m_eff * sigma_e^2 / sigma_g^2.  K over ALL genotyped samples once (global allele frequencies, like the marker-space
+        # routes), then per fit eigendecomposition of K[train, train] + Brent on its spectrum + K[test, train] alpha
+        # (`gblup_reml_grm`: the kernels of the `-BLUP` branch)
+        p_std = np.clip(maf[keep], 0.0, 0.5)
+        m_eff_std = int(np.count_nonzero(2.0 * p_std * (1.0 - p_std) > 1e-12))
+        t0k = time.perf_counter()
+        k_std = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], None, method=2)
+        print(f"standardised kernel of {n_all} samples over {m_eff_std} markers ({time.perf_counter() - t0k:.2f}s)")
     for ti in traits:
         name = names[ti]
         yv = np.array([ph[pos[s], ti] if s in pos else np.nan for s in fam])
@@ -434,7 +453,7 @@ def cmd_gs_rrblup(args):
             print(f"[{name}] only {len(train)} phenotyped samples, skipped")
             continue
         t1 = time.perf_counter()
-        if solver == "exact":
+        if solver in ("exact", "fast"):
             lam, src = None, "REML on the spectrum"
         elif args.lam is not None:
             lam, src = float(args.lam), "manual"
@@ -453,7 +472,7 @@ def cmd_gs_rrblup(args):
                     lam, src = None, "HE on the boundary"
         else:
             lam, src = None, ""
-        if lam is None and solver != "exact":
+        if lam is None and solver == "pcg":
             rng = np.random.default_rng(args.seed)
             sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
             ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
@@ -467,6 +486,10 @@ def cmd_gs_rrblup(args):
         pred = np.full(n_all, np.nan)
 
         def fit_predict(tr, te):
+            if solver == "fast":
+                r = jxrs.gblup_reml_grm(k_std, tr, yv[tr], te if len(te) else None, return_variance_components=True)
+                # (pred_train, pred_test, pve, lambda_k, ml, reml, ..., sigma_g2, sigma_e2): same slots as the marker-space fit
+                return (r[0], r[1], r[2], float(r[3]) * float(m_eff_std), r[5], (r[9], r[10]), m_eff_std)
             if solver == "exact":
                 return jxrs.rrblup_exact_snp_packed(packed, n_all, tr, yv[tr], te if len(te) else None, site_keep=keep,
                                                     maf=maf, row_flip=flip)
@@ -499,8 +522,8 @@ def cmd_gs_rrblup(args):
                 obs = "NA" if not math.isfinite(yv[j]) else f"{yv[j]:.6g}"
                 fh.write(f"{sid}\t{obs}\t{pred[j]:.6g}\t{'NA' if fold[j] < 0 else fold[j]}\n")
         os.replace(tmp, path)
-        if solver == "exact":
-            print(f"[{name}] rrBLUP-EXACT: n_train={len(train)} n_pred={len(test)} lambda={full[3]:.5g} [{src}] "
+        if solver in ("exact", "fast"):
+            print(f"[{name}] rrBLUP-{'EXACT' if solver == 'exact' else 'FAST (sample space)'}: n_train={len(train)} n_pred={len(test)} lambda={full[3]:.5g} [{src}] "
                   f"reml={full[4]:.6g} var_g={full[5][0]:.5g} sigma_e2={full[5][1]:.5g} m_effective={full[6]} "
                   f"pve={full[2]:.4f} -> {path} ({time.perf_counter() - t1:.2f}s)")
         else:
@@ -555,7 +578,7 @@ def main(argv=None):
     q.add_argument("-BLUP", "--BLUP", dest="blup", action="store_true", default=False)
     q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
     q.add_argument("-rrBLUP", "--rrBLUP", dest="rrblup", action="store_true", default=False)
-    q.add_argument("-rr-solver", "--rr-solver", dest="rr_solver", choices=["auto", "exact", "pcg"], default="auto",
+    q.add_argument("-rr-solver", "--rr-solver", dest="rr_solver", choices=["auto", "exact", "fast", "pcg"], default="auto",
                    help="rrBLUP: exact marker-space route (auto up to 15000 kept markers) or PCG")
     q.add_argument("-lambda", "--lambda", dest="lam", type=float, default=None)
     q.add_argument("-lambda-reml", "--lambda-reml", dest="lambda_reml", action="store_true", default=False,

@@ -1416,6 +1416,14 @@ def test_cli_gs_rrblup(oracle, tmp_path):
     p3 = np.array([float(r[2]) for r in rows3[1:]])
     rex = oracle.rrblup_exact_snp_packed(packed, n, train, y[train], test, site_keep=keep, maf=maf, row_flip=flip)
     assert np.max(np.abs(p3[test] - rex[1].ravel())) < 1e-4 * scale and np.max(np.abs(p3[train] - rex[0].ravel())) < 1e-4 * scale
+    # the exact SAMPLE-space route (the reference's "fast" backend for m > 15 000, n_train <= 10 000): ridge regression on the
+    # standardised markers = GBLUP on their kernel with an unpenalised intercept, so it must land on the marker-space optimum
+    # (two Brent searches over the same restricted likelihood: agreement to their tolerances)
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-rrBLUP", "-rr-solver", "fast", "-o",
+                     prefix + "_fast"]) == 0
+    rows4 = [ln.split("\t") for ln in open(prefix + "_fast.trait.gs.rrBLUP.tsv").read().splitlines()]
+    p4 = np.array([float(r[2]) for r in rows4[1:]])
+    assert np.max(np.abs(p4 - p3)) < 2e-3 * scale, float(np.max(np.abs(p4 - p3)) / scale)
 
 
 @pytest.mark.gpu

@@ -222,6 +222,18 @@ int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int
 int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                             const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
                             const uint16_t *d_ulo, int scale_exp, float *d_out, int64_t ld_out, void *stream);
+/* D2 on the int8 matrix pipes for exact design rows (no counterpart in the reference, which runs one f32 SGEMM,
+ * src/stats/lmm.rs:728-784).  jxg_ut_quant3: U^T (n x n f32, row j = eigenvector j) -> three int8 planes d_q (3 x npad x npad
+ * bytes, npad = 128 ceil(n / 128)) + one scale per eigenvector d_umax (npad f32): U_ij = umax_j (q1 / 127 + q2 / (127 254) +
+ * q3 / (127 254^2)) to 2^-24 umax_j.  jxg_rotate_packed16x_q = jxg_rotate_packed16x with those planes and the block's rows
+ * split into two lists of positions: d_sel_exact (rows that factor as beta + {0,1,2} without missing calls, i.e. finite
+ * d_rowoff: three exact v_mfma_i32_32x32x32_i8 products combined in f64) and d_sel_rest (fp16 hi / lo kernel); together
+ * they must cover 0 .. nrows-1.  A row's path, and its bits, do not depend on the block it is scanned in. */
+int jxg_ut_quant3(const float *d_ut, int n, int8_t *d_q, float *d_umax, void *stream);
+int jxg_rotate_packed16x_q(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const void *d_lut16,
+                           const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi, const uint16_t *d_ulo,
+                           int scale_exp, const int8_t *d_q, const float *d_umax, const int32_t *d_sel_exact, int n_exact,
+                           const int32_t *d_sel_rest, int n_rest, float *d_out, void *stream);
 
 /* Rotation with the fused fixed-lambda reduction (src/stats/fvlmm.rs:1691-1805 consumes G~ only through three weighted sums):
  * G~ is not written; column tile t of this call (128 eigenvector columns, t < jxg_num_tiles(n)) writes its share of

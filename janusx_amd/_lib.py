@@ -66,6 +66,8 @@ SIGNATURES = {
     "jxg_ut_rowsum": [c_p, c_i, c_p, c_p],
     "jxg_rotate_packed16x": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "jxg_rotate_packed16x_ld": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
+    "jxg_ut_quant3": [c_p, c_i, c_p, c_p, c_p],
+    "jxg_rotate_packed16x_q": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],
     "jxg_rotate_dense_f32": [c_p, c_i, c_i, c_p, c_p, c_p],
     "jxg_lmm_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_i, c_d, c_p, c_p, c_p],
     "jxg_lmm_tables_bytes": [c_i, c_i, c_d, c_d],

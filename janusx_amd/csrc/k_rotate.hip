@@ -543,7 +543,10 @@ using namespace jx;
 namespace jx {
 int launch_rotate256(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                      const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
-                     const uint16_t *d_ulo, float out_scale, float *d_out, int64_t ld_out, int *took);
+                     const uint16_t *d_ulo, float out_scale, float *d_out, int64_t ld_out, const int32_t *d_sel, int *took);
+int launch_rotate_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
+                     int nsel, const void *d_lut16, const float *d_rowoff, const float *d_usum, const int8_t *d_q,
+                     const float *d_umax, float *d_out, int64_t ld_out);
 extern float g_last_ms[16];
 extern int g_timer_pending[4];
 hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
@@ -631,10 +634,36 @@ extern "C" int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n
 
 // ld_out >= n: row pitch of d_out in floats (a block of eigenvector columns of a wider rotated-row buffer: the
 // block-diagonal rotation of the sparse-GRM routes)
+static int rotate_core(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const void *d_lut16,
+                       const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi, const uint16_t *d_ulo,
+                       int scale_exp, const int8_t *d_q, const float *d_umax, const int32_t *d_sel_exact, int n_exact,
+                       const int32_t *d_sel_rest, int n_rest, float *d_out, int64_t ld_out, void *stream);
+
 extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                        const void *d_lut16, const float *d_rowoff, const float *d_usum,
                                        const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, float *d_out,
                                        int64_t ld_out, void *stream) {
+    return rotate_core(d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo, scale_exp, nullptr, nullptr,
+                       nullptr, 0, nullptr, 0, d_out, ld_out, stream);
+}
+
+// The same with the int8 planes of the eigenvectors (jxg_ut_quant3) and the block's rows split by the caller into the
+// positions d_sel_exact (rows that factor as beta + {0,1,2} without missing calls: rowoff finite; int8 matrix pipes,
+// k_rotate_i8.hip) and d_sel_rest (all other rows: fp16 kernel).  A row's path does not depend on its neighbours.
+extern "C" int jxg_rotate_packed16x_q(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                      const void *d_lut16, const float *d_rowoff, const float *d_usum,
+                                      const uint16_t *d_uhi, const uint16_t *d_ulo, int scale_exp, const int8_t *d_q,
+                                      const float *d_umax, const int32_t *d_sel_exact, int n_exact,
+                                      const int32_t *d_sel_rest, int n_rest, float *d_out, void *stream) {
+    if (n_exact < 0 || n_rest < 0 || n_exact + n_rest != nrows) return fail("jxg_rotate_packed16x_q: the two row lists must cover the block");
+    return rotate_core(d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo, scale_exp, d_q, d_umax,
+                       d_sel_exact, n_exact, d_sel_rest, n_rest, d_out, (int64_t)n, stream);
+}
+
+static int rotate_core(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const void *d_lut16,
+                       const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi, const uint16_t *d_ulo,
+                       int scale_exp, const int8_t *d_q, const float *d_umax, const int32_t *d_sel_exact, int n_exact,
+                       const int32_t *d_sel_rest, int n_rest, float *d_out, int64_t ld_out, void *stream) {
     if (ld_out < n) return fail("jxg_rotate_packed16x_ld: ld_out < n");
     if (nrows <= 0) return 0;
     static const int exact_env = getenv("JXGPU_ROT_EXACT") ? atoi(getenv("JXGPU_ROT_EXACT")) : 1;
@@ -650,10 +679,21 @@ extern "C" int jxg_rotate_packed16x_ld(const uint8_t *d_p32, int64_t m_total, in
     const int nrt = (nrows + 127) / 128;
     dim3 grid((unsigned)(((nt + 7) / 8) * 8 * nrt));
     JX_HIP(hipEventRecord(g_rot_a, st));
-    int took = 0;                         // full-size blocks: 256 x 256 tiles (k_rotate256.hip)
-    if (launch_rotate256(st, d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
-                         ldexpf(1.0f, -scale_exp), d_out, ld_out, &took))
+    int took = 0;
+    if (d_q) {
+        // exact rows on the int8 planes, the rest on the fp16 kernel, each as a compacted list of positions
+        if (!d_rowoff || !exact_env) return fail("jxg_rotate_packed16x_q needs the exact-row LUTs (jxg_lut_split_rows)");
+        if (launch_rotate_i8(st, d_p32, m_total, n, d_rows, d_sel_exact, n_exact, d_lut16, d_rowoff, d_usum, d_q, d_umax, d_out,
+                             ld_out))
+            return 1;
+        if (launch_rotate256(st, d_p32, m_total, n, d_rows, n_rest, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
+                             ldexpf(1.0f, -scale_exp), d_out, ld_out, d_sel_rest ? d_sel_rest : d_sel_exact, &took))
+            return 1;
+        g_last_ms[13] = n_exact > 0 ? 1.f : 0.f;
+    } else if (launch_rotate256(st, d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
+                                ldexpf(1.0f, -scale_exp), d_out, ld_out, nullptr, &took)) {   // full-size blocks: 256 x 256 tiles
         return 1;
+    }
     if (!took) {
         hipLaunchKernelGGL(rotate_f16x2_kernel<false>, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows,
                            (const uint4 *)d_lut16, d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n,

@@ -39,10 +39,13 @@ __global__ __launch_bounds__(512, 2) void rotate256_kernel(const uint8_t *__rest
                                                            const uint4 *__restrict__ lut16, const float *__restrict__ rowoff,
                                                            const float *__restrict__ usum, const __half *__restrict__ uhi,
                                                            const __half *__restrict__ ulo, int64_t npad, int n,
-                                                           float out_scale, float *__restrict__ out, int64_t ldo) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t r2_smem[];       // 2 sets | seltab (64 B) | row offsets (1 KB)
+                                                           float out_scale, float *__restrict__ out, int64_t ldo,
+                                                           const int32_t *__restrict__ sel) {
+    // `sel` (optional): positions of this launch's rows inside the block (rows / lut16 / rowoff / out are indexed by position)
+    extern __shared__ __attribute__((aligned(16))) uint8_t r2_smem[];       // 2 sets | seltab (64 B) | row offsets | positions
     uint32_t *seltab = reinterpret_cast<uint32_t *>(r2_smem + 2 * R2_SET);
     float *sOff = reinterpret_cast<float *>(r2_smem + 2 * R2_SET + 64);
+    int *sPos = reinterpret_cast<int *>(sOff + R2_T);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,19 +75,24 @@ __global__ __launch_bounds__(512, 2) void rotate256_kernel(const uint8_t *__rest
     {
         const int r = r0 + arow;
         float boff = 0.0f;
+        int pos = -1;
         if (r < nrows) {
-            const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+            pos = sel ? sel[r] : r;
+            const int64_t rec = rows ? (int64_t)rows[pos] : (int64_t)pos;
             arec = p32 + rec * 32;
-            L = lut16[r];
+            L = lut16[pos];
             if (rowoff) {
-                const float t = rowoff[r];
+                const float t = rowoff[pos];
                 row_exact = (t == t) ? 1 : 0;
                 boff = row_exact ? t : 0.0f;
             } else {
                 row_exact = 0;
             }
         }
-        if (ahalf == 0) sOff[arow] = boff;
+        if (ahalf == 0) {
+            sOff[arow] = boff;
+            sPos[arow] = pos;
+        }
     }
     arec += 4 * ahalf;
     const bool tile_exact = __syncthreads_and(row_exact) != 0 && rowoff != nullptr;
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void rotate256_kernel(const uint8_t *__rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int gr = r0 + lr;
-                if (gr < nrows && gj < n) out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
+                const int gr = sPos[lr];
+                if (gr >= 0 && gj < n) out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, acc[mi][ni][r] * out_scale);
             }
         }
 }
@@ -255,23 +263,29 @@ __global__ __launch_bounds__(512, 2) void rotate256_kernel(const uint8_t *__rest
 // nonzero when the 256-tile kernel took the call
 int launch_rotate256(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                      const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,
-                     const uint16_t *d_ulo, float out_scale, float *d_out, int64_t ld_out, int *took) {
+                     const uint16_t *d_ulo, float out_scale, float *d_out, int64_t ld_out, const int32_t *d_sel, int *took) {
+    // d_sel != NULL: `nrows` selected positions of a block (always this kernel: it gives the same bits as the 128-tile one)
     *took = 0;
     static const int env = getenv("JXGPU_ROT256") ? atoi(getenv("JXGPU_ROT256")) : 1;
     const int nt = num_tiles(n);
     const int64_t npad = (int64_t)nt * JXG_TILE;
     // full-size blocks only: at least a few rounds of 256 workgroups
     const int nct = (int)((npad + R2_T - 1) / R2_T), nrt = (nrows + R2_T - 1) / R2_T;
-    if (!env || (int64_t)nct * nrt < 2 * 256) return 0;
+    if (!d_sel && (!env || (int64_t)nct * nrt < 2 * 256)) return 0;
+    if (nrows <= 0) {
+        *took = 1;
+        return 0;
+    }
     static bool attr = false;
-    const int lds = 2 * R2_SET + 64 + 1024;
+    const int lds = 2 * R2_SET + 64 + 2048;
     if (!attr) {
         JX_HIP(hipFuncSetAttribute((const void *)rotate256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
     dim3 grid((unsigned)(((nct + 7) / 8) * 8 * nrt));
     hipLaunchKernelGGL(rotate256_kernel, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nrows, (const uint4 *)d_lut16,
-                       d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n, out_scale, d_out, ld_out);
+                       d_rowoff, d_usum, (const __half *)d_uhi, (const __half *)d_ulo, npad, n, out_scale, d_out, ld_out,
+                       d_sel);
     JX_LAUNCH_CHECK();
     *took = 1;
     return 0;

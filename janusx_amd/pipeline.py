@@ -300,6 +300,17 @@ class SpectralModel:
             self._planes = (hi, lo, usum)
         return self._planes
 
+    def qplanes(self):
+        """Three int8 planes of U^T with one scale per eigenvector (jxg_ut_quant3): operands of the int8 rotation of exact
+        design rows (csrc/k_rotate_i8.hip)."""
+        if getattr(self, "_qplanes", None) is None:
+            npad = lib().jxg_num_tiles(self.n) * 128
+            q = torch.empty((3, npad, npad), dtype=torch.int8, device=self.S.device)
+            umax = torch.empty(npad, dtype=torch.float32, device=self.S.device)
+            check(lib().jxg_ut_quant3(_ptr(self.ut), self.n, _ptr(q), _ptr(umax), _stream()))
+            self._qplanes = (q, umax)
+        return self._qplanes
+
     def fv_cache(self, log10_lbd=None):
         lbd = self.null.lbd if log10_lbd is None else 10.0 ** float(log10_lbd)
         if self._fv is None or self._fv[0] != lbd:
@@ -347,6 +358,9 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
     hi, lo, usum = model.planes()
+    # int8 planes of the eigenvectors for the exact-row tiles of full-size blocks (k_rotate_i8.hip)
+    qpl = model.qplanes() if (not (mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)) and n >= 4096
+                              and os.environ.get("JXGPU_ROT_I8", "1") != "0") else None
     # one-off per call: fp16 hi/lo LUT records (range-checked; rows without missing calls as integer LUT + offset, see
     # jxg_lut_split_rows) and, for the exact scan, the Chebyshev tables of the lambda-only REML sums; the block loop
     # below then only launches kernels (no allocation, no host sync).
@@ -385,6 +399,28 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     br = int(min(block_rows, mk))
     nbuf = 2 if mk > br else 1
     fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)
+    if qpl is not None:
+        # per block: positions of the exact rows (finite row offset: int8 rotation) and of the others (fp16 rotation); a row's
+        # path does not depend on the blocking, so chunked scans stay bit-identical to unchunked ones
+        n_inexact = int(torch.isnan(rowoff).sum().item())
+        se, sr, sel_bounds = [], [], []
+        ne = nx = 0
+        if n_inexact == 0:
+            # every row exact (a panel without missing calls): identity lists, nothing to build
+            for b0 in range(0, mk, br):
+                sel_bounds.append((0, min(br, mk - b0), 0, 0))
+            sel_exact_t = sel_rest_t = None
+        else:
+            ex = ~np.isnan(rowoff.cpu().numpy())
+            for b0 in range(0, mk, br):
+                blk = ex[b0:b0 + br]
+                a, b = np.flatnonzero(blk).astype(np.int32), np.flatnonzero(~blk).astype(np.int32)
+                sel_bounds.append((ne, ne + len(a), nx, nx + len(b)))
+                ne, nx = ne + len(a), nx + len(b)
+                se.append(a)
+                sr.append(b)
+            sel_exact_t = torch.from_numpy(np.concatenate(se) if ne else np.zeros(1, np.int32)).to(dev)
+            sel_rest_t = torch.from_numpy(np.concatenate(sr) if nx else np.zeros(1, np.int32)).to(dev)
     if fused:
         sums = [torch.empty((panel.nt, br, model.p + 2), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         grots = [None] * nbuf
@@ -414,9 +450,19 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                                    _ptr(lo), SCALE_EXP, _ptr(w), _ptr(py), _ptr(wx), model.p, _ptr(sm),
                                                    model.p + 2, 0, _stream()))
         else:
-            check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
-                                             lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
-                                             SCALE_EXP, _ptr(grot), _stream()))
+            if qpl is not None:
+                e0, e1, x0, x1 = sel_bounds[bi]
+                check(lib().jxg_rotate_packed16x_q(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                                   lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
+                                                   SCALE_EXP, _ptr(qpl[0]), _ptr(qpl[1]),
+                                                   sel_exact_t[e0:].data_ptr() if (sel_exact_t is not None and e1 > e0) else None,
+                                                   e1 - e0,
+                                                   sel_rest_t[x0:].data_ptr() if (sel_rest_t is not None and x1 > x0) else None,
+                                                   x1 - x0, _ptr(grot), _stream()))
+            else:
+                check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                                 lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),
+                                                 SCALE_EXP, _ptr(grot), _stream()))
         if times is not None:
             ev_rot[bi][1].record()
             ev_scan[bi][0].record()

@@ -1,6 +1,7 @@
 // Host layer of libjxgpu: reference-shaped entry points (host arrays in, host arrays out) that stage through
 // HBM and drive the device layer; per-SNP statistics / filter logic (integer counts -> f32/f64 decisions) is
 // done on the host exactly as the reference writes it, so the kept-SNP set is bit-exact.
+#include <errno.h>
 #include <math.h>
 #include <cmath>
 #include <stdio.h>
@@ -472,10 +473,13 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
     bool ok = fwrite(hdr, 8, 2, fh) == 2 && fwrite(colptr.data(), 8, colptr.size(), fh) == colptr.size() &&
               fwrite(rows.data(), 4, rows.size(), fh) == rows.size() && fwrite(zeros, 1, pad, fh) == pad &&
               fwrite(vals.data(), 8, vals.size(), fh) == vals.size();
-    ok = (fclose(fh) == 0) && ok;
-    if (!ok) {
+    const int werr = ok ? 0 : errno;
+    const bool closed = fclose(fh) == 0;
+    if (!ok || !closed) {
+        const int e = ok ? errno : werr;
         remove(out_path);
-        return fail(std::string("write sparse GRM file failed: ") + out_path);
+        return fail(std::string("write sparse GRM file failed: ") + out_path + " (" + std::to_string(nnz) + " entries, " +
+                    strerror(e) + ")");
     }
     if (out_n) *out_n = n;
     if (out_nnz) *out_nnz = (int64_t)nnz;

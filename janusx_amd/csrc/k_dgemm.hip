@@ -245,6 +245,7 @@ static int dg_fit_split(int ksplit, int m, int n, size_t ws_doubles) {
 }
 
 static int dg_reduce(hipStream_t st, const DgemmArgs &g) {
+    if ((int64_t)g.m * g.n > 0xffffff00LL) return fail("dgemm: result beyond 2^32 elements (one dispatch dimension)");
     hipLaunchKernelGGL(dg_reduce_kernel, dim3((unsigned)(((int64_t)g.m * g.n + 255) / 256)), dim3(256), 0, st, g.c, g.ldc,
                        g.m, g.n, g.beta, g.ws, g.ksplit);
     JX_LAUNCH_CHECK();

@@ -11,11 +11,13 @@ __global__ __launch_bounds__(256) void repack_p32_kernel(const uint8_t *__restri
                                                          const int32_t *__restrict__ sample_idx, int n_sel,
                                                          const int64_t *__restrict__ row_idx, int64_t m_out,
                                                          uint32_t *__restrict__ dst, int nt) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid: x over the dwords of one tile, y = tile (a dispatch holds at most 2^32 work-items per dimension: the flat form
+    // silently lost the tail of a 50 GB payload)
     const int64_t per_tile = m_out * 8;  // dwords per tile
-    if (gid >= per_tile * nt) return;
-    const int tile = (int)(gid / per_tile);
-    const int64_t rem = gid - (int64_t)tile * per_tile;
+    const int64_t rem = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= per_tile) return;
+    const int tile = (int)blockIdx.y;
+    const int64_t gid = (int64_t)tile * per_tile + rem;
     const int64_t j = rem >> 3;
     const int d = (int)(rem & 7);
     const int64_t srow = row_idx ? row_idx[j] : j;
@@ -59,10 +61,9 @@ __global__ __launch_bounds__(256) void repack_p32_kernel(const uint8_t *__restri
 // from `missing` afterwards by the host (n_pad - n_sel).  One thread per (SNP, tile) record of 32 bytes.
 __global__ __launch_bounds__(256) void row_counts_p32_kernel(const uint4 *__restrict__ p32, int64_t m, int nt,
                                                              int32_t *__restrict__ counts) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= m * nt) return;
-    const int tile = (int)(gid / m);
-    const int64_t j = gid - (int64_t)tile * m;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // grid: x over SNPs, y = tile
+    if (j >= m) return;
+    const int tile = (int)blockIdx.y;
     const uint4 *rec = p32 + ((int64_t)tile * m + j) * 2;
     int mis = 0, het = 0, hom = 0;
 #pragma unroll
@@ -106,10 +107,9 @@ extern "C" int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, i
     (void)m_src;
     if (n_sel <= 0 || m_out <= 0) return fail("jxg_repack_p32: empty input");
     const int nt = num_tiles(n_sel);
-    const int64_t total = m_out * 8 * nt;
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return fail("jxg_repack_p32: grid too large");
-    hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_packed, bps,
+    const int64_t blocks = (m_out * 8 + 255) / 256;
+    if (blocks * 256 > 0xffffffffLL || nt > 65535) return fail("jxg_repack_p32: grid too large");
+    hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, d_packed, bps,
                        n_src, d_sample_idx, n_sel, d_row_idx, m_out, (uint32_t *)d_p32, nt);
     JX_LAUNCH_CHECK();
     return 0;
@@ -119,10 +119,9 @@ extern "C" int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, in
     const int nt = num_tiles(n_sel);
     hipStream_t st = (hipStream_t)stream;
     JX_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * 3 * (size_t)m, st));
-    const int64_t total = m * nt;
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return fail("jxg_row_counts_p32: grid too large");
-    hipLaunchKernelGGL(row_counts_p32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint4 *)d_p32, m, nt,
+    const int64_t blocks = (m + 255) / 256;
+    if (blocks * 256 > 0xffffffffLL || nt > 65535) return fail("jxg_row_counts_p32: grid too large");
+    hipLaunchKernelGGL(row_counts_p32_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, st, (const uint4 *)d_p32, m, nt,
                        d_counts);
     JX_LAUNCH_CHECK();
     const int pad = nt * JXG_TILE - n_sel;

@@ -557,7 +557,7 @@ extern "C" int jxg_ut_split(const float *d_ut, int n, uint16_t *d_hi, uint16_t *
     const int64_t npad = (int64_t)num_tiles(n) * JXG_TILE;
     const int64_t total = npad * npad;
     const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return fail("jxg_ut_split: grid too large");
+    if (blocks * 256 > 0xffffffffLL) return fail("jxg_ut_split: grid too large (n beyond 65 408)");
     hipLaunchKernelGGL(ut_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_ut, n, npad,
                        (__half *)d_hi, (__half *)d_lo, ldexpf(1.0f, scale_exp));
     JX_LAUNCH_CHECK();

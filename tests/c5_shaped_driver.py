@@ -1,5 +1,5 @@
 """BASELINE configs[4]-shaped `-splmm` run with the panel GENERATED ON THE DEVICE (run as its own process by
-tests/test_gpu_parity.py::test_c5_shaped_splmm_device_panel, so that the peak host RSS it reports is this run's alone).
+tests/test_gpu_parity.py::test_c5_full_size_splmm_device_panel, so that the peak host RSS it reports is this run's alone).
 
 n samples in sibships of four, m SNPs; sparse GRM through the row-panel builder (`jxg_grm_accumulate_rows`, the accumulator of
 n = 200 000 does not fit HBM as a square), block-diagonal spectral route, SparseLMM exact scan.  No (m x n) or packed

@@ -393,6 +393,78 @@ def test_scan_exact_design_rows(oracle, oracle_c):
         assert max(be, se, pe) < TOL, (miss_frac, be, se, pe)
 
 
+def test_repack_and_counts_beyond_2e32_work_items(oracle):
+    """A dispatch dimension holds 2^32 work-items: the flat one-thread-per-dword grid of the P32 re-tiling silently lost the
+    tail of a payload with more than 2^32 dwords (BASELINE configs[4] at full size: 50 GB).  n = 400 000 x m = 175 000
+    is 17.5 GB = 4.375e9 dwords; the first / middle / last tiles and the per-SNP counts are compared with the source."""
+    import torch
+    from janusx_amd import pipeline
+    n, m = 400_000, 175_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    src = torch.randint(0, 256, (m, n // 4), dtype=torch.uint8, device="cuda", generator=g)
+    p = pipeline.Panel(src, n)
+    assert p.nt == 3125
+    for t in (0, 1, 1562, 3123, 3124):
+        assert torch.equal(p.p32[t], src[:, 32 * t:32 * (t + 1)]), t
+    c = p.counts()
+    pick = np.r_[0:40, m // 2:m // 2 + 40, m - 40:m]
+    mi, he, ho = oracle.row_counts(src[torch.from_numpy(pick).cuda()].cpu().numpy(), n)
+    assert np.array_equal(c[pick], np.stack([mi, he, ho], 1))
+
+
+def test_full_size_rotation_kernels_with_mixed_rows(oracle, oracle_c, monkeypatch):
+    """From n = 4096 the rotation deals the rows of a block to two kernels by position lists: design rows without a missing
+    call to the int8 kernel (three int8 planes of U, csrc/k_rotate_i8.hip), the others to the 256 x 256-tile fp16 kernel
+    (csrc/k_rotate256.hip).  n = 4200 (ragged against the 128 / 256 tiles), missing calls in 40 % of the SNPs, flipped
+    alleles: (i) beta / SE / p against the oracle's scan of the f64 rotation, (ii) chunked == unchunked bit for bit (a
+    row's path must not depend on its neighbours), (iii) all-fp16 (JXGPU_ROT_I8=0) within the same bound."""
+    import torch
+    from janusx_amd import pipeline, stats
+    n, m = 4200, 900
+    packed, g = bed.synth_panel_numpy(n, m, seed=23, missing_rate=0.0)
+    rng = np.random.default_rng(5)
+    for r in np.nonzero(rng.random(m) < 0.4)[0]:
+        for j in rng.integers(0, n, size=rng.integers(1, 6)):
+            b, sh = j >> 2, 2 * (j & 3)
+            packed[r, b] = (packed[r, b] & ~(3 << sh)) | (1 << sh)
+    y = bed.synth_phenotype(g, n_causal=20, pve=0.5, seed=23)
+    x = np.concatenate([np.ones((n, 1)), np.random.default_rng(6).normal(size=(n, 1))], axis=1)
+    dev = torch.device("cuda", 0)
+    pk_t = torch.from_numpy(packed).to(dev)
+    k, _eff, p = pipeline.build_grm(pk_t, n)
+    s_t, ut_t = pipeline.eigh_from_grm(k)
+    model = pipeline.SpectralModel(s_t, ut_t, x, y)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    flip_k = np.random.default_rng(9).random(len(rows)) < 0.3
+    lut = stats.scan_lut_from_counts(maf[rows], flip_k, p.counts()[rows], n)
+    lo_b, hi_b = model.null.bounds
+    res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
+    # oracle: the reference's decode, rotation by the SAME eigenvectors in f64, its scan
+    gd = oracle.decode_centered_block_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows])
+    ut = ut_t.cpu().numpy()
+    grot = (gd.astype(np.float64) @ ut.T).astype(np.float32)
+    xy = ut @ np.concatenate([x, y[:, None]], axis=1)
+    ref = oracle_c.lmm_scan_rotated_block(grot, s_t.cpu().numpy(), np.ascontiguousarray(xy[:, :2]),
+                                          np.ascontiguousarray(xy[:, 2]), lo_b, hi_b, 30, 1e-2)
+    be, se, pe = _assoc_err(res, ref)
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    n_exact = int(np.sum(mi[rows] == 0))
+    assert 0 < n_exact < len(rows)                      # both kernels ran
+    # (ii) chunking changes the position lists, not the bits
+    res_c = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2,
+                               block_rows=300).cpu().numpy()
+    assert np.array_equal(res_c, res)
+    # (iii) every row through the fp16 kernels
+    monkeypatch.setenv("JXGPU_ROT_I8", "0")
+    res_h = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
+    be, se, pe = _assoc_err(res_h, ref)
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    assert not np.array_equal(res_h, res)               # the switch really changes the path
+
+
 def test_pipeline_end_to_end(oracle, oracle_c):
     import torch
     from janusx_amd import pipeline
@@ -749,19 +821,20 @@ def test_full_size_c4_properties(oracle, oracle_c):
     torch.cuda.empty_cache()
 
 
-def test_c5_shaped_splmm_device_panel():
-    """BASELINE configs[4] shape (`-splmm`, n = 200 000) with the panel generated ON THE DEVICE (tests/c5_shaped_driver.py in
-    its own process): families of four, m = 200 000 SNPs, sparse GRM through the row-panel builder
+def test_c5_full_size_splmm_device_panel():
+    """BASELINE configs[4] AT FULL SIZE (`-splmm`, n = 200 000, m = 1 000 000) with the panel generated ON THE DEVICE
+    (tests/c5_shaped_driver.py in its own process; measured 20.8 s sparse GRM + 8.4 s scan on one MI355X, 103 GB of HBM at the
+    peak): families of four, sparse GRM through the row-panel builder
     (`jxg_grm_accumulate_rows`), block-diagonal spectral route, exact scan; 150-SNP sample against the oracle's restatement
     of `exact_scan_blocks_core` (src/stats/splmm.rs:2567-2880) with a sparse factor of K + lambda I, sparse REML optimum
-    against the oracle's evaluation; no (m x n) host array (the packed payload alone is 10 GB, its dosages 40 GB): the host RSS
-    the run adds on top of the process baseline (interpreter + torch + HIP runtime, recorded) stays < 8 GiB."""
+    against the oracle's evaluation; no (m x n) host array (the packed payload alone is 50 GB, its dosages 200 GB): the host RSS
+    the run adds on top of the process baseline (interpreter + torch + HIP runtime, recorded) stays < 4 GiB (measured 1.2)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tests", "c5_shaped_driver.py"), "200000", "200000", "150"]
+    cmd = [sys.executable, os.path.join(root, "tests", "c5_shaped_driver.py"), "200000", "1000000", "150"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -771,7 +844,7 @@ def test_c5_shaped_splmm_device_panel():
         json.dump(d, open(os.path.join(root, "gpurun_out", "c5_shaped.json"), "w"), indent=1)
     except OSError:
         pass
-    assert d["route"] == "block" and d["m_kept"] > 190000 and d["max_relatives"] <= 3
+    assert d["route"] == "block" and d["m_kept"] > 950000 and d["max_relatives"] <= 3 and d["nnz"] <= 3 * d["n"]
     assert d["nan_pattern_equal"] and d["all_rows_finite_p"]
     assert max(d["beta_err"], d["se_err"], d["p_err"]) < TOL, d
     assert d["reml_err"] < 1e-9 and d["ml_err"] < 1e-9, d

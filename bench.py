@@ -230,10 +230,11 @@ def pmc_traffic_bytes(kernel_prefix, run="fetch", fetch_scale=2.0):
     return None, None
 
 
-def pmc_mfma_util(kernel_substr):
-    """(MFMA-pipe utilisation, source file) of a kernel from a committed counter pass of THIS shape:
+def pmc_mfma_util(kernel_substr, kind="mfma"):
+    """(MFMA-pipe utilisation, source file) of a kernel from a committed counter pass of THIS shape (kind "mfma": the clean
+    panel; "mfma_missing1pct": the same shape with 1 % missing calls):
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs). (None, None) when absent."""
-    for src, d in _pmc_files("mfma"):
+    for src, d in _pmc_files(kind):
         for name, rec in d.get("kernels", {}).items():
             if kernel_substr in name:
                 try:
@@ -609,11 +610,18 @@ def main():
             try:
                 leg = run_leg(20000, 200000, 0.01, 2, 1)
                 sm = leg_summary(leg, 20000, 2)
+                mu_g, mu_g_src = pmc_mfma_util("grm_f16x2_kernel<128, 128, 64, 64, false, false", "mfma_missing1pct")
+                mu_r, mu_r_src = pmc_mfma_util("rotate256_kernel", "mfma_missing1pct")
                 res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_f16x2_kernel (SNPs with a missing call among "
                                                        "the samples: fp16 hi/lo three-product variant)",
+                                                       mfma_util_pmc=mu_g, mfma_util_source=mu_g_src,
                                                        note="2 timed steps of the configs[2] shape with 1 % missing calls; "
-                                                            "algorithmic n(n+1)m flops over the whole accumulate call")
-                res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"], kernel="rotate_f16x2_kernel",
+                                                            "algorithmic n(n+1)m flops over the whole accumulate call; the "
+                                                            "kernel issues three f16 products per algorithmic product")
+                res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"],
+                                                          kernel="rotate256_kernel (fp16 hi/lo, three products: every row has a "
+                                                                 "missing call at this rate)",
+                                                          mfma_util_pmc=mu_r, mfma_util_source=mu_r_src,
                                                           note="same leg; algorithmic 2 m n^2 flops")
                 res["extra_c3_missing1pct"] = {k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
                                                                   "stages_ms_per_step")}

@@ -463,6 +463,20 @@ int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t 
                     const double *d_xr, int q0, const double *d_ixx, double yy_r, double *d_work, double *d_out,
                     void *stream);
 
+/* SparseLMM approximate (GRAMMAR-gamma) scan = `grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316; the
+ * scan of `scan_with_py_and_rhat`, :3318-3363, behind `splmm_assoc_pcg_bed[_to_tsv]` in scan_mode "approx", :4641, 4814):
+ * d_lut (nrows, 4) f32 = mean-imputed additive value by 2-bit code (not centred), d_xr (n, p + 1) f64 = [X | score vector]
+ * already rounded through f32 (`pack_score_design_rhs_f32`), d_ixx (p, p) f64 = (X'X)^-1, d_work (nrows * (p + 2)) f64
+ * scratch, d_out (nrows, 3) f64 = beta, se, p; score = score_scale g.score_vec, denominator = denom_scale g'M_X g. */
+int jxg_splmm_grammar_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                               const float *d_lut, const double *d_xr, int p, const double *d_ixx, double score_scale,
+                               double denom_scale, double sigma2, double *d_work, double *d_out, void *stream);
+
+/* Sums behind `estimate_gamma_from_markers` (src/stats/splmm_approx.rs:921-1068) over rotated marker rows g~ = U'g:
+ * d_out (nrows, 3 + 2 p) = [g~'g~, g~'Wg~, g~'a~, X~'g~ (p), X~'Wg~ (p)]; d_w, d_a (n) f64, d_x (n, p) f64 row-major. */
+int jxg_splmm_gamma_sums(const float *d_grot, int nrows, int n, int64_t ld, int p, const double *d_w, const double *d_a,
+                         const double *d_x, double *d_out, void *stream);
+
 /* `gblup_reml_npy_grm` (src/stats/gblup.rs:1242-1516) on an in-memory GRM: fit on K[train,train] + g_eps I, predict
  * K[*,train] alpha + beta0.  out_scalars = (pve, lambda, ml, reml, sigma_g2, sigma_e2, beta0). */
 int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const int64_t *train_idx, int n_train,

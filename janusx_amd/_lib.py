@@ -117,6 +117,8 @@ SIGNATURES = {
                                    c_p],
     "jxg_fvlmm_finish_dev": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_d, c_i, c_i, c_d, c_d, c_i, c_p, c_p],
     "jxg_lm_scan_p32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_d, c_p, c_p, c_p],
+    "jxg_splmm_grammar_scan_p32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_d, c_d, c_d, c_p, c_p, c_p],
+    "jxg_splmm_gamma_sums": [c_p, c_i, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     "jx_lm_residualize": [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "jx_lm_assoc_packed": [c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_p],
 }

@@ -10,7 +10,7 @@ python/janusx/script/grm.py:18-23, 1874-1975, python/janusx/assoc/workflow_model
   python -m janusx_amd gs   -bfile PREFIX -p PHENO.tsv [-n TRAIT ...] -rrBLUP [-lambda L] [-tol 1e-4] [-max-iter 100] [-cv K]
                             [-maf 0.02] [-geno 0.05] [-o OUT]
 
-Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm2.tsv` (`gwas -splmm-exact [cutoff]`, exact SparseLMM scan; `-splmm` writes the same scan as `.splmm.tsv`); `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
+Outputs: `{out}.{trait}.lmm.tsv` / `.lmm2.tsv` / `.fvlmm.tsv` / `.splmm2.tsv` (`gwas -splmm-exact [cutoff]`, exact SparseLMM scan) / `.splmm.tsv` (`gwas -splmm [cutoff]`, GRAMMAR-gamma SparseLMM scan); `{out}.cGRM.npy` (method 1) or `.sGRM.npy` (method 2) + `.npy.id`; `{out}.spgrm` + `.spgrm.id` with `grm -sparse [cutoff]`;
 `{out}.{trait}.gs.GBLUP.tsv` (sample, observed, predicted, fold) for `gs`.
 Only PLINK BED input, the additive model, the -lmm / -fvlmm scans and the GBLUP branch of `-BLUP`
 (python/janusx/gs/blup.py:72-163 routes n <= BLUP_SMALL_N there; `gblup_reml_npy_grm` call of
@@ -28,6 +28,9 @@ import sys
 import time
 
 import numpy as np
+
+
+SPLMM_APPROX_RHAT_MARKERS = 1000      # python/janusx/assoc/workflow_model_packed.py:99
 
 
 def _read_table(path):
@@ -182,9 +185,9 @@ def cmd_gwas(args):
     from .bed import read_bed_payload, read_fam_ids
     from .tsv import AsyncAssocTsvWriter, write_assoc_tsv
     # SparseLMM flags of the reference (python/janusx/assoc/workflow.py:6689-6725, 6992-7017): -splmm-exact = exact g'Pg scan,
-    # raw REML null objective, result stem "splmm2"; -splmm = GRAMMAR-gamma denominator, stem "splmm" (the approximation is not
-    # built: -splmm runs the exact scan too -- what the reference itself does for a trait with fewer kept markers than its
-    # gamma sample, workflow_model_packed.py:8087-8107 -- and says so)
+    # raw REML null objective, result stem "splmm2"; -splmm = fastGWA fixed-Vp null objective + residualised GRAMMAR-gamma
+    # denominator from 1000 sampled markers, stem "splmm" (a trait with fewer kept markers than that falls back to the exact
+    # scan, workflow_model_packed.py:8087-8107)
     sp_stems = []
     if getattr(args, "splmm_exact", None) is not None:
         sp_stems.append("splmm2")
@@ -192,8 +195,6 @@ def cmd_gwas(args):
         sp_stems.append("splmm")
         if getattr(args, "splmm_exact", None) is not None and float(args.splmm_exact) != float(args.splmm):
             raise SystemExit("-splmm and -splmm-exact in one run must use the same sparse-GRM cut-off")
-        print("note: -splmm: the GRAMMAR-gamma denominator is not built, the exact g'Pg scan (-splmm-exact) is written "
-              "under the -splmm result name")
     if args.splmm is None and sp_stems:
         args.splmm = float(args.splmm_exact)
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
@@ -317,17 +318,42 @@ def cmd_gwas(args):
                 if missing_ids:
                     raise SystemExit(f"{sparse_path}.id lacks {len(missing_ids)} phenotyped sample(s), e.g. {missing_ids[0]}")
                 grm_idx = np.array([sparse_pos[fam[j]] for j in keep_idx], dtype=np.int64)
-            stats, l10, null = jxrs.splmm_exact_scan_from_jxgrm(
-                sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool),
-                x[:, 1:] if x.shape[1] > 1 else None, keep_idx if (grm_idx is not None or not full) else None, kept,
-                grm_sample_indices=grm_idx)
+            xc = x[:, 1:] if x.shape[1] > 1 else None
+            sidx = keep_idx if (grm_idx is not None or not full) else None
+            meta = ([bim.chrom[j] for j in kept], [bim.pos[j] for j in kept], [bim.snp[j] for j in kept],
+                    [bim.a0[j] for j in kept], [bim.a1[j] for j in kept])
             for stem in sp_stems:
+                t2 = time.perf_counter()
                 path = f"{out}.{name}.{stem}.tsv"
-                write_assoc_tsv(path, [bim.chrom[j] for j in kept], [bim.pos[j] for j in kept],
-                                [bim.snp[j] for j in kept], [bim.a0[j] for j in kept], [bim.a1[j] for j in kept],
-                                af[kept], miss[kept], stats)
-            print(f"[{name}] -{'splmm-exact' if sp_stems[0] == 'splmm2' else 'splmm'}: n={n} snps={len(kept)} lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} "
-                  f"sigma_e2={null[2]:.4g} -> {path} ({time.perf_counter() - t1:.2f}s)")
+                approx = stem == "splmm" and len(kept) >= SPLMM_APPROX_RHAT_MARKERS
+                if stem == "splmm" and not approx:
+                    # python/janusx/assoc/workflow_model_packed.py:8087-8107
+                    print(f"[{name}] Warning: SparseLMM approx scan has fewer filtered markers than the default gamma sample size "
+                          f"({len(kept)} < {SPLMM_APPROX_RHAT_MARKERS}); falling back to splmm-exact for this trait.")
+                if approx:
+                    # null: fastGWA fixed-Vp objective on the OLS residual (workflow_model_packed.py:3134-3156, 3430-3451), then
+                    # the residualised GRAMMAR-gamma scan (`splmm_assoc_pcg_bed_to_tsv`, scan_mode "approx", :8527-8563)
+                    xd = np.ones((n, 1)) if xc is None else np.concatenate([np.ones((n, 1)), xc], axis=1)
+                    yc = y - xd @ np.linalg.solve(xd.T @ xd, xd.T @ y)
+                    yc = yc - float(np.mean(yc))
+                    vp = float(yc @ yc) / float(n - 1)
+                    null = jxrs.spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(sparse_path, yc, vp, sample_indices=grm_idx if grm_idx is not None else sidx,
+                                                                               low=-5.0, high=5.0, grid_size=17, tol=1e-3, max_iter=20)
+                    res = jxrs.splmm_assoc_pcg_bed_to_tsv(args.bfile, y, float(null[0]), *meta, path, x_cov=xc, sample_indices=sidx,
+                                                          packed=packed, packed_n_samples=n_fam, maf=af[kept], row_flip=np.zeros(len(kept), bool),
+                                                          row_missing=miss[kept], row_indices=kept, sparse_sample_indices=grm_idx,
+                                                          sparse_jxgrm_path=sparse_path, rhat_markers=SPLMM_APPROX_RHAT_MARKERS,
+                                                          rhat_seed=20260527, scan_mode="approx")
+                    print(f"[{name}] -splmm: n={n} snps={len(kept)} lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} sigma_e2={null[2]:.4g} "
+                          f"gamma={res[0]:.6g} (markers used {res[8]}) -> {path} ({time.perf_counter() - t2:.2f}s)")
+                else:
+                    stats, l10, null = jxrs.splmm_exact_scan_from_jxgrm(
+                        sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool), xc, sidx, kept,
+                        grid_size=17, tol=1e-3, max_iter=20, grm_sample_indices=grm_idx)
+                    write_assoc_tsv(path, *meta, af[kept], miss[kept], stats)
+                    print(f"[{name}] -{'splmm-exact' if stem == 'splmm2' else 'splmm (exact scan)'}: n={n} snps={len(kept)} "
+                          f"lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} sigma_e2={null[2]:.4g} -> {path} "
+                          f"({time.perf_counter() - t2:.2f}s)")
     return 0
 
 

@@ -175,6 +175,87 @@ __global__ __launch_bounds__(256) void lm_stats_kernel(const double *__restrict_
     o[0] = beta, o[1] = se, o[2] = pw, o[3] = pl;
 }
 
+// ---- SparseLMM approximate (GRAMMAR-gamma) scan: `grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316) ----
+// Same streaming dots as the LM scan (lm_dots_kernel: [X | score] columns rounded to f32 by the caller like
+// `pack_score_design_rhs_f32`, :1732-1757; the f32 sgemm outputs of the reference are reproduced by rounding the f64 sums to
+// f32), then per SNP  g'Mg = max(g'g - (X'g)'(X'X)^-1(X'g), 0)  (rows whose residual sum of squares is effectively zero are
+// (NaN, NaN, 1), :1710-1717),  denominator = r_hat g'Mg  and `splmm_wald_from_score_denom` (:2517-2538).
+__device__ double sp_chi2_sf_df1(double stat) {        // src/math/linalg.rs:7-17
+    if (!isfinite(stat) || stat <= 0.0) return 1.0;
+    const double p = erfc(sqrt(0.5 * stat));
+    if (!isfinite(p)) return 1.0;
+    return fmin(fmax(p, LM_MIN_POS), 1.0);
+}
+
+__global__ __launch_bounds__(256) void splmm_grammar_stats_kernel(const double *__restrict__ sums, int lds,
+                                                                  const double *__restrict__ dsum, int nrows, int p,
+                                                                  const double *__restrict__ ixx, double score_scale,
+                                                                  double denom_scale, double sigma2,
+                                                                  double *__restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const double *u = sums + (int64_t)r * lds;
+    double quad = 0.0;
+    for (int k = 0; k < p; ++k) {
+        double acc = 0.0;
+        for (int t = 0; t < p; ++t) acc += ixx[k * p + t] * (double)(float)u[t];
+        quad += (double)(float)u[k] * acc;
+    }
+    const double s_sq = dsum[r];
+    const double s_m_s = fmax(s_sq - quad, 0.0);
+    double beta = NAN, se = NAN, pw = 1.0;
+    const bool zero = !(isfinite(s_m_s) && isfinite(s_sq)) || s_m_s <= fmax(1e-10, 1e-12 * fmax(fabs(s_sq), 1.0));
+    if (!zero) {
+        const double score = score_scale * (double)(float)u[p];
+        const double denom = denom_scale * s_m_s;
+        if (isfinite(score) && isfinite(denom) && denom > 1e-30 && isfinite(sigma2) && sigma2 > 0.0) {
+            const double b = score / denom, vb = sigma2 / denom;
+            if (isfinite(b) && isfinite(vb) && vb > 0.0) {
+                const double s = sqrt(vb), chisq = (score * score) / (sigma2 * denom);
+                if (isfinite(s) && s > 0.0 && isfinite(chisq) && chisq >= 0.0) beta = b, se = s, pw = sp_chi2_sf_df1(chisq);
+            }
+        }
+    }
+    double *o = out + (int64_t)r * 3;
+    o[0] = beta, o[1] = se, o[2] = pw;
+}
+
+// ---- gamma of the approximate route: sums over a ROTATED marker row g~ = U'g (src/stats/splmm_approx.rs:921-1068) -------------
+// With V^-1 = U diag(w) U', g_r = M_X g and c = (X'X)^-1 X'g every quantity of `estimate_gamma_from_markers` is a combination
+// of   g~'g~,  g~'W g~,  g~'a~,  X~'g~ (p),  X~'W g~ (p)   (a~ = U'a):  g_r'g_r = g~'g~ - (X~'g~)'c,
+// g_r'V^-1 g_r = g~'Wg~ - 2 c'(X~'Wg~) + c'(X~'WX~)c,  g_r'a = g~'a~ - c'(X~'a~).  One workgroup per sampled marker.
+constexpr int SG_MAXP = 16;
+__global__ __launch_bounds__(256) void splmm_gamma_sums_kernel(const float *__restrict__ grot, int64_t ld, int n, int p,
+                                                               const double *__restrict__ w, const double *__restrict__ a,
+                                                               const double *__restrict__ x, double *__restrict__ out) {
+    __shared__ double red[256];
+    const float *g = grot + (int64_t)blockIdx.x * ld;
+    const int tid = threadIdx.x;
+    double acc[3 + 2 * SG_MAXP];
+    for (int k = 0; k < 3 + 2 * p; ++k) acc[k] = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const double gv = (double)g[i], wi = w[i], wg = wi * gv;
+        acc[0] = fma(gv, gv, acc[0]);
+        acc[1] = fma(wg, gv, acc[1]);
+        acc[2] = fma(gv, a[i], acc[2]);
+        for (int k = 0; k < p; ++k) {
+            const double xv = x[(int64_t)i * p + k];
+            acc[3 + k] = fma(gv, xv, acc[3 + k]);
+            acc[3 + p + k] = fma(wg, xv, acc[3 + p + k]);
+        }
+    }
+    for (int k = 0; k < 3 + 2 * p; ++k) {
+        red[tid] = acc[k];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) out[(int64_t)blockIdx.x * (3 + 2 * p) + k] = red[0];
+        __syncthreads();
+    }
+}
+
 }  // namespace jx
 
 using namespace jx;
@@ -206,6 +287,54 @@ extern "C" int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, con
     const double ln_beta = lgamma(0.5 * df) + lgamma(0.5) - lgamma(0.5 * df + 0.5);
     hipLaunchKernelGGL(lm_stats_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, sums, ncols, dsum, nrows, q0, d_ixx,
                        yy_r, n, df, ln_beta, d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// GRAMMAR-gamma scan of `nrows` SNPs of a resident P32 image.  d_lut (nrows, 4) f32: mean-imputed additive values by 2-bit
+// code ([0, 2 maf, 1, 2] or flipped, not centred); d_xr (n, p + 1) f64 = [X | score vector] (rounded to f32 by the caller);
+// d_ixx (p, p) f64 = (X'X)^-1; d_work (nrows * (p + 2)) f64 scratch; d_out (nrows, 3) f64 = beta, se, p.
+extern "C" int jxg_splmm_grammar_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                          const float *d_lut, const double *d_xr, int p, const double *d_ixx,
+                                          double score_scale, double denom_scale, double sigma2, double *d_work,
+                                          double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || n <= p) return fail("SparseLMM scan requires n > p >= 1");
+    if (!(std::isfinite(score_scale) && score_scale > 0.0))
+        return fail("SparseLMM scan requires finite positive score scale, got " + std::to_string(score_scale));
+    if (!(std::isfinite(denom_scale) && denom_scale > 0.0))
+        return fail("SparseLMM scan requires finite positive denominator scale, got " + std::to_string(denom_scale));
+    if (!(std::isfinite(sigma2) && sigma2 > 0.0))
+        return fail("SparseLMM scan requires finite positive Wald sigma2, got " + std::to_string(sigma2));
+    hipStream_t st = (hipStream_t)stream;
+    const int ncols = p + 1;
+    double *sums = d_work, *dsum = d_work + (size_t)nrows * ncols;
+    const dim3 grid((nrows + LM_THREADS - 1) / LM_THREADS), block(LM_THREADS);
+    for (int c0 = 0; c0 < ncols; c0 += LM_MAXC) {
+        const int nc = std::min(LM_MAXC, ncols - c0);
+        double *dd = c0 == 0 ? dsum : nullptr;
+        switch (nc) {
+        case 1: hipLaunchKernelGGL(lm_dots_kernel<1>, grid, block, 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        case 2: hipLaunchKernelGGL(lm_dots_kernel<2>, grid, block, 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        case 3: hipLaunchKernelGGL(lm_dots_kernel<3>, grid, block, 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        default: hipLaunchKernelGGL(lm_dots_kernel<4>, grid, block, 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        }
+        JX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(splmm_grammar_stats_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, sums, ncols, dsum, nrows, p,
+                       d_ixx, score_scale, denom_scale, sigma2, d_out);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// d_grot (nrows, ld) f32 rotated marker rows; d_w, d_a (n) f64; d_x (n, p) f64 row-major (X~ = U'X);
+// d_out (nrows, 3 + 2 p) f64 = [g~'g~, g~'Wg~, g~'a~, X~'g~ (p), X~'Wg~ (p)].
+extern "C" int jxg_splmm_gamma_sums(const float *d_grot, int nrows, int n, int64_t ld, int p, const double *d_w,
+                                    const double *d_a, const double *d_x, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > SG_MAXP) return fail("SparseLMM gamma estimation supports 1 .. 16 design columns, got " + std::to_string(p));
+    hipLaunchKernelGGL(splmm_gamma_sums_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, d_grot, ld, n, p, d_w, d_a,
+                       d_x, d_out);
     JX_LAUNCH_CHECK();
     return 0;
 }

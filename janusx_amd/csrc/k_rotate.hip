@@ -686,10 +686,15 @@ static int rotate_core(const uint8_t *d_p32, int64_t m_total, int n, const int32
         if (launch_rotate_i8(st, d_p32, m_total, n, d_rows, d_sel_exact, n_exact, d_lut16, d_rowoff, d_usum, d_q, d_umax, d_out,
                              ld_out))
             return 1;
-        if (launch_rotate256(st, d_p32, m_total, n, d_rows, n_rest, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
-                             ldexpf(1.0f, -scale_exp), d_out, ld_out, d_sel_rest ? d_sel_rest : d_sel_exact, &took))
-            return 1;
-        g_last_ms[13] = n_exact > 0 ? 1.f : 0.f;
+        if (n_rest > 0) {
+            if (!d_sel_rest) return fail("jxg_rotate_packed16x_q: the list of the non-exact rows is missing");
+            if (launch_rotate256(st, d_p32, m_total, n, d_rows, n_rest, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
+                                 ldexpf(1.0f, -scale_exp), d_out, ld_out, d_sel_rest, &took))
+                return 1;
+        }
+        took = 1;   // every row of the block has been written by one of the two kernels: no 128-tile fallback behind them
+        g_last_ms[14] = (float)((n_exact > 0) + (n_rest > 0));      // rotation kernels launched for this block
+        g_last_ms[13] = (float)((double)n_exact / (double)nrows);   // share of the rows on the int8 kernel
     } else if (launch_rotate256(st, d_p32, m_total, n, d_rows, nrows, d_lut16, d_rowoff, d_usum, d_uhi, d_ulo,
                                 ldexpf(1.0f, -scale_exp), d_out, ld_out, nullptr, &took)) {   // full-size blocks: 256 x 256 tiles
         return 1;

@@ -924,6 +924,399 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     return out.cpu().numpy(), float(log10_lambda), null
 
 
+# ------------------------------------------------------------------------------------------------
+# `jx gwas -splmm` / `-splmm-exact`: splmm_assoc_pcg_bed[_to_tsv] (src/stats/splmm.rs:4641-5026)
+# ------------------------------------------------------------------------------------------------
+
+SPLMM_DEFAULT_RHAT_MARKERS = 30          # src/stats/splmm.rs:65-66
+SPLMM_DEFAULT_RHAT_SEED = 20260527
+
+
+class _StdRngU32:
+    """`StdRng::seed_from_u64` of rand 0.9.2 (Cargo.toml:42; the crate is not part of /root/reference): ChaCha12 keyed from a
+    PCG32 expansion of the seed, words in block order; `random_range(0..m)` with Canon's single-sample method (u32 draws
+    when the range fits 32 bits).  Restated from the published algorithm; the ChaCha core is pinned to RFC 7539, the seeding
+    and range-sampling conventions are not pinned by any vector of the reference."""
+
+    def __init__(self, seed):
+        state = int(seed) & 0xffffffffffffffff
+        key = []
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & 0xffffffffffffffff
+            xs = (((state >> 18) ^ state) >> 27) & 0xffffffff
+            rot = state >> 59
+            key.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xffffffff)
+        self.key, self.counter, self.buf = key, 0, []
+
+    def _block(self):
+        def rotl(v, c):
+            return ((v << c) & 0xffffffff) | (v >> (32 - c))
+        st = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + self.key + [self.counter & 0xffffffff,
+                                                                            (self.counter >> 32) & 0xffffffff, 0, 0]
+        x = list(st)
+
+        def qr(a, b, c, d):
+            x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 16)
+            x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 12)
+            x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 8)
+            x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 7)
+        for _ in range(6):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        self.counter += 1
+        return [(x[i] + st[i]) & 0xffffffff for i in range(16)]
+
+    def next_u32(self):
+        if not self.buf:
+            self.buf = self._block()
+        return self.buf.pop(0)
+
+    def random_range(self, m):
+        if m - 1 > 0xffffffff:
+            bits, draw = 64, lambda: self.next_u32() | (self.next_u32() << 32)
+        else:
+            bits, draw = 32, self.next_u32
+        mask = (1 << bits) - 1
+        prod = draw() * m
+        result, lo = prod >> bits, prod & mask
+        if lo > ((-m) & mask):
+            if lo + ((draw() * m) >> bits) > mask:
+                result += 1
+        return result
+
+
+def splmm_choose_rhat_rows(m, count, seed):
+    """`choose_rhat_rows` (src/stats/splmm.rs:1493-1507)."""
+    soft_cap = min(int(count), int(m))
+    if soft_cap == m:
+        return np.arange(m, dtype=np.int64)
+    rng = _StdRngU32(seed)
+    return np.unique(np.array([rng.random_range(int(m)) for _ in range(max(2 * soft_cap, soft_cap))], dtype=np.int64))
+
+
+def _splmm_prepare_inputs(prefix, y, x_cov, sample_indices, operator_sample_indices, site_keep, packed, packed_n_samples,
+                          maf, row_flip, row_missing, row_indices, model, mmap_window_mb):
+    """`prepare_splmm_assoc_inputs` (src/stats/splmm.rs:1302-1490): the three input forms -- external packed payload,
+    BED prefix with the caller's row metadata, BED prefix alone (row statistics on the scan samples, no filter)."""
+    from . import bed as _bed
+    from . import stats as st
+    if str(model) != "add":
+        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
+    bed_prefix = _bed_prefix(prefix)
+    if not bed_prefix:
+        raise RuntimeError("BED-prefix mode requires a non-empty prefix")
+    yv = _c(y, np.float64).ravel()
+    n = int(yv.shape[0])
+    if n == 0:
+        raise RuntimeError("y must not be empty")
+    xc = None
+    if x_cov is not None:
+        xc = _c(x_cov, np.float64)
+        if xc.ndim != 2:
+            raise RuntimeError("x_cov must be 2D (n, p_cov)")
+        if xc.shape[0] != n:
+            raise RuntimeError(f"x_cov row count mismatch: got {xc.shape[0]}, expected {n}")
+    p = 1 + (0 if xc is None else int(xc.shape[1]))
+    if n <= p:
+        raise RuntimeError(f"n must be > p for SparseLMM: n={n}, p={p}")
+    use_packed = packed is not None or int(packed_n_samples) > 0
+    use_meta = (not use_packed) and any(a is not None for a in (maf, row_flip, row_missing, row_indices))
+    if use_packed:
+        for name, arr in (("packed", packed), ("maf", maf), ("row_flip", row_flip)):
+            if arr is None:
+                raise RuntimeError(f"splmm_assoc_pcg_bed: packed payload path requires `{name}` argument.")
+        if int(packed_n_samples) <= 0:
+            raise RuntimeError("splmm_assoc_pcg_bed: packed payload path requires packed_n_samples > 0")
+        n_full = int(packed_n_samples)
+        pk, _ptr_, m_packed = _payload(packed, n_full)
+    else:
+        if use_meta:
+            for name, arr in (("maf", maf), ("row_flip", row_flip), ("row_indices", row_indices)):
+                if arr is None:
+                    raise RuntimeError(f"splmm_assoc_pcg_bed: mmap metadata path requires `{name}` argument.")
+        pk, n_full, _bim = _bed.stage_bed_payload(bed_prefix, mmap_window_mb)
+        m_packed = int(pk.shape[0])
+    if n_full == 0:
+        raise RuntimeError("No samples found in BED input.")
+
+    def idx(a, label):
+        if a is None:
+            return None
+        v = _c(a, np.int64).ravel()
+        if v.size and (v.min() < 0 or v.max() >= n_full):
+            raise RuntimeError(f"{label} out of range for n_samples={n_full}")
+        return v
+    scan_idx = idx(sample_indices, "sample_indices")
+    op_idx = idx(operator_sample_indices, "operator_sample_indices")
+    if op_idx is None:
+        op_idx = scan_idx
+    for v, label in ((scan_idx, "sample_indices"), (op_idx, "operator_sample_indices")):
+        if v is not None and v.shape[0] != n:
+            raise RuntimeError(f"{label} length mismatch: got {v.shape[0]}, expected {n}")
+    if scan_idx is None and n != n_full:
+        raise RuntimeError(f"len(y)={n} must equal scan n_samples={n_full} when sample_indices is not provided")
+    if use_packed or use_meta:
+        rows = None if row_indices is None else _c(row_indices, np.int64).ravel()
+        if rows is not None and rows.size and (rows.min() < 0 or rows.max() >= m_packed):
+            raise RuntimeError("row_indices out of range")
+        m = m_packed if rows is None else int(rows.shape[0])
+        maf32 = _c(maf, np.float32).ravel()
+        flip = np.asarray(row_flip).astype(bool).ravel()
+        miss = np.full(m, np.nan, dtype=np.float32) if row_missing is None else _c(row_missing, np.float32).ravel()
+        if maf32.shape[0] != m or flip.shape[0] != m or miss.shape[0] != m:
+            raise RuntimeError(f"{'packed' if use_packed else 'mmap'} metadata length mismatch: rows={m}, "
+                               f"row_maf={maf32.shape[0]}, row_flip={flip.shape[0]}, row_missing={miss.shape[0]}")
+        if rows is None:
+            rows = np.arange(m, dtype=np.int64)
+    else:
+        # `prepare_prefix_input` (:1248-1290): packed-prep row statistics on the scan samples, thresholds (0, 1, 0); the
+        # logic meta keeps maf = ALT frequency and never flips (src/io/gfreader.rs:5139, 5378-5460)
+        counts = bed_row_counts(pk, n_full, scan_idx)
+        keep, miss_all, maf_all, _std = st.packed_prep_row_stats(counts, n if scan_idx is not None else n_full, 0.0, 1.0, 0.0)
+        flip_all = np.zeros(m_packed, dtype=bool)
+        if site_keep is not None:
+            sk = np.asarray(site_keep).astype(bool).ravel()
+            if sk.shape[0] != m_packed:
+                raise RuntimeError(f"site_keep length mismatch: got {sk.shape[0]}, expected {m_packed}")
+            keep = keep & sk
+        rows = np.nonzero(keep)[0].astype(np.int64)
+        maf32, flip, miss = maf_all[rows].astype(np.float32), flip_all[rows], miss_all[rows].astype(np.float32)
+    return dict(pk=pk, n_full=n_full, rows=rows, maf=maf32, flip=flip, miss=miss, y=yv, x_cov=xc, scan_idx=scan_idx,
+                op_idx=op_idx, bed_prefix=None if use_packed else bed_prefix, n=n, p=p)
+
+
+def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat_markers, rhat_seed, rhat_rows=None,
+                       on_block=None):
+    """`estimate_residualized_approx_scan_sparse` (src/stats/splmm_approx.rs:701-795) on the spectral form of K + lambda I
+    (`_SpectralSparseReml`): residualised response, a = V^-1 y_r / sigma2 through the eigenbasis, gamma from the sampled
+    markers (their rotation by the MFMA kernel + `jxg_splmm_gamma_sums`), scan model a_r = M_X a, GRAMMAR scan in sample
+    space (`jxg_splmm_grammar_scan_p32`).  -> (gamma, stats (m, 3) on the device, markers requested, markers used)."""
+    import math
+    import torch
+    from . import pipeline as pl
+    n, p = model.n, model.p
+    x, yv = model.x_design, model.y_raw                   # the model's sample order (block order on the block route)
+    xtx = x.T @ x
+    cx = _spd_cholesky_with_jitter(xtx, "SparseLMM approx XtX")
+    solve = lambda b: np.linalg.solve(cx.T, np.linalg.solve(cx, b))        # noqa: E731
+    c_y = solve(x.T @ yv)
+    y_resid = yv - x @ c_y
+    rss = float(y_resid @ y_resid)
+    if not (math.isfinite(rss) and rss > 1e-30):
+        raise RuntimeError(f"SparseLMM residualized approx produced invalid residualized RSS: {rss}")
+    sigma2 = rss / (float(n - p) * (1.0 + lam))
+    if not (math.isfinite(sigma2) and sigma2 > 0.0):
+        raise RuntimeError(f"SparseLMM residualized approx produced invalid scan sigma2 at lambda={lam}: {sigma2}")
+    w = 1.0 / (model.s + lam)
+    a_rot = w * (model.yr - model.xr @ c_y) / sigma2      # U'a,  a = (K + lambda I)^-1 y_r / sigma2
+    dev = model.s_dev.device
+    a_rot_t = torch.from_numpy(a_rot).to(dev)
+    if model.blocks is not None:
+        a_t = torch.empty(n, dtype=torch.float64, device=dev)
+        for off, nb, utb in model.blocks:
+            a_t[off:off + nb] = utb.T @ a_rot_t[off:off + nb]
+    else:
+        a_t = model.ut_dev.T @ a_rot_t
+    a_vec = a_t.cpu().numpy()
+    # ---- gamma from sampled markers
+    m = len(rows)
+    rr = splmm_choose_rhat_rows(m, rhat_markers, rhat_seed) if rhat_rows is None else _c(rhat_rows, np.int64).ravel()
+    if rr.size and (rr.min() < 0 or rr.max() >= m):
+        raise RuntimeError("rhat rows out of range")
+    mean_g = np.clip(np.float32(2.0) * maf32, np.float32(0.0), np.float32(2.0)).astype(np.float32)
+    lut = np.empty((m, 4), dtype=np.float32)
+    lut[:, 0] = np.where(flip, 2.0, 0.0)
+    lut[:, 1] = mean_g
+    lut[:, 2] = 1.0
+    lut[:, 3] = np.where(flip, 0.0, 2.0)
+    if _is_device_tensor(pk):
+        packed_t = pk.to(dev)
+    else:
+        packed_t = torch.from_numpy(pk if pk.flags.writeable else pk.copy()).to(dev)
+    panel_idx = scan_idx
+    if model.perm is not None:
+        panel_idx = model.perm if scan_idx is None else scan_idx[model.perm]
+    sub = packed_t[torch.from_numpy(rows[rr]).to(dev)]    # payload of the sampled markers only
+    sub_rows = np.arange(len(rr), dtype=np.int32)
+    if model.blocks is not None:
+        full_idx = np.arange(n_full, dtype=np.int64) if panel_idx is None else panel_idx
+        rot = pl.BlockRotation(sub, n_full, full_idx, model.blocks)
+        grot = pl.rotate_rows_blocks(rot, sub_rows, lut[rr])
+        del rot
+    else:
+        sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
+        grot = pl.rotate_rows(pl.Panel(sub, n_full, panel_idx), sm, sub_rows, lut[rr])
+    sums = torch.empty((len(rr), 3 + 2 * p), dtype=torch.float64, device=dev)
+    xr_t = torch.from_numpy(np.ascontiguousarray(model.xr)).to(dev)
+    w_t = torch.from_numpy(w).to(dev)
+    check(lib().jxg_splmm_gamma_sums(grot.data_ptr(), len(rr), n, n, p, w_t.data_ptr(), a_rot_t.data_ptr(), xr_t.data_ptr(),
+                                     sums.data_ptr(), pl._stream()))
+    sums = sums.cpu().numpy()
+    del grot, sub
+    xtwx = model.xr.T @ (model.xr * w[:, None])
+    xta = model.xr.T @ a_rot
+    fast_sum = res_sum = 0.0
+    n_used = res_used = 0
+    for k in range(len(rr)):
+        gg, wgg, ag = sums[k, 0], sums[k, 1], sums[k, 2]
+        xg, wxg = sums[k, 3:3 + p], sums[k, 3 + p:]
+        c = solve(xg)
+        s_ms = gg - float(xg @ c)
+        if not (math.isfinite(s_ms) and math.isfinite(gg)) or s_ms <= max(1e-10, 1e-12 * max(abs(gg), 1.0)):
+            continue
+        svs = wgg - 2.0 * float(c @ wxg) + float(c @ xtwx @ c)
+        if not (math.isfinite(svs) and svs > 1e-30):
+            continue
+        ratio = svs / s_ms
+        if not (math.isfinite(ratio) and ratio > 0.0):
+            continue
+        res_sum += ratio
+        res_used += 1
+        score = ag - float(c @ xta)
+        chisq = score * score / svs
+        if math.isfinite(chisq) and chisq < 5.0:
+            fast_sum += ratio
+            n_used += 1
+        if k + 1 >= rhat_markers and n_used >= 100:
+            break
+    if n_used == 0 and res_used == 0:
+        raise RuntimeError("SparseLMM residualized approx gamma estimation found no valid sampled markers")
+    gamma, used = (fast_sum / n_used, n_used) if n_used >= 100 else (res_sum / res_used, res_used)
+    gamma *= 1.0 / sigma2
+    if not (math.isfinite(gamma) and gamma > 0.0):
+        raise RuntimeError(f"SparseLMM residualized approx gamma must be finite and > 0, got {gamma}")
+    # ---- scan model + scan, in the caller's sample order
+    a_resid = a_vec - x @ solve(x.T @ a_vec)
+    if model.perm is not None:
+        inv = np.empty(n, dtype=np.int64)
+        inv[model.perm] = np.arange(n)
+        a_resid, x_scan = a_resid[inv], x[inv]
+    else:
+        x_scan = x
+    panel = pl.Panel(packed_t, n_full, scan_idx)
+    out = pl.scan_rows_grammar(panel, rows.astype(np.int32), lut, x_scan, a_resid, gamma, on_block=on_block)
+    return float(gamma), out, int(len(rr)), int(used)
+
+
+def _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices, site_keep, tol, max_iter, block_rows,
+                 std_eps, threads, model, rhat_markers, rhat_seed, packed, packed_n_samples, maf, row_flip, row_missing,
+                 row_indices, sparse_sample_indices, sparse_jxgrm_path, progress_callback, progress_every, scan_mode,
+                 mmap_window_mb, rhat_rows=None):
+    import math
+    if int(max_iter) == 0:
+        raise RuntimeError("max_iter must be > 0")
+    if not (math.isfinite(tol) and tol > 0.0):
+        raise RuntimeError("tol must be finite and > 0")
+    if not (math.isfinite(std_eps) and std_eps > 0.0):
+        raise RuntimeError("std_eps must be finite and > 0")
+    if not (math.isfinite(lbd) and lbd >= 0.0):
+        raise RuntimeError("lbd must be finite and >= 0")
+    mode = str(scan_mode).strip().lower()
+    if mode not in ("approx", "exact"):
+        raise RuntimeError(f"unsupported SparseLMM scan mode: {scan_mode}")
+    if mode == "approx" and int(rhat_markers) == 0:
+        raise RuntimeError("rhat_markers must be > 0")
+    inp = _splmm_prepare_inputs(prefix, y, x_cov, sample_indices, operator_sample_indices, site_keep, packed,
+                                packed_n_samples, maf, row_flip, row_missing, row_indices, model, mmap_window_mb)
+    path = sparse_jxgrm_path if sparse_jxgrm_path else _normalize_spgrm_path(_bed_prefix(prefix))
+    sp_idx = inp["op_idx"] if sparse_sample_indices is None else _c(sparse_sample_indices, np.int64).ravel()
+    if sp_idx is not None and sp_idx.shape[0] != inp["n"]:
+        raise RuntimeError(f"sparse_sample_indices length mismatch: got {sp_idx.shape[0]}, expected {inp['n']}")
+    lam = float(lbd)
+    with _progress_hook(progress_callback, progress_every):
+        if mode == "exact":
+            if not lam > 0.0:
+                raise RuntimeError("K + lambda I is not positive definite at lambda=0")
+            out, _l10, _null = splmm_exact_scan_from_jxgrm(path, inp["y"], inp["pk"], inp["n_full"],
+                                                           _expand_rows(inp["maf"], inp["rows"], inp["pk"].shape[0]),
+                                                           _expand_rows(inp["flip"], inp["rows"], inp["pk"].shape[0]),
+                                                           inp["x_cov"], inp["scan_idx"], inp["rows"], math.log10(lam),
+                                                           grm_sample_indices=sp_idx)
+            r_hat, req, used = float("nan"), 0, 0
+        else:
+            spm = _SpectralSparseReml(path, inp["y"], inp["x_cov"], sp_idx)
+            if not spm.factorizable(lam) and not (lam == 0.0 and spm.smin > 0.0):
+                raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
+            r_hat, out_t, req, used = _splmm_approx_scan(spm, lam, inp["pk"], inp["n_full"], inp["maf"], inp["flip"],
+                                                         inp["rows"], inp["scan_idx"], int(rhat_markers), int(rhat_seed),
+                                                         rhat_rows)
+            out = out_t.cpu().numpy()
+            req = int(rhat_markers)
+    _done(progress_callback, len(inp["rows"]))
+    n_all, col_ptr, _r, _v = load_spgrm(path)
+    return inp, r_hat, out, req, used, int(col_ptr[-1])
+
+
+def _expand_rows(values, rows, m_total):
+    """Row metadata given for the selected rows -> an array indexed by payload row (what the packed entry points take)."""
+    full = np.zeros(int(m_total), dtype=np.asarray(values).dtype)
+    full[rows] = values
+    return full
+
+
+def splmm_assoc_pcg_bed(prefix, y, lbd, x_cov=None, sample_indices=None, operator_sample_indices=None, site_keep=None,
+                        tol=1e-5, max_iter=200, block_rows=0, std_eps=1e-12, use_train_maf=True, threads=0, model="add",
+                        rhat_markers=SPLMM_DEFAULT_RHAT_MARKERS, rhat_seed=SPLMM_DEFAULT_RHAT_SEED, packed=None,
+                        packed_n_samples=0, maf=None, row_flip=None, row_missing=None, row_indices=None,
+                        sparse_sample_indices=None, sparse_jxgrm_path=None, stage1_progress_callback=None,
+                        scan_progress_callback=None, progress_every=0, rhat_tol=1e-3, scan_mode="exact",
+                        mmap_window_mb=None, rhat_rows=None):
+    """src/stats/splmm.rs:4608-4773 -> (r_hat, y_converged, y_iters, y_rel_res, x_converged_all, x_max_iters, x_max_rel_res,
+    rhat_markers_requested, rhat_markers_used, stats f64 (m, 3), factor_nnz).  scan_mode "exact" = null state + score-form
+    exact scan at the given lambda (`estimate_rhat_and_scan_sparse`, :3711); "approx" = the residualised GRAMMAR-gamma route
+    (`estimate_residualized_approx_scan_sparse`, src/stats/splmm_approx.rs:701).  V^-1 comes from the eigendecomposition of
+    the sparse K, so the solve diagnostics are those of a direct method (converged, one iteration, zero residual: what the
+    reference reports for its sparse Cholesky, :3620-3645); `factor_nnz` is the number of stored entries of the sparse GRM
+    (no L factor exists here).  `rhat_rows` (extension) overrides the seeded choice of the sampled markers."""
+    inp, r_hat, out, req, used, nnz = _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices, site_keep,
+                                                   tol, max_iter, block_rows, std_eps, threads, model, rhat_markers,
+                                                   rhat_seed, packed, packed_n_samples, maf, row_flip, row_missing,
+                                                   row_indices, sparse_sample_indices, sparse_jxgrm_path,
+                                                   scan_progress_callback, progress_every, scan_mode, mmap_window_mb,
+                                                   rhat_rows)
+    return (r_hat, True, 1, 0.0, True, 1, 0.0, req, used, out, nnz)
+
+
+def splmm_assoc_pcg_bed_to_tsv(prefix, y, lbd, chrom, pos, snp, allele0, allele1, out_tsv, x_cov=None, sample_indices=None,
+                               operator_sample_indices=None, site_keep=None, tol=1e-5, max_iter=200, block_rows=0,
+                               std_eps=1e-12, use_train_maf=True, threads=0, model="add",
+                               rhat_markers=SPLMM_DEFAULT_RHAT_MARKERS, rhat_seed=SPLMM_DEFAULT_RHAT_SEED, packed=None,
+                               packed_n_samples=0, maf=None, row_flip=None, row_missing=None, row_indices=None,
+                               sparse_sample_indices=None, sparse_jxgrm_path=None, stage1_progress_callback=None,
+                               scan_progress_callback=None, progress_every=0, rhat_tol=1e-3, scan_mode="exact",
+                               mmap_window_mb=None, rhat_rows=None):
+    """src/stats/splmm.rs:4775-5026 -> (r_hat, y_converged, y_iters, y_rel_res, x_converged_all, x_max_iters, x_max_rel_res,
+    rhat_markers_requested, rhat_markers_used, rows written, (prepare, bim, null + scan, writer wait, ...) seconds); the TSV
+    has the Basic3 schema with `af` = row_maf and `miss` = the missing rate (:461-475).  Empty metadata lists: the BIM file
+    of `prefix` is read for the selected rows."""
+    import time
+    from .tsv import write_assoc_tsv
+    t0 = time.perf_counter()
+    inp, r_hat, out, req, used, _nnz = _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices, site_keep,
+                                                    tol, max_iter, block_rows, std_eps, threads, model, rhat_markers,
+                                                    rhat_seed, packed, packed_n_samples, maf, row_flip, row_missing,
+                                                    row_indices, sparse_sample_indices, sparse_jxgrm_path,
+                                                    scan_progress_callback, progress_every, scan_mode, mmap_window_mb,
+                                                    rhat_rows)
+    t1 = time.perf_counter()
+    m = out.shape[0]
+    if not len(chrom):
+        from .bed import read_bim
+        bim = read_bim(_bed_prefix(prefix))
+        sel = inp["rows"]
+        chrom = [bim.chrom[j] for j in sel]
+        pos = [bim.pos[j] for j in sel]
+        snp = [bim.snp[j] for j in sel]
+        allele0 = [bim.a0[j] for j in sel]
+        allele1 = [bim.a1[j] for j in sel]
+    elif not (len(chrom) == len(pos) == len(snp) == len(allele0) == len(allele1) == m):
+        raise RuntimeError(f"SparseLMM TSV metadata length mismatch: rows={m}")
+    t2 = time.perf_counter()
+    written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, inp["maf"], inp["miss"], out)
+    t3 = time.perf_counter()
+    return (r_hat, True, 1, 0.0, True, 1, 0.0, req, used, int(written), (0.0, t2 - t1, t1 - t0, t3 - t2))
+
+
 def _bed_prefix(prefix):
     """PLINK prefix with a trailing .bed / .bim / .fam removed (`normalize_plink_prefix`, src/io/gfcore.rs)."""
     t = str(prefix).strip()

@@ -582,6 +582,69 @@ def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np
     return out
 
 
+def rotate_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray) -> torch.Tensor:
+    """G~ = G U for a (small) list of SNP rows, written out: (len(rows), n) f32 on the device (the fp16 hi / lo rotation of
+    `scan_rows` without a scan behind it; used for the sampled markers of the SparseLMM gamma estimate)."""
+    dev, n, mk = panel.device, model.n, len(rows)
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    hi, lo, usum = model.planes()
+    lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
+    rowoff = torch.empty(mk, dtype=torch.float32, device=dev)
+    check(lib().jxg_lut_split_rows(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16), _ptr(rowoff),
+                                   _stream()))
+    grot = torch.empty((mk, n), dtype=torch.float32, device=dev)
+    check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, _ptr(rows_t), mk, _ptr(lut16), _ptr(rowoff), _ptr(usum),
+                                     _ptr(hi), _ptr(lo), SCALE_EXP, _ptr(grot), _stream()))
+    return grot
+
+
+def rotate_rows_blocks(rot: BlockRotation, rows: np.ndarray, lut: np.ndarray) -> torch.Tensor:
+    """`rotate_rows` for a block-diagonal eigenbasis: every diagonal block writes its columns of the rotated rows."""
+    dev, n, mk = rot.device, rot.n, len(rows)
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
+    check(lib().jxg_lut_split(_ptr(lut_t), mk, _ptr(lut16), _stream()))
+    grot = torch.empty((mk, n), dtype=torch.float32, device=dev)
+    for off, nb, hi, lo, panel in rot.parts:
+        check(lib().jxg_rotate_packed16x_ld(_ptr(panel.p32), panel.m, nb, _ptr(rows_t), mk, _ptr(lut16), None, None, _ptr(hi),
+                                            _ptr(lo), SCALE_EXP, grot[:, off:].data_ptr(), n, _stream()))
+    return grot
+
+
+def scan_rows_grammar(panel: Panel, rows: np.ndarray, lut: np.ndarray, x: np.ndarray, score_vec: np.ndarray, r_hat: float,
+                      block_rows=65536, on_block=None):
+    """SparseLMM approximate (GRAMMAR-gamma) scan over the payload in sample space (`jxg_splmm_grammar_scan_p32`,
+    src/stats/splmm.rs:2935-3316 as called by `scan_with_py_and_rhat`, :3318): no rotation, (p + 1) dots per SNP.
+    x (n, p) f64 design with intercept, score_vec (n) f64; both are rounded to f32 like `pack_score_design_rhs_f32`.
+    Returns (len(rows), 3) f64 [beta, se, p] on the device."""
+    dev, n, mk = panel.device, panel.n, len(rows)
+    p = int(x.shape[1])
+    out = torch.empty((mk, 3), dtype=torch.float64, device=dev)
+    if mk == 0:
+        return out
+    if not (np.all(np.isfinite(score_vec)) and np.all(np.isfinite(x))):
+        raise RuntimeError("SparseLMM scan received non-finite dense operand")
+    xr = np.concatenate([x, np.asarray(score_vec, dtype=np.float64)[:, None]], axis=1).astype(np.float32).astype(np.float64)
+    xtx = np.asarray(x, dtype=np.float64).T @ np.asarray(x, dtype=np.float64)
+    ixx = np.linalg.inv(xtx)
+    xr_t = torch.from_numpy(np.ascontiguousarray(xr)).to(dev)
+    ixx_t = torch.from_numpy(np.ascontiguousarray(ixx)).to(dev)
+    rows_t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
+    br = int(min(block_rows, mk))
+    work = torch.empty(br * (p + 2), dtype=torch.float64, device=dev)
+    for r0 in range(0, mk, br):
+        nr = min(br, mk - r0)
+        check(lib().jxg_splmm_grammar_scan_p32(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr, lut_t[r0:].data_ptr(),
+                                               _ptr(xr_t), p, _ptr(ixx_t), 1.0, float(r_hat), 1.0, _ptr(work),
+                                               out[r0:].data_ptr(), _stream()))
+        if on_block is not None:
+            on_block(r0, out[r0:r0 + nr].cpu().numpy())
+    return out
+
+
 def scan_rows_lm(panel: Panel, rows: np.ndarray, af: np.ndarray, x: np.ndarray, y: np.ndarray, on_block=None):
     """Plain LM scan of the given SNP rows of a resident panel (`lm_block_assoc_packed`, src/stats/glm.rs:3550-3860; the `LM`
     wrapper python/janusx/pyBLUP/assoc.py:2185-2228): mean-imputed additive decode with the rows' allele frequencies, `x`

@@ -755,6 +755,216 @@ def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip
     return out
 
 
+# ---- SparseLMM approximate (GRAMMAR-gamma / fastGWA-style) route: `jx gwas -splmm` -----------------------------------------
+
+def _chacha_block(key_words, counter, rounds, stream=(0, 0)):
+    """One 64-byte ChaCha block (D. J. Bernstein's original layout: 64-bit block counter in words 12-13, 64-bit stream id
+    in words 14-15, 0 for `StdRng`), `rounds` rounds -> 16 u32 words."""
+    def rotl(v, c):
+        return ((v << c) & 0xffffffff) | (v >> (32 - c))
+    st = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + list(key_words) + [counter & 0xffffffff, (counter >> 32) & 0xffffffff, stream[0], stream[1]]
+    x = list(st)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 7)
+    for _ in range(rounds // 2):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(x[i] + st[i]) & 0xffffffff for i in range(16)]
+
+
+class StdRngU32:
+    """`StdRng::seed_from_u64(seed)` of the rand crate 0.9.2 (Cargo.toml:42; the crate itself is NOT in /root/reference and
+    there is no Cargo.lock): ChaCha12 keyed by 32 bytes that rand_core's default `seed_from_u64` draws from a PCG32 stream
+    (multiplier 6364136223846793005, increment 11634580027462260723, state advanced before every output, XSH-RR output,
+    little-endian), words handed out in block order.  Restated from the published algorithm; **parity unpinned** (no
+    golden vector of the reference depends on it, and the crate cannot be run here).  The ChaCha core itself is pinned to
+    RFC 7539 section 2.3.2 with 20 rounds in tests/test_oracle_golden.py."""
+
+    def __init__(self, seed):
+        state = int(seed) & 0xffffffffffffffff
+        key = []
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & 0xffffffffffffffff
+            xorshifted = (((state >> 18) ^ state) >> 27) & 0xffffffff
+            rot = state >> 59
+            key.append(((xorshifted >> rot) | (xorshifted << ((32 - rot) & 31))) & 0xffffffff)
+        self.key, self.counter, self.buf = key, 0, []
+
+    def next_u32(self):
+        if not self.buf:
+            self.buf = _chacha_block(self.key, self.counter, 12)
+            self.counter += 1
+        return self.buf.pop(0)
+
+    def next_u64(self):
+        lo = self.next_u32()
+        return lo | (self.next_u32() << 32)
+
+    def random_range(self, m):
+        """`rng.random_range(0..m)` for usize (rand 0.9 `UniformUsize::sample_single`: ranges that fit 32 bits are sampled
+        as u32 for portability, others as u64) with Canon's biased single-sample method: widening multiply, one more draw
+        only when the low half could carry."""
+        if m <= 0:
+            raise ValueError("empty range")
+        if m - 1 > 0xffffffff:
+            bits, draw = 64, self.next_u64
+        else:
+            bits, draw = 32, self.next_u32
+        mask = (1 << bits) - 1
+        prod = draw() * m
+        result, lo = prod >> bits, prod & mask
+        if lo > ((-m) & mask):
+            new_hi = (draw() * m) >> bits
+            if lo + new_hi > mask:
+                result += 1
+        return result
+
+
+def choose_rhat_rows(m, count, seed):
+    """src/stats/splmm.rs:1493-1507: all rows when count >= m, else 2 count draws with replacement, sorted, deduplicated."""
+    soft_cap = min(int(count), int(m))
+    if soft_cap == m:
+        return np.arange(m, dtype=np.int64)
+    rng = StdRngU32(seed)
+    return np.unique(np.array([rng.random_range(m) for _ in range(max(2 * soft_cap, soft_cap))], dtype=np.int64))
+
+
+def splmm_xtx_chol(x_design):
+    """`xtx_chol_from_design` (src/stats/splmm_approx.rs:310-328)."""
+    return spd_cholesky_with_jitter(x_design.T @ x_design, "SparseLMM approx XtX")
+
+
+def splmm_residualize(x_design, cx, v):
+    """`residualize_vector_with_chol` (src/stats/splmm_approx.rs:400-428): v - X (X'X)^-1 X'v."""
+    return v - x_design @ cholesky_solve(cx, x_design.T @ v)
+
+
+def splmm_additive_row_f64(codes_row, maf32, flip):
+    """`decode_packed_row_model_into_f64` (src/decode/decode.rs:307-364), additive model: missing -> max(2 maf, 0) in f64."""
+    mean_g = max(2.0 * float(F32(maf32)), 0.0)
+    lut = np.array([2.0, mean_g, 1.0, 0.0] if flip else [0.0, mean_g, 1.0, 2.0], dtype=np.float64)
+    return lut[codes_row]
+
+
+def splmm_approx_null(k, x_design, y, lam):
+    """`build_residualized_approx_scan_null_from_lambda_and_factor` (src/stats/splmm_approx.rs:612-699): y_r = M_X y,
+    sigma2 = y_r'y_r / ((n - p)(1 + lambda)), a = (K + lambda I)^-1 y_r / sigma2, gamma scale 1 / sigma2.
+    -> (factor, y_resid, a_vec, sigma2_scan)."""
+    y = np.asarray(y, dtype=np.float64)
+    n, p = x_design.shape
+    if n <= p:
+        raise RuntimeError(f"SparseLMM residualized approx requires n > p, got n={n}, p={p}")
+    cx = splmm_xtx_chol(x_design)
+    y_resid = splmm_residualize(x_design, cx, y)
+    rss = float(y_resid @ y_resid)
+    if not (math.isfinite(rss) and rss > 1e-30):
+        raise RuntimeError(f"SparseLMM residualized approx produced invalid residualized RSS: {rss}")
+    sigma2 = rss / (float(n - p) * (1.0 + lam))
+    fac = SpdFactor(k, lam)
+    return fac, y_resid, fac.solve(y_resid) / sigma2, sigma2
+
+
+def splmm_estimate_gamma(fac, x_design, markers, a_vec, soft_cap, gamma_scale):
+    """`estimate_gamma_from_markers` (src/stats/splmm_approx.rs:921-1068): per sampled marker g_r = M_X g, ratio =
+    g_r'V^-1 g_r / g_r'g_r; markers whose score chi-square (g_r.a)^2 / g_r'V^-1 g_r is below 5 are "nulls"; gamma = mean
+    ratio over the nulls when there are at least 100 of them (stopping once soft_cap markers were looked at), else over all
+    valid markers; times the scale.  markers: (n_markers, n) f64.  -> (gamma, markers used)."""
+    cx = splmm_xtx_chol(x_design)
+    fast_sum = res_sum = 0.0
+    n_used = res_used = 0
+    for idx, g in enumerate(markers):
+        g_sq = float(g @ g)
+        g_r = splmm_residualize(x_design, cx, g)
+        s_ms = float(g_r @ g_r)
+        if splmm_residual_sumsq_is_effectively_zero(s_ms, g_sq):
+            continue
+        svs = float(g_r @ fac.solve(g_r))
+        if not (math.isfinite(svs) and svs > 1e-30):
+            continue
+        ratio = svs / s_ms
+        if not (math.isfinite(ratio) and ratio > 0.0):
+            continue
+        res_sum += ratio
+        res_used += 1
+        score = float(g_r @ a_vec)
+        chisq = score * score / svs
+        if math.isfinite(chisq) and chisq < 5.0:
+            fast_sum += ratio
+            n_used += 1
+        if idx + 1 >= soft_cap and n_used >= 100:
+            break
+    if n_used == 0 and res_used == 0:
+        raise RuntimeError("SparseLMM residualized approx gamma estimation found no valid sampled markers")
+    if n_used >= 100:
+        return fast_sum / n_used * gamma_scale, n_used
+    return res_sum / res_used * gamma_scale, res_used
+
+
+def splmm_residual_sumsq_is_effectively_zero(resid, raw):
+    """src/stats/splmm.rs:1710-1717."""
+    if not (math.isfinite(resid) and math.isfinite(raw)):
+        return True
+    return resid <= max(1e-10, 1e-12 * max(abs(raw), 1.0))
+
+
+def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_hat, sample_idx=None, rows=None,
+                       score_scale=1.0, wald_sigma2=1.0):
+    """`grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316) as `scan_with_py_and_rhat` calls it (:3318):
+    mean-imputed additive f32 decode (not centred), [score | X'g] = f32 GEMM of the block with f32([score_vec | X]), row sum
+    of squares from the counts (`additive_row_sumsq_from_counts`, :1801-1820), g'M g = max(g'g - (X'g)'(X'X)^-1 (X'g), 0),
+    denominator r_hat g'M g, `splmm_wald_from_score_denom` with sigma2 = 1; rows whose residual sum of squares is
+    effectively zero and failed rows are (NaN, NaN, 1).  -> (m, 3) f64."""
+    n, p = x_design.shape
+    cx = splmm_xtx_chol(x_design)
+    rhs32 = np.concatenate([np.asarray(score_vec, dtype=np.float64)[:, None], x_design], axis=1).astype(np.float32)
+    codes = unpack_codes(np.ascontiguousarray(packed, dtype=np.uint8), n_samples)
+    if sample_idx is not None:
+        codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
+    rows = np.arange(codes.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
+    out = np.empty((len(rows), 3), dtype=np.float64)
+    for k, r in enumerate(rows):
+        mean32 = F32(min(max(F32(2.0) * F32(maf[r]), F32(0.0)), F32(2.0)))
+        lut = np.array([2.0, mean32, 1.0, 0.0] if row_flip[r] else [0.0, mean32, 1.0, 2.0], dtype=np.float32)
+        c = codes[r]
+        g32 = lut[c]
+        dots = (g32 @ rhs32).astype(np.float32)               # sgemm output, f32
+        missing, het, hom_alt = int(np.sum(c == 1)), int(np.sum(c == 2)), int(np.sum(c == 3))
+        hom_two = (n - missing - het - hom_alt) if row_flip[r] else hom_alt
+        mean_g = min(max(2.0 * float(F32(maf[r])), 0.0), 2.0)
+        s_sq = 4.0 * hom_two + (het + missing * mean_g * mean_g)
+        xts = dots[1:].astype(np.float64)
+        s_m_s = max(s_sq - float(xts @ cholesky_solve(cx, xts)), 0.0)
+        res = None
+        if not splmm_residual_sumsq_is_effectively_zero(s_m_s, s_sq):
+            res = splmm_wald_from_score_denom(score_scale * float(dots[0]), r_hat * s_m_s, wald_sigma2)
+        out[k] = res if res is not None else (float("nan"), float("nan"), 1.0)
+    return out
+
+
+def splmm_approx_assoc(k, lam, x_design, y, packed, n_samples, maf, row_flip, rhat_markers=30, rhat_seed=20260527,
+                       sample_idx=None, rhat_rows=None):
+    """`estimate_residualized_approx_scan_sparse` (src/stats/splmm_approx.rs:701-795) = the `-splmm` default of the
+    reference's workflow (scan_mode "approx"): null from lambda, gamma from sampled markers, scan model a_r = M_X a,
+    GRAMMAR scan.  `rhat_rows` overrides the seeded choice (see StdRngU32).  -> (gamma, (m, 3) f64, markers used, rows)."""
+    fac, _y_resid, a_vec, sigma2 = splmm_approx_null(k, x_design, y, lam)
+    m = np.asarray(packed).shape[0]
+    rr = choose_rhat_rows(m, rhat_markers, rhat_seed) if rhat_rows is None else np.asarray(rhat_rows, dtype=np.int64)
+    codes = unpack_codes(np.ascontiguousarray(np.asarray(packed)[rr], dtype=np.uint8), n_samples)
+    if sample_idx is not None:
+        codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
+    markers = np.stack([splmm_additive_row_f64(codes[i], maf[r], bool(row_flip[r])) for i, r in enumerate(rr)])
+    gamma, n_used = splmm_estimate_gamma(fac, x_design, markers, a_vec, rhat_markers, 1.0 / sigma2)
+    if not (math.isfinite(gamma) and gamma > 0.0):
+        raise RuntimeError(f"SparseLMM residualized approx gamma must be finite and > 0, got {gamma}")
+    a_resid = splmm_residualize(x_design, splmm_xtx_chol(x_design), a_vec)
+    out = splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, a_resid, gamma, sample_idx)
+    return gamma, out, n_used, rr
+
+
 def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
                    het_threshold=0.0, block_rows=65536):
     """`grm_stream_bed_f32` restatement (src/stats/grm.rs:4690-5455): prestat pass -> keep/flip/mean/

@@ -40,17 +40,19 @@ def main():
                            "gfx950 (double before comparing with bytes). Per-kernel means over dispatches "
                            "(scripts/pmc_summarize.py).", "shape": shape, "runs": runs}, open(out, "w"), indent=1)
         print("wrote", out, {k: len(v) for k, v in runs.items()})
-    path = os.path.join(src, "mfma.json")
-    if os.path.exists(path):
+    for fname, kind, extra in (("mfma.json", "mfma", ""), ("mfma_missing.json", "mfma_missing1pct", " --missing 0.01")):
+        path = os.path.join(src, fname)
+        if not os.path.exists(path):
+            continue
         d = json.load(open(path))
         d["note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 "
-                     f"GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra; MI355X, {note} (n={n} "
+                     f"GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra{extra}; MI355X, {note} (n={n} "
                      f"m={m} -lmm). MFMA-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 "
                      "SIMDs). Per-kernel means over dispatches.")
         d["shape"] = shape
         # keep the summary small: only this library's kernels
         d["kernels"] = {k: v for k, v in d["kernels"].items() if "jx::" in k}
-        out = os.path.join(root, f"{tag}_pmc_mfma.json")
+        out = os.path.join(root, f"{tag}_pmc_{kind}.json")
         json.dump(d, open(out, "w"), indent=1)
         print("wrote", out)
 

@@ -15,4 +15,6 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_fv -- pyt
 python3 scripts/pmc_summarize.py $O/fetch_fv $O/fetch_fv.json fetch_fv > /dev/null; rm -rf $O/fetch_fv
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $O/mfma.log 2>&1
 python3 scripts/pmc_summarize.py $O/mfma $O/mfma.json mfma > /dev/null; rm -rf $O/mfma
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_missing -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --missing 0.01 > $O/mfma_missing.log 2>&1
+python3 scripts/pmc_summarize.py $O/mfma_missing $O/mfma_missing.json mfma_missing > /dev/null; rm -rf $O/mfma_missing
 ls -la $O $O/stats/*

@@ -457,6 +457,13 @@ def test_full_size_rotation_kernels_with_mixed_rows(oracle, oracle_c, monkeypatc
     res_c = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2,
                                block_rows=300).cpu().numpy()
     assert np.array_equal(res_c, res)
+    # a block made of exact rows only: ONE kernel (the int8 one) and the same bits those rows get inside mixed blocks (an
+    # all-exact block once fell through to the 128-tile fp16 kernel behind the int8 one: 2.7 x the time, other bits)
+    from janusx_amd._lib import lib
+    ex = np.flatnonzero(mi[rows] == 0)
+    res_e = pipeline.scan_rows(p, model, rows[ex], lut[ex], mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
+    assert lib().jxg_last_kernel_ms(14) == 1.0 and lib().jxg_last_kernel_ms(13) == 1.0
+    assert np.array_equal(res_e, res[ex])
     # (iii) every row through the fp16 kernels
     monkeypatch.setenv("JXGPU_ROT_I8", "0")
     res_h = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
@@ -1984,6 +1991,92 @@ def test_splmm_exact_scan_from_jxgrm(oracle, tmp_path, subset, cov):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["dense", "block"])
+def test_splmm_assoc_pcg_bed_approx_and_exact(oracle, tmp_path, monkeypatch, route):
+    """`splmm_assoc_pcg_bed[_to_tsv]` (src/stats/splmm.rs:4641-5026), the entry points behind `jx gwas -splmm` (scan_mode
+    "approx": residualised GRAMMAR-gamma route, src/stats/splmm_approx.rs:701-795 + src/stats/splmm.rs:2935-3316) and
+    `-splmm-exact` (scan_mode "exact"): BED prefix + the caller's row metadata, a sample subset, covariates, flipped rows,
+    sparse GRM file of the subset.  Against the oracle's restatement with a dense Cholesky of K + lambda I: gamma at 1e-6,
+    beta / se / p at TOL, NaN rows equal; the seeded marker choice must be the oracle's; the TSV must hold the same rows."""
+    from janusx_amd import janusx as jxrs
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", route)
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "64")
+    n, m = 320, 700
+    packed, g = _related_panel(n, m, 37, 0.02)
+    prefix = str(tmp_path / "p")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(12)
+    sub = np.sort(rng.permutation(n)[:290]).astype(np.int64)
+    ns = len(sub)
+    mi, he, ho = oracle.row_counts(packed, n, sub)
+    keep, miss, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, ns, 0.02, 0.05, 0.0)
+    pk_sub_rows = np.ascontiguousarray(packed[keep])
+    # sparse GRM of the subset's samples (file order = subset order)
+    path, _, _ = jxrs.spgrm_packed_to_jxgrm(pk_sub_rows, n, np.zeros(int(keep.sum()), bool), af[keep], str(tmp_path / "k"), sub,
+                                            1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    assert nn == ns
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, None)
+    gv = np.where(g < 0, 0, g).astype(np.float64)
+    y = (gv[40] * 0.5 + gv[300:330].T @ rng.normal(0, 0.2, 30) + rng.normal(0, 1.0, n))[sub]
+    xc = rng.normal(size=(ns, 2))
+    xd = oracle.spreml_design_matrix(xc, ns)
+    rows = np.nonzero(keep)[0][::2].astype(np.int64)
+    maf_r, miss_r = af[rows].astype(np.float32), miss[rows].astype(np.float32)
+    flip_r = np.zeros(len(rows), dtype=bool)
+    flip_r[::6] = True
+    lam = 1.7
+    grm_pos = np.arange(ns, dtype=np.int64)               # positions of the scan samples inside the sparse GRM file
+    assert np.array_equal(jxrs.splmm_choose_rhat_rows(len(rows), 40, 20260527), oracle.choose_rhat_rows(len(rows), 40, 20260527))
+    # ---- approx
+    got = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, sample_indices=sub, maf=maf_r, row_flip=flip_r,
+                                   row_missing=miss_r, row_indices=rows, sparse_sample_indices=grm_pos,
+                                   sparse_jxgrm_path=path, rhat_markers=40, scan_mode="approx")
+    full_maf, full_flip = np.zeros(m, np.float32), np.zeros(m, bool)
+    full_maf[rows], full_flip[rows] = maf_r, flip_r
+    gamma, ref, used, rr = oracle.splmm_approx_assoc(kd, lam, xd, y, packed[rows], n, maf_r, flip_r, rhat_markers=40,
+                                                     sample_idx=sub)
+    assert got[1:9] == (True, 1, 0.0, True, 1, 0.0, 40, used)
+    assert abs(got[0] - gamma) < 1e-6 * gamma, (got[0], gamma)
+    out = got[9]
+    assert out.shape == ref.shape == (len(rows), 3)
+    bad = np.isnan(ref[:, 0])
+    assert np.array_equal(np.isnan(out[:, 0]), bad) and np.all(out[bad, 2] == 1.0)
+    be, se, pe = _assoc_err(out[~bad], ref[~bad])
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    assert ref[~bad, 2].min() < 1e-3
+    # ---- exact
+    gote = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, sample_indices=sub, maf=maf_r, row_flip=flip_r,
+                                    row_missing=miss_r, row_indices=rows, sparse_sample_indices=grm_pos,
+                                    sparse_jxgrm_path=path, scan_mode="exact")
+    refe = oracle.splmm_exact_scan(kd, lam, xd, y, packed[rows], n, maf_r, flip_r, sub)
+    assert math.isnan(gote[0]) and gote[7:9] == (0, 0)
+    bad = np.isnan(refe[:, 0])
+    assert np.array_equal(np.isnan(gote[9][:, 0]), bad)
+    be, se, pe = _assoc_err(gote[9][~bad], refe[~bad])
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    # ---- TSV (metadata read from the BIM), packed-payload input form
+    tsv_path = str(tmp_path / "o.tsv")
+    gt = jxrs.splmm_assoc_pcg_bed_to_tsv(prefix, y, lam, [], [], [], [], [], tsv_path, x_cov=xc, sample_indices=sub,
+                                         packed=packed, packed_n_samples=n, maf=maf_r, row_flip=flip_r, row_missing=miss_r,
+                                         row_indices=rows, sparse_sample_indices=grm_pos, sparse_jxgrm_path=path,
+                                         rhat_markers=40, scan_mode="approx")
+    assert gt[9] == len(rows) and abs(gt[0] - got[0]) < 1e-9 * got[0]
+    lines = open(tsv_path).read().splitlines()
+    assert lines[0].split("\t") == ["chrom", "pos", "snp", "allele0", "allele1", "af", "miss", "beta", "se", "chisq", "pwald"]
+    assert len(lines) == 1 + len(rows)
+    k = int(np.flatnonzero(~np.isnan(out[:, 0]))[5])
+    f = lines[1 + k].split("\t")
+    assert f[2] == f"rs{rows[k]}" and f[5] == oracle.rust_fmt_f4(float(maf_r[k])) and f[7] == oracle.rust_fmt_f4(out[k, 0])
+    with pytest.raises(RuntimeError, match="rhat_markers must be > 0"):
+        jxrs.splmm_assoc_pcg_bed(prefix, y, lam, sample_indices=sub, maf=maf_r, row_flip=flip_r, row_indices=rows,
+                                 sparse_jxgrm_path=path, rhat_markers=0, scan_mode="approx")
+    with pytest.raises(RuntimeError, match="mmap metadata path requires `row_indices`"):
+        jxrs.splmm_assoc_pcg_bed(prefix, y, lam, sample_indices=sub, maf=maf_r, row_flip=flip_r, sparse_jxgrm_path=path)
+
+
+@pytest.mark.gpu
 def test_sparse_grm_row_panels_write_the_same_file(oracle, tmp_path, monkeypatch):
     """Row-panel form of the sparse GRM builder (the n x n accumulator replaced by 256-row bands: GRM tile rows +
     threshold + column-wise merge of the panels) against the whole-accumulator form: byte-identical `.spgrm` files, for a
@@ -2071,7 +2164,9 @@ def test_splmm_block_route_matches_the_dense_route(oracle, tmp_path, monkeypatch
 @pytest.mark.gpu
 def test_cli_gwas_splmm(oracle, tmp_path):
     """`jx gwas -splmm [cutoff]`: sparse GRM of all genotyped samples, then for the trait's phenotyped samples the
-    sparse REML null model and the exact scan; TSV rows against the dense-Cholesky restatement on the written `.spgrm`."""
+    sparse REML null model and the scan; TSV rows against the dense-Cholesky restatement on the written `.spgrm`.  With fewer
+    than 1000 kept markers (here) `-splmm` falls back to the exact scan as the reference's workflow does
+    (python/janusx/assoc/workflow_model_packed.py:8087-8107); `test_cli_gwas_splmm_approx` covers the GRAMMAR-gamma route."""
     from janusx_amd import cli
     n, m = 300, 700
     packed, g = _related_panel(n, m, 41, 0.015)
@@ -2102,7 +2197,7 @@ def test_cli_gwas_splmm(oracle, tmp_path):
     keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, len(keep_idx), 0.02, 0.05, 1.0)
     rows = np.nonzero(keep)[0]
     assert len(lines) == len(rows) + 1
-    null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y[keep_idx], None, keep_idx)
+    null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y[keep_idx], None, keep_idx, grid_size=17)   # the workflow's grid
     kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, keep_idx)
     maf_all = np.zeros(m, dtype=np.float32)
     maf_all[rows] = maf[rows]
@@ -2141,6 +2236,49 @@ def test_cli_gwas_splmm(oracle, tmp_path):
         cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-k", ppath, "-o", out2])
     with pytest.raises(SystemExit, match="sparse GRM"):
         cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-splmm", "0.05", "-k", prefix + ".spgrm", "-o", out2])
+
+
+@pytest.mark.gpu
+def test_cli_gwas_splmm_approx(oracle, tmp_path):
+    """`jx gwas -splmm` with at least 1000 kept markers = the reference's default SparseLMM route: fastGWA fixed-Vp null
+    objective on the OLS residual (workflow_model_packed.py:3134-3156, 3430-3451; grid 17, tol 1e-3, 20 iterations), then
+    `splmm_assoc_pcg_bed_to_tsv` in scan_mode "approx" with 1000 sampled markers (seed 20260527).  TSV rows against the
+    oracle's restatement of both stages on the written `.spgrm`."""
+    from janusx_amd import cli
+    n, m = 260, 1500
+    packed, g = _related_panel(n, m, 43, 0.01)
+    y = bed.synth_phenotype(g, n_causal=10, pve=0.5, seed=5)
+    prefix = str(tmp_path / "toy")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ttraitA\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{repr(float(y[i]))}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-o", prefix]) == 0
+    lines = open(prefix + ".traitA.splmm.tsv").read().splitlines()
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(prefix + ".spgrm")
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    assert len(rows) >= 1000 and len(lines) == len(rows) + 1
+    yc = y - y.mean()
+    vp = float(yc @ yc) / (n - 1)
+    null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, yc, None, None, grid_size=17, vp_fixed=vp)
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, None)
+    gamma, ref, used, rr = oracle.splmm_approx_assoc(kd, null[0], np.ones((n, 1)), y, packed[rows], n, maf[rows],
+                                                     np.zeros(len(rows), bool), rhat_markers=1000)
+    assert used >= 100
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert f[2] == f"rs{rows[i]}"
+        if math.isnan(ref[i, 0]):
+            assert f[7] == "NaN"
+            continue
+        assert abs(float(f[7]) - ref[i, 0]) <= 1.5e-4 * max(1.0, abs(ref[i, 0]))     # 4 significant digits in the TSV
+        assert abs(float(f[8]) - ref[i, 1]) <= 1.5e-4 * max(1.0, abs(ref[i, 1]))
+        assert abs(float(f[10]) - ref[i, 2]) <= 3e-4 * ref[i, 2] + 1e-300
 
 
 @pytest.mark.gpu

@@ -446,3 +446,45 @@ def test_lm_restatement_is_ordinary_least_squares_with_a_t_test():
     gj = O.lm_value_lut_f32(maf[3], bool(flip[3]))[codes[3, sub]].astype(np.float64)
     coef, *_ = np.linalg.lstsq(np.concatenate([x[sub], gj[:, None]], axis=1), y[sub], rcond=None)
     assert abs(o2[3, 0] - coef[3]) <= 2e-6 * abs(coef[3])
+
+
+def test_splmm_approx_route_restatement(oracle):
+    """The `-splmm` approximate route (src/stats/splmm_approx.rs:612-795, src/stats/splmm.rs:2935-3316): (i) the ChaCha core
+    behind the seeded marker choice against RFC 7539 section 2.3.2 (20 rounds; `StdRng` runs the same core with 12 -- the
+    seeding and range-sampling conventions of rand 0.9.2 are restated from memory of the published source and stay unpinned,
+    as the oracle's header says); (ii) `choose_rhat_rows`: sorted, unique, inside the range, at most 2 count, everything
+    when count >= m, a function of the seed; (iii) with K = I the route must collapse to ordinary least squares: gamma =
+    1 / ((1 + lambda) sigma2), beta = the OLS coefficient of the SNP given X, se^2 = RSS0 / (df g'M g)."""
+    import math
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    blk = oracle._chacha_block(key, 1 | (0x09000000 << 32), 20, (0x4a000000, 0))
+    assert blk[:4] == [0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3] and blk[15] == 0x4e3c50a2
+    rr = oracle.choose_rhat_rows(100000, 30, 20260527)
+    assert np.all(np.diff(rr) > 0) and rr.min() >= 0 and rr.max() < 100000 and 30 <= len(rr) <= 60
+    assert np.array_equal(rr, oracle.choose_rhat_rows(100000, 30, 20260527))
+    assert not np.array_equal(rr, oracle.choose_rhat_rows(100000, 30, 20260528))
+    assert np.array_equal(oracle.choose_rhat_rows(20, 30, 1), np.arange(20))
+    big = oracle.StdRngU32(7)
+    assert all(0 <= big.random_range(5_000_000_000) < 5_000_000_000 for _ in range(50))
+    rng = np.random.default_rng(3)
+    n, m = 120, 40
+    g = rng.integers(0, 3, size=(m, n)).astype(np.int8)
+    packed = oracle.pack_codes(oracle.genotypes_to_codes(g))
+    maf = (g.sum(1) / (2.0 * n)).astype(np.float32)
+    flip = np.zeros(m, dtype=bool)
+    x = np.concatenate([np.ones((n, 1)), rng.normal(size=(n, 1))], axis=1)
+    y = rng.normal(size=n) + 0.4 * g[3]
+    lam = 0.7
+    gamma, out, used, rows = oracle.splmm_approx_assoc(np.eye(n), lam, x, y, packed, n, maf, flip, rhat_markers=30)
+    q, _ = np.linalg.qr(x)
+    yr = y - q @ (q.T @ y)
+    rss, df = float(yr @ yr), n - 2
+    sigma2 = rss / (df * (1.0 + lam))
+    assert abs(gamma - 1.0 / ((1.0 + lam) * sigma2)) < 1e-12 * gamma and used == len(rows)
+    for j in range(m):
+        gj = g[j].astype(np.float64)
+        gr = gj - q @ (q.T @ gj)
+        sms = float(gr @ gr)
+        beta, se = float(gr @ yr) / sms, math.sqrt(rss / (df * sms))
+        assert abs(out[j, 0] - beta) < 2e-6 * max(abs(beta), se) and abs(out[j, 1] - se) < 1e-6 * se       # f32 dots
+        assert abs(out[j, 2] - oracle.chi2_sf_df1((beta / se) ** 2)) < 1e-4 * out[j, 2] + 1e-300

@@ -491,7 +491,7 @@ def main():
                                      "duration = HIP start/stop events bound to the dispatch (hipExtLaunchKernelGGL) on the "
                                      "launch stream; peak = f64 MFMA 78.6 TFLOP/s (public MI355X figure, = 64 cycles per "
                                      "16x16x4 block per SIMD; rocBLAS dgemm reaches 75 here); traffic = rocprofv3 FETCH_SIZE "
-                                     "(8-byte-per-lane row reads: counter calibrated exact on the known row bytes, no x2) + "
+                                     "(calibrated on the known row bytes of this kernel, n^3 / 8 per launch: the raw counter equals them with 8-byte and with 16-byte row reads alike, so no x2 here) + "
                                      "WRITE_SIZE, each in its own pass, per launch, from the committed "
                                      "summary of this shape (algorithmic: every row of C read and written once per group of "
                                      "32 sweeps = 8 n^3 / 32 B); mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}

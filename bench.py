@@ -478,8 +478,8 @@ def main():
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
             # reflectors (one launch per decomposition; profiles/r02*_kernel_stats.csv)
             q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
-            # this kernel reads its rows 8 bytes per lane (16 lanes = one 128-byte line): calibrated on its known row bytes
-            # (n^3 / 8 = 1.00 TB at n = 20000 vs 1.02 TB raw FETCH_SIZE) the counter is exact here, not halved
+            # calibrated on the kernel's known row bytes (n^3 / 8 = 1.00 TB at n = 20000 vs 1.01 - 1.02 TB raw FETCH_SIZE, with
+            # 8-byte row reads in profiles/r03a and 16-byte ones in r03b) the counter is exact here, not halved
             tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_reg_kernel", fetch_scale=1.0)
             mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_reg_kernel")
             roofline_main = {"bound": "mfma", "kernel": "sbback_apply_reg_kernel", "achieved": q2_tflops,
@@ -517,8 +517,8 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64 (eigendecomposition on f64 MFMA, REML); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
-                     "or fp16 hi+lo split of the f32 operands with f32 accumulation, f64 merge; rotation: fp16 hi+lo split, "
-                     "f32 accumulation",
+                     "or fp16 hi+lo split of the f32 operands with f32 accumulation, f64 merge; rotation: exact design rows x three "
+                     "int8 planes of U (int8 MFMA, exact i32 sums, f64 combine), other rows fp16 hi+lo split with f32 accumulation",
             "data": "synthetic",
             "config": {"workload": f"synthetic HWE panel n={n} m={m} ({baseline_config_label(n, args.m)}{f' x{world} SNPs (weak scaling)' if (args.scaling == 'weak' and world > 1) else ''}), -{args.mode}, "
                                    f"maf 0.02 geno 0.05, intercept only, missing={args.missing}",

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "jx_common.h"
 
@@ -351,6 +352,217 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One wave per unit (large n: at least eight 16-column units per CU).  A wave holds the WHOLE 96-row window of its unit in
+// registers (three 32-row chunk sets of the layout above), so Y = U' Cwin is complete inside the wave -- its accumulator
+// layout is the B-operand layout of the update, as above -- and nothing is exchanged between waves: no partial sums, ONE
+// workgroup barrier per block (the hand-over of the image buffers), 96 MFMAs per wave between barriers instead of 16 + 16.
+// The chunk set at window position p of step k is set (p - k) mod 3 (the set at position 2 keeps its rows when the window
+// slides); the step loop is unrolled by three so that the set indices are compile-time.  Row traffic per step: the two
+// leading chunks are final after the update and are stored at the END of the step (behind the prefetch of the two next
+// chunks, issued at the top of the step: the wait at the top of step k + 1 is vmcnt(8) = "everything but my eight stores").
+// LDS: the two image buffers only (96 KB); up to 15 compute waves + the loader wave per workgroup.
+template <int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_solo_kernel(QrParams P) {
+    extern __shared__ __attribute__((aligned(16))) double qb_smem[];
+    double *vl = qb_smem;                                      // [2][QR_BLK]
+    double *ul = vl + 2 * QR_BLK;                              // [2][QR_BLK]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = P.n;
+
+    if (wave == NW) {
+        // ------------------------------------------------------------------------------------------------ loader wave
+        auto img_copy = [&](int grp, int k, int buf) {
+            const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
+            const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
+#pragma unroll
+            for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + i * 1024), "s"(__builtin_amdgcn_readfirstlane(v_dst + i * 1024))
+                             : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
+                             : "memory");
+            }
+        };
+        for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
+            const int s0 = grp * QB_G;
+            if (s0 + 1 >= n) continue;
+            const int nk = (n - s0 - 1 + QB_SB - 1) / QB_SB;
+            __syncthreads();                                   // G0
+            img_copy(grp, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            qr_lds_barrier();                                  // G1
+            for (int k = 0; k < nk; ++k) {
+                if (k + 1 < nk) img_copy(grp, k + 1, (k + 1) & 1);      // the buffer block k - 1 used: everyone is past B(k - 1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                qr_lds_barrier();                              // B(k)
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------------ compute waves
+    const int lx = lane & 15, lk = lane >> 4;
+    const int unit = wave;
+    {
+        const int ub = (int)((int64_t)blockIdx.x * P.units / gridDim.x);
+        const int nb = (int)((int64_t)(blockIdx.x + 1) * P.units / gridDim.x) - ub;
+        if (unit >= nb) {                                      // absent unit of a narrower slab: the barrier sequence only
+            for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
+                const int s0 = grp * QB_G;
+                if (s0 + 1 >= n) continue;
+                const int nk = (n - s0 - 1 + QB_SB - 1) / QB_SB;
+                __syncthreads();                               // G0
+                qr_lds_barrier();                              // G1
+                for (int k = 0; k < nk; ++k) qr_lds_barrier(); // B(k)
+            }
+            return;
+        }
+    }
+    constexpr int W = NW * 16;
+    const int n2 = (n + 1) & ~1;
+    double *cp = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (unit * 16 + lx);
+    const int rm_a = 8 * (lx >> 3) + 2 * (lx & 3) + ((lx >> 2) & 1);
+
+    auto chunk_load = [&](int rb, d2 (&raw)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rb + 8 * q + 2 * lk;
+            const double *src = cp + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[q]) : "v"(src) : "memory");
+        }
+    };
+    auto chunk_unpack = [&](int rb, const d2 (&raw)[4], d4 (&reg)[2]) {
+        const bool inside = rb + 32 <= n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            reg[i >> 2][i & 3] = (inside || row < n) ? raw[i >> 1][i & 1] : 0.0;
+        }
+    };
+    auto chunk_store = [&](int rb, const d4 (&reg)[2]) {
+        if (rb + 32 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d2 v = {reg[q >> 1][2 * (q & 1)], reg[q >> 1][2 * (q & 1) + 1]};
+                *reinterpret_cast<d2 *>(cp + (int64_t)((rb + 8 * q + 2 * lk) >> 1) * (2 * W)) = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            if (row < n) cp[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[i >> 2][i & 3];
+        }
+    };
+
+    d4 S[3][2];
+    d2 pf[2][4];
+    bool stored8 = false;
+    int s0 = 0, nk = 0;
+    // one block: PH = k mod 3 (compile time), the set at window position p is S[(p + 3 - PH) % 3]
+    auto step = [&](auto phc, int k) {
+        constexpr int PH = decltype(phc)::value;
+        d4 (&a0)[2] = S[(0 + 3 - PH) % 3];
+        d4 (&a1)[2] = S[(1 + 3 - PH) % 3];
+        d4 (&a2)[2] = S[(2 + 3 - PH) % 3];
+        const int wb = s0 + k * QB_SB;
+        const bool has_next = k + 1 < nk;
+        if (k > 0) {
+            if (stored8)
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                             "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                             "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+            chunk_unpack(wb + 32, pf[0], a1);
+            chunk_unpack(wb + 64, pf[1], a2);
+        }
+        if (has_next && !(P.skip & 18)) {
+            chunk_load(wb + QB_WIN, pf[0]);
+            chunk_load(wb + QB_WIN + 32, pf[1]);
+        }
+        const int buf = k & 1;
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        if (!(P.skip & 1)) {
+            const int o0 = 16 * (lk & 1), o1 = 16 - o0;
+            auto ypart = [&](int w, const d4 (&cw)[2]) {
+                const double *up = ul + buf * QR_BLK + (32 * w + 2 * lk) * QB_G + lx;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int q = 8 * (ks >> 1) + (ks & 1);
+                    const double b = cw[ks >> 2][ks & 3];
+                    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+                }
+            };
+            ypart(0, a0);
+            ypart(1, a1);
+            ypart(2, a2);
+            double yn[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yn[r] = -y0[r];
+                yn[4 + r] = -y1[r];
+            }
+            auto upd = [&](int w, d4 (&cw)[2]) {
+                const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int m = (4 * ks + lk) ^ (2 * rm_a);
+                    cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                    cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+                }
+            };
+            upd(0, a0);
+            upd(1, a1);
+            upd(2, a2);
+        }
+        qr_lds_barrier();                                      // B(k): images of block k + 1 in place, buffer of block k free
+        stored8 = false;
+        if (!(P.skip & 10)) {
+            chunk_store(wb, a0);
+            chunk_store(wb + 32, a1);
+            stored8 = wb + 64 <= n;
+            if (!has_next) chunk_store(wb + 64, a2);
+        }
+    };
+    for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
+        s0 = grp * QB_G;
+        if (s0 + 1 >= n) continue;
+        nk = (n - s0 - 1 + QB_SB - 1) / QB_SB;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // G0: the previous group's stores are done, LDS is free
+        chunk_load(s0, pf[0]);
+        chunk_load(s0 + 32, pf[1]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]), "+v"(pf[1][1]),
+                     "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+        chunk_unpack(s0, pf[0], S[0]);
+        chunk_unpack(s0 + 32, pf[1], S[1]);
+        chunk_load(s0 + 64, pf[0]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]) : : "memory");
+        chunk_unpack(s0 + 64, pf[0], S[2]);
+        stored8 = false;
+        qr_lds_barrier();                                      // G1: the images of block 0 are in place
+        int k = 0;
+        for (; k + 3 <= nk; k += 3) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+            step(std::integral_constant<int, 2>{}, k + 2);
+        }
+        if (k < nk) step(std::integral_constant<int, 0>{}, k);
+        if (k + 1 < nk) step(std::integral_constant<int, 1>{}, k + 1);
+    }
+}
+
 // C (n x ncols, column-major, ld = n) <-> slab layout [slab][row][w] (w = slab width in columns; columns past ncols are
 // zero on the way in and dropped on the way out).  One workgroup = 64 rows of one slab through LDS: both sides coalesced.
 template <bool TO_SLAB>
@@ -405,10 +617,29 @@ static int device_cus();
 // evenly (a slab holds NU or NU - 1).  Up to 5 units per CU: one round with NU = ceil(units / CUs).  Beyond: R = ceil(units /
 // (5 CUs)) rounds of CUs workgroups, so that every round is full and as short as its widest slab (n = 50 000: 3125 units ->
 // 768 slabs of 4 or 5 units instead of 625 of 5 = 2.44 rounds each as long as a full one).
+// one wave per unit (sbback_apply_solo_kernel) from eight units per CU (n >= 32768 on 256 CUs); JXGPU_SBBACK_SOLO=0 / 1
+// switches it off / on from four units per CU
+static bool qr_solo(int ncols) {
+    const int units = (ncols + 15) / 16;
+    static const int env = getenv("JXGPU_SBBACK_SOLO") ? atoi(getenv("JXGPU_SBBACK_SOLO")) : -1;
+    if (env == 0) return false;
+    return units >= (env == 1 ? 4 : 8) * device_cus();
+}
+constexpr int QR_SOLO_MAX = 11;           // compute waves (units) per workgroup of the solo form: 12 waves = 3 per SIMD, the kernel needs 168 - 179 registers (the 128 of four waves per SIMD spill 40)
+
 static void qr_plan(int ncols, int *g_out, int *nu_out) {
     const int units = (ncols + 15) / 16;
     const int cus = device_cus();
     int nu, g;
+    if (qr_solo(ncols)) {
+        // R = ceil(units / (15 CUs)) full rounds of CUs workgroups, units dealt evenly (n = 50 000: 256 slabs of 12 or 13)
+        const int rounds = (units + QR_SOLO_MAX * cus - 1) / (QR_SOLO_MAX * cus);
+        g = rounds * cus;
+        nu = (units + g - 1) / g;
+        *g_out = std::max(g, 1);
+        *nu_out = std::max(nu, 4);
+        return;
+    }
     if (getenv("JXGPU_SBBACK_NW") && atoi(getenv("JXGPU_SBBACK_NW")) > 0) {       // fixed width, whole slabs (diagnostic)
         nu = std::min(atoi(getenv("JXGPU_SBBACK_NW")), 5);
         g = (units + nu - 1) / nu;
@@ -463,13 +694,24 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         if ((size_t)gslabs * nu * 16 > std::max((size_t)gn * nun * 16, (size_t)n + 96))
             return fail("sbback_apply_q2: slab plan exceeds the workspace");
     }
-    const size_t lds = sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
+    const bool solo = qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const size_t lds = solo ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
     const dim3 grid(gslabs);
     const int skip = getenv("JXGPU_QB_SKIP") ? atoi(getenv("JXGPU_QB_SKIP")) : 0;
     const int w = nu * 16;
     double *d_ct = d_vu + (size_t)gpl * ks * 2 * QR_BLK;
     const dim3 sgrid(ceil_div(n, 64), grid.x);
     const size_t slds = sizeof(double) * 64 * (w + 1);
+    {
+        static bool slab_attr = false;                         // slabs of the solo form are up to 240 columns wide: 123 KB tiles
+        if (!slab_attr) {
+            JX_HIP(hipFuncSetAttribute((const void *)sbback_slab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * 64 * (QR_SOLO_MAX * 16 + 1))));
+            JX_HIP(hipFuncSetAttribute((const void *)sbback_slab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * 64 * (QR_SOLO_MAX * 16 + 1))));
+            slab_attr = true;
+        }
+    }
     hipLaunchKernelGGL(sbback_slab_kernel<true>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w, units);
     JX_LAUNCH_CHECK();
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
@@ -488,13 +730,38 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         }                                                                                                              \
         hipExtLaunchKernelGGL(sbback_apply_reg_kernel<NUV>, grid, dim3(NUV * 192 + 64), lds, st, e0, e1, 0, P);             \
     } while (0)
-        switch (nu) {
-            case 1: JX_QR_LAUNCH(1); break;
-            case 2: JX_QR_LAUNCH(2); break;
-            case 3: JX_QR_LAUNCH(3); break;
-            case 4: JX_QR_LAUNCH(4); break;
-            default: JX_QR_LAUNCH(5); break;
+#define JX_QR_SOLO(NWV)                                                                                                \
+    do {                                                                                                               \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_solo_kernel<NWV>,                                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipExtLaunchKernelGGL(sbback_apply_solo_kernel<NWV>, grid, dim3((NWV + 1) * 64), lds, st, e0, e1, 0, P);        \
+    } while (0)
+        if (solo) {
+            switch (nu) {
+                case 4: JX_QR_SOLO(4); break;
+                case 5: JX_QR_SOLO(5); break;
+                case 6: JX_QR_SOLO(6); break;
+                case 7: JX_QR_SOLO(7); break;
+                case 8: JX_QR_SOLO(8); break;
+                case 9: JX_QR_SOLO(9); break;
+                case 10: JX_QR_SOLO(10); break;
+                case 11: JX_QR_SOLO(11); break;
+                default: return fail("sbback_apply_q2: solo slab width out of range");
+            }
+        } else {
+            switch (nu) {
+                case 1: JX_QR_LAUNCH(1); break;
+                case 2: JX_QR_LAUNCH(2); break;
+                case 3: JX_QR_LAUNCH(3); break;
+                case 4: JX_QR_LAUNCH(4); break;
+                default: JX_QR_LAUNCH(5); break;
+            }
         }
+#undef JX_QR_SOLO
 #undef JX_QR_LAUNCH
         JX_LAUNCH_CHECK();
     }

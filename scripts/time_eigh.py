@@ -27,8 +27,9 @@ def main():
         wref = torch.linalg.eigvalsh(kk) if n <= 6000 else None
         werr = float((w - wref).abs().max()) if wref is not None else float("nan")
         asc = bool((w[1:] >= w[:-1]).all())
+        st = {nm: round(float(lib().jxg_last_kernel_ms(i)), 1) for i, nm in ((6, "band"), (7, "chase"), (8, "dc"), (9, "q1"), (4, "q2_kernel"))}
         print(f"n={n} mode={os.environ.get('JXGPU_EIGH','custom')} eigh {dt*1e3:.1f} ms  resid {res:.2e} orth {orth:.2e} "
-              f"eval_err {werr:.2e} ascending {asc}", flush=True)
+              f"eval_err {werr:.2e} ascending {asc} stages_ms {st}", flush=True)
         del a, k, kk, v
 
 main()

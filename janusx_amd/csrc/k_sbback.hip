@@ -563,6 +563,250 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_solo_kernel(QrPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One wave per unit, TWO sweep groups per pass over the rows.  At n = 50 000 the one-group form streams the whole of C once
+// per group: 62.5 TB per decomposition, 6.9 TB/s -- the HBM roof, not the matrix pipes, bounds it.  Block (g - 1, k) touches
+// the rows [32 (g - 1) + 64 k, + 96), block (g, k) the rows [32 g + 64 k, + 96): (g - 1, k) has to follow (g, k) and (g, k - 1)
+// and commutes with every (g, k' > k) (disjoint rows), so the order (g, 0), (g - 1, 0), (g, 1), (g - 1, 1), ... is a valid
+// one and both blocks of a step live in the 128-row window [32 (g - 1) + 64 k, + 128): four chunk sets in registers, block
+// (g, k) on window positions 1 - 3, block (g - 1, k) on positions 0 - 2, then the two leading chunks are final for BOTH groups.
+// Row traffic per pair of groups = that of one group before; MFMA work unchanged (the 96-row parallelograms stay).
+// The two image buffers alternate between the upper and the lower group: buffer A holds (g, k), B holds (g - 1, k); the
+// loader refills A with (g, k + 1) while the waves work on B and B with (g - 1, k + 1) while they work on A: one barrier per
+// block, 96 KB of LDS as before.  The set at window position p of step k is set (p + 2 k) mod 4: two compile-time phases.
+template <int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrParams P) {
+    extern __shared__ __attribute__((aligned(16))) double qb_smem[];
+    double *vl = qb_smem;                                      // [2][QR_BLK]: 0 = upper group's block, 1 = lower group's
+    double *ul = vl + 2 * QR_BLK;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = P.n;
+    // passes: pairs (g, g - 1) from g_hi - 1 down; an odd count leaves the lowest group alone (upper block absent)
+    auto pass_groups = [&](int pass, int &g_up, int &g_lo_grp) {
+        g_up = P.g_hi - 1 - 2 * pass;
+        g_lo_grp = g_up - 1;
+        if (g_lo_grp < P.g_lo) {                               // single group: it plays the lower role
+            g_lo_grp = g_up;
+            g_up = -1;
+        }
+    };
+    const int npass = (P.g_hi - P.g_lo + 1) / 2;
+    auto steps_of = [&](int grp) { return (grp < 0 || grp * QB_G + 1 >= n) ? 0 : (n - grp * QB_G - 1 + QB_SB - 1) / QB_SB; };
+
+    if (wave == NW) {
+        // ------------------------------------------------------------------------------------------------ loader wave
+        auto img_copy = [&](int grp, int k, int buf) {
+            const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
+            const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
+#pragma unroll
+            for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + i * 1024), "s"(__builtin_amdgcn_readfirstlane(v_dst + i * 1024))
+                             : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
+                             : "memory");
+            }
+        };
+        for (int pass = 0; pass < npass; ++pass) {
+            int gu, gl;
+            pass_groups(pass, gu, gl);
+            const int nku = steps_of(gu), nkl = steps_of(gl);
+            if (nkl == 0) continue;
+            __syncthreads();                                   // G0
+            if (nku > 0) img_copy(gu, 0, 0);
+            img_copy(gl, 0, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            qr_lds_barrier();                                  // G1
+            for (int k = 0; k < nkl; ++k) {
+                qr_lds_barrier();                              // B1(k): buffer 0 consumed
+                if (k + 1 < nku) img_copy(gu, k + 1, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                qr_lds_barrier();                              // B2(k): buffer 1 consumed, buffer 0 holds (gu, k + 1)
+                if (k + 1 < nkl) img_copy(gl, k + 1, 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------------ compute waves
+    const int lx = lane & 15, lk = lane >> 4;
+    const int unit = wave;
+    {
+        const int ub = (int)((int64_t)blockIdx.x * P.units / gridDim.x);
+        const int nb = (int)((int64_t)(blockIdx.x + 1) * P.units / gridDim.x) - ub;
+        if (unit >= nb) {                                      // absent unit of a narrower slab: the barrier sequence only
+            for (int pass = 0; pass < npass; ++pass) {
+                int gu, gl;
+                pass_groups(pass, gu, gl);
+                const int nkl = steps_of(gl);
+                if (nkl == 0) continue;
+                __syncthreads();                               // G0
+                qr_lds_barrier();                              // G1
+                for (int k = 0; k < nkl; ++k) {
+                    qr_lds_barrier();                          // B1
+                    qr_lds_barrier();                          // B2
+                }
+            }
+            return;
+        }
+    }
+    constexpr int W = NW * 16;
+    const int n2 = (n + 1) & ~1;
+    double *cp = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (unit * 16 + lx);
+    const int rm_a = 8 * (lx >> 3) + 2 * (lx & 3) + ((lx >> 2) & 1);
+
+    auto chunk_load = [&](int rb, d2 (&raw)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rb + 8 * q + 2 * lk;
+            const double *src = cp + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[q]) : "v"(src) : "memory");
+        }
+    };
+    auto chunk_unpack = [&](int rb, const d2 (&raw)[4], d4 (&reg)[2]) {
+        const bool inside = rb + 32 <= n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            reg[i >> 2][i & 3] = (inside || row < n) ? raw[i >> 1][i & 1] : 0.0;
+        }
+    };
+    auto chunk_store = [&](int rb, const d4 (&reg)[2]) {
+        if (rb + 32 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d2 v = {reg[q >> 1][2 * (q & 1)], reg[q >> 1][2 * (q & 1) + 1]};
+                *reinterpret_cast<d2 *>(cp + (int64_t)((rb + 8 * q + 2 * lk) >> 1) * (2 * W)) = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            if (row < n) cp[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[i >> 2][i & 3];
+        }
+    };
+    // one 96-row block on three chunk sets (image rows 32 w + ... of buffer `buf` <-> set cw_w)
+    auto block = [&](int buf, d4 (&c0)[2], d4 (&c1)[2], d4 (&c2)[2]) {
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        const int o0 = 16 * (lk & 1), o1 = 16 - o0;
+        auto ypart = [&](int w, const d4 (&cw)[2]) {
+            const double *up = ul + buf * QR_BLK + (32 * w + 2 * lk) * QB_G + lx;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int q = 8 * (ks >> 1) + (ks & 1);
+                const double b = cw[ks >> 2][ks & 3];
+                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+            }
+        };
+        ypart(0, c0);
+        ypart(1, c1);
+        ypart(2, c2);
+        double yn[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            yn[r] = -y0[r];
+            yn[4 + r] = -y1[r];
+        }
+        auto upd = [&](int w, d4 (&cw)[2]) {
+            const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int m = (4 * ks + lk) ^ (2 * rm_a);
+                cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+            }
+        };
+        upd(0, c0);
+        upd(1, c1);
+        upd(2, c2);
+    };
+
+    d4 S[4][2];
+    d2 pf[2][4];
+    bool stored8 = false;
+    int sl = 0, nku = 0, nkl = 0;
+    auto wait_pf = [&](bool eight_behind) {
+        if (eight_behind)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+    };
+    // one step of a pass: PH = k mod 2 (compile time), the set at window position p is S[(p + 2 PH) % 4]
+    auto step = [&](auto phc, int k) {
+        constexpr int PH = decltype(phc)::value;
+        d4 (&a0)[2] = S[(0 + 2 * PH) % 4];
+        d4 (&a1)[2] = S[(1 + 2 * PH) % 4];
+        d4 (&a2)[2] = S[(2 + 2 * PH) % 4];
+        d4 (&a3)[2] = S[(3 + 2 * PH) % 4];
+        const int wb = sl + k * QB_SB;                         // first row of the 128-row window
+        const bool has_next = k + 1 < nkl;
+        if (k > 0) {
+            wait_pf(stored8);
+            chunk_unpack(wb + 64, pf[0], a2);
+            chunk_unpack(wb + 96, pf[1], a3);
+        }
+        if (has_next && !(P.skip & 18)) {
+            chunk_load(wb + 128, pf[0]);
+            chunk_load(wb + 160, pf[1]);
+        }
+        if (k < nku && !(P.skip & 1)) block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
+        qr_lds_barrier();                                      // B1(k)
+        if (!(P.skip & 1)) block(1, a0, a1, a2);               // block (g - 1, k): rows wb ...
+        qr_lds_barrier();                                      // B2(k)
+        stored8 = false;
+        if (!(P.skip & 10)) {
+            chunk_store(wb, a0);
+            chunk_store(wb + 32, a1);
+            stored8 = wb + 64 <= n;
+            if (!has_next) {
+                chunk_store(wb + 64, a2);
+                chunk_store(wb + 96, a3);
+            }
+        }
+    };
+    for (int pass = 0; pass < npass; ++pass) {
+        int gu, gl;
+        pass_groups(pass, gu, gl);
+        nku = steps_of(gu);
+        nkl = steps_of(gl);
+        if (nkl == 0) continue;
+        sl = gl * QB_G;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // G0: the previous pass' stores are done, LDS is free
+        chunk_load(sl, pf[0]);
+        chunk_load(sl + 32, pf[1]);
+        wait_pf(false);
+        chunk_unpack(sl, pf[0], S[0]);
+        chunk_unpack(sl + 32, pf[1], S[1]);
+        chunk_load(sl + 64, pf[0]);
+        chunk_load(sl + 96, pf[1]);
+        wait_pf(false);
+        chunk_unpack(sl + 64, pf[0], S[2]);
+        chunk_unpack(sl + 96, pf[1], S[3]);
+        stored8 = false;
+        qr_lds_barrier();                                      // G1: the images of the first two blocks are in place
+        int k = 0;
+        for (; k + 2 <= nkl; k += 2) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+        }
+        if (k < nkl) step(std::integral_constant<int, 0>{}, k);
+    }
+}
+
 // C (n x ncols, column-major, ld = n) <-> slab layout [slab][row][w] (w = slab width in columns; columns past ncols are
 // zero on the way in and dropped on the way out).  One workgroup = 64 rows of one slab through LDS: both sides coalesced.
 template <bool TO_SLAB>
@@ -625,7 +869,13 @@ static bool qr_solo(int ncols) {
     if (env == 0) return false;
     return units >= (env == 1 ? 4 : 8) * device_cus();
 }
-constexpr int QR_SOLO_MAX = 11;           // compute waves (units) per workgroup of the solo form: 12 waves = 3 per SIMD, the kernel needs 168 - 179 registers (the 128 of four waves per SIMD spill 40)
+constexpr int QR_SOLO_MAX = 11;           // units per workgroup of the one-group solo form: 12 waves = 3 per SIMD (168 - 179 registers)
+constexpr int QR_PAIR_MAX = 7;            // of the two-group form: 8 waves = 2 per SIMD (four chunk sets: ~200 registers)
+// two sweep groups per pass (sbback_apply_pair_kernel) whenever the solo form applies; JXGPU_SBBACK_PAIR=0: one group per pass
+static bool qr_pair() {
+    static const int env = getenv("JXGPU_SBBACK_PAIR") ? atoi(getenv("JXGPU_SBBACK_PAIR")) : 1;
+    return env != 0;
+}
 
 static void qr_plan(int ncols, int *g_out, int *nu_out) {
     const int units = (ncols + 15) / 16;
@@ -633,7 +883,8 @@ static void qr_plan(int ncols, int *g_out, int *nu_out) {
     int nu, g;
     if (qr_solo(ncols)) {
         // R = ceil(units / (15 CUs)) full rounds of CUs workgroups, units dealt evenly (n = 50 000: 256 slabs of 12 or 13)
-        const int rounds = (units + QR_SOLO_MAX * cus - 1) / (QR_SOLO_MAX * cus);
+        const int wmax = qr_pair() ? QR_PAIR_MAX : QR_SOLO_MAX;
+        const int rounds = (units + wmax * cus - 1) / (wmax * cus);
         g = rounds * cus;
         nu = (units + g - 1) / g;
         *g_out = std::max(g, 1);
@@ -740,7 +991,26 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         }                                                                                                              \
         hipExtLaunchKernelGGL(sbback_apply_solo_kernel<NWV>, grid, dim3((NWV + 1) * 64), lds, st, e0, e1, 0, P);        \
     } while (0)
-        if (solo) {
+        if (solo && qr_pair()) {
+#define JX_QR_PAIR(NWV)                                                                                                \
+    do {                                                                                                               \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_pair_kernel<NWV>,                                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipExtLaunchKernelGGL(sbback_apply_pair_kernel<NWV>, grid, dim3((NWV + 1) * 64), lds, st, e0, e1, 0, P);        \
+    } while (0)
+            switch (nu) {
+                case 4: JX_QR_PAIR(4); break;
+                case 5: JX_QR_PAIR(5); break;
+                case 6: JX_QR_PAIR(6); break;
+                case 7: JX_QR_PAIR(7); break;
+                default: return fail("sbback_apply_q2: pair slab width out of range");
+            }
+#undef JX_QR_PAIR
+        } else if (solo) {
             switch (nu) {
                 case 4: JX_QR_SOLO(4); break;
                 case 5: JX_QR_SOLO(5); break;

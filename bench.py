@@ -480,9 +480,11 @@ def main():
             q2_tflops = kern["q2_gflop"] / max(kern["q2_ms"], 1e-9)
             # calibrated on the kernel's known row bytes (n^3 / 8 = 1.00 TB at n = 20000 vs 1.01 - 1.02 TB raw FETCH_SIZE, with
             # 8-byte row reads in profiles/r03a and 16-byte ones in r03b) the counter is exact here, not halved
-            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::sbback_apply_reg_kernel", fetch_scale=1.0)
-            mu_q2, mu_q2_src = pmc_mfma_util("sbback_apply_reg_kernel")
-            roofline_main = {"bound": "mfma", "kernel": "sbback_apply_reg_kernel", "achieved": q2_tflops,
+            # n >= 32768 (eight 16-column units per CU): one wave per unit, two sweep groups per pass (k_sbback.hip)
+            q2_kernel = "sbback_apply_pair_kernel" if (n + 15) // 16 >= 8 * int(info[0]) else "sbback_apply_reg_kernel"
+            tr_q2, tr_q2_src = pmc_traffic_bytes("jx::" + q2_kernel, fetch_scale=1.0)
+            mu_q2, mu_q2_src = pmc_mfma_util(q2_kernel)
+            roofline_main = {"bound": "mfma", "kernel": q2_kernel, "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
                              "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
                              "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
@@ -494,7 +496,8 @@ def main():
                                      "(calibrated on the known row bytes of this kernel, n^3 / 8 per launch: the raw counter equals them with 8-byte and with 16-byte row reads alike, so no x2 here) + "
                                      "WRITE_SIZE, each in its own pass, per launch, from the committed "
                                      "summary of this shape (algorithmic: every row of C read and written once per group of "
-                                     "32 sweeps = 8 n^3 / 32 B); mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}
+                                     "32 sweeps = 8 n^3 / 32 B; once per PAIR of groups in sbback_apply_pair_kernel: 8 n^3 / 64 B); "
+                                     "mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}
         else:
             # one-stage path (n < 10000): the dominant kernel is the symv of the tridiagonalisation, one launch per column
             roofline_main = {"bound": "hbm", "kernel": "sytrd_symv_kernel",

@@ -43,19 +43,19 @@ struct DgemmArgs {
 // wait for each load before the next address was formed: eight exposed memory latencies per K step).
 // Returns the bit mask of the in-range elements: the zeroing is left to dg_store_tile (behind the MFMAs of the step), so
 // that nothing consumes a loaded value while the step is multiplied.
-template <int BX>
+template <int BX, int NT = DG_THREADS>
 __device__ __forceinline__ unsigned dg_load_tile(const double *__restrict__ p, int64_t ld, bool trans, bool symm, int x0,
-                                                 int xmax, int k0, int kmax, double (&r)[BX * DG_BK / DG_THREADS]) {
+                                                 int xmax, int k0, int kmax, double (&r)[BX * DG_BK / NT]) {
     // element (x, kk) of the BX x 16 operand tile; storage: !trans -> p[x + kk * ld], trans -> p[kk + x * ld];
     // lower-stored symmetric operand: (x, kk) = p[max + min * ld], tiles entirely above the diagonal take the k-fast
     // (coalesced along the stored columns) thread mapping, the others the x-fast one
-    constexpr int NL = BX * DG_BK / DG_THREADS;
+    constexpr int NL = BX * DG_BK / NT;
     const int t = threadIdx.x;
     const bool kfast = symm ? (x0 + BX <= k0) : trans;
     unsigned okmask = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int idx = i * DG_THREADS + t;
+        const int idx = i * NT + t;
         const int xo = kfast ? idx / DG_BK : idx % BX;
         const int ko = kfast ? idx % DG_BK : idx / BX;
         const int x = x0 + xo, kk = k0 + ko;
@@ -70,24 +70,25 @@ __device__ __forceinline__ unsigned dg_load_tile(const double *__restrict__ p, i
     return okmask;
 }
 
-template <int BX>
-__device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast, const double (&r)[BX * DG_BK / DG_THREADS],
+template <int BX, int NT = DG_THREADS>
+__device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast, const double (&r)[BX * DG_BK / NT],
                                               unsigned okmask) {
-    constexpr int NL = BX * DG_BK / DG_THREADS;
+    constexpr int NL = BX * DG_BK / NT;
     constexpr int PITCH = BX + 17;
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int idx = i * DG_THREADS + t;
+        const int idx = i * NT + t;
         const int pos = kfast ? (idx % DG_BK) * PITCH + idx / DG_BK : (idx / BX) * PITCH + idx % BX;
         s[pos] = ((okmask >> i) & 1u) ? r[i] : 0.0;
     }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
+template <int BM, int BN, int NT = DG_THREADS>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void dgemm_kernel(DgemmArgs g) {
     constexpr int PA = BM + 17, PB = BN + 17;
-    constexpr int WM = BM / 4, WN = BN / 2;          // wave tile
+    constexpr int WGM = NT == 512 ? 4 : 2;           // waves along M (x 2 along N)
+    constexpr int WM = BM / WGM, WN = BN / 2;        // wave tile
     constexpr int MB = WM / 16, NB = WN / 16;        // 16x16 blocks per wave
     extern __shared__ __attribute__((aligned(16))) double dg_smem[];
     double *as = dg_smem;                            // [2][16][PA]
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
         if (kbeg > kend) kbeg = kend;                 // an empty slice still writes its zeros
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 3) * WM, wn = (wave >> 2) * WN;
+    const int wm = (wave % WGM) * WM, wn = (wave / WGM) * WN;
     const int lx = lane & 15, lk = lane >> 4;
 
     d4 acc[NB][MB];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
 #pragma unroll
         for (int i = 0; i < MB; ++i) acc[j][i] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    double ra[BM * DG_BK / DG_THREADS], rb[BN * DG_BK / DG_THREADS];
+    double ra[BM * DG_BK / NT], rb[BN * DG_BK / NT];
     const bool symm = g.symm_a != 0;
     const bool ta = g.ta != 0, tb_kfast = g.tb == 0;   // B stored (k, n): k contiguous -> k-fast mapping
     auto a_kfast = [&](int k0) -> bool {
@@ -135,13 +136,13 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
     };
     unsigned oka = 0, okb = 0;
     auto load = [&](int k0) {
-        oka = dg_load_tile<BM>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
+        oka = dg_load_tile<BM, NT>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
         // op(B)(kk, x): !tb -> b[kk + x ldb] (k contiguous = "trans" mapping of the loader), tb -> b[x + kk ldb]
-        okb = dg_load_tile<BN>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
+        okb = dg_load_tile<BN, NT>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
     };
     load(kbeg);
-    dg_store_tile<BM>(as, a_kfast(kbeg), ra, oka);
-    dg_store_tile<BN>(bs, tb_kfast, rb, okb);
+    dg_store_tile<BM, NT>(as, a_kfast(kbeg), ra, oka);
+    dg_store_tile<BN, NT>(bs, tb_kfast, rb, okb);
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += DG_BK) {
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
         if (more) {
-            dg_store_tile<BM>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra, oka);
-            dg_store_tile<BN>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb, okb);
+            dg_store_tile<BM, NT>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra, oka);
+            dg_store_tile<BN, NT>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb, okb);
         }
         __syncthreads();
         buf ^= 1;
@@ -206,15 +207,15 @@ __global__ __launch_bounds__(DG_THREADS, 4) void dgemm_kernel(DgemmArgs g) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NT = DG_THREADS>
 static int dg_launch(const DgemmArgs &g, dim3 grid, hipStream_t st) {
     constexpr size_t smem = sizeof(double) * 2 * DG_BK * ((BM + 17) + (BN + 17));
     static bool attr_set = false;
     if (!attr_set) {
-        JX_HIP(hipFuncSetAttribute((const void *)dgemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        JX_HIP(hipFuncSetAttribute((const void *)dgemm_kernel<BM, BN, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dgemm_kernel<BM, BN>), grid, dim3(DG_THREADS), smem, st, g);
+    hipLaunchKernelGGL((dgemm_kernel<BM, BN, NT>), grid, dim3(NT), smem, st, g);
     JX_LAUNCH_CHECK();
     return 0;
 }
@@ -280,7 +281,8 @@ int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, c
     g.ksplit = dg_fit_split(ksplit, m, n, ws ? ws_doubles : 0);
     dim3 grid(tm, tn, g.ksplit);
     int rc;
-    if (bm == 128 && bn == 128) rc = dg_launch<128, 128>(g, grid, st);
+    static const int nt_env = getenv("JXGPU_DGEMM_NT") ? atoi(getenv("JXGPU_DGEMM_NT")) : 512;
+    if (bm == 128 && bn == 128) rc = nt_env == 256 ? dg_launch<128, 128, 256>(g, grid, st) : dg_launch<128, 128>(g, grid, st);
     else if (bm == 128) rc = dg_launch<128, 64>(g, grid, st);
     else rc = dg_launch<64, 64>(g, grid, st);
     if (rc) return rc;

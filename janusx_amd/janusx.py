@@ -558,6 +558,38 @@ def _check_spectral_sparse_size(n):
                 "default from n = 16384) or restrict the samples")
 
 
+# One-entry cache of the spectral form of a sparse GRM (eigenvalues + eigenvectors of the dense image or of its diagonal
+# blocks, in HBM): the reference's workflow calls the null fit and then the scan of a trait as separate functions, each of
+# which factorises the same K; here the second call (and every further trait on the same samples) reuses the decomposition.
+# Keyed by the file's identity (path, size, mtime), the sample list and the route; `spectral_cache_clear()` frees the HBM.
+_SPECTRAL_CACHE = {}
+
+
+def _spectral_cache_key(path, sample_indices, route):
+    import hashlib
+    if os.environ.get("JXGPU_SPECTRAL_CACHE", "1").strip() == "0":
+        return None
+    try:
+        st = os.stat(path)
+    except OSError:
+        return None
+    idx, _n = _opt_idx(sample_indices)
+    h = "all" if idx is None else hashlib.sha1(np.ascontiguousarray(idx, dtype=np.int64).tobytes()).hexdigest()
+    return (os.path.abspath(path), st.st_size, st.st_mtime_ns, h, route)
+
+
+def _spectral_cache_put(key, value):
+    if key is None:
+        return
+    _SPECTRAL_CACHE.clear()
+    _SPECTRAL_CACHE[key] = value
+
+
+def spectral_cache_clear():
+    """Drop the cached spectral form of the last sparse GRM (frees its eigenvector blocks in HBM)."""
+    _SPECTRAL_CACHE.clear()
+
+
 class _SpectralSparseReml:
     """K + lambda I of a (subset of a) sparse GRM handled through ONE eigendecomposition on the GPU instead of one
     sparse LLT per lambda (src/stats/spreml.rs:384-512 factorises at every evaluation): K = U diag(s) U', so
@@ -573,9 +605,14 @@ class _SpectralSparseReml:
         if _sparse_block_route(y.shape[0]):
             self._init_blocks(path, y, x_cov, sample_indices)
             return
-        _check_spectral_sparse_size(y.shape[0])
-        k, idx = _spgrm_dense_device(path, sample_indices)
-        n = int(k.shape[0])
+        key = _spectral_cache_key(path, sample_indices, "dense")
+        hit = _SPECTRAL_CACHE.get(key)
+        if hit is None:
+            _check_spectral_sparse_size(y.shape[0])
+            k, idx = _spgrm_dense_device(path, sample_indices)
+            n = int(k.shape[0])
+        else:
+            n, idx = int(hit[0].shape[0]), hit[2]
         if n != y.shape[0]:
             raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={n}, phenotype n={y.shape[0]}")
         if n == 0:
@@ -588,9 +625,13 @@ class _SpectralSparseReml:
                 raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
             x = np.concatenate([np.ones((n, 1)), xc], axis=1)
         self.n, self.p = n, int(x.shape[1])
-        dev = k.device
-        s, ut = pl.eigh_from_grm(k, ridge=0.0)                   # row j of ut = eigenvector j
-        del k
+        if hit is None:
+            s, ut = pl.eigh_from_grm(k, ridge=0.0)               # row j of ut = eigenvector j
+            del k
+            _spectral_cache_put(key, (s, ut, idx))
+        else:
+            s, ut = hit[0], hit[1]
+        dev = s.device
         rot = ut @ torch.from_numpy(np.concatenate([y[:, None], x], axis=1)).to(dev)
         rot = rot.cpu().numpy()
         self.s = s.cpu().numpy()
@@ -628,6 +669,25 @@ class _SpectralSparseReml:
                 raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
             x = np.concatenate([np.ones((n, 1)), xc], axis=1)
         self.n, self.p = n, int(x.shape[1])
+        key = _spectral_cache_key(path, sample_indices, f"block{_sparse_block_size()}")
+        hit = _SPECTRAL_CACHE.get(key)
+        if hit is not None:
+            # the eigendecompositions of the diagonal blocks depend on the GRM and the sample list only: a null fit followed by
+            # a scan of the same trait (or the next trait on the same samples) reuses them and only rotates its own [y | X]
+            perm, blocks, s_all, glob = hit
+            dev = blocks[0][2].device
+            yx = np.concatenate([y[:, None], x], axis=1)[perm]
+            rot_all = np.empty((n, 1 + self.p), dtype=np.float64)
+            for o0, nb, utb in blocks:
+                rot_all[o0:o0 + nb] = (utb @ torch.from_numpy(yx[o0:o0 + nb]).to(dev)).cpu().numpy()
+            self.s = s_all
+            self.yr, self.xr = rot_all[:, 0].copy(), rot_all[:, 1:].copy()
+            self.smin = float(self.s.min())
+            self.perm, self.blocks = perm, blocks
+            self.s_dev, self.ut_dev = torch.from_numpy(s_all).to(dev), None
+            self.x_design, self.y_raw = x[perm], y[perm]
+            self.sample_idx = glob
+            return
         # connected components of the selected sub-graph (host: one pass over the nnz entries)
         cp = col_ptr.astype(np.int64)
         cols = np.repeat(np.arange(n_all, dtype=np.int64), np.diff(cp))
@@ -681,6 +741,7 @@ class _SpectralSparseReml:
         self.s_dev, self.ut_dev = torch.from_numpy(s_all).to(dev), None
         self.x_design, self.y_raw = x[perm], y[perm]
         self.sample_idx = glob
+        _spectral_cache_put(key, (perm, blocks, s_all, glob))
 
     def factorizable(self, lam):
         import math

@@ -912,12 +912,15 @@ def splmm_residual_sumsq_is_effectively_zero(resid, raw):
 
 
 def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_hat, sample_idx=None, rows=None,
-                       score_scale=1.0, wald_sigma2=1.0):
+                       score_scale=1.0, wald_sigma2=1.0, exact_dots=False):
     """`grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316) as `scan_with_py_and_rhat` calls it (:3318):
     mean-imputed additive f32 decode (not centred), [score | X'g] = f32 GEMM of the block with f32([score_vec | X]), row sum
     of squares from the counts (`additive_row_sumsq_from_counts`, :1801-1820), g'M g = max(g'g - (X'g)'(X'X)^-1 (X'g), 0),
     denominator r_hat g'M g, `splmm_wald_from_score_denom` with sigma2 = 1; rows whose residual sum of squares is
-    effectively zero and failed rows are (NaN, NaN, 1).  -> (m, 3) f64."""
+    effectively zero and failed rows are (NaN, NaN, 1).  -> (m, 3) f64.
+    exact_dots: accumulate the products of the f32 operands in f64 and round the sum to f32 once (what a correctly rounded
+    sgemm would return); the default accumulates in f32 like a BLAS sgemm, whose summation order is its own -- at n = 200 000
+    that order alone moves beta by 1e-5 of its standard error."""
     n, p = x_design.shape
     cx = splmm_xtx_chol(x_design)
     rhs32 = np.concatenate([np.asarray(score_vec, dtype=np.float64)[:, None], x_design], axis=1).astype(np.float32)
@@ -931,7 +934,10 @@ def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_
         lut = np.array([2.0, mean32, 1.0, 0.0] if row_flip[r] else [0.0, mean32, 1.0, 2.0], dtype=np.float32)
         c = codes[r]
         g32 = lut[c]
-        dots = (g32 @ rhs32).astype(np.float32)               # sgemm output, f32
+        if exact_dots:
+            dots = (g32.astype(np.float64) @ rhs32.astype(np.float64)).astype(np.float32)
+        else:
+            dots = (g32 @ rhs32).astype(np.float32)           # sgemm output, f32
         missing, het, hom_alt = int(np.sum(c == 1)), int(np.sum(c == 2)), int(np.sum(c == 3))
         hom_two = (n - missing - het - hom_alt) if row_flip[r] else hom_alt
         mean_g = min(max(2.0 * float(F32(maf[r])), 0.0), 2.0)

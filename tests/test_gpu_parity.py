@@ -857,6 +857,9 @@ def test_c5_full_size_splmm_device_panel():
     assert d["nan_pattern_equal"] and d["all_rows_finite_p"]
     assert max(d["beta_err"], d["se_err"], d["p_err"]) < TOL, d
     assert d["reml_err"] < 1e-9 and d["ml_err"] < 1e-9, d
+    # the reference's default `-splmm` route (fastGWA null + GRAMMAR-gamma scan) on the same panel
+    assert d["approx_nan_pattern_equal"] and d["approx_used_equal"] and d["approx_gamma_err"] < 1e-6, d
+    assert max(d["approx_beta_err"], d["approx_se_err"], d["approx_p_err"]) < TOL, d
     assert d["host_maxrss_gib"] < 8.0 and d["host_rss_growth_gib"] < 4.0, d
 
 

@@ -242,19 +242,24 @@ int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int
     const int64_t cnt = r1 - r0;
     if (cnt <= 0) return 0;
     if (!rows) return fail("launch_grm_i8: the SNP row list is required");
-    static const int tile_env = getenv("JXGPU_GRM_I8_TILE") ? atoi(getenv("JXGPU_GRM_I8_TILE")) : 0;
+    const int tile_env = getenv("JXGPU_GRM_I8_TILE") ? atoi(getenv("JXGPU_GRM_I8_TILE")) : 0;   // 256 / 128 force a tile shape
     const int nt256 = (nt128 + 1) / 2;
-    const int64_t tiles256 = (int64_t)nt256 * (nt256 + 1) / 2;
-    // 256 x 256 tiles (one workgroup per CU) once they fill the chip a few times over; never for row panels, whose tile
-    // rows are counted in 128-row units
-    const bool big = !panel && (tile_env ? tile_env >= 256 : tiles256 >= 3 * 256);
+    // 256 x 256 tiles (one workgroup per CU) once they fill the chip a few times over; row panels (tile rows counted in
+    // 128-row units) take them when the panel starts on a 256-row boundary: rows [begin / 2, ceil(end / 2)) of the 256-tile
+    // triangle (a trailing half tile is masked by the kernel's row guards)
+    const int pb256 = panel ? tile_row_begin / 2 : 0, pe256 = panel ? (tile_row_end + 1) / 2 : nt256;
+    const int64_t base256 = (int64_t)pb256 * (pb256 + 1) / 2;
+    const int64_t ntl256 = (int64_t)pe256 * (pe256 + 1) / 2 - base256;
+    const bool big = (!panel || (tile_row_begin % 2 == 0 && (tile_row_end % 2 == 0 || tile_row_end == nt128))) &&
+                     (tile_env ? tile_env >= 256 : ntl256 >= 3 * 256);
     if (big) {
-        if (tiles256 > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
+        if (base256 + ntl256 > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
         // i32 sums stay exact for 2^29 SNPs per chunk: one launch for the whole range
         for (int64_t kb = r0; kb < r1; kb += (int64_t)1 << 29) {
             const int64_t ke = (kb + ((int64_t)1 << 29) < r1) ? kb + ((int64_t)1 << 29) : r1;
-            hipLaunchKernelGGL((grm_i8_kernel<256, 256, 128, 64, 128, true, 2>), dim3((unsigned)tiles256, 1), dim3(512), 0, st,
-                               p32, m_total, rows, kb, ke, (int64_t)1 << 29, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr, 0);
+            hipLaunchKernelGGL((grm_i8_kernel<256, 256, 128, 64, 128, true, 2>), dim3((unsigned)ntl256, 1), dim3(512), 0, st,
+                               p32, m_total, rows, kb, ke, (int64_t)1 << 29, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr,
+                               (int)base256);
             JX_LAUNCH_CHECK();
         }
         return 0;

@@ -2105,6 +2105,12 @@ def test_sparse_grm_row_panels_write_the_same_file(oracle, tmp_path, monkeypatch
             p1, n1, z1 = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, af[keep], str(tmp_path / f"p{prow}"), idx, method, thr,
                                                     abs_thr)
             assert (n1, z1) == (n0, z0) and open(p1, "rb").read() == ref, (method, thr, prow)
+        # the 256 x 256-tile int8 kernel on row panels (what a 200 000-sample GRM takes; forced here): same bytes
+        monkeypatch.setenv("JXGPU_GRM_I8_TILE", "256")
+        monkeypatch.setenv("JXGPU_SPGRM_PANEL_ROWS", "256")
+        p2, n2, z2 = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, af[keep], str(tmp_path / "big"), idx, method, thr, abs_thr)
+        monkeypatch.delenv("JXGPU_GRM_I8_TILE", raising=False)
+        assert (n2, z2) == (n0, z0) and open(p2, "rb").read() == ref, (method, thr, "256-tile panels")
 
 
 @pytest.mark.gpu

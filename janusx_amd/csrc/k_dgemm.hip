@@ -84,8 +84,45 @@ __device__ __forceinline__ void dg_store_tile(double *__restrict__ s, bool kfast
     }
 }
 
-template <int BM, int BN, int NT = DG_THREADS>
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void dgemm_kernel(DgemmArgs g) {
+// Steady-state loader: inside the K range (no K tail) and, for the lower-stored symmetric operand, away from the diagonal the
+// address of element i of step t + 1 is the address of step t plus a constant, and the in-range mask of x does not change:
+// one 64-bit add per element and step instead of the clamps and the 64-bit index product of dg_load_tile (by ablation --
+// scripts/probes/dgemm_probe.hip -- the loop skeleton reaches 69 TFLOP/s, the general loader held the kernel at 52).
+template <int BX, int NT>
+struct DgStream {
+    static constexpr int NL = BX * DG_BK / NT;
+    const char *base;        // wave-uniform: origin of the current step's tile (an SGPR pair, advanced by `step` per K step)
+    unsigned off[NL];        // byte offset of this lane's elements from it (< 128 ld doubles: 32 bits)
+    int64_t step;            // bytes per K step (uniform)
+    unsigned xmask;
+    __device__ __forceinline__ void init(const double *__restrict__ mat, int64_t ld, bool kfast, int x0, int xmax, int k0) {
+        const int t = threadIdx.x;
+        xmask = 0;
+        base = reinterpret_cast<const char *>(mat + (kfast ? (int64_t)k0 + (int64_t)x0 * ld : (int64_t)x0 + (int64_t)k0 * ld));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = i * NT + t;
+            const int xo = kfast ? idx / DG_BK : idx % BX;
+            const int ko = kfast ? idx % DG_BK : idx / BX;
+            const int xoc = min(x0 + xo, xmax - 1) - x0;                  // clamped: always a valid address
+            off[i] = (unsigned)(8 * (kfast ? (int64_t)ko + (int64_t)xoc * ld : (int64_t)xoc + (int64_t)ko * ld));
+            xmask |= (x0 + xo < xmax) ? (1u << i) : 0u;
+        }
+        step = 8 * (kfast ? (int64_t)DG_BK : (int64_t)DG_BK * ld);
+    }
+    __device__ __forceinline__ void load(double (&r)[NL]) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r[i] = *reinterpret_cast<const double *>(base + off[i]);
+        base += step;
+    }
+};
+
+// STREAM: K loop split into runs of steady-state steps (DgStream) and general steps; it wants ~230 registers (two waves per
+// SIMD = one workgroup per CU), which pays for long K loops (plain GEMM 52 -> 56 TFLOP/s, the symmetric product 38 -> 45) and
+// costs the short-K rank-2k update its second resident workgroup (40 -> 34): that one keeps the single general loop at four
+// waves per SIMD.
+template <int BM, int BN, int NT = DG_THREADS, bool STREAM = true>
+__global__ __launch_bounds__(NT, STREAM ? 2 : (NT == 512 ? 4 : 2)) void dgemm_kernel(DgemmArgs g) {
     constexpr int PA = BM + 17, PB = BN + 17;
     constexpr int WGM = NT == 512 ? 4 : 2;           // waves along M (x 2 along N)
     constexpr int WM = BM / WGM, WN = BN / 2;        // wave tile
@@ -135,19 +172,20 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void dgemm_kernel(DgemmArgs 
         return ta;
     };
     unsigned oka = 0, okb = 0;
-    auto load = [&](int k0) {
-        oka = dg_load_tile<BM, NT>(g.a, g.lda, ta, symm, m0, g.m, k0, kend, ra);
-        // op(B)(kk, x): !tb -> b[kk + x ldb] (k contiguous = "trans" mapping of the loader), tb -> b[x + kk ldb]
-        okb = dg_load_tile<BN, NT>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0, kend, rb);
+    DgStream<BM, NT> sa;
+    DgStream<BN, NT> sb;
+    static_assert(BM >= DG_BK, "tile rows");
+    // regime of the K step that starts at k: 0 = A stored as (x, k) (plain, or symmetric left of the tile's rows), 1 = A read
+    // transposed (ta, or symmetric right of the tile's rows), 2 = general loader (K tail, symmetric step crossing the diagonal)
+    auto mode_of = [&](int k) -> int {
+        if (k + DG_BK > kend) return 2;
+        if (!symm) return ta ? 1 : 0;
+        if (k + DG_BK <= m0) return 0;
+        if (k >= m0 + BM) return 1;
+        return 2;
     };
-    load(kbeg);
-    dg_store_tile<BM, NT>(as, a_kfast(kbeg), ra, oka);
-    dg_store_tile<BN, NT>(bs, tb_kfast, rb, okb);
-    __syncthreads();
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += DG_BK) {
-        const bool more = k0 + DG_BK < kend;
-        if (more) load(k0 + DG_BK);
+    auto multiply = [&]() {
         const double *ap = as + buf * DG_BK * PA + wm + lx;
         const double *bp = bs + buf * DG_BK * PB + wn + lx;
 #pragma unroll
@@ -163,12 +201,53 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void dgemm_kernel(DgemmArgs 
                 for (int i = 0; i < MB; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
         }
+    };
+    // one K step with the GENERAL loader for the next one (or none)
+    auto step_general = [&](int k0) {
+        const bool more = k0 + DG_BK < kend;
+        if (more) {
+            oka = dg_load_tile<BM, NT>(g.a, g.lda, ta, symm, m0, g.m, k0 + DG_BK, kend, ra);
+            // op(B)(kk, x): !tb -> b[kk + x ldb] (k contiguous = "trans" mapping of the loader), tb -> b[x + kk ldb]
+            okb = dg_load_tile<BN, NT>(g.b, g.ldb, g.tb == 0, false, n0, g.n, k0 + DG_BK, kend, rb);
+        }
+        multiply();
         if (more) {
             dg_store_tile<BM, NT>(as + (buf ^ 1) * DG_BK * PA, a_kfast(k0 + DG_BK), ra, oka);
             dg_store_tile<BN, NT>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb, okb);
         }
         __syncthreads();
         buf ^= 1;
+    };
+    oka = dg_load_tile<BM, NT>(g.a, g.lda, ta, symm, m0, g.m, kbeg, kend, ra);
+    okb = dg_load_tile<BN, NT>(g.b, g.ldb, g.tb == 0, false, n0, g.n, kbeg, kend, rb);
+    dg_store_tile<BM, NT>(as, a_kfast(kbeg), ra, oka);
+    dg_store_tile<BN, NT>(bs, tb_kfast, rb, okb);
+    __syncthreads();
+    int k0 = kbeg;
+    while (k0 < kend) {
+        const int kn = k0 + DG_BK;
+        const int md = (STREAM && kn < kend) ? mode_of(kn) : 2;
+        if (!STREAM || md == 2) {
+            step_general(k0);
+            k0 = kn;
+            continue;
+        }
+        // run of steps whose NEXT step is in regime md: the streams advance by a constant per step (nothing but the loads,
+        // the MFMAs and the staging stores inside this loop)
+        int k_hi = kbeg + ((kend - kbeg) / DG_BK - 1) * DG_BK;     // last step that lies inside the K range
+        if (symm && md == 0) k_hi = min(k_hi, m0 - DG_BK);
+        sa.init(g.a, g.lda, md == 1, m0, g.m, kn);
+        sb.init(g.b, g.ldb, g.tb == 0, n0, g.n, kn);
+        const bool akf = md == 1;
+        for (; k0 + DG_BK <= k_hi; k0 += DG_BK) {
+            sa.load(ra);
+            sb.load(rb);
+            multiply();
+            dg_store_tile<BM, NT>(as + (buf ^ 1) * DG_BK * PA, akf, ra, sa.xmask);
+            dg_store_tile<BN, NT>(bs + (buf ^ 1) * DG_BK * PB, tb_kfast, rb, sb.xmask);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
     // epilogue: acc[j][i][r] = C[m0 + wm + 16 i + lx][n0 + wn + 16 j + lk + 4 r]
     const bool split = g.ksplit > 1;
@@ -207,15 +286,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2) void dgemm_kernel(DgemmArgs 
     }
 }
 
-template <int BM, int BN, int NT = DG_THREADS>
+template <int BM, int BN, int NT = DG_THREADS, bool STREAM = true>
 static int dg_launch(const DgemmArgs &g, dim3 grid, hipStream_t st) {
     constexpr size_t smem = sizeof(double) * 2 * DG_BK * ((BM + 17) + (BN + 17));
     static bool attr_set = false;
     if (!attr_set) {
-        JX_HIP(hipFuncSetAttribute((const void *)dgemm_kernel<BM, BN, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        JX_HIP(hipFuncSetAttribute((const void *)dgemm_kernel<BM, BN, NT, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dgemm_kernel<BM, BN, NT>), grid, dim3(NT), smem, st, g);
+    hipLaunchKernelGGL((dgemm_kernel<BM, BN, NT, STREAM>), grid, dim3(NT), smem, st, g);
     JX_LAUNCH_CHECK();
     return 0;
 }
@@ -281,8 +360,7 @@ int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, c
     g.ksplit = dg_fit_split(ksplit, m, n, ws ? ws_doubles : 0);
     dim3 grid(tm, tn, g.ksplit);
     int rc;
-    static const int nt_env = getenv("JXGPU_DGEMM_NT") ? atoi(getenv("JXGPU_DGEMM_NT")) : 512;
-    if (bm == 128 && bn == 128) rc = nt_env == 256 ? dg_launch<128, 128, 256>(g, grid, st) : dg_launch<128, 128>(g, grid, st);
+    if (bm == 128 && bn == 128) rc = dg_launch<128, 128>(g, grid, st);
     else if (bm == 128) rc = dg_launch<128, 64>(g, grid, st);
     else rc = dg_launch<64, 64>(g, grid, st);
     if (rc) return rc;
@@ -335,7 +413,12 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
     DgemmArgs g{a, b, c, lda, ldb, ldc, m, m, k, alpha, beta, 0, 1, 0, 1, 1, nullptr};
     const int t = ceil_div(m, 128);
     dim3 grid((unsigned)((int64_t)t * (t + 1) / 2), 1, 1);
-    return dg_launch<128, 128>(g, grid, st);
+    // the rank-2k update alone is faster in the general-loop form with two resident workgroups per CU (1.31 vs 1.50 ms at n_t =
+    // 20000), the band reduction as a whole is faster with the one-workgroup stream form (397 vs 426 ms): the panel chain of
+    // the NEXT panel runs on the second stream beside this kernel and is the critical path -- it gets the CU resources the
+    // second workgroup would take.  JXGPU_DSYR2K_GENERAL=1 selects the general-loop form.
+    static const bool general = getenv("JXGPU_DSYR2K_GENERAL") && atoi(getenv("JXGPU_DSYR2K_GENERAL")) != 0;
+    return general ? dg_launch<128, 128, DG_THREADS, false>(g, grid, st) : dg_launch<128, 128>(g, grid, st);
 }
 
 }  // namespace jx

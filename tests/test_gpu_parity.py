@@ -228,6 +228,59 @@ def test_grm_exact_integer_path(oracle, miss_frac, monkeypatch):
     assert _grm_err(k2, ref2) < TOL
 
 
+def test_f64_gemm_family():
+    """The eigensolver's own f64-MFMA products (csrc/k_dgemm.hip: `jxg_dgemm_f64` NN / TN / NT / TT with and without a split
+    over K, `jxg_dsymm_lower_f64` on a lower-stored symmetric operand, `jxg_dsyr2k_lower_nt_f64` on the lower tiles) against
+    torch's f64 matmul: ragged shapes (tails in M, N and K; K runs that start in the general loader, continue in the
+    steady-state stream loader and end in the general one; symmetric tiles left of, on and right of the diagonal)."""
+    import torch
+    from janusx_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=dev, dtype=torch.float64)   # noqa: E731
+    L = lib()
+    for (m, n, k, ta, tb, alpha, beta, ksplit) in [(300, 200, 177, 0, 0, 1.0, 0.0, 0), (257, 129, 1000, 1, 0, -0.5, 2.0, 0),
+                                                   (130, 390, 64, 0, 1, 1.5, 1.0, 0), (515, 77, 333, 1, 1, 1.0, 0.0, 0),
+                                                   (64, 64, 5000, 1, 0, 1.0, 0.0, 4), (1000, 1100, 48, 0, 0, 1.0, -1.0, 0),
+                                                   (129, 131, 15, 0, 0, 1.0, 0.0, 0), (640, 384, 2048, 0, 0, 1.0, 0.5, 3)]:
+        a = rnd(k, m) if not ta else rnd(m, k)          # column-major buffers of the STORED operands
+        b = rnd(n, k) if not tb else rnd(k, n)
+        c = rnd(n, m)
+        opa = a.T if not ta else a
+        opb = b.T if not tb else b
+        ref = alpha * (opa @ opb) + beta * c.T
+        got = c.clone()
+        check(L.jxg_dgemm_f64(ta, tb, m, n, k, alpha, a.data_ptr(), k if ta else m, b.data_ptr(), n if tb else k, beta,
+                              got.data_ptr(), m, ksplit, st))
+        err = float((got.T - ref).abs().max() / ref.abs().max())
+        assert err < 1e-13, (m, n, k, ta, tb, ksplit, err)
+    for (m, n) in [(700, 64), (513, 40), (1300, 200)]:
+        a = rnd(m, m)
+        full = torch.tril(a.T) + torch.tril(a.T, -1).T   # the lower triangle of A = a.T is what the kernel may read
+        a.T.masked_fill_(torch.triu(torch.ones((m, m), device=dev, dtype=torch.bool), 1), 1e300)   # poison the rest
+        b = rnd(n, m)
+        c = rnd(n, m)
+        ref = 0.7 * (full @ b.T) + 0.3 * c.T
+        got = c.clone()
+        check(L.jxg_dsymm_lower_f64(m, n, 0.7, a.data_ptr(), m, b.data_ptr(), m, 0.3, got.data_ptr(), m, st))
+        err = float((got.T - ref).abs().max() / ref.abs().max())
+        assert err < 1e-13, ("symm", m, n, err)
+    for (m, k) in [(700, 128), (515, 100), (1290, 256)]:
+        a, b = rnd(k, m), rnd(k, m)
+        c = rnd(m, m)
+        ref = -1.0 * (a.T @ b) + c.T
+        got = c.clone()
+        check(L.jxg_dsyr2k_lower_nt_f64(m, k, -1.0, a.data_ptr(), m, b.data_ptr(), m, 1.0, got.data_ptr(), m, st))
+        low = torch.tril(torch.ones((m, m), device=dev, dtype=torch.bool))
+        err = float(((got.T - ref).abs() * low).max() / ref.abs().max())
+        assert err < 1e-13, ("syr2k", m, k, err)
+        tile = torch.arange(m, device=dev) // 128          # tiles strictly above the diagonal are not touched at all
+        above = tile[:, None] < tile[None, :]
+        assert torch.equal(got.T[above], c.T[above])
+
+
 def test_eigh_invariants(oracle):
     from janusx_amd import janusx as jxrs
     # reference's own known-answer test: [[2,1],[1,2]] -> {1,3} (src/math/eigh.rs:1982-1998)

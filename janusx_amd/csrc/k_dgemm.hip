@@ -386,7 +386,7 @@ int dsymm_lower(hipStream_t st, int m, int n, double alpha, const double *a, int
         if (rule > 0) {
             ksplit = (int)((rule + tiles - 1) / tiles);
         } else {
-            const int64_t slots = 512;
+            static const int64_t slots = getenv("JXGPU_DSYMM_SLOTS") ? atoll(getenv("JXGPU_DSYMM_SLOTS")) : 512;
             double best = 1e300;
             for (int ks = 1; ks <= 16 && ks <= maxsplit; ++ks) {
                 const double cost = (double)((tiles * ks + slots - 1) / slots) / (double)ks;

@@ -24,13 +24,32 @@ namespace jx {
 
 constexpr int CH_N = 32;          // Chebyshev terms per segment
 constexpr int CH_MAXSEG = 8;      // (high - low) <= 16
+constexpr int CH_HDR = 24;        // doubles in front of y_c in the table workspace: smin, 7 spare, beta_mid (<= 15), 1 spare
 
 struct ChebHeader {
     int nseg;
-    int nf;       // number of tabulated functions: 1 + NAc + p + 1
+    int nf;       // number of tabulated functions: 1 + NAc + p + 1 (plain form), 4 + 2 p + NAc (block form)
     double low;
     double segw;
 };
+
+// Block form (dim = p + 1 >= 5, i.e. the MAXD = 8 / 16 instantiations).  The normal matrix of an evaluation is
+//   A + eps I = [ Ac  c ; c'  d + eps ],   Ac = X~'WX~ + eps I = L L' (lambda-only),   c = X~'Wg~, d = g~'Wg~ (per SNP),
+// so the Cholesky factorisation of the full matrix is L, the row w' = (L^-1 c)' and the last pivot sk = d + eps - w'w: with L
+// tabulated (its entries are as analytic in x as the sums they come from) an evaluation needs two triangular solves instead
+// of a factorisation and no dim x dim matrix in registers:
+//   w = L^-1 c,  t = L^-1 bc (tabulated; bc = X~'Wy~),  beta_k = (bk - w't) / sk,  log det = 2 sum ln L_ii + ln sk,
+//   r'V^-1 r = (yy - t't) - beta_k^2 sk - eps |beta|^2,  |beta|^2 = |u|^2 - 2 beta_k u'z + beta_k^2 (|z|^2 + 1)  with
+//   u = L^-T t (tabulated), z = L^-T w,   [(A + eps I)^-1]_kk = 1 / sk.
+// (Tabulating M = Ac^-1 instead and forming c'Mc is NOT an option: an error of 1e-9 |M| in M is amplified by |c|^2 |M| /
+// c'Mc -- two covariates collinear to 1e-3 cost 4e-5 on beta that way; a perturbed L is a small relative perturbation of Ac.)
+// Tabulated per node: f0 = sum ln v, f1 = log det Ac, f2 = yy - t't, f3 = |u|^2, then t (p), u (p), the lower triangle of L.
+// The plain form keeps two dim x dim matrices per lane in registers: 2.2 KB of scratch per lane at MAXD = 16, and the
+// one-wave-per-SNP kernel was all that could take it (measured 2.36 s per 100 000 SNPs with ten covariates at n = 20 000).
+__host__ __device__ __forceinline__ int cheb_nf(int p, bool blk) {
+    return blk ? 4 + 2 * p + p * (p + 1) / 2 : 1 + p * (p + 1) / 2 + p + 1;
+}
+__host__ __device__ __forceinline__ bool cheb_blk(int p) { return p + 1 >= 5; }
 
 __device__ __forceinline__ double fast_rcp(double v) {
     double r = __builtin_amdgcn_rcp(v);
@@ -108,6 +127,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void yshift_kernel(const double *__re
         double m = smin_sh[0];
         for (int w = 1; w < SCAN_WAVES; ++w) m = fmin(m, smin_sh[w]);
         smin_out[0] = m;
+        // the shift itself: with the 1e-6 ridge the SNP coefficient is invariant to it only up to eps [N beta_mid]_k
+        // (N = (A + eps I)^-1) -- invisible for a well-conditioned design, 4e-5 of a standard error with two covariates
+        // collinear to 1e-3; the final evaluation adds it back (fast_eval_finish*)
+#pragma unroll
+        for (int r = 0; r < MAXD; ++r)
+            if (r < p) smin_out[8 + r] = ok ? beta[r] : 0.0;
     }
 }
 
@@ -151,6 +176,68 @@ __global__ __launch_bounds__(SCAN_THREADS) void cheb_nodes_kernel(const double *
         }
     }
     block_sum<NV>(v, NV, shm);
+    if (cheb_blk(p)) {
+        // block form: M = (X~'WX~ + eps I)^-1 and what hangs on it, by thread 0 on shared arrays (run-time loops: p <= 15)
+        __shared__ double am[MAXD * MAXD], bm[MAXD], um[MAXD], col[MAXD];
+        if (threadIdx.x == 0) {
+            int idx = 0;
+#pragma unroll
+            for (int r = 0; r < MAXD; ++r) {
+                bm[r] = v[NA + r];
+#pragma unroll
+                for (int c = 0; c <= r; ++c) {
+                    am[r * MAXD + c] = v[idx];
+                    am[c * MAXD + r] = v[idx];
+                    ++idx;
+                }
+            }
+            const double yy = v[NA + MAXD + 1];
+            bool ok = true;
+            for (int i = 0; i < p; ++i) am[i * MAXD + i] += 1e-6;
+            for (int i = 0; i < p; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double sum = am[i * MAXD + j];
+                    for (int q = 0; q < j; ++q) sum -= am[i * MAXD + q] * am[j * MAXD + q];
+                    if (i == j) {
+                        if (!(sum > 1e-18)) ok = false;
+                        am[i * MAXD + i] = sqrt(sum);
+                    } else {
+                        am[i * MAXD + j] = sum / am[j * MAXD + j];
+                    }
+                }
+            double lnd = 0.0;
+            for (int i = 0; i < p; ++i) lnd += 2.0 * log(am[i * MAXD + i]);
+            // t = L^-1 bc (into col), u = L^-T t (into um)
+            for (int i = 0; i < p; ++i) {
+                double sum = bm[i];
+                for (int q = 0; q < i; ++q) sum -= am[i * MAXD + q] * col[q];
+                col[i] = sum / am[i * MAXD + i];
+            }
+            for (int i = p - 1; i >= 0; --i) {
+                double sum = col[i];
+                for (int q = i + 1; q < p; ++q) sum -= am[q * MAXD + i] * um[q];
+                um[i] = sum / am[i * MAXD + i];
+            }
+            double tt = 0.0, uu = 0.0;
+            for (int i = 0; i < p; ++i) {
+                tt += col[i] * col[i];
+                uu += um[i] * um[i];
+            }
+            const double bad = nan("");
+            double *o = vals + (int64_t)seg * nf * CH_N;
+            o[0 * CH_N + k] = v[NA + MAXD];
+            o[1 * CH_N + k] = ok ? lnd : bad;
+            o[2 * CH_N + k] = ok ? yy - tt : bad;
+            o[3 * CH_N + k] = ok ? uu : bad;
+            for (int i = 0; i < p; ++i) {
+                o[(4 + i) * CH_N + k] = ok ? col[i] : bad;
+                o[(4 + p + i) * CH_N + k] = ok ? um[i] : bad;
+            }
+            for (int r = 0; r < p; ++r)
+                for (int c = 0; c <= r; ++c) o[(4 + 2 * p + r * (r + 1) / 2 + c) * CH_N + k] = ok ? am[r * MAXD + c] : bad;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         double *o = vals + (int64_t)seg * nf * CH_N;
         o[0 * CH_N + k] = v[NA + MAXD];
@@ -289,7 +376,8 @@ __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const d
 
 template <int MAXD>
 __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
-                                                 bool want_ainv, double (&acc)[MAXD + 1], FastEval<MAXD> &o);
+                                                 bool want_ainv, const double *__restrict__ bmid, double (&acc)[MAXD + 1],
+                                                 FastEval<MAXD> &o);
 
 // One evaluation for the SNP owned by this wave. MAXD bounds dim = p + 1.
 template <int MAXD>
@@ -297,7 +385,7 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
                                           double smin, const double *__restrict__ s,
                                           const double *__restrict__ xcov, const double *__restrict__ yc,
                                           const float *__restrict__ g, int n, int p, bool want_ainv,
-                                          FastEval<MAXD> &o) {
+                                          FastEval<MAXD> &o, const double *__restrict__ bmid = nullptr) {
     const int dim = p + 1;
     o.ok = false;
     o.reml_neg = 1e8;
@@ -311,14 +399,108 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
 #pragma unroll
     for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
     fast_eval_accumulate<MAXD>(lbd, s, xcov, yc, g, 0, n, 0, p, acc);
-    fast_eval_finish<MAXD>(x, hd, coef, n, p, want_ainv, acc, o);
+    fast_eval_finish<MAXD>(x, hd, coef, n, p, want_ainv, bmid, acc, o);
 }
 
 // Second half of an evaluation: wave sums of the per-lane accumulators, lambda-only sums from the Chebyshev tables,
 // normal equations, REML.  `o` must have been reset by the caller.
+// Block form of the second half (see ChebHeader): two triangular solves with the tabulated factor, no dim x dim matrix in
+// registers.  The tabulated values live one per lane (function f in lane f % 64, slot f / 64) and are read with a uniform
+// source lane; every lane carries the same w / z (wave-uniform arithmetic).
+template <int MAXD>
+__device__ __forceinline__ void fast_eval_finish_blk(double x, const ChebHeader hd, const double *__restrict__ coef, int n,
+                                                     int p, bool want_ainv, const double *__restrict__ bmid,
+                                                     double (&acc)[MAXD + 1], FastEval<MAXD> &o) {
+    const int dim = p + 1;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+    int seg = (int)((x - hd.low) / hd.segw);
+    if (seg < 0) seg = 0;
+    if (seg >= hd.nseg) seg = hd.nseg - 1;
+    const double t = (x - (hd.low + hd.segw * ((double)seg + 0.5))) / (0.5 * hd.segw);
+    const double *cf = coef + (int64_t)seg * hd.nf * CH_N;
+    constexpr int NS = (4 + 2 * (MAXD - 1) + (MAXD - 1) * MAXD / 2 + 63) / 64;   // table slots per lane
+    double mv[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int f = lane + 64 * sl;
+        mv[sl] = (64 * sl < hd.nf) ? clenshaw(cf + (int64_t)(f < hd.nf ? f : 0) * CH_N, t) : 0.0;
+    }
+    auto tab = [&](int f) -> double {                     // f is wave-uniform
+        double r = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const double v = __shfl(mv[sl], f & 63, 64);
+            if ((f >> 6) == sl) r = v;
+        }
+        return r;
+    };
+    const double logdetv = tab(0), lnd = tab(1), q0 = tab(2), uu = tab(3);
+    const int ft = 4, fu = 4 + p, fl = 4 + 2 * p;
+    // w = L^-1 c (forward), then z = L^-T w (backward); c_r = acc[r]
+    double w[MAXD - 1], z[MAXD - 1];
+    double ww = 0.0, wt = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXD - 1; ++i) {
+        w[i] = 0.0;
+        if (i < p) {
+            double sum = acc[i];
+#pragma unroll
+            for (int q = 0; q < i; ++q) sum = fma(-tab(fl + i * (i + 1) / 2 + q), w[q], sum);
+            w[i] = sum / tab(fl + i * (i + 1) / 2 + i);
+            ww = fma(w[i], w[i], ww);
+            wt = fma(w[i], tab(ft + i), wt);
+        }
+    }
+    double uz = 0.0, zz = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < MAXD - 1; ++ii) {
+        const int i = MAXD - 2 - ii;
+        z[i] = 0.0;
+        if (i < p) {
+            double sum = w[i];
+#pragma unroll
+            for (int q = i + 1; q < MAXD - 1; ++q)
+                if (q < p) sum = fma(-tab(fl + q * (q + 1) / 2 + i), z[q], sum);
+            z[i] = sum / tab(fl + i * (i + 1) / 2 + i);
+            uz = fma(tab(fu + i), z[i], uz);
+            zz = fma(z[i], z[i], zz);
+        }
+    }
+    const double sk = acc[MAXD - 1] + 1e-6 - ww;          // the last pivot of the Cholesky factorisation, squared
+    if (!(sk > 1e-18) || !isfinite(lnd)) return;          // chol_inplace would have failed
+    const double bk = (acc[MAXD] - wt) / sk;
+    const double nb2 = uu - 2.0 * bk * uz + bk * bk * (zz + 1.0);
+    const double q = q0 - bk * bk * sk - 1e-6 * nb2;
+    const double nf = (double)n, pf = (double)dim;
+    const double total = (nf - pf) * jx_log(q) + logdetv + (lnd + jx_log(sk));
+    const double cst = (nf - pf) * (jx_log(nf - pf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0;
+    const double reml = cst - 0.5 * total;
+    o.ok = true;
+    o.reml_neg = isfinite(reml) ? -reml : 1e8;
+    o.q = q;
+    o.logdetv = logdetv;
+    o.beta_k = bk;
+    o.ainv_kk = 1.0 / sk;
+    if (want_ainv && bmid) {
+        // y was shifted by X beta_mid: beta_k(y) = beta_k(y_c) - eps [N beta_mid]_k, and the k-th row of N is [-z' / sk, 1 / sk]
+        double zb = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXD - 1; ++i)
+            if (i < p) zb = fma(z[i], bmid[i], zb);
+        o.beta_k = bk + 1e-6 * zb / sk;
+    }
+}
+
 template <int MAXD>
 __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
-                                                 bool want_ainv, double (&acc)[MAXD + 1], FastEval<MAXD> &o) {
+                                                 bool want_ainv, const double *__restrict__ bmid, double (&acc)[MAXD + 1],
+                                                 FastEval<MAXD> &o) {
+    if constexpr (MAXD >= 8) {                            // dim >= 5: block form (the tables were built for it: cheb_blk)
+        fast_eval_finish_blk<MAXD>(x, hd, coef, n, p, want_ainv, bmid, acc, o);
+        return;
+    }
     const int dim = p + 1;
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -407,6 +589,14 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
         for (int r = 0; r < MAXD; ++r) e[r] = (r == dim - 1) ? 1.0 : 0.0;
         chol_solve<MAXD>(a, dim, e, xk);
         o.ainv_kk = pick<MAXD>(xk, dim - 1);
+        if (bmid) {
+            // y was shifted by X beta_mid: beta_k(y) = beta_k(y_c) - eps [N beta_mid]_k = beta_k(y_c) - eps beta_mid'(N e_k)
+            double corr = 0.0;
+#pragma unroll
+            for (int r = 0; r < MAXD - 1; ++r)
+                if (r < p) corr = fma(bmid[r], xk[r], corr);
+            o.beta_k -= 1e-6 * corr;
+        }
     }
 }
 
@@ -538,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             }
         }
         // ---- final_beta_se (src/stats/reml.rs:472-568) at the optimum ------------------------------------
-        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, true, ev);
+        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, true, ev, smin_ptr + 8);
         double beta = nan(""), se = nan("");
         const int dim = p + 1;
         if (ev.ok) {
@@ -759,7 +949,7 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
         ev.logdetv = 0.0;
         ev.beta_k = 0.0;
         ev.ainv_kk = 0.0;
-        if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd_r, coef_r, n_r, p, phase == 3, acc, ev);
+        if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd_r, coef_r, n_r, p, phase == 3, smin_ptr + 8, acc, ev);
         double *o = out + (int64_t)r * out_cols;
         if (phase == 1) {
             ssq = wave_allsum(ssq);
@@ -876,25 +1066,30 @@ extern "C" int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const d
                                   int warm, double init_log10_lbd, int with_plrt, double nullml, double *d_out,
                                   int32_t *d_evals, void *stream);
 
-// Workspace layout (doubles): [0] smin | [8..8+n) y_c | coef (total_funcs*CH_N) | vals (total_funcs*CH_N)
+// Workspace layout (doubles): [0] smin | [8..8+p) beta_mid (the shift of y) | [CH_HDR..CH_HDR+n) y_c | coef (total_funcs*CH_N) |
+// vals (total_funcs*CH_N)
 static bool fast_path_ok(int p, double low, double high) {
-    return (high - low) <= 2.0 * CH_MAXSEG && (1 + p * (p + 1) / 2 + p + 1) <= 64 && !getenv("JXGPU_SCAN_EXACT");
+    // plain form: one table value per lane (nf <= 64, always true for dim <= 4); block form: up to three per lane
+    return (high - low) <= 2.0 * CH_MAXSEG && cheb_nf(p, cheb_blk(p)) <= (cheb_blk(p) ? 192 : 64) && !getenv("JXGPU_SCAN_EXACT");
 }
 
 static ChebHeader make_header(int p, double low, double high) {
     ChebHeader hd;
-    hd.nseg = (int)ceil((high - low) / 2.0);
+    // block form: segments of width <= 1 (rho = 5.8: the entries of M = Ac^-1 are as analytic as the sums but, for an
+    // ill-conditioned Ac, much larger on the Bernstein ellipse than on the interval -- with width 2 two covariates collinear
+    // to 1e-3 cost 3e-6 on beta; the narrower segment buys seven more digits)
+    hd.nseg = (int)ceil((high - low) / (cheb_blk(p) ? 1.0 : 2.0));
     if (hd.nseg < 1) hd.nseg = 1;
     hd.segw = (high - low) / hd.nseg;
     hd.low = low;
-    hd.nf = 1 + p * (p + 1) / 2 + p + 1;
+    hd.nf = cheb_nf(p, cheb_blk(p));
     return hd;
 }
 
 extern "C" int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high) {
     if (!fast_path_ok(p, low, high)) return 0;
     const ChebHeader hd = make_header(p, low, high);
-    return (int64_t)sizeof(double) * (8 + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N);
+    return (int64_t)sizeof(double) * (CH_HDR + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N);
 }
 
 extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
@@ -906,7 +1101,7 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     const ChebHeader hd = make_header(p, low, high);
     const int total_funcs = hd.nseg * hd.nf;
     double *w = (double *)d_work;
-    double *smin = w, *yc = w + 8, *coef = yc + n, *vals = coef + (int64_t)total_funcs * CH_N;
+    double *smin = w, *yc = w + CH_HDR, *coef = yc + n, *vals = coef + (int64_t)total_funcs * CH_N;
     const double lbd_mid = pow(10.0, 0.5 * (low + high));
     JX_DISPATCH_DIM_F(p, hipLaunchKernelGGL(yshift_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, st, d_s, d_xcov, d_y,
                                             n, p, lbd_mid, yc, smin));
@@ -931,7 +1126,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_scan_tab: configuration needs the exact scan path");
     const ChebHeader hd = make_header(p, low, high);
     const double *w = (const double *)d_work;
-    const double *smin = w, *yc = w + 8, *coef = yc + n;
+    const double *smin = w, *yc = w + CH_HDR, *coef = yc + n;
     const int dim = p + 1;
     // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
     const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
@@ -968,7 +1163,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         JX_LAUNCH_CHECK();
         return 0;
     }
-    if (dim <= 4 && !getenv("JXGPU_SCAN_NOTILE")) {
+    if (!getenv("JXGPU_SCAN_NOTILE")) {
         // n beyond the LDS-resident limit: tiles of the shared vectors in LDS, NW SNPs per workgroup in lock step
         g_last_ms[11] = 1.f;
         const int per_sample = 8 * (2 + p);
@@ -999,19 +1194,27 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
                                yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
                                d_out, d_evals, tile, rows_per_wg);
         } else {
-            constexpr int NW = 8;
-            auto kfn = lmm_scan_tiled_kernel<4, NW>;
-            static bool attr_t4 = false;
-            if (!attr_t4) {
-                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-                attr_t4 = true;
-            }
-            int grid = cus;
-            if (grid * NW > nrows) grid = (nrows + NW - 1) / NW;
-            const int rows_per_wg = (nrows + grid - 1) / grid;
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_tile, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
-                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
-                               d_out, d_evals, tile, rows_per_wg);
+            // dim 3 - 4: plain evaluation tail; dim 5 - 8 and 9 - 16: block form (fast_eval_finish_blk), same tiling
+#define JX_TILED_LAUNCH(MAXDV)                                                                                            \
+    do {                                                                                                                  \
+        constexpr int NW = 8;                                                                                             \
+        auto kfn = lmm_scan_tiled_kernel<MAXDV, NW>;                                                                      \
+        static bool attr_t = false;                                                                                       \
+        if (!attr_t) {                                                                                                    \
+            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));       \
+            attr_t = true;                                                                                                \
+        }                                                                                                                 \
+        int grid = cus;                                                                                                   \
+        if (grid * NW > nrows) grid = (nrows + NW - 1) / NW;                                                              \
+        const int rows_per_wg = (nrows + grid - 1) / grid;                                                                \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_tile, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,  \
+                           yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,      \
+                           d_out, d_evals, tile, rows_per_wg);                                                            \
+    } while (0)
+            if (dim <= 4) JX_TILED_LAUNCH(4);
+            else if (dim <= 8) JX_TILED_LAUNCH(8);
+            else JX_TILED_LAUNCH(16);
+#undef JX_TILED_LAUNCH
         }
         JX_LAUNCH_CHECK();
         return 0;

@@ -392,7 +392,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     else:
         lbd, w, py, wx, a_chol, ypy, log_det_v, df = model.fv_cache(init_log10_lbd)
         a_dev = torch.from_numpy(a_chol).to(dev)
-    if mode == "lmm" and block_rows == 8192 and 8 * n * (2 + model.p) > 156 * 1024 and model.p + 1 <= 4:
+    if mode == "lmm" and block_rows == 8192 and (8 * n * (2 + model.p) > 156 * 1024 or model.p + 1 > 4):
         # beyond the LDS-resident limit the exact scan runs its tiled form: one workgroup per CU walks a queue of SNPs in
         # lock step over LDS tiles of (s, X~, y~); longer blocks keep every wave's queue deep (8 SNPs per wave)
         block_rows = 32768

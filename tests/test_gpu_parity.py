@@ -1409,6 +1409,50 @@ def test_eigh_own_divide_and_conquer(monkeypatch):
         assert np.max(np.abs(a @ u - u * w)) < 1e-11 * scale, (name, float(np.max(np.abs(a @ u - u * w))))
 
 
+@pytest.mark.parametrize("q", [3, 6, 11, 14])
+def test_exact_scan_with_covariates_block_form(oracle, oracle_c, q):
+    """The exact per-SNP scan with q covariates beside the intercept at a size where Brent has well-defined optima
+    (n = 3000): dim = q + 2 >= 5 takes the BLOCK form of the evaluation (csrc/k_scan_fast.hip: M = (X~'WX~ + eps I)^-1 and
+    u = M X~'Wy~ tabulated as Chebyshev series, no factorisation per evaluation: last pivot, beta_k, log det and r'V^-1 r
+    from c'Mc, c'u, u'z, |z|^2) inside the tiled kernel; against the oracle's line-by-line restatement of
+    `run_rotated_reml_assoc_block_f32` (src/stats/lmm.rs:94-199, src/stats/reml.rs:255-568) on the same rotated rows, the
+    device pipeline route and the host C-ABI route."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import pipeline, stats
+    n, m = 3000, 400
+    packed, g = bed.synth_panel_numpy(n, m, seed=60 + q, missing_rate=0.01, family=True)
+    y = bed.synth_phenotype(g, n_causal=15, pve=0.5, seed=60 + q)
+    rng = np.random.default_rng(q)
+    cov = rng.normal(size=(n, q))
+    cov[:, 0] += 0.5 * y                                     # a covariate that matters
+    if q >= 6:
+        cov[:, 5] = cov[:, 1] + 1e-3 * rng.normal(size=n)    # two nearly collinear covariates: an ill-conditioned X~'WX~
+    x = np.concatenate([np.ones((n, 1)), cov], axis=1)
+    k, eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    s, u = oracle.gwas_eigh_from_grm(k)
+    nm = oracle.spectral_null_model(y, x, s, u)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    pk = np.ascontiguousarray(packed[keep])
+    gd = oracle.decode_centered_block_f32(pk, n, flip[keep], maf[keep])
+    grot = oracle.rotate_block_f32(gd, nm.Dh)
+    lo, hi = nm.bounds
+    ref = oracle_c.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2)
+    out = jxrs.lmm_reml_chunk_f32(nm.S, nm.Xcov, nm.y, lo, hi, grot, 30, 1e-2)
+    be, se, pe = _assoc_err(out, ref)
+    # identical rotated input: f64 summation order, and -- with the two collinear covariates -- the second-order effect of the
+    # y shift under the 1e-6 ridge on r'V^-1 r (4.5e-8 on SE at q = 14; its first-order effect on beta, 4.5e-5, is corrected)
+    assert max(be, se, pe) < 2e-7, (q, be, se, pe)
+    p = pipeline.Panel(torch.from_numpy(pk).cuda(), n)
+    model = pipeline.SpectralModel(torch.from_numpy(nm.S).cuda(),
+                                   torch.from_numpy(np.ascontiguousarray(nm.Dh.astype(np.float64))).cuda(), x, y)
+    lut = stats.scan_lut_from_counts(maf[keep], flip[keep], p.counts(), n)
+    res = pipeline.scan_rows(p, model, np.arange(pk.shape[0]), lut, mode="lmm", low=lo, high=hi, max_iter=30, tol=1e-2).cpu().numpy()
+    be, se, pe = _assoc_err(res, ref)
+    assert max(be, se, pe) < TOL, (q, be, se, pe)
+
+
 @pytest.mark.parametrize("n,m,p,seed", [(17, 40, 1, 1), (130, 90, 4, 2), (257, 120, 8, 3), (300, 64, 15, 4), (64, 33, 2, 5)])
 def test_small_shapes_and_many_covariates(oracle, oracle_c, n, m, p, seed):
     """Edge shapes through the C ABI: n below / across the 128-sample tile, n not a multiple of 4, one SNP block smaller

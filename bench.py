@@ -301,7 +301,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    def run_leg(n, m_arg, missing, steps, warmup):
+    def run_leg(n, m_arg, missing, steps, warmup, covariates=0):
         """One timed configuration: synthetic panel resident in HBM, `warmup` untimed + `steps` timed passes of the whole
         hot path.  -> dict(elapsed, kept_total, kern, stage, null, packed, y, x, eigh_sharded, m)."""
         # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
@@ -324,6 +324,8 @@ def main():
             dist.broadcast(y_t, 0)
         y = y_t.cpu().numpy()
         x = np.ones((n, 1))
+        if covariates > 0:      # fixed-effect columns beside the intercept (principal components in a real run): standard normal
+            x = np.concatenate([x, np.random.default_rng(args.seed + 17).normal(size=(n, covariates))], axis=1)
 
         kern = {"grm_ms": 0.0, "rot_ms": 0.0, "scan_ms": 0.0, "grm_flops": 0.0, "rot_flops": 0.0, "scan_bytes": 0.0,
                 "launches": 0}
@@ -632,6 +634,18 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:   # an extra leg never takes the headline line down
                 res["extra_c3_missing1pct"] = {"error": repr(e)}
+            try:
+                # the configs[2] shape with five covariates beside the intercept (what a GWAS with principal components runs):
+                # only the scan differs -- block form of the exact per-SNP evaluation
+                leg = run_leg(20000, 200000, 0.0, 2, 1, covariates=5)
+                sm = leg_summary(leg, 20000, 2)
+                res["extra_c3_cov5"] = dict({k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
+                                                                "stages_ms_per_step")},
+                                            note="configs[2] shape, -lmm with 5 covariates beside the intercept (dim = 7)")
+                del leg
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["extra_c3_cov5"] = {"error": repr(e)}
             try:
                 leg = run_leg(50000, 500000, 0.0, 1, 1)
                 sm = leg_summary(leg, 50000, 1)

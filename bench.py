@@ -475,6 +475,7 @@ def main():
         rot_kernel = "rotate_i8_kernel" if rot_i8 else ("rotate256_kernel" if n >= 4096 else "rotate_f16x2_kernel")
         rot_peak = MFMA_I8_PEAK_TOPS if rot_i8 else MFMA_F16_PEAK_TFLOPS
         mu_rot, mu_rot_src = pmc_mfma_util(rot_kernel)
+        tr_rot, tr_rot_src = pmc_traffic_bytes("jx::" + rot_kernel)
         F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: one 2048-flop block per 64 cycles per SIMD = the f64 vector rate
         if kern.get("two_stage"):
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
@@ -556,6 +557,10 @@ def main():
             "roofline_rotate": {"bound": "mfma", "kernel": rot_kernel, "achieved": rot_tflops,
                                 "peak": rot_peak, "unit": "TFLOP/s", "frac": rot_tflops / rot_peak,
                                 "mfma_util_pmc": mu_rot, "mfma_util_source": mu_rot_src,
+                                "traffic": tr_rot, "traffic_source": tr_rot_src,
+                                "traffic_note": "HBM bytes per launch (one launch per block of <= 32768 SNP rows): FETCH_SIZE x2 + "
+                                                "WRITE_SIZE; algorithmic = the block's payload + the U planes once + 4 n bytes "
+                                                "written per row",
                                 "note": "algorithmic 2 m n^2 flops; exact design rows (allele counts, no missing call): THREE "
                                         "int8 MFMA products per algorithmic product (U in three int8 planes, exact i32 sums, "
                                         "f64 combine) against the dense int8 peak 5 POP/s -- 0.75 of the matrix-pipe cycles of "

@@ -851,9 +851,28 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     if (jxg_lut_split_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(), nullptr))
         return 1;
     const int64_t brows = 8192;
-    // fixed lambda: the rotation kernel's fused epilogue reduces the tile in place, G~ is never written (k_rotate.hip)
-    static const bool fused_env = !(getenv("JXGPU_FVLMM_FUSED") && atoi(getenv("JXGPU_FVLMM_FUSED")) == 0);
-    const bool fused = model == 1 && p <= 8 && fused_env;
+    // From n = 4096 the rows of a block are dealt to the int8 rotation (design rows without a missing call: three int8 planes
+    // of U, k_rotate_i8.hip) and the 256-tile fp16 kernel by position lists, as pipeline.scan_rows does (JXGPU_ROT_I8=0: off)
+    static const bool q_env = !(getenv("JXGPU_ROT_I8") && atoi(getenv("JXGPU_ROT_I8")) == 0);
+    const int fused_mode = getenv("JXGPU_FVLMM_FUSED") ? atoi(getenv("JXGPU_FVLMM_FUSED")) : 1;
+    const bool use_q = n >= 4096 && q_env && !(model == 1 && p <= 8 && fused_mode == 2);
+    // fixed lambda below that size: the rotation kernel's fused epilogue reduces the tile in place, G~ is never written
+    const bool fused = model == 1 && p <= 8 && fused_mode != 0 && !use_q;
+    DevBuf dq, dumax, dsel;
+    std::vector<float> hrowoff;
+    std::vector<int32_t> hsel;
+    if (use_q) {
+        if (dq.alloc((size_t)3 * (size_t)(npad * npad)) || dumax.alloc(sizeof(float) * (size_t)npad)) return 1;
+        DevBuf dut2;
+        if (dut2.alloc(sizeof(float) * (size_t)n * n)) return 1;
+        JX_HIP(hipMemcpy(dut2.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
+        if (jxg_ut_quant3(dut2.as<float>(), n, dq.as<int8_t>(), dumax.as<float>(), nullptr)) return 1;
+        JX_HIP(hipDeviceSynchronize());
+        hrowoff.resize((size_t)m);
+        JX_HIP(hipMemcpy(hrowoff.data(), drowoff.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+        if (dsel.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
+        hsel.resize((size_t)brows);
+    }
     DevBuf dsums, dachol;
     if (fused) {
         if (dsums.alloc(sizeof(double) * (size_t)num_tiles(n) * brows * (p + 2)) || dachol.alloc(sizeof(double) * (size_t)p * p))
@@ -879,6 +898,21 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                                            p + 2, 0, nullptr) ||
                 jxg_fvlmm_finish_dev(dsums.as<double>(), num_tiles(n), p + 2, rows, n, p, dachol.as<double>(), fv.sc[0], (int)fv.sc[2],
                                      has_nullml, nullml, fv.sc[1], 0, dout.as<double>(), nullptr))
+                return 1;
+        } else if (use_q) {
+            // positions of the exact rows (finite row offset) first, the others behind them
+            int ne = 0;
+            for (int i = 0; i < rows; ++i)
+                if (!std::isnan(hrowoff[(size_t)r0 + i])) hsel[ne++] = i;
+            int nx = ne;
+            for (int i = 0; i < rows; ++i)
+                if (std::isnan(hrowoff[(size_t)r0 + i])) hsel[nx++] = i;
+            JX_HIP(hipMemcpy(dsel.p, hsel.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice));
+            if (jxg_rotate_packed16x_q(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                       (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0, dusum.as<float>(),
+                                       uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, dq.as<int8_t>(), dumax.as<float>(),
+                                       ne > 0 ? dsel.as<int32_t>() : nullptr, ne, rows > ne ? dsel.as<int32_t>() + ne : nullptr,
+                                       rows - ne, drot.as<float>(), nullptr))
                 return 1;
         } else if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
                                         (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,

@@ -359,8 +359,13 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, dtype=np.float32)).to(dev)
     hi, lo, usum = model.planes()
     # int8 planes of the eigenvectors for the exact-row tiles of full-size blocks (k_rotate_i8.hip)
-    qpl = model.qplanes() if (not (mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)) and n >= 4096
-                              and os.environ.get("JXGPU_ROT_I8", "1") != "0") else None
+    # From n = 4096 the int8 / 256-tile rotation kernels write G~ and the fixed-lambda scans read it back (10 ms per 200 000
+    # SNPs at n = 20 000) instead of the fused epilogue of the 128-tile fp16 kernel: 225 vs 360 ms for the scan of `-fvlmm` at
+    # BASELINE configs[2].  JXGPU_FVLMM_FUSED=2 keeps the fused form at every size.
+    use_q = n >= 4096 and os.environ.get("JXGPU_ROT_I8", "1") != "0"
+    if mode in ("fvlmm", "splmm") and os.environ.get("JXGPU_FVLMM_FUSED", "1").strip() == "2" and _fused_fixed_lambda(model.p):
+        use_q = False
+    qpl = model.qplanes() if use_q else None
     # one-off per call: fp16 hi/lo LUT records (range-checked; rows without missing calls as integer LUT + offset, see
     # jxg_lut_split_rows) and, for the exact scan, the Chebyshev tables of the lambda-only REML sums; the block loop
     # below then only launches kernels (no allocation, no host sync).
@@ -398,7 +403,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         block_rows = 32768
     br = int(min(block_rows, mk))
     nbuf = 2 if mk > br else 1
-    fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p)
+    fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p) and qpl is None
     if qpl is not None:
         # per block: positions of the exact rows (finite row offset: int8 rotation) and of the others (fp16 rotation); a row's
         # path does not depend on the blocking, so chunked scans stay bit-identical to unchunked ones

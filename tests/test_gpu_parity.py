@@ -517,6 +517,17 @@ def test_full_size_rotation_kernels_with_mixed_rows(oracle, oracle_c, monkeypatc
     res_e = pipeline.scan_rows(p, model, rows[ex], lut[ex], mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
     assert lib().jxg_last_kernel_ms(14) == 1.0 and lib().jxg_last_kernel_ms(13) == 1.0
     assert np.array_equal(res_e, res[ex])
+    # the host C-ABI route (`jx_assoc_packed`, 8192-row blocks) deals its rows to the same two kernels: same bits
+    from janusx_amd import janusx as jxrs
+    s_h, x_h, y_h, ut_h = s_t.cpu().numpy(), model.xcov.cpu().numpy(), model.y.cpu().numpy(), model.ut.cpu().numpy()
+    out_h = jxrs.lmm_reml_assoc_packed_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows], s_h, x_h, y_h, ut_h,
+                                           low=lo_b, high=hi_b, max_iter=30, tol=1e-2)
+    assert np.array_equal(out_h, res)
+    l10 = math.log10(model.null.lbd)
+    fv_h = jxrs.fvlmm_assoc_packed_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows], s_h, x_h, y_h, ut_h, l10)
+    fv_p = pipeline.scan_rows(p, model, rows, lut, mode="fvlmm", init_log10_lbd=l10).cpu().numpy()
+    be, se, pe = _assoc_err(fv_h, fv_p)
+    assert max(be, se, pe) < 1e-9, (be, se, pe)          # same rotated rows; the two routes prepare W / Py on different sides
     # (iii) every row through the fp16 kernels
     monkeypatch.setenv("JXGPU_ROT_I8", "0")
     res_h = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()

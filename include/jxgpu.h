@@ -302,6 +302,12 @@ int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double *d_s, cons
                   const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
                   double init_log10_lbd, double nullml, double *d_out6, void *stream);
 
+/* The same scan through the reference-formulation kernel (one wave per SNP, every evaluation a pass over the n samples);
+ * jxg_lmm2_scan takes the tabulated tiled kernel whenever the lambda range and p fit its tables, this one otherwise. */
+int jxg_lmm2_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                        const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                        double init_log10_lbd, double nullml, double *d_out6, void *stream);
+
 /* Null ML for the LMM2 scan: Brent on -ml_loglike without a SNP column -> d_out2 = (log10 lambda, ml0).
  * src/stats/lmm.rs:2902-2921. */
 int jxg_lmm2_null_ml(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double low,

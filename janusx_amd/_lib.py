@@ -77,6 +77,7 @@ SIGNATURES = {
     "jxg_fvlmm_prepare": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_p, c_p, c_p, c_p],
     "jxg_fvlmm_scan": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
     "jxg_lmm2_scan": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
+    "jxg_lmm2_scan_exact": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_i, c_d, c_d, c_p, c_p],
     "jxg_lmm2_null_ml": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i, c_d, c_p, c_p],
     "jx_lmm2_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_p, c_l, c_p, c_d, c_i, c_d, c_p],
     "jx_lmm2_null_ml": [c_p, c_p, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i, c_d, c_p],

@@ -822,11 +822,11 @@ extern "C" int jxg_lmm_reml_null(const double *d_s, const double *d_xcov, const 
     return 0;
 }
 
-extern "C" int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+extern "C" int jxg_lmm2_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
                              const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
                              double init_log10_lbd, double nullml, double *d_out6, void *stream) {
     if (nrows <= 0) return 0;
-    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm2_scan: p out of range");
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm2_scan_exact: p out of range");
     if (!(low < high)) return fail("low must be < high");
     const int dim = p + 1;
     int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;

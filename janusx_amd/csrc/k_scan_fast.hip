@@ -858,7 +858,11 @@ __device__ __forceinline__ void brent_update(BrentState &b, double u, double fu)
     ++b.it;
 }
 
-template <int MAXD, int NW>
+// LMM2 = true (src/stats/lmm.rs:202-330): behind the REML search and its Wald statistics a second Brent search on -ML, seeded
+// with the REML optimum, and the likelihood-ratio test against `nullml`; out (nrows, 6) = [beta, se, pwald, lambda_reml, ml_alt,
+// plrt].  The evaluations are the same passes (an evaluation yields q and sum ln v, i.e. both objectives); the Wald results
+// wait in a per-wave LDS slot while the second search runs (phases 4 / 5).
+template <int MAXD, int NW, bool LMM2 = false>
 __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
     const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
@@ -877,7 +881,9 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
     // into scratch (58 spilled registers, 1.4 GB of scratch writes per launch at BASELINE configs[2]).  Lane 0 stores it,
     // every lane reads it back (one broadcast read per value) where the round's evaluation is folded in.
     BrentState *const bslot = reinterpret_cast<BrentState *>(scan_lds + (int64_t)tile * (2 + p) + 2) + (threadIdx.x >> 6);
-    const int out_cols = with_plrt ? 4 : 3;
+    double *const kslot = reinterpret_cast<double *>(reinterpret_cast<BrentState *>(scan_lds + (int64_t)tile * (2 + p) + 2) + 16) +
+                          4 * (threadIdx.x >> 6);       // LMM2: beta, se, pwald, lambda of the REML stage
+    const int out_cols = LMM2 ? 6 : (with_plrt ? 4 : 3);
     const int lane = threadIdx.x & 63;
     const double smin = smin_ptr[0];
     const int dim = p + 1;
@@ -951,6 +957,54 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
         ev.ainv_kk = 0.0;
         if (lbd >= 0.0) fast_eval_finish<MAXD>(x_eval, hd_r, coef_r, n_r, p, phase == 3, smin_ptr + 8, acc, ev);
         double *o = out + (int64_t)r * out_cols;
+        if (LMM2 && phase >= 4) {
+            // ---- second search: -ML (neg_ml of k_scan.hip: 1e8 on any failure), Brent seeded with the REML optimum
+            double mlneg = 1e8;
+            if (ev.ok && isfinite(ev.q) && ev.q > 0.0) {
+                const double nf = (double)n_r;
+                const double ml = nf * (jx_log(nf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0 - 0.5 * (nf * jx_log(ev.q) + ev.logdetv);
+                if (isfinite(ml)) mlneg = -ml;
+            }
+            BrentState b;
+            if (phase == 4) {
+                b.a = lo_b;
+                b.c = hi_b;
+                b.x = x_eval;
+                b.w = b.x;
+                b.v = b.x;
+                b.d = 0.0;
+                b.e = 0.0;
+                b.it = 0;
+                b.fx = mlneg;
+                b.fw = b.fx;
+                b.fv = b.fx;
+                b.evals = 1;
+            } else {
+                b = *bslot;
+                brent_update(b, x_eval, mlneg);
+            }
+            double u;
+            if (brent_propose(b, tol, max_iter, u)) {
+                phase = 5;
+                x_eval = u;
+                if (lane == 0) *bslot = b;
+                continue;
+            }
+            if (lane == 0) {
+                const double ml_alt = -b.fx;
+                double stat = isfinite(ml_alt) ? 2.0 * (ml_alt - nullml) : 0.0;
+                if (!isfinite(stat) || stat < 0.0) stat = 0.0;
+                const double plrt = chi2_sf_df1_dev(stat);
+                o[0] = kslot[0];
+                o[1] = kslot[1];
+                o[2] = kslot[2];
+                o[3] = kslot[3];
+                o[4] = ml_alt;
+                o[5] = isfinite(plrt) ? plrt : 1.0;
+            }
+            phase = 0;
+            continue;
+        }
         if (phase == 1) {
             ssq = wave_allsum(ssq);
             if (!isfinite(ssq) || ssq <= 1e-12) {
@@ -958,7 +1012,13 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                     o[0] = nan("");
                     o[1] = nan("");
                     o[2] = 1.0;
-                    if (with_plrt) o[3] = 1.0;
+                    if (LMM2) {
+                        o[3] = nan("");
+                        o[4] = nan("");
+                        o[5] = 1.0;
+                    } else if (with_plrt) {
+                        o[3] = 1.0;
+                    }
                     if (evals_out) evals_out[r] = 0;
                 }
                 phase = 0;
@@ -1004,6 +1064,31 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                 beta = ev.beta_k;
                 se = sqrt(var);
             }
+        }
+        if (LMM2) {
+            if (isfinite(beta) && isfinite(se) && se > 0.0) {
+                if (lane == 0) {
+                    double pv = 2.0 * (0.5 * jx_erfc(fabs(beta / se) / 1.4142135623730951));
+                    if (pv < 2.2250738585072014e-308) pv = 2.2250738585072014e-308;
+                    if (pv > 1.0) pv = 1.0;
+                    kslot[0] = beta;
+                    kslot[1] = se;
+                    kslot[2] = isfinite(pv) ? pv : 1.0;
+                    kslot[3] = jx_pow10(x_eval);
+                }
+                phase = 4;                                 // x_eval stays: the ML search starts at the REML optimum
+            } else {
+                if (lane == 0) {
+                    o[0] = nan("");
+                    o[1] = nan("");
+                    o[2] = 1.0;
+                    o[3] = nan("");
+                    o[4] = nan("");
+                    o[5] = 1.0;
+                }
+                phase = 0;
+            }
+            continue;
         }
         if (lane == 0) {
             if (evals_out) evals_out[r] = bslot->evals;
@@ -1130,7 +1215,8 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     const int dim = p + 1;
     // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
     const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
-    const bool use_lds = dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
+    const bool lmm2 = with_plrt == 2;               // the two-search scan (out has six columns): tiled kernel at every n
+    const bool use_lds = !lmm2 && dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
     if (use_lds) {
         g_last_ms[11] = 0.f;
         if (dim <= 2) {
@@ -1163,14 +1249,14 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         JX_LAUNCH_CHECK();
         return 0;
     }
-    if (!getenv("JXGPU_SCAN_NOTILE")) {
+    if (lmm2 || !getenv("JXGPU_SCAN_NOTILE")) {
         // n beyond the LDS-resident limit: tiles of the shared vectors in LDS, NW SNPs per workgroup in lock step
         g_last_ms[11] = 1.f;
         const int per_sample = 8 * (2 + p);
         int tile = (150 * 1024 / per_sample) / 256 * 256;
         const int ntiles = (n + tile - 1) / tile;
         tile = ((n + ntiles - 1) / ntiles + 255) / 256 * 256;
-        const size_t lds_tile = (size_t)per_sample * tile + 16 + 16 * sizeof(BrentState);   // + queue head + one Brent state per wave
+        const size_t lds_tile = (size_t)per_sample * tile + 16 + 16 * sizeof(BrentState) + 16 * 4 * sizeof(double);   // + queue head + one Brent state per wave + the LMM2 slots
         static int cus = 0;
         if (!cus) {
             int dev = 0;
@@ -1179,29 +1265,14 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             JX_HIP(hipGetDeviceProperties(&prop, dev));
             cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        if (dim <= 2) {
-            constexpr int NW = 16;
-            auto kfn = lmm_scan_tiled_kernel<2, NW>;
-            static bool attr_t2 = false;
-            if (!attr_t2) {
-                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-                attr_t2 = true;
-            }
-            int grid = cus;
-            if (grid * NW > nrows) grid = (nrows + NW - 1) / NW;
-            const int rows_per_wg = (nrows + grid - 1) / grid;
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_tile, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
-                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
-                               d_out, d_evals, tile, rows_per_wg);
-        } else {
-            // dim 3 - 4: plain evaluation tail; dim 5 - 8 and 9 - 16: block form (fast_eval_finish_blk), same tiling
-#define JX_TILED_LAUNCH(MAXDV)                                                                                            \
+        // dim 2: 16 SNPs per workgroup; dim 3 - 4: plain evaluation tail; dim 5 - 8 and 9 - 16: block form (fast_eval_finish_blk)
+#define JX_TILED_LAUNCH(MAXDV, NWV, L2)                                                                                   \
     do {                                                                                                                  \
-        constexpr int NW = 8;                                                                                             \
-        auto kfn = lmm_scan_tiled_kernel<MAXDV, NW>;                                                                      \
+        constexpr int NW = NWV;                                                                                           \
+        auto kfn = lmm_scan_tiled_kernel<MAXDV, NW, L2>;                                                                  \
         static bool attr_t = false;                                                                                       \
         if (!attr_t) {                                                                                                    \
-            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));       \
+            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 157 * 1024));       \
             attr_t = true;                                                                                                \
         }                                                                                                                 \
         int grid = cus;                                                                                                   \
@@ -1211,11 +1282,17 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
                            yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,      \
                            d_out, d_evals, tile, rows_per_wg);                                                            \
     } while (0)
-            if (dim <= 4) JX_TILED_LAUNCH(4);
-            else if (dim <= 8) JX_TILED_LAUNCH(8);
-            else JX_TILED_LAUNCH(16);
+#define JX_TILED_BY_DIM(L2)                                                                                               \
+    do {                                                                                                                  \
+        if (dim <= 2) JX_TILED_LAUNCH(2, 16, L2);                                                                         \
+        else if (dim <= 4) JX_TILED_LAUNCH(4, 8, L2);                                                                     \
+        else if (dim <= 8) JX_TILED_LAUNCH(8, 8, L2);                                                                     \
+        else JX_TILED_LAUNCH(16, 8, L2);                                                                                  \
+    } while (0)
+        if (lmm2) JX_TILED_BY_DIM(true);
+        else JX_TILED_BY_DIM(false);
+#undef JX_TILED_BY_DIM
 #undef JX_TILED_LAUNCH
-        }
         JX_LAUNCH_CHECK();
         return 0;
     }
@@ -1247,6 +1324,33 @@ extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double 
     if (!rc)
         rc = jxg_lmm_scan_tab(d_grot, nrows, n, d_s, d_xcov, p, low, high, work, tol, max_iter, warm, init_log10_lbd,
                               with_plrt, nullml, d_out, d_evals, stream);
+    (void)hipFreeAsync(work, st);
+    return rc;
+}
+
+extern "C" int jxg_lmm2_scan_exact(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                                   const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                                   double init_log10_lbd, double nullml, double *d_out, void *stream);
+
+// The LMM2 scan (src/stats/lmm.rs:202-330) through the tabulated evaluations: two Brent searches per SNP (REML, then ML
+// seeded with the REML optimum) inside the tiled kernel; configurations outside the tables go to the reference-formulation
+// kernel (jxg_lmm2_scan_exact).
+extern "C" int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                             const double *d_y, int p, double low, double high, double tol, int max_iter, int warm,
+                             double init_log10_lbd, double nullml, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm2_scan: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    if (!fast_path_ok(p, low, high) || getenv("JXGPU_LMM2_EXACT"))
+        return jxg_lmm2_scan_exact(d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high, tol, max_iter, warm, init_log10_lbd,
+                                   nullml, d_out, stream);
+    hipStream_t st = (hipStream_t)stream;
+    void *work = nullptr;
+    JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
+    int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
+    if (!rc)
+        rc = jxg_lmm_scan_tab(d_grot, nrows, n, d_s, d_xcov, p, low, high, work, tol, max_iter, warm, init_log10_lbd, 2,
+                              nullml, d_out, nullptr, stream);
     (void)hipFreeAsync(work, st);
     return rc;
 }

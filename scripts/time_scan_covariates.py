@@ -1,6 +1,7 @@
 """Exact per-SNP scan with covariates: time of the rotation + association stages for several covariate counts (the
 BASELINE shapes are intercept-only; a GWAS with principal components as covariates is not).  GPU box only.
-usage: time_scan_covariates.py [n] [m] [q1 q2 ...]   (q = covariates beside the intercept; default 0 2 5 10)"""
+usage: time_scan_covariates.py [n] [m] [q1 q2 ...]   (q = covariates beside the intercept; default 0 2 5 10)
+JX_SCAN_MODE=lmm|lmm2|fvlmm selects the scan (default lmm)."""
 import os
 import sys
 import time
@@ -37,7 +38,9 @@ def main():
             tm = pl.StageTimes()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = pl.scan_rows(panel, model, rows, lut, mode="lmm", low=lo, high=hi, max_iter=30, tol=1e-2, times=tm)
+            mode = os.environ.get("JX_SCAN_MODE", "lmm")
+            kw = {"nullml": model.null.ml0} if mode == "lmm2" else {}
+            out = pl.scan_rows(panel, model, rows, lut, mode=mode, low=lo, high=hi, max_iter=30, tol=1e-2, times=tm, **kw)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         form = {0.0: "lds-resident", 1.0: "tiled", 2.0: "one wave per SNP (global)"}.get(float(lib().jxg_last_kernel_ms(11)), "?")

@@ -468,6 +468,14 @@ int jx_lm_residualize(const double *y, const double *x, const double *ixx, int n
 int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const float *d_lut,
                     const double *d_xr, int q0, const double *d_ixx, double yy_r, double *d_work, double *d_out,
                     void *stream);
+/* `lm_block_assoc_f32` (src/stats/glm.rs:4313-4497): the same LM formulas on an already decoded SNP-major f32 block
+ * g (m, n) on the host; out (m, 4).  Row rules of that entry point (s must exceed 1e-12; a non-finite variance or standard
+ * error voids the row, glm.rs:4457-4479). */
+int jx_lm_assoc_dense(const double *y, const double *x, const double *ixx, int q0, const float *g, int64_t m, int n,
+                      double *out);
+/* Device half for dense rows: d_g (nrows, ld >= n) f32 on the device, the other arguments as jxg_lm_scan_p32. */
+int jxg_lm_scan_dense(const float *d_g, int nrows, int n, int64_t ld, const double *d_xr, int q0, const double *d_ixx,
+                      double yy_r, double *d_work, double *d_out, void *stream);
 
 /* SparseLMM approximate (GRAMMAR-gamma) scan = `grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316; the
  * scan of `scan_with_py_and_rhat`, :3318-3363, behind `splmm_assoc_pcg_bed[_to_tsv]` in scan_mode "approx", :4641, 4814):

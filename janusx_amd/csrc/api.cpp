@@ -1026,6 +1026,31 @@ extern "C" int jx_lm_assoc_packed(const double *y, const double *x, const double
     return 0;
 }
 
+// `lm_block_assoc_f32` (src/stats/glm.rs:4313-4497): dense SNP-major f32 rows on the host, blocks staged to the device.
+extern "C" int jx_lm_assoc_dense(const double *y, const double *x, const double *ixx, int q0, const float *g, int64_t m, int n,
+                                 double *out) {
+    if (m <= 0) return 0;
+    std::vector<double> xr((size_t)n * (q0 + 1));
+    double yy_r = 0.0;
+    if (jx_lm_residualize(y, x, ixx, n, q0, xr.data(), &yy_r)) return 1;
+    DevBuf dxr, dixx, dwork, dout, dg;
+    if (dxr.alloc(xr.size() * sizeof(double)) || dixx.alloc(sizeof(double) * (size_t)std::max(q0 * q0, 1))) return 1;
+    JX_HIP(hipMemcpy(dxr.p, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (q0 > 0) JX_HIP(hipMemcpy(dixx.p, ixx, sizeof(double) * (size_t)q0 * q0, hipMemcpyHostToDevice));
+    const int64_t brows = std::max<int64_t>(1, std::min<int64_t>(m, ((int64_t)1 << 30) / ((int64_t)n * 4)));   // <= 1 GiB of rows
+    if (dg.alloc(sizeof(float) * (size_t)brows * n) || dwork.alloc(sizeof(double) * (size_t)brows * (q0 + 2)) ||
+        dout.alloc(sizeof(double) * (size_t)brows * 4))
+        return 1;
+    for (int64_t r0 = 0; r0 < m; r0 += brows) {
+        const int rows = (int)std::min<int64_t>(brows, m - r0);
+        JX_HIP(hipMemcpy(dg.p, g + (size_t)r0 * n, sizeof(float) * (size_t)rows * n, hipMemcpyHostToDevice));
+        if (jxg_lm_scan_dense(dg.as<float>(), rows, n, n, dxr.as<double>(), q0, dixx.as<double>(), yy_r, dwork.as<double>(),
+                              dout.as<double>(), nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)r0 * 4, dout.p, sizeof(double) * (size_t)rows * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
 
 // ---- association TSV writer (host) ------------------------------------------------------------------------------------
 // Native counterpart of the reference's row formatter + writer (src/io/assoc2tsv.rs:430-548, `AsyncTsvWriter`

@@ -79,6 +79,51 @@ __global__ __launch_bounds__(LM_THREADS) void lm_dots_kernel(const uint8_t *__re
     if (dsum) dsum[r] = dd;
 }
 
+// Dense rows (`lm_block_assoc_f32`, src/stats/glm.rs:4313-4497: an already decoded SNP-major f32 block): one wave per LM_DR
+// rows, lanes over the samples (coalesced row reads), the columns of [X | r_y] read once per sample and lane for the LM_DR rows.
+constexpr int LM_DR = 4;
+template <int NC>
+__global__ __launch_bounds__(256) void lm_dots_dense_kernel(const float *__restrict__ g, int64_t ld, int nrows,
+                                                            const double *__restrict__ xr, int ldx, int c0, int n,
+                                                            double *__restrict__ sums, int lds, double *__restrict__ dsum) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LM_DR;
+    if (r0 >= nrows) return;
+    double acc[LM_DR][NC], dd[LM_DR];
+#pragma unroll
+    for (int j = 0; j < LM_DR; ++j) {
+        dd[j] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[j][c] = 0.0;
+    }
+    for (int i = lane; i < n; i += 64) {
+        double xv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xv[c] = xr[(int64_t)i * ldx + c0 + c];
+#pragma unroll
+        for (int j = 0; j < LM_DR; ++j) {
+            const double v = (r0 + j < nrows) ? (double)g[(int64_t)(r0 + j) * ld + i] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[j][c] = fma(v, xv[c], acc[j][c]);
+            dd[j] = fma(v, v, dd[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LM_DR; ++j) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            dd[j] += __shfl_xor(dd[j], o);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[j][c] += __shfl_xor(acc[j][c], o);
+        }
+        if (lane == 0 && r0 + j < nrows) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sums[(int64_t)(r0 + j) * lds + c0 + c] = acc[j][c];
+            if (dsum) dsum[r0 + j] = dd[j];
+        }
+    }
+}
+
 // ---- p-values (glm.rs:383-500) ------------------------------------------------------------------------------------
 __device__ double lm_betacf(double a, double b, double x) {
     const int maxit = 200;
@@ -145,7 +190,7 @@ __device__ double lm_chi2_sf_df1(double stat) {
 __global__ __launch_bounds__(256) void lm_stats_kernel(const double *__restrict__ sums, int lds,
                                                        const double *__restrict__ dsum, int nrows, int q0,
                                                        const double *__restrict__ ixx, double yy_r, int n_obs, int df,
-                                                       double ln_beta, double *__restrict__ out) {
+                                                       double ln_beta, double *__restrict__ out, int dense_rules) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nrows) return;
     const double *u = sums + (int64_t)r * lds;
@@ -158,17 +203,23 @@ __global__ __launch_bounds__(256) void lm_stats_kernel(const double *__restrict_
     const double s = dsum[r] - corr;
     const double a = u[q0];
     double beta = NAN, se = NAN, pw = NAN, pl = NAN;
-    if (!(s < 1e-12) && isfinite(s)) {
+    // dense_rules: the row conditions of the dense-block entry point (glm.rs:4457-4479: s must exceed 1e-12, a non-finite
+    // variance or standard error voids the row) instead of those of the packed one (glm.rs:3790-3830)
+    if (dense_rules ? (isfinite(s) && s > 1e-12) : (!(s < 1e-12) && isfinite(s))) {
         beta = a / s;
         const double rss = fmax(yy_r - beta * a, 0.0);
         const double ve = rss / (double)df;
-        if (ve > 0.0) {
+        if (dense_rules ? (isfinite(ve) && ve > 0.0) : (ve > 0.0)) {
             se = sqrt(ve / s);
-            const double t = beta / se;
-            const double t2 = t * t;
-            pw = lm_student_t_two_sided(t, df, ln_beta);
-            pl = (df <= 0 || !isfinite(t2) || t2 < 0.0) ? NAN
-                                                         : lm_chi2_sf_df1((double)n_obs * log(1.0 + t2 / (double)df));
+            if (dense_rules && !(isfinite(beta) && isfinite(se) && se > 0.0)) {
+                beta = se = NAN;
+            } else {
+                const double t = beta / se;
+                const double t2 = t * t;
+                pw = lm_student_t_two_sided(t, df, ln_beta);
+                pl = (df <= 0 || !isfinite(t2) || t2 < 0.0) ? NAN
+                                                             : lm_chi2_sf_df1((double)n_obs * log(1.0 + t2 / (double)df));
+            }
         }
     }
     double *o = out + (int64_t)r * 4;
@@ -286,7 +337,37 @@ extern "C" int jxg_lm_scan_p32(const uint8_t *d_p32, int64_t m_total, int n, con
     const int df = n - q0 - 1;
     const double ln_beta = lgamma(0.5 * df) + lgamma(0.5) - lgamma(0.5 * df + 0.5);
     hipLaunchKernelGGL(lm_stats_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, sums, ncols, dsum, nrows, q0, d_ixx,
-                       yy_r, n, df, ln_beta, d_out);
+                       yy_r, n, df, ln_beta, d_out, 0);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// LM scan of a dense SNP-major f32 block on the device: d_g (nrows, ld >= n); the other arguments as jxg_lm_scan_p32.
+// `lm_block_assoc_f32`, src/stats/glm.rs:4313-4497.
+extern "C" int jxg_lm_scan_dense(const float *d_g, int nrows, int n, int64_t ld, const double *d_xr, int q0,
+                                 const double *d_ixx, double yy_r, double *d_work, double *d_out, void *stream) {
+    if (nrows <= 0) return 0;
+    if (q0 < 0 || n <= q0 + 1) return fail("n too small: require n > q0+1");
+    if (ld < n) return fail("jxg_lm_scan_dense: ld must be >= n");
+    hipStream_t st = (hipStream_t)stream;
+    const int ncols = q0 + 1;
+    double *sums = d_work, *dsum = d_work + (size_t)nrows * ncols;
+    const dim3 grid((nrows + 4 * LM_DR - 1) / (4 * LM_DR)), block(256);
+    for (int c0 = 0; c0 < ncols; c0 += LM_MAXC) {
+        const int nc = std::min(LM_MAXC, ncols - c0);
+        double *dd = c0 == 0 ? dsum : nullptr;
+        switch (nc) {
+        case 1: hipLaunchKernelGGL(lm_dots_dense_kernel<1>, grid, block, 0, st, d_g, ld, nrows, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        case 2: hipLaunchKernelGGL(lm_dots_dense_kernel<2>, grid, block, 0, st, d_g, ld, nrows, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        case 3: hipLaunchKernelGGL(lm_dots_dense_kernel<3>, grid, block, 0, st, d_g, ld, nrows, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        default: hipLaunchKernelGGL(lm_dots_dense_kernel<4>, grid, block, 0, st, d_g, ld, nrows, d_xr, ncols, c0, n, sums, ncols, dd); break;
+        }
+        JX_LAUNCH_CHECK();
+    }
+    const int df = n - q0 - 1;
+    const double ln_beta = lgamma(0.5 * df) + lgamma(0.5) - lgamma(0.5 * df + 0.5);
+    hipLaunchKernelGGL(lm_stats_kernel, dim3((nrows + 255) / 256), dim3(256), 0, st, sums, ncols, dsum, nrows, q0, d_ixx,
+                       yy_r, n, df, ln_beta, d_out, 1);
     JX_LAUNCH_CHECK();
     return 0;
 }

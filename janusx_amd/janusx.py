@@ -286,17 +286,10 @@ def _write_spgrm(path, n, col_ptr, rows, vals):
     os.replace(tmp, path)
 
 
-def spgrm_dense_npy_to_jxgrm(npy_path, out_prefix, threshold=0.05, abs_threshold=False, progress_callback=None,
-                             progress_every=0):
-    """src/stats/spgrm.rs:5972-6003 -> `spgrm_dense_npy_to_jxgrm_core` :5103-5199 / `spgrm_dense_f32_to_jxgrm_core`
-    :5027-5101: an existing dense GRM (`.npy`, f32 or f64, square) thresholded into `<out_prefix>.spgrm` — lower triangle
-    of the stored matrix, values widened to f64, same keep rule, (col, row) order.  The matrix goes to HBM once and the
-    count / fill kernels of the sparse GRM build compact it (bit-exact: no arithmetic besides the widening).
-    -> (path, n_samples, nnz)."""
+def _spgrm_dense_to_jxgrm(k, out_prefix, threshold, abs_threshold, progress_callback):
     import math
     import torch
     from . import pipeline as pl
-    k = np.load(npy_path, mmap_mode="r")
     if k.ndim != 2 or k.shape[0] != k.shape[1]:
         raise RuntimeError(f"Sparse GRM dense writer expects a square matrix, got shape {tuple(k.shape)}")
     if k.dtype not in (np.float32, np.float64):
@@ -328,6 +321,67 @@ def spgrm_dense_npy_to_jxgrm(npy_path, out_prefix, threshold=0.05, abs_threshold
     if progress_callback is not None:
         progress_callback(n, n)
     return out_path, n, nnz
+
+
+def spgrm_dense_npy_to_jxgrm(npy_path, out_prefix, threshold=0.05, abs_threshold=False, progress_callback=None,
+                             progress_every=0):
+    """src/stats/spgrm.rs:5972-6003 -> `spgrm_dense_npy_to_jxgrm_core` :5103-5199 / `spgrm_dense_f32_to_jxgrm_core`
+    :5027-5101: an existing dense GRM (`.npy`, f32 or f64, square) thresholded into `<out_prefix>.spgrm` — lower triangle
+    of the stored matrix, values widened to f64, same keep rule, (col, row) order.  The matrix goes to HBM once and the
+    count / fill kernels of the sparse GRM build compact it (bit-exact: no arithmetic besides the widening).
+    -> (path, n_samples, nnz)."""
+    return _spgrm_dense_to_jxgrm(np.load(npy_path, mmap_mode="r"), out_prefix, threshold, abs_threshold, progress_callback)
+
+
+def spgrm_dense_f32_to_jxgrm(grm, out_prefix, threshold=0.05, abs_threshold=False, progress_callback=None,
+                             progress_every=0):
+    """src/stats/spgrm.rs:5924-5970 (core :5027-5101): an in-memory dense f32 GRM thresholded into `<out_prefix>.spgrm`
+    (the `SparseLMM` API of python/janusx/assoc/api.py:769-780) -> (path, n_samples, nnz)."""
+    grm = np.asarray(grm)
+    if grm.ndim != 2:
+        raise RuntimeError("grm must be 2D (n, n).")
+    if grm.shape[0] != grm.shape[1]:
+        raise RuntimeError(f"grm must be square, got shape=({grm.shape[0]}, {grm.shape[1]})")
+    return _spgrm_dense_to_jxgrm(_c(grm, np.float32), out_prefix, threshold, abs_threshold, progress_callback)
+
+
+def spgrm_bed_to_jxgrm_from_meta(prefix, row_source_indices, row_flip, row_maf, n_total_sites, out_prefix=None,
+                                 sample_indices=None, method=1, threshold=0.05, abs_threshold=False, block_rows=0,
+                                 sample_block=0, threads=0, mmap_window_mb=None, progress_callback=None, progress_every=0):
+    """src/stats/spgrm.rs:5377-5500: the stream core of `spgrm_bed_to_jxgrm` (:3910-4264) on rows, flips and allele
+    frequencies the caller prepared (`jx grm -sparse` after its own QC pass, python/janusx/script/grm.py:1771)
+    -> (path, n_samples_used, nnz)."""
+    import torch
+    from .bed import stage_bed_payload
+    bed_prefix = _bed_prefix(prefix)
+    if int(n_total_sites) <= 0:
+        raise RuntimeError("n_total_sites must be positive for sparse GRM meta route.")
+    src = _c(row_source_indices, np.int64).ravel()
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if src.size == 0:
+        raise RuntimeError("row_source_indices must not be empty")
+    if (src < 0).any():
+        raise RuntimeError(f"row_source_indices must be non-negative, got {int(src[src < 0][0])}")
+    if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
+        raise RuntimeError(f"row meta length mismatch: row_source_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    if int(src.max()) >= int(n_total_sites):
+        raise RuntimeError(f"row_source index out of range: {int(src[src >= int(n_total_sites)][0])} >= "
+                           f"n_total_sites={int(n_total_sites)}")
+    packed, n_fam, _bim = stage_bed_payload(bed_prefix, mmap_window_mb)
+    if n_fam == 0:
+        raise RuntimeError("No samples found in BED input.")
+    if int(src.max()) >= int(packed.shape[0]):
+        raise RuntimeError(f"row_source index out of range for the BED payload: {int(src.max())} >= {int(packed.shape[0])}")
+    idx, n_sel = _opt_idx(sample_indices)
+    pk = packed[torch.from_numpy(src).to(packed.device)]
+    del packed
+    out = _spgrm_packed(pk, n_fam, flip, maf, out_prefix if out_prefix is not None else bed_prefix,
+                        idx if (idx is not None and n_sel) else None, method, threshold, abs_threshold, True)
+    if progress_callback is not None:
+        progress_callback(1, 1)
+    return out
 
 
 def load_spgrm(path):
@@ -913,6 +967,72 @@ def spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(jxgrm_path, y_resid, vp_fixe
     return _spreml_brent(model, low, high, grid_size, tol, max_iter, float(vp_fixed), progress_callback)
 
 
+def _splmm_exact_null_state(model, lam):
+    """Null state of the exact scan on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`,
+    src/stats/splmm.rs:3500-3660): W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976),
+    Py~ = W (y~ - X~ b), yPy -> (w, Py~, WX~ as f32 device tensors, chol(A), yPy)."""
+    import torch
+    dev = model.s_dev.device
+    d = model.s + lam
+    wxh = model.xr / d[:, None]
+    a_chol = _spd_cholesky_with_jitter(model.xr.T @ wxh, "SparseLMM XtWX")
+    b0 = np.linalg.solve(a_chol.T, np.linalg.solve(a_chol, wxh.T @ model.yr))
+    pyh = (model.yr - model.xr @ b0) / d
+    ypy = float(model.yr @ pyh)
+    if not (np.isfinite(ypy) and ypy > 0.0):
+        raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)   # noqa: E731
+    return f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy
+
+
+def splmm_assoc_pcg_dense_f32(g, y, lbd, sparse_jxgrm_path, x_cov=None, sparse_sample_indices=None, threads=0, block_rows=0):
+    """src/stats/splmm.rs:5464-5650: SparseLMM exact scan of an already decoded SNP-major f32 matrix `g` (m, n) at a GIVEN
+    lambda against the sparse GRM file (the `SparseLMM.gwas` API of python/janusx/assoc/api.py:898-940): null state of
+    `build_sparse_splmm_null_state`, then `exact_scan_blocks_core` with the rows taken as they are (no flip, no imputation)
+    -> f64 (m, 3) = beta, se, p.  V = K + lambda I through the eigenbasis of the sparse K (one dense or block-diagonal
+    decomposition, cached per GRM): rows rotated on the device, g'V^-1 g / X'V^-1 g / g.Py as weighted sums."""
+    import torch
+    from . import pipeline as pl
+    lbd = float(lbd)
+    if not (np.isfinite(lbd) and lbd >= 0.0):
+        raise RuntimeError("lbd must be finite and >= 0")
+    g = np.asarray(g)
+    if g.ndim != 2:
+        raise RuntimeError("g must be 2D SNP-major (m, n)")
+    m, n = int(g.shape[0]), int(g.shape[1])
+    if m == 0 or n == 0:
+        raise RuntimeError("g must have positive shape (m > 0, n > 0)")
+    g = _c(g, np.float32)
+    y = _c(y, np.float64).ravel()
+    if y.shape[0] != n:
+        raise RuntimeError(f"Dense SparseLMM requires len(y) to equal g.shape[1], got len(y)={y.shape[0]} and n={n}")
+    p = 1
+    if x_cov is not None:
+        xc = _c(x_cov, np.float64)
+        if xc.ndim != 2:
+            raise RuntimeError("x_cov must be 2D (n, p_cov)")
+        if xc.shape[0] != n:
+            raise RuntimeError(f"x_cov row count mismatch: got {xc.shape[0]}, expected {n}")
+        p += int(xc.shape[1])
+    if n <= p:
+        raise RuntimeError(f"Dense SparseLMM requires n > p, got n={n}, p={p}")
+    if sparse_sample_indices is not None and len(np.asarray(sparse_sample_indices).ravel()) != n:
+        raise RuntimeError("Dense SparseLMM scan requires factor subset n to match g/y n; "
+                           f"factor_n={len(np.asarray(sparse_sample_indices).ravel())}, y_n={n}")
+    model = _SpectralSparseReml(sparse_jxgrm_path, y, x_cov, sparse_sample_indices)
+    if not model.factorizable(lbd):
+        raise RuntimeError(f"K + lambda I is not positive definite at lambda={lbd}")
+    fv_state = _splmm_exact_null_state(model, lbd)
+    dev = model.s_dev.device
+    if model.blocks is not None:
+        parts = [(off, nb, ut64.to(torch.float32), torch.from_numpy(np.ascontiguousarray(model.perm[off:off + nb])).to(dev))
+                 for off, nb, ut64 in model.blocks]
+    else:
+        parts = [(0, n, model.ut_dev.to(torch.float32), None)]
+    out = pl.scan_rows_splmm_dense(g, parts, n, model.p, fv_state, dev, int(block_rows) if int(block_rows) > 0 else 8192)
+    return out.cpu().numpy()
+
+
 def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, row_flip, x_cov=None,
                                 sample_indices=None, row_indices=None, log10_lambda=None, low=-5.0, high=5.0,
                                 grid_size=9, tol=1e-3, max_iter=20, grm_sample_indices=None):
@@ -957,18 +1077,7 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 2] = 1.0
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
     dev = model.s_dev.device
-    # null state on the K + lambda I scale from the f64 spectrum (`build_sparse_splmm_null_state`, splmm.rs:3500-3660):
-    # W = 1 / (s + lambda), A = X~'WX~ (jittered only if it fails, :1947-1976), Py~ = W (y~ - X~ b), yPy
-    d = model.s + lam
-    wxh = model.xr / d[:, None]
-    a_chol = _spd_cholesky_with_jitter(model.xr.T @ wxh, "SparseLMM XtWX")
-    b0 = np.linalg.solve(a_chol.T, np.linalg.solve(a_chol, wxh.T @ model.yr))
-    pyh = (model.yr - model.xr @ b0) / d
-    ypy = float(model.yr @ pyh)
-    if not (np.isfinite(ypy) and ypy > 0.0):
-        raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
-    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)   # noqa: E731
-    fv_state = (f32(1.0 / d), f32(pyh), f32(wxh), a_chol, ypy)
+    fv_state = _splmm_exact_null_state(model, lam)
     if _is_device_tensor(pk):
         packed_t = pk.to(dev)
     else:   # torch.from_numpy wants a writable array (memmapped payloads are not)
@@ -1373,7 +1482,7 @@ def splmm_assoc_pcg_bed_to_tsv(prefix, y, lbd, chrom, pos, snp, allele0, allele1
     elif not (len(chrom) == len(pos) == len(snp) == len(allele0) == len(allele1) == m):
         raise RuntimeError(f"SparseLMM TSV metadata length mismatch: rows={m}")
     t2 = time.perf_counter()
-    written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, inp["maf"], inp["miss"], out)
+    written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, inp["maf"], inp["miss"], out, resolve=False)
     t3 = time.perf_counter()
     return (r_hat, True, 1, 0.0, True, 1, 0.0, req, used, int(written), (0.0, t2 - t1, t1 - t0, t3 - t2))
 
@@ -1476,6 +1585,55 @@ def grm_stream_bed_f32_to_npy(prefix, out_path, method=1, maf_threshold=0.02, ma
 # eigh  (src/math/eigh.rs)
 # ------------------------------------------------------------------------------------------------
 
+def grm_bed_f64_from_meta(prefix, row_indices, row_flip, row_maf, sample_indices=None, method=1, block_cols=65536,
+                          threads=0, progress_callback=None, progress_every=0, mmap_window_mb=None):
+    """src/stats/grm.rs:3639-3753 -> `build_grm_from_meta_stream` (src/stats/gblup.rs:406-652): the GRM of the BED rows
+    `row_indices` over `sample_indices` with the caller's flip / allele-frequency metadata (`jx grm` after its own QC,
+    python/janusx/script/grm.py:1365; `jx gs`, python/janusx/gs/workflow.py:4139) -> f64 (n, n).  method 1: centred
+    additive, scaled by 1 / sum(2p(1-p)); method 2: standardised additive, scaled by 1 / m; 3 (dominance) is not built."""
+    import torch
+    from .bed import stage_bed_payload
+    if int(method) not in (1, 2, 3):
+        raise RuntimeError(f"unsupported method={method}; expected 1 (centered additive), 2 (standardized additive), or 3 "
+                           "(centered dominance)")
+    if int(method) == 3:
+        raise RuntimeError("method=3 (centered dominance) is outside this build's scope (additive GRMs only)")
+    packed, n_fam, _bim = stage_bed_payload(_bed_prefix(prefix), mmap_window_mb)
+    if n_fam == 0:
+        raise RuntimeError("no samples found in PLINK input")
+    src = _c(row_indices, np.int64).ravel()
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if src.size == 0:
+        raise RuntimeError("row_indices must not be empty")
+    if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
+        raise RuntimeError(f"row meta length mismatch: row_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    if (src < 0).any():
+        raise RuntimeError(f"row index must be non-negative, got {int(src[src < 0][0])}")
+    if int(src.max()) >= int(packed.shape[0]):
+        raise RuntimeError("row index out of range")
+    if sample_indices is None:
+        tr = np.arange(n_fam, dtype=np.int64)
+    else:
+        tr = _c(sample_indices, np.int64).ravel()
+        if tr.size == 0:
+            raise RuntimeError("sample_indices must not be empty")
+        if tr.min() < 0 or tr.max() >= n_fam:
+            raise RuntimeError("sample_indices out of range")
+    rows_payload = packed[torch.from_numpy(src).to(packed.device)]
+    del packed
+    if int(method) == 1:
+        k, _var_sum, _panel, _row_mean = _gblup_meta_grm(rows_payload, n_fam, tr, flip, maf)
+        out = k.cpu().numpy()
+    else:
+        out = grm_packed_f64(rows_payload.cpu().numpy(), n_fam, flip, maf, None if sample_indices is None else tr, 2,
+                             block_cols, threads)
+    if progress_callback is not None:
+        progress_callback(int(src.shape[0]), int(src.shape[0]))
+    return np.ascontiguousarray(out, dtype=np.float64)
+
+
 def rust_eigh_from_array_f64(a, threads=0, driver=None, jobz="V", require_lapack=False, diag_shift=0.0):
     """src/math/eigh.rs:1621-1703 -> 10-tuple (evals asc, evecs (columns) or None, blas_backend, evd_backend,
     n, threads_before, threads_in_stage, threads_after, lapack_used, elapsed_s)."""
@@ -1556,6 +1714,25 @@ def lmm_rotate_x_y_with_ut_f64(u_t, x, y, threads=0):
     oy = np.empty((n, 1), dtype=np.float64)
     check(lib().jx_lmm_rotate_x_y_with_ut_f64(_p(u_t), n, _p(x), q, _p(y), _p(ox), _p(oy)))
     return ox, oy
+
+
+def lmm_rotate_y_with_ut_f64(u_t, y, threads=0):
+    """src/stats/reml.rs:200-250 -> y_rot f64 (n): row i = <u_t[i, :], y> in f64 (what `workflow_model_packed.py:6309` calls
+    per trait once X has been rotated)."""
+    y = _c(y, np.float64).ravel()
+    n = int(y.shape[0])
+    if n == 0:
+        raise RuntimeError("y must not be empty")
+    u_t = _c(u_t, np.float32)
+    if u_t.ndim != 2:
+        raise RuntimeError("u_t must be 2D (n, n)")
+    if u_t.shape != (n, n):
+        raise RuntimeError("u_t must be shape (n, n) and row-major U^T")
+    x = np.zeros((n, 1), dtype=np.float64)
+    ox = np.empty((n, 1), dtype=np.float64)
+    oy = np.empty((n, 1), dtype=np.float64)
+    check(lib().jx_lmm_rotate_x_y_with_ut_f64(_p(u_t), n, _p(x), 1, _p(y), _p(ox), _p(oy)))
+    return oy.ravel()
 
 
 def _null_args(s, xcov, y_rot):
@@ -1719,6 +1896,115 @@ def fvlmm_assoc_chunk_from_snp_f32(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, th
                                    rotate_block_rows=512):
     """src/stats/fvlmm.rs:2114-2262 -> f64 (m, 3)."""
     return _fv_chunk(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, nullml, "snp_chunk")
+
+
+def _fixed_lambda_checks(s, xcov, y_rot, log10_lbd):
+    """Argument checks shared by the fixed-lambda entry points (src/stats/lmm.rs:2025-2066, src/stats/fvlmm.rs:1816-1836)."""
+    s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
+    if n <= p + 1:
+        raise RuntimeError("n must be > p_cov+1")
+    with np.errstate(over="ignore", under="ignore"):
+        lbd = float(np.float64(10.0) ** np.float64(log10_lbd))     # powf semantics: inf / 0 instead of an exception
+    if not (np.isfinite(lbd) and lbd > 0.0):
+        raise RuntimeError("invalid log10_lbd")
+    if np.any(s_ + lbd <= 0.0):
+        raise RuntimeError("non-positive s[i]+lbd")
+    return n, p
+
+
+def lmm_assoc_chunk_f32(s, xcov, y_rot, log10_lbd, g_rot_chunk, threads=0, nullml=None):
+    """src/stats/lmm.rs:2010-2224: Wald statistics of already rotated rows at ONE given lambda (the `lmm_assoc` wrapper of
+    python/janusx/pyBLUP/assoc.py:1305-1345) -> f64 (m, 3 or 4).  The same sums as the fixed-lambda scan of `-fvlmm`
+    (c = X'Wg, d = g'Wg, e = g'Wy with W = 1 / (s + lambda) held in f32); a row whose Schur complement is <= 1e-12 is
+    (NaN, NaN, NaN) and its plrt entry keeps the 0.0 the output was allocated with (:2155-2160)."""
+    _fixed_lambda_checks(s, xcov, y_rot, log10_lbd)
+    out = _fv_chunk(s, xcov, y_rot, log10_lbd, g_rot_chunk, None, nullml, "g_rot_chunk")
+    if nullml is not None:
+        out[np.isnan(out[:, 2]), 3] = 0.0
+    return out
+
+
+def lmm_assoc_chunk_from_snp_f32(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, threads=0, nullml=None,
+                                 rotate_block_rows=512):
+    """src/stats/lmm.rs:2226-2486: `lmm_assoc_chunk_f32` behind the rotation of raw SNP rows -> f64 (m, 3 or 4)."""
+    _fixed_lambda_checks(s, xcov, y_rot, log10_lbd)
+    out = _fv_chunk(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, nullml, "snp_chunk")
+    if nullml is not None:
+        out[np.isnan(out[:, 2]), 3] = 0.0
+    return out
+
+
+class FvLmmAssocCache:
+    """`FvLmmAssocCache` (src/stats/fvlmm.rs:1808-1849): the lambda-only state of the fixed-lambda scan (W, P y, W X, the
+    Cholesky factor of X'WX, y'Py, df, log det V) prepared once per trait.  Here the handle keeps the host inputs; the
+    device state is rebuilt per call by one small kernel (`jxg_fvlmm_prepare`)."""
+
+    def __init__(self, s, xcov, y_rot, log10_lbd):
+        self.n, self.p = _fixed_lambda_checks(s, xcov, y_rot, log10_lbd)
+        self.s, self.xcov, self.y_rot = (np.array(_c(a, np.float64), copy=True) for a in (s, xcov, y_rot))
+        self.log10_lbd = float(log10_lbd)
+        self.lbd = float(np.float64(10.0) ** np.float64(self.log10_lbd))
+
+
+def fvlmm_assoc_prepare_cache_f32(s, xcov, y_rot, log10_lbd):
+    """src/stats/fvlmm.rs:1808-1849 -> cache handle for `fvlmm_assoc_chunk_with_cache_f32`."""
+    return FvLmmAssocCache(s, xcov, y_rot, log10_lbd)
+
+
+def fvlmm_assoc_chunk_with_cache_f32(cache, g_rot_chunk, threads=0, nullml=None):
+    """src/stats/fvlmm.rs:1920-1939 -> f64 (m, 3 or 4) for already rotated rows."""
+    if not isinstance(cache, FvLmmAssocCache):
+        raise TypeError("cache must come from fvlmm_assoc_prepare_cache_f32")
+    return _fv_chunk(cache.s, cache.xcov, cache.y_rot, cache.log10_lbd, g_rot_chunk, None, nullml, "g_rot_chunk")
+
+
+def fvlmm_assoc_chunk_from_snp_with_cache_f32(cache, snp_chunk, u_t, threads=0, nullml=None, rotate_block_rows=512):
+    """src/stats/fvlmm.rs:1997-2112 -> f64 (m, 3 or 4) for raw SNP rows (rotation + scan)."""
+    if not isinstance(cache, FvLmmAssocCache):
+        raise TypeError("cache must come from fvlmm_assoc_prepare_cache_f32")
+    return _fv_chunk(cache.s, cache.xcov, cache.y_rot, cache.log10_lbd, snp_chunk, u_t, nullml, "snp_chunk")
+
+
+def fvlmm_assoc_chunk_from_snp_to_tsv_f32(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, chrom, pos, snp, allele0, allele1, maf,
+                                          miss, threads=0, nullml=None, rotate_block_rows=512, progress_callback=None,
+                                          progress_every=0):
+    """src/stats/fvlmm.rs:2266-2480: rotation + fixed-lambda scan of a dense SNP chunk, the result rows already formatted
+    -> (list of byte blocks of `rotate_block_rows` TSV rows each, no header; rows).  The streaming `-fvlmm` workflow writes
+    the blocks to its result file (python/janusx/assoc/workflow_model_stream.py:1678)."""
+    import tempfile
+    from .tsv import _native_rows
+    n, _p_cov = _fixed_lambda_checks(s, xcov, y_rot, log10_lbd)
+    g = _c(snp_chunk, np.float32)
+    if g.ndim != 2 or g.shape[1] != n:
+        raise RuntimeError("snp_chunk must be (m, n)")
+    m = int(g.shape[0])
+    if m == 0:
+        return [], 0
+    if not all(len(a) == m for a in (chrom, pos, snp, allele0, allele1, maf, miss)):
+        raise RuntimeError("TSV metadata length mismatch with snp_chunk rows")
+    stats = _fv_chunk(s, xcov, y_rot, log10_lbd, g, u_t, nullml, "snp_chunk")
+    br = max(int(rotate_block_rows), 1)
+    blocks = []
+    fd, tmp = tempfile.mkstemp(prefix="jx_fvlmm_chunk_", suffix=".tsv")
+    os.close(fd)
+    try:
+        for r0 in range(0, m, br):
+            r1 = min(r0 + br, m)
+            open(tmp, "wb").close()
+            _native_rows(tmp, chrom[r0:r1], pos[r0:r1], snp[r0:r1], allele0[r0:r1], allele1[r0:r1], maf[r0:r1],
+                         miss[r0:r1], stats[r0:r1], True, False, False)
+            with open(tmp, "rb") as fh:
+                blocks.append(fh.read())
+            if progress_callback is not None and progress_every:
+                progress_callback(r1, m)
+    finally:
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
+    if progress_callback is not None:
+        progress_callback(m, m)
+    return blocks, m
 
 
 def fvlmm_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, log10_lbd,
@@ -1928,7 +2214,7 @@ def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_m
         allele0 = [bim.a0[j] for j in sel]
         allele1 = [bim.a1[j] for j in sel]
     written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
-                              np.asarray(row_missing, dtype=np.float32), out)
+                              np.asarray(row_missing, dtype=np.float32), out, resolve=False)
     return written
 
 
@@ -2040,7 +2326,7 @@ def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_miss
         allele0 = [bim.a0[j] for j in sel]
         allele1 = [bim.a1[j] for j in sel]
     write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, np.asarray(row_maf, dtype=np.float32),
-                    np.asarray(row_missing, dtype=np.float32), out)
+                    np.asarray(row_missing, dtype=np.float32), out, resolve=False)
     return float(lbd), float(ml0), float(reml0)
 
 
@@ -2155,6 +2441,100 @@ def lm_block_assoc_packed(y, x, ixx, packed, n_samples, row_flip, row_maf, sampl
     return out
 
 
+def _resolve_assoc_tsv_metadata(bed_prefix, chrom, pos, snp, allele0, allele1, row_indices, expected_len):
+    """`resolve_assoc_tsv_metadata` (src/io/assoc2tsv.rs:139-195): all five lists empty -> the BIM columns of `bed_prefix`
+    (rows `row_indices` when given); otherwise every list must have `expected_len` entries."""
+    if not any(len(a) for a in (chrom, pos, snp, allele0, allele1)):
+        prefix = (bed_prefix or "").strip()
+        if not prefix:
+            raise RuntimeError("empty TSV metadata requires non-empty bed_prefix")
+        from .bed import read_bim
+        bim = read_bim(_bed_prefix(prefix))
+        sel = range(len(bim.chrom)) if row_indices is None else [int(j) for j in row_indices]
+        chrom, pos, snp = [bim.chrom[j] for j in sel], [int(bim.pos[j]) for j in sel], [bim.snp[j] for j in sel]
+        allele0, allele1 = [bim.a0[j] for j in sel], [bim.a1[j] for j in sel]
+        if len(chrom) != expected_len:
+            raise RuntimeError(f"BIM metadata length mismatch: expected={expected_len}, chrom={len(chrom)}, pos={len(pos)}, "
+                               f"snp={len(snp)}, allele0={len(allele0)}, allele1={len(allele1)}")
+        return chrom, pos, snp, allele0, allele1
+    if not all(len(a) == expected_len for a in (chrom, pos, snp, allele0, allele1)):
+        raise RuntimeError(f"TSV metadata length mismatch: rows={expected_len}, chrom={len(chrom)}, pos={len(pos)}, "
+                           f"snp={len(snp)}, allele0={len(allele0)}, allele1={len(allele1)}")
+    return chrom, pos, snp, allele0, allele1
+
+
+def lm_block_assoc_f32(y, x, ixx, g, chunk_size=10000, threads=0):
+    """src/stats/glm.rs:4313-4497: the LM formulas of `lm_block_assoc_packed` on an already decoded SNP-major f32 block
+    `g` (m, n) (the `LM.gwas` wrapper of python/janusx/pyBLUP/assoc.py:613) -> f64 (m, 4) = beta, se, pwald, plrt."""
+    if int(chunk_size) <= 0:
+        raise RuntimeError("chunk_size must be > 0")
+    y = _c(y, np.float64).ravel()
+    x = _c(x, np.float64)
+    ixx = _c(ixx, np.float64)
+    g = _c(g, np.float32)
+    n = int(y.shape[0])
+    if x.ndim != 2 or x.shape[0] != n:
+        raise RuntimeError("X.n_rows must equal len(y)")
+    q0 = int(x.shape[1])
+    if ixx.shape != (q0, q0):
+        raise RuntimeError("ixx must be (q0,q0)")
+    if g.ndim != 2 or g.shape[1] != n:
+        raise RuntimeError("g must be shape (m, n)")
+    if n <= q0 + 1:
+        raise RuntimeError(f"n too small: require n > q0+1, got n={n}, q0={q0}")
+    m = int(g.shape[0])
+    out = np.zeros((m, 4), dtype=np.float64)
+    check(lib().jx_lm_assoc_dense(_p(y), _p(x), _p(ixx), q0, _p(g), m, n, _p(out)))
+    return out
+
+
+def lm_block_assoc_packed_to_tsv(y, x, ixx, packed, n_samples, row_flip, row_maf, row_missing, chrom, pos, snp, allele0,
+                                 allele1, out_tsv, maf_threshold=0.0, max_missing_rate=1.0, het_threshold=0.0,
+                                 sample_indices=None, row_indices=None, chunk_size=10000, threads=0,
+                                 progress_callback=None, progress_every=0, bed_prefix=None):
+    """src/stats/glm.rs:3862-4305: `lm_block_assoc_packed` with the result table written (11 columns, `miss` as the count
+    `(row_missing * n_samples) as i64` in f32 arithmetic, pwald sanitised; the thresholds are only range-checked, the rows
+    arrive filtered) -> (rows written, rows scanned).  Empty metadata lists are read from `<bed_prefix>.bim`."""
+    from .tsv import write_assoc_tsv_counts
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if int(chunk_size) <= 0:
+        raise RuntimeError("chunk_size must be > 0")
+    if not (0.0 <= maf_threshold <= 0.5):
+        raise ValueError("maf_threshold must be within [0, 0.5]")
+    if not (0.0 <= max_missing_rate <= 1.0):
+        raise ValueError("max_missing_rate must be within [0, 1.0]")
+    if not (0.0 <= het_threshold <= 1.0):
+        raise ValueError("het_threshold must be within [0, 1.0]")
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    if row_indices is not None:
+        ri = _c(row_indices, np.int64).ravel()
+        if ri.size and (ri.min() < 0 or ri.max() >= packed.shape[0]):
+            raise RuntimeError("row_indices out of range")
+        packed = np.ascontiguousarray(packed[ri])
+    else:
+        ri = None
+    m = int(packed.shape[0])
+    miss = _c(row_missing, np.float32).ravel()
+    if np.asarray(row_flip).ravel().shape[0] != m:
+        raise RuntimeError("row_flip length mismatch")
+    if _c(row_maf, np.float32).ravel().shape[0] != m:
+        raise RuntimeError("row_maf length mismatch")
+    if miss.shape[0] != m:
+        raise RuntimeError("row_missing length mismatch")
+    chrom, pos, snp, allele0, allele1 = _resolve_assoc_tsv_metadata(bed_prefix, chrom, pos, snp, allele0, allele1, ri, m)
+    stats = lm_block_assoc_packed(y, x, ixx, packed, n_samples, row_flip, row_maf, sample_indices, chunk_size, threads,
+                                  progress_callback, progress_every)
+    counts = (miss * np.float32(int(n_samples))).astype(np.int64).astype(np.float32)
+    rows = write_assoc_tsv_counts(out_tsv, chrom, pos, snp, allele0, allele1, _c(row_maf, np.float32).ravel(), counts,
+                                  stats[:, :3], resolve=False)
+    if progress_callback is not None:
+        progress_callback(m, m)
+    return rows, m
+
+
 # ------------------------------------------------------------------------------------------------
 # GBLUP (`jx gs -BLUP`, n <= 15 000 branch): src/stats/gblup.rs:1242-1516 `gblup_reml_npy_grm`
 # ------------------------------------------------------------------------------------------------
@@ -2204,6 +2584,38 @@ def gblup_reml_grm(grm, train_sample_indices, y_train, test_sample_indices=None,
     se2 = float(sc[5]) if return_variance_components else float("nan")
     return (ptr, pte, float(sc[0]), float(sc[1]), float(sc[2]), float(sc[3]), "rocsolver", el, 0, sg2, se2,
             np.zeros(0, dtype=np.float64))
+
+
+def _gblup_meta_grm(rows_payload, n_samples, tr, flip, maf):
+    """Centred-additive GRM of the samples `tr` over the payload rows with the caller's flip / maf metadata, the
+    formulation of `build_grm_from_meta_stream` (src/stats/gblup.rs:406-652; per-row centring and variance of
+    `decode_meta_block_f32` :239-404, bedmath.rs:1359-1441 for a sample subset) -> (K f64 (n_tr, n_tr) on the device,
+    scaled by 1 / sum(var); sum(var); the panel; the row means in f64)."""
+    import torch
+    from . import pipeline as pl
+    from . import stats as st
+    n_tr = int(tr.shape[0])
+    m = int(rows_payload.shape[0])
+    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
+    mafc = np.clip(maf, np.float32(0.0), np.float32(1.0))
+    if identity:
+        p64 = mafc.astype(np.float64)
+        mean64 = 2.0 * p64
+        var = 2.0 * p64 * (1.0 - p64)
+        mean32 = mean64.astype(np.float32)
+        row_mean = mean64
+    else:
+        mean32 = (np.float32(2.0) * mafc).astype(np.float32)
+        pg = np.clip(np.float32(0.5) * mean32, np.float32(0.0), np.float32(1.0))
+        var = np.maximum(np.float32(2.0) * pg * (np.float32(1.0) - pg), np.float32(0.0)).astype(np.float64)
+        row_mean = mean32.astype(np.float64)
+    var_sum = float(np.sum(var))
+    glut = st.grm_lut_from_mean_scale(mean32, np.ones(m, dtype=np.float32), flip)
+    panel = pl.Panel(rows_payload, n_samples, None if identity else tr)
+    acc = pl.grm_accumulate(panel, np.arange(m, dtype=np.int64), glut)
+    k = pl.grm_finalize(acc, n_tr, var_sum, torch.float64)
+    del acc
+    return k, var_sum, panel, row_mean
 
 
 def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_indices=None,
@@ -2294,26 +2706,7 @@ def gblup_reml_packed_bed(prefix, train_sample_indices, y_train, test_sample_ind
     dev = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream().cuda_stream
     rows_payload = torch.from_numpy(np.ascontiguousarray(packed[src])).to(dev)
-    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
-    # per-row centring / variance (decode_meta_block_f32 :239-404; bedmath.rs:1359-1441 for a sample subset)
-    mafc = np.clip(maf, np.float32(0.0), np.float32(1.0))
-    if identity:
-        p64 = mafc.astype(np.float64)
-        mean64 = 2.0 * p64
-        var = 2.0 * p64 * (1.0 - p64)
-        mean32 = mean64.astype(np.float32)
-        row_mean = mean64
-    else:
-        mean32 = (np.float32(2.0) * mafc).astype(np.float32)
-        pg = np.clip(np.float32(0.5) * mean32, np.float32(0.0), np.float32(1.0))
-        var = np.maximum(np.float32(2.0) * pg * (np.float32(1.0) - pg), np.float32(0.0)).astype(np.float64)
-        row_mean = mean32.astype(np.float64)
-    var_sum = float(np.sum(var))
-    glut = st.grm_lut_from_mean_scale(mean32, np.ones(m, dtype=np.float32), flip)
-    panel = pl.Panel(rows_payload, n_samples, None if identity else tr)
-    acc = pl.grm_accumulate(panel, np.arange(m, dtype=np.int64), glut)
-    k = pl.grm_finalize(acc, n_tr, var_sum, torch.float64)
-    del acc
+    k, var_sum, panel, row_mean = _gblup_meta_grm(rows_payload, n_samples, tr, flip, maf)
     k.diagonal().add_(float(g_eps))
     y_mean = float(np.sum(y) / n_tr)
     yc = torch.from_numpy(y - y_mean).to(dev)
@@ -2966,3 +3359,25 @@ def he_pcg_bed(prefix, train_sample_indices, y_train, site_keep=None, trace_samp
     h2 = sg / den if (math.isfinite(den) and den > 0.0) else float("nan")
     lam = se / sg if (math.isfinite(sg) and sg > 0.0) else float("inf")
     return (sg, se, h2, bool(converged), 1, rel_res, min(m_effective, eff_m), tr_k2, y_ky, y_y, lam, tr_k2_solve)
+
+
+# ------------------------------------------------------------------------------------------------
+# Names the reference's Python layer imports unconditionally beside the hot path (python/janusx/pyBLUP/assoc.py:207-218)
+# for a model this library does not replace (FastLMM, low-rank GRM): present so that the module imports, loud when called.
+# ------------------------------------------------------------------------------------------------
+
+def _out_of_scope(name, what):
+    def stub(*_args, **_kwargs):
+        raise RuntimeError(f"{name}: {what} is outside the mixed-model hot path this library replaces "
+                           "(GRM -> eigendecomposition -> REML -> per-SNP scan); use the reference's CPU extension for it")
+    stub.__name__ = name
+    stub.__doc__ = f"Out of scope ({what}); raises RuntimeError."
+    return stub
+
+
+fastlmm_prepare_lowrank_f64 = _out_of_scope("fastlmm_prepare_lowrank_f64", "the FastLMM low-rank model")
+fastlmm_assoc_from_snp_f32 = _out_of_scope("fastlmm_assoc_from_snp_f32", "the FastLMM low-rank model")
+fastlmm_reml_chunk_f32 = _out_of_scope("fastlmm_reml_chunk_f32", "the FastLMM low-rank model")
+fastlmm_reml_null_f32 = _out_of_scope("fastlmm_reml_null_f32", "the FastLMM low-rank model")
+fastlmm_assoc_chunk_f32 = _out_of_scope("fastlmm_assoc_chunk_f32", "the FastLMM low-rank model")
+

@@ -587,6 +587,33 @@ def scan_rows_splmm_blocks(rot: BlockRotation, p: int, rows: np.ndarray, lut: np
     return out
 
 
+def scan_rows_splmm_dense(g: np.ndarray, parts, n: int, p: int, fv_state, dev, block_rows=8192):
+    """SparseLMM exact scan of DENSE f32 rows `g` (m, n) on the host (`splmm_assoc_pcg_dense_f32`, src/stats/splmm.rs:5464-5650):
+    blocks of rows are staged to the device, rotated by the eigenbasis (`parts`: (offset, nb, U' (nb, nb) f32, sample positions of
+    the block or None for the identity) -- one part for a dense decomposition, the diagonal blocks otherwise) with the f32
+    rotation kernel and scanned (`jxg_splmm_exact_scan_dev`).  -> (m, 3) f64 on the device."""
+    m = int(g.shape[0])
+    out = torch.empty((m, 3), dtype=torch.float64, device=dev)
+    w, py, wx, a_chol, ypy = fv_state
+    a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
+    br = int(max(1, min(block_rows, m)))
+    grot = torch.empty((br, n), dtype=torch.float32, device=dev)
+    for r0 in range(0, m, br):
+        nr = min(br, m - r0)
+        gb = torch.from_numpy(g[r0:r0 + nr]).to(dev)
+        for off, nb, ut32, cols in parts:
+            if cols is None and nb == n:
+                check(lib().jxg_rotate_dense_f32(_ptr(gb), nr, n, _ptr(ut32), _ptr(grot), _stream()))
+            else:
+                sub = gb[:, cols].contiguous()
+                rb = torch.empty((nr, nb), dtype=torch.float32, device=dev)
+                check(lib().jxg_rotate_dense_f32(_ptr(sub), nr, nb, _ptr(ut32), _ptr(rb), _stream()))
+                grot[:nr, off:off + nb] = rb
+        check(lib().jxg_splmm_exact_scan_dev(_ptr(grot), nr, n, p, _ptr(w), _ptr(py), _ptr(wx), _ptr(a_dev), ypy, n - p,
+                                             out[r0:].data_ptr(), _stream()))
+    return out
+
+
 def rotate_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray) -> torch.Tensor:
     """G~ = G U for a (small) list of SNP rows, written out: (len(rows), n) f32 on the device (the fp16 hi / lo rotation of
     `scan_rows` without a scan behind it; used for the sampled markers of the SparseLMM gamma estimate)."""

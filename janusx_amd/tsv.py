@@ -85,7 +85,10 @@ def write_assoc_tsv_python(path, chrom, pos, snp, a0, a1, af, miss, stats) -> in
     return int(stats.shape[0])
 
 
-def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append, miss_count=False) -> int:
+def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append, miss_count=False, resolve=True) -> int:
+    """resolve: replace an empty / "." SNP name by chrom_pos -- what the reference's BED streaming routes do while they read
+    the BIM (`resolve_snp_name`, src/stats/lmm.rs:1242, 1952-1958); its entry points that take the metadata as lists print
+    the names as given (src/io/assoc2tsv.rs:430-548)."""
     import ctypes as C
 
     import numpy as np
@@ -96,8 +99,8 @@ def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append, miss_cou
         raise RuntimeError(f"unsupported GWAS result column count: {stats.shape[1] if stats.ndim == 2 else stats.shape} "
                            "(expected 3, 4, or 6)")
     rows = int(stats.shape[0])
-    prefixes = [f"{chrom[i]}\t{pos[i]}\t{resolve_snp_name(snp[i], chrom[i], pos[i])}\t{a0[i]}\t{a1[i]}".encode()
-                for i in range(rows)]
+    prefixes = [f"{chrom[i]}\t{pos[i]}\t{resolve_snp_name(snp[i], chrom[i], pos[i]) if resolve else snp[i]}\t{a0[i]}\t{a1[i]}"
+                .encode() for i in range(rows)]
     off = np.zeros(rows + 1, dtype=np.int64)
     if rows:
         np.cumsum([len(p) for p in prefixes], out=off[1:])
@@ -115,13 +118,22 @@ def _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, append, miss_cou
     return int(written)
 
 
-def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats) -> int:
+def write_assoc_tsv(path, chrom, pos, snp, a0, a1, af, miss, stats, resolve=True) -> int:
     """stats (rows, 3|4|6) f64 [beta, se, p(, plrt | , lambda, ml, plrt)] in BED order of the kept SNPs.
     The numeric columns are formatted and written by the native writer (`jx_assoc_tsv_append`, the counterpart of the
     reference's Rust formatter, src/io/assoc2tsv.rs:430-548); only the per-row `chrom pos snp a0 a1` prefix is put
     together here.  Returns rows written."""
     tmp = f"{path}.tmp.{os.getpid()}"
-    written = _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, False)
+    written = _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss, stats, False, False, resolve)
+    os.replace(tmp, path)
+    return written
+
+
+def write_assoc_tsv_counts(path, chrom, pos, snp, a0, a1, af, miss_counts, stats, resolve=True) -> int:
+    """`write_assoc_tsv` with the `miss` column holding COUNTS of missing samples, printed as integers
+    (`AssocMissValue::Count`, src/io/assoc2tsv.rs:452-458: the reference's LM routes)."""
+    tmp = f"{path}.tmp.{os.getpid()}"
+    written = _native_rows(tmp, chrom, pos, snp, a0, a1, af, miss_counts, stats, False, True, resolve)
     os.replace(tmp, path)
     return written
 

@@ -715,7 +715,8 @@ def splmm_wald_from_score_denom(score, denom, sigma2):
     return beta, se, chi2_sf_df1(chisq)
 
 
-def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip, sample_idx=None, rows=None):
+def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip, sample_idx=None, rows=None,
+                     dense_rows=None):
     """SparseLMM exact scan (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880) with the sparse factor of
     V = K + lambda I restated as a dense Cholesky: null state Py = V^-1 (y - X b), yPy, sigma2 = yPy / (n - p),
     chol(X'V^-1 X); per SNP the mean-imputed additive f32 decode ([0, 2 maf, 1, 2] or flipped, NOT centred:
@@ -736,15 +737,24 @@ def splmm_exact_scan(k_dense, lam, x_design, y, packed, n_samples, maf, row_flip
         raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
     sigma2 = ypy / df
     py32 = py.astype(np.float32)
-    codes = unpack_codes(np.ascontiguousarray(packed, dtype=np.uint8), n_samples)
-    if sample_idx is not None:
-        codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
-    rows = np.arange(codes.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
+    if dense_rows is not None:
+        # `splmm_assoc_pcg_dense_f32` (src/stats/splmm.rs:5464-5650): already decoded f32 rows, taken as they are
+        dense_rows = np.asarray(dense_rows, dtype=np.float32)
+        codes = None
+        rows = np.arange(dense_rows.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
+    else:
+        codes = unpack_codes(np.ascontiguousarray(packed, dtype=np.uint8), n_samples)
+        if sample_idx is not None:
+            codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
+        rows = np.arange(codes.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
     out = np.empty((len(rows), 3), dtype=np.float64)
     for k, r in enumerate(rows):
-        mean_g = F32(min(max(F32(2.0) * F32(maf[r]), F32(0.0)), F32(2.0)))
-        lut = np.array([2.0, mean_g, 1.0, 0.0] if row_flip[r] else [0.0, mean_g, 1.0, 2.0], dtype=np.float32)
-        g32 = lut[codes[r]]
+        if codes is None:
+            g32 = dense_rows[r]
+        else:
+            mean_g = F32(min(max(F32(2.0) * F32(maf[r]), F32(0.0)), F32(2.0)))
+            lut = np.array([2.0, mean_g, 1.0, 0.0] if row_flip[r] else [0.0, mean_g, 1.0, 2.0], dtype=np.float32)
+            g32 = lut[codes[r]]
         score = float(np.dot(g32, py32))                      # f32 GEMV output
         g = g32.astype(np.float64)
         z = fac.solve(g)
@@ -1573,6 +1583,60 @@ def fvlmm_assoc_chunk_from_snp(s, xcov, y_rot, log10_lbd, snp_chunk, u_t, nullml
 # G2  LMM -> LM fallback decision (src/stats/gwas_unified.rs:54-175)
 # --------------------------------------------------------------------------------------------
 
+def lmm_assoc_fixed_lambda_block(g_rot, s, xcov, y, log10_lbd, nullml=None):
+    """`lmm_assoc_chunk_f32` (src/stats/lmm.rs:2010-2224): Wald statistics of rotated rows at ONE lambda.  W = 1 / (s + lambda)
+    held in f32, c = X'Wg, d = g'Wg, e = g'Wy summed in f64, A = X'WX + 1e-6 I (Cholesky), Schur complement d - c'A^-1 c
+    (<= 1e-12 -> (NaN, NaN, NaN), the plrt entry keeps the 0.0 of the allocation), beta = (e - c'A^-1 b) / schur,
+    r'Wr = max(y'Wy - b'A^-1 b - num^2 / schur, 0), sigma2 = r'Wr / (n - p - 1).  -> (m, 3 or 4)."""
+    s = np.asarray(s, dtype=np.float64)
+    x = np.asarray(xcov, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    g_rot = np.asarray(g_rot, dtype=np.float32)
+    n, p = x.shape
+    lbd = 10.0 ** float(log10_lbd)
+    vv = s + lbd
+    w = (1.0 / vv).astype(np.float32).astype(np.float64)
+    log_det_v = float(np.sum(np.log(vv)))
+    nf = float(n)
+    c_ml = nf * (math.log(nf) - 1.0 - math.log(2.0 * math.pi)) / 2.0
+    a = (x * w[:, None]).T @ x + 1e-6 * np.eye(p)
+    b = x.T @ (w * y)
+    ywy = float(np.sum(w * y * y))
+    la = a.copy()
+    if not cholesky_inplace(la):
+        raise RuntimeError("X'WX not SPD")
+    a_inv_b = cholesky_solve(la, b)
+    b_aib = float(b @ a_inv_b)
+    df = n - p - 1
+    m = g_rot.shape[0]
+    out = np.zeros((m, 4 if nullml is not None else 3), dtype=np.float64)
+    for j in range(m):
+        g = g_rot[j].astype(np.float64)
+        wg = w * g
+        d = float(wg @ g)
+        e = float(wg @ y)
+        c = x.T @ wg
+        schur = d - float(c @ cholesky_solve(la, c))
+        if schur <= 1e-12 or not math.isfinite(schur):
+            out[j, :3] = np.nan
+            continue
+        num = e - float(c @ a_inv_b)
+        beta = num / schur
+        rwr = max(ywy - (b_aib + num * num / schur), 0.0)
+        se = math.sqrt(rwr / float(df) / schur)
+        pv = 1.0
+        if math.isfinite(se) and se > 0.0 and math.isfinite(beta):
+            pv = min(max(2.0 * normal_sf(abs(beta / se)), 2.2250738585072014e-308), 1.0)
+        out[j, :3] = (beta, se, pv)
+        if nullml is not None:
+            ml = c_ml - 0.5 * (nf * math.log(rwr) + log_det_v) if (rwr > 0.0 and math.isfinite(rwr)) else float("nan")
+            stat = 2.0 * (ml - nullml) if math.isfinite(ml) else 0.0
+            if not math.isfinite(stat) or stat < 0.0:
+                stat = 0.0
+            out[j, 3] = chi2_sf_df1(stat)
+    return out
+
+
 def lm_null_ml(y, xcov):
     y = np.asarray(y, dtype=np.float64).ravel()
     x = np.asarray(xcov, dtype=np.float64)
@@ -1732,6 +1796,41 @@ def lm_block_assoc_packed(y, x, ixx, packed, n_samples, row_flip, row_maf, sampl
     return out
 
 
+def lm_block_assoc_dense(y, x, ixx, g):
+    """`lm_block_assoc_f32` (src/stats/glm.rs:4313-4497): the formulas of `lm_block_assoc_packed` on decoded f32 rows g (m, n);
+    u = G X and a = G r_y are f32 sgemm outputs (f32 operands, summed in f64 here, rounded to f32), d = sum g^2 in f64; a row
+    needs a finite Schur complement > 1e-12, a finite positive variance (else only beta is kept) and a finite positive se."""
+    y = np.asarray(y, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    ixx = np.asarray(ixx, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float32)
+    n, q0 = x.shape
+    df = n - q0 - 1
+    ry = y - x @ (ixx @ (x.T @ y))
+    yy_r = float(ry @ ry)
+    ry32 = ry.astype(np.float32).astype(np.float64)
+    x32 = x.astype(np.float32).astype(np.float64)
+    out = np.full((g.shape[0], 4), np.nan, dtype=np.float64)
+    for j in range(g.shape[0]):
+        gj = g[j].astype(np.float64)
+        u = (gj @ x32).astype(np.float32).astype(np.float64)
+        a = float(np.float32(gj @ ry32))
+        schur = float(gj @ gj) - float(u @ (ixx @ u))
+        if not (math.isfinite(schur) and schur > 1e-12):
+            continue
+        b = a / schur
+        ve = max(yy_r - b * a, 0.0) / float(df)
+        if not (math.isfinite(ve) and ve > 0.0):
+            out[j, 0] = b
+            continue
+        se = math.sqrt(ve / schur)
+        if not (math.isfinite(b) and math.isfinite(se) and se > 0.0):
+            continue
+        t = b / se
+        out[j] = (b, se, student_t_p_two_sided(t, df), lm_plrt_from_t2(t * t, n, df))
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # A.10  TSV formatting (src/io/assoc2tsv.rs:45-57, 430-548; src/math/linalg.rs:327-340)
 # --------------------------------------------------------------------------------------------
@@ -1855,22 +1954,16 @@ def gblup_reml_grm(k_full, train_idx, y_train, test_idx=None, g_eps=1e-8, low=-6
     return pred_train, pred_test, fit
 
 
-def gblup_reml_packed_meta(packed, n_samples, row_source_indices, row_flip, row_maf, train_idx, y_train,
-                           test_idx=None, train_pred_local=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50,
-                           tol=1e-4, block_rows=65536):
-    """Metadata-streaming path of `gblup_reml_packed_bed` (src/stats/gblup.rs:1594-1958): GRM of the training samples
-    from the 2-bit payload (`build_grm_from_meta_stream` :406-857 with `decode_meta_block_f32` :239-404, Additive mode;
-    sample-subset rows through `decode_subset_row_from_full_scratch`, src/math/bedmath.rs:1359-1441, method 1), the
-    spectral REML fit (:1756-1848), then marker effects instead of cross-GRM rows: m_alpha = M' alpha over the
-    mean-imputed raw genotypes (`compute_malpha_from_meta_stream` :859-925, decode src/math/bedmath.rs:940-1010),
-    effect_beta / effect_alpha0 (:1865-1882) and predictions alpha0 + M beta (`predict_from_effect_stream` :1037-1103).
-    Returns (pred_train, pred_test, fit dict incl. effect_beta, effect_alpha0, var_sum)."""
+def grm_from_meta_additive(packed, n_samples, row_source_indices, row_flip, row_maf, sample_idx, block_rows=65536):
+    """`build_grm_from_meta_stream`, Additive mode (src/stats/gblup.rs:406-652; `decode_meta_block_f32` :239-404; sample-subset
+    rows through `decode_subset_row_from_full_scratch`, src/math/bedmath.rs:1359-1441, method 1) -- also what
+    `grm_bed_f64_from_meta` (src/stats/grm.rs:3639-3753, method 1) returns.  -> (K f64 (n, n) scaled by 1 / sum(var) and
+    symmetrised from the lower triangle, row_sum (m), sum(var))."""
     packed = np.asarray(packed, dtype=np.uint8)
     src = np.asarray(row_source_indices, dtype=np.int64)
     flip = np.asarray(row_flip, dtype=bool)
     maf = np.asarray(row_maf, dtype=np.float32)
-    tr = np.asarray(train_idx, dtype=np.int64)
-    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    tr = np.asarray(sample_idx, dtype=np.int64)
     n_tr = tr.shape[0]
     m = src.shape[0]
     codes = unpack_codes(packed[src], n_samples)
@@ -1903,6 +1996,29 @@ def gblup_reml_packed_meta(packed, n_samples, row_source_indices, row_flip, row_
     var_sum = float(np.sum(var))
     k = acc * (1.0 / var_sum)
     k = np.tril(k) + np.tril(k, -1).T
+    return k, row_sum, var_sum
+
+
+def gblup_reml_packed_meta(packed, n_samples, row_source_indices, row_flip, row_maf, train_idx, y_train,
+                           test_idx=None, train_pred_local=None, g_eps=1e-8, low=-6.0, high=6.0, max_iter=50,
+                           tol=1e-4, block_rows=65536):
+    """Metadata-streaming path of `gblup_reml_packed_bed` (src/stats/gblup.rs:1594-1958): GRM of the training samples
+    from the 2-bit payload (`build_grm_from_meta_stream` :406-857 with `decode_meta_block_f32` :239-404, Additive mode;
+    sample-subset rows through `decode_subset_row_from_full_scratch`, src/math/bedmath.rs:1359-1441, method 1), the
+    spectral REML fit (:1756-1848), then marker effects instead of cross-GRM rows: m_alpha = M' alpha over the
+    mean-imputed raw genotypes (`compute_malpha_from_meta_stream` :859-925, decode src/math/bedmath.rs:940-1010),
+    effect_beta / effect_alpha0 (:1865-1882) and predictions alpha0 + M beta (`predict_from_effect_stream` :1037-1103).
+    Returns (pred_train, pred_test, fit dict incl. effect_beta, effect_alpha0, var_sum)."""
+    packed = np.asarray(packed, dtype=np.uint8)
+    src = np.asarray(row_source_indices, dtype=np.int64)
+    flip = np.asarray(row_flip, dtype=bool)
+    maf = np.asarray(row_maf, dtype=np.float32)
+    tr = np.asarray(train_idx, dtype=np.int64)
+    te = np.zeros(0, dtype=np.int64) if test_idx is None else np.asarray(test_idx, dtype=np.int64)
+    n_tr = tr.shape[0]
+    m = src.shape[0]
+    codes = unpack_codes(packed[src], n_samples)
+    k, row_sum, var_sum = grm_from_meta_additive(packed, n_samples, src, flip, maf, tr, block_rows)
     k[np.diag_indices_from(k)] += g_eps
     fit = gblup_fit(k, y_train, low, high, tol, max_iter)
     alpha = fit["alpha"]

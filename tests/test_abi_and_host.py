@@ -316,3 +316,37 @@ def test_host_payload_guard_refuses_what_cannot_be_staged(monkeypatch):
     with pytest.raises(RuntimeError, match="device .torch CUDA uint8. tensor"):
         jxrs._guard_host_payload(5 << 30, "packed")
     jxrs._guard_host_payload(1 << 20, "packed")                   # small arrays are never refused
+
+
+def test_reference_python_layer_import_surface():
+    """The `janusx.janusx` names the reference's Python layer binds on the hot path and either side of it (hard imports of
+    python/janusx/pyBLUP/assoc.py:207-241, the all-or-nothing optional group there, workflow_model_stream.py:726-1678,
+    workflow_model_packed.py:4292-6309, script/grm.py:97-122, gs/workflow.py:4090-4139, assoc/api.py:45-57): every one is a
+    callable of the mirror module; the FastLMM ones are present but out of scope (loud when called).  A missing name of the
+    optional group would switch the reference's fused routes off wholesale."""
+    import janusx_amd.janusx as jxrs
+    hard = """fastlmm_prepare_lowrank_f64 fastlmm_assoc_from_snp_f32 lm_block_assoc_f32 lmm_reml_chunk_f32 lmm_reml_null_f32
+              ml_loglike_null_f32 lmm_assoc_chunk_f32 fastlmm_reml_chunk_f32 fastlmm_reml_null_f32 fastlmm_assoc_chunk_f32""".split()
+    optional = """lmm_reml_chunk_from_snp_f32 lmm_reml_lmm2_chunk_from_snp_f32 lmm_assoc_chunk_from_snp_f32 fvlmm_assoc_chunk_f32
+                  fvlmm_assoc_chunk_from_snp_f32 fvlmm_assoc_chunk_from_snp_to_tsv_f32 fvlmm_assoc_bed_to_tsv_f32
+                  fvlmm_assoc_prepare_cache_f32 fvlmm_assoc_chunk_with_cache_f32 fvlmm_assoc_chunk_from_snp_with_cache_f32
+                  lmm_rotate_x_y_with_ut_f64 lmm_rotate_y_with_ut_f64 lm_block_assoc_packed lm_block_assoc_packed_to_tsv
+                  grm_bed_f64_from_meta spgrm_bed_to_jxgrm_from_meta spgrm_dense_f32_to_jxgrm spgrm_dense_npy_to_jxgrm
+                  spgrm_bed_to_jxgrm spgrm_packed_to_jxgrm splmm_assoc_pcg_dense_f32 splmm_assoc_pcg_bed
+                  splmm_assoc_pcg_bed_to_tsv lmm_reml_assoc_bed_to_tsv_f32 lmm_reml_lmm2_assoc_bed_to_tsv_f32
+                  lmm_reml_assoc_packed_f32 lmm_reml_assoc_packed_f32_to_tsv fvlmm_assoc_packed_f32_to_tsv
+                  gwas_lmm_lm_null_lrt_decision gblup_reml_packed_bed gblup_reml_npy_grm rrblup_pcg_bed he_pcg_bed""".split()
+    for name in hard + optional:
+        assert callable(getattr(jxrs, name, None)), name
+    with pytest.raises(RuntimeError, match="outside the mixed-model hot path"):
+        jxrs.fastlmm_reml_null_f32()
+    # argument checks of the new fixed-lambda family run before any device call
+    s, x, y = np.linspace(0.1, 2.0, 12), np.ones((12, 1)), np.arange(12.0)
+    with pytest.raises(RuntimeError, match="invalid log10_lbd"):
+        jxrs.lmm_assoc_chunk_f32(s, x, y, 400.0, np.zeros((1, 12), np.float32))
+    with pytest.raises(RuntimeError, match="non-positive"):
+        jxrs.fvlmm_assoc_prepare_cache_f32(s - 5.0, x, y, 0.0)
+    with pytest.raises(RuntimeError, match="n must be > p_cov\\+1"):
+        jxrs.lmm_assoc_chunk_f32(s[:2], np.ones((2, 1)), y[:2], 0.0, np.zeros((1, 2), np.float32))
+    c = jxrs.fvlmm_assoc_prepare_cache_f32(s, x, y, -1.0)
+    assert (c.n, c.p) == (12, 1) and abs(c.lbd - 0.1) < 1e-15

@@ -2632,3 +2632,233 @@ def test_fixed_lambda_scan_fused_into_the_rotation_epilogue(oracle, monkeypatch)
                                                 oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null), nullml=nm.ML0)
         be, se, pe = _assoc_err(a[:, :3], fref[:, :3])
         assert max(be, se, pe) < TOL, (q, be, se, pe)
+
+
+@pytest.mark.gpu
+def test_fixed_lambda_entry_points_either_side_of_the_scan(oracle, null_case, tmp_path):
+    """The fixed-lambda callers the reference's Python layer imports beside the -fvlmm core (python/janusx/pyBLUP/assoc.py:
+    207-241): `lmm_assoc_chunk_f32` / `_from_snp_f32` (src/stats/lmm.rs:2010-2486), the cache pair `fvlmm_assoc_prepare_cache_f32`
+    / `fvlmm_assoc_chunk[_from_snp]_with_cache_f32` (src/stats/fvlmm.rs:1808-2112), `fvlmm_assoc_chunk_from_snp_to_tsv_f32`
+    (:2266-2480) and `lmm_rotate_y_with_ut_f64` (src/stats/reml.rs:200-250), against the restatements."""
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import tsv as jtsv
+    n, m, packed, g, y, x, nm = null_case
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, rows=rows)
+    gd[5] = 0.0                                              # Schur complement 0 -> (NaN, NaN, NaN)
+    grot = oracle.rotate_block_f32(gd, nm.Dh)
+    l10 = math.log10(nm.lbd_null)
+    # rotate y alone
+    yr = jxrs.lmm_rotate_y_with_ut_f64(nm.Dh, y)
+    assert yr.shape == (n,) and np.max(np.abs(yr - nm.Dh.astype(np.float64) @ y)) < 1e-11
+    with pytest.raises(RuntimeError, match="row-major"):
+        jxrs.lmm_rotate_y_with_ut_f64(nm.Dh[:, :-1], y)
+    # lmm_assoc_chunk: direct f64 sums, with and without the plrt column
+    ref = oracle.lmm_assoc_fixed_lambda_block(grot, nm.S, nm.Xcov, nm.y, l10)
+    out = jxrs.lmm_assoc_chunk_f32(nm.S, nm.Xcov, nm.y, l10, grot)
+    assert out.shape == ref.shape == (len(rows), 3) and np.isnan(out[5]).all() and np.isnan(ref[5]).all()
+    be, se, pe = _assoc_err(out, ref)
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    ref4 = oracle.lmm_assoc_fixed_lambda_block(grot, nm.S, nm.Xcov, nm.y, l10, nullml=nm.ML0)
+    out4 = jxrs.lmm_assoc_chunk_f32(nm.S, nm.Xcov, nm.y, l10, grot, nullml=nm.ML0)
+    ok = ~np.isnan(ref4[:, 0])
+    assert out4.shape == (len(rows), 4) and out4[5, 3] == 0.0 and ref4[5, 3] == 0.0
+    assert np.max(np.abs(np.log(out4[ok, 3]) - np.log(ref4[ok, 3]))) < 1e-4
+    out_s = jxrs.lmm_assoc_chunk_from_snp_f32(nm.S, nm.Xcov, nm.y, l10, gd, nm.Dh, nullml=nm.ML0)
+    be, se, pe = _assoc_err(out_s[:, :3], ref)
+    assert max(be, se, pe) < TOL and out_s[5, 3] == 0.0
+    with pytest.raises(RuntimeError, match="non-positive"):
+        jxrs.lmm_assoc_chunk_f32(nm.S - nm.S.max() - 20.0, nm.Xcov, nm.y, 0.0, grot)
+    with pytest.raises(RuntimeError, match="invalid log10_lbd"):
+        jxrs.lmm_assoc_chunk_f32(nm.S, nm.Xcov, nm.y, 400.0, grot)
+    # cache pair = the plain fixed-lambda entry points
+    cache = jxrs.fvlmm_assoc_prepare_cache_f32(nm.S, nm.Xcov, nm.y, l10)
+    assert (cache.n, cache.p) == (n, nm.Xcov.shape[1]) and abs(cache.lbd - nm.lbd_null) < 1e-12 * nm.lbd_null
+    a = jxrs.fvlmm_assoc_chunk_with_cache_f32(cache, grot, nullml=nm.ML0)
+    b = jxrs.fvlmm_assoc_chunk_f32(nm.S, nm.Xcov, nm.y, l10, grot, nullml=nm.ML0)
+    assert np.array_equal(a, b, equal_nan=True)
+    a = jxrs.fvlmm_assoc_chunk_from_snp_with_cache_f32(cache, gd, nm.Dh)
+    b = jxrs.fvlmm_assoc_chunk_from_snp_f32(nm.S, nm.Xcov, nm.y, l10, gd, nm.Dh)
+    assert np.array_equal(a, b, equal_nan=True)
+    fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
+    be, se, pe = _assoc_err(a, fref)
+    assert max(be, se, pe) < TOL
+    with pytest.raises(TypeError):
+        jxrs.fvlmm_assoc_chunk_with_cache_f32(object(), grot)
+    # formatted blocks: rows of rotate_block_rows, no header, the text of the file writer
+    mk = len(rows)
+    chrom, pos, snp = ["2"] * mk, list(range(10, 10 + mk)), [f"rs{j}" if j % 9 else "." for j in range(mk)]
+    a0, a1 = ["A"] * mk, ["C"] * mk
+    blocks, nrow = jxrs.fvlmm_assoc_chunk_from_snp_to_tsv_f32(nm.S, nm.Xcov, nm.y, l10, gd, nm.Dh, chrom, pos, snp, a0, a1,
+                                                              list(maf[rows]), list(miss[rows]), nullml=nm.ML0,
+                                                              rotate_block_rows=100)
+    assert nrow == mk and len(blocks) == (mk + 99) // 100 and all(isinstance(bk, bytes) for bk in blocks)
+    st4 = jxrs.fvlmm_assoc_chunk_from_snp_f32(nm.S, nm.Xcov, nm.y, l10, gd, nm.Dh, nullml=nm.ML0)
+    want = "".join(jtsv.format_row(chrom[i], pos[i], snp[i], a0[i], a1[i], maf[rows][i], miss[rows][i], float(st4[i, 0]),
+                                   float(st4[i, 1]), float(st4[i, 2]), st4[i, 3]) for i in range(mk))
+    # names are printed as given: '.' stays '.' on the entry points that take the metadata as lists (assoc2tsv.rs:430-548)
+    got_rows = b"".join(blocks).decode().splitlines()
+    want_rows = want.splitlines()
+    for i in range(mk):
+        gf, wf = got_rows[i].split("\t"), want_rows[i].split("\t")
+        assert gf[2] == snp[i] and gf[:2] == wf[:2] and gf[3:] == wf[3:]
+    assert blocks[0].count(b"\n") == 100 and b"2\t19\t.\tA" in blocks[0]
+    assert jxrs.fvlmm_assoc_chunk_from_snp_to_tsv_f32(nm.S, nm.Xcov, nm.y, l10, gd[:0], nm.Dh, [], [], [], [], [], [], []) == ([], 0)
+    with pytest.raises(RuntimeError, match="metadata length mismatch"):
+        jxrs.fvlmm_assoc_chunk_from_snp_to_tsv_f32(nm.S, nm.Xcov, nm.y, l10, gd, nm.Dh, chrom[:3], pos, snp, a0, a1,
+                                                   list(maf[rows]), list(miss[rows]))
+
+
+@pytest.mark.gpu
+def test_lm_dense_block_and_packed_to_tsv(oracle, tmp_path):
+    """`lm_block_assoc_f32` (src/stats/glm.rs:4313-4497; the `LM.gwas` wrapper, python/janusx/pyBLUP/assoc.py:613) on decoded
+    f32 rows and `lm_block_assoc_packed_to_tsv` (glm.rs:3862-4305; workflow_model_packed.py:4457): the restatement's values,
+    the row rules of the dense entry point, the 11-column table with the miss column as a count."""
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import tsv as jtsv
+    n, m = 613, 301
+    packed, g = bed.synth_panel_numpy(n, m, seed=29, missing_rate=0.02)
+    rng = np.random.default_rng(8)
+    mi, he, ho = oracle.row_counts(packed, n)
+    _k, maf, miss, _f = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.0, 1.0, 1.0)
+    flip = rng.random(m) < 0.3
+    codes = oracle.unpack_codes(packed, n)
+    gd = np.stack([oracle.lm_value_lut_f32(maf[j], bool(flip[j]))[codes[j]] for j in range(m)]).astype(np.float32)
+    gd[11] = 1.0                                            # collinear with the intercept: Schur complement 0 -> NaN row
+    for q0 in (1, 4, 6):
+        x = np.concatenate([np.ones((n, 1)), rng.standard_normal((n, q0 - 1))], axis=1)
+        y = x @ rng.standard_normal(q0) + 1.0 * gd[5] + rng.standard_normal(n)
+        ixx = jxrs.lm_precompute_ixx_qr(x)
+        ref = oracle.lm_block_assoc_dense(y, x, ixx, gd)
+        out = jxrs.lm_block_assoc_f32(y, x, ixx, gd, chunk_size=100)
+        assert out.shape == (m, 4) and np.isnan(out[11]).all() and np.isnan(ref[11]).all()
+        ok = ~np.isnan(ref[:, 0])
+        assert np.array_equal(ok, ~np.isnan(out[:, 0]))
+        for c, lim in ((0, TOL), (1, TOL), (2, TOL), (3, TOL)):   # the restatement rounds u and a to f32 (sgemm outputs): 1.4e-6
+            scale = np.abs(ref[ok, c]) + (ref[ok, 1] if c == 0 else 0.0)
+            if c >= 2:
+                err = np.max(np.abs(np.log(out[ok, c]) - np.log(ref[ok, c])) / np.maximum(1.0, np.abs(np.log(ref[ok, c]))))
+            else:
+                err = np.max(np.abs(out[ok, c] - ref[ok, c]) / scale)
+            assert err < lim, (q0, c, err)
+        assert out[5, 2] < 1e-4
+    with pytest.raises(RuntimeError, match="g must be shape"):
+        jxrs.lm_block_assoc_f32(y, x, ixx, gd[:, :-1])
+    with pytest.raises(RuntimeError, match="chunk_size"):
+        jxrs.lm_block_assoc_f32(y, x, ixx, gd, chunk_size=0)
+    # packed -> table
+    prefix = str(tmp_path / "p")
+    bim = bed.Bim(["3"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    sel = np.arange(0, m, 2, dtype=np.int64)
+    out_tsv = str(tmp_path / "lm.tsv")
+    kept, scanned = jxrs.lm_block_assoc_packed_to_tsv(y, x, ixx, packed, n, flip[sel], maf[sel], miss[sel], [], [], [], [], [],
+                                                      out_tsv, row_indices=sel, bed_prefix=prefix)
+    assert kept == scanned == len(sel)
+    st = jxrs.lm_block_assoc_packed(y, x, ixx, np.ascontiguousarray(packed[sel]), n, flip[sel], maf[sel])
+    lines = open(out_tsv).read().splitlines()
+    assert lines[0] == jtsv.HEADER3.rstrip("\n") and len(lines) == len(sel) + 1
+    for i in (0, 3, len(sel) - 1):
+        f = lines[1 + i].split("\t")
+        assert f[:5] == ["3", str(int(sel[i]) + 1), f"rs{int(sel[i])}", "A", "T"] and len(f) == 11
+        assert f[6] == str(int(np.float32(miss[sel][i]) * np.float32(n)))          # a COUNT, not a rate
+        assert f[7] == jtsv.fmt_f4(float(st[i, 0])) and f[8] == jtsv.fmt_f4(float(st[i, 1]))
+        assert f[10] == jtsv.fmt_e4(float(st[i, 2]))
+    with pytest.raises(ValueError, match="maf_threshold"):
+        jxrs.lm_block_assoc_packed_to_tsv(y, x, ixx, packed, n, flip, maf, miss, [], [], [], [], [], out_tsv, maf_threshold=0.7)
+    with pytest.raises(RuntimeError, match="requires non-empty bed_prefix"):
+        jxrs.lm_block_assoc_packed_to_tsv(y, x, ixx, packed, n, flip, maf, miss, [], [], [], [], [], out_tsv)
+
+
+@pytest.mark.gpu
+def test_grm_and_sparse_grm_from_caller_metadata(oracle, tmp_path):
+    """`grm_bed_f64_from_meta` (src/stats/grm.rs:3639-3753; `jx grm` / `jx gs` after their own QC pass), `spgrm_bed_to_jxgrm_from_meta`
+    (src/stats/spgrm.rs:5377-5500) and `spgrm_dense_f32_to_jxgrm` (:5924-5970): BED prefix + caller-prepared row indices, flips
+    and allele frequencies, whole cohort and a sample subset."""
+    from janusx_amd import janusx as jxrs
+    n, m = 301, 640
+    packed, g = _related_panel(n, m, 43, 0.02)
+    prefix = str(tmp_path / "p")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(2)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, _miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    src = np.nonzero(keep)[0].astype(np.int64)[::2]
+    for sub in (None, np.sort(rng.permutation(n)[:257]).astype(np.int64)):
+        tr = np.arange(n) if sub is None else sub
+        k = jxrs.grm_bed_f64_from_meta(prefix, src, flip[src], maf[src], sub, 1)
+        ref, _rs, _vs = oracle.grm_from_meta_additive(packed, n, src, flip[src], maf[src], tr)
+        assert k.shape == ref.shape == (len(tr), len(tr)) and k.dtype == np.float64
+        assert np.max(np.abs(k - ref)) < TOL * np.max(np.abs(ref)) and np.array_equal(k, k.T)
+        k2 = jxrs.grm_bed_f64_from_meta(prefix, src, flip[src], maf[src], sub, 2)
+        ref2 = oracle.grm_packed(np.ascontiguousarray(packed[src]), n, flip[src], maf[src], sub, 2)[0]
+        assert np.max(np.abs(k2 - ref2)) < TOL * np.max(np.abs(ref2))
+        # sparse GRM from the same metadata = the packed entry point on the selected rows with the stream denominator
+        path, nn, nnz = jxrs.spgrm_bed_to_jxgrm_from_meta(prefix, src, flip[src], maf[src], m, str(tmp_path / "meta"), sub, 1, 0.05)
+        cp, ri, va = oracle.sparse_grm_csc_from_packed(np.ascontiguousarray(packed[src]), n, flip[src], maf[src], sub, 1, 0.05,
+                                                       stream_denominator=True)[:3]
+        gn, gcp, gri, gva = oracle.read_sparse_grm_csc(path)
+        assert nn == gn == len(tr) and nnz == len(va) and np.array_equal(gcp, cp) and np.array_equal(gri, ri)
+        assert np.max(np.abs(gva - va)) < TOL * np.max(np.abs(va))
+    with pytest.raises(RuntimeError, match="dominance"):
+        jxrs.grm_bed_f64_from_meta(prefix, src, flip[src], maf[src], None, 3)
+    with pytest.raises(RuntimeError, match="row meta length mismatch"):
+        jxrs.grm_bed_f64_from_meta(prefix, src, flip[src][:-1], maf[src])
+    with pytest.raises(RuntimeError, match="out of range"):
+        jxrs.spgrm_bed_to_jxgrm_from_meta(prefix, src, flip[src], maf[src], int(src.max()), str(tmp_path / "bad"))
+    # dense f32 matrix in memory -> the same bytes as the .npy route
+    kd = rng.normal(size=(90, 90)).astype(np.float32)
+    kd = (kd @ kd.T / 90).astype(np.float32)
+    np.save(str(tmp_path / "d.npy"), kd)
+    pa, na, za = jxrs.spgrm_dense_f32_to_jxgrm(kd, str(tmp_path / "a"), 0.1)
+    pb, nb, zb = jxrs.spgrm_dense_npy_to_jxgrm(str(tmp_path / "d.npy"), str(tmp_path / "b"), 0.1)
+    assert (na, za) == (nb, zb) and open(pa, "rb").read() == open(pb, "rb").read()
+    with pytest.raises(RuntimeError, match="square"):
+        jxrs.spgrm_dense_f32_to_jxgrm(kd[:, :-1], str(tmp_path / "c"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["dense", "block"])
+def test_splmm_assoc_pcg_dense_f32(oracle, tmp_path, monkeypatch, route):
+    """`splmm_assoc_pcg_dense_f32` (src/stats/splmm.rs:5464-5650; the `SparseLMM.gwas` API, python/janusx/assoc/api.py:898-940):
+    decoded f32 rows against a sparse GRM file at a given lambda, with covariates and a GRM sample subset, through the dense and
+    the block-diagonal eigenbasis; restatement with a dense Cholesky of K + lambda I."""
+    from janusx_amd import janusx as jxrs
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", route)
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "64")
+    jxrs.spectral_cache_clear()
+    n, m = 300, 420
+    packed, g = _related_panel(n, m, 51, 0.0)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    path, _, _ = jxrs.spgrm_packed_to_jxgrm(np.ascontiguousarray(packed[keep]), n, np.zeros(int(keep.sum()), bool), af[keep],
+                                            str(tmp_path / "k"), None, 1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.permutation(n)[:270]).astype(np.int64)
+    gd = g[:, sub].astype(np.float32) + rng.normal(0, 0.01, size=(m, len(sub))).astype(np.float32)   # any f32 values, not only codes
+    gd[9] = 0.0                                                                               # g'Pg = 0 -> (NaN, NaN, 1)
+    y = 0.6 * gd[100] + gd[200:230].T @ rng.normal(0, 0.2, 30) + rng.normal(0, 1.0, len(sub))
+    xc = rng.normal(size=(len(sub), 2))
+    lam = 0.8
+    got = jxrs.splmm_assoc_pcg_dense_f32(gd, y, lam, path, xc, sub)
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, sub)
+    ref = oracle.splmm_exact_scan(kd, lam, oracle.spreml_design_matrix(xc, len(sub)), y, None, n, None, None, dense_rows=gd)
+    assert got.shape == ref.shape == (m, 3)
+    bad = np.isnan(ref[:, 0])
+    assert bad[9] and np.array_equal(np.isnan(got[:, 0]), bad) and np.all(got[bad, 2] == 1.0)
+    ok = ~bad
+    scale = np.maximum(np.abs(ref[ok, 0]), ref[ok, 1])
+    assert np.max(np.abs(got[ok, 0] - ref[ok, 0]) / scale) < TOL
+    assert np.max(np.abs(got[ok, 1] - ref[ok, 1]) / ref[ok, 1]) < TOL
+    lp = np.abs(np.log(np.maximum(got[ok, 2], 1e-300)) - np.log(np.maximum(ref[ok, 2], 1e-300)))
+    assert np.max(lp / np.maximum(1.0, np.abs(np.log(np.maximum(ref[ok, 2], 1e-300))))) < 10 * TOL
+    assert ref[100, 2] < 1e-6
+    with pytest.raises(RuntimeError, match="len\\(y\\) to equal"):
+        jxrs.splmm_assoc_pcg_dense_f32(gd, y[:-1], lam, path, None, sub)
+    with pytest.raises(RuntimeError, match="lbd must be finite"):
+        jxrs.splmm_assoc_pcg_dense_f32(gd, y, -1.0, path, xc, sub)
+    jxrs.spectral_cache_clear()

@@ -226,6 +226,65 @@ def spgrm_packed_to_jxgrm(packed, n_samples, row_flip, row_maf, out_prefix, samp
     return out
 
 
+def prepare_bed_logic_meta_selected(prefix, sample_indices=None, maf_threshold=0.0, max_missing_rate=1.0, het_threshold=1.0,
+                                    snps_only=False, mmap_window_mb=None, threads=1):
+    """src/io/gfreader.rs:7108-7235 -> `prepare_bed_logic_meta_owned_for_stats_samples_with_mmap_window` (:5236-5480): the QC
+    pre-pass of the SparseLMM / sparse-GRM routes over the selected samples (python/janusx/assoc/workflow_model_packed.py:1106,
+    1248) -> (row_source_indices i64 (kept), missing_rate f32 (kept), maf f32 (kept) = ALT allele frequency, row_flip bool
+    (kept, all False), site_keep bool (all rows), n_samples_full, n_snps_total).  Per-SNP counts are popcounts on the device,
+    the O(m) f32 decisions run on the host with the reference's expressions (`stats.packed_prep_row_stats`)."""
+    from . import stats as st
+    from .bed import snps_only_mask, stage_bed_payload
+    if not (0.0 <= maf_threshold <= 0.5):
+        raise ValueError("maf_threshold must be within [0, 0.5]")
+    if not (0.0 <= max_missing_rate <= 1.0):
+        raise ValueError("max_missing_rate must be within [0, 1.0]")
+    if not (0.0 <= het_threshold <= 1.0):
+        raise ValueError("het_threshold must be within [0, 1.0]")
+    packed, n_fam, bim = stage_bed_payload(_bed_prefix(prefix), mmap_window_mb)
+    if n_fam == 0:
+        raise RuntimeError("no samples found in PLINK input")
+    idx, n_sel = _opt_idx(sample_indices)
+    if idx is not None and n_sel and (idx.min() < 0 or idx.max() >= n_fam):
+        bad = int(idx[(idx < 0) | (idx >= n_fam)][0])
+        raise ValueError(f"sample index out of range: {bad} for n_samples={n_fam}")
+    n_stats = n_sel if (idx is not None and n_sel) else n_fam
+    counts = bed_row_counts(packed, n_fam, idx if (idx is not None and n_sel) else None)
+    keep, miss, maf, _std = st.packed_prep_row_stats(counts, n_stats, np.float32(maf_threshold), np.float32(max_missing_rate),
+                                                     np.float32(het_threshold))
+    if snps_only:
+        keep = keep & snps_only_mask(bim)
+    if not keep.any():
+        raise RuntimeError("No SNPs left after packed BED filtering. Please relax thresholds.")
+    rows = np.nonzero(keep)[0].astype(np.int64)
+    return (rows, np.ascontiguousarray(miss[rows], dtype=np.float32), np.ascontiguousarray(maf[rows], dtype=np.float32),
+            np.zeros(len(rows), dtype=bool), np.ascontiguousarray(keep, dtype=bool), int(n_fam), int(packed.shape[0]))
+
+
+def load_bim_columns(path_or_prefix, row_indices=None):
+    """src/io/gfreader.rs:8813-8862 -> (chrom, pos, snp, allele0, allele1) lists of a PLINK prefix (or explicit .bed/.bim/.fam
+    path), optionally of the rows `row_indices` (the result-table metadata of python/janusx/assoc/workflow.py:4633)."""
+    from .bed import read_bim
+    p = str(path_or_prefix).strip()
+    if not p:
+        raise ValueError("path_or_prefix must not be empty")
+    explicit = p.lower().endswith((".bed", ".bim", ".fam"))
+    if not (explicit or all(os.path.exists(p + e) for e in (".bed", ".bim", ".fam"))):
+        raise ValueError("load_bim_columns requires a PLINK BED/BIM/FAM prefix or explicit PLINK file path")
+    bim = read_bim(_bed_prefix(p))
+    if row_indices is None:
+        sel = range(len(bim.chrom))
+    else:
+        sel = [int(v) for v in np.asarray(row_indices).ravel()]
+        for v in sel:
+            if v < 0:
+                raise ValueError(f"row_indices must be non-negative, got {v}")
+            if v >= len(bim.chrom):
+                raise RuntimeError(f"BIM row index out of range: {v} >= {len(bim.chrom)}")
+    return ([bim.chrom[j] for j in sel], [int(bim.pos[j]) for j in sel], [bim.snp[j] for j in sel],
+            [bim.a0[j] for j in sel], [bim.a1[j] for j in sel])
+
+
 def spgrm_bed_to_jxgrm(prefix, out_prefix=None, sample_indices=None, method=1, threshold=0.05, abs_threshold=False,
                        maf_threshold=0.02, max_missing_rate=0.05, het_threshold=0.0, snps_only=False, block_rows=0,
                        sample_block=0, threads=0, mmap_window_mb=None, progress_callback=None, progress_every=0):
@@ -1632,6 +1691,147 @@ def grm_bed_f64_from_meta(prefix, row_indices, row_flip, row_maf, sample_indices
     if progress_callback is not None:
         progress_callback(int(src.shape[0]), int(src.shape[0]))
     return np.ascontiguousarray(out, dtype=np.float64)
+
+
+def _write_npy_f32(out_path, arr):
+    tmp = f"{out_path}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        np.lib.format.write_array(fh, np.ascontiguousarray(arr, dtype=np.float32), version=(1, 0))
+    os.replace(tmp, out_path)
+
+
+def gblup_grm_from_meta_to_npy(prefix, out_npy_path, row_source_indices, row_flip, row_maf, sample_indices=None, method=1,
+                               block_rows=65536, threads=0, progress_callback=None, progress_every=0, mmap_window_mb=None):
+    """src/stats/gblup.rs:718-857: `build_grm_from_meta_stream` written as NPY v1 f32 (`jx grm` rust-meta route,
+    python/janusx/script/grm.py:1459) -> (eff_m, n_samples)."""
+    k = grm_bed_f64_from_meta(prefix, row_source_indices, row_flip, row_maf, sample_indices, method, block_rows, threads,
+                              None, 0, mmap_window_mb)
+    _write_npy_f32(out_npy_path, k)
+    eff_m = int(np.asarray(row_source_indices).ravel().shape[0])
+    if progress_callback is not None:
+        progress_callback(eff_m, eff_m)
+    return eff_m, int(k.shape[0])
+
+
+_DENSE_META_GRM_CACHE = {}      # one entry: the dense GRM a sequence of row-band calls is cut from
+
+
+def _dense_grm_from_meta_f32(prefix, row_source_indices, row_flip, row_maf, n_total_sites, sample_indices, method,
+                             mmap_window_mb, what):
+    """Dense GRM under the conventions of the sparse-GRM stream core (`grm_stream_bed_row_band_f32_fill_core`,
+    src/stats/spgrm.rs:4266-4570): rows decoded with mean 2 maf (clamped) and, for method 2, 1 / sqrt(2p(1-p)) (0 below
+    1e-12), missing = mean; denominator = the f64 sum of the positive finite 2p(1-p) (method 1) or m (method 2) whatever
+    the sample selection.  -> (K f32 (n_use, n_use) on the host, eff_m, n_use).  The reference builds the matrix band by
+    band to bound host memory; here the whole accumulator lives in HBM and consecutive band calls on the same inputs are
+    cut from one cached matrix."""
+    import hashlib
+    import torch
+    from . import pipeline as pl
+    from . import stats as st
+    from .bed import stage_bed_payload
+    bed_prefix = _bed_prefix(prefix)
+    if int(n_total_sites) <= 0:
+        raise RuntimeError(f"n_total_sites must be positive for dense GRM {what} meta route.")
+    if int(method) not in (1, 2):
+        raise RuntimeError(f"Dense GRM part method must be 1 (centered) or 2 (standardized); got {method}")
+    src = _c(row_source_indices, np.int64).ravel()
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if src.size == 0:
+        raise RuntimeError("row_source_indices must not be empty")
+    if (src < 0).any():
+        raise RuntimeError(f"row_source_indices must be non-negative, got {int(src[src < 0][0])}")
+    if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
+        raise RuntimeError(f"row meta length mismatch: row_source_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    if int(src.max()) >= int(n_total_sites):
+        raise RuntimeError(f"row_source index out of range: {int(src[src >= int(n_total_sites)][0])} >= "
+                           f"n_total_sites={int(n_total_sites)}")
+    idx, n_sel = _opt_idx(sample_indices)
+    st_bed = os.stat(bed_prefix + ".bed")
+    h = hashlib.sha1()
+    for a in (src, flip.astype(np.uint8), maf, idx if idx is not None else np.zeros(0, np.int64)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    key = (os.path.abspath(bed_prefix), st_bed.st_size, st_bed.st_mtime_ns, int(method), h.hexdigest())
+    hit = _DENSE_META_GRM_CACHE.get(key)
+    if hit is not None:
+        return hit
+    _DENSE_META_GRM_CACHE.clear()
+    packed, n_fam, _bim = stage_bed_payload(bed_prefix, mmap_window_mb)
+    if n_fam == 0:
+        raise RuntimeError("No samples found in BED input.")
+    if int(src.max()) >= int(packed.shape[0]):
+        raise RuntimeError(f"row_source index out of range for the BED payload: {int(src.max())} >= {int(packed.shape[0])}")
+    if idx is not None and n_sel and (idx.min() < 0 or idx.max() >= n_fam):
+        raise RuntimeError(f"Dense GRM part sample index out of range: {int(idx.max())} >= {n_fam}")
+    n_use = n_sel if (idx is not None and n_sel) else n_fam
+    m = int(src.shape[0])
+    if int(method) == 1:
+        v = 2.0 * maf.astype(np.float64) * (1.0 - maf.astype(np.float64))
+        denom = float(np.sum(v[np.isfinite(v) & (v > 0.0)]))
+        if not (np.isfinite(denom) and denom > 0.0):
+            raise RuntimeError("Dense GRM part centered denominator is not positive")
+    else:
+        denom = float(m)
+    rows_payload = packed[torch.from_numpy(src).to(packed.device)]
+    del packed
+    panel = pl.Panel(rows_payload, n_fam, idx if (idx is not None and n_sel) else None)
+    acc = pl.grm_accumulate(panel, np.arange(m, dtype=np.int64), st.grm_lut_from_maf(maf, flip, int(method)))
+    k = pl.grm_finalize(acc, n_use, denom, torch.float32).cpu().numpy()
+    del acc
+    out = (k, m, n_use)
+    if k.nbytes <= (8 << 30):
+        _DENSE_META_GRM_CACHE[key] = out
+    return out
+
+
+def _row_band(k, row_part_start, row_part_end):
+    n_use = int(k.shape[0])
+    a, b = int(row_part_start), int(row_part_end)
+    if a >= b or b > n_use:
+        raise RuntimeError(f"row band is invalid: start={a}, end={b}, n_samples={n_use}")
+    # the band holds the LOWER triangle only (column <= global row; `spgrm_collect_batch_dense_rows`, spgrm.rs:2706-2753): the
+    # caller mirrors when it assembles the parts
+    return np.ascontiguousarray(np.tril(k[a:b], k=a))
+
+
+def grm_bed_f32_row_band_from_meta(prefix, row_source_indices, row_flip, row_maf, n_total_sites, row_part_start,
+                                   row_part_end, sample_indices=None, method=1, block_rows=0, sample_block=0, threads=0,
+                                   mmap_window_mb=None, progress_callback=None, progress_every=0):
+    """src/stats/spgrm.rs:5496-5642: rows [row_part_start, row_part_end) of the dense GRM of caller-prepared BED rows
+    (`jx grm` part builds, python/janusx/script/grm.py:819) -> (f32 (part_rows, n_use), eff_m, n_use)."""
+    k, eff_m, n_use = _dense_grm_from_meta_f32(prefix, row_source_indices, row_flip, row_maf, n_total_sites, sample_indices,
+                                               method, mmap_window_mb, "part")
+    band = _row_band(k, row_part_start, row_part_end)
+    if progress_callback is not None:
+        progress_callback(eff_m, eff_m)
+    return band, eff_m, n_use
+
+
+def grm_bed_f32_row_band_from_meta_to_npy(prefix, out_npy_path, row_source_indices, row_flip, row_maf, n_total_sites,
+                                          row_part_start, row_part_end, sample_indices=None, method=1, block_rows=0,
+                                          sample_block=0, threads=0, mmap_window_mb=None, progress_callback=None,
+                                          progress_every=0):
+    """src/stats/spgrm.rs:5644-5783: the same band written as NPY v1 f32 (part_rows, n_use) -> (eff_m, n_use)."""
+    k, eff_m, n_use = _dense_grm_from_meta_f32(prefix, row_source_indices, row_flip, row_maf, n_total_sites, sample_indices,
+                                               method, mmap_window_mb, "part")
+    _write_npy_f32(out_npy_path, _row_band(k, row_part_start, row_part_end))
+    if progress_callback is not None:
+        progress_callback(eff_m, eff_m)
+    return eff_m, n_use
+
+
+def grm_bed_f32_tiled_from_meta_to_npy(prefix, out_npy_path, row_source_indices, row_flip, row_maf, n_total_sites,
+                                       sample_indices=None, method=1, block_rows=0, sample_block=0, threads=0,
+                                       mmap_window_mb=None, progress_callback=None, progress_every=0):
+    """src/stats/spgrm.rs:5785-5922: the whole dense GRM of caller-prepared BED rows written as NPY v1 f32 (n_use, n_use)
+    -> (eff_m, n_use) (`jx grm` tiled route, python/janusx/script/grm.py:985)."""
+    k, eff_m, n_use = _dense_grm_from_meta_f32(prefix, row_source_indices, row_flip, row_maf, n_total_sites, sample_indices,
+                                               method, mmap_window_mb, "tiled")
+    _write_npy_f32(out_npy_path, k)
+    if progress_callback is not None:
+        progress_callback(eff_m, eff_m)
+    return eff_m, n_use
 
 
 def rust_eigh_from_array_f64(a, threads=0, driver=None, jobz="V", require_lapack=False, diag_shift=0.0):

@@ -335,7 +335,9 @@ def test_reference_python_layer_import_surface():
                   spgrm_bed_to_jxgrm spgrm_packed_to_jxgrm splmm_assoc_pcg_dense_f32 splmm_assoc_pcg_bed
                   splmm_assoc_pcg_bed_to_tsv lmm_reml_assoc_bed_to_tsv_f32 lmm_reml_lmm2_assoc_bed_to_tsv_f32
                   lmm_reml_assoc_packed_f32 lmm_reml_assoc_packed_f32_to_tsv fvlmm_assoc_packed_f32_to_tsv
-                  gwas_lmm_lm_null_lrt_decision gblup_reml_packed_bed gblup_reml_npy_grm rrblup_pcg_bed he_pcg_bed""".split()
+                  gwas_lmm_lm_null_lrt_decision gblup_reml_packed_bed gblup_reml_npy_grm rrblup_pcg_bed he_pcg_bed
+                  gblup_grm_from_meta_to_npy grm_bed_f32_row_band_from_meta grm_bed_f32_row_band_from_meta_to_npy
+                  grm_bed_f32_tiled_from_meta_to_npy prepare_bed_logic_meta_selected load_bim_columns""".split()
     for name in hard + optional:
         assert callable(getattr(jxrs, name, None)), name
     with pytest.raises(RuntimeError, match="outside the mixed-model hot path"):

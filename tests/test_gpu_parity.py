@@ -2862,3 +2862,98 @@ def test_splmm_assoc_pcg_dense_f32(oracle, tmp_path, monkeypatch, route):
     with pytest.raises(RuntimeError, match="lbd must be finite"):
         jxrs.splmm_assoc_pcg_dense_f32(gd, y, -1.0, path, xc, sub)
     jxrs.spectral_cache_clear()
+
+
+@pytest.mark.gpu
+def test_dense_grm_parts_from_caller_metadata(oracle, tmp_path):
+    """The `jx grm` builders on caller-prepared rows (python/janusx/script/grm.py:819-1000, 1459): `grm_bed_f32_row_band_from_meta`
+    [`_to_npy`], `grm_bed_f32_tiled_from_meta_to_npy` (src/stats/spgrm.rs:5496-5922: conventions of the sparse-GRM stream core --
+    f64 sum of 2p(1-p) or m as the denominator whatever the sample selection, a band holds the lower triangle of its rows) and
+    `gblup_grm_from_meta_to_npy` (src/stats/gblup.rs:718-857)."""
+    from janusx_amd import janusx as jxrs
+    n, m = 277, 520
+    packed, g = bed.synth_panel_numpy(n, m, seed=47, missing_rate=0.02)
+    prefix = str(tmp_path / "p")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(3)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, _miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    src = np.nonzero(keep)[0].astype(np.int64)[::3]
+    codes = oracle.unpack_codes(np.ascontiguousarray(packed[src]), n)
+    for sub in (None, np.sort(rng.permutation(n)[:201]).astype(np.int64)):
+        cols = np.arange(n) if sub is None else sub
+        nu = len(cols)
+        for method in (1, 2):
+            z = np.stack([oracle.grm_value_lut_f32(maf[src][j], bool(flip[src][j]), method)[codes[j, cols]]
+                          for j in range(len(src))]).astype(np.float64)
+            p = maf[src].astype(np.float64)
+            denom = float(np.sum(2.0 * p * (1.0 - p))) if method == 1 else float(len(src))
+            ref = (z.T @ z) / denom
+            full_npy = str(tmp_path / f"full_{method}.npy")
+            eff, nn = jxrs.grm_bed_f32_tiled_from_meta_to_npy(prefix, full_npy, src, flip[src], maf[src], m, sub, method)
+            full = np.load(full_npy)
+            assert (eff, nn) == (len(src), nu) and full.dtype == np.float32 and full.shape == (nu, nu)
+            assert np.array_equal(full, full.T) and np.max(np.abs(full - ref)) < TOL * np.max(np.abs(ref))
+            # two bands = the lower triangle of the full matrix, cut from ONE cached build
+            a, b = 0, nu // 3
+            band, eff2, nn2 = jxrs.grm_bed_f32_row_band_from_meta(prefix, src, flip[src], maf[src], m, a, b, sub, method)
+            assert (eff2, nn2) == (len(src), nu) and band.shape == (b - a, nu) and band.dtype == np.float32
+            assert np.array_equal(band, np.tril(full[a:b], k=a))
+            part_npy = str(tmp_path / f"part_{method}.npy")
+            jxrs.grm_bed_f32_row_band_from_meta_to_npy(prefix, part_npy, src, flip[src], maf[src], m, b, nu, sub, method)
+            assert np.array_equal(np.load(part_npy), np.tril(full[b:nu], k=b))
+        # gblup flavour (row variances of the decode for a sample subset) as an .npy
+        gnpy = str(tmp_path / "gblup.npy")
+        eff, nn = jxrs.gblup_grm_from_meta_to_npy(prefix, gnpy, src, flip[src], maf[src], sub, 1)
+        kref, _rs, _vs = oracle.grm_from_meta_additive(packed, n, src, flip[src], maf[src], cols)
+        kg = np.load(gnpy)
+        assert (eff, nn) == (len(src), nu) and kg.dtype == np.float32
+        assert np.max(np.abs(kg - kref)) < TOL * np.max(np.abs(kref))
+    with pytest.raises(RuntimeError, match="row band is invalid"):
+        jxrs.grm_bed_f32_row_band_from_meta(prefix, src, flip[src], maf[src], m, 5, 5)
+    with pytest.raises(RuntimeError, match="method must be 1"):
+        jxrs.grm_bed_f32_tiled_from_meta_to_npy(prefix, str(tmp_path / "x.npy"), src, flip[src], maf[src], m, None, 3)
+    with pytest.raises(RuntimeError, match="n_total_sites must be positive"):
+        jxrs.grm_bed_f32_row_band_from_meta(prefix, src, flip[src], maf[src], 0, 0, 5)
+
+
+@pytest.mark.gpu
+def test_qc_prepass_and_bim_columns_for_the_sparse_routes(oracle, tmp_path):
+    """`prepare_bed_logic_meta_selected` (src/io/gfreader.rs:7108-7235; the SparseLMM memmap path's QC pre-pass,
+    python/janusx/assoc/workflow_model_packed.py:1106) and `load_bim_columns` (:8813-8862): kept rows / missing rate / ALT
+    frequency bit-identical to the restatement of the packed-prep rule, over all samples and a subset."""
+    from janusx_amd import janusx as jxrs
+    n, m = 190, 410
+    packed, g = bed.synth_panel_numpy(n, m, seed=53, missing_rate=0.03)
+    prefix = str(tmp_path / "q")
+    a0 = ["A" if j % 11 else "AT" for j in range(m)]                      # a few indels for snps_only
+    bim = bed.Bim([str(1 + j % 3) for j in range(m)], [f"v{j}" for j in range(m)], list(range(5, 5 + m)), a0, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(1)
+    for sub in (None, np.sort(rng.permutation(n)[:140]).astype(np.int64)):
+        ns = n if sub is None else len(sub)
+        mi, he, ho = oracle.row_counts(packed, n, sub)
+        keep, miss, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, ns, 0.03, 0.04, 0.6)
+        rows, miss_k, maf_k, flip_k, site_keep, n_full, m_total = jxrs.prepare_bed_logic_meta_selected(
+            prefix, sub, 0.03, 0.04, 0.6)
+        assert (n_full, m_total) == (n, m) and np.array_equal(site_keep, keep) and np.array_equal(rows, np.nonzero(keep)[0])
+        assert rows.dtype == np.int64 and miss_k.dtype == maf_k.dtype == np.float32 and flip_k.dtype == bool
+        assert np.array_equal(miss_k, miss[keep]) and np.array_equal(maf_k, af[keep]) and not flip_k.any()
+    rows_s = jxrs.prepare_bed_logic_meta_selected(prefix, None, 0.03, 0.04, 0.6, snps_only=True)[0]
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep = oracle.packed_prep_row_stats(mi, he, ho, n, 0.03, 0.04, 0.6)[0]
+    assert np.array_equal(rows_s, np.nonzero(keep & (np.arange(m) % 11 != 0))[0])
+    with pytest.raises(ValueError, match="maf_threshold"):
+        jxrs.prepare_bed_logic_meta_selected(prefix, None, 0.9)
+    with pytest.raises(ValueError, match="sample index out of range"):
+        jxrs.prepare_bed_logic_meta_selected(prefix, np.array([0, n], dtype=np.int64))
+    with pytest.raises(RuntimeError, match="No SNPs left"):
+        jxrs.prepare_bed_logic_meta_selected(prefix, None, 0.5, 0.0)
+    chrom, pos, snp, b0, b1 = jxrs.load_bim_columns(prefix + ".bed", np.array([3, 0, 22], dtype=np.int64))
+    assert (chrom, pos, snp, b0, b1) == (["1", "1", "2"], [8, 5, 27], ["v3", "v0", "v22"], ["A", "AT", "AT"], ["G"] * 3)
+    assert len(jxrs.load_bim_columns(prefix)[0]) == m
+    with pytest.raises(ValueError, match="non-negative"):
+        jxrs.load_bim_columns(prefix, np.array([-1]))
+    with pytest.raises(ValueError, match="requires a PLINK"):
+        jxrs.load_bim_columns(str(tmp_path / "nothing"))

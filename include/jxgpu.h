@@ -337,6 +337,12 @@ int jxg_cross_dot(const void *d_k, int k_is_f64, int64_t n_full, const int32_t *
                   const int32_t *d_cols, int ncols, const double *d_alpha, double beta0, double *d_out,
                   void *stream);
 
+/* Decoded rows of a P32 image: d_out[r][i] = d_lut[r][code(rows[r], i)] for the n selected samples, d_out (nrows, ld >= n)
+ * f32, d_rows = SNP records or NULL for 0 .. nrows-1.  `bed_packed_decode_rows_f32`, src/stats/packed.rs:577-672 (the decode
+ * the reference's Python layer asks for when it wants genotype rows as numbers). */
+int jxg_decode_rows_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                        const float *d_lut, float *d_out, int64_t ld, void *stream);
+
 /* Matrix-free products with the 2-bit genotype matrix of a P32 image (n selected samples, rows = SNP records or NULL
  * for all m_total); the decoded value of (SNP r, sample i) is d_lut[r][code], d_lut (nrows, 4) f32:
  *   jxg_packed_tdot: d_out[r] = sum_i lut[r][code(r,i)] alpha[i]   (nrows)  `compute_malpha_from_meta_stream`,

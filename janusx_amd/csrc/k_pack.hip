@@ -1,5 +1,7 @@
 // 2-bit genotype payload kernels: re-tiling into the P32 layout and per-SNP popcounts.
 // Reference semantics: src/math/bedmath.rs:20-27 (codes), src/io/gfreader.rs:1378-1395 (counts).
+#include <algorithm>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -130,6 +132,34 @@ extern "C" int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, in
                            pad);
         JX_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Decoded rows of a P32 image: out[r][i] = lut[r][code(rows[r], i)], i < n (`bed_packed_decode_rows_f32`,
+// src/stats/packed.rs:577-672).  One workgroup = one (sample tile, row): the 32-byte record is read once (uniform), the 128
+// values of the tile are stored side by side.
+__global__ __launch_bounds__(128) void p32_decode_rows_kernel(const uint32_t *__restrict__ p32, int64_t m_total,
+                                                             const int32_t *__restrict__ rows, int nrows,
+                                                             const float *__restrict__ lut, int n, float *__restrict__ out,
+                                                             int64_t ld) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int i = tile * JXG_TILE + t;
+    for (int r = blockIdx.y; r < nrows; r += gridDim.y) {
+        const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+        const uint32_t w = p32[((int64_t)tile * m_total + rec) * 8 + (t >> 4)];
+        const uint32_t code = (w >> (2 * (t & 15))) & 3u;
+        if (i < n) out[(int64_t)r * ld + i] = lut[(int64_t)r * 4 + code];
+    }
+}
+
+extern "C" int jxg_decode_rows_p32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                   const float *d_lut, float *d_out, int64_t ld, void *stream) {
+    if (nrows <= 0 || n <= 0) return 0;
+    if (ld < n) return fail("jxg_decode_rows_p32: ld must be >= n");
+    const dim3 grid((unsigned)num_tiles(n), (unsigned)std::min(nrows, 65535));
+    hipLaunchKernelGGL(p32_decode_rows_kernel, grid, dim3(128), 0, (hipStream_t)stream, (const uint32_t *)d_p32, m_total,
+                       d_rows, nrows, d_lut, n, d_out, ld);
+    JX_LAUNCH_CHECK();
     return 0;
 }
 

@@ -2736,6 +2736,162 @@ def lm_block_assoc_packed_to_tsv(y, x, ixx, packed, n_samples, row_flip, row_maf
 
 
 # ------------------------------------------------------------------------------------------------
+# Genotype rows as numbers and the two matrix-free products the reference's Python layer asks for beside the path
+# (src/stats/packed.rs:577-760, 2060-2560): decode of selected rows, M'alpha, cross-GRM times alpha
+# ------------------------------------------------------------------------------------------------
+
+def _raw_additive_lut(maf_rows, flip_rows, clamp_low_only):
+    """[0, mean, 1, 2] or flipped per row; mean = max(2 maf, 0) (`bed_packed_decode_rows_f32`, packed.rs:652) or 2 maf as it is
+    (`packed_malpha_f64` / `cross_grm_times_alpha_packed_f64`, packed.rs:2470, 2240)."""
+    maf = np.asarray(maf_rows, dtype=np.float32)
+    mean_g = (np.float32(2.0) * maf).astype(np.float32)
+    if clamp_low_only:
+        mean_g = np.maximum(mean_g, np.float32(0.0))
+    flip = np.asarray(flip_rows).astype(bool)
+    lut = np.empty((len(maf), 4), dtype=np.float32)
+    lut[:, 0] = np.where(flip, 2.0, 0.0)
+    lut[:, 1] = mean_g
+    lut[:, 2] = 1.0
+    lut[:, 3] = np.where(flip, 0.0, 2.0)
+    return lut
+
+
+def _packed_host_checks(packed, n_samples):
+    packed = _c(packed, np.uint8)
+    if packed.ndim != 2:
+        raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    bps = (int(n_samples) + 3) // 4
+    if packed.shape[1] != bps:
+        raise RuntimeError(f"packed second dimension mismatch: got {packed.shape[1]}, expected {bps} for "
+                           f"n_samples={int(n_samples)}")
+    return packed
+
+
+def bed_packed_decode_rows_f32(packed, n_samples, row_indices, row_flip, row_maf, sample_indices=None):
+    """src/stats/packed.rs:577-672: rows `row_indices` of the 2-bit payload as f32 values over `sample_indices` (0 / 1 / 2,
+    missing = max(2 maf, 0), flipped rows 2 - g) -> f32 (len(row_indices), n_out).  `row_flip` / `row_maf` are indexed by
+    payload row when they have one entry per payload row, else by position in `row_indices`."""
+    import torch
+    from . import pipeline as pl
+    packed = _packed_host_checks(packed, n_samples)
+    m = int(packed.shape[0])
+    rows = _c(row_indices, np.int64).ravel()
+    if rows.size and (rows.min() < 0 or rows.max() >= m):
+        raise RuntimeError(f"row_indices out of range for {m} rows")
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    packed_space = flip.shape[0] == m and maf.shape[0] == m
+    if not (packed_space or (flip.shape[0] == rows.shape[0] and maf.shape[0] == rows.shape[0])):
+        raise RuntimeError(f"row_flip/row_maf length mismatch: got row_flip={flip.shape[0]}, row_maf={maf.shape[0]}, expected "
+                           f"either packed_rows={m} or selected_rows={rows.shape[0]}")
+    idx, n_sel = _opt_idx(sample_indices)
+    if idx is not None and n_sel and (idx.min() < 0 or idx.max() >= int(n_samples)):
+        raise RuntimeError("sample_indices out of range")
+    n_out = n_sel if idx is not None else int(n_samples)
+    if n_out == 0 or rows.size == 0:
+        return np.zeros((rows.shape[0], n_out), dtype=np.float32)
+    lut = _raw_additive_lut(maf[rows] if packed_space else maf, flip[rows] if packed_space else flip, True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    payload = torch.from_numpy(np.ascontiguousarray(packed[rows])).to(dev)
+    panel = pl.Panel(payload, int(n_samples), idx)
+    out = torch.empty((rows.shape[0], n_out), dtype=torch.float32, device=dev)
+    lut_t = torch.from_numpy(lut).to(dev)
+    check(lib().jxg_decode_rows_p32(panel.p32.data_ptr(), panel.m, n_out, None, int(rows.shape[0]), lut_t.data_ptr(),
+                                    out.data_ptr(), n_out, pl._stream()))
+    return out.cpu().numpy()
+
+
+def bed_decode_rows_f32_from_meta(prefix, row_indices, row_flip, row_maf, sample_indices=None, mmap_window_mb=None):
+    """src/stats/packed.rs:674-760: `bed_packed_decode_rows_f32` on the rows of a BED prefix (metadata per selected row)."""
+    from .bed import read_bed_payload
+    packed, n_samples, _bim = read_bed_payload(_bed_prefix(prefix))
+    rows = _c(row_indices, np.int64).ravel()
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if flip.shape[0] != rows.shape[0] or maf.shape[0] != rows.shape[0]:
+        raise RuntimeError(f"row meta length mismatch: row_indices={rows.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    if rows.size and (rows.min() < 0 or rows.max() >= packed.shape[0]):
+        raise RuntimeError("row_indices out of range")
+    sub = np.ascontiguousarray(packed[rows])
+    return bed_packed_decode_rows_f32(sub, n_samples, np.arange(rows.shape[0], dtype=np.int64), flip, maf, sample_indices)
+
+
+def _malpha_inputs(packed, n_samples, row_flip, row_maf, sample_indices):
+    import torch
+    from . import pipeline as pl
+    packed = _packed_host_checks(packed, n_samples)
+    m = int(packed.shape[0])
+    if m == 0:
+        raise RuntimeError("packed must contain at least one SNP row")
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if flip.shape[0] != m:
+        raise RuntimeError(f"row_flip length mismatch: got {flip.shape[0]}, expected {m}")
+    if maf.shape[0] != m:
+        raise RuntimeError(f"row_maf length mismatch: got {maf.shape[0]}, expected {m}")
+    idx = _c(sample_indices, np.int64).ravel()
+    if idx.size == 0:
+        raise RuntimeError("sample_indices must not be empty")
+    if idx.min() < 0 or idx.max() >= int(n_samples):
+        raise RuntimeError("sample_indices out of range")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    identity = idx.shape[0] == int(n_samples) and np.array_equal(idx, np.arange(int(n_samples)))
+    panel = pl.Panel(torch.from_numpy(packed).to(dev), int(n_samples), None if identity else idx)
+    lut_t = torch.from_numpy(_raw_additive_lut(maf, flip, False)).to(dev)
+    return panel, lut_t, m, int(idx.shape[0]), dev
+
+
+def packed_malpha_f64(packed, n_samples, row_flip, row_maf, sample_indices, alpha, block_rows=4096, threads=0):
+    """src/stats/packed.rs:2352-2575: m_alpha[r] = sum_j g[r, s_j] alpha[j] over the mean-imputed raw genotypes
+    ([0, 2 maf, 1, 2] or flipped) of the selected samples -> f64 (m).  (`jxg_packed_tdot`: f64 sums on the device; the
+    reference rounds alpha to f32 and sums in an f32 sgemm.)"""
+    import torch
+    from . import pipeline as pl
+    panel, lut_t, m, n_out, dev = _malpha_inputs(packed, n_samples, row_flip, row_maf, sample_indices)
+    a = _c(alpha, np.float64).ravel()
+    if a.shape[0] != n_out:
+        raise RuntimeError(f"alpha length mismatch: got {a.shape[0]}, expected {n_out} (len(sample_indices))")
+    out = torch.empty(m, dtype=torch.float64, device=dev)
+    check(lib().jxg_packed_tdot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(),
+                                torch.from_numpy(a).to(dev).data_ptr(), out.data_ptr(), pl._stream()))
+    return out.cpu().numpy()
+
+
+def cross_grm_times_alpha_packed_f64(packed, n_samples, row_flip, row_maf, sample_indices, m_alpha, m_mean, alpha_sum,
+                                     mean_sq, mean_malpha, m_var_sum, block_rows=4096, threads=0):
+    """src/stats/packed.rs:2060-2350: K_cross alpha for the samples `sample_indices` without the cross GRM:
+    ((M_s' m_alpha) - (M_s' m_mean) alpha_sum + mean_sq alpha_sum - mean_malpha) / m_var_sum -> f64 (n_out, 1)
+    (`jxg_packed_dot`, two passes over the payload)."""
+    import math
+    import torch
+    from . import pipeline as pl
+    if int(n_samples) <= 0:
+        raise RuntimeError("n_samples must be > 0")
+    if not (math.isfinite(m_var_sum) and m_var_sum > 0.0):
+        raise RuntimeError("m_var_sum must be finite and > 0 for compact cross-GRM prediction")
+    if not (math.isfinite(alpha_sum) and math.isfinite(mean_sq) and math.isfinite(mean_malpha)):
+        raise RuntimeError("alpha_sum/mean_sq/mean_malpha must be finite")
+    panel, lut_t, m, n_out, dev = _malpha_inputs(packed, n_samples, row_flip, row_maf, sample_indices)
+    ma = _c(m_alpha, np.float64).ravel()
+    mm = _c(m_mean, np.float64).ravel()
+    if ma.shape[0] != m:
+        raise RuntimeError(f"m_alpha length mismatch: got {ma.shape[0]}, expected {m}")
+    if mm.shape[0] != m:
+        raise RuntimeError(f"m_mean length mismatch: got {mm.shape[0]}, expected {m}")
+    t1 = torch.empty(n_out, dtype=torch.float64, device=dev)
+    t2 = torch.empty(n_out, dtype=torch.float64, device=dev)
+    for vec, dst in ((ma, t1), (mm, t2)):
+        check(lib().jxg_packed_dot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(),
+                                   torch.from_numpy(vec).to(dev).data_ptr(), dst.data_ptr(), pl._stream()))
+    const_term = float(mean_sq) * float(alpha_sum) - float(mean_malpha)
+    out = (t1.cpu().numpy() - t2.cpu().numpy() * float(alpha_sum) + const_term) * (1.0 / float(m_var_sum))
+    return out.reshape(-1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
 # GBLUP (`jx gs -BLUP`, n <= 15 000 branch): src/stats/gblup.rs:1242-1516 `gblup_reml_npy_grm`
 # ------------------------------------------------------------------------------------------------
 

@@ -2957,3 +2957,67 @@ def test_qc_prepass_and_bim_columns_for_the_sparse_routes(oracle, tmp_path):
         jxrs.load_bim_columns(prefix, np.array([-1]))
     with pytest.raises(ValueError, match="requires a PLINK"):
         jxrs.load_bim_columns(str(tmp_path / "nothing"))
+
+
+@pytest.mark.gpu
+def test_decoded_rows_and_matrix_free_products_beside_the_path(oracle, tmp_path):
+    """`bed_packed_decode_rows_f32` / `bed_decode_rows_f32_from_meta` (src/stats/packed.rs:577-760; bit-exact: a table lookup),
+    `packed_malpha_f64` (:2352-2575) and `cross_grm_times_alpha_packed_f64` (:2060-2350), the helpers of the reference's GBLUP
+    Python layer (python/janusx/pyBLUP/mlm.py:402-1870, gs/workflow.py:2465, 8368), against numpy on the decoded matrix."""
+    from janusx_amd import janusx as jxrs
+    n, m = 263, 350
+    packed, g = bed.synth_panel_numpy(n, m, seed=59, missing_rate=0.04)
+    rng = np.random.default_rng(6)
+    mi, he, ho = oracle.row_counts(packed, n)
+    _k, maf, _miss, _f = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.0, 1.0, 1.0)
+    maf[3] = np.float32(-0.1)                                  # a negative "maf": the decode clamps the mean at 0, the products do not
+    flip = rng.random(m) < 0.3
+    codes = oracle.unpack_codes(packed, n)
+
+    def dense(rows, cols, clamp):
+        out = np.empty((len(rows), len(cols)), dtype=np.float32)
+        for k, r in enumerate(rows):
+            mg = np.float32(2.0) * maf[r]
+            if clamp:
+                mg = max(mg, np.float32(0.0))
+            lut = np.array([2.0, mg, 1.0, 0.0] if flip[r] else [0.0, mg, 1.0, 2.0], dtype=np.float32)
+            out[k] = lut[codes[r, cols]]
+        return out
+
+    rows = np.array([5, 3, 300, 3, 0], dtype=np.int64)
+    for sub in (None, np.array([7, 0, 262, 130, 131], dtype=np.int64), np.sort(rng.permutation(n)[:200]).astype(np.int64)):
+        cols = np.arange(n) if sub is None else sub
+        want = dense(rows, cols, True)
+        got = jxrs.bed_packed_decode_rows_f32(packed, n, rows, flip, maf, sub)                   # metadata per payload row
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        got2 = jxrs.bed_packed_decode_rows_f32(packed, n, rows, flip[rows], maf[rows], sub)      # compact metadata
+        assert np.array_equal(got2, want)
+    assert jxrs.bed_packed_decode_rows_f32(packed, n, rows, flip, maf, np.zeros(0, dtype=np.int64)).shape == (5, 0)
+    with pytest.raises(RuntimeError, match="row_flip/row_maf length mismatch"):
+        jxrs.bed_packed_decode_rows_f32(packed, n, rows, flip[:7], maf[:7])
+    prefix = str(tmp_path / "d")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    sub = np.sort(rng.permutation(n)[:77]).astype(np.int64)
+    assert np.array_equal(jxrs.bed_decode_rows_f32_from_meta(prefix, rows, flip[rows], maf[rows], sub), dense(rows, sub, True))
+    # M' alpha and the compact cross-GRM prediction
+    tr = np.sort(rng.permutation(n)[:180]).astype(np.int64)
+    te = np.setdiff1d(np.arange(n), tr)[:60].astype(np.int64)
+    alpha = rng.normal(size=len(tr))
+    mtr = dense(np.arange(m), tr, False).astype(np.float64)
+    mal = jxrs.packed_malpha_f64(packed, n, flip, maf, tr, alpha)
+    ref = mtr @ alpha
+    assert mal.shape == (m,) and np.max(np.abs(mal - ref)) < 1e-10 * np.max(np.abs(ref))
+    m_mean = mtr.mean(axis=1)
+    a_sum, mean_sq, mean_mal, vs = float(alpha.sum()), float(m_mean @ m_mean), float(m_mean @ ref), 37.5
+    mte = dense(np.arange(m), te, False).astype(np.float64)
+    want = ((mte.T @ ref) - (mte.T @ m_mean) * a_sum + (mean_sq * a_sum - mean_mal)) / vs
+    got = jxrs.cross_grm_times_alpha_packed_f64(packed, n, flip, maf, te, mal, m_mean, a_sum, mean_sq, mean_mal, vs)
+    assert got.shape == (len(te), 1) and np.max(np.abs(got.ravel() - want)) < 1e-9 * np.max(np.abs(want))
+    # = (centred cross GRM) alpha, the quantity it stands for
+    kx = (mte - m_mean[:, None]).T @ (mtr - m_mean[:, None]) / vs
+    assert np.max(np.abs(kx @ alpha - want)) < 1e-9 * np.max(np.abs(want))
+    with pytest.raises(RuntimeError, match="alpha length mismatch"):
+        jxrs.packed_malpha_f64(packed, n, flip, maf, tr, alpha[:-1])
+    with pytest.raises(RuntimeError, match="m_var_sum"):
+        jxrs.cross_grm_times_alpha_packed_f64(packed, n, flip, maf, te, mal, m_mean, a_sum, mean_sq, mean_mal, 0.0)

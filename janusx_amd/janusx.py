@@ -2855,8 +2855,9 @@ def packed_malpha_f64(packed, n_samples, row_flip, row_maf, sample_indices, alph
     if a.shape[0] != n_out:
         raise RuntimeError(f"alpha length mismatch: got {a.shape[0]}, expected {n_out} (len(sample_indices))")
     out = torch.empty(m, dtype=torch.float64, device=dev)
-    check(lib().jxg_packed_tdot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(),
-                                torch.from_numpy(a).to(dev).data_ptr(), out.data_ptr(), pl._stream()))
+    a_t = torch.from_numpy(a).to(dev)
+    check(lib().jxg_packed_tdot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(), a_t.data_ptr(),
+                                out.data_ptr(), pl._stream()))
     return out.cpu().numpy()
 
 
@@ -2884,8 +2885,9 @@ def cross_grm_times_alpha_packed_f64(packed, n_samples, row_flip, row_maf, sampl
     t1 = torch.empty(n_out, dtype=torch.float64, device=dev)
     t2 = torch.empty(n_out, dtype=torch.float64, device=dev)
     for vec, dst in ((ma, t1), (mm, t2)):
-        check(lib().jxg_packed_dot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(),
-                                   torch.from_numpy(vec).to(dev).data_ptr(), dst.data_ptr(), pl._stream()))
+        v_t = torch.from_numpy(vec).to(dev)
+        check(lib().jxg_packed_dot(panel.p32.data_ptr(), panel.m, n_out, None, m, lut_t.data_ptr(), v_t.data_ptr(),
+                                   dst.data_ptr(), pl._stream()))
     const_term = float(mean_sq) * float(alpha_sum) - float(mean_malpha)
     out = (t1.cpu().numpy() - t2.cpu().numpy() * float(alpha_sum) + const_term) * (1.0 / float(m_var_sum))
     return out.reshape(-1, 1)
@@ -2942,17 +2944,11 @@ def gblup_reml_grm(grm, train_sample_indices, y_train, test_sample_indices=None,
             np.zeros(0, dtype=np.float64))
 
 
-def _gblup_meta_grm(rows_payload, n_samples, tr, flip, maf):
-    """Centred-additive GRM of the samples `tr` over the payload rows with the caller's flip / maf metadata, the
-    formulation of `build_grm_from_meta_stream` (src/stats/gblup.rs:406-652; per-row centring and variance of
-    `decode_meta_block_f32` :239-404, bedmath.rs:1359-1441 for a sample subset) -> (K f64 (n_tr, n_tr) on the device,
-    scaled by 1 / sum(var); sum(var); the panel; the row means in f64)."""
-    import torch
-    from . import pipeline as pl
+def _gblup_meta_lut(maf, flip, identity):
+    """Centred additive decode of `decode_meta_block_f32` (src/stats/gblup.rs:239-404; bedmath.rs:1359-1441 for a sample
+    subset) -> (LUT (m, 4) f32 of centred values, missing = 0; sum of the row variances; row means f64)."""
     from . import stats as st
-    n_tr = int(tr.shape[0])
-    m = int(rows_payload.shape[0])
-    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
+    m = int(maf.shape[0])
     mafc = np.clip(maf, np.float32(0.0), np.float32(1.0))
     if identity:
         p64 = mafc.astype(np.float64)
@@ -2965,8 +2961,74 @@ def _gblup_meta_grm(rows_payload, n_samples, tr, flip, maf):
         pg = np.clip(np.float32(0.5) * mean32, np.float32(0.0), np.float32(1.0))
         var = np.maximum(np.float32(2.0) * pg * (np.float32(1.0) - pg), np.float32(0.0)).astype(np.float64)
         row_mean = mean32.astype(np.float64)
-    var_sum = float(np.sum(var))
-    glut = st.grm_lut_from_mean_scale(mean32, np.ones(m, dtype=np.float32), flip)
+    return st.grm_lut_from_mean_scale(mean32, np.ones(m, dtype=np.float32), flip), float(np.sum(var)), row_mean
+
+
+def gblup_effect_from_meta_stream(prefix, sample_indices, alpha, row_source_indices, row_flip, row_maf, mode="a",
+                                  block_rows=4096, threads=0, mmap_window_mb=None):
+    """src/stats/gblup.rs:2788-2895 -> `compute_effect_beta_from_meta_stream` (:930-1033): marker effects
+    beta[r] = sum_j z[r, s_j] alpha[j] / sum(var) over the centred decode of the caller-prepared BED rows (the marker-effect
+    output of `jx gs -BLUP`, python/janusx/gs/workflow.py:5103) -> f64 (m).  `jxg_packed_tdot` on the centred LUT."""
+    import torch
+    from . import pipeline as pl
+    from .bed import stage_bed_payload
+    mode_n = str(mode).strip().lower()
+    if mode_n not in ("a", "add", "additive", "d", "dom", "dominance"):
+        raise RuntimeError("mode must be one of {'a','additive','d','dominance'}")
+    if mode_n in ("d", "dom", "dominance"):
+        raise RuntimeError("mode 'dominance' is outside this build's scope (additive model only)")
+    packed, n_fam, _bim = stage_bed_payload(_bed_prefix(prefix), mmap_window_mb)
+    if n_fam == 0:
+        raise RuntimeError("No samples found in BED input.")
+    tr = _c(sample_indices, np.int64).ravel()
+    if tr.size and (tr.min() < 0 or tr.max() >= n_fam):
+        raise RuntimeError("sample_indices out of range")
+    a = _c(alpha, np.float64).ravel()
+    if a.shape[0] != tr.shape[0]:
+        raise RuntimeError(f"alpha length mismatch: got {a.shape[0]}, expected {tr.shape[0]}")
+    src = _c(row_source_indices, np.int64).ravel()
+    if src.size == 0:
+        raise RuntimeError("row_source_indices must not be empty.")
+    if (src < 0).any():
+        raise RuntimeError("row_source_indices must be non-negative.")
+    flip = np.asarray(row_flip).astype(bool).ravel()
+    maf = _c(row_maf, np.float32).ravel()
+    if flip.shape[0] != src.shape[0] or maf.shape[0] != src.shape[0]:
+        raise RuntimeError(f"metadata length mismatch: row_source_indices={src.shape[0]}, row_flip={flip.shape[0]}, "
+                           f"row_maf={maf.shape[0]}")
+    if tr.size == 0:
+        raise RuntimeError("compute_effect_beta_from_meta_stream: sample_idx must not be empty")
+    if int(src.max()) >= int(packed.shape[0]):
+        raise RuntimeError("row_source_indices out of range")
+    identity = tr.shape[0] == n_fam and np.array_equal(tr, np.arange(n_fam))
+    glut, var_sum, _row_mean = _gblup_meta_lut(maf, flip, identity)
+    if not (np.isfinite(var_sum) and var_sum > 0.0):
+        raise RuntimeError("compute_effect_beta_from_meta_stream: invalid denominator")
+    dev = packed.device
+    rows_payload = packed[torch.from_numpy(src).to(dev)]
+    del packed
+    panel = pl.Panel(rows_payload, n_fam, None if identity else tr)
+    m = int(src.shape[0])
+    out = torch.empty(m, dtype=torch.float64, device=dev)
+    lut_t = torch.from_numpy(np.ascontiguousarray(glut, dtype=np.float32)).to(dev)     # named: alive until the launch is queued
+    a_t = torch.from_numpy(a).to(dev)
+    check(lib().jxg_packed_tdot(panel.p32.data_ptr(), panel.m, int(tr.shape[0]), None, m, lut_t.data_ptr(), a_t.data_ptr(),
+                                out.data_ptr(), pl._stream()))
+    return out.cpu().numpy() * (1.0 / var_sum)
+
+
+def _gblup_meta_grm(rows_payload, n_samples, tr, flip, maf):
+    """Centred-additive GRM of the samples `tr` over the payload rows with the caller's flip / maf metadata, the
+    formulation of `build_grm_from_meta_stream` (src/stats/gblup.rs:406-652; per-row centring and variance of
+    `decode_meta_block_f32` :239-404, bedmath.rs:1359-1441 for a sample subset) -> (K f64 (n_tr, n_tr) on the device,
+    scaled by 1 / sum(var); sum(var); the panel; the row means in f64)."""
+    import torch
+    from . import pipeline as pl
+    from . import stats as st
+    n_tr = int(tr.shape[0])
+    m = int(rows_payload.shape[0])
+    identity = n_tr == n_samples and np.array_equal(tr, np.arange(n_samples))
+    glut, var_sum, row_mean = _gblup_meta_lut(maf, flip, identity)
     panel = pl.Panel(rows_payload, n_samples, None if identity else tr)
     acc = pl.grm_accumulate(panel, np.arange(m, dtype=np.int64), glut)
     k = pl.grm_finalize(acc, n_tr, var_sum, torch.float64)

@@ -339,7 +339,7 @@ def test_reference_python_layer_import_surface():
                   gblup_grm_from_meta_to_npy grm_bed_f32_row_band_from_meta grm_bed_f32_row_band_from_meta_to_npy
                   grm_bed_f32_tiled_from_meta_to_npy prepare_bed_logic_meta_selected load_bim_columns
                   bed_packed_decode_rows_f32 bed_decode_rows_f32_from_meta packed_malpha_f64
-                  cross_grm_times_alpha_packed_f64""".split()
+                  cross_grm_times_alpha_packed_f64 gblup_effect_from_meta_stream""".split()
     for name in hard + optional:
         assert callable(getattr(jxrs, name, None)), name
     with pytest.raises(RuntimeError, match="outside the mixed-model hot path"):

@@ -3021,3 +3021,45 @@ def test_decoded_rows_and_matrix_free_products_beside_the_path(oracle, tmp_path)
         jxrs.packed_malpha_f64(packed, n, flip, maf, tr, alpha[:-1])
     with pytest.raises(RuntimeError, match="m_var_sum"):
         jxrs.cross_grm_times_alpha_packed_f64(packed, n, flip, maf, te, mal, m_mean, a_sum, mean_sq, mean_mal, 0.0)
+
+
+@pytest.mark.gpu
+def test_gblup_effect_from_meta_stream(oracle, tmp_path):
+    """`gblup_effect_from_meta_stream` (src/stats/gblup.rs:2788-2895, 930-1033): marker effects Z' alpha / sum(var) from
+    caller-prepared BED rows, whole cohort and a training subset, against the centred decode of the restatement."""
+    from janusx_amd import janusx as jxrs
+    n, m = 231, 480
+    packed, g = bed.synth_panel_numpy(n, m, seed=67, missing_rate=0.03)
+    prefix = str(tmp_path / "e")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(9)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, _miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    src = np.nonzero(keep)[0].astype(np.int64)[::2]
+    for tr in (np.arange(n, dtype=np.int64), np.sort(rng.permutation(n)[:170]).astype(np.int64)):
+        alpha = rng.normal(size=len(tr))
+        # the restatement's GRM is Z'Z / sum(var): recover Z' alpha / sum(var) from two GRM-vector identities is roundabout --
+        # decode the centred rows as `grm_from_meta_additive` does and multiply
+        k, _rs, var_sum = oracle.grm_from_meta_additive(packed, n, src, flip[src], maf[src], tr)
+        codes = oracle.unpack_codes(np.ascontiguousarray(packed[src]), n)
+        ident = len(tr) == n
+        z = np.empty((len(src), len(tr)), dtype=np.float32)
+        for r in range(len(src)):
+            mr, fl = maf[src][r], bool(flip[src][r])
+            if ident:
+                mg32 = np.float32(2.0 * float(min(max(mr, np.float32(0.0)), np.float32(1.0))))
+                lut = np.array([2.0, mg32, 1.0, 0.0] if fl else [0.0, mg32, 1.0, 2.0], dtype=np.float32)
+                z[r] = lut[codes[r]] - mg32
+            else:
+                dmg = np.float32(2.0) * min(max(mr, np.float32(0.0)), np.float32(1.0))
+                lut = np.array([2.0, dmg, 1.0, 0.0] if fl else [0.0, dmg, 1.0, 2.0], dtype=np.float32)
+                z[r] = lut[codes[r, tr]] - dmg
+        assert np.max(np.abs((z.astype(np.float64).T @ z.astype(np.float64)) / var_sum - k)) < 1e-6 * np.max(np.abs(k))
+        want = (z.astype(np.float64) @ alpha) / var_sum
+        got = jxrs.gblup_effect_from_meta_stream(prefix, tr, alpha, src, flip[src], maf[src])
+        assert got.shape == (len(src),) and np.max(np.abs(got - want)) < 1e-10 * np.max(np.abs(want))
+    with pytest.raises(RuntimeError, match="mode must be one of"):
+        jxrs.gblup_effect_from_meta_stream(prefix, tr, alpha, src, flip[src], maf[src], mode="x")
+    with pytest.raises(RuntimeError, match="alpha length mismatch"):
+        jxrs.gblup_effect_from_meta_stream(prefix, tr, alpha[:-1], src, flip[src], maf[src])

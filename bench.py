@@ -620,14 +620,19 @@ def main():
             try:
                 leg = run_leg(20000, 200000, 0.01, 2, 1)
                 sm = leg_summary(leg, 20000, 2)
-                mu_g, mu_g_src = pmc_mfma_util("grm_f16x2_kernel<128, 128, 64, 64, false, false", "mfma_missing1pct")
+                mu_g, mu_g_src = pmc_mfma_util("grm_i8_kernel", "mfma_missing1pct")
                 mu_r, mu_r_src = pmc_mfma_util("rotate256_kernel", "mfma_missing1pct")
-                res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_f16x2_kernel (SNPs with a missing call among "
-                                                       "the samples: fp16 hi/lo three-product variant)",
+                res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_i8_kernel + gm_spmm_kernel (SNPs with missing "
+                                                       "calls: exact int8 Gram of the clean form + sparse correction, "
+                                                       "csrc/k_grm_miss.hip)",
                                                        mfma_util_pmc=mu_g, mfma_util_source=mu_g_src,
                                                        note="2 timed steps of the configs[2] shape with 1 % missing calls; "
-                                                            "algorithmic n(n+1)m flops over the whole accumulate call; the "
-                                                            "kernel issues three f16 products per algorithmic product")
+                                                            "algorithmic n(n+1)m flops over the whole accumulate call, priced "
+                                                            "against the int8 peak (all SNPs take the int8 Gram); about a fifth of "
+                                                            "the call is that MFMA kernel, the rest is the correction W + W' for "
+                                                            "the missing calls -- nnz(e) n table lookups, VALU / LDS bound, f64 "
+                                                            "sums (229 ms on the fp16 three-product kernel it replaces up to "
+                                                            "1.2 % missing calls: JXGPU_GRM_MISS=0)")
                 res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"],
                                                           kernel="rotate256_kernel (fp16 hi/lo, three products: every row has a "
                                                                  "missing call at this rate)",

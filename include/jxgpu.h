@@ -67,8 +67,12 @@ int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, int32_t *d_co
  * d_rows may be NULL (identity).  d_acc is (n_pad, n_pad) f64 row-major, n_pad = 128*tiles; only tiles
  * (ti >= tj) are written.  Numerics: value LUT split into fp16 hi+lo, three MFMA products with f32
  * accumulation over <= kchunk SNPs, f64 merge -- the counterpart of the reference's f32 SSYRK per block +
- * f64 merge (src/stats/grm.rs:1638-1667, 1700-1772).  precision: 0 = fp16x2 split (default), 1 = exact
- * f32 MFMA.  kchunk <= 0 selects the default (8192). */
+ * f64 merge (src/stats/grm.rs:1638-1667, 1700-1772).  SNPs whose values are b + {0, 1, 2} (either orientation) run as
+ * an exact integer Gram on the int8 matrix pipes with f64 affine terms; with missing calls they additionally get the sparse
+ * correction of k_grm_miss.hip (whole-triangle calls; f64, independent of scheduling).  precision: 0 = default,
+ * 2 = rows with missing calls stay on the fp16 split kernel (what row-panel calls always do; the sparse-GRM builder
+ * passes it so that its file does not depend on the memory plan), 1 = exact f32 MFMA (not built).  kchunk <= 0 selects
+ * the default (8192). */
 int jxg_grm_accumulate(const uint8_t *d_p32, int64_t m_total, int n_sel, const int32_t *d_rows,
                        const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
                        void *stream);

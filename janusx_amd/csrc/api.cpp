@@ -389,7 +389,7 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
             const int b1 = std::min(nbands, b0 + bands_per);
             const int t0 = b0 * 2, t1 = std::min((int)num_tiles(n), b1 * 2);       // 128-row tiles of the bands
             JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)((int64_t)(t1 - t0) * JXG_TILE * npad)));
-            if (jxg_grm_accumulate_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, t0, t1,
+            if (jxg_grm_accumulate_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 2, t0, t1,
                                         nullptr))
                 return 1;
             if (jxg_spgrm_count_bands(acc.as<double>(), n, inv, threshold, abs_threshold, b0, b1, work.p,
@@ -440,7 +440,9 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
     } else {
         if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
         JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));
-        if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 0, nullptr))
+        // precision 2: rows with missing calls on the general kernel, as in the row-panel form above (one file whatever the
+        // memory plan)
+        if (jxg_grm_accumulate(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, acc.as<double>(), 0, 2, nullptr))
             return 1;
         p32.release();
         if (work.alloc((size_t)jxg_spgrm_work_bytes(n))) return 1;

@@ -365,7 +365,8 @@ __global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__rest
                                                            const int32_t *__restrict__ rows,
                                                            const float *__restrict__ lut, int64_t mk, int n_sel,
                                                            int nt128, int32_t *__restrict__ flag,
-                                                           double *__restrict__ beta, float *__restrict__ ilut) {
+                                                           double *__restrict__ beta, float *__restrict__ ilut,
+                                                           unsigned long long *__restrict__ miss_total) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const float v0 = lut[k * 4 + 0], v2 = lut[k * 4 + 2], v3 = lut[k * 4 + 3];
@@ -376,9 +377,10 @@ __global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__rest
               ((fabsf(c0) <= tol && fabsf(c3 - 2.0f) <= tol) || (fabsf(c0 - 2.0f) <= tol && fabsf(c3) <= tol)) &&
               fabsf(b) <= 4.0f;
     const float r0 = (c0 > 1.0f) ? 2.0f : 0.0f, r3 = 2.0f - r0;
+    int fl = 1;
     if (ok) {
         const int64_t rec = rows ? (int64_t)rows[k] : k;
-        uint32_t any = 0;
+        uint32_t any = 0, nmiss = 0;
         for (int t = 0; t < nt128; ++t) {
             const uint4 *q = reinterpret_cast<const uint4 *>(p32 + ((int64_t)t * m_total + rec) * 32);
             const uint4 a = q[0], c = q[1];
@@ -391,11 +393,18 @@ __global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__rest
                 if (left <= 0) miss = 0;
                 else if (left < 16) miss &= (1u << (2 * left)) - 1u;
                 any |= miss;
+                nmiss += __popc(miss);
             }
         }
-        ok = (any == 0);
+        // flag 2: affine in the count but with missing calls -- int8 Gram + the sparse correction of k_grm_miss.hip
+        // (the missing call's own LUT value must be finite)
+        if (any != 0) {
+            fl = isfinite(lut[k * 4 + 1]) ? 2 : 0;
+            if (fl == 2 && miss_total) atomicAdd(miss_total, (unsigned long long)nmiss);
+        }
+        ok = fl != 0;
     }
-    flag[k] = ok ? 1 : 0;
+    flag[k] = ok ? fl : 0;
     beta[k] = ok ? ((double)(v0 - r0) + (double)(v2 - 1.0f) + (double)(v3 - r3)) / 3.0 : 0.0;
     ilut[k * 4 + 0] = r0;
     ilut[k * 4 + 1] = 0.0f;
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(1024) void grm_partition_kernel(const int32_t *__re
     const int64_t per = (mk + 1023) / 1024;
     const int64_t b = tid * per, e = (b + per < mk) ? b + per : mk;
     int64_t cnt = 0;
-    for (int64_t k = b; k < e; ++k) cnt += flag[k];
+    for (int64_t k = b; k < e; ++k) cnt += flag[k] != 0;
     part[tid] = cnt;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
@@ -429,6 +438,12 @@ __global__ __launch_bounds__(1024) void grm_partition_kernel(const int32_t *__re
     if (tid == 0) info[0] = (int32_t)total;
 }
 
+// the rows with missing calls go to the general kernel after all (panel mode, too many missing calls, JXGPU_GRM_MISS=0)
+__global__ __launch_bounds__(256) void grm_demote_kernel(int32_t *__restrict__ flag, int64_t mk) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < mk && flag[k] == 2) flag[k] = 0;
+}
+
 // reordered SNP list: rows2, split LUT (integer LUT below the 32-aligned exact prefix), f32 integer LUT and beta for
 // the affine terms (zero beyond the prefix); info[1] |= 1 if a general value leaves the safe fp16 range.
 __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restrict__ rows, const float *__restrict__ lut,
@@ -436,12 +451,29 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ pos, int64_t mk,
                                                          int32_t *__restrict__ info, int32_t *__restrict__ rows2,
                                                          uint4 *__restrict__ lut16, float *__restrict__ ilut2,
-                                                         double *__restrict__ beta2, int i8mode) {
+                                                         double *__restrict__ beta2, int i8mode,
+                                                         const int32_t *__restrict__ flag, uint8_t *__restrict__ miss2,
+                                                         double *__restrict__ wl) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const int32_t nex = info[0] & ~63;
     const int32_t dst = pos[k];
     const bool exact = dst < nex;
+    if (miss2) {
+        // table of the sparse correction (k_grm_miss.hip): clean-form value b + s c by code, d = lut(missing) - b
+        const bool m2 = exact && flag[k] == 2;
+        miss2[dst] = m2 ? 1 : 0;
+        if (exact) {
+            const double r0d = (double)ilut[k * 4 + 0];
+            const double bb = beta[k] + r0d, ss = (r0d == 0.0) ? 1.0 : -1.0;
+            const double d = m2 ? (double)lut[k * 4 + 1] - bb : 0.0;
+            double *t = wl + (int64_t)dst * 4;
+            t[0] = d * bb;
+            t[1] = d * (bb + 0.5 * d);
+            t[2] = d * (bb + ss);
+            t[3] = d * (bb + 2.0 * ss);
+        }
+    }
     rows2[dst] = rows ? rows[k] : (int32_t)k;
     uint16_t hi[4], lo[4];
     bool bad = false;
@@ -542,6 +574,8 @@ static EventPair g_grm_ev;
 namespace jx {
 int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, int64_t r0, int64_t r1, int nt128,
                   double *d_acc, int64_t ld, const double *corr, bool panel, int tile_row_begin, int tile_row_end);
+int grm_missing_correction(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n_sel, int nt, const int32_t *rows2,
+                           const uint8_t *miss2, const double *wl, int64_t nex, double *d_acc, int64_t ld);
 }
 
 extern "C" int jxg_debug_occupancy(int *out) {
@@ -587,7 +621,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                                        const float *d_lut, int64_t mk, double *d_acc, int kchunk, int precision,
                                        int tile_row_begin, int tile_row_end, void *stream) {
     if (mk <= 0) return 0;
-    if (precision != 0) return fail("jxg_grm_accumulate: precision=1 (f32 MFMA) path not built yet");
+    if (precision != 0 && precision != 2) return fail("jxg_grm_accumulate: precision=1 (f32 MFMA) path not built yet");
     hipStream_t st = (hipStream_t)stream;
     const int nt = num_tiles(n_sel);
     const int64_t ld = (int64_t)nt * JXG_TILE;
@@ -600,7 +634,12 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     // exact prefix on the int8 matrix pipes (k_grm_i8.hip); JXGPU_GRM_I8=0 keeps the fp16 single-product variant
     static const int i8_env = getenv("JXGPU_GRM_I8") ? atoi(getenv("JXGPU_GRM_I8")) : 1;
     if (mk > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many SNPs in one call");
-    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb;
+    const int miss_env = getenv("JXGPU_GRM_MISS") ? atoi(getenv("JXGPU_GRM_MISS")) : 1;
+    // largest share of missing calls (over the rows that hold any) for which the sparse correction is taken: its cost grows
+    // with the number of missing calls (nnz n table lookups), the split kernel's does not; measured at n = 20000,
+    // m = 200000: 54 ms + 11.5 ms per 0.1 % against 229 ms, i.e. a crossover at ~1.5 %
+    const double miss_max = getenv("JXGPU_GRM_MISS_MAX") ? atof(getenv("JXGPU_GRM_MISS_MAX")) : 0.012;
+    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb;
     if (lut16.alloc(sizeof(uint4) * (size_t)mk) || flagb.alloc(sizeof(int32_t) * (size_t)mk) ||
         betab.alloc(sizeof(double) * (size_t)mk) || ilutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
         posb.alloc(sizeof(int32_t) * (size_t)mk) || infob.alloc(2 * sizeof(int32_t)) ||
@@ -609,10 +648,26 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
         return 1;
     JX_HIP(hipMemsetAsync(infob.p, 0, 2 * sizeof(int32_t), st));
     const unsigned gk = (unsigned)((mk + 255) / 256);
+    // rows that are affine in the count but hold missing calls: int8 Gram + sparse correction (k_grm_miss.hip) when the whole
+    // triangle is built here (not a row panel), the int8 path is on and the missing calls are few enough (miss_max)
+    bool use_miss = exact_env && i8_env && miss_env && tile_row_end < 0 && precision != 2;
+    if (use_miss && misstotb.alloc(sizeof(unsigned long long))) return 1;
+    if (use_miss) JX_HIP(hipMemsetAsync(misstotb.p, 0, sizeof(unsigned long long), st));
     if (exact_env) {
         hipLaunchKernelGGL(grm_classify_kernel, dim3(gk), dim3(256), 0, st, d_p32, m_total, d_rows, d_lut, mk, n_sel, nt,
-                           flagb.as<int32_t>(), betab.as<double>(), ilutb.as<float>());
+                           flagb.as<int32_t>(), betab.as<double>(), ilutb.as<float>(),
+                           use_miss ? misstotb.as<unsigned long long>() : (unsigned long long *)nullptr);
         JX_LAUNCH_CHECK();
+        if (use_miss) {
+            unsigned long long hm = 0;
+            JX_HIP(hipMemcpyAsync(&hm, misstotb.p, sizeof(hm), hipMemcpyDeviceToHost, st));
+            JX_HIP(hipStreamSynchronize(st));
+            if (hm == 0 || (double)hm > miss_max * (double)mk * (double)n_sel || hm > 0x7fffffffULL) use_miss = false;
+        }
+        if (!use_miss) {
+            hipLaunchKernelGGL(grm_demote_kernel, dim3(gk), dim3(256), 0, st, flagb.as<int32_t>(), mk);
+            JX_LAUNCH_CHECK();
+        }
     } else {
         JX_HIP(hipMemsetAsync(flagb.p, 0, sizeof(int32_t) * (size_t)mk, st));
         JX_HIP(hipMemsetAsync(ilutb.p, 0, sizeof(float) * 4 * (size_t)mk, st));
@@ -621,9 +676,11 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     hipLaunchKernelGGL(grm_partition_kernel, dim3(1), dim3(1024), 0, st, flagb.as<int32_t>(), mk, posb.as<int32_t>(),
                        infob.as<int32_t>());
     JX_LAUNCH_CHECK();
+    if (use_miss && (miss2b.alloc((size_t)mk) || wlb.alloc(sizeof(double) * 4 * (size_t)mk))) return 1;
     hipLaunchKernelGGL(grm_gather_kernel, dim3(gk), dim3(256), 0, st, d_rows, d_lut, ilutb.as<float>(),
                        betab.as<double>(), posb.as<int32_t>(), mk, infob.as<int32_t>(), rows2b.as<int32_t>(),
-                       lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>(), i8_env);
+                       lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>(), i8_env, flagb.as<int32_t>(),
+                       use_miss ? miss2b.as<uint8_t>() : (uint8_t *)nullptr, use_miss ? wlb.as<double>() : (double *)nullptr);
     JX_LAUNCH_CHECK();
     int32_t hinfo[2] = {0, 0};
     JX_HIP(hipMemcpyAsync(hinfo, infob.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -726,6 +783,13 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
         if (launch_grm_i8(st, d_p32, m_total, rows2, 0, n_exact, nt, d_acc, ld, n_exact > 0 ? corrb.as<double>() : nullptr,
                           panel, tile_row_begin, tile_row_end))
             return 1;
+        if (use_miss && n_exact > 0) {
+            const int rc = grm_missing_correction(st, d_p32, m_total, n_sel, nt, rows2, miss2b.as<uint8_t>(), wlb.as<double>(),
+                                                  n_exact, d_acc, ld);
+            if (rc == 2) return fail("jxg_grm_accumulate: not enough device memory for the missing-call correction "
+                                     "(set JXGPU_GRM_MISS=0 to take the general kernel for rows with missing calls)");
+            if (rc) return 1;
+        }
     } else if (run_range(true, 0, n_exact)) {
         return 1;
     }

@@ -3063,3 +3063,34 @@ def test_gblup_effect_from_meta_stream(oracle, tmp_path):
         jxrs.gblup_effect_from_meta_stream(prefix, tr, alpha, src, flip[src], maf[src], mode="x")
     with pytest.raises(RuntimeError, match="alpha length mismatch"):
         jxrs.gblup_effect_from_meta_stream(prefix, tr, alpha[:-1], src, flip[src], maf[src])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,rate", [(333, 900, 0.02), (700, 2100, 0.004), (129, 300, 0.2)])
+def test_grm_missing_calls_sparse_correction(oracle, monkeypatch, n, m, rate):
+    """Rows with missing calls on the int8 Gram + sparse correction (csrc/k_grm_miss.hip; src/stats/grm.rs:1638-1772 with the
+    mean-imputing decode of src/decode/decode.rs:813-839): forced on (`JXGPU_GRM_MISS_MAX=1`) against the oracle at TOL and against
+    the fp16 split kernel (`JXGPU_GRM_MISS=0`) -- flipped rows, a sample subset (lists of the selected samples only), a sample
+    count that is not a multiple of the tile, rows without any missing call mixed in, and repeatability (no atomics)."""
+    from janusx_amd import janusx as jxrs
+    packed, g = bed.synth_panel_numpy(n, m, seed=71, missing_rate=rate)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, _miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.01, 0.5, 1.0)
+    pk = np.ascontiguousarray(packed[keep])
+    pk[::5] = oracle.pack_codes(np.where(oracle.unpack_codes(pk[::5], n) == 1, 0, oracle.unpack_codes(pk[::5], n)))  # clean rows
+    maf_k, flip_k = maf[keep], np.random.default_rng(2).random(int(keep.sum())) < 0.4
+    rng = np.random.default_rng(8)
+    for sub in (None, np.sort(rng.permutation(n)[:(2 * n) // 3]).astype(np.int64)):
+        ref = oracle.grm_packed(pk, n, flip_k, maf_k, sub, 1)[0]
+        monkeypatch.setenv("JXGPU_GRM_MISS", "1")
+        monkeypatch.setenv("JXGPU_GRM_MISS_MAX", "1")
+        k1 = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
+        k1b = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
+        monkeypatch.setenv("JXGPU_GRM_MISS", "0")
+        k0 = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
+        scale = np.max(np.abs(ref))
+        assert np.array_equal(k1, k1b) and np.array_equal(k1, k1.T)
+        assert np.max(np.abs(k1 - ref)) < TOL * scale, np.max(np.abs(k1 - ref)) / scale
+        assert np.max(np.abs(k1 - k0)) < 5e-6 * scale, np.max(np.abs(k1 - k0)) / scale     # the split kernel drops lo x lo: ~1e-6
+    monkeypatch.delenv("JXGPU_GRM_MISS")
+    monkeypatch.delenv("JXGPU_GRM_MISS_MAX")

@@ -31,10 +31,24 @@ __global__ __launch_bounds__(128) void gm_lists_kernel(const uint32_t *__restric
     const int dsel = s >> 4, sh = 2 * (s & 15);
     const uint32_t *base = p32 + (int64_t)t * m_total * 8 + dsel;
     int64_t at = FILL ? cnt_or_off[(int64_t)i * GM_CHUNKS + c] : 0;
-    for (int64_t k = k0; k < k1; ++k) {
+    const bool real = i < n_sel;
+    int64_t k = k0;
+    for (; k + 8 <= k1; k += 8) {                      // eight records in flight (the loop is a chain of dependent loads)
+        uint32_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = miss2[k + u] ? base[(int64_t)rows2[k + u] * 8] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (((w[u] >> sh) & 3u) == 1u && real) {
+                if (FILL) ent[at] = (int32_t)(k + u);
+                ++at;
+            }
+        }
+    }
+    for (; k < k1; ++k) {
         if (!miss2[k]) continue;                                   // uniform
         const uint32_t w = base[(int64_t)rows2[k] * 8];
-        if (((w >> sh) & 3u) == 1u && i < n_sel) {
+        if (((w >> sh) & 3u) == 1u && real) {
             if (FILL) ent[at] = (int32_t)k;
             ++at;
         }

@@ -332,7 +332,12 @@ template <int MAXD, int B, bool V4>
 __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const double *__restrict__ s,
                                                              const double *__restrict__ xcov, const double *__restrict__ yc,
                                                              const float *__restrict__ g, int i0, int i1, int base, int p,
-                                                             double (&acc)[MAXD + 1], double &ssq, bool want_ssq) {
+                                                             double (&acc)[MAXD + 1], double &ssq, bool want_ssq,
+                                                             int xs_j = -1, int xs_r = 1) {
+    // X~ element (sample j, covariate r) at xcov[j * xs_j + r * xs_r]: row-major per sample by default (xs_j = p), covariate-
+    // major in the tiled kernel's LDS image (xs_j = 1, xs_r = tile: a lane's consecutive samples are then consecutive words
+    // like s and y~ -- with the per-sample layout the reads of a wave were 4-way bank conflicted from three covariates on)
+    if (xs_j < 0) xs_j = p;
     const int lane = threadIdx.x & 63;
     constexpr int W = V4 ? 4 : 1;
     for (int i = i0 + W * lane; i < i1; i += 64 * W * B) {
@@ -364,7 +369,7 @@ __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const d
                         const double gv = gi * vi;
 #pragma unroll
                         for (int r = 0; r < MAXD - 1; ++r)
-                            if (r < p) acc[r] = fma(gv, xcov[(int64_t)j * p + r], acc[r]);
+                            if (r < p) acc[r] = fma(gv, xcov[(int64_t)j * xs_j + (int64_t)r * xs_r], acc[r]);
                         acc[MAXD - 1] = fma(gv, gi, acc[MAXD - 1]);
                         acc[MAXD] = fma(gv, yc[j], acc[MAXD]);
                     }
@@ -940,11 +945,20 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
                 ls[i] = s_r[t0 + i];
                 ly[i] = y_r[t0 + i];
             }
-            for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) lx[i] = x_r[(int64_t)t0 * p + i];
+            if (MAXD == 2) {
+                for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) lx[i] = x_r[t0 + i];
+            } else {                                           // covariate-major image: lx[r * tile + j]
+                for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) {
+                    const int j = i / p, rr = i - j * p;
+                    lx[rr * tile + j] = x_r[(int64_t)t0 * p + i];
+                }
+            }
             __syncthreads();
             if (active && (lbd >= 0.0 || phase == 1)) {
-                if (vec4) fast_eval_accumulate_batched<MAXD, 4, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1);
-                else fast_eval_accumulate_batched<MAXD, 8, false>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1);
+                if (vec4)
+                    fast_eval_accumulate_batched<MAXD, 4, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1, 1, tile);
+                else
+                    fast_eval_accumulate_batched<MAXD, 8, false>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1, 1, tile);
             }
         }
         if (!active) continue;
@@ -1265,7 +1279,8 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             JX_HIP(hipGetDeviceProperties(&prop, dev));
             cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
-        // dim 2: 16 SNPs per workgroup; dim 3 - 4: plain evaluation tail; dim 5 - 8 and 9 - 16: block form (fast_eval_finish_blk)
+        // dim 2 - 4: 16 SNPs per workgroup (<= 128 VGPRs), plain evaluation tail; dim 5 - 8: 12 SNPs, dim 9 - 16: 8, block form
+        // (fast_eval_finish_blk)
 #define JX_TILED_LAUNCH(MAXDV, NWV, L2)                                                                                   \
     do {                                                                                                                  \
         constexpr int NW = NWV;                                                                                           \
@@ -1285,8 +1300,8 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
 #define JX_TILED_BY_DIM(L2)                                                                                               \
     do {                                                                                                                  \
         if (dim <= 2) JX_TILED_LAUNCH(2, 16, L2);                                                                         \
-        else if (dim <= 4) JX_TILED_LAUNCH(4, 8, L2);                                                                     \
-        else if (dim <= 8) JX_TILED_LAUNCH(8, 8, L2);                                                                     \
+        else if (dim <= 4) JX_TILED_LAUNCH(4, 16, L2);                                                                    \
+        else if (dim <= 8) JX_TILED_LAUNCH(8, 12, L2);                                                                    \
         else JX_TILED_LAUNCH(16, 8, L2);                                                                                  \
     } while (0)
         if (lmm2) JX_TILED_BY_DIM(true);

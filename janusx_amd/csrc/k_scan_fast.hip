@@ -328,7 +328,10 @@ __device__ __forceinline__ void fast_eval_accumulate(double lbd, const double *_
 // bytes in flight, so a lane takes FOUR consecutive samples per load (16 bytes; 1 KB per wave instruction) and keeps B
 // loads in flight; V4 = false is the scalar form (rows not 16-byte aligned: n % 4 != 0).  Optionally the sum of squares of
 // the row in the same pass.  (Per-lane sample order differs from the one-wave-per-SNP kernels: results agree to rounding.)
-template <int MAXD, int B, bool V4>
+// PERM: the LDS images are stored so that the samples 4 L + e of the 64 lanes are consecutive words for fixed e (position
+// 256 G + 64 e + L for sample 256 G + 4 L + e): with the natural order the 8-byte reads of a wave were 32 bytes apart, i.e.
+// 4-way bank conflicted -- the reads, three per sample and evaluation, were what bounded the kernel.
+template <int MAXD, int B, bool V4, bool PERM = false>
 __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const double *__restrict__ s,
                                                              const double *__restrict__ xcov, const double *__restrict__ yc,
                                                              const float *__restrict__ g, int i0, int i1, int base, int p,
@@ -361,7 +364,9 @@ __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const d
             if (idx < i1) {
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
-                    const int j = idx + e - base;
+                    // PERM: (i - base) - 4 lane is a multiple of 256, so the position is one lane-dependent base per loop
+                    // iteration plus the compile-time offset 256 u + 64 e (an immediate of the LDS instruction)
+                    const int j = PERM ? ((i - base) - 3 * lane + 256 * u + 64 * e) : (idx + e - base);
                     const double gi = (double)gb[u][e];
                     if (want_ssq) ssq += gi * gi;
                     if (lbd >= 0.0) {
@@ -941,22 +946,26 @@ __global__ __launch_bounds__(NW * 64) void lmm_scan_tiled_kernel(
         for (int t0 = 0; t0 < n; t0 += tile) {
             const int t1 = min(n, t0 + tile);
             __syncthreads();                                   // the previous tile has been consumed
+            // position of sample i of the tile in the LDS images: permuted in the 16-byte-load form (see PERM above)
+            auto lpos = [&](int i) { return vec4 ? ((i & ~255) + ((i & 3) << 6) + ((i & 255) >> 2)) : i; };
             for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) {
-                ls[i] = s_r[t0 + i];
-                ly[i] = y_r[t0 + i];
+                const int q = lpos(i);
+                ls[q] = s_r[t0 + i];
+                ly[q] = y_r[t0 + i];
             }
             if (MAXD == 2) {
-                for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) lx[i] = x_r[t0 + i];
-            } else {                                           // covariate-major image: lx[r * tile + j]
+                for (int i = threadIdx.x; i < t1 - t0; i += NW * 64) lx[lpos(i)] = x_r[t0 + i];
+            } else {                                           // covariate-major image: lx[r * tile + position]
                 for (int i = threadIdx.x; i < (t1 - t0) * p; i += NW * 64) {
                     const int j = i / p, rr = i - j * p;
-                    lx[rr * tile + j] = x_r[(int64_t)t0 * p + i];
+                    lx[rr * tile + lpos(j)] = x_r[(int64_t)t0 * p + i];
                 }
             }
             __syncthreads();
             if (active && (lbd >= 0.0 || phase == 1)) {
                 if (vec4)
-                    fast_eval_accumulate_batched<MAXD, 4, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1, 1, tile);
+                    fast_eval_accumulate_batched<MAXD, 4, true, true>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1, 1,
+                                                                      tile);
                 else
                     fast_eval_accumulate_batched<MAXD, 8, false>(lbd, ls, lx, ly, g, t0, t1, t0, p, acc, ssq, phase == 1, 1, tile);
             }

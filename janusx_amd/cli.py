@@ -178,6 +178,21 @@ def cv_fold_metrics(y_true, y_pred):
     return float(pearsonr(yt, yp).statistic), float(spearmanr(yt, yp).statistic), r2
 
 
+def _parse_qcov_dim(qcov_opt) -> int:
+    """`_parse_qcov_dim` (python/janusx/assoc/workflow.py:1813-1828): -q takes a PC count, not a file."""
+    s = str(qcov_opt if qcov_opt is not None else "").strip()
+    if s == "":
+        raise SystemExit("Invalid -q/--qcov: empty value. Use an integer PC dimension (>=0).")
+    try:
+        q = int(s)
+    except ValueError:
+        raise SystemExit("External Q matrix via -q/--qcov is no longer supported. Use -c <file> for external covariates and "
+                         "-q <int> for the PC dimension.")
+    if q < 0:
+        raise SystemExit(f"Invalid -q/--qcov: {q}. Q/PC dimension must be >= 0.")
+    return q
+
+
 def cmd_gwas(args):
     import torch
     from . import janusx as jxrs
@@ -225,6 +240,23 @@ def cmd_gwas(args):
         print(f"GRM method {args.grm}: eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
     elif dense_models:
         k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)
+    # -q N: the N leading principal components of the whole-cohort GRM as fixed-effect columns beside the intercept
+    # (`load_or_build_q_with_cache` -> `build_pcs_from_grm`, python/janusx/assoc/workflow.py:3389-3422, 3577-3789: the last N
+    # columns of the ascending eigendecomposition of the GRM without a ridge, stored as f32; the reference switches to a
+    # randomised SVD of the genotypes above 15 000 samples, here the GRM route serves every size)
+    qdim = _parse_qcov_dim(getattr(args, "qcov", "0"))
+    qmat = None
+    if qdim > 0:
+        if qdim >= n_fam:
+            raise SystemExit(f"Q/PC dimension out of range: {qdim}. valid=[0..{max(0, n_fam - 1)}]")
+        kq = k
+        if kq is None:
+            kq, _eff_q, _ = pl.build_grm(packed_t, n_fam, int(args.grm) if args.grm in ("1", "2") else 1, args.maf, args.geno)
+        tq = time.perf_counter()
+        _s_all, ut_all = pl.eigh_from_grm(kq, ridge=0.0)
+        qmat = ut_all[-qdim:].T.to(torch.float32).cpu().numpy().astype(np.float64)
+        del _s_all, ut_all, kq
+        print(f"Q matrix: {qdim} principal components of the GRM ({time.perf_counter() - tq:.2f}s)")
     sparse_path = None
     sparse_pos = None
     if args.splmm is not None:
@@ -267,6 +299,8 @@ def cmd_gwas(args):
             continue
         y = np.array([ph[pos[fam[j]], ti] for j in keep_idx])
         x = np.ones((n, 1))
+        if qmat is not None:                    # design = [1 | Q | C] (workflow.py:1545-1560)
+            x = np.concatenate([x, qmat[keep_idx]], axis=1)
         if args.cov:
             x = np.concatenate([x, np.array([cv[cpos[fam[j]]] for j in keep_idx])], axis=1)
         for mode in (["lmm"] if args.lmm else []) + (["lmm2"] if args.lmm2 else []) + (["fvlmm"] if args.fvlmm else []):
@@ -571,6 +605,9 @@ def main(argv=None):
     g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
     g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
     g.add_argument("-c", "--cov", dest="cov", default=None)
+    g.add_argument("-q", "--qcov", dest="qcov", type=str, default="0",
+                   help="number of principal components of the GRM added as covariates (integer >= 0; external covariates "
+                        "go through -c)")
     g.add_argument("-mmap-window-mb", "--mmap-window-mb", dest="mmap_window_mb", type=int, default=None,
                    help="stage the .bed payload to the device in windows of this many MiB (default 256)")
     g.add_argument("-maf", "--maf", type=float, default=0.02)

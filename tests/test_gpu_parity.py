@@ -3094,3 +3094,56 @@ def test_grm_missing_calls_sparse_correction(oracle, monkeypatch, n, m, rate):
         assert np.max(np.abs(k1 - k0)) < 5e-6 * scale, np.max(np.abs(k1 - k0)) / scale     # the split kernel drops lo x lo: ~1e-6
     monkeypatch.delenv("JXGPU_GRM_MISS")
     monkeypatch.delenv("JXGPU_GRM_MISS_MAX")
+
+
+@pytest.mark.gpu
+def test_cli_gwas_with_principal_components(oracle, oracle_c, tmp_path):
+    """`jx gwas -lmm -q 3 [-c FILE]`: the three leading principal components of the whole-cohort GRM (no ridge) as covariates,
+    design [1 | Q | C] on the trait's samples (python/janusx/assoc/workflow.py:1545-1560, 3389-3422, 3577-3789), with a trait that
+    has missing phenotypes; eigenvector signs do not matter."""
+    from janusx_amd import cli
+    n, m = 260, 500
+    packed, g = bed.synth_panel_numpy(n, m, seed=83, missing_rate=0.01)
+    y = bed.synth_phenotype(g, n_causal=15, pve=0.6, seed=83)
+    rng = np.random.default_rng(4)
+    na = rng.random(n) < 0.15
+    cvals = rng.normal(size=n)
+    prefix = str(tmp_path / "pc")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ttraitA\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{'NA' if na[i] else repr(float(y[i]))}\n")
+    with open(prefix + ".cov", "w") as fh:
+        fh.write("id\tage\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{float(cvals[i])!r}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", "3", "-c", prefix + ".cov",
+                     "-force-model", "-o", prefix]) == 0
+    lines = open(prefix + ".traitA.lmm.tsv").read().splitlines()
+    keep_idx = np.nonzero(~na)[0]
+    k_ref, _eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    _s_all, u_all = oracle.gwas_eigh_from_grm(k_ref, 0.0)
+    u_all = np.asarray(u_all, dtype=np.float64)
+    # rows or columns hold the eigenvectors depending on the helper: take the orientation in which they are orthonormal rows
+    vecs = u_all if abs(float(u_all[-1] @ k_ref @ u_all[-1]) - float(_s_all[-1])) < 1e-6 * abs(float(_s_all[-1])) else u_all.T
+    q = vecs[-3:].T.astype(np.float32).astype(np.float64)
+    x = np.concatenate([np.ones((len(keep_idx), 1)), q[keep_idx], cvals[keep_idx, None]], axis=1)
+    s, u = oracle.gwas_eigh_from_grm(k_ref, 1e-6, keep_idx)
+    nm = oracle.spectral_null_model(y[keep_idx], x, s, u)
+    mi, he, ho = oracle.row_counts(packed, n, keep_idx)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, len(keep_idx), 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    assert len(lines) == len(rows) + 1
+    gd = oracle.decode_centered_block_f32(packed, n, flip, maf, sample_idx=keep_idx, rows=rows)
+    ref = oracle_c.lmm_scan_rotated_block(oracle.rotate_block_f32(gd, nm.Dh), nm.S, nm.Xcov, nm.y, nm.bounds[0],
+                                          nm.bounds[1], 30, 1e-2)
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split("\t")
+        assert abs(float(f[7]) - ref[i, 0]) <= 2e-4 and abs(float(f[8]) - ref[i, 1]) <= 2e-4, (i, f[7], ref[i, 0])
+    with pytest.raises(SystemExit, match="no longer supported"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", prefix + ".cov", "-o", prefix])
+    with pytest.raises(SystemExit, match="out of range"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", str(n), "-o", prefix])

@@ -131,10 +131,15 @@ def cmd_grm(args):
     k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
                                         max_missing_rate=args.geno, het_threshold=0.0)
     tag = "cGRM" if args.method == 1 else "sGRM"
-    path = f"{out}.{tag}.npy"
-    tmp = f"{path}.tmp.{os.getpid()}"
-    with open(tmp, "wb") as fh:
-        np.lib.format.write_array(fh, k, version=(1, 0))
+    if getattr(args, "txt", False):             # python/janusx/script/grm.py:2684-2690
+        path = f"{out}.{tag}.txt"
+        tmp = f"{path}.tmp.{os.getpid()}"
+        np.savetxt(tmp, k, fmt="%.6f")
+    else:
+        path = f"{out}.{tag}.npy"
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as fh:
+            np.lib.format.write_array(fh, k, version=(1, 0))
     os.replace(tmp, path)
     with open(path + ".id", "w") as fh:
         for sid in read_fam_ids(args.bfile):
@@ -391,6 +396,10 @@ def cmd_gwas(args):
     return 0
 
 
+BLUP_SMALL_N = 15000      # python/janusx/gs/blup.py:8-9
+BLUP_SMALL_M = 15000
+
+
 def cmd_gs(args):
     """`jx gs -BLUP`: centred GRM of all genotyped samples (once), then per trait a GBLUP fit on the phenotyped
     samples (spectral REML, src/stats/gblup.rs:1105-1240) -- K-fold cross-validated with `-cv` (folds of
@@ -405,6 +414,21 @@ def cmd_gs(args):
     ids, names, ph = _read_table(args.pheno)
     pos = {s: i for i, s in enumerate(ids)}
     traits = _select_traits(names, args.ncol)
+    if args.blup and not args.gblup:
+        # -BLUP = automatic dispatch (`resolve_blup_dispatch`, python/janusx/gs/blup.py:8-163): n_train <= 15000 -> GBLUP;
+        # beyond that rrBLUP, exact (marker space) up to 15000 kept markers and PCG above; GS_BLUP=0/1/2 forces a route
+        force = os.environ.get("GS_BLUP", "").strip()
+        if force not in ("", "0", "1", "2"):
+            raise SystemExit(f"Invalid GS_BLUP={force!r}; expected 0 (GBLUP), 1 (rrBLUP exact), or 2 (rrBLUP PCG).")
+        n_train_max = 0
+        for ti in traits:
+            n_train_max = max(n_train_max, sum(1 for sid in fam if sid in pos and math.isfinite(ph[pos[sid], ti])))
+        if force in ("1", "2") or (force == "" and n_train_max > BLUP_SMALL_N):
+            args.rr_solver = {"1": "exact", "2": "pcg"}.get(force, "auto")     # auto: exact up to 15000 kept markers
+            print(f"-BLUP dispatch: n_train={n_train_max} -> rrBLUP ({args.rr_solver})"
+                  + (f" (forced by GS_BLUP={force})" if force else ""))
+            return cmd_gs_rrblup(args)
+        print(f"-BLUP dispatch: n_train={n_train_max} -> GBLUP" + (" (forced by GS_BLUP=0)" if force == "0" else ""))
     out = args.out or args.bfile
     t0 = time.perf_counter()
     if args.grm:
@@ -628,8 +652,11 @@ def main(argv=None):
     r.add_argument("-maf", "--maf", type=float, default=0.02)
     r.add_argument("-geno", "--geno", type=float, default=0.05)
     r.add_argument("-o", "--out", default=None)
-    r.add_argument("-grm", "--grm", default=None,
-                   help="existing dense GRM (.npy with a sibling .id); with -sparse it is thresholded into a .spgrm")
+    r.add_argument("-grm", "--grm", "-k", "--dense-grm", dest="grm", default=None,
+                   help="existing dense GRM (.npy with a sibling .id); with -sparse it is thresholded into a .spgrm "
+                        "(-k / --dense-grm is the reference's name of this option)")
+    r.add_argument("-txt", "--txt", action="store_true", default=False,
+                   help="write the dense GRM as plain text ({out}.cGRM.txt, %%.6f) instead of NPY")
     r.add_argument("-sparse", "--sparse", nargs="?", const=0.05, default=None, type=float,
                    help="write a sparse `.spgrm` keeping off-diagonal kinship > cutoff (negative: keep everything)")
     r.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
@@ -641,9 +668,9 @@ def main(argv=None):
     q.add_argument("-BLUP", "--BLUP", dest="blup", action="store_true", default=False)
     q.add_argument("-GBLUP", "--GBLUP", dest="gblup", action="store_true", default=False)
     q.add_argument("-rrBLUP", "--rrBLUP", dest="rrblup", action="store_true", default=False)
-    q.add_argument("-rr-solver", "--rr-solver", dest="rr_solver", choices=["auto", "exact", "fast", "pcg"], default="auto",
+    q.add_argument("-rr-solver", "--rr-solver", "--rrblup-solver", dest="rr_solver", choices=["auto", "exact", "fast", "pcg"], default="auto",
                    help="rrBLUP: exact marker-space route (auto up to 15000 kept markers) or PCG")
-    q.add_argument("-lambda", "--lambda", dest="lam", type=float, default=None)
+    q.add_argument("-lambda", "--lambda", "--rrblup-lambda", dest="lam", type=float, default=None)
     q.add_argument("-lambda-reml", "--lambda-reml", dest="lambda_reml", action="store_true", default=False,
                    help="rrBLUP: take lambda from the subsample GBLUP REML instead of Haseman-Elston")
     q.add_argument("-tol", "--tol", type=float, default=1e-4)

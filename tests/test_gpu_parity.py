@@ -6,6 +6,7 @@ Norms (SURVEY.md §8d): GRM  max|dK| / max(|K_ij|, mean diag K);  SE relative;  
 p relative on rows finite in both, identical NaN / p=1 pattern.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -3147,3 +3148,42 @@ def test_cli_gwas_with_principal_components(oracle, oracle_c, tmp_path):
         cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", prefix + ".cov", "-o", prefix])
     with pytest.raises(SystemExit, match="out of range"):
         cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", str(n), "-o", prefix])
+
+
+@pytest.mark.gpu
+def test_cli_gs_blup_dispatch_and_grm_text(oracle, tmp_path, monkeypatch, capsys):
+    """`jx gs -BLUP` is the reference's automatic dispatch (`resolve_blup_dispatch`, python/janusx/gs/blup.py:8-163): GBLUP up to
+    15 000 training samples, rrBLUP beyond (exact up to 15 000 kept markers, PCG above), `GS_BLUP=0/1/2` forces a route;
+    `jx grm -txt` writes the text matrix of python/janusx/script/grm.py:2684-2690 and `-k` names the dense-GRM input."""
+    from janusx_amd import cli
+    n, m = 150, 300
+    packed, g = bed.synth_panel_numpy(n, m, seed=91, missing_rate=0.0)
+    y = bed.synth_phenotype(g, n_causal=20, pve=0.7, seed=91)
+    prefix = str(tmp_path / "d")
+    ids = [f"id{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C"] * m, ["T"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\ty\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{'NA' if i % 9 == 0 else repr(float(y[i]))}\n")
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-BLUP", "-o", prefix + "_a"]) == 0
+    assert "-> GBLUP" in capsys.readouterr().out and os.path.exists(prefix + "_a.y.gs.GBLUP.tsv")
+    monkeypatch.setenv("GS_BLUP", "1")
+    assert cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-BLUP", "-o", prefix + "_b"]) == 0
+    out = capsys.readouterr().out
+    assert "rrBLUP (exact)" in out and "forced by GS_BLUP=1" in out
+    assert any(f.startswith("d_b.y.gs.rrBLUP") for f in os.listdir(tmp_path))
+    monkeypatch.setenv("GS_BLUP", "7")
+    with pytest.raises(SystemExit, match="Invalid GS_BLUP"):
+        cli.main(["gs", "-bfile", prefix, "-p", prefix + ".pheno", "-BLUP", "-o", prefix + "_c"])
+    monkeypatch.delenv("GS_BLUP")
+    # jx grm -txt, then -k FILE.npy -sparse
+    assert cli.main(["grm", "-bfile", prefix, "-txt", "-o", prefix + "_t"]) == 0
+    kt = np.loadtxt(prefix + "_t.cGRM.txt")
+    k_ref, _, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    assert kt.shape == (n, n) and np.max(np.abs(kt - k_ref)) < 1e-6 + TOL * np.max(np.abs(k_ref))
+    assert open(prefix + "_t.cGRM.txt.id").read().split() == ids
+    assert cli.main(["grm", "-bfile", prefix, "-o", prefix + "_n"]) == 0
+    assert cli.main(["grm", "-k", prefix + "_n.cGRM.npy", "-sparse", "0.05", "-o", prefix + "_s"]) == 0
+    assert os.path.exists(prefix + "_s.spgrm") and open(prefix + "_s.spgrm.id").read().split() == ids

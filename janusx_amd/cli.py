@@ -641,9 +641,11 @@ def main(argv=None):
     g.add_argument("-force-model", "--force-model", dest="force_model", action="store_true", default=False)
     g.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     g.set_defaults(func=cmd_gwas)
-    g.add_argument("-splmm", "--splmm", nargs="?", const=0.05, default=None, type=float,
-                   help="SparseLMM exact scan on a sparse GRM thresholded at this kinship cut-off (default 0.05); "
-                        "-grm FILE.spgrm reuses an existing sparse GRM")
+    g.add_argument("-splmm", "--splmm", "-splmm-approx", "--splmm-approx", dest="splmm", nargs="?", const=0.05, default=None,
+                   type=float,
+                   help="SparseLMM with the GRAMMAR-gamma scan approximation (fastGWA null + residualised scan) on a sparse GRM "
+                        "thresholded at this kinship cut-off (default 0.05; negative: keep every entry); -k FILE.spgrm reuses "
+                        "an existing sparse GRM")
     g.add_argument("-splmm-exact", "--splmm-exact", dest="splmm_exact", nargs="?", const=0.05, default=None, type=float,
                    help="SparseLMM with the exact g'Pg denominator for every SNP -> {out}.{trait}.splmm2.tsv")
     r = sub.add_parser("grm")

@@ -267,8 +267,15 @@ def cmd_gwas(args):
     if args.splmm is not None:
         # SparseLMM, exact mode: thresholded sparse GRM of all genotyped samples once (`.spgrm`, or an existing one given
         # with -grm FILE.spgrm), then per trait the sparse REML null model and the exact g'Pg scan on its samples
-        if str(args.grm).lower().endswith((".spgrm", ".jxgrm")):
-            sparse_path = args.grm
+        # -spk / --grm-sparse (python/janusx/assoc/workflow.py:6747-6754): 1 | 2 = method of the sparse GRM built here, or the
+        # path of a precomputed .spgrm / .jxgrm; -k FILE.spgrm is this build's older way of naming the same file
+        spk = str(getattr(args, "grm_sparse", "1") or "1").strip()
+        spk_file = spk if spk.lower().endswith((".spgrm", ".jxgrm")) else None
+        if spk_file is None and spk not in ("1", "2"):
+            raise SystemExit(f"-spk {spk}: expected 1 (centering), 2 (standardization) or a .spgrm / .jxgrm file "
+                             "(GCTA / fastGWA .grm.sp inputs are not read by this build)")
+        if spk_file is not None or str(args.grm).lower().endswith((".spgrm", ".jxgrm")):
+            sparse_path = spk_file if spk_file is not None else args.grm
             # the sparse GRM's own sample order: map by id, like the dense -grm FILE path (_load_grm)
             id_path = sparse_path + ".id"
             if not os.path.exists(id_path):
@@ -279,7 +286,7 @@ def cmd_gwas(args):
             if len(sparse_pos) != len(sparse_ids):
                 raise SystemExit(f"{id_path} lists duplicate sample ids")
         else:
-            method = int(args.grm) if args.grm in ("1", "2") else 1
+            method = int(spk) if spk == "2" else (int(args.grm) if args.grm in ("1", "2") else 1)
             sparse_path, _, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=method,
                                                          threshold=float(args.splmm), maf_threshold=args.maf,
                                                          max_missing_rate=args.geno, het_threshold=0.0)
@@ -646,6 +653,9 @@ def main(argv=None):
                    help="SparseLMM with the GRAMMAR-gamma scan approximation (fastGWA null + residualised scan) on a sparse GRM "
                         "thresholded at this kinship cut-off (default 0.05; negative: keep every entry); -k FILE.spgrm reuses "
                         "an existing sparse GRM")
+    g.add_argument("-spk", "--grm-sparse", dest="grm_sparse", type=str, default="1",
+                   help="sparse GRM of the SparseLMM models: 1 (centering), 2 (standardization) or a precomputed .spgrm / .jxgrm "
+                        "file with its .id sibling")
     g.add_argument("-splmm-exact", "--splmm-exact", dest="splmm_exact", nargs="?", const=0.05, default=None, type=float,
                    help="SparseLMM with the exact g'Pg denominator for every SNP -> {out}.{trait}.splmm2.tsv")
     r = sub.add_parser("grm")

@@ -2350,6 +2350,13 @@ def test_cli_gwas_splmm(oracle, tmp_path):
         assert fa[:7] == fb[:7]
         for c in (7, 8, 10):
             assert abs(float(fa[c]) - float(fb[c])) <= 2e-4 * max(abs(float(fa[c])), 1e-300) + (1e-4 if c < 10 else 0.0)
+    # the reference's name of that option: -spk FILE (python/janusx/assoc/workflow.py:6747-6754) -- same table; it can then
+    # stand beside a dense model, which -k FILE.spgrm cannot
+    out3 = str(tmp_path / "toy3")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-spk", ppath, "-o", out3]) == 0
+    assert open(out3 + ".traitA.splmm.tsv").read() == open(out2 + ".traitA.splmm.tsv").read()
+    with pytest.raises(SystemExit, match="expected 1"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-spk", "plink.grm.sp", "-o", out3])
     import os
     os.remove(ppath + ".id")
     with pytest.raises(SystemExit, match="not found"):

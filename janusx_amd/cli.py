@@ -94,12 +94,32 @@ def _load_grm(path, fam_ids):
     return np.ascontiguousarray(k, dtype=np.float32)
 
 
+def _resolve_out(args, src):
+    """Output prefix as the reference resolves it (python/janusx/assoc/workflow.py:6907-6921, script/_common/cli_args.py:727-760):
+    -o PREFIX or DIR/PREFIX (an existing directory or a trailing separator: the input's basename inside it), -prefix NAME names
+    the files inside -o DIR; nothing given: the input's basename in the current directory."""
+    base = os.path.basename(src[:-4] if src.lower().endswith((".bed", ".bim", ".fam", ".npy")) else src)
+    o, pfx = getattr(args, "out", None), getattr(args, "prefix", None)
+    if pfx:
+        res = os.path.join(o or ".", pfx)
+    elif o is None:
+        res = base
+    elif o.endswith(os.sep) or os.path.isdir(o):
+        res = os.path.join(o, base)
+    else:
+        res = o
+    parent = os.path.dirname(res)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    return res
+
+
 def cmd_grm(args):
     from . import janusx as jxrs
     from .bed import read_fam_ids
     if args.grm is None and not args.bfile:
         raise SystemExit("grm needs -bfile PREFIX (or -grm FILE.npy -sparse [cutoff])")
-    out = args.out or args.bfile or (args.grm[:-4] if args.grm.lower().endswith(".npy") else args.grm)
+    out = _resolve_out(args, args.bfile or args.grm)
     t0 = time.perf_counter()
     if args.grm is not None:
         # python/janusx/script/grm.py:1806-1868, 1896: an existing dense GRM (`.npy` + sibling `.id`) thresholded into `.spgrm`
@@ -232,7 +252,7 @@ def cmd_gwas(args):
         cids, _, cv = _read_table(args.cov)
         cpos = {s: i for i, s in enumerate(cids)}
     traits = _select_traits(names, args.ncol)
-    out = args.out or args.bfile
+    out = _resolve_out(args, args.bfile)
     dev = packed_t.device
     t0 = time.perf_counter()
     dense_models = args.lmm or args.fvlmm or args.lmm2
@@ -436,7 +456,7 @@ def cmd_gs(args):
                   + (f" (forced by GS_BLUP={force})" if force else ""))
             return cmd_gs_rrblup(args)
         print(f"-BLUP dispatch: n_train={n_train_max} -> GBLUP" + (" (forced by GS_BLUP=0)" if force == "0" else ""))
-    out = args.out or args.bfile
+    out = _resolve_out(args, args.bfile)
     t0 = time.perf_counter()
     if args.grm:
         k = _load_grm(args.grm, fam)
@@ -501,7 +521,7 @@ def cmd_gs_rrblup(args):
     ids, names, ph = _read_table(args.pheno)
     pos = {s: i for i, s in enumerate(ids)}
     traits = _select_traits(names, args.ncol)
-    out = args.out or args.bfile
+    out = _resolve_out(args, args.bfile)
     packed, miss, maf, _std, n_all = jxrs.load_bed_2bit_packed(args.bfile)
     flip = jxrs.bed_packed_row_flip_mask(packed, n_all)
     keep = (maf >= np.float32(args.maf)) & (miss <= np.float32(args.geno))
@@ -645,6 +665,7 @@ def main(argv=None):
     g.add_argument("-geno", "--geno", type=float, default=0.05)
     g.add_argument("-het", "--het", type=float, default=1.0)
     g.add_argument("-o", "--out", default=None)
+    g.add_argument("-prefix", "--prefix", default=None, help="file name prefix inside the -o directory")
     g.add_argument("-force-model", "--force-model", dest="force_model", action="store_true", default=False)
     g.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     g.set_defaults(func=cmd_gwas)
@@ -664,6 +685,7 @@ def main(argv=None):
     r.add_argument("-maf", "--maf", type=float, default=0.02)
     r.add_argument("-geno", "--geno", type=float, default=0.05)
     r.add_argument("-o", "--out", default=None)
+    r.add_argument("-prefix", "--prefix", default=None, help="file name prefix inside the -o directory")
     r.add_argument("-grm", "--grm", "-k", "--dense-grm", dest="grm", default=None,
                    help="existing dense GRM (.npy with a sibling .id); with -sparse it is thresholded into a .spgrm "
                         "(-k / --dense-grm is the reference's name of this option)")
@@ -693,6 +715,7 @@ def main(argv=None):
     q.add_argument("-maf", "--maf", type=float, default=0.02)
     q.add_argument("-geno", "--geno", type=float, default=0.05)
     q.add_argument("-o", "--out", default=None)
+    q.add_argument("-prefix", "--prefix", default=None, help="file name prefix inside the -o directory")
     q.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     q.set_defaults(func=cmd_gs)
     args = ap.parse_args(argv)

@@ -3194,3 +3194,10 @@ def test_cli_gs_blup_dispatch_and_grm_text(oracle, tmp_path, monkeypatch, capsys
     assert cli.main(["grm", "-bfile", prefix, "-o", prefix + "_n"]) == 0
     assert cli.main(["grm", "-k", prefix + "_n.cGRM.npy", "-sparse", "0.05", "-o", prefix + "_s"]) == 0
     assert os.path.exists(prefix + "_s.spgrm") and open(prefix + "_s.spgrm.id").read().split() == ids
+    # -o DIR [-prefix NAME] and the default (input basename in the current directory), as the reference resolves them
+    outdir = str(tmp_path / "res" / "deep")
+    assert cli.main(["grm", "-bfile", prefix, "-o", outdir + os.sep]) == 0 and os.path.exists(os.path.join(outdir, "d.cGRM.npy"))
+    assert cli.main(["grm", "-bfile", prefix, "-o", outdir, "-prefix", "run7"]) == 0
+    assert os.path.exists(os.path.join(outdir, "run7.cGRM.npy"))
+    monkeypatch.chdir(tmp_path / "res")
+    assert cli.main(["grm", "-bfile", prefix]) == 0 and os.path.exists(str(tmp_path / "res" / "d.cGRM.npy"))

@@ -141,7 +141,8 @@ def cmd_grm(args):
         # python/janusx/script/grm.py:1574-1675 (`-sparse [cutoff]`): thresholded lower-triangle CSC `.spgrm` + `.id`
         path, n, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=args.method,
                                                threshold=float(args.sparse), maf_threshold=args.maf,
-                                               max_missing_rate=args.geno, het_threshold=0.0)
+                                               max_missing_rate=args.geno, het_threshold=0.0,
+                                               snps_only=bool(getattr(args, "snps_only", False)))
         with open(path + ".id", "w") as fh:
             for sid in read_fam_ids(args.bfile):
                 fh.write(f"{sid}\n")
@@ -149,7 +150,8 @@ def cmd_grm(args):
               f"({time.perf_counter() - t0:.2f}s)")
         return 0
     k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
-                                        max_missing_rate=args.geno, het_threshold=0.0)
+                                        max_missing_rate=args.geno, het_threshold=0.0,
+                                        snps_only=bool(getattr(args, "snps_only", False)))
     tag = "cGRM" if args.method == 1 else "sGRM"
     if getattr(args, "txt", False):             # python/janusx/script/grm.py:2684-2690
         path = f"{out}.{tag}.txt"
@@ -243,6 +245,17 @@ def cmd_gwas(args):
     # below holds a host copy of it
     from .bed import stage_bed_payload
     packed_t, n_fam, bim = stage_bed_payload(args.bfile, getattr(args, "mmap_window_mb", None))
+    if getattr(args, "snps_only", False):
+        # -snps-only: sites whose two alleles are not single A/C/G/T leave the run altogether -- GRM, QC and scan
+        # (`snps_only` of the reference's BED routes, src/io/gfreader.rs:7013-7019)
+        from .bed import Bim, snps_only_mask
+        mask = snps_only_mask(bim)
+        if not mask.all():
+            sel = np.nonzero(mask)[0]
+            packed_t = packed_t[torch.from_numpy(sel).to(packed_t.device)]
+            bim = Bim([bim.chrom[j] for j in sel], [bim.snp[j] for j in sel], [bim.pos[j] for j in sel],
+                      [bim.a0[j] for j in sel], [bim.a1[j] for j in sel])
+            print(f"-snps-only: {len(sel)} of {len(mask)} sites kept")
     packed = packed_t
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
@@ -309,7 +322,8 @@ def cmd_gwas(args):
             method = int(spk) if spk == "2" else (int(args.grm) if args.grm in ("1", "2") else 1)
             sparse_path, _, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=method,
                                                          threshold=float(args.splmm), maf_threshold=args.maf,
-                                                         max_missing_rate=args.geno, het_threshold=0.0)
+                                                         max_missing_rate=args.geno, het_threshold=0.0,
+                                                         snps_only=bool(getattr(args, "snps_only", False)))
             with open(sparse_path + ".id", "w") as fh:
                 for sid in fam:
                     fh.write(f"{sid}\n")
@@ -656,6 +670,11 @@ def main(argv=None):
     g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
     g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
     g.add_argument("-c", "--cov", dest="cov", default=None)
+    g.add_argument("-snps-only", "--snps-only", dest="snps_only", action="store_true", default=False,
+                   help="drop sites whose alleles are not single A/C/G/T")
+    g.add_argument("-mem", "--memory", dest="memory", type=float, default=None,
+                   help="accepted for compatibility; unused (the working set lives in HBM)")
+    g.add_argument("-v", "--verbose", action="store_true", default=False, help="accepted for compatibility")
     g.add_argument("-q", "--qcov", dest="qcov", type=str, default="0",
                    help="number of principal components of the GRM added as covariates (integer >= 0; external covariates "
                         "go through -c)")
@@ -689,6 +708,10 @@ def main(argv=None):
     r.add_argument("-grm", "--grm", "-k", "--dense-grm", dest="grm", default=None,
                    help="existing dense GRM (.npy with a sibling .id); with -sparse it is thresholded into a .spgrm "
                         "(-k / --dense-grm is the reference's name of this option)")
+    r.add_argument("-snps-only", "--snps-only", dest="snps_only", action="store_true", default=False,
+                   help="drop sites whose alleles are not single A/C/G/T")
+    r.add_argument("-mem", "--memory", dest="memory", type=float, default=None, help="accepted for compatibility; unused")
+    r.add_argument("-v", "--verbose", action="store_true", default=False, help="accepted for compatibility")
     r.add_argument("-txt", "--txt", action="store_true", default=False,
                    help="write the dense GRM as plain text ({out}.cGRM.txt, %%.6f) instead of NPY")
     r.add_argument("-sparse", "--sparse", nargs="?", const=0.05, default=None, type=float,

@@ -3151,6 +3151,19 @@ def test_cli_gwas_with_principal_components(oracle, oracle_c, tmp_path):
     for i, ln in enumerate(lines[1:]):
         f = ln.split("\t")
         assert abs(float(f[7]) - ref[i, 0]) <= 2e-4 and abs(float(f[8]) - ref[i, 1]) <= 2e-4, (i, f[7], ref[i, 0])
+    # -snps-only: the sites with a non-SNP allele leave the run altogether = the run on a BED without them
+    bim2 = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C" if j % 13 else "CAT" for j in range(m)],
+                   ["T"] * m)
+    pre2 = str(tmp_path / "indel")
+    bed.write_bed(pre2, packed, ids, bim2)
+    snp_rows = np.array([j for j in range(m) if j % 13])
+    pre3 = str(tmp_path / "snps")
+    bed.write_bed(pre3, np.ascontiguousarray(packed[snp_rows]), ids,
+                  bed.Bim(["1"] * len(snp_rows), [f"rs{j}" for j in snp_rows], [int(j) + 1 for j in snp_rows],
+                          ["C"] * len(snp_rows), ["T"] * len(snp_rows)))
+    assert cli.main(["gwas", "-bfile", pre2, "-p", prefix + ".pheno", "-lmm", "-snps-only", "-force-model", "-o", pre2]) == 0
+    assert cli.main(["gwas", "-bfile", pre3, "-p", prefix + ".pheno", "-lmm", "-force-model", "-mem", "4", "-v", "-o", pre3]) == 0
+    assert open(pre2 + ".traitA.lmm.tsv").read() == open(pre3 + ".traitA.lmm.tsv").read()
     with pytest.raises(SystemExit, match="no longer supported"):
         cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-q", prefix + ".cov", "-o", prefix])
     with pytest.raises(SystemExit, match="out of range"):

@@ -220,6 +220,34 @@ def _parse_qcov_dim(qcov_opt) -> int:
     return q
 
 
+def _parse_cov_site_token(token):
+    """`_parse_cov_site_token` (python/janusx/assoc/workflow.py:1742-1776): chr:pos or chr:start:end with start = end."""
+    parts = [p.strip() for p in str(token).strip().replace("\uff1a", ":").split(":")]
+    if len(parts) not in (2, 3) or parts[0] == "":
+        return None
+    try:
+        start = int(float(parts[1]))
+    except Exception:
+        return None
+    if start <= 0:
+        raise SystemExit(f"Invalid site position in --cov: {token}")
+    if len(parts) == 3:
+        try:
+            end = int(float(parts[2]))
+        except Exception:
+            return None
+        if end <= 0:
+            raise SystemExit(f"Invalid site position in --cov: {token}")
+        if end != start:
+            raise SystemExit(f"--cov site token must specify a single site (start=end), got: {token}")
+    return parts[0], start
+
+
+def _canon_site_key(chrom, pos):
+    c = str(chrom).strip().lower()
+    return (c[3:] if c.startswith("chr") else c), int(pos)
+
+
 def cmd_gwas(args):
     import torch
     from . import janusx as jxrs
@@ -260,10 +288,48 @@ def cmd_gwas(args):
     fam = read_fam_ids(args.bfile)
     ids, names, ph = _read_table(args.pheno)
     pos = {s: i for i, s in enumerate(ids)}
-    cov = None
-    if args.cov:
-        cids, _, cv = _read_table(args.cov)
-        cpos = {s: i for i, s in enumerate(cids)}
+    # -c may be repeated; an item is a covariate table or a SNP site `chr:pos` (`chr:start:end` with start = end) whose additive
+    # genotype -- missing calls at the site's mean over all genotyped samples -- becomes a covariate (conditional analysis;
+    # `_load_covariates_for_models` / `_load_site_covariates`, python/janusx/assoc/workflow.py:1742-1789, 1979-2145).  The
+    # columns of all items are joined on the samples they share.
+    cov_items = args.cov if isinstance(args.cov, list) else ([args.cov] if args.cov else [])
+    args.cov = bool(cov_items)
+    cv, cpos = None, {}
+    if cov_items:
+        parts = []
+        for item in cov_items:
+            site = _parse_cov_site_token(item)
+            if site is None:
+                if not os.path.isfile(item):
+                    print(f"Covariate file not found: {item}; skipped.")
+                    continue
+                cids_i, _, cv_i = _read_table(item)
+                parts.append((list(cids_i), np.asarray(cv_i, dtype=np.float64).reshape(len(cids_i), -1)))
+            else:
+                key = _canon_site_key(*site)
+                hit = next((j for j in range(len(bim.chrom)) if _canon_site_key(bim.chrom[j], bim.pos[j]) == key), None)
+                if hit is None:
+                    raise SystemExit(f"Some --cov SNP site(s) were not found in genotype: {site[0]}:{site[1]}")
+                row = packed_t[hit].cpu().numpy()
+                codes = ((row[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3).reshape(-1)[:n_fam]
+                gv = np.array([0.0, np.nan, 1.0, 2.0])[codes]
+                gv[np.isnan(gv)] = float(np.nanmean(gv)) if np.isfinite(gv).any() else 0.0
+                parts.append((list(fam), gv.reshape(-1, 1)))
+        if parts:
+            common = set(parts[0][0])
+            for ids_i, _m in parts[1:]:
+                common &= set(ids_i)
+            cids = [sid for sid in fam if sid in common]
+            if not cids:
+                raise SystemExit("No overlapping samples between genotype and covariates.")
+            cols = []
+            for ids_i, m_i in parts:
+                ix = {sid: i for i, sid in enumerate(ids_i)}
+                cols.append(m_i[[ix[sid] for sid in cids]])
+            cv = np.concatenate(cols, axis=1)
+            cpos = {s: i for i, s in enumerate(cids)}
+        else:
+            args.cov = False
     traits = _select_traits(names, args.ncol)
     out = _resolve_out(args, args.bfile)
     dev = packed_t.device
@@ -669,7 +735,8 @@ def main(argv=None):
     g.add_argument("-lmm2", "--lmm2", action="store_true", default=False)
     g.add_argument("-fvlmm", "--fvlmm", action="store_true", default=False)
     g.add_argument("-k", "--grm", dest="grm", type=str, default="1")
-    g.add_argument("-c", "--cov", dest="cov", default=None)
+    g.add_argument("-c", "--cov", dest="cov", action="append", default=None,
+                   help="covariate table (sample id + columns) or a SNP site chr:pos taken as a covariate; may be repeated")
     g.add_argument("-snps-only", "--snps-only", dest="snps_only", action="store_true", default=False,
                    help="drop sites whose alleles are not single A/C/G/T")
     g.add_argument("-mem", "--memory", dest="memory", type=float, default=None,

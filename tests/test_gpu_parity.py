@@ -3151,6 +3151,31 @@ def test_cli_gwas_with_principal_components(oracle, oracle_c, tmp_path):
     for i, ln in enumerate(lines[1:]):
         f = ln.split("\t")
         assert abs(float(f[7]) - ref[i, 0]) <= 2e-4 and abs(float(f[8]) - ref[i, 1]) <= 2e-4, (i, f[7], ref[i, 0])
+    # -c repeated, with a SNP site as a covariate (conditional analysis): the same table as a covariate file that already holds
+    # the site's genotype (missing calls at the site's mean)
+    site = 57                                                    # BIM position 58 on chromosome 1
+    gsite = g[site].astype(np.float64)
+    gsite[gsite < 0] = np.mean(gsite[gsite >= 0])
+    with open(prefix + ".cov2", "w") as fh:
+        fh.write("id\tage\tsnp\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{float(cvals[i])!r}\t{float(gsite[i])!r}\n")
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-c", prefix + ".cov", "-c", "chr1:58:58",
+                     "-force-model", "-o", prefix + "_s1"]) == 0
+    assert cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-c", prefix + ".cov2", "-force-model",
+                     "-o", prefix + "_s2"]) == 0
+    la, lb = (open(prefix + sfx + ".traitA.lmm.tsv").read().splitlines() for sfx in ("_s1", "_s2"))
+    assert len(la) == len(lb) and la[0] == lb[0]
+    for ra, rb in zip(la[1:], lb[1:]):
+        fa, fb = ra.split("\t"), rb.split("\t")
+        assert fa[:7] == fb[:7]
+        for c in (7, 8):
+            if fa[c] != "NaN" or fb[c] != "NaN":       # the conditioned SNP itself: se blows up, digits are noise on both sides
+                assert abs(float(fa[c]) - float(fb[c])) <= 2e-4 * max(1.0, abs(float(fb[c]))) or fa[2] == f"rs{site}"
+    with pytest.raises(SystemExit, match="not found in genotype"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-c", "7:123", "-o", prefix + "_s3"])
+    with pytest.raises(SystemExit, match="single site"):
+        cli.main(["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-c", "1:5:9", "-o", prefix + "_s3"])
     # -snps-only: the sites with a non-SNP allele leave the run altogether = the run on a BED without them
     bim2 = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["C" if j % 13 else "CAT" for j in range(m)],
                    ["T"] * m)

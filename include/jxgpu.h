@@ -217,6 +217,21 @@ int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int3
  * 128-row tile whose rows all qualify skips the lo plane of the design (two MFMA products instead of three). */
 int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
                        int64_t mk, void *d_lut16, float *d_rowoff, void *stream);
+/* jxg_lut_split_rows with a tolerance for rows that hold 1 .. miss_max missing calls (jxg_rot_miss_max(n, mean number of
+ * missing calls per row) is the default limit: 256 up to n / 800 missing calls per row on average, else 0 -- one decision per
+ * scan, a block is not split between the kernels for a handful of rows): they keep the exact path (finite d_rowoff) and d_rowmiss[k] = lut[k][missing] - (value of the int8 rotation's clean
+ * form at a missing call = offset + 2 [flipped]) is the weight of their
+ * missing-call term, which jxg_rotate_missing_correct adds behind the rotation: out[r][j] += d_r * sum over the row's missing
+ * samples i of U[i][j].  d_usamp (n, n) f32 = U with one row per sample (jxg_transpose_f32 of u_t).  Rows with more missing
+ * calls stay general (NaN offset, fp16 kernel) as before.  src/stats/lmm.rs:728-784 with the decode of
+ * src/decode/decode.rs:192-271. */
+int jxg_rot_miss_max(int n, double mean_missing_per_row);
+int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
+                         int64_t mk, void *d_lut16, float *d_rowoff, float *d_rowmiss, int miss_max, void *stream);
+int jxg_transpose_f32(const float *d_src, int n, float *d_dst, void *stream);
+int jxg_rotate_missing_correct(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                               const float *d_rowmiss, const float *d_usamp, float *d_out, int64_t ld_out, void *stream);
+
 int jxg_ut_rowsum(const float *d_ut, int n, float *d_usum, void *stream);
 int jxg_rotate_packed16x(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                          const void *d_lut16, const float *d_rowoff, const float *d_usum, const uint16_t *d_uhi,

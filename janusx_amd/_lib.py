@@ -125,6 +125,10 @@ SIGNATURES = {
     "jx_lm_assoc_dense": [c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p],
     "jxg_lm_scan_dense": [c_p, c_i, c_i, c_l, c_p, c_i, c_p, c_d, c_p, c_p, c_p],
     "jxg_decode_rows_p32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_l, c_p],
+    "jxg_rot_miss_max": [c_i, c_d],
+    "jxg_lut_split_rows_m": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p],
+    "jxg_transpose_f32": [c_p, c_i, c_p, c_p],
+    "jxg_rotate_missing_correct": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p],
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,

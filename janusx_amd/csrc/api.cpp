@@ -850,8 +850,6 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     JX_HIP(hipMemcpy(dlut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice));
     // fp16 LUT records once for all rows; rows without missing calls as integer LUT + offset (exact-row rotation)
     if (dlut16.alloc((size_t)16 * (size_t)m) || drowoff.alloc(sizeof(float) * (size_t)m)) return 1;
-    if (jxg_lut_split_rows(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(), nullptr))
-        return 1;
     const int64_t brows = 8192;
     // From n = 4096 the rows of a block are dealt to the int8 rotation (design rows without a missing call: three int8 planes
     // of U, k_rotate_i8.hip) and the 256-tile fp16 kernel by position lists, as pipeline.scan_rows does (JXGPU_ROT_I8=0: off)
@@ -860,6 +858,25 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     const bool use_q = n >= 4096 && q_env && !(model == 1 && p <= 8 && fused_mode == 2);
     // fixed lambda below that size: the rotation kernel's fused epilogue reduces the tile in place, G~ is never written
     const bool fused = model == 1 && p <= 8 && fused_mode != 0 && !use_q;
+    // rows with a few missing calls keep the exact rotation where the int8 kernel runs; their missing-call term is added behind
+    // it (jxg_rotate_missing_correct), exactly as pipeline.scan_rows does
+    DevBuf drowmiss, dusamp;
+    double miss_sum = 0.0;
+    for (int64_t j = 0; j < m; ++j) miss_sum += (double)cnt[(size_t)j * 3];
+    const int miss_max = use_q ? jxg_rot_miss_max(n, m > 0 ? miss_sum / (double)m : 0.0) : 0;
+    bool any_rowmiss = false;
+    if (miss_max > 0) {
+        if (drowmiss.alloc(sizeof(float) * (size_t)m)) return 1;
+        JX_HIP(hipMemset(drowmiss.p, 0, sizeof(float) * (size_t)m));
+    }
+    if (jxg_lut_split_rows_m(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(),
+                             miss_max > 0 ? drowmiss.as<float>() : nullptr, miss_max, nullptr))
+        return 1;
+    if (miss_max > 0) {
+        std::vector<float> hm((size_t)m);
+        JX_HIP(hipMemcpy(hm.data(), drowmiss.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < m && !any_rowmiss; ++i) any_rowmiss = hm[(size_t)i] != 0.0f;
+    }
     DevBuf dq, dumax, dsel;
     std::vector<float> hrowoff;
     std::vector<int32_t> hsel;
@@ -869,6 +886,10 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         if (dut2.alloc(sizeof(float) * (size_t)n * n)) return 1;
         JX_HIP(hipMemcpy(dut2.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
         if (jxg_ut_quant3(dut2.as<float>(), n, dq.as<int8_t>(), dumax.as<float>(), nullptr)) return 1;
+        if (any_rowmiss) {
+            if (dusamp.alloc(sizeof(float) * (size_t)n * n)) return 1;
+            if (jxg_transpose_f32(dut2.as<float>(), n, dusamp.as<float>(), nullptr)) return 1;
+        }
         JX_HIP(hipDeviceSynchronize());
         hrowoff.resize((size_t)m);
         JX_HIP(hipMemcpy(hrowoff.data(), drowoff.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
@@ -915,6 +936,10 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                                        uhi.as<uint16_t>(), ulo.as<uint16_t>(), scale_exp, dq.as<int8_t>(), dumax.as<float>(),
                                        ne > 0 ? dsel.as<int32_t>() : nullptr, ne, rows > ne ? dsel.as<int32_t>() + ne : nullptr,
                                        rows - ne, drot.as<float>(), nullptr))
+                return 1;
+            if (any_rowmiss && jxg_rotate_missing_correct(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                                          drowmiss.as<float>() + r0, dusamp.as<float>(), drot.as<float>(), n,
+                                                          nullptr))
                 return 1;
         } else if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
                                         (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void lut_split_rows_kernel(const uint8_t *__re
                                                              const int32_t *__restrict__ rows,
                                                              const float *__restrict__ lut, int64_t mk, int n_sel,
                                                              int nt128, uint4 *__restrict__ out,
-                                                             float *__restrict__ rowoff, int *__restrict__ flags) {
+                                                             float *__restrict__ rowoff, int *__restrict__ flags,
+                                                             float *__restrict__ rowmiss, int miss_max) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     float v[4];
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void lut_split_rows_kernel(const uint8_t *__re
     bool ok = fabsf(c2 - 1.0f) <= tol &&
               ((fabsf(c0) <= tol && fabsf(c3 - 2.0f) <= tol) || (fabsf(c0 - 2.0f) <= tol && fabsf(c3) <= tol)) &&
               fabsf(b) <= 4.0f;
+    int nmiss = 0;
     if (ok) {
         const int64_t rec = rows ? (int64_t)rows[k] : k;
-        uint32_t any = 0;
         for (int t = 0; t < nt128; ++t) {
             const uint4 *q = reinterpret_cast<const uint4 *>(p32 + ((int64_t)t * m_total + rec) * 32);
             const uint4 a = q[0], c = q[1];
@@ -109,18 +110,25 @@ __global__ __launch_bounds__(256) void lut_split_rows_kernel(const uint8_t *__re
                 const int left = valid - d * 16;
                 if (left <= 0) miss = 0;
                 else if (left < 16) miss &= (1u << (2 * left)) - 1u;
-                any |= miss;
+                nmiss += __popc(miss);
             }
         }
-        ok = (any == 0);
+        // a few missing calls: the row stays on the exact path (their code decodes to count 0 there) and
+        // rot_miss_correct_kernel adds d * sum_{i missing} U[i, :] behind the rotation
+        ok = (nmiss == 0) || (rowmiss != nullptr && nmiss <= miss_max && isfinite(v[1]));
     }
     float off = __builtin_nanf("");
+    float dmiss = 0.0f;
     if (ok) {
         const float r0 = (c0 > 1.0f) ? 2.0f : 0.0f, r3 = 2.0f - r0;
         off = ((v[0] - r0) + (v[2] - 1.0f) + (v[3] - r3)) * (1.0f / 3.0f);
+        // the int8 rotation (the only one this tolerance is used with) forms s (c U) + (offset + 2 [flipped]) usum with the
+        // unflipped count c, which is 0 at a missing call: its value there is offset + r0
+        if (nmiss > 0) dmiss = v[1] - (off + r0);
         v[0] = r0; v[1] = 0.0f; v[2] = 1.0f; v[3] = r3;
     }
     rowoff[k] = off;
+    if (rowmiss) rowmiss[k] = dmiss;
     uint16_t hi[4], lo[4];
     bool bad = false;
 #pragma unroll
@@ -581,21 +589,140 @@ extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void
     return 0;
 }
 
+// Largest number of missing calls with which a design row still takes the exact (int8) rotation + the gather correction
+// (rot_miss_correct_kernel).  The correction reads one row of U (4 n bytes) per missing call -- 19 ns at n = 20 000 --, the
+// fp16 kernel it avoids costs ~1 us per row there, but ALSO a fixed ~18 ms per launch, so a block should not be split between
+// the two for a handful of rows: the decision is made for the whole scan from the mean number of missing calls per row.  Up to
+// n / 800 of them (0.125 %) every row with <= 256 missing calls keeps the exact path, beyond that none does.
+// JXGPU_ROT_MISS_MAX overrides the limit (0: off).
+extern "C" int jxg_rot_miss_max(int n, double mean_missing_per_row) {
+    const char *e = getenv("JXGPU_ROT_MISS_MAX");
+    if (e) {
+        int v = atoi(e);
+        return v < 0 ? 0 : (v > 256 ? 256 : v);
+    }
+    if (!(mean_missing_per_row > 0.0)) return 0;
+    return mean_missing_per_row <= (double)n / 800.0 ? 256 : 0;
+}
+
+extern "C" int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
+                                    int64_t mk, void *d_lut16, float *d_rowoff, float *d_rowmiss, int miss_max, void *stream);
+
 extern "C" int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows,
                                   const float *d_lut, int64_t mk, void *d_lut16, float *d_rowoff, void *stream) {
+    return jxg_lut_split_rows_m(d_p32, m_total, n, d_rows, d_lut, mk, d_lut16, d_rowoff, nullptr, 0, stream);
+}
+
+// d_rowmiss (mk) f32 or NULL: d of the rows that keep the exact path although they hold 1 .. miss_max missing calls (0 for
+// every other row); see jxg_rotate_missing_correct.
+extern "C" int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
+                                    int64_t mk, void *d_lut16, float *d_rowoff, float *d_rowmiss, int miss_max, void *stream) {
     if (mk <= 0) return 0;
+    if (miss_max > 256) miss_max = 256;
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
     JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));
     JX_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
     hipLaunchKernelGGL(lut_split_rows_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_p32, m_total,
-                       d_rows, d_lut, mk, n, num_tiles(n), (uint4 *)d_lut16, d_rowoff, flags);
+                       d_rows, d_lut, mk, n, num_tiles(n), (uint4 *)d_lut16, d_rowoff, flags, d_rowmiss, miss_max);
     JX_LAUNCH_CHECK();
     int hflag = 0;
     JX_HIP(hipMemcpyAsync(&hflag, flags, sizeof(int), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
     JX_HIP(hipFreeAsync(flags, st));
     if (hflag) return fail("design values exceed the fp16 split range (|z| > 3e4)");
+    return 0;
+}
+
+// out[r][j] += d_r * sum_{i : sample i of row r is missing} usamp[i][j]   (usamp = U, sample-major: usamp[i][j] = u_t[j][i]).
+// One workgroup per row with d_r != 0: the missing samples are listed in sample order (count, scan, fill: no atomics), then
+// the threads walk the eigenvector index j and add the listed rows of U (coalesced), f64 sums.
+constexpr int RM_MAXLIST = 256;
+__global__ __launch_bounds__(256) void rot_miss_correct_kernel(const uint32_t *__restrict__ p32, int64_t m_total, int n,
+                                                               int nt, const int32_t *__restrict__ rows,
+                                                               const float *__restrict__ rowmiss,
+                                                               const float *__restrict__ usamp, float *__restrict__ out,
+                                                               int64_t ld) {
+    const int r = blockIdx.x;
+    const float d = rowmiss[r];
+    if (d == 0.0f) return;                                  // uniform
+    __shared__ int cnt[257];
+    __shared__ int list[RM_MAXLIST];
+    const int tid = threadIdx.x;
+    const int64_t rec = rows ? (int64_t)rows[r] : (int64_t)r;
+    const int ndw = nt * 8, per = (ndw + 255) / 256;
+    const int q0 = tid * per, q1 = min(ndw, q0 + per);
+    int c = 0;
+    for (int q = q0; q < q1; ++q) {
+        const uint32_t w = p32[((int64_t)(q >> 3) * m_total + rec) * 8 + (q & 7)];
+        uint32_t miss = w & ~(w >> 1) & 0x55555555u;
+        const int left = n - q * 16;
+        if (left < 16) miss &= (left <= 0) ? 0u : ((1u << (2 * left)) - 1u);
+        c += __popc(miss);
+    }
+    cnt[tid + 1] = c;
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= 256; ++t) cnt[t] += cnt[t - 1];
+    __syncthreads();
+    int at = cnt[tid];
+    const int total = min(cnt[256], RM_MAXLIST);
+    for (int q = q0; q < q1; ++q) {
+        const uint32_t w = p32[((int64_t)(q >> 3) * m_total + rec) * 8 + (q & 7)];
+        uint32_t miss = w & ~(w >> 1) & 0x55555555u;
+        const int left = n - q * 16;
+        if (left < 16) miss &= (left <= 0) ? 0u : ((1u << (2 * left)) - 1u);
+        while (miss) {
+            const int b = __ffs(miss) - 1;
+            miss &= miss - 1;
+            if (at < RM_MAXLIST) list[at] = q * 16 + (b >> 1);
+            ++at;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        double acc = 0.0;
+        int e = 0;
+        for (; e + 4 <= total; e += 4) {
+            const float a0 = usamp[(int64_t)list[e] * n + j], a1 = usamp[(int64_t)list[e + 1] * n + j];
+            const float a2 = usamp[(int64_t)list[e + 2] * n + j], a3 = usamp[(int64_t)list[e + 3] * n + j];
+            acc += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        }
+        for (; e < total; ++e) acc += (double)usamp[(int64_t)list[e] * n + j];
+        out[(int64_t)r * ld + j] += (float)((double)d * acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float *__restrict__ src, int n, float *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < n && bx + tx < n) tile[r][tx] = src[(int64_t)(by + r) * n + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < n && by + tx < n) dst[(int64_t)(bx + r) * n + by + tx] = tile[tx][r];
+}
+
+// dst = src' for an (n, n) f32 matrix: the sample-major copy of U the correction below gathers from
+extern "C" int jxg_transpose_f32(const float *d_src, int n, float *d_dst, void *stream) {
+    if (n <= 0) return 0;
+    const unsigned nb = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, d_src, n, d_dst);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// Behind the rotation of a block of rows: adds the missing-call term of the rows jxg_lut_split_rows_m kept on the exact path
+// (d_rowmiss[r] != 0).  d_usamp (n, n) f32 = U with one ROW per sample (jxg_transpose_f32 of u_t); d_out (nrows, ld_out).
+extern "C" int jxg_rotate_missing_correct(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
+                                          const float *d_rowmiss, const float *d_usamp, float *d_out, int64_t ld_out,
+                                          void *stream) {
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(rot_miss_correct_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t *)d_p32, m_total, n, num_tiles(n), d_rows, d_rowmiss, d_usamp, d_out, ld_out);
+    JX_LAUNCH_CHECK();
     return 0;
 }
 

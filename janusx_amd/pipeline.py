@@ -311,6 +311,15 @@ class SpectralModel:
             self._qplanes = (q, umax)
         return self._qplanes
 
+    def usamp(self):
+        """U with one row per sample (the transpose of `ut`, f32): what the missing-call term of the rotation gathers from
+        (jxg_rotate_missing_correct)."""
+        if getattr(self, "_usamp", None) is None:
+            us = torch.empty((self.n, self.n), dtype=torch.float32, device=self.S.device)
+            check(lib().jxg_transpose_f32(_ptr(self.ut), self.n, _ptr(us), _stream()))
+            self._usamp = us
+        return self._usamp
+
     def fv_cache(self, log10_lbd=None):
         lbd = self.null.lbd if log10_lbd is None else 10.0 ** float(log10_lbd)
         if self._fv is None or self._fv[0] != lbd:
@@ -371,8 +380,18 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     # below then only launches kernels (no allocation, no host sync).
     lut16 = torch.empty((mk, 16), dtype=torch.uint8, device=dev)
     rowoff = torch.empty(mk, dtype=torch.float32, device=dev)
-    check(lib().jxg_lut_split_rows(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16),
-                                   _ptr(rowoff), _stream()))
+    # rows with a few missing calls keep the exact (int8) rotation and get their missing-call term added behind it
+    # (jxg_rotate_missing_correct: d * the sum of the missing samples' rows of U); only where the int8 rotation runs
+    miss_max = 0
+    if qpl is not None:
+        cnt = panel.counts()
+        miss_max = int(lib().jxg_rot_miss_max(n, float(np.mean(cnt[np.asarray(rows, dtype=np.int64), 0])) if mk else 0.0))
+    rowmiss = torch.zeros(mk, dtype=torch.float32, device=dev) if miss_max > 0 else None
+    check(lib().jxg_lut_split_rows_m(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16),
+                                     _ptr(rowoff), _ptr(rowmiss) if rowmiss is not None else None, miss_max, _stream()))
+    if rowmiss is not None and not bool((rowmiss != 0).any().item()):
+        rowmiss = None
+    usamp = model.usamp() if rowmiss is not None else None
     tables = None
     if mode == "splmm" and fv_state is None:
         raise RuntimeError("the SparseLMM exact scan needs its null state (fv_state = w, py, wx, a_chol, ypy)")
@@ -464,6 +483,9 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                                    e1 - e0,
                                                    sel_rest_t[x0:].data_ptr() if (sel_rest_t is not None and x1 > x0) else None,
                                                    x1 - x0, _ptr(grot), _stream()))
+                if rowmiss is not None:
+                    check(lib().jxg_rotate_missing_correct(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
+                                                           rowmiss[r0:].data_ptr(), _ptr(usamp), _ptr(grot), n, _stream()))
             else:
                 check(lib().jxg_rotate_packed16x(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
                                                  lut16[r0:].data_ptr(), rowoff[r0:].data_ptr(), _ptr(usum), _ptr(hi), _ptr(lo),

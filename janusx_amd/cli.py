@@ -507,6 +507,23 @@ BLUP_SMALL_N = 15000      # python/janusx/gs/blup.py:8-9
 BLUP_SMALL_M = 15000
 
 
+def resolve_blup_dispatch(n_samples, n_markers, force=None):
+    """`resolve_blup_dispatch` (python/janusx/gs/blup.py:73-163) -> (effective method, rrBLUP solver or None).  `force` = the
+    value of GS_BLUP ("0" GBLUP, "1" exact rrBLUP, "2" PCG rrBLUP; None / "" = automatic)."""
+    force = (force or "").strip()
+    if force not in ("", "0", "1", "2"):
+        raise ValueError(f"Invalid GS_BLUP={force!r}; expected 0 (GBLUP), 1 (rrBLUP exact), or 2 (rrBLUP PCG).")
+    if force == "0":
+        return "GBLUP", None
+    if force == "1":
+        return "rrBLUP", "exact"
+    if force == "2":
+        return "rrBLUP", "pcg"
+    if max(0, int(n_samples)) <= BLUP_SMALL_N:
+        return "GBLUP", None
+    return "rrBLUP", ("exact" if max(0, int(n_markers)) <= BLUP_SMALL_M else "pcg")
+
+
 def cmd_gs(args):
     """`jx gs -BLUP`: centred GRM of all genotyped samples (once), then per trait a GBLUP fit on the phenotyped
     samples (spectral REML, src/stats/gblup.rs:1105-1240) -- K-fold cross-validated with `-cv` (folds of
@@ -525,13 +542,17 @@ def cmd_gs(args):
         # -BLUP = automatic dispatch (`resolve_blup_dispatch`, python/janusx/gs/blup.py:8-163): n_train <= 15000 -> GBLUP;
         # beyond that rrBLUP, exact (marker space) up to 15000 kept markers and PCG above; GS_BLUP=0/1/2 forces a route
         force = os.environ.get("GS_BLUP", "").strip()
-        if force not in ("", "0", "1", "2"):
-            raise SystemExit(f"Invalid GS_BLUP={force!r}; expected 0 (GBLUP), 1 (rrBLUP exact), or 2 (rrBLUP PCG).")
         n_train_max = 0
         for ti in traits:
             n_train_max = max(n_train_max, sum(1 for sid in fam if sid in pos and math.isfinite(ph[pos[sid], ti])))
-        if force in ("1", "2") or (force == "" and n_train_max > BLUP_SMALL_N):
-            args.rr_solver = {"1": "exact", "2": "pcg"}.get(force, "auto")     # auto: exact up to 15000 kept markers
+        try:
+            method, _solver = resolve_blup_dispatch(n_train_max, 0, force)
+        except ValueError as e:
+            raise SystemExit(str(e))
+        if method == "rrBLUP":
+            # the kept-marker count is known only behind the QC of the rrBLUP route: its "auto" solver applies the same
+            # 15000-marker rule (exact up to it, PCG above)
+            args.rr_solver = {"1": "exact", "2": "pcg"}.get(force, "auto")
             print(f"-BLUP dispatch: n_train={n_train_max} -> rrBLUP ({args.rr_solver})"
                   + (f" (forced by GS_BLUP={force})" if force else ""))
             return cmd_gs_rrblup(args)

@@ -35,6 +35,7 @@ int sy2sb_bandwidth();
 int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work, int *d_flags);
 int sb2st_ldab();
 int sb2st_steps(int n);
+size_t sb2st_ctrl_bytes(int n);
 int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, double *d_v2, double *d_tau2, int *d_ctrl);
 // k_sbback.hip: C <- Q2 C (reflectors of the bulge chasing); k_ormtr.hip: C <- Q1 C (reflectors of the band reduction)
 size_t sbback_tq_doubles(int n, int ks);
@@ -203,7 +204,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             if (ts_ab.alloc(sizeof(double) * (size_t)ldab * n)) return 1;
             if (ts_v2.take(4, sizeof(double) * (size_t)n * n)) return 1;
             if (ts_tau2.alloc(sizeof(double) * (size_t)n * ks)) return 1;
-            if (ts_ctrl.alloc(sizeof(int) * ((size_t)n + 4))) return 1;
+            if (ts_ctrl.alloc(sb2st_ctrl_bytes(n))) return 1;
             if (ts_flags.alloc(sizeof(int) * 4)) return 1;
             // the band reduction overwrites A: keep a copy (in the buffer the divide and conquer fills later) in case a
             // panel cannot be factored
@@ -389,7 +390,7 @@ extern "C" int jxg_sy2st_f64(double *d_a, int n, double *d_d, double *d_e, doubl
     if (tau.alloc(sizeof(double) * (size_t)n)) return 1;
     if (v2.alloc(sizeof(double) * (size_t)n * n)) return 1;
     if (tau2.alloc(sizeof(double) * (size_t)n * ks)) return 1;
-    if (ctrl.alloc(sizeof(int) * ((size_t)n + 4))) return 1;
+    if (ctrl.alloc(sb2st_ctrl_bytes(n))) return 1;
     if (flags.alloc(sizeof(int) * 4)) return 1;
     const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
     if (trace) JX_HIP(hipStreamSynchronize(st));

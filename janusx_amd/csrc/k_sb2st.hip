@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const double wc = wsh[c0 + c];
-                    dD[c] -= v_lane * wc + w_lane * vq[c];
+                    dD[c] -= __dadd_rn(__dmul_rn(v_lane, wc), __dmul_rn(w_lane, vq[c]));   // no contraction: D stays exactly symmetric
                     dB[c] -= z * vq[c];
                 }
                 if (rowsB > 0) {
@@ -308,6 +308,268 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Position-owned form.  Workgroup k owns STEP k of every sweep: its window (D, B of the columns [s + 1 + 64 k, + 64)) stays
+// in registers for the whole chase and slides by one row and column per sweep; what travels between workgroups is
+//   R(s, k + 1): the reflector formed by step (s, k)                    (k -> k + 1, 64 doubles + tau),
+//   C(s, k - 1): column 0 of the window after step (s, k) (final for the sweep: D[0..63][0], B[0][0]; it is the column
+//                that enters the window of position k - 1 when that slides to sweep s + 1)   (k -> k - 1, 65 doubles),
+// instead of a 64 KB window per step.  Both leave as soon as the new reflector exists (before the left application on
+// B, which is off the chain).  Position 0 keeps its column: it is the source of the next sweep's first reflector and of
+// d[s + 1], e[s + 1].  The arithmetic of a step is the statement sequence of sb2st_chase_kernel on the same values (the
+// symmetric update is written so that D stays exactly symmetric in both), so d, e, v2 and tau2 are bit-identical to it.
+// Every workgroup must be resident (the host checks the occupancy and falls back to the sweep-owned kernel).
+struct BoParams {
+    const double *ab;
+    int n;
+    double *v2, *tau2;
+    int ks;
+    double *d, *e;
+    double *rmsg;      // [positions][2 slots][BO_MSG]: v[0..63], tau
+    double *cmsg;      // [positions][2 slots][BO_MSG]: D[0..63][0], B[0][0]
+    int *rflag;        // [positions] reflectors delivered (s + 1 after sweep s)
+    int *cflag;        // [positions] columns delivered
+    int *abort_flag;
+};
+constexpr int BO_MSG = 72;
+
+constexpr int BO_LDS_DOUBLES = 2 * BC_SB + 8 * BC_SB + 8 + 4 * BC_SB + 64 + 4 * 16 * BC_P + BO_MSG + BC_SB + 2;
+
+__global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void sb2st_owned_kernel(BoParams P) {
+    // dynamic LDS (38 KB): a static size would make the compiler assume one workgroup per CU and take 250 registers
+    extern __shared__ __attribute__((aligned(16))) double bo_smem[];
+    double *vv = bo_smem, *vn = vv + BC_SB, *part = vn + BC_SB, *sc = part + 8 * BC_SB, *wcopy = sc + 8, *usum = wcopy + 4 * BC_SB,
+           *colscr = usum + 64, *inc = colscr + 4 * 16 * BC_P, *brow = inc + BO_MSG;
+    int *ish = reinterpret_cast<int *>(brow + BC_SB);
+    double *edge = colscr;                       // [2][4][SB]: column 0 of every wave's D and B (slide; colscr is idle then)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = P.n, k = blockIdx.x;
+    const int row = lane, quarter = wave, c0 = quarter * 16;
+
+    // ---- the window of sweep 0
+    double dD[16], dB[16];
+    {
+        const int r = 1 + BC_SB * k, L = min(BC_SB, n - r);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int col = c0 + c;
+            const int lo = min(row, col), hi = max(row, col);
+            dD[c] = (row < L && col < L) ? P.ab[(int64_t)(r + lo) * BC_LD + (hi - lo)] : 0.0;
+            dB[c] = (col < L && r + BC_SB + row < n) ? P.ab[(int64_t)(r + col) * BC_LD + (BC_SB + row - col)] : 0.0;
+        }
+    }
+    double v0 = 0.0, tau0 = 0.0;                 // position 0, wave 0: the reflector of the next sweep
+    if (k == 0 && wave == 0) {
+        const int L = min(BC_SB, n - 1);
+        const double xc = (lane < L) ? P.ab[1 + lane] : 0.0;
+        double beta;
+        bc_house_wave(xc, lane, L, v0, tau0, beta);
+        if (lane == 0) {
+            P.d[0] = P.ab[0];
+            P.e[0] = beta;
+        }
+    }
+    if (t < BO_MSG) inc[t] = 0.0;
+
+    for (int s = 0; s < n - 2; ++s) {
+        const int r = s + 1 + BC_SB * k;
+        if (r >= n) break;
+        const int L = min(BC_SB, n - r);
+        const int L1 = min(BC_SB, n - (r + L));
+        const int rowsB = L1 > 0 ? L1 : 0;
+        const bool need_r = k > 0, need_c = s > 0 && r + BC_SB - 1 < n;
+        // ---- messages: the reflector of this step, the column that completes the slide
+        if (wave == 0) {
+            bool ok = true;
+            if (need_r || need_c) {
+                unsigned spins = 0;
+                for (;;) {
+                    const int fr = need_r ? __hip_atomic_load(P.rflag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BC_DONE;
+                    const int fc = need_c ? __hip_atomic_load(P.cflag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BC_DONE;
+                    if (fr >= s + 1 && fc >= s) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if (spins > BC_SPIN_LIMIT ||
+                        ((spins & 63u) == 0 && __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        ok = false;
+                        break;
+                    }
+                }
+            }
+            if (ok) {
+                if (need_r) {
+                    const double *m = P.rmsg + ((int64_t)k * 2 + (s & 1)) * BO_MSG;
+                    const double a = bc_ld(m + lane);
+                    double b = 0.0;
+                    if (lane == 0) b = bc_ld(m + BC_SB);
+                    vv[lane] = a;
+                    if (lane == 0) sc[0] = b;
+                } else {
+                    vv[lane] = v0;
+                    if (lane == 0) sc[0] = tau0;
+                }
+                if (need_c) {
+                    const double *m = P.cmsg + ((int64_t)k * 2 + ((s - 1) & 1)) * BO_MSG;
+                    const double a = bc_ld(m + lane);
+                    double b = 0.0;
+                    if (lane == 0) b = bc_ld(m + BC_SB);
+                    inc[lane] = a;
+                    if (lane == 0) inc[BC_SB] = b;
+                } else {
+                    inc[lane] = 0.0;
+                    if (lane == 0) inc[BC_SB] = 0.0;
+                }
+            }
+            if (lane == 0) ish[0] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ish[0]) {
+            if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // ---- the slide's last piece: the entering column (logical column 63 = wave 3, register 15)
+        if (s > 0 && wave == 3) {
+            if (lane == 63) dD[15] = inc[0];
+            dB[15] = inc[1 + lane];
+        }
+        const double tau = sc[0];
+        double taun = 0.0;
+        if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
+        if (t == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
+        const double v_lane = (lane < L) ? vv[lane] : 0.0;
+        double vq[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vq[c] = (c0 + c < L) ? vv[c0 + c] : 0.0;
+        // ---- y = D v, z = B v
+        {
+            double py = 0.0, pz = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                py += dD[c] * vq[c];
+                pz += dB[c] * vq[c];
+            }
+            part[quarter * BC_SB + row] = py;
+            part[(4 + quarter) * BC_SB + row] = pz;
+        }
+        __syncthreads();
+        const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
+        const double z = tau * ((part[4 * BC_SB + row] + part[5 * BC_SB + row]) + (part[6 * BC_SB + row] + part[7 * BC_SB + row]));
+        double vy = y * v_lane;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vy += __shfl_xor(vy, o);
+        const double w_lane = tau * y - (0.5 * tau * tau * vy) * v_lane;
+        double *wsh = wcopy + wave * BC_SB;
+        wsh[lane] = w_lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double wc = wsh[c0 + c];
+            dD[c] -= __dadd_rn(__dmul_rn(v_lane, wc), __dmul_rn(w_lane, vq[c]));
+            dB[c] -= z * vq[c];
+        }
+        // ---- new reflector from the first column of B; the two messages leave at once
+        if (wave == 0) {
+            double vnl = 0.0, tn = 0.0;
+            if (rowsB > 0) {
+                double beta;
+                bc_house_wave(dB[0], lane, rowsB, vnl, tn, beta);
+                dB[0] = (lane == 0) ? beta : 0.0;
+                vnl = (lane < rowsB) ? vnl : 0.0;
+                vn[lane] = vnl;
+                if (lane == 0) sc[1] = tn;
+                double *m = P.rmsg + ((int64_t)(k + 1) * 2 + (s & 1)) * BO_MSG;
+                bc_st(m + lane, vnl);
+                if (lane == 0) bc_st(m + BC_SB, tn);
+            }
+            if (k > 0) {
+                double *m = P.cmsg + ((int64_t)(k - 1) * 2 + (s & 1)) * BO_MSG;
+                bc_st(m + lane, dD[0]);
+                if (lane == 0) bc_st(m + BC_SB, dB[0]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    if (rowsB > 0) __hip_atomic_store(P.rflag + k + 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(P.cflag + k - 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0 && rowsB > 0) __hip_atomic_store(P.rflag + 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // position 0: column s + 1 is final: d[s + 1], and either the next sweep's reflector or the last entries
+                const double below = __shfl(dD[0], (lane + 1) & 63), b00 = __shfl(dB[0], 0);
+                const double xc = (lane < 63) ? below : b00;          // A(s + 2 + lane, s + 1)
+                if (lane == 0) P.d[s + 1] = dD[0];
+                if (s + 1 < n - 2) {
+                    const int Ln = min(BC_SB, n - (s + 2));
+                    double beta;
+                    bc_house_wave((lane < Ln) ? xc : 0.0, lane, Ln, v0, tau0, beta);
+                    if (lane == 0) P.e[s + 1] = beta;
+                } else {
+                    if (lane == 0) P.e[s + 1] = xc;
+                    if (lane == 1) {
+                        P.d[s + 2] = dD[1];
+                        P.e[s + 2] = 0.0;
+                    }
+                }
+            }
+        }
+        if (rowsB > 0) {
+            __syncthreads();
+            taun = sc[1];
+            const double vn_lane = vn[lane];
+            // ---- B <- H1 B on the columns 1 .. L-1 (off the chain)
+            double *scr = colscr + wave * (16 * BC_P);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) scr[c * BC_P + lane] = vn_lane * dB[c];
+            __syncthreads();
+            {
+                const int cl = lane >> 2, sub = lane & 3;
+                double acc = 0.0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) acc += scr[cl * BC_P + sub * 16 + p];
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (sub == 0) usum[wave * 16 + cl] = acc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c0 + c == 0) continue;
+                dB[c] -= taun * vn_lane * usum[wave * 16 + c];
+            }
+        }
+        __syncthreads();                                   // colscr (edge) and part are free
+        // ---- slide by one row and column: D'[i][j] = D[i+1][j+1], D'[63][j] = B[0][j+1] = D'[j][63], B'[i][j] = B[i+1][j+1],
+        // row 63 of B' is zero up to the entering column (set at the top of the next sweep)
+        edge[quarter * BC_SB + lane] = dD[0];
+        edge[(4 + quarter) * BC_SB + lane] = dB[0];
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c0 + c >= 1) brow[c0 + c - 1] = dB[c];
+        }
+        __syncthreads();
+        {
+            const double eD = (quarter < 3) ? edge[(quarter + 1) * BC_SB + lane] : 0.0;
+            const double eB = (quarter < 3) ? edge[(4 + quarter + 1) * BC_SB + lane] : 0.0;
+            const int src = (lane + 1) & 63;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double tD = (c < 15) ? dD[(c + 1) & 15] : eD;
+                const double tB = (c < 15) ? dB[(c + 1) & 15] : eB;
+                const double rD = __shfl(tD, src), rB = __shfl(tB, src);
+                dD[c] = (lane < 63) ? rD : rB;
+                dB[c] = (lane < 63) ? rB : 0.0;
+            }
+            if (quarter == 3) {
+                dD[15] = (lane < 63) ? brow[lane] : 0.0;
+                dB[15] = 0.0;
+            }
+        }
+        // (the barrier at the top of the next sweep separates these reads of edge / brow from their next writes)
+    }
+}
+
 __global__ void sb2st_de_kernel(const double *__restrict__ ab, int n, double *__restrict__ d, double *__restrict__ e) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -317,25 +579,44 @@ __global__ void sb2st_de_kernel(const double *__restrict__ ab, int n, double *__
 
 int sb2st_ldab() { return BC_LD; }
 int sb2st_steps(int n) { return (n + BC_SB - 1) / BC_SB + 1; }
+static int sb2st_positions(int n) { return n > 2 ? (n - 2) / BC_SB + 1 : 0; }
+static size_t sb2st_ctrl_ints(int n) { return (((size_t)n + 4) + 3) & ~(size_t)3; }
+// bytes of d_ctrl: progress counters / message flags + abort flag, then the message slots of the position-owned kernel
+size_t sb2st_ctrl_bytes(int n) {
+    return sizeof(int) * sb2st_ctrl_ints(n) + sizeof(double) * (size_t)sb2st_positions(n) * 4 * BO_MSG;
+}
 
-// d_ab (2 SB x n band, lower, ld = 2 SB; destroyed) -> d, e of the tridiagonal matrix; reflectors to d_v2 (n x n,
-// column s = sweep s; only the entries written are meaningful) and d_tau2 (n x sb2st_steps(n)).
-// d_ctrl: >= n + 4 ints (progress counters + abort flag), zeroed here.  d_ctrl[n] != 0 after synchronisation = a
-// bounded wait expired (never observed; the caller then reports an error instead of hanging).
+// d_ab (2 SB x n band, lower, ld = 2 SB; the sweep-owned kernel destroys it) -> d, e of the tridiagonal matrix; reflectors to
+// d_v2 (n x n, column s = sweep s; only the entries written are meaningful) and d_tau2 (n x sb2st_steps(n)).
+// d_ctrl: sb2st_ctrl_bytes(n), zeroed here.  d_ctrl[n] != 0 after synchronisation = a bounded wait expired (never
+// observed; the caller then reports an error instead of hanging).
+// JXGPU_BC_OWNED=0 selects the sweep-owned kernel (also taken when the positions do not all fit the device at once).
 int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, double *d_v2, double *d_tau2, int *d_ctrl) {
     const int ks = sb2st_steps(n);
     JX_HIP(hipMemsetAsync(d_ctrl, 0, sizeof(int) * ((size_t)n + 4), st));
     JX_HIP(hipMemsetAsync(d_tau2, 0, sizeof(double) * (size_t)n * ks, st));
+    static int cus = 0, owned_occ = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        JX_HIP(hipGetDevice(&dev));
+        JX_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&owned_occ, (const void *)sb2st_owned_kernel, BC_THREADS, sizeof(double) * BO_LDS_DOUBLES) != hipSuccess)
+            owned_occ = 0;
+    }
+    const int np = sb2st_positions(n);
+    const char *om = getenv("JXGPU_BC_OWNED");
+    const bool owned = n > 2 * BC_SB + 2 && !(om && atoi(om) == 0) && np <= cus * owned_occ && 2 * np <= n;
+    if (owned) {
+        double *msg = reinterpret_cast<double *>(d_ctrl + sb2st_ctrl_ints(n));
+        BoParams P{d_ab, n, d_v2, d_tau2, ks, d_d, d_e, msg, msg + (size_t)np * 2 * BO_MSG, d_ctrl, d_ctrl + np, d_ctrl + n};
+        hipLaunchKernelGGL(sb2st_owned_kernel, dim3(np), dim3(BC_THREADS), sizeof(double) * BO_LDS_DOUBLES, st, P);
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
     if (n > 2) {
         BcParams P{d_ab, n, d_v2, d_tau2, ks, d_ctrl, d_ctrl + n, getenv("JXGPU_BC_SKIP") ? atoi(getenv("JXGPU_BC_SKIP")) : 0};
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            JX_HIP(hipGetDevice(&dev));
-            JX_HIP(hipGetDeviceProperties(&prop, dev));
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        }
         // sweeps in flight are at most half the steps of a sweep (lag of two steps); one workgroup per CU
         int g = (ks + 1) / 2 + 1;
         if (getenv("JXGPU_SB2ST_WGS") && atoi(getenv("JXGPU_SB2ST_WGS")) > 0) g = atoi(getenv("JXGPU_SB2ST_WGS"));

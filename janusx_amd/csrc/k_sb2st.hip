@@ -325,13 +325,37 @@ struct BoParams {
     double *v2, *tau2;
     int ks;
     double *d, *e;
-    double *rmsg;      // [positions][2 slots][BO_MSG]: v[0..63], tau
-    double *cmsg;      // [positions][2 slots][BO_MSG]: D[0..63][0], B[0][0]
-    int *rflag;        // [positions] reflectors delivered (s + 1 after sweep s)
-    int *cflag;        // [positions] columns delivered
+    double *rmsg;      // [positions][2 slots][BO_MSG] cells of 16 bytes: v[0..63], tau
+    double *cmsg;      // [positions][2 slots][BO_MSG] cells: D[0..63][0], B[0][0]
     int *abort_flag;
 };
 constexpr int BO_MSG = 72;
+// A message has no flag: every value travels in a 16-byte cell {value, value bits ^ pattern(sequence number)} written by ONE
+// 16-byte write-through store and the receiver polls the cells themselves -- one store and one load on the chain instead of
+// store, drain, flag store, flag load, payload load.  A cell whose halves belonged to different messages would fail the
+// check (the tag binds the value), so the protocol does not rest on the 16 bytes arriving together.
+__device__ __forceinline__ unsigned long long bo_pattern(int seq) {
+    return ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)seq;
+}
+__device__ __forceinline__ void bo_put(__amdgpu_buffer_rsrc_t rs, int cell, double v, int seq) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = bits ^ bo_pattern(seq);
+    bc_v4i o;
+    o[0] = (int)(unsigned)bits;
+    o[1] = (int)(unsigned)(bits >> 32);
+    o[2] = (int)(unsigned)tag;
+    o[3] = (int)(unsigned)(tag >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(o, rs, cell * 16, 0, BC_AUX_SC1);
+}
+__device__ __forceinline__ bool bo_get(__amdgpu_buffer_rsrc_t rs, int cell, int seq, double &v) {
+    const bc_v4i x = __builtin_amdgcn_raw_buffer_load_b128(rs, cell * 16, 0, BC_AUX_SC1);
+    const unsigned long long bits = ((unsigned long long)(unsigned)x[1] << 32) | (unsigned)x[0];
+    const unsigned long long tag = ((unsigned long long)(unsigned)x[3] << 32) | (unsigned)x[2];
+    v = __longlong_as_double((long long)bits);
+    return (bits ^ tag) == bo_pattern(seq);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bo_slot(double *base, int pos, int slot) {
+    return __builtin_amdgcn_make_buffer_rsrc(base + ((int64_t)pos * 2 + slot) * (2 * BO_MSG), 0, BO_MSG * 16, 0x00020000);
+}
 
 constexpr int BO_LDS_DOUBLES = 2 * BC_SB + 8 * BC_SB + 8 + 4 * BC_SB + 64 + 4 * 16 * BC_P + BO_MSG + BC_SB + 2;
 
@@ -381,15 +405,24 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // ---- messages: the reflector of this step, the column that completes the slide
         if (wave == 0) {
             bool ok = true;
+            double ra = v0, rb = tau0, ca = 0.0, cb = 0.0;
             if (need_r || need_c) {
+                const __amdgpu_buffer_rsrc_t rr = bo_slot(P.rmsg, k, s & 1), rc = bo_slot(P.cmsg, k, (s - 1) & 1);
                 unsigned spins = 0;
                 for (;;) {
-                    const int fr = need_r ? __hip_atomic_load(P.rflag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BC_DONE;
-                    const int fc = need_c ? __hip_atomic_load(P.cflag + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BC_DONE;
-                    if (fr >= s + 1 && fc >= s) break;
+                    bool good = true;
+                    if (need_r) {
+                        good = bo_get(rr, lane, s + 1, ra) && good;
+                        if (lane == 0) good = bo_get(rr, BC_SB, s + 1, rb) && good;
+                    }
+                    if (need_c) {
+                        good = bo_get(rc, lane, s, ca) && good;
+                        if (lane == 0) good = bo_get(rc, BC_SB, s, cb) && good;
+                    }
+                    if (__ballot(good) == ~0ull) break;
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
-                    if (spins > BC_SPIN_LIMIT ||
+                    if (spins > (BC_SPIN_LIMIT >> 2) ||
                         ((spins & 63u) == 0 && __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         ok = false;
                         break;
@@ -397,27 +430,11 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
             }
             if (ok) {
-                if (need_r) {
-                    const double *m = P.rmsg + ((int64_t)k * 2 + (s & 1)) * BO_MSG;
-                    const double a = bc_ld(m + lane);
-                    double b = 0.0;
-                    if (lane == 0) b = bc_ld(m + BC_SB);
-                    vv[lane] = a;
-                    if (lane == 0) sc[0] = b;
-                } else {
-                    vv[lane] = v0;
-                    if (lane == 0) sc[0] = tau0;
-                }
-                if (need_c) {
-                    const double *m = P.cmsg + ((int64_t)k * 2 + ((s - 1) & 1)) * BO_MSG;
-                    const double a = bc_ld(m + lane);
-                    double b = 0.0;
-                    if (lane == 0) b = bc_ld(m + BC_SB);
-                    inc[lane] = a;
-                    if (lane == 0) inc[BC_SB] = b;
-                } else {
-                    inc[lane] = 0.0;
-                    if (lane == 0) inc[BC_SB] = 0.0;
+                vv[lane] = ra;
+                inc[lane] = need_c ? ca : 0.0;
+                if (lane == 0) {
+                    sc[0] = rb;
+                    inc[BC_SB] = need_c ? cb : 0.0;
                 }
             }
             if (lane == 0) ish[0] = ok ? 1 : 0;
@@ -479,22 +496,15 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 vnl = (lane < rowsB) ? vnl : 0.0;
                 vn[lane] = vnl;
                 if (lane == 0) sc[1] = tn;
-                double *m = P.rmsg + ((int64_t)(k + 1) * 2 + (s & 1)) * BO_MSG;
-                bc_st(m + lane, vnl);
-                if (lane == 0) bc_st(m + BC_SB, tn);
+                const __amdgpu_buffer_rsrc_t rs = bo_slot(P.rmsg, k + 1, s & 1);
+                bo_put(rs, lane, vnl, s + 1);
+                if (lane == 0) bo_put(rs, BC_SB, tn, s + 1);
             }
             if (k > 0) {
-                double *m = P.cmsg + ((int64_t)(k - 1) * 2 + (s & 1)) * BO_MSG;
-                bc_st(m + lane, dD[0]);
-                if (lane == 0) bc_st(m + BC_SB, dB[0]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    if (rowsB > 0) __hip_atomic_store(P.rflag + k + 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(P.cflag + k - 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                const __amdgpu_buffer_rsrc_t rs = bo_slot(P.cmsg, k - 1, s & 1);
+                bo_put(rs, lane, dD[0], s + 1);
+                if (lane == 0) bo_put(rs, BC_SB, dB[0], s + 1);
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0 && rowsB > 0) __hip_atomic_store(P.rflag + 1, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // position 0: column s + 1 is final: d[s + 1], and either the next sweep's reflector or the last entries
                 const double below = __shfl(dD[0], (lane + 1) & 63), b00 = __shfl(dB[0], 0);
                 const double xc = (lane < 63) ? below : b00;          // A(s + 2 + lane, s + 1)
@@ -583,7 +593,7 @@ static int sb2st_positions(int n) { return n > 2 ? (n - 2) / BC_SB + 1 : 0; }
 static size_t sb2st_ctrl_ints(int n) { return (((size_t)n + 4) + 3) & ~(size_t)3; }
 // bytes of d_ctrl: progress counters / message flags + abort flag, then the message slots of the position-owned kernel
 size_t sb2st_ctrl_bytes(int n) {
-    return sizeof(int) * sb2st_ctrl_ints(n) + sizeof(double) * (size_t)sb2st_positions(n) * 4 * BO_MSG;
+    return sizeof(int) * sb2st_ctrl_ints(n) + sizeof(double) * (size_t)sb2st_positions(n) * 4 * (2 * BO_MSG);
 }
 
 // d_ab (2 SB x n band, lower, ld = 2 SB; the sweep-owned kernel destroys it) -> d, e of the tridiagonal matrix; reflectors to
@@ -610,7 +620,8 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
     const bool owned = n > 2 * BC_SB + 2 && !(om && atoi(om) == 0) && np <= cus * owned_occ && 2 * np <= n;
     if (owned) {
         double *msg = reinterpret_cast<double *>(d_ctrl + sb2st_ctrl_ints(n));
-        BoParams P{d_ab, n, d_v2, d_tau2, ks, d_d, d_e, msg, msg + (size_t)np * 2 * BO_MSG, d_ctrl, d_ctrl + np, d_ctrl + n};
+        BoParams P{d_ab, n, d_v2, d_tau2, ks, d_d, d_e, msg, msg + (size_t)np * 2 * (2 * BO_MSG), d_ctrl + n};
+        JX_HIP(hipMemsetAsync(msg, 0, sizeof(double) * (size_t)np * 4 * (2 * BO_MSG), st));   // tags of an earlier chase
         hipLaunchKernelGGL(sb2st_owned_kernel, dim3(np), dim3(BC_THREADS), sizeof(double) * BO_LDS_DOUBLES, st, P);
         JX_LAUNCH_CHECK();
         return 0;

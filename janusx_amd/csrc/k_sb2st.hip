@@ -47,12 +47,34 @@ __device__ __forceinline__ void bc_st(double *p, double v) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// sum over the 64 lanes, the same value in every lane: DPP prefix steps (row_shr 1, 2, 4, 8, row_bcast 15, row_bcast 31: the
+// total arrives in lane 63) and one v_readlane -- ~20 instructions on the chain instead of six ds_bpermute round trips.
+// Both chase kernels use it, so they add in the same order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double bc_dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(phi, plo);
+}
+__device__ __forceinline__ double bc_bcast_lane(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+__device__ __forceinline__ double bc_wave_sum(double v) {
+    v = bc_dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = bc_dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = bc_dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = bc_dpp_add<0x118, 0xf>(v);      // row_shr:8
+    v = bc_dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1, 3
+    v = bc_dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3
+    return bc_bcast_lane(v, 63);
+}
+
 // LAPACK dlarfg on x[0 .. len-1] held one element per lane of wave 0 (lane < len): returns v (v[0] = 1), tau, beta
 __device__ __forceinline__ void bc_house_wave(double x, int lane, int len, double &v, double &tau, double &beta) {
     double ss = (lane >= 1 && lane < len) ? x * x : 0.0;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-    const double alpha = __shfl(x, 0);
+    ss = bc_wave_sum(ss);
+    const double alpha = bc_bcast_lane(x, 0);
     if (ss == 0.0) {
         tau = 0.0;
         beta = alpha;
@@ -197,8 +219,7 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
                 const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
                 const double z = tau * ((part[4 * BC_SB + row] + part[5 * BC_SB + row]) + (part[6 * BC_SB + row] + part[7 * BC_SB + row]));
                 double vy = y * v_lane;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) vy += __shfl_xor(vy, o);
+                vy = bc_wave_sum(vy);
                 const double w_lane = tau * y - (0.5 * tau * tau * vy) * v_lane;
                 // w of this wave's columns: through a per-wave LDS copy (a wave's LDS operations complete in order)
                 double *wsh = wcopy + wave * BC_SB;
@@ -472,8 +493,7 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
         const double z = tau * ((part[4 * BC_SB + row] + part[5 * BC_SB + row]) + (part[6 * BC_SB + row] + part[7 * BC_SB + row]));
         double vy = y * v_lane;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) vy += __shfl_xor(vy, o);
+        vy = bc_wave_sum(vy);
         const double w_lane = tau * y - (0.5 * tau * tau * vy) * v_lane;
         double *wsh = wcopy + wave * BC_SB;
         wsh[lane] = w_lane;

@@ -378,14 +378,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bo_slot(double *base, int pos,
     return __builtin_amdgcn_make_buffer_rsrc(base + ((int64_t)pos * 2 + slot) * (2 * BO_MSG), 0, BO_MSG * 16, 0x00020000);
 }
 
-constexpr int BO_LDS_DOUBLES = 2 * BC_SB + 8 * BC_SB + 8 + 4 * BC_SB + 64 + 4 * 16 * BC_P + BO_MSG + BC_SB + 2;
+constexpr int BO_LDS_DOUBLES = 2 * BC_SB + BC_SB + 8 * BC_SB + 8 + 64 + 4 * 16 * BC_P + BC_SB;
 
-__global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void sb2st_owned_kernel(BoParams P) {
-    // dynamic LDS (38 KB): a static size would make the compiler assume one workgroup per CU and take 250 registers
+__global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void sb2st_owned_kernel(BoParams P) {
+    // dynamic LDS (39 KB): a static size would make the compiler assume one workgroup per CU and take 250 registers
     extern __shared__ __attribute__((aligned(16))) double bo_smem[];
-    double *vv = bo_smem, *vn = vv + BC_SB, *part = vn + BC_SB, *sc = part + 8 * BC_SB, *wcopy = sc + 8, *usum = wcopy + 4 * BC_SB,
-           *colscr = usum + 64, *inc = colscr + 4 * 16 * BC_P, *brow = inc + BO_MSG;
-    int *ish = reinterpret_cast<int *>(brow + BC_SB);
+    double *vv0 = bo_smem;                       // [2][SB] position 0: first reflector of the sweep, by sweep parity
+    double *vn = vv0 + 2 * BC_SB;                // [SB] the reflector formed in this step
+    double *part = vn + BC_SB;                   // [8][SB] partial row sums
+    double *sc = part + 8 * BC_SB;               // [8] 1: tau of vn, 2 + parity: tau of vv0
+    double *usum = sc + 8;                       // [4][16]
+    double *colscr = usum + 64;                  // [4][16][SB + 1]
+    double *brow = colscr + 4 * 16 * BC_P;       // [SB]
     double *edge = colscr;                       // [2][4][SB]: column 0 of every wave's D and B (slide; colscr is idle then)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = P.n, k = blockIdx.x;
@@ -403,18 +407,21 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             dB[c] = (col < L && r + BC_SB + row < n) ? P.ab[(int64_t)(r + col) * BC_LD + (BC_SB + row - col)] : 0.0;
         }
     }
-    double v0 = 0.0, tau0 = 0.0;                 // position 0, wave 0: the reflector of the next sweep
+    // position 0: the reflector of the next sweep is formed by wave 0 and handed to the other waves through vv0[parity]
     if (k == 0 && wave == 0) {
         const int L = min(BC_SB, n - 1);
         const double xc = (lane < L) ? P.ab[1 + lane] : 0.0;
-        double beta;
+        double v0, tau0, beta;
         bc_house_wave(xc, lane, L, v0, tau0, beta);
+        vv0[lane] = v0;
         if (lane == 0) {
+            sc[2] = tau0;
             P.d[0] = P.ab[0];
             P.e[0] = beta;
         }
     }
-    if (t < BO_MSG) inc[t] = 0.0;
+    const int c0s = __builtin_amdgcn_readfirstlane(c0);
+    __syncthreads();
 
     for (int s = 0; s < n - 2; ++s) {
         const int r = s + 1 + BC_SB * k;
@@ -422,62 +429,56 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int L = min(BC_SB, n - r);
         const int L1 = min(BC_SB, n - (r + L));
         const int rowsB = L1 > 0 ? L1 : 0;
-        const bool need_r = k > 0, need_c = s > 0 && r + BC_SB - 1 < n;
-        // ---- messages: the reflector of this step, the column that completes the slide
-        if (wave == 0) {
-            bool ok = true;
-            double ra = v0, rb = tau0, ca = 0.0, cb = 0.0;
-            if (need_r || need_c) {
-                const __amdgpu_buffer_rsrc_t rr = bo_slot(P.rmsg, k, s & 1), rc = bo_slot(P.cmsg, k, (s - 1) & 1);
-                unsigned spins = 0;
-                for (;;) {
-                    bool good = true;
-                    if (need_r) {
-                        good = bo_get(rr, lane, s + 1, ra) && good;
-                        if (lane == 0) good = bo_get(rr, BC_SB, s + 1, rb) && good;
-                    }
-                    if (need_c) {
-                        good = bo_get(rc, lane, s, ca) && good;
-                        if (lane == 0) good = bo_get(rc, BC_SB, s, cb) && good;
-                    }
-                    if (__ballot(good) == ~0ull) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    ++spins;
-                    if (spins > (BC_SPIN_LIMIT >> 2) ||
-                        ((spins & 63u) == 0 && __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        ok = false;
-                        break;
-                    }
+        const bool need_r = k > 0, need_c = s > 0 && r + BC_SB - 1 < n && wave == 3;
+        // ---- messages, polled by every wave for itself (no LDS hop, no barrier): the reflector of this step (lane = entry);
+        // wave 3 also takes the column that completes the slide (lane l: cell 1 + l = its row of B's entering column, lane 63
+        // also cell 0 = the new diagonal entry)
+        double v_lane, tau, ca = 0.0, cb = 0.0;
+        if (need_r || need_c) {
+            const __amdgpu_buffer_rsrc_t rr = bo_slot(P.rmsg, k, s & 1), rc = bo_slot(P.cmsg, k, (s - 1) & 1);
+            double ra = 0.0, rb = 0.0;
+            unsigned spins = 0;
+            for (;;) {
+                bool good = true;
+                if (need_r) {
+                    good = bo_get(rr, lane, s + 1, ra) && good;
+                    if (lane == 0) good = bo_get(rr, BC_SB, s + 1, rb) && good;
+                }
+                if (need_c) {
+                    good = bo_get(rc, 1 + lane, s, ca) && good;
+                    if (lane == 63) good = bo_get(rc, 0, s, cb) && good;
+                }
+                if (__ballot(good) == ~0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > (BC_SPIN_LIMIT >> 2) ||
+                    ((spins & 63u) == 0 && __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    // a wave that ends leaves the workgroup's barriers; the other waves meet the flag in their next poll
+                    if (lane == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
                 }
             }
-            if (ok) {
-                vv[lane] = ra;
-                inc[lane] = need_c ? ca : 0.0;
-                if (lane == 0) {
-                    sc[0] = rb;
-                    inc[BC_SB] = need_c ? cb : 0.0;
-                }
-            }
-            if (lane == 0) ish[0] = ok ? 1 : 0;
+            v_lane = ra;
+            tau = bc_bcast_lane(rb, 0);
         }
-        __syncthreads();
-        if (!ish[0]) {
-            if (t == 0) __hip_atomic_store(P.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+        if (!need_r) {
+            v_lane = vv0[(s & 1) * BC_SB + lane];
+            tau = sc[2 + (s & 1)];
         }
+        v_lane = (lane < L) ? v_lane : 0.0;
         // ---- the slide's last piece: the entering column (logical column 63 = wave 3, register 15)
         if (s > 0 && wave == 3) {
-            if (lane == 63) dD[15] = inc[0];
-            dB[15] = inc[1 + lane];
+            if (lane == 63) dD[15] = cb;
+            dB[15] = ca;
         }
-        const double tau = sc[0];
         double taun = 0.0;
-        if (t < L) P.v2[(int64_t)s * n + r + t] = vv[t];
-        if (t == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
-        const double v_lane = (lane < L) ? vv[lane] : 0.0;
-        double vq[16];
+        if (wave == 0) {
+            if (lane < L) P.v2[(int64_t)s * n + r + lane] = v_lane;
+            if (lane == 0) P.tau2[(int64_t)s * P.ks + k] = tau;
+        }
+        double vq[16];                                   // v of this wave's columns: wave-uniform (scalar registers)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) vq[c] = (c0 + c < L) ? vv[c0 + c] : 0.0;
+        for (int c = 0; c < 16; ++c) vq[c] = bc_bcast_lane(v_lane, c0s + c);
         // ---- y = D v, z = B v
         {
             double py = 0.0, pz = 0.0;
@@ -490,50 +491,50 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             part[(4 + quarter) * BC_SB + row] = pz;
         }
         __syncthreads();
-        const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
         const double z = tau * ((part[4 * BC_SB + row] + part[5 * BC_SB + row]) + (part[6 * BC_SB + row] + part[7 * BC_SB + row]));
+        // ---- wave 0: the new reflector needs only column 0 of B H; it leaves before anything else is updated
+        double vnl = 0.0, beta_n = 0.0;
+        if (wave == 0 && rowsB > 0) {
+            double tn;
+            bc_house_wave(dB[0] - z * vq[0], lane, rowsB, vnl, tn, beta_n);
+            vnl = (lane < rowsB) ? vnl : 0.0;
+            const __amdgpu_buffer_rsrc_t rs = bo_slot(P.rmsg, k + 1, s & 1);
+            bo_put(rs, lane, vnl, s + 1);
+            if (lane == 0) bo_put(rs, BC_SB, tn, s + 1);
+            vn[lane] = vnl;
+            if (lane == 0) sc[1] = tn;
+        }
+        const double y = (part[row] + part[BC_SB + row]) + (part[2 * BC_SB + row] + part[3 * BC_SB + row]);
         double vy = y * v_lane;
         vy = bc_wave_sum(vy);
         const double w_lane = tau * y - (0.5 * tau * tau * vy) * v_lane;
-        double *wsh = wcopy + wave * BC_SB;
-        wsh[lane] = w_lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- D <- H D H = D - v w' - w v';  B <- B H = B - (tau B v) v'
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const double wc = wsh[c0 + c];
+            const double wc = bc_bcast_lane(w_lane, c0s + c);
             dD[c] -= __dadd_rn(__dmul_rn(v_lane, wc), __dmul_rn(w_lane, vq[c]));
             dB[c] -= z * vq[c];
         }
-        // ---- new reflector from the first column of B; the two messages leave at once
         if (wave == 0) {
-            double vnl = 0.0, tn = 0.0;
-            if (rowsB > 0) {
-                double beta;
-                bc_house_wave(dB[0], lane, rowsB, vnl, tn, beta);
-                dB[0] = (lane == 0) ? beta : 0.0;
-                vnl = (lane < rowsB) ? vnl : 0.0;
-                vn[lane] = vnl;
-                if (lane == 0) sc[1] = tn;
-                const __amdgpu_buffer_rsrc_t rs = bo_slot(P.rmsg, k + 1, s & 1);
-                bo_put(rs, lane, vnl, s + 1);
-                if (lane == 0) bo_put(rs, BC_SB, tn, s + 1);
-            }
+            if (rowsB > 0) dB[0] = (lane == 0) ? beta_n : 0.0;
             if (k > 0) {
                 const __amdgpu_buffer_rsrc_t rs = bo_slot(P.cmsg, k - 1, s & 1);
                 bo_put(rs, lane, dD[0], s + 1);
                 if (lane == 0) bo_put(rs, BC_SB, dB[0], s + 1);
             } else {
                 // position 0: column s + 1 is final: d[s + 1], and either the next sweep's reflector or the last entries
-                const double below = __shfl(dD[0], (lane + 1) & 63), b00 = __shfl(dB[0], 0);
+                const double below = __shfl(dD[0], (lane + 1) & 63), b00 = bc_bcast_lane(dB[0], 0);
                 const double xc = (lane < 63) ? below : b00;          // A(s + 2 + lane, s + 1)
                 if (lane == 0) P.d[s + 1] = dD[0];
                 if (s + 1 < n - 2) {
                     const int Ln = min(BC_SB, n - (s + 2));
-                    double beta;
+                    double v0, tau0, beta;
                     bc_house_wave((lane < Ln) ? xc : 0.0, lane, Ln, v0, tau0, beta);
-                    if (lane == 0) P.e[s + 1] = beta;
+                    vv0[((s + 1) & 1) * BC_SB + lane] = v0;
+                    if (lane == 0) {
+                        sc[2 + ((s + 1) & 1)] = tau0;
+                        P.e[s + 1] = beta;
+                    }
                 } else {
                     if (lane == 0) P.e[s + 1] = xc;
                     if (lane == 1) {

@@ -349,6 +349,7 @@ struct BoParams {
     double *rmsg;      // [positions][2 slots][BO_MSG] cells of 16 bytes: v[0..63], tau
     double *cmsg;      // [positions][2 slots][BO_MSG] cells: D[0..63][0], B[0][0]
     int *abort_flag;
+    int poll_sleep;    // diagnostic (JXGPU_BO_SLEEP): s_sleep units between two polls
 };
 constexpr int BO_MSG = 72;
 // A message has no flag: every value travels in a 16-byte cell {value, value bits ^ pattern(sequence number)} written by ONE
@@ -367,8 +368,7 @@ __device__ __forceinline__ void bo_put(__amdgpu_buffer_rsrc_t rs, int cell, doub
     o[3] = (int)(unsigned)(tag >> 32);
     __builtin_amdgcn_raw_buffer_store_b128(o, rs, cell * 16, 0, BC_AUX_SC1);
 }
-__device__ __forceinline__ bool bo_get(__amdgpu_buffer_rsrc_t rs, int cell, int seq, double &v) {
-    const bc_v4i x = __builtin_amdgcn_raw_buffer_load_b128(rs, cell * 16, 0, BC_AUX_SC1);
+__device__ __forceinline__ bool bo_check(const bc_v4i &x, int seq, double &v) {
     const unsigned long long bits = ((unsigned long long)(unsigned)x[1] << 32) | (unsigned)x[0];
     const unsigned long long tag = ((unsigned long long)(unsigned)x[3] << 32) | (unsigned)x[2];
     v = __longlong_as_double((long long)bits);
@@ -380,7 +380,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bo_slot(double *base, int pos,
 
 constexpr int BO_LDS_DOUBLES = 2 * BC_SB + BC_SB + 8 * BC_SB + 8 + 64 + 4 * 16 * BC_P + BC_SB;
 
-__global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void sb2st_owned_kernel(BoParams P) {
+// DEPTH = polls in flight per wave (1: measured best), WPE = waves per SIMD the register budget is cut for (WPE workgroups per CU)
+template <int DEPTH, int WPE>
+__global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void sb2st_owned_kernel(BoParams P) {
     // dynamic LDS (39 KB): a static size would make the compiler assume one workgroup per CU and take 250 registers
     extern __shared__ __attribute__((aligned(16))) double bo_smem[];
     double *vv0 = bo_smem;                       // [2][SB] position 0: first reflector of the sweep, by sweep parity
@@ -436,20 +438,47 @@ __global__ __launch_bounds__(BC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         double v_lane, tau, ca = 0.0, cb = 0.0;
         if (need_r || need_c) {
             const __amdgpu_buffer_rsrc_t rr = bo_slot(P.rmsg, k, s & 1), rc = bo_slot(P.cmsg, k, (s - 1) & 1);
-            double ra = 0.0, rb = 0.0;
-            unsigned spins = 0;
-            for (;;) {
-                bool good = true;
+            // DEPTH polls in flight: memory is sampled every 1 / DEPTH of a round trip
+            struct Raw {
+                bc_v4i a, b, c, d;
+            };
+            auto issue = [&](Raw &x) {
                 if (need_r) {
-                    good = bo_get(rr, lane, s + 1, ra) && good;
-                    if (lane == 0) good = bo_get(rr, BC_SB, s + 1, rb) && good;
+                    x.a = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, BC_AUX_SC1);
+                    if (lane == 0) x.b = __builtin_amdgcn_raw_buffer_load_b128(rr, BC_SB * 16, 0, BC_AUX_SC1);
                 }
                 if (need_c) {
-                    good = bo_get(rc, 1 + lane, s, ca) && good;
-                    if (lane == 63) good = bo_get(rc, 0, s, cb) && good;
+                    x.c = __builtin_amdgcn_raw_buffer_load_b128(rc, (1 + lane) * 16, 0, BC_AUX_SC1);
+                    if (lane == 63) x.d = __builtin_amdgcn_raw_buffer_load_b128(rc, 0, 0, BC_AUX_SC1);
                 }
-                if (__ballot(good) == ~0ull) break;
-                __builtin_amdgcn_s_sleep(1);
+            };
+            double ra = 0.0, rb = 0.0;
+            auto take = [&](const Raw &x) {
+                bool good = true;
+                if (need_r) {
+                    good = bo_check(x.a, s + 1, ra) && good;
+                    if (lane == 0) good = bo_check(x.b, s + 1, rb) && good;
+                }
+                if (need_c) {
+                    good = bo_check(x.c, s, ca) && good;
+                    if (lane == 63) good = bo_check(x.d, s, cb) && good;
+                }
+                return __ballot(good) == ~0ull;
+            };
+            Raw x[DEPTH];
+            unsigned spins = 0;
+#pragma unroll
+            for (int d = 0; d + 1 < DEPTH; ++d) issue(x[d]);
+            for (bool got = false; !got;) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    if (!got) {
+                        issue(x[(d + DEPTH - 1) % DEPTH]);
+                        got = take(x[d]);
+                    }
+                }
+                if (got) break;
+                for (int q = 0; q < P.poll_sleep; ++q) __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if (spins > (BC_SPIN_LIMIT >> 2) ||
                     ((spins & 63u) == 0 && __hip_atomic_load(P.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -626,24 +655,36 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
     const int ks = sb2st_steps(n);
     JX_HIP(hipMemsetAsync(d_ctrl, 0, sizeof(int) * ((size_t)n + 4), st));
     JX_HIP(hipMemsetAsync(d_tau2, 0, sizeof(double) * (size_t)n * ks, st));
-    static int cus = 0, owned_occ = 0;
+    static int cus = 0, occ_fast = 0, occ_wide = 0;
+    const size_t owned_lds = sizeof(double) * BO_LDS_DOUBLES;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
         JX_HIP(hipGetDevice(&dev));
         JX_HIP(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&owned_occ, (const void *)sb2st_owned_kernel, BC_THREADS, sizeof(double) * BO_LDS_DOUBLES) != hipSuccess)
-            owned_occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_fast, (const void *)sb2st_owned_kernel<1, 2>, BC_THREADS, owned_lds) != hipSuccess)
+            occ_fast = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_wide, (const void *)sb2st_owned_kernel<1, 4>, BC_THREADS, owned_lds) != hipSuccess)
+            occ_wide = 0;
     }
     const int np = sb2st_positions(n);
     const char *om = getenv("JXGPU_BC_OWNED");
-    const bool owned = n > 2 * BC_SB + 2 && !(om && atoi(om) == 0) && np <= cus * owned_occ && 2 * np <= n;
+    // every position must be resident at once: the spill-free form where two workgroups per CU hold them all (n <= 32 768),
+    // else the 128-register form at four workgroups per CU (n <= 65 536); beyond that the sweep-owned kernel.
+    // (More than one poll in flight per wave is slower -- 88.8 / 94.1 / 106.3 / 116.8 ms at n = 20 000 for 1 / 2 / 3 / 4 --
+    // and so is pausing between polls: 91.8 / 93.6 / 98.6 / 105.6 ms for 0 / 2 / 6 / 16 s_sleep units.)
+    const bool fast = np <= cus * occ_fast, wide = np <= cus * occ_wide;
+    const bool owned = n > 2 * BC_SB + 2 && !(om && atoi(om) == 0) && (fast || wide) && 2 * np <= n;
     if (owned) {
         double *msg = reinterpret_cast<double *>(d_ctrl + sb2st_ctrl_ints(n));
-        BoParams P{d_ab, n, d_v2, d_tau2, ks, d_d, d_e, msg, msg + (size_t)np * 2 * (2 * BO_MSG), d_ctrl + n};
+        BoParams P{d_ab, n, d_v2, d_tau2, ks, d_d, d_e, msg, msg + (size_t)np * 2 * (2 * BO_MSG), d_ctrl + n,
+                   getenv("JXGPU_BO_SLEEP") ? atoi(getenv("JXGPU_BO_SLEEP")) : 0};
         JX_HIP(hipMemsetAsync(msg, 0, sizeof(double) * (size_t)np * 4 * (2 * BO_MSG), st));   // tags of an earlier chase
-        hipLaunchKernelGGL(sb2st_owned_kernel, dim3(np), dim3(BC_THREADS), sizeof(double) * BO_LDS_DOUBLES, st, P);
+        if (fast && !(om && atoi(om) == 2))
+            hipLaunchKernelGGL((sb2st_owned_kernel<1, 2>), dim3(np), dim3(BC_THREADS), owned_lds, st, P);
+        else
+            hipLaunchKernelGGL((sb2st_owned_kernel<1, 4>), dim3(np), dim3(BC_THREADS), owned_lds, st, P);
         JX_LAUNCH_CHECK();
         return 0;
     }

@@ -24,7 +24,7 @@ def make(n, seed):
 
 
 def run(a, owned):
-    os.environ["JXGPU_BC_OWNED"] = "1" if owned else "0"
+    os.environ["JXGPU_BC_OWNED"] = os.environ.get("OWNED_MODE", "1") if owned else "0"
     n = a.shape[0]
     w = a.clone()
     d = torch.zeros(n, device=dev, dtype=torch.float64)

@@ -674,7 +674,9 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
     // else the 128-register form at four workgroups per CU (n <= 65 536); beyond that the sweep-owned kernel.
     // (More than one poll in flight per wave is slower -- 88.8 / 94.1 / 106.3 / 116.8 ms at n = 20 000 for 1 / 2 / 3 / 4 --
     // and so is pausing between polls: 91.8 / 93.6 / 98.6 / 105.6 ms for 0 / 2 / 6 / 16 s_sleep units.)
-    const bool fast = np <= cus * occ_fast, wide = np <= cus * occ_wide;
+    // (the occupancy query does not know the waves-per-SIMD cap of the register budget: <1, 2> is held to two workgroups
+    // per CU by its attribute, <1, 4> to four)
+    const bool fast = np <= cus * (occ_fast < 2 ? occ_fast : 2), wide = np <= cus * (occ_wide < 4 ? occ_wide : 4);
     const bool owned = n > 2 * BC_SB + 2 && !(om && atoi(om) == 0) && (fast || wide) && 2 * np <= n;
     if (owned) {
         double *msg = reinterpret_cast<double *>(d_ctrl + sb2st_ctrl_ints(n));

@@ -53,6 +53,15 @@ constexpr int QR_BLK = QB_WIN * QB_G;      // doubles of one V (or U) image: [q]
 __host__ __device__ __forceinline__ int qr_v_at(int q, int m) { return q * QB_G + (m ^ (2 * (q & 15))); }
 __host__ __device__ __forceinline__ int qr_u_at(int q, int m) { return q * QB_G + (m ^ (16 * ((q >> 1) & 1))); }
 
+// Zero tiles of the images (a reflector of sweep s0 + i covers the window rows i + 1 .. i + 64; column j of U = V T' starts at
+// row j + 1 because T is upper triangular): 12 of the 96 MFMA operand tiles of a block are zero and their instructions are
+// skipped -- V: rows 0 .. 15 x columns >= 16 and rows 80 .. 95 x columns < 16; U: rows 0 .. 15 x columns >= 16.
+// w = 32-row chunk of the window, h = 16-row half of the chunk, ks = MFMA step (V: columns 4 ks .., U: rows 8 (ks >> 1) ..)
+__device__ __forceinline__ constexpr bool qr_v_tile_zero(int w, int h, int ks) {
+    return (w == 0 && h == 0 && ks >= 4) || (w == 2 && h == 1 && ks < 4);
+}
+__device__ __forceinline__ constexpr bool qr_u_tile_zero(int w, int ks) { return w == 0 && ks < 4; }   // the column half 16 .. 31
+
 struct QrParams {
     const double *v2;       // (n, n): column s = reflectors of sweep s by matrix row
     const double *tau2;     // (n, ks)
@@ -308,17 +317,26 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
                 stored8 = wb - QB_WIN + 32 * w + 32 <= n;
             }
             d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+            const int wu = __builtin_amdgcn_readfirstlane(w);          // scalar: the zero-tile branches below are s_cbranch
             if (!(P.skip & 1)) {
                 // U(q, 16 mb + lx), q = 32 w + 8 (ks >> 1) + 2 lk + (ks & 1): the swizzle bit of the row is lk & 1
                 const double *up = ul + (k & 1) * QR_BLK + (32 * w + 2 * lk) * QB_G + lx;
                 const int o0 = 16 * (lk & 1), o1 = 16 - o0;
+                // one straight-line instance per chunk position (branches around single MFMAs cost more than the skipped ones)
+                auto ypart = [&](auto wc) {
+                    constexpr int WC = decltype(wc)::value;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int q = 8 * (ks >> 1) + (ks & 1);
-                    const double b = cw[ks >> 2][ks & 3];
-                    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
-                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
-                }
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int q = 8 * (ks >> 1) + (ks & 1);
+                        const double b = cw[ks >> 2][ks & 3];
+                        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
+                        if (!qr_u_tile_zero(WC, ks)) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+                    }
+                };
+                if (wu == 0)
+                    ypart(std::integral_constant<int, 0>{});
+                else
+                    ypart(std::integral_constant<int, 1>{});
             }
             {
                 double *pp = part + (wave * 8) * 64 + lane;
@@ -338,12 +356,22 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
             if (!(P.skip & 1)) {
                 // V(32 w + 16 h + rm_a, 4 ks + lk): the swizzle of the row is 2 rm_a
                 const double *vp = vl + (k & 1) * QR_BLK + (32 * w + rm_a) * QB_G;
+                auto upd = [&](auto wc) {
+                    constexpr int WC = decltype(wc)::value;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const int m = (4 * ks + lk) ^ (2 * rm_a);
-                    cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
-                    cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
-                }
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int m = (4 * ks + lk) ^ (2 * rm_a);
+                        if (!qr_v_tile_zero(WC, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                        if (!qr_v_tile_zero(WC, 1, ks))
+                            cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+                    }
+                };
+                if (wu == 0)
+                    upd(std::integral_constant<int, 0>{});
+                else if (wu == 1)
+                    upd(std::integral_constant<int, 1>{});
+                else
+                    upd(std::integral_constant<int, 2>{});
             }
             qr_lds_barrier();                                  // B3: the partial sums have been read, the images of block k + 1 are in place
             if (!has_next && !(P.skip & 2)) chunk_store(wb + 32 * w, cw);
@@ -501,7 +529,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_solo_kernel(QrPara
                     const int q = 8 * (ks >> 1) + (ks & 1);
                     const double b = cw[ks >> 2][ks & 3];
                     y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
-                    y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+                    if (!qr_u_tile_zero(w, ks)) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
                 }
             };
             ypart(0, a0);
@@ -518,8 +546,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_solo_kernel(QrPara
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const int m = (4 * ks + lk) ^ (2 * rm_a);
-                    cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
-                    cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+                    if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                    if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
                 }
             };
             upd(0, a0);
@@ -706,7 +734,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrPara
                 const int q = 8 * (ks >> 1) + (ks & 1);
                 const double b = cw[ks >> 2][ks & 3];
                 y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
-                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+                if (!qr_u_tile_zero(w, ks)) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
             }
         };
         ypart(0, c0);
@@ -723,8 +751,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrPara
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int m = (4 * ks + lk) ^ (2 * rm_a);
-                cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
-                cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+                if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
             }
         };
         upd(0, c0);

@@ -2513,6 +2513,43 @@ def test_eigh_two_stage_path_and_its_fallback(case, monkeypatch):
     assert float((s - ref).abs().max()) < 1e-11 * smax
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [131, 193, 194, 258, 700, 2049])
+def test_bulge_chasing_position_owned_equals_sweep_owned(n, monkeypatch):
+    """Band -> tridiagonal (csrc/k_sb2st.hip, behind src/math/eigh.rs:1422-1528): the position-owned kernel (workgroup k keeps
+    the window of step k in registers, reflectors and one column travel as tagged 16-byte cells) must give d and e
+    BIT-identical to the sweep-owned kernel in both of its instantiations (two / four workgroups per CU), without the abort
+    flag, at sizes around the 64-column window edges (a last window of 1, 2, 64 and 65 columns); the tridiagonal matrix
+    carries the spectrum of the input."""
+    import ctypes
+    import torch
+    from scipy.linalg import eigvalsh_tridiagonal
+    from janusx_amd._lib import check, lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(n)
+    z = torch.randn((n, 2 * n), generator=g, device=dev, dtype=torch.float64)
+    a = z @ z.T / (2 * n)
+    a = 0.5 * (a + a.T)
+    a.diagonal().add_(1e-6)
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("JXGPU_BC_OWNED", mode)
+        w = a.clone()
+        d = torch.zeros(n, device=dev, dtype=torch.float64)
+        e = torch.zeros(n, device=dev, dtype=torch.float64)
+        hf = (ctypes.c_int * 4)()
+        check(lib().jxg_sy2st_f64(w.data_ptr(), n, d.data_ptr(), e.data_ptr(), None, hf, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert list(hf)[:2] == [0, 0]
+        out[mode] = (d.cpu().numpy(), e.cpu().numpy())
+    for mode in ("1", "2"):
+        assert np.array_equal(out[mode][0], out["0"][0]) and np.array_equal(out[mode][1], out["0"][1]), mode
+    ev = torch.linalg.eigvalsh(a).cpu().numpy()
+    evt = eigvalsh_tridiagonal(out["1"][0], out["1"][1][: n - 1])
+    assert np.abs(evt - ev).max() < 1e-12 * np.abs(ev).max()
+
+
 def test_lm_block_assoc_packed(oracle):
     """Plain LM scan (src/stats/glm.rs:3550-3860) through the C ABI against the restatement: one to seven design columns
     (more than one column pass), flipped rows, missing calls, a ragged last sample tile, a sample subset, a monomorphic

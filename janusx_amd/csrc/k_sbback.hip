@@ -164,13 +164,19 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
     double *part = ul + 2 * QR_BLK;                            // [3 NU][8][64]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = P.n;
+    // Staggered units: the units >= QR_EARLY run one barrier interval behind the others, so in every interval one set of waves
+    // is in its first product (then writes its partial sums) while the other reads partial sums (then runs its update): the LDS
+    // exchange of one set overlaps the MFMAs of the other.  U(k) is then live for the intervals 2k, 2k + 1 and V(k) for 2k + 1,
+    // 2k + 2 (2 nk + 1 intervals per group); the loader copies U(k + 1) in interval 2k and V(k + 1) in interval 2k + 1.
+    const bool stag = (P.skip & 64) == 0;                      // JXGPU_QB_SKIP=64: lockstep units (547 vs 513 ms at n = 20 000)
 
     if (wave == 3 * NU) {
         // ------------------------------------------------------------------------------------------------ loader wave
         // images of block (grp, k) -> buffer `buf`: 2 x 24 wave instructions of 1 KB
-        auto img_copy = [&](int grp, int k, int buf) {
+        auto img_copy = [&](int grp, int k, int buf, int which) {          // which: 1 = V image, 2 = U image, 3 = both
             const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
             const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
+            if (which & 1)
 #pragma unroll
             for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
                 unsigned keep;
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
                              : "v"(src + i * 1024), "s"(__builtin_amdgcn_readfirstlane(v_dst + i * 1024))
                              : "memory");
             }
+            if (which & 2)
 #pragma unroll
             for (int i = 0; i < QR_BLK * 8 / 1024; ++i) {
                 unsigned keep;
@@ -193,15 +200,18 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
             if (s0 + 1 >= n) continue;
             const int nk = (n - s0 - 1 + QB_SB - 1) / QB_SB;
             __syncthreads();                                   // G0
-            img_copy(grp, 0, 0);
+            img_copy(grp, 0, 0, 3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             qr_lds_barrier();                                  // G1
             for (int k = 0; k < nk; ++k) {
-                if (k + 1 < nk && !(P.skip & 4)) img_copy(grp, k + 1, (k + 1) & 1);
+                // staggered: the late units still read V(k - 1) in the first interval of block k, so only U(k + 1) may go now
+                if (k + 1 < nk && !(P.skip & 4)) img_copy(grp, k + 1, (k + 1) & 1, stag ? 2 : 3);
                 qr_lds_barrier();                              // B2
+                if (stag && k + 1 < nk && !(P.skip & 4)) img_copy(grp, k + 1, (k + 1) & 1, 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 qr_lds_barrier();                              // B3
             }
+            if (stag) qr_lds_barrier();                        // the late units' last interval
         }
         return;
     }
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
                     qr_lds_barrier();                          // B2
                     qr_lds_barrier();                          // B3
                 }
+                if (stag) qr_lds_barrier();
             }
             return;
         }
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
 
     d4 cw[2];
     d2 pf[4];
+    const bool late = stag && unit >= (NU + 1) / 2;
     for (int grp = P.g_hi - 1; grp >= P.g_lo; --grp) {
         const int s0 = grp * QB_G;
         if (s0 + 1 >= n) continue;
@@ -296,6 +308,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
         chunk_unpack(s0 + 32 * j, pf, cw);
         bool stored8 = false;                                  // exactly four stores were issued behind the last prefetch
         qr_lds_barrier();                                      // G1: the images of block 0 are in place
+        if (late) qr_lds_barrier();                            // staggered: the late units start one interval behind
         int w = j;                                             // position of this wave's chunk in the window: (j + k) mod 3
         for (int k = 0; k < nk; ++k) {
             const int wb = s0 + k * QB_SB;
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
             if (!has_next && !(P.skip & 2)) chunk_store(wb + 32 * w, cw);
             w = (w == 2) ? 0 : w + 1;
         }
+        if (stag && !late) qr_lds_barrier();                   // the late units' last interval
     }
 }
 

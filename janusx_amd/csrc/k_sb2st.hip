@@ -8,7 +8,11 @@
 // Only the first column of every bulge is annihilated (Haidar, Ltaief, Dongarra 2011), so a window is 2 SB x SB
 // doubles = one contiguous 64 KB run of the compact band storage ab[d + j ldab] = A[j+d, j], ldab = 2 SB.
 // Step (s, k) overlaps the windows of (s-1, k) and (s-1, k+1) only: sweep s may run step k once sweep s-1 has finished
-// step k+1.  Workgroup g owns the sweeps g, g+G, g+2G, ...; progress[s] counts finished steps.  Windows are exchanged
+// step k+1.
+// Two kernels: the POSITION-owned one below (sb2st_owned_kernel, the default: workgroup k keeps the window of step k in
+// registers for the whole chase, 4.4 us per sweep) and the SWEEP-owned one (sb2st_chase_kernel, 18 us per sweep; the fallback
+// when the positions do not all fit the device at once, and the reference the other is bit-identical to):
+// workgroup g owns the sweeps g, g+G, g+2G, ...; progress[s] counts finished steps.  Windows are exchanged
 // through memory with write-through (sc1) stores and L1-bypassing (sc1) loads, every storing wave drains its stores
 // before the workgroup's barrier and ONE lane then publishes the counter (cdna_hip_programming.md guideline 16, form R1
 // with sc1 loads on the consumer side); every spin is bounded and raises an abort flag the other workgroups honour.
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(BC_THREADS) void sb2st_chase_kernel(BcParams P) {
 // B, which is off the chain).  Position 0 keeps its column: it is the source of the next sweep's first reflector and of
 // d[s + 1], e[s + 1].  The arithmetic of a step is the statement sequence of sb2st_chase_kernel on the same values (the
 // symmetric update is written so that D stays exactly symmetric in both), so d, e, v2 and tau2 are bit-identical to it.
-// Every workgroup must be resident (the host checks the occupancy and falls back to the sweep-owned kernel).
+// Every workgroup must be resident (the host checks the occupancy and falls back to the sweep-owned kernel); every poll is
+// bounded and raises the abort flag (the driver then reduces the matrix in one stage, as for the sweep-owned kernel).
 struct BoParams {
     const double *ab;
     int n;

@@ -14,7 +14,8 @@ def main():
     # kernel stats
     cand = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if cand:
-        rows = list(csv.DictReader(open(cand[0])))
+        cand.sort(key=os.path.getmtime)                    # gpurun merges into gpurun_out: older collections stay beside the new one
+        rows = list(csv.DictReader(open(cand[-1])))
         out = os.path.join(root, f"{tag}_bench_{label}_lmm_kernel_stats.csv")
         with open(out, "w") as fh:
             fh.write(f'"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 '

@@ -2550,6 +2550,34 @@ def test_bulge_chasing_position_owned_equals_sweep_owned(n, monkeypatch):
     assert np.abs(evt - ev).max() < 1e-12 * np.abs(ev).max()
 
 
+@pytest.mark.gpu
+def test_q2_staggered_units_equal_lockstep(monkeypatch):
+    """Back-transformation of the bulge chasing (csrc/k_sbback.hip, behind src/math/eigh.rs:1422-1528): the staggered form (the
+    late units of a workgroup run one barrier interval behind; the loader copies U(k+1) and V(k+1) in separate intervals) does
+    the same operations in the same order per unit as the lockstep form (`JXGPU_QB_SKIP=64`), so the eigenvectors must be
+    BIT-identical -- a race on an image buffer or on the partial sums would show here -- and the zero-tile skipping must not
+    change what the invariants see."""
+    import torch
+    from janusx_amd import pipeline
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n = 10240
+    z = torch.randn((n, n + 64), generator=g, device=dev, dtype=torch.float32)
+    k = (z @ z.T / (n + 64)).to(torch.float64)
+    k = 0.5 * (k + k.T)
+    del z
+    s1, u1 = pipeline.eigh_from_grm(k, 1e-6)
+    monkeypatch.setenv("JXGPU_QB_SKIP", "64")
+    s2, u2 = pipeline.eigh_from_grm(k, 1e-6)
+    assert torch.equal(s1, s2) and torch.equal(u1, u2)
+    kk = k.clone()
+    kk.diagonal().add_(1e-6)
+    smax = float(s1.abs().max())
+    assert float((u1 @ kk - s1[:, None] * u1).abs().max()) < 1e-11 * smax
+    assert float((u1 @ u1.T - torch.eye(n, device=dev, dtype=torch.float64)).abs().max()) < 1e-11
+
+
 def test_lm_block_assoc_packed(oracle):
     """Plain LM scan (src/stats/glm.rs:3550-3860) through the C ABI against the restatement: one to seven design columns
     (more than one column pass), flipped rows, missing calls, a ragged last sample tile, a sample subset, a monomorphic

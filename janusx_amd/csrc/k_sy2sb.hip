@@ -67,11 +67,12 @@ __device__ __forceinline__ int tiny_chol_upper(Tiny &m, TinyVec *vec) {
 #pragma unroll 1
     for (int j = 0; j < SB; ++j) {
         const int ja = j >> 4, jr = j & 15, p = j & 1;
-        if (ti == jr) {
+        if (ti == jr) {                          // only block ja is read: publish that one (the switch keeps the register indices static)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
+                if (a == ja)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = m.v[a][b];      // rows jr + 16 a; row j is block ja
+                    for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = m.v[a][b];  // rows jr + 16 a; row j is block ja
         }
         __syncthreads();
         const double *rowj = vec[p][ja];
@@ -112,9 +113,10 @@ __device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)
         const int cb = c >> 4, cr = c & 15, p = c & 1;
         if (tk == cr) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+                if (b == cb)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) vec[p][b][ti + 16 * a] = x.v[a][b];      // columns cr + 16 b; column c is block cb
+                    for (int a = 0; a < 4; ++a) vec[p][b][ti + 16 * a] = x.v[a][b];  // columns cr + 16 b; column c is block cb
         }
         __syncthreads();
         const double *colc = vec[p][cb];
@@ -145,14 +147,16 @@ __device__ __forceinline__ void tiny_lu_modified(Tiny &w, TinyVec *vec, TinyVec 
         if (ti == jr) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
+                if (a == ja)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = w.v[a][b];       // row j = block ja
+                    for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = w.v[a][b];   // row j = block ja
         }
         if (tk == jr) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+                if (b == ja)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) vec2[p][b][ti + 16 * a] = w.v[a][b];      // column j = block ja
+                    for (int a = 0; a < 4; ++a) vec2[p][b][ti + 16 * a] = w.v[a][b];  // column j = block ja
         }
         __syncthreads();
         const double *rowj = vec[p][ja], *colj = vec2[p][ja];

@@ -61,39 +61,44 @@ typedef double TinyVec[4][SB];      // [16-block][position]
 
 // G (symmetric, full, identity-padded) -> R upper triangular (G = R'R), strict lower part zero.  Returns 0 when a pivot
 // is not positive and finite (the factor is then meaningless; the caller raises the failure flag).
+// The step loops are split by the 16-block of the pivot (compile time) x its position in the block (run time): the blocks above /
+// left of the pivot's are finished, so a step of block ja touches only the (4 - ja)^2 register blocks a, b >= ja, the row /
+// column comparisons survive only in the blocks a == ja or b == ja, and the pivot owners publish m.v[ja][..] directly.  Same
+// operations on the same values as the plain 64-step form (the skipped ones were predicated off or subtracted exact zeros).
 __device__ __forceinline__ int tiny_chol_upper(Tiny &m, TinyVec *vec) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
     int ok = 1;
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja) {
 #pragma unroll 1
-    for (int j = 0; j < SB; ++j) {
-        const int ja = j >> 4, jr = j & 15, p = j & 1;
-        if (ti == jr) {                          // only block ja is read: publish that one (the switch keeps the register indices static)
+        for (int jr = 0; jr < 16; ++jr) {
+            const int j = 16 * ja + jr, p = j & 1;
+            if (ti == jr) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                if (a == ja)
+                for (int b = 0; b < 4; ++b) vec[p][ja][tk + 16 * b] = m.v[ja][b];    // row j = row jr of block ja
+            }
+            __syncthreads();
+            const double *rowj = vec[p][ja];
+            double d = rowj[j];
+            if (!(d > 0.0) || !(d < 1e300)) {
+                ok = 0;
+                d = 1.0;
+            }
+            const double ri = 1.0 / sqrt(d);
+            double rk[4], rr[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = m.v[a][b];  // rows jr + 16 a; row j is block ja
-        }
-        __syncthreads();
-        const double *rowj = vec[p][ja];
-        double d = rowj[j];
-        if (!(d > 0.0) || !(d < 1e300)) {
-            ok = 0;
-            d = 1.0;
-        }
-        const double ri = 1.0 / sqrt(d);
-        double rk[4], rr[4];
+            for (int b = ja; b < 4; ++b) rk[b] = rowj[tk + 16 * b] * ri;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rk[b] = rowj[tk + 16 * b] * ri;
+            for (int a = ja; a < 4; ++a) rr[a] = rowj[ti + 16 * a] * ri;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) rr[a] = rowj[ti + 16 * a] * ri;
+            for (int a = ja; a < 4; ++a) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ti + 16 * a, k = tk + 16 * b;
-                if (i > j && k > j) m.v[a][b] -= rr[a] * rk[b];
-                else if (i == j) m.v[a][b] = (k >= j) ? rk[b] : 0.0;
+                for (int b = ja; b < 4; ++b) {
+                    const bool i_gt = (a > ja) || ti > jr, i_eq = (a == ja) && ti == jr;
+                    const bool k_gt = (b > ja) || tk > jr, k_ge = (b > ja) || tk >= jr;
+                    if (i_gt && k_gt) m.v[a][b] -= rr[a] * rk[b];
+                    else if (i_eq) m.v[a][b] = k_ge ? rk[b] : 0.0;
+                }
             }
         }
     }
@@ -108,30 +113,30 @@ __device__ __forceinline__ int tiny_chol_upper(Tiny &m, TinyVec *vec) {
 // X <- X U^-1, U upper triangular in LDS (u[c][k], c <= k) with its diagonal stored as the reciprocal
 __device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)[SB_P], TinyVec *vec) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
 #pragma unroll 1
-    for (int c = 0; c < SB; ++c) {
-        const int cb = c >> 4, cr = c & 15, p = c & 1;
-        if (tk == cr) {
+        for (int cr = 0; cr < 16; ++cr) {
+            const int c = 16 * cb + cr, p = c & 1;
+            if (tk == cr) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b == cb)
+                for (int a = 0; a < 4; ++a) vec[p][cb][ti + 16 * a] = x.v[a][cb];    // column c = column cr of block cb
+            }
+            __syncthreads();
+            const double *colc = vec[p][cb];
+            const double rd = u[c][c];
+            double xc[4], uk[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) vec[p][b][ti + 16 * a] = x.v[a][b];  // columns cr + 16 b; column c is block cb
-        }
-        __syncthreads();
-        const double *colc = vec[p][cb];
-        const double rd = u[c][c];
-        double xc[4], uk[4];
+            for (int a = 0; a < 4; ++a) xc[a] = colc[ti + 16 * a] * rd;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xc[a] = colc[ti + 16 * a] * rd;
+            for (int b = cb; b < 4; ++b) uk[b] = ((b > cb) || tk > cr) ? u[c][tk + 16 * b] : 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > c) ? u[c][tk + 16 * b] : 0.0;
+            for (int b = cb; b < 4; ++b) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (tk + 16 * b == c) x.v[a][b] = xc[a];
-                else x.v[a][b] -= xc[a] * uk[b];
+                for (int a = 0; a < 4; ++a) {
+                    if (b == cb && tk == cr) x.v[a][b] = xc[a];
+                    else x.v[a][b] -= xc[a] * uk[b];
+                }
             }
         }
     }
@@ -141,45 +146,43 @@ __device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)
 // upper part incl. diagonal U; sgn[j] = the sign subtracted from the j-th pivot
 __device__ __forceinline__ void tiny_lu_modified(Tiny &w, TinyVec *vec, TinyVec *vec2, double *sgn) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja) {
 #pragma unroll 1
-    for (int j = 0; j < SB; ++j) {
-        const int ja = j >> 4, jr = j & 15, p = j & 1;
-        if (ti == jr) {
+        for (int jr = 0; jr < 16; ++jr) {
+            const int j = 16 * ja + jr, p = j & 1;
+            if (ti == jr) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                if (a == ja)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) vec[p][a][tk + 16 * b] = w.v[a][b];   // row j = block ja
-        }
-        if (tk == jr) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b == ja)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) vec2[p][b][ti + 16 * a] = w.v[a][b];  // column j = block ja
-        }
-        __syncthreads();
-        const double *rowj = vec[p][ja], *colj = vec2[p][ja];
-        const double d = rowj[j];
-        const double sj = (d >= 0.0) ? -1.0 : 1.0;
-        const double piv = d - sj;
-        const double pinv = 1.0 / piv;
-        double li[4], uk[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > j) ? colj[ti + 16 * a] * pinv : 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) uk[b] = (tk + 16 * b > j) ? rowj[tk + 16 * b] : 0.0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ti + 16 * a, k = tk + 16 * b;
-                if (k == j && i > j) w.v[a][b] = li[a];
-                else if (k == j && i == j) w.v[a][b] = piv;
-                else w.v[a][b] -= li[a] * uk[b];
+                for (int b = 0; b < 4; ++b) vec[p][ja][tk + 16 * b] = w.v[ja][b];     // row j
             }
+            if (tk == jr) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) vec2[p][ja][ti + 16 * a] = w.v[a][ja];    // column j
+            }
+            __syncthreads();
+            const double *rowj = vec[p][ja], *colj = vec2[p][ja];
+            const double d = rowj[j];
+            const double sj = (d >= 0.0) ? -1.0 : 1.0;
+            const double piv = d - sj;
+            const double pinv = 1.0 / piv;
+            double li[4], uk[4];
+#pragma unroll
+            for (int a = ja; a < 4; ++a) li[a] = ((a > ja) || ti > jr) ? colj[ti + 16 * a] * pinv : 0.0;
+#pragma unroll
+            for (int b = ja; b < 4; ++b) uk[b] = ((b > ja) || tk > jr) ? rowj[tk + 16 * b] : 0.0;
+#pragma unroll
+            for (int a = ja; a < 4; ++a) {
+#pragma unroll
+                for (int b = ja; b < 4; ++b) {
+                    const bool k_eq = (b == ja) && tk == jr;
+                    const bool i_gt = (a > ja) || ti > jr, i_eq = (a == ja) && ti == jr;
+                    if (k_eq && i_gt) w.v[a][b] = li[a];
+                    else if (k_eq && i_eq) w.v[a][b] = piv;
+                    else w.v[a][b] -= li[a] * uk[b];
+                }
+            }
+            if (threadIdx.x == 0) sgn[j] = sj;
         }
-        if (threadIdx.x == 0) sgn[j] = sj;
     }
     __syncthreads();
 }

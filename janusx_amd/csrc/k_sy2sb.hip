@@ -110,32 +110,41 @@ __device__ __forceinline__ int tiny_chol_upper(Tiny &m, TinyVec *vec) {
     return ok;
 }
 
-// X <- X U^-1, U upper triangular in LDS (u[c][k], c <= k) with its diagonal stored as the reciprocal
+// X <- X U^-1, U upper triangular in LDS (u[c][k], c <= k) with its diagonal stored as the reciprocal.
+// UPPER_X: X is upper triangular itself (an inverse or a product of upper triangular factors built from the identity): column c
+// is zero below row c, so only the row blocks a <= cb take part (half the multiply-adds; the skipped entries stay exact zeros).
+template <bool UPPER_X = false>
 __device__ __forceinline__ void tiny_trsm_right_upper(Tiny &x, const double (*u)[SB_P], TinyVec *vec) {
     const int ti = threadIdx.x >> 4, tk = threadIdx.x & 15;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
+        constexpr int A_ALL = 4;
+        const int na = UPPER_X ? cb + 1 : A_ALL;             // compile time inside the unrolled loop
 #pragma unroll 1
         for (int cr = 0; cr < 16; ++cr) {
             const int c = 16 * cb + cr, p = c & 1;
             if (tk == cr) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) vec[p][cb][ti + 16 * a] = x.v[a][cb];    // column c = column cr of block cb
+                for (int a = 0; a < 4; ++a)
+                    if (a < na) vec[p][cb][ti + 16 * a] = x.v[a][cb];                // column c = column cr of block cb
             }
             __syncthreads();
             const double *colc = vec[p][cb];
             const double rd = u[c][c];
             double xc[4], uk[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) xc[a] = colc[ti + 16 * a] * rd;
+            for (int a = 0; a < 4; ++a)
+                if (a < na) xc[a] = colc[ti + 16 * a] * rd;
 #pragma unroll
             for (int b = cb; b < 4; ++b) uk[b] = ((b > cb) || tk > cr) ? u[c][tk + 16 * b] : 0.0;
 #pragma unroll
             for (int b = cb; b < 4; ++b) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    if (b == cb && tk == cr) x.v[a][b] = xc[a];
-                    else x.v[a][b] -= xc[a] * uk[b];
+                    if (a < na) {
+                        if (b == cb && tk == cr) x.v[a][b] = xc[a];
+                        else x.v[a][b] -= xc[a] * uk[b];
+                    }
                 }
             }
         }
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(256) void sb_chol_kernel(const double *__restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) x.v[a][b] = (ti + 16 * a == tk + 16 * b) ? 1.0 : 0.0;
     __syncthreads();
-    tiny_trsm_right_upper(x, s, vec);
+    tiny_trsm_right_upper<true>(x, s, vec);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
             x.v[a][b] = (k >= i && i < pw && k < pw) ? -w.v[a][b] * sgn[k] : 0.0;
         }
     __syncthreads();
-    tiny_trsm_right_upper(x, s2, vec);
+    tiny_trsm_right_upper<true>(x, s2, vec);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -453,10 +462,10 @@ __global__ __launch_bounds__(256) void sb_recon_kernel(const double *__restrict_
         }
     __syncthreads();
     if (third) {
-        tiny_trsm_right_upper(x, s, vec);
+        tiny_trsm_right_upper<true>(x, s, vec);
         __syncthreads();
     }
-    tiny_trsm_right_upper(x, s2, vec);
+    tiny_trsm_right_upper<true>(x, s2, vec);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll

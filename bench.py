@@ -357,7 +357,7 @@ def main():
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
-            two_stage = lib().jxg_last_kernel_ms(10) > 0.5        # which reduction jxg_eigh_f64 took (two-stage from n = 4000)
+            two_stage = lib().jxg_last_kernel_ms(10) > 0.5        # which reduction jxg_eigh_f64 took (two-stage from n = 1500)
             q2_ms, q2_gflop = lib().jxg_last_kernel_ms(4), lib().jxg_last_kernel_ms(5)
             eig_st = [lib().jxg_last_kernel_ms(i) for i in (6, 7, 8, 9)]
             model = pl.SpectralModel(s, ut64, x, y)
@@ -502,7 +502,7 @@ def main():
                                      "32 sweeps = 8 n^3 / 32 B; once per PAIR of groups in sbback_apply_pair_kernel: 8 n^3 / 64 B); "
                                      "mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles"}
         else:
-            # one-stage path (n < 4000): the dominant kernel is the symv of the tridiagonalisation, one launch per column
+            # one-stage path (n < 1500): the dominant kernel is the symv of the tridiagonalisation, one launch per column
             roofline_main = {"bound": "hbm", "kernel": "sytrd_symv_kernel",
                              "achieved": symv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": symv_gbs / HBM_PEAK_GBS,
                              "traffic": tr_symv, "traffic_source": tr_symv_src,

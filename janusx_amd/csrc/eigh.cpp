@@ -186,7 +186,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         // on: its O(n^3) work is f64-MFMA products instead of one HBM-bound symv per column.  JXGPU_EIGH=onestage keeps
         // the one-stage form; it is also the fallback when a panel of the band reduction cannot be factored, and the
         // form the rank-sharded tridiagonalisation (jxg_eigh_set_dist) uses.
-        static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : 4000;
+        static const int ts_min = getenv("JXGPU_EIGH_TWOSTAGE_MIN") ? atoi(getenv("JXGPU_EIGH_TWOSTAGE_MIN")) : 1500;
         int drank = 0, dworld = 1;
         sytrd_dist_rank(&drank, &dworld);
         // several ranks: the two-stage path with column-sharded back-transformations when a gather callback is registered

@@ -135,7 +135,7 @@ int jxg_eigh_grid_check(int n);
 int64_t jxg_eigh_dist_staging_doubles(int n);
 int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                       int64_t staging_doubles, int min_n);
-/* Node-level distribution of the two-stage path of B1 (n >= 1500): with rank / world set by jxg_eigh_set_dist and a
+/* Node-level distribution of the two-stage path of B1 (one rank: n >= 1500; several ranks: n >= 10000): with rank / world set by jxg_eigh_set_dist and a
  * gather callback registered here, every rank runs the (bit-reproducible) reduction stages and the divide and conquer on
  * the same matrix, back-transforms only the eigenvectors [n r / world, n (r + 1) / world) -- two thirds of the flops of
  * the decomposition shard this way -- and gather(user) must then deliver the other ranks' rows of the row-major result

@@ -193,7 +193,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         // (JXGPU_DIST_EIGH_ONESTAGE=1 keeps the rank-sharded one-stage tridiagonalisation instead)
         static const bool dist_onestage = getenv("JXGPU_DIST_EIGH_ONESTAGE") && atoi(getenv("JXGPU_DIST_EIGH_ONESTAGE")) != 0;
         const bool dist_two = dworld > 1 && g_gather.gather != nullptr && !dist_onestage;
-        bool twostage = n >= ts_min && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
+        // several ranks: the sharded back-transformations keep the round-2 threshold (what the multi-rank tests cover)
+        const int ts_eff = (dworld > 1 && !getenv("JXGPU_EIGH_TWOSTAGE_MIN")) ? std::max(ts_min, 10000) : ts_min;
+        bool twostage = n >= ts_eff && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
                         (dist_two || !sytrd_dist_active(n));
         if (mode && strcmp(mode, "twostage") == 0 && n > 2 * sy2sb_bandwidth() + 2) twostage = true;
         DevBuf ts_work, ts_ab, ts_tau2, ts_ctrl, ts_flags, ts_tq;

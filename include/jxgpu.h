@@ -153,12 +153,18 @@ int jxg_eigh_last_dist_agree(void);
 /* Building blocks of B1's two-stage reduction, exported for tests and timing scripts (no counterpart in the reference,
  * which calls LAPACK dsyevd, src/math/eigh.rs:1320-1400).  All matrices column-major f64 in HBM.
  *   jxg_dgemm_f64:            C = alpha op(A) op(B) + beta C on the f64 matrix pipes (ksplit <= 0: automatic split over K)
+ *   jxg_oz_dgemm_f64:         the same product on the int8 matrix pipes (csrc/k_ozgemm.hip: operands sliced into jxg_oz_planes()
+ *                             signed base-254 digit planes, exact i32 digit products, f64 combination; ~254^-planes relative
+ *                             to max|row of op(A)| max|column of op(B)|); h_ms (optional, 3 floats): slice A / slice B / product ms
  *   jxg_dsymm_lower_f64:      C = alpha A B + beta C, A (m,m) symmetric with only its lower triangle stored
  *   jxg_dsyr2k_lower_nt_f64:  lower tiles of C (m,m) = alpha A B' + beta C, A, B (m,k)
  *   jxg_sy2st_f64:            dense symmetric -> band (half bandwidth 64) -> tridiagonal (d_d, d_e); d_ab_out (optional,
  *                             128 x n) = the band after stage 1; h_flags[0] / [1] = stage-1 failure / stage-2 abort flag */
 int jxg_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,
                   int64_t ldb, double beta, double *d_c, int64_t ldc, int ksplit, void *stream);
+int jxg_oz_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,
+                     int64_t ldb, double beta, double *d_c, int64_t ldc, float *h_ms, void *stream);
+int jxg_oz_planes(void);
 int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,
                         double beta, double *d_c, int64_t ldc, void *stream);
 int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,

@@ -28,7 +28,7 @@ void gather_cols_grid(int n, unsigned *gx, unsigned *gy);
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
                    int min_n);
 // k_ormtr.hip: C <- Q C with wide compact-WY blocks (dormtr left / lower / no-transpose)
-int ormtr_lower(rocblas_handle h, hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c);
+int ormtr_lower(hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c);
 // k_sy2sb.hip / k_sb2st.hip: two-stage reduction (dense -> band -> tridiagonal)
 size_t sy2sb_work_doubles(int n);
 int sy2sb_bandwidth();
@@ -43,8 +43,7 @@ int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, in
                     double *d_tq, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern float g_last_ms[16];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
                               // [8] divide and conquer ms, [9] Q1 back-transformation ms, [10] 1 = two-stage path taken
-int ormtr_lower_off(rocblas_handle h, hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau,
-                    double *d_c, int ncols);
+int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols);
 int sytrd_dist_active(int n);
 void sytrd_dist_rank(int *rank, int *world);
 int launch_gather_cols_range(const double *src, const int *d_perm, int n, int count, double *dst, hipStream_t st);
@@ -316,7 +315,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation (this rank's columns)")) return 1;
-                if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), blk.as<double>(), nr)) return 1;
+                if (ormtr_lower_off(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), blk.as<double>(), nr)) return 1;
                 // column j of the block = eigenvector r0 + j = row r0 + j of the row-major result
                 JX_HIP(hipMemcpyAsync(d_a + (size_t)r0 * n, blk.p, sizeof(double) * (size_t)n * nr, hipMemcpyDeviceToDevice, st));
                 JX_HIP(hipStreamSynchronize(st));
@@ -328,7 +327,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation")) return 1;
-                if (ormtr_lower_off(h, st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>(), n)) return 1;
+                if (ormtr_lower_off(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>(), n)) return 1;
             }
         } else {
             const char *om = getenv("JXGPU_ORMTR");
@@ -338,7 +337,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 if (rs != rocblas_status_success)
                     return fail("rocsolver_dormtr failed with status " + std::to_string((int)rs));
             } else {
-                if (ormtr_lower(h, st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
+                if (ormtr_lower(st, d_a, n, tau.as<double>(), c.as<double>())) return 1;
             }
         }
         JX_HIP(hipEventRecord(ev[5], st));

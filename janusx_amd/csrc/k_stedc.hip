@@ -15,9 +15,13 @@
 #include <chrono>
 #include <vector>
 
-#include "jx_common.h"
+#include "k_ozgemm.h"
 
 namespace jx {
+
+int dgemm(hipStream_t st, bool ta, bool tb, int m, int n, int k, double alpha, const double *a, int64_t lda, const double *b,
+          int64_t ldb, double beta, double *c, int64_t ldc, int ksplit, double *ws, size_t ws_doubles);
+int ormtr_oz_min_n();
 
 constexpr int SD_THREADS = 256;
 constexpr int SD_WAVES = SD_THREADS / 64;
@@ -496,12 +500,20 @@ static void lane_release(const Lane &l) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     g_free_lanes.push_back(l);
 }
+// merge products on the int8 pipes: from JXGPU_OZ_MIN_N / 4 rows, columns and inner dimension on (JXGPU_STEDC_OZ=0: never)
+static bool sd_use_oz(int qrows, int cols, int inner) {
+    static const bool on = !(getenv("JXGPU_STEDC_OZ") && atoi(getenv("JXGPU_STEDC_OZ")) == 0);
+    const int lim = std::max(256, ormtr_oz_min_n() / 4);
+    return on && qrows >= lim && cols >= lim && inner >= lim;
+}
 static size_t dc_arena_bytes(int n) {
     const size_t nn = (size_t)n * (size_t)n;
     // q1/q2 (n^2/2), their compacted copies (<= n^2/2) and one U factor at a time (<= n^2/2), or q1/q2 plus the two
     // children's arenas (n^2 + ...): 2 n^2 covers both for n >= 128; vectors, index lists and the 256-byte alignment
     // of every block are O(n) per level
-    return sizeof(double) * (2 * nn + 256 * (size_t)n) + (64u << 10);
+    // + the int8 images of one merge product (k_ozgemm.hip): planes (n / 2 + n) (n / 2) bytes and their row scales
+    return sizeof(double) * (2 * nn + 256 * (size_t)n) + (64u << 10) + (size_t)6 * (3 * nn / 4 + 512 * (size_t)n) +
+           (64u << 10);
 }
 
 static std::chrono::steady_clock::time_point g_dc_t0;
@@ -881,9 +893,20 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
                                dk.as<double>(), dzh.as<double>(), dtau.as<double>(), dorg.as<int>(), dinv.as<double>(),
                                rm.as<int>(), nr, K, u.as<double>(), (int64_t)nr);
             JX_LAUNCH_CHECK();
-            rocblas_status g = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, qrows, K, nr, &one, q,
-                                             (rocblas_int)ldq, u.as<double>(), nr, &beta, cdst, n);
-            if (g != rocblas_status_success) return fail("rocblas_dgemm failed in stedc merge: " + std::to_string((int)g));
+            // C (qrows x K) = Q (qrows x nr) U (nr x K) + beta C: on the int8 matrix pipes (k_ozgemm.hip) when the product is
+            // large enough to pay for slicing its operands, else the own f64 MFMA GEMM.  No vendor GEMM (rounds 1 - 3: rocBLAS).
+            if (sd_use_oz(qrows, K, nr)) {
+                ABuf img;
+                static const int pl = getenv("JXGPU_STEDC_OZ_PLANES") ? std::min(6, std::max(4, atoi(getenv("JXGPU_STEDC_OZ_PLANES")))) : 0;
+                const size_t ba = oz_image_bytes(qrows, nr, pl), bb = oz_image_bytes(K, nr, pl);
+                SD_TAKE(img, ba + bb);
+                OzImage ia = oz_image_at(img.p, qrows, nr, pl), ib = oz_image_at(img.as<char>() + ba, K, nr, pl);
+                if (oz_slice(st, q, 1, ldq, ia)) return 1;                       // element (r, k) = q[r + k ldq]
+                if (oz_slice(st, u.as<double>(), nr, 1, ib)) return 1;           // element (j, k) = u[k + j nr]
+                if (oz_mm(st, ia, ib, qrows, K, one, beta, cdst, n, 0)) return 1;
+            } else {
+                if (dgemm(st, false, false, qrows, K, nr, one, q, ldq, u.as<double>(), nr, beta, cdst, n, 1, nullptr, 0)) return 1;
+            }
             C.ar.off = gmark;   // stream order protects the reuse
             return 0;
         };

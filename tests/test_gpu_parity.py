@@ -229,6 +229,50 @@ def test_grm_exact_integer_path(oracle, miss_frac, monkeypatch):
     assert _grm_err(k2, ref2) < TOL
 
 
+def test_sliced_int8_gemm():
+    """`jxg_oz_dgemm_f64` (csrc/k_ozgemm.hip): f64 products on the int8 matrix pipes -- operands sliced into base-254 digit planes,
+    exact i32 digit products, f64 combination -- against torch's f64 matmul: NN / TN / NT / TT, ragged M, N, K (tails of the 128-row
+    image blocks and of the 32-deep k steps), rows / columns of very different magnitude (one scale per row of op(A) and per
+    column of op(B)), alpha / beta, a zero row, and a K beyond one launch's exact-i32 range (several launches accumulate)."""
+    import ctypes
+    import torch
+    from janusx_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=dev, dtype=torch.float64)   # noqa: E731
+    L = lib()
+    planes = L.jxg_oz_planes()
+    tol = {4: 3e-9, 5: 2e-11, 6: 1e-13}[planes]
+    for (m, n, k, ta, tb, alpha, beta) in [(300, 200, 177, 0, 0, 1.0, 0.0), (257, 129, 1000, 1, 0, -0.5, 2.0),
+                                           (130, 390, 64, 0, 1, 1.5, 1.0), (515, 77, 333, 1, 1, 1.0, 0.0),
+                                           (1100, 1300, 31, 0, 0, 1.0, -1.0), (128, 256, 23000, 1, 0, 1.0, 0.5),
+                                           (2048, 1500, 3000, 1, 0, 1.0, 0.0)]:
+        a = rnd(k, m) if not ta else rnd(m, k)          # column-major buffers of the STORED operands
+        b = rnd(n, k) if not tb else rnd(k, n)
+        opa = a.T if not ta else a                      # views of op(A) (m, k) and op(B) (k, n)
+        opb = b.T if not tb else b
+        opa *= torch.exp(4.0 * rnd(m, 1))               # rows of op(A) over many orders of magnitude
+        opb *= torch.exp(4.0 * rnd(1, n))
+        opa[m // 2] = 0.0                               # a zero row takes scale 1
+        c = rnd(n, m)
+        ref = alpha * (opa @ opb) + beta * c.T
+        got = c.clone()
+        ms = (ctypes.c_float * 3)()
+        check(L.jxg_oz_dgemm_f64(ta, tb, m, n, k, alpha, a.data_ptr(), k if ta else m, b.data_ptr(), n if tb else k, beta,
+                                 got.data_ptr(), m, ms, st))
+        den = abs(alpha) * (opa.abs() @ opb.abs()) + abs(beta) * c.T.abs()   # the scale of an entry: |row| . |column|
+        err = float(((got.T - ref).abs() / den.clamp_min(1e-300)).max())
+        assert err < tol, (m, n, k, ta, tb, planes, err)
+        assert float(got.T[m // 2].sub(beta * c.T[m // 2]).abs().max()) == 0.0
+    # a NaN in a row of op(A) poisons that row of C and nothing else
+    a, b, c = rnd(200, 140), rnd(130, 200), torch.zeros((130, 140), device=dev, dtype=torch.float64)
+    a[7, 5] = float("nan")
+    check(L.jxg_oz_dgemm_f64(0, 0, 140, 130, 200, 1.0, a.data_ptr(), 140, b.data_ptr(), 200, 0.0, c.data_ptr(), 140, None, st))
+    assert bool(torch.isnan(c[:, 5]).all()) and int(torch.isnan(c).sum()) == 130
+
+
 def test_f64_gemm_family():
     """The eigensolver's own f64-MFMA products (csrc/k_dgemm.hip: `jxg_dgemm_f64` NN / TN / NT / TT with and without a split
     over K, `jxg_dsymm_lower_f64` on a lower-stored symmetric operand, `jxg_dsyr2k_lower_nt_f64` on the lower tiles) against

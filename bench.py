@@ -262,9 +262,22 @@ def main():
     args = ap.parse_args()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched with one rank per GPU: python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py "
-                         f"--gpus {args.gpus} ... (WORLD_SIZE is {world_env})")
+        # Started without a launcher (`python bench.py --gpus N`): start one rank per GPU as a CHILD process -- before anything
+        # here has touched the GPU (torch is imported below), never an exec -- relay its output (rank 0 prints the JSON line)
+        # and leave with its exit code.
+        if os.environ.get("JXGPU_BENCH_CHILD"):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: the launcher started WORLD_SIZE={world_env} ranks")
+        import socket
+        import subprocess
+        with socket.socket() as sk:                   # a free rendezvous port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, JXGPU_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(key, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     # BASELINE.json configs: [2] (n = 20k, m = 200k) is the largest one-GPU configuration of the metric, [3] (n = 50k,
     # m = 500k) the panel the multi-GPU target is quoted on
     if args.n is None:
@@ -337,20 +350,14 @@ def main():
             t0 = time.perf_counter()
             panel = pl.Panel(packed, n)
             counts = panel.counts()
-            gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, 1, 0.02, 0.05, 0.0)
-            grows = np.nonzero(gkeep)[0]
-            glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
-            denom = torch.tensor([float(np.sum(var[grows])), float(len(grows))], dtype=torch.float64, device=dev)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            acc = pl.grm_accumulate(panel, grows, glut)
+            # the product's own composition (pipeline.build_grm, rank-aware): this rank's SNP shard -> partial Z Z' -> ONE
+            # sum-reduction of the f64 lower-triangle tiles + the two denominators over xGMI (RCCL) -> K on every rank
+            k32, geff, _ = pl.build_grm(packed, n, 1, 0.02, 0.05, panel=panel, payload_sharded=True)
             grm_ms = lib().jxg_last_kernel_ms(0)
             kern["grm_i8_share"] = float(lib().jxg_last_kernel_ms(12))   # SNPs on the exact int8 path / all kept SNPs
-            if distributed:
-                jd.allreduce_grm_accumulator_(acc)     # f64 partial GRMs summed over xGMI (RCCL): lower-triangle tiles only
-                jd.allreduce_sum_(denom)
-            k32 = pl.grm_finalize(acc, n, float(denom[0]), torch.float32)
-            del acc
+            geff_local = int(panel.grm_rows_local)                        # kept SNPs of this rank's launch
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             s, ut64 = pl.eigh_from_grm(k32, 1e-6)
@@ -375,6 +382,7 @@ def main():
                 n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
             else:
                 n_evals = 0.0
+            out = pl.gather_results(out)              # result rows of every rank in BED order (12 MB at configs[3])
             torch.cuda.synchronize()
             t5 = time.perf_counter()
             if record:
@@ -392,7 +400,7 @@ def main():
                         stage[name] = stage.get(name, 0.0) + v * 1e-3
                     stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3
                 kern["grm_ms"] += grm_ms
-                kern["grm_flops"] += float(n) * (n + 1) * len(grows)
+                kern["grm_flops"] += float(n) * (n + 1) * geff_local
                 kern["rot_ms"] += tm.t.get("rotate", 0.0) * 1e3
                 # exact rows present: int8 planes (three products per algorithmic product) priced against the int8 peak
                 kern["rot_peak"] = MFMA_I8_PEAK_TOPS if float(lib().jxg_last_kernel_ms(13)) > 0.5 else MFMA_F16_PEAK_TFLOPS
@@ -404,7 +412,7 @@ def main():
                 kern["scan_flops"] = kern.get("scan_flops", 0.0) + (n_evals + len(rows)) * n * (1.5 * dim * (dim + 1) + 5 * dim + 8)
                 kern["scan_evals"] = kern.get("scan_evals", 0.0) + n_evals / max(1, len(rows))
                 kern["launches"] += 1
-            return len(rows), len(grows), model.null, out
+            return len(rows), geff, model.null, out
 
         for _ in range(warmup):
             one_step(False)

@@ -114,11 +114,43 @@ def _resolve_out(args, src):
     return res
 
 
+def _dist_setup():
+    """Under a launcher (`python -m torch.distributed.run --nproc-per-node N -m janusx_amd gwas ...`: WORLD_SIZE > 1) bind this
+    process to its GPU, join the process group (backend JXGPU_DIST_BACKEND, default "nccl" = RCCL over xGMI; "gloo" lets several
+    ranks share one GPU in the functional tests) and switch the rank-aware pipeline on: SNP-sharded GRM + one reduction, the
+    eigenvectors shared out over the ranks, SNP-sharded scan, rows gathered in BED order.  Rank 0 alone prints
+    and writes.  -> (rank, world); (0, 1) without a launcher."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    from . import pipeline as pl
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("JXGPU_DIST_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU of its own ({ndev} visible); one process per GPU")
+    torch.cuda.set_device(local % ndev)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    pl.init_distributed()
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")      # one voice: rank 0 reports
+    return rank, world
+
+
 def cmd_grm(args):
     from . import janusx as jxrs
     from .bed import read_fam_ids
     if args.grm is None and not args.bfile:
         raise SystemExit("grm needs -bfile PREFIX (or -grm FILE.npy -sparse [cutoff])")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and (args.grm is not None or args.sparse is not None):
+        raise SystemExit("the sparse-GRM routes run on one GPU: start them without the launcher")
     out = _resolve_out(args, args.bfile or args.grm)
     t0 = time.perf_counter()
     if args.grm is not None:
@@ -149,9 +181,23 @@ def cmd_grm(args):
         print(f"Sparse GRM method {args.method}: n={n} nnz={nnz} cutoff={args.sparse} -> {path} "
               f"({time.perf_counter() - t0:.2f}s)")
         return 0
-    k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
-                                        max_missing_rate=args.geno, het_threshold=0.0,
-                                        snps_only=bool(getattr(args, "snps_only", False)))
+    rank, world = _dist_setup()
+    if world > 1:
+        # one process per GPU: every rank accumulates its share of the kept SNPs, one reduction over xGMI (pipeline.build_grm)
+        import torch
+        from . import pipeline as pl
+        from .bed import snps_only_mask, stage_bed_payload
+        packed_t, n, bim = stage_bed_payload(args.bfile, None)
+        if getattr(args, "snps_only", False):
+            packed_t = packed_t[torch.from_numpy(np.nonzero(snps_only_mask(bim))[0]).to(packed_t.device)]
+        k_t, eff, _ = pl.build_grm(packed_t, n, args.method, args.maf, args.geno)
+        if rank != 0:
+            return 0
+        k = k_t.cpu().numpy()
+    else:
+        k, eff, n = jxrs.grm_stream_bed_f32(args.bfile, method=args.method, maf_threshold=args.maf,
+                                            max_missing_rate=args.geno, het_threshold=0.0,
+                                            snps_only=bool(getattr(args, "snps_only", False)))
     tag = "cGRM" if args.method == 1 else "sGRM"
     if getattr(args, "txt", False):             # python/janusx/script/grm.py:2684-2690
         path = f"{out}.{tag}.txt"
@@ -269,6 +315,9 @@ def cmd_gwas(args):
         args.splmm = float(args.splmm_exact)
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
         raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm, -splmm and/or -splmm-exact")
+    rank, world = _dist_setup()
+    if world > 1 and args.splmm is not None:
+        raise SystemExit("the SparseLMM routes run on one GPU: start -splmm / -splmm-exact without the launcher")
     # the payload goes to HBM in windows (bed.stage_bed_payload: `mmap_window_mb` of the reference's BED routes); nothing
     # below holds a host copy of it
     from .bed import stage_bed_payload
@@ -343,7 +392,7 @@ def cmd_gwas(args):
         k, eff, _ = pl.build_grm(packed_t, n_fam, int(args.grm), args.maf, args.geno)
         print(f"GRM method {args.grm}: eff_m={eff} ({time.perf_counter() - t0:.2f}s)")
     elif dense_models:
-        k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)
+        k = torch.from_numpy(_load_grm(args.grm, fam)).to(dev)    # every rank reads the same file
     # -q N: the N leading principal components of the whole-cohort GRM as fixed-effect columns beside the intercept
     # (`load_or_build_q_with_cache` -> `build_pcs_from_grm`, python/janusx/assoc/workflow.py:3389-3422, 3577-3789: the last N
     # columns of the ascending eigendecomposition of the GRM without a ridge, stored as f32; the reference switches to a

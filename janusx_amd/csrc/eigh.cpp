@@ -197,6 +197,25 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         bool twostage = n >= ts_eff && n > 4 * sy2sb_bandwidth() && !(mode && strcmp(mode, "onestage") == 0) &&
                         (dist_two || !sytrd_dist_active(n));
         if (mode && strcmp(mode, "twostage") == 0 && n > 2 * sy2sb_bandwidth() + 2) twostage = true;
+        // Several ranks: a stage's failure flag (a panel the band reduction could not factor, a bulge-chasing spin that expired
+        // -- the latter depends on timing) must send EVERY rank down the same branch, or the ranks' collectives no longer
+        // match (one rank in the one-stage fallback, the others in the gather): the flag is compared over the ranks through
+        // the agreement callback (checksum = the flag); any disagreement means some rank failed, and all of them fall back.
+        // Without a callback a rank cannot coordinate: it fails loudly instead of diverging.
+        auto flag_on_any_rank = [&](int local_flag, int *any) -> int {
+            *any = local_flag != 0;
+            if (!dist_two) return 0;
+            if (!g_gather.agree) {
+                if (local_flag != 0)
+                    return fail("jxg_eigh_f64: a reduction stage failed on this rank and no agreement callback is registered "
+                                "(jxg_eigh_set_agree): the ranks cannot take the fallback together");
+                return 0;
+            }
+            const int ag = g_gather.agree(g_gather.agree_user, local_flag != 0 ? 0x9e3779b97f4a7c15ull : 0ull);
+            if (ag < 0) return fail("jxg_eigh_f64: the agreement callback failed");
+            if (ag == 0) *any = 1;
+            return 0;
+        };
         DevBuf ts_work, ts_ab, ts_tau2, ts_ctrl, ts_flags, ts_tq;
         ScratchLease ts_v2;
         const int ldab = sb2st_ldab(), ks = sb2st_steps(n);
@@ -223,7 +242,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > need + ((size_t)8 << 30) && ts_tq.alloc(need)) return 1;
             }
             JX_HIP(hipStreamSynchronize(st));
-            if (hf[0] != 0) {
+            int flagged = 0;
+            if (flag_on_any_rank(hf[0], &flagged)) return 1;
+            if (flagged) {
                 if (trace) (void)stage_done("sy2sb (flagged)");
                 if (trace) fprintf(stderr, "[jxgpu eigh n=%d] band reduction flagged a panel (code %d): one-stage fallback\n", n, hf[0]);
                 JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
@@ -240,7 +261,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             int habort = 0;
             JX_HIP(hipMemcpyAsync(&habort, ts_ctrl.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
-            if (habort != 0) {
+            int aborted = 0;
+            if (flag_on_any_rank(habort, &aborted)) return 1;
+            if (aborted) {
                 // a sweep's bounded spin on its predecessor expired (the persistent launch assumes its workgroups are
                 // co-resident: a shared device can break that): restore the input from the copy and reduce it in one stage
                 if (trace) fprintf(stderr, "[jxgpu eigh n=%d] bulge chasing gave up waiting for a neighbour sweep: one-stage fallback\n", n);

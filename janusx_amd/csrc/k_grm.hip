@@ -663,6 +663,15 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
             JX_HIP(hipMemcpyAsync(&hm, misstotb.p, sizeof(hm), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
             if (hm == 0 || (double)hm > miss_max * (double)mk * (double)n_sel || hm > 0x7fffffffULL) use_miss = false;
+            if (use_miss) {
+                // the correction needs an n_pad^2 f64 buffer + the lists (20 GB at n = 50 000, 80 GB at n = 100 000): decided
+                // HERE, while the flagged rows can still be handed to the general kernel -- once the int8 kernel has added
+                // their clean form there is no way back
+                size_t fr = 0, tot = 0;
+                const size_t need = sizeof(double) * (size_t)ld * (size_t)ld + sizeof(int32_t) * (size_t)hm +
+                                    sizeof(int64_t) * ((size_t)ld * 32 + 2) + 5 * (size_t)mk + sizeof(double) * 4 * (size_t)mk;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + ((size_t)2 << 30)) use_miss = false;
+            }
         }
         if (!use_miss) {
             hipLaunchKernelGGL(grm_demote_kernel, dim3(gk), dim3(256), 0, st, flagb.as<int32_t>(), mk);

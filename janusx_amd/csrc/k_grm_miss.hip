@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void gm_merge_kernel(const double *__restrict_
 
 // Adds (W + W') of the flagged rows (miss2[k] != 0, k < nex of the reordered list) to the lower triangle of d_acc.
 // wl: (nex, 4) f64 table per SNP and 2-bit code.  Returns 0 on success, 1 on a failed launch / allocation, 2 when the lists
-// would not fit (nothing has been added then: the caller takes the general kernel for these rows).
+// would not fit (nothing has been added then).  The caller (k_grm.hip) checks the memory BEFORE it commits rows to this path
+// -- n_pad^2 doubles + 4 bytes per missing call, known right after the classification -- and sends them to the general kernel
+// instead; a 2 here (another process took the memory in between) is a hard failure, the clean form has been accumulated.
 int grm_missing_correction(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n_sel, int nt, const int32_t *rows2,
                            const uint8_t *miss2, const double *wl, int64_t nex, double *d_acc, int64_t ld) {
     if (nex <= 0) return 0;

@@ -81,6 +81,15 @@ class Panel:
         check(lib().jxg_repack_p32(_ptr(packed), bps, self.n_src, self.m, _ptr(idx_t), self.n, None, self.m,
                                    _ptr(self.p32), _stream()))
         self._counts = None
+        self._mean_missing = None
+
+    def mean_missing(self) -> float:
+        """Mean number of missing calls per row over ALL rows of the payload (cached): the call-independent statistic behind
+        the choice of the rotation path for rows with a few missing calls (`jxg_rot_miss_max`)."""
+        if self._mean_missing is None:
+            c = self.counts()
+            self._mean_missing = float(np.mean(c[:, 0])) if len(c) else 0.0
+        return self._mean_missing
 
     def counts(self) -> np.ndarray:
         """(m,3) int32 (missing, het, hom_alt) over the selected samples (host copy, cached)."""
@@ -113,6 +122,60 @@ def grm_finalize(acc: torch.Tensor, n: int, scale: float, dtype=torch.float32):
 
 
 _DIST_EIGH = {}   # keeps the ctypes callback and the staging tensor alive
+
+
+def dist_info():
+    """(rank, world) of the initialised torch.distributed group; (0, 1) without one (or with a single rank)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_distributed(eigh_min_n: int = 16384):
+    """Call once per process after `torch.distributed.init_process_group` (one process per GPU; backend "nccl" = RCCL over
+    xGMI, "gloo" in the functional tests): switches the rank-aware forms of `build_grm` / `run_trait` / `run_gwas` on (they
+    look at the process group themselves) and distributes the eigendecomposition (`enable_distributed_eigh`).
+    SURVEY.md 8(e): SNP ranges per rank for the GRM, one sum-reduction of the partial accumulators, eigenvectors sharded over
+    the ranks, SNP-sharded scan, results gathered in BED order.  -> (rank, world)."""
+    rank, world = dist_info()
+    if world > 1 and os.environ.get("JXGPU_DIST_EIGH", "1") != "0":
+        enable_distributed_eigh(eigh_min_n)
+    return rank, world
+
+
+def _my_slice(count: int, payload_sharded: bool):
+    """This rank's contiguous share [lo, hi) of `count` work items (all of them when the payload itself is the rank's shard)."""
+    rank, world = dist_info()
+    if world == 1 or payload_sharded:
+        return 0, count
+    from .dist import shard_range
+    return shard_range(count, rank, world)
+
+
+def _allgather_rows(t: torch.Tensor) -> torch.Tensor:
+    """Per-rank (rows_r, ...) tensors concatenated in rank order on every rank (= BED order of contiguous SNP shards)."""
+    from .dist import gather_rows
+    import torch.distributed as dist
+    if dist_info()[1] == 1:
+        return t
+    if t.is_cuda and dist.get_backend() != "nccl":
+        return gather_rows(t.cpu()).to(t.device)         # functional multi-rank mode on shared GPUs (gloo): through host memory
+    return gather_rows(t)
+
+
+gather_results = _allgather_rows
+
+
+def _allgather_np(a: np.ndarray) -> np.ndarray:
+    if dist_info()[1] == 1:
+        return a
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dist.get_backend() == "nccl":
+        return _allgather_rows(t.to(torch.device("cuda", torch.cuda.current_device()))).cpu().numpy()
+    from .dist import gather_rows
+    return gather_rows(t).numpy()
 
 
 def enable_distributed_eigh(min_n: int = 0):
@@ -174,8 +237,10 @@ def enable_distributed_eigh(min_n: int = 0):
         # MIN and MAX of the 64-bit checksum (as two 32-bit halves in int64 lanes) over the ranks
         try:
             cs = int(checksum) & 0xFFFFFFFFFFFFFFFF
-            if os.environ.get("JXGPU_DIST_EIGH_TEST_DISAGREE", "") == str(rank):
-                cs ^= 1                                   # test hook: this rank pretends to hold different bits
+            # test hook: this rank pretends to hold different bits (the replicated results' checksum only -- the failure flags of
+            # the reduction stages, compared through the same callback, are 0 or the constant below)
+            if os.environ.get("JXGPU_DIST_EIGH_TEST_DISAGREE", "") == str(rank) and cs not in (0, 0x9E3779B97F4A7C15):
+                cs ^= 1
             v = torch.tensor([cs >> 32, cs & 0xFFFFFFFF], dtype=torch.int64)
             lo, hi = v.clone(), v.clone()
             if dist.get_backend() == "nccl":
@@ -382,10 +447,12 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
     rowoff = torch.empty(mk, dtype=torch.float32, device=dev)
     # rows with a few missing calls keep the exact (int8) rotation and get their missing-call term added behind it
     # (jxg_rotate_missing_correct: d * the sum of the missing samples' rows of U); only where the int8 rotation runs
+    # The limit is decided from a statistic of the PANEL (mean missing calls over all its rows, cached), never from the rows of
+    # this call: a row takes the same path -- and gets the same bits -- in chunked, unchunked and rank-sharded scans, and the
+    # host entry point (api.cpp, all rows of the payload) decides the same way.
     miss_max = 0
     if qpl is not None:
-        cnt = panel.counts()
-        miss_max = int(lib().jxg_rot_miss_max(n, float(np.mean(cnt[np.asarray(rows, dtype=np.int64), 0])) if mk else 0.0))
+        miss_max = int(lib().jxg_rot_miss_max(n, panel.mean_missing()))
     rowmiss = torch.zeros(mk, dtype=torch.float32, device=dev) if miss_max > 0 else None
     check(lib().jxg_lut_split_rows_m(_ptr(panel.p32), panel.m, n, _ptr(rows_t), _ptr(lut_t), mk, _ptr(lut16),
                                      _ptr(rowoff), _ptr(rowmiss) if rowmiss is not None else None, miss_max, _stream()))
@@ -747,29 +814,46 @@ class GwasResult:
     null_lrt: tuple = None  # (switch_to_lm, LRT statistic, p) of `gwas_lmm_lm_null_lrt_decision` when it was evaluated
 
 
-def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.05, panel: Panel = None):
+def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.05, panel: Panel = None,
+              payload_sharded: bool = False):
     """`build_grm_streaming` -> `grm_stream_bed_f32` on an HBM-resident payload (all samples; het filter off,
-    python/janusx/assoc/workflow.py:2928-3095). Returns (K f32 device tensor (n,n), eff_m, panel)."""
+    python/janusx/assoc/workflow.py:2928-3095). Returns (K f32 device tensor (n,n), eff_m, panel).
+    Several ranks (torch.distributed initialised, SURVEY.md 8(e) / BASELINE north_star): every rank accumulates the partial
+    Z Z' of ITS SNPs -- a contiguous share of the kept rows of a replicated payload, or all kept rows of its own payload shard
+    (`payload_sharded`) --, ONE sum-reduction of the lower-triangle tiles of the f64 accumulators (RCCL over xGMI) and of the two
+    scalar denominators follows, and every rank finalises the same K."""
     if panel is None:
         panel = Panel(packed, n_samples)
     counts = panel.counts()
     n = panel.n
     gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, method, maf, geno, 0.0)
     grows = np.nonzero(gkeep)[0]
-    if len(grows) == 0:
+    lo, hi = _my_slice(len(grows), payload_sharded)
+    grows = grows[lo:hi]
+    panel.grm_rows_local = int(len(grows))          # this rank's share (bench.py prices its launch with it)
+    totals = torch.tensor([float(np.sum(var[grows])), float(len(grows))], dtype=torch.float64, device=panel.device)
+    world = dist_info()[1]
+    if world > 1:
+        from .dist import allreduce_sum_
+        allreduce_sum_(totals)
+    var_sum, eff = (float(v) for v in totals.cpu().numpy())
+    if int(round(eff)) == 0:
         raise RuntimeError("No SNPs remained after filtering; GRM is empty.")
-    glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
-    denom = float(np.sum(var[grows])) if method == 1 else float(len(grows))
+    denom = var_sum if method == 1 else eff
     if not (math.isfinite(denom) and denom > 0.0):
         raise RuntimeError("invalid centered GRM denominator: sum(2p(1-p)) <= 0")
+    glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
     acc = grm_accumulate(panel, grows, glut)
+    if world > 1:
+        from .dist import allreduce_grm_accumulator_
+        allreduce_grm_accumulator_(acc)
     k32 = grm_finalize(acc, n, denom, torch.float32)
-    return k32, len(grows), panel
+    return k32, int(round(eff)), panel
 
 
 def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y: np.ndarray, x: np.ndarray,
               mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False, on_rows=None,
-              force_model=True):
+              force_model=True, payload_sharded: bool = False):
     """One trait of `run_chunked_gwas_lmm_lm` (python/janusx/assoc/workflow_model_stream.py:464-1480):
     eigh of K[keep, keep] + 1e-6 I, spectral null model, QC on the trait's samples, rotate + scan.
     `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order).
@@ -777,7 +861,12 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     returns the `on_block` callback of `scan_rows` (or None): the streaming writer is opened there.
     force_model=False: the null likelihood-ratio test against the plain LM (`gwas_lmm_lm_null_lrt_decision`) runs after the
     null fit and, when it finds no polygenic variance (p >= 0.05), the trait is scanned with the LM instead
-    (workflow_model_stream.py:930-963; result.model_tag == "lm", three columns beta, se, Student-t p)."""
+    (workflow_model_stream.py:930-963; result.model_tag == "lm", three columns beta, se, Student-t p).
+    Several ranks (torch.distributed initialised; `init_distributed`): the eigendecomposition is shared out over the ranks, the
+    null model is fitted on every rank (deterministic), every rank scans ITS kept SNPs -- a contiguous share of the kept rows of
+    a replicated payload, or the kept rows of its own payload shard (`payload_sharded`) -- and the result rows are gathered in
+    BED order on every rank; `on_rows` is called on rank 0 only, with the whole table as one block."""
+    rank, world = dist_info()
     keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
     s, ut64 = eigh_from_grm(k, 1e-6, keep_idx)
     model = SpectralModel(s, ut64, x, y)
@@ -787,6 +876,9 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     n = panel.n
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
     rows = np.nonzero(keep)[0]
+    if world > 1:
+        return _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max_iter, tol, warm_start, on_rows,
+                                force_model, payload_sharded)
     lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
     lrt = None
     if not force_model:
@@ -829,9 +921,65 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     return res
 
 
+def _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max_iter, tol, warm_start, on_rows, force_model,
+                     payload_sharded):
+    """Scan stage of `run_trait` on several ranks: this rank's rows -> gather in BED order -> rank 0 hands the table on."""
+    rank, world = dist_info()
+    n = panel.n
+    lo, hi = _my_slice(len(rows), payload_sharded)
+    mine = rows[lo:hi]
+    lrt, tag, ncol = None, mode, (6 if mode == "lmm2" else 3)
+    miss_col = miss[rows]
+    if not force_model:
+        from .janusx import gwas_lmm_lm_null_lrt_decision
+        sw, stat, pv, _ml = gwas_lmm_lm_null_lrt_decision(y, np.asarray(x)[:, 1:], model.null.ml0)   # same on every rank
+        lrt = (sw, stat, pv)
+        if sw:
+            tag, ncol = "lm", 3
+            miss_col = counts[rows, 0].astype(np.float32)
+    if tag == "lm":
+        out = scan_rows_lm(panel, mine, af[mine], x, y)[:, :3].contiguous()
+    else:
+        lut = st.scan_lut_from_counts(af[mine], np.zeros(len(mine), dtype=bool), counts[mine], n)
+        init, nullml = None, None
+        lo_b, hi_b = model.null.bounds
+        if mode == "lmm" and warm_start and model.null.lbd > 0:
+            init = min(max(math.log10(model.null.lbd), lo_b), hi_b)
+        if mode == "lmm2":
+            o2 = torch.empty(2, dtype=torch.float64, device=panel.device)
+            init = min(max(math.log10(model.null.lbd), lo_b), hi_b) if model.null.lbd > 0 else None
+            check(lib().jxg_lmm2_null_ml(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b, int(max_iter),
+                                         float(tol), 1 if init is not None else 0, float(init or 0.0), o2.data_ptr(),
+                                         _stream()))
+            nullml = float(o2.cpu().numpy()[1])
+            if not math.isfinite(nullml):
+                raise RuntimeError("failed to optimize null ML for LMM2 unified scan")
+        if mode in ("lmm", "lmm2"):
+            out = scan_rows(panel, model, mine, lut, mode, max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=nullml)
+        else:
+            out = scan_rows(panel, model, mine, lut, "fvlmm")
+    out = _allgather_rows(out)
+    keep_all, af_k, miss_k = keep, af[rows], miss_col
+    if payload_sharded:       # the QC columns are per shard too: concatenate them in rank (= BED) order
+        keep_all, af_k, miss_k = _allgather_np(keep), _allgather_np(af[rows]), _allgather_np(miss_col)
+    stats = out.cpu().numpy()
+    if on_rows is not None and rank == 0:
+        on_block = on_rows(keep_all, af_k, miss_k, ncol, tag)
+        if on_block is not None:
+            on_block(0, stats)
+    res = GwasResult(keep_all, af_k, miss_k, stats, model.null, 0, {})
+    res.model_tag, res.null_lrt = tag, lrt
+    return res
+
+
 def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndarray = None, mode="lmm",
-             maf=0.02, geno=0.05, het=1.0, grm_method=1, max_iter=30, tol=1e-2, timing=True) -> GwasResult:
-    """Single-GPU `jx gwas -lmm/-fvlmm` on an HBM-resident payload (all samples phenotyped)."""
+             maf=0.02, geno=0.05, het=1.0, grm_method=1, max_iter=30, tol=1e-2, timing=True,
+             payload_sharded: bool = False) -> GwasResult:
+    """`jx gwas -lmm/-fvlmm` on an HBM-resident payload (all samples phenotyped): GRM -> eigh -> null REML -> per-SNP scan.
+    Several ranks (torch.distributed initialised; `init_distributed`): the composition of SURVEY.md 8(e) -- SNP-sharded GRM with
+    one sum-reduction (`build_grm`), eigenvectors shared out over the ranks (`eigh_from_grm`), SNP-sharded scan, result rows
+    gathered in BED order on every rank; `packed` is the whole payload on every rank, or this rank's contiguous SNP shard of it
+    (`payload_sharded`)."""
     tm = StageTimes()
 
     def tick():
@@ -843,20 +991,10 @@ def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndar
     panel = Panel(packed, n_samples)
     counts = panel.counts()
     n = panel.n
-    # GRM: `grm_stream_bed_f32` defaults maf/geno from the CLI, het filter off (workflow.py:3095)
-    gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, grm_method, maf, geno, 0.0)
-    grows = np.nonzero(gkeep)[0]
-    if len(grows) == 0:
-        raise RuntimeError("No SNPs remained after filtering; GRM is empty.")
-    glut = st.grm_lut_from_mean_scale(mean_g[grows], scale[grows], flip[grows])
-    denom = float(np.sum(var[grows])) if grm_method == 1 else float(len(grows))
-    if not (math.isfinite(denom) and denom > 0.0):
-        raise RuntimeError("invalid centered GRM denominator: sum(2p(1-p)) <= 0")
     t1 = tick()
     tm.add("prep", t1 - t0)
-    acc = grm_accumulate(panel, grows, glut)
-    k32 = grm_finalize(acc, n, denom, torch.float32)
-    del acc
+    # GRM: `grm_stream_bed_f32` defaults maf/geno from the CLI, het filter off (workflow.py:3095)
+    k32, geff, _ = build_grm(packed, n_samples, grm_method, maf, geno, panel=panel, payload_sharded=payload_sharded)
     t2 = tick()
     tm.add("grm", t2 - t1)
     s, ut64 = eigh_from_grm(k32, 1e-6)
@@ -869,14 +1007,19 @@ def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndar
     tm.add("null", t4 - t3)
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
     rows = np.nonzero(keep)[0]
-    lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
+    lo, hi = _my_slice(len(rows), payload_sharded)
+    mine = rows[lo:hi]
+    lut = st.scan_lut_from_counts(af[mine], np.zeros(len(mine), dtype=bool), counts[mine], n)
     if mode == "lmm":
-        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol,
+        out = scan_rows(panel, model, mine, lut, "lmm", max_iter=max_iter, tol=tol,
                         times=tm if timing else None)
     else:
-        out = scan_rows(panel, model, rows, lut, "fvlmm", times=tm if timing else None)
-    res = out.cpu().numpy()
+        out = scan_rows(panel, model, mine, lut, "fvlmm", times=tm if timing else None)
+    res = _allgather_rows(out).cpu().numpy()
+    af_k, miss_k = af[rows], miss[rows]
+    if payload_sharded and dist_info()[1] > 1:
+        keep, af_k, miss_k = _allgather_np(keep), _allgather_np(af_k), _allgather_np(miss_k)
     t5 = tick()
     tm.add("scan_total", t5 - t4)
     tm.add("total", t5 - t0)
-    return GwasResult(keep, af[rows], miss[rows], res, model.null, len(grows), tm.t)
+    return GwasResult(keep, af_k, miss_k, res, model.null, geff, tm.t)

@@ -149,6 +149,19 @@ int jxg_eigh_set_gather(int (*gather)(void *), void *user);
  * jxg_eigh_last_dist_agree: -1 not checked, 1 the replicas agreed, 0 they differed, for the last decomposition. */
 int jxg_eigh_set_agree(int (*agree)(void *, uint64_t checksum), void *user);
 int jxg_eigh_last_dist_agree(void);
+/* Band reduction of the two-stage path with the trailing matrix SHARDED over the ranks (B1 on several GPUs; no counterpart in
+ * the reference, which factors on one host: src/math/eigh.rs:1422-1528): ownership by block rows of `block` samples (<= 0:
+ * 2048) dealt cyclically; per panel two collectives through allreduce(user, count) = the sum over the ranks of the first
+ * `count` doubles of d_staging (jxg_eigh_band_staging_doubles(n) doubles) on the stream passed to jxg_eigh_f64: the partial
+ * symmetric products Z = A22 V, and the gather of the next panel's block column.  From min_n rows on (<= 0: 8192), on the
+ * multi-rank two-stage path only.  jxg_eigh_last_band_sharded: 1 when the last decomposition took it. */
+int jxg_eigh_set_band_dist(int rank, int world, int (*allreduce)(void *, int64_t count), void *user, double *d_staging,
+                           int64_t staging_doubles, int min_n, int block);
+int64_t jxg_eigh_band_staging_doubles(int n);
+int jxg_eigh_last_band_sharded(void);
+/* 1 when the last multi-rank decomposition's divide and conquer formed only this rank's eigenvector columns in its top-level
+ * merge (three quarters of its product flops; JXGPU_DIST_DC_WINDOW=0 switches that off). */
+int jxg_eigh_last_dc_windowed(void);
 
 /* Building blocks of B1's two-stage reduction, exported for tests and timing scripts (no counterpart in the reference,
  * which calls LAPACK dsyevd, src/math/eigh.rs:1320-1400).  All matrices column-major f64 in HBM.

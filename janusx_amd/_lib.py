@@ -46,6 +46,10 @@ SIGNATURES = {
     "jxg_eigh_set_gather": [c_p, c_p],
     "jxg_eigh_set_agree": [c_p, c_p],
     "jxg_eigh_last_dist_agree": [],
+    "jxg_eigh_set_band_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i, c_i],
+    "jxg_eigh_band_staging_doubles": [c_i],
+    "jxg_eigh_last_band_sharded": [],
+    "jxg_eigh_last_dc_windowed": [],
     "jxg_dgemm_f64": [c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_i, c_p],
     "jxg_oz_dgemm_f64": [c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p, c_p],
     "jxg_oz_planes": [],
@@ -133,7 +137,7 @@ SIGNATURES = {
     "jxg_rotate_missing_correct": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p],
 }
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
-             "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64,
+             "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64, "jxg_eigh_band_staging_doubles": C.c_int64,
              "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
              "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64}
 

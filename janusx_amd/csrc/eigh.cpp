@@ -22,7 +22,7 @@ int launch_symmetrize(double *d_a, int n, hipStream_t st);
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau);
 // k_stedc.hip: Cuppen divide and conquer (batched QL leaves, merges level by level; no 32-bit size limit)
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
-                std::vector<int> &h_perm);
+                std::vector<int> &h_perm, int sel_lo = 0, int sel_hi = 0);
 int launch_gather_cols(const double *src, const int *d_perm, int n, double *dst, hipStream_t st);
 void gather_cols_grid(int n, unsigned *gx, unsigned *gy);
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
@@ -32,7 +32,12 @@ int ormtr_lower(hipStream_t st, const double *d_a, int n, const double *d_tau, d
 // k_sy2sb.hip / k_sb2st.hip: two-stage reduction (dense -> band -> tridiagonal)
 size_t sy2sb_work_doubles(int n);
 int sy2sb_bandwidth();
-int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work, int *d_flags);
+int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work, int *d_flags,
+                bool allow_shard = false);
+int sy2sb_set_band_dist(int rank, int world, int (*allreduce)(void *, int64_t), void *user, double *staging,
+                        int64_t staging_doubles, int min_n, int block);
+int64_t sy2sb_band_staging_doubles(int n);
+int sy2sb_band_dist_active(int n);
 int sb2st_ldab();
 int sb2st_steps(int n);
 size_t sb2st_ctrl_bytes(int n);
@@ -96,6 +101,21 @@ extern "C" int jxg_eigh_set_gather(int (*gather)(void *), void *user) {
     g_gather.user = user;
     return 0;
 }
+
+// Band reduction with the trailing matrix sharded over the ranks (k_sy2sb.hip, BandDist): ownership by block rows of `block`
+// samples dealt cyclically, two collectives per panel through allreduce(user, count) -- the sum over the ranks of the first
+// `count` doubles of d_staging, on the stream passed to jxg_eigh_f64 -- from `min_n` rows on (<= 0: 8192).  Takes effect on the
+// two-stage path of a multi-rank decomposition (jxg_eigh_set_dist + jxg_eigh_set_gather).  d_staging needs
+// jxg_eigh_band_staging_doubles(n) doubles.  allreduce = NULL: off.
+extern "C" int jxg_eigh_set_band_dist(int rank, int world, int (*allreduce)(void *, int64_t), void *user, double *d_staging,
+                                      int64_t staging_doubles, int min_n, int block) {
+    return sy2sb_set_band_dist(rank, world, allreduce, user, d_staging, staging_doubles, min_n, block);
+}
+extern "C" int64_t jxg_eigh_band_staging_doubles(int n) { return sy2sb_band_staging_doubles(n); }
+static int g_last_dc_windowed = 0;    // 1 when the last decomposition's top-level merge formed this rank's columns only
+extern "C" int jxg_eigh_last_dc_windowed(void) { return g_last_dc_windowed; }
+static int g_last_band_sharded = 0;   // 1 when the last decomposition ran the band reduction on a sharded trailing matrix
+extern "C" int jxg_eigh_last_band_sharded(void) { return g_last_band_sharded; }
 
 // Agreement check in front of the sharded back-transformations: the ranks' replicated results (tridiagonal eigenvalues,
 // divide-and-conquer permutation, first row of its eigenvector matrix) are hashed and `agree(user, checksum)` has to say
@@ -229,8 +249,13 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             // the band reduction overwrites A: keep a copy (in the buffer the divide and conquer fills later) in case a
             // panel cannot be factored
             JX_HIP(hipMemcpyAsync(c.p, d_a, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
+            // JXGPU_DIST_EIGH_FORCE: the sharded code path with ONE rank (every block row is its own: same launches, the
+            // collectives through the registered callback -- how the RCCL leg is exercised on a one-GPU box)
+            static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
+            const bool shard_band = (dist_two || force_single) && sy2sb_band_dist_active(n);
+            g_last_band_sharded = shard_band ? 1 : 0;
             if (sy2sb_lower(st, d_a, n, tau.as<double>(), ts_ab.as<double>(), ldab, ts_work.as<double>(),
-                            ts_flags.as<int>()))
+                            ts_flags.as<int>(), shard_band))
                 return 1;
             int hf[4] = {0, 0, 0, 0};
             JX_HIP(hipMemcpyAsync(hf, ts_flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
@@ -292,8 +317,35 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (leaf > kRocsolverStedcMaxN) leaf = kRocsolverStedcMaxN;
         std::vector<int> perm;
         rocblas_status rs = rocblas_status_success;
+        // Several ranks on the two-stage path: the replicated stages (band reduction -- its collectives hand every rank the
+        // same bits --, bulge chasing) must have produced the SAME tridiagonal matrix everywhere before anything is shared out:
+        // its (d, e) are hashed and compared over the ranks.  When they agree, the divide and conquer's top-level merge forms
+        // only the eigenvector columns this rank back-transforms (JXGPU_DIST_DC_WINDOW=0: all of them) and Q2 / Q1 run on that
+        // block; when they differ every rank finishes its own replica unsharded (self-consistent, only slower).
+        bool replicas_agree = true;
+        g_last_dist_agree = -1;
+        if (twostage && dist_two && split && g_gather.agree) {
+            std::vector<double> hw((size_t)2 * n, 0.0);
+            JX_HIP(hipMemcpyAsync(hw.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+            JX_HIP(hipMemcpyAsync(hw.data() + n, e.p, sizeof(double) * (size_t)(n - 1), hipMemcpyDeviceToHost, st));
+            JX_HIP(hipStreamSynchronize(st));
+            const uint64_t cs = fnv1a(hw.data(), sizeof(double) * hw.size(), 1469598103934665603ull);
+            const int ag = g_gather.agree(g_gather.agree_user, cs);
+            if (ag < 0) return fail("jxg_eigh_f64: the agreement callback failed");
+            replicas_agree = ag != 0;
+            g_last_dist_agree = replicas_agree ? 1 : 0;
+            if (!replicas_agree && trace)
+                fprintf(stderr, "[jxgpu eigh n=%d] the ranks' tridiagonal matrices differ: every rank finishes its own replica\n", n);
+        }
+        const bool shard_cols = twostage && dist_two && split && replicas_agree;
+        const int sh_r0 = (int)((int64_t)n * drank / dworld), sh_r1 = (int)((int64_t)n * (drank + 1) / dworld);
+        static const bool dc_window = !(getenv("JXGPU_DIST_DC_WINDOW") && atoi(getenv("JXGPU_DIST_DC_WINDOW")) == 0);
+        const bool dc_windowed = shard_cols && dc_window && sh_r1 > sh_r0;
+        g_last_dc_windowed = (dc_windowed && split) ? 1 : 0;
         if (split) {
-            if (stedc_split(h, st, n, d_w, e.as<double>(), c.as<double>(), leaf, perm)) return 1;
+            if (stedc_split(h, st, n, d_w, e.as<double>(), c.as<double>(), leaf, perm, dc_windowed ? sh_r0 : 0,
+                            dc_windowed ? sh_r1 : 0))
+                return 1;
         } else {
             rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
                                   info.as<rocblas_int>());
@@ -307,32 +359,18 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (twostage) {
             if (!ts_tq.p && ts_tq.alloc(sizeof(double) * sbback_tq_doubles(n, ks))) return 1;
             const int ncol = n - sy2sb_bandwidth() - 1;
-            bool replicas_agree = true;
-            g_last_dist_agree = -1;
-            if (dist_two && split && g_gather.agree) {
-                std::vector<double> hw((size_t)2 * n);
-                JX_HIP(hipMemcpyAsync(hw.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-                JX_HIP(hipMemcpyAsync(hw.data() + n, c.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-                JX_HIP(hipStreamSynchronize(st));
-                uint64_t cs = fnv1a(hw.data(), sizeof(double) * hw.size(), 1469598103934665603ull);
-                cs = fnv1a(perm.data(), sizeof(int) * perm.size(), cs);
-                const int ag = g_gather.agree(g_gather.agree_user, cs);
-                if (ag < 0) return fail("jxg_eigh_f64: the agreement callback failed");
-                replicas_agree = ag != 0;
-                g_last_dist_agree = replicas_agree ? 1 : 0;
-                if (!replicas_agree && trace)
-                    fprintf(stderr, "[jxgpu eigh n=%d] the ranks' replicated results differ: unsharded back-transformation\n", n);
-            }
-            if (dist_two && split && replicas_agree) {
-                // this rank's eigenvectors only: columns perm[r0 .. r1) of C, gathered into a contiguous (n, nr) block
-                const int r0 = (int)((int64_t)n * drank / dworld), r1 = (int)((int64_t)n * (drank + 1) / dworld);
+            if (shard_cols) {
+                // this rank's eigenvectors only: columns perm[r0 .. r1) of C (the window's own column list when the divide
+                // and conquer formed nothing else), gathered into a contiguous (n, nr) block
+                const int r0 = sh_r0, r1 = sh_r1;
                 const int nr = r1 - r0;
+                const int poff = dc_windowed ? 0 : r0;
                 q2_cols = nr;
                 DevBuf dperm, blk;
-                if (dperm.alloc(sizeof(int) * (size_t)n)) return 1;
+                if (dperm.alloc(sizeof(int) * (size_t)(perm.size() + 1))) return 1;
                 if (blk.alloc(sizeof(double) * (size_t)n * (size_t)(nr > 0 ? nr : 1))) return 1;
-                JX_HIP(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
-                if (launch_gather_cols_range(c.as<double>(), dperm.as<int>() + r0, n, nr, blk.as<double>(), st)) return 1;
+                JX_HIP(hipMemcpyAsync(dperm.p, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, st));
+                if (launch_gather_cols_range(c.as<double>(), dperm.as<int>() + poff, n, nr, blk.as<double>(), st)) return 1;
                 if (sbback_apply_q2(st, ts_v2.as<double>(), ts_tau2.as<double>(), n, ks, blk.as<double>(), nr,
                                     ts_tq.as<double>(), ev[6], ev[7]))
                     return 1;

@@ -402,12 +402,15 @@ __global__ __launch_bounds__(SD_THREADS) void sd_form_u_kernel(const double *__r
                                                                const int *__restrict__ org,
                                                                const double *__restrict__ invn,
                                                                const int *__restrict__ rowmap, int nrows, int K,
-                                                               double *__restrict__ u, int64_t ldu) {
+                                                               double *__restrict__ u, int64_t ldu,
+                                                               const int *__restrict__ colsel) {
+    // colsel (optional): output column y = root colsel[y] (K = number of selected roots)
     const int r = blockIdx.x * SD_THREADS + threadIdx.x;
-    const int i = blockIdx.y;
-    if (r >= nrows || i >= K) return;
+    const int y = blockIdx.y;
+    if (r >= nrows || y >= K) return;
+    const int i = colsel ? colsel[y] : y;
     const int j = rowmap[r];
-    u[(int64_t)i * ldu + r] = zhat[j] / ((d[j] - d[org[i]]) - tau[i]) * invn[i];
+    u[(int64_t)y * ldu + r] = zhat[j] / ((d[j] - d[org[i]]) - tau[i]) * invn[i];
 }
 
 // columns x <- c x + s y ; y <- -s x + c y   (drot on two columns of length n)
@@ -459,6 +462,12 @@ struct DcCtx {
     int depth = 0;      // recursion depth of the current call
     int par_depth = 0;  // the two halves of a problem run concurrently (own host thread, stream, handle) above it
     int device = 0;
+    // Column window of the ROOT problem (several ranks: a rank back-transforms the eigenvectors [sel_lo, sel_hi) only): the
+    // top-level merge -- three quarters of the divide and conquer's product flops -- then forms and multiplies only the
+    // columns whose eigenvalues rank inside the window; sel_cols[t] = column of d_c that holds the (sel_lo + t)-th smallest
+    // eigenvalue on return.  sel_hi <= sel_lo: all columns (sel_cols stays empty).
+    int sel_lo = 0, sel_hi = 0;
+    std::vector<int> sel_cols;
     // own leaf solver (sd_leaf_ql_kernel): every leaf of the tree is solved by one batched launch before the recursion
     bool own_leaf = false;
     const std::vector<int> *leaf_off = nullptr;     // ascending global offsets of the leaves
@@ -804,6 +813,39 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
     for (int r = 0; r < K; ++r) w[r] = lam[r];
     for (size_t r = 0; r < defl.size(); ++r) w[K + r] = D[defl[r]];
 
+    // ---- column window of the root problem (DcCtx::sel_lo / sel_hi): only the columns whose eigenvalues rank inside it ------
+    const bool windowed = C.depth == 0 && C.sel_hi > C.sel_lo;
+    int Kout = K;                                   // root columns this call forms (all of them without a window)
+    std::vector<int> root_sel;                      // selected roots, ascending (windowed)
+    std::vector<int> defl_dst(defl.size());         // destination column of a deflated vector, -1 = not wanted
+    for (size_t r = 0; r < defl.size(); ++r) defl_dst[r] = K + (int)r;
+    ABuf dcolsel;
+    if (windowed) {
+        std::vector<int> order((size_t)n);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return w[a] < w[b] || (w[a] == w[b] && a < b); });
+        std::vector<int> pos((size_t)n, -1);        // full-layout column -> compact column
+        std::vector<char> want((size_t)n, 0);
+        for (int t = C.sel_lo; t < C.sel_hi; ++t) want[order[t]] = 1;
+        int at = 0;
+        for (int c = 0; c < K; ++c)
+            if (want[c]) {
+                root_sel.push_back(c);
+                pos[c] = at++;
+            }
+        Kout = at;
+        for (size_t r = 0; r < defl.size(); ++r) {
+            defl_dst[r] = want[K + r] ? at : -1;
+            if (want[K + r]) pos[K + r] = at++;
+        }
+        C.sel_cols.resize((size_t)(C.sel_hi - C.sel_lo));
+        for (int t = C.sel_lo; t < C.sel_hi; ++t) C.sel_cols[t - C.sel_lo] = pos[order[t]];
+        if (Kout > 0) {
+            SD_TAKE(dcolsel, sizeof(int) * (size_t)Kout);
+            JX_HIP(hipMemcpyAsync(dcolsel.p, C.stage(root_sel), sizeof(int) * (size_t)Kout, hipMemcpyHostToDevice, st));
+        }
+    }
+
     // ---- eigenvectors: C[:, 0:K] = [Q1(:,S1) U1 ; Q2(:,S2) U2] + Side(:,Sm) Um ; deflated columns copied -----
     std::vector<int> rows1, rows2, rowsm;      // kept-list positions by where the column lives
     std::vector<int> c1, c2, cm;               // and the column index inside that storage
@@ -818,7 +860,8 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         std::vector<int> s0, t0, s1, t1, s2, t2;
         for (size_t r = 0; r < defl.size(); ++r) {
             const Loc l = loc[defl[r]];
-            const int dstc = K + (int)r;
+            const int dstc = defl_dst[r];
+            if (dstc < 0) continue;                     // outside the column window
             if (l.kind == 0) { s0.push_back(l.idx); t0.push_back(dstc); }
             else if (l.kind == 1) { s1.push_back(l.idx); t1.push_back(dstc); }
             else { s2.push_back(l.idx); t2.push_back(dstc); }
@@ -840,7 +883,7 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
         if (place(s1, t1, q2.as<double>(), k2, k2, k1)) return 1;
         if (place(s2, t2, side.as<double>(), n, n, 0)) return 1;
     }
-    if (K > 0) {
+    if (K > 0 && Kout > 0) {
         // the kept columns of Q1 / Q2 as contiguous blocks: in place when nothing was deflated there, else one
         // gather launch into the arena
         auto compact = [&](std::vector<int> &rows, std::vector<int> &cols, double *&q, int len) -> int {
@@ -881,31 +924,31 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
             if (nr == 0) {
                 if (beta == 0.0)     // nothing of this block survives: its rows of the root columns are zero
                     JX_HIP(hipMemset2DAsync(cdst, sizeof(double) * (size_t)n, 0, sizeof(double) * (size_t)qrows,
-                                            (size_t)K, st));
+                                            (size_t)Kout, st));
                 return 0;
             }
             const size_t gmark = C.ar.off;
             ABuf u, rm;
-            SD_TAKE(u, sizeof(double) * (size_t)nr * K);
+            SD_TAKE(u, sizeof(double) * (size_t)nr * Kout);
             SD_TAKE(rm, sizeof(int) * (size_t)nr);
             JX_HIP(hipMemcpyAsync(rm.p, C.stage(rows), sizeof(int) * (size_t)nr, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(sd_form_u_kernel, dim3((nr + SD_THREADS - 1) / SD_THREADS, K), dim3(SD_THREADS), 0, st,
+            hipLaunchKernelGGL(sd_form_u_kernel, dim3((nr + SD_THREADS - 1) / SD_THREADS, Kout), dim3(SD_THREADS), 0, st,
                                dk.as<double>(), dzh.as<double>(), dtau.as<double>(), dorg.as<int>(), dinv.as<double>(),
-                               rm.as<int>(), nr, K, u.as<double>(), (int64_t)nr);
+                               rm.as<int>(), nr, Kout, u.as<double>(), (int64_t)nr, windowed ? dcolsel.as<int>() : (const int *)nullptr);
             JX_LAUNCH_CHECK();
             // C (qrows x K) = Q (qrows x nr) U (nr x K) + beta C: on the int8 matrix pipes (k_ozgemm.hip) when the product is
             // large enough to pay for slicing its operands, else the own f64 MFMA GEMM.  No vendor GEMM (rounds 1 - 3: rocBLAS).
-            if (sd_use_oz(qrows, K, nr)) {
+            if (sd_use_oz(qrows, Kout, nr)) {
                 ABuf img;
                 static const int pl = getenv("JXGPU_STEDC_OZ_PLANES") ? std::min(6, std::max(4, atoi(getenv("JXGPU_STEDC_OZ_PLANES")))) : 0;
-                const size_t ba = oz_image_bytes(qrows, nr, pl), bb = oz_image_bytes(K, nr, pl);
+                const size_t ba = oz_image_bytes(qrows, nr, pl), bb = oz_image_bytes(Kout, nr, pl);
                 SD_TAKE(img, ba + bb);
-                OzImage ia = oz_image_at(img.p, qrows, nr, pl), ib = oz_image_at(img.as<char>() + ba, K, nr, pl);
+                OzImage ia = oz_image_at(img.p, qrows, nr, pl), ib = oz_image_at(img.as<char>() + ba, Kout, nr, pl);
                 if (oz_slice(st, q, 1, ldq, ia)) return 1;                       // element (r, k) = q[r + k ldq]
                 if (oz_slice(st, u.as<double>(), nr, 1, ib)) return 1;           // element (j, k) = u[k + j nr]
-                if (oz_mm(st, ia, ib, qrows, K, one, beta, cdst, n, 0)) return 1;
+                if (oz_mm(st, ia, ib, qrows, Kout, one, beta, cdst, n, 0)) return 1;
             } else {
-                if (dgemm(st, false, false, qrows, K, nr, one, q, ldq, u.as<double>(), nr, beta, cdst, n, 1, nullptr, 0)) return 1;
+                if (dgemm(st, false, false, qrows, Kout, nr, one, q, ldq, u.as<double>(), nr, beta, cdst, n, 1, nullptr, 0)) return 1;
             }
             C.ar.off = gmark;   // stream order protects the reuse
             return 0;
@@ -932,8 +975,10 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
 // d_d (n), d_e (n-1): tridiagonal T (both overwritten).  d_c: (n,n) column-major, receives the eigenvectors of T as
 // columns in the order given by h_perm (h_perm[r] = column holding the r-th smallest eigenvalue); d_d receives the
 // eigenvalues ascending.  leaf: largest problem handed to rocSOLVER's dstedc.
+// sel_lo < sel_hi (several ranks): only the columns of the eigenvalues ranked [sel_lo, sel_hi) are formed by the top-level
+// merge; h_perm then has sel_hi - sel_lo entries, h_perm[t] = column of d_c holding the (sel_lo + t)-th smallest eigenvalue.
 int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_e, double *d_c, int leaf,
-                std::vector<int> &h_perm) {
+                std::vector<int> &h_perm, int sel_lo, int sel_hi) {
     std::vector<double> hd((size_t)n), he((size_t)n);
     JX_HIP(hipMemcpyAsync(hd.data(), d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
     JX_HIP(hipMemcpyAsync(he.data(), d_e, sizeof(double) * (size_t)(n - 1), hipMemcpyDeviceToHost, st));
@@ -1035,12 +1080,22 @@ int stedc_split(rocblas_handle h, hipStream_t st, int n, double *d_d, double *d_
         C.hleaf_w = hleaf_w.data();
     }
     std::vector<double> w;
+    const bool windowed = sel_hi > sel_lo && sel_lo >= 0 && sel_hi <= n;
+    if (windowed) {
+        C.sel_lo = sel_lo;
+        C.sel_hi = sel_hi;
+    }
     if (stedc_dc(C, n, d_d, d_e, d_c, w)) return 1;
     h_perm.resize((size_t)n);
     std::iota(h_perm.begin(), h_perm.end(), 0);
     std::sort(h_perm.begin(), h_perm.end(), [&](int a, int b) { return w[a] < w[b] || (w[a] == w[b] && a < b); });
     std::vector<double> ws((size_t)n);
     for (int r = 0; r < n; ++r) ws[r] = w[h_perm[r]];
+    if (windowed) {
+        // the root problem was a leaf or had nothing to merge (sel_cols empty): the full layout stands, take its window
+        if (C.sel_cols.empty()) h_perm.assign(h_perm.begin() + sel_lo, h_perm.begin() + sel_hi);
+        else h_perm = C.sel_cols;
+    }
     JX_HIP(hipMemcpyAsync(d_d, ws.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
     JX_HIP(hipStreamSynchronize(st));
     return 0;

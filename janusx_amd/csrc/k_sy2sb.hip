@@ -13,6 +13,8 @@
 // one-stage reduction (k_sytrd.hip).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -539,6 +541,51 @@ constexpr size_t SB_WS = (size_t)7 << 20;   // split-K workspace of one launch c
 size_t sy2sb_work_doubles(int n) { return (size_t)n * 8 * SB + 12 * SB * SB + 64 + 2 * SB_WS; }
 int sy2sb_bandwidth() { return SB; }
 
+// ---- trailing matrix sharded over ranks (jxg_eigh_set_band_dist) --------------------------------------------------------
+// Ownership by ABSOLUTE block rows of `block` samples, dealt cyclically: rank r keeps the lower-triangle entries of the rows
+// [b block, (b + 1) block), b mod world == r, current and never reads anybody else's.  Per panel two collectives through
+// `allreduce(user, count)` on the staging buffer (sum over the ranks of its first `count` doubles, on the eigensolver's stream):
+//   (1) Z = A22 V as partial sums over the owned block rows (rectangle left of the diagonal block from both sides + the
+//       diagonal block) into a zeroed n x 64 buffer: the sum is the same bits on every rank, and everything derived from it
+//       (M, W, the next panel's factorisation chain) is replicated arithmetic on identical inputs;
+//   (2) the block column of the NEXT panel, updated by the owners of its rows, gathered as a sum with zeros and written back on
+//       every rank (it also holds the reflectors the Q1 back-transformation reads later).
+// The rest of the rank-2k update touches owned rows only.  From a trailing size <= 2 `block` on the trailing square is gathered
+// once and the last panels run replicated.
+struct BandDist {
+    int rank = 0, world = 1;
+    int (*allreduce)(void *, int64_t) = nullptr;
+    void *user = nullptr;
+    double *staging = nullptr;
+    int64_t staging_doubles = 0;
+    int min_n = 8192;
+    int block = 2048;
+};
+static BandDist g_band;
+
+int sy2sb_set_band_dist(int rank, int world, int (*allreduce)(void *, int64_t), void *user, double *staging,
+                        int64_t staging_doubles, int min_n, int block) {
+    if (world < 1 || rank < 0 || rank >= world) return fail("sy2sb_set_band_dist: bad rank / world");
+    g_band.rank = rank;
+    g_band.world = world;
+    g_band.allreduce = allreduce;
+    g_band.user = user;
+    g_band.staging = staging;
+    g_band.staging_doubles = staging_doubles;
+    g_band.min_n = min_n > 0 ? min_n : 8192;
+    g_band.block = block >= 2 * SB ? (block / SB) * SB : 2048;
+    return 0;
+}
+int64_t sy2sb_band_staging_doubles(int n) {
+    const int64_t b = g_band.block + 2 * SB;
+    return std::max<int64_t>((int64_t)n * SB, (2 * b) * (2 * b));
+}
+int sy2sb_band_dist_active(int n) {
+    const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
+    return ((g_band.world > 1 || force_single) && g_band.allreduce && n >= g_band.min_n &&
+            g_band.staging_doubles >= sy2sb_band_staging_doubles(n)) ? 1 : 0;
+}
+
 // d_a (n x n, column-major, symmetric, lower referenced) -> band form in place (V below the band, see above);
 // d_tau (n): tau of every stage-1 reflector (0 beyond the last eliminated column); d_ab (ldab x n): band copy for
 // stage 2.  d_flags[0] != 0 on return (after the caller's synchronisation) means a panel could not be factored.
@@ -547,7 +594,7 @@ int sy2sb_bandwidth() { return SB; }
 // rest; the factorisation chain of panel p + 1 (~15 small launches, latency-bound) then runs on a side stream beside the
 // rest of the update, which is what fills the chip.  Panel buffers, T and the zero-panel flag alternate by panel parity.
 int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab, int ldab, double *d_work,
-                int *d_flags) {
+                int *d_flags, bool allow_shard) {
     const int ncol = n - SB - 1;                     // columns with entries below the band
     JX_HIP(hipMemsetAsync(d_tau, 0, sizeof(double) * (size_t)n, st));
     JX_HIP(hipMemsetAsync(d_flags, 0, sizeof(int) * 4, st));
@@ -610,6 +657,24 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             }
             return 0;
         };
+        // ---- sharded trailing matrix (BandDist above) ---------------------------------------------------------------
+        bool sharded = allow_shard && sy2sb_band_dist_active(n) != 0;
+        const int BR = g_band.block;
+        // owned block rows of the trailing matrix that starts at absolute row s0, in trailing coordinates, rows >= lo only
+        auto for_owned = [&](int s0, int lo, auto &&fn) -> int {
+            for (int b = s0 / BR; (int64_t)b * BR < n; ++b) {
+                if (b % g_band.world != g_band.rank) continue;
+                const int a0 = std::max(b * BR, s0 + lo), a1 = std::min((b + 1) * BR, n);
+                if (a1 <= a0) continue;
+                if (fn(a0 - s0, a1 - a0)) return 1;
+            }
+            return 0;
+        };
+        auto reduce_staging = [&](int64_t count) -> int {
+            if (count > g_band.staging_doubles) return fail("sy2sb: staging buffer of the band collectives too small");
+            if (g_band.allreduce(g_band.user, count)) return fail("sy2sb: the all-reduce callback failed");
+            return 0;
+        };
         if (panel_qr(st, 0, 0, ws_main)) return 1;
         int par = 0;
         for (int j0 = 0; j0 < ncol; j0 += SB, par ^= 1) {
@@ -619,6 +684,21 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             double *zc = pan[par], *v1 = pan[par] + (size_t)SB * ld, *wc = pan[par] + (size_t)2 * SB * ld;
             const bool has_next = j0 + SB < ncol;
             if (j0 > 0 && lookahead) JX_HIP(hipStreamWaitEvent(st, ev_qr[par], 0));     // this panel's chain ran on the side stream
+            if (sharded && nt <= 2 * BR) {
+                // the last panels run replicated: one gather of the trailing square (owners' rows, zeros elsewhere, summed)
+                double *stg = g_band.staging;
+                JX_HIP(hipMemsetAsync(stg, 0, sizeof(double) * (size_t)nt * nt, st));
+                if (for_owned(j0 + SB, 0, [&](int r0, int rl) -> int {
+                        JX_HIP(hipMemcpy2DAsync(stg + r0, sizeof(double) * (size_t)nt, a22 + r0, sizeof(double) * (size_t)ld,
+                                                sizeof(double) * (size_t)rl, (size_t)(r0 + rl), hipMemcpyDeviceToDevice, st));
+                        return 0;
+                    }))
+                    return 1;
+                if (reduce_staging((int64_t)nt * nt)) return 1;
+                JX_HIP(hipMemcpy2DAsync(a22, sizeof(double) * (size_t)ld, stg, sizeof(double) * (size_t)nt,
+                                        sizeof(double) * (size_t)nt, (size_t)nt, hipMemcpyDeviceToDevice, st));
+                sharded = false;
+            }
             if (pw < SB) {
                 // last, narrower panel: the columns j0 + pw .. j0 + SB - 1 of the block row see Q' from the left only
                 const int nc = SB - pw;
@@ -628,7 +708,24 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
                 if (dgemm(st, false, false, nt, nc, pw, -1.0, v1, ld, tmp2, SB, 1.0, cb, ld, 1, nullptr, 0)) return 1;
             }
             // two-sided update of the trailing matrix
-            if (dsymm_lower(st, nt, pw, 1.0, a22, ld, v1, ld, 0.0, zc, ld, ws_main, SB_WS)) return 1;
+            if (!sharded) {
+                if (dsymm_lower(st, nt, pw, 1.0, a22, ld, v1, ld, 0.0, zc, ld, ws_main, SB_WS)) return 1;
+            } else {
+                // Z = A22 V from the owned block rows: the rectangle left of the diagonal block acts from both sides
+                JX_HIP(hipMemsetAsync(zc, 0, sizeof(double) * (size_t)ld * SB, st));
+                if (for_owned(j0 + SB, 0, [&](int r0, int rl) -> int {
+                        if (r0 > 0) {
+                            if (dgemm(st, false, false, rl, pw, r0, 1.0, a22 + r0, ld, v1, ld, 1.0, zc + r0, ld, 0, ws_main, SB_WS)) return 1;
+                            if (dgemm(st, true, false, r0, pw, rl, 1.0, a22 + r0, ld, v1 + r0, ld, 1.0, zc, ld, 0, ws_main, SB_WS)) return 1;
+                        }
+                        return dsymm_lower(st, rl, pw, 1.0, a22 + r0 + (int64_t)r0 * ld, ld, v1 + r0, ld, 1.0, zc + r0, ld, ws_main, SB_WS);
+                    }))
+                    return 1;
+                const int64_t cnt = (int64_t)(pw - 1) * ld + nt;
+                JX_HIP(hipMemcpyAsync(g_band.staging, zc, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, st));
+                if (reduce_staging(cnt)) return 1;
+                JX_HIP(hipMemcpyAsync(zc, g_band.staging, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, st));
+            }
             if (dgemm(st, true, false, pw, pw, nt, 1.0, v1, ld, zc, ld, 0.0, gu, SB, 0, ws_main, SB_WS)) return 1;
             hipLaunchKernelGGL(sb_tm_kernel, dim3(1), dim3(256), 0, st, tmat[par], gu, pw, tm);
             JX_LAUNCH_CHECK();
@@ -636,7 +733,23 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
             if (has_next) {
                 // block column of the next panel first: A22[:, 0:SB] -= [V | W] ([W | V][0:SB, :])'
                 const int nb = SB;                                      // has_next => nt > SB
-                if (dgemm(st, false, true, nt, nb, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld, 1, nullptr, 0)) return 1;
+                if (!sharded) {
+                    if (dgemm(st, false, true, nt, nb, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld, 1, nullptr, 0)) return 1;
+                } else {
+                    // owners update their rows of the block column; gathered (sum with zeros) and written back everywhere
+                    double *stg = g_band.staging;
+                    JX_HIP(hipMemsetAsync(stg, 0, sizeof(double) * (size_t)nt * nb, st));
+                    if (for_owned(j0 + SB, 0, [&](int r0, int rl) -> int {
+                            if (dgemm(st, false, true, rl, nb, 2 * SB, -1.0, v1 + r0, ld, wc, ld, 1.0, a22 + r0, ld, 1, nullptr, 0)) return 1;
+                            JX_HIP(hipMemcpy2DAsync(stg + r0, sizeof(double) * (size_t)nt, a22 + r0, sizeof(double) * (size_t)ld,
+                                                    sizeof(double) * (size_t)rl, (size_t)nb, hipMemcpyDeviceToDevice, st));
+                            return 0;
+                        }))
+                        return 1;
+                    if (reduce_staging((int64_t)nt * nb)) return 1;
+                    JX_HIP(hipMemcpy2DAsync(a22, sizeof(double) * (size_t)ld, stg, sizeof(double) * (size_t)nt,
+                                            sizeof(double) * (size_t)nt, (size_t)nb, hipMemcpyDeviceToDevice, st));
+                }
                 if (lookahead) {
                     JX_HIP(hipEventRecord(ev_a[par], st));
                     JX_HIP(hipStreamWaitEvent(side, ev_a[par], 0));
@@ -644,8 +757,21 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
                     JX_HIP(hipEventRecord(ev_qr[par ^ 1], side));
                 }
                 // the rest of the trailing update runs beside that chain
-                if (dsyr2k_lower_nt(st, nt - nb, 2 * SB, -1.0, v1 + nb, ld, wc + nb, ld, 1.0, a22 + nb + (int64_t)nb * ld, ld))
+                if (!sharded) {
+                    if (dsyr2k_lower_nt(st, nt - nb, 2 * SB, -1.0, v1 + nb, ld, wc + nb, ld, 1.0, a22 + nb + (int64_t)nb * ld, ld))
+                        return 1;
+                } else if (for_owned(j0 + SB, nb, [&](int r0, int rl) -> int {
+                               // owned rows only: the rectangle between the next panel's block column and the diagonal block, then
+                               // the diagonal block
+                               if (r0 > nb &&
+                                   dgemm(st, false, true, rl, r0 - nb, 2 * SB, -1.0, v1 + r0, ld, wc + nb, ld, 1.0,
+                                         a22 + r0 + (int64_t)nb * ld, ld, 1, nullptr, 0))
+                                   return 1;
+                               return dsyr2k_lower_nt(st, rl, 2 * SB, -1.0, v1 + r0, ld, wc + r0, ld, 1.0,
+                                                      a22 + r0 + (int64_t)r0 * ld, ld);
+                           })) {
                     return 1;
+                }
                 if (!lookahead && panel_qr(st, j0 + SB, par ^ 1, ws_main)) return 1;
             } else {
                 if (dsyr2k_lower_nt(st, nt, 2 * SB, -1.0, v1, ld, wc, ld, 1.0, a22, ld)) return 1;

@@ -196,6 +196,7 @@ def enable_distributed_eigh(min_n: int = 0):
         check(lib().jxg_eigh_set_dist(0, 1, None, None, None, 0, 0))
         check(lib().jxg_eigh_set_gather(None, None))
         check(lib().jxg_eigh_set_agree(None, None))
+        check(lib().jxg_eigh_set_band_dist(0, 1, None, None, None, 0, 0, 0))
         _DIST_EIGH.clear()
         return False
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -256,14 +257,45 @@ def enable_distributed_eigh(min_n: int = 0):
     acb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)(_agree)
     check(lib().jxg_eigh_set_agree(C.cast(acb, C.c_void_p) if world > 1 else None, None))
 
+    def _band(_user, count):
+        # band reduction with the trailing matrix sharded over the ranks (k_sy2sb.hip): per panel the partial products Z = A22 V
+        # and the gather of the next panel's block column are summed over the ranks (RCCL over xGMI with nccl, on the stream
+        # the eigensolver runs on)
+        try:
+            t = state["band_staging"][: int(count)]
+            if world > 1:
+                allreduce_sum_(t)
+            elif dist.get_backend() == "nccl":
+                dist.all_reduce(t)      # one-rank run of the same code path (JXGPU_DIST_EIGH_FORCE): the RCCL call itself
+            return 0
+        except Exception as e:   # noqa: BLE001 - reported through the C status
+            import sys
+            print(f"distributed eigh: band all-reduce failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1
+
+    bcb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64)(_band)
+    band_on = os.environ.get("JXGPU_DIST_BAND", "1") != "0"
+    band_min_n = int(os.environ.get("JXGPU_DIST_BAND_MIN_N", "8192"))
+    band_block = int(os.environ.get("JXGPU_DIST_BAND_BLOCK", "2048"))
+
     def prepare(n):
         need = int(lib().jxg_eigh_dist_staging_doubles(int(n)))
         if state["staging"] is None or state["staging"].numel() != need:
             state["staging"] = torch.zeros(need, dtype=torch.float64, device=dev)
             check(lib().jxg_eigh_set_dist(rank, world, C.cast(cb, C.c_void_p), None, _ptr(state["staging"]), need,
                                           int(min_n)))
+        if band_on and int(n) >= band_min_n:
+            # block size first (it sizes the staging buffer), then the buffer itself
+            check(lib().jxg_eigh_set_band_dist(rank, world, None, None, None, 0, band_min_n, band_block))
+            bneed = int(lib().jxg_eigh_band_staging_doubles(int(n)))
+            if state.get("band_staging") is None or state["band_staging"].numel() < bneed:
+                state["band_staging"] = torch.zeros(bneed, dtype=torch.float64, device=dev)
+            check(lib().jxg_eigh_set_band_dist(rank, world, C.cast(bcb, C.c_void_p), None, _ptr(state["band_staging"]),
+                                               int(state["band_staging"].numel()), band_min_n, band_block))
+        else:
+            check(lib().jxg_eigh_set_band_dist(rank, world, None, None, None, 0, band_min_n, band_block))
 
-    _DIST_EIGH.update(cb=cb, gcb=gcb, acb=acb, state=state, prepare=prepare)
+    _DIST_EIGH.update(cb=cb, gcb=gcb, acb=acb, bcb=bcb, state=state, prepare=prepare)
     return True
 
 

@@ -45,12 +45,14 @@ def main():
     digest = torch.tensor([float(np.frombuffer(wh.tobytes(), dtype=np.uint64).sum() % (1 << 52)),
                            float(np.frombuffer(uh.tobytes(), dtype=np.uint64).sum() % (1 << 52))],
                           dtype=torch.float64)
+    if backend == "nccl":
+        digest = digest.to(dev)
     lo, hi = digest.clone(), digest.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     same = bool((lo == hi).all())
     ok = eval_err < 1e-11 and resid < 1e-11 and orth < 1e-11 and same
-    flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64)
+    flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else None)
     dist.all_reduce(flag)
     if rank == 0:
         from janusx_amd._lib import lib
@@ -58,7 +60,8 @@ def main():
         # agree: the replicas' checksum comparison in front of the sharded back-transformations of the two-stage path
         # (-1 not run, 1 agreed, 0 differed -> unsharded fallback; JXGPU_DIST_EIGH_TEST_DISAGREE=<rank> forces a difference)
         print(f"{tag} n={n} world={world} eval_err={eval_err:.2e} resid={resid:.2e} orth={orth:.2e} "
-              f"replicas_identical={same} agree={int(lib().jxg_eigh_last_dist_agree())}", flush=True)
+              f"replicas_identical={same} agree={int(lib().jxg_eigh_last_dist_agree())} "
+              f"band_sharded={int(lib().jxg_eigh_last_band_sharded())} dc_windowed={int(lib().jxg_eigh_last_dc_windowed())}", flush=True)
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 0 else 1)
 

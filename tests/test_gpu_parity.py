@@ -1992,12 +1992,25 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "replicas_identical=True" in out.stdout
     assert "agree=1" in out.stdout        # the replicas' checksums were compared (and matched) before rows were mixed
+    assert "dc_windowed=1" in out.stdout  # ... and the top-level merge of the divide and conquer formed each rank's columns only
     # a rank whose replicated results differ (forced through the test hook): every rank must notice and back-transform
     # all its eigenvectors itself instead of mixing rows of different bases -- still a correct decomposition everywhere
     env3 = dict(env2, JXGPU_DIST_EIGH_TEST_DISAGREE="1")
     out = subprocess.run(cmd, env=env3, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "agree=0" in out.stdout
+    # the band reduction with the trailing matrix SHARDED over the two ranks (k_sy2sb.hip BandDist; the default from n = 8192):
+    # block rows of 256 samples dealt cyclically, per panel the all-reduce of the partial products Z = A22 V and the gather of
+    # the next panel's block column, the last panels replicated after one gather of the trailing square; the ranks' results
+    # stay bit-identical (everything replicated is computed from collective results) and meet the same invariants
+    env4 = dict(env2, JXGPU_DIST_BAND_MIN_N="1000", JXGPU_DIST_BAND_BLOCK="256")
+    for nn in ("2300", "3001"):
+        cmd[-1] = nn
+        out = subprocess.run(cmd, env=env4, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+        assert f"DIST_EIGH_OK n={nn} world=2" in out.stdout and "replicas_identical=True" in out.stdout
+        assert "band_sharded=1" in out.stdout and "agree=1" in out.stdout
+    cmd[-1] = "2300"
 
 
 @pytest.mark.gpu
@@ -2045,6 +2058,30 @@ def test_distributed_eigh_rccl_callback_single_rank():
     assert "eigh symv tiles sharded" not in res["0"]["config"]["parallelism"]
     assert abs(res["1"]["null"]["lbd"] - res["0"]["null"]["lbd"]) <= 1e-6 * res["0"]["null"]["lbd"]
     assert res["1"]["config"]["m_kept"] == res["0"]["config"]["m_kept"]
+
+
+@pytest.mark.gpu
+def test_sharded_band_reduction_rccl_single_rank():
+    """The two collectives per panel of the sharded band reduction (k_sy2sb.hip BandDist) through RCCL (nccl backend) with ONE
+    rank: JXGPU_DIST_EIGH_FORCE runs the sharded launch sequence (every block row owned: partial products per block row,
+    staging copies, ncclAllReduce through the torch callback on the eigensolver's stream, gather of the next panel's block
+    column, replicated tail) on the one-GPU box; scripts/dist_eigh_check.py checks the eigen-invariants against LAPACK."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="nccl", JXGPU_EIGH="twostage", JXGPU_DIST_EIGH_FORCE="1",
+               JXGPU_DIST_BAND_MIN_N="1000", JXGPU_DIST_BAND_BLOCK="256", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "dist_eigh_check.py"), "2300"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_OK n=2300 world=1" in out.stdout and "band_sharded=1" in out.stdout
 
 
 def _related_panel(n, m, seed, missing_rate):

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -49,6 +50,12 @@ int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, in
 extern float g_last_ms[16];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
                               // [8] divide and conquer ms, [9] Q1 back-transformation ms, [10] 1 = two-stage path taken
 int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols);
+// the C-independent part of the Q1 back-transformation (V images, Gram, T, V T per block) prepared ahead on a side stream
+struct OrmtrPlan;
+OrmtrPlan *ormtr_plan_new();
+void ormtr_plan_free(OrmtrPlan *p);
+int ormtr_prepare(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, OrmtrPlan &plan);
+int ormtr_apply(hipStream_t st, const OrmtrPlan &plan, double *d_c, int ncols);
 int sytrd_dist_active(int n);
 void sytrd_dist_rank(int *rank, int *world);
 int launch_gather_cols_range(const double *src, const int *d_perm, int n, int count, double *dst, hipStream_t st);
@@ -300,6 +307,34 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 if (stage_done("sb2st")) return 1;
             }
         }
+        // Q1 back-transformation, C-independent part (reflector images, Gram, T^-1, V T of every block: ~40 of its 210 ms at
+        // n = 20 000): enqueued NOW on a stream of its own, so it runs in the gaps of the divide and conquer (host-driven, many
+        // small launches); the application behind Q2 then only waits for its event.  JXGPU_Q1_AHEAD=0: in line.
+        static hipStream_t q1_side = nullptr;
+        static hipEvent_t q1_go = nullptr, q1_done = nullptr;
+        static const bool q1_ahead = !(getenv("JXGPU_Q1_AHEAD") && atoi(getenv("JXGPU_Q1_AHEAD")) == 0);
+        auto q1_free = [](OrmtrPlan *p) {
+            if (q1_side) (void)hipStreamSynchronize(q1_side);   // nothing of the plan may still be in flight
+            ormtr_plan_free(p);
+        };
+        std::unique_ptr<OrmtrPlan, decltype(q1_free)> q1_plan(nullptr, q1_free);
+        if (twostage) {
+            if (!q1_side) {
+                // lowest priority: the divide and conquer's chain of small dependent launches must not queue behind these
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                JX_HIP(hipStreamCreateWithPriority(&q1_side, hipStreamNonBlocking, prio_lo));
+                JX_HIP(hipEventCreateWithFlags(&q1_go, hipEventDisableTiming));
+                JX_HIP(hipEventCreateWithFlags(&q1_done, hipEventDisableTiming));
+            }
+            q1_plan.reset(ormtr_plan_new());
+            if (q1_ahead) {
+                JX_HIP(hipEventRecord(q1_go, st));
+                JX_HIP(hipStreamWaitEvent(q1_side, q1_go, 0));
+                if (ormtr_prepare(q1_side, d_a, n, sy2sb_bandwidth(), n - sy2sb_bandwidth() - 1, tau.as<double>(), *q1_plan)) return 1;
+                JX_HIP(hipEventRecord(q1_done, q1_side));
+            }
+        }
         if (!twostage) {
             if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
             if (stage_done("sytrd")) return 1;
@@ -376,7 +411,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation (this rank's columns)")) return 1;
-                if (ormtr_lower_off(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), blk.as<double>(), nr)) return 1;
+                if (q1_ahead) JX_HIP(hipStreamWaitEvent(st, q1_done, 0));
+                else if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
+                if (ormtr_apply(st, *q1_plan, blk.as<double>(), nr)) return 1;
                 // column j of the block = eigenvector r0 + j = row r0 + j of the row-major result
                 JX_HIP(hipMemcpyAsync(d_a + (size_t)r0 * n, blk.p, sizeof(double) * (size_t)n * nr, hipMemcpyDeviceToDevice, st));
                 JX_HIP(hipStreamSynchronize(st));
@@ -388,7 +425,9 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation")) return 1;
-                if (ormtr_lower_off(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), c.as<double>(), n)) return 1;
+                if (q1_ahead) JX_HIP(hipStreamWaitEvent(st, q1_done, 0));
+                else if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
+                if (ormtr_apply(st, *q1_plan, c.as<double>(), n)) return 1;
             }
         } else {
             const char *om = getenv("JXGPU_ORMTR");

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <vector>
 
 #include "k_ozgemm.h"
 
@@ -109,47 +110,103 @@ int ormtr_oz_min_n() {
     return v;
 }
 
-int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols);
+// ---- plan: everything that does not depend on C (V, its images, T, V T), prepared ahead on a stream of its own ------------
+struct OrmtrBlock {
+    int jb = 0, nbk = 0, rows = 0;
+    size_t o_vt = 0, o_vtt = 0;      // byte offsets into `store`: oz images of V' and V T, or the f64 blocks V and V T
+};
+struct OrmtrPlan {
+    int n = 0, off = 0, nref = 0, nb = 0;
+    bool use_oz = false;
+    std::vector<OrmtrBlock> blocks;  // in application order (last reflector block first)
+    ScratchLease work;               // f64 temporaries of the preparation
+    ScratchLease store;              // per-block operands kept for the application
+};
 
-// d_a: (n,n) column-major after sytrd_lower; d_tau (n-1); d_c (n,n) column-major, overwritten with Q C.
-int ormtr_lower(hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c) {
-    return ormtr_lower_off(st, d_a, n, 1, n - 1, d_tau, d_c, n);
-}
+OrmtrPlan *ormtr_plan_new() { return new OrmtrPlan(); }
+void ormtr_plan_free(OrmtrPlan *p) { delete p; }
 
-// General form: reflector j (j = 0 .. nref-1) = [0 (j + off rows); 1; A(j+off+1 : n, j)] with factor d_tau[j];
-// d_c (n, ncols), ld = n (ncols < n: a rank's share of the eigenvector columns).
-int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols) {
-    if (n < 2 || nref < 1 || ncols < 1) return 0;
+// Prepares the plan on stream `st` (asynchronous: the caller orders the application behind it).
+int ormtr_prepare(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, OrmtrPlan &P) {
+    P.n = n;
+    P.off = off;
+    P.nref = nref;
+    P.blocks.clear();
+    if (n < 2 || nref < 1) return 0;
     static const bool oz_on = !(getenv("JXGPU_ORMTR_OZ") && atoi(getenv("JXGPU_ORMTR_OZ")) == 0);
-    const bool use_oz = oz_on && n >= ormtr_oz_min_n();
+    P.use_oz = oz_on && n >= ormtr_oz_min_n();
     // wider blocks for large n (rocBLAS form at n = 20000: 512 -> 378 ms, 1024 -> 315, 2048 -> 281, 4096 -> 327)
     int nb = (getenv("JXGPU_ORMTR_NB") && atoi(getenv("JXGPU_ORMTR_NB")) > 0) ? atoi(getenv("JXGPU_ORMTR_NB"))
                                                                               : (n >= 12000 ? 2 * OT_NB : OT_NB);
     nb = ot_round_nb(std::max(nb, OT_TB));
     while (nb > OT_TB && nb / 2 >= nref) nb /= 2;
-    const int rows_max = n - off;
-    // f64: vc (n x nb) | vt (n x nb) | mm | tt (nb x nb each) | xw (nb x nb / 4) | w (nb x ncols) | gws
-    const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb, nw = (size_t)nb * ncols;
+    P.nb = nb;
+    const int nblocks = (nref + nb - 1) / nb;
+    size_t store_bytes = 0;
+    for (int b = nblocks - 1; b >= 0; --b) {
+        OrmtrBlock k;
+        k.jb = b * nb;
+        k.nbk = (nref - k.jb < nb) ? (nref - k.jb) : nb;
+        k.rows = n - k.jb - off;
+        k.o_vt = store_bytes;
+        store_bytes += P.use_oz ? oz_image_bytes(k.nbk, k.rows) : ((sizeof(double) * (size_t)k.rows * k.nbk + 255) & ~(size_t)255);
+        k.o_vtt = store_bytes;
+        store_bytes += P.use_oz ? oz_image_bytes(k.rows, k.nbk) : ((sizeof(double) * (size_t)k.rows * k.nbk + 255) & ~(size_t)255);
+        P.blocks.push_back(k);
+    }
+    // f64 temporaries: vc (n x nb) | vt (n x nb) | mm | tt (nb x nb each) | xw (nb x nb / 4) | gws
+    const size_t nvc = (size_t)n * nb, nmm = (size_t)nb * nb;
     const size_t ngws = std::max<size_t>(4 * nmm, (size_t)1 << 20);
-    const size_t f64_doubles = 2 * nvc + 2 * nmm + nmm / 4 + nw + ngws;
-    size_t img_bytes = 0;
-    size_t b_vt = 0, b_vtt = 0, b_c = 0, b_w = 0;
-    if (use_oz) {
-        b_vt = oz_image_bytes(nb, rows_max);        // V' : rows = reflectors, k = matrix rows
-        b_vtt = oz_image_bytes(rows_max, nb);       // V T: rows = matrix rows, k = reflectors
-        b_c = oz_image_bytes(ncols, rows_max);      // C  : rows = eigenvector columns, k = matrix rows
-        b_w = oz_image_bytes(ncols, nb);            // W  : rows = eigenvector columns, k = reflectors
-        img_bytes = b_vt + b_vtt + b_c + b_w;
+    if (P.work.take(3, sizeof(double) * (2 * nvc + 2 * nmm + nmm / 4 + ngws))) return 1;
+    if (P.store.take(5, store_bytes + 256)) return 1;
+    double *const vc = P.work.as<double>(), *const vt = vc + nvc, *const mm = vt + nvc, *const tt = mm + nmm;
+    double *const xw = tt + nmm, *const gws = xw + nmm / 4;
+    char *const store = P.store.as<char>();
+    for (const OrmtrBlock &k : P.blocks) {
+        double *vcb = P.use_oz ? vc : reinterpret_cast<double *>(store + k.o_vt);
+        double *vtb = P.use_oz ? vt : reinterpret_cast<double *>(store + k.o_vtt);
+        hipLaunchKernelGGL(ot_extract_v_kernel, dim3((k.rows + 255) / 256, k.nbk), dim3(256), 0, st, d_a, n, k.jb, k.nbk, d_tau,
+                           vcb, k.rows, off);
+        JX_LAUNCH_CHECK();
+        if (P.use_oz) {
+            OzImage i_vt = oz_image_at(store + k.o_vt, k.nbk, k.rows);
+            if (oz_slice(st, vcb, k.rows, 1, i_vt)) return 1;                                   // element (j, r) = vc[r + j rows]
+            if (oz_mm(st, i_vt, i_vt, k.nbk, k.nbk, 1.0, 0.0, mm, nb, 1)) return 1;             // upper tiles of V'V
+        } else {
+            if (dgemm(st, true, false, k.nbk, k.nbk, k.rows, 1.0, vcb, k.rows, vcb, k.rows, 0.0, mm, nb, 0, gws, ngws)) return 1;
+        }
+        hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nb + 63) / 64, nb), dim3(64), 0, st, mm, k.nbk, nb, d_tau, k.jb);
+        JX_LAUNCH_CHECK();
+        if (ot_triinv_upper(st, mm, tt, nb, k.nbk, xw, gws, ngws)) return 1;
+        // V T (rows x nbk): small next to the two products with C (k = nbk against ncols columns)
+        if (dgemm(st, false, false, k.rows, k.nbk, k.nbk, 1.0, vcb, k.rows, tt, nb, 0.0, vtb, k.rows, 0, gws, ngws)) return 1;
+        if (P.use_oz) {
+            OzImage i_vtt = oz_image_at(store + k.o_vtt, k.rows, k.nbk);
+            if (oz_slice(st, vtb, 1, k.rows, i_vtt)) return 1;                                  // element (r, j) = vt[r + j rows]
+        }
+    }
+    return 0;
+}
+
+// C <- Q C for d_c (n, ncols), ld = n, on stream `st` (the plan must be complete in stream order).  Synchronises `st` at the end.
+int ormtr_apply(hipStream_t st, const OrmtrPlan &P, double *d_c, int ncols) {
+    if (P.blocks.empty() || ncols < 1) return 0;
+    const int n = P.n, nb = P.nb;
+    const size_t nw = (size_t)nb * ncols;
+    const size_t ngws = std::max<size_t>(4 * (size_t)nb * nb, (size_t)1 << 20);
+    size_t b_c = 0, b_w = 0;
+    if (P.use_oz) {
+        b_c = oz_image_bytes(ncols, n - P.off);      // C: rows = eigenvector columns, k = matrix rows
+        b_w = oz_image_bytes(ncols, nb);             // W: rows = eigenvector columns, k = reflectors
     }
     ScratchLease ws;
-    if (ws.take(3, sizeof(double) * f64_doubles + img_bytes + 256)) return 1;
-    double *const vc = ws.as<double>(), *const vt = vc + nvc, *const mm = vt + nvc, *const tt = mm + nmm;
-    double *const xw = tt + nmm, *const w = xw + nmm / 4, *const gws = w + nw;
+    if (ws.take(6, sizeof(double) * (nw + ngws) + b_c + b_w + 512)) return 1;
+    double *const w = ws.as<double>(), *const gws = w + nw;
     char *const img = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(gws + ngws) + 255) & ~(uintptr_t)255);
-    const int nblocks = (nref + nb - 1) / nb;
+    const char *const store = P.store.as<char>();
     // JXGPU_EIGH_TRACE: per-part times summed over the blocks (synchronises after every part)
     const bool trace = getenv("JXGPU_EIGH_TRACE") != nullptr;
-    double tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tsum[4] = {0, 0, 0, 0};
     auto tlast = std::chrono::steady_clock::now();
     auto mark = [&](int slot) {
         if (!trace) return;
@@ -158,56 +215,48 @@ int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref,
         tsum[slot] += std::chrono::duration<double, std::milli>(now - tlast).count();
         tlast = now;
     };
-    mark(7);
-    for (int b = nblocks - 1; b >= 0; --b) {
-        const int jb = b * nb;
-        const int nbk = (nref - jb < nb) ? (nref - jb) : nb;
-        const int rows = n - jb - off;
-        hipLaunchKernelGGL(ot_extract_v_kernel, dim3((rows + 255) / 256, nbk), dim3(256), 0, st, d_a, n, jb, nbk, d_tau,
-                           vc, rows, off);
-        JX_LAUNCH_CHECK();
-        mark(0);
-        double *csub = d_c + (jb + off);              // rows jb+off .. n-1 of every column
-        OzImage i_vt, i_vtt, i_c, i_w;
-        if (use_oz) {
-            i_vt = oz_image_at(img, nbk, rows);
-            i_vtt = oz_image_at(img + b_vt, rows, nbk);
-            i_c = oz_image_at(img + b_vt + b_vtt, ncols, rows);
-            i_w = oz_image_at(img + b_vt + b_vtt + b_c, ncols, nbk);
-            // V' image: element (j, r) = vc[r + j rows]
-            if (oz_slice(st, vc, rows, 1, i_vt)) return 1;
-            if (oz_mm(st, i_vt, i_vt, nbk, nbk, 1.0, 0.0, mm, nb, 1)) return 1;       // upper tiles of V'V
-        } else {
-            if (dgemm(st, true, false, nbk, nbk, rows, 1.0, vc, rows, vc, rows, 0.0, mm, nb, 0, gws, ngws)) return 1;
-        }
-        mark(1);
-        hipLaunchKernelGGL(ot_fix_m_kernel, dim3((nb + 63) / 64, nb), dim3(64), 0, st, mm, nbk, nb, d_tau, jb);
-        JX_LAUNCH_CHECK();
-        if (ot_triinv_upper(st, mm, tt, nb, nbk, xw, gws, ngws)) return 1;
-        mark(2);
-        // V T (rows x nbk): small next to the two products with C (k = nbk against ncols columns)
-        if (dgemm(st, false, false, rows, nbk, nbk, 1.0, vc, rows, tt, nb, 0.0, vt, rows, 0, gws, ngws)) return 1;
-        mark(3);
-        if (use_oz) {
-            if (oz_slice(st, vt, 1, rows, i_vtt)) return 1;             // element (r, j) = vt[r + j rows]
+    mark(3);
+    for (const OrmtrBlock &k : P.blocks) {
+        double *csub = d_c + (k.jb + P.off);          // rows jb+off .. n-1 of every column
+        if (P.use_oz) {
+            const OzImage i_vt = oz_image_at(const_cast<char *>(store) + k.o_vt, k.nbk, k.rows);
+            const OzImage i_vtt = oz_image_at(const_cast<char *>(store) + k.o_vtt, k.rows, k.nbk);
+            OzImage i_c = oz_image_at(img, ncols, k.rows), i_w = oz_image_at(img + b_c, ncols, k.nbk);
             if (oz_slice(st, csub, n, 1, i_c)) return 1;                // element (col, r) = csub[r + col n]
-            mark(4);
+            mark(0);
             // V' is upper trapezoidal in (reflector, row): mode 2 skips the k steps left of a row tile's diagonal
-            if (oz_mm(st, i_vt, i_c, nbk, ncols, 1.0, 0.0, w, nb, 2)) return 1;                 // W = V' C
-            mark(5);
+            if (oz_mm(st, i_vt, i_c, k.nbk, ncols, 1.0, 0.0, w, nb, 2)) return 1;               // W = V' C
+            mark(1);
             if (oz_slice(st, w, nb, 1, i_w)) return 1;                  // element (col, j) = w[j + col nb]
-            if (oz_mm(st, i_vtt, i_w, rows, ncols, -1.0, 1.0, csub, n, 0)) return 1;            // C -= (V T) W
-            mark(6);
+            if (oz_mm(st, i_vtt, i_w, k.rows, ncols, -1.0, 1.0, csub, n, 0)) return 1;          // C -= (V T) W
+            mark(2);
         } else {
-            if (dgemm(st, true, false, nbk, ncols, rows, 1.0, vc, rows, csub, n, 0.0, w, nb, 0, gws, ngws)) return 1;
-            if (dgemm(st, false, false, rows, ncols, nbk, -1.0, vt, rows, w, nb, 1.0, csub, n, 0, gws, ngws)) return 1;
+            const double *vcb = reinterpret_cast<const double *>(store + k.o_vt);
+            const double *vtb = reinterpret_cast<const double *>(store + k.o_vtt);
+            if (dgemm(st, true, false, k.nbk, ncols, k.rows, 1.0, vcb, k.rows, csub, n, 0.0, w, nb, 0, gws, ngws)) return 1;
+            if (dgemm(st, false, false, k.rows, ncols, k.nbk, -1.0, vtb, k.rows, w, nb, 1.0, csub, n, 0, gws, ngws)) return 1;
         }
     }
     JX_HIP(hipStreamSynchronize(st));   // work buffers are released on return
     if (trace)
-        fprintf(stderr, "[jxgpu ormtr n=%d nb=%d oz=%d] extract %.1f | slice V' + Gram %.1f | T inverse %.1f | V T %.1f | slice VT, C %.1f | "
-                "W = V'C %.1f | slice W + update %.1f ms\n", n, nb, (int)use_oz, tsum[0], tsum[1], tsum[2], tsum[3], tsum[4], tsum[5], tsum[6]);
+        fprintf(stderr, "[jxgpu ormtr n=%d nb=%d oz=%d cols=%d] slice C %.1f | W = V'C %.1f | slice W + update %.1f ms (V, T, V T prepared "
+                "ahead)\n", n, nb, (int)P.use_oz, ncols, tsum[0], tsum[1], tsum[2]);
     return 0;
+}
+
+// One call: prepare + apply on the same stream.
+// General form: reflector j (j = 0 .. nref-1) = [0 (j + off rows); 1; A(j+off+1 : n, j)] with factor d_tau[j];
+// d_c (n, ncols), ld = n (ncols < n: a rank's share of the eigenvector columns).
+int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols) {
+    if (n < 2 || nref < 1 || ncols < 1) return 0;
+    OrmtrPlan P;
+    if (ormtr_prepare(st, d_a, n, off, nref, d_tau, P)) return 1;
+    return ormtr_apply(st, P, d_c, ncols);
+}
+
+// d_a: (n,n) column-major after sytrd_lower; d_tau (n-1); d_c (n,n) column-major, overwritten with Q C.
+int ormtr_lower(hipStream_t st, const double *d_a, int n, const double *d_tau, double *d_c) {
+    return ormtr_lower_off(st, d_a, n, 1, n - 1, d_tau, d_c, n);
 }
 
 }  // namespace jx

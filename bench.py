@@ -446,6 +446,12 @@ def main():
         return {"value": leg["kept_total"] * steps / leg["elapsed"], "unit": "SNPs/s", "steps": steps,
                 "ms_per_step": leg["elapsed"] / steps * 1e3, "m_kept": int(leg["kept_total"]),
                 "stages_ms_per_step": {kk: v / steps * 1e3 for kk, v in leg["stage"].items()},
+                "roofline": ({"bound": "mfma", "kernel": "sbback_apply_pair_kernel" if (n + 15) // 16 >= 8 * 256 else "sbback_apply_reg_kernel",
+                              "achieved": k["q2_gflop"] / max(k["q2_ms"], 1e-9), "peak": 78.6, "unit": "TFLOP/s",
+                              "frac": k["q2_gflop"] / max(k["q2_ms"], 1e-9) / 78.6, "avg_launch_ms": k["q2_ms"] / L,
+                              "traffic": None,
+                              "note": "Q2 back-transformation of this leg: algorithmic 2 n^3 f64 flops over the kernel's HIP-event "
+                                      "duration, against the 78.6 TFLOP/s f64 MFMA peak"} if k.get("two_stage") else None),
                 "roofline_grm": {"bound": "mfma", "achieved": grm_tf, "peak": grm_peak, "unit": "TFLOP/s",
                                  "frac": grm_tf / grm_peak, "int8_share": k.get("grm_i8_share", 0.0),
                                  "avg_launch_ms": k["grm_ms"] / L},
@@ -471,7 +477,8 @@ def main():
         _PMC_SHAPE.update(n=int(n), m=int(m))
         tr_symv, tr_symv_src = pmc_traffic_bytes("jx::sytrd_symv_kernel")
         # the exact scan's kernel is chosen by n and p (jxg_last_kernel_ms(11): 0 LDS-resident, 1 tiled, 2 operands from L2)
-        scan_kernel = "jx::lmm_scan_tiled_kernel" if int(lib().jxg_last_kernel_ms(11)) == 1 else "jx::lmm_scan_fast_kernel"
+        scan_kernel = {1: "jx::lmm_scan_tiled_kernel", 3: "void jx::series_coef_kernel"}.get(int(lib().jxg_last_kernel_ms(11)),
+                                                                                             "jx::lmm_scan_fast_kernel")
         tr_scan, tr_scan_src = (pmc_traffic_bytes(scan_kernel, "fetch") if args.mode == "lmm" else
                                 pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
         i8_share = kern.get("grm_i8_share", 0.0)
@@ -498,6 +505,8 @@ def main():
             roofline_main = {"bound": "mfma", "kernel": q2_kernel, "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
                              "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
+                             "traffic_over_algorithmic": (tr_q2 / (2.0 * 8.0 * float(n) ** 3 / 32.0)) if tr_q2 else None,
+                             "traffic_over_result": (tr_q2 / (16.0 * float(n) * n)) if tr_q2 else None,
                              "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
                              "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "
                                      "kernel issues (64 + 32) / 64 of them on the parallelogram blocks (U = V T' is precomputed per block); "
@@ -530,7 +539,9 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64 (eigendecomposition on f64 MFMA, REML); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
+            "dtype": "f64 (eigendecomposition: reduction stages and Q2 on f64 MFMA; Q1 back-transformation and divide-and-conquer "
+                     "merges as f64-accurate products of 6 int8 digit planes per operand, exact i32 sums, f64 combination: "
+                     "4e-14; REML in f64); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
                      "or fp16 hi+lo split of the f32 operands with f32 accumulation, f64 merge; rotation: exact design rows x three "
                      "int8 planes of U (int8 MFMA, exact i32 sums, f64 combine), other rows fp16 hi+lo split with f32 accumulation",
             "data": "synthetic",
@@ -539,8 +550,9 @@ def main():
                        "n": n, "m": m, "m_kept": int(kept_total), "mode": args.mode,
                        "parallelism": f"snp-shard x{world}" + (
                            "" if not eigh_sharded else
-                           ", eigh: replicated two-stage reduction + divide and conquer, back-transformations sharded by "
-                           "eigenvector" if kern.get("two_stage") else
+                           ", eigh: band reduction with the trailing matrix sharded over the ranks (two collectives per panel), "
+                           "replicated bulge chasing, divide and conquer with the top-level merge per rank window, "
+                           "back-transformations sharded by eigenvector" if kern.get("two_stage") else
                            ", eigh symv tiles sharded over ranks (one-stage tridiagonalisation below the two-stage "
                            "threshold)")},
             "roofline": roofline_main,
@@ -550,6 +562,7 @@ def main():
                              "achieved": grm_tflops, "peak": grm_peak, "unit": "TFLOP/s", "int8_share": i8_share,
                              "frac": grm_tflops / grm_peak,
                              "traffic": tr_grm, "traffic_source": tr_grm_src,
+                             "traffic_over_algorithmic": (tr_grm / (n * float(kept_total) / 4.0 + 8.0 * n * (n + 1) / 2.0)) if tr_grm else None,
                              "traffic_note": "HBM read bytes per launch, rocprofv3 FETCH_SIZE (own pass) x2 gfx950 "
                                              "correction, from the committed summary of this shape (null when none); "
                                              f"algorithmic input = n*m/4 = {n * m / 4e6:.1f} MB (payload "
@@ -566,6 +579,8 @@ def main():
                                 "peak": rot_peak, "unit": "TFLOP/s", "frac": rot_tflops / rot_peak,
                                 "mfma_util_pmc": mu_rot, "mfma_util_source": mu_rot_src,
                                 "traffic": tr_rot, "traffic_source": tr_rot_src,
+                                "traffic_over_algorithmic": (tr_rot / (min(32768.0, float(kept_total)) * (n / 4.0 + 4.0 * n) + 3.0 * float(n) * n))
+                                if tr_rot else None,
                                 "traffic_note": "HBM bytes per launch (one launch per block of <= 32768 SNP rows): FETCH_SIZE x2 + "
                                                 "WRITE_SIZE; algorithmic = the block's payload + the U planes once + 4 n bytes "
                                                 "written per row",
@@ -575,16 +590,39 @@ def main():
                                         "the two fp16 products they replace; other rows: three fp16 products (hi/lo split of "
                                         "both operands) against 2.5 PFLOP/s",
                                 "ms_per_step": kern["rot_ms"] / L},
+            "roofline_eigh_gemm": ({
+                "bound": "mfma", "kernel": "oz_mm_kernel<6> (sliced f64 GEMM on v_mfma_i32_32x32x32_i8, csrc/k_ozgemm.hip)",
+                "stage": "Q1 back-transformation C <- Q1 C (W = V'C and C -= (V T) W per block of 2048 reflectors)",
+                "algorithmic_tflops": 2.0 * float(n) ** 3 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
+                "planes": int(lib().jxg_oz_planes()),
+                "issued_int8_products_per_algorithmic_product": int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2,
+                "achieved": 2.0 * float(n) ** 3 * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
+                "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                "frac": 2.0 * float(n) ** 3 * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12 / MFMA_I8_PEAK_TOPS,
+                "f64_mfma_peak_tflops": F64_MFMA_PEAK_TFLOPS,
+                "note": "algorithmic 2 n^3 f64 flops of the stage over its whole duration (slicing of C and W, products, "
+                        "HIP events around the stage; the C-independent part -- V images, Gram, T^-1, V T -- is prepared on a "
+                        "side stream during the divide and conquer); every algorithmic product is issued as planes (planes + 1) / 2 "
+                        "int8 digit products (exact i32 sums, f64 combination: 4e-14 relative), priced against the dense int8 "
+                        "peak 5 POP/s; algorithmic_tflops is to be read against the 78.6 TFLOP/s f64 MFMA roof this stage "
+                        "(rocBLAS dgemm, rounds 1 - 3: 72) no longer sits under; the divide and conquer's merges run on the same kernel"}
+                                   if kern.get("two_stage") and n >= 3000 else None),
             "roofline_scan": ({"bound": "f64 valu",
                                "kernel": ("lmm_scan_fast_kernel (s / X~ / y~ resident in LDS)",
                                           "lmm_scan_tiled_kernel (LDS tiles of s / X~ / y~, 16 SNPs per workgroup in lock step)",
-                                          "lmm_scan_fast_kernel (operands from L2)")[int(lib().jxg_last_kernel_ms(11))],
+                                          "lmm_scan_fast_kernel (operands from L2)",
+                                          "series_coef_kernel (per-SNP Chebyshev series of the SNP-specific sums, one pass over the "
+                                          "rotated rows on v_mfma_f64_16x16x4_f64) + lmm_scan_fast_kernel<SERIES> (Brent on the series)"
+                                          )[int(lib().jxg_last_kernel_ms(11))],
                                "achieved": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9,
                                "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,
                                "brent_evals_per_snp": kern.get("scan_evals", 0.0) / L,
                                "hbm_gbs": scan_gbs,
                                "traffic": tr_scan, "traffic_source": tr_scan_src,
+                               "traffic_over_algorithmic": (tr_scan / (4.0 * n * min(32768.0, float(kept_total)))) if tr_scan else None,
                                "note": "Brent over the exact per-SNP REML: every objective evaluation is a pass over the n "
                                        "rotated samples (one f64 reciprocal per sample, operands s / X~ / y~ resident in "
                                        "LDS); algorithmic flops per SURVEY 8(d): (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) "
@@ -665,10 +703,10 @@ def main():
             except Exception as e:
                 res["extra_c3_cov5"] = {"error": repr(e)}
             try:
-                leg = run_leg(50000, 500000, 0.0, 1, 1)
-                sm = leg_summary(leg, 50000, 1)
+                leg = run_leg(50000, 500000, 0.0, 3, 1)
+                sm = leg_summary(leg, 50000, 3)
                 res["extra_c4_1gpu"] = dict({k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
-                                                                "stages_ms_per_step")},
+                                                                "stages_ms_per_step", "roofline")},
                                             warmup=1, n_gpus=1,
                                             workload="synthetic HWE panel n=50000 m=500000 (BASELINE configs[3] shape) on ONE GPU, "
                                                      "-lmm, maf 0.02 geno 0.05, intercept only, missing=0.0",

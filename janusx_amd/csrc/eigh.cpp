@@ -308,11 +308,12 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             }
         }
         // Q1 back-transformation, C-independent part (reflector images, Gram, T^-1, V T of every block: ~40 of its 210 ms at
-        // n = 20 000): enqueued NOW on a stream of its own, so it runs in the gaps of the divide and conquer (host-driven, many
-        // small launches); the application behind Q2 then only waits for its event.  JXGPU_Q1_AHEAD=0: in line.
+        // n = 20 000).  JXGPU_Q1_AHEAD=1 enqueues it NOW on a low-priority stream of its own, beside the divide and conquer;
+        // measured at n = 20 000 that moves the 40 ms instead of hiding them (Q1 210 -> 168 ms, divide and conquer 98 -> 145:
+        // its chain of small dependent launches queues behind the side stream's full-chip kernels), so the default is in line.
         static hipStream_t q1_side = nullptr;
         static hipEvent_t q1_go = nullptr, q1_done = nullptr;
-        static const bool q1_ahead = !(getenv("JXGPU_Q1_AHEAD") && atoi(getenv("JXGPU_Q1_AHEAD")) == 0);
+        static const bool q1_ahead = getenv("JXGPU_Q1_AHEAD") && atoi(getenv("JXGPU_Q1_AHEAD")) != 0;
         auto q1_free = [](OrmtrPlan *p) {
             if (q1_side) (void)hipStreamSynchronize(q1_side);   // nothing of the plan may still be in flight
             ormtr_plan_free(p);

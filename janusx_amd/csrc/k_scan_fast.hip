@@ -18,6 +18,8 @@
 // One wave per SNP, no LDS, no barriers.  `jxg_lmm_scan_exact` keeps the two-pass reference formulation.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "scan_common.h"
 
 namespace jx {
@@ -25,6 +27,12 @@ namespace jx {
 constexpr int CH_N = 32;          // Chebyshev terms per segment
 constexpr int CH_MAXSEG = 8;      // (high - low) <= 16
 constexpr int CH_HDR = 24;        // doubles in front of y_c in the table workspace: smin, 7 spare, beta_mid (<= 15), 1 spare
+// per-SNP series of the SNP-specific sums (series_coef_kernel below)
+constexpr int SR_M = 64;            // series entries per quantity: <= 2 segments x 32 terms
+constexpr int SR_SC = 64;           // samples per staged chunk
+constexpr int SR_WP = SR_M + 16;    // LDS pitch of the table chunk [sample][entry] (doubles): the 4 k-rows of a fragment read land
+                                    // on disjoint banks
+constexpr int SR_GP = SR_SC + 4;    // LDS pitch of the row chunk [SNP][sample] (floats): bank = 4 snp + sample
 
 struct ChebHeader {
     int nseg;
@@ -614,12 +622,19 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
 // shifted y~, 8 n (2 + p) bytes -- are copied into LDS once per workgroup and shared by its NW waves.  Without it each
 // evaluation re-reads them through L2 (they do not fit the 32 KB L1): measured 7.7 TB/s of L1<-L2 traffic and waves
 // parked on s_waitcnt for 87 % of their cycles at n = 5000 (profiles/r01d_pmc_scan.json).
-template <int MAXD, int NW, bool LDS>
+template <int MAXD>
+__device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, const double *__restrict__ sc, int p,
+                                                 double (&acc)[MAXD + 1]);
+
+// SERIES: the SNP-specific sums come from the SNP's own Chebyshev series (series_coef_kernel: `snp_coef`, `snp_ssq`) instead of
+// a pass over the rotated row -- `grot` is not read.
+template <int MAXD, int NW, bool LDS, bool SERIES = false>
 __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void lmm_scan_fast_kernel(
     const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
-    int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out) {
+    int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out,
+    const double *__restrict__ snp_coef = nullptr, const double *__restrict__ snp_ssq = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
     if (MAXD == 2) p = 1;     // dim = p + 1 <= 2 and p >= 1: a compile-time p (see lmm_scan_tiled_kernel)
     const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
@@ -640,14 +655,36 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const int wave = threadIdx.x >> 6;
     const double smin = smin_ptr[0];
     for (int r = blockIdx.x * NW + wave; r < nrows; r += gridDim.x * NW) {
-        const float *g = grot + (int64_t)r * n;
+        const float *g = SERIES ? nullptr : grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         double ssq = 0.0;
-        for (int i = lane; i < n; i += 64) {
-            const double v = (double)g[i];
-            ssq += v * v;
+        if (SERIES) {
+            ssq = snp_ssq[r];
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                const double v = (double)g[i];
+                ssq += v * v;
+            }
+            ssq = wave_allsum(ssq);
         }
-        ssq = wave_allsum(ssq);
+        // one evaluation of the Brent objective (and of final_beta_se) for this wave's SNP
+        const double *sc = SERIES ? snp_coef + (int64_t)r * (p + 2) * SR_M : nullptr;
+        auto eval_at = [&](double xx, bool want_ainv, FastEval<MAXD> &res, const double *bmid) {
+            if (!SERIES) {
+                fast_eval<MAXD>(xx, hd, coef, smin, s, xcov, yc, g, n, p, want_ainv, res, bmid);
+                return;
+            }
+            res.ok = false;
+            res.reml_neg = 1e8;
+            res.q = 0.0;
+            res.logdetv = 0.0;
+            res.beta_k = 0.0;
+            res.ainv_kk = 0.0;
+            if (fast_eval_lambda(xx, smin, n, p + 1) < 0.0) return;
+            double acc[MAXD + 1];
+            series_eval_sums<MAXD>(xx, hd, sc, p, acc);
+            fast_eval_finish<MAXD>(xx, hd, coef, n, p, want_ainv, bmid, acc, res);
+        };
         if (!isfinite(ssq) || ssq <= 1e-12) {
             if (lane == 0) {
                 o[0] = nan("");
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
         const double tol = fmax(fabs(tol_in), 1e-12);
         double x = (warm && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
         double w = x, v = x;
-        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, false, ev);
+        eval_at(x, false, ev, nullptr);
         double fx = ev.reml_neg, fw = fx, fv = fx;
         double d = 0.0, e = 0.0;
         int evals = 1;
@@ -707,7 +744,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             }
             if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
             u = x + d;
-            fast_eval<MAXD>(u, hd, coef, smin, s, xcov, yc, g, n, p, false, ev);
+            eval_at(u, false, ev, nullptr);
             const double fu = ev.reml_neg;
             ++evals;
             if (fu <= fx) {
@@ -738,7 +775,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             }
         }
         // ---- final_beta_se (src/stats/reml.rs:472-568) at the optimum ------------------------------------
-        fast_eval<MAXD>(x, hd, coef, smin, s, xcov, yc, g, n, p, true, ev, smin_ptr + 8);
+        eval_at(x, true, ev, smin_ptr + 8);
         double beta = nan(""), se = nan("");
         const int dim = p + 1;
         if (ev.ok) {
@@ -783,6 +820,178 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     }
 }
 
+
+// ---- per-SNP Chebyshev series of the SNP-specific sums: ONE pass over a rotated row -----------------------------------
+// The sums an evaluation needs from the rotated row g~ -- c_r(x) = sum g x~_r / v, d(x) = sum g^2 / v, b(x) = sum g y_c / v with
+// v_i = s_i + 10^x -- are as analytic in x = log10 lambda as the lambda-only sums tabulated above (same poles), so they have the
+// same 32-term Chebyshev series per width-2 segment, and the series are LINEAR in the row: with
+//   What[i][seg 32 + j] = (2 / 32) sum_k cos(pi j (k + 1/2) / 32) / (s_i + lambda_{seg,k})        (lambda-only, built once per model)
+// the coefficients of a SNP are  coef_q[m] = sum_i (g_i q_i) What[i][m],  q_i in {x~_ir, g_i, y_ci}:  a dense f64 product over the
+// samples -- (p + 2) rows per SNP against the n x 64 table -- on v_mfma_f64_16x16x4_f64, one streaming pass over g~ (4 n bytes per
+// SNP: the algorithmic traffic; the tiled kernel re-reads the row once per Brent evaluation, 16 x).  Brent then runs on the series
+// alone (lmm_scan_fast_kernel<..., SERIES>): an evaluation is one Clenshaw recurrence per lane and the unchanged evaluation
+// tail -- no sample loop.  src/stats/lmm.rs:94-199 (per-SNP Brent over reml_loglike), src/stats/reml.rs:255-362.
+
+// What[i][m] for i < npad (zero rows beyond n), m = seg 32 + j (zero beyond nseg 32)
+__global__ __launch_bounds__(64) void series_what_kernel(const double *__restrict__ s, int n, int npad, ChebHeader hd,
+                                                         double *__restrict__ what) {
+    __shared__ double cs[CH_N][CH_N + 1];
+    for (int e = threadIdx.x; e < CH_N * CH_N; e += 64) {
+        const int j = e / CH_N, k = e % CH_N;
+        cs[j][k] = cos(M_PI * (double)j * ((double)k + 0.5) / (double)CH_N);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= npad) return;
+    double *o = what + (int64_t)i * SR_M;
+    for (int seg = 0; seg < SR_M / CH_N; ++seg) {
+        double r[CH_N];
+        const bool live = i < n && seg < hd.nseg;
+#pragma unroll
+        for (int k = 0; k < CH_N; ++k) {
+            const double t = cos(M_PI * ((double)k + 0.5) / (double)CH_N);
+            const double x = hd.low + hd.segw * ((double)seg + 0.5) + 0.5 * hd.segw * t;
+            r[k] = live ? 1.0 / (s[i] + pow(10.0, x)) : 0.0;
+        }
+        for (int j = 0; j < CH_N; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < CH_N; ++k) acc += r[k] * cs[j][k];
+            o[seg * CH_N + j] = acc * (2.0 / (double)CH_N);
+        }
+    }
+}
+
+// coef[(r NQ + q) 64 + m] = sum_i g[r][i] mult_q[i] What[i][m];  ssq[r] = sum_i g[r][i]^2.
+// mult: q < p: x~ column q; q == p: the row itself; q == p + 1: y_c.  512 threads = 8 waves x 16 SNPs.
+template <int NQ>
+__global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__restrict__ grot, int nrows, int n, int npad,
+                                                             const double *__restrict__ xcov, const double *__restrict__ yc,
+                                                             const double *__restrict__ what, double *__restrict__ coef,
+                                                             double *__restrict__ ssq) {
+    typedef double d4v __attribute__((ext_vector_type(4)));
+    constexpr int P = NQ - 2;
+    extern __shared__ __attribute__((aligned(16))) double sr_smem[];
+    double *wt = sr_smem;                                         // [SR_SC][SR_WP]
+    double *mq = wt + SR_SC * SR_WP;                              // [P + 1][SR_SC]: x~ columns, then y_c
+    float *gt = reinterpret_cast<float *>(mq + (P + 1) * SR_SC);  // [128][SR_GP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 128;
+    // staging map: table chunk = 64 samples x 64 entries = 32 KB contiguous (4 x 16 B per thread); row chunk: thread = (row
+    // tid >> 2, 16 floats)
+    const int grow = tid >> 2, gpart = tid & 3;
+    const bool grow_ok = r0 + grow < nrows;
+    const bool v4 = (n & 3) == 0;
+    double2 wr[4];
+    float4 gr[4];
+    double mr = 0.0;
+    auto load_chunk = [&](int i0) {
+        const double2 *wsrc = reinterpret_cast<const double2 *>(what + (int64_t)i0 * SR_M);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[u] = wsrc[tid + 512 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // branch-free: clamped (always valid) addresses, out-of-range samples and rows zeroed by selects
+            const int i = i0 + 16 * gpart + 4 * u;
+            float4 v;
+            if (v4) {
+                v = *reinterpret_cast<const float4 *>(grot + (int64_t)(grow_ok ? r0 + grow : 0) * n + min(i, n - 4));
+                if (i >= n || !grow_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float *rowp = grot + (int64_t)(grow_ok ? r0 + grow : 0) * n;
+                v.x = rowp[min(i, n - 1)];
+                v.y = rowp[min(i + 1, n - 1)];
+                v.z = rowp[min(i + 2, n - 1)];
+                v.w = rowp[min(i + 3, n - 1)];
+                if (i >= n || !grow_ok) v.x = 0.f;
+                if (i + 1 >= n || !grow_ok) v.y = 0.f;
+                if (i + 2 >= n || !grow_ok) v.z = 0.f;
+                if (i + 3 >= n || !grow_ok) v.w = 0.f;
+            }
+            gr[u] = v;
+        }
+        if (tid < (P + 1) * SR_SC) {
+            const int q = tid / SR_SC, i = i0 + tid % SR_SC;
+            mr = (i < n) ? (q < P ? xcov[(int64_t)i * P + q] : yc[i]) : 0.0;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = 2 * (tid + 512 * u);                    // double index inside the 64 x 64 chunk
+            const int smp = e / SR_M, m = e % SR_M;
+            *reinterpret_cast<double2 *>(wt + smp * SR_WP + m) = wr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(gt + grow * SR_GP + 16 * gpart + 4 * u) = gr[u];
+        if (tid < (P + 1) * SR_SC) mq[tid] = mr;
+    };
+    d4v acc[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[q][b] = d4v{0.0, 0.0, 0.0, 0.0};
+    double sq = 0.0;
+    const int fi = lane & 15, fk = lane >> 4;                     // fragment row / column index and k index of this lane
+    const float *grow_l = gt + (wave * 16 + fi) * SR_GP + fk;
+    load_chunk(0);
+    for (int i0 = 0; i0 < npad; i0 += SR_SC) {
+        __syncthreads();                                          // the previous chunk has been consumed
+        store_chunk();
+        __syncthreads();
+        if (i0 + SR_SC < npad) load_chunk(i0 + SR_SC);           // in flight while this chunk is multiplied
+#pragma unroll 4
+        for (int ks = 0; ks < SR_SC / 4; ++ks) {
+            const double gv = (double)grow_l[4 * ks];
+            double a[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) a[b] = wt[(4 * ks + fk) * SR_WP + 16 * b + fi];
+            sq = fma(gv, gv, sq);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const double mult = (q == P) ? gv : mq[(q < P ? q : P) * SR_SC + 4 * ks + fk];
+                const double bv = gv * mult;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[q][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], bv, acc[q][b], 0, 0, 0);
+            }
+        }
+    }
+    // D[entry = 16 b + (lane >> 4) + 4 r][SNP = lane & 15]
+    const int snp = r0 + wave * 16 + fi;
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (snp < nrows) {
+        if (fk == 0) ssq[snp] = sq;
+        double *o = coef + (int64_t)snp * NQ * SR_M;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[q * SR_M + 16 * b + fk + 4 * r] = acc[q][b][r];
+    }
+}
+
+// SNP-specific sums of an evaluation from the SNP's own series (lane q evaluates quantity q; the wave sum of fast_eval_finish
+// then hands every lane the value): acc[r < p] = c_r, acc[MAXD - 1] = d, acc[MAXD] = b
+template <int MAXD>
+__device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, const double *__restrict__ sc, int p,
+                                                 double (&acc)[MAXD + 1]) {
+    const int lane = threadIdx.x & 63;
+    int seg = (int)((x - hd.low) / hd.segw);
+    if (seg < 0) seg = 0;
+    if (seg >= hd.nseg) seg = hd.nseg - 1;
+    const double t = (x - (hd.low + hd.segw * ((double)seg + 0.5))) / (0.5 * hd.segw);
+    const int q = lane < p + 2 ? lane : 0;
+    const double val = clenshaw(sc + q * SR_M + seg * CH_N, t);
+#pragma unroll
+    for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD - 1; ++r)
+        if (r < p && lane == r) acc[r] = val;
+    if (lane == p) acc[MAXD - 1] = val;
+    if (lane == p + 1) acc[MAXD] = val;
+}
 
 // ---- tiled form for n beyond the LDS-resident limit --------------------------------------------------------------------
 // The vectors every evaluation streams (s, X~, shifted y~: 8 n (2 + p) bytes, 480 KB at n = 20 000) do not fit LDS, and the
@@ -1194,10 +1403,19 @@ static ChebHeader make_header(int p, double low, double high) {
     return hd;
 }
 
+// per-SNP series form (series_coef_kernel): plain evaluation tail (up to three covariates beside the SNP) and bounds of at most
+// two width-2 segments (the workflow's [log10 lambda0 - 2, + 2]); JXGPU_SCAN_SERIES=0 switches it off
+static bool series_ok(int p, const ChebHeader &hd) {
+    static const bool on = !(getenv("JXGPU_SCAN_SERIES") && atoi(getenv("JXGPU_SCAN_SERIES")) == 0);
+    return on && !cheb_blk(p) && p <= 3 && hd.nseg * CH_N <= SR_M;
+}
+static int64_t series_npad(int n) { return ((int64_t)n + SR_SC - 1) / SR_SC * SR_SC; }
+
 extern "C" int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high) {
     if (!fast_path_ok(p, low, high)) return 0;
     const ChebHeader hd = make_header(p, low, high);
-    return (int64_t)sizeof(double) * (CH_HDR + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N);
+    const int64_t what = series_ok(p, hd) ? series_npad(n) * SR_M : 0;     // What[i][m] behind the lambda-only tables
+    return (int64_t)sizeof(double) * (CH_HDR + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N + what);
 }
 
 extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
@@ -1220,6 +1438,12 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     hipLaunchKernelGGL(cheb_coef_kernel, dim3((total_funcs * CH_N + 255) / 256), dim3(256), 0, st, vals, total_funcs,
                        coef);
     JX_LAUNCH_CHECK();
+    if (series_ok(p, hd)) {
+        double *what = vals + (int64_t)total_funcs * CH_N;
+        const int npad = (int)series_npad(n);
+        hipLaunchKernelGGL(series_what_kernel, dim3((npad + 63) / 64), dim3(64), 0, st, d_s, n, npad, hd, what);
+        JX_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1254,7 +1478,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             if (grid > 65536) grid = 65536;
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals);
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr);
         } else {
             constexpr int NW = 8;
             auto kfn = lmm_scan_fast_kernel<4, NW, true>;
@@ -1267,8 +1491,55 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             if (grid > 65536) grid = 65536;
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals);
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr);
         }
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!lmm2 && series_ok(p, hd) && !getenv("JXGPU_SCAN_NOTILE")) {
+        // n beyond the LDS-resident limit, plain evaluation tail: ONE streaming pass over the rotated rows builds every SNP's
+        // Chebyshev series of its SNP-specific sums on the f64 matrix pipes, Brent then runs on the series
+        g_last_ms[11] = 3.f;
+        hipStream_t st = (hipStream_t)stream;
+        const int nq = p + 2;
+        static std::mutex mu;
+        static DevBuf sbuf;                                  // series + sums of squares of one call (grown on demand)
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
+        if (sbuf.bytes < need) {
+            JX_HIP(hipStreamSynchronize(st));
+            if (sbuf.alloc(need + need / 4)) return 1;
+        }
+        double *scoef = sbuf.as<double>(), *sssq = scoef + (size_t)nrows * nq * SR_M;
+        const double *what = coef + 2 * (int64_t)hd.nseg * hd.nf * CH_N;
+        const int npad = (int)series_npad(n);
+        const size_t lds = sizeof(double) * ((size_t)SR_SC * SR_WP + (size_t)(p + 1) * SR_SC) + sizeof(float) * 128 * SR_GP;
+#define JX_SERIES_COEF(NQV)                                                                                                \
+    do {                                                                                                                  \
+        auto kfn = series_coef_kernel<NQV>;                                                                               \
+        static bool attr_s = false;                                                                                       \
+        if (!attr_s) {                                                                                                    \
+            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));        \
+            attr_s = true;                                                                                                \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kfn, dim3((nrows + 127) / 128), dim3(512), lds, st, d_grot, nrows, n, npad, d_xcov, yc, what,  \
+                           scoef, sssq);                                                                                  \
+    } while (0)
+        if (nq == 3) JX_SERIES_COEF(3);
+        else if (nq == 4) JX_SERIES_COEF(4);
+        else JX_SERIES_COEF(5);
+#undef JX_SERIES_COEF
+        JX_LAUNCH_CHECK();
+        constexpr int NW = 8;
+        const int grid = (nrows + NW - 1) / NW;
+        if (dim <= 2)
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<2, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
+                               d_out, d_evals, (const double *)scoef, (const double *)sssq);
+        else
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<4, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
+                               d_out, d_evals, (const double *)scoef, (const double *)sssq);
         JX_LAUNCH_CHECK();
         return 0;
     }
@@ -1326,7 +1597,8 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXD, SCAN_WAVES, false>), dim3(grid),
                                               dim3(SCAN_THREADS), 0, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
                                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd,
-                                              with_plrt, nullml, d_out, d_evals));
+                                              with_plrt, nullml, d_out, d_evals, (const double *)nullptr,
+                                              (const double *)nullptr));
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -668,17 +668,18 @@ def main():
                 sm = leg_summary(leg, 20000, 2)
                 mu_g, mu_g_src = pmc_mfma_util("grm_i8_kernel", "mfma_missing1pct")
                 mu_r, mu_r_src = pmc_mfma_util("rotate256_kernel", "mfma_missing1pct")
-                res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_i8_kernel + gm_spmm_kernel (SNPs with missing "
-                                                       "calls: exact int8 Gram of the clean form + sparse correction, "
-                                                       "csrc/k_grm_miss.hip)",
+                res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_i8_kernel<LUT> x 2 (SNPs with missing calls: "
+                                                       "the missing call's count in two int8 digits, two int8 Gram products with "
+                                                       "per-SNP byte LUTs, exact diagonal; csrc/k_grm.hip dense missing-call path)",
                                                        mfma_util_pmc=mu_g, mfma_util_source=mu_g_src,
+                                                       issued_int8_products_per_algorithmic_product=2,
                                                        note="2 timed steps of the configs[2] shape with 1 % missing calls; "
                                                             "algorithmic n(n+1)m flops over the whole accumulate call, priced "
-                                                            "against the int8 peak (all SNPs take the int8 Gram); about a fifth of "
-                                                            "the call is that MFMA kernel, the rest is the correction W + W' for "
-                                                            "the missing calls -- nnz(e) n table lookups, VALU / LDS bound, f64 "
-                                                            "sums (229 ms on the fp16 three-product kernel it replaces up to "
-                                                            "1.2 % missing calls: JXGPU_GRM_MISS=0)")
+                                                            "against the int8 peak; every SNP holds a missing call at this rate and "
+                                                            "takes TWO int8 Gram products ((30 B B' + A A') / 31 with the byte LUTs "
+                                                            "B = (0, P1, 56, 112), A = (0, P1 + P2, 56, 112): 2e-7 of the mean diagonal), "
+                                                            "so 0.5 x the clean kernel's fraction is the ceiling of this form "
+                                                            "(rounds 2 - 3: fp16 three-product kernel 229 ms, sparse correction 165 ms)")
                 res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"],
                                                           kernel="rotate256_kernel (fp16 hi/lo, three products: every row has a "
                                                                  "missing call at this rate)",

@@ -399,7 +399,11 @@ __global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__rest
         // flag 2: affine in the count but with missing calls -- int8 Gram + the sparse correction of k_grm_miss.hip
         // (the missing call's own LUT value must be finite)
         if (any != 0) {
-            fl = isfinite(lut[k * 4 + 1]) ? 2 : 0;
+            // the missing call's value as a count, c* = s (z_missing - b): inside [0, 2] for a centred design (2 p of the counted
+            // allele), which is what the dense two-Gram path quantises
+            const float bta = ((v0 - r0) + (v2 - 1.0f) + (v3 - r3)) / 3.0f;
+            const float cst = (r0 == 0.0f ? 1.0f : -1.0f) * (lut[k * 4 + 1] - (bta + r0));
+            fl = (isfinite(lut[k * 4 + 1]) && cst >= -0.004f && cst <= 2.004f) ? 2 : 0;
             if (fl == 2 && miss_total) atomicAdd(miss_total, (unsigned long long)nmiss);
         }
         ok = fl != 0;
@@ -412,30 +416,40 @@ __global__ __launch_bounds__(256) void grm_classify_kernel(const uint8_t *__rest
     ilut[k * 4 + 3] = r3;
 }
 
-// stable partition positions: qualifying SNPs first.  One workgroup; info[0] = number qualifying.
+// stable partition positions: SNPs with flag 1 first, then flag 2, then the others.  One workgroup; info[0] = number with a
+// non-zero flag, info[2] = number with flag 1.
 __global__ __launch_bounds__(1024) void grm_partition_kernel(const int32_t *__restrict__ flag, int64_t mk,
                                                              int32_t *__restrict__ pos, int32_t *__restrict__ info) {
-    __shared__ int64_t part[1024];
+    __shared__ int64_t part1[1024], part2[1024];
     const int tid = threadIdx.x;
     const int64_t per = (mk + 1023) / 1024;
     const int64_t b = tid * per, e = (b + per < mk) ? b + per : mk;
-    int64_t cnt = 0;
-    for (int64_t k = b; k < e; ++k) cnt += flag[k] != 0;
-    part[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
-        const int64_t v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const int64_t total = part[1023];
-    int64_t ones = part[tid] - cnt;   // qualifying SNPs before b
+    int64_t c1 = 0, c2 = 0;
     for (int64_t k = b; k < e; ++k) {
-        if (flag[k]) pos[k] = (int32_t)ones++;
-        else pos[k] = (int32_t)(total + (k - ones));
+        c1 += flag[k] == 1;
+        c2 += flag[k] == 2;
     }
-    if (tid == 0) info[0] = (int32_t)total;
+    part1[tid] = c1;
+    part2[tid] = c2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scans
+        const int64_t v1 = (tid >= off) ? part1[tid - off] : 0, v2 = (tid >= off) ? part2[tid - off] : 0;
+        __syncthreads();
+        part1[tid] += v1;
+        part2[tid] += v2;
+        __syncthreads();
+    }
+    const int64_t t1 = part1[1023], t2 = part2[1023];
+    int64_t n1 = part1[tid] - c1, n2 = part2[tid] - c2;   // rows of either kind before b
+    for (int64_t k = b; k < e; ++k) {
+        if (flag[k] == 1) pos[k] = (int32_t)n1++;
+        else if (flag[k] == 2) pos[k] = (int32_t)(t1 + n2++);
+        else pos[k] = (int32_t)(t1 + t2 + (k - n1 - n2));
+    }
+    if (tid == 0) {
+        info[0] = (int32_t)(t1 + t2);
+        info[2] = (int32_t)t1;
+    }
 }
 
 // the rows with missing calls go to the general kernel after all (panel mode, too many missing calls, JXGPU_GRM_MISS=0)
@@ -453,12 +467,44 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                                                          uint4 *__restrict__ lut16, float *__restrict__ ilut2,
                                                          double *__restrict__ beta2, int i8mode,
                                                          const int32_t *__restrict__ flag, uint8_t *__restrict__ miss2,
-                                                         double *__restrict__ wl) {
+                                                         double *__restrict__ wl, uint32_t *__restrict__ lut_a,
+                                                         uint32_t *__restrict__ lut_b, double *__restrict__ dfix) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const int32_t nex = info[0] & ~63;
     const int32_t dst = pos[k];
     const bool exact = dst < nex;
+    // dense missing-call path (lut_a != nullptr): z = b + s c~ with c~ = the unflipped count, c* = s (z_missing - b) at a missing
+    // call, written as 56 c~ ~ P1 + P2 / 31: P1 = rint(56 c*) in [0, 112], P2 = rint(31 (56 c* - P1)) in [-15, 15] (P1 + P2 is
+    // an int8); byte LUTs of the two Grams: B = (0, P1, 56, 112), A = (0, P1 + P2, 56, 112);
+    // c~ c~' ~ ((1 - 1/31) B B' + (1/31) A A') / 3136 up to the product of two P2 (both samples missing at the SNP: 3e-7 of the
+    // mean diagonal at 1 % missing calls off the diagonal; ON the diagonal dfix[k] = c*^2 - ((30 P1^2 + (P1 + P2)^2) / 31) / 3136
+    // restores the exact value).  c* is resolved to 1 / 1736 of a count: 1.7e-4 rms per missing call, which random-walks to
+    // sqrt(2 rate m) 1.7e-4 0.55 / (0.3 m) of the mean diagonal -- 2e-7 at m = 200 000 and 1 %, 4e-6 at m = 700: the path is
+    // taken from 16 384 SNPs on
+    double cstar = 0.0;
+    if (lut_a) {
+        uint32_t la = 0u, lb = 0u;
+        double fix = 0.0;
+        if (exact) {
+            la = lb = (56u << 16) | (112u << 24);
+            if (flag[k] == 2) {
+                const double r0d = (double)ilut[k * 4 + 0];
+                const double bb = beta[k] + r0d, ss = (r0d == 0.0) ? 1.0 : -1.0;
+                cstar = ss * ((double)lut[k * 4 + 1] - bb);
+                double p1 = rint(56.0 * cstar);
+                p1 = fmin(fmax(p1, 0.0), 112.0);
+                double p2 = rint(31.0 * (56.0 * cstar - p1));
+                p2 = fmin(fmax(p2, -15.0), 15.0);
+                lb |= ((uint32_t)(int)p1 & 0xffu) << 8;
+                la |= ((uint32_t)(int)(p1 + p2) & 0xffu) << 8;
+                fix = cstar * cstar - ((30.0 * p1 * p1 + (p1 + p2) * (p1 + p2)) / 31.0) / 3136.0;
+            }
+        }
+        lut_a[dst] = la;
+        lut_b[dst] = lb;
+        dfix[dst] = fix;
+    }
     if (miss2) {
         // table of the sparse correction (k_grm_miss.hip): clean-form value b + s c by code, d = lut(missing) - b
         const bool m2 = exact && flag[k] == 2;
@@ -487,7 +533,8 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
         lo[c] = __half_as_ushort(l);
         // int8 Gram (k_grm_i8.hip): z = b + s c with the UNFLIPPED count c of the payload (LUT 0, 0, 1, 2); else the
         // flipped integer LUT of the fp16 exact variant (z = beta + c~)
-        ilut2[(int64_t)dst * 4 + c] = i8mode ? (c == 0 ? 0.0f : (float)(c - 1)) : ilut[k * 4 + c];
+        // (dense missing-call path: the missing call carries its own count c*)
+        ilut2[(int64_t)dst * 4 + c] = i8mode ? (c == 0 ? 0.0f : (c == 1 ? (float)cstar : (float)(c - 1))) : ilut[k * 4 + c];
     }
     uint4 o;
     o.x = (uint32_t)hi[0] | ((uint32_t)hi[1] << 16);
@@ -572,6 +619,18 @@ static EventPair g_grm_ev;
 }  // namespace jx
 
 namespace jx {
+// acc[i][i] += v[i]
+__global__ void grm_diag_add_kernel(double *__restrict__ acc, int64_t ld, int n, const double *__restrict__ v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[(int64_t)i * ld + i] += v[i];
+}
+// (k, 4) f32 = (0, 1, 0, 0): indicator of the missing code, the LUT of the diagonal term of the dense missing-call path
+__global__ void grm_elut_kernel(float *__restrict__ e, int64_t mk) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < mk) *reinterpret_cast<float4 *>(e + k * 4) = make_float4(0.f, 1.f, 0.f, 0.f);
+}
+int launch_grm_i8_lut(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, const uint32_t *luts, int64_t r0,
+                      int64_t r1, int nt128, double *d_acc, int64_t ld, const double *corr, double gscale);
 int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, int64_t r0, int64_t r1, int nt128,
                   double *d_acc, int64_t ld, const double *corr, bool panel, int tile_row_begin, int tile_row_end);
 int grm_missing_correction(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n_sel, int nt, const int32_t *rows2,
@@ -639,14 +698,23 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     // with the number of missing calls (nnz n table lookups), the split kernel's does not; measured at n = 20000,
     // m = 200000: 54 ms + 11.5 ms per 0.1 % against 229 ms, i.e. a crossover at ~1.5 %
     const double miss_max = getenv("JXGPU_GRM_MISS_MAX") ? atof(getenv("JXGPU_GRM_MISS_MAX")) : 0.012;
-    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb;
+    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb, lutab, lutbb, dfixb, elutb, dvecb;
+    // Rows that are affine in the count but hold missing calls, two forms: the SPARSE correction behind the
+    // clean int8 Gram (k_grm_miss.hip: nnz n table lookups -- 54 ms + 11.5 ms per 0.1 % of missing calls at n = 20 000,
+    // m = 200 000) up to JXGPU_GRM_MISS_DENSE_MIN (0.15 %) of missing calls, the DENSE two-Gram form above it: the missing
+    // call's count c* in two int8 digits, (30 B B' + A A') / 31 / 3136 with the byte LUTs B = (0, P1, 56, 112) and
+    // A = (0, P1 + P2, 56, 112) -- two int8 Gram products whatever the rate, 2e-7 of the mean diagonal at m = 200 000 (the
+    // quantisation noise of c* falls with sqrt(m): from JXGPU_GRM_MISS_DENSE_ROWS = 16 384 SNPs on).
+    const double dense_min = getenv("JXGPU_GRM_MISS_DENSE_MIN") ? atof(getenv("JXGPU_GRM_MISS_DENSE_MIN")) : 0.0015;
+    const int64_t dense_rows = getenv("JXGPU_GRM_MISS_DENSE_ROWS") ? atoll(getenv("JXGPU_GRM_MISS_DENSE_ROWS")) : 16384;
+    bool use_dense = false;
     if (lut16.alloc(sizeof(uint4) * (size_t)mk) || flagb.alloc(sizeof(int32_t) * (size_t)mk) ||
         betab.alloc(sizeof(double) * (size_t)mk) || ilutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
-        posb.alloc(sizeof(int32_t) * (size_t)mk) || infob.alloc(2 * sizeof(int32_t)) ||
+        posb.alloc(sizeof(int32_t) * (size_t)mk) || infob.alloc(4 * sizeof(int32_t)) ||
         rows2b.alloc(sizeof(int32_t) * (size_t)mk) || ilut2b.alloc(sizeof(float) * 4 * (size_t)mk) ||
         beta2b.alloc(sizeof(double) * (size_t)mk) || corrb.alloc(sizeof(double) * (size_t)(ld + 1)))
         return 1;
-    JX_HIP(hipMemsetAsync(infob.p, 0, 2 * sizeof(int32_t), st));
+    JX_HIP(hipMemsetAsync(infob.p, 0, 4 * sizeof(int32_t), st));
     const unsigned gk = (unsigned)((mk + 255) / 256);
     // rows that are affine in the count but hold missing calls: int8 Gram + sparse correction (k_grm_miss.hip) when the whole
     // triangle is built here (not a row panel), the int8 path is on and the missing calls are few enough (miss_max)
@@ -662,7 +730,12 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
             unsigned long long hm = 0;
             JX_HIP(hipMemcpyAsync(&hm, misstotb.p, sizeof(hm), hipMemcpyDeviceToHost, st));
             JX_HIP(hipStreamSynchronize(st));
-            if (hm == 0 || (double)hm > miss_max * (double)mk * (double)n_sel || hm > 0x7fffffffULL) use_miss = false;
+            const double rate = (double)hm / ((double)mk * (double)n_sel);
+            if (hm > 0 && rate >= dense_min && rate <= 0.06 && mk >= dense_rows) {
+                use_dense = true;          // flagged rows keep flag 2 and take the two-Gram form
+                use_miss = false;
+            }
+            if (!use_dense && (hm == 0 || (double)hm > miss_max * (double)mk * (double)n_sel || hm > 0x7fffffffULL)) use_miss = false;
             if (use_miss) {
                 // the correction needs an n_pad^2 f64 buffer + the lists (20 GB at n = 50 000, 80 GB at n = 100 000): decided
                 // HERE, while the flagged rows can still be handed to the general kernel -- once the int8 kernel has added
@@ -673,7 +746,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                 if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + ((size_t)2 << 30)) use_miss = false;
             }
         }
-        if (!use_miss) {
+        if (!use_miss && !use_dense) {
             hipLaunchKernelGGL(grm_demote_kernel, dim3(gk), dim3(256), 0, st, flagb.as<int32_t>(), mk);
             JX_LAUNCH_CHECK();
         }
@@ -686,13 +759,19 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                        infob.as<int32_t>());
     JX_LAUNCH_CHECK();
     if (use_miss && (miss2b.alloc((size_t)mk) || wlb.alloc(sizeof(double) * 4 * (size_t)mk))) return 1;
+    if (use_dense && (lutab.alloc(sizeof(uint32_t) * (size_t)mk) || lutbb.alloc(sizeof(uint32_t) * (size_t)mk) ||
+                      dfixb.alloc(sizeof(double) * (size_t)mk) || elutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
+                      dvecb.alloc(sizeof(double) * (size_t)(ld + 1))))
+        return 1;
     hipLaunchKernelGGL(grm_gather_kernel, dim3(gk), dim3(256), 0, st, d_rows, d_lut, ilutb.as<float>(),
                        betab.as<double>(), posb.as<int32_t>(), mk, infob.as<int32_t>(), rows2b.as<int32_t>(),
                        lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>(), i8_env, flagb.as<int32_t>(),
-                       use_miss ? miss2b.as<uint8_t>() : (uint8_t *)nullptr, use_miss ? wlb.as<double>() : (double *)nullptr);
+                       use_miss ? miss2b.as<uint8_t>() : (uint8_t *)nullptr, use_miss ? wlb.as<double>() : (double *)nullptr,
+                       use_dense ? lutab.as<uint32_t>() : (uint32_t *)nullptr, use_dense ? lutbb.as<uint32_t>() : (uint32_t *)nullptr,
+                       use_dense ? dfixb.as<double>() : (double *)nullptr);
     JX_LAUNCH_CHECK();
-    int32_t hinfo[2] = {0, 0};
-    JX_HIP(hipMemcpyAsync(hinfo, infob.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t hinfo[4] = {0, 0, 0, 0};
+    JX_HIP(hipMemcpyAsync(hinfo, infob.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
     if (hinfo[1]) return fail("jxg_grm_accumulate: design values exceed the fp16 split range (|z| > 3e4)");
     const int64_t n_exact = (int64_t)(hinfo[0] & ~63);
@@ -788,7 +867,30 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
         }
         return 0;
     };
-    if (i8_env) {
+    if (i8_env && use_dense) {
+        // clean rows [0, n_clean): counts as they are; rows with missing calls [n_clean, n_exact): the two Grams
+        const int64_t n_clean = std::min<int64_t>(hinfo[2], n_exact);
+        if (launch_grm_i8(st, d_p32, m_total, rows2, 0, n_clean, nt, d_acc, ld, n_clean > 0 ? corrb.as<double>() : nullptr,
+                          panel, tile_row_begin, tile_row_end))
+            return 1;
+        if (n_exact > n_clean) {
+            if (launch_grm_i8_lut(st, d_p32, m_total, rows2, lutbb.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld,
+                                  n_clean > 0 ? nullptr : corrb.as<double>(), (30.0 / 31.0) / 3136.0))
+                return 1;
+            if (launch_grm_i8_lut(st, d_p32, m_total, rows2, lutab.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld, nullptr,
+                                  (1.0 / 31.0) / 3136.0))
+                return 1;
+            // the diagonal exactly: sum over the SNPs a sample misses of dfix
+            hipLaunchKernelGGL(grm_elut_kernel, dim3((unsigned)((n_exact - n_clean + 255) / 256)), dim3(256), 0, st,
+                               elutb.as<float>(), n_exact - n_clean);
+            JX_LAUNCH_CHECK();
+            if (jxg_packed_dot(d_p32, m_total, n_sel, rows2 + n_clean, (int)(n_exact - n_clean), elutb.as<float>(),
+                               dfixb.as<double>() + n_clean, dvecb.as<double>(), st))
+                return 1;
+            hipLaunchKernelGGL(grm_diag_add_kernel, dim3((n_sel + 255) / 256), dim3(256), 0, st, d_acc, ld, n_sel, dvecb.as<double>());
+            JX_LAUNCH_CHECK();
+        }
+    } else if (i8_env) {
         if (launch_grm_i8(st, d_p32, m_total, rows2, 0, n_exact, nt, d_acc, ld, n_exact > 0 ? corrb.as<double>() : nullptr,
                           panel, tile_row_begin, tile_row_end))
             return 1;

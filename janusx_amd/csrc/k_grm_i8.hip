@@ -25,6 +25,8 @@
 //    MFMA are half those of a 128 x 128 tile); few tiles / row panels: 128 x 128 per 256-thread workgroup, 4 per CU.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -49,6 +51,17 @@ __device__ __forceinline__ u32x4v decode16_counts(uint32_t w) {
     return o;
 }
 
+// 16 two-bit codes -> 16 bytes through a per-SNP byte LUT (byte c of `lut` = value of code c): v_perm_b32 with the code bytes
+// as selectors.  Same byte order as decode16_counts.
+__device__ __forceinline__ u32x4v decode16_lut(uint32_t w, uint32_t lut) {
+    u32x4v o;
+    o.x = __builtin_amdgcn_perm(lut, lut, w & 0x03030303u);
+    o.y = __builtin_amdgcn_perm(lut, lut, (w >> 2) & 0x03030303u);
+    o.z = __builtin_amdgcn_perm(lut, lut, (w >> 4) & 0x03030303u);
+    o.w = __builtin_amdgcn_perm(lut, lut, (w >> 6) & 0x03030303u);
+    return o;
+}
+
 // MFMA operand of this lane (16 consecutive k of one position) from a [k][position] byte image: two transposed reads.
 // `lane_base` = image + (k0 + 16 (lane >> 5) + ((lane & 15) >> 1)) * PITCH + pos0 + 16 ((lane >> 4) & 1) + 8 (lane & 1).
 template <int PITCH>
@@ -64,11 +77,14 @@ __device__ __forceinline__ i32x4 tr8_frag(const uint8_t *lane_base) {
     return r;
 }
 
-template <int TM, int TN, int WM, int WN, int BK, bool DBUF, int MINW>
+// LUT = true: the operand bytes come from a per-SNP byte LUT `luts[k]` (byte c = value of the 2-bit code c; k = position in the
+// row list) instead of the counts {0, 0, 1, 2}, and the i32 Gram is scaled by `gscale` in the merge: the two-Gram form of rows
+// with missing calls (k_grm.hip, "dense missing-call path").
+template <int TM, int TN, int WM, int WN, int BK, bool DBUF, int MINW, bool LUT = false>
 __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), MINW) void grm_i8_kernel(
     const uint8_t *__restrict__ p32, int64_t m_total, const int32_t *__restrict__ rows, int64_t k_begin, int64_t k_end,
     int64_t kchunk, int nt128, double *__restrict__ acc, int64_t ld, int use_atomic, const double *__restrict__ corr,
-    int tile_base) {
+    int tile_base, const uint32_t *__restrict__ luts, double gscale) {
     static_assert(TM == TN, "square workgroup tiles");
     constexpr int NWN = TN / WN;
     constexpr int NTHREADS = 64 * (TM / WM) * NWN;
@@ -110,20 +126,29 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), MINW) void grm_i8_kerne
     const uint8_t *const baseB = p32 + (int64_t)(recB128 < nt128 ? recB128 : nt128 - 1) * m_total * 32 + 4 * (d_of & 7);
 
     int32_t rec[NL];                               // payload record (SNP row), loaded two steps ahead of its payload's use
+    uint32_t lutn[NL], lutw[NL];                   // LUT: the SNP's byte LUT, travelling with rec (lutn) and with the payload (lutw)
     uint32_t wA[NL], wB[NL];                       // payload dwords, loaded one step ahead of their decode
     auto load_rec = [&](int u, int64_t kbase) {
         const int64_t k = kbase + kk_of + u * KSTRIDE;
         rec[u] = rows[k < k1 ? k : k1 - 1];
+        if constexpr (LUT) lutn[u] = luts[k < k1 ? k : k1 - 1];
     };
     auto load_payload = [&](int u) {               // consumes rec[u]
         wA[u] = *reinterpret_cast<const uint32_t *>(baseA + (int64_t)rec[u] * 32);
         wB[u] = *reinterpret_cast<const uint32_t *>(baseB + (int64_t)rec[u] * 32);
+        if constexpr (LUT) lutw[u] = lutn[u];
     };
     auto decode_to = [&](uint8_t *base, int u, int64_t kbase) {     // payload of the step that starts at kbase
         const bool valid = kbase + kk_of + u * KSTRIDE < k1;
         const int o = (kk_of + u * KSTRIDE) * PITCH + d_of * 16;
-        *reinterpret_cast<u32x4v *>(base + o) = decode16_counts(wA[u] & (valid ? maskA : 0u));
-        *reinterpret_cast<u32x4v *>(base + IMG + o) = decode16_counts(wB[u] & (valid ? maskB : 0u));
+        if constexpr (LUT) {
+            // code 00 -> byte 0 of the LUT = 0: masked rows / tiles vanish as in the count decode
+            *reinterpret_cast<u32x4v *>(base + o) = decode16_lut(wA[u] & (valid ? maskA : 0u), lutw[u]);
+            *reinterpret_cast<u32x4v *>(base + IMG + o) = decode16_lut(wB[u] & (valid ? maskB : 0u), lutw[u]);
+        } else {
+            *reinterpret_cast<u32x4v *>(base + o) = decode16_counts(wA[u] & (valid ? maskA : 0u));
+            *reinterpret_cast<u32x4v *>(base + IMG + o) = decode16_counts(wB[u] & (valid ? maskB : 0u));
+        }
     };
 
     i32x16 c[MI][NI];
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), MINW) void grm_i8_kerne
                 if (gi < ld && gj < ld) {
                     double *dst = acc + gi * ld + gj;
                     double v = (double)c[mi][ni][r];
+                    if constexpr (LUT) v *= gscale;
                     if (add_corr) v += corr[gi] + corr_j;
                     if (use_atomic) {
                         unsafeAtomicAdd(dst, v);
@@ -259,7 +285,7 @@ int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int
             const int64_t ke = (kb + ((int64_t)1 << 29) < r1) ? kb + ((int64_t)1 << 29) : r1;
             hipLaunchKernelGGL((grm_i8_kernel<256, 256, 128, 64, 128, true, 2>), dim3((unsigned)ntl256, 1), dim3(512), 0, st,
                                p32, m_total, rows, kb, ke, (int64_t)1 << 29, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr,
-                               (int)base256);
+                               (int)base256, (const uint32_t *)nullptr, 1.0);
             JX_LAUNCH_CHECK();
         }
         return 0;
@@ -278,7 +304,7 @@ int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int
         const int64_t ny = (cnt + kc - 1) / kc;
         if (ny > 65535) return fail("jxg_grm_accumulate: too many chunks");
         hipLaunchKernelGGL((grm_i8_kernel<128, 128, 64, 64, 64, false, 4>), dim3((unsigned)ntiles, (unsigned)ny), dim3(256), 0,
-                           st, p32, m_total, rows, r0, r1, kc, nt128, d_acc, ld, 1, corr, (int)tile_base);
+                           st, p32, m_total, rows, r0, r1, kc, nt128, d_acc, ld, 1, corr, (int)tile_base, (const uint32_t *)nullptr, 1.0);
         JX_LAUNCH_CHECK();
         return 0;
     }
@@ -286,7 +312,32 @@ int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int
         const int64_t ke = (kb + ((int64_t)1 << 29) < r1) ? kb + ((int64_t)1 << 29) : r1;
         hipLaunchKernelGGL((grm_i8_kernel<128, 128, 64, 64, 64, false, 4>), dim3((unsigned)ntiles, 1), dim3(256), 0, st, p32,
                            m_total, rows, kb, ke, (int64_t)1 << 29, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr,
-                           (int)tile_base);
+                           (int)tile_base, (const uint32_t *)nullptr, 1.0);
+        JX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// The same Gram with the operand bytes taken from the per-SNP LUTs `luts` (positions r0 .. r1 of the list) and the i32 sums
+// scaled by `gscale`: whole lower triangle only (no row panels).  |byte| <= 127, so the i32 sums are exact for 2^31 / 127^2 SNPs:
+// chunks of 131072.
+int launch_grm_i8_lut(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, const uint32_t *luts, int64_t r0,
+                      int64_t r1, int nt128, double *d_acc, int64_t ld, const double *corr, double gscale) {
+    if (r1 <= r0) return 0;
+    const int nt256 = (nt128 + 1) / 2;
+    const int64_t ntl256 = (int64_t)nt256 * (nt256 + 1) / 2;
+    const int64_t ntiles = (int64_t)nt128 * (nt128 + 1) / 2;
+    if (ntiles > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
+    const int64_t kc = 131072;
+    const bool big = ntl256 >= 3 * 256;
+    for (int64_t kb = r0; kb < r1; kb += kc) {
+        const int64_t ke = std::min(r1, kb + kc);
+        if (big)
+            hipLaunchKernelGGL((grm_i8_kernel<256, 256, 128, 64, 128, true, 2, true>), dim3((unsigned)ntl256, 1), dim3(512), 0, st,
+                               p32, m_total, rows, kb, ke, kc, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr, 0, luts, gscale);
+        else
+            hipLaunchKernelGGL((grm_i8_kernel<128, 128, 64, 64, 64, false, 4, true>), dim3((unsigned)ntiles, 1), dim3(256), 0, st,
+                               p32, m_total, rows, kb, ke, kc, nt128, d_acc, ld, 0, kb == r0 ? corr : nullptr, 0, luts, gscale);
         JX_LAUNCH_CHECK();
     }
     return 0;

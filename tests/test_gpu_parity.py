@@ -3361,7 +3361,7 @@ def test_gblup_effect_from_meta_stream(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,m,rate", [(333, 900, 0.02), (700, 2100, 0.004), (129, 300, 0.2)])
+@pytest.mark.parametrize("n,m,rate", [(333, 900, 0.02), (700, 2100, 0.004), (129, 300, 0.2), (600, 24000, 0.01)])
 def test_grm_missing_calls_sparse_correction(oracle, monkeypatch, n, m, rate):
     """Rows with missing calls on the int8 Gram + sparse correction (csrc/k_grm_miss.hip; src/stats/grm.rs:1638-1772 with the
     mean-imputing decode of src/decode/decode.rs:813-839): forced on (`JXGPU_GRM_MISS_MAX=1`) against the oracle at TOL and against
@@ -3379,16 +3379,33 @@ def test_grm_missing_calls_sparse_correction(oracle, monkeypatch, n, m, rate):
         ref = oracle.grm_packed(pk, n, flip_k, maf_k, sub, 1)[0]
         monkeypatch.setenv("JXGPU_GRM_MISS", "1")
         monkeypatch.setenv("JXGPU_GRM_MISS_MAX", "1")
+        monkeypatch.setenv("JXGPU_GRM_MISS_DENSE_MIN", "1")          # sparse correction whatever the rate
         k1 = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
         k1b = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
+        # the DENSE two-Gram form (the default from 0.15 % missing calls on): the missing call's count in two int8 digits,
+        # (14 B B' + A A') / 15 on the int8 pipes, exact diagonal -- 3e-7 of the largest entry at most
+        monkeypatch.setenv("JXGPU_GRM_MISS_DENSE_MIN", "0")
+        monkeypatch.setenv("JXGPU_GRM_MISS_DENSE_ROWS", "1")         # (the default takes this form from 16 384 SNPs on)
+        k2 = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
+        k2b = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
         monkeypatch.setenv("JXGPU_GRM_MISS", "0")
         k0 = jxrs.grm_packed_f64(pk, n, flip_k, maf_k, sub, 1)
         scale = np.max(np.abs(ref))
-        assert np.array_equal(k1, k1b) and np.array_equal(k1, k1.T)
+        # few tiles and many SNPs (n = 600, m = 24 000): the int8 Gram splits the SNPs over blockIdx.y and merges with f64 atomics
+        # (exact i32 partial sums; only the f64 adds of the affine terms depend on the order): equal to 1e-14 there, bit for bit else
+        same = (lambda a, b: np.array_equal(a, b)) if m < 16384 else (lambda a, b: np.max(np.abs(a - b)) < 1e-13 * scale)
+        assert same(k1, k1b) and np.array_equal(k1, k1.T)
         assert np.max(np.abs(k1 - ref)) < TOL * scale, np.max(np.abs(k1 - ref)) / scale
         assert np.max(np.abs(k1 - k0)) < 5e-6 * scale, np.max(np.abs(k1 - k0)) / scale     # the split kernel drops lo x lo: ~1e-6
+        assert same(k2, k2b) and np.array_equal(k2, k2.T)
+        # c* resolved to 1 / 1736 of a count: the noise random-walks to ~sqrt(2 rate m) 1.7e-4 / (0.6 m) of the diagonal, i.e.
+        # 2e-6 at these tiny m (2e-7 at m = 200 000: test_full_size_c3_properties[0.01] runs this form)
+        assert np.max(np.abs(k2 - ref)) < (0.1 if m >= 16384 else 1.0) * TOL * scale, np.max(np.abs(k2 - ref)) / scale
+        assert np.max(np.abs(np.diag(k2) - np.diag(k1))) < 1e-9 * scale               # the diagonal is restored exactly
     monkeypatch.delenv("JXGPU_GRM_MISS")
     monkeypatch.delenv("JXGPU_GRM_MISS_MAX")
+    monkeypatch.delenv("JXGPU_GRM_MISS_DENSE_MIN")
+    monkeypatch.delenv("JXGPU_GRM_MISS_DENSE_ROWS")
 
 
 @pytest.mark.gpu

@@ -505,7 +505,7 @@ def main():
             roofline_main = {"bound": "mfma", "kernel": q2_kernel, "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
                              "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
-                             "traffic_over_algorithmic": (tr_q2 / (2.0 * 8.0 * float(n) ** 3 / 32.0)) if tr_q2 else None,
+                             "traffic_over_algorithmic": (tr_q2 / (2.0 * float(n) ** 3 / 8.0)) if tr_q2 else None,   # n^3 / 8 B each way
                              "traffic_over_result": (tr_q2 / (16.0 * float(n) * n)) if tr_q2 else None,
                              "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
                              "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "

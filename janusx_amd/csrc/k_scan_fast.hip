@@ -634,7 +634,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out,
-    const double *__restrict__ snp_coef = nullptr, const double *__restrict__ snp_ssq = nullptr) {
+    const double *__restrict__ snp_coef, const double *__restrict__ snp_ssq, const ChebHeader shd) {
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
     if (MAXD == 2) p = 1;     // dim = p + 1 <= 2 and p >= 1: a compile-time p (see lmm_scan_tiled_kernel)
     const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             res.ainv_kk = 0.0;
             if (fast_eval_lambda(xx, smin, n, p + 1) < 0.0) return;
             double acc[MAXD + 1];
-            series_eval_sums<MAXD>(xx, hd, sc, p, acc);
+            series_eval_sums<MAXD>(xx, shd, sc, p, acc);
             fast_eval_finish<MAXD>(xx, hd, coef, n, p, want_ainv, bmid, acc, res);
         };
         if (!isfinite(ssq) || ssq <= 1e-12) {
@@ -862,29 +862,31 @@ __global__ __launch_bounds__(64) void series_what_kernel(const double *__restric
     }
 }
 
-// coef[(r NQ + q) 64 + m] = sum_i g[r][i] mult_q[i] What[i][m];  ssq[r] = sum_i g[r][i]^2.
-// mult: q < p: x~ column q; q == p: the row itself; q == p + 1: y_c.  512 threads = 8 waves x 16 SNPs.
+// coef[(r nq + q) 64 + m] = sum_i g[r][i] mult_q[i] What[i][m] for the quantities q0 <= q < q0 + NQ of the nq = p + 2;
+// ssq[r] = sum_i g[r][i]^2 (written by the launch with q0 == 0).  mult: q < p: x~ column q; q == p: the row itself; q == p + 1: y_c.
+// 512 threads = 8 waves x 16 SNPs; more than four quantities per SNP (two or more covariates beside the intercept) take several
+// launches -- a pass over the rows each -- because 16 SNPs x NQ quantities x 64 entries of f64 accumulators are 32 NQ registers.
 template <int NQ>
-__global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__restrict__ grot, int nrows, int n, int npad,
-                                                             const double *__restrict__ xcov, const double *__restrict__ yc,
-                                                             const double *__restrict__ what, double *__restrict__ coef,
-                                                             double *__restrict__ ssq) {
+__global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__restrict__ grot, int nrows, int n, int npad, int p,
+                                                             int q0, const double *__restrict__ xcov,
+                                                             const double *__restrict__ yc, const double *__restrict__ what,
+                                                             double *__restrict__ coef, double *__restrict__ ssq) {
     typedef double d4v __attribute__((ext_vector_type(4)));
-    constexpr int P = NQ - 2;
     extern __shared__ __attribute__((aligned(16))) double sr_smem[];
     double *wt = sr_smem;                                         // [SR_SC][SR_WP]
-    double *mq = wt + SR_SC * SR_WP;                              // [P + 1][SR_SC]: x~ columns, then y_c
-    float *gt = reinterpret_cast<float *>(mq + (P + 1) * SR_SC);  // [128][SR_GP]
+    double *mq = wt + SR_SC * SR_WP;                              // [p + 1][SR_SC]: x~ columns, then y_c
+    float *gt = reinterpret_cast<float *>(mq + (p + 1) * SR_SC);  // [128][SR_GP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * 128;
+    const int nq = p + 2;
     // staging map: table chunk = 64 samples x 64 entries = 32 KB contiguous (4 x 16 B per thread); row chunk: thread = (row
-    // tid >> 2, 16 floats)
+    // tid >> 2, 16 floats); multipliers: (p + 1) x 64 doubles, up to two per thread
     const int grow = tid >> 2, gpart = tid & 3;
     const bool grow_ok = r0 + grow < nrows;
     const bool v4 = (n & 3) == 0;
     double2 wr[4];
     float4 gr[4];
-    double mr = 0.0;
+    double mr[2] = {0.0, 0.0};
     auto load_chunk = [&](int i0) {
         const double2 *wsrc = reinterpret_cast<const double2 *>(what + (int64_t)i0 * SR_M);
 #pragma unroll
@@ -910,9 +912,13 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
             }
             gr[u] = v;
         }
-        if (tid < (P + 1) * SR_SC) {
-            const int q = tid / SR_SC, i = i0 + tid % SR_SC;
-            mr = (i < n) ? (q < P ? xcov[(int64_t)i * P + q] : yc[i]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u;
+            if (e < (p + 1) * SR_SC) {
+                const int q = e / SR_SC, i = i0 + e % SR_SC;
+                mr[u] = (i < n) ? (q < p ? xcov[(int64_t)i * p + q] : yc[i]) : 0.0;
+            }
         }
     };
     auto store_chunk = [&]() {
@@ -924,7 +930,9 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(gt + grow * SR_GP + 16 * gpart + 4 * u) = gr[u];
-        if (tid < (P + 1) * SR_SC) mq[tid] = mr;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + 512 * u < (p + 1) * SR_SC) mq[tid + 512 * u] = mr[u];
     };
     d4v acc[NQ][4];
 #pragma unroll
@@ -934,6 +942,13 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
     double sq = 0.0;
     const int fi = lane & 15, fk = lane >> 4;                     // fragment row / column index and k index of this lane
     const float *grow_l = gt + (wave * 16 + fi) * SR_GP + fk;
+    // multiplier row of quantity q0 + q (the row itself for quantity p: flagged by -1)
+    int mrow[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int gq = q0 + q;
+        mrow[q] = (gq == p) ? -1 : (gq < p ? gq : p);
+    }
     load_chunk(0);
     for (int i0 = 0; i0 < npad; i0 += SR_SC) {
         __syncthreads();                                          // the previous chunk has been consumed
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
             sq = fma(gv, gv, sq);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const double mult = (q == P) ? gv : mq[(q < P ? q : P) * SR_SC + 4 * ks + fk];
+                const double mult = (mrow[q] < 0) ? gv : mq[mrow[q] * SR_SC + 4 * ks + fk];
                 const double bv = gv * mult;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[q][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[b], bv, acc[q][b], 0, 0, 0);
@@ -961,14 +976,16 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
     sq += __shfl_xor(sq, 16, 64);
     sq += __shfl_xor(sq, 32, 64);
     if (snp < nrows) {
-        if (fk == 0) ssq[snp] = sq;
-        double *o = coef + (int64_t)snp * NQ * SR_M;
+        if (fk == 0 && q0 == 0) ssq[snp] = sq;
+        double *o = coef + ((int64_t)snp * nq + q0) * SR_M;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
+            if (q0 + q < nq) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[q * SR_M + 16 * b + fk + 4 * r] = acc[q][b][r];
+                    for (int r = 0; r < 4; ++r) o[q * SR_M + 16 * b + fk + 4 * r] = acc[q][b][r];
+            }
     }
 }
 
@@ -977,6 +994,7 @@ __global__ __launch_bounds__(512, 2) void series_coef_kernel(const float *__rest
 template <int MAXD>
 __device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, const double *__restrict__ sc, int p,
                                                  double (&acc)[MAXD + 1]) {
+    // hd: the SERIES' own segmentation (series_header)
     const int lane = threadIdx.x & 63;
     int seg = (int)((x - hd.low) / hd.segw);
     if (seg < 0) seg = 0;
@@ -1405,16 +1423,27 @@ static ChebHeader make_header(int p, double low, double high) {
 
 // per-SNP series form (series_coef_kernel): plain evaluation tail (up to three covariates beside the SNP) and bounds of at most
 // two width-2 segments (the workflow's [log10 lambda0 - 2, + 2]); JXGPU_SCAN_SERIES=0 switches it off
-static bool series_ok(int p, const ChebHeader &hd) {
+// The series have their OWN segmentation -- width-2 segments whatever the evaluation tail: the block form's narrower segments
+// are about the conditioning of the tabulated Cholesky factor, the SNP-specific sums are plain sums.
+static ChebHeader series_header(double low, double high) {
+    ChebHeader hd;
+    hd.nseg = (int)ceil((high - low) / 2.0);
+    if (hd.nseg < 1) hd.nseg = 1;
+    hd.segw = (high - low) / hd.nseg;
+    hd.low = low;
+    hd.nf = 0;
+    return hd;
+}
+static bool series_ok(int p, double low, double high) {
     static const bool on = !(getenv("JXGPU_SCAN_SERIES") && atoi(getenv("JXGPU_SCAN_SERIES")) == 0);
-    return on && !cheb_blk(p) && p <= 3 && hd.nseg * CH_N <= SR_M;
+    return on && p >= 1 && p <= 14 && series_header(low, high).nseg * CH_N <= SR_M;
 }
 static int64_t series_npad(int n) { return ((int64_t)n + SR_SC - 1) / SR_SC * SR_SC; }
 
 extern "C" int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high) {
     if (!fast_path_ok(p, low, high)) return 0;
     const ChebHeader hd = make_header(p, low, high);
-    const int64_t what = series_ok(p, hd) ? series_npad(n) * SR_M : 0;     // What[i][m] behind the lambda-only tables
+    const int64_t what = series_ok(p, low, high) ? series_npad(n) * SR_M : 0;     // What[i][m] behind the lambda-only tables
     return (int64_t)sizeof(double) * (CH_HDR + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N + what);
 }
 
@@ -1438,10 +1467,10 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     hipLaunchKernelGGL(cheb_coef_kernel, dim3((total_funcs * CH_N + 255) / 256), dim3(256), 0, st, vals, total_funcs,
                        coef);
     JX_LAUNCH_CHECK();
-    if (series_ok(p, hd)) {
+    if (series_ok(p, low, high)) {
         double *what = vals + (int64_t)total_funcs * CH_N;
         const int npad = (int)series_npad(n);
-        hipLaunchKernelGGL(series_what_kernel, dim3((npad + 63) / 64), dim3(64), 0, st, d_s, n, npad, hd, what);
+        hipLaunchKernelGGL(series_what_kernel, dim3((npad + 63) / 64), dim3(64), 0, st, d_s, n, npad, series_header(low, high), what);
         JX_LAUNCH_CHECK();
     }
     return 0;
@@ -1463,7 +1492,11 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
     const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
     const bool lmm2 = with_plrt == 2;               // the two-search scan (out has six columns): tiled kernel at every n
-    const bool use_lds = !lmm2 && dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
+    const bool lds_fits = !lmm2 && dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
+    // per-SNP series form (one MFMA pass over the rows + Brent on the series) wherever s / X~ / y~ do not stay in LDS for the
+    // one-wave-per-SNP form (measured at n = 5000, intercept only: LDS-resident form 6.8 ms, series form 10.5 ms per 50 000 SNPs)
+    const bool series = !lmm2 && !lds_fits && series_ok(p, low, high) && !getenv("JXGPU_SCAN_NOTILE");
+    const bool use_lds = lds_fits;
     if (use_lds) {
         g_last_ms[11] = 0.f;
         if (dim <= 2) {
@@ -1478,7 +1511,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             if (grid > 65536) grid = 65536;
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr);
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd);
         } else {
             constexpr int NW = 8;
             auto kfn = lmm_scan_fast_kernel<4, NW, true>;
@@ -1491,17 +1524,18 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
             if (grid > 65536) grid = 65536;
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr);
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd);
         }
         JX_LAUNCH_CHECK();
         return 0;
     }
-    if (!lmm2 && series_ok(p, hd) && !getenv("JXGPU_SCAN_NOTILE")) {
-        // n beyond the LDS-resident limit, plain evaluation tail: ONE streaming pass over the rotated rows builds every SNP's
-        // Chebyshev series of its SNP-specific sums on the f64 matrix pipes, Brent then runs on the series
+    if (series) {
+        // n beyond the LDS-resident limit: ONE streaming pass over the rotated rows per group of four quantities builds every
+        // SNP's Chebyshev series of its SNP-specific sums on the f64 matrix pipes, Brent then runs on the series
         g_last_ms[11] = 3.f;
         hipStream_t st = (hipStream_t)stream;
         const int nq = p + 2;
+        const ChebHeader shd = series_header(low, high);
         static std::mutex mu;
         static DevBuf sbuf;                                  // series + sums of squares of one call (grown on demand)
         std::lock_guard<std::mutex> lk(mu);
@@ -1514,32 +1548,37 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         const double *what = coef + 2 * (int64_t)hd.nseg * hd.nf * CH_N;
         const int npad = (int)series_npad(n);
         const size_t lds = sizeof(double) * ((size_t)SR_SC * SR_WP + (size_t)(p + 1) * SR_SC) + sizeof(float) * 128 * SR_GP;
-#define JX_SERIES_COEF(NQV)                                                                                                \
+#define JX_SERIES_COEF(NQV, Q0)                                                                                            \
     do {                                                                                                                  \
         auto kfn = series_coef_kernel<NQV>;                                                                               \
         static bool attr_s = false;                                                                                       \
         if (!attr_s) {                                                                                                    \
-            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));        \
+            JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));        \
             attr_s = true;                                                                                                \
         }                                                                                                                 \
-        hipLaunchKernelGGL(kfn, dim3((nrows + 127) / 128), dim3(512), lds, st, d_grot, nrows, n, npad, d_xcov, yc, what,  \
-                           scoef, sssq);                                                                                  \
+        hipLaunchKernelGGL(kfn, dim3((nrows + 127) / 128), dim3(512), lds, st, d_grot, nrows, n, npad, p, Q0, d_xcov, yc,  \
+                           what, scoef, sssq);                                                                            \
+        JX_LAUNCH_CHECK();                                                                                                \
     } while (0)
-        if (nq == 3) JX_SERIES_COEF(3);
-        else if (nq == 4) JX_SERIES_COEF(4);
-        else JX_SERIES_COEF(5);
+        for (int q0 = 0; q0 < nq;) {
+            const int left = nq - q0;
+            if (left == 3) { JX_SERIES_COEF(3, q0); q0 += 3; }
+            else if (left >= 4) { JX_SERIES_COEF(4, q0); q0 += 4; }
+            else if (left == 2) { JX_SERIES_COEF(2, q0); q0 += 2; }
+            else { JX_SERIES_COEF(1, q0); q0 += 1; }
+        }
 #undef JX_SERIES_COEF
-        JX_LAUNCH_CHECK();
         constexpr int NW = 8;
         const int grid = (nrows + NW - 1) / NW;
-        if (dim <= 2)
-            hipLaunchKernelGGL((lmm_scan_fast_kernel<2, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,
-                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
-                               d_out, d_evals, (const double *)scoef, (const double *)sssq);
-        else
-            hipLaunchKernelGGL((lmm_scan_fast_kernel<4, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,
-                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
-                               d_out, d_evals, (const double *)scoef, (const double *)sssq);
+#define JX_SERIES_BRENT(MAXDV)                                                                                             \
+    hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,   \
+                       d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out,    \
+                       d_evals, (const double *)scoef, (const double *)sssq, shd)
+        if (dim <= 2) JX_SERIES_BRENT(2);
+        else if (dim <= 4) JX_SERIES_BRENT(4);
+        else if (dim <= 8) JX_SERIES_BRENT(8);
+        else JX_SERIES_BRENT(16);
+#undef JX_SERIES_BRENT
         JX_LAUNCH_CHECK();
         return 0;
     }
@@ -1598,7 +1637,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
                                               dim3(SCAN_THREADS), 0, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
                                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd,
                                               with_plrt, nullml, d_out, d_evals, (const double *)nullptr,
-                                              (const double *)nullptr));
+                                              (const double *)nullptr, hd));
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -18,6 +18,7 @@
 // Accumulators are double-buffered by column parity so no launch zeroes what a concurrent block still reads.
 #include <hip/hip_ext.h>
 #include <rocblas/rocblas.h>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -26,6 +27,9 @@
 #include "jx_common.h"
 
 namespace jx {
+
+int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a, int64_t lda, const double *b, int64_t ldb,
+                    double beta, double *c, int64_t ldc);
 
 constexpr int TD_NB = 64;     // panel width
 constexpr int TD_TS = 64;     // symv tile
@@ -820,10 +824,20 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
         const int n2 = n - j1;
         if (n2 > 0) {
             // T -= V W' + W V'  (lower), V = A(j1:n, j0:j1), W = w(j1:n, 0:pw)
-            rocblas_status rs = rocblas_dsyr2k(h, rocblas_fill_lower, rocblas_operation_none, n2, pw, &minus1,
-                                               d_a + j1 + (int64_t)j0 * n, n, P.w + j1, n, &one,
-                                               d_a + j1 + (int64_t)j1 * n, n);
-            if (rs != rocblas_status_success) return fail("rocblas_dsyr2k failed: " + std::to_string((int)rs));
+            // own f64 MFMA GEMM on the lower tiles (k_dgemm.hip), the two halves of the rank-2k update in turn; JXGPU_SYTRD_SYR2K=
+            // rocblas keeps the vendor routine for A/B runs
+            static const bool vendor = getenv("JXGPU_SYTRD_SYR2K") && strcmp(getenv("JXGPU_SYTRD_SYR2K"), "rocblas") == 0;
+            if (vendor) {
+                rocblas_status rs = rocblas_dsyr2k(h, rocblas_fill_lower, rocblas_operation_none, n2, pw, &minus1,
+                                                   d_a + j1 + (int64_t)j0 * n, n, P.w + j1, n, &one,
+                                                   d_a + j1 + (int64_t)j1 * n, n);
+                if (rs != rocblas_status_success) return fail("rocblas_dsyr2k failed: " + std::to_string((int)rs));
+            } else {
+                if (dsyr2k_lower_nt(st, n2, pw, -1.0, d_a + j1 + (int64_t)j0 * n, n, P.w + j1, n, 1.0, d_a + j1 + (int64_t)j1 * n, n))
+                    return 1;
+                if (dsyr2k_lower_nt(st, n2, pw, -1.0, P.w + j1, n, d_a + j1 + (int64_t)j0 * n, n, 1.0, d_a + j1 + (int64_t)j1 * n, n))
+                    return 1;
+            }
             if (getenv("JXGPU_EIGH_TRACE") && (j0 % (64 * TD_NB)) == 0) {
                 JX_HIP(hipStreamSynchronize(st));
                 fprintf(stderr, "[jxgpu sytrd n=%d] syr2k after column %d done\n", n, j0);

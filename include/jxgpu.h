@@ -135,6 +135,10 @@ int jxg_eigh_grid_check(int n);
 int64_t jxg_eigh_dist_staging_doubles(int n);
 int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                       int64_t staging_doubles, int min_n);
+/* on != 0: the following jxg_eigh_f64 calls of this process decompose matrices of its own (no collective, no sharding, the
+ * one-rank thresholds) although a distribution is registered; on = 0 restores it.  Used where a multi-rank job deals whole
+ * small problems over the ranks instead of sharding one (the diagonal blocks of the sparse GRM, janusx._SpectralSparseReml). */
+int jxg_eigh_set_local(int on);
 /* Node-level distribution of the two-stage path of B1 (one rank: n >= 1500; several ranks: n >= 10000): with rank / world set by jxg_eigh_set_dist and a
  * gather callback registered here, every rank runs the (bit-reproducible) reduction stages and the divide and conquer on
  * the same matrix, back-transforms only the eigenvectors [n r / world, n (r + 1) / world) -- two thirds of the flops of
@@ -583,6 +587,16 @@ int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_samples, co
                              const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
                              double threshold, int abs_threshold, int stream_denominator, const char *out_path,
                              int64_t *out_n, int64_t *out_nnz);
+
+/* Several processes (one per GPU) build ONE sparse GRM (BASELINE.json configs[5]; the reference has no counterpart: its
+ * tile plan runs on the threads of one process, src/stats/spgrm.rs:3769-3908).  jx_spgrm_set_part(part, nparts) makes the
+ * next jx_spgrm_packed_to_jxgrm call of this process compute only the row panels dealt to `part` (back and forth over the
+ * parts, so that the cost of the lower triangle's rows is even) and leave them in `<out_path>.part<part>` (out_nnz = the
+ * entries of the part); after a barrier one process calls jx_spgrm_merge_parts, which joins the nparts files into the
+ * `.spgrm` file of `write_sparse_grm_csc` (:3745-3767) -- byte-identical to the file of a single process -- and removes
+ * them.  (0, 1) switches the mode off. */
+int jx_spgrm_set_part(int part, int nparts);
+int jx_spgrm_merge_parts(const char *out_path, int n, int nparts, int64_t *out_nnz);
 
 /* Haseman-Elston sufficient statistics over the same matrix-free operator (`he_pcg_bed`, src/stats/he.rs:1633-2070,
  * 2101-2636): K = Z'Z / m_scale on the training samples, P the projector off [1, x_cov] (x_cov (n_train, p_cov)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "jxg_eigh_grid_check": [c_i],
     "jxg_eigh_dist_staging_doubles": [c_i],
     "jxg_eigh_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l, c_i],
+    "jxg_eigh_set_local": [c_i],
     "jxg_eigh_set_gather": [c_p, c_p],
     "jxg_eigh_set_agree": [c_p, c_p],
     "jxg_eigh_last_dist_agree": [],
@@ -112,6 +113,8 @@ SIGNATURES = {
     "jx_fvlmm_assoc_chunk": [c_p, c_p, c_p, c_i, c_i, c_d, c_p, c_l, c_p, c_i, c_d, c_p],
     "jx_gblup_reml_grm": [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_d, c_i, c_p, c_p, c_p],
     "jx_spgrm_packed_to_jxgrm": [c_p, c_l, c_i, c_p, c_p, c_p, c_i, c_i, c_d, c_i, c_i, C.c_char_p, c_p, c_p],
+    "jx_spgrm_set_part": [c_i, c_i],
+    "jx_spgrm_merge_parts": [C.c_char_p, c_i, c_i, c_p],
     "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
     "jx_pcg_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l],
     "jx_pcg_dist_count": [],

@@ -149,8 +149,8 @@ def cmd_grm(args):
     from .bed import read_fam_ids
     if args.grm is None and not args.bfile:
         raise SystemExit("grm needs -bfile PREFIX (or -grm FILE.npy -sparse [cutoff])")
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and (args.grm is not None or args.sparse is not None):
-        raise SystemExit("the sparse-GRM routes run on one GPU: start them without the launcher")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.grm is not None:
+        raise SystemExit("thresholding an existing dense GRM runs on one GPU: start it without the launcher")
     out = _resolve_out(args, args.bfile or args.grm)
     t0 = time.perf_counter()
     if args.grm is not None:
@@ -170,14 +170,17 @@ def cmd_grm(args):
               f"({time.perf_counter() - t0:.2f}s)")
         return 0
     if args.sparse is not None:
-        # python/janusx/script/grm.py:1574-1675 (`-sparse [cutoff]`): thresholded lower-triangle CSC `.spgrm` + `.id`
+        # python/janusx/script/grm.py:1574-1675 (`-sparse [cutoff]`): thresholded lower-triangle CSC `.spgrm` + `.id`; under
+        # the launcher the row panels of the matrix are dealt over the ranks (janusx._spgrm_packed)
+        rank, world = _dist_setup()
         path, n, nnz = jxrs.spgrm_bed_to_jxgrm(args.bfile, out_prefix=out, method=args.method,
                                                threshold=float(args.sparse), maf_threshold=args.maf,
                                                max_missing_rate=args.geno, het_threshold=0.0,
                                                snps_only=bool(getattr(args, "snps_only", False)))
-        with open(path + ".id", "w") as fh:
-            for sid in read_fam_ids(args.bfile):
-                fh.write(f"{sid}\n")
+        if rank == 0:
+            with open(path + ".id", "w") as fh:
+                for sid in read_fam_ids(args.bfile):
+                    fh.write(f"{sid}\n")
         print(f"Sparse GRM method {args.method}: n={n} nnz={nnz} cutoff={args.sparse} -> {path} "
               f"({time.perf_counter() - t0:.2f}s)")
         return 0
@@ -316,8 +319,6 @@ def cmd_gwas(args):
     if not (args.lmm or args.fvlmm or args.lmm2 or args.splmm is not None):
         raise SystemExit("select at least one model: -lmm, -lmm2, -fvlmm, -splmm and/or -splmm-exact")
     rank, world = _dist_setup()
-    if world > 1 and args.splmm is not None:
-        raise SystemExit("the SparseLMM routes run on one GPU: start -splmm / -splmm-exact without the launcher")
     # the payload goes to HBM in windows (bed.stage_bed_payload: `mmap_window_mb` of the reference's BED routes); nothing
     # below holds a host copy of it
     from .bed import stage_bed_payload
@@ -439,9 +440,10 @@ def cmd_gwas(args):
                                                          threshold=float(args.splmm), maf_threshold=args.maf,
                                                          max_missing_rate=args.geno, het_threshold=0.0,
                                                          snps_only=bool(getattr(args, "snps_only", False)))
-            with open(sparse_path + ".id", "w") as fh:
-                for sid in fam:
-                    fh.write(f"{sid}\n")
+            if rank == 0:
+                with open(sparse_path + ".id", "w") as fh:
+                    for sid in fam:
+                        fh.write(f"{sid}\n")
             print(f"Sparse GRM cutoff={args.splmm}: nnz={nnz} -> {sparse_path} ({time.perf_counter() - t0:.2f}s)")
     for ti in traits:
         name = names[ti]
@@ -545,7 +547,8 @@ def cmd_gwas(args):
                     stats, l10, null = jxrs.splmm_exact_scan_from_jxgrm(
                         sparse_path, y, packed, n_fam, maf_all, np.zeros(packed.shape[0], dtype=bool), xc, sidx, kept,
                         grid_size=17, tol=1e-3, max_iter=20, grm_sample_indices=grm_idx)
-                    write_assoc_tsv(path, *meta, af[kept], miss[kept], stats)
+                    if rank == 0:
+                        write_assoc_tsv(path, *meta, af[kept], miss[kept], stats)
                     print(f"[{name}] -{'splmm-exact' if stem == 'splmm2' else 'splmm (exact scan)'}: n={n} snps={len(kept)} "
                           f"lambda0={null[0]:.5g} sigma_g2={null[1]:.4g} sigma_e2={null[2]:.4g} -> {path} "
                           f"({time.perf_counter() - t2:.2f}s)")

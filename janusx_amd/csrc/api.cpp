@@ -330,6 +330,111 @@ extern "C" int jxg_spgrm_fill(const double *d_acc, int n, double inv_scale, doub
                               const void *d_work, const uint64_t *d_colptr, uint32_t *d_rows, double *d_vals,
                               void *stream);
 
+// ---- sparse GRM by row panels: entries of a panel, merge + file writer, part files for several ranks ---------------------
+namespace {
+struct PanelEntries {
+    int64_t index = 0;                 // position of the panel (rows ascend with it)
+    std::vector<uint64_t> cp;          // n + 1 offsets into r / v
+    std::vector<uint32_t> r;
+    std::vector<double> v;
+};
+// (part, nparts) of this process for jx_spgrm_packed_to_jxgrm: with nparts > 1 the row panels are dealt cyclically, a process
+// builds only its own and writes them to `<out>.part<k>`; jx_spgrm_merge_parts joins the files (jx_spgrm_set_part)
+int g_spgrm_part = 0, g_spgrm_nparts = 1;
+
+// write_sparse_grm_csc (src/stats/spgrm.rs:3745-3767): u64 n, u64 nnz, col_ptr, row_indices, zero padding to 8 bytes, values (LE);
+// the panels (ascending index) are merged column by column (rows ascend with the panels, so the order inside a column is kept)
+int spgrm_merge_write(const std::vector<PanelEntries> &panels, int n, const char *out_path, uint64_t *out_nnz) {
+    std::vector<uint64_t> colptr((size_t)n + 1);
+    uint64_t nnz = 0;
+    for (const auto &pe : panels) nnz += pe.cp[(size_t)n];
+    colptr[0] = 0;
+    for (int c = 0; c < n; ++c) {
+        uint64_t k = 0;
+        for (const auto &pe : panels) k += pe.cp[(size_t)c + 1] - pe.cp[(size_t)c];
+        colptr[(size_t)c + 1] = colptr[(size_t)c] + k;
+    }
+    std::vector<uint32_t> rows;
+    std::vector<double> vals;
+    try {
+        rows.resize((size_t)nnz);
+        vals.resize((size_t)nnz);
+    } catch (const std::bad_alloc &) {
+        return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
+    }
+    std::vector<uint64_t> cursor(colptr.begin(), colptr.end() - 1);
+    for (const auto &pe : panels)
+        for (int c = 0; c < n; ++c)
+            for (uint64_t k = pe.cp[(size_t)c]; k < pe.cp[(size_t)c + 1]; ++k) {
+                rows[(size_t)cursor[(size_t)c]] = pe.r[(size_t)k];
+                vals[(size_t)cursor[(size_t)c]++] = pe.v[(size_t)k];
+            }
+    FILE *fh = fopen(out_path, "wb");
+    if (!fh) return fail(std::string("create ") + out_path + " failed");
+    const uint64_t hdr[2] = {(uint64_t)n, nnz};
+    const size_t pad = (size_t)((8 - ((nnz * 4) & 7)) & 7);
+    const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = fwrite(hdr, 8, 2, fh) == 2 && fwrite(colptr.data(), 8, colptr.size(), fh) == colptr.size() &&
+              fwrite(rows.data(), 4, rows.size(), fh) == rows.size() && fwrite(zeros, 1, pad, fh) == pad &&
+              fwrite(vals.data(), 8, vals.size(), fh) == vals.size();
+    const int werr = ok ? 0 : errno;
+    const bool closed = fclose(fh) == 0;
+    if (!ok || !closed) {
+        const int e = ok ? errno : werr;
+        remove(out_path);
+        return fail(std::string("write sparse GRM file failed: ") + out_path + " (" + std::to_string(nnz) + " entries, " +
+                    strerror(e) + ")");
+    }
+    if (out_nnz) *out_nnz = nnz;
+    return 0;
+}
+}  // namespace
+
+// Several processes (one per GPU) build ONE sparse GRM: process `part` of `nparts` computes the row panels p = part (mod nparts)
+// in its next jx_spgrm_packed_to_jxgrm call and leaves them in `<out>.part<part>`; after a barrier ONE process calls
+// jx_spgrm_merge_parts(out, n, nparts).  (0, 1): off.
+extern "C" int jx_spgrm_set_part(int part, int nparts) {
+    if (nparts < 1 || part < 0 || part >= nparts) return fail("jx_spgrm_set_part: bad part / nparts");
+    g_spgrm_part = part;
+    g_spgrm_nparts = nparts;
+    return 0;
+}
+
+extern "C" int jx_spgrm_merge_parts(const char *out_path, int n, int nparts, int64_t *out_nnz) {
+    if (!out_path || !out_path[0] || n <= 0 || nparts < 1) return fail("jx_spgrm_merge_parts: bad arguments");
+    std::vector<PanelEntries> panels;
+    for (int k = 0; k < nparts; ++k) {
+        const std::string path = std::string(out_path) + ".part" + std::to_string(k);
+        FILE *fh = fopen(path.c_str(), "rb");
+        if (!fh) return fail("jx_spgrm_merge_parts: " + path + " is missing");
+        uint64_t hdr[2] = {0, 0};
+        bool ok = fread(hdr, 8, 2, fh) == 2 && hdr[0] == (uint64_t)n;
+        for (uint64_t q = 0; ok && q < hdr[1]; ++q) {
+            PanelEntries pe;
+            uint64_t idx = 0;
+            pe.cp.resize((size_t)n + 1);
+            ok = fread(&idx, 8, 1, fh) == 1 && fread(pe.cp.data(), 8, pe.cp.size(), fh) == pe.cp.size();
+            if (!ok) break;
+            pe.index = (int64_t)idx;
+            const uint64_t pn = pe.cp[(size_t)n];
+            pe.r.resize((size_t)pn);
+            pe.v.resize((size_t)pn);
+            ok = fread(pe.r.data(), 4, (size_t)pn, fh) == (size_t)pn && fread(pe.v.data(), 8, (size_t)pn, fh) == (size_t)pn;
+            panels.push_back(std::move(pe));
+        }
+        fclose(fh);
+        if (!ok) return fail("jx_spgrm_merge_parts: " + path + " is truncated or belongs to another matrix");
+    }
+    std::sort(panels.begin(), panels.end(), [](const PanelEntries &a, const PanelEntries &b) { return a.index < b.index; });
+    for (size_t q = 1; q < panels.size(); ++q)
+        if (panels[q].index == panels[q - 1].index) return fail("jx_spgrm_merge_parts: a panel appears twice");
+    uint64_t nnz = 0;
+    if (spgrm_merge_write(panels, n, out_path, &nnz)) return 1;
+    for (int k = 0; k < nparts; ++k) remove((std::string(out_path) + ".part" + std::to_string(k)).c_str());
+    if (out_nnz) *out_nnz = (int64_t)nnz;
+    return 0;
+}
+
 extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
                                         const float *row_maf, const int64_t *sample_indices, int n_sel, int method,
                                         double threshold, int abs_threshold, int stream_denominator,
@@ -372,6 +477,9 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
     int64_t panel_rows = 0;
     if (env_rows && atoll(env_rows) > 0) panel_rows = atoll(env_rows);
     else if ((double)npad * (double)npad * 8.0 > acc_gb * 1073741824.0) panel_rows = (int64_t)(32.0 * 1073741824.0 / (8.0 * npad));
+    const int nparts = g_spgrm_nparts, part = g_spgrm_part;
+    if (nparts > 1 && panel_rows <= 0)      // several processes: about four panels each (the same plan on every one of them)
+        panel_rows = std::max<int64_t>(256, ((int64_t)n / (4 * nparts)) / 256 * 256);
     if (panel_rows > 0) {
         panel_rows = std::max<int64_t>(256, (panel_rows / 256) * 256);
         const int nbands = (n + 255) / 256;
@@ -379,13 +487,12 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
         if (acc.alloc(sizeof(double) * (size_t)(panel_rows * npad))) return 1;
         if (work.alloc((size_t)((int64_t)bands_per * n * 4 + 16))) return 1;
         if (dcolptr.alloc(sizeof(uint64_t) * ((size_t)n + 1))) return 1;
-        struct PanelEntries {
-            std::vector<uint64_t> cp;
-            std::vector<uint32_t> r;
-            std::vector<double> v;
-        };
         std::vector<PanelEntries> panels;
-        for (int b0 = 0; b0 < nbands; b0 += bands_per) {
+        int64_t pidx = 0;
+        for (int b0 = 0; b0 < nbands; b0 += bands_per, ++pidx) {
+            // dealt back and forth (0 .. nparts-1, nparts-1 .. 0, ...): a panel's cost grows with its row index (lower triangle)
+            const int64_t round = pidx / nparts, pos = pidx % nparts;
+            if (((round & 1) ? nparts - 1 - pos : pos) != part) continue;          // another process's panel
             const int b1 = std::min(nbands, b0 + bands_per);
             const int t0 = b0 * 2, t1 = std::min((int)num_tiles(n), b1 * 2);       // 128-row tiles of the bands
             JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)((int64_t)(t1 - t0) * JXG_TILE * npad)));
@@ -396,6 +503,7 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
                                       dcolptr.as<uint64_t>(), nullptr))
                 return 1;
             PanelEntries pe;
+            pe.index = pidx;
             pe.cp.resize((size_t)n + 1);
             JX_HIP(hipMemcpy(pe.cp.data(), dcolptr.p, sizeof(uint64_t) * pe.cp.size(), hipMemcpyDeviceToHost));
             const uint64_t pn = pe.cp[(size_t)n];
@@ -418,25 +526,32 @@ extern "C" int jx_spgrm_packed_to_jxgrm(const uint8_t *packed, int64_t m, int n_
             panels.push_back(std::move(pe));
         }
         p32.release();
-        colptr[0] = 0;
-        for (int c = 0; c < n; ++c) {
-            uint64_t k = 0;
-            for (const auto &pe : panels) k += pe.cp[(size_t)c + 1] - pe.cp[(size_t)c];
-            colptr[(size_t)c + 1] = colptr[(size_t)c] + k;
+        if (nparts > 1) {
+            // this process's panels only: left in `<out>.part<k>` for jx_spgrm_merge_parts
+            const std::string path = std::string(out_path) + ".part" + std::to_string(part);
+            FILE *fh = fopen(path.c_str(), "wb");
+            if (!fh) return fail("create " + path + " failed");
+            const uint64_t hdr[2] = {(uint64_t)n, (uint64_t)panels.size()};
+            bool ok = fwrite(hdr, 8, 2, fh) == 2;
+            for (const auto &pe : panels) {
+                const uint64_t idx = (uint64_t)pe.index;
+                ok = ok && fwrite(&idx, 8, 1, fh) == 1 && fwrite(pe.cp.data(), 8, pe.cp.size(), fh) == pe.cp.size() &&
+                     fwrite(pe.r.data(), 4, pe.r.size(), fh) == pe.r.size() && fwrite(pe.v.data(), 8, pe.v.size(), fh) == pe.v.size();
+            }
+            const bool closed = fclose(fh) == 0;
+            if (!ok || !closed) {
+                remove(path.c_str());
+                return fail("write sparse GRM part file failed: " + path);
+            }
+            if (out_n) *out_n = n;
+            if (out_nnz) *out_nnz = (int64_t)nnz;
+            return 0;
         }
-        try {
-            rows.resize((size_t)nnz);
-            vals.resize((size_t)nnz);
-        } catch (const std::bad_alloc &) {
-            return fail("Sparse GRM: host allocation of " + std::to_string(nnz) + " entries failed");
-        }
-        std::vector<uint64_t> cursor(colptr.begin(), colptr.end() - 1);
-        for (const auto &pe : panels)
-            for (int c = 0; c < n; ++c)
-                for (uint64_t k = pe.cp[(size_t)c]; k < pe.cp[(size_t)c + 1]; ++k) {
-                    rows[(size_t)cursor[(size_t)c]] = pe.r[(size_t)k];
-                    vals[(size_t)cursor[(size_t)c]++] = pe.v[(size_t)k];
-                }
+        uint64_t total = 0;
+        if (spgrm_merge_write(panels, n, out_path, &total)) return 1;
+        if (out_n) *out_n = n;
+        if (out_nnz) *out_nnz = (int64_t)total;
+        return 0;
     } else {
         if (acc.alloc(sizeof(double) * (size_t)(npad * npad))) return 1;
         JX_HIP(hipMemset(acc.p, 0, sizeof(double) * (size_t)(npad * npad)));

@@ -58,6 +58,7 @@ int ormtr_prepare(hipStream_t st, const double *d_a, int n, int off, int nref, c
 int ormtr_apply(hipStream_t st, const OrmtrPlan &plan, double *d_c, int ncols);
 int sytrd_dist_active(int n);
 void sytrd_dist_rank(int *rank, int *world);
+void sytrd_dist_pause(int on);
 int launch_gather_cols_range(const double *src, const int *d_perm, int n, int count, double *dst, hipStream_t st);
 // Node-level distribution of the two-stage path (jxg_eigh_set_gather): reduction stages and divide and conquer run
 // replicated (bit-reproducible kernels, identical inputs), every rank back-transforms its own share of the eigenvectors
@@ -94,6 +95,13 @@ using namespace jx;
 // matrix; from `min_n` rows on each rank streams 1 / world of the tiles per column and `allreduce(user)` has to sum the
 // `jxg_eigh_dist_staging_doubles(n)` doubles at `d_staging` over the ranks on the stream passed to jxg_eigh_f64.
 extern "C" int64_t jxg_eigh_dist_staging_doubles(int n) { return (int64_t)n + 32 * 16 + 2 * 64; }
+
+// A rank of a multi-rank job decomposes matrices of its OWN between on = 1 and on = 0 (the diagonal blocks of a sparse GRM, dealt
+// over the ranks by the caller): no collective, no sharding, the one-rank thresholds.  The registered callbacks stay in place.
+extern "C" int jxg_eigh_set_local(int on) {
+    jx::sytrd_dist_pause(on);
+    return 0;
+}
 
 extern "C" int jxg_eigh_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging,
                                  int64_t staging_doubles, int min_n) {

@@ -691,6 +691,7 @@ struct SytrdDist {
     int min_n = 16384;
 };
 static SytrdDist g_dist;
+static bool g_dist_paused = false;   // jxg_eigh_set_local: this rank decomposes a matrix of its own (no collective) for a while
 
 extern float g_last_ms[16];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
 
@@ -735,7 +736,7 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
     // JXGPU_DIST_EIGH_FORCE: run the distributed instantiation and the collective with a single rank too (how the RCCL
     // callback path is exercised on a one-GPU box)
     static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
-    const bool dist_on = (g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n &&
+    const bool dist_on = !g_dist_paused && (g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n &&
                          g_dist.staging_doubles >= (int64_t)red_doubles;
     if (dist_on) {
         JX_HIP(hipMemsetAsync(P.s1count, 0, 8 * sizeof(double), st));
@@ -895,13 +896,15 @@ int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_
 // whether sytrd_lower would deal the symv tiles of an n-row problem over ranks (the eigensolver then keeps the one-stage form)
 int sytrd_dist_active(int n) {
     static const bool force_single = getenv("JXGPU_DIST_EIGH_FORCE") && atoi(getenv("JXGPU_DIST_EIGH_FORCE")) != 0;
-    return ((g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n) ? 1 : 0;
+    return (!g_dist_paused && (g_dist.world > 1 || force_single) && g_dist.allreduce && n >= g_dist.min_n) ? 1 : 0;
 }
 
 void sytrd_dist_rank(int *rank, int *world) {
-    *rank = g_dist.rank;
-    *world = g_dist.world;
+    *rank = g_dist_paused ? 0 : g_dist.rank;
+    *world = g_dist_paused ? 1 : g_dist.world;
 }
+
+void sytrd_dist_pause(int on) { g_dist_paused = on != 0; }
 
 int sytrd_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *staging, int64_t staging_doubles,
                    int min_n) {

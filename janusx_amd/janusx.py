@@ -206,11 +206,51 @@ def _spgrm_packed(packed, n_samples, row_flip, row_maf, out_prefix, sample_indic
     if not out_path:
         raise RuntimeError("Sparse GRM output prefix must not be empty")
     out_n, out_nnz = C.c_int64(0), C.c_int64(0)
-    check(lib().jx_spgrm_packed_to_jxgrm(pk_ptr, m, n_samples, _p(flip), _p(maf), _p(idx) if idx is not None else None,
-                                         n_sel, int(method), float(threshold), int(bool(abs_threshold)),
-                                         int(bool(stream_denominator)), out_path.encode(), C.byref(out_n),
-                                         C.byref(out_nnz)))
+    from .pipeline import dist_info
+    rank, world = dist_info()
+    if world > 1:
+        # one process per GPU (SURVEY.md 8(e), configs[5]): the row panels of the lower triangle are dealt over the ranks, every
+        # rank thresholds its own and leaves them in `<out>.part<rank>`; rank 0 joins the parts into the one `.spgrm` file (the
+        # output directory is shared: one node).  No data-path collective: two barriers around the merge.
+        import torch.distributed as dist
+        check(lib().jx_spgrm_set_part(rank, world))
+    try:
+        check(lib().jx_spgrm_packed_to_jxgrm(pk_ptr, m, n_samples, _p(flip), _p(maf), _p(idx) if idx is not None else None,
+                                             n_sel, int(method), float(threshold), int(bool(abs_threshold)),
+                                             int(bool(stream_denominator)), out_path.encode(), C.byref(out_n),
+                                             C.byref(out_nnz)))
+    finally:
+        if world > 1:
+            lib().jx_spgrm_set_part(0, 1)
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            check(lib().jx_spgrm_merge_parts(out_path.encode(), int(out_n.value), world, C.byref(out_nnz)))
+        dist.barrier()
+        nnz_t = _bcast_int(int(out_nnz.value))
+        return out_path, int(out_n.value), nnz_t
     return out_path, int(out_n.value), int(out_nnz.value)
+
+
+def _bcast_int(v):
+    """Rank 0's integer on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(v)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(t, src=0)
+    return int(t.cpu()[0])
+
+
+def _scan_my_rows(scan, rows, lut):
+    """SNP-sharded SparseLMM scan: `scan(rows, lut)` over this rank's contiguous share of the rows, the per-rank tables
+    concatenated in rank (= row) order on every rank.  One rank: the plain call."""
+    from . import pipeline as pl
+    if pl.dist_info()[1] == 1:
+        return scan(rows, lut)
+    lo, hi = pl._my_slice(len(rows), False)
+    return pl.gather_results(scan(rows[lo:hi], lut[lo:hi]).contiguous())
 
 
 def spgrm_packed_to_jxgrm(packed, n_samples, row_flip, row_maf, out_prefix, sample_indices=None, method=1,
@@ -830,23 +870,59 @@ class _SpectralSparseReml:
         s_all = np.empty(n, dtype=np.float64)
         rot_all = np.empty((n, 1 + self.p), dtype=np.float64)
         blocks = []
-        for b in range(len(fill)):
-            o0, o1 = int(offs[b]), int(offs[b + 1])
-            nb = o1 - o0
-            mp = np.full(n_all, -1, dtype=np.int32)
-            mp[glob[o0:o1]] = np.arange(nb, dtype=np.int32)
-            d_map = torch.from_numpy(mp).to(dev)
-            kb = torch.empty((nb, nb), dtype=torch.float64, device=dev)
-            check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all), d_map.data_ptr(), nb,
-                                          kb.data_ptr(), pl._stream()))
-            if nb == 1:                                  # a lone sample: its own eigenpair
-                sb, utb = kb.reshape(1).clone(), torch.ones((1, 1), dtype=torch.float64, device=dev)
-            else:
-                sb, utb = pl.eigh_from_grm(kb, ridge=0.0)
-            del kb
-            s_all[o0:o1] = sb.cpu().numpy()
-            rot_all[o0:o1] = (utb @ torch.from_numpy(yx[o0:o1]).to(dev)).cpu().numpy()
-            blocks.append((o0, nb, utb))
+        # several ranks: the blocks are dealt over the ranks (largest first, each to the rank with the least n^3 so far), a rank
+        # decomposes its own with the eigensolver's distribution paused (jxg_eigh_set_local) and the owner's (s, U) go to
+        # everybody afterwards: same bits on every rank, the decompositions of the null fit in 1 / world of the time
+        rank, world = pl.dist_info()
+        owner = np.zeros(len(fill), dtype=np.int64)
+        if world > 1:
+            load = np.zeros(world)
+            for b in np.argsort(-fill, kind="stable"):
+                owner[b] = int(np.argmin(load))
+                load[owner[b]] += float(fill[b]) ** 3
+            check(lib().jxg_eigh_set_local(1))
+        try:
+            for b in range(len(fill)):
+                o0, o1 = int(offs[b]), int(offs[b + 1])
+                nb = o1 - o0
+                if owner[b] != rank:
+                    blocks.append((o0, nb, torch.empty((nb, nb), dtype=torch.float64, device=dev)))
+                    continue
+                mp = np.full(n_all, -1, dtype=np.int32)
+                mp[glob[o0:o1]] = np.arange(nb, dtype=np.int32)
+                d_map = torch.from_numpy(mp).to(dev)
+                kb = torch.empty((nb, nb), dtype=torch.float64, device=dev)
+                check(lib().jxg_spgrm_densify(d_cp.data_ptr(), d_ri.data_ptr(), d_va.data_ptr(), int(n_all), d_map.data_ptr(), nb,
+                                              kb.data_ptr(), pl._stream()))
+                if nb == 1:                                  # a lone sample: its own eigenpair
+                    sb, utb = kb.reshape(1).clone(), torch.ones((1, 1), dtype=torch.float64, device=dev)
+                else:
+                    sb, utb = pl.eigh_from_grm(kb, ridge=0.0)
+                del kb
+                s_all[o0:o1] = sb.cpu().numpy()
+                blocks.append((o0, nb, utb))
+        finally:
+            if world > 1:
+                lib().jxg_eigh_set_local(0)
+        if world > 1:
+            import torch.distributed as dist
+            through_host = dist.get_backend() != "nccl"        # functional mode on shared GPUs (gloo): through host memory
+            s_t = torch.from_numpy(s_all)
+            for b, (o0, nb, utb) in enumerate(blocks):
+                src = int(owner[b])
+                if through_host:
+                    h = utb.cpu()
+                    dist.broadcast(h, src=src)
+                    if src != rank:
+                        utb.copy_(h)
+                    dist.broadcast(s_t[o0:o0 + nb], src=src)
+                else:
+                    dist.broadcast(utb, src=src)
+                    sd = s_t[o0:o0 + nb].to(dev)
+                    dist.broadcast(sd, src=src)
+                    s_t[o0:o0 + nb] = sd.cpu()
+        for o0, nb, utb in blocks:
+            rot_all[o0:o0 + nb] = (utb @ torch.from_numpy(yx[o0:o0 + nb]).to(dev)).cpu().numpy()
         self.s = s_all
         self.yr, self.xr = rot_all[:, 0].copy(), rot_all[:, 1:].copy()
         self.smin = float(self.s.min())
@@ -1145,11 +1221,12 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
         if panel_idx is None:
             panel_idx = np.arange(n_full, dtype=np.int64)
         rot = pl.BlockRotation(packed_t, n_full, panel_idx, model.blocks)
-        out = pl.scan_rows_splmm_blocks(rot, model.p, rows.astype(np.int32), lut, fv_state)
+        out = _scan_my_rows(lambda r, l: pl.scan_rows_splmm_blocks(rot, model.p, r, l, fv_state), rows.astype(np.int32), lut)
     else:
         panel = pl.Panel(packed_t, n_full, panel_idx)
         sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
-        out = pl.scan_rows(panel, sm, rows.astype(np.int32), lut, mode="splmm", fv_state=fv_state)
+        out = _scan_my_rows(lambda r, l: pl.scan_rows(panel, sm, r, l, mode="splmm", fv_state=fv_state),
+                            rows.astype(np.int32), lut)
     return out.cpu().numpy(), float(log10_lambda), null
 
 
@@ -1423,7 +1500,10 @@ def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat
     else:
         x_scan = x
     panel = pl.Panel(packed_t, n_full, scan_idx)
-    out = pl.scan_rows_grammar(panel, rows.astype(np.int32), lut, x_scan, a_resid, gamma, on_block=on_block)
+    if pl.dist_info()[1] > 1:
+        on_block = None        # block offsets are those of a rank's share: the gathered table is handed on by the caller
+    out = _scan_my_rows(lambda r, l: pl.scan_rows_grammar(panel, r, l, x_scan, a_resid, gamma, on_block=on_block),
+                        rows.astype(np.int32), lut)
     return float(gamma), out, int(len(rr)), int(used)
 
 
@@ -1541,7 +1621,11 @@ def splmm_assoc_pcg_bed_to_tsv(prefix, y, lbd, chrom, pos, snp, allele0, allele1
     elif not (len(chrom) == len(pos) == len(snp) == len(allele0) == len(allele1) == m):
         raise RuntimeError(f"SparseLMM TSV metadata length mismatch: rows={m}")
     t2 = time.perf_counter()
-    written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, inp["maf"], inp["miss"], out, resolve=False)
+    from .pipeline import dist_info
+    if dist_info()[0] == 0:        # several ranks: every rank holds the gathered table, rank 0 writes it
+        written = write_assoc_tsv(out_tsv, chrom, pos, snp, allele0, allele1, inp["maf"], inp["miss"], out, resolve=False)
+    else:
+        written = m
     t3 = time.perf_counter()
     return (r_hat, True, 1, 0.0, True, 1, 0.0, req, used, int(written), (0.0, t2 - t1, t1 - t0, t3 - t2))
 

@@ -1965,6 +1965,92 @@ def test_cli_two_ranks_share_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sparse_routes_two_ranks_share_one_gpu(tmp_path):
+    """BASELINE.json configs[5] on several ranks: `jx grm -sparse` and `jx gwas -splmm -splmm-exact` under the launcher (two ranks
+    on the one device, gloo).  The row panels of the sparse GRM are dealt over the ranks and merged by rank 0
+    (jx_spgrm_set_part / jx_spgrm_merge_parts); the SparseLMM scans are SNP-sharded and gathered in BED order.  Every output file
+    must equal the one-process run's byte for byte: a panel's entries and a SNP's statistics do not depend on who computes
+    them."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, m = 900, 2400
+    packed, g = _related_panel(n, m, 47, 0.01)
+    y = bed.synth_phenotype(g, n_causal=12, pve=0.5, seed=7)
+    prefix = str(tmp_path / "p")
+    ids = [f"s{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    rng = np.random.default_rng(47)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\tt1\tt2\n")
+        for i in range(n):
+            t2 = "NA" if i % 7 == 0 else repr(float(y[i] + rng.normal()))     # second trait: a sample subset
+            fh.write(f"{ids[i]}\t{float(y[i])!r}\t{t2}\n")
+    # the eigendecomposition of the sparse K on its two-stage path on both sides: the one-stage tridiagonalisation it takes
+    # below n = 1500 accumulates with f64 atomics, i.e. its eigenvectors move by ~1e-12 from run to run (one rank or several),
+    # which flips a last printed digit here and there
+    env = dict(os.environ, JXGPU_DIST_BACKEND="gloo", PYTHONPATH=root, JXGPU_EIGH_TWOSTAGE_MIN="300")
+
+    def run(out, ranks, extra_env=None):
+        base = [sys.executable]
+        if ranks > 1:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            base += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                     "--master-port", str(port)]
+        for sub in (["grm", "-bfile", prefix, "-sparse", "0.05", "-o", out + "_g"],
+                    ["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-splmm", "0.05", "-splmm-exact", "0.05", "-o", out]):
+            r = subprocess.run(base + ["-m", "janusx_amd"] + sub, env=dict(env, **(extra_env or {})), cwd=root,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, (sub[0], ranks, r.stdout[-1500:], r.stderr[-3000:])
+
+    one, two, two_p = str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "two_p")
+    run(one, 1)
+    run(two, 2)                                             # the default plan of two ranks: about four panels each
+    run(two_p, 2, {"JXGPU_SPGRM_PANEL_ROWS": "256"})       # four 256-row panels, dealt 0 1 1 0
+    # the block-diagonal spectral route (what n = 200 000 takes): the blocks' eigendecompositions are dealt over the ranks and
+    # broadcast; one rank and two must write the same tables
+    # (blocks below the two-stage size take the one-stage tridiagonalisation, see above: a last printed digit may differ in
+    # a few rows, whatever the number of ranks)
+    blk = {"JXGPU_SPLMM_ROUTE": "block", "JXGPU_SPLMM_BLOCK": "450"}
+    one_b, two_b = str(tmp_path / "one_b"), str(tmp_path / "two_b")
+    run(one_b, 1, blk)
+    run(two_b, 2, blk)
+    for trait in ("t1", "t2"):
+        for stem in ("splmm", "splmm2"):
+            a, b = open(f"{one_b}.{trait}.{stem}.tsv").read().splitlines(), open(f"{two_b}.{trait}.{stem}.tsv").read().splitlines()
+            assert len(a) > 2000 and len(a) == len(b), (trait, stem)
+            bad = [i for i in range(len(a)) if a[i] != b[i]]
+            assert len(bad) <= len(a) // 50, (trait, stem, len(bad))
+            for i in bad:
+                fa, fb = a[i].split("\t"), b[i].split("\t")
+                assert fa[:5] == fb[:5]
+                assert np.allclose([float(v) for v in fa[5:]], [float(v) for v in fb[5:]], rtol=3e-4, atol=1e-4), (a[i], b[i])
+    ref = open(one + "_g.spgrm", "rb").read()
+    nnz = int(np.frombuffer(ref[8:16], dtype=np.uint64)[0])
+    assert nnz > n                                          # relatives above the cut-off, not only the diagonal
+    differing = []
+    for other in (two, two_p):
+        assert open(other + "_g.spgrm", "rb").read() == ref
+        assert open(other + "_g.spgrm.id").read() == open(one + "_g.spgrm.id").read()
+        assert open(other + ".spgrm", "rb").read() == open(one + ".spgrm", "rb").read()
+        assert not [f for f in os.listdir(tmp_path) if ".part" in f]           # the part files are gone after the merge
+        for trait in ("t1", "t2"):
+            for stem in ("splmm", "splmm2"):
+                a, b = open(f"{one}.{trait}.{stem}.tsv").read().splitlines(), open(f"{other}.{trait}.{stem}.tsv").read().splitlines()
+                assert len(a) > 2000 and len(a) == len(b), (other, trait, stem)
+                bad = [i for i in range(len(a)) if a[i] != b[i]]
+                if bad:
+                    differing.append((os.path.basename(other), trait, stem, len(bad), bad[:3], a[bad[0]], b[bad[0]]))
+    assert not differing, differing
+
+
+@pytest.mark.gpu
 def test_distributed_eigh_two_ranks_share_one_gpu():
     """Rank-sharded tridiagonalisation (jxg_eigh_set_dist): two ranks on the one device, gloo collectives through host
     memory; scripts/dist_eigh_check.py checks residual / orthogonality / eigenvalues against LAPACK on every rank and

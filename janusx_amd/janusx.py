@@ -3460,8 +3460,10 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
         import torch.distributed as tdist
         rank, world = shard
         lo, hi = shard_range(eff_m, rank, world)
-        if hi <= lo:
-            raise RuntimeError(f"distributed rrBLUP PCG: rank {rank} of {world} has no marker ({eff_m} kept rows)")
+        if eff_m < world:
+            # the same count on every rank: all of them stop here, before any collective (a rank left alone in the first
+            # all-reduce would wait for ever)
+            raise RuntimeError(f"distributed rrBLUP PCG: {eff_m} kept rows cannot be dealt over {world} ranks")
         rows_all = rows if rows is not None else np.arange(m_total, dtype=np.int64)
         pk_s = np.ascontiguousarray(pk[rows_all[lo:hi]])
         lut_s = np.ascontiguousarray(lut[lo:hi])

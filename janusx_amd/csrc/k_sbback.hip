@@ -849,6 +849,376 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrPara
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Balanced form for FIVE units per CU (1024 < units <= 1280 on 256 CUs: n = 16 400 ... 20 480, BASELINE configs[2]).  With one
+// wave per unit a CU holds five compute waves on four SIMDs: the SIMD with two of them sets the pace (measured 536 ms at
+// n = 20 000, the three-waves-per-unit form 516 ms -- its 15 waves meet at two barriers per block).  Here every SIMD gets the
+// same matrix-pipe load: waves 0 - 3 own one 16-column unit each (the two-groups-per-pass code of sbback_apply_pair_kernel,
+// v_mfma_f64_16x16x4_f64), waves 4 - 7 own FOUR columns each of the fifth unit on v_mfma_f64_4x4x4_f64 (four 4 x 4 x 4 blocks
+// per instruction at the same flop rate -- 17.3 against 64.8 cycles, scripts/probes/mfma_rate_probe.hip: a quarter of a unit's
+// matrix-pipe time) and share the loader's work (each issues a quarter of the LDS-DMA copies of the next V / U images).
+// 1.25 units per SIMD, no partial-sum exchange, one barrier per block.
+// 4 x 4 x 4 layout (probed, scripts/probes/mfma4x4_probe.hip): lane = 16 kq + 4 blk + x; A_blk[i = x][k = kq], B[k = kq][c = 4 blk + x],
+// D[i = kq][c = 4 blk + x] = sum_k A_blk(c)[i][k] B[k][c].  Window rows 16 h + 4 blk + kq of a 32-row set live at lane (kq, blk, x = column):
+// at once the B operand of the first product (Y' partial per blk: rows 4 blk + kq; summed over blk by two DPP row rotations) and
+// the accumulator of the second (blk = row sub-block, Y replicated over blk).
+template <int CTRL>
+__device__ __forceinline__ double qb_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
+    extern __shared__ __attribute__((aligned(16))) double qb_smem[];
+    double *vl = qb_smem;                                      // [2][QR_BLK]: 0 = upper group's block, 1 = lower group's
+    double *ul = vl + 2 * QR_BLK;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = P.n;
+    auto pass_groups = [&](int pass, int &g_up, int &g_lo_grp) {
+        g_up = P.g_hi - 1 - 2 * pass;
+        g_lo_grp = g_up - 1;
+        if (g_lo_grp < P.g_lo) {                               // single group: it plays the lower role
+            g_lo_grp = g_up;
+            g_up = -1;
+        }
+    };
+    const int npass = (P.g_hi - P.g_lo + 1) / 2;
+    auto steps_of = [&](int grp) { return (grp < 0 || grp * QB_G + 1 >= n) ? 0 : (n - grp * QB_G - 1 + QB_SB - 1) / QB_SB; };
+    const int ub = (int)((int64_t)blockIdx.x * P.units / gridDim.x);
+    const int nb = (int)((int64_t)(blockIdx.x + 1) * P.units / gridDim.x) - ub;
+    const int n2 = (n + 1) & ~1;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------ four-column waves (+ a quarter of the loader)
+        const int mw = wave - 4;
+        const int kq = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
+        const bool have = nb >= 5 && !(P.skip & 32);           // a slab of four units has no fifth: loader duty only
+        auto dma_part = [&](int grp, int k, int buf) {
+            const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
+            const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
+            constexpr int PER = QR_BLK * 8 / 1024 / 4;         // 6 of the 24 KB-sized copies of each image
+#pragma unroll
+            for (int ii = 0; ii < PER; ++ii) {
+                const int i = mw * PER + ii;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + i * 1024), "s"(__builtin_amdgcn_readfirstlane(v_dst + i * 1024))
+                             : "memory");
+            }
+#pragma unroll
+            for (int ii = 0; ii < PER; ++ii) {
+                const int i = mw * PER + ii;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
+                             : "memory");
+            }
+        };
+        constexpr int W = 80;
+        double *cpm = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (64 + 4 * mw + x);
+        // a 32-row set: registers [h] <-> row rb + 16 h + 4 blk + kq; one 16-byte access = the row pair of that row
+        auto set_load = [&](int rb, d2 (&raw)[2]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = rb + 16 * h + 4 * blk + kq;
+                const double *src = cpm + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[h]) : "v"(src) : "memory");
+            }
+        };
+        auto set_unpack = [&](int rb, const d2 (&raw)[2], double (&reg)[2]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = rb + 16 * h + 4 * blk + kq;
+                reg[h] = (row < n) ? raw[h][kq & 1] : 0.0;
+            }
+        };
+        auto set_store = [&](int rb, const double (&reg)[2]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = rb + 16 * h + 4 * blk + kq;
+                if (row < n) cpm[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[h];
+            }
+        };
+        // one 96-row block on three sets (image rows 32 w + 16 h + ...)
+        auto mini_block = [&](int buf, double (&c0)[2], double (&c1)[2], double (&c2)[2]) {
+            const double *ubuf = ul + buf * QR_BLK;
+            const double *vbuf = vl + buf * QR_BLK;
+            double y[8];
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) y[tt] = 0.0;
+#pragma unroll
+            for (int hh = 0; hh < 6; ++hh) {
+                const double b = hh < 2 ? c0[hh] : (hh < 4 ? c1[hh - 2] : c2[hh - 4]);
+                const int q = 16 * hh + 4 * blk + kq;
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) {
+                    if (hh == 0 && tt >= 4) continue;          // U[q][m] = 0 for q <= m: rows 0 .. 15 against columns >= 16
+                    y[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ubuf[qr_u_at(q, 4 * tt + x)], b, y[tt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                double s = y[tt];
+                s += qb_dpp<0x124>(s);                         // row_ror:4
+                s += qb_dpp<0x128>(s);                         // row_ror:8: the sum over the four blocks in every lane
+                y[tt] = -s;
+            }
+            auto upd = [&](int hh, double &cw) {
+                const int q = 16 * hh + 4 * blk + x;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if ((hh == 0 && ks >= 4) || (hh == 5 && ks < 4)) continue;      // V[q][m] != 0 only for m < q <= m + 64
+                    cw = __builtin_amdgcn_mfma_f64_4x4x4f64(vbuf[qr_v_at(q, 4 * ks + kq)], y[ks], cw, 0, 0, 0);
+                }
+            };
+            upd(0, c0[0]);
+            upd(1, c0[1]);
+            upd(2, c1[0]);
+            upd(3, c1[1]);
+            upd(4, c2[0]);
+            upd(5, c2[1]);
+        };
+        double M[4][2];
+        d2 pfm[2][2];
+        for (int pass = 0; pass < npass; ++pass) {
+            int gu, gl;
+            pass_groups(pass, gu, gl);
+            const int nku = steps_of(gu), nkl = steps_of(gl);
+            if (nkl == 0) continue;
+            const int sl = gl * QB_G;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // G0
+            if (nku > 0) dma_part(gu, 0, 0);
+            dma_part(gl, 0, 1);
+            if (have) {
+                set_load(sl, pfm[0]);
+                set_load(sl + 32, pfm[1]);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                set_unpack(sl, pfm[0], M[0]);
+                set_unpack(sl + 32, pfm[1], M[1]);
+                set_load(sl + 64, pfm[0]);
+                set_load(sl + 96, pfm[1]);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                set_unpack(sl + 64, pfm[0], M[2]);
+                set_unpack(sl + 96, pfm[1], M[3]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            qr_lds_barrier();                                  // G1: the images of the first two blocks are in place
+            auto step = [&](auto phc, int k) {
+                constexpr int PH = decltype(phc)::value;
+                double (&a0)[2] = M[(0 + 2 * PH) % 4];
+                double (&a1)[2] = M[(1 + 2 * PH) % 4];
+                double (&a2)[2] = M[(2 + 2 * PH) % 4];
+                double (&a3)[2] = M[(3 + 2 * PH) % 4];
+                const int wb = sl + k * QB_SB;
+                const bool has_next = k + 1 < nkl;
+                if (have) {
+                    if (k > 0) {                               // the prefetch landed before B2 of the previous step (vmcnt(0) there)
+                        set_unpack(wb + 64, pfm[0], a2);
+                        set_unpack(wb + 96, pfm[1], a3);
+                    }
+                    if (has_next && !(P.skip & 18)) {
+                        set_load(wb + 128, pfm[0]);
+                        set_load(wb + 160, pfm[1]);
+                    }
+                    if (k < nku && !(P.skip & 1)) mini_block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                qr_lds_barrier();                              // B1(k): buffer 0 consumed, buffer 1 holds (gl, k)
+                if (k + 1 < nku && !(P.skip & 4)) dma_part(gu, k + 1, 0);
+                if (have && !(P.skip & 1)) mini_block(1, a0, a1, a2);           // block (g - 1, k): rows wb ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                qr_lds_barrier();                              // B2(k): buffer 1 consumed, buffer 0 holds (gu, k + 1)
+                if (k + 1 < nkl && !(P.skip & 4)) dma_part(gl, k + 1, 1);
+                if (have && !(P.skip & 10)) {
+                    set_store(wb, a0);
+                    set_store(wb + 32, a1);
+                    if (!has_next) {
+                        set_store(wb + 64, a2);
+                        set_store(wb + 96, a3);
+                    }
+                }
+            };
+            int k = 0;
+            for (; k + 2 <= nkl; k += 2) {
+                step(std::integral_constant<int, 0>{}, k);
+                step(std::integral_constant<int, 1>{}, k + 1);
+            }
+            if (k < nkl) step(std::integral_constant<int, 0>{}, k);
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------ 16-column waves
+    const int lx = lane & 15, lk = lane >> 4;
+    const int unit = wave;
+    if (unit >= nb) {                                          // absent unit of a narrower slab: the barrier sequence only
+        for (int pass = 0; pass < npass; ++pass) {
+            int gu, gl;
+            pass_groups(pass, gu, gl);
+            const int nkl = steps_of(gl);
+            if (nkl == 0) continue;
+            __syncthreads();                                   // G0
+            qr_lds_barrier();                                  // G1
+            for (int k = 0; k < nkl; ++k) {
+                qr_lds_barrier();                              // B1
+                qr_lds_barrier();                              // B2
+            }
+        }
+        return;
+    }
+    constexpr int W = 80;                                      // four full units + the four-column shares of the fifth
+    double *cp = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (unit * 16 + lx);
+    const int rm_a = 8 * (lx >> 3) + 2 * (lx & 3) + ((lx >> 2) & 1);
+
+    auto chunk_load = [&](int rb, d2 (&raw)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = rb + 8 * q + 2 * lk;
+            const double *src = cp + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[q]) : "v"(src) : "memory");
+        }
+    };
+    auto chunk_unpack = [&](int rb, const d2 (&raw)[4], d4 (&reg)[2]) {
+        const bool inside = rb + 32 <= n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            reg[i >> 2][i & 3] = (inside || row < n) ? raw[i >> 1][i & 1] : 0.0;
+        }
+    };
+    auto chunk_store = [&](int rb, const d4 (&reg)[2]) {
+        if (rb + 32 <= n) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d2 v = {reg[q >> 1][2 * (q & 1)], reg[q >> 1][2 * (q & 1) + 1]};
+                *reinterpret_cast<d2 *>(cp + (int64_t)((rb + 8 * q + 2 * lk) >> 1) * (2 * W)) = v;
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = rb + 8 * (i >> 1) + 2 * lk + (i & 1);
+            if (row < n) cp[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[i >> 2][i & 3];
+        }
+    };
+    // one 96-row block on three chunk sets (image rows 32 w + ... of buffer `buf` <-> set cw_w)
+    auto block = [&](int buf, d4 (&c0)[2], d4 (&c1)[2], d4 (&c2)[2]) {
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+        const int o0 = 16 * (lk & 1), o1 = 16 - o0;
+        auto ypart = [&](int w, const d4 (&cw)[2]) {
+            const double *up = ul + buf * QR_BLK + (32 * w + 2 * lk) * QB_G + lx;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int q = 8 * (ks >> 1) + (ks & 1);
+                const double b = cw[ks >> 2][ks & 3];
+                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o0], b, y0, 0, 0, 0);
+                if (!qr_u_tile_zero(w, ks)) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(up[q * QB_G + o1], b, y1, 0, 0, 0);
+            }
+        };
+        ypart(0, c0);
+        ypart(1, c1);
+        ypart(2, c2);
+        double yn[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            yn[r] = -y0[r];
+            yn[4 + r] = -y1[r];
+        }
+        auto upd = [&](int w, d4 (&cw)[2]) {
+            const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int m = (4 * ks + lk) ^ (2 * rm_a);
+                if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
+                if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
+            }
+        };
+        upd(0, c0);
+        upd(1, c1);
+        upd(2, c2);
+    };
+
+    d4 S[4][2];
+    d2 pf[2][4];
+    bool stored8 = false;
+    int sl = 0, nku = 0, nkl = 0;
+    auto wait_pf = [&](bool eight_behind) {
+        if (eight_behind)
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+    };
+    // one step of a pass: PH = k mod 2 (compile time), the set at window position p is S[(p + 2 PH) % 4]
+    auto step = [&](auto phc, int k) {
+        constexpr int PH = decltype(phc)::value;
+        d4 (&a0)[2] = S[(0 + 2 * PH) % 4];
+        d4 (&a1)[2] = S[(1 + 2 * PH) % 4];
+        d4 (&a2)[2] = S[(2 + 2 * PH) % 4];
+        d4 (&a3)[2] = S[(3 + 2 * PH) % 4];
+        const int wb = sl + k * QB_SB;                         // first row of the 128-row window
+        const bool has_next = k + 1 < nkl;
+        if (k > 0) {
+            wait_pf(stored8);
+            chunk_unpack(wb + 64, pf[0], a2);
+            chunk_unpack(wb + 96, pf[1], a3);
+        }
+        if (has_next && !(P.skip & 18)) {
+            chunk_load(wb + 128, pf[0]);
+            chunk_load(wb + 160, pf[1]);
+        }
+        if (k < nku && !(P.skip & 1)) block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
+        qr_lds_barrier();                                      // B1(k)
+        if (!(P.skip & 1)) block(1, a0, a1, a2);               // block (g - 1, k): rows wb ...
+        qr_lds_barrier();                                      // B2(k)
+        stored8 = false;
+        if (!(P.skip & 10)) {
+            chunk_store(wb, a0);
+            chunk_store(wb + 32, a1);
+            stored8 = wb + 64 <= n;
+            if (!has_next) {
+                chunk_store(wb + 64, a2);
+                chunk_store(wb + 96, a3);
+            }
+        }
+    };
+    for (int pass = 0; pass < npass; ++pass) {
+        int gu, gl;
+        pass_groups(pass, gu, gl);
+        nku = steps_of(gu);
+        nkl = steps_of(gl);
+        if (nkl == 0) continue;
+        sl = gl * QB_G;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // G0: the previous pass' stores are done, LDS is free
+        chunk_load(sl, pf[0]);
+        chunk_load(sl + 32, pf[1]);
+        wait_pf(false);
+        chunk_unpack(sl, pf[0], S[0]);
+        chunk_unpack(sl + 32, pf[1], S[1]);
+        chunk_load(sl + 64, pf[0]);
+        chunk_load(sl + 96, pf[1]);
+        wait_pf(false);
+        chunk_unpack(sl + 64, pf[0], S[2]);
+        chunk_unpack(sl + 96, pf[1], S[3]);
+        stored8 = false;
+        qr_lds_barrier();                                      // G1: the images of the first two blocks are in place
+        int k = 0;
+        for (; k + 2 <= nkl; k += 2) {
+            step(std::integral_constant<int, 0>{}, k);
+            step(std::integral_constant<int, 1>{}, k + 1);
+        }
+        if (k < nkl) step(std::integral_constant<int, 0>{}, k);
+    }
+}
+
 // C (n x ncols, column-major, ld = n) <-> slab layout [slab][row][w] (w = slab width in columns; columns past ncols are
 // zero on the way in and dropped on the way out).  One workgroup = 64 rows of one slab through LDS: both sides coalesced.
 template <bool TO_SLAB>
@@ -919,10 +1289,23 @@ static bool qr_pair() {
     return env != 0;
 }
 
+// balanced five-units-per-CU form (sbback_apply_bal_kernel): more than four and at most five units per CU; JXGPU_SBBACK_BAL5=0: off
+static bool qr_bal(int ncols) {
+    const int units = (ncols + 15) / 16;
+    static const int env = getenv("JXGPU_SBBACK_BAL5") ? atoi(getenv("JXGPU_SBBACK_BAL5")) : 1;
+    const int cus = device_cus();
+    return env != 0 && units > 4 * cus && units <= 5 * cus;
+}
+
 static void qr_plan(int ncols, int *g_out, int *nu_out) {
     const int units = (ncols + 15) / 16;
     const int cus = device_cus();
     int nu, g;
+    if (qr_bal(ncols) && !qr_solo(ncols)) {
+        *g_out = (units + 4) / 5;              // slabs of five units (a few of four when 5 does not divide the count)
+        *nu_out = 5;
+        return;
+    }
     if (qr_solo(ncols)) {
         // R = ceil(units / (15 CUs)) full rounds of CUs workgroups, units dealt evenly (n = 50 000: 256 slabs of 12 or 13)
         const int wmax = qr_pair() ? QR_PAIR_MAX : QR_SOLO_MAX;
@@ -988,7 +1371,8 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
             return fail("sbback_apply_q2: slab plan exceeds the workspace");
     }
     const bool solo = qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
-    const size_t lds = solo ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
+    const bool bal = !solo && qr_bal(ncols) && nu == 5 && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const size_t lds = (solo || bal) ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
     const dim3 grid(gslabs);
     const int skip = getenv("JXGPU_QB_SKIP") ? atoi(getenv("JXGPU_QB_SKIP")) : 0;
     const int w = nu * 16;
@@ -1033,7 +1417,14 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         }                                                                                                              \
         hipExtLaunchKernelGGL(sbback_apply_solo_kernel<NWV>, grid, dim3((NWV + 1) * 64), lds, st, e0, e1, 0, P);        \
     } while (0)
-        if (solo && qr_pair()) {
+        if (bal) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipExtLaunchKernelGGL(sbback_apply_bal_kernel, grid, dim3(512), lds, st, e0, e1, 0, P);
+        } else if (solo && qr_pair()) {
 #define JX_QR_PAIR(NWV)                                                                                                \
     do {                                                                                                               \
         static bool attr_set = false;                                                                                  \

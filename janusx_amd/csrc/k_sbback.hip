@@ -895,6 +895,10 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         // ------------------------------------------------------------------------ four-column waves (+ a quarter of the loader)
         const int mw = wave - 4;
         const int kq = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
+        // the short 4 x 4 x 4 instructions of this wave go first whenever they are ready (JXGPU_QB_SKIP=256: default priority): the
+        // 16-column wave on the same SIMD is never short of ready work, and with equal priorities the older wave wins every
+        // arbitration, so this wave's products would only start when the other one has reached the barrier
+        if (!(P.skip & 256)) __builtin_amdgcn_s_setprio(3);
         const bool have = nb >= 5 && !(P.skip & 32);           // a slab of four units has no fifth: loader duty only
         auto dma_part = [&](int grp, int k, int buf) {
             const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
@@ -945,43 +949,66 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
             }
         };
         // one 96-row block on three sets (image rows 32 w + 16 h + ...)
+        // LDS addresses of the operands: the bank swizzles of the images (qr_u_at / qr_v_at) depend on the lane only, not on the
+        // 16-row half hh of the window: eight lane terms per image + hh * 512 doubles as an immediate offset
+        const int usw = 16 * ((kq >> 1) & 1), vsw = 2 * (4 * blk + x);
+        int uoff[8], voff[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uoff[i] = (4 * blk + kq) * QB_G + ((4 * i + x) ^ usw);           // U[q = 16 hh + 4 blk + kq][m = 4 tt + x]
+            voff[i] = (4 * blk + x) * QB_G + ((4 * i + kq) ^ vsw);           // V[q = 16 hh + 4 blk + x][m = 4 ks + kq]
+        }
         auto mini_block = [&](int buf, double (&c0)[2], double (&c1)[2], double (&c2)[2]) {
             const double *ubuf = ul + buf * QR_BLK;
             const double *vbuf = vl + buf * QR_BLK;
+            // operands one 16-row half (first product) / one 4-column step (second product) ahead of the instructions that use
+            // them: eight or six LDS reads in flight behind the previous step's products.  (All 84 reads of the block at once
+            // made the four waves of this kind queue ~4800 LDS cycles right behind every barrier -- the 4-way bank conflicts of
+            // the U image under this access pattern included --, and the 16-column waves waited for their own operands behind
+            // that queue: the block interval grew by about that much.)
+            double ua[2][8], va[2][6];
+            auto u_load = [&](int hh, double (&dst)[8]) {
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt)
+                    if (!(hh == 0 && tt >= 4)) dst[tt] = ubuf[uoff[tt] + hh * 16 * QB_G];    // U[q][m] = 0 for q <= m
+            };
+            auto v_load = [&](int ks, double (&dst)[6]) {
+#pragma unroll
+                for (int hh = 0; hh < 6; ++hh)
+                    if (!((hh == 0 && ks >= 4) || (hh == 5 && ks < 4))) dst[hh] = vbuf[voff[ks] + hh * 16 * QB_G];   // V[q][m] != 0: m < q <= m + 64
+            };
             double y[8];
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) y[tt] = 0.0;
+            u_load(0, ua[0]);
 #pragma unroll
             for (int hh = 0; hh < 6; ++hh) {
+                if (hh + 1 < 6) u_load(hh + 1, ua[(hh + 1) & 1]);
+                else v_load(0, va[0]);
                 const double b = hh < 2 ? c0[hh] : (hh < 4 ? c1[hh - 2] : c2[hh - 4]);
-                const int q = 16 * hh + 4 * blk + kq;
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
-                    if (hh == 0 && tt >= 4) continue;          // U[q][m] = 0 for q <= m: rows 0 .. 15 against columns >= 16
-                    y[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ubuf[qr_u_at(q, 4 * tt + x)], b, y[tt], 0, 0, 0);
+                    if (hh == 0 && tt >= 4) continue;
+                    y[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[hh & 1][tt], b, y[tt], 0, 0, 0);
                 }
             }
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) {
-                double s = y[tt];
-                s += qb_dpp<0x124>(s);                         // row_ror:4
-                s += qb_dpp<0x128>(s);                         // row_ror:8: the sum over the four blocks in every lane
-                y[tt] = -s;
+                double sm = y[tt];
+                sm += qb_dpp<0x124>(sm);                       // row_ror:4
+                sm += qb_dpp<0x128>(sm);                       // row_ror:8: the sum over the four blocks in every lane
+                y[tt] = -sm;
             }
-            auto upd = [&](int hh, double &cw) {
-                const int q = 16 * hh + 4 * blk + x;
+            double *cw[6] = {&c0[0], &c0[1], &c1[0], &c1[1], &c2[0], &c2[1]};
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    if ((hh == 0 && ks >= 4) || (hh == 5 && ks < 4)) continue;      // V[q][m] != 0 only for m < q <= m + 64
-                    cw = __builtin_amdgcn_mfma_f64_4x4x4f64(vbuf[qr_v_at(q, 4 * ks + kq)], y[ks], cw, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) v_load(ks + 1, va[(ks + 1) & 1]);
+#pragma unroll
+                for (int hh = 0; hh < 6; ++hh) {               // six independent accumulators per step
+                    if ((hh == 0 && ks >= 4) || (hh == 5 && ks < 4)) continue;
+                    *cw[hh] = __builtin_amdgcn_mfma_f64_4x4x4f64(va[ks & 1][hh], y[ks], *cw[hh], 0, 0, 0);
                 }
-            };
-            upd(0, c0[0]);
-            upd(1, c0[1]);
-            upd(2, c1[0]);
-            upd(3, c1[1]);
-            upd(4, c2[0]);
-            upd(5, c2[1]);
+            }
         };
         double M[4][2];
         d2 pfm[2][2];
@@ -1028,11 +1055,19 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                     }
                     if (k < nku && !(P.skip & 1)) mini_block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                // the copies into buffer 1 were issued behind B2 of the previous step; younger than them are only that step's four
+                // row stores and this step's four prefetch loads (the counter retires in issue order): waiting for everything would
+                // put an HBM round trip of the prefetch in front of every barrier
+                if (have && k > 0 && !(P.skip & 512)) {
+                    if (has_next && !(P.skip & 18)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 qr_lds_barrier();                              // B1(k): buffer 0 consumed, buffer 1 holds (gl, k)
                 if (k + 1 < nku && !(P.skip & 4)) dma_part(gu, k + 1, 0);
                 if (have && !(P.skip & 1)) mini_block(1, a0, a1, a2);           // block (g - 1, k): rows wb ...
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
                 qr_lds_barrier();                              // B2(k): buffer 1 consumed, buffer 0 holds (gu, k + 1)
                 if (k + 1 < nkl && !(P.skip & 4)) dma_part(gl, k + 1, 1);
                 if (have && !(P.skip & 10)) {

@@ -74,7 +74,17 @@ struct QrParams {
     int g_lo, g_hi;         // groups [g_lo, g_hi) of this launch (applied from g_hi - 1 down)
     int skip;               // diagnostic bit mask (JXGPU_QB_SKIP): 1 no MFMA phases, 2 no row traffic, 4 no V / U loads,
                             // 8 no row stores, 16 no row loads
+    double *um;             // balanced form only (else null): third image per block, U in the order the four-column waves read it
 };
+
+// U image of the four-column waves (sbback_apply_bal_kernel): lane l = 16 kq + 4 blk + x reads U[q = 16 hh + 4 blk + kq][m = 4 tt + x],
+// tt = 0 .. 7, per 16-row half hh.  Under that pattern the [q][m] image costs an 8-way bank conflict per read (a row is one bank
+// cycle and a half wave only varies m through x); stored as [hh][u = tt / 2][lane][tt % 2] a lane's eight values are four 16-byte
+// reads, each over 64 consecutive 16-byte slots: conflict-free (probe: the first product of those waves 433 -> 365 ms in total).
+__host__ __device__ __forceinline__ int qr_um_at(int q, int m) {
+    const int hh = q >> 4, blk = (q >> 2) & 3, kq = q & 3, tt = m >> 2, x = m & 3;
+    return (((hh * 4 + (tt >> 1)) * 64) + 16 * kq + 4 * blk + x) * 2 + (tt & 1);
+}
 
 // one workgroup (128 threads) per (k, group): V image of the block (window rows [s0 + 64 k, + 96), zero off the
 // supports), T = (striu(V'V) + diag(1 / tau))^-1 with zero rows / columns for tau = 0, U = V T'
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(128) void sbback_vu_kernel(QrParams P) {
         for (int i = 0; i < QB_G; ++i) acc = fma(vs[q][i], m[mp][i], acc);     // U[q][m'] = sum_m V[q][m] T[m'][m]
         out[qr_v_at(q, mp)] = vs[q][mp];
         out[QR_BLK + qr_u_at(q, mp)] = acc;
+        if (P.um) P.um[((int64_t)blockIdx.y * P.ks + k) * QR_BLK + qr_um_at(q, mp)] = acc;
     }
 }
 
@@ -875,6 +886,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     extern __shared__ __attribute__((aligned(16))) double qb_smem[];
     double *vl = qb_smem;                                      // [2][QR_BLK]: 0 = upper group's block, 1 = lower group's
     double *ul = vl + 2 * QR_BLK;
+    double *uml = ul + 2 * QR_BLK;                             // [2][QR_BLK]: U again, in the four-column waves' order (qr_um_at)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = P.n;
     auto pass_groups = [&](int pass, int &g_up, int &g_lo_grp) {
@@ -922,6 +934,17 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                              : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
                              : "memory");
             }
+            const char *srcm = reinterpret_cast<const char *>(P.um + ((int64_t)(grp - P.g_lo) * P.ks + k) * QR_BLK) + lane * 16;
+            const unsigned m_dst = (unsigned)(uintptr_t)(uml + buf * QR_BLK);
+#pragma unroll
+            for (int ii = 0; ii < PER; ++ii) {
+                const int i = mw * PER + ii;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(srcm + i * 1024), "s"(__builtin_amdgcn_readfirstlane(m_dst + i * 1024))
+                             : "memory");
+            }
         };
         constexpr int W = 80;
         double *cpm = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (64 + 4 * mw + x);
@@ -951,15 +974,11 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         // one 96-row block on three sets (image rows 32 w + 16 h + ...)
         // LDS addresses of the operands: the bank swizzles of the images (qr_u_at / qr_v_at) depend on the lane only, not on the
         // 16-row half hh of the window: eight lane terms per image + hh * 512 doubles as an immediate offset
-        const int usw = 16 * ((kq >> 1) & 1), vsw = 2 * (4 * blk + x);
-        int uoff[8], voff[8];
+        const int vsw = 2 * (4 * blk + x);
+        int voff[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uoff[i] = (4 * blk + kq) * QB_G + ((4 * i + x) ^ usw);           // U[q = 16 hh + 4 blk + kq][m = 4 tt + x]
-            voff[i] = (4 * blk + x) * QB_G + ((4 * i + kq) ^ vsw);           // V[q = 16 hh + 4 blk + x][m = 4 ks + kq]
-        }
+        for (int i = 0; i < 8; ++i) voff[i] = (4 * blk + x) * QB_G + ((4 * i + kq) ^ vsw);       // V[q = 16 hh + 4 blk + x][m = 4 ks + kq]
         auto mini_block = [&](int buf, double (&c0)[2], double (&c1)[2], double (&c2)[2]) {
-            const double *ubuf = ul + buf * QR_BLK;
             const double *vbuf = vl + buf * QR_BLK;
             // operands one 16-row half (first product) / one 4-column step (second product) ahead of the instructions that use
             // them: eight or six LDS reads in flight behind the previous step's products.  (All 84 reads of the block at once
@@ -967,10 +986,15 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
             // the U image under this access pattern included --, and the 16-column waves waited for their own operands behind
             // that queue: the block interval grew by about that much.)
             double ua[2][8], va[2][6];
+            const d2 *umb = reinterpret_cast<const d2 *>(uml + buf * QR_BLK) + lane;
             auto u_load = [&](int hh, double (&dst)[8]) {
 #pragma unroll
-                for (int tt = 0; tt < 8; ++tt)
-                    if (!(hh == 0 && tt >= 4)) dst[tt] = ubuf[uoff[tt] + hh * 16 * QB_G];    // U[q][m] = 0 for q <= m
+                for (int u = 0; u < 4; ++u) {
+                    if (hh == 0 && u >= 2) continue;           // U[q][m] = 0 for q <= m: rows 0 .. 15 against columns >= 16
+                    const d2 pr = umb[(hh * 4 + u) * 64];
+                    dst[2 * u] = pr[0];
+                    dst[2 * u + 1] = pr[1];
+                }
             };
             auto v_load = [&](int ks, double (&dst)[6]) {
 #pragma unroll
@@ -995,8 +1019,10 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) {
                 double sm = y[tt];
-                sm += qb_dpp<0x124>(sm);                       // row_ror:4
-                sm += qb_dpp<0x128>(sm);                       // row_ror:8: the sum over the four blocks in every lane
+                if (!(P.skip & 2048)) {
+                    sm += qb_dpp<0x124>(sm);                   // row_ror:4
+                    sm += qb_dpp<0x128>(sm);                   // row_ror:8: the sum over the four blocks in every lane
+                }
                 y[tt] = -sm;
             }
             double *cw[6] = {&c0[0], &c0[1], &c1[0], &c1[1], &c2[0], &c2[1]};
@@ -1183,8 +1209,38 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     d2 pf[2][4];
     bool stored8 = false;
     int sl = 0, nku = 0, nkl = 0;
+    // L2 warm-up of the images two steps ahead.  Every block interval is gated by the LDS-DMA copies of the next block's images,
+    // which all workgroups issue at the same moment for the same, never-touched lines: an HBM round trip (~2.6 us: the interval
+    // measured without any arithmetic).  Wave 0 of every workgroup therefore touches a 1 / 32 slice (the workgroups of one XCD
+    // share an L2 and run in step) of the images of step k + 2 -- five 1 KB LDS-DMA loads into a dummy KB, no register written,
+    // nobody waits for them; they only count in this wave's memory counter (13 instead of 8 younger operations at the wait).
+    const bool l2warm = unit == 0 && P.um != nullptr && !(P.skip & 4096);
+    int cur_gu = -1, cur_gl = -1;
+    auto warm = [&](int k2) {
+        const int j = (int)(blockIdx.x >> 3) & 31;
+        const unsigned dst = (unsigned)(uintptr_t)(uml + 2 * QR_BLK);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = (j + 32 * i) % 144;                  // 2 groups x (48 KB of V | U + 24 KB of the third image)
+            const bool up = c < 72 && cur_gu >= 0 && nku > 0;
+            const int cc = c < 72 ? c : c - 72;
+            const int grp = up ? cur_gu : cur_gl;
+            const int kk = min(k2, (up ? nku : nkl) - 1);
+            const int64_t blkid = (int64_t)(grp - P.g_lo) * P.ks + kk;
+            const char *src = (cc < 48 ? reinterpret_cast<const char *>(P.vu + blkid * (2 * QR_BLK)) + cc * 1024
+                                       : reinterpret_cast<const char *>(P.um + blkid * QR_BLK) + (cc - 48) * 1024) + lane * 16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                         : "memory");
+        }
+    };
     auto wait_pf = [&](bool eight_behind) {
-        if (eight_behind)
+        if (eight_behind && l2warm)
+            asm volatile("s_waitcnt vmcnt(13)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+        else if (eight_behind)
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
                          "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
         else
@@ -1208,6 +1264,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         if (has_next && !(P.skip & 18)) {
             chunk_load(wb + 128, pf[0]);
             chunk_load(wb + 160, pf[1]);
+            if (l2warm) warm(k + 2);
         }
         if (k < nku && !(P.skip & 1)) block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
         qr_lds_barrier();                                      // B1(k)
@@ -1230,6 +1287,8 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         nku = steps_of(gu);
         nkl = steps_of(gl);
         if (nkl == 0) continue;
+        cur_gu = gu;
+        cur_gl = gl;
         sl = gl * QB_G;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // G0: the previous pass' stores are done, LDS is free
@@ -1293,10 +1352,15 @@ __global__ __launch_bounds__(256) void sbback_slab_kernel(double *__restrict__ c
 }
 
 // groups per launch of the register form: the V / U images of a launch stay below ~12 GB (one launch up to n ~ 22000)
+static bool qr_bal(int ncols);
 static int qr_groups_per_launch(int n, int ks) {
     const int ngroups = (n - 2 + QB_G - 1) / QB_G;
-    const double per_group = (double)ks * 2 * QR_BLK * sizeof(double);
-    int g = (int)(12.0e9 / per_group);
+    // balanced form: three images per block, and the whole workspace (images + slabs) stays below 6 GB -- a hipMalloc of 17 GB
+    // did not hide behind the band reduction any more (366 -> 985 ms until the stage's synchronisation); a launch boundary costs
+    // the drain and refill of one block interval
+    const bool bal = qr_bal(n);
+    const double per_group = (double)ks * (bal ? 3 : 2) * QR_BLK * sizeof(double);
+    int g = (int)((bal ? 2.5e9 : 12.0e9) / per_group);
     if (getenv("JXGPU_SBBACK_GROUPS") && atoi(getenv("JXGPU_SBBACK_GROUPS")) > 0) g = atoi(getenv("JXGPU_SBBACK_GROUPS"));
     if (g < 1) g = 1;
     return g < ngroups ? g : ngroups;
@@ -1371,7 +1435,8 @@ size_t sbback_tq_doubles(int n, int ks) {
     int g, nu;
     qr_plan(n, &g, &nu);
     const size_t padded = std::max((size_t)g * nu * 16, (size_t)n + 96);
-    return (size_t)qr_groups_per_launch(n, ks) * ks * 2 * QR_BLK + padded * (size_t)(n + 1);
+    // (+ the third image per block of the balanced form, behind the slabs)
+    return (size_t)qr_groups_per_launch(n, ks) * ks * (2 + (qr_bal(n) ? 1 : 0)) * QR_BLK + padded * (size_t)(n + 1);
 }
 
 static int device_cus() {
@@ -1406,12 +1471,19 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
             return fail("sbback_apply_q2: slab plan exceeds the workspace");
     }
     const bool solo = qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
-    const bool bal = !solo && qr_bal(ncols) && nu == 5 && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
-    const size_t lds = (solo || bal) ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64);
+    const bool bal = !solo && qr_bal(ncols) && qr_bal(n) && nu == 5 && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const size_t lds = bal ? sizeof(double) * (6 * (size_t)QR_BLK + 128)
+                           : (solo ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64));
     const dim3 grid(gslabs);
     const int skip = getenv("JXGPU_QB_SKIP") ? atoi(getenv("JXGPU_QB_SKIP")) : 0;
     const int w = nu * 16;
     double *d_ct = d_vu + (size_t)gpl * ks * 2 * QR_BLK;
+    double *d_um = nullptr;                                    // third image per block of the balanced form: behind the slabs
+    {
+        int gn, nun;
+        qr_plan(n, &gn, &nun);
+        d_um = d_ct + std::max((size_t)gn * nun * 16, (size_t)n + 96) * (size_t)(n + 1);
+    }
     const dim3 sgrid(ceil_div(n, 64), grid.x);
     const size_t slds = sizeof(double) * 64 * (w + 1);
     {
@@ -1428,7 +1500,7 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
     JX_LAUNCH_CHECK();
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
         const int g_lo = g_hi > gpl ? g_hi - gpl : 0;
-        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip};
+        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, bal ? d_um : nullptr};
         hipLaunchKernelGGL(sbback_vu_kernel, dim3(ks, g_hi - g_lo), dim3(128), 0, st, P);
         JX_LAUNCH_CHECK();
         hipEvent_t e0 = (g_hi == ngroups) ? ev_start : nullptr, e1 = (g_lo == 0) ? ev_stop : nullptr;

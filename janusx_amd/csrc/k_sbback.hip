@@ -877,11 +877,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrPara
 template <int CTRL>
 __device__ __forceinline__ double qb_dpp(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);      // old = source: no zero-initialised register per call
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
+template <int W>                                               // slab width: 80 (five units) or 64 (four units: waves 4 - 7 are the loader only)
 __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     extern __shared__ __attribute__((aligned(16))) double qb_smem[];
     double *vl = qb_smem;                                      // [2][QR_BLK]: 0 = upper group's block, 1 = lower group's
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         // 16-column wave on the same SIMD is never short of ready work, and with equal priorities the older wave wins every
         // arbitration, so this wave's products would only start when the other one has reached the barrier
         if (!(P.skip & 256)) __builtin_amdgcn_s_setprio(3);
-        const bool have = nb >= 5 && !(P.skip & 32);           // a slab of four units has no fifth: loader duty only
+        const bool have = W == 80 && nb >= 5 && !(P.skip & 32);           // a slab of four units has no fifth: loader duty only
         auto dma_part = [&](int grp, int k, int buf) {
             const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
             const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
@@ -934,6 +935,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                              : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
                              : "memory");
             }
+            if (W != 80) return;
             const char *srcm = reinterpret_cast<const char *>(P.um + ((int64_t)(grp - P.g_lo) * P.ks + k) * QR_BLK) + lane * 16;
             const unsigned m_dst = (unsigned)(uintptr_t)(uml + buf * QR_BLK);
 #pragma unroll
@@ -946,7 +948,6 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                              : "memory");
             }
         };
-        constexpr int W = 80;
         double *cpm = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (64 + 4 * mw + x);
         // a 32-row set: registers [h] <-> row rb + 16 h + 4 blk + kq; one 16-byte access = the row pair of that row
         auto set_load = [&](int rb, d2 (&raw)[2]) {
@@ -1133,7 +1134,6 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         }
         return;
     }
-    constexpr int W = 80;                                      // four full units + the four-column shares of the fifth
     double *cp = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (unit * 16 + lx);
     const int rm_a = 8 * (lx >> 3) + 2 * (lx & 3) + ((lx >> 2) & 1);
 
@@ -1214,16 +1214,18 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     // measured without any arithmetic).  Wave 0 of every workgroup therefore touches a 1 / 32 slice (the workgroups of one XCD
     // share an L2 and run in step) of the images of step k + 2 -- five 1 KB LDS-DMA loads into a dummy KB, no register written,
     // nobody waits for them; they only count in this wave's memory counter (13 instead of 8 younger operations at the wait).
-    const bool l2warm = unit == 0 && P.um != nullptr && !(P.skip & 4096);
+    const bool l2warm = unit == 0 && !(P.skip & 4096);
+    constexpr int NWARM = W == 80 ? 5 : 3;                     // 144 (96 without the third image) KB-sized pieces over 32 workgroups
+    constexpr int NPIECE = W == 80 ? 72 : 48;                  // pieces per group
     int cur_gu = -1, cur_gl = -1;
     auto warm = [&](int k2) {
         const int j = (int)(blockIdx.x >> 3) & 31;
         const unsigned dst = (unsigned)(uintptr_t)(uml + 2 * QR_BLK);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = (j + 32 * i) % 144;                  // 2 groups x (48 KB of V | U + 24 KB of the third image)
-            const bool up = c < 72 && cur_gu >= 0 && nku > 0;
-            const int cc = c < 72 ? c : c - 72;
+        for (int i = 0; i < NWARM; ++i) {
+            const int c = (j + 32 * i) % (2 * NPIECE);         // 2 groups x (48 KB of V | U + 24 KB of the third image)
+            const bool up = c < NPIECE && cur_gu >= 0 && nku > 0;
+            const int cc = c < NPIECE ? c : c - NPIECE;
             const int grp = up ? cur_gu : cur_gl;
             const int kk = min(k2, (up ? nku : nkl) - 1);
             const int64_t blkid = (int64_t)(grp - P.g_lo) * P.ks + kk;
@@ -1237,8 +1239,11 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         }
     };
     auto wait_pf = [&](bool eight_behind) {
-        if (eight_behind && l2warm)
+        if (eight_behind && l2warm && W == 80)
             asm volatile("s_waitcnt vmcnt(13)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
+                         "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
+        else if (eight_behind && l2warm)
+            asm volatile("s_waitcnt vmcnt(11)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
                          "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
         else if (eight_behind)
             asm volatile("s_waitcnt vmcnt(8)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
@@ -1392,17 +1397,21 @@ static bool qr_pair() {
 static bool qr_bal(int ncols) {
     const int units = (ncols + 15) / 16;
     static const int env = getenv("JXGPU_SBBACK_BAL5") ? atoi(getenv("JXGPU_SBBACK_BAL5")) : 1;
+    static const int lo = getenv("JXGPU_SBBACK_BAL_MIN") ? atoi(getenv("JXGPU_SBBACK_BAL_MIN")) : 2;   // more than `lo` units per CU (measured: 84.8 against 89.3 ms at n = 10 000, slower at 8000)
     const int cus = device_cus();
-    return env != 0 && units > 4 * cus && units <= 5 * cus;
+    return env != 0 && units > lo * cus && units <= 5 * cus;
 }
+// units per slab of the balanced form: five (four 16-column waves + the four-column waves) above four units per CU, else four
+static int qr_bal_nu(int ncols) { return (ncols + 15) / 16 > 4 * device_cus() ? 5 : 4; }
 
 static void qr_plan(int ncols, int *g_out, int *nu_out) {
     const int units = (ncols + 15) / 16;
     const int cus = device_cus();
     int nu, g;
     if (qr_bal(ncols) && !qr_solo(ncols)) {
-        *g_out = (units + 4) / 5;              // slabs of five units (a few of four when 5 does not divide the count)
-        *nu_out = 5;
+        const int per = qr_bal_nu(ncols);      // slabs of five (four) units, a few of one less when the count does not divide
+        *g_out = (units + per - 1) / per;
+        *nu_out = per;
         return;
     }
     if (qr_solo(ncols)) {
@@ -1471,7 +1480,7 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
             return fail("sbback_apply_q2: slab plan exceeds the workspace");
     }
     const bool solo = qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
-    const bool bal = !solo && qr_bal(ncols) && qr_bal(n) && nu == 5 && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const bool bal = !solo && qr_bal(ncols) && qr_bal(n) && nu == qr_bal_nu(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
     const size_t lds = bal ? sizeof(double) * (6 * (size_t)QR_BLK + 128)
                            : (solo ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64));
     const dim3 grid(gslabs);
@@ -1500,7 +1509,7 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
     JX_LAUNCH_CHECK();
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
         const int g_lo = g_hi > gpl ? g_hi - gpl : 0;
-        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, bal ? d_um : nullptr};
+        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, (bal && nu == 5) ? d_um : nullptr};
         hipLaunchKernelGGL(sbback_vu_kernel, dim3(ks, g_hi - g_lo), dim3(128), 0, st, P);
         JX_LAUNCH_CHECK();
         hipEvent_t e0 = (g_hi == ngroups) ? ev_start : nullptr, e1 = (g_lo == 0) ? ev_stop : nullptr;
@@ -1527,10 +1536,12 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         if (bal) {
             static bool attr_set = false;
             if (!attr_set) {
-                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_set = true;
             }
-            hipExtLaunchKernelGGL(sbback_apply_bal_kernel, grid, dim3(512), lds, st, e0, e1, 0, P);
+            if (nu == 5) hipExtLaunchKernelGGL(sbback_apply_bal_kernel<80>, grid, dim3(512), lds, st, e0, e1, 0, P);
+            else hipExtLaunchKernelGGL(sbback_apply_bal_kernel<64>, grid, dim3(512), lds, st, e0, e1, 0, P);
         } else if (solo && qr_pair()) {
 #define JX_QR_PAIR(NWV)                                                                                                \
     do {                                                                                                               \

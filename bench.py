@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+# form of the Q2 back-transformation the last decomposition took (jxg_last_kernel_ms(13), csrc/k_sbback.hip)
+Q2_FORMS = ("sbback_apply_reg_kernel", "sbback_apply_solo_kernel", "sbback_apply_pair_kernel", "sbback_apply_bal_kernel")
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores: I8 row)
 F64_VALU_PEAK_TFLOPS = 78.6    # f64 vector peak (public MI355X spec; 256 CUs x 128 flop/clk x 2.4 GHz)
@@ -396,6 +398,8 @@ def main():
                 if two_stage:
                     kern["q2_ms"] = kern.get("q2_ms", 0.0) + q2_ms
                     kern["q2_gflop"] = kern.get("q2_gflop", 0.0) + q2_gflop
+                    kern["q2_launches"] = int(round(lib().jxg_last_kernel_ms(12)))
+                    kern["q2_form"] = int(round(lib().jxg_last_kernel_ms(13)))
                     for name, v in zip(("eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform"), eig_st):
                         stage[name] = stage.get(name, 0.0) + v * 1e-3
                     stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3
@@ -446,9 +450,11 @@ def main():
         return {"value": leg["kept_total"] * steps / leg["elapsed"], "unit": "SNPs/s", "steps": steps,
                 "ms_per_step": leg["elapsed"] / steps * 1e3, "m_kept": int(leg["kept_total"]),
                 "stages_ms_per_step": {kk: v / steps * 1e3 for kk, v in leg["stage"].items()},
-                "roofline": ({"bound": "mfma", "kernel": "sbback_apply_pair_kernel" if (n + 15) // 16 >= 8 * 256 else "sbback_apply_reg_kernel",
+                "roofline": ({"bound": "mfma", "kernel": Q2_FORMS[int(k.get("q2_form", 0))],
                               "achieved": k["q2_gflop"] / max(k["q2_ms"], 1e-9), "peak": 78.6, "unit": "TFLOP/s",
-                              "frac": k["q2_gflop"] / max(k["q2_ms"], 1e-9) / 78.6, "avg_launch_ms": k["q2_ms"] / L,
+                              "frac": k["q2_gflop"] / max(k["q2_ms"], 1e-9) / 78.6,
+                              "avg_launch_ms": k["q2_ms"] / L / max(1, int(k.get("q2_launches", 1))),
+                              "launches_per_decomposition": int(k.get("q2_launches", 1)),
                               "traffic": None,
                               "note": "Q2 back-transformation of this leg: algorithmic 2 n^3 f64 flops over the kernel's HIP-event "
                                       "duration, against the 78.6 TFLOP/s f64 MFMA peak"} if k.get("two_stage") else None),
@@ -499,13 +505,16 @@ def main():
             # calibrated on the kernel's known row bytes (n^3 / 8 = 1.00 TB at n = 20000 vs 1.01 - 1.02 TB raw FETCH_SIZE, with
             # 8-byte row reads in profiles/r03a and 16-byte ones in r03b) the counter is exact here, not halved
             # n >= 32768 (eight 16-column units per CU): one wave per unit, two sweep groups per pass (k_sbback.hip)
-            q2_kernel = "sbback_apply_pair_kernel" if (n + 15) // 16 >= 8 * int(info[0]) else "sbback_apply_reg_kernel"
+            q2_kernel = Q2_FORMS[int(kern.get("q2_form", 0))]
+            q2_launches = max(1, int(kern.get("q2_launches", 1)))
+            q2_pairs = kern.get("q2_form", 0) in (2, 3)             # two sweep groups per pass over the rows
             tr_q2, tr_q2_src = pmc_traffic_bytes("jx::" + q2_kernel, fetch_scale=1.0)
             mu_q2, mu_q2_src = pmc_mfma_util(q2_kernel)
             roofline_main = {"bound": "mfma", "kernel": q2_kernel, "achieved": q2_tflops,
                              "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": q2_tflops / F64_MFMA_PEAK_TFLOPS,
-                             "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L,
-                             "traffic_over_algorithmic": (tr_q2 / (2.0 * float(n) ** 3 / 8.0)) if tr_q2 else None,   # n^3 / 8 B each way
+                             "traffic": tr_q2, "traffic_source": tr_q2_src, "avg_launch_ms": kern["q2_ms"] / L / q2_launches,
+                             "launches_per_decomposition": q2_launches,
+                             "traffic_over_algorithmic": (tr_q2 * q2_launches / (2.0 * float(n) ** 3 / (16.0 if q2_pairs else 8.0))) if tr_q2 else None,   # n^3 / 8 B each way (n^3 / 16 with two groups per pass)
                              "traffic_over_result": (tr_q2 / (16.0 * float(n) * n)) if tr_q2 else None,
                              "mfma_util_pmc": mu_q2, "mfma_util_source": mu_q2_src,
                              "note": "algorithmic flops = 4 n sum(reflector lengths) ~ 2 n^3 for C <- Q2 C (DESIGN.md 3.5); the "

@@ -2292,6 +2292,32 @@ def test_eigh_panel_and_tail_boundaries(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [8210, 16390])
+def test_eigh_balanced_q2_forms(n):
+    """The balanced form of the Q2 back-transformation (csrc/k_sbback.hip, sbback_apply_bal_kernel) at its two slab widths:
+    n = 8210 -> 514 units, slabs of four / three 16-column units (waves 4 - 7 are the loader only); n = 16 390 -> 1025 units,
+    slabs of five (four 16-column waves + the four-column waves on v_mfma_f64_4x4x4_f64), the last unit partly padding.
+    Residual and orthogonality on the device at the eigensolver's usual thresholds, against the three-waves-per-unit form
+    (JXGPU_SBBACK_BAL5=0 in a second process is not needed: the invariants pin the result)."""
+    import torch
+    from janusx_amd import pipeline as jp
+    from janusx_amd._lib import lib
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    z = torch.randn((n, n + 40), generator=g, device="cuda", dtype=torch.float32)
+    k = (z @ z.T / (n + 40)).to(torch.float64)
+    k = 0.5 * (k + k.T)
+    del z
+    w, u = jp.eigh_from_grm(k, ridge=0.0)
+    assert int(round(lib().jxg_last_kernel_ms(13))) == 3             # the balanced form ran
+    sc = float(w.abs().max())
+    assert bool((w[1:] >= w[:-1]).all())
+    assert float((u @ k - w[:, None] * u).abs().max()) / sc < 1e-10
+    assert float((u @ u.T - torch.eye(n, device="cuda", dtype=torch.float64)).abs().max()) < 1e-10
+    assert abs(float(w.sum()) - float(torch.diagonal(k).sum())) / (n * sc) < 1e-12
+
+
+@pytest.mark.gpu
 def test_spreml_reference_vectors_through_the_gpu_path(oracle, tmp_path):
     """The reference's own sparse-REML cases (src/stats/spreml.rs:1209-1329) through the spectral GPU evaluation:
     fixed lambda on an indefinite K and the fastGWA objective agree with the dense-Cholesky restatement to 1e-12."""

@@ -882,7 +882,7 @@ __device__ __forceinline__ double qb_dpp(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <int W>                                               // slab width: 80 (five units) or 64 (four units: waves 4 - 7 are the loader only)
+template <int W>                                               // slab width: 16 x (4 .. 7 units); 64: waves 4 - 7 are the loader only
 __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     extern __shared__ __attribute__((aligned(16))) double qb_smem[];
     double *vl = qb_smem;                                      // [2][QR_BLK]: 0 = upper group's block, 1 = lower group's
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         // 16-column wave on the same SIMD is never short of ready work, and with equal priorities the older wave wins every
         // arbitration, so this wave's products would only start when the other one has reached the barrier
         if (!(P.skip & 256)) __builtin_amdgcn_s_setprio(3);
-        const bool have = W == 80 && nb >= 5 && !(P.skip & 32);           // a slab of four units has no fifth: loader duty only
+        const bool have = W > 64 && nb >= 5 && !(P.skip & 32);            // a slab of four units has no fifth: loader duty only
         auto dma_part = [&](int grp, int k, int buf) {
             const char *src = reinterpret_cast<const char *>(P.vu + ((int64_t)(grp - P.g_lo) * P.ks + k) * (2 * QR_BLK)) + lane * 16;
             const unsigned v_dst = (unsigned)(uintptr_t)(vl + buf * QR_BLK), u_dst = (unsigned)(uintptr_t)(ul + buf * QR_BLK);
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                              : "v"(src + QR_BLK * 8 + i * 1024), "s"(__builtin_amdgcn_readfirstlane(u_dst + i * 1024))
                              : "memory");
             }
-            if (W != 80) return;
+            if (W == 64) return;
             const char *srcm = reinterpret_cast<const char *>(P.um + ((int64_t)(grp - P.g_lo) * P.ks + k) * QR_BLK) + lane * 16;
             const unsigned m_dst = (unsigned)(uintptr_t)(uml + buf * QR_BLK);
 #pragma unroll
@@ -948,47 +948,69 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                              : "memory");
             }
         };
-        double *cpm = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (64 + 4 * mw + x);
-        // a 32-row set: registers [h] <-> row rb + 16 h + 4 blk + kq; one 16-byte access = the row pair of that row
-        auto set_load = [&](int rb, d2 (&raw)[2]) {
+        // this wave's share: four columns of each unit beyond the fourth of the slab (mc = nb - 4 units, at most MCMAX)
+        constexpr int MCMAX = W / 16 - 4 > 0 ? W / 16 - 4 : 1;
+        const int mc = have ? nb - 4 : 0;
+        double *cpm = P.ct + (int64_t)blockIdx.x * n2 * W + 2 * (64 + 4 * mw + x);      // + 32 qd doubles for the unit 4 + qd
+        // a 32-row set: registers [qd][h] <-> row rb + 16 h + 4 blk + kq of unit 4 + qd; one 16-byte access = the row pair of that row
+        auto set_load = [&](int rb, d2 (&raw)[MCMAX][2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = rb + 16 * h + 4 * blk + kq;
-                const double *src = cpm + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[h]) : "v"(src) : "memory");
+            for (int qd = 0; qd < MCMAX; ++qd) {
+                if (qd >= mc) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = rb + 16 * h + 4 * blk + kq;
+                    // a plain load (the compiler tracks it): the asm loads of the 16-column code leave the register unwritten until
+                    // the data lands, which is only safe while the compiler never copies the value in between -- with two or
+                    // three units per wave it does (v_mov_b64 of the in-flight registers: garbage).  The memory-clobbering asm
+                    // statements around keep the load where it is written; the compiler's own wait sits in front of the first use,
+                    // behind the counter wait of the barrier before
+                    const double *src = cpm + 32 * qd + (int64_t)(min(row, n2 - 2) >> 1) * (2 * W);
+                    raw[qd][h] = *reinterpret_cast<const d2 *>(src);
+                }
             }
         };
-        auto set_unpack = [&](int rb, const d2 (&raw)[2], double (&reg)[2]) {
+        auto set_unpack = [&](int rb, const d2 (&raw)[MCMAX][2], double (&reg)[MCMAX][2]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = rb + 16 * h + 4 * blk + kq;
-                reg[h] = (row < n) ? raw[h][kq & 1] : 0.0;
+            for (int qd = 0; qd < MCMAX; ++qd)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = rb + 16 * h + 4 * blk + kq;
+                    const double el = (kq & 1) ? raw[qd][h][1] : raw[qd][h][0];      // (a run-time vector index would go through scratch)
+                    reg[qd][h] = (row < n) ? el : 0.0;
+                }
+        };
+        auto set_store = [&](int rb, const double (&reg)[MCMAX][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int qd = 0; qd < MCMAX; ++qd) {
+                if (qd >= mc) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = rb + 16 * h + 4 * blk + kq;
+                    // asm: a store the compiler tracked would make it wait (by its own count, which does not know the image copies)
+                    // before the next step's loads reuse a register -- i.e. for the copies just issued and the stores' acknowledgements
+                    double *dst = cpm + 32 * qd + (int64_t)(row >> 1) * (2 * W) + (row & 1);
+                    if (row < n) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(reg[qd][h]) : "memory");
+                }
             }
         };
-        auto set_store = [&](int rb, const double (&reg)[2]) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = rb + 16 * h + 4 * blk + kq;
-                if (row < n) cpm[(int64_t)(row >> 1) * (2 * W) + (row & 1)] = reg[h];
-            }
-        };
-        // one 96-row block on three sets (image rows 32 w + 16 h + ...)
-        // LDS addresses of the operands: the bank swizzles of the images (qr_u_at / qr_v_at) depend on the lane only, not on the
-        // 16-row half hh of the window: eight lane terms per image + hh * 512 doubles as an immediate offset
+        // LDS addresses of the V operands: the bank swizzle of the image (qr_v_at) depends on the lane only, not on the 16-row half
+        // hh of the window: eight lane terms + hh * 512 doubles as an immediate offset
         const int vsw = 2 * (4 * blk + x);
         int voff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) voff[i] = (4 * blk + x) * QB_G + ((4 * i + kq) ^ vsw);       // V[q = 16 hh + 4 blk + x][m = 4 ks + kq]
-        auto mini_block = [&](int buf, double (&c0)[2], double (&c1)[2], double (&c2)[2]) {
+        // one 96-row block on three sets (image rows 32 w + 16 h + ...), every unit of this wave with the same operands
+        auto mini_block = [&](int buf, double (&c0)[MCMAX][2], double (&c1)[MCMAX][2], double (&c2)[MCMAX][2]) __attribute__((always_inline)) {
             const double *vbuf = vl + buf * QR_BLK;
             // operands one 16-row half (first product) / one 4-column step (second product) ahead of the instructions that use
             // them: eight or six LDS reads in flight behind the previous step's products.  (All 84 reads of the block at once
-            // made the four waves of this kind queue ~4800 LDS cycles right behind every barrier -- the 4-way bank conflicts of
-            // the U image under this access pattern included --, and the 16-column waves waited for their own operands behind
-            // that queue: the block interval grew by about that much.)
+            // made the four waves of this kind queue ~4800 LDS cycles right behind every barrier -- the 8-way bank conflicts of
+            // the [q][m] U image under this access pattern included --, and the 16-column waves waited for their own operands
+            // behind that queue: the block interval grew by about that much.)
             double ua[2][8], va[2][6];
             const d2 *umb = reinterpret_cast<const d2 *>(uml + buf * QR_BLK) + lane;
-            auto u_load = [&](int hh, double (&dst)[8]) {
+            auto u_load = [&](int hh, double (&dst)[8]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (hh == 0 && u >= 2) continue;           // U[q][m] = 0 for q <= m: rows 0 .. 15 against columns >= 16
@@ -997,48 +1019,79 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                     dst[2 * u + 1] = pr[1];
                 }
             };
-            auto v_load = [&](int ks, double (&dst)[6]) {
+            auto v_load = [&](int ks, double (&dst)[6]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int hh = 0; hh < 6; ++hh)
                     if (!((hh == 0 && ks >= 4) || (hh == 5 && ks < 4))) dst[hh] = vbuf[voff[ks] + hh * 16 * QB_G];   // V[q][m] != 0: m < q <= m + 64
             };
-            double y[8];
+            double y[MCMAX][8];
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) y[tt] = 0.0;
+            for (int qd = 0; qd < MCMAX; ++qd)
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) y[qd][tt] = 0.0;
             u_load(0, ua[0]);
 #pragma unroll
             for (int hh = 0; hh < 6; ++hh) {
                 if (hh + 1 < 6) u_load(hh + 1, ua[(hh + 1) & 1]);
                 else v_load(0, va[0]);
-                const double b = hh < 2 ? c0[hh] : (hh < 4 ? c1[hh - 2] : c2[hh - 4]);
+#pragma unroll
+                for (int qd = 0; qd < MCMAX; ++qd) {
+                    if (qd >= mc) continue;
+                    const double b = hh < 2 ? c0[qd][hh] : (hh < 4 ? c1[qd][hh - 2] : c2[qd][hh - 4]);
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt) {
+                        if (hh == 0 && tt >= 4) continue;
+                        y[qd][tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[hh & 1][tt], b, y[qd][tt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int qd = 0; qd < MCMAX; ++qd) {
+                if (qd >= mc) continue;
 #pragma unroll
                 for (int tt = 0; tt < 8; ++tt) {
-                    if (hh == 0 && tt >= 4) continue;
-                    y[tt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[hh & 1][tt], b, y[tt], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                double sm = y[tt];
-                if (!(P.skip & 2048)) {
+                    double sm = y[qd][tt];
                     sm += qb_dpp<0x124>(sm);                   // row_ror:4
                     sm += qb_dpp<0x128>(sm);                   // row_ror:8: the sum over the four blocks in every lane
+                    y[qd][tt] = -sm;
                 }
-                y[tt] = -sm;
             }
-            double *cw[6] = {&c0[0], &c0[1], &c1[0], &c1[1], &c2[0], &c2[1]};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) v_load(ks + 1, va[(ks + 1) & 1]);
 #pragma unroll
-                for (int hh = 0; hh < 6; ++hh) {               // six independent accumulators per step
-                    if ((hh == 0 && ks >= 4) || (hh == 5 && ks < 4)) continue;
-                    *cw[hh] = __builtin_amdgcn_mfma_f64_4x4x4f64(va[ks & 1][hh], y[ks], *cw[hh], 0, 0, 0);
+                for (int qd = 0; qd < MCMAX; ++qd) {
+                    if (qd >= mc) continue;
+#pragma unroll
+                    for (int hh = 0; hh < 6; ++hh) {           // six independent accumulators per step
+                        if ((hh == 0 && ks >= 4) || (hh == 5 && ks < 4)) continue;
+                        double &cw = hh < 2 ? c0[qd][hh] : (hh < 4 ? c1[qd][hh - 2] : c2[qd][hh - 4]);
+                        cw = __builtin_amdgcn_mfma_f64_4x4x4f64(va[ks & 1][hh], y[qd][ks], cw, 0, 0, 0);
+                    }
                 }
             }
         };
-        double M[4][2];
-        d2 pfm[2][2];
+        double M[4][MCMAX][2];
+        d2 pfm[2][MCMAX][2];
+        // wait until at most `younger` of this wave's vector-memory operations are outstanding (4 per unit and kind: the counts
+        // are those of mc = 1 .. 3 units)
+        auto wait_vm = [&](int younger) __attribute__((always_inline)) {
+            switch (younger) {
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+        // everything landed; the prefetch registers pass through the statement so that their unpacking cannot be scheduled in front
+        // of it (the selects have no other dependence: hoisted into the second block they took the compiler's wait with them)
+        auto wait_all_pf = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int qd = 0; qd < MCMAX; ++qd)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][qd][0]), "+v"(pfm[0][qd][1]), "+v"(pfm[1][qd][0]), "+v"(pfm[1][qd][1]) : : "memory");
+        };
         for (int pass = 0; pass < npass; ++pass) {
             int gu, gl;
             pass_groups(pass, gu, gl);
@@ -1052,59 +1105,75 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
             if (have) {
                 set_load(sl, pfm[0]);
                 set_load(sl + 32, pfm[1]);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                wait_all_pf();
                 set_unpack(sl, pfm[0], M[0]);
                 set_unpack(sl + 32, pfm[1], M[1]);
                 set_load(sl + 64, pfm[0]);
                 set_load(sl + 96, pfm[1]);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                wait_all_pf();
                 set_unpack(sl + 64, pfm[0], M[2]);
                 set_unpack(sl + 96, pfm[1], M[3]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             qr_lds_barrier();                                  // G1: the images of the first two blocks are in place
-            auto step = [&](auto phc, int k) {
+            auto step = [&](auto phc, int k) __attribute__((always_inline)) {
                 constexpr int PH = decltype(phc)::value;
-                double (&a0)[2] = M[(0 + 2 * PH) % 4];
-                double (&a1)[2] = M[(1 + 2 * PH) % 4];
-                double (&a2)[2] = M[(2 + 2 * PH) % 4];
-                double (&a3)[2] = M[(3 + 2 * PH) % 4];
+                double (&a0)[MCMAX][2] = M[(0 + 2 * PH) % 4];
+                double (&a1)[MCMAX][2] = M[(1 + 2 * PH) % 4];
+                double (&a2)[MCMAX][2] = M[(2 + 2 * PH) % 4];
+                double (&a3)[MCMAX][2] = M[(3 + 2 * PH) % 4];
                 const int wb = sl + k * QB_SB;
                 const bool has_next = k + 1 < nkl;
-                if (have) {
-                    if (k > 0) {                               // the prefetch landed before B2 of the previous step (vmcnt(0) there)
-                        set_unpack(wb + 64, pfm[0], a2);
-                        set_unpack(wb + 96, pfm[1], a3);
-                    }
-                    if (has_next && !(P.skip & 18)) {
-                        set_load(wb + 128, pfm[0]);
-                        set_load(wb + 160, pfm[1]);
-                    }
-                    if (k < nku && !(P.skip & 1)) mini_block(0, a1, a2, a3);    // block (g, k): rows wb + 32 ...
-                }
-                // the copies into buffer 1 were issued behind B2 of the previous step; younger than them are only that step's four
-                // row stores and this step's four prefetch loads (the counter retires in issue order): waiting for everything would
-                // put an HBM round trip of the prefetch in front of every barrier
-                if (have && k > 0 && !(P.skip & 512)) {
-                    if (has_next && !(P.skip & 18)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
+                if (!have) {                                   // loader duty only
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    qr_lds_barrier();                          // B1(k)
+                    if (k + 1 < nku) dma_part(gu, k + 1, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    qr_lds_barrier();                          // B2(k)
+                    if (k + 1 < nkl) dma_part(gl, k + 1, 1);
+                    return;
                 }
+                // The row prefetch and its unpacking are UNCONDITIONAL on this path (row addresses are clamped; the last step of
+                // a pass loads 4 mc row pairs nobody uses): the compiler tracks these loads with its own counter, and on a path
+                // where loads might be pending it waits -- by its count, which knows nothing of the image copies -- before the
+                // next loads reuse the registers; with conditions it cannot correlate that wait landed on every step.
+                set_load(wb + 128, pfm[0]);
+                set_load(wb + 160, pfm[1]);
+                if (k < nku) mini_block(0, a1, a2, a3);        // block (g, k): rows wb + 32 ...
+                // the copies into buffer 1 were issued behind B2 of the previous step; younger than them are only that step's 4 mc
+                // row stores and this step's 4 mc prefetch loads (the counter retires in issue order): waiting for everything would
+                // put an HBM round trip of the prefetch in front of every barrier
+                if (k > 0 && !(P.skip & 512)) wait_vm(8 * mc);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 qr_lds_barrier();                              // B1(k): buffer 0 consumed, buffer 1 holds (gl, k)
-                if (k + 1 < nku && !(P.skip & 4)) dma_part(gu, k + 1, 0);
-                if (have && !(P.skip & 1)) mini_block(1, a0, a1, a2);           // block (g - 1, k): rows wb ...
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pfm[0][0]), "+v"(pfm[0][1]), "+v"(pfm[1][0]), "+v"(pfm[1][1]) : : "memory");
+                if (k + 1 < nku) dma_part(gu, k + 1, 0);
+                mini_block(1, a0, a1, a2);                     // block (g - 1, k): rows wb ...
+                wait_all_pf();
+                // the prefetched rows are taken out of their load registers HERE, behind the wait that has just drained the counter:
+                // at the top of the next step the compiler's own wait in front of the first use would also cover the image copies
+                // issued behind B2 (invisible to it), i.e. the copies' latency would no longer hide behind the first block
+                double nx[2][MCMAX][2];
+                set_unpack(wb + 128, pfm[0], nx[0]);
+                set_unpack(wb + 160, pfm[1], nx[1]);
+#pragma unroll
+                for (int qd = 0; qd < MCMAX; ++qd)             // materialise the values here (the scheduler would sink the selects -- and
+#pragma unroll                                                 // with them its wait -- to their use behind the copies and the stores)
+                    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(nx[0][qd][h]), "+v"(nx[1][qd][h]));
                 qr_lds_barrier();                              // B2(k): buffer 1 consumed, buffer 0 holds (gu, k + 1)
-                if (k + 1 < nkl && !(P.skip & 4)) dma_part(gl, k + 1, 1);
-                if (have && !(P.skip & 10)) {
-                    set_store(wb, a0);
-                    set_store(wb + 32, a1);
-                    if (!has_next) {
-                        set_store(wb + 64, a2);
-                        set_store(wb + 96, a3);
-                    }
+                if (k + 1 < nkl) dma_part(gl, k + 1, 1);
+                set_store(wb, a0);                             // 4 mc stores (the last step's other two sets: behind the loop)
+                set_store(wb + 32, a1);
+                if (!has_next) {
+                    set_store(wb + 64, a2);
+                    set_store(wb + 96, a3);
                 }
+#pragma unroll
+                for (int qd = 0; qd < MCMAX; ++qd)             // the two leading sets are stored: they become the next step's a2, a3
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        a0[qd][h] = nx[0][qd][h];
+                        a1[qd][h] = nx[1][qd][h];
+                    }
             };
             int k = 0;
             for (; k + 2 <= nkl; k += 2) {
@@ -1215,8 +1284,8 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
     // share an L2 and run in step) of the images of step k + 2 -- five 1 KB LDS-DMA loads into a dummy KB, no register written,
     // nobody waits for them; they only count in this wave's memory counter (13 instead of 8 younger operations at the wait).
     const bool l2warm = unit == 0 && !(P.skip & 4096);
-    constexpr int NWARM = W == 80 ? 5 : 3;                     // 144 (96 without the third image) KB-sized pieces over 32 workgroups
-    constexpr int NPIECE = W == 80 ? 72 : 48;                  // pieces per group
+    constexpr int NWARM = W > 64 ? 5 : 3;                      // 144 (96 without the third image) KB-sized pieces over 32 workgroups
+    constexpr int NPIECE = W > 64 ? 72 : 48;                   // pieces per group
     int cur_gu = -1, cur_gl = -1;
     auto warm = [&](int k2) {
         const int j = (int)(blockIdx.x >> 3) & 31;
@@ -1239,7 +1308,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         }
     };
     auto wait_pf = [&](bool eight_behind) {
-        if (eight_behind && l2warm && W == 80)
+        if (eight_behind && l2warm && W > 64)
             asm volatile("s_waitcnt vmcnt(13)" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[0][2]), "+v"(pf[0][3]), "+v"(pf[1][0]),
                          "+v"(pf[1][1]), "+v"(pf[1][2]), "+v"(pf[1][3]) : : "memory");
         else if (eight_behind && l2warm)
@@ -1365,7 +1434,7 @@ static int qr_groups_per_launch(int n, int ks) {
     // the drain and refill of one block interval
     const bool bal = qr_bal(n);
     const double per_group = (double)ks * (bal ? 3 : 2) * QR_BLK * sizeof(double);
-    int g = (int)((bal ? 2.5e9 : 12.0e9) / per_group);
+    int g = (int)(((bal && n <= 20480) ? 2.5e9 : 12.0e9) / per_group);
     if (getenv("JXGPU_SBBACK_GROUPS") && atoi(getenv("JXGPU_SBBACK_GROUPS")) > 0) g = atoi(getenv("JXGPU_SBBACK_GROUPS"));
     if (g < 1) g = 1;
     return g < ngroups ? g : ngroups;
@@ -1398,20 +1467,41 @@ static bool qr_bal(int ncols) {
     const int units = (ncols + 15) / 16;
     static const int env = getenv("JXGPU_SBBACK_BAL5") ? atoi(getenv("JXGPU_SBBACK_BAL5")) : 1;
     static const int lo = getenv("JXGPU_SBBACK_BAL_MIN") ? atoi(getenv("JXGPU_SBBACK_BAL_MIN")) : 2;   // more than `lo` units per CU (measured: 84.8 against 89.3 ms at n = 10 000, slower at 8000)
-    const int cus = device_cus();
-    return env != 0 && units > lo * cus && units <= 5 * cus;
+    // one round of slabs only (at most seven units per CU, n <= 28 672): with two rounds at n = 50 000 the four-column waves carry
+    // 2 - 3 of a slab's 6 - 7 units through their 8-byte row stores and the stage is as much HBM- as pipe-bound there -- 7.71 s
+    // against 6.82 s for the two-groups-per-pass form with one wave per unit
+    return env != 0 && units > lo * device_cus() && units <= 7 * device_cus();
 }
-// units per slab of the balanced form: five (four 16-column waves + the four-column waves) above four units per CU, else four
-static int qr_bal_nu(int ncols) { return (ncols + 15) / 16 > 4 * device_cus() ? 5 : 4; }
+// slabs of the balanced form: R = ceil(units / (7 CUs)) full rounds of CUs workgroups with the units dealt evenly, 4 .. 7 units
+// per slab (four 16-column waves + the four-column waves on the units beyond the fourth); below four units per CU whole slabs of four
+static void qr_bal_plan(int ncols, int *g, int *per) {
+    const int units = (ncols + 15) / 16, cus = device_cus();
+    int gg = ((units + 7 * cus - 1) / (7 * cus)) * cus;
+    int pp = (units + gg - 1) / gg;
+    if (pp < 4) {
+        pp = 4;
+        gg = (units + 3) / 4;
+    }
+    static const int force = getenv("JXGPU_SBBACK_BAL_PER") ? atoi(getenv("JXGPU_SBBACK_BAL_PER")) : 0;   // diagnostic: units per slab
+    if (force >= 4 && force <= 7) {
+        pp = force;
+        gg = (units + pp - 1) / pp;
+    }
+    *g = gg;
+    *per = pp;
+}
+static int qr_bal_nu(int ncols) {
+    int g, per;
+    qr_bal_plan(ncols, &g, &per);
+    return per;
+}
 
 static void qr_plan(int ncols, int *g_out, int *nu_out) {
     const int units = (ncols + 15) / 16;
     const int cus = device_cus();
     int nu, g;
-    if (qr_bal(ncols) && !qr_solo(ncols)) {
-        const int per = qr_bal_nu(ncols);      // slabs of five (four) units, a few of one less when the count does not divide
-        *g_out = (units + per - 1) / per;
-        *nu_out = per;
+    if (qr_bal(ncols)) {
+        qr_bal_plan(ncols, g_out, nu_out);
         return;
     }
     if (qr_solo(ncols)) {
@@ -1481,8 +1571,8 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
         if ((size_t)gslabs * nu * 16 > std::max((size_t)gn * nun * 16, (size_t)n + 96))
             return fail("sbback_apply_q2: slab plan exceeds the workspace");
     }
-    const bool solo = qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
-    const bool bal = !solo && qr_bal(ncols) && qr_bal(n) && nu == qr_bal_nu(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const bool bal = qr_bal(ncols) && qr_bal(n) && nu == qr_bal_nu(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
+    const bool solo = !bal && qr_solo(ncols) && !(getenv("JXGPU_SBBACK_BAL") && atoi(getenv("JXGPU_SBBACK_BAL")) == 0);
     const size_t lds = bal ? sizeof(double) * (6 * (size_t)QR_BLK + 128)
                            : (solo ? sizeof(double) * 4 * (size_t)QR_BLK : sizeof(double) * (4 * (size_t)QR_BLK + (size_t)nu * 3 * 8 * 64));
     const dim3 grid(gslabs);
@@ -1513,7 +1603,7 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
     g_last_ms[13] = bal ? 3.f : (solo ? (qr_pair() ? 2.f : 1.f) : 0.f);
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
         const int g_lo = g_hi > gpl ? g_hi - gpl : 0;
-        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, (bal && nu == 5) ? d_um : nullptr};
+        QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, (bal && nu >= 5) ? d_um : nullptr};
         hipLaunchKernelGGL(sbback_vu_kernel, dim3(ks, g_hi - g_lo), dim3(128), 0, st, P);
         JX_LAUNCH_CHECK();
         hipEvent_t e0 = (g_hi == ngroups) ? ev_start : nullptr, e1 = (g_lo == 0) ? ev_stop : nullptr;
@@ -1542,10 +1632,17 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
             if (!attr_set) {
                 JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                JX_HIP(hipFuncSetAttribute((const void *)sbback_apply_bal_kernel<112>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_set = true;
             }
-            if (nu == 5) hipExtLaunchKernelGGL(sbback_apply_bal_kernel<80>, grid, dim3(512), lds, st, e0, e1, 0, P);
-            else hipExtLaunchKernelGGL(sbback_apply_bal_kernel<64>, grid, dim3(512), lds, st, e0, e1, 0, P);
+            switch (nu) {
+                case 4: hipExtLaunchKernelGGL(sbback_apply_bal_kernel<64>, grid, dim3(512), lds, st, e0, e1, 0, P); break;
+                case 5: hipExtLaunchKernelGGL(sbback_apply_bal_kernel<80>, grid, dim3(512), lds, st, e0, e1, 0, P); break;
+                case 6: hipExtLaunchKernelGGL(sbback_apply_bal_kernel<96>, grid, dim3(512), lds, st, e0, e1, 0, P); break;
+                case 7: hipExtLaunchKernelGGL(sbback_apply_bal_kernel<112>, grid, dim3(512), lds, st, e0, e1, 0, P); break;
+                default: return fail("sbback_apply_q2: balanced slab width out of range");
+            }
         } else if (solo && qr_pair()) {
 #define JX_QR_PAIR(NWV)                                                                                                \
     do {                                                                                                               \

@@ -2292,11 +2292,12 @@ def test_eigh_panel_and_tail_boundaries(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [8210, 16390])
+@pytest.mark.parametrize("n", [8210, 16390, 22010])
 def test_eigh_balanced_q2_forms(n):
-    """The balanced form of the Q2 back-transformation (csrc/k_sbback.hip, sbback_apply_bal_kernel) at its two slab widths:
+    """The balanced form of the Q2 back-transformation (csrc/k_sbback.hip, sbback_apply_bal_kernel) at its slab widths:
     n = 8210 -> 514 units, slabs of four / three 16-column units (waves 4 - 7 are the loader only); n = 16 390 -> 1025 units,
-    slabs of five (four 16-column waves + the four-column waves on v_mfma_f64_4x4x4_f64), the last unit partly padding.
+    slabs of five (four 16-column waves + the four-column waves on v_mfma_f64_4x4x4_f64), the last unit partly padding;
+    n = 22 010 -> 1376 units, slabs of six / five (two units / one unit per four-column wave).
     Residual and orthogonality on the device at the eigensolver's usual thresholds, against the three-waves-per-unit form
     (JXGPU_SBBACK_BAL5=0 in a second process is not needed: the invariants pin the result)."""
     import torch

@@ -1127,10 +1127,10 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
                 if (!have) {                                   // loader duty only
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     qr_lds_barrier();                          // B1(k)
-                    if (k + 1 < nku) dma_part(gu, k + 1, 0);
+                    if (k + 1 < nku && !(P.skip & 4)) dma_part(gu, k + 1, 0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     qr_lds_barrier();                          // B2(k)
-                    if (k + 1 < nkl) dma_part(gl, k + 1, 1);
+                    if (k + 1 < nkl && !(P.skip & 4)) dma_part(gl, k + 1, 1);
                     return;
                 }
                 // The row prefetch and its unpacking are UNCONDITIONAL on this path (row addresses are clamped; the last step of

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-# form of the Q2 back-transformation the last decomposition took (jxg_last_kernel_ms(13), csrc/k_sbback.hip)
+# form of the Q2 back-transformation the last decomposition took (jxg_last_kernel_ms(17), csrc/k_sbback.hip)
 Q2_FORMS = ("sbback_apply_reg_kernel", "sbback_apply_solo_kernel", "sbback_apply_pair_kernel", "sbback_apply_bal_kernel")
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec, no sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2 x the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores: I8 row)
@@ -398,8 +398,8 @@ def main():
                 if two_stage:
                     kern["q2_ms"] = kern.get("q2_ms", 0.0) + q2_ms
                     kern["q2_gflop"] = kern.get("q2_gflop", 0.0) + q2_gflop
-                    kern["q2_launches"] = int(round(lib().jxg_last_kernel_ms(12)))
-                    kern["q2_form"] = int(round(lib().jxg_last_kernel_ms(13)))
+                    kern["q2_launches"] = int(round(lib().jxg_last_kernel_ms(16)))
+                    kern["q2_form"] = int(round(lib().jxg_last_kernel_ms(17)))
                     for name, v in zip(("eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform"), eig_st):
                         stage[name] = stage.get(name, 0.0) + v * 1e-3
                     stage["eigh_q2_backtransform_kernel"] = stage.get("eigh_q2_backtransform_kernel", 0.0) + q2_ms * 1e-3

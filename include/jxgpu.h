@@ -366,7 +366,7 @@ int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *
  * of the symv launches sampled by the most recent jxg_eigh_f64 (one per 64-column panel), which = 3: the mean
  * algorithmic megabytes (lower triangle of the trailing matrix, f64) of those launches; which = 4 / 5: duration (ms) and algorithmic
  * GFLOP of the Q2 back-transformation of the most recent two-stage decomposition, 6 - 9: band reduction, bulge chasing, divide and
- * conquer, Q1 (ms), 10: 1 when the two-stage path ran, 12: apply launches of that Q2, 13: its form (0 three waves per unit, 1 one
+ * conquer, Q1 (ms), 10: 1 when the two-stage path ran, 16: apply launches of that Q2, 17: its form (0 three waves per unit, 1 one
  * wave per unit, 2 two sweep groups per pass, 3 balanced five / four units per CU).  Counterpart of the
  * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
 float jxg_last_kernel_ms(int which);

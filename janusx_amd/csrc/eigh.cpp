@@ -47,7 +47,7 @@ int sb2st_chase(hipStream_t st, double *d_ab, int n, double *d_d, double *d_e, d
 size_t sbback_tq_doubles(int n, int ks);
 int sbback_apply_q2(hipStream_t st, const double *d_v2, const double *d_tau2, int n, int ks, double *d_c, int ncols,
                     double *d_tq, hipEvent_t ev_start, hipEvent_t ev_stop);
-extern float g_last_ms[16];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
+extern float g_last_ms[24];   // [4] Q2 apply kernel ms, [5] its algorithmic GFLOP, [6] band reduction ms, [7] bulge chasing ms,
                               // [8] divide and conquer ms, [9] Q1 back-transformation ms, [10] 1 = two-stage path taken
 int ormtr_lower_off(hipStream_t st, const double *d_a, int n, int off, int nref, const double *d_tau, double *d_c, int ncols);
 // the C-independent part of the Q1 back-transformation (V images, Gram, T, V T per block) prepared ahead on a side stream

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void grm_finalize_kernel(const double *__restr
 using namespace jx;
 
 namespace jx {
-float g_last_ms[16] = {0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2-3: symv sample, 4-10: eigensolver stages (eigh.cpp), 11: scan form, 12: int8 share of the last GRM
+float g_last_ms[24] = {0.f};  // 0: GRM MFMA kernel(s), 1: rotation kernel, 2-3: symv sample, 4-10: eigensolver stages (eigh.cpp), 11: scan form, 12: int8 share of the last GRM
 int g_timer_pending[4] = {0, 0, 0, 0};
 extern hipEvent_t g_rot_a, g_rot_b;
 struct EventPair {
@@ -655,7 +655,7 @@ extern "C" int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, cons
                               const float *d_lut, const double *d_beta, double *d_out, void *stream);
 
 extern "C" float jxg_last_kernel_ms(int which) {
-    if (which < 0 || which >= 16) return 0.f;
+    if (which < 0 || which >= 24) return 0.f;
     if (which == 1 && g_timer_pending[1] && g_rot_b) {
         if (hipEventSynchronize(g_rot_b) == hipSuccess) (void)hipEventElapsedTime(&g_last_ms[1], g_rot_a, g_rot_b);
         g_timer_pending[1] = 0;

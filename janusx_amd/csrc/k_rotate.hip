@@ -555,7 +555,7 @@ int launch_rotate256(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int 
 int launch_rotate_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
                      int nsel, const void *d_lut16, const float *d_rowoff, const float *d_usum, const int8_t *d_q,
                      const float *d_umax, float *d_out, int64_t ld_out);
-extern float g_last_ms[16];
+extern float g_last_ms[24];
 extern int g_timer_pending[4];
 hipEvent_t g_rot_a = nullptr, g_rot_b = nullptr;
 }  // namespace jx

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
     }
 }
 
-extern float g_last_ms[16];
+extern float g_last_ms[24];
 
 }  // namespace jx
 

@@ -1551,7 +1551,7 @@ static int device_cus() {
 
 // register form: launches of <= qr_groups_per_launch groups, from the last group down; ev_start / ev_stop bracket the
 // apply kernels (first / last launch)
-extern float g_last_ms[16];   // [12] apply launches of the last back-transformation, [13] its form: 0 three waves per unit, 1 one
+extern float g_last_ms[24];   // [16] apply launches of the last back-transformation, [17] its form: 0 three waves per unit, 1 one
                               // wave per unit, 2 one wave per unit and two groups per pass, 3 balanced (five / four units per CU)
 static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double *d_tau2, int n, int ks, double *d_c, int ncols,
                                double *d_vu, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1599,8 +1599,8 @@ static int sbback_apply_q2_reg(hipStream_t st, const double *d_v2, const double 
     }
     hipLaunchKernelGGL(sbback_slab_kernel<true>, sgrid, dim3(256), slds, st, d_c, d_ct, n, ncols, w, units);
     JX_LAUNCH_CHECK();
-    g_last_ms[12] = (float)ceil_div(ngroups, gpl);
-    g_last_ms[13] = bal ? 3.f : (solo ? (qr_pair() ? 2.f : 1.f) : 0.f);
+    g_last_ms[16] = (float)ceil_div(ngroups, gpl);
+    g_last_ms[17] = bal ? 3.f : (solo ? (qr_pair() ? 2.f : 1.f) : 0.f);
     for (int g_hi = ngroups; g_hi > 0; g_hi -= gpl) {
         const int g_lo = g_hi > gpl ? g_hi - gpl : 0;
         QrParams P{d_v2, d_tau2, d_vu, d_ct, n, ks, ncols, units, g_lo, g_hi, skip, (bal && nu >= 5) ? d_um : nullptr};

@@ -1476,7 +1476,7 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     return 0;
 }
 
-namespace jx { extern float g_last_ms[16]; }   // [11]: form the last exact scan launch took (0 LDS-resident, 1 tiled, 2 plain)
+namespace jx { extern float g_last_ms[24]; }   // [11]: form the last exact scan launch took (0 LDS-resident, 1 tiled, 2 plain)
 
 extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
                                 double low, double high, const void *d_work, double tol, int max_iter, int warm,

@@ -693,7 +693,7 @@ struct SytrdDist {
 static SytrdDist g_dist;
 static bool g_dist_paused = false;   // jxg_eigh_set_local: this rank decomposes a matrix of its own (no collective) for a while
 
-extern float g_last_ms[16];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
+extern float g_last_ms[24];   // [2] mean duration (ms) of the sampled symv launches, [3] their mean algorithmic MB
 
 // d_a: (n,n) column-major symmetric (lower referenced), overwritten with the LAPACK dsytrd(lower) result.
 int sytrd_lower(rocblas_handle h, hipStream_t st, double *d_a, int n, double *d_d, double *d_e, double *d_tau) {

@@ -2310,7 +2310,7 @@ def test_eigh_balanced_q2_forms(n):
     k = 0.5 * (k + k.T)
     del z
     w, u = jp.eigh_from_grm(k, ridge=0.0)
-    assert int(round(lib().jxg_last_kernel_ms(13))) == 3             # the balanced form ran
+    assert int(round(lib().jxg_last_kernel_ms(17))) == 3             # the balanced form ran
     sc = float(w.abs().max())
     assert bool((w[1:] >= w[:-1]).all())
     assert float((u @ k - w[:, None] * u).abs().max()) / sc < 1e-10

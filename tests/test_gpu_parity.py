@@ -2100,6 +2100,28 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
 
 
 @pytest.mark.gpu
+def test_distributed_eigh_balanced_q2_two_ranks_share_one_gpu():
+    """Column-sharded back-transformations at a size where a rank's share of the eigenvectors takes the balanced Q2 form (n = 20 000
+    on two ranks: 10 000 columns = 625 units in slabs of four; scripts/dist_eigh_bal_check.py): residual / orthogonality on the
+    device at 1e-10, the form reported by the library, and the two ranks' results identical."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JXGPU_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "scripts", "dist_eigh_bal_check.py"), "20000"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_BAL OK" in out.stdout and "q2_form=3" in out.stdout and "ranks_identical=True" in out.stdout
+
+
+@pytest.mark.gpu
 def test_marker_sharded_pcg_two_ranks_share_one_gpu():
     """rrBLUP PCG with the markers dealt over two ranks (jx_pcg_set_dist: one all-reduce of an n_train-vector per iteration,
     SURVEY.md 8e last row), two ranks on the one device over gloo: same iterations (+-1), beta and predictions as the

@@ -246,9 +246,16 @@ int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32
  * form at a missing call = offset + 2 [flipped]) is the weight of their
  * missing-call term, which jxg_rotate_missing_correct adds behind the rotation: out[r][j] += d_r * sum over the row's missing
  * samples i of U[i][j].  d_usamp (n, n) f32 = U with one row per sample (jxg_transpose_f32 of u_t).  Rows with more missing
- * calls stay general (NaN offset, fp16 kernel) as before.  src/stats/lmm.rs:728-784 with the decode of
+ * calls stay general (NaN offset, fp16 kernel) as before.  Beyond n / 800 missing calls per row on average jxg_rot_miss_max
+ * returns a value > 256 ("no limit"): every affine row keeps the exact path and its missing-call term is ONE MORE int8 product
+ * with the indicator of the missing calls as the integer operand, jxg_rotate_missing_dense (d_sel: positions, inside the block,
+ * of the rows with d_rowmiss != 0; d_q / d_umax: the three planes of jxg_ut_quant3) -- the cost of the fp16 kernel those rows
+ * took before, but exact; JXGPU_ROT_MISS_DENSE=0 restores the fp16 kernel.  src/stats/lmm.rs:728-784 with the decode of
  * src/decode/decode.rs:192-271. */
 int jxg_rot_miss_max(int n, double mean_missing_per_row);
+int jxg_rotate_missing_dense(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel, int nsel,
+                             const float *d_rowmiss, const int8_t *d_q, const float *d_umax, float *d_out, int64_t ld_out,
+                             void *stream);
 int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
                          int64_t mk, void *d_lut16, float *d_rowoff, float *d_rowmiss, int miss_max, void *stream);
 int jxg_transpose_f32(const float *d_src, int n, float *d_dst, void *stream);

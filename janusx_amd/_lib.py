@@ -135,6 +135,7 @@ SIGNATURES = {
     "jxg_lm_scan_dense": [c_p, c_i, c_i, c_l, c_p, c_i, c_p, c_d, c_p, c_p, c_p],
     "jxg_decode_rows_p32": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_l, c_p],
     "jxg_rot_miss_max": [c_i, c_d],
+    "jxg_rotate_missing_dense": [c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_p],
     "jxg_lut_split_rows_m": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p],
     "jxg_transpose_f32": [c_p, c_i, c_p, c_p],
     "jxg_rotate_missing_correct": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_l, c_p],

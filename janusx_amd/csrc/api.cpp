@@ -987,12 +987,16 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     if (jxg_lut_split_rows_m(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(),
                              miss_max > 0 ? drowmiss.as<float>() : nullptr, miss_max, nullptr))
         return 1;
+    // beyond n / 800 missing calls per row (limit > 256 = none): the missing-call term as one more int8 product
+    // (jxg_rotate_missing_dense) over the rows that have one, instead of the gather form
+    const bool miss_dense = miss_max > 256;
+    std::vector<float> hm;
     if (miss_max > 0) {
-        std::vector<float> hm((size_t)m);
+        hm.resize((size_t)m);
         JX_HIP(hipMemcpy(hm.data(), drowmiss.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < m && !any_rowmiss; ++i) any_rowmiss = hm[(size_t)i] != 0.0f;
     }
-    DevBuf dq, dumax, dsel;
+    DevBuf dq, dumax, dsel, dselm;
     std::vector<float> hrowoff;
     std::vector<int32_t> hsel;
     if (use_q) {
@@ -1001,7 +1005,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         if (dut2.alloc(sizeof(float) * (size_t)n * n)) return 1;
         JX_HIP(hipMemcpy(dut2.p, u_t, sizeof(float) * (size_t)n * n, hipMemcpyHostToDevice));
         if (jxg_ut_quant3(dut2.as<float>(), n, dq.as<int8_t>(), dumax.as<float>(), nullptr)) return 1;
-        if (any_rowmiss) {
+        if (any_rowmiss && !miss_dense) {
             if (dusamp.alloc(sizeof(float) * (size_t)n * n)) return 1;
             if (jxg_transpose_f32(dut2.as<float>(), n, dusamp.as<float>(), nullptr)) return 1;
         }
@@ -1010,6 +1014,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
         JX_HIP(hipMemcpy(hrowoff.data(), drowoff.p, sizeof(float) * (size_t)m, hipMemcpyDeviceToHost));
         if (dsel.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
         hsel.resize((size_t)brows);
+        if (any_rowmiss && miss_dense && dselm.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
     }
     DevBuf dsums, dachol;
     if (fused) {
@@ -1052,9 +1057,20 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
                                        ne > 0 ? dsel.as<int32_t>() : nullptr, ne, rows > ne ? dsel.as<int32_t>() + ne : nullptr,
                                        rows - ne, drot.as<float>(), nullptr))
                 return 1;
-            if (any_rowmiss && jxg_rotate_missing_correct(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
-                                                          drowmiss.as<float>() + r0, dusamp.as<float>(), drot.as<float>(), n,
-                                                          nullptr))
+            if (any_rowmiss && miss_dense) {
+                int nm = 0;
+                for (int i = 0; i < rows; ++i)
+                    if (hm[(size_t)r0 + i] != 0.0f) hsel[nm++] = i;
+                if (nm > 0) {
+                    JX_HIP(hipMemcpy(dselm.p, hsel.data(), sizeof(int32_t) * (size_t)nm, hipMemcpyHostToDevice));
+                    if (jxg_rotate_missing_dense(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), dselm.as<int32_t>(), nm,
+                                                 drowmiss.as<float>() + r0, dq.as<int8_t>(), dumax.as<float>(), drot.as<float>(), n,
+                                                 nullptr))
+                        return 1;
+                }
+            } else if (any_rowmiss && jxg_rotate_missing_correct(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
+                                                                 drowmiss.as<float>() + r0, dusamp.as<float>(), drot.as<float>(), n,
+                                                                 nullptr))
                 return 1;
         } else if (jxg_rotate_packed16x(p32.as<uint8_t>(), m, n, drows.as<int32_t>(), rows,
                                         (const uint8_t *)dlut16.p + (size_t)r0 * 16, drowoff.as<float>() + r0,

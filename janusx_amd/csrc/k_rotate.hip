@@ -595,6 +595,7 @@ extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void
 // the two for a handful of rows: the decision is made for the whole scan from the mean number of missing calls per row.  Up to
 // n / 800 of them (0.125 %) every row with <= 256 missing calls keeps the exact path, beyond that none does.
 // JXGPU_ROT_MISS_MAX overrides the limit (0: off).
+constexpr int JXG_ROT_MISS_DENSE = 1 << 30;      // "no limit": the dense form of the correction (any value > 256 means that)
 extern "C" int jxg_rot_miss_max(int n, double mean_missing_per_row) {
     const char *e = getenv("JXGPU_ROT_MISS_MAX");
     if (e) {
@@ -602,7 +603,13 @@ extern "C" int jxg_rot_miss_max(int n, double mean_missing_per_row) {
         return v < 0 ? 0 : (v > 256 ? 256 : v);
     }
     if (!(mean_missing_per_row > 0.0)) return 0;
-    return mean_missing_per_row <= (double)n / 800.0 ? 256 : 0;
+    if (mean_missing_per_row <= (double)n / 800.0) return 256;
+    // beyond: EVERY affine row keeps the exact path, and the missing-call term is one more int8 product with the indicator of the
+    // missing calls (jxg_rotate_missing_dense) instead of a gather per call -- the cost of the fp16 kernel these rows took before
+    // (two int8 passes against three fp16 products), but exact.  JXGPU_ROT_MISS_DENSE=0: the fp16 kernel as before.
+    const char *dn = getenv("JXGPU_ROT_MISS_DENSE");
+    if (dn && atoi(dn) == 0) return 0;
+    return JXG_ROT_MISS_DENSE;
 }
 
 extern "C" int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,

@@ -52,6 +52,17 @@ __device__ __forceinline__ u32x4q ri_decode16(uint32_t w) {
     return o;
 }
 
+// 16 two-bit codes -> 16 bytes that are 1 at a missing call (code 01) and 0 elsewhere, same byte order
+__device__ __forceinline__ u32x4q ri_decode16_missing(uint32_t w) {
+    const uint32_t v = w & ~(w >> 1) & 0x55555555u;
+    u32x4q o;
+    o.x = v & 0x03030303u;
+    o.y = (v >> 2) & 0x03030303u;
+    o.z = (v >> 4) & 0x03030303u;
+    o.w = (v >> 6) & 0x03030303u;
+    return o;
+}
+
 // ---- quantisation of U^T (n x n f32, row j = eigenvector j) into three int8 planes (npad x npad each) ---------------------
 __global__ __launch_bounds__(256) void ut_rowmax_kernel(const float *__restrict__ ut, int n, int npad, float *__restrict__ umax) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -98,6 +109,13 @@ __global__ __launch_bounds__(256) void ut_quant3_kernel(const float *__restrict_
 }
 
 // ---- rotation --------------------------------------------------------------------------------------------------------
+// MODE 0: the rotation of exact design rows (above).  MODE 1: the missing-call term of rows that keep the exact path although
+// they hold missing calls -- the SAME product with the indicator of the missing calls as the integer operand (e U, exact) and
+// the epilogue  out += d_r (e_r U),  d_r = `rowoff[pos]` (the value jxg_lut_split_rows_m leaves in d_rowmiss: imputed value minus
+// what the count form puts at a missing call): `lut16` / `usum` are not read.  One more pass of the int8 kernel over those
+// rows = the cost of the fp16 hi / lo kernel they took before, but exact (the fp16 rotation of a row with missing calls was
+// measurably noisier than the reference's f32 SGEMM: 4.3e-6 against 1.1e-6 on beta at n = 20 000).
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
                                                            const int32_t *__restrict__ rows, int nrows,
                                                            const uint4 *__restrict__ lut16, const float *__restrict__ rowoff,
@@ -135,11 +153,15 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
             const int64_t rec = rows ? (int64_t)rows[pos] : (int64_t)pos;
             arec = p32 + rec * 32;
             const float t = rowoff[pos];
-            row_exact = (t == t) ? 1 : 0;
-            // integer LUT {c(00), 0, c(10), c(11)} = {0, 0, 1, 2} or flipped {2, 0, 1, 0} (fp16 in lut16.x low half)
-            const bool flipped = (lut16[pos].x & 0xffffu) != 0u;
-            sgn = flipped ? -1.0f : 1.0f;
-            boff = row_exact ? (t + (flipped ? 2.0f : 0.0f)) : 0.0f;
+            if (MODE == 1) {
+                boff = t;                                   // d_r
+            } else {
+                row_exact = (t == t) ? 1 : 0;
+                // integer LUT {c(00), 0, c(10), c(11)} = {0, 0, 1, 2} or flipped {2, 0, 1, 0} (fp16 in lut16.x low half)
+                const bool flipped = (lut16[pos].x & 0xffffu) != 0u;
+                sgn = flipped ? -1.0f : 1.0f;
+                boff = row_exact ? (t + (flipped ? 2.0f : 0.0f)) : 0.0f;
+            }
         }
         if (ahalf == 0) {
             sOff[arow] = boff;
@@ -170,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
         b2 = *reinterpret_cast<const u32x4q *>(bsrc + 2 * plane + kcol);
     };
     auto stage = [&](uint8_t *set) {
-        *reinterpret_cast<u32x4q *>(set + ri_chunk_off(arow, 2 * ahalf)) = ri_decode16(wa.x);
-        *reinterpret_cast<u32x4q *>(set + ri_chunk_off(arow, 2 * ahalf + 1)) = ri_decode16(wa.y);
+        *reinterpret_cast<u32x4q *>(set + ri_chunk_off(arow, 2 * ahalf)) = MODE == 1 ? ri_decode16_missing(wa.x) : ri_decode16(wa.x);
+        *reinterpret_cast<u32x4q *>(set + ri_chunk_off(arow, 2 * ahalf + 1)) = MODE == 1 ? ri_decode16_missing(wa.y) : ri_decode16(wa.y);
         const u32x4q mk = {bmask, bmask, bmask, bmask};
         *reinterpret_cast<u32x4q *>(set + RI_IMG_A + boff_lds) = b0 & mk;
         *reinterpret_cast<u32x4q *>(set + RI_IMG_A + RI_IMG_B + boff_lds) = b1 & mk;
@@ -238,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
     const bool colok = gj < n;
     const double um = colok ? (double)umax[gj] : 0.0;
     const double w1 = um / 127.0, w2 = um / (127.0 * 254.0), w3 = um / (127.0 * 254.0 * 254.0);
-    const float us = colok ? usum[gj] : 0.0f;
+    const float us = (MODE == 0 && colok) ? usum[gj] : 0.0f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -247,7 +269,9 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
             const int gr = sPos[lr];
             if (gr >= 0 && colok) {
                 const double v = (double)acc[0][mi][r] * w1 + (double)acc[1][mi][r] * w2 + (double)acc[2][mi][r] * w3;
-                out[(int64_t)gr * ldo + gj] = fmaf(sOff[lr], us, sSgn[lr] * (float)v);
+                float *dst = out + (int64_t)gr * ldo + gj;
+                if (MODE == 1) *dst = fmaf(sOff[lr], (float)v, *dst);
+                else *dst = fmaf(sOff[lr], us, sSgn[lr] * (float)v);
             }
         }
     }
@@ -258,6 +282,21 @@ extern float g_last_ms[24];
 }  // namespace jx
 
 using namespace jx;
+
+namespace jx {
+int launch_rotate_i8_missing(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
+                             int nsel, const float *d_rowmiss, const int8_t *d_q, const float *d_umax, float *d_out, int64_t ld_out);
+}
+// Missing-call term of design rows that keep the exact (int8) rotation, as ONE MORE int8 product (indicator of the missing calls
+// x the three planes of U) instead of a gather per missing call: d_out[d_sel[i]] += d_rowmiss[d_sel[i]] * (e U) for the nsel
+// rows listed in d_sel (positions inside the block d_rows / d_rowmiss / d_out are indexed by).  Used when the rows of a scan
+// hold more than n / 800 missing calls on average (jxg_rot_miss_max > 256), where the gather form (jxg_rotate_missing_correct)
+// costs more than the product.
+extern "C" int jxg_rotate_missing_dense(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
+                                        int nsel, const float *d_rowmiss, const int8_t *d_q, const float *d_umax, float *d_out,
+                                        int64_t ld_out, void *stream) {
+    return launch_rotate_i8_missing((hipStream_t)stream, d_p32, m_total, n, d_rows, d_sel, nsel, d_rowmiss, d_q, d_umax, d_out, ld_out);
+}
 
 // U^T (n x n f32, row j = eigenvector j) -> three int8 planes (npad x npad each, npad = 128 ceil(n / 128); plane p at
 // d_q + p npad^2; k order inside 16-sample groups as decoded by the rotation kernel) + umax (npad) f32
@@ -287,12 +326,34 @@ int launch_rotate_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int 
     static bool attr = false;
     const int lds = 2 * RI_SET + 3072;
     if (!attr) {
-        JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
     dim3 grid((unsigned)(((nct + 7) / 8) * 8 * nrt));
-    hipLaunchKernelGGL(rotate_i8_kernel, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nrows, (const uint4 *)d_lut16,
+    hipLaunchKernelGGL(rotate_i8_kernel<0>, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nrows, (const uint4 *)d_lut16,
                        d_rowoff, d_usum, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// the missing-call term of the `nsel` rows d_sel (positions inside the block): d_out[row] += d_rowmiss[row] * (indicator row) U
+int launch_rotate_i8_missing(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
+                             int nsel, const float *d_rowmiss, const int8_t *d_q, const float *d_umax, float *d_out, int64_t ld_out) {
+    if (nsel <= 0) return 0;
+    const int nt = num_tiles(n);
+    const int64_t npad = (int64_t)nt * JXG_TILE;
+    if (!d_q || !d_umax || !d_rowmiss || !d_sel || n > 66000) return fail("launch_rotate_i8_missing: planes / list missing or n > 66000");
+    const int nct = (int)((npad + RI_TN - 1) / RI_TN), nrt = (nsel + RI_TM - 1) / RI_TM;
+    static bool attr = false;
+    const int lds = 2 * RI_SET + 3072;
+    if (!attr) {
+        JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    dim3 grid((unsigned)(((nct + 7) / 8) * 8 * nrt));
+    hipLaunchKernelGGL(rotate_i8_kernel<1>, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nsel, (const uint4 *)nullptr,
+                       d_rowmiss, (const float *)nullptr, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -490,7 +490,11 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                      _ptr(rowoff), _ptr(rowmiss) if rowmiss is not None else None, miss_max, _stream()))
     if rowmiss is not None and not bool((rowmiss != 0).any().item()):
         rowmiss = None
-    usamp = model.usamp() if rowmiss is not None else None
+    # the missing-call term as one more int8 product (jxg_rotate_missing_dense) when the limit is "none" (> 256: more than n / 800
+    # missing calls per row on average), else as a gather per missing call over U with one row per sample
+    miss_dense = rowmiss is not None and miss_max > 256
+    usamp = model.usamp() if (rowmiss is not None and not miss_dense) else None
+    sel_miss_t, sel_miss_bounds = None, []
     tables = None
     if mode == "splmm" and fv_state is None:
         raise RuntimeError("the SparseLMM exact scan needs its null state (fv_state = w, py, wx, a_chol, ypy)")
@@ -520,6 +524,16 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         # lock step over LDS tiles of (s, X~, y~); longer blocks keep every wave's queue deep (8 SNPs per wave)
         block_rows = 32768
     br = int(min(block_rows, mk))
+    if miss_dense:
+        # per block: positions of the rows with a missing-call term (a row's path does not depend on the blocking)
+        has = (rowmiss != 0).cpu().numpy()
+        parts, nm_ = [], 0
+        for b0 in range(0, mk, br):
+            a = np.flatnonzero(has[b0:b0 + br]).astype(np.int32)
+            sel_miss_bounds.append((nm_, nm_ + len(a)))
+            nm_ += len(a)
+            parts.append(a)
+        sel_miss_t = torch.from_numpy(np.concatenate(parts) if nm_ else np.zeros(1, np.int32)).to(dev)
     nbuf = 2 if mk > br else 1
     fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p) and qpl is None
     if qpl is not None:
@@ -582,7 +596,13 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                                    e1 - e0,
                                                    sel_rest_t[x0:].data_ptr() if (sel_rest_t is not None and x1 > x0) else None,
                                                    x1 - x0, _ptr(grot), _stream()))
-                if rowmiss is not None:
+                if miss_dense:
+                    m0, m1 = sel_miss_bounds[bi]
+                    if m1 > m0:
+                        check(lib().jxg_rotate_missing_dense(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(),
+                                                             sel_miss_t[m0:].data_ptr(), m1 - m0, rowmiss[r0:].data_ptr(),
+                                                             _ptr(qpl[0]), _ptr(qpl[1]), _ptr(grot), n, _stream()))
+                elif rowmiss is not None:
                     check(lib().jxg_rotate_missing_correct(_ptr(panel.p32), panel.m, n, rows_t[r0:].data_ptr(), nr,
                                                            rowmiss[r0:].data_ptr(), _ptr(usamp), _ptr(grot), n, _stream()))
             else:

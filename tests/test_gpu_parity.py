@@ -969,7 +969,9 @@ def _full_size_properties(oracle, oracle_c, n, m, missing, scan_cap):
     be, se, pe = _assoc_err(fa[pick], fref)
     assert max(be, se, pe) < TOL, (be, se, pe)
     # the same sample against the EXACT rotation: beta / SE within 1e-6, raw Wald p within 1e-5 for z^2 <= 10
-    i8 = missing == 0.0 and n >= 4096           # every design row is exact: the int8 rotation takes all of them
+    # every design row is on the int8 rotation from n = 4096: rows without missing calls as they are, rows with missing calls with
+    # their missing-call term as one more int8 product (jxg_rotate_missing_dense) or, for a few calls, as a gather
+    i8 = n >= 4096
     _exact_rotation_leg(oracle, oracle_c, a[pick], ref, gd, dh, sh, xh, yh, model.null.bounds[0], model.null.bounds[1], i8)
     # fixed lambda: the reference's scan itself sums in f32 (sgemm dots, src/stats/fvlmm.rs:1691-1805), so its own arithmetic
     # noise stays whatever the rotation: bounded against that noise
@@ -3681,6 +3683,68 @@ def test_cli_gs_blup_dispatch_and_grm_text(oracle, tmp_path, monkeypatch, capsys
 
 
 @pytest.mark.gpu
+def test_rotation_rows_with_many_missing_calls_stay_exact(oracle, oracle_c, monkeypatch):
+    """Beyond n / 800 missing calls per row on average every affine design row still takes the int8 rotation, and its
+    missing-call term d * (e U) is ONE MORE int8 product with the indicator e of the missing calls as the integer operand
+    (`jxg_rotate_missing_dense`, csrc/k_rotate_i8.hip MODE 1) -- the rows took the fp16 hi / lo kernel before, which is noisier
+    than the reference's f32 SGEMM.  n = 4300, 5 .. 60 missing calls per SNP (1 % of the calls), flipped alleles: (i) beta / SE
+    against the scan of the EXACT (f64) rotation at the int8 path's own bound (1e-6; the fp16 kernel: a few 1e-6); (ii) chunked ==
+    unchunked and host C-ABI route == pipeline bit for bit; (iii) JXGPU_ROT_MISS_DENSE=0 restores the fp16 kernel (other bits,
+    same result within the tolerance)."""
+    import torch
+    from janusx_amd import pipeline, stats
+    from janusx_amd._lib import lib
+    n, m = 4300, 600
+    packed, g = bed.synth_panel_numpy(n, m, seed=31, missing_rate=0.0)
+    rng = np.random.default_rng(11)
+    for r in range(m):
+        for j in rng.choice(n, size=int(rng.integers(5, 61)), replace=False):
+            b, sh = j >> 2, 2 * (j & 3)
+            packed[r, b] = (packed[r, b] & ~(3 << sh)) | (1 << sh)
+    y = bed.synth_phenotype(g, n_causal=20, pve=0.5, seed=31)
+    x = np.concatenate([np.ones((n, 1)), np.random.default_rng(8).normal(size=(n, 1))], axis=1)
+    dev = torch.device("cuda", 0)
+    pk_t = torch.from_numpy(packed).to(dev)
+    k, _eff, p = pipeline.build_grm(pk_t, n)
+    s_t, ut_t = pipeline.eigh_from_grm(k)
+    model = pipeline.SpectralModel(s_t, ut_t, x, y)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    rows = np.nonzero(keep)[0]
+    flip_k = np.random.default_rng(10).random(len(rows)) < 0.3
+    lut = stats.scan_lut_from_counts(maf[rows], flip_k, p.counts()[rows], n)
+    lo_b, hi_b = model.null.bounds
+    assert float(np.mean(mi)) > n / 800.0 and lib().jxg_rot_miss_max(n, p.mean_missing()) > 256
+    res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
+    assert float(lib().jxg_last_kernel_ms(13)) == 1.0 and bool(np.all(mi[rows] > 0))     # every row on the int8 kernel
+    gd = oracle.decode_centered_block_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows])
+    ut = ut_t.cpu().numpy()
+    grot = (gd.astype(np.float64) @ ut.T).astype(np.float32)                             # exact rotation, one f32 rounding
+    xy = ut @ np.concatenate([x, y[:, None]], axis=1)
+    ref = oracle_c.lmm_scan_rotated_block(grot, s_t.cpu().numpy(), np.ascontiguousarray(xy[:, :2]),
+                                          np.ascontiguousarray(xy[:, 2]), lo_b, hi_b, 30, 1e-2)
+    be, se, pe = _assoc_err(res, ref)
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    res_c = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2,
+                               block_rows=170).cpu().numpy()
+    assert np.array_equal(res_c, res)
+    from janusx_amd import janusx as jxrs
+    s_h, x_h, y_h, ut_h = s_t.cpu().numpy(), model.xcov.cpu().numpy(), model.y.cpu().numpy(), model.ut.cpu().numpy()
+    out_h = jxrs.lmm_reml_assoc_packed_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows], s_h, x_h, y_h, ut_h,
+                                           low=lo_b, high=hi_b, max_iter=30, tol=1e-2)
+    assert np.array_equal(out_h, res)
+    monkeypatch.setenv("JXGPU_ROT_MISS_DENSE", "0")
+    assert lib().jxg_rot_miss_max(n, p.mean_missing()) == 0
+    res0 = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
+    assert float(lib().jxg_last_kernel_ms(13)) == 0.0                                    # every row on the fp16 kernel
+    be0, se0, pe0 = _assoc_err(res0, ref)
+    assert max(be0, se0, pe0) < TOL and not np.array_equal(res0, res)
+    # measured: dense beta 2.1e-6 / SE 6.6e-8 / p 2.1e-6, fp16 kernel 3.9e-6 / 4.7e-7 / 4.5e-6
+    assert be < 3e-6 and se < 2e-7 and be < be0 and se < se0, (be, se, pe, be0, se0, pe0)
+    _MAXIMA["rot_missing_dense_vs_fp16"] = [be, se, be0, se0, pe0]
+
+
+@pytest.mark.gpu
 def test_rotation_rows_with_a_few_missing_calls_take_the_exact_path(oracle, oracle_c, monkeypatch):
     """From n = 4096, when the rows of a scan hold at most n / 800 missing calls on average, a design row with missing calls
     keeps the int8 rotation; its missing-call term d * sum_{i missing} U[i, :] is added behind it (`jxg_lut_split_rows_m`,
@@ -3711,7 +3775,7 @@ def test_rotation_rows_with_a_few_missing_calls_take_the_exact_path(oracle, orac
     flip_k = np.random.default_rng(9).random(len(rows)) < 0.3
     lut = stats.scan_lut_from_counts(maf[rows], flip_k, p.counts()[rows], n)
     lo_b, hi_b = model.null.bounds
-    assert lib().jxg_rot_miss_max(n, float(np.mean(mi[rows]))) == 256 and lib().jxg_rot_miss_max(n, 6.0) == 0
+    assert lib().jxg_rot_miss_max(n, float(np.mean(mi[rows]))) == 256 and lib().jxg_rot_miss_max(n, 6.0) > 256   # beyond n / 800: dense form
     res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
     assert float(lib().jxg_last_kernel_ms(13)) == 1.0 and float(np.mean(mi[rows] > 0)) > 0.8   # every row on the int8 kernel
     gd = oracle.decode_centered_block_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows])

@@ -676,7 +676,7 @@ def main():
                 leg = run_leg(20000, 200000, 0.01, 2, 1)
                 sm = leg_summary(leg, 20000, 2)
                 mu_g, mu_g_src = pmc_mfma_util("grm_i8_kernel", "mfma_missing1pct")
-                mu_r, mu_r_src = pmc_mfma_util("rotate256_kernel", "mfma_missing1pct")
+                mu_r, mu_r_src = pmc_mfma_util("rotate_i8_kernel", "mfma_missing1pct")
                 res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_i8_kernel<LUT> x 2 (SNPs with missing calls: "
                                                        "the missing call's count in two int8 digits, two int8 Gram products with "
                                                        "per-SNP byte LUTs, exact diagonal; csrc/k_grm.hip dense missing-call path)",
@@ -690,9 +690,12 @@ def main():
                                                             "so 0.5 x the clean kernel's fraction is the ceiling of this form "
                                                             "(rounds 2 - 3: fp16 three-product kernel 229 ms, sparse correction 165 ms)")
                 res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"],
-                                                          kernel="rotate256_kernel (fp16 hi/lo, three products: every row has a "
-                                                                 "missing call at this rate)",
+                                                          kernel="rotate_i8_kernel<0> + rotate_i8_kernel<1> (every row has missing calls "
+                                                                 "at this rate: the count operand and the indicator of the missing "
+                                                                 "calls against the three int8 planes of U, exact; the fp16 hi/lo "
+                                                                 "kernel until round 4)",
                                                           mfma_util_pmc=mu_r, mfma_util_source=mu_r_src,
+                                                          issued_int8_products_per_algorithmic_product=6,
                                                           note="same leg; algorithmic 2 m n^2 flops")
                 res["extra_c3_missing1pct"] = {k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
                                                                   "stages_ms_per_step")}

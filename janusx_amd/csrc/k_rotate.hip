@@ -625,7 +625,8 @@ extern "C" int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, 
 extern "C" int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
                                     int64_t mk, void *d_lut16, float *d_rowoff, float *d_rowmiss, int miss_max, void *stream) {
     if (mk <= 0) return 0;
-    if (miss_max > 256) miss_max = 256;
+    // <= 256: the capacity of the gather form's per-row list (rot_miss_correct_kernel); > 256 = "no limit" (the dense form of the
+    // missing-call term, jxg_rotate_missing_dense, needs no list): passed through
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
     JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));

@@ -241,12 +241,12 @@ int jxg_rotate_packed16(const uint8_t *d_p32, int64_t m_total, int n, const int3
 int jxg_lut_split_rows(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const float *d_lut,
                        int64_t mk, void *d_lut16, float *d_rowoff, void *stream);
 /* jxg_lut_split_rows with a tolerance for rows that hold 1 .. miss_max missing calls (jxg_rot_miss_max(n, mean number of
- * missing calls per row) is the default limit: 256 up to n / 800 missing calls per row on average, else 0 -- one decision per
+ * missing calls per row) is the default limit: 256 up to n / 300 missing calls per row on average, else 0 -- one decision per
  * scan, a block is not split between the kernels for a handful of rows): they keep the exact path (finite d_rowoff) and d_rowmiss[k] = lut[k][missing] - (value of the int8 rotation's clean
  * form at a missing call = offset + 2 [flipped]) is the weight of their
  * missing-call term, which jxg_rotate_missing_correct adds behind the rotation: out[r][j] += d_r * sum over the row's missing
  * samples i of U[i][j].  d_usamp (n, n) f32 = U with one row per sample (jxg_transpose_f32 of u_t).  Rows with more missing
- * calls stay general (NaN offset, fp16 kernel) as before.  Beyond n / 800 missing calls per row on average jxg_rot_miss_max
+ * calls stay general (NaN offset, fp16 kernel) as before.  Beyond n / 300 missing calls per row on average jxg_rot_miss_max
  * returns a value > 256 ("no limit"): every affine row keeps the exact path and its missing-call term is ONE MORE int8 product
  * with the indicator of the missing calls as the integer operand, jxg_rotate_missing_dense (d_sel: positions, inside the block,
  * of the rows with d_rowmiss != 0; d_q / d_umax: the three planes of jxg_ut_quant3) -- the cost of the fp16 kernel those rows

@@ -987,7 +987,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     if (jxg_lut_split_rows_m(p32.as<uint8_t>(), m, n, nullptr, dlut.as<float>(), m, dlut16.p, drowoff.as<float>(),
                              miss_max > 0 ? drowmiss.as<float>() : nullptr, miss_max, nullptr))
         return 1;
-    // beyond n / 800 missing calls per row (limit > 256 = none): the missing-call term as one more int8 product
+    // beyond n / 300 missing calls per row (limit > 256 = none): the missing-call term as one more int8 product
     // (jxg_rotate_missing_dense) over the rows that have one, instead of the gather form
     const bool miss_dense = miss_max > 256;
     std::vector<float> hm;

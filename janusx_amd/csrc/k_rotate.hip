@@ -593,7 +593,9 @@ extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void
 // (rot_miss_correct_kernel).  The correction reads one row of U (4 n bytes) per missing call -- 19 ns at n = 20 000 --, the
 // fp16 kernel it avoids costs ~1 us per row there, but ALSO a fixed ~18 ms per launch, so a block should not be split between
 // the two for a handful of rows: the decision is made for the whole scan from the mean number of missing calls per row.  Up to
-// n / 800 of them (0.125 %) every row with <= 256 missing calls keeps the exact path, beyond that none does.
+// n / 300 of them (0.33 %) every row with <= 256 missing calls keeps the exact path with the gather correction (measured at
+// n = 20 000, m = 200 000: rotation 288 / 305 / 358 / 397 ms at 0.15 / 0.2 / 0.3 / 0.4 % missing calls against 388 for the dense
+// form below; n / 800 until the end of round 4, when the alternative was the fp16 kernel), beyond that the dense form takes over.
 // JXGPU_ROT_MISS_MAX overrides the limit (0: off).
 constexpr int JXG_ROT_MISS_DENSE = 1 << 30;      // "no limit": the dense form of the correction (any value > 256 means that)
 extern "C" int jxg_rot_miss_max(int n, double mean_missing_per_row) {
@@ -603,7 +605,7 @@ extern "C" int jxg_rot_miss_max(int n, double mean_missing_per_row) {
         return v < 0 ? 0 : (v > 256 ? 256 : v);
     }
     if (!(mean_missing_per_row > 0.0)) return 0;
-    if (mean_missing_per_row <= (double)n / 800.0) return 256;
+    if (mean_missing_per_row <= (double)n / 300.0) return 256;
     // beyond: EVERY affine row keeps the exact path, and the missing-call term is one more int8 product with the indicator of the
     // missing calls (jxg_rotate_missing_dense) instead of a gather per call -- the cost of the fp16 kernel these rows took before
     // (two int8 passes against three fp16 products), but exact.  JXGPU_ROT_MISS_DENSE=0: the fp16 kernel as before.

@@ -290,7 +290,7 @@ int launch_rotate_i8_missing(hipStream_t st, const uint8_t *d_p32, int64_t m_tot
 // Missing-call term of design rows that keep the exact (int8) rotation, as ONE MORE int8 product (indicator of the missing calls
 // x the three planes of U) instead of a gather per missing call: d_out[d_sel[i]] += d_rowmiss[d_sel[i]] * (e U) for the nsel
 // rows listed in d_sel (positions inside the block d_rows / d_rowmiss / d_out are indexed by).  Used when the rows of a scan
-// hold more than n / 800 missing calls on average (jxg_rot_miss_max > 256), where the gather form (jxg_rotate_missing_correct)
+// hold more than n / 300 missing calls on average (jxg_rot_miss_max > 256), where the gather form (jxg_rotate_missing_correct)
 // costs more than the product.
 extern "C" int jxg_rotate_missing_dense(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, const int32_t *d_sel,
                                         int nsel, const float *d_rowmiss, const int8_t *d_q, const float *d_umax, float *d_out,

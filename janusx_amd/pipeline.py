@@ -490,7 +490,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                      _ptr(rowoff), _ptr(rowmiss) if rowmiss is not None else None, miss_max, _stream()))
     if rowmiss is not None and not bool((rowmiss != 0).any().item()):
         rowmiss = None
-    # the missing-call term as one more int8 product (jxg_rotate_missing_dense) when the limit is "none" (> 256: more than n / 800
+    # the missing-call term as one more int8 product (jxg_rotate_missing_dense) when the limit is "none" (> 256: more than n / 300
     # missing calls per row on average), else as a gather per missing call over U with one row per sample
     miss_dense = rowmiss is not None and miss_max > 256
     usamp = model.usamp() if (rowmiss is not None and not miss_dense) else None

@@ -3684,7 +3684,7 @@ def test_cli_gs_blup_dispatch_and_grm_text(oracle, tmp_path, monkeypatch, capsys
 
 @pytest.mark.gpu
 def test_rotation_rows_with_many_missing_calls_stay_exact(oracle, oracle_c, monkeypatch):
-    """Beyond n / 800 missing calls per row on average every affine design row still takes the int8 rotation, and its
+    """Beyond n / 300 missing calls per row on average every affine design row still takes the int8 rotation, and its
     missing-call term d * (e U) is ONE MORE int8 product with the indicator e of the missing calls as the integer operand
     (`jxg_rotate_missing_dense`, csrc/k_rotate_i8.hip MODE 1) -- the rows took the fp16 hi / lo kernel before, which is noisier
     than the reference's f32 SGEMM.  n = 4300, 5 .. 60 missing calls per SNP (1 % of the calls), flipped alleles: (i) beta / SE
@@ -3714,7 +3714,7 @@ def test_rotation_rows_with_many_missing_calls_stay_exact(oracle, oracle_c, monk
     flip_k = np.random.default_rng(10).random(len(rows)) < 0.3
     lut = stats.scan_lut_from_counts(maf[rows], flip_k, p.counts()[rows], n)
     lo_b, hi_b = model.null.bounds
-    assert float(np.mean(mi)) > n / 800.0 and lib().jxg_rot_miss_max(n, p.mean_missing()) > 256
+    assert float(np.mean(mi)) > n / 300.0 and lib().jxg_rot_miss_max(n, p.mean_missing()) > 256
     res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
     assert float(lib().jxg_last_kernel_ms(13)) == 1.0 and bool(np.all(mi[rows] > 0))     # every row on the int8 kernel
     gd = oracle.decode_centered_block_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows])
@@ -3746,7 +3746,7 @@ def test_rotation_rows_with_many_missing_calls_stay_exact(oracle, oracle_c, monk
 
 @pytest.mark.gpu
 def test_rotation_rows_with_a_few_missing_calls_take_the_exact_path(oracle, oracle_c, monkeypatch):
-    """From n = 4096, when the rows of a scan hold at most n / 800 missing calls on average, a design row with missing calls
+    """From n = 4096, when the rows of a scan hold at most n / 300 missing calls on average, a design row with missing calls
     keeps the int8 rotation; its missing-call term d * sum_{i missing} U[i, :] is added behind it (`jxg_lut_split_rows_m`,
     `jxg_rotate_missing_correct`; the decode of src/decode/decode.rs:192-271 puts the centred mean at a missing call).
     n = 4300: 0 .. 7 missing calls per SNP, flipped alleles.  (i) beta / SE / p against the oracle's scan of the f64 rotation;
@@ -3775,7 +3775,7 @@ def test_rotation_rows_with_a_few_missing_calls_take_the_exact_path(oracle, orac
     flip_k = np.random.default_rng(9).random(len(rows)) < 0.3
     lut = stats.scan_lut_from_counts(maf[rows], flip_k, p.counts()[rows], n)
     lo_b, hi_b = model.null.bounds
-    assert lib().jxg_rot_miss_max(n, float(np.mean(mi[rows]))) == 256 and lib().jxg_rot_miss_max(n, 6.0) > 256   # beyond n / 800: dense form
+    assert lib().jxg_rot_miss_max(n, float(np.mean(mi[rows]))) == 256 and lib().jxg_rot_miss_max(n, 20.0) > 256   # beyond n / 300: dense form
     res = pipeline.scan_rows(p, model, rows, lut, mode="lmm", low=lo_b, high=hi_b, max_iter=30, tol=1e-2).cpu().numpy()
     assert float(lib().jxg_last_kernel_ms(13)) == 1.0 and float(np.mean(mi[rows] > 0)) > 0.8   # every row on the int8 kernel
     gd = oracle.decode_centered_block_f32(np.ascontiguousarray(packed[rows]), n, flip_k, maf[rows])

@@ -73,7 +73,8 @@ struct QrParams {
     int units;              // 16-column units of C; slab b of the gridDim.x slabs holds the units [b units / G, (b+1) units / G)
     int g_lo, g_hi;         // groups [g_lo, g_hi) of this launch (applied from g_hi - 1 down)
     int skip;               // diagnostic bit mask (JXGPU_QB_SKIP): 1 no MFMA phases, 2 no row traffic, 4 no V / U loads,
-                            // 8 no row stores, 16 no row loads
+                            // 8 no row stores, 16 no row loads, 64 lockstep units (three-waves form); balanced form only: 32 no
+                            // four-column waves, 256 default wave priority, 512 full counter wait in front of B1, 4096 no L2 warm-up
     double *um;             // balanced form only (else null): third image per block, U in the order the four-column waves read it
 };
 

@@ -108,14 +108,20 @@ def make_phenotype(dos_head, n, seed, device):
     return (gv + e).cpu().numpy()
 
 
-def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
+def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000, scale_to_n=None, m_full=None):
     """The oracle (C + numpy/OpenBLAS restatement of the reference algorithm) timed on the host cores on a
-    bounded SNP sample; GRM and scan are linear in m and are extrapolated, eigh + null are timed at full n."""
+    bounded SNP sample; GRM and scan are linear in m and are extrapolated, eigh + null are timed at full n.
+    `scale_to_n` (largest config): the panel handed in holds the first n samples of a larger
+    configuration; every stage is then scaled to `scale_to_n` samples by its own exponent (SSYRK and the rotation SGEMM n^2,
+    decode and the per-SNP Brent evaluations n, eigh n^3) and the rule is printed with the number."""
     from oracle import jx_oracle as O
     from oracle import jx_oracle_c as OC
-    m_full = packed_cpu.shape[0]
-    ms = min(sample_m, m_full)
+    from scipy.linalg import blas as sblas
+    m_full = int(packed_cpu.shape[0] if m_full is None else m_full)
+    ms = min(sample_m, packed_cpu.shape[0])
     sub = np.ascontiguousarray(packed_cpu[:ms])
+    n_to = float(n if scale_to_n is None else scale_to_n)
+    g1, g2, g3 = n_to / n, (n_to / n) ** 2, (n_to / n) ** 3
     t0 = time.perf_counter()
     mi, he, ho = OC.row_counts(sub, n)
     cnt = np.stack([mi, he, ho], 1)
@@ -124,8 +130,12 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
     rows = np.nonzero(gkeep)[0]
     lut = st.grm_lut_from_mean_scale(mean_g[rows], scale[rows], flip[rows])
     z = OC.decode_rows_lut(sub, n, lut, rows, center=False)
-    acc = (z.T @ z).astype(np.float64)  # f32 SYRK-equivalent (OpenBLAS sgemm) + f64 merge
-    t_grm = time.perf_counter() - t0
+    t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    # f32 SSYRK into an f32 scratch (lower triangle: the n(n+1)k flops the reference issues, src/stats/grm.rs:1650-1662) + f64 merge
+    acc = sblas.ssyrk(1.0, z.T, trans=0, lower=1).astype(np.float64)
+    t_syrk = time.perf_counter() - t0
+    t_grm = t_dec * g1 + t_syrk * g2
     k = acc / float(np.sum(var[rows]))  # GRM of the SNP sample: same size/spectrum class as the full one for timing eigh
     k = np.tril(k) + np.tril(k, -1).T
     # LAPACK dsyevd is O(n^3): above n_eig_cap rows the decomposition is TIMED on the leading n_eig_cap x n_eig_cap block
@@ -137,7 +147,7 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
     t0 = time.perf_counter()
     s_b, u_b = O.gwas_eigh_from_grm(np.ascontiguousarray(k[:n_eig, :n_eig]).astype(np.float32))
     t_eig_block = time.perf_counter() - t0
-    eig_scale = (n / float(n_eig)) ** 3
+    eig_scale = (n_to / float(n_eig)) ** 3
     t_eig = t_eig_block * eig_scale
     if n_eig < n:
         s = np.concatenate([s_b, np.diag(k)[n_eig:].astype(np.float64) + 1e-6])
@@ -148,31 +158,42 @@ def cpu_baseline(packed_cpu, n, y, mode, sample_m, threads, eig_cap=5000):
         s, u = s_b, u_b
     t0 = time.perf_counter()
     nm = O.spectral_null_model(y, np.ones((n, 1)), s, u)
-    t_null = time.perf_counter() - t0
+    t_null = (time.perf_counter() - t0) * g2
     t0 = time.perf_counter()
     keep, af, miss = st.gwas_scan_row_stats(cnt, n, 0.02, 0.05, 1.0)
     srows = np.nonzero(keep)[0]
     slut = st.scan_lut_from_counts(af[srows], np.zeros(len(srows), bool), cnt[srows], n)
     gd = OC.decode_rows_lut(sub, n, slut, srows, center=False)
+    t_sdec = time.perf_counter() - t0
+    t0 = time.perf_counter()
     grot = gd @ nm.Dh.T
+    t_rot = time.perf_counter() - t0
+    t0 = time.perf_counter()
     if mode == "lmm":
         OC.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, nm.bounds[0], nm.bounds[1], 30, 1e-2, threads=threads)
     else:
         c = O.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null)
         OC.fvlmm_assoc_block(grot, c.w, grot @ c.py, grot @ c.wx, c.a_chol, c.ypy, c.df, threads=threads)
-    t_scan = time.perf_counter() - t0
+    t_assoc = time.perf_counter() - t0
+    t_scan = t_sdec * g1 + t_rot * g2 + t_assoc * g1
     scale_m = m_full / float(ms)
     total = t_grm * scale_m + t_eig + t_null + t_scan * scale_m
+    rule = ("" if scale_to_n is None else
+            f"; timed on the first {n} of {int(n_to)} samples and scaled per stage: decode and per-SNP evaluations x{g1:.2f} (n), "
+            f"SSYRK, rotation SGEMM and the null rotation x{g2:.2f} (n^2), eigh (n^3) as stated")
     return {
         "value": m_full / total,
         "unit": "SNPs/s",
         "cores": int(threads),
         "kind": "port",
-        "sample": (f"oracle (C restatement + numpy/OpenBLAS sgemm + scipy dsyevd) on the first {ms} of {m_full} SNPs at "
-                   f"full n={n}: grm {t_grm:.2f}s and scan {t_scan:.2f}s scaled x{scale_m:.1f} (linear in m); eigh "
-                   + (f"{t_eig:.2f}s at full size" if n_eig == n else
+        "stages_s": {"grm": t_grm * scale_m, "eigh": t_eig, "null": t_null, "rotate": (t_sdec * g1 + t_rot * g2) * scale_m,
+                     "assoc": t_assoc * g1 * scale_m},
+        "sample": (f"oracle (C restatement + OpenBLAS ssyrk / sgemm + scipy dsyevd) on the first {ms} of {m_full} SNPs at "
+                   f"n={n}: grm {t_dec + t_syrk:.2f}s (decode {t_dec:.2f} + SSYRK {t_syrk:.2f}) and scan {t_sdec + t_rot + t_assoc:.2f}s "
+                   f"(decode {t_sdec:.2f} + SGEMM {t_rot:.2f} + per-SNP {t_assoc:.2f}) scaled x{scale_m:.1f} (linear in m); eigh "
+                   + (f"{t_eig:.2f}s at full size" if (n_eig == n and scale_to_n is None) else
                       f"{t_eig_block:.2f}s measured on the leading {n_eig} x {n_eig} block, scaled by (n/{n_eig})^3 = "
-                      f"{eig_scale:.1f} -> {t_eig:.1f}s") + f"; null {t_null:.2f}s at full size"),
+                      f"{eig_scale:.1f} -> {t_eig:.1f}s") + f"; null {t_null:.2f}s" + rule),
     }
 
 
@@ -259,6 +280,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--leg", default=None, choices=["c1", "c2_fvlmm", "c5_splmm", "c5_pcg"],
+                    help="run ONE extra leg of the default run alone and print its record (profiling)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the two extra legs of the default one-GPU run (1 %% missing calls; BASELINE configs[3] on one GPU)")
     args = ap.parse_args()
@@ -316,11 +339,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    def run_leg(n, m_arg, missing, steps, warmup, covariates=0):
+    def run_leg(n, m_arg, missing, steps, warmup, covariates=0, mode=None):
         """One timed configuration: synthetic panel resident in HBM, `warmup` untimed + `steps` timed passes of the whole
         hot path.  -> dict(elapsed, kept_total, kern, stage, null, packed, y, x, eigh_sharded, m)."""
         # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
         # the ranks and summed by one all-reduce per column (JXGPU_DIST_EIGH=0 keeps every rank on the whole matrix)
+        mode = args.mode if mode is None else mode
         eigh_min_n = int(os.environ.get("JXGPU_DIST_EIGH_MIN_N", "16384"))
         eigh_ranks = world > 1 or (distributed and os.environ.get("JXGPU_DIST_EIGH_FORCE", "0") != "0")
         eigh_sharded = bool(eigh_ranks and os.environ.get("JXGPU_DIST_EIGH", "1") != "0" and n >= eigh_min_n and
@@ -377,9 +401,9 @@ def main():
             rows = np.nonzero(keep)[0]
             lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
             tm = pl.StageTimes()
-            out = pl.scan_rows(panel, model, rows, lut, args.mode, max_iter=30, tol=1e-2, times=tm,
-                               return_evals=(args.mode == "lmm"))
-            if args.mode == "lmm":
+            out = pl.scan_rows(panel, model, rows, lut, mode, max_iter=30, tol=1e-2, times=tm,
+                               return_evals=(mode == "lmm"))
+            if mode == "lmm":
                 out, evals = out
                 n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
             else:
@@ -465,6 +489,164 @@ def main():
                                     "unit": "TFLOP/s", "frac": rot_tf / k.get("rot_peak", MFMA_F16_PEAK_TFLOPS),
                                     "ms_per_step": k["rot_ms"] / L}}
 
+    def leg_c1_mouse(steps=3, warmup=1):
+        """BASELINE configs[0]: the reference's own example panel (example/mouse_hs1940: n = 1940, 10 300 sites, trait test0 with
+        1410 phenotyped samples; committed as 2-bit codes in tests/golden/mouse_hs1940.npz), `jx gwas -lmm`: GRM on all samples,
+        eigendecomposition + null + exact scan on the phenotyped ones (pipeline.run_trait)."""
+        d = np.load(os.path.join(ROOT, "tests", "golden", "mouse_hs1940.npz"))
+        pk, n1 = np.ascontiguousarray(d["packed"]), len(d["ids"])
+        ph = d["pheno"][:, 0]
+        pos = {sid: i for i, sid in enumerate(d["pheno_ids"])}
+        yfull = np.array([ph[pos[sid]] if sid in pos else np.nan for sid in d["ids"]])
+        keep_idx = np.nonzero(np.isfinite(yfull))[0]
+        y1 = yfull[keep_idx]
+        pt = torch.from_numpy(pk).to(dev)
+        x1 = np.ones((len(keep_idx), 1))
+        kept = 0
+        for it in range(warmup + steps):
+            if it == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            k1, eff, _ = pl.build_grm(pt, n1, 1, 0.02, 0.05)
+            r1 = pl.run_trait(pt, n1, k1, keep_idx, y1, x1, "lmm")
+            kept = int(np.count_nonzero(r1.keep))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"value": kept * steps / el, "unit": "SNPs/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+                "m_kept": kept, "grm_eff_snps": int(eff), "null": {"lbd": r1.null.lbd, "pve": r1.null.pve},
+                "workload": f"example/mouse_hs1940 (BASELINE configs[0]; real panel, n={n1} of which {len(keep_idx)} phenotyped, "
+                            f"m={pk.shape[0]}), -lmm, maf 0.02 geno 0.05, intercept only", "data": "reference example panel"}
+
+    def legs_c5(want=("splmm", "pcg")):
+        """BASELINE configs[4] on ONE GPU (n = 200 000 in sibships of four, m = 1 000 000; panel generated in HBM): one step of the
+        `-splmm` routes (sparse GRM by row panels -> sparse REML null + exact scan; fastGWA null + GRAMMAR-gamma scan) and of the
+        `-BLUP` PCG leg (`rrblup_pcg_bed` with 160 000 training samples, `he_pcg_bed`) through the reference's entry points."""
+        import tempfile
+        import shutil
+        from janusx_amd import janusx as jxrs
+        n5, m5, n_tr = 200000, 1000000, 160000
+        out = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pk, dos = family_panel_gpu(n5, m5, 4, 11, dev)
+        y5 = make_phenotype(dos, n5, 7, dev)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t0
+        counts = jxrs.bed_row_counts(pk, n5)
+        keep, _miss, maf, _std = st.packed_prep_row_stats(counts, n5, 0.02, 0.05, 0.0)
+        if not bool(keep.all()):
+            pk = pk[torch.from_numpy(np.nonzero(keep)[0]).to(dev)]
+            counts, maf = counts[keep], maf[keep]
+            m5 = int(pk.shape[0])
+        flip = np.zeros(m5, dtype=bool)
+        wl = f"synthetic family panel n={n5} m={m5} (BASELINE configs[4] shape; sibships of four) on ONE GPU"
+        if "splmm" in want:
+            td = tempfile.mkdtemp()
+            try:
+                jxrs.spectral_cache_clear()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                path, _nn, nnz = jxrs.spgrm_packed_to_jxgrm(pk, n5, flip, maf, os.path.join(td, "k"), None, 1, 0.05)
+                t1 = time.perf_counter()
+                res_e, l10, _null = jxrs.splmm_exact_scan_from_jxgrm(path, y5, pk, n5, maf, flip)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                jxrs.spectral_cache_clear()
+                yc = y5 - y5.mean()
+                vp = float(yc @ yc) / float(n5 - 1)
+                nullf = jxrs.spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(path, yc, vp, low=-5.0, high=5.0, grid_size=17,
+                                                                             tol=1e-3, max_iter=20)
+                t3 = time.perf_counter()
+                ga = jxrs.splmm_assoc_pcg_bed("device", y5, float(nullf[0]), packed=pk, packed_n_samples=n5, maf=maf, row_flip=flip,
+                                              sparse_jxgrm_path=path, rhat_markers=1000, scan_mode="approx")
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                out["extra_c5_splmm"] = {
+                    "workload": wl + ", jx grm -sparse (cut-off 0.05) + jx gwas -splmm (the reference's default: fastGWA null + "
+                                     "GRAMMAR-gamma scan, 1000 sampled markers) and -splmm-exact (sparse REML null + exact scan)",
+                    "steps": 1, "warmup": 0, "unit": "SNPs/s", "m_kept": int(m5), "nnz": int(nnz),
+                    "value": m5 / ((t1 - t0) + (t4 - t2)), "ms_per_step": ((t1 - t0) + (t4 - t2)) * 1e3,
+                    "value_exact_route": m5 / (t2 - t0), "ms_per_step_exact_route": (t2 - t0) * 1e3,
+                    "stages_ms_per_step": {"panel_generation_untimed": t_gen * 1e3, "sparse_grm": (t1 - t0) * 1e3,
+                                           "exact_null_and_scan": (t2 - t1) * 1e3, "approx_null": (t3 - t2) * 1e3,
+                                           "approx_scan": (t4 - t3) * 1e3},
+                    "log10_lambda_exact": float(l10), "lambda_fastgwa": float(nullf[0]), "gamma": float(ga[0]),
+                    "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2**30}
+                del res_e, ga
+            finally:
+                shutil.rmtree(td, True)
+                jxrs.spectral_cache_clear()
+            torch.cuda.empty_cache()
+        if "pcg" in want:
+            rng = np.random.default_rng(5)
+            perm = rng.permutation(n5)
+            tr = np.sort(perm[:n_tr]).astype(np.int64)
+            te = np.sort(perm[n_tr:]).astype(np.int64)
+            ytr = np.ascontiguousarray(y5[tr])
+            cnt3 = counts.astype(np.int64)
+            nm = n5 - cnt3[:, 0]
+            alt = cnt3[:, 1] + 2 * cnt3[:, 2]
+            pfr = (alt.astype(np.float32) / (np.float32(2.0) * np.maximum(nm, 1).astype(np.float32))).astype(np.float32)
+            maf_l = np.minimum(pfr, np.float32(1.0) - pfr).astype(np.float32)      # `load_bed_2bit_packed` (gfreader.rs:4460-4485)
+            flip_l = (alt.astype(np.float64) / (2.0 * np.maximum(nm, 1))) > 0.5      # `bed_packed_row_flip_mask`
+            torch.cuda.reset_peak_memory_stats()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = jxrs.rrblup_pcg_bed("", tr, ytr, te, lambda_value=float(m5), tol=1e-6, max_iter=200, packed=pk,
+                                    packed_n_samples=n5, maf=maf_l, row_flip=flip_l)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loop_ms, iters, op_ms, setup_ms = (float(lib().jxg_last_kernel_ms(i)) for i in (18, 19, 20, 21))
+            h = jxrs.he_pcg_bed("", tr, ytr, packed=pk, packed_n_samples=n5, maf=maf_l, row_flip=flip_l, trace_samples=32)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            he_ms, he_apps = float(lib().jxg_last_kernel_ms(22)), float(lib().jxg_last_kernel_ms(23))
+            op_bytes = 2.0 * n_tr * float(m5) / 4.0            # both images of the training payload once per application
+            iters = max(iters, 1.0)
+            _PMC_SHAPE.update(n=n5, m=m5)
+            tr_a, tr_a_src = pmc_traffic_bytes("jx::packed_dot_t32_kernel")
+            tr_b, tr_b_src = pmc_traffic_bytes("jx::packed_tdot_f32_kernel")
+            _PMC_SHAPE.update(n=int(args.n), m=int(args.m))
+            out["extra_c5_pcg"] = {
+                "workload": wl + f", jx gs -rrBLUP -rr-solver pcg: rrblup_pcg_bed with {n_tr} training / {n5 - n_tr} test samples, "
+                                 "lambda = m, tol 1e-6; then he_pcg_bed (32 Hutchinson probes)",
+                "steps": 1, "warmup": 0, "unit": "SNPs/s", "value": m5 / (t1 - t0), "ms_per_step": (t1 - t0) * 1e3,
+                "pcg_iterations": int(iters), "converged": bool(o[3]), "rel_res": float(o[5]),
+                "stages_ms_per_step": {"setup_images_and_prepass": setup_ms, "iteration_loop": loop_ms,
+                                       "operator_kernels": op_ms, "predictions_and_rest": (t1 - t0) * 1e3 - setup_ms - loop_ms,
+                                       "he_pcg_bed": (t2 - t1) * 1e3, "he_operator_kernels": he_ms},
+                "he": {"sigma_g2": h[0], "sigma_e2": h[1], "h2": h[2], "operator_applications": int(he_apps)},
+                "roofline": {"bound": "hbm", "kernel": "packed_dot_t32_kernel (Z'p, sample-major image) + packed_tdot_f32_kernel "
+                                                       "(Z (Z'p), SNP-major image): one operator application",
+                             "achieved": op_bytes * iters / max(op_ms, 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": op_bytes * iters / max(op_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                             "avg_application_ms": op_ms / iters, "applications": int(iters),
+                             "he_achieved": op_bytes * max(he_apps, 1.0) / max(he_ms, 1e-9) / 1e6,
+                             "traffic": (tr_a + tr_b) if (tr_a and tr_b) else None, "traffic_source": tr_a_src or tr_b_src,
+                             "traffic_over_algorithmic": ((tr_a + tr_b) / op_bytes) if (tr_a and tr_b) else None,
+                             "note": "algorithmic bytes per operator application = 2 x n_train x m / 4 (the 2-bit payload of the "
+                                     "training samples once per half of (Z_c Z_c' + lambda I) p); duration = HIP events around the "
+                                     "two streaming kernels on the launch stream, summed over the iterations (jxg_last_kernel_ms 20); "
+                                     "both kernels are instruction-bound bit-plane table kernels (DESIGN.md 3.6), not HBM-bound; "
+                                     "traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the two kernels from the committed pass of "
+                                     "this shape (null when none)"},
+                "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2**30}
+        del pk
+        torch.cuda.empty_cache()
+        return out
+
+    if args.leg:
+        # one extra leg alone (profiling: `rocprofv3 ... -- python3 bench.py --leg c5_pcg`); prints that leg's record
+        if args.leg == "c1":
+            rec = {"extra_c1_mouse": leg_c1_mouse()}
+        elif args.leg == "c2_fvlmm":
+            lg = run_leg(5000, 50000, 0.0, args.steps, args.warmup, mode="fvlmm")
+            rec = {"extra_c2_fvlmm": {k: v for k, v in leg_summary(lg, 5000, args.steps).items() if k != "roofline"}}
+        else:
+            rec = legs_c5((args.leg[3:],))
+        print(json.dumps(rec), flush=True)
+        return
+
     n = args.n
     main_leg = run_leg(n, args.m, args.missing, args.steps, args.warmup)
     elapsed, kept_total, kern, stage, null = (main_leg[k] for k in ("elapsed", "kept_total", "kern", "stage", "null"))
@@ -497,6 +679,11 @@ def main():
         rot_peak = MFMA_I8_PEAK_TOPS if rot_i8 else MFMA_F16_PEAK_TFLOPS
         mu_rot, mu_rot_src = pmc_mfma_util(rot_kernel)
         tr_rot, tr_rot_src = pmc_traffic_bytes("jx::" + rot_kernel)
+        q1_share = float(world) if eigh_sharded else 1.0      # a rank of a sharded decomposition back-transforms n / world columns
+        scan_series = int(lib().jxg_last_kernel_ms(11)) == 3
+        # what the association stage is priced on: the series form executes 2 (p + 2) n 64 flops per SNP on the f64 matrix pipes
+        # (k_scan_fast.hip series_coef_kernel), the other forms the reference formulation's evaluations
+        scan_flops_priced = (2.0 * (x.shape[1] + 2) * 64.0 * n * kern["scan_bytes"] / (4.0 * n)) if scan_series else kern.get("scan_flops", 0.0)
         F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: one 2048-flop block per 64 cycles per SIMD = the f64 vector rate
         if kern.get("two_stage"):
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
@@ -602,32 +789,37 @@ def main():
             "roofline_eigh_gemm": ({
                 "bound": "mfma", "kernel": "oz_mm_kernel<6> (sliced f64 GEMM on v_mfma_i32_32x32x32_i8, csrc/k_ozgemm.hip)",
                 "stage": "Q1 back-transformation C <- Q1 C (W = V'C and C -= (V T) W per block of 2048 reflectors)",
-                "algorithmic_tflops": 2.0 * float(n) ** 3 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
+                "algorithmic_tflops": 2.0 * float(n) ** 3 / q1_share / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
+                "columns_per_rank": int(round(n / q1_share)),
                 "planes": int(lib().jxg_oz_planes()),
                 "issued_int8_products_per_algorithmic_product": int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2,
-                "achieved": 2.0 * float(n) ** 3 * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                "achieved": 2.0 * float(n) ** 3 / q1_share * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
                 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
                 "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                "frac": 2.0 * float(n) ** 3 * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                "frac": 2.0 * float(n) ** 3 / q1_share * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
                 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12 / MFMA_I8_PEAK_TOPS,
                 "f64_mfma_peak_tflops": F64_MFMA_PEAK_TFLOPS,
                 "note": "algorithmic 2 n^3 f64 flops of the stage over its whole duration (slicing of C and W, products, "
-                        "HIP events around the stage; the C-independent part -- V images, Gram, T^-1, V T -- is prepared on a "
-                        "side stream during the divide and conquer); every algorithmic product is issued as planes (planes + 1) / 2 "
+                        "HIP events around the stage, C-independent part -- V images, Gram, T^-1, V T -- included: it runs in line; on "
+                        "several ranks a rank back-transforms its n / world eigenvector columns and is priced on those); every algorithmic product is issued as planes (planes + 1) / 2 "
                         "int8 digit products (exact i32 sums, f64 combination: 4e-14 relative), priced against the dense int8 "
                         "peak 5 POP/s; algorithmic_tflops is to be read against the 78.6 TFLOP/s f64 MFMA roof this stage "
                         "(rocBLAS dgemm, rounds 1 - 3: 72) no longer sits under; the divide and conquer's merges run on the same kernel"}
                                    if kern.get("two_stage") and n >= 3000 else None),
-            "roofline_scan": ({"bound": "f64 valu",
+            "roofline_scan": ({"bound": "f64 mfma" if scan_series else "f64 valu",
                                "kernel": ("lmm_scan_fast_kernel (s / X~ / y~ resident in LDS)",
                                           "lmm_scan_tiled_kernel (LDS tiles of s / X~ / y~, 16 SNPs per workgroup in lock step)",
                                           "lmm_scan_fast_kernel (operands from L2)",
                                           "series_coef_kernel (per-SNP Chebyshev series of the SNP-specific sums, one pass over the "
                                           "rotated rows on v_mfma_f64_16x16x4_f64) + lmm_scan_fast_kernel<SERIES> (Brent on the series)"
                                           )[int(lib().jxg_last_kernel_ms(11))],
-                               "achieved": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9,
+                               "achieved": scan_flops_priced / max(kern["scan_ms"], 1e-9) / 1e9,
                                "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": kern.get("scan_flops", 0.0) / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,
+                               "frac": scan_flops_priced / max(kern["scan_ms"], 1e-9) / 1e9 / F64_VALU_PEAK_TFLOPS,
+                               "priced_work": ("series_coef_kernel: 2 (p + 2) n 64 f64 MFMA flops per SNP (the (p + 2) rotated rows of "
+                                               "a SNP against the n x 64 Chebyshev table), over the whole association time; the "
+                                               "reference formulation's (B + 1) n (...) flops are NOT executed by this form"
+                                               if scan_series else "SURVEY 8(d): (B + 1) n (3 dim (dim + 1) / 2 + 5 dim + 8) flops per SNP"),
                                "brent_evals_per_snp": kern.get("scan_evals", 0.0) / L,
                                "hbm_gbs": scan_gbs,
                                "traffic": tr_scan, "traffic_source": tr_scan_src,
@@ -724,10 +916,50 @@ def main():
                                             workload="synthetic HWE panel n=50000 m=500000 (BASELINE configs[3] shape) on ONE GPU, "
                                                      "-lmm, maf 0.02 geno 0.05, intercept only, missing=0.0",
                                             roofline_grm=sm["roofline_grm"], roofline_rotate=sm["roofline_rotate"])
+                _PMC_SHAPE.update(n=50000, m=500000)
+                q2k = res["extra_c4_1gpu"]["roofline"]["kernel"] if res["extra_c4_1gpu"].get("roofline") else None
+                if q2k:
+                    tr4, tr4_src = pmc_traffic_bytes("jx::" + q2k, fetch_scale=1.0)
+                    res["extra_c4_1gpu"]["roofline"].update(traffic=tr4, traffic_source=tr4_src)
+                _PMC_SHAPE.update(n=int(n), m=int(m))
+                if not args.no_cpu_baseline:
+                    # the north star's >= 10 x is quoted on THIS configuration: the oracle on the host cores, BASELINE.md section 2's
+                    # sub-sample rule (first 20 000 of the 50 000 samples, first --cpu-sample SNPs, every stage scaled by its exponent)
+                    try:
+                        n_c = 20000
+                        sub = leg["packed"][: args.cpu_sample, : n_c // 4].contiguous().cpu().numpy()
+                        cb = cpu_baseline(sub, n_c, leg["y"][:n_c], "lmm", args.cpu_sample, os.cpu_count() or 1, scale_to_n=50000,
+                                          m_full=500000)
+                        res["extra_c4_1gpu"]["cpu_baseline"] = cb
+                        res["extra_c4_1gpu"]["gpu_over_cpu_baseline"] = res["extra_c4_1gpu"]["value"] / cb["value"]
+                        del sub
+                    except Exception as e:   # noqa: BLE001 - a reported number, never the product path
+                        res["extra_c4_1gpu"]["cpu_baseline"] = {"error": repr(e)}
                 del leg
                 torch.cuda.empty_cache()
             except Exception as e:
                 res["extra_c4_1gpu"] = {"error": repr(e)}
+            try:
+                # BASELINE configs[1] (n = 5000, m = 50 000, -fvlmm: GRM + eigendecomposition + null + fixed-lambda scan)
+                leg = run_leg(5000, 50000, 0.0, 5, 2, mode="fvlmm")
+                sm = leg_summary(leg, 5000, 5)
+                res["extra_c2_fvlmm"] = dict({k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept",
+                                                                 "stages_ms_per_step", "roofline_grm", "roofline_rotate")},
+                                             warmup=2, workload="synthetic HWE panel n=5000 m=50000 (BASELINE configs[1] shape), -fvlmm, "
+                                                                "maf 0.02 geno 0.05, intercept only, missing=0.0")
+                del leg
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["extra_c2_fvlmm"] = {"error": repr(e)}
+            try:
+                res["extra_c1_mouse"] = leg_c1_mouse()
+            except Exception as e:
+                res["extra_c1_mouse"] = {"error": repr(e)}
+            try:
+                res.update(legs_c5())
+            except Exception as e:
+                res["extra_c5_splmm"] = res.get("extra_c5_splmm", {"error": repr(e)})
+                res["extra_c5_pcg"] = res.get("extra_c5_pcg", {"error": repr(e)})
         # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it first so that the
         # JSON line is the last line on stdout
         try:

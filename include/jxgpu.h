@@ -374,7 +374,10 @@ int jxg_lmm_loglike_null(const double *d_s, const double *d_xcov, const double *
  * algorithmic megabytes (lower triangle of the trailing matrix, f64) of those launches; which = 4 / 5: duration (ms) and algorithmic
  * GFLOP of the Q2 back-transformation of the most recent two-stage decomposition, 6 - 9: band reduction, bulge chasing, divide and
  * conquer, Q1 (ms), 10: 1 when the two-stage path ran, 16: apply launches of that Q2, 17: its form (0 three waves per unit, 1 one
- * wave per unit, 2 two sweep groups per pass, 3 balanced five / four units per CU).  Counterpart of the
+ * wave per unit, 2 two sweep groups per pass, 3 balanced five / four units per CU); 18 - 21: the last jx_rrblup_pcg_packed solve --
+ * wall ms of its iteration loop, its iterations, the summed HIP-event ms of its two streaming operator kernels (Z'p and Z (Z'p):
+ * 2 x n_train x m / 4 payload bytes per application), wall ms of its set-up (images + pre-pass); 22 / 23: summed operator kernel
+ * ms and operator applications of the last jx_he_traces_packed call.  Counterpart of the
  * reference's JX_GRM_*_STAGE_TIMING / JX_LMM_*_STAGE_TIMING stage timers (src/stats/grm.rs:3521-3568). */
 float jxg_last_kernel_ms(int which);
 
@@ -562,7 +565,9 @@ int jx_gblup_reml_grm(const void *k_full, int k_is_f64, int64_t n_full, const in
  * 2-bit code [00, 01 (missing, must be 0), 10, 11] (src/math/bedmath.rs:1199-1214); row_indices (eff_m) selects the
  * kept SNP rows (NULL = all m_total).  out_beta (eff_m) f32; out_pred_train (n_train) and out_pred_test (n_test) f64
  * (either may be NULL); out_scalars = (converged, iterations, relative residual, sum of centred row sums of squares,
- * intercept).  The iteration follows `pcg_solve_into` for f32 (src/math/pcg.rs:870-949). */
+ * intercept).  The iteration follows `pcg_solve_into` for f32 (src/math/pcg.rs:870-949).  `packed` is a host pointer
+ * (uploaded once) or a DEVICE pointer (a payload already resident in HBM is used in place -- BASELINE configs[4]: 50 GB);
+ * jx_he_traces_packed likewise. */
 int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
                          int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
                          const double *y_train, const int64_t *test_idx, int n_test, double lambda_value, double tol,

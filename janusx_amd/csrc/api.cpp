@@ -148,7 +148,7 @@ static int make_sample_sel(const int64_t *sample_indices, int n_sel, int n_sampl
 }
 
 // true when `p` points into device memory (a payload that is already resident in HBM: torch CUDA tensor, hipMalloc)
-static bool is_device_ptr(const void *p) {
+bool is_device_ptr(const void *p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
         (void)hipGetLastError();                     // plain (unregistered) host memory: not an error for the caller

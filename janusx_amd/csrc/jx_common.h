@@ -30,6 +30,9 @@ int fail(const std::string &msg);
         }                                                                                             \
     } while (0)
 
+// true when `p` points into device memory (a payload that is already resident in HBM: torch CUDA tensor, hipMalloc).  api.cpp
+bool is_device_ptr(const void *p);
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int num_tiles(int n) { return ceil_div(n, JXG_TILE); }
 

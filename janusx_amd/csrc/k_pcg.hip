@@ -13,11 +13,16 @@
 // reference's; only three scalars per iteration cross to the host (the convergence test is the reference's).
 #include <math.h>
 
+#include <chrono>
 #include <vector>
 
 #include "jx_common.h"
 
 namespace jx {
+
+extern float g_last_ms[24];   // [18] iteration loop of the last rrBLUP PCG solve (ms, wall), [19] its iterations, [20] summed
+                              // durations of its operator kernels (HIP events), [21] its set-up (ms, wall); [22] / [23]: summed
+                              // operator kernel time (ms) and operator applications of the last Haseman-Elston call
 
 constexpr int PCG_T = 256;
 
@@ -153,18 +158,40 @@ int pcg_allreduce_dev(double *a, int64_t na, double *b, int64_t nb, hipStream_t 
     JX_HIP(hipStreamSynchronize(st));
     return 0;
 }
-// the same for a few host doubles
-int pcg_allreduce_host(double *h, int cnt, hipStream_t st) {
+// the same for a few host doubles.  `lerr` (this rank failed since the last collective: an allocation, a launch) rides in one
+// more slot: every rank learns it in the same collective and all of them leave together -- a rank that returned on its own
+// would leave the others blocked in their next all-reduce.  -> 0, 1 (collective failed), 2 (a
+// rank reported a failure; the message of the failing rank is its own, the others get a generic one)
+int pcg_allreduce_host(double *h, int cnt, hipStream_t st, int lerr = 0) {
     PcgDist &D = g_pcg_dist;
-    if (D.world <= 1) return 0;
-    if (cnt > D.cap) return fail("jx_pcg_set_dist: staging buffer too small");
-    JX_HIP(hipMemcpyAsync(D.staging, h, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, st));
+    if (D.world <= 1) return lerr ? 2 : 0;
+    if (cnt + 1 > D.cap) return fail("jx_pcg_set_dist: staging buffer too small");
+    double buf[8];
+    if (cnt > 7) return fail("pcg_allreduce_host: at most 7 scalars");
+    for (int i = 0; i < cnt; ++i) buf[i] = lerr ? 0.0 : h[i];
+    buf[cnt] = lerr ? 1.0 : 0.0;
+    JX_HIP(hipMemcpyAsync(D.staging, buf, sizeof(double) * (size_t)(cnt + 1), hipMemcpyHostToDevice, st));
     JX_HIP(hipStreamSynchronize(st));
-    D.count = cnt;
+    D.count = cnt + 1;
     if (D.allreduce(D.user)) return fail("jx_rrblup_pcg_packed: the all-reduce callback failed");
-    JX_HIP(hipMemcpyAsync(h, D.staging, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, st));
+    JX_HIP(hipMemcpyAsync(buf, D.staging, sizeof(double) * (size_t)(cnt + 1), hipMemcpyDeviceToHost, st));
     JX_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < cnt; ++i) h[i] = buf[i];
+    if (buf[cnt] != 0.0) {
+        if (!lerr) set_error("jx_rrblup_pcg_packed: another rank of the marker-sharded solve failed (" +
+                             std::to_string((int)buf[cnt]) + " of " + std::to_string(D.world) + "); all ranks stop");
+        return 2;
+    }
     return 0;
+}
+// a collective a failed rank still has to take part in: same count as the healthy ranks use, zeros as its share
+int pcg_allreduce_dev_or_zero(double *a, int64_t na, double *b, int64_t nb, hipStream_t st, int lerr) {
+    if (g_pcg_dist.world <= 1) return 0;
+    if (lerr) {
+        (void)hipMemsetAsync(a, 0, sizeof(double) * (size_t)na, st);
+        if (nb > 0) (void)hipMemsetAsync(b, 0, sizeof(double) * (size_t)nb, st);
+    }
+    return pcg_allreduce_dev(a, na, b, nb, st);
 }
 }  // namespace
 
@@ -190,6 +217,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
                                     const double *y_train, const int64_t *test_idx, int n_test, double lambda_value,
                                     double tol, int max_iter, float *out_beta, double *out_pred_train,
                                     double *out_pred_test, double *out_scalars) {
+    // Argument checks first: they see the same values on every rank of a marker-sharded solve (or fail on all of them).
     if (n_samples <= 0) return fail("n_samples must be > 0");
     if (m_total <= 0 || eff_m <= 0) return fail("No SNP rows found in BED input.");
     if (n_train <= 0) return fail("train_sample_indices must not be empty.");
@@ -207,9 +235,6 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         if (test_idx[i] < 0 || test_idx[i] >= n_samples) return fail("test_sample_indices out of range");
         te32[i] = (int32_t)test_idx[i];
     }
-    if (row_indices)
-        for (int64_t j = 0; j < eff_m; ++j)
-            if (row_indices[j] < 0 || row_indices[j] >= m_total) return fail("site_keep row index out of range");
     double y_mean = 0.0;
     for (int i = 0; i < n_train; ++i) {
         if (!isfinite(y_train[i])) return fail("y_train contains non-finite values.");
@@ -218,110 +243,144 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     y_mean /= (double)n_train;
     const float lambda_use = (float)(lambda_value > 1e-8 ? lambda_value : 1e-8);
     const double tol_use = tol > 1e-12 ? tol : 1e-12;
+    const bool multi = g_pcg_dist.world > 1;
+    // stage timers of the last solve (jxg_last_kernel_ms 18 - 21): wall time of the set-up (images, pre-pass) and of the
+    // iteration loop, and the summed HIP-event durations of the two streaming operator kernels (Z'p on the sample-major image,
+    // Z (Z'p) on the SNP-major one): the kernels an HBM roofline of this route is quoted on
+    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (!ev[0])
+        for (auto &e : ev) JX_HIP(hipEventCreate(&e));
+    double op_ms = 0.0;
+    const auto wall0 = std::chrono::steady_clock::now();
 
+    // From here on a failure may be this rank's alone (its shard's row list, an allocation, a launch): with several ranks it is
+    // carried as `lerr` into the next collective, where every rank learns it and all of them leave together.
     hipStream_t st = nullptr;
-    DevBuf raw, didx, drow, p32, dlut, dcnt;
-    if (raw.alloc((size_t)(m_total * bps))) return 1;
-    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
-    if (didx.alloc(sizeof(int32_t) * (size_t)n_train)) return 1;
-    JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n_train, hipMemcpyHostToDevice));
-    const int64_t *d_rowidx = nullptr;
-    if (row_indices) {
-        if (drow.alloc(sizeof(int64_t) * (size_t)eff_m)) return 1;
-        JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
-        d_rowidx = drow.as<int64_t>();
-    }
-    const int nt = num_tiles(n_train);
-    if (p32.alloc((size_t)nt * (size_t)eff_m * 32)) return 1;
-    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m,
-                       p32.as<uint8_t>(), st))
-        return 1;
-    if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m)) return 1;
-    JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
-    if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
-    if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
-    // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
-    DevBuf t32, dwork;
-    if (t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m))) return 1;
-    if (dwork.alloc(16 * (size_t)eff_m + 16)) return 1;
-    if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
-    std::vector<int32_t> cnt(3 * (size_t)eff_m);
-    JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
-
-    // pre-pass (row_major_block_prepare_rhs_diag_f32, rrblup.rs:396-466): the f64 sums over the f32 row values are
-    // count-weighted sums of the three genotype values
-    std::vector<float> mu(eff_m), dinv(eff_m);
-    double sum_ss = 0.0;
-    for (int64_t j = 0; j < eff_m; ++j) {
-        const double c1 = cnt[3 * j + 1], c2 = cnt[3 * j + 2];
-        const double c0 = (double)n_train - (double)cnt[3 * j] - c1 - c2;
-        const double v0 = value_lut[4 * j], v2 = value_lut[4 * j + 2], v3 = value_lut[4 * j + 3];
-        const double sum = c0 * v0 + c1 * v2 + c2 * v3;
-        const double mean = sum / (double)n_train;
-        const double ss_raw = c0 * v0 * v0 + c1 * v2 * v2 + c2 * v3 * v3;
-        double ss = ss_raw - (double)n_train * mean * mean;
-        if (!(ss > 0.0)) ss = 0.0;
-        sum_ss += ss;
-        mu[j] = (float)mean;
-        float d = (float)ss + lambda_use;
-        if (!(d > 1e-12f)) d = 1e-12f;
-        dinv[j] = 1.0f / d;
-    }
-
+    DevBuf raw, didx, drow, p32, dlut, dcnt, t32, dwork;
     DevBuf dmu, ddinv, dx, dr, dz, dp, dap, dv64m, dv64n, dsc;
+    const uint8_t *d_raw = packed;                 // a payload that already lives in HBM is used in place
+    const int64_t *d_rowidx = nullptr;
+    std::vector<float> mu(eff_m);
     const size_t mb = sizeof(float) * (size_t)eff_m;
-    if (dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) || dz.alloc(mb) || dp.alloc(mb) ||
-        dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
-        dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
-        return 1;
-    JX_HIP(hipMemcpy(dmu.p, mu.data(), mb, hipMemcpyHostToDevice));
-    JX_HIP(hipMemcpy(ddinv.p, dinv.data(), mb, hipMemcpyHostToDevice));
-    float *x = dx.as<float>(), *r = dr.as<float>(), *z = dz.as<float>(), *p = dp.as<float>(), *ap = dap.as<float>();
-    double *v64m = dv64m.as<double>(), *v64n = dv64n.as<double>(), *sc = dsc.as<double>();
-    const uint8_t *P = p32.as<uint8_t>();
-    const float *L = dlut.as<float>();
+    float *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *ap = nullptr;
+    double *v64m = nullptr, *v64n = nullptr, *sc = nullptr;
+    const uint8_t *P = nullptr;
+    const float *L = nullptr;
     const unsigned gm = pcg_grid(eff_m), gmf = pcg_grid_full(eff_m), gnf = pcg_grid_full(n_train);
+    double sum_ss = 0.0, bb = 0.0, rz_old = 0.0;
 
     auto scalar = [&](int k, double &out) -> int {
         JX_HIP(hipMemcpyAsync(&out, sc + k, sizeof(double), hipMemcpyDeviceToHost, st));
         JX_HIP(hipStreamSynchronize(st));
         return 0;
     };
-    auto zero_scalar = [&](int k) -> int {
-        JX_HIP(hipMemsetAsync(sc + k, 0, sizeof(double), st));
+
+    auto setup = [&]() -> int {
+        if (row_indices)
+            for (int64_t j = 0; j < eff_m; ++j)
+                if (row_indices[j] < 0 || row_indices[j] >= m_total) return fail("site_keep row index out of range");
+        const bool on_device = is_device_ptr(packed);
+        const int nt = num_tiles(n_train);
+        {
+            size_t fr = 0, tot = 0;
+            const double need = (on_device ? 0.0 : (double)m_total * (double)bps) + (double)nt * (double)eff_m * 32.0 +
+                                (double)jxg_t32_bytes(n_train, (int)eff_m) + 64.0 * (double)eff_m;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > 0.97 * (double)fr)
+                return fail("rrBLUP PCG: the payload images of " + std::to_string((long long)eff_m) + " markers x " +
+                            std::to_string(n_train) + " training samples need " + std::to_string((long long)(need / 1048576.0)) +
+                            " MiB of HBM, " + std::to_string((long long)(fr >> 20)) +
+                            " MiB are free (deal the markers over more ranks: dist.enable_distributed_pcg)");
+        }
+        if (!on_device) {
+            if (raw.alloc((size_t)(m_total * bps))) return 1;
+            JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
+            d_raw = raw.as<uint8_t>();
+        }
+        if (didx.alloc(sizeof(int32_t) * (size_t)n_train)) return 1;
+        JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n_train, hipMemcpyHostToDevice));
+        if (row_indices) {
+            if (drow.alloc(sizeof(int64_t) * (size_t)eff_m)) return 1;
+            JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
+            d_rowidx = drow.as<int64_t>();
+        }
+        if (p32.alloc((size_t)nt * (size_t)eff_m * 32)) return 1;
+        if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m, p32.as<uint8_t>(), st))
+            return 1;
+        if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m)) return 1;
+        JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
+        if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
+        if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
+        // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
+        if (t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m))) return 1;
+        if (dwork.alloc(16 * (size_t)eff_m + 16)) return 1;
+        if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
+        std::vector<int32_t> cnt(3 * (size_t)eff_m);
+        JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
+        dcnt.release();
+
+        // pre-pass (row_major_block_prepare_rhs_diag_f32, rrblup.rs:396-466): the f64 sums over the f32 row values are
+        // count-weighted sums of the three genotype values
+        std::vector<float> dinv(eff_m);
+        for (int64_t j = 0; j < eff_m; ++j) {
+            const double c1 = cnt[3 * j + 1], c2 = cnt[3 * j + 2];
+            const double c0 = (double)n_train - (double)cnt[3 * j] - c1 - c2;
+            const double v0 = value_lut[4 * j], v2 = value_lut[4 * j + 2], v3 = value_lut[4 * j + 3];
+            const double sum = c0 * v0 + c1 * v2 + c2 * v3;
+            const double mean = sum / (double)n_train;
+            const double ss_raw = c0 * v0 * v0 + c1 * v2 * v2 + c2 * v3 * v3;
+            double ss = ss_raw - (double)n_train * mean * mean;
+            if (!(ss > 0.0)) ss = 0.0;
+            sum_ss += ss;
+            mu[j] = (float)mean;
+            float d = (float)ss + lambda_use;
+            if (!(d > 1e-12f)) d = 1e-12f;
+            dinv[j] = 1.0f / d;
+        }
+        if (dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) || dz.alloc(mb) || dp.alloc(mb) ||
+            dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
+            dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
+            return 1;
+        JX_HIP(hipMemcpy(dmu.p, mu.data(), mb, hipMemcpyHostToDevice));
+        JX_HIP(hipMemcpy(ddinv.p, dinv.data(), mb, hipMemcpyHostToDevice));
+        x = dx.as<float>(), r = dr.as<float>(), z = dz.as<float>(), p = dp.as<float>(), ap = dap.as<float>();
+        v64m = dv64m.as<double>(), v64n = dv64n.as<double>(), sc = dsc.as<double>();
+        P = p32.as<uint8_t>();
+        L = dlut.as<float>();
+        // b = Z y_c (f32 GEMV in the reference; f64 accumulation rounded once here)
+        {
+            std::vector<double> yc(n_train);
+            for (int i = 0; i < n_train; ++i) yc[i] = (double)(float)(y_train[i] - y_mean);
+            JX_HIP(hipMemcpy(v64n, yc.data(), sizeof(double) * (size_t)n_train, hipMemcpyHostToDevice));
+            if (jxg_packed_tdot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;
+        }
+        // r = b (f32), x = 0, z = M^-1 r, p = z
+        std::vector<double> b64(eff_m);
+        JX_HIP(hipMemcpy(b64.data(), v64m, sizeof(double) * (size_t)eff_m, hipMemcpyDeviceToHost));
+        std::vector<float> b32(eff_m);
+        for (int64_t j = 0; j < eff_m; ++j) {
+            b32[j] = (float)b64[j];
+            bb += (double)b32[j] * (double)b32[j];
+        }
+        JX_HIP(hipMemcpy(r, b32.data(), mb, hipMemcpyHostToDevice));
+        JX_HIP(hipMemsetAsync(x, 0, mb, st));
+        JX_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 8, st));
+        hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
+        JX_LAUNCH_CHECK();
+        JX_HIP(hipMemcpyAsync(p, z, mb, hipMemcpyDeviceToDevice, st));
+        if (scalar(0, rz_old)) return 1;
         return 0;
     };
-
-    // b = Z y_c (f32 GEMV in the reference; f64 accumulation rounded once here)
+    int lerr = setup() ? 1 : 0;
+    const auto wall1 = std::chrono::steady_clock::now();
     {
-        std::vector<double> yc(n_train);
-        for (int i = 0; i < n_train; ++i) yc[i] = (double)(float)(y_train[i] - y_mean);
-        JX_HIP(hipMemcpy(v64n, yc.data(), sizeof(double) * (size_t)n_train, hipMemcpyHostToDevice));
-        if (jxg_packed_tdot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;
+        // markers sharded over ranks: |b|^2, the trace and r'z over all markers -- and every rank's setup verdict
+        double three[3] = {bb, sum_ss, rz_old};
+        if (pcg_allreduce_host(three, 3, st, lerr)) return 1;
+        bb = three[0], sum_ss = three[1], rz_old = three[2];
     }
-    // r = b (f32), x = 0, z = M^-1 r, p = z
-    std::vector<double> b64(eff_m);
-    JX_HIP(hipMemcpy(b64.data(), v64m, sizeof(double) * (size_t)eff_m, hipMemcpyDeviceToHost));
-    std::vector<float> b32(eff_m);
-    double bb = 0.0;
-    for (int64_t j = 0; j < eff_m; ++j) {
-        b32[j] = (float)b64[j];
-        bb += (double)b32[j] * (double)b32[j];
-    }
-    if (pcg_allreduce_host(&bb, 1, st)) return 1;          // markers sharded over ranks: |b|^2 and the trace over all markers
-    if (pcg_allreduce_host(&sum_ss, 1, st)) return 1;
     if (!isfinite(bb)) return fail("PCG invalid RHS norm.");
     const double bnorm = sqrt(bb);
     const double denom_b = bnorm > 1e-12 ? bnorm : 1e-12;
-    JX_HIP(hipMemcpy(r, b32.data(), mb, hipMemcpyHostToDevice));
-    JX_HIP(hipMemsetAsync(x, 0, mb, st));
-    if (zero_scalar(0)) return 1;
-    hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
-    JX_LAUNCH_CHECK();
-    JX_HIP(hipMemcpyAsync(p, z, mb, hipMemcpyDeviceToDevice, st));
-    double rz_old = 0.0;
-    if (scalar(0, rz_old)) return 1;
-    if (pcg_allreduce_host(&rz_old, 1, st)) return 1;
     double rel_res = bnorm / denom_b;   // r = b
     if (rel_res < 0.0) rel_res = 0.0;
     bool converged = false;
@@ -332,40 +391,54 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     } else {
         for (int it = 0; it < max_iter; ++it) {
             // ap = A p
-            hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
-            JX_LAUNCH_CHECK();
-            if (jxg_packed_dot_t32(t32.as<uint8_t>(), n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
-            JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
-            hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);    // mu'p
-            JX_LAUNCH_CHECK();
-            if (pcg_allreduce_dev(v64n, n_train, sc + 1, 1, st)) return 1;      // this rank's markers -> all markers
-            hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
-            JX_LAUNCH_CHECK();
-            if (jxg_packed_tdot_f32(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
-            hipLaunchKernelGGL(pcg_finish_ap_kernel, dim3(gm), dim3(PCG_T), 0, st, v64m, p, dmu.as<float>(),
-                               (float)n_train, sc + 1, lambda_use, eff_m, ap, sc + 2);
-            JX_LAUNCH_CHECK();
+            auto half1 = [&]() -> int {
+                hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
+                JX_LAUNCH_CHECK();
+                JX_HIP(hipEventRecord(ev[0], st));
+                if (jxg_packed_dot_t32(t32.as<uint8_t>(), n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
+                JX_HIP(hipEventRecord(ev[1], st));
+                JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
+                hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);    // mu'p
+                JX_LAUNCH_CHECK();
+                return 0;
+            };
+            if (!lerr) lerr = half1() ? 1 : 0;
+            if (pcg_allreduce_dev_or_zero(v64n, n_train, sc + 1, 1, st, lerr)) return 1;      // this rank's markers -> all markers
             double denom = 0.0;
-            if (scalar(2, denom)) return 1;
-            if (pcg_allreduce_host(&denom, 1, st)) return 1;
+            auto half2 = [&]() -> int {
+                hipLaunchKernelGGL(pcg_round_kernel, dim3(gnf), dim3(PCG_T), 0, st, v64n, (int64_t)n_train);
+                JX_LAUNCH_CHECK();
+                JX_HIP(hipEventRecord(ev[2], st));
+                if (jxg_packed_tdot_f32(P, eff_m, n_train, nullptr, (int)eff_m, L, v64n, v64m, st)) return 1;  // Z (Z'p)
+                JX_HIP(hipEventRecord(ev[3], st));
+                hipLaunchKernelGGL(pcg_finish_ap_kernel, dim3(gm), dim3(PCG_T), 0, st, v64m, p, dmu.as<float>(),
+                                   (float)n_train, sc + 1, lambda_use, eff_m, ap, sc + 2);
+                JX_LAUNCH_CHECK();
+                if (scalar(2, denom)) return 1;
+                float a = 0.f, b = 0.f;
+                if (hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&b, ev[2], ev[3]) == hipSuccess)
+                    op_ms += (double)a + (double)b;
+                return 0;
+            };
+            if (!lerr) lerr = half2() ? 1 : 0;
+            if (pcg_allreduce_host(&denom, 1, st, lerr)) return 1;
             if (!isfinite(denom) || denom <= tiny_use) break;
             const double alpha = rz_old / denom;
-            if (zero_scalar(3)) return 1;
-            hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gm), dim3(PCG_T), 0, st, x, r, p, ap, (float)alpha, eff_m,
-                               sc + 3);
-            JX_LAUNCH_CHECK();
-            if (zero_scalar(0)) return 1;
-            hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
-            JX_LAUNCH_CHECK();
-            double rr = 0.0, rz_new = 0.0;
-            JX_HIP(hipMemcpyAsync(&rr, sc + 3, sizeof(double), hipMemcpyDeviceToHost, st));
-            if (scalar(0, rz_new)) return 1;
-            {
-                double two[2] = {rr, rz_new};
-                if (pcg_allreduce_host(two, 2, st)) return 1;
-                rr = two[0];
-                rz_new = two[1];
-            }
+            double two[2] = {0.0, 0.0};     // r'r, r'z
+            auto half3 = [&]() -> int {
+                JX_HIP(hipMemsetAsync(sc + 3, 0, sizeof(double), st));
+                hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(gm), dim3(PCG_T), 0, st, x, r, p, ap, (float)alpha, eff_m,
+                                   sc + 3);
+                JX_LAUNCH_CHECK();
+                JX_HIP(hipMemsetAsync(sc + 0, 0, sizeof(double), st));
+                hipLaunchKernelGGL(pcg_precond_kernel, dim3(gm), dim3(PCG_T), 0, st, r, ddinv.as<float>(), z, eff_m, sc + 0);
+                JX_LAUNCH_CHECK();
+                JX_HIP(hipMemcpyAsync(&two[0], sc + 3, sizeof(double), hipMemcpyDeviceToHost, st));
+                return scalar(0, two[1]);
+            };
+            lerr = half3() ? 1 : 0;
+            if (pcg_allreduce_host(two, 2, st, lerr)) return 1;
+            const double rr = two[0], rz_new = two[1];
             rel_res = sqrt(rr) / denom_b;
             if (rel_res < 0.0) rel_res = 0.0;
             iters = it + 1;
@@ -376,47 +449,73 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             if (!isfinite(rz_new) || rz_new <= tiny_use) break;
             const double beta = rz_new / (rz_old > tiny_use ? rz_old : tiny_use);
             hipLaunchKernelGGL(pcg_update_p_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, z, (float)beta, eff_m);
-            JX_LAUNCH_CHECK();
+            if (hipGetLastError() != hipSuccess) lerr = fail("kernel launch failed: pcg_update_p_kernel");   // reported in the next collective
             rz_old = rz_new;
         }
     }
-    JX_HIP(hipMemcpy(out_beta, x, mb, hipMemcpyDeviceToHost));
+    g_last_ms[18] = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall1).count();
+    g_last_ms[19] = (float)iters;
+    g_last_ms[20] = (float)op_ms;
+    g_last_ms[21] = (float)std::chrono::duration<double, std::milli>(wall1 - wall0).count();
     float acc = 0.0f;   // `.map(mu * b).sum::<f32>()`, sequential (rrblup.rs:4057-4062)
-    for (int64_t j = 0; j < eff_m; ++j) {
-        volatile float t = mu[j] * out_beta[j];
-        acc = acc + t;
+    if (!lerr) {
+        if (hipMemcpy(out_beta, x, mb, hipMemcpyDeviceToHost) != hipSuccess) lerr = fail("download of the marker effects failed");
+        for (int64_t j = 0; j < eff_m && !lerr; ++j) {
+            volatile float t = mu[j] * out_beta[j];
+            acc = acc + t;
+        }
     }
-    if (g_pcg_dist.world > 1) {      // sum over all markers (the single-rank form keeps the reference's sequential f32 sum)
+    if (multi) {      // sum over all markers (the single-rank form keeps the reference's sequential f32 sum)
         double a64 = (double)acc;
-        if (pcg_allreduce_host(&a64, 1, st)) return 1;
+        if (pcg_allreduce_host(&a64, 1, st, lerr)) return 1;
         acc = (float)a64;
+    } else if (lerr) {
+        return 1;
     }
     const float alpha_use = (float)y_mean - acc;
 
     // predictions: alpha + Z_samples' beta (pcg_x_mul_samples, f32 output)
-    hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, x, v64m, eff_m);
-    JX_LAUNCH_CHECK();
+    auto pred_train = [&]() -> int {
+        hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, x, v64m, eff_m);
+        JX_LAUNCH_CHECK();
+        if (out_pred_train && jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+        return 0;
+    };
+    lerr = pred_train() ? 1 : 0;
     if (out_pred_train) {
-        if (jxg_packed_dot(P, eff_m, n_train, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
-        if (pcg_allreduce_dev(v64n, n_train, nullptr, 0, st)) return 1;
-        JX_HIP(hipStreamSynchronize(st));
-        JX_HIP(hipMemcpy(out_pred_train, v64n, sizeof(double) * (size_t)n_train, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n_train; ++i) out_pred_train[i] = (double)((float)out_pred_train[i] + alpha_use);
+        if (pcg_allreduce_dev_or_zero(v64n, n_train, nullptr, 0, st, lerr)) return 1;
+        if (!lerr) {
+            JX_HIP(hipStreamSynchronize(st));
+            JX_HIP(hipMemcpy(out_pred_train, v64n, sizeof(double) * (size_t)n_train, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n_train; ++i) out_pred_train[i] = (double)((float)out_pred_train[i] + alpha_use);
+        }
     }
     if (n_test > 0 && out_pred_test) {
         DevBuf dte, p32t;
-        if (dte.alloc(sizeof(int32_t) * (size_t)n_test)) return 1;
-        JX_HIP(hipMemcpy(dte.p, te32.data(), sizeof(int32_t) * (size_t)n_test, hipMemcpyHostToDevice));
-        const int ntt = num_tiles(n_test);
-        if (p32t.alloc((size_t)ntt * (size_t)eff_m * 32)) return 1;
-        if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, dte.as<int32_t>(), n_test, d_rowidx, eff_m,
-                           p32t.as<uint8_t>(), st))
-            return 1;
-        if (jxg_packed_dot(p32t.as<uint8_t>(), eff_m, n_test, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
-        if (pcg_allreduce_dev(v64n, n_test, nullptr, 0, st)) return 1;
-        JX_HIP(hipStreamSynchronize(st));
-        JX_HIP(hipMemcpy(out_pred_test, v64n, sizeof(double) * (size_t)n_test, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n_test; ++i) out_pred_test[i] = (double)(float)out_pred_test[i] + (double)alpha_use;
+        auto pred_test = [&]() -> int {
+            // the training images are no longer needed: at biobank size they are what the test image has to fit beside
+            t32.release();
+            if (dte.alloc(sizeof(int32_t) * (size_t)n_test)) return 1;
+            JX_HIP(hipMemcpy(dte.p, te32.data(), sizeof(int32_t) * (size_t)n_test, hipMemcpyHostToDevice));
+            const int ntt = num_tiles(n_test);
+            if (p32t.alloc((size_t)ntt * (size_t)eff_m * 32)) return 1;
+            if (jxg_repack_p32(d_raw, bps, n_samples, m_total, dte.as<int32_t>(), n_test, d_rowidx, eff_m, p32t.as<uint8_t>(), st))
+                return 1;
+            if (jxg_packed_dot(p32t.as<uint8_t>(), eff_m, n_test, nullptr, (int)eff_m, L, v64m, v64n, st)) return 1;
+            return 0;
+        };
+        if (!lerr) lerr = pred_test() ? 1 : 0;
+        if (pcg_allreduce_dev_or_zero(v64n, n_test, nullptr, 0, st, lerr)) return 1;
+        if (!lerr) {
+            JX_HIP(hipStreamSynchronize(st));
+            JX_HIP(hipMemcpy(out_pred_test, v64n, sizeof(double) * (size_t)n_test, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n_test; ++i) out_pred_test[i] = (double)(float)out_pred_test[i] + (double)alpha_use;
+        }
+    }
+    if (multi) {
+        if (pcg_allreduce_host(nullptr, 0, st, lerr)) return 1;      // the last verdict: every rank returns the same status
+    } else if (lerr) {
+        return 1;
     }
     JX_HIP(hipStreamSynchronize(st));
     out_scalars[0] = converged ? 1.0 : 0.0;
@@ -543,8 +642,12 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
 
     hipStream_t st = nullptr;
     DevBuf raw, didx, drow, p32, t32, dlut, dwork, dvn, dvm;
-    if (raw.alloc((size_t)(m_total * bps))) return 1;
-    JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
+    const uint8_t *d_raw = packed;                 // a payload that already lives in HBM is used in place
+    if (!is_device_ptr(packed)) {
+        if (raw.alloc((size_t)(m_total * bps))) return 1;
+        JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
+        d_raw = raw.as<uint8_t>();
+    }
     if (didx.alloc(sizeof(int32_t) * (size_t)n)) return 1;
     JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     const int64_t *d_rowidx = nullptr;
@@ -554,8 +657,7 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         d_rowidx = drow.as<int64_t>();
     }
     if (p32.alloc((size_t)num_tiles(n) * (size_t)eff_m * 32)) return 1;
-    if (jxg_repack_p32(raw.as<uint8_t>(), bps, n_samples, m_total, didx.as<int32_t>(), n, d_rowidx, eff_m,
-                       p32.as<uint8_t>(), st))
+    if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n, d_rowidx, eff_m, p32.as<uint8_t>(), st))
         return 1;
     JX_HIP(hipStreamSynchronize(st));
     raw.release();
@@ -569,9 +671,15 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
     const float inv_m = 1.0f / (ms > 1.0f ? ms : 1.0f);
     std::vector<double> h64(n);
     // out = K v (f32 in, f32 out): Z v (f32 GEMV in the reference) -> Z'(.) -> * 1/m   (he.rs:1273-1327)
+    static hipEvent_t hev[2] = {nullptr, nullptr};
+    if (!hev[0])
+        for (auto &e : hev) JX_HIP(hipEventCreate(&e));
+    double he_ms = 0.0;
+    int he_apps = 0;
     auto apply_k = [&](const std::vector<float> &v, std::vector<float> &o) -> int {
         for (int i = 0; i < n; ++i) h64[i] = (double)v[i];
         JX_HIP(hipMemcpyAsync(dvn.p, h64.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        JX_HIP(hipEventRecord(hev[0], st));
         if (jxg_packed_tdot_f32(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, dlut.as<float>(), dvn.as<double>(),
                                 dvm.as<double>(), st))
             return 1;
@@ -580,8 +688,12 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         if (jxg_packed_dot_t32(t32.as<uint8_t>(), n, (int)eff_m, dlut.as<float>(), dvm.as<double>(), dwork.p,
                                dvn.as<double>(), st))
             return 1;
+        JX_HIP(hipEventRecord(hev[1], st));
         JX_HIP(hipMemcpyAsync(h64.data(), dvn.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
         JX_HIP(hipStreamSynchronize(st));
+        float ems = 0.f;
+        if (hipEventElapsedTime(&ems, hev[0], hev[1]) == hipSuccess) he_ms += (double)ems;
+        ++he_apps;
         o.resize(n);
         for (int i = 0; i < n; ++i) o[i] = (float)h64[i] * inv_m;
         return 0;
@@ -628,6 +740,8 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         trk /= (double)trace_samples;
         trk2 /= (double)trace_samples;
     }
+    g_last_ms[22] = (float)he_ms;
+    g_last_ms[23] = (float)he_apps;
     out5[0] = y_ky;
     out5[1] = y_y;
     out5[2] = trk;

@@ -3349,9 +3349,14 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
         if int(packed_n_samples) == 0:
             raise RuntimeError("rrblup_pcg_bed: packed payload path requires packed_n_samples > 0.")
         n_samples = int(packed_n_samples)
-        pk = _c(packed, np.uint8)
-        if pk.ndim != 2:
-            raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+        if _is_device_tensor(packed):        # a payload that already lives in HBM is used in place (no host copy of 50 GB)
+            if packed.dim() != 2:
+                raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+            pk = packed.contiguous()
+        else:
+            pk = _c(packed, np.uint8)
+            if pk.ndim != 2:
+                raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
     elif maf is not None or row_flip is not None or int(packed_n_samples) > 0:
         if maf is None:
             raise RuntimeError("rrblup_pcg_bed: streaming stats path requires `maf` argument.")
@@ -3465,10 +3470,13 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
             # all-reduce would wait for ever)
             raise RuntimeError(f"distributed rrBLUP PCG: {eff_m} kept rows cannot be dealt over {world} ranks")
         rows_all = rows if rows is not None else np.arange(m_total, dtype=np.int64)
-        pk_s = np.ascontiguousarray(pk[rows_all[lo:hi]])
+        if _is_device_tensor(pk):
+            pk_s = pk[torch.from_numpy(rows_all[lo:hi]).to(pk.device)].contiguous() if rows is not None else pk[lo:hi]
+        else:
+            pk_s = np.ascontiguousarray(pk[rows_all[lo:hi]])
         lut_s = np.ascontiguousarray(lut[lo:hi])
         beta_s = np.zeros(hi - lo, dtype=f32)
-        check(lib().jx_rrblup_pcg_packed(_p(pk_s), hi - lo, n_samples, None, hi - lo, _p(lut_s), _p(tr), n_train, _p(y),
+        check(lib().jx_rrblup_pcg_packed(_payload(pk_s, n_samples)[1], hi - lo, n_samples, None, hi - lo, _p(lut_s), _p(tr), n_train, _p(y),
                                          _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
                                          int(max_iter), _p(beta_s), _p(pred_tr_full), _p(pred_te) if te.size else None,
                                          _p(sc)))
@@ -3487,7 +3495,7 @@ def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=No
         for (a, b), t in zip(sizes, parts):
             beta[a:b] = t[: b - a].numpy()
     else:
-        check(lib().jx_rrblup_pcg_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
+        check(lib().jx_rrblup_pcg_packed(_payload(pk, n_samples)[1], m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n_train, _p(y),
                                          _p(te) if te.size else None, int(te.shape[0]), float(lambda_value), float(tol),
                                          int(max_iter), _p(beta), _p(pred_tr_full), _p(pred_te) if te.size else None,
                                          _p(sc)))
@@ -3733,9 +3741,14 @@ def he_pcg_bed(prefix, train_sample_indices, y_train, site_keep=None, trace_samp
         if int(packed_n_samples) == 0:
             raise RuntimeError("he_pcg_bed: packed payload path requires packed_n_samples > 0.")
         n_samples = int(packed_n_samples)
-        pk = _c(packed, np.uint8)
-        if pk.ndim != 2:
-            raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+        if _is_device_tensor(packed):        # a payload that already lives in HBM is used in place
+            if packed.dim() != 2:
+                raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
+            pk = packed.contiguous()
+        else:
+            pk = _c(packed, np.uint8)
+            if pk.ndim != 2:
+                raise RuntimeError("packed BED payload must be 2D (m, bytes_per_snp).")
     elif meta:
         if site_keep is not None:
             raise RuntimeError("he_pcg_bed: metadata streaming path does not accept site_keep; subset rows via "
@@ -3815,8 +3828,15 @@ def he_pcg_bed(prefix, train_sample_indices, y_train, site_keep=None, trace_samp
     af = np.clip(maf_keep, f32(0.0), f32(1.0))
     pfr = np.where(af <= f32(0.5), af, np.where(flip_keep, f32(1.0) - af, af)).astype(f32)
     if use_train_maf:
-        pk_rows = pk if rows is None else np.ascontiguousarray(pk[rows])
+        if rows is None:
+            pk_rows = pk
+        elif _is_device_tensor(pk):
+            import torch
+            pk_rows = pk[torch.from_numpy(rows).to(pk.device)]
+        else:
+            pk_rows = np.ascontiguousarray(pk[rows])
         cnt = bed_row_counts(pk_rows, n_samples, tr).astype(np.int64)
+        del pk_rows
         nm = n - cnt[:, 0]
         alt = cnt[:, 1] + 2 * cnt[:, 2]
         dos = np.where(flip_keep, 2 * nm - alt, alt)
@@ -3841,7 +3861,7 @@ def he_pcg_bed(prefix, train_sample_indices, y_train, site_keep=None, trace_samp
     lut[:, 3] = (g2 - rm) * ri
     exact = bool(exact_trace_debug) and n <= max(int(exact_trace_max_n), 1)
     out5 = np.zeros(5, dtype=np.float64)
-    check(lib().jx_he_traces_packed(_p(pk), m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n, _p(y), _p(xc), p_cov,
+    check(lib().jx_he_traces_packed(_payload(pk, n_samples)[1], m_total, n_samples, _p(rows), eff_m, _p(lut), _p(tr), n, _p(y), _p(xc), p_cov,
                                     int(trace_samples), int(seed) & ((1 << 64) - 1), 1 if exact else 0,
                                     float(m_effective), _p(out5)))
     y_ky, y_y, tr_k, tr_k2, tr_p = (float(v) for v in out5)

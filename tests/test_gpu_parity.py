@@ -1037,6 +1037,48 @@ def test_c5_full_size_splmm_device_panel():
     assert d["host_maxrss_gib"] < 8.0 and d["host_rss_growth_gib"] < 4.0, d
 
 
+def test_c5_full_size_blup_pcg_device_panel():
+    """BASELINE configs[4]'s `-BLUP` PCG leg AT FULL SIZE (n = 200 000 samples of which 160 000 train, m = 1 000 000 SNPs; the
+    panel generated ON THE DEVICE, tests/c5_pcg_driver.py in its own process): `rrblup_pcg_bed` (src/stats/rrblup.rs:3519) and
+    `he_pcg_bed` (src/stats/he.rs:2101) with the payload as a device tensor, operator src/math/pcg.rs:300-575.
+    (1) the ridge residual recomputed in f64 on the device from an independent decode over all markers and training samples;
+    (2) every test prediction against that decode, a 150-sample slice against the oracle's prediction operator;
+    (3) the oracle's whole solve on a marker sub-panel with ALL 160 000 training samples (1250 sample tiles) against the device
+    solve of the same sub-panel; (4) Haseman-Elston sufficient statistics at full size against the f64 decode with the same
+    splitmix64 probes, tr(PKP) against its exact value from the genotype counts, and the exact-trace route on a sample sub-block
+    against dense f64 traces.  Host RSS growth bounded: no (m x n) array on the host (the payload alone is 50 GB)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    free, _tot = torch.cuda.mem_get_info()
+    if free < 200 * 2**30:
+        pytest.skip("needs ~200 GiB of free HBM (MI355X: 288 GB)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "c5_pcg_driver.py"), "200000", "1000000", "160000"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        json.dump(d, open(os.path.join(root, "gpurun_out", "c5_pcg.json"), "w"), indent=1)
+    except OSError:
+        pass
+    tol = 1e-6
+    assert d["converged"] and d["rel_res"] <= tol and 1 <= d["iters"] < 200 and d["m_effective"] > 950000, d
+    assert d["ridge_residual"] <= 5 * tol, d        # f32 vectors: the true residual tracks the recurrence residual to a small factor
+    assert max(d["pred_test_err"], d["pred_train_err"], d["pred_oracle_slice_err"]) <= 2e-5, d
+    # the oracle's whole solve on the marker sub-panel, all training samples
+    assert d["sub_converged"] and abs(d["sub_iters"] - d["sub_iters_ref"]) <= 1, d
+    assert d["sub_beta_err"] <= 2e-5 and max(d["sub_pred_train_err"], d["sub_pred_test_err"]) <= 2e-5 and d["sub_k_trace_err"] <= 1e-9, d
+    # Haseman-Elston: sufficient statistics (f32 GEMV outputs in the reference, f64-merged tile sums here)
+    assert d["he_m_effective_equal"] and max(d["he_y_ky_err"], d["he_y_y_err"], d["he_tr_k2_err"]) <= 5e-5, d
+    assert d["he_sigma_err"] <= 2e-3 and d["he_tr_k_vs_exact"] <= 5e-3, d
+    assert d["he_sub_m_effective_equal"] and max(d["he_sub_tr_k2_err"], d["he_sub_y_ky_err"], d["he_sub_y_y_err"]) <= 5e-5, d
+    assert d["host_maxrss_gib"] < 12.0 and d["host_rss_growth_gib"] < 8.0, d
+
+
 def test_bed_payload_is_staged_in_windows(oracle, tmp_path):
     """`mmap_window_mb` (src/io/gload.rs WindowedBedMatrix; src/stats/lmm.rs:2488-2520): the BED routes stage the payload to
     HBM window by window -- several windows (1 MiB each here) give the same device payload as the file, the same GRM and the

@@ -735,6 +735,78 @@ def test_reference_python_values_through_the_gpu_path():
     assert np.max(np.abs(out[ok, 0] - gold["lm_out"][ok, 0]) / (np.abs(gold["lm_out"][ok, 0]) + gold["lm_out"][ok, 1])) < 1e-8
 
 
+def test_reference_model_layer_replayed_through_the_gpu_library():
+    """The reference's own model layer (python/janusx/pyBLUP/assoc.py `LMM.__init__` / `_initialize_from_spectral` :1702-1876,
+    `LMM.gwas` :1962, `LMM2.gwas`, `FastLMM.gwas`, `FvLMM.gwas / gwas_rotated` :2072-2180; `janusx/assoc/api.py::ASSOC`) was run in
+    the build container over a recording stub of the native module (tests/golden/gen_reference_model_fixtures.py).  Here every
+    native call it made is REPLAYED with the recorded argument values through `janusx_amd.janusx` -- the HIP library behind the
+    same names -- and `pipeline.SpectralModel` is compared with the model attributes the REFERENCE'S code derived (lambda_0, ML0,
+    LL0, sigma_g2, sigma_e2, PVE, scan bounds incl. the (-5, 5) fallback on both sides of 0.05 <= PVE <= 0.95)."""
+    import os
+    import torch
+    from janusx_amd import janusx as jxrs
+    from janusx_amd import pipeline
+    r = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz"))
+    n = int(r["n"])
+    # 1. `rust_eigh_from_array_f64_inplace(K + 1e-6 I, threads, driver="auto", jobz="V", require_lapack=False)`
+    a = np.array(r["eigh_input"], copy=True)
+    ret = jxrs.rust_eigh_from_array_f64_inplace(a, threads=0, driver="auto", jobz="V", require_lapack=False)
+    assert len(ret) == 10
+    w, v = np.asarray(ret[0]), np.asarray(ret[1])
+    smax = max(1.0, float(np.max(np.abs(r["eigh_w"]))))
+    assert np.max(np.abs(w - r["eigh_w"])) < 1e-11 * smax
+    assert np.max(np.abs(r["eigh_input"] @ v - v * w[None, :])) < 1e-11 * smax and np.max(np.abs(v.T @ v - np.eye(n))) < 1e-11
+    # 2. `lmm_rotate_x_y_with_ut_f64(Dh, [1, X], y, threads)`
+    xr, yr = jxrs.lmm_rotate_x_y_with_ut_f64(r["lmm_Dh"], r["rot_x_in"], r["y"], 0)
+    assert np.max(np.abs(xr - r["lmm_Xcov"])) < 1e-12 and np.max(np.abs(np.asarray(yr).ravel() - r["lmm_yrot"])) < 1e-12
+    # 3. `lmm_reml_null_f32(S, Xcov, y, -5, 5, 50, 1e-3)`
+    lo0, hi0, it0, tol0 = r["null_args"]
+    lbd, ml, reml = jxrs.lmm_reml_null_f32(r["lmm_S"], r["lmm_Xcov"], r["lmm_yrot"], lo0, hi0, int(it0), tol0)
+    assert abs(lbd - r["null_ret"][0]) < 1e-8 * lbd and abs(ml - r["null_ret"][1]) < 1e-9 * abs(ml)
+    assert abs(reml - r["null_ret"][2]) < 1e-9 * abs(reml)
+    # 4. the device-resident model against what the reference's Python derived around those calls
+    dev = torch.device("cuda", 0)
+    x = r["rot_x_in"]
+    for tag, yy in (("lmm", r["y"]), ("noise", r["y_noise"]), ("gen", r["y_gen"])):
+        model = pipeline.SpectralModel(torch.from_numpy(r["eigh_w"]).to(dev), torch.from_numpy(np.ascontiguousarray(r["eigh_v"].T)).to(dev),
+                                       x, yy)
+        nf = model.null
+        for mine, key, tol in ((nf.lbd, "lbd_null", 1e-7), (nf.ml0, "ML0", 1e-9), (nf.reml0, "LL0", 1e-9), (nf.sigma_g2, "sigma_g2", 1e-7),
+                               (nf.sigma_e2, "sigma_e2", 1e-7), (nf.pve, "pve", 1e-7)):
+            ref = float(r[f"{tag}_{key}"])
+            assert abs(mine - ref) <= tol * max(1.0, abs(ref)) + (1e-7 * abs(ref) if key != "pve" else 0.0), (tag, key, mine, ref)
+        assert np.allclose(np.array(nf.bounds), r[f"{tag}_bounds"], rtol=0, atol=1e-7), (tag, nf.bounds, r[f"{tag}_bounds"])
+        assert np.array_equal(model.ut.cpu().numpy(), r[f"{tag}_Dh"])
+    # 5. `LMM.gwas` -> lmm_reml_chunk_from_snp_f32 with the layer's bounds / 30 / 1e-2 / no null ML
+    lo, hi, it, tol, rot_rows = r["lmm_gwas_args"]
+    s_, x_, y_ = r["lmm_S"], r["lmm_Xcov"], r["lmm_yrot"]
+    t = jxrs.lmm_reml_chunk_from_snp_f32(s_, x_, y_, lo, hi, r["snp"], r["lmm_Dh"], int(it), tol, 1, None, int(rot_rows))
+    assert t.shape == r["lmm_gwas"].shape
+    be, se, pe = _assoc_err(t, r["lmm_gwas"], "lmm")
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    # 6. FvLMM: one cache per trait, raw and rotated entry points; 7. FastLMM's fixed-lambda kernel
+    cache = jxrs.fvlmm_assoc_prepare_cache_f32(s_, x_, y_, float(r["fvlmm_log10_lbd"]))
+    assert int(cache.n) == n and int(cache.p) == x_.shape[1]                       # assoc.py:2093-2097 reads both
+    f1 = jxrs.fvlmm_assoc_chunk_from_snp_with_cache_f32(cache, r["snp"], r["lmm_Dh"], 1, None, int(rot_rows))
+    f2 = jxrs.fvlmm_assoc_chunk_with_cache_f32(cache, r["grot"], 1, None)
+    f3 = jxrs.lmm_assoc_chunk_from_snp_f32(s_, x_, y_, float(r["fvlmm_log10_lbd"]), r["snp"], r["lmm_Dh"], 1, None, int(rot_rows))
+    for got, ref, tag in ((f1, r["fvlmm_gwas"], "fv_snp"), (f2, r["fvlmm_gwas_rotated"], "fv_rot"), (f3, r["fastlmm_gwas"], "fastlmm")):
+        be, se, pe = _assoc_err(got, ref, tag)
+        assert max(be, se, pe) < TOL, (tag, be, se, pe)
+    # 8. LMM2: the native ML likelihood at every point the layer's scipy search evaluated, then the scan with its optimum
+    for l10, val in zip(r["lmm2_ml_evals"], r["lmm2_ml_values"]):
+        got = jxrs.ml_loglike_null_f32(s_, x_, y_, float(l10))
+        assert abs(got - val) < 1e-9 * abs(val), (l10, got, val)
+    lo2, hi2, it2, tol2, nullml = r["lmm2_gwas_args"]
+    l2 = jxrs.lmm_reml_lmm2_chunk_from_snp_f32(s_, x_, y_, lo2, hi2, r["snp"], r["lmm_Dh"], float(nullml), int(it2), tol2, 1, int(rot_rows))
+    ref2 = r["lmm2_gwas"]
+    be, se, pe = _assoc_err(l2[:, :3], ref2[:, :3], "lmm2")
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    ok = ~np.isnan(ref2[:, 0])
+    assert np.max(np.abs(l2[ok, 4] - ref2[ok, 4]) / np.maximum(1.0, np.abs(ref2[ok, 4]))) < 1e-6        # ml_alt
+    assert np.max(np.abs(np.log10(l2[ok, 3]) - np.log10(ref2[ok, 3]))) < 2e-2                              # lambda_reml: Brent tolerance
+
+
 def test_bed_to_tsv_routes(oracle, oracle_c, null_case, tmp_path):
     """`jx gwas -lmm/-fvlmm` kernel entry points: BED file -> QC -> scan -> TSV (rows in BED order)."""
     from janusx_amd import janusx as jxrs

@@ -488,3 +488,100 @@ def test_splmm_approx_route_restatement(oracle):
         beta, se = float(gr @ yr) / sms, math.sqrt(rss / (df * sms))
         assert abs(out[j, 0] - beta) < 2e-6 * max(abs(beta), se) and abs(out[j, 1] - se) < 1e-6 * se       # f32 dots
         assert abs(out[j, 2] - oracle.chi2_sf_df1((beta / se) ** 2)) < 1e-4 * out[j, 2] + 1e-300
+
+
+REFMODEL = os.path.join(os.path.dirname(__file__), "golden", "reference_model.npz")
+
+
+def test_reference_model_layer_pins_the_oracle_composition(oracle):
+    """Values the REFERENCE'S OWN model layer produced in the build container (tests/golden/gen_reference_model_fixtures.py:
+    python/janusx/pyBLUP/assoc.py `LMM.__init__` / `_initialize_from_spectral` :1702-1876, `LMM.gwas` :1962, `LMM2.gwas`,
+    `FastLMM.gwas`, `FvLMM.gwas / gwas_rotated` :2072-2180 and `janusx/assoc/api.py::ASSOC` run over a stub native module
+    that records its calls).  The oracle's own composition of the path -- the 1e-6 ridge before the eigendecomposition, the
+    design [1, X], `spectral_null_model` (lambda_0, ML0, LL0, sigma_g2, sigma_e2, trace mean, the diagonal-scaled PVE, the scan
+    bounds log10 lambda_0 +- 2 with the (-5, 5) fallback outside 0.05 <= PVE <= 0.95), the exact scan's bounds / 30 iterations /
+    tolerance 1e-2 without a null ML, the fixed-lambda scans at log10 lambda_0, FastLMM's switch -- must reproduce them."""
+    r = np.load(REFMODEL)
+    n = int(r["n"])
+    y, xe, k = r["y"], r["x_extra"], r["k"]
+    # the layer's eigendecomposition input: f64 copy of K with 1e-6 on the diagonal (assoc.py:1623-1628)
+    a = k.astype(np.float64)
+    a.flat[:: n + 1] += 1e-6
+    assert np.array_equal(a, r["eigh_input"])
+    s, u = oracle.gwas_eigh_from_grm(k, 1e-6)
+    assert np.max(np.abs(s - r["eigh_w"])) < 1e-12 * max(1.0, float(np.max(np.abs(s))))
+    x = np.concatenate([np.ones((n, 1)), xe], axis=1)
+    assert np.array_equal(x, r["rot_x_in"])
+    assert r["null_args"].tolist() == [-5.0, 5.0, 50.0, 1e-3]
+    for tag, yy in (("lmm", y), ("noise", r["y_noise"]), ("gen", r["y_gen"])):
+        nm = oracle.spectral_null_model(yy, x, r["eigh_w"], r["eigh_v"])
+        for mine, key in ((nm.lbd_null, "lbd_null"), (nm.ML0, "ML0"), (nm.LL0, "LL0"), (nm.sigma_g2, "sigma_g2"),
+                          (nm.sigma_e2, "sigma_e2"), (nm.pve, "pve"), (nm.trace_mean, "trace_mean")):
+            ref = float(r[f"{tag}_{key}"])
+            assert abs(mine - ref) <= 1e-12 * max(1.0, abs(ref)), (tag, key, mine, ref)
+        assert np.allclose(np.array(nm.bounds), r[f"{tag}_bounds"], rtol=0, atol=1e-12), (tag, nm.bounds)
+        assert np.array_equal(nm.Dh, r[f"{tag}_Dh"]) and np.array_equal(nm.Xcov, r[f"{tag}_Xcov"])
+        assert np.array_equal(nm.y, r[f"{tag}_yrot"]) and not bool(r[f"{tag}_lowrank"]) and int(r[f"{tag}_rank"]) == n
+    assert r["noise_bounds"].tolist() == [-5.0, 5.0] and float(r["noise_pve"]) < 0.05
+    assert r["gen_bounds"].tolist() == [-5.0, 5.0] and float(r["gen_pve"]) > 0.95
+    nm = oracle.spectral_null_model(y, x, r["eigh_w"], r["eigh_v"])
+    # LMM.gwas: what the layer hands the exact scan
+    lo, hi, it, tol, rot_rows = r["lmm_gwas_args"]
+    assert (lo, hi) == nm.bounds and it == 30 and tol == 1e-2 and rot_rows == r["snp"].shape[0] and bool(r["lmm_gwas_nullml_is_none"])
+    t = oracle.lmm_reml_chunk_from_snp(nm.S, nm.Xcov, nm.y, lo, hi, r["snp"], nm.Dh, 30, 1e-2)
+    assert np.array_equal(t, r["lmm_gwas"], equal_nan=True)
+    # the in-memory API ends in the same native calls with the same arguments
+    assert np.array_equal(r["api_lmm_table"], r["lmm_gwas"], equal_nan=True)
+    assert np.array_equal(r["api_fvlmm_table"], r["fvlmm_gwas"], equal_nan=True)
+    assert str(r["api_lmm_native_calls"]).split(";")[-1] == "lmm_reml_chunk_from_snp_f32"
+    assert str(r["api_fvlmm_native_calls"]).split(";")[-2:] == ["fvlmm_assoc_prepare_cache_f32", "fvlmm_assoc_chunk_from_snp_with_cache_f32"]
+    # FvLMM / FastLMM: log10 lambda_0, one cache per trait, raw and rotated entry points agree
+    assert abs(float(r["fvlmm_log10_lbd"]) - math.log10(nm.lbd_null)) < 1e-15
+    fv = oracle.fvlmm_assoc_chunk_from_snp(nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null), r["snp"], nm.Dh)
+    assert np.array_equal(fv, r["fvlmm_gwas"], equal_nan=True)
+    assert np.array_equal(oracle.rotate_block_f32(r["snp"], nm.Dh), r["grot"])
+    assert np.array_equal(r["fvlmm_gwas_rotated"], r["fvlmm_gwas"], equal_nan=True)
+    assert str(r["fastlmm_route"]) == "lmm_assoc_chunk_from_snp_f32"            # 0.05 <= PVE <= 0.95: the fixed-lambda kernel
+    fl = oracle.lmm_assoc_fixed_lambda_block(r["grot"], nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null))
+    assert np.array_equal(fl, r["fastlmm_gwas"], equal_nan=True)
+    # LMM2: the layer's null ML optimum (scipy bounded search over the native ML likelihood inside the scan bounds)
+    lo2, hi2, it2, tol2, nullml = r["lmm2_gwas_args"]
+    assert (lo2, hi2, it2, tol2) == (lo, hi, 30.0, 1e-2) and nullml == float(r["lmm2_ml0_exact"])
+    ev = r["lmm2_ml_evals"]
+    assert np.all((ev >= lo) & (ev <= hi))
+    best = max(oracle.ml_loglike(float(t_), nm.S, nm.Xcov, nm.y, None) for t_ in ev)
+    assert abs(best - nullml) < 1e-12 * abs(nullml)
+    assert abs(10.0 ** float(ev[-1]) - float(r["lmm2_lbd_null_ml"])) < 1e-12
+    l2 = oracle.lmm2_scan_rotated_block(r["grot"], nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2, nullml)
+    assert np.array_equal(l2, r["lmm2_gwas"], equal_nan=True)
+    # the oracle's own LMM2 null ML (Brent, the BED route src/stats/lmm.rs:2902-2921: a different optimiser, tolerance 1e-2 in
+    # log10 lambda) stops at the same boundary optimum within its tolerance
+    xm, ml0 = oracle.lmm2_null_ml(nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2)
+    assert abs(xm - math.log10(float(r["lmm2_lbd_null_ml"]))) < 5e-2 and nullml - 0.1 < ml0 <= nullml + 1e-9
+
+
+def test_stdrng_published_vectors(oracle):
+    """`StdRng` (rand 0.9: ChaCha12, `splmm_choose_rhat_rows` draws from it; src/stats/splmm.rs:1493-1507) against PUBLISHED
+    known answers: the all-zero key / nonce keystream blocks of ChaCha8 / 12 / 20 (Strombergson's ChaCha test vectors, TC1), rand's
+    own value-stability test of `StdRng` (rngs/std.rs `test_stdrng_construction`: seed bytes 1, 23, 200+256, 210+30*256 ->
+    next_u64 = 10719222850664546238, then an StdRng filled from that one -> 14064965282130556830: ChaCha12, word order, u64
+    assembly, `from_rng` filling the seed from consecutive words) and rand_chacha's `test_chacha_construction` (ChaCha20, seed words
+    0, 0, 1, 0, 2, 0, 3, 0 -> next_u32 = 137206642).  What stays restated without a vector: the PCG32 expansion of `seed_from_u64` and
+    the Canon range sampler of `random_range` (oracle header; README)."""
+    import struct
+    def hexblock(rounds):
+        return b"".join(struct.pack("<I", w) for w in oracle._chacha_block([0] * 8, 0, rounds)).hex()
+    assert hexblock(8).startswith("3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e")
+    assert hexblock(12).startswith("9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f")
+    assert hexblock(20).startswith("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7")
+
+    def rng_from_words(words):
+        g = oracle.StdRngU32.__new__(oracle.StdRngU32)
+        g.key, g.counter, g.buf = list(words), 0, []
+        return g
+    seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+    g0 = rng_from_words(struct.unpack("<8I", seed))
+    assert g0.next_u64() == 10719222850664546238
+    g1 = rng_from_words([g0.next_u32() for _ in range(8)])
+    assert g1.next_u64() == 14064965282130556830
+    assert oracle._chacha_block([0, 0, 1, 0, 2, 0, 3, 0], 0, 20)[0] == 137206642

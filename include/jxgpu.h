@@ -510,6 +510,16 @@ int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8
                     const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
                     double high, int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml,
                     double nullml, double *out);
+/* The same with the `model` / `genetic_model` argument of the reference's entry points (`PackedGeneticModel`,
+ * src/decode/decode.rs:100-147: 0 add, 1 dom (g > 0), 2 rec (g = 2), 3 het (g = 1) applied to the decode table
+ * [0 | 2, 2 maf, 1, 2 | 0] INCLUDING its imputed entry (:163-178), then the row is centred by its own mean (:181-189)).
+ * jx_assoc_packed is genetic_model = 0.  Non-additive rows are not affine in the allele count: they take the general
+ * (fp16 hi / lo) rotation. */
+int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                    const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                    const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
+                    double high, int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml,
+                    double nullml, double *out, int genetic_model);
 
 /* `lm_block_assoc_packed` (src/stats/glm.rs:3550-3860): the plain LM scan `jx gwas -lmm / -fvlmm` switches to when the null
  * likelihood-ratio test (jx_gwas_lmm_lm_null_lrt_decision) finds no polygenic variance

@@ -123,6 +123,8 @@ SIGNATURES = {
                                    c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
+    "jx_assoc_packed_gm": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
+                           c_d, c_i, c_d, c_p, c_i],
     "jxg_rotate_packed16x_fused": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i,
                                    c_p],
     "jxg_fvlmm_finish_dev": [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_d, c_i, c_i, c_d, c_d, c_i, c_p, c_p],

@@ -81,11 +81,21 @@ static void grm_lut_from_maf(float maf, bool flip, int method, float out[4]) {
     out[3] = (g2 - mean_g) * sc;
 }
 
-// scan design LUT: [0, mu, 1, 2] (or flipped) minus the actual row mean
+// `PackedGeneticModel::apply` (src/decode/decode.rs:132-160): 0 add, 1 dom, 2 rec, 3 het
+static inline float gm_apply(int gm, float gf) {
+    const double g = (double)gf;
+    switch (gm) {
+    case 1: return g > 0.0 ? 1.0f : 0.0f;
+    case 2: return fabs(g - 2.0) < 1e-6 ? 1.0f : 0.0f;
+    case 3: return fabs(g - 1.0) < 1e-6 ? 1.0f : 0.0f;
+    default: return gf;
+    }
+}
+// scan design LUT: the genetic model applied to [0, mu, 1, 2] (or flipped), minus the actual row mean
 // (src/decode/decode.rs:163-189, 218-221). counts = (missing, het, hom_alt) over the n selected samples.
-static void scan_lut_from_counts(float maf, bool flip, const int32_t *cnt, int n, float out[4]) {
-    const float mu = (float)fmax(2.0 * (double)maf, 0.0);
-    const float v0 = flip ? 2.0f : 0.0f, v2 = 1.0f, v3 = flip ? 0.0f : 2.0f;
+static void scan_lut_from_counts(float maf, bool flip, const int32_t *cnt, int n, float out[4], int gm = 0) {
+    const float mu = gm_apply(gm, (float)fmax(2.0 * (double)maf, 0.0));
+    const float v0 = gm_apply(gm, flip ? 2.0f : 0.0f), v2 = gm_apply(gm, 1.0f), v3 = gm_apply(gm, flip ? 0.0f : 2.0f);
     const double c00 = (double)(n - cnt[0] - cnt[1] - cnt[2]);
     const double sum = c00 * (double)v0 + (double)cnt[0] * (double)mu + (double)cnt[1] * (double)v2 +
                        (double)cnt[2] * (double)v3;
@@ -918,11 +928,25 @@ extern "C" int jx_fvlmm_assoc_chunk(const double *s, const double *xcov, const d
 // ---------------------------------------------------------------------------------------------------
 // lmm_reml_assoc_packed_f32 (src/stats/lmm.rs:3040-3362) / fixed-lambda sibling
 // ---------------------------------------------------------------------------------------------------
+extern "C" int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                                  const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                                  const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
+                                  double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
+                                  int has_nullml, double nullml, double *out, int genetic_model);
 extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
                                const float *row_maf, const double *s, const double *xcov, const double *y_rot,
                                const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
                                double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
                                int has_nullml, double nullml, double *out) {
+    return jx_assoc_packed_gm(packed, m, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, p, sample_indices, n_sel, model, low,
+                              high, max_iter, tol, warm, init_log10_lbd, has_nullml, nullml, out, 0);
+}
+extern "C" int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                                  const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                                  const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
+                                  double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
+                                  int has_nullml, double nullml, double *out, int genetic_model) {
+    if (genetic_model < 0 || genetic_model > 3) return fail("model must be one of: add, dom, rec, het");
     const int cols = model == 2 ? 6 : (has_nullml ? 4 : 3);
     if (model < 0 || model > 2) return fail("model must be 0 (lmm), 1 (fvlmm) or 2 (lmm2)");
     if (model == 2 && !(has_nullml && std::isfinite(nullml))) return fail("nullml must be finite");
@@ -941,7 +965,7 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     JX_HIP(hipMemcpy(cnt.data(), dcnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::vector<float> lut((size_t)m * 4);
     for (int64_t j = 0; j < m; ++j)
-        scan_lut_from_counts(row_maf[j], row_flip[j] != 0, &cnt[(size_t)j * 3], n, &lut[(size_t)j * 4]);
+        scan_lut_from_counts(row_maf[j], row_flip[j] != 0, &cnt[(size_t)j * 3], n, &lut[(size_t)j * 4], genetic_model);
 
     NullDev nd;
     if (nd.upload(s, xcov, y_rot, n, p)) return 1;
@@ -976,9 +1000,18 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     // rows with a few missing calls keep the exact rotation where the int8 kernel runs; their missing-call term is added behind
     // it (jxg_rotate_missing_correct), exactly as pipeline.scan_rows does
     DevBuf drowmiss, dusamp;
+    // mean missing calls per row over the rows that can pass a quality filter (<= n / 10 missing calls), as
+    // pipeline.Panel.mean_missing does: mostly-missing junk rows must not decide the path of the others
     double miss_sum = 0.0;
-    for (int64_t j = 0; j < m; ++j) miss_sum += (double)cnt[(size_t)j * 3];
-    const int miss_max = use_q ? jxg_rot_miss_max(n, m > 0 ? miss_sum / (double)m : 0.0) : 0;
+    int64_t miss_rows = 0;
+    for (int64_t j = 0; j < m; ++j) {
+        const double mi = (double)cnt[(size_t)j * 3];
+        if (mi <= (double)n / 10.0) {
+            miss_sum += mi;
+            ++miss_rows;
+        }
+    }
+    const int miss_max = use_q ? jxg_rot_miss_max(n, miss_rows > 0 ? miss_sum / (double)miss_rows : 0.0) : 0;
     bool any_rowmiss = false;
     if (miss_max > 0) {
         if (drowmiss.alloc(sizeof(float) * (size_t)m)) return 1;

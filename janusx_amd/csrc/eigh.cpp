@@ -403,15 +403,52 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             if (!replicas_agree && trace)
                 fprintf(stderr, "[jxgpu eigh n=%d] the ranks' tridiagonal matrices differ: every rank finishes its own replica\n", n);
         }
-        const bool shard_cols = twostage && dist_two && split && replicas_agree;
+        bool shard_cols = twostage && dist_two && split && replicas_agree;
         const int sh_r0 = (int)((int64_t)n * drank / dworld), sh_r1 = (int)((int64_t)n * (drank + 1) / dworld);
         static const bool dc_window = !(getenv("JXGPU_DIST_DC_WINDOW") && atoi(getenv("JXGPU_DIST_DC_WINDOW")) == 0);
-        const bool dc_windowed = shard_cols && dc_window && sh_r1 > sh_r0;
+        bool dc_windowed = shard_cols && dc_window && sh_r1 > sh_r0;
         g_last_dc_windowed = (dc_windowed && split) ? 1 : 0;
         if (split) {
+            // (d, e) as they enter the divide and conquer: kept on the host when the ranks are about to share columns out, so
+            // that a replica which fails the second comparison below can redo the stage without the window
+            std::vector<double> de_keep;
+            if (shard_cols && g_gather.agree) {
+                de_keep.resize((size_t)2 * n);
+                JX_HIP(hipMemcpyAsync(de_keep.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                JX_HIP(hipMemcpyAsync(de_keep.data() + n, e.p, sizeof(double) * (size_t)(n - 1), hipMemcpyDeviceToHost, st));
+                JX_HIP(hipStreamSynchronize(st));
+            }
             if (stedc_split(h, st, n, d_w, e.as<double>(), c.as<double>(), leaf, perm, dc_windowed ? sh_r0 : 0,
                             dc_windowed ? sh_r1 : 0))
                 return 1;
+            if (shard_cols && g_gather.agree) {
+                // SECOND comparison: the divide and conquer itself ran replicated, and from here on a rank
+                // forms only the columns whose eigenvalues rank inside ITS window -- if the replicas' results differed, the
+                // windows would overlap or leave gaps and the gathered matrix would be silently wrong.  Every rank holds all n
+                // eigenvalues in ascending order (the rank of an eigenvalue is what assigns its column to a window): they are
+                // hashed and compared; the window's own column list differs per rank by construction and is not part of it.
+                std::vector<double> hw2((size_t)n);
+                JX_HIP(hipMemcpyAsync(hw2.data(), d_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+                JX_HIP(hipStreamSynchronize(st));
+                uint64_t cs2 = fnv1a(hw2.data(), sizeof(double) * hw2.size(), 1469598103934665603ull ^ (uint64_t)n);
+                static const int test_rank2 = getenv("JXGPU_DIST_EIGH_TEST_DISAGREE2") ? atoi(getenv("JXGPU_DIST_EIGH_TEST_DISAGREE2")) : -1;
+                if (test_rank2 == drank) cs2 ^= 2;       // test hook: this rank pretends its divide and conquer differed
+                const int ag2 = g_gather.agree(g_gather.agree_user, cs2);
+                if (ag2 < 0) return fail("jxg_eigh_f64: the agreement callback failed");
+                if (ag2 == 0) {
+                    if (trace)
+                        fprintf(stderr, "[jxgpu eigh n=%d] the ranks' divide-and-conquer results differ: every rank finishes its own replica\n", n);
+                    g_last_dist_agree = 0;
+                    shard_cols = false;
+                    if (dc_windowed) {                   // only a window of the columns exists: redo the stage for all of them
+                        dc_windowed = false;
+                        g_last_dc_windowed = 0;
+                        JX_HIP(hipMemcpyAsync(d_w, de_keep.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+                        JX_HIP(hipMemcpyAsync(e.p, de_keep.data() + n, sizeof(double) * (size_t)(n - 1), hipMemcpyHostToDevice, st));
+                        if (stedc_split(h, st, n, d_w, e.as<double>(), c.as<double>(), leaf, perm, 0, 0)) return 1;
+                    }
+                }
+            }
         } else {
             rs = rocsolver_dstedc(h, rocblas_evect_tridiagonal, n, d_w, e.as<double>(), c.as<double>(), n,
                                   info.as<rocblas_int>());

@@ -1439,12 +1439,15 @@ static bool series_ok(int p, double low, double high) {
     return on && p >= 1 && p <= 14 && series_header(low, high).nseg * CH_N <= SR_M;
 }
 static int64_t series_npad(int n) { return ((int64_t)n + SR_SC - 1) / SR_SC * SR_SC; }
+// the y_c segment of the table workspace, rounded up to an even number of doubles: everything behind it (the coefficient
+// tables, What) stays 16-byte aligned for odd n too -- series_coef_kernel reads What with dwordx4 loads
+static int64_t yc_doubles(int n) { return ((int64_t)n + 1) & ~(int64_t)1; }
 
 extern "C" int64_t jxg_lmm_tables_bytes(int n, int p, double low, double high) {
     if (!fast_path_ok(p, low, high)) return 0;
     const ChebHeader hd = make_header(p, low, high);
     const int64_t what = series_ok(p, low, high) ? series_npad(n) * SR_M : 0;     // What[i][m] behind the lambda-only tables
-    return (int64_t)sizeof(double) * (CH_HDR + (int64_t)n + 2 * (int64_t)hd.nseg * hd.nf * CH_N + what);
+    return (int64_t)sizeof(double) * (CH_HDR + yc_doubles(n) + 2 * (int64_t)hd.nseg * hd.nf * CH_N + what);
 }
 
 extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, const double *d_y, int n, int p,
@@ -1456,7 +1459,7 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
     const ChebHeader hd = make_header(p, low, high);
     const int total_funcs = hd.nseg * hd.nf;
     double *w = (double *)d_work;
-    double *smin = w, *yc = w + CH_HDR, *coef = yc + n, *vals = coef + (int64_t)total_funcs * CH_N;
+    double *smin = w, *yc = w + CH_HDR, *coef = yc + yc_doubles(n), *vals = coef + (int64_t)total_funcs * CH_N;
     const double lbd_mid = pow(10.0, 0.5 * (low + high));
     JX_DISPATCH_DIM_F(p, hipLaunchKernelGGL(yshift_kernel<MAXD>, dim3(1), dim3(SCAN_THREADS), 0, st, d_s, d_xcov, d_y,
                                             n, p, lbd_mid, yc, smin));
@@ -1487,7 +1490,7 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
     if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_scan_tab: configuration needs the exact scan path");
     const ChebHeader hd = make_header(p, low, high);
     const double *w = (const double *)d_work;
-    const double *smin = w, *yc = w + CH_HDR, *coef = yc + n;
+    const double *smin = w, *yc = w + CH_HDR, *coef = yc + yc_doubles(n);
     const int dim = p + 1;
     // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
     const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
@@ -1536,15 +1539,17 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         hipStream_t st = (hipStream_t)stream;
         const int nq = p + 2;
         const ChebHeader shd = series_header(low, high);
-        static std::mutex mu;
-        static DevBuf sbuf;                                  // series + sums of squares of one call (grown on demand)
-        std::lock_guard<std::mutex> lk(mu);
+        // series + sums of squares of THIS call: stream-ordered allocation, released behind the Brent kernel on the same stream
+        // (a process-wide buffer would be shared by concurrent calls on other streams while their kernels are in flight: ADVICE r4)
         const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
-        if (sbuf.bytes < need) {
-            JX_HIP(hipStreamSynchronize(st));
-            if (sbuf.alloc(need + need / 4)) return 1;
-        }
-        double *scoef = sbuf.as<double>(), *sssq = scoef + (size_t)nrows * nq * SR_M;
+        void *sraw = nullptr;
+        JX_HIP(hipMallocAsync(&sraw, need, st));
+        struct SeriesFree {
+            void *p;
+            hipStream_t s;
+            ~SeriesFree() { (void)hipFreeAsync(p, s); }
+        } sfree{sraw, st};
+        double *scoef = (double *)sraw, *sssq = scoef + (size_t)nrows * nq * SR_M;
         const double *what = coef + 2 * (int64_t)hd.nseg * hd.nf * CH_N;
         const int npad = (int)series_npad(n);
         const size_t lds = sizeof(double) * ((size_t)SR_SC * SR_WP + (size_t)(p + 1) * SR_SC) + sizeof(float) * 128 * SR_GP;

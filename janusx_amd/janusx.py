@@ -696,19 +696,51 @@ def _pack_components_into_blocks(lab, bsz):
     return perm, offs
 
 
-def _check_spectral_sparse_size(n):
-    """The single-eigenproblem form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors
-    and the eigensolver's workspace (~5 n^2 doubles) in HBM (the block-diagonal form, `_sparse_block_route`, does not).
-    Refuse clearly instead of failing inside hipMalloc."""
+def _hbm_free_agreed():
+    """Free HBM in bytes; under a multi-rank run the MINIMUM over the ranks, so that a size check decides the same way on every
+    rank (a rank that raised alone would leave the others waiting in their next collective)."""
     import torch
-    need = 5 * int(n) * int(n) * 8
-    if torch.cuda.is_available():
-        free, _total = torch.cuda.mem_get_info()
-        if need > free:
-            raise RuntimeError(
-                f"sparse-GRM spectral route: n = {n} needs about {need / 2**30:.0f} GiB of HBM for the dense image of K and "
-                f"its eigenvectors, {free / 2**30:.0f} GiB are free; use the block-diagonal form (JXGPU_SPLMM_ROUTE=block, the "
-                "default from n = 16384) or restrict the samples")
+    free, _total = torch.cuda.mem_get_info()
+    try:
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            t = torch.tensor([float(free)], dtype=torch.float64)
+            if tdist.get_backend() == "nccl":
+                t = t.to(torch.device("cuda", torch.cuda.current_device()))
+            tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+            free = int(t.item())
+    except Exception:   # noqa: BLE001 - no usable process group: the local figure
+        pass
+    return int(free)
+
+
+def sparse_component_limit(free_bytes=None):
+    """Largest connected component (samples) of a thresholded GRM the spectral SparseLMM / sparse-REML routes take: one dense
+    eigenproblem per component on ONE GPU -- the f64 image of the component, its eigenvectors and the eigensolver's workspace,
+    about 5 n^2 doubles -- so n <= sqrt(free HBM / 40 B): ~ 79 000 samples on an empty MI355X (288 GB; BASELINE configs[3] runs
+    n = 50 000 in 16 s).  The reference factorises K + lambda I sparsely for any structure (src/math/cholesky.rs:776-1075,
+    src/stats/spreml.rs:384-760); beyond this limit the routes here refuse with the size and the limit in the message.
+    JXGPU_SPLMM_COMPONENT_MAX overrides (tests)."""
+    import math
+    v = os.environ.get("JXGPU_SPLMM_COMPONENT_MAX", "").strip()
+    if v:
+        return max(int(v), 1)
+    free = _hbm_free_agreed() if free_bytes is None else int(free_bytes)
+    return int(math.isqrt(max(free, 0) // 40))
+
+
+def _check_spectral_sparse_size(n, what="the selected samples"):
+    """The single-eigenproblem form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors
+    and the eigensolver's workspace (~5 n^2 doubles) in HBM.  Refuse clearly -- on every rank alike -- instead of failing
+    inside hipMalloc."""
+    limit = sparse_component_limit()
+    if int(n) > limit:
+        raise RuntimeError(
+            f"sparse-GRM spectral route: {what} form one dense eigenproblem of {int(n)} samples; the limit on this GPU is "
+            f"{limit} samples (about 5 n^2 doubles of HBM: the f64 image of K, its eigenvectors and the eigensolver's workspace). "
+            "Raise the GRM cut-off so that the relatedness graph falls apart into smaller components, or restrict the samples; "
+            "the reference's sparse factorisation of K + lambda I for arbitrary structure (src/math/cholesky.rs) is not "
+            "rebuilt here")
 
 
 # One-entry cache of the spectral form of a sparse GRM (eigenvalues + eigenvectors of the dense image or of its diagonal
@@ -855,10 +887,10 @@ class _SpectralSparseReml:
         ncomp, lab = connected_components(graph, directed=False)
         sizes = np.bincount(lab, minlength=ncomp)
         bsz = _sparse_block_size()
-        free, _tot = torch.cuda.mem_get_info()
-        if int(sizes.max()) > bsz and 5 * int(sizes.max()) ** 2 * 8 > free:
-            raise RuntimeError(f"sparse-GRM block route: a connected component of {int(sizes.max())} samples does not fit one "
-                               "dense block in HBM (raise the GRM cutoff or restrict the samples)")
+        # a component beyond the block size is a block of its own, up to what one GPU's eigensolver holds (the same decision on
+        # every rank: `sparse_component_limit` agrees the free HBM over the ranks)
+        if int(sizes.max()) > bsz:
+            _check_spectral_sparse_size(int(sizes.max()), what="the samples of the largest connected component of the sparse GRM")
         perm, offs = _pack_components_into_blocks(lab, bsz)
         fill = np.diff(offs)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -2099,7 +2131,10 @@ def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_i
 
 
 def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
-                  low, high, max_iter, tol, warm, init, nullml=None, progress_callback=None, progress_every=0):
+                  low, high, max_iter, tol, warm, init, nullml=None, progress_callback=None, progress_every=0,
+                  genetic_model="add"):
+    from .stats import genetic_model_code
+    gm = genetic_model_code(genetic_model)          # `PackedGeneticModel::parse` (src/decode/decode.rs:107-119)
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
     if row_indices is not None:
         ri = np.asarray(row_indices, dtype=np.int64)
@@ -2120,10 +2155,10 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
     out = np.zeros((m, 6 if int(model) == 2 else (4 if nullml is not None else 3)), dtype=np.float64)
     with _progress_hook(progress_callback, progress_every):
-        check(lib().jx_assoc_packed(pk_ptr, m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
-                                    _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
-                                    int(warm), float(init), 1 if nullml is not None else 0,
-                                    float(nullml if nullml is not None else 0.0), _p(out)))
+        check(lib().jx_assoc_packed_gm(pk_ptr, m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
+                                       _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
+                                       int(warm), float(init), 1 if nullml is not None else 0,
+                                       float(nullml if nullml is not None else 0.0), _p(out), gm))
     return out
 
 
@@ -2137,8 +2172,6 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     (lmm.rs:134-140), which makes its output depend on thread scheduling.  This implementation is
     deterministic: every SNP starts from `init_log10_lbd` when given (the head of the reference's chain),
     else from the interval midpoint (the reference's `JX_LMM_UNIFIED_NO_WARM_START` / core-API behaviour)."""
-    if str(model) != "add":
-        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
     if low >= high:
         raise RuntimeError("low must be < high")
     if not (np.isfinite(tol) and tol > 0):
@@ -2147,7 +2180,8 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
         warm, init = 1, float(min(max(init_log10_lbd, low), high))
     return _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
-                         low, high, max_iter, tol, warm, init, nullml, progress_callback, progress_every)
+                         low, high, max_iter, tol, warm, init, nullml, progress_callback, progress_every,
+                         genetic_model=model)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -2322,8 +2356,7 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
     from . import stats as st
     from .bed import read_fam_ids, snps_only_mask, stage_bed_payload
     from .tsv import write_assoc_tsv
-    if str(genetic_model) != "add":
-        raise RuntimeError(f"unsupported genetic model '{genetic_model}' (only 'add' is built)")
+    st.genetic_model_code(genetic_model)             # add / dom / rec / het (src/decode/decode.rs:100-147); anything else raises
     if nullml is not None and not np.isfinite(nullml):
         raise RuntimeError("nullml must be finite when provided")
     s_, xcov_, y_, n, p = _null_args(s, xcov, y_rot)
@@ -2370,16 +2403,16 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init,
-                            nullml, progress_callback, progress_every)
+                            nullml, progress_callback, progress_every, genetic_model=genetic_model)
     elif mode == "lmm2":
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 2, low, high, max_iter, tol, warm, init,
-                            nullml, progress_callback, progress_every)
+                            nullml, progress_callback, progress_every, genetic_model=genetic_model)
     else:
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 1, float(low), float(low) + 1.0, 0,
-                            1e-2, 0, 0.0, nullml, progress_callback, progress_every)
+                            1e-2, 0, 0.0, nullml, progress_callback, progress_every, genetic_model=genetic_model)
     chrom = [bim.chrom[j] for j in rows]
     posv = [bim.pos[j] for j in rows]
     snp = [bim.snp[j] for j in rows]
@@ -2522,8 +2555,8 @@ def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_miss
         raise RuntimeError("tau must be finite and >= 0")
     if int(n_samples) <= 0:
         raise RuntimeError("n_samples must be > 0")
-    if str(model) != "add":
-        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
+    from .stats import genetic_model_code
+    genetic_model_code(model)                        # add / dom / rec / het (src/decode/decode.rs:100-147); anything else raises
     packed = _c(packed, np.uint8)
     if packed.ndim != 2:
         raise RuntimeError("packed must be 2D (m, bytes_per_snp)")
@@ -2597,7 +2630,7 @@ def fvlmm_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_miss
     out = _assoc_packed(packed, n_samples, row_flip, row_maf, s_vec, x_rot, y_rot, u_t,
                         None if sample_indices is None else sidx, row_indices, 1, math.log10(lbd),
                         math.log10(lbd) + 1.0, 0, 1e-2, 0, 0.0, float(fixed_ml0) if with_plrt else None,
-                        progress_callback, progress_every)
+                        progress_callback, progress_every, genetic_model=model)
     if not len(chrom):
         if not bed_prefix:
             raise RuntimeError("metadata lists are empty and bed_prefix is not set")

@@ -82,13 +82,30 @@ class Panel:
                                    _ptr(self.p32), _stream()))
         self._counts = None
         self._mean_missing = None
+        self.sharded = False            # True: this payload is one rank's SNP shard of a larger panel (`payload_sharded`)
 
     def mean_missing(self) -> float:
-        """Mean number of missing calls per row over ALL rows of the payload (cached): the call-independent statistic behind
-        the choice of the rotation path for rows with a few missing calls (`jxg_rot_miss_max`)."""
+        """Mean number of missing calls per row over the rows of the payload that CAN pass a quality filter (at most n / 10
+        missing calls: a few percent of mostly-missing junk rows must not push every kept row into the dense missing-call form;
+        ADVICE r4), cached: the call-independent statistic behind the choice of the rotation path for rows with a few missing
+        calls (`jxg_rot_miss_max`; api.cpp applies the same rule to the rows it is handed).  Under a distributed run the sum and
+        the row count are added over the ranks, so that every rank of a payload-sharded scan decides from the same number (with
+        a replicated payload every rank already holds the same rows)."""
         if self._mean_missing is None:
             c = self.counts()
-            self._mean_missing = float(np.mean(c[:, 0])) if len(c) else 0.0
+            mi = c[:, 0].astype(np.float64) if len(c) else np.zeros(0)
+            ok = mi <= self.n / 10.0
+            tot = np.array([float(mi[ok].sum()), float(np.count_nonzero(ok))], dtype=np.float64)
+            if self.sharded:
+                from . import dist as jd
+                rank, world = dist_info()
+                if world > 1:
+                    t = torch.from_numpy(tot)
+                    if torch.distributed.get_backend() == "nccl":
+                        t = t.to(self.device)
+                    jd.allreduce_sum_(t)
+                    tot = t.cpu().numpy()
+            self._mean_missing = float(tot[0] / tot[1]) if tot[1] > 0 else 0.0
         return self._mean_missing
 
     def counts(self) -> np.ndarray:
@@ -876,6 +893,7 @@ def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.0
     scalar denominators follows, and every rank finalises the same K."""
     if panel is None:
         panel = Panel(packed, n_samples)
+    panel.sharded = bool(payload_sharded)
     counts = panel.counts()
     n = panel.n
     gkeep, mean_g, scale, flip, var = st.stream_grm_row_prepare(counts, n, method, maf, geno, 0.0)
@@ -924,6 +942,7 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     model = SpectralModel(s, ut64, x, y)
     del ut64
     panel = Panel(packed, n_samples, keep_idx)
+    panel.sharded = bool(payload_sharded)
     counts = panel.counts()
     n = panel.n
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)

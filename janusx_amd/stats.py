@@ -135,22 +135,49 @@ def grm_lut_from_maf(row_maf, row_flip, method: int):
     return grm_lut_from_mean_scale(mean_g, scale, row_flip)
 
 
-def scan_lut_from_counts(row_maf, row_flip, counts, n: int):
-    """(m,4) f32 scan design LUT: [0, mu, 1, 2] (or flipped), minus the actual row mean
-    (f64 sum / n -> f32; the sum of f32 values {0,1,2,mu} is exact in f64, so counts reproduce it)."""
+GENETIC_MODELS = ("add", "dom", "rec", "het")
+
+
+def genetic_model_code(model) -> int:
+    """`PackedGeneticModel::parse` (src/decode/decode.rs:107-119): case-insensitive add / dom / rec / het -> 0 .. 3."""
+    m = str(model).lower()
+    if m not in GENETIC_MODELS:
+        raise RuntimeError("model must be one of: add, dom, rec, het")
+    return GENETIC_MODELS.index(m)
+
+
+def _apply_genetic_model(code: int, g):
+    """`PackedGeneticModel::apply` (decode.rs:132-160) on f32 table values (evaluated in f64 like the reference)."""
+    g = np.asarray(g, dtype=np.float32)
+    g64 = g.astype(np.float64)
+    if code == 1:
+        return (g64 > 0.0).astype(np.float32)
+    if code == 2:
+        return (np.abs(g64 - 2.0) < 1e-6).astype(np.float32)
+    if code == 3:
+        return (np.abs(g64 - 1.0) < 1e-6).astype(np.float32)
+    return g
+
+
+def scan_lut_from_counts(row_maf, row_flip, counts, n: int, model="add"):
+    """(m,4) f32 scan design LUT: the genetic model applied to [0, mu, 1, 2] (or flipped; the imputed entry mu = 2 maf
+    included, src/decode/decode.rs:163-178), minus the actual row mean (f64 sum / n -> f32; the sum of the f32 table
+    values is exact in f64, so counts reproduce it)."""
+    code = genetic_model_code(model)
     maf = np.asarray(row_maf, dtype=np.float32)
     flip = np.asarray(row_flip, dtype=bool)
     counts = np.asarray(counts, dtype=np.int64)
-    mu = np.maximum(2.0 * maf.astype(np.float64), 0.0).astype(np.float32)
-    v0 = np.where(flip, F32(2.0), F32(0.0)).astype(np.float32)
-    v3 = np.where(flip, F32(0.0), F32(2.0)).astype(np.float32)
+    mu = _apply_genetic_model(code, np.maximum(2.0 * maf.astype(np.float64), 0.0).astype(np.float32))
+    v0 = _apply_genetic_model(code, np.where(flip, F32(2.0), F32(0.0)).astype(np.float32))
+    v2 = _apply_genetic_model(code, np.full(len(maf), 1.0, dtype=np.float32))
+    v3 = _apply_genetic_model(code, np.where(flip, F32(0.0), F32(2.0)).astype(np.float32))
     c00 = (n - counts[:, 0] - counts[:, 1] - counts[:, 2]).astype(np.float64)
-    total = (c00 * v0.astype(np.float64) + counts[:, 0] * mu.astype(np.float64) + counts[:, 1] * 1.0 +
+    total = (c00 * v0.astype(np.float64) + counts[:, 0] * mu.astype(np.float64) + counts[:, 1] * v2.astype(np.float64) +
              counts[:, 2] * v3.astype(np.float64))
     mean = (total / float(n)).astype(np.float32)
     lut = np.empty((len(maf), 4), dtype=np.float32)
     lut[:, 0] = v0 - mean
     lut[:, 1] = mu - mean
-    lut[:, 2] = F32(1.0) - mean
+    lut[:, 2] = v2 - mean
     lut[:, 3] = v3 - mean
     return lut

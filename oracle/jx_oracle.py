@@ -1366,17 +1366,32 @@ def spectral_null_model(y, X, S, U) -> NullModel:
 # D  scan design decode + rotation + exact per-SNP scan
 # --------------------------------------------------------------------------------------------
 
-def scan_value_lut_f32(row_maf_f32, flip: bool):
-    """[0, mu, 1, 2] (or flipped) with mu = f32(max(2*f64(maf), 0)) (src/decode/decode.rs:163-178, 218)."""
+def genetic_model_apply(model: str, g: float) -> float:
+    """`PackedGeneticModel::parse` + `apply` (src/decode/decode.rs:107-160): add g; dom 1 if g > 0; rec 1 if |g - 2| < 1e-6;
+    het 1 if |g - 1| < 1e-6; else 0."""
+    m = str(model).lower()
+    if m == "add":
+        return g
+    if m == "dom":
+        return 1.0 if g > 0.0 else 0.0
+    if m == "rec":
+        return 1.0 if abs(g - 2.0) < 1e-6 else 0.0
+    if m == "het":
+        return 1.0 if abs(g - 1.0) < 1e-6 else 0.0
+    raise RuntimeError("model must be one of: add, dom, rec, het")
+
+
+def scan_value_lut_f32(row_maf_f32, flip: bool, model: str = "add"):
+    """The genetic model applied to [0, mu, 1, 2] (or flipped) with mu = f32(max(2*f64(maf), 0)) -- the imputed entry
+    included (`packed_model_value_lut_f32`, src/decode/decode.rs:163-178, 218)."""
     mu = F32(max(2.0 * float(F32(row_maf_f32)), 0.0))
-    if flip:
-        return np.array([2.0, mu, 1.0, 0.0], dtype=np.float32)
-    return np.array([0.0, mu, 1.0, 2.0], dtype=np.float32)
+    raw = [2.0, float(mu), 1.0, 0.0] if flip else [0.0, float(mu), 1.0, 2.0]
+    return np.array([F32(genetic_model_apply(model, float(F32(v)))) for v in raw], dtype=np.float32)
 
 
-def decode_centered_block_f32(packed, n_samples, row_flip, row_maf, sample_idx=None, rows=None):
+def decode_centered_block_f32(packed, n_samples, row_flip, row_maf, sample_idx=None, rows=None, model: str = "add"):
     """`decode_centered_block_packed_f32` (src/decode/decode.rs:192-271): mean-impute from the passed
-    maf, then subtract the *actual* row mean (f64 sum -> f32, decode.rs:181-189)."""
+    maf, apply the genetic model to the table, then subtract the *actual* row mean (f64 sum -> f32, decode.rs:181-189)."""
     if rows is None:
         rows = np.arange(packed.shape[0])
     codes = unpack_codes(packed[rows], n_samples)
@@ -1384,7 +1399,7 @@ def decode_centered_block_f32(packed, n_samples, row_flip, row_maf, sample_idx=N
         codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
     out = np.empty(codes.shape, dtype=np.float32)
     for k, j in enumerate(rows):
-        lut = scan_value_lut_f32(row_maf[j], bool(row_flip[j]))
+        lut = scan_value_lut_f32(row_maf[j], bool(row_flip[j]), model)
         g = lut[codes[k]]
         mean = F32(np.sum(g.astype(np.float64)) / float(g.shape[0]))
         out[k] = g - mean

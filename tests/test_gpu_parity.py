@@ -455,6 +455,52 @@ def test_rotate_dense_and_scan(oracle, oracle_c, null_case):
     assert max(be, se, pe) < TOL, (be, se, pe)
 
 
+@pytest.mark.parametrize("gm", ["dom", "rec", "het", "ADD"])
+def test_assoc_packed_genetic_models(oracle, oracle_c, null_case, gm, tmp_path):
+    """`model=` / `genetic_model=` of the packed and BED entry points (`PackedGeneticModel`, src/decode/decode.rs:100-178: dom / rec /
+    het applied to the decode table including its imputed entry, then the row centred by its own mean; parsed case-insensitively;
+    src/stats/lmm.rs:3040, 2488): exact scan, fixed-lambda scan and the BED -> TSV route against the oracle's decode with the same
+    model.  Rows that the model makes constant (e.g. `rec` of a SNP without a homozygous-alt call) have zero variance after
+    centring and must come back as the reference's invalid rows (NaN, NaN, 1)."""
+    from janusx_amd import janusx as jxrs
+    n, m, packed, g, y, x, nm = null_case
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    pk = np.ascontiguousarray(packed[keep])
+    maf_k = maf[keep]
+    flip_k = np.random.default_rng(9).random(keep.sum()) < 0.25
+    gd = oracle.decode_centered_block_f32(pk, n, flip_k, maf_k, model=gm)
+    if gm.lower() != "add":
+        assert not np.array_equal(gd, oracle.decode_centered_block_f32(pk, n, flip_k, maf_k))
+    grot = oracle.rotate_block_f32(gd, nm.Dh)
+    ref = oracle_c.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, -5.0, 5.0, 50, 1e-2)
+    out = jxrs.lmm_reml_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, model=gm)
+    be, se, pe = _assoc_err(out, ref, gm)
+    assert max(be, se, pe) < TOL, (gm, be, se, pe)
+    fref = oracle.fvlmm_assoc_rotated_block(grot, oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
+    prefix = str(tmp_path / "gm")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    tsv = str(tmp_path / "gm.tsv")
+    rows = jxrs.fvlmm_assoc_bed_to_tsv_f32(prefix, tsv, nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null), nm.Dh, 0.02, 0.05, 1.0,
+                                           genetic_model=gm)
+    kept = np.nonzero(keep)[0]
+    assert rows == len(kept)
+    # the BED route decodes with flip = False for every row (QC from the file): its own oracle table
+    gd0 = oracle.decode_centered_block_f32(packed, n, np.zeros(m, bool), maf, rows=kept, model=gm)
+    fref0 = oracle.fvlmm_assoc_rotated_block(oracle.rotate_block_f32(gd0, nm.Dh),
+                                             oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
+    lines = open(tsv).read().splitlines()[1:]
+    got = np.array([[float(f) if f != "NaN" else np.nan for f in (ln.split("\t")[7], ln.split("\t")[8], ln.split("\t")[10])]
+                    for ln in lines])
+    okr = ~np.isnan(fref0[:, 0])
+    assert np.array_equal(np.isnan(got[:, 0]), ~okr)
+    assert np.max(np.abs(got[okr, 0] - fref0[okr, 0])) < 1.01e-4 and np.max(np.abs(got[okr, 1] - fref0[okr, 1])) < 1.01e-4
+    with pytest.raises(RuntimeError, match="model must be one of: add, dom, rec, het"):
+        jxrs.lmm_reml_assoc_packed_f32(pk, n, flip_k, maf_k, nm.S, nm.Xcov, nm.y, nm.Dh, model="overdominant")
+    del fref
+
+
 def test_assoc_packed(oracle, oracle_c, null_case):
     """packed route: decode (mean-impute, re-centre) + fp16x2 MFMA rotation + scan, with a sample subset."""
     from janusx_amd import janusx as jxrs
@@ -2201,6 +2247,12 @@ def test_distributed_eigh_two_ranks_share_one_gpu():
     out = subprocess.run(cmd, env=env3, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
     assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "agree=0" in out.stdout
+    # ... and a rank whose DIVIDE AND CONQUER result differs although the tridiagonal matrices agreed (second comparison, behind
+    # the stage: ADVICE r4): the windowed merge is redone for all columns and every rank finishes its own replica
+    env3b = dict(env2, JXGPU_DIST_EIGH_TEST_DISAGREE2="1")
+    out = subprocess.run(cmd, env=env3b, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    assert "DIST_EIGH_OK n=2300 world=2" in out.stdout and "agree=0" in out.stdout and "dc_windowed=0" in out.stdout
     # the band reduction with the trailing matrix SHARDED over the two ranks (k_sy2sb.hip BandDist; the default from n = 8192):
     # block rows of 256 samples dealt cyclically, per panel the all-reduce of the partial products Z = A22 V and the gather of
     # the next panel's block column, the last panels replicated after one gather of the trailing square; the ranks' results
@@ -2575,6 +2627,67 @@ def test_splmm_exact_scan_from_jxgrm(oracle, tmp_path, subset, cov):
     got2, l2, null2 = jxrs.splmm_exact_scan_from_jxgrm(path, ys, packed, n, maf_all, flip, xc, sub, rows, log10_lambda=l10)
     assert null2 is None and l2 == l10 and np.array_equal(np.isnan(got2), np.isnan(got))
     assert np.allclose(got2[ok], got[ok], rtol=1e-4, atol=1e-7)    # a second eigendecomposition: atomics reorder the sums
+
+
+def _chained_relatives_panel(n, m, seed):
+    """Every sample copies each SNP of its predecessor with probability 0.6: neighbours are related far above any cut-off, so
+    the thresholded GRM is ONE connected component (a chain through all n samples) whatever the block size."""
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(0.1, 0.45, size=m)
+    g = np.empty((m, n), dtype=np.int8)
+    g[:, 0] = rng.binomial(2, p)
+    for i in range(1, n):
+        fresh = rng.binomial(2, p).astype(np.int8)
+        g[:, i] = np.where(rng.random(m) < 0.6, g[:, i - 1], fresh)
+    return bed.pack_dosage(g), g
+
+
+def test_splmm_giant_component_both_sides_of_the_limit(oracle, tmp_path, monkeypatch):
+    """A sparse GRM whose relatedness graph is ONE giant connected component (chained relatives; the reference's own
+    `mouse_hs1940` at cut-off 0.05 is of this kind).  The reference factorises K + lambda I sparsely for any structure
+    (src/math/cholesky.rs:776-1075, src/stats/spreml.rs:384-760); here a component is one dense eigenproblem on the GPU up to
+    `sparse_component_limit()` samples (~ 79 000 on an empty MI355X).  Below the limit the block route must take the component
+    through the dense spectral form AUTOMATICALLY (one block of n samples although the block size is 128) and agree with the
+    oracle's dense-Cholesky restatement; above it the route fails with the size and the limit in the message."""
+    from janusx_amd import janusx as jxrs
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "block")
+    monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "128")
+    n, m = 700, 2400
+    packed, g = _chained_relatives_panel(n, m, 5)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, _, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.02, 0.05, 0.0)
+    pk = np.ascontiguousarray(packed[keep])
+    maf_k = af[keep]
+    flip = np.zeros(int(keep.sum()), bool)
+    path, _, nnz = jxrs.spgrm_packed_to_jxgrm(pk, n, flip, maf_k, str(tmp_path / "k"), None, 1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    low = sp.csc_matrix((va, ri.astype(np.int64), cp.astype(np.int64)), shape=(n, n))
+    ncomp, _lab = connected_components(low + low.T, directed=False)
+    assert ncomp == 1 and nnz >= 2 * n - 1                                 # one chain through every sample
+    assert 10000 < jxrs.sparse_component_limit() < 120000                  # what one MI355X holds: ~ 79 000 when empty
+    rng = np.random.default_rng(8)
+    gv = g[keep].astype(np.float64)
+    y = gv[50] * 0.6 + gv[300:330].T @ rng.normal(0, 0.2, 30) + rng.normal(0, 1.0, n)
+    rows = np.arange(0, int(keep.sum()), 3, dtype=np.int64)
+    jxrs.spectral_cache_clear()
+    got, l10, null = jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip, None, None, rows)
+    ref_null = oracle.spreml_sparse_reml_brent(nn, cp, ri, va, y, None, None)
+    assert abs(l10 - ref_null[5]) < 1e-6 and abs(null[4] - ref_null[4]) < 1e-8 * max(1.0, abs(ref_null[4]))
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, None)
+    ref = oracle.splmm_exact_scan(kd, 10.0 ** l10, oracle.spreml_design_matrix(None, n), y, pk, n, maf_k, flip, None, rows)
+    be, se, pe = _assoc_err(got, ref)
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    # the other side of the threshold: the same panel with the limit below the component's size
+    jxrs.spectral_cache_clear()
+    monkeypatch.setenv("JXGPU_SPLMM_COMPONENT_MAX", "512")
+    with pytest.raises(RuntimeError, match=r"700 samples; the limit on this GPU is 512 samples"):
+        jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip, None, None, rows)
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "dense")
+    with pytest.raises(RuntimeError, match=r"700 samples; the limit on this GPU is 512 samples"):
+        jxrs.spreml_sparse_reml_brent_from_jxgrm(path, y)
+    jxrs.spectral_cache_clear()
 
 
 @pytest.mark.gpu

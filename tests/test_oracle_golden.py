@@ -585,3 +585,40 @@ def test_stdrng_published_vectors(oracle):
     g1 = rng_from_words([g0.next_u32() for _ in range(8)])
     assert g1.next_u64() == 14064965282130556830
     assert oracle._chacha_block([0, 0, 1, 0, 2, 0, 3, 0], 0, 20)[0] == 137206642
+
+
+def test_genetic_model_tables(oracle):
+    """`PackedGeneticModel` (src/decode/decode.rs:100-178): the model is applied to the decode table [0 | 2, 2 maf, 1, 2 | 0] -- the
+    imputed entry included -- before the row is centred; parse is case-insensitive and refuses anything else.  The host-side
+    table of the product (stats.scan_lut_from_counts: model, then the row mean from the genotype counts) must reproduce the
+    oracle's decoded rows bit for bit."""
+    from janusx_amd import stats
+    f = np.float32
+    assert oracle.scan_value_lut_f32(f(0.25), False, "dom").tolist() == [0.0, 1.0, 1.0, 1.0]      # imputed 0.5 > 0 -> 1
+    assert oracle.scan_value_lut_f32(f(0.25), True, "DOM").tolist() == [1.0, 1.0, 1.0, 0.0]
+    assert oracle.scan_value_lut_f32(f(0.25), False, "rec").tolist() == [0.0, 0.0, 0.0, 1.0]
+    assert oracle.scan_value_lut_f32(f(1.0), False, "rec").tolist() == [0.0, 1.0, 0.0, 1.0]       # imputed 2 maf = 2 counts as hom-alt
+    assert oracle.scan_value_lut_f32(f(0.5), False, "het").tolist() == [0.0, 1.0, 1.0, 0.0]       # imputed 2 maf = 1 counts as het
+    assert oracle.scan_value_lut_f32(f(0.3), True, "Het").tolist() == [0.0, 0.0, 1.0, 0.0]
+    with pytest.raises(RuntimeError, match="model must be one of: add, dom, rec, het"):
+        oracle.scan_value_lut_f32(f(0.3), False, "overdominant")
+    with pytest.raises(RuntimeError, match="model must be one of: add, dom, rec, het"):
+        stats.genetic_model_code("x")
+    rng = np.random.default_rng(11)
+    n, m = 97, 60
+    g = rng.integers(0, 3, size=(m, n)).astype(np.int8)
+    g[rng.random((m, n)) < 0.05] = -9
+    g[5, :] = np.where(g[5] == 2, 1, g[5])                      # no hom-alt call: `rec` makes the row constant
+    from janusx_amd import bed
+    packed = bed.pack_dosage(g)
+    mi, he, ho = oracle.row_counts(packed, n)
+    counts = np.stack([mi, he, ho], 1)
+    maf = ((he + 2 * ho) / np.maximum(2 * (n - mi), 1)).astype(np.float32)
+    maf[7] = 0.5                                                 # imputed entry = 1: a het under `het`
+    flip = rng.random(m) < 0.3
+    for gm in ("add", "dom", "rec", "het"):
+        lut = stats.scan_lut_from_counts(maf, flip, counts, n, model=gm)
+        dec = oracle.decode_centered_block_f32(packed, n, flip, maf, model=gm)
+        codes = oracle.unpack_codes(packed, n)
+        assert np.array_equal(np.take_along_axis(lut, codes.astype(np.int64), axis=1), dec), gm
+    assert np.all(oracle.decode_centered_block_f32(packed, n, flip, maf, rows=np.array([5]), model="rec") == 0.0) or flip[5]

@@ -386,7 +386,7 @@ def main():
             geff_local = int(panel.grm_rows_local)                        # kept SNPs of this rank's launch
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            s, ut64 = pl.eigh_from_grm(k32, 1e-6)
+            s, ut64 = pl.eigh_from_grm(k32, 1e-6, f32_consumer=True)    # as pipeline.run_gwas does: U is kept as the f32 U^T only
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             symv_ms, symv_mb = lib().jxg_last_kernel_ms(2), lib().jxg_last_kernel_ms(3)
@@ -736,8 +736,9 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64 (eigendecomposition: reduction stages and Q2 on f64 MFMA; Q1 back-transformation and divide-and-conquer "
-                     "merges as f64-accurate products of 6 int8 digit planes per operand, exact i32 sums, f64 combination: "
-                     "4e-14; REML in f64); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
+                     "merges as products of 5 int8 digit planes per operand (6 behind rust_eigh_from_array_f64: the eigenvectors are kept "
+                     "here only as the f32 U^T the reference's scan consumes), exact i32 sums, f64 combination: orthogonality of U "
+                     "4e-10, eigenvalues unchanged; REML in f64); GRM: int8 MFMA with i32 accumulation (exact integer Gram term) "
                      "or fp16 hi+lo split of the f32 operands with f32 accumulation, f64 merge; rotation: exact design rows x three "
                      "int8 planes of U (int8 MFMA, exact i32 sums, f64 combine), other rows fp16 hi+lo split with f32 accumulation",
             "data": "synthetic",

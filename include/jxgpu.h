@@ -182,6 +182,11 @@ int jxg_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const doubl
 int jxg_oz_dgemm_f64(int ta, int tb, int m, int n, int k, double alpha, const double *d_a, int64_t lda, const double *d_b,
                      int64_t ldb, double beta, double *d_c, int64_t ldc, float *h_ms, void *stream);
 int jxg_oz_planes(void);
+/* Digit planes per operand of the sliced products for the calls that follow (4 .. 6; anything else: back to the default of
+ * JXGPU_OZ_PLANES / 6); returns the previous override.  pipeline.eigh_from_grm(f32_consumer=True) runs Q1 and the
+ * divide-and-conquer merges with 5 planes (15 int8 products instead of 21) when the eigenvectors are only kept as the f32
+ * U^T the reference's scan consumes (src/stats/reml.rs:109-198): orthogonality 4e-10 instead of 2e-12, far inside f32. */
+int jxg_oz_set_planes(int planes);
 int jxg_dsymm_lower_f64(int m, int n, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,
                         double beta, double *d_c, int64_t ldc, void *stream);
 int jxg_dsyr2k_lower_nt_f64(int m, int k, double alpha, const double *d_a, int64_t lda, const double *d_b, int64_t ldb,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "jxg_dgemm_f64": [c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_i, c_p],
     "jxg_oz_dgemm_f64": [c_i, c_i, c_i, c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p, c_p],
     "jxg_oz_planes": [],
+    "jxg_oz_set_planes": [c_i],
     "jxg_dsymm_lower_f64": [c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p],
     "jxg_dsyr2k_lower_nt_f64": [c_i, c_i, c_d, c_p, c_l, c_p, c_l, c_d, c_p, c_l, c_p],
     "jxg_sy2st_f64": [c_p, c_i, c_p, c_p, c_p, c_p, c_p],

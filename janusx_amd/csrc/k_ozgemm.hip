@@ -39,13 +39,16 @@ constexpr int OZ_BK = 32;                     // k per step
 constexpr int OZ_PLANE = OZ_TM * OZ_BK;       // bytes of one plane of one (row block, k step)
 constexpr int OZ_NST = 3;                     // LDS ring depth
 
+// run-time override of the plane count (0: none), set around a decomposition whose eigenvectors the caller keeps in f32
+static int g_oz_planes_override = 0;
 int oz_planes() {
     static const int p = [] {
         const char *e = getenv("JXGPU_OZ_PLANES");
         const int v = e ? atoi(e) : 6;
         return (v >= 4 && v <= 6) ? v : 6;
     }();
-    return p;
+    const int o = g_oz_planes_override;
+    return (o >= 4 && o <= 6) ? o : p;
 }
 
 static inline size_t oz_align(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -439,3 +442,8 @@ extern "C" int jxg_oz_dgemm_f64(int ta, int tb, int m, int n, int k, double alph
 }
 
 extern "C" int jxg_oz_planes(void) { return oz_planes(); }
+extern "C" int jxg_oz_set_planes(int planes) {
+    const int prev = g_oz_planes_override;
+    g_oz_planes_override = (planes >= 4 && planes <= 6) ? planes : 0;
+    return prev;
+}

@@ -316,8 +316,13 @@ def enable_distributed_eigh(min_n: int = 0):
     return True
 
 
-def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
-    """K (n,n) f32/f64 on device -> (S f64 (k), U^T f64 (k,k) row j = eigenvector j)."""
+def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None, f32_consumer=False):
+    """K (n,n) f32/f64 on device -> (S f64 (k), U^T f64 (k,k) row j = eigenvector j).
+    f32_consumer: the caller keeps the eigenvectors only as the f32 U^T of the scan (`SpectralModel`, the reference's `Dh`,
+    python/janusx/pyBLUP/assoc.py:1817; src/stats/reml.rs:109-198): the sliced int8 products of the Q1 back-transformation and of
+    the divide-and-conquer merges then run with 5 digit planes (15 products) instead of 6 (21) -- orthogonality of U 4e-10
+    instead of 2e-12 at n = 20 000, three orders inside the f32 rounding of the copy that is kept; eigenvalues unchanged
+    (JXGPU_OZ_PLANES, when set, decides alone; JXGPU_EIGH_F32_PLANES=0 keeps 6)."""
     dev = k.device
     n = int(k.shape[0])
     idx = np.arange(n, dtype=np.int32) if subset_idx is None else np.asarray(subset_idx, dtype=np.int32)
@@ -331,7 +336,13 @@ def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None):
     if _DIST_EIGH:
         _DIST_EIGH["prepare"](kk)   # staging buffer of the per-column all-reduce (sized by n)
         _DIST_EIGH["state"]["out"] = a   # the gather callback of the two-stage path completes this tensor
-    check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
+    five = bool(f32_consumer) and not os.environ.get("JXGPU_OZ_PLANES") and os.environ.get("JXGPU_EIGH_F32_PLANES", "5") == "5"
+    prev = lib().jxg_oz_set_planes(5) if five else 0
+    try:
+        check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
+    finally:
+        if five:
+            lib().jxg_oz_set_planes(prev)
     return w, a
 
 
@@ -938,7 +949,7 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     BED order on every rank; `on_rows` is called on rank 0 only, with the whole table as one block."""
     rank, world = dist_info()
     keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
-    s, ut64 = eigh_from_grm(k, 1e-6, keep_idx)
+    s, ut64 = eigh_from_grm(k, 1e-6, keep_idx, f32_consumer=True)     # only the f32 U^T of SpectralModel is kept
     model = SpectralModel(s, ut64, x, y)
     del ut64
     panel = Panel(packed, n_samples, keep_idx)
@@ -1068,7 +1079,7 @@ def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndar
     k32, geff, _ = build_grm(packed, n_samples, grm_method, maf, geno, panel=panel, payload_sharded=payload_sharded)
     t2 = tick()
     tm.add("grm", t2 - t1)
-    s, ut64 = eigh_from_grm(k32, 1e-6)
+    s, ut64 = eigh_from_grm(k32, 1e-6, f32_consumer=True)             # only the f32 U^T of SpectralModel is kept
     t3 = tick()
     tm.add("eigh", t3 - t2)
     x = np.ones((n, 1)) if covar is None else np.concatenate([np.ones((n, 1)), np.asarray(covar, dtype=np.float64)], 1)

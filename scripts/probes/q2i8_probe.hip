@@ -1,0 +1,370 @@
+// Prototype of the Q2 back-transformation's block operation on the INT8 matrix pipes ("next" item 2):
+//   Y = U' C_win ;  C_win -= V Y        (U, V: 96 x 32 per block; C_win: 96-row window of a 32-column unit, f64)
+// C's columns are unit vectors and stay so under Q2, so the window is sliced with a FIXED scale: x in (-2, 2) -> P signed
+// base-256 digits of the fixed-point number rint(x 2^F), F = 8 P - 2.  The digits are the bytes of ONE f64 addition
+// (x + MAGIC puts the two's-complement integer, already biased by 0x80 per lower byte, into the mantissa; an XOR turns the lower
+// bytes into signed digits).  A window tile lives in the registers of ONE wave in the D layout of v_mfma_i32_32x32x32_i8
+// (lane = column, 16 registers = rows (j & 3) + 8 (j >> 2) + 4 (lane >> 5)): that is at once the B-operand layout of the next
+// product over the tile's rows, so nothing moves between lanes: slice in place, multiply, combine the P level sums
+// (pairs of levels merged in i32, then three conversions and fused multiply-adds in f64).
+// Modes: check (one wave, a chain of blocks against the host's f64 result) and time (every SIMD busy; window resident or
+// sliding over a slab in HBM, G sweep groups per pass).
+//   hipcc --offload-arch=gfx950 -O3 -o q2i8_probe q2i8_probe.hip
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int P> struct Fix {
+    static constexpr int F = 8 * P - 2;                                   // fractional bits; digit p (0 = top) has weight 2^(8 (P-1-p) - F)
+    static constexpr uint64_t bias = (P == 6) ? 0x0000008080808080ull : 0x0000000080808080ull;   // 0x80 at every byte below the top one
+    static double magic() { return ldexp(1.5, 52 - F) + ldexp((double)bias, -F); }
+    static double level_scale(int l) { return ldexp(1.0, 16 * (P - 1) - 8 * l - 2 * F); }        // weight of the level-l sum
+};
+
+__host__ __device__ inline int d_row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }  // tile row of register j of lane half h
+
+// host: signed digits of x (the device's arithmetic restated): dig[p], p = 0 top
+template <int P> static void host_digits(double x, int8_t *dig) {
+    const int F = Fix<P>::F;
+    const int64_t X = (int64_t)nearbyint(ldexp(x, F));
+    int64_t Xb = X + (int64_t)Fix<P>::bias;
+    for (int q = 0; q < P; ++q) {                                        // byte q, q = 0 least significant
+        const uint8_t u = (uint8_t)((uint64_t)Xb >> (8 * q));
+        dig[P - 1 - q] = (q == P - 1) ? (int8_t)u : (int8_t)(u ^ 0x80);
+    }
+}
+
+// one 16-byte A fragment (plane p of a 32 x 32 operand tile): image byte of lane l, element j
+// image layout per block: [which: U = 0, V = 1][plane][tile][lane][16]
+template <int P> static size_t img_bytes() { return (size_t)2 * P * 3 * 1024; }
+
+__device__ __forceinline__ uint32_t perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
+
+// slice the 16 f64 values of a D-layout tile into P planes of 16 bytes (i32x4 each, byte j = register j)
+template <int P> __device__ __forceinline__ void slice_tile(const double (&x)[16], double magic, i32x4 (&q)[P]) {
+    uint32_t lo[16], hi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double y = x[j] + magic;
+        const uint64_t b = (uint64_t)__double_as_longlong(y);
+        if (P == 6) {
+            lo[j] = (uint32_t)b ^ 0x80808080u;
+            hi[j] = (uint32_t)(b >> 32) ^ 0x80u;
+        } else {
+            lo[j] = (uint32_t)b ^ 0x80808080u;
+            hi[j] = (uint32_t)(b >> 32);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t w0 = lo[4 * g], w1 = lo[4 * g + 1], w2 = lo[4 * g + 2], w3 = lo[4 * g + 3];
+        const uint32_t t0 = perm(w1, w0, 0x05010400u), t1 = perm(w1, w0, 0x07030602u);
+        const uint32_t t2 = perm(w3, w2, 0x05010400u), t3 = perm(w3, w2, 0x07030602u);
+        q[P - 1][g] = (int)perm(t2, t0, 0x05040100u);      // byte 0 of every element: the least significant digit
+        q[P - 2][g] = (int)perm(t2, t0, 0x07060302u);
+        q[P - 3][g] = (int)perm(t3, t1, 0x05040100u);
+        q[P - 4][g] = (int)perm(t3, t1, 0x07060302u);
+        const uint32_t h0 = hi[4 * g], h1 = hi[4 * g + 1], h2 = hi[4 * g + 2], h3 = hi[4 * g + 3];
+        const uint32_t u0 = perm(h1, h0, 0x05010400u), u2 = perm(h3, h2, 0x05010400u);
+        q[P - 5][g] = (int)perm(u2, u0, 0x05040100u);      // byte 4
+        if (P == 6) q[0][g] = (int)perm(u2, u0, 0x07060302u);   // byte 5: the signed top digit
+    }
+}
+
+// level sums -> f64 (without the level scale): pairs of levels merged in i32 (bounds: see DESIGN), Horner in f64
+template <int P> __device__ __forceinline__ double combine(const i32x16 (&s)[P], int j) {
+    if (P == 6) {
+        const int m01 = (s[0][j] << 8) + s[1][j], m23 = (s[2][j] << 8) + s[3][j], m45 = (s[4][j] << 8) + s[5][j];
+        double r = (double)m45;
+        r = fma(r, 0x1p-16, (double)m23);
+        r = fma(r, 0x1p-16, (double)m01);
+        return r;                                            // in units of the level-1 weight
+    } else {
+        const int m01 = (s[0][j] << 8) + s[1][j], m23 = (s[2][j] << 8) + s[3][j];
+        double r = (double)s[4][j];
+        r = fma(r, 0x1p-8, (double)m23);
+        r = fma(r, 0x1p-16, (double)m01);
+        return r;
+    }
+}
+
+// One block on a window of three tiles: c[t][j].  img: LDS, this block's images.
+// Phases: the 21 products of a tile are issued interleaved (sched_group_barrier) with the VALU work that does not depend on
+// them -- the slicing of the NEXT tile during the first product, the combination of the PREVIOUS tile's level sums during the
+// update (two accumulator sets) --; exposed: the first tile's slicing, Y's combination + slicing, the last tile's combination.
+#define Q2_INTERLEAVE(NM, NV)                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < (NM); ++q_) {             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+        __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);         \
+    }
+template <int P> __device__ __forceinline__ void mfma_tile(const uint8_t *iu, int which, int t, const i32x4 (&bq)[P], i32x16 (&acc)[P]) {
+    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(iu + ((size_t)(which * P + i) * 3 + t) * 1024);
+#pragma unroll
+        for (int j = 0; j + i < P; ++j) {
+            if (i == 0) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[j], zero, 0, 0, 0);       // first product of level j
+            else acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[j], acc[i + j], 0, 0, 0);
+        }
+    }
+}
+template <int P> __device__ __forceinline__ void mfma_tile_acc(const uint8_t *iu, int which, int t, const i32x4 (&bq)[P], i32x16 (&acc)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(iu + ((size_t)(which * P + i) * 3 + t) * 1024);
+#pragma unroll
+        for (int j = 0; j + i < P; ++j) acc[i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[j], acc[i + j], 0, 0, 0);
+    }
+}
+template <int P> __device__ __forceinline__ void block_op(double (&c0)[16], double (&c1)[16], double (&c2)[16], const uint8_t *img,
+                                                          int lane, double magic, double sy, double sc) {
+    constexpr int NPR = P * (P + 1) / 2;
+    const uint8_t *iu = img + (size_t)lane * 16;
+    i32x16 acc[P];
+    i32x4 cqa[P], cqb[P];
+    slice_tile<P>(c0, magic, cqa);
+    __builtin_amdgcn_sched_barrier(0);
+    slice_tile<P>(c1, magic, cqb);
+    mfma_tile<P>(iu, 0, 0, cqa, acc);
+    Q2_INTERLEAVE(NPR, 6)
+    __builtin_amdgcn_sched_barrier(0);
+    slice_tile<P>(c2, magic, cqa);
+    mfma_tile_acc<P>(iu, 0, 1, cqb, acc);
+    Q2_INTERLEAVE(NPR, 6)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile_acc<P>(iu, 0, 2, cqa, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    double y[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) y[j] = combine<P>(acc, j) * sy;
+    i32x4 yq[P];
+    slice_tile<P>(y, magic, yq);
+    __builtin_amdgcn_sched_barrier(0);
+    i32x16 acc2[P];
+    mfma_tile<P>(iu, 1, 0, yq, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile<P>(iu, 1, 1, yq, acc2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c0[j] = fma(combine<P>(acc, j), -sc, c0[j]);
+    Q2_INTERLEAVE(NPR, 8)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile<P>(iu, 1, 2, yq, acc);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c1[j] = fma(combine<P>(acc2, j), -sc, c1[j]);
+    Q2_INTERLEAVE(NPR, 8)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c2[j] = fma(combine<P>(acc, j), -sc, c2[j]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// check mode: one wave, nblk blocks applied to one window (no sliding); images straight from global memory through LDS
+template <int P> __global__ __launch_bounds__(64) void check_kernel(const uint8_t *img, int nblk, double *c /*[3][32 rows][32 cols]*/,
+                                                                     double magic, double sy, double sc) {
+    extern __shared__ uint8_t lds[];
+    const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+    double c0[16], c1[16], c2[16];
+    for (int j = 0; j < 16; ++j) {
+        c0[j] = c[(0 * 32 + d_row(j, h)) * 32 + col];
+        c1[j] = c[(1 * 32 + d_row(j, h)) * 32 + col];
+        c2[j] = c[(2 * 32 + d_row(j, h)) * 32 + col];
+    }
+    const size_t ib = (size_t)2 * P * 3 * 1024;
+    for (int b = 0; b < nblk; ++b) {
+        for (size_t o = lane * 16; o < ib; o += 64 * 16)
+            *reinterpret_cast<uint4 *>(lds + o) = *reinterpret_cast<const uint4 *>(img + (size_t)b * ib + o);
+        __syncthreads();
+        block_op<P>(c0, c1, c2, lds, lane, magic, sy, sc);
+        __syncthreads();
+    }
+    for (int j = 0; j < 16; ++j) {
+        c[(0 * 32 + d_row(j, h)) * 32 + col] = c0[j];
+        c[(1 * 32 + d_row(j, h)) * 32 + col] = c1[j];
+        c[(2 * 32 + d_row(j, h)) * 32 + col] = c2[j];
+    }
+}
+
+// time mode: NW waves per workgroup, each its own unit; two blocks' images resident in LDS (alternating); G groups per pass.
+// slide = 0: the window stays (compute only).  slide = 1: after every step the two leading tiles are stored to the slab and two new
+// ones loaded (the row traffic of the real kernel: 2 x 32 rows x 32 columns x 8 B each way per step and unit).
+template <int P, int G, int NW> __global__ __launch_bounds__(NW * 64) void time_kernel(const uint8_t *img, double *slab, int nsteps,
+                                                                                       int slide, double magic, double sy, double sc) {
+    extern __shared__ uint8_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t ib = (size_t)2 * P * 3 * 1024;
+    for (size_t o = threadIdx.x * 16; o < 2 * ib; o += (size_t)NW * 64 * 16)
+        *reinterpret_cast<uint4 *>(lds + o) = *reinterpret_cast<const uint4 *>(img + o);
+    __syncthreads();
+    constexpr int NT = G + 2;
+    double c[NT][16];
+    const size_t unit = (size_t)blockIdx.x * NW + wave;
+    // slab: [unit][tile index][reg pair][lane][..]: a lane's 16 values of a tile as four 32-byte runs ([j >> 2][lane][j & 3])
+    double *base = slab + unit * (size_t)(nsteps * 2 + NT) * 1024;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[t][j] = base[(size_t)t * 1024 + ((j >> 2) * 64 + lane) * 4 + (j & 3)];
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int g = G - 1; g >= 0; --g)                     // group g acts on tiles g, g + 1, g + 2 (highest group first)
+            block_op<P>(c[g], c[g + 1], c[g + 2], lds + (size_t)((s * G + g) & 1) * ib, lane, magic, sy, sc);
+        if (slide) {
+            double *out = base + (size_t)(2 * s) * 1024, *in = base + (size_t)(2 * s + NT) * 1024;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    double4 v = make_double4(c[t][4 * jj], c[t][4 * jj + 1], c[t][4 * jj + 2], c[t][4 * jj + 3]);
+                    *reinterpret_cast<double4 *>(out + (size_t)t * 1024 + (jj * 64 + lane) * 4) = v;
+                }
+#pragma unroll
+            for (int t = 0; t + 2 < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) c[t][j] = c[t + 2][j];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const double4 v = *reinterpret_cast<const double4 *>(in + (size_t)t * 1024 + (jj * 64 + lane) * 4);
+                    c[NT - 2 + t][4 * jj] = v.x; c[NT - 2 + t][4 * jj + 1] = v.y; c[NT - 2 + t][4 * jj + 2] = v.z; c[NT - 2 + t][4 * jj + 3] = v.w;
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) base[(size_t)t * 1024 + ((j >> 2) * 64 + lane) * 4 + (j & 3)] = c[t][j];
+}
+
+template <int P> static void build_images(const std::vector<double> &U, const std::vector<double> &V, int nblk, std::vector<uint8_t> &img) {
+    // U, V: [blk][96][32] (row-major: window row, reflector m)
+    img.assign(img_bytes<P>() * nblk, 0);
+    int8_t dig[8];
+    for (int b = 0; b < nblk; ++b)
+        for (int which = 0; which < 2; ++which)
+            for (int t = 0; t < 3; ++t)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 16; ++j) {
+                        const int r = l & 31, h = l >> 5;
+                        double x;
+                        if (which == 0) x = U[((size_t)b * 96 + 32 * t + d_row(j, h)) * 32 + r];          // A = U': row m = r, k = window row
+                        else x = V[((size_t)b * 96 + 32 * t + r) * 32 + d_row(j, h)];                     // A = V: row = window row r, k = m
+                        host_digits<P>(x, dig);
+                        for (int p = 0; p < P; ++p)
+                            img[(size_t)b * img_bytes<P>() + (((size_t)(which * P + p) * 3 + t) * 64 + l) * 16 + j] = (uint8_t)dig[p];
+                    }
+}
+
+template <int P> static int run_check() {
+    const int nblk = 40;
+    std::vector<double> U((size_t)nblk * 96 * 32), V(U.size()), C(96 * 32), R;
+    srand(7);
+    auto rnd = [] { return 2.0 * rand() / RAND_MAX - 1.0; };
+    for (auto &v : V) v = rnd();
+    for (int b = 0; b < nblk; ++b)                                        // U columns of norm <= 1 so that |Y| <= 1
+        for (int m = 0; m < 32; ++m) {
+            double ss = 0;
+            for (int r = 0; r < 96; ++r) { double x = rnd(); U[((size_t)b * 96 + r) * 32 + m] = x; ss += x * x; }
+            for (int r = 0; r < 96; ++r) U[((size_t)b * 96 + r) * 32 + m] /= sqrt(ss) * 1.001;
+        }
+    for (int cix = 0; cix < 32; ++cix) {                                  // unit columns
+        double ss = 0;
+        for (int r = 0; r < 96; ++r) { double x = rnd(); C[r * 32 + cix] = x; ss += x * x; }
+        for (int r = 0; r < 96; ++r) C[r * 32 + cix] /= sqrt(ss) * 3.0;   // the rest of the column lives outside the window
+    }
+    // V scaled so that the block is a contraction (keeps |C| bounded over the chain): V := 0.1 V
+    for (auto &v : V) v *= 0.1;
+    R = C;
+    for (int b = 0; b < nblk; ++b) {
+        double Y[32][32];
+        for (int m = 0; m < 32; ++m)
+            for (int cix = 0; cix < 32; ++cix) {
+                double s = 0;
+                for (int r = 0; r < 96; ++r) s += U[((size_t)b * 96 + r) * 32 + m] * R[r * 32 + cix];
+                Y[m][cix] = s;
+            }
+        for (int r = 0; r < 96; ++r)
+            for (int cix = 0; cix < 32; ++cix) {
+                double s = 0;
+                for (int m = 0; m < 32; ++m) s += V[((size_t)b * 96 + r) * 32 + m] * Y[m][cix];
+                R[r * 32 + cix] -= s;
+            }
+    }
+    std::vector<uint8_t> img;
+    build_images<P>(U, V, nblk, img);
+    uint8_t *dimg; double *dc;
+    CK(hipMalloc(&dimg, img.size())); CK(hipMalloc(&dc, C.size() * 8));
+    CK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dc, C.data(), C.size() * 8, hipMemcpyHostToDevice));
+    // level-1 units: sum_l 2^(w_l) S_l with w_1 the unit: scale = level_scale(1)
+    const double sc = Fix<P>::level_scale(1);
+    hipLaunchKernelGGL(check_kernel<P>, dim3(1), dim3(64), img_bytes<P>(), 0, dimg, nblk, dc, Fix<P>::magic(), sc, sc);
+    CK(hipDeviceSynchronize());
+    std::vector<double> got(C.size());
+    CK(hipMemcpy(got.data(), dc, C.size() * 8, hipMemcpyDeviceToHost));
+    double err = 0, mag = 0;
+    for (size_t i = 0; i < got.size(); ++i) { err = fmax(err, fabs(got[i] - R[i])); mag = fmax(mag, fabs(R[i])); }
+    printf("check P=%d: %d blocks chained, max |C_int8 - C_f64| = %.3e (max |C| = %.3f)\n", P, nblk, err, mag);
+    hipFree(dimg); hipFree(dc);
+    return err < (P == 6 ? 1e-11 : 1e-9) ? 0 : 1;
+}
+
+template <int P, int G, int NW> static void run_time(int slide) {
+    const int nsteps = 300, ncu = 256;
+    std::vector<uint8_t> img(2 * img_bytes<P>());
+    for (auto &b : img) b = (uint8_t)(rand() & 0x3f);
+    uint8_t *dimg; double *slab;
+    const size_t per_unit = (size_t)(nsteps * 2 + G + 2) * 1024;
+    const size_t units = (size_t)ncu * NW;
+    CK(hipMalloc(&dimg, img.size()));
+    CK(hipMalloc(&slab, units * per_unit * 8));
+    CK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    CK(hipMemset(slab, 0, units * per_unit * 8));
+    auto kfn = time_kernel<P, G, NW>;
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * img_bytes<P>())));
+    hipFuncAttributes fa;
+    CK(hipFuncGetAttributes(&fa, (const void *)kfn));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kfn, dim3(ncu), dim3(NW * 64), 2 * img_bytes<P>(), 0, dimg, slab, nsteps, slide, Fix<P>::magic(), 1e-30, 1e-30);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    const double blocks = (double)nsteps * G;                              // per wave
+    const double cyc = best * 1e-3 * 2.4e9 / blocks;                      // cycles per block and wave (= per SIMD when NW = 4)
+    // the f64 MFMA form issues 96 x 2 (32 columns) v_mfma_f64_16x16x4 of 64 cycles per block: 12288 cycles per SIMD
+    const double flops = blocks * units * (2.0 * 2 * 96 * 32 * 32);
+    printf("time P=%d G=%d waves/WG=%d slide=%d: %.2f ms, %.0f cycles per block and wave (f64 MFMA form: 12288 per SIMD and 32 columns), "
+           "%.1f TFLOP/s issued-equivalent, regs %d (spill %d B), rows %.2f TB/s\n", P, G, NW, slide, best, cyc, flops / (best * 1e-3) / 1e12,
+           fa.numRegs, (int)fa.localSizeBytes, slide ? (double)nsteps * units * 2 * 2 * 1024 * 8 / (best * 1e-3) / 1e12 : 0.0);
+    hipFree(dimg); hipFree(slab);
+}
+
+int main(int argc, char **argv) {
+    int rc = run_check<6>();
+    rc |= run_check<5>();
+    run_time<6, 1, 4>(0);
+    run_time<6, 2, 4>(0);
+    run_time<6, 2, 4>(1);
+    run_time<5, 2, 4>(0);
+    run_time<5, 2, 4>(1);
+    run_time<6, 4, 4>(1);
+    run_time<5, 4, 4>(1);
+    return rc;
+}

@@ -47,7 +47,9 @@ import atexit  # noqa: E402
 atexit.register(_dump_maxima)
 
 
-RAW_P_BOUND = 2e-4      # raw relative error of the Wald p, every leg (measured maximum: 9.9e-5 on the strongest SNP of C4)
+RAW_P_BOUND = 1.2e-4    # raw relative error of the Wald p, EVERY row of every leg (measured maximum: 9.9e-5 on the strongest SNP
+                        # of C4, z^2 ~ 170: a relative error eps on beta / SE is z^2 eps on the normal tail); rows with z^2 <= 10: 1e-5
+                        # on the exact-rotation legs (`_exact_rotation_leg`), recorded for every leg as maxima[5]
 
 
 def _assoc_err(out, ref, tag=None):
@@ -120,13 +122,47 @@ def _exact_rotation_leg(oracle, oracle_c, gpu_stats, ref_f32, g_design, dh, s, x
     nrm = np.maximum(1.0, z2 / 10.0)
     pn = float(np.max(np.abs(out[ok, 2] - ref[ok, 2]) / ref[ok, 2] / nrm))
     pn_n = float(np.max(np.abs(np.asarray(ref_f32)[ok, 2] - ref[ok, 2]) / ref[ok, 2] / nrm))
+    praw = np.abs(out[ok, 2] - ref[ok, 2]) / ref[ok, 2]
+    p10 = float(np.max(praw[z2 <= 10.0])) if np.any(z2 <= 10.0) else 0.0
     if int8_path:
         assert be < 1e-6 and se < 1e-6, ("exact-rotation leg (int8 rotation): beta / SE", be, se)
-        assert pn < 1e-5, ("exact-rotation leg (int8 rotation): raw p", pn)
+        # the north star's own statement: Wald p within 1e-5 relative -- on ALL rows with z^2 <= 10 (p >= 1.6e-3), raw
+        assert p10 < 1e-5, ("exact-rotation leg (int8 rotation): raw p of the rows with z^2 <= 10", p10)
+        assert pn < 1e-5, ("exact-rotation leg (int8 rotation): raw p / max(1, z^2 / 10)", pn)
     else:
         assert be <= max(1e-6, 5.0 * be_n) and se < 1e-6, ("exact-rotation leg: beta / SE vs the f32 noise", be, se, be_n, se_n)
         assert pn <= max(1e-5, 5.0 * pn_n), ("exact-rotation leg: raw p vs the f32 noise", pn, pn_n)
     return be, se, pn
+
+
+def _tsv_rows_match_text(lines, expected_lines, max_flip_share=0.03):
+    """TSV rows against the text `oracle.format_assoc_row` renders from the ORACLE's numbers, byte for byte.  A row may differ only
+    by a flip of the LAST printed digit of a numeric field (the two sides' beta / SE differ by ~1e-6 relative, which crosses a
+    rounding boundary of the 4-decimal / 4-significant-digit print now and then); such rows are counted and their share bounded.
+    -> (rows equal byte for byte, rows with a last-digit flip)."""
+    assert len(lines) == len(expected_lines)
+    same = flips = 0
+
+    def last_digit_unit(txt):
+        mant, _, exp = txt.partition("e")
+        dec = len(mant.partition(".")[2])
+        return 10.0 ** (-dec) * (10.0 ** int(exp) if exp else 1.0)
+    for got, exp in zip(lines, expected_lines):
+        exp = exp.rstrip("\n")
+        if got == exp:
+            same += 1
+            continue
+        fg, fe = got.split("\t"), exp.split("\t")
+        assert len(fg) == len(fe) and fg[:5] == fe[:5], (got, exp)
+        for a, b in zip(fg[5:], fe[5:]):
+            if a == b:
+                continue
+            assert a not in ("NaN", "inf") and b not in ("NaN", "inf"), (got, exp)
+            unit = max(last_digit_unit(a), last_digit_unit(b))
+            assert abs(float(a) - float(b)) <= 1.0001 * unit, ("more than a last-digit flip", a, b, got, exp)
+        flips += 1
+    assert flips <= max(2, int(max_flip_share * len(lines))), (flips, len(lines))
+    return same, flips
 
 
 @pytest.fixture(scope="module")
@@ -882,12 +918,25 @@ def test_bed_to_tsv_routes(oracle, oracle_c, null_case, tmp_path):
         assert f[5] == f"{float(maf[j]):.4f}" and f[6] == f"{float(miss[j]):.4f}"
         assert abs(float(f[7]) - ref[i, 0]) <= 1.01e-4 and abs(float(f[8]) - ref[i, 1]) <= 1.01e-4
         assert abs(float(f[10]) - ref[i, 2]) <= 2e-4 * ref[i, 2] + 1e-300
+    # the text itself, byte for byte against the oracle's rendering of the oracle's numbers (last-digit flips counted)
+    exp_lines = [oracle.format_assoc_row(bim.chrom[j], bim.pos[j], bim.snp[j], bim.a0[j], bim.a1[j], maf[j], miss[j], ref[i, 0],
+                                         ref[i, 1], ref[i, 2]) for i, j in enumerate(kept)]
+    same, flips = _tsv_rows_match_text(lines[1:], exp_lines)
+    _MAXIMA["tsv_text:lmm"] = [float(same), float(flips)]
+    assert lines[0] + "\n" == oracle.TSV_HEADER
     # fixed lambda route returns (rows, pve, log_det_v)
     out2 = str(tmp_path / "res.fvlmm.tsv")
     r2, pve, ldv = jxrs.fvlmm_assoc_bed_to_tsv_f32(prefix, out2, nm.S, nm.Xcov, nm.y, math.log10(nm.lbd_null), nm.Dh,
                                                    0.02, 0.05, 1.0)
     assert r2 == rows and abs(ldv - float(np.sum(np.log(nm.S + nm.lbd_null)))) < 1e-9
-    assert len(open(out2).read().splitlines()) == rows + 1
+    lines2 = open(out2).read().splitlines()
+    assert len(lines2) == rows + 1
+    fref = oracle.fvlmm_assoc_rotated_block(oracle.rotate_block_f32(gd, nm.Dh),
+                                            oracle.fvlmm_prepare_cache(nm.S, nm.Xcov, nm.y, nm.lbd_null))
+    exp2 = [oracle.format_assoc_row(bim.chrom[j], bim.pos[j], bim.snp[j], bim.a0[j], bim.a1[j], maf[j], miss[j], fref[i, 0],
+                                    fref[i, 1], fref[i, 2]) for i, j in enumerate(kept)]
+    same2, flips2 = _tsv_rows_match_text(lines2[1:], exp2)
+    _MAXIMA["tsv_text:fvlmm"] = [float(same2), float(flips2)]
 
 
 def test_fast_scan_matches_exact_scan(oracle, null_case, monkeypatch):

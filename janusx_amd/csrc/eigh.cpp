@@ -251,44 +251,10 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
             if (ag == 0) *any = 1;
             return 0;
         };
-        // Q1 back-transformation, C-independent part (reflector images, Gram, T^-1, V T of every block: ~40 of its 210 ms at
-        // n = 20 000), in line in front of the Q1 products by default.  JXGPU_Q1_AHEAD=2 enqueues it on a low-priority stream of
-        // its own BESIDE THE BULGE CHASING (latency-bound: one workgroup per position spinning on its neighbour's messages; the
-        // divide and conquer waits for the plan): measured at n = 20 000 Q1 208 -> 169 ms but the chase 88 -> 111 -- 17 ms
-        // net, not worth the risk that the side stream's kernels delay the co-residency the persistent chase kernel relies on
-        // (a bounded spin that expires sends the whole decomposition down the one-stage fallback).  =1: beside the divide and
-        // conquer -- that moves the 40 ms instead of hiding them (divide and conquer 98 -> 145: its chain of small dependent
-        // launches queues behind the side stream's full-chip kernels).
-        static hipStream_t q1_side = nullptr;
-        static hipEvent_t q1_go = nullptr, q1_done = nullptr;
-        static const int q1_mode = getenv("JXGPU_Q1_AHEAD") ? atoi(getenv("JXGPU_Q1_AHEAD")) : 0;
-        bool q1_ahead = false;                                  // the plan was (or is being) prepared on the side stream
-        auto q1_free = [](OrmtrPlan *p) {
-            if (q1_side) (void)hipStreamSynchronize(q1_side);   // nothing of the plan may still be in flight
-            ormtr_plan_free(p);
-        };
-        std::unique_ptr<OrmtrPlan, decltype(q1_free)> q1_plan(nullptr, q1_free);
-        auto q1_side_setup = [&]() -> int {
-            if (!q1_side) {
-                // lowest priority: chains of small dependent launches on the main stream must not queue behind these
-                int prio_lo = 0, prio_hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-                JX_HIP(hipStreamCreateWithPriority(&q1_side, hipStreamNonBlocking, prio_lo));
-                JX_HIP(hipEventCreateWithFlags(&q1_go, hipEventDisableTiming));
-                JX_HIP(hipEventCreateWithFlags(&q1_done, hipEventDisableTiming));
-            }
-            return 0;
-        };
-        auto q1_launch_side = [&]() -> int {
-            if (q1_side_setup()) return 1;
-            q1_plan.reset(ormtr_plan_new());
-            JX_HIP(hipEventRecord(q1_go, st));
-            JX_HIP(hipStreamWaitEvent(q1_side, q1_go, 0));
-            if (ormtr_prepare(q1_side, d_a, n, sy2sb_bandwidth(), n - sy2sb_bandwidth() - 1, tau.as<double>(), *q1_plan)) return 1;
-            JX_HIP(hipEventRecord(q1_done, q1_side));
-            q1_ahead = true;
-            return 0;
-        };
+        // Q1 back-transformation, C-independent part (reflector images, Gram, T^-1, V T of every block: ~40 of its 165 ms at
+        // n = 20 000): prepared in line in front of the Q1 products.  Preparing it on a side stream beside the bulge chasing or the
+        // divide and conquer was measured in round 4 and moved the 40 ms instead of hiding them; removed.
+        std::unique_ptr<OrmtrPlan, void (*)(OrmtrPlan *)> q1_plan(nullptr, ormtr_plan_free);
         DevBuf ts_work, ts_ab, ts_tau2, ts_ctrl, ts_flags, ts_tq;
         ScratchLease ts_v2;
         const int ldab = sb2st_ldab(), ks = sb2st_steps(n);
@@ -333,7 +299,6 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
         if (twostage) {
             JX_HIP(hipEventRecord(ev[1], st));
             if (stage_done("sy2sb")) return 1;
-            if (q1_mode == 2 && q1_launch_side()) return 1;      // reads d_a (reflectors below the band) and tau only
             if (sb2st_chase(st, ts_ab.as<double>(), n, d_w, e.as<double>(), ts_v2.as<double>(), ts_tau2.as<double>(),
                             ts_ctrl.as<int>()))
                 return 1;
@@ -346,26 +311,15 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                 // a sweep's bounded spin on its predecessor expired (the persistent launch assumes its workgroups are
                 // co-resident: a shared device can break that): restore the input from the copy and reduce it in one stage
                 if (trace) fprintf(stderr, "[jxgpu eigh n=%d] bulge chasing gave up waiting for a neighbour sweep: one-stage fallback\n", n);
-                if (q1_ahead) {                                  // the side stream still reads d_a
-                    q1_plan.reset(nullptr);
-                    q1_ahead = false;
-                }
                 JX_HIP(hipMemcpyAsync(d_a, c.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, st));
                 ts_tq.release();
                 twostage = false;
             } else {
                 JX_HIP(hipEventRecord(ev[2], st));
                 if (stage_done("sb2st")) return 1;
-                if (q1_ahead) JX_HIP(hipStreamWaitEvent(st, q1_done, 0));      // the divide and conquer starts behind the plan
             }
         }
-        if (twostage && !q1_ahead) {
-            if (q1_mode == 1) {
-                if (q1_launch_side()) return 1;
-            } else {
-                q1_plan.reset(ormtr_plan_new());
-            }
-        }
+        if (twostage) q1_plan.reset(ormtr_plan_new());
         if (!twostage) {
             if (sytrd_lower(h, st, d_a, n, d_w, e.as<double>(), tau.as<double>())) return 1;
             if (stage_done("sytrd")) return 1;
@@ -479,8 +433,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation (this rank's columns)")) return 1;
-                if (q1_ahead) JX_HIP(hipStreamWaitEvent(st, q1_done, 0));
-                else if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
+                if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
                 if (ormtr_apply(st, *q1_plan, blk.as<double>(), nr)) return 1;
                 // column j of the block = eigenvector r0 + j = row r0 + j of the row-major result
                 JX_HIP(hipMemcpyAsync(d_a + (size_t)r0 * n, blk.p, sizeof(double) * (size_t)n * nr, hipMemcpyDeviceToDevice, st));
@@ -493,8 +446,7 @@ extern "C" int jxg_eigh_f64(double *d_a, int n, double ridge, double *d_w, void 
                     return 1;
                 JX_HIP(hipEventRecord(ev[4], st));
                 if (stage_done("Q2 back-transformation")) return 1;
-                if (q1_ahead) JX_HIP(hipStreamWaitEvent(st, q1_done, 0));
-                else if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
+                if (ormtr_prepare(st, d_a, n, sy2sb_bandwidth(), ncol, tau.as<double>(), *q1_plan)) return 1;
                 if (ormtr_apply(st, *q1_plan, c.as<double>(), n)) return 1;
             }
         } else {

@@ -416,9 +416,8 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
     // the rank-2k update alone is faster in the general-loop form with two resident workgroups per CU (1.31 vs 1.50 ms at n_t =
     // 20000), the band reduction as a whole is faster with the one-workgroup stream form (397 vs 426 ms): the panel chain of
     // the NEXT panel runs on the second stream beside this kernel and is the critical path -- it gets the CU resources the
-    // second workgroup would take.  JXGPU_DSYR2K_GENERAL=1 selects the general-loop form.
-    static const bool general = getenv("JXGPU_DSYR2K_GENERAL") && atoi(getenv("JXGPU_DSYR2K_GENERAL")) != 0;
-    return general ? dg_launch<128, 128, DG_THREADS, false>(g, grid, st) : dg_launch<128, 128>(g, grid, st);
+    // second workgroup would take.
+    return dg_launch<128, 128>(g, grid, st);
 }
 
 }  // namespace jx

@@ -1471,7 +1471,7 @@ static bool qr_bal(int ncols) {
     // one round of slabs only (at most seven units per CU, n <= 28 672): with two rounds at n = 50 000 the four-column waves carry
     // 2 - 3 of a slab's 6 - 7 units through their 8-byte row stores and the stage is as much HBM- as pipe-bound there -- 7.71 s
     // against 6.82 s for the two-groups-per-pass form with one wave per unit
-    static const int hi = getenv("JXGPU_SBBACK_BAL_MAX") ? atoi(getenv("JXGPU_SBBACK_BAL_MAX")) : 7;    // at most `hi` units per CU
+    constexpr int hi = 7;                                        // at most seven units per CU
     return env != 0 && units > lo * device_cus() && units <= hi * device_cus();
 }
 // slabs of the balanced form: R = ceil(units / (7 CUs)) full rounds of CUs workgroups with the units dealt evenly, 4 .. 7 units

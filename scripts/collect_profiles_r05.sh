@@ -35,10 +35,10 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "c4" ]; then
   rm -f $O/c4/stats/*/*kernel_trace.csv
   for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do
     name=${pass%%:*}; ctr=${pass#*:}
-    timeout 900 rocprofv3 --pmc $ctr --kernel-include-regex "$RX" --output-format csv -d $O/c4/$name -- $B4 > $O/c4_$name.log 2>&1
+    timeout 700 rocprofv3 --pmc $ctr --kernel-include-regex "$RX" --output-format csv -d $O/c4/$name -- $B4 > $O/c4_$name.log 2>&1
     python3 scripts/pmc_summarize.py $O/c4/$name $O/c4/$name.json $name > /dev/null; rm -rf $O/c4/$name
   done
-  timeout 900 rocprofv3 --pmc $MF --kernel-include-regex "$RX" --output-format csv -d $O/c4/mfma -- $B4 > $O/c4_mfma.log 2>&1
+  timeout 700 rocprofv3 --pmc $MF --kernel-include-regex "$RX" --output-format csv -d $O/c4/mfma -- $B4 > $O/c4_mfma.log 2>&1
   python3 scripts/pmc_summarize.py $O/c4/mfma $O/c4/mfma.json mfma > /dev/null; rm -rf $O/c4/mfma
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then

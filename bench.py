@@ -920,8 +920,14 @@ def main():
                 _PMC_SHAPE.update(n=50000, m=500000)
                 q2k = res["extra_c4_1gpu"]["roofline"]["kernel"] if res["extra_c4_1gpu"].get("roofline") else None
                 if q2k:
-                    tr4, tr4_src = pmc_traffic_bytes("jx::" + q2k, fetch_scale=1.0)
-                    res["extra_c4_1gpu"]["roofline"].update(traffic=tr4, traffic_source=tr4_src)
+                    # the two-groups-per-pass kernel's raw FETCH_SIZE is 0.53 x the n^3 / 16 bytes it must read (16-byte row reads:
+                    # the guide's x2 applies, calibrated on the known byte count; profiles/r05a_c4_pmc_hbm_traffic.json), WRITE as is
+                    tr4, tr4_src = pmc_traffic_bytes("jx::" + q2k, fetch_scale=2.0 if "pair" in q2k else 1.0)
+                    mu4, _ = pmc_mfma_util(q2k)
+                    nl = max(1, int(res["extra_c4_1gpu"]["roofline"].get("launches_per_decomposition", 1)))
+                    res["extra_c4_1gpu"]["roofline"].update(
+                        traffic=tr4, traffic_source=tr4_src, mfma_util_pmc=mu4,
+                        traffic_over_algorithmic=(tr4 * nl / (2.0 * 50000.0 ** 3 / 16.0)) if tr4 else None)
                 _PMC_SHAPE.update(n=int(n), m=int(m))
                 if not args.no_cpu_baseline:
                     # the north star's >= 10 x is quoted on THIS configuration: the oracle on the host cores, BASELINE.md section 2's
@@ -961,6 +967,40 @@ def main():
             except Exception as e:
                 res["extra_c5_splmm"] = res.get("extra_c5_splmm", {"error": repr(e)})
                 res["extra_c5_pcg"] = res.get("extra_c5_pcg", {"error": repr(e)})
+        # What the multi-rank code path costs BEFORE any wire time (no multi-GPU box exists on this pool): the same
+        # configuration once more in a child process with ONE rank on the RCCL path -- the GRM partials through the lower-triangle
+        # pack / ncclAllReduce / unpack, the band reduction in its sharded launch sequence (per block row, two collectives per
+        # panel through the counted callback), the agreement checks, the column-sharded back-transformations with their gather --
+        # against the unsharded stages of the main leg above.
+        if (world == 1 and not distributed and not args.no_extra and args.mode == "lmm" and args.missing == 0.0
+                and (int(n), int(args.m)) == (20000, 200000) and not os.environ.get("JXGPU_BENCH_CHILD")):
+            try:
+                import socket
+                import subprocess
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                env = dict(os.environ, JXGPU_BENCH_FORCE_DIST="1", JXGPU_DIST_EIGH_FORCE="1", JXGPU_BENCH_CHILD="1",
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"]
+                cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                if cp.returncode != 0 or not line:
+                    raise RuntimeError(f"child rc={cp.returncode}: {cp.stderr[-400:]}")
+                ch = json.loads(line[-1])
+                a, b = res["stages_ms_per_step"], ch["stages_ms_per_step"]
+                keys = ("grm", "eigh", "eigh_band_reduction", "eigh_bulge_chasing", "eigh_divide_conquer", "eigh_q1_backtransform",
+                        "eigh_q2_backtransform_kernel", "scan")
+                panels = int(math.ceil((n - 64 - 1) / 64.0))
+                res["dist_overhead"] = {
+                    "what": "one rank, RCCL (nccl backend, world size 1): the sharded launch sequences and their collectives against "
+                            "the unsharded stages of the main leg; NOT a multi-GPU measurement",
+                    "unsharded_ms": {k: a.get(k) for k in keys}, "one_rank_rccl_ms": {k: b.get(k) for k in keys},
+                    "delta_ms": {k: (b.get(k) - a.get(k)) if (a.get(k) is not None and b.get(k) is not None) else None for k in keys},
+                    "band_reduction_ms_per_panel": (b.get("eigh_band_reduction", 0.0) - a.get("eigh_band_reduction", 0.0)) / max(1, panels),
+                    "panels": panels, "ms_per_step": ch["ms_per_step"], "parallelism": ch["config"]["parallelism"]}
+            except Exception as e:   # noqa: BLE001 - a reported side measurement
+                res["dist_overhead"] = {"error": repr(e)}
         # RCCL writes its version banner through C stdio (buffered when stdout is a pipe): flush it first so that the
         # JSON line is the last line on stdout
         try:

@@ -275,6 +275,13 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         return 0;
     };
 
+    static const bool pcg_trace = getenv("JXGPU_PCG_TRACE") != nullptr;
+    auto tmark = [&](const char *what) {
+        if (!pcg_trace) return;
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "[jxgpu pcg] %-28s %8.1f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+    };
     auto setup = [&]() -> int {
         if (row_indices)
             for (int64_t j = 0; j < eff_m; ++j)
@@ -303,20 +310,27 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
             d_rowidx = drow.as<int64_t>();
         }
+        tmark("checks + small uploads");
         if (p32.alloc((size_t)nt * (size_t)eff_m * 32)) return 1;
+        tmark("hipMalloc p32");
         if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m, p32.as<uint8_t>(), st))
             return 1;
+        tmark("repack_p32");
         if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m)) return 1;
         JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
         if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
         if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
         // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
+        tmark("row counts");
         if (t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m))) return 1;
+        tmark("hipMalloc t32");
         if (dwork.alloc(16 * (size_t)eff_m + 16)) return 1;
         if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
+        tmark("transpose");
         std::vector<int32_t> cnt(3 * (size_t)eff_m);
         JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
         dcnt.release();
+        tmark("counts download");
 
         // pre-pass (row_major_block_prepare_rhs_diag_f32, rrblup.rs:396-466): the f64 sums over the f32 row values are
         // count-weighted sums of the three genotype values
@@ -368,6 +382,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         JX_LAUNCH_CHECK();
         JX_HIP(hipMemcpyAsync(p, z, mb, hipMemcpyDeviceToDevice, st));
         if (scalar(0, rz_old)) return 1;
+        tmark("pre-pass, b, first z");
         return 0;
     };
     int lerr = setup() ? 1 : 0;

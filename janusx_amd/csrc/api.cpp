@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <mutex>
 #include <new>
+#include <chrono>
 #include <vector>
 
 #include "jx_common.h"
@@ -182,6 +183,14 @@ static int stage_p32(const uint8_t *packed, int64_t m, int n_samples, const Samp
                         std::to_string((long long)(need / 1048576.0)) + " MiB of HBM, " + std::to_string((long long)(fr >> 20)) +
                         " MiB are free (split the SNP rows over several calls)");
     }
+    static const bool trace = getenv("JXGPU_PCG_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "[jxgpu stage_p32] %-20s %8.1f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     DevBuf raw, didx;
     const uint8_t *d_raw = packed;
     if (!on_device) {
@@ -195,10 +204,13 @@ static int stage_p32(const uint8_t *packed, int64_t m, int n_samples, const Samp
         JX_HIP(hipMemcpy(didx.p, sel.idx.data(), sizeof(int32_t) * sel.idx.size(), hipMemcpyHostToDevice));
         d_idx = didx.as<int32_t>();
     }
+    mark("index upload");
     if (p32.alloc((size_t)nt * (size_t)m * 32)) return 1;
+    mark("hipMalloc p32");
     if (jxg_repack_p32(d_raw, bps, n_samples, m, d_idx, sel.n, nullptr, m, p32.as<uint8_t>(), nullptr))
         return 1;
     JX_HIP(hipDeviceSynchronize());
+    mark("repack");
     return 0;
 }
 

@@ -298,8 +298,17 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
                             " MiB of HBM, " + std::to_string((long long)(fr >> 20)) +
                             " MiB are free (deal the markers over more ranks: dist.enable_distributed_pcg)");
         }
+        // Every allocation of the solve BEFORE the first kernel is launched: a hipMalloc issued while kernels are in flight takes
+        // hundreds of milliseconds to seconds on this stack (measured at BASELINE configs[4]: set-up 2.3 - 3.6 s with the
+        // allocations interleaved with the repack / transpose launches, 0.33 s with the device idle at every allocation)
+        if (!on_device && raw.alloc((size_t)(m_total * bps))) return 1;
+        if (p32.alloc((size_t)nt * (size_t)eff_m * 32) || t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m)) ||
+            dwork.alloc(16 * (size_t)eff_m + 16) || dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) ||
+            dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m) || dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) ||
+            dz.alloc(mb) || dp.alloc(mb) || dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
+            dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
+            return 1;
         if (!on_device) {
-            if (raw.alloc((size_t)(m_total * bps))) return 1;
             JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
             d_raw = raw.as<uint8_t>();
         }
@@ -310,26 +319,18 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
             d_rowidx = drow.as<int64_t>();
         }
-        tmark("checks + small uploads");
-        if (p32.alloc((size_t)nt * (size_t)eff_m * 32)) return 1;
-        tmark("hipMalloc p32");
+        tmark("allocations + small uploads");
         if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m, p32.as<uint8_t>(), st))
             return 1;
         tmark("repack_p32");
-        if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m)) return 1;
         JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
-        if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m)) return 1;
         if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
         // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
         tmark("row counts");
-        if (t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m))) return 1;
-        tmark("hipMalloc t32");
-        if (dwork.alloc(16 * (size_t)eff_m + 16)) return 1;
         if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
         tmark("transpose");
         std::vector<int32_t> cnt(3 * (size_t)eff_m);
         JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
-        dcnt.release();
         tmark("counts download");
 
         // pre-pass (row_major_block_prepare_rhs_diag_f32, rrblup.rs:396-466): the f64 sums over the f32 row values are
@@ -350,10 +351,6 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             if (!(d > 1e-12f)) d = 1e-12f;
             dinv[j] = 1.0f / d;
         }
-        if (dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) || dz.alloc(mb) || dp.alloc(mb) ||
-            dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
-            dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
-            return 1;
         JX_HIP(hipMemcpy(dmu.p, mu.data(), mb, hipMemcpyHostToDevice));
         JX_HIP(hipMemcpy(ddinv.p, dinv.data(), mb, hipMemcpyHostToDevice));
         x = dx.as<float>(), r = dr.as<float>(), z = dz.as<float>(), p = dp.as<float>(), ap = dap.as<float>();
@@ -509,6 +506,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         DevBuf dte, p32t;
         auto pred_test = [&]() -> int {
             // the training images are no longer needed: at biobank size they are what the test image has to fit beside
+            JX_HIP(hipStreamSynchronize(st));                 // allocate / free with the device idle (see setup)
             t32.release();
             if (dte.alloc(sizeof(int32_t) * (size_t)n_test)) return 1;
             JX_HIP(hipMemcpy(dte.p, te32.data(), sizeof(int32_t) * (size_t)n_test, hipMemcpyHostToDevice));
@@ -663,24 +661,32 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m_total * bps), hipMemcpyHostToDevice));
         d_raw = raw.as<uint8_t>();
     }
-    if (didx.alloc(sizeof(int32_t) * (size_t)n)) return 1;
+    static const bool he_trace = getenv("JXGPU_PCG_TRACE") != nullptr;
+    const auto he_t0 = std::chrono::steady_clock::now();
+    auto hmark = [&](const char *what) {
+        if (!he_trace) return;
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "[jxgpu he ] %-28s %8.1f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - he_t0).count());
+    };
+    // every allocation before the first kernel launch (a hipMalloc behind kernels in flight costs up to seconds: see the PCG)
+    if (p32.alloc((size_t)num_tiles(n) * (size_t)eff_m * 32) || t32.alloc((size_t)jxg_t32_bytes(n, (int)eff_m)) ||
+        dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) || dwork.alloc(16 * (size_t)eff_m + 16) ||
+        dvn.alloc(sizeof(double) * (size_t)n) || dvm.alloc(sizeof(double) * (size_t)eff_m) ||
+        didx.alloc(sizeof(int32_t) * (size_t)n) || (row_indices && drow.alloc(sizeof(int64_t) * (size_t)eff_m)))
+        return 1;
     JX_HIP(hipMemcpy(didx.p, tr32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     const int64_t *d_rowidx = nullptr;
     if (row_indices) {
-        if (drow.alloc(sizeof(int64_t) * (size_t)eff_m)) return 1;
         JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
         d_rowidx = drow.as<int64_t>();
     }
-    if (p32.alloc((size_t)num_tiles(n) * (size_t)eff_m * 32)) return 1;
     if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n, d_rowidx, eff_m, p32.as<uint8_t>(), st))
         return 1;
     JX_HIP(hipStreamSynchronize(st));
     raw.release();
-    if (t32.alloc((size_t)jxg_t32_bytes(n, (int)eff_m))) return 1;
     if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
-    if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) || dwork.alloc(16 * (size_t)eff_m + 16) ||
-        dvn.alloc(sizeof(double) * (size_t)n) || dvm.alloc(sizeof(double) * (size_t)eff_m))
-        return 1;
+    hmark("images");
     JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
     const float ms = (float)m_scale;
     const float inv_m = 1.0f / (ms > 1.0f ? ms : 1.0f);
@@ -718,6 +724,7 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
     std::vector<float> y32(n), kv, probe(n);
     for (int i = 0; i < n; ++i) y32[i] = (float)yp[i];
     if (apply_k(y32, kv)) return 1;
+    hmark("first application");
     double y_ky = 0.0, y_y = 0.0;
     for (int i = 0; i < n; ++i) {
         y_ky += (double)y32[i] * (double)kv[i];
@@ -755,6 +762,7 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         trk /= (double)trace_samples;
         trk2 /= (double)trace_samples;
     }
+    hmark("all probes");
     g_last_ms[22] = (float)he_ms;
     g_last_ms[23] = (float)he_apps;
     out5[0] = y_ky;

@@ -61,6 +61,10 @@ int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, int64_t m_sr
 /* A1. per-SNP (missing, het, hom_alt) counts over the n_sel real samples of a P32 buffer
  * -> d_counts (m,3) int32.  src/io/gfreader.rs:1378-1395 `count_packed_row_counts`. */
 int jxg_row_counts_p32(const uint8_t *d_p32, int64_t m, int n_sel, int32_t *d_counts, void *stream);
+/* The same counts over a duplicate-free sample subset straight from a device-resident PLINK payload (m rows of bps bytes), without a
+ * P32 image: d_mask (bps bytes) has both bits set at every selected sample.  jx_row_counts takes this route for device payloads. */
+int jxg_row_counts_raw_masked(const uint8_t *d_packed, int64_t bps, int64_t m, const uint8_t *d_mask, int32_t *d_counts,
+                              void *stream);
 
 /* A3+A4. acc(lower tiles) += Z Z^T over the SNPs rows[k], k in [0, mk), where
  * z = lut[k][code] (4 f32 values per SNP indexed by the 2-bit code; lut[k][1] must be 0).

@@ -30,6 +30,7 @@ SIGNATURES = {
     "jxg_num_tiles": [c_i],
     "jxg_repack_p32": [c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_l, c_p, c_p],
     "jxg_row_counts_p32": [c_p, c_l, c_i, c_p, c_p],
+    "jxg_row_counts_raw_masked": [c_p, c_l, c_l, c_p, c_p, c_p],
     "jxg_grm_accumulate": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "jxg_grm_accumulate_rows": [c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "jxg_grm_finalize": [c_p, c_i, c_d, c_p, c_i, c_p],

@@ -284,6 +284,30 @@ extern "C" int jx_row_counts(const uint8_t *packed, int64_t m, int n_samples, co
     SampleSel sel;
     if (make_sample_sel(sample_indices, n_sel, n_samples, sel)) return 1;
     DevBuf p32, dcnt;
+    if (is_device_ptr(packed)) {
+        // a payload that already lives in HBM: counts straight from it under a sample mask (no 40 GB image allocated, filled and
+        // freed for three numbers per SNP) -- when the selection has no duplicate (a mask counts a sample once)
+        const int64_t bps = ((int64_t)n_samples + 3) / 4;
+        std::vector<uint8_t> mask((size_t)bps, 0);
+        bool dup = false;
+        if (sel.identity) {
+            for (int i = 0; i < n_samples; ++i) mask[(size_t)(i >> 2)] |= (uint8_t)(3u << (2 * (i & 3)));
+        } else {
+            for (int32_t v : sel.idx) {
+                const uint8_t bit = (uint8_t)(3u << (2 * (v & 3)));
+                if (mask[(size_t)(v >> 2)] & bit) dup = true;
+                mask[(size_t)(v >> 2)] |= bit;
+            }
+        }
+        if (!dup) {
+            DevBuf dmask;
+            if (dmask.alloc((size_t)bps) || dcnt.alloc(sizeof(int32_t) * 3 * (size_t)m)) return 1;
+            JX_HIP(hipMemcpy(dmask.p, mask.data(), (size_t)bps, hipMemcpyHostToDevice));
+            if (jxg_row_counts_raw_masked(packed, bps, m, dmask.as<uint8_t>(), dcnt.as<int32_t>(), nullptr)) return 1;
+            JX_HIP(hipMemcpy(out_counts, dcnt.p, sizeof(int32_t) * 3 * (size_t)m, hipMemcpyDeviceToHost));
+            return 0;
+        }
+    }
     if (stage_p32(packed, m, n_samples, sel, p32)) return 1;
     if (dcnt.alloc(sizeof(int32_t) * 3 * (size_t)m)) return 1;
     if (jxg_row_counts_p32(p32.as<uint8_t>(), m, sel.n, dcnt.as<int32_t>(), nullptr)) return 1;

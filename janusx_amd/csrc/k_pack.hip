@@ -86,6 +86,49 @@ __global__ __launch_bounds__(256) void row_counts_p32_kernel(const uint4 *__rest
     if (hom) atomicAdd(&counts[j * 3 + 2], hom);
 }
 
+// counts over a SAMPLE SUBSET straight from the PLINK payload (no P32 image): one wave per SNP row, lanes stride over the row's
+// bytes four at a time where alignment allows; `mask` (bps bytes) holds 11 at every selected sample's two bits.  The selection
+// must be duplicate-free (a mask cannot count a sample twice); order does not matter for counts.
+__global__ __launch_bounds__(256) void row_counts_raw_masked_kernel(const uint8_t *__restrict__ src, int64_t bps, int64_t m,
+                                                                    const uint8_t *__restrict__ mask,
+                                                                    int32_t *__restrict__ counts) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= m) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t *row = src + j * bps;
+    int mis = 0, het = 0, hom = 0;
+    auto add = [&](uint32_t w, uint32_t mk) {
+        const uint32_t sel = mk & 0x55555555u;                 // one bit per selected sample
+        const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+        mis += __popc(lo & ~hi & sel);
+        het += __popc(hi & ~lo & sel);
+        hom += __popc(hi & lo & sel);
+    };
+    // head bytes up to the first 4-byte boundary of this row, then dwords, then the tail
+    const int64_t mis_al = (4 - ((uintptr_t)row & 3)) & 3;
+    const int64_t head = mis_al < bps ? mis_al : bps;
+    for (int64_t b = lane; b < head; b += 64) add(row[b], mask[b]);
+    const int64_t nd = (bps - head) >> 2;
+    const uint32_t *rw = reinterpret_cast<const uint32_t *>(row + head);
+    for (int64_t d = lane; d < nd; d += 64) {
+        const uint8_t *mp = mask + head + 4 * d;
+        const uint32_t mk = (uint32_t)mp[0] | ((uint32_t)mp[1] << 8) | ((uint32_t)mp[2] << 16) | ((uint32_t)mp[3] << 24);
+        add(rw[d], mk);
+    }
+    for (int64_t b = head + 4 * nd + lane; b < bps; b += 64) add(row[b], mask[b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mis += __shfl_xor(mis, off, 64);
+        het += __shfl_xor(het, off, 64);
+        hom += __shfl_xor(hom, off, 64);
+    }
+    if (lane == 0) {
+        counts[j * 3 + 0] = mis;
+        counts[j * 3 + 1] = het;
+        counts[j * 3 + 2] = hom;
+    }
+}
+
 __global__ void fix_pad_missing_kernel(int32_t *counts, int64_t m, int pad) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < m) counts[j * 3] -= pad;
@@ -172,3 +215,17 @@ extern "C" int jxg_cast_f64_to_f32(const double *d_src, float *d_dst, int64_t co
     JX_LAUNCH_CHECK();
     return 0;
 }
+
+// Counts over a duplicate-free sample subset straight from a DEVICE-resident PLINK payload (m x bps bytes): d_mask (bps bytes) holds
+// 11 at the selected samples.  No P32 image: a 50 GB payload is read once (the staged form allocates, fills and frees a 40 GB image).
+extern "C" int jxg_row_counts_raw_masked(const uint8_t *d_packed, int64_t bps, int64_t m, const uint8_t *d_mask, int32_t *d_counts,
+                                         void *stream) {
+    if (m <= 0) return 0;
+    const int64_t blocks = (m + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail("jxg_row_counts_raw_masked: grid too large");
+    hipLaunchKernelGGL(row_counts_raw_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_packed, bps, m,
+                       d_mask, d_counts);
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+

@@ -179,6 +179,27 @@ def panel_small():
     return n, m, packed, g
 
 
+def test_row_counts_of_a_device_payload_under_a_sample_mask(oracle):
+    """`bed_row_counts` on a payload that already lives in HBM counts straight from it under a sample mask (no P32 image: at
+    BASELINE configs[4] that image is 40 GB per call): all samples, a subset in arbitrary order, rows that are not 4-byte aligned
+    (odd bytes per SNP), a row count that does not fill the last workgroup; a list with a duplicate takes the staged route."""
+    import torch
+    from janusx_amd import janusx as jxrs
+    for n, m in ((331, 203), (1024, 64), (77, 5)):
+        packed, g = bed.synth_panel_numpy(n, m, seed=n, missing_rate=0.05)
+        pt = torch.from_numpy(packed).cuda()
+        mi, he, ho = oracle.row_counts(packed, n)
+        c = jxrs.bed_row_counts(pt, n)
+        assert np.array_equal(c, np.stack([mi, he, ho], 1))
+        sub = np.random.default_rng(n).permutation(n)[: max(3, n // 3)].astype(np.int64)
+        mi, he, ho = oracle.row_counts(packed, n, sub)
+        assert np.array_equal(jxrs.bed_row_counts(pt, n, sub), np.stack([mi, he, ho], 1))
+        assert np.array_equal(jxrs.bed_row_counts(packed, n, sub), np.stack([mi, he, ho], 1))          # host payload: staged route
+        dup = np.concatenate([sub[:5], sub[:2]])
+        mi, he, ho = oracle.row_counts(packed, n, dup)
+        assert np.array_equal(jxrs.bed_row_counts(pt, n, dup), np.stack([mi, he, ho], 1))
+
+
 def test_repack_and_counts(oracle, panel_small):
     import torch
     from janusx_amd import pipeline

@@ -599,6 +599,11 @@ int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, 
  * the ranks through allreduce(user), which must add the first jx_pcg_dist_count() doubles of d_staging in place on every
  * rank; predictions and out_scalars are complete on every rank, out_beta is the shard's.  world <= 1 or allreduce NULL: off. */
 int jx_pcg_set_dist(int rank, int world, int (*allreduce)(void *), void *user, double *d_staging, int64_t staging_doubles);
+/* Image scope of the PCG / Haseman-Elston routes: between jx_pcg_image_scope(1) and jx_pcg_image_scope(0) the two images of the
+ * training payload (SNP-major P32, sample-major T32) that jx_he_traces_packed / jx_rrblup_pcg_packed build stay in HBM, keyed by
+ * (payload pointer, row list, training samples), and a second call on the same inputs reuses them (`jx gs -rrBLUP -rr-solver pcg`:
+ * lambda by HE, then the solve).  The caller guarantees that the payload does not change inside the scope.  (0) frees them. */
+int jx_pcg_image_scope(int on);
 int64_t jx_pcg_dist_count(void);
 /* Exact marker-space rrBLUP on a resident payload: `rrblup_exact_snp_packed` (src/stats/rrblup.rs:3179-3490; cache
  * :1613-1899, fit :1951-2430).  A* = Z Z' - rs rs' / n_train over the training samples (f64), eigendecomposition, Brent on the

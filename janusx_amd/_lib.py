@@ -120,6 +120,7 @@ SIGNATURES = {
     "jx_he_traces_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_i, C.c_uint64, c_i, c_d, c_p],
     "jx_pcg_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l],
     "jx_pcg_dist_count": [],
+    "jx_pcg_image_scope": [c_i],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
     "jx_rrblup_exact_snp_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_p,
                                    c_p, c_p],

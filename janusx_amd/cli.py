@@ -22,6 +22,7 @@ lambda) beyond, `-rr-solver exact|fast|pcg` forces one (fast = exact sample-spac
 from __future__ import annotations
 
 import argparse
+import contextlib
 import math
 import os
 import sys
@@ -708,6 +709,16 @@ def cmd_gs_rrblup(args):
         t0k = time.perf_counter()
         k_std = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], None, method=2)
         print(f"standardised kernel of {n_all} samples over {m_eff_std} markers ({time.perf_counter() - t0k:.2f}s)")
+    pcg_payload = packed
+    if solver == "pcg":
+        # the PCG route streams the payload from HBM for the whole solve: upload it ONCE and hand the device tensor to both
+        # he_pcg_bed and rrblup_pcg_bed (their images of the training payload are shared inside `pcg_image_scope`)
+        try:
+            import torch
+            if torch.cuda.is_available() and 3.2 * packed.nbytes < torch.cuda.mem_get_info()[0]:
+                pcg_payload = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
+        except Exception:   # noqa: BLE001 - the host array works everywhere (uploaded per call)
+            pcg_payload = packed
     for ti in traits:
         name = names[ti]
         yv = np.array([ph[pos[s], ti] if s in pos else np.nan for s in fam])
@@ -717,6 +728,8 @@ def cmd_gs_rrblup(args):
             print(f"[{name}] only {len(train)} phenotyped samples, skipped")
             continue
         t1 = time.perf_counter()
+        scope = jxrs.pcg_image_scope() if solver == "pcg" else contextlib.nullcontext()
+        scope.__enter__()
         if solver in ("exact", "fast"):
             lam, src = None, "REML on the spectrum"
         elif args.lam is not None:
@@ -725,7 +738,7 @@ def cmd_gs_rrblup(args):
             # Haseman-Elston first (python/janusx/gs/workflow.py:5564 `he_first`): lambda_equation = lambda_k * m_effective
             try:
                 he = jxrs.he_pcg_bed("", train, yv[train], site_keep=keep, seed=args.seed if args.seed != 42 else 20260512,
-                                     packed=packed, packed_n_samples=n_all, maf=maf, row_flip=flip)
+                                     packed=pcg_payload, packed_n_samples=n_all, maf=maf, row_flip=flip)
             except RuntimeError as e:   # e.g. the stochastic traces violate the PSD bound on a small panel
                 he = None
                 lam, src = None, f"HE failed ({e})"
@@ -758,7 +771,7 @@ def cmd_gs_rrblup(args):
                 return jxrs.rrblup_exact_snp_packed(packed, n_all, tr, yv[tr], te if len(te) else None, site_keep=keep,
                                                     maf=maf, row_flip=flip)
             return jxrs.rrblup_pcg_bed("", tr, yv[tr], te if len(te) else None, site_keep=keep, lambda_value=lam,
-                                       tol=args.tol, max_iter=args.max_iter, packed=packed, packed_n_samples=n_all,
+                                       tol=args.tol, max_iter=args.max_iter, packed=pcg_payload, packed_n_samples=n_all,
                                        maf=maf, row_flip=flip)
 
         if args.cv and args.cv > 1:
@@ -774,6 +787,7 @@ def cmd_gs_rrblup(args):
             r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
             print(f"[{name}] rrBLUP {args.cv}-fold CV: pearson={rr:.4f} R2={r2:.4f}")
         full = fit_predict(train, test)
+        scope.__exit__(None, None, None)
         if not (args.cv and args.cv > 1):
             pred[train] = full[0].ravel()
         if len(test):

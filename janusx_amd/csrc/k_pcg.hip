@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "jx_common.h"
@@ -212,6 +213,80 @@ extern "C" int jx_pcg_set_dist(int rank, int world, int (*allreduce)(void *), vo
 }
 extern "C" int64_t jx_pcg_dist_count(void) { return g_pcg_dist.count; }
 
+// ---- image scope -------------------------------------------------------------------------------------------------------
+// `jx gs -rrBLUP -rr-solver pcg` calls he_pcg_bed (lambda) and then rrblup_pcg_bed on the SAME payload, rows and training samples.
+// Each of them builds the same two images of the training payload (SNP-major P32 and sample-major T32: 40 GB each at BASELINE
+// configs[4]) and frees them again -- and a hipMalloc right behind the hipFree of a 40 GB block stalls for seconds on this stack
+// (measured: he_pcg_bed 1.7 s alone, 6.7 s directly behind rrblup_pcg_bed).  Inside a scope (jx_pcg_image_scope(1) ... (0), opened by
+// the caller that knows the payload does not change in between) the images of the last (payload pointer, rows, samples) stay in HBM
+// and the second call reuses them: no allocation, no repack, no transpose.  Outside a scope nothing is kept.
+namespace {
+struct PcgImages {
+    bool scope = false, valid = false;
+    const void *src = nullptr;
+    int64_t m_total = 0, eff_m = 0;
+    int n_samples = 0, n_train = 0;
+    uint64_t h_train = 0, h_rows = 0;
+    DevBuf p32, t32;
+    void drop() {
+        p32.release();
+        t32.release();
+        valid = false;
+    }
+};
+PcgImages g_img;
+std::mutex g_img_mu;
+uint64_t img_hash(const void *p, size_t bytes) {
+    uint64_t h = 1469598103934665603ull;
+    const uint8_t *b = static_cast<const uint8_t *>(p);
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+// -> 0 and *p32 / *t32 (device pointers: borrowed from the scope's cache, or owned by `own_p32` / `own_t32`); `built` = the images
+// had to be made (the caller then continues with its own pre-pass as before)
+int pcg_images(const uint8_t *d_raw, int64_t bps, int64_t m_total, int n_samples, const int64_t *row_indices,
+               const int64_t *d_rowidx, int64_t eff_m, const int64_t *train_idx, const int32_t *d_train32, int n_train,
+               DevBuf &own_p32, DevBuf &own_t32, const uint8_t **p32, const uint8_t **t32, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    const uint64_t ht = img_hash(train_idx, sizeof(int64_t) * (size_t)n_train);
+    const uint64_t hr = row_indices ? img_hash(row_indices, sizeof(int64_t) * (size_t)eff_m) : 0ull;
+    PcgImages &G = g_img;
+    if (G.scope && G.valid && G.src == (const void *)d_raw && G.m_total == m_total && G.eff_m == eff_m && G.n_samples == n_samples &&
+        G.n_train == n_train && G.h_train == ht && G.h_rows == hr) {
+        *p32 = G.p32.as<uint8_t>();
+        *t32 = G.t32.as<uint8_t>();
+        return 0;
+    }
+    const size_t b_p32 = (size_t)num_tiles(n_train) * (size_t)eff_m * 32, b_t32 = (size_t)jxg_t32_bytes(n_train, (int)eff_m);
+    DevBuf &dp = G.scope ? G.p32 : own_p32, &dt = G.scope ? G.t32 : own_t32;
+    if (G.scope) G.valid = false;
+    if (dp.bytes < b_p32 && dp.alloc(b_p32)) return 1;
+    if (dt.bytes < b_t32 && dt.alloc(b_t32)) return 1;
+    if (jxg_repack_p32(d_raw, bps, n_samples, m_total, d_train32, n_train, d_rowidx, eff_m, dp.as<uint8_t>(), st)) return 1;
+    if (jxg_p32_transpose(dp.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, dt.as<uint8_t>(), st)) return 1;
+    if (G.scope) {
+        G.valid = true;
+        G.src = d_raw;
+        G.m_total = m_total;
+        G.eff_m = eff_m;
+        G.n_samples = n_samples;
+        G.n_train = n_train;
+        G.h_train = ht;
+        G.h_rows = hr;
+    }
+    *p32 = dp.as<uint8_t>();
+    *t32 = dt.as<uint8_t>();
+    return 0;
+}
+}  // namespace
+
+extern "C" int jx_pcg_image_scope(int on) {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    g_img.drop();
+    g_img.scope = on != 0;
+    return 0;
+}
+
 extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int n_samples, const int64_t *row_indices,
                                     int64_t eff_m, const float *value_lut, const int64_t *train_idx, int n_train,
                                     const double *y_train, const int64_t *test_idx, int n_test, double lambda_value,
@@ -264,7 +339,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     const size_t mb = sizeof(float) * (size_t)eff_m;
     float *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *ap = nullptr;
     double *v64m = nullptr, *v64n = nullptr, *sc = nullptr;
-    const uint8_t *P = nullptr;
+    const uint8_t *P = nullptr, *T32 = nullptr;     // SNP-major / sample-major image of the training payload
     const float *L = nullptr;
     const unsigned gm = pcg_grid(eff_m), gmf = pcg_grid_full(eff_m), gnf = pcg_grid_full(n_train);
     double sum_ss = 0.0, bb = 0.0, rz_old = 0.0;
@@ -302,8 +377,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         // hundreds of milliseconds to seconds on this stack (measured at BASELINE configs[4]: set-up 2.3 - 3.6 s with the
         // allocations interleaved with the repack / transpose launches, 0.33 s with the device idle at every allocation)
         if (!on_device && raw.alloc((size_t)(m_total * bps))) return 1;
-        if (p32.alloc((size_t)nt * (size_t)eff_m * 32) || t32.alloc((size_t)jxg_t32_bytes(n_train, (int)eff_m)) ||
-            dwork.alloc(16 * (size_t)eff_m + 16) || dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) ||
+        if (dwork.alloc(16 * (size_t)eff_m + 16) || dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) ||
             dcnt.alloc(sizeof(int32_t) * 3 * (size_t)eff_m) || dmu.alloc(mb) || ddinv.alloc(mb) || dx.alloc(mb) || dr.alloc(mb) ||
             dz.alloc(mb) || dp.alloc(mb) || dap.alloc(mb) || dv64m.alloc(sizeof(double) * (size_t)eff_m) ||
             dv64n.alloc(sizeof(double) * (size_t)(n_train > n_test ? n_train : n_test)) || dsc.alloc(sizeof(double) * 8))
@@ -320,15 +394,14 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
             d_rowidx = drow.as<int64_t>();
         }
         tmark("allocations + small uploads");
-        if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n_train, d_rowidx, eff_m, p32.as<uint8_t>(), st))
+        // the two images of the training payload: made here (allocated with the device idle), or borrowed from the caller's scope
+        if (pcg_images(d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m, train_idx, didx.as<int32_t>(), n_train, p32, t32,
+                       &P, &T32, st))
             return 1;
-        tmark("repack_p32");
+        tmark("images (repack + transpose, or the scope's)");
         JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
-        if (jxg_row_counts_p32(p32.as<uint8_t>(), eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
-        // sample-major image for the Z'p half (one transpose per solve) + its per-iteration weight workspace
+        if (jxg_row_counts_p32(P, eff_m, n_train, dcnt.as<int32_t>(), st)) return 1;
         tmark("row counts");
-        if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
-        tmark("transpose");
         std::vector<int32_t> cnt(3 * (size_t)eff_m);
         JX_HIP(hipMemcpy(cnt.data(), dcnt.p, sizeof(int32_t) * 3 * (size_t)eff_m, hipMemcpyDeviceToHost));
         tmark("counts download");
@@ -355,7 +428,6 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         JX_HIP(hipMemcpy(ddinv.p, dinv.data(), mb, hipMemcpyHostToDevice));
         x = dx.as<float>(), r = dr.as<float>(), z = dz.as<float>(), p = dp.as<float>(), ap = dap.as<float>();
         v64m = dv64m.as<double>(), v64n = dv64n.as<double>(), sc = dsc.as<double>();
-        P = p32.as<uint8_t>();
         L = dlut.as<float>();
         // b = Z y_c (f32 GEMV in the reference; f64 accumulation rounded once here)
         {
@@ -407,7 +479,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
                 hipLaunchKernelGGL(pcg_widen_kernel, dim3(gmf), dim3(PCG_T), 0, st, p, v64m, eff_m);
                 JX_LAUNCH_CHECK();
                 JX_HIP(hipEventRecord(ev[0], st));
-                if (jxg_packed_dot_t32(t32.as<uint8_t>(), n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
+                if (jxg_packed_dot_t32(T32, n_train, (int)eff_m, L, v64m, dwork.p, v64n, st)) return 1;   // Z'p
                 JX_HIP(hipEventRecord(ev[1], st));
                 JX_HIP(hipMemsetAsync(sc + 1, 0, 2 * sizeof(double), st));
                 hipLaunchKernelGGL(pcg_dot_kernel, dim3(gm), dim3(PCG_T), 0, st, dmu.as<float>(), p, eff_m, sc + 1);    // mu'p
@@ -507,7 +579,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         auto pred_test = [&]() -> int {
             // the training images are no longer needed: at biobank size they are what the test image has to fit beside
             JX_HIP(hipStreamSynchronize(st));                 // allocate / free with the device idle (see setup)
-            t32.release();
+            t32.release();                                    // (a no-op when the images belong to the caller's scope)
             if (dte.alloc(sizeof(int32_t) * (size_t)n_test)) return 1;
             JX_HIP(hipMemcpy(dte.p, te32.data(), sizeof(int32_t) * (size_t)n_test, hipMemcpyHostToDevice));
             const int ntt = num_tiles(n_test);
@@ -670,8 +742,7 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - he_t0).count());
     };
     // every allocation before the first kernel launch (a hipMalloc behind kernels in flight costs up to seconds: see the PCG)
-    if (p32.alloc((size_t)num_tiles(n) * (size_t)eff_m * 32) || t32.alloc((size_t)jxg_t32_bytes(n, (int)eff_m)) ||
-        dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) || dwork.alloc(16 * (size_t)eff_m + 16) ||
+    if (dlut.alloc(sizeof(float) * 4 * (size_t)eff_m) || dwork.alloc(16 * (size_t)eff_m + 16) ||
         dvn.alloc(sizeof(double) * (size_t)n) || dvm.alloc(sizeof(double) * (size_t)eff_m) ||
         didx.alloc(sizeof(int32_t) * (size_t)n) || (row_indices && drow.alloc(sizeof(int64_t) * (size_t)eff_m)))
         return 1;
@@ -681,11 +752,11 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         JX_HIP(hipMemcpy(drow.p, row_indices, sizeof(int64_t) * (size_t)eff_m, hipMemcpyHostToDevice));
         d_rowidx = drow.as<int64_t>();
     }
-    if (jxg_repack_p32(d_raw, bps, n_samples, m_total, didx.as<int32_t>(), n, d_rowidx, eff_m, p32.as<uint8_t>(), st))
+    const uint8_t *P32 = nullptr, *T32 = nullptr;
+    if (pcg_images(d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m, train_idx, didx.as<int32_t>(), n, p32, t32, &P32, &T32, st))
         return 1;
     JX_HIP(hipStreamSynchronize(st));
     raw.release();
-    if (jxg_p32_transpose(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, t32.as<uint8_t>(), st)) return 1;
     hmark("images");
     JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
     const float ms = (float)m_scale;
@@ -701,12 +772,12 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         for (int i = 0; i < n; ++i) h64[i] = (double)v[i];
         JX_HIP(hipMemcpyAsync(dvn.p, h64.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
         JX_HIP(hipEventRecord(hev[0], st));
-        if (jxg_packed_tdot_f32(p32.as<uint8_t>(), eff_m, n, nullptr, (int)eff_m, dlut.as<float>(), dvn.as<double>(),
+        if (jxg_packed_tdot_f32(P32, eff_m, n, nullptr, (int)eff_m, dlut.as<float>(), dvn.as<double>(),
                                 dvm.as<double>(), st))
             return 1;
         hipLaunchKernelGGL(pcg_round_kernel, dim3(pcg_grid_full(eff_m)), dim3(PCG_T), 0, st, dvm.as<double>(), eff_m);
         JX_LAUNCH_CHECK();
-        if (jxg_packed_dot_t32(t32.as<uint8_t>(), n, (int)eff_m, dlut.as<float>(), dvm.as<double>(), dwork.p,
+        if (jxg_packed_dot_t32(T32, n, (int)eff_m, dlut.as<float>(), dvm.as<double>(), dwork.p,
                                dvn.as<double>(), st))
             return 1;
         JX_HIP(hipEventRecord(hev[1], st));

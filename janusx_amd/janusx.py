@@ -3355,6 +3355,21 @@ def bed_packed_row_flip_mask(packed, n_samples):
     return out
 
 
+class pcg_image_scope:
+    """`with pcg_image_scope():` -- inside, the two images of the training payload that `he_pcg_bed` / `rrblup_pcg_bed` build
+    (SNP-major and sample-major, 40 GB each at BASELINE configs[4]) stay in HBM between the calls and a second call on the same
+    DEVICE payload, kept rows and training samples reuses them (`jx gs -rrBLUP -rr-solver pcg`: lambda by Haseman-Elston, then the
+    solve).  The caller guarantees the payload does not change inside the scope; leaving it frees the images (`jx_pcg_image_scope`)."""
+
+    def __enter__(self):
+        check(lib().jx_pcg_image_scope(1))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib().jx_pcg_image_scope(0)
+        return False
+
+
 def rrblup_pcg_bed(prefix, train_sample_indices, y_train, test_sample_indices=None, train_pred_local_indices=None,
                    site_keep=None, lambda_value=10000.0, tol=1e-4, max_iter=100, block_rows=4096, std_eps=1e-12,
                    threads=0, progress_callback=None, progress_every=0, compute_trainvar=False, packed=None,

@@ -135,10 +135,11 @@ def _exact_rotation_leg(oracle, oracle_c, gpu_stats, ref_f32, g_design, dh, s, x
     return be, se, pn
 
 
-def _tsv_rows_match_text(lines, expected_lines, max_flip_share=0.03):
+def _tsv_rows_match_text(lines, expected_lines, max_flip_share=0.05):
     """TSV rows against the text `oracle.format_assoc_row` renders from the ORACLE's numbers, byte for byte.  A row may differ only
     by a flip of the LAST printed digit of a numeric field (the two sides' beta / SE differ by ~1e-6 relative, which crosses a
-    rounding boundary of the 4-decimal / 4-significant-digit print now and then); such rows are counted and their share bounded.
+    rounding boundary of the 4-decimal print now and then; the 5-significant-digit chisq / p fields of strong SNPs may move by the
+    raw-p bound on top of that); such rows are counted and their share bounded.
     -> (rows equal byte for byte, rows with a last-digit flip)."""
     assert len(lines) == len(expected_lines)
     same = flips = 0
@@ -154,12 +155,16 @@ def _tsv_rows_match_text(lines, expected_lines, max_flip_share=0.03):
             continue
         fg, fe = got.split("\t"), exp.split("\t")
         assert len(fg) == len(fe) and fg[:5] == fe[:5], (got, exp)
-        for a, b in zip(fg[5:], fe[5:]):
+        for col, (a, b) in enumerate(zip(fg[5:], fe[5:]), start=5):
             if a == b:
                 continue
             assert a not in ("NaN", "inf") and b not in ("NaN", "inf"), (got, exp)
             unit = max(last_digit_unit(a), last_digit_unit(b))
-            assert abs(float(a) - float(b)) <= 1.0001 * unit, ("more than a last-digit flip", a, b, got, exp)
+            # af, miss, beta, se (4 decimals): a flip of the last printed digit.  chisq / pwald (5 significant digits): the two sides'
+            # beta / SE differ by ~1e-6 .. 1e-5 relative, which is z^2 times that on the tail probability (RAW_P_BOUND): up to a few
+            # units of the last digit on the strongest SNPs
+            slack = RAW_P_BOUND * abs(float(b)) if col >= 9 else 0.0
+            assert abs(float(a) - float(b)) <= 1.0001 * unit + slack, ("more than a last-digit flip", col, a, b, got, exp)
         flips += 1
     assert flips <= max(2, int(max_flip_share * len(lines))), (flips, len(lines))
     return same, flips

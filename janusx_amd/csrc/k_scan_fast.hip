@@ -1543,6 +1543,21 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         // (a process-wide buffer would be shared by concurrent calls on other streams while their kernels are in flight: ADVICE r4)
         const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
         void *sraw = nullptr;
+        {
+            // keep the stream-ordered pool's blocks across synchronisations (default threshold 0: every hipFreeAsync'ed block goes back to
+            // the driver at the next synchronisation and the next call pays a fresh allocation): 256 MB cover the largest call
+            static bool pool_set = false;
+            if (!pool_set) {
+                int dev = 0;
+                hipMemPool_t pool = nullptr;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+                    uint64_t thr = (uint64_t)256 << 20;
+                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+                }
+                (void)hipGetLastError();
+                pool_set = true;
+            }
+        }
         JX_HIP(hipMallocAsync(&sraw, need, st));
         struct SeriesFree {
             void *p;

@@ -455,6 +455,16 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         return 0;
     };
     int lerr = setup() ? 1 : 0;
+    // test hook: JXGPU_PCG_TEST_FAIL="<rank>:<where>" makes that rank fail on its own -- where = 0: in the set-up, k > 0: in the
+    // first half of iteration k -- so that the agreed failure (every rank leaves in the same collective) can be exercised
+    int test_fail_it = -1;
+    if (const char *tf = getenv("JXGPU_PCG_TEST_FAIL")) {
+        int r = -1, w = -1;
+        if (sscanf(tf, "%d:%d", &r, &w) == 2 && r == g_pcg_dist.rank && multi) {
+            if (w == 0 && !lerr) lerr = fail("jx_rrblup_pcg_packed: test hook, this rank fails in its set-up");
+            test_fail_it = w;
+        }
+    }
     const auto wall1 = std::chrono::steady_clock::now();
     {
         // markers sharded over ranks: |b|^2, the trace and r'z over all markers -- and every rank's setup verdict
@@ -487,6 +497,7 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
                 return 0;
             };
             if (!lerr) lerr = half1() ? 1 : 0;
+            if (!lerr && test_fail_it == it + 1) lerr = fail("jx_rrblup_pcg_packed: test hook, this rank fails in iteration " + std::to_string(it + 1));
             if (pcg_allreduce_dev_or_zero(v64n, n_train, sc + 1, 1, st, lerr)) return 1;      // this rank's markers -> all markers
             double denom = 0.0;
             auto half2 = [&]() -> int {

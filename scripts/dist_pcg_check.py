@@ -40,6 +40,24 @@ def main():
               maf=maf, row_flip=flip)
     single = jxrs.rrblup_pcg_bed("", tr, y[tr], te, **kw)
     assert jd.enable_distributed_pcg(max_samples=n)
+    if len(sys.argv) > 3 and sys.argv[3] == "fail":
+        # one rank fails on its own (JXGPU_PCG_TEST_FAIL=<rank>:<where>): EVERY rank must come back with an error from the same
+        # collective -- none may stay behind in an all-reduce (the launcher's timeout would end the test)
+        raised = 0.0
+        try:
+            jxrs.rrblup_pcg_bed("", tr, y[tr], te, **kw)
+        except RuntimeError as e:
+            raised = 1.0
+            print(f"rank {rank}: {e}", flush=True)
+        cnt = torch.tensor([raised], dtype=torch.float64)
+        dist.all_reduce(cnt)
+        if rank == 0:
+            print(f"{'DIST_PCG_FAIL_TOGETHER_OK' if cnt.item() == world else 'DIST_PCG_FAIL_TOGETHER_BAD'} raised={int(cnt.item())} world={world}",
+                  flush=True)
+        # the group is still usable: the healthy path runs afterwards
+        os.environ.pop("JXGPU_PCG_TEST_FAIL", None)
+        dist.destroy_process_group()
+        sys.exit(0 if cnt.item() == world else 1)
     shard = jxrs.rrblup_pcg_bed("", tr, y[tr], te, **kw)
     b1, b2 = single[9], shard[9]
     scale = float(np.max(np.abs(b1)))

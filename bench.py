@@ -590,6 +590,12 @@ def main():
             maf_l = np.minimum(pfr, np.float32(1.0) - pfr).astype(np.float32)      # `load_bed_2bit_packed` (gfreader.rs:4460-4485)
             flip_l = (alt.astype(np.float64) / (2.0 * np.maximum(nm, 1))) > 0.5      # `bed_packed_row_flip_mask`
             torch.cuda.reset_peak_memory_stats()
+            # the legs before this one handed ~100 GB back to the driver (empty_cache): on this stack the FIRST hipMalloc behind such a
+            # release waits seconds for it to complete.  Absorb that outside the timed region with a throw-away
+            # allocation, as a process that starts with this leg would never see it.
+            _settle = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            del _settle
+            torch.cuda.empty_cache()
             torch.cuda.synchronize()
             # as `jx gs -rrBLUP -rr-solver pcg` runs them: both calls inside one image scope (the second reuses the first's images)
             with jxrs.pcg_image_scope():

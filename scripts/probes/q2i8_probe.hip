@@ -375,6 +375,137 @@ template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16_kernel(con
         for (int j = 0; j < 4; ++j) base[(size_t)t * 256 + lane * 4 + j] = c[t][j];
 }
 
+template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16b_kernel(const uint8_t *img, double *slab, int nsteps, double magic,
+                                                                            double sc) {
+    extern __shared__ uint8_t lds[];
+    constexpr int P = 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t o = threadIdx.x * 16; o < 64 * 1024; o += (size_t)NWV * 64 * 16)
+        *reinterpret_cast<uint4 *>(lds + o) = *reinterpret_cast<const uint4 *>(img + (o & 0xffff));
+    __syncthreads();
+    double c[8][4];                                           // two groups per pass: 128-row window = 8 tiles of 16 rows
+    double *base = slab + ((size_t)blockIdx.x * NWV + wave) * (size_t)(nsteps * 4 + 8) * 256;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[t][j] = base[(size_t)t * 256 + lane * 4 + j];
+    const uint8_t *iu = lds + (size_t)lane * 16;
+    auto slice4 = [&](const double (&x)[4], int (&q)[P]) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t b = (uint64_t)__double_as_longlong(x[j] + magic);
+            lo[j] = (uint32_t)b ^ 0x80808080u;
+            hi[j] = (uint32_t)(b >> 32) ^ 0x80u;
+        }
+        const uint32_t t0 = perm(lo[1], lo[0], 0x05010400u), t1 = perm(lo[1], lo[0], 0x07030602u);
+        const uint32_t t2 = perm(lo[3], lo[2], 0x05010400u), t3 = perm(lo[3], lo[2], 0x07030602u);
+        q[5] = (int)perm(t2, t0, 0x05040100u);
+        q[4] = (int)perm(t2, t0, 0x07060302u);
+        q[3] = (int)perm(t3, t1, 0x05040100u);
+        q[2] = (int)perm(t3, t1, 0x07060302u);
+        const uint32_t u0 = perm(hi[1], hi[0], 0x05010400u), u2 = perm(hi[3], hi[2], 0x05010400u);
+        q[1] = (int)perm(u2, u0, 0x05040100u);
+        q[0] = (int)perm(u2, u0, 0x07060302u);
+    };
+    auto comb = [&](const i32x4b (&s)[P], int j) {
+        const int m01 = (s[0][j] << 8) + s[1][j], m23 = (s[2][j] << 8) + s[3][j], m45 = (s[4][j] << 8) + s[5][j];
+        double r = (double)m45;
+        r = fma(r, 0x1p-16, (double)m23);
+        return fma(r, 0x1p-16, (double)m01);
+    };
+    const i32x4b zero = {0, 0, 0, 0};
+    auto block = [&](int t0) {                                // window tiles t0 .. t0 + 5; fragments loaded in bursts of <= 12
+        int q[6][P];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) slice4(c[t0 + t], q[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        i32x4b yacc[2][P];
+        int frag = 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            i32x4b a[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) a[i] = *reinterpret_cast<const i32x4b *>(iu + (size_t)((frag++) & 63) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j + i < P; ++j) {
+                    const i32x4b b = {q[0][j], q[1][j], q[2][j], q[3][j]};
+                    yacc[mt][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b, i == 0 ? zero : yacc[mt][i + j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            i32x4b a2[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a2[i] = *reinterpret_cast<const i32x4b *>(iu + (size_t)((frag++) & 63) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            int cnt = 0;
+#pragma unroll
+            for (int l = 0; l < P; ++l)
+#pragma unroll
+                for (int h = 0; h < (l + 2) / 2; ++h) {
+                    const int j0 = 2 * h, j1 = (2 * h + 1 <= l) ? 2 * h + 1 : 2 * h;
+                    const i32x4b b = {q[4][j0], q[5][j0], q[4][j1], q[5][j1]};
+                    yacc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[cnt++], b, yacc[mt][l], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double y[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[mt][j] = comb(yacc[mt], j) * sc;
+        int yq[2][P];
+        slice4(y[0], yq[0]);
+        slice4(y[1], yq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            i32x4b a2[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) a2[i] = *reinterpret_cast<const i32x4b *>(iu + (size_t)((frag++) & 63) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            i32x4b acc[P];
+            int cnt = 0;
+#pragma unroll
+            for (int l = 0; l < P; ++l)
+#pragma unroll
+                for (int h = 0; h < (l + 2) / 2; ++h) {
+                    const int j0 = 2 * h, j1 = (2 * h + 1 <= l) ? 2 * h + 1 : 2 * h;
+                    const i32x4b b = {yq[0][j0], yq[1][j0], yq[0][j1], yq[1][j1]};
+                    acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[cnt++], b, h == 0 ? zero : acc[l], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[t0 + t][j] = fma(comb(acc, j), -sc, c[t0 + t][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s < nsteps; ++s) {
+        block(2);
+        block(0);
+        double *out = base + (size_t)(4 * s) * 256, *in = base + (size_t)(4 * s + 8) * 256;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double4 v = make_double4(c[t][0], c[t][1], c[t][2], c[t][3]);
+            *reinterpret_cast<double4 *>(out + (size_t)t * 256 + lane * 4) = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[t][j] = c[t + 4][j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double4 v = *reinterpret_cast<const double4 *>(in + (size_t)t * 256 + lane * 4);
+            c[4 + t][0] = v.x; c[4 + t][1] = v.y; c[4 + t][2] = v.z; c[4 + t][3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) base[(size_t)t * 256 + lane * 4 + j] = c[t][j];
+}
+
 template <int NWV> static void run_time16() {
     const int nsteps = 300, ncu = 256;
     std::vector<uint8_t> img(64 * 1024);
@@ -404,6 +535,40 @@ template <int NWV> static void run_time16() {
     const double blocks = (double)nsteps * 2;                             // per wave (16 columns)
     const double per_simd = best * 1e-3 * 2.4e9 / blocks / (NWV / 4.0);   // cycles per block of 16 columns and SIMD
     printf("time16 P=6 G=2 waves/WG=%d (%d per SIMD), sliding: %.2f ms, %.0f cycles per 16-column block and SIMD = %.0f per 32 columns "
+           "(f64 MFMA form: 12288), regs %d (spill %d B), rows %.2f TB/s\n", NWV, NWV / 4, best, per_simd, 2 * per_simd, fa.numRegs,
+           (int)fa.localSizeBytes, (double)nsteps * units * 2 * 4 * 256 * 8 / (best * 1e-3) / 1e12);
+    hipFree(dimg); hipFree(slab);
+}
+
+template <int NWV> static void run_time16b() {
+    const int nsteps = 300, ncu = 256;
+    std::vector<uint8_t> img(64 * 1024);
+    for (auto &b : img) b = (uint8_t)(rand() & 0x3f);
+    uint8_t *dimg; double *slab;
+    const size_t per_unit = (size_t)(nsteps * 4 + 8) * 256, units = (size_t)ncu * NWV;
+    CK(hipMalloc(&dimg, img.size()));
+    CK(hipMalloc(&slab, units * per_unit * 8));
+    CK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+    CK(hipMemset(slab, 0, units * per_unit * 8));
+    auto kfn = time16b_kernel<NWV>;
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    hipFuncAttributes fa;
+    CK(hipFuncGetAttributes(&fa, (const void *)kfn));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kfn, dim3(ncu), dim3(NWV * 64), 64 * 1024, 0, dimg, slab, nsteps, Fix<6>::magic(), 1e-30);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    const double blocks = (double)nsteps * 2;                             // per wave (16 columns)
+    const double per_simd = best * 1e-3 * 2.4e9 / blocks / (NWV / 4.0);   // cycles per block of 16 columns and SIMD
+    printf("time16b (burst-loaded fragments) P=6 G=2 waves/WG=%d (%d per SIMD), sliding: %.2f ms, %.0f cycles per 16-column block and SIMD = %.0f per 32 columns "
            "(f64 MFMA form: 12288), regs %d (spill %d B), rows %.2f TB/s\n", NWV, NWV / 4, best, per_simd, 2 * per_simd, fa.numRegs,
            (int)fa.localSizeBytes, (double)nsteps * units * 2 * 4 * 256 * 8 / (best * 1e-3) / 1e12);
     hipFree(dimg); hipFree(slab);
@@ -522,15 +687,10 @@ template <int P, int G, int NW> static void run_time(int slide) {
 int main(int argc, char **argv) {
     int rc = run_check<6>();
     rc |= run_check<5>();
-    run_time16<4>();
     run_time16<8>();
-    run_time16<12>();
-    run_time<6, 1, 4>(0);
-    run_time<6, 2, 4>(0);
+    run_time16b<4>();
+    run_time16b<8>();
+    run_time16b<12>();
     run_time<6, 2, 4>(1);
-    run_time<5, 2, 4>(0);
-    run_time<5, 2, 4>(1);
-    run_time<6, 4, 4>(1);
-    run_time<5, 4, 4>(1);
     return rc;
 }

@@ -384,7 +384,7 @@ template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16b_kernel(co
         *reinterpret_cast<uint4 *>(lds + o) = *reinterpret_cast<const uint4 *>(img + (o & 0xffff));
     __syncthreads();
     double c[8][4];                                           // two groups per pass: 128-row window = 8 tiles of 16 rows
-    double *base = slab + ((size_t)blockIdx.x * NWV + wave) * (size_t)(nsteps * 4 + 8) * 256;
+    double *base = slab + ((size_t)blockIdx.x * NWV + wave) * (size_t)((nsteps < 0 ? -nsteps : nsteps) * 4 + 8) * 256;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -442,9 +442,10 @@ template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16b_kernel(co
             __builtin_amdgcn_sched_barrier(0);
             int cnt = 0;
 #pragma unroll
-            for (int l = 0; l < P; ++l)
+            for (int h = 0; h < 3; ++h)                       // pair index outermost: consecutive products hit different level sums
 #pragma unroll
-                for (int h = 0; h < (l + 2) / 2; ++h) {
+                for (int l = 0; l < P; ++l) {
+                    if (h >= (l + 2) / 2) continue;
                     const int j0 = 2 * h, j1 = (2 * h + 1 <= l) ? 2 * h + 1 : 2 * h;
                     const i32x4b b = {q[4][j0], q[5][j0], q[4][j1], q[5][j1]};
                     yacc[mt][l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[cnt++], b, yacc[mt][l], 0, 0, 0);
@@ -469,9 +470,10 @@ template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16b_kernel(co
             i32x4b acc[P];
             int cnt = 0;
 #pragma unroll
-            for (int l = 0; l < P; ++l)
+            for (int h = 0; h < 3; ++h)
 #pragma unroll
-                for (int h = 0; h < (l + 2) / 2; ++h) {
+                for (int l = 0; l < P; ++l) {
+                    if (h >= (l + 2) / 2) continue;
                     const int j0 = 2 * h, j1 = (2 * h + 1 <= l) ? 2 * h + 1 : 2 * h;
                     const i32x4b b = {yq[0][j0], yq[1][j0], yq[0][j1], yq[1][j1]};
                     acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2[cnt++], b, h == 0 ? zero : acc[l], 0, 0, 0);
@@ -481,9 +483,12 @@ template <int NWV> __global__ __launch_bounds__(NWV * 64) void time16b_kernel(co
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int s = 0; s < nsteps; ++s) {
+    const bool slide = nsteps > 0;
+    const int ns = slide ? nsteps : -nsteps;
+    for (int s = 0; s < ns; ++s) {
         block(2);
         block(0);
+        if (!slide) continue;
         double *out = base + (size_t)(4 * s) * 256, *in = base + (size_t)(4 * s + 8) * 256;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -540,7 +545,7 @@ template <int NWV> static void run_time16() {
     hipFree(dimg); hipFree(slab);
 }
 
-template <int NWV> static void run_time16b() {
+template <int NWV> static void run_time16b(int slide = 1) {
     const int nsteps = 300, ncu = 256;
     std::vector<uint8_t> img(64 * 1024);
     for (auto &b : img) b = (uint8_t)(rand() & 0x3f);
@@ -559,7 +564,7 @@ template <int NWV> static void run_time16b() {
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kfn, dim3(ncu), dim3(NWV * 64), 64 * 1024, 0, dimg, slab, nsteps, Fix<6>::magic(), 1e-30);
+        hipLaunchKernelGGL(kfn, dim3(ncu), dim3(NWV * 64), 64 * 1024, 0, dimg, slab, slide ? nsteps : -nsteps, Fix<6>::magic(), 1e-30);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -568,8 +573,8 @@ template <int NWV> static void run_time16b() {
     CK(hipGetLastError());
     const double blocks = (double)nsteps * 2;                             // per wave (16 columns)
     const double per_simd = best * 1e-3 * 2.4e9 / blocks / (NWV / 4.0);   // cycles per block of 16 columns and SIMD
-    printf("time16b (burst-loaded fragments) P=6 G=2 waves/WG=%d (%d per SIMD), sliding: %.2f ms, %.0f cycles per 16-column block and SIMD = %.0f per 32 columns "
-           "(f64 MFMA form: 12288), regs %d (spill %d B), rows %.2f TB/s\n", NWV, NWV / 4, best, per_simd, 2 * per_simd, fa.numRegs,
+    printf("time16b (burst-loaded fragments, slide=%d) P=6 G=2 waves/WG=%d (%d per SIMD): %.2f ms, %.0f cycles per 16-column block and SIMD = %.0f per 32 columns "
+           "(f64 MFMA form: 12288), regs %d (spill %d B), rows %.2f TB/s\n", slide, NWV, NWV / 4, best, per_simd, 2 * per_simd, fa.numRegs,
            (int)fa.localSizeBytes, (double)nsteps * units * 2 * 4 * 256 * 8 / (best * 1e-3) / 1e12);
     hipFree(dimg); hipFree(slab);
 }
@@ -688,9 +693,9 @@ int main(int argc, char **argv) {
     int rc = run_check<6>();
     rc |= run_check<5>();
     run_time16<8>();
-    run_time16b<4>();
-    run_time16b<8>();
-    run_time16b<12>();
+    run_time16b<4>(0);
+    run_time16b<8>(0);
+    run_time16b<8>(1);
     run_time<6, 2, 4>(1);
     return rc;
 }

@@ -387,3 +387,19 @@ def test_cli_helpers_match_reference_produced_values():
     for row in gold["cv_splits"]:
         got = cli.build_cv_splits(row["n"], row["k"], row["seed"])
         assert [[list(map(int, te)), list(map(int, tr))] for te, tr in got] == row["folds"], (row["n"], row["k"], row["seed"])
+
+
+def test_sparse_component_limit_host_logic(monkeypatch):
+    """`sparse_component_limit` (one dense eigenproblem per connected component of a thresholded GRM: ~5 n^2 doubles of HBM) and the
+    refusal beyond it, with the size and the limit in the message (src/math/cholesky.rs:776-1075 factorises any structure; this
+    library does not): the arithmetic and the message, no GPU needed."""
+    import pytest
+    from janusx_amd import janusx as jxrs
+    assert jxrs.sparse_component_limit(288 * 10**9) == 84852          # isqrt(288e9 / 40)
+    assert jxrs.sparse_component_limit(250 * 2**30) == 81920
+    assert jxrs.sparse_component_limit(0) == 0
+    monkeypatch.setenv("JXGPU_SPLMM_COMPONENT_MAX", "512")
+    assert jxrs.sparse_component_limit() == 512
+    jxrs._check_spectral_sparse_size(512)
+    with pytest.raises(RuntimeError, match=r"one dense eigenproblem of 700 samples; the limit on this GPU is 512 samples"):
+        jxrs._check_spectral_sparse_size(700, what="the samples of the largest connected component of the sparse GRM")

@@ -590,12 +590,6 @@ def main():
             maf_l = np.minimum(pfr, np.float32(1.0) - pfr).astype(np.float32)      # `load_bed_2bit_packed` (gfreader.rs:4460-4485)
             flip_l = (alt.astype(np.float64) / (2.0 * np.maximum(nm, 1))) > 0.5      # `bed_packed_row_flip_mask`
             torch.cuda.reset_peak_memory_stats()
-            # the legs before this one handed ~100 GB back to the driver (empty_cache): on this stack the FIRST hipMalloc behind such a
-            # release waits seconds for it to complete.  Absorb that outside the timed region with a throw-away
-            # allocation, as a process that starts with this leg would never see it.
-            _settle = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-            del _settle
-            torch.cuda.empty_cache()
             torch.cuda.synchronize()
             # as `jx gs -rrBLUP -rr-solver pcg` runs them: both calls inside one image scope (the second reuses the first's images)
             with jxrs.pcg_image_scope():
@@ -971,10 +965,25 @@ def main():
             except Exception as e:
                 res["extra_c1_mouse"] = {"error": repr(e)}
             try:
-                res.update(legs_c5())
+                res.update(legs_c5(("splmm",)))
             except Exception as e:
-                res["extra_c5_splmm"] = res.get("extra_c5_splmm", {"error": repr(e)})
-                res["extra_c5_pcg"] = res.get("extra_c5_pcg", {"error": repr(e)})
+                res["extra_c5_splmm"] = {"error": repr(e)}
+            try:
+                # the -BLUP PCG leg in a process of its own, as `jx gs` runs it: inside THIS process the first large hipMalloc behind
+                # the ~100 GB the legs above released waits 4 - 6 s once (scripts/probes/vram_recycle_probe.py: 6.0 s for a 40 GB
+                # block behind 120 GB released, 0.3 ms in a fresh process or ten seconds later), which is this
+                # run's history and not the solver's cost
+                import subprocess
+                torch.cuda.empty_cache()
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "c5_pcg"], capture_output=True, text=True,
+                                    timeout=600, env=dict(os.environ, JXGPU_BENCH_CHILD="1"))
+                line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                if cp.returncode != 0 or not line:
+                    raise RuntimeError(f"child rc={cp.returncode}: {cp.stderr[-400:]}")
+                res.update(json.loads(line[-1]))
+                res["extra_c5_pcg"]["process"] = "child process of its own (python bench.py --leg c5_pcg), one GPU"
+            except Exception as e:
+                res["extra_c5_pcg"] = {"error": repr(e)}
         # What the multi-rank code path costs BEFORE any wire time (no multi-GPU box exists on this pool): the same
         # configuration once more in a child process with ONE rank on the RCCL path -- the GRM partials through the lower-triangle
         # pack / ncclAllReduce / unpack, the band reduction in its sharded launch sequence (per block row, two collectives per

@@ -604,6 +604,11 @@ int jx_pcg_set_dist(int rank, int world, int (*allreduce)(void *), void *user, d
  * (payload pointer, row list, training samples), and a second call on the same inputs reuses them (`jx gs -rrBLUP -rr-solver pcg`:
  * lambda by HE, then the solve).  The caller guarantees that the payload does not change inside the scope.  (0) frees them. */
 int jx_pcg_image_scope(int on);
+
+/* Releases the scratch blocks the library keeps between calls (the eigensolver's workspaces, at most 6 GB each; the reference's
+ * CPU path has no counterpart: faer / LAPACK workspaces are freed per call, src/math/linalg.rs:120-184).  Blocks leased by a running call stay.
+ * Returns the number of bytes handed back to the driver. */
+int64_t jxg_scratch_trim(void);
 int64_t jx_pcg_dist_count(void);
 /* Exact marker-space rrBLUP on a resident payload: `rrblup_exact_snp_packed` (src/stats/rrblup.rs:3179-3490; cache
  * :1613-1899, fit :1951-2430).  A* = Z Z' - rs rs' / n_train over the training samples (f64), eigendecomposition, Brent on the

@@ -121,6 +121,7 @@ SIGNATURES = {
     "jx_pcg_set_dist": [c_i, c_i, c_p, c_p, c_p, c_l],
     "jx_pcg_dist_count": [],
     "jx_pcg_image_scope": [c_i],
+    "jxg_scratch_trim": [],
     "jx_rrblup_pcg_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_i, c_p, c_p, c_p, c_p],
     "jx_rrblup_exact_snp_packed": [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_p,
                                    c_p, c_p],
@@ -148,7 +149,7 @@ SIGNATURES = {
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64, "jxg_eigh_band_staging_doubles": C.c_int64,
              "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
-             "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64}
+             "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64, "jxg_scratch_trim": C.c_int64}
 
 
 def lib():

@@ -60,6 +60,21 @@ void scratch_release(int which) {
     g_scratch[which & 7].busy = false;
 }
 
+// Hand the kept scratch blocks (<= 6 GB each, grown on demand by the eigensolver's stages) back to the driver: for a long-lived
+// host process between two problems of very different size.  Blocks leased by a running call stay.  -> bytes released
+extern "C" int64_t jxg_scratch_trim(void) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int64_t freed = 0;
+    for (ScratchSlot &s : g_scratch) {
+        if (s.busy || !s.p) continue;
+        (void)hipFree(s.p);
+        freed += (int64_t)s.cap;
+        s.p = nullptr;
+        s.cap = 0;
+    }
+    return freed;
+}
+
 int launch_symmetrize(double *d_a, int n, hipStream_t st);
 int launch_transpose_f64(const double *src, double *dst, int n, hipStream_t st);
 

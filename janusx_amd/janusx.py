@@ -775,6 +775,14 @@ def spectral_cache_clear():
     _SPECTRAL_CACHE.clear()
 
 
+def release_device_scratch():
+    """Hand everything this library keeps in HBM between calls back to the driver: the cached spectral form of the last sparse
+    GRM and the eigensolver's kept workspaces (`jxg_scratch_trim`; at most 6 GB each).  For a long-lived process between two
+    problems of very different size; returns the bytes of workspace released.  (The reference's CPU path frees per call.)"""
+    _SPECTRAL_CACHE.clear()
+    return int(lib().jxg_scratch_trim())
+
+
 class _SpectralSparseReml:
     """K + lambda I of a (subset of a) sparse GRM handled through ONE eigendecomposition on the GPU instead of one
     sparse LLT per lambda (src/stats/spreml.rs:384-512 factorises at every evaluation): K = U diag(s) U', so

@@ -686,6 +686,7 @@ def main():
         # what the association stage is priced on: the series form executes 2 (p + 2) n 64 flops per SNP on the f64 matrix pipes
         # (k_scan_fast.hip series_coef_kernel), the other forms the reference formulation's evaluations
         scan_flops_priced = (2.0 * (x.shape[1] + 2) * 64.0 * n * kern["scan_bytes"] / (4.0 * n)) if scan_series else kern.get("scan_flops", 0.0)
+        oz_p = int(pl.LAST_EIGH.get("planes") or lib().jxg_oz_planes())   # digit planes the pipeline's eigendecomposition ran with
         F64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: one 2048-flop block per 64 cycles per SIMD = the f64 vector rate
         if kern.get("two_stage"):
             # dominant kernel by time of the two-stage eigensolver path: the back-transformation of the bulge-chasing
@@ -790,22 +791,22 @@ def main():
                                         "both operands) against 2.5 PFLOP/s",
                                 "ms_per_step": kern["rot_ms"] / L},
             "roofline_eigh_gemm": ({
-                "bound": "mfma", "kernel": "oz_mm_kernel<6> (sliced f64 GEMM on v_mfma_i32_32x32x32_i8, csrc/k_ozgemm.hip)",
+                "bound": "mfma", "kernel": f"oz_mm_kernel<{oz_p}> (sliced f64 GEMM on v_mfma_i32_32x32x32_i8, csrc/k_ozgemm.hip)",
                 "stage": "Q1 back-transformation C <- Q1 C (W = V'C and C -= (V T) W per block of 2048 reflectors)",
                 "algorithmic_tflops": 2.0 * float(n) ** 3 / q1_share / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
                 "columns_per_rank": int(round(n / q1_share)),
-                "planes": int(lib().jxg_oz_planes()),
-                "issued_int8_products_per_algorithmic_product": int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2,
-                "achieved": 2.0 * float(n) ** 3 / q1_share * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                "planes": oz_p,
+                "issued_int8_products_per_algorithmic_product": oz_p * (oz_p + 1) // 2,
+                "achieved": 2.0 * float(n) ** 3 / q1_share * (oz_p * (oz_p + 1) // 2)
                 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12,
                 "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
-                "frac": 2.0 * float(n) ** 3 / q1_share * (int(lib().jxg_oz_planes()) * (int(lib().jxg_oz_planes()) + 1) // 2)
+                "frac": 2.0 * float(n) ** 3 / q1_share * (oz_p * (oz_p + 1) // 2)
                 / max(stage.get("eigh_q1_backtransform", 0.0) / args.steps, 1e-9) / 1e12 / MFMA_I8_PEAK_TOPS,
                 "f64_mfma_peak_tflops": F64_MFMA_PEAK_TFLOPS,
                 "note": "algorithmic 2 n^3 f64 flops of the stage over its whole duration (slicing of C and W, products, "
                         "HIP events around the stage, C-independent part -- V images, Gram, T^-1, V T -- included: it runs in line; on "
                         "several ranks a rank back-transforms its n / world eigenvector columns and is priced on those); every algorithmic product is issued as planes (planes + 1) / 2 "
-                        "int8 digit products (exact i32 sums, f64 combination: 4e-14 relative), priced against the dense int8 "
+                        "int8 digit products (exact i32 sums, f64 combination: 4e-14 relative at 6 planes = 21 products, 1e-11 at the 5 planes = 15 products of the f32-consuming pipeline), priced against the dense int8 "
                         "peak 5 POP/s; algorithmic_tflops is to be read against the 78.6 TFLOP/s f64 MFMA roof this stage "
                         "(rocBLAS dgemm, rounds 1 - 3: 72) no longer sits under; the divide and conquer's merges run on the same kernel"}
                                    if kern.get("two_stage") and n >= 3000 else None),

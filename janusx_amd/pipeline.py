@@ -316,6 +316,9 @@ def enable_distributed_eigh(min_n: int = 0):
     return True
 
 
+LAST_EIGH = {"planes": 0}      # digit planes of the sliced int8 products in the last eigh_from_grm call
+
+
 def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None, f32_consumer=False):
     """K (n,n) f32/f64 on device -> (S f64 (k), U^T f64 (k,k) row j = eigenvector j).
     f32_consumer: the caller keeps the eigenvectors only as the f32 U^T of the scan (`SpectralModel`, the reference's `Dh`,
@@ -339,6 +342,7 @@ def eigh_from_grm(k: torch.Tensor, ridge=1e-6, subset_idx=None, f32_consumer=Fal
     five = bool(f32_consumer) and not os.environ.get("JXGPU_OZ_PLANES") and os.environ.get("JXGPU_EIGH_F32_PLANES", "5") == "5"
     prev = lib().jxg_oz_set_planes(5) if five else 0
     try:
+        LAST_EIGH["planes"] = int(lib().jxg_oz_planes())      # what bench.py prices the Q1 stage on
         check(lib().jxg_eigh_f64(_ptr(a), kk, float(ridge), _ptr(w), _stream()))
     finally:
         if five:

@@ -714,9 +714,13 @@ def cmd_gs_rrblup(args):
         # the PCG route streams the payload from HBM for the whole solve: upload it ONCE and hand the device tensor to both
         # he_pcg_bed and rrblup_pcg_bed (their images of the training payload are shared inside `pcg_image_scope`)
         try:
+            import warnings
             import torch
             if torch.cuda.is_available() and 3.2 * packed.nbytes < torch.cuda.mem_get_info()[0]:
-                pcg_payload = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
+                with warnings.catch_warnings():
+                    # a read-only view of the mapped file: it is only read (copied to the device), never written through
+                    warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+                    pcg_payload = torch.from_numpy(np.ascontiguousarray(packed)).cuda()
         except Exception:   # noqa: BLE001 - the host array works everywhere (uploaded per call)
             pcg_payload = packed
     for ti in traits:

@@ -733,65 +733,64 @@ def cmd_gs_rrblup(args):
             continue
         t1 = time.perf_counter()
         scope = jxrs.pcg_image_scope() if solver == "pcg" else contextlib.nullcontext()
-        scope.__enter__()
-        if solver in ("exact", "fast"):
-            lam, src = None, "REML on the spectrum"
-        elif args.lam is not None:
-            lam, src = float(args.lam), "manual"
-        elif not args.lambda_reml:
-            # Haseman-Elston first (python/janusx/gs/workflow.py:5564 `he_first`): lambda_equation = lambda_k * m_effective
-            try:
-                he = jxrs.he_pcg_bed("", train, yv[train], site_keep=keep, seed=args.seed if args.seed != 42 else 20260512,
-                                     packed=pcg_payload, packed_n_samples=n_all, maf=maf, row_flip=flip)
-            except RuntimeError as e:   # e.g. the stochastic traces violate the PSD bound on a small panel
-                he = None
-                lam, src = None, f"HE failed ({e})"
-            if he is not None:
-                if np.isfinite(he[10]) and he[10] >= 0.0:
-                    lam, src = max(1e-8, float(he[10]) * float(max(1, he[6]))), f"HE (h2={he[2]:.4f}, lambda_k={he[10]:.5g})"
-                else:
-                    lam, src = None, "HE on the boundary"
-        else:
-            lam, src = None, ""
-        if lam is None and solver == "pcg":
-            rng = np.random.default_rng(args.seed)
-            sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
-            ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
-            fit = jxrs.gblup_reml_grm(ks, np.arange(len(sub), dtype=np.int64), yv[train[sub]], None,
-                                      return_variance_components=True)
-            lam_k = float(fit[3])
-            p = np.clip(maf[keep], 0.0, 0.5)
-            m_eff = int(np.count_nonzero(2.0 * p * (1.0 - p) > 1e-12))
-            lam, src = lam_k * m_eff, (src + " -> " if src else "") + f"subsample REML (n_sub={len(sub)}, lambda_k={lam_k:.5g})"
-        fold = np.full(n_all, -1, dtype=np.int64)
-        pred = np.full(n_all, np.nan)
+        with scope:   # the images are released when the block is left, also by an exception
+            if solver in ("exact", "fast"):
+                lam, src = None, "REML on the spectrum"
+            elif args.lam is not None:
+                lam, src = float(args.lam), "manual"
+            elif not args.lambda_reml:
+                # Haseman-Elston first (python/janusx/gs/workflow.py:5564 `he_first`): lambda_equation = lambda_k * m_effective
+                try:
+                    he = jxrs.he_pcg_bed("", train, yv[train], site_keep=keep, seed=args.seed if args.seed != 42 else 20260512,
+                                         packed=pcg_payload, packed_n_samples=n_all, maf=maf, row_flip=flip)
+                except RuntimeError as e:   # e.g. the stochastic traces violate the PSD bound on a small panel
+                    he = None
+                    lam, src = None, f"HE failed ({e})"
+                if he is not None:
+                    if np.isfinite(he[10]) and he[10] >= 0.0:
+                        lam, src = max(1e-8, float(he[10]) * float(max(1, he[6]))), f"HE (h2={he[2]:.4f}, lambda_k={he[10]:.5g})"
+                    else:
+                        lam, src = None, "HE on the boundary"
+            else:
+                lam, src = None, ""
+            if lam is None and solver == "pcg":
+                rng = np.random.default_rng(args.seed)
+                sub = np.sort(rng.permutation(len(train))[:min(len(train), 2000)])
+                ks = jxrs.grm_packed_f32(np.ascontiguousarray(packed[keep]), n_all, flip[keep], maf[keep], train[sub], method=2)
+                fit = jxrs.gblup_reml_grm(ks, np.arange(len(sub), dtype=np.int64), yv[train[sub]], None,
+                                          return_variance_components=True)
+                lam_k = float(fit[3])
+                p = np.clip(maf[keep], 0.0, 0.5)
+                m_eff = int(np.count_nonzero(2.0 * p * (1.0 - p) > 1e-12))
+                lam, src = lam_k * m_eff, (src + " -> " if src else "") + f"subsample REML (n_sub={len(sub)}, lambda_k={lam_k:.5g})"
+            fold = np.full(n_all, -1, dtype=np.int64)
+            pred = np.full(n_all, np.nan)
 
-        def fit_predict(tr, te):
-            if solver == "fast":
-                r = jxrs.gblup_reml_grm(k_std, tr, yv[tr], te if len(te) else None, return_variance_components=True)
-                # (pred_train, pred_test, pve, lambda_k, ml, reml, ..., sigma_g2, sigma_e2): same slots as the marker-space fit
-                return (r[0], r[1], r[2], float(r[3]) * float(m_eff_std), r[5], (r[9], r[10]), m_eff_std)
-            if solver == "exact":
-                return jxrs.rrblup_exact_snp_packed(packed, n_all, tr, yv[tr], te if len(te) else None, site_keep=keep,
-                                                    maf=maf, row_flip=flip)
-            return jxrs.rrblup_pcg_bed("", tr, yv[tr], te if len(te) else None, site_keep=keep, lambda_value=lam,
-                                       tol=args.tol, max_iter=args.max_iter, packed=pcg_payload, packed_n_samples=n_all,
-                                       maf=maf, row_flip=flip)
+            def fit_predict(tr, te):
+                if solver == "fast":
+                    r = jxrs.gblup_reml_grm(k_std, tr, yv[tr], te if len(te) else None, return_variance_components=True)
+                    # (pred_train, pred_test, pve, lambda_k, ml, reml, ..., sigma_g2, sigma_e2): same slots as the marker-space fit
+                    return (r[0], r[1], r[2], float(r[3]) * float(m_eff_std), r[5], (r[9], r[10]), m_eff_std)
+                if solver == "exact":
+                    return jxrs.rrblup_exact_snp_packed(packed, n_all, tr, yv[tr], te if len(te) else None, site_keep=keep,
+                                                        maf=maf, row_flip=flip)
+                return jxrs.rrblup_pcg_bed("", tr, yv[tr], te if len(te) else None, site_keep=keep, lambda_value=lam,
+                                           tol=args.tol, max_iter=args.max_iter, packed=pcg_payload, packed_n_samples=n_all,
+                                           maf=maf, row_flip=flip)
 
-        if args.cv and args.cv > 1:
-            print("Fold Method     Pearsonr Spearmanr R2")
-            for f, (te_loc, tr_loc) in enumerate(build_cv_splits(len(train), args.cv, args.seed)):
-                r = fit_predict(train[tr_loc], train[te_loc])
-                pred[train[te_loc]] = r[1].ravel()
-                fold[train[te_loc]] = f
-                pe, sp, r2f = cv_fold_metrics(yv[train[te_loc]], r[1].ravel())
-                print(f"{f + 1:<4d} rrBLUP     {pe:.3f}    {sp:.3f}     {r2f:.3f}")
-            yo, po = yv[train], pred[train]
-            rr = float(np.corrcoef(yo, po)[0, 1])
-            r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
-            print(f"[{name}] rrBLUP {args.cv}-fold CV: pearson={rr:.4f} R2={r2:.4f}")
-        full = fit_predict(train, test)
-        scope.__exit__(None, None, None)
+            if args.cv and args.cv > 1:
+                print("Fold Method     Pearsonr Spearmanr R2")
+                for f, (te_loc, tr_loc) in enumerate(build_cv_splits(len(train), args.cv, args.seed)):
+                    r = fit_predict(train[tr_loc], train[te_loc])
+                    pred[train[te_loc]] = r[1].ravel()
+                    fold[train[te_loc]] = f
+                    pe, sp, r2f = cv_fold_metrics(yv[train[te_loc]], r[1].ravel())
+                    print(f"{f + 1:<4d} rrBLUP     {pe:.3f}    {sp:.3f}     {r2f:.3f}")
+                yo, po = yv[train], pred[train]
+                rr = float(np.corrcoef(yo, po)[0, 1])
+                r2 = 1.0 - float(np.sum((yo - po) ** 2) / np.sum((yo - yo.mean()) ** 2))
+                print(f"[{name}] rrBLUP {args.cv}-fold CV: pearson={rr:.4f} R2={r2:.4f}")
+            full = fit_predict(train, test)
         if not (args.cv and args.cv > 1):
             pred[train] = full[0].ravel()
         if len(test):

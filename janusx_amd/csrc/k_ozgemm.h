@@ -13,6 +13,9 @@ struct OzImage {
 // digit planes per operand: JXGPU_OZ_PLANES (4 .. 6), default 6 = 21 int8 products, ~4e-14 relative (5: 15 products, 1e-11:
 // the eigenvectors then leave the 1e-10 orthogonality bar after the ~25 products in a row of one decomposition)
 int oz_planes();
+// the calling thread's override (0: none) -- handed on to worker threads of a decomposition
+int oz_planes_override_get();
+void oz_planes_override_set(int planes);
 size_t oz_image_bytes(int rows, int k, int planes = 0);
 OzImage oz_image_at(void *mem, int rows, int k, int planes = 0);
 // operand element (r, k) = x[r * rs + k * cs], rs == 1 or cs == 1

@@ -39,8 +39,12 @@ constexpr int OZ_BK = 32;                     // k per step
 constexpr int OZ_PLANE = OZ_TM * OZ_BK;       // bytes of one plane of one (row block, k step)
 constexpr int OZ_NST = 3;                     // LDS ring depth
 
-// run-time override of the plane count (0: none), set around a decomposition whose eigenvectors the caller keeps in f32
-static int g_oz_planes_override = 0;
+// run-time override of the plane count (0: none), set around a decomposition whose eigenvectors the caller keeps in f32.
+// Per THREAD: a decomposition running on another thread of the process keeps its own plane count; a worker thread a
+// decomposition starts (k_stedc.hip) inherits its parent's through oz_planes_override_set.
+static thread_local int g_oz_planes_override = 0;
+int oz_planes_override_get() { return g_oz_planes_override; }
+void oz_planes_override_set(int planes) { g_oz_planes_override = (planes >= 4 && planes <= 6) ? planes : 0; }
 int oz_planes() {
     static const int p = [] {
         const char *e = getenv("JXGPU_OZ_PLANES");

@@ -244,14 +244,17 @@ uint64_t img_hash(const void *p, size_t bytes) {
 }
 // -> 0 and *p32 / *t32 (device pointers: borrowed from the scope's cache, or owned by `own_p32` / `own_t32`); `built` = the images
 // had to be made (the caller then continues with its own pre-pass as before)
-int pcg_images(const uint8_t *d_raw, int64_t bps, int64_t m_total, int n_samples, const int64_t *row_indices,
+// `key`: the CALLER's payload pointer when the payload already lives in HBM, nullptr for a host payload (its device copy is a
+// buffer of this call: the next call's upload usually gets the same address back, so that address identifies nothing -- a host
+// payload uses the scope's buffers but never hits, and leaves the cache invalid)
+int pcg_images(const void *key, const uint8_t *d_raw, int64_t bps, int64_t m_total, int n_samples, const int64_t *row_indices,
                const int64_t *d_rowidx, int64_t eff_m, const int64_t *train_idx, const int32_t *d_train32, int n_train,
                DevBuf &own_p32, DevBuf &own_t32, const uint8_t **p32, const uint8_t **t32, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_img_mu);
     const uint64_t ht = img_hash(train_idx, sizeof(int64_t) * (size_t)n_train);
     const uint64_t hr = row_indices ? img_hash(row_indices, sizeof(int64_t) * (size_t)eff_m) : 0ull;
     PcgImages &G = g_img;
-    if (G.scope && G.valid && G.src == (const void *)d_raw && G.m_total == m_total && G.eff_m == eff_m && G.n_samples == n_samples &&
+    if (key && G.scope && G.valid && G.src == key && G.m_total == m_total && G.eff_m == eff_m && G.n_samples == n_samples &&
         G.n_train == n_train && G.h_train == ht && G.h_rows == hr) {
         *p32 = G.p32.as<uint8_t>();
         *t32 = G.t32.as<uint8_t>();
@@ -264,9 +267,9 @@ int pcg_images(const uint8_t *d_raw, int64_t bps, int64_t m_total, int n_samples
     if (dt.bytes < b_t32 && dt.alloc(b_t32)) return 1;
     if (jxg_repack_p32(d_raw, bps, n_samples, m_total, d_train32, n_train, d_rowidx, eff_m, dp.as<uint8_t>(), st)) return 1;
     if (jxg_p32_transpose(dp.as<uint8_t>(), eff_m, n_train, nullptr, (int)eff_m, dt.as<uint8_t>(), st)) return 1;
-    if (G.scope) {
+    if (G.scope && key) {
         G.valid = true;
-        G.src = d_raw;
+        G.src = key;
         G.m_total = m_total;
         G.eff_m = eff_m;
         G.n_samples = n_samples;
@@ -278,6 +281,28 @@ int pcg_images(const uint8_t *d_raw, int64_t bps, int64_t m_total, int n_samples
     *t32 = dt.as<uint8_t>();
     return 0;
 }
+// HBM the next pcg_images call of this shape still has to allocate: nothing on a cache hit, the shortfall of the scope's buffers
+// inside a scope, both images otherwise
+double pcg_images_pending_bytes(int n_train, int64_t eff_m) {
+    std::lock_guard<std::mutex> lk(g_img_mu);
+    const size_t b_p32 = (size_t)num_tiles(n_train) * (size_t)eff_m * 32, b_t32 = (size_t)jxg_t32_bytes(n_train, (int)eff_m);
+    if (!g_img.scope) return (double)b_p32 + (double)b_t32;
+    return (double)(g_img.p32.bytes < b_p32 ? b_p32 : 0) + (double)(g_img.t32.bytes < b_t32 ? b_t32 : 0);
+}
+// HIP events of ONE call (created for the device that is current now, destroyed with the call): concurrent solves do not share
+// timing events
+struct EvSet {
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    int make(int k) {
+        for (int i = 0; i < k; ++i) JX_HIP(hipEventCreate(&e[i]));
+        return 0;
+    }
+    ~EvSet() {
+        for (auto &x : e)
+            if (x) (void)hipEventDestroy(x);
+    }
+    hipEvent_t operator[](int i) const { return e[i]; }
+};
 }  // namespace
 
 extern "C" int jx_pcg_image_scope(int on) {
@@ -322,9 +347,8 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
     // stage timers of the last solve (jxg_last_kernel_ms 18 - 21): wall time of the set-up (images, pre-pass) and of the
     // iteration loop, and the summed HIP-event durations of the two streaming operator kernels (Z'p on the sample-major image,
     // Z (Z'p) on the SNP-major one): the kernels an HBM roofline of this route is quoted on
-    static hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (!ev[0])
-        for (auto &e : ev) JX_HIP(hipEventCreate(&e));
+    EvSet ev;
+    if (ev.make(4)) return 1;
     double op_ms = 0.0;
     const auto wall0 = std::chrono::steady_clock::now();
 
@@ -365,8 +389,11 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         const int nt = num_tiles(n_train);
         {
             size_t fr = 0, tot = 0;
-            const double need = (on_device ? 0.0 : (double)m_total * (double)bps) + (double)nt * (double)eff_m * 32.0 +
-                                (double)jxg_t32_bytes(n_train, (int)eff_m) + 64.0 * (double)eff_m;
+            // images a surrounding scope already holds (jx_he_traces_packed before this call, the CLI's default order) are
+            // reused, not allocated again: only what is still to be allocated counts
+            (void)nt;
+            const double need = (on_device ? 0.0 : (double)m_total * (double)bps) + pcg_images_pending_bytes(n_train, eff_m) +
+                                64.0 * (double)eff_m;
             if (hipMemGetInfo(&fr, &tot) == hipSuccess && need > 0.97 * (double)fr)
                 return fail("rrBLUP PCG: the payload images of " + std::to_string((long long)eff_m) + " markers x " +
                             std::to_string(n_train) + " training samples need " + std::to_string((long long)(need / 1048576.0)) +
@@ -395,8 +422,8 @@ extern "C" int jx_rrblup_pcg_packed(const uint8_t *packed, int64_t m_total, int 
         }
         tmark("allocations + small uploads");
         // the two images of the training payload: made here (allocated with the device idle), or borrowed from the caller's scope
-        if (pcg_images(d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m, train_idx, didx.as<int32_t>(), n_train, p32, t32,
-                       &P, &T32, st))
+        if (pcg_images(on_device ? (const void *)packed : nullptr, d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m,
+                       train_idx, didx.as<int32_t>(), n_train, p32, t32, &P, &T32, st))
             return 1;
         tmark("images (repack + transpose, or the scope's)");
         JX_HIP(hipMemcpy(dlut.p, value_lut, sizeof(float) * 4 * (size_t)eff_m, hipMemcpyHostToDevice));
@@ -764,7 +791,8 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
         d_rowidx = drow.as<int64_t>();
     }
     const uint8_t *P32 = nullptr, *T32 = nullptr;
-    if (pcg_images(d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m, train_idx, didx.as<int32_t>(), n, p32, t32, &P32, &T32, st))
+    if (pcg_images(is_device_ptr(packed) ? (const void *)packed : nullptr, d_raw, bps, m_total, n_samples, row_indices, d_rowidx, eff_m,
+                   train_idx, didx.as<int32_t>(), n, p32, t32, &P32, &T32, st))
         return 1;
     JX_HIP(hipStreamSynchronize(st));
     raw.release();
@@ -774,9 +802,8 @@ extern "C" int jx_he_traces_packed(const uint8_t *packed, int64_t m_total, int n
     const float inv_m = 1.0f / (ms > 1.0f ? ms : 1.0f);
     std::vector<double> h64(n);
     // out = K v (f32 in, f32 out): Z v (f32 GEMV in the reference) -> Z'(.) -> * 1/m   (he.rs:1273-1327)
-    static hipEvent_t hev[2] = {nullptr, nullptr};
-    if (!hev[0])
-        for (auto &e : hev) JX_HIP(hipEventCreate(&e));
+    EvSet hev;
+    if (hev.make(2)) return 1;
     double he_ms = 0.0;
     int he_apps = 0;
     auto apply_k = [&](const std::vector<float> &v, std::vector<float> &o) -> int {

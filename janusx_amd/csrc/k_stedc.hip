@@ -635,7 +635,9 @@ static int stedc_dc(DcCtx &C, int n, double *d_d, double *d_e, double *d_c, std:
             C2.leaf_zoff = C.leaf_zoff;
             C2.zpool = C.zpool;
             C2.hleaf_w = C.hleaf_w;
+            const int planes_ov = oz_planes_override_get();
             std::thread th([&]() {
+                oz_planes_override_set(planes_ov);     // the override is per thread: the child merges with its parent's planes
                 if (hipSetDevice(C2.device) != hipSuccess || hipStreamWaitEvent(C2.st, ready, 0) != hipSuccess) {
                     rc2 = 1;
                     return;

@@ -127,3 +127,21 @@ def enable_distributed_pcg(max_samples: int = 0):
 def distributed_pcg():
     """(rank, world) of the marker-sharded PCG mode, or None when it is off."""
     return (_DIST_PCG["rank"], _DIST_PCG["world"]) if _DIST_PCG else None
+
+
+_COLLECTIVE_SIZE_CHECKS = {"on": False}
+
+
+def enable_collective_size_checks(on: bool = True):
+    """State that the sparse-GRM routes of `janusx` (sparse REML, SparseLMM) are called by EVERY rank of the process group with the
+    same arguments.  Their HBM size check then takes the minimum of the free HBM over the ranks (one MIN all-reduce), so that all
+    ranks accept or refuse together.  Off by default: the routes may equally be called on one rank only (`if rank == 0:` in a
+    torchrun job) or be answered from the spectral cache on some ranks, where a hidden collective would leave the other ranks
+    waiting for ever; the check then uses the local figure.  -> the previous setting."""
+    prev = _COLLECTIVE_SIZE_CHECKS["on"]
+    _COLLECTIVE_SIZE_CHECKS["on"] = bool(on)
+    return prev
+
+
+def collective_size_checks():
+    return _COLLECTIVE_SIZE_CHECKS["on"]

@@ -697,13 +697,17 @@ def _pack_components_into_blocks(lab, bsz):
 
 
 def _hbm_free_agreed():
-    """Free HBM in bytes; under a multi-rank run the MINIMUM over the ranks, so that a size check decides the same way on every
-    rank (a rank that raised alone would leave the others waiting in their next collective)."""
+    """Free HBM in bytes.  When the caller has declared the sparse routes collective (`dist.enable_collective_size_checks()`:
+    every rank makes the same calls) the MINIMUM over the ranks, so that a size check decides the same way on every rank (a rank
+    that raised alone would leave the others waiting in their next collective).  Otherwise the local figure: these routes may be
+    called on one rank only, or be answered from the spectral cache on some ranks, and a hidden collective would hang the rest."""
     import torch
+    from . import dist as _jd
     free, _total = torch.cuda.mem_get_info()
     try:
         import torch.distributed as tdist
-        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        if (_jd.collective_size_checks() and tdist.is_available() and tdist.is_initialized()
+                and tdist.get_world_size() > 1):
             t = torch.tensor([float(free)], dtype=torch.float64)
             if tdist.get_backend() == "nccl":
                 t = t.to(torch.device("cuda", torch.cuda.current_device()))
@@ -896,7 +900,7 @@ class _SpectralSparseReml:
         sizes = np.bincount(lab, minlength=ncomp)
         bsz = _sparse_block_size()
         # a component beyond the block size is a block of its own, up to what one GPU's eigensolver holds (the same decision on
-        # every rank: `sparse_component_limit` agrees the free HBM over the ranks)
+        # every rank once the caller has declared the call collective: dist.enable_collective_size_checks)
         if int(sizes.max()) > bsz:
             _check_spectral_sparse_size(int(sizes.max()), what="the samples of the largest connected component of the sparse GRM")
         perm, offs = _pack_components_into_blocks(lab, bsz)

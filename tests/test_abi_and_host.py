@@ -403,3 +403,37 @@ def test_sparse_component_limit_host_logic(monkeypatch):
     jxrs._check_spectral_sparse_size(512)
     with pytest.raises(RuntimeError, match=r"one dense eigenproblem of 700 samples; the limit on this GPU is 512 samples"):
         jxrs._check_spectral_sparse_size(700, what="the samples of the largest connected component of the sparse GRM")
+
+
+def test_bench_headline_line_is_short_strict_json():
+    """The driver parses the LAST stdout line of bench.py; round 5's ~20 kB line was not parsed.  Build the line from the
+    largest detail record a default run has produced (profiles/r05i_bench_default.json: ten legs with paragraph-long notes),
+    with non-finite values and an over-long note planted, and hold it under 6 kB of strict JSON with every contract field."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    res = json.loads(open(os.path.join(ROOT, "profiles", "r05i_bench_default.json")).read().strip().splitlines()[-1])
+    res["roofline"]["traffic"] = float("nan")
+    res["stages_ms_per_step"]["planted_inf"] = float("inf")
+    res["roofline"]["note"] = "x" * 50000
+    res["extra_c4_1gpu"]["note"] = "y" * 50000
+    out, line = bench.headline_record(res)
+    assert len(line.encode()) < bench.HEADLINE_MAX_BYTES == 6144
+    assert "\n" not in line
+    back = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))   # NaN / Infinity refused
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in back, key
+    assert back["roofline"]["traffic"] is None and back["stages_ms_per_step"]["planted_inf"] is None
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in back["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in back["cpu_baseline"], key
+    assert back["config"]["workload"] and "model" not in back["config"]
+    assert abs(back["value"] - res["value"]) <= 1e-6 * res["value"]
+    assert set(back["legs"]) >= {"c1", "c2", "c3_miss", "c4_1gpu", "c5_splmm", "c5_pcg"}
+    # a record so large that even the short form would overflow sheds its optional parts instead of growing
+    res["stages_ms_per_step"].update({f"stage_{i}": float(i) for i in range(400)})
+    _, line2 = bench.headline_record(res)
+    assert len(line2.encode()) < 6144 and "value" in json.loads(line2)

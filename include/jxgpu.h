@@ -341,6 +341,36 @@ int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const double *d_s,
                        double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
                        void *stream);
 
+/* D3 along the reference's warm-start chains (`carry_warm_start`, src/stats/lmm.rs:134-161: each SNP's Brent starts from the
+ * optimum of the valid SNP before it; the default of `lmm_reml_assoc_packed_f32`, src/stats/lmm.rs:3244-3245, and of the BED
+ * route, :2627).  d_chain_off: nchains + 1 ascending int32 row offsets into this block (device); d_carry: nchains doubles
+ * (device): the log10 lambda a chain starts from on entry (NaN: none -- the interval midpoint), the optimum of its last valid
+ * SNP on return, so that a chain cut by the caller's blocking continues in the next call.  One wave per chain, the chains in
+ * parallel.  _tab: tables from jxg_lmm_tables_build; jxg_lmm_scan_chain = build + scan (and jxg_lmm_scan_exact_chain, the
+ * reference-formulation kernel, for configurations outside the tables). */
+int jxg_lmm_scan_chain_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p, double low,
+                           double high, const void *d_work, double tol, int max_iter, const int32_t *d_chain_off, int nchains,
+                           double *d_carry, int with_plrt, double nullml, double *d_out, int32_t *d_evals, void *stream);
+int jxg_lmm_scan_chain(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, const double *d_y, int p,
+                       double low, double high, double tol, int max_iter, const int32_t *d_chain_off, int nchains,
+                       double *d_carry, int with_plrt, double nullml, double *d_out, int32_t *d_evals, void *stream);
+int jxg_lmm_scan_exact_chain(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, const double *d_y,
+                             int p, double low, double high, double tol, int max_iter, const int32_t *d_chain_off, int nchains,
+                             double *d_carry, int with_plrt, double nullml, double *d_out, int32_t *d_evals, void *stream);
+/* The series form of D3 in two steps (csrc/k_scan_fast.hip): jxg_lmm_series_coef_tab turns a block of rotated rows into every
+ * SNP's Chebyshev series of its SNP-specific sums (one pass over the rows on the f64 matrix pipes; d_scoef: nrows x
+ * jxg_lmm_series_doubles(p, low, high) doubles, d_ssq: nrows), jxg_lmm_series_brent_tab runs the Brent searches on stored series
+ * -- one per row (d_chain_off NULL; warm / init as jxg_lmm_scan_tab) or along chains (as jxg_lmm_scan_chain_tab).  Chain scans of
+ * a whole payload keep the series of many blocks and walk all chains in ONE launch.  jxg_lmm_series_doubles = 0: this
+ * (p, low, high) has no series form (more than two width-2 segments, p > 14). */
+int64_t jxg_lmm_series_doubles(int p, double low, double high);
+int jxg_lmm_series_coef_tab(const float *d_grot, int nrows, int n, const double *d_xcov, int p, double low, double high,
+                            const void *d_work, double *d_scoef, double *d_ssq, void *stream);
+int jxg_lmm_series_brent_tab(int nrows, int n, const double *d_s, const double *d_xcov, int p, double low, double high,
+                             const void *d_work, double tol, int max_iter, int warm, double init_log10_lbd, const double *d_scoef,
+                             const double *d_ssq, const int32_t *d_chain_off, int nchains, double *d_carry, int with_plrt,
+                             double nullml, double *d_out, int32_t *d_evals, void *stream);
+
 /* E1. fixed-lambda cache (device vectors): w f32(n), py f32(n), wx f32(n,p); scalars to HOST out:
  * a_chol (p*p), ypy, log_det_v, df.  src/stats/fvlmm.rs:1484-1563. */
 int jxg_fvlmm_prepare(const double *d_s, const double *d_xcov, const double *d_y, int n, int p, double lbd,
@@ -529,6 +559,16 @@ int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_samples, const ui
                     const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model, double low,
                     double high, int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml,
                     double nullml, double *out, int genetic_model);
+/* lmm_reml_assoc_packed_f32 with the reference's default warm-start chains (src/stats/lmm.rs:3244-3245 `true, true`; the BED
+ * route's `use_warm_start`, :2627): the exact scan (model 0) where chain c = rows [chain_off[c], chain_off[c + 1]) of the payload
+ * in order (host int64 offsets, chain_off[0] = 0, ascending, chain_off[n_chains] = m; the reference's chains are its blocks of
+ * `rotate_block_rows` rows, cut further by rayon's work splitting).  The first valid SNP of a chain starts from init_log10_lbd
+ * (warm != 0) or the interval midpoint, every later one from the optimum of the valid SNP before it (:134-161). */
+int jx_assoc_packed_chain(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip, const float *row_maf,
+                          const double *s, const double *xcov, const double *y_rot, const float *u_t, int p,
+                          const int64_t *sample_indices, int n_sel, double low, double high, int max_iter, double tol, int warm,
+                          double init_log10_lbd, int has_nullml, double nullml, double *out, int genetic_model,
+                          const int64_t *chain_off, int64_t n_chains);
 
 /* `lm_block_assoc_packed` (src/stats/glm.rs:3550-3860): the plain LM scan `jx gwas -lmm / -fvlmm` switches to when the null
  * likelihood-ratio test (jx_gwas_lmm_lm_null_lrt_decision) finds no polygenic variance

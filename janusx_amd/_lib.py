@@ -127,6 +127,15 @@ SIGNATURES = {
                                    c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
+    "jx_assoc_packed_chain": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_d, c_d, c_i, c_d, c_i,
+                              c_d, c_i, c_d, c_p, c_i, c_p, c_l],
+    "jxg_lmm_scan_chain_tab": [c_p, c_i, c_i, c_p, c_p, c_i, c_d, c_d, c_p, c_d, c_i, c_p, c_i, c_p, c_i, c_d, c_p, c_p, c_p],
+    "jxg_lmm_scan_chain": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_i, c_p, c_i, c_d, c_p, c_p, c_p],
+    "jxg_lmm_scan_exact_chain": [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_d, c_d, c_d, c_i, c_p, c_i, c_p, c_i, c_d, c_p, c_p, c_p],
+    "jxg_lmm_series_doubles": [c_i, c_d, c_d],
+    "jxg_lmm_series_coef_tab": [c_p, c_i, c_i, c_p, c_i, c_d, c_d, c_p, c_p, c_p, c_p],
+    "jxg_lmm_series_brent_tab": [c_i, c_i, c_p, c_p, c_i, c_d, c_d, c_p, c_d, c_i, c_i, c_d, c_p, c_p, c_p, c_i, c_p, c_i, c_d,
+                                 c_p, c_p, c_p],
     "jx_assoc_packed_gm": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                            c_d, c_i, c_d, c_p, c_i],
     "jxg_rotate_packed16x_fused": [c_p, c_l, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i,
@@ -149,7 +158,8 @@ SIGNATURES = {
 _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_lmm_tables_bytes": C.c_int64,
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64, "jxg_eigh_band_staging_doubles": C.c_int64,
              "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
-             "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64, "jxg_scratch_trim": C.c_int64}
+             "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64, "jxg_scratch_trim": C.c_int64,
+             "jxg_lmm_series_doubles": C.c_int64}
 
 
 def lib():

@@ -298,6 +298,14 @@ def _canon_site_key(chrom, pos):
     return (c[3:] if c.startswith("chr") else c), int(pos)
 
 
+def _warm_start_mode(args):
+    """'chain' | 'none' for `jx gwas -lmm`: the flag, else the reference's rule (chain unless JX_LMM_UNIFIED_NO_WARM_START)."""
+    from .stats import env_truthy
+    if getattr(args, "warm_start", None) is not None:
+        return args.warm_start
+    return "none" if env_truthy("JX_LMM_UNIFIED_NO_WARM_START") else "chain"
+
+
 def cmd_gwas(args):
     import torch
     from . import janusx as jxrs
@@ -482,8 +490,14 @@ def cmd_gwas(args):
                 return wr["w"].put
 
             try:
+                # `-lmm`: the reference's default scan -- warm-start chains over chunks of `-chunksize` rows of the file, seeded
+                # with log10 lambda0 (workflow_model_stream.py:1436-1480; src/stats/lmm.rs:2627); JX_LMM_UNIFIED_NO_WARM_START=1
+                # or `-warm-start none` give every SNP the same start (and the faster one-wave-per-SNP scan)
+                chain = None
+                if mode == "lmm" and _warm_start_mode(args) == "chain":
+                    chain = (max(1, int(args.chunksize)), max(1, int(args.warm_chain_pieces)))
                 res = pl.run_trait(packed_t, n_fam, k, keep_idx, y, x, mode, args.maf, args.geno, args.het,
-                                   on_rows=open_writer, force_model=bool(args.force_model))
+                                   on_rows=open_writer, force_model=bool(args.force_model), warm_chain=chain)
             except BaseException:
                 if "w" in wr:
                     wr["w"].abort()
@@ -843,6 +857,14 @@ def main(argv=None):
     g.add_argument("-o", "--out", default=None)
     g.add_argument("-prefix", "--prefix", default=None, help="file name prefix inside the -o directory")
     g.add_argument("-force-model", "--force-model", dest="force_model", action="store_true", default=False)
+    g.add_argument("-chunksize", "--chunksize", dest="chunksize", type=int, default=10000,
+                   help="SNP rows per scan chunk (the reference's default 10000): the length of a warm-start chain of -lmm")
+    g.add_argument("-warm-start", "--warm-start", dest="warm_start", choices=["chain", "none"], default=None,
+                   help="-lmm: 'chain' (the reference's default: each SNP's Brent starts from the previous SNP's optimum inside "
+                        "a chunk) or 'none'; default chain unless JX_LMM_UNIFIED_NO_WARM_START is set")
+    g.add_argument("-warm-chain-pieces", "--warm-chain-pieces", dest="warm_chain_pieces", type=int, default=1,
+                   help="cut every chunk's chain into this many pieces (power of two) by halving, as rayon's splitter does on "
+                        "the reference's thread pool (2 x threads pieces); 1 = one chain per chunk")
     g.add_argument("-t", "--thread", type=int, default=0, help="accepted for compatibility; unused")
     g.set_defaults(func=cmd_gwas)
     g.add_argument("-splmm", "--splmm", "-splmm-approx", "--splmm-approx", dest="splmm", nargs="?", const=0.05, default=None,

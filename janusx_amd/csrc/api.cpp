@@ -992,11 +992,45 @@ extern "C" int jx_assoc_packed(const uint8_t *packed, int64_t m, int n_samples, 
     return jx_assoc_packed_gm(packed, m, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, p, sample_indices, n_sel, model, low,
                               high, max_iter, tol, warm, init_log10_lbd, has_nullml, nullml, out, 0);
 }
+static int assoc_packed_impl(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                             const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                             const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
+                             double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
+                             int has_nullml, double nullml, double *out, int genetic_model, const int64_t *chain_off,
+                             int64_t n_chains);
 extern "C" int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
                                   const float *row_maf, const double *s, const double *xcov, const double *y_rot,
                                   const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
                                   double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
                                   int has_nullml, double nullml, double *out, int genetic_model) {
+    return assoc_packed_impl(packed, m, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, p, sample_indices, n_sel, model, low,
+                             high, max_iter, tol, warm, init_log10_lbd, has_nullml, nullml, out, genetic_model, nullptr, 0);
+}
+// The exact scan (model 0) along the reference's warm-start chains (`carry_warm_start`, src/stats/lmm.rs:134-161: on in
+// `lmm_reml_assoc_packed_f32` :3244-3245 and, unless JX_LMM_UNIFIED_NO_WARM_START is set, in the BED route :2627): chain c is the
+// rows [chain_off[c], chain_off[c + 1]) of the payload in order (chain_off[0] = 0, ascending, chain_off[n_chains] = m); the
+// first valid SNP of a chain starts from init_log10_lbd (warm != 0) or the interval midpoint, every later one from the optimum
+// of the valid SNP before it.  The chains run in parallel, the rows of a chain in sequence.
+extern "C" int jx_assoc_packed_chain(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                                     const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                                     const float *u_t, int p, const int64_t *sample_indices, int n_sel, double low, double high,
+                                     int max_iter, double tol, int warm, double init_log10_lbd, int has_nullml, double nullml,
+                                     double *out, int genetic_model, const int64_t *chain_off, int64_t n_chains) {
+    if (m > 0) {
+        if (!chain_off || n_chains <= 0) return fail("jx_assoc_packed_chain: chain offsets are required");
+        if (chain_off[0] != 0 || chain_off[n_chains] != m) return fail("jx_assoc_packed_chain: chain offsets must run from 0 to m");
+        for (int64_t c = 0; c < n_chains; ++c)
+            if (chain_off[c + 1] < chain_off[c]) return fail("jx_assoc_packed_chain: chain offsets must ascend");
+    }
+    return assoc_packed_impl(packed, m, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, p, sample_indices, n_sel, 0, low, high,
+                             max_iter, tol, warm, init_log10_lbd, has_nullml, nullml, out, genetic_model, chain_off, n_chains);
+}
+static int assoc_packed_impl(const uint8_t *packed, int64_t m, int n_samples, const uint8_t *row_flip,
+                             const float *row_maf, const double *s, const double *xcov, const double *y_rot,
+                             const float *u_t, int p, const int64_t *sample_indices, int n_sel, int model,
+                             double low, double high, int max_iter, double tol, int warm, double init_log10_lbd,
+                             int has_nullml, double nullml, double *out, int genetic_model, const int64_t *chain_off,
+                             int64_t n_chains) {
     if (genetic_model < 0 || genetic_model > 3) return fail("model must be one of: add, dom, rec, het");
     const int cols = model == 2 ? 6 : (has_nullml ? 4 : 3);
     if (model < 0 || model > 2) return fail("model must be 0 (lmm), 1 (fvlmm) or 2 (lmm2)");
@@ -1112,6 +1146,57 @@ extern "C" int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_sample
     DevBuf drows;
     if (drows.alloc(sizeof(int32_t) * (size_t)brows)) return 1;
     std::vector<int32_t> hrows((size_t)brows);
+    // ---- warm-start chains (model 0) ------------------------------------------------------------------------------------
+    // carry: one state per chain (NaN: none).  With the series form (k_scan_fast.hip) the series of a SUPER-BLOCK of rows are kept
+    // and ONE Brent launch walks every chain that touches it -- a block of 8192 rows holds 16 chains of 512 rows, far too few
+    // sequential jobs for 256 CUs; without it (wide bounds, many covariates) the chains are walked block by block.  A chain cut
+    // by a block or super-block boundary continues from its carry state.
+    const bool chain = chain_off != nullptr && model == 0;
+    DevBuf dcarry, dchoff, dtab, dscoef, dsssq, dout_sb;
+    std::vector<int32_t> hchoff;
+    int64_t sd = 0, sb_rows = 0, sb0 = 0;            // series doubles per row; rows per super-block; first row of the open one
+    if (chain) {
+        if (dcarry.alloc(sizeof(double) * (size_t)n_chains)) return 1;
+        std::vector<double> hc((size_t)n_chains, (warm && std::isfinite(init_log10_lbd)) ? init_log10_lbd : std::nan(""));
+        JX_HIP(hipMemcpy(dcarry.p, hc.data(), sizeof(double) * (size_t)n_chains, hipMemcpyHostToDevice));
+        const int64_t tb = jxg_lmm_tables_bytes(n, p, low, high);
+        sd = tb > 0 ? jxg_lmm_series_doubles(p, low, high) : 0;
+        if (sd > 0) {
+            if (dtab.alloc((size_t)tb)) return 1;
+            if (jxg_lmm_tables_build(nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), n, p, low, high, dtab.p, nullptr))
+                return 1;
+            const int64_t cap = ((int64_t)8 << 30) / (8 * (sd + 1 + cols));
+            sb_rows = std::min<int64_t>(m, std::max<int64_t>(brows, cap / brows * brows));
+            if (dscoef.alloc(sizeof(double) * (size_t)(sb_rows * sd)) || dsssq.alloc(sizeof(double) * (size_t)sb_rows) ||
+                dout_sb.alloc(sizeof(double) * (size_t)(sb_rows * cols)))
+                return 1;
+        }
+        if (dchoff.alloc(sizeof(int32_t) * (size_t)(std::min<int64_t>(n_chains, sd > 0 ? sb_rows : brows) + 2))) return 1;
+    }
+    // chains touching the rows [a, b): local offsets into hchoff, -> index of the first one
+    auto chain_segments = [&](int64_t a, int64_t b, int64_t &c_first) -> int {
+        const int64_t *lo = std::upper_bound(chain_off, chain_off + n_chains + 1, a) - 1;       // last offset <= a
+        c_first = lo - chain_off;
+        if (c_first >= n_chains) c_first = n_chains - 1;
+        hchoff.clear();
+        int64_t c = c_first;
+        for (; c < n_chains && chain_off[c] < b; ++c)
+            hchoff.push_back((int32_t)(std::max<int64_t>(chain_off[c], a) - a));
+        hchoff.push_back((int32_t)(std::min<int64_t>(chain_off[c], b) - a));
+        return (int)(c - c_first);
+    };
+    auto chain_brent_superblock = [&](int64_t a, int64_t b) -> int {
+        int64_t c_first = 0;
+        const int nch = chain_segments(a, b, c_first);
+        if ((size_t)(nch + 1) * sizeof(int32_t) > dchoff.bytes && dchoff.alloc(sizeof(int32_t) * (size_t)(nch + 1))) return 1;
+        JX_HIP(hipMemcpy(dchoff.p, hchoff.data(), sizeof(int32_t) * (size_t)(nch + 1), hipMemcpyHostToDevice));
+        if (jxg_lmm_series_brent_tab((int)(b - a), n, nd.s.as<double>(), nd.x.as<double>(), p, low, high, dtab.p, tol, max_iter, 0,
+                                     0.0, dscoef.as<double>(), dsssq.as<double>(), dchoff.as<int32_t>(), nch,
+                                     dcarry.as<double>() + c_first, has_nullml, nullml, dout_sb.as<double>(), nullptr, nullptr))
+            return 1;
+        JX_HIP(hipMemcpy(out + (size_t)a * cols, dout_sb.p, sizeof(double) * (size_t)(b - a) * cols, hipMemcpyDeviceToHost));
+        return 0;
+    };
     ProgressTicker ticker;
     for (int64_t r0 = 0; r0 < m; r0 += brows) {
         const int rows = (int)std::min<int64_t>(brows, m - r0);
@@ -1163,6 +1248,26 @@ extern "C" int jx_assoc_packed_gm(const uint8_t *packed, int64_t m, int n_sample
             return 1;
         }
         if (fused) {
+        } else if (chain && sd > 0) {
+            // series of this block behind those of the open super-block; Brent when the super-block is full or the payload ends
+            if (jxg_lmm_series_coef_tab(drot.as<float>(), rows, n, nd.x.as<double>(), p, low, high, dtab.p,
+                                        dscoef.as<double>() + (size_t)(r0 - sb0) * sd, dsssq.as<double>() + (r0 - sb0), nullptr))
+                return 1;
+            if (r0 + rows - sb0 >= sb_rows || r0 + rows >= m) {
+                if (chain_brent_superblock(sb0, r0 + rows)) return 1;
+                sb0 = r0 + rows;
+            }
+            if (ticker.tick(r0 + rows, m, brows)) return fail("interrupted by the progress callback");
+            continue;
+        } else if (chain) {
+            int64_t c_first = 0;
+            const int nch = chain_segments(r0, r0 + rows, c_first);
+            if ((size_t)(nch + 1) * sizeof(int32_t) > dchoff.bytes && dchoff.alloc(sizeof(int32_t) * (size_t)(nch + 1))) return 1;
+            JX_HIP(hipMemcpy(dchoff.p, hchoff.data(), sizeof(int32_t) * (size_t)(nch + 1), hipMemcpyHostToDevice));
+            if (jxg_lmm_scan_chain(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low, high,
+                                   tol, max_iter, dchoff.as<int32_t>(), nch, dcarry.as<double>() + c_first, has_nullml, nullml,
+                                   dout.as<double>(), nullptr, nullptr))
+                return 1;
         } else if (model == 0) {
             if (jxg_lmm_scan(drot.as<float>(), rows, n, nd.s.as<double>(), nd.x.as<double>(), nd.y.as<double>(), p, low,
                              high, tol, max_iter, warm, init_log10_lbd, has_nullml, nullml, dout.as<double>(), nullptr,

@@ -268,13 +268,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
                                                                 double high, double tol, int max_iter, int warm,
                                                                 double init, int with_plrt, double nullml,
                                                                 double *__restrict__ out,
-                                                                int32_t *__restrict__ evals_out) {
+                                                                int32_t *__restrict__ evals_out,
+                                                                const int32_t *__restrict__ chain_off, int nchains,
+                                                                double *__restrict__ carry) {
     constexpr bool WAVE = true;
     double *shm = nullptr;
     const int out_cols = with_plrt ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (int r = blockIdx.x * SCAN_WAVES + wave; r < nrows; r += gridDim.x * SCAN_WAVES) {
+    // chain_off: the reference's warm-start chain (carry_warm_start, lmm.rs:134-161): a wave walks the rows
+    // [chain_off[c], chain_off[c + 1]) in order, every SNP's Brent starts from the optimum of the row before it; carry[c] holds
+    // the state a chain starts from (NaN: none -- the interval midpoint) and receives the state it ends with, so that a chain
+    // may continue in the next launch.  Without chain_off: one row per unit, `warm` / `init` as before.
+    const int nunits = chain_off ? nchains : nrows;
+    for (int unit = blockIdx.x * SCAN_WAVES + wave; unit < nunits; unit += gridDim.x * SCAN_WAVES) {
+      const int r_beg = chain_off ? chain_off[unit] : unit, r_end = chain_off ? chain_off[unit + 1] : unit + 1;
+      double last = chain_off ? carry[unit] : init;
+      bool have_last = chain_off ? isfinite(last) : (warm != 0);
+      for (int r = r_beg; r < r_end; ++r) {
         const float *g = grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         // lmm.rs:63-72: ssq of the rotated row
@@ -296,7 +307,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
         }
         double xb, fb;
         int ne = 0;
-        brent_reml<MAXD, WAVE>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, warm != 0, init, shm, xb, fb, ne);
+        brent_reml<MAXD, WAVE>(s, xcov, y, g, n, p_cov, low, high, tol, max_iter, have_last, last, shm, xb, fb, ne);
+        if (chain_off) {
+            last = xb;
+            have_last = true;
+        }
         // final_beta_se (reml.rs:472-568)
         const double lbd = pow(10.0, xb);
         const int dim = p_cov + 1;
@@ -349,6 +364,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void lmm_scan_kernel(const float *__r
                 if (with_plrt) o[3] = 1.0;
             }
         }
+      }
+      if (chain_off && lane == 0 && have_last) carry[unit] = last;
     }
 }
 
@@ -871,7 +888,28 @@ extern "C" int jxg_lmm_scan_exact(const float *d_grot, int nrows, int n, const d
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM(dim, hipLaunchKernelGGL(lmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
                                             (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high,
-                                            tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out, d_evals));
+                                            tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out, d_evals,
+                                            (const int32_t *)nullptr, 0, (double *)nullptr));
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same scan along the reference's warm-start chains (src/stats/lmm.rs:134-161): d_chain_off (nchains + 1 row offsets into
+// this block, ascending), d_carry (nchains doubles: start state in, end state out; NaN = no state).
+extern "C" int jxg_lmm_scan_exact_chain(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                                        const double *d_y, int p, double low, double high, double tol, int max_iter,
+                                        const int32_t *d_chain_off, int nchains, double *d_carry, int with_plrt, double nullml,
+                                        double *d_out, int32_t *d_evals, void *stream) {
+    if (nrows <= 0 || nchains <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_exact_chain: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    if (!d_chain_off || !d_carry) return fail("jxg_lmm_scan_exact_chain: chain offsets and carry states are required");
+    const int dim = p + 1;
+    const int grid = (nchains + SCAN_WAVES - 1) / SCAN_WAVES;
+    JX_DISPATCH_DIM(dim, hipLaunchKernelGGL(lmm_scan_kernel<MAXD>, dim3(grid), dim3(SCAN_THREADS), 0,
+                                            (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high,
+                                            tol, max_iter, 0, 0.0, with_plrt, nullml, d_out, d_evals, d_chain_off, nchains,
+                                            d_carry));
     JX_LAUNCH_CHECK();
     return 0;
 }

@@ -634,7 +634,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out,
-    const double *__restrict__ snp_coef, const double *__restrict__ snp_ssq, const ChebHeader shd) {
+    const double *__restrict__ snp_coef, const double *__restrict__ snp_ssq, const ChebHeader shd,
+    const int32_t *__restrict__ chain_off = nullptr, int nchains = 0, double *__restrict__ carry = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
     if (MAXD == 2) p = 1;     // dim = p + 1 <= 2 and p >= 1: a compile-time p (see lmm_scan_tiled_kernel)
     const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
@@ -654,7 +655,16 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const double smin = smin_ptr[0];
-    for (int r = blockIdx.x * NW + wave; r < nrows; r += gridDim.x * NW) {
+    // chain_off: the reference's warm-start chain (carry_warm_start, src/stats/lmm.rs:134-161): this wave walks the rows
+    // [chain_off[c], chain_off[c + 1]) in order and every SNP's Brent starts from the optimum of the valid row before it; carry[c]
+    // is the state the chain starts from (NaN: none) and receives the state it ends with (a chain may continue in a later launch).
+    // Without chain_off a unit is one row and `warm` / `init` seed every row alike (seed_with_init_guess).
+    const int nunits = chain_off ? nchains : nrows;
+    for (int unit = blockIdx.x * NW + wave; unit < nunits; unit += gridDim.x * NW) {
+      const int r_beg = chain_off ? chain_off[unit] : unit, r_end = chain_off ? chain_off[unit + 1] : unit + 1;
+      double last = chain_off ? carry[unit] : init;
+      bool have_last = chain_off ? isfinite(last) : (warm != 0);
+      for (int r = r_beg; r < r_end; ++r) {
         const float *g = SERIES ? nullptr : grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         double ssq = 0.0;
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
         }
         const double eps = 2.220446049250313e-16;
         const double tol = fmax(fabs(tol_in), 1e-12);
-        double x = (warm && isfinite(init) && init >= a && init <= c) ? init : 0.5 * (a + c);
+        double x = (have_last && isfinite(last) && last >= a && last <= c) ? last : 0.5 * (a + c);
         double w = x, v = x;
         eval_at(x, false, ev, nullptr);
         double fx = ev.reml_neg, fw = fx, fv = fx;
@@ -774,6 +784,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
                 }
             }
         }
+        if (chain_off) {
+            last = x;
+            have_last = true;
+        }
         // ---- final_beta_se (src/stats/reml.rs:472-568) at the optimum ------------------------------------
         eval_at(x, true, ev, smin_ptr + 8);
         double beta = nan(""), se = nan("");
@@ -817,6 +831,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
                 if (with_plrt) o[3] = 1.0;
             }
         }
+      }
+      if (chain_off && lane == 0 && have_last) carry[unit] = last;
     }
 }
 
@@ -1481,93 +1497,31 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
 
 namespace jx { extern float g_last_ms[24]; }   // [11]: form the last exact scan launch took (0 LDS-resident, 1 tiled, 2 plain)
 
-extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
-                                double low, double high, const void *d_work, double tol, int max_iter, int warm,
-                                double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
-                                void *stream) {
-    if (nrows <= 0) return 0;
-    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_tab: p out of range");
-    if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_scan_tab: configuration needs the exact scan path");
+// keep the stream-ordered pool's blocks across synchronisations (default threshold 0: every hipFreeAsync'ed block goes back to the
+// driver at the next synchronisation and the next call pays a fresh allocation): 256 MB cover the largest call
+static void series_pool_keep() {
+    static bool pool_set = false;
+    if (pool_set) return;
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        uint64_t thr = (uint64_t)256 << 20;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    (void)hipGetLastError();
+    pool_set = true;
+}
+
+// per-SNP series of a block of rotated rows: scoef (nrows, p + 2, SR_M), sssq (nrows) -- series_coef_kernel per group of quantities
+static int series_coef_launch(const float *d_grot, int nrows, int n, int p, const double *d_xcov, const void *d_work, double low,
+                              double high, double *scoef, double *sssq, hipStream_t st) {
     const ChebHeader hd = make_header(p, low, high);
     const double *w = (const double *)d_work;
-    const double *smin = w, *yc = w + CH_HDR, *coef = yc + yc_doubles(n);
-    const int dim = p + 1;
-    // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
-    const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
-    const bool lmm2 = with_plrt == 2;               // the two-search scan (out has six columns): tiled kernel at every n
-    const bool lds_fits = !lmm2 && dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
-    // per-SNP series form (one MFMA pass over the rows + Brent on the series) wherever s / X~ / y~ do not stay in LDS for the
-    // one-wave-per-SNP form (measured at n = 5000, intercept only: LDS-resident form 6.8 ms, series form 10.5 ms per 50 000 SNPs)
-    const bool series = !lmm2 && !lds_fits && series_ok(p, low, high) && !getenv("JXGPU_SCAN_NOTILE");
-    const bool use_lds = lds_fits;
-    if (use_lds) {
-        g_last_ms[11] = 0.f;
-        if (dim <= 2) {
-            constexpr int NW = 16;
-            auto kfn = lmm_scan_fast_kernel<2, NW, true>;
-            static bool attr_done = false;
-            if (!attr_done) {
-                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done = true;
-            }
-            int grid = (nrows + NW - 1) / NW;
-            if (grid > 65536) grid = 65536;
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
-                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd);
-        } else {
-            constexpr int NW = 8;
-            auto kfn = lmm_scan_fast_kernel<4, NW, true>;
-            static bool attr_done4 = false;
-            if (!attr_done4) {
-                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_done4 = true;
-            }
-            int grid = (nrows + NW - 1) / NW;
-            if (grid > 65536) grid = 65536;
-            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
-                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
-                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd);
-        }
-        JX_LAUNCH_CHECK();
-        return 0;
-    }
-    if (series) {
-        // n beyond the LDS-resident limit: ONE streaming pass over the rotated rows per group of four quantities builds every
-        // SNP's Chebyshev series of its SNP-specific sums on the f64 matrix pipes, Brent then runs on the series
-        g_last_ms[11] = 3.f;
-        hipStream_t st = (hipStream_t)stream;
-        const int nq = p + 2;
-        const ChebHeader shd = series_header(low, high);
-        // series + sums of squares of THIS call: stream-ordered allocation, released behind the Brent kernel on the same stream
-        // (a process-wide buffer would be shared by concurrent calls on other streams while their kernels are in flight: ADVICE r4)
-        const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
-        void *sraw = nullptr;
-        {
-            // keep the stream-ordered pool's blocks across synchronisations (default threshold 0: every hipFreeAsync'ed block goes back to
-            // the driver at the next synchronisation and the next call pays a fresh allocation): 256 MB cover the largest call
-            static bool pool_set = false;
-            if (!pool_set) {
-                int dev = 0;
-                hipMemPool_t pool = nullptr;
-                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-                    uint64_t thr = (uint64_t)256 << 20;
-                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-                }
-                (void)hipGetLastError();
-                pool_set = true;
-            }
-        }
-        JX_HIP(hipMallocAsync(&sraw, need, st));
-        struct SeriesFree {
-            void *p;
-            hipStream_t s;
-            ~SeriesFree() { (void)hipFreeAsync(p, s); }
-        } sfree{sraw, st};
-        double *scoef = (double *)sraw, *sssq = scoef + (size_t)nrows * nq * SR_M;
-        const double *what = coef + 2 * (int64_t)hd.nseg * hd.nf * CH_N;
-        const int npad = (int)series_npad(n);
-        const size_t lds = sizeof(double) * ((size_t)SR_SC * SR_WP + (size_t)(p + 1) * SR_SC) + sizeof(float) * 128 * SR_GP;
+    const double *yc = w + CH_HDR, *coef = yc + yc_doubles(n);
+    const double *what = coef + 2 * (int64_t)hd.nseg * hd.nf * CH_N;
+    const int nq = p + 2;
+    const int npad = (int)series_npad(n);
+    const size_t lds = sizeof(double) * ((size_t)SR_SC * SR_WP + (size_t)(p + 1) * SR_SC) + sizeof(float) * 128 * SR_GP;
 #define JX_SERIES_COEF(NQV, Q0)                                                                                            \
     do {                                                                                                                  \
         auto kfn = series_coef_kernel<NQV>;                                                                               \
@@ -1580,29 +1534,140 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
                            what, scoef, sssq);                                                                            \
         JX_LAUNCH_CHECK();                                                                                                \
     } while (0)
-        for (int q0 = 0; q0 < nq;) {
-            const int left = nq - q0;
-            if (left == 3) { JX_SERIES_COEF(3, q0); q0 += 3; }
-            else if (left >= 4) { JX_SERIES_COEF(4, q0); q0 += 4; }
-            else if (left == 2) { JX_SERIES_COEF(2, q0); q0 += 2; }
-            else { JX_SERIES_COEF(1, q0); q0 += 1; }
-        }
+    for (int q0 = 0; q0 < nq;) {
+        const int left = nq - q0;
+        if (left == 3) { JX_SERIES_COEF(3, q0); q0 += 3; }
+        else if (left >= 4) { JX_SERIES_COEF(4, q0); q0 += 4; }
+        else if (left == 2) { JX_SERIES_COEF(2, q0); q0 += 2; }
+        else { JX_SERIES_COEF(1, q0); q0 += 1; }
+    }
 #undef JX_SERIES_COEF
-        constexpr int NW = 8;
-        const int grid = (nrows + NW - 1) / NW;
+    return 0;
+}
+
+// Brent on stored series: one wave per SNP, or -- chain_off given -- one wave per warm-start chain
+static int series_brent_launch(int nrows, int n, const double *d_s, const double *d_xcov, int p, double low, double high,
+                               const void *d_work, double tol, int max_iter, int warm, double init_log10_lbd, int with_plrt,
+                               double nullml, double *d_out, int32_t *d_evals, const double *scoef, const double *sssq,
+                               hipStream_t st, const int32_t *chain_off, int nchains, double *carry) {
+    const ChebHeader hd = make_header(p, low, high);
+    const ChebHeader shd = series_header(low, high);
+    const double *w = (const double *)d_work;
+    const double *smin = w, *yc = w + CH_HDR, *coef = yc + yc_doubles(n);
+    const int dim = p + 1;
+    const bool chain = chain_off != nullptr;
+    const int nunits = chain ? nchains : nrows;
+    if (nunits <= 0) return 0;
+    const float *d_grot = nullptr;
+    constexpr int NW = 8;
+    // chains: ONE wave per workgroup -- a chain is a long sequential job and there are few of them (m / 512): spread over the
+    // CUs they do not share a SIMD's issue slots
+    const int grid = chain ? nunits : (nunits + NW - 1) / NW;
 #define JX_SERIES_BRENT(MAXDV)                                                                                             \
-    hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, d_s,   \
-                       d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, d_out,    \
-                       d_evals, (const double *)scoef, (const double *)sssq, shd)
-        if (dim <= 2) JX_SERIES_BRENT(2);
-        else if (dim <= 4) JX_SERIES_BRENT(4);
-        else if (dim <= 8) JX_SERIES_BRENT(8);
-        else JX_SERIES_BRENT(16);
+    do {                                                                                                                  \
+        if (chain)                                                                                                        \
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, 1, false, true>), dim3(grid), dim3(64), 0, st, d_grot, nrows, n, d_s, \
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,  \
+                               d_out, d_evals, scoef, sssq, shd, chain_off, nchains, carry);                                      \
+        else                                                                                                              \
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, NW, false, true>), dim3(grid), dim3(NW * 64), 0, st, d_grot, nrows, n, \
+                               d_s, d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,     \
+                               nullml, d_out, d_evals, scoef, sssq, shd);                                                         \
+    } while (0)
+    if (dim <= 2) JX_SERIES_BRENT(2);
+    else if (dim <= 4) JX_SERIES_BRENT(4);
+    else if (dim <= 8) JX_SERIES_BRENT(8);
+    else JX_SERIES_BRENT(16);
 #undef JX_SERIES_BRENT
+    JX_LAUNCH_CHECK();
+    return 0;
+}
+
+// chain_off / nchains / carry: the warm-start chains of the reference (device pointers; see lmm_scan_fast_kernel), or nullptr
+static int lmm_scan_tab_impl(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
+                             double low, double high, const void *d_work, double tol, int max_iter, int warm,
+                             double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                             void *stream, const int32_t *chain_off, int nchains, double *carry) {
+    if (nrows <= 0) return 0;
+    const bool chain = chain_off != nullptr;
+    if (chain && nchains <= 0) return 0;
+    const int nunits = chain ? nchains : nrows;      // waves of work: one per chain, or one per row
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_tab: p out of range");
+    if (!fast_path_ok(p, low, high)) return fail("jxg_lmm_scan_tab: configuration needs the exact scan path");
+    const ChebHeader hd = make_header(p, low, high);
+    const double *w = (const double *)d_work;
+    const double *smin = w, *yc = w + CH_HDR, *coef = yc + yc_doubles(n);
+    const int dim = p + 1;
+    // LDS-resident s / X~ / y~ when they fit one workgroup's share (one workgroup per CU: 160 KB less a margin)
+    const size_t lds_bytes = sizeof(double) * (size_t)n * (size_t)(2 + p);
+    const bool lmm2 = with_plrt == 2;               // the two-search scan (out has six columns): tiled kernel at every n
+    if (chain && lmm2) return fail("jxg_lmm_scan_chain: the two-search scan has no chain form");
+    const bool lds_fits0 = !lmm2 && dim <= 4 && lds_bytes <= (size_t)156 * 1024 && !getenv("JXGPU_SCAN_NOLDS");
+    // per-SNP series form (one MFMA pass over the rows + Brent on the series) wherever s / X~ / y~ do not stay in LDS for the
+    // one-wave-per-SNP form (measured at n = 5000, intercept only: LDS-resident form 6.8 ms, series form 10.5 ms per 50 000 SNPs).
+    // Along chains the series form is taken wherever it exists: the pass over the rows stays parallel over all SNPs, only the
+    // Brent searches on the series run in chain order (one wave per chain), where an evaluation is a Clenshaw recurrence
+    const bool series = !lmm2 && (chain || !lds_fits0) && series_ok(p, low, high) && !getenv("JXGPU_SCAN_NOTILE");
+    const bool lds_fits = lds_fits0 && !series;
+    const bool use_lds = lds_fits;
+    if (use_lds) {
+        g_last_ms[11] = 0.f;
+        if (dim <= 2) {
+            constexpr int NW = 16;
+            auto kfn = lmm_scan_fast_kernel<2, NW, true>;
+            static bool attr_done = false;
+            if (!attr_done) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done = true;
+            }
+            int grid = (nunits + NW - 1) / NW;
+            if (grid > 65536) grid = 65536;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd, chain_off, nchains,
+                               carry);
+        } else {
+            constexpr int NW = 8;
+            auto kfn = lmm_scan_fast_kernel<4, NW, true>;
+            static bool attr_done4 = false;
+            if (!attr_done4) {
+                JX_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_done4 = true;
+            }
+            int grid = (nunits + NW - 1) / NW;
+            if (grid > 65536) grid = 65536;
+            hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
+                               d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                               nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd, chain_off, nchains,
+                               carry);
+        }
         JX_LAUNCH_CHECK();
         return 0;
     }
-    if (lmm2 || !getenv("JXGPU_SCAN_NOTILE")) {
+    if (series) {
+        // n beyond the LDS-resident limit (and every chain scan): ONE streaming pass over the rotated rows per group of four
+        // quantities builds every SNP's Chebyshev series of its SNP-specific sums on the f64 matrix pipes, Brent then runs on
+        // the series
+        g_last_ms[11] = 3.f;
+        hipStream_t st = (hipStream_t)stream;
+        const int nq = p + 2;
+        // series + sums of squares of THIS call: stream-ordered allocation, released behind the Brent kernel on the same stream
+        // (a process-wide buffer would be shared by concurrent calls on other streams while their kernels are in flight: ADVICE r4)
+        const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
+        void *sraw = nullptr;
+        series_pool_keep();
+        JX_HIP(hipMallocAsync(&sraw, need, st));
+        struct SeriesFree {
+            void *p;
+            hipStream_t s;
+            ~SeriesFree() { (void)hipFreeAsync(p, s); }
+        } sfree{sraw, st};
+        double *scoef = (double *)sraw, *sssq = scoef + (size_t)nrows * nq * SR_M;
+        if (series_coef_launch(d_grot, nrows, n, p, d_xcov, d_work, low, high, scoef, sssq, st)) return 1;
+        return series_brent_launch(nrows, n, d_s, d_xcov, p, low, high, d_work, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                                   nullml, d_out, d_evals, scoef, sssq, st, chain_off, nchains, carry);
+    }
+    if (!chain && (lmm2 || !getenv("JXGPU_SCAN_NOTILE"))) {
         // n beyond the LDS-resident limit: tiles of the shared vectors in LDS, NW SNPs per workgroup in lock step
         g_last_ms[11] = 1.f;
         const int per_sample = 8 * (2 + p);
@@ -1651,15 +1716,95 @@ extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const dou
         return 0;
     }
     g_last_ms[11] = 2.f;
-    int grid = (nrows + SCAN_WAVES - 1) / SCAN_WAVES;
+    int grid = (nunits + SCAN_WAVES - 1) / SCAN_WAVES;
     if (grid > 65536 * 8) grid = 65536 * 8;
     JX_DISPATCH_DIM_F(dim, hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXD, SCAN_WAVES, false>), dim3(grid),
                                               dim3(SCAN_THREADS), 0, (hipStream_t)stream, d_grot, nrows, n, d_s, d_xcov,
                                               yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd,
                                               with_plrt, nullml, d_out, d_evals, (const double *)nullptr,
-                                              (const double *)nullptr, hd));
+                                              (const double *)nullptr, hd, chain_off, nchains, carry));
     JX_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int jxg_lmm_scan_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
+                                double low, double high, const void *d_work, double tol, int max_iter, int warm,
+                                double init_log10_lbd, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                                void *stream) {
+    return lmm_scan_tab_impl(d_grot, nrows, n, d_s, d_xcov, p, low, high, d_work, tol, max_iter, warm, init_log10_lbd, with_plrt,
+                             nullml, d_out, d_evals, stream, nullptr, 0, nullptr);
+}
+
+// The exact scan along the reference's warm-start chains (`carry_warm_start`, src/stats/lmm.rs:134-161; the default of
+// `lmm_reml_assoc_packed_f32` :3244-3245 and of the BED route :2627).  d_chain_off: nchains + 1 ascending row offsets into this
+// block of rotated rows (device, int32); d_carry: nchains doubles (device) -- the log10 lambda a chain starts from (NaN: none, the
+// first valid SNP starts from the interval midpoint) on entry, the optimum of the chain's last valid SNP on return, so that a
+// chain cut by the caller's blocking continues in the next call.  Tables as for jxg_lmm_scan_tab.
+extern "C" int jxg_lmm_scan_chain_tab(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov, int p,
+                                      double low, double high, const void *d_work, double tol, int max_iter,
+                                      const int32_t *d_chain_off, int nchains, double *d_carry, int with_plrt, double nullml,
+                                      double *d_out, int32_t *d_evals, void *stream) {
+    if (!d_chain_off || !d_carry) return fail("jxg_lmm_scan_chain_tab: chain offsets and carry states are required");
+    if (with_plrt != 0 && with_plrt != 1) return fail("jxg_lmm_scan_chain_tab: with_plrt must be 0 or 1");
+    return lmm_scan_tab_impl(d_grot, nrows, n, d_s, d_xcov, p, low, high, d_work, tol, max_iter, 0, 0.0, with_plrt, nullml,
+                             d_out, d_evals, stream, d_chain_off, nchains, d_carry);
+}
+
+extern "C" int jxg_lmm_scan_exact_chain(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                                        const double *d_y, int p, double low, double high, double tol, int max_iter,
+                                        const int32_t *d_chain_off, int nchains, double *d_carry, int with_plrt, double nullml,
+                                        double *d_out, int32_t *d_evals, void *stream);
+
+// Chain scan of one block with the tables built here (host entry points; pipeline.scan_rows builds them once per call).
+extern "C" int jxg_lmm_scan_chain(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,
+                                  const double *d_y, int p, double low, double high, double tol, int max_iter,
+                                  const int32_t *d_chain_off, int nchains, double *d_carry, int with_plrt, double nullml,
+                                  double *d_out, int32_t *d_evals, void *stream) {
+    if (nrows <= 0 || nchains <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_scan_chain: p out of range");
+    if (!(low < high)) return fail("low must be < high");
+    if (!fast_path_ok(p, low, high))
+        return jxg_lmm_scan_exact_chain(d_grot, nrows, n, d_s, d_xcov, d_y, p, low, high, tol, max_iter, d_chain_off, nchains,
+                                        d_carry, with_plrt, nullml, d_out, d_evals, stream);
+    hipStream_t st = (hipStream_t)stream;
+    void *work = nullptr;
+    JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
+    int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
+    if (!rc)
+        rc = jxg_lmm_scan_chain_tab(d_grot, nrows, n, d_s, d_xcov, p, low, high, work, tol, max_iter, d_chain_off, nchains, d_carry,
+                                    with_plrt, nullml, d_out, d_evals, stream);
+    (void)hipFreeAsync(work, st);
+    return rc;
+}
+
+// ---- the series form in two steps (chain scans of a whole payload): the series of every block of rotated rows are kept, ONE Brent
+// launch then walks all chains -- m / 512 sequential jobs are too few per block to fill the device block by block.
+// jxg_lmm_series_doubles: doubles per row of the series storage ((p + 2) SR_M), 0 when this (p, low, high) has no series form.
+extern "C" int64_t jxg_lmm_series_doubles(int p, double low, double high) {
+    return (fast_path_ok(p, low, high) && series_ok(p, low, high)) ? (int64_t)(p + 2) * SR_M : 0;
+}
+extern "C" int jxg_lmm_series_coef_tab(const float *d_grot, int nrows, int n, const double *d_xcov, int p, double low, double high,
+                                       const void *d_work, double *d_scoef, double *d_ssq, void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_series_coef_tab: p out of range");
+    if (!jxg_lmm_series_doubles(p, low, high)) return fail("jxg_lmm_series_coef_tab: this configuration has no series form");
+    return series_coef_launch(d_grot, nrows, n, p, d_xcov, d_work, low, high, d_scoef, d_ssq, (hipStream_t)stream);
+}
+// Brent on the stored series of `nrows` rows.  d_chain_off == NULL: one search per row (warm / init as jxg_lmm_scan_tab);
+// otherwise along the chains (nchains + 1 offsets, d_carry as jxg_lmm_scan_chain_tab).
+extern "C" int jxg_lmm_series_brent_tab(int nrows, int n, const double *d_s, const double *d_xcov, int p, double low, double high,
+                                        const void *d_work, double tol, int max_iter, int warm, double init_log10_lbd,
+                                        const double *d_scoef, const double *d_ssq, const int32_t *d_chain_off, int nchains,
+                                        double *d_carry, int with_plrt, double nullml, double *d_out, int32_t *d_evals,
+                                        void *stream) {
+    if (nrows <= 0) return 0;
+    if (p < 1 || p > JXG_MAX_COV) return fail("jxg_lmm_series_brent_tab: p out of range");
+    if (!jxg_lmm_series_doubles(p, low, high)) return fail("jxg_lmm_series_brent_tab: this configuration has no series form");
+    if (d_chain_off && !d_carry) return fail("jxg_lmm_series_brent_tab: chains need their carry states");
+    if (with_plrt != 0 && with_plrt != 1) return fail("jxg_lmm_series_brent_tab: with_plrt must be 0 or 1");
+    g_last_ms[11] = 3.f;
+    return series_brent_launch(nrows, n, d_s, d_xcov, p, low, high, d_work, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,
+                               d_out, d_evals, d_scoef, d_ssq, (hipStream_t)stream, d_chain_off, nchains, d_carry);
 }
 
 extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double *d_s, const double *d_xcov,

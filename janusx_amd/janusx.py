@@ -2142,9 +2142,25 @@ def lmm_reml_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, max_i
     return _chunk(s, xcov, y_rot, low, high, snp_chunk, u_t, max_iter, tol, nullml, "snp_chunk")
 
 
+def _resolve_warm_start(warm_start, route_env=None):
+    """`warm_start` of the exact-scan entry points -> "chain" | "none".  None = the reference's default: the chain
+    (`carry_warm_start`, src/stats/lmm.rs:134-161), switched off by a truthy JX_LMM_UNIFIED_NO_WARM_START.  The reference reads
+    that variable in the BED route only (:2627; its packed routes pass `true, true` unconditionally, :3244-3245, :3609-3610);
+    here one setting gives every exact-scan entry point and `jx gwas -lmm` the no-chain scan."""
+    from .stats import env_truthy
+    if warm_start is None:
+        return "none" if (route_env and env_truthy(route_env)) else "chain"
+    w = str(warm_start).strip().lower()
+    if w in ("chain", "carry", "on", "true", "1"):
+        return "chain"
+    if w in ("none", "off", "false", "0"):
+        return "none"
+    raise RuntimeError("warm_start must be 'chain' or 'none'")
+
+
 def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, model,
                   low, high, max_iter, tol, warm, init, nullml=None, progress_callback=None, progress_every=0,
-                  genetic_model="add"):
+                  genetic_model="add", chain_off=None):
     from .stats import genetic_model_code
     gm = genetic_model_code(genetic_model)          # `PackedGeneticModel::parse` (src/decode/decode.rs:107-119)
     s, xcov, y, n, p = _null_args(s, xcov, y_rot)
@@ -2166,6 +2182,14 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
     if n_eff != n:
         raise RuntimeError(f"selected sample count {n_eff} != len(y_rot) {n}")
     out = np.zeros((m, 6 if int(model) == 2 else (4 if nullml is not None else 3)), dtype=np.float64)
+    if chain_off is not None and int(model) == 0 and m > 0:
+        co = np.ascontiguousarray(chain_off, dtype=np.int64)
+        with _progress_hook(progress_callback, progress_every):
+            check(lib().jx_assoc_packed_chain(pk_ptr, m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
+                                              _p(idx), n_sel, float(low), float(high), int(max_iter), float(tol), int(warm),
+                                              float(init), 1 if nullml is not None else 0,
+                                              float(nullml if nullml is not None else 0.0), _p(out), gm, _p(co), len(co) - 1))
+        return out
     with _progress_hook(progress_callback, progress_every):
         check(lib().jx_assoc_packed_gm(pk_ptr, m, int(n_samples), _p(flip), _p(maf), _p(s), _p(xcov), _p(y), _p(u_t), p,
                                        _p(idx), n_sel, int(model), float(low), float(high), int(max_iter), float(tol),
@@ -2177,13 +2201,19 @@ def _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sam
 def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices=None,
                               row_indices=None, low=-5.0, high=5.0, max_iter=50, tol=1e-2, threads=0, model="add",
                               progress_callback=None, progress_every=0, nullml=None, init_log10_lbd=None,
-                              rotate_block_rows=256):
+                              rotate_block_rows=256, warm_start=None, warm_chain_pieces=1):
     """src/stats/lmm.rs:3040-3362 -> f64 (m, 3), or (m, 4) with `nullml` (plrt column, lmm.rs:202-330).
 
-    Warm start: the reference chains each SNP's optimum into the next one *per rayon work split*
-    (lmm.rs:134-140), which makes its output depend on thread scheduling.  This implementation is
-    deterministic: every SNP starts from `init_log10_lbd` when given (the head of the reference's chain),
-    else from the interval midpoint (the reference's `JX_LMM_UNIFIED_NO_WARM_START` / core-API behaviour)."""
+    Warm start (`warm_start`, None = the reference's default for this entry point = "chain"): the reference runs this scan
+    with `seed_with_init_guess = carry_warm_start = true` (lmm.rs:3244-3245): inside a block of `rotate_block_rows` rows
+    (blocks restart at every `progress_every` rows, :3253-3256) each SNP's Brent starts from the optimum of the valid SNP before it,
+    the first one from `init_log10_lbd` or the interval midpoint (:134-161).  Here the chains run in parallel, one wave per
+    chain, the rows of a chain in order -- bit-for-bit the sequential semantics.  rayon additionally cuts a block into pieces
+    with a fresh state each (2 T pieces on T idle threads, more under work stealing: the reference's own output depends on
+    scheduling); `warm_chain_pieces` (power of two) reproduces that halving deterministically, 1 = one chain per block.
+    warm_start="none": every SNP starts from `init_log10_lbd` when given, else from the midpoint (the core-API contract,
+    lmm.rs:1577-1579; what JX_LMM_UNIFIED_NO_WARM_START selects on the BED route)."""
+    from .stats import warm_chain_blocks_packed, warm_chain_offsets
     if low >= high:
         raise RuntimeError("low must be < high")
     if not (np.isfinite(tol) and tol > 0):
@@ -2191,9 +2221,14 @@ def lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_r
     warm, init = 0, 0.0
     if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
         warm, init = 1, float(min(max(init_log10_lbd, low), high))
+    chain_off = None
+    if _resolve_warm_start(warm_start, "JX_LMM_UNIFIED_NO_WARM_START") == "chain":
+        m_rows = int(len(row_indices)) if row_indices is not None else int(packed.shape[0])
+        chain_off = warm_chain_offsets(warm_chain_blocks_packed(m_rows, rotate_block_rows, progress_every), m_rows,
+                                       warm_chain_pieces)
     return _assoc_packed(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices, row_indices, 0,
                          low, high, max_iter, tol, warm, init, nullml, progress_callback, progress_every,
-                         genetic_model=model)
+                         genetic_model=model, chain_off=chain_off)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -2363,7 +2398,8 @@ def bed_row_counts(packed, n_samples, sample_indices=None):
 
 def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model, snps_only,
                      sample_ids, row_indices, row_flip, row_missing, row_maf, mode, low, high, max_iter, tol, nullml,
-                     init_log10_lbd, progress_callback, progress_every=0, mmap_window_mb=None):
+                     init_log10_lbd, progress_callback, progress_every=0, mmap_window_mb=None, warm_chain=None):
+    # warm_chain: None, or (rotate_block_rows, pieces) -- the exact scan along the reference's warm-start chains
     import torch
     from . import stats as st
     from .bed import read_fam_ids, snps_only_mask, stage_bed_payload
@@ -2414,8 +2450,15 @@ def _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
             warm, init = 1, float(min(max(init_log10_lbd, low), high))
+        chain_off = None
+        if warm_chain is not None:
+            from .stats import warm_chain_blocks_bed, warm_chain_offsets
+            # scan units: the prepared row list, or every SNP row of the file (src/stats/lmm.rs:1103-1106, 1121-1145)
+            units = np.arange(len(rows), dtype=np.int64) if row_indices is not None else rows
+            n_units = len(rows) if row_indices is not None else m
+            chain_off = warm_chain_offsets(warm_chain_blocks_bed(units, n_units, warm_chain[0]), len(rows), warm_chain[1])
         res = _assoc_packed(pk, n_fam, flip, af, s_, xcov_, y_, u_t, sidx, None, 0, low, high, max_iter, tol, warm, init,
-                            nullml, progress_callback, progress_every, genetic_model=genetic_model)
+                            nullml, progress_callback, progress_every, genetic_model=genetic_model, chain_off=chain_off)
     elif mode == "lmm2":
         warm, init = 0, 0.0
         if init_log10_lbd is not None and np.isfinite(init_log10_lbd):
@@ -2438,16 +2481,21 @@ def lmm_reml_assoc_bed_to_tsv_f32(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_
                                   genetic_model="add", snps_only=False, sample_ids=None, row_indices=None,
                                   row_flip=None, row_missing=None, row_maf=None, low=-5.0, high=5.0, max_iter=30,
                                   tol=1e-2, threads=0, nullml=None, init_log10_lbd=None, rotate_block_rows=512,
-                                  progress_callback=None, progress_every=0, mmap_window_mb=None):
+                                  progress_callback=None, progress_every=0, mmap_window_mb=None, warm_start=None,
+                                  warm_chain_pieces=1):
     """src/stats/lmm.rs:2488-2751 (the default `jx gwas -lmm` kernel call) -> rows written.
-    Deterministic start (see `lmm_reml_assoc_packed_f32`)."""
+    Warm start: as the reference, the chain is ON unless JX_LMM_UNIFIED_NO_WARM_START is truthy (:2627) or
+    warm_start="none"; a chain is the kept rows of one chunk of `rotate_block_rows` scan units (:1121-1145), see
+    `lmm_reml_assoc_packed_f32` for the semantics and `warm_chain_pieces`."""
     if low >= high:
         raise RuntimeError("low must be < high")
     if not (np.isfinite(tol) and tol > 0):
         raise RuntimeError("tol must be positive and finite")
+    chain = _resolve_warm_start(warm_start, "JX_LMM_UNIFIED_NO_WARM_START") == "chain"
     return _bed_scan_to_tsv(bed_prefix, out_tsv, s, xcov, y_rot, u_t, maf_thr, miss_thr, het_thr, genetic_model,
                             snps_only, sample_ids, row_indices, row_flip, row_missing, row_maf, "lmm", low, high,
-                            max_iter, tol, nullml, init_log10_lbd, progress_callback, progress_every, mmap_window_mb)
+                            max_iter, tol, nullml, init_log10_lbd, progress_callback, progress_every, mmap_window_mb,
+                            warm_chain=(int(rotate_block_rows), int(warm_chain_pieces)) if chain else None)
 
 
 def lmm_reml_lmm2_chunk_from_snp_f32(s, xcov, y_rot, low, high, snp_chunk, u_t, nullml, max_iter=50, tol=1e-2,
@@ -2524,12 +2572,14 @@ def lmm_reml_assoc_packed_f32_to_tsv(packed, n_samples, row_flip, row_maf, row_m
                                      chrom, pos, snp, allele0, allele1, out_tsv, sample_indices=None,
                                      row_indices=None, low=-5.0, high=5.0, max_iter=50, tol=1e-2, threads=0,
                                      model="add", progress_callback=None, progress_every=0, nullml=None,
-                                     init_log10_lbd=None, rotate_block_rows=256, bed_prefix=None):
-    """src/stats/lmm.rs:3364-3790 -> rows written (metadata lists empty => read the BIM via `bed_prefix`)."""
+                                     init_log10_lbd=None, rotate_block_rows=256, bed_prefix=None, warm_start=None,
+                                     warm_chain_pieces=1):
+    """src/stats/lmm.rs:3364-3790 -> rows written (metadata lists empty => read the BIM via `bed_prefix`); the scan with the
+    warm-start chain of `lmm_reml_assoc_packed_f32` (the reference passes `true, true` here as well, lmm.rs:3609-3610)."""
     from .tsv import write_assoc_tsv
     out = lmm_reml_assoc_packed_f32(packed, n_samples, row_flip, row_maf, s, xcov, y_rot, u_t, sample_indices,
                                     row_indices, low, high, max_iter, tol, threads, model, progress_callback,
-                                    progress_every, nullml, init_log10_lbd, rotate_block_rows)
+                                    progress_every, nullml, init_log10_lbd, rotate_block_rows, warm_start, warm_chain_pieces)
     m = out.shape[0]
     if not len(chrom):
         if not bed_prefix:

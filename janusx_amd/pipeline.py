@@ -475,11 +475,16 @@ def _fused_fixed_lambda(p: int) -> bool:
 
 def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray, mode="lmm", low=None,
               high=None, max_iter=30, tol=1e-2, init_log10_lbd=None, block_rows=8192, return_evals=False,
-              times: StageTimes = None, nullml=None, fv_state=None, on_block=None):
+              times: StageTimes = None, nullml=None, fv_state=None, on_block=None, chain_off=None):
     """Rotate + scan the given SNP rows. mode: 'lmm' (exact per-SNP REML), 'fvlmm' (fixed lambda) or 'lmm2' (REML Wald +
     ML likelihood ratio, needs `nullml`).  Returns a (len(rows), 3) f64 device tensor [beta, se, p] -- 4 columns
     [.., plrt] when `nullml` is given, 6 columns [beta, se, pwald, lambda, ml, plrt] for 'lmm2' -- (and the per-SNP
-    Brent evaluation counts)."""
+    Brent evaluation counts).
+    chain_off ('lmm' only): offsets into `rows` (int64, 0 ... len(rows), ascending; `stats.warm_chain_offsets`) of the
+    reference's warm-start chains (src/stats/lmm.rs:134-161): inside a chain every SNP's Brent starts from the optimum of the
+    valid SNP before it, the first one from `init_log10_lbd` or the interval midpoint.  The rotation and the per-SNP series stay
+    parallel over all SNPs; the Brent searches run one wave per chain -- in ONE launch behind the last block where the series
+    form exists (`on_block` then receives the whole table at the end), block by block with carried states otherwise."""
     dev = panel.device
     n = model.n
     if panel.n != n:
@@ -543,6 +548,17 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             tables = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             check(lib().jxg_lmm_tables_build(_ptr(model.S), _ptr(model.xcov), _ptr(model.y), n, model.p, lo_b, hi_b,
                                              _ptr(tables), _stream()))
+        if chain_off is not None:
+            co = np.ascontiguousarray(chain_off, dtype=np.int64)
+            if co.ndim != 1 or len(co) < 2 or co[0] != 0 or co[-1] != mk or np.any(np.diff(co) < 0):
+                raise RuntimeError("chain_off must ascend from 0 to len(rows)")
+            nch = len(co) - 1
+            carry = torch.full((nch,), init if warm else float("nan"), dtype=torch.float64, device=dev)
+            sd = int(lib().jxg_lmm_series_doubles(model.p, lo_b, hi_b)) if tables is not None else 0
+            if sd > 0:
+                scoef = torch.empty((mk, sd), dtype=torch.float64, device=dev)
+                sssq = torch.empty(mk, dtype=torch.float64, device=dev)
+                co_t = torch.from_numpy(co.astype(np.int32)).to(dev)
     elif mode == "splmm":
         # null state on the K + lambda I scale, formed in f64 by the caller without the 1e-6 ridge jxg_fvlmm_prepare puts
         # on X'WX (fvlmm.rs): at the large lambda of a trait without polygenic signal that ridge is a 1e-4 relative error
@@ -566,6 +582,7 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
             nm_ += len(a)
             parts.append(a)
         sel_miss_t = torch.from_numpy(np.concatenate(parts) if nm_ else np.zeros(1, np.int32)).to(dev)
+    chain_series = mode == "lmm" and chain_off is not None and sd > 0
     nbuf = 2 if mk > br else 1
     fused = mode in ("fvlmm", "splmm") and _fused_fixed_lambda(model.p) and qpl is None
     if qpl is not None:
@@ -655,6 +672,26 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
         elif mode == "lmm2":
             check(lib().jxg_lmm2_scan(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p, lo_b,
                                       hi_b, float(tol), int(max_iter), warm, init, nullml_v, o.data_ptr(), _stream()))
+        elif mode == "lmm" and chain_off is not None:
+            ev_p = evals[r0:].data_ptr() if evals is not None else None
+            if sd > 0:
+                # the series of this block; the Brent searches follow behind the last block, all chains in one launch
+                check(lib().jxg_lmm_series_coef_tab(_ptr(grot), nr, n, _ptr(model.xcov), model.p, lo_b, hi_b, _ptr(tables),
+                                                    scoef[r0:].data_ptr(), sssq[r0:].data_ptr(), _stream()))
+            else:
+                # no series form (wide bounds, many covariates): the chains that touch this block, states carried across blocks
+                c0 = int(np.searchsorted(co, r0, side="right")) - 1
+                c0 = min(c0, nch - 1)
+                c1 = c0
+                loc = []
+                while c1 < nch and co[c1] < r0 + nr:
+                    loc.append(max(int(co[c1]), r0) - r0)
+                    c1 += 1
+                loc.append(min(int(co[c1]), r0 + nr) - r0)
+                loc_t = torch.from_numpy(np.asarray(loc, dtype=np.int32)).to(dev)
+                check(lib().jxg_lmm_scan_chain(_ptr(grot), nr, n, _ptr(model.S), _ptr(model.xcov), _ptr(model.y), model.p, lo_b,
+                                               hi_b, float(tol), int(max_iter), _ptr(loc_t), c1 - c0, carry[c0:].data_ptr(),
+                                               with_plrt, nullml_v, o.data_ptr(), ev_p, _stream()))
         elif mode == "lmm":
             ev_p = evals[r0:].data_ptr() if evals is not None else None
             if tables is not None:
@@ -673,12 +710,25 @@ def scan_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndar
                                            ypy, df, with_plrt, nullml_v, log_det_v, o.data_ptr(), _stream()))
         if times is not None:
             ev_scan[bi][1].record()
-        if on_block is not None:
+        if on_block is not None and not chain_series:
             done = torch.cuda.Event()
             done.record()
             if pending is not None:
                 hand_over(pending)       # the previous block, while this one runs
             pending = (r0, r0 + nr, done)
+    if chain_series:
+        ev_c = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev_c[0].record()
+        check(lib().jxg_lmm_series_brent_tab(mk, n, _ptr(model.S), _ptr(model.xcov), model.p, lo_b, hi_b, _ptr(tables), float(tol),
+                                             int(max_iter), 0, 0.0, _ptr(scoef), _ptr(sssq), _ptr(co_t), nch, _ptr(carry),
+                                             with_plrt, nullml_v, _ptr(out), _ptr(evals) if evals is not None else None,
+                                             _stream()))
+        ev_c[1].record()
+        ev_scan.append(ev_c)
+        if on_block is not None:
+            done = torch.cuda.Event()
+            done.record()
+            pending = (0, mk, done)
     if pending is not None:
         hand_over(pending)
     if times is not None:
@@ -938,7 +988,7 @@ def build_grm(packed: torch.Tensor, n_samples: int, method=1, maf=0.02, geno=0.0
 
 def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y: np.ndarray, x: np.ndarray,
               mode="lmm", maf=0.02, geno=0.05, het=1.0, max_iter=30, tol=1e-2, warm_start=False, on_rows=None,
-              force_model=True, payload_sharded: bool = False):
+              force_model=True, payload_sharded: bool = False, warm_chain=None):
     """One trait of `run_chunked_gwas_lmm_lm` (python/janusx/assoc/workflow_model_stream.py:464-1480):
     eigh of K[keep, keep] + 1e-6 I, spectral null model, QC on the trait's samples, rotate + scan.
     `x` includes the intercept column; `y`, `x` are already restricted to keep_idx (in that order).
@@ -950,7 +1000,12 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     Several ranks (torch.distributed initialised; `init_distributed`): the eigendecomposition is shared out over the ranks, the
     null model is fitted on every rank (deterministic), every rank scans ITS kept SNPs -- a contiguous share of the kept rows of
     a replicated payload, or the kept rows of its own payload shard (`payload_sharded`) -- and the result rows are gathered in
-    BED order on every rank; `on_rows` is called on rank 0 only, with the whole table as one block."""
+    BED order on every rank; `on_rows` is called on rank 0 only, with the whole table as one block.
+    warm_chain = (chunk_rows, pieces) ('lmm' only): the reference's default scan of this route (`lmm_reml_assoc_bed_to_tsv_f32`
+    as workflow_model_stream.py:1449-1480 calls it: init_log10_lbd = log10 lambda0, rotate_block_rows = the CLI chunk size,
+    warm-start chain on, src/stats/lmm.rs:2627): a chain is the kept rows of one chunk of `chunk_rows` SNP rows of the file
+    (`stats.warm_chain_blocks_bed`), cut into `pieces` by halving.  On several ranks over a replicated payload the rows are dealt
+    at chain boundaries (same table as one rank); with a payload shard per rank the chunks count from the shard's first row."""
     rank, world = dist_info()
     keep_idx = None if keep_idx is None else np.asarray(keep_idx, dtype=np.int64)
     s, ut64 = eigh_from_grm(k, 1e-6, keep_idx, f32_consumer=True)     # only the f32 U^T of SpectralModel is kept
@@ -962,9 +1017,13 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
     n = panel.n
     keep, af, miss = st.gwas_scan_row_stats(counts, n, maf, geno, het)
     rows = np.nonzero(keep)[0]
+    chain_off = None
+    if warm_chain is not None and mode == "lmm":
+        chain_off = st.warm_chain_offsets(st.warm_chain_blocks_bed(rows, panel.m, int(warm_chain[0])), len(rows), int(warm_chain[1]))
+        warm_start = True            # the route passes init_log10_lbd = log10 lambda0 (workflow_model_stream.py:1436-1440)
     if world > 1:
         return _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max_iter, tol, warm_start, on_rows,
-                                force_model, payload_sharded)
+                                force_model, payload_sharded, chain_off)
     lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
     lrt = None
     if not force_model:
@@ -985,7 +1044,8 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
         init = math.log10(model.null.lbd) if (warm_start and model.null.lbd > 0) else None
         if init is not None:
             init = min(max(init, model.null.bounds[0]), model.null.bounds[1])
-        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init, on_block=on_block)
+        out = scan_rows(panel, model, rows, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init, on_block=on_block,
+                        chain_off=chain_off)
     elif mode == "lmm2":
         # null ML by Brent on -ml_loglike, seeded with the REML optimum (src/stats/lmm.rs:2902-2921; the workflow passes
         # bounds, max_iter = 30, tol = 1e-2 and init_log10_lbd_reml = log10 lambda0: workflow_model_stream.py:1499-1590)
@@ -1008,11 +1068,20 @@ def run_trait(packed: torch.Tensor, n_samples: int, k: torch.Tensor, keep_idx, y
 
 
 def _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max_iter, tol, warm_start, on_rows, force_model,
-                     payload_sharded):
+                     payload_sharded, chain_off=None):
     """Scan stage of `run_trait` on several ranks: this rank's rows -> gather in BED order -> rank 0 hands the table on."""
     rank, world = dist_info()
     n = panel.n
     lo, hi = _my_slice(len(rows), payload_sharded)
+    my_chain = None
+    if chain_off is not None and mode == "lmm":
+        if not payload_sharded:
+            # deal whole chains: the cut nearest to the even share, so that no chain starts without its predecessor's state
+            cuts = [int(chain_off[np.argmin(np.abs(chain_off - (len(rows) * r) // world))]) for r in range(world + 1)]
+            cuts[0], cuts[-1] = 0, len(rows)
+            lo, hi = cuts[rank], cuts[rank + 1]
+        inside = chain_off[(chain_off >= lo) & (chain_off <= hi)] - lo
+        my_chain = np.unique(np.concatenate([[0], inside, [hi - lo]])).astype(np.int64)
     mine = rows[lo:hi]
     lrt, tag, ncol = None, mode, (6 if mode == "lmm2" else 3)
     miss_col = miss[rows]
@@ -1041,7 +1110,8 @@ def _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max
             if not math.isfinite(nullml):
                 raise RuntimeError("failed to optimize null ML for LMM2 unified scan")
         if mode in ("lmm", "lmm2"):
-            out = scan_rows(panel, model, mine, lut, mode, max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=nullml)
+            out = scan_rows(panel, model, mine, lut, mode, max_iter=max_iter, tol=tol, init_log10_lbd=init, nullml=nullml,
+                            chain_off=my_chain if (mode == "lmm" and len(mine)) else None)
         else:
             out = scan_rows(panel, model, mine, lut, "fvlmm")
     out = _allgather_rows(out)
@@ -1060,7 +1130,7 @@ def _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max
 
 def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndarray = None, mode="lmm",
              maf=0.02, geno=0.05, het=1.0, grm_method=1, max_iter=30, tol=1e-2, timing=True,
-             payload_sharded: bool = False) -> GwasResult:
+             payload_sharded: bool = False, warm_chain=None) -> GwasResult:
     """`jx gwas -lmm/-fvlmm` on an HBM-resident payload (all samples phenotyped): GRM -> eigh -> null REML -> per-SNP scan.
     Several ranks (torch.distributed initialised; `init_distributed`): the composition of SURVEY.md 8(e) -- SNP-sharded GRM with
     one sum-reduction (`build_grm`), eigenvectors shared out over the ranks (`eigh_from_grm`), SNP-sharded scan, result rows
@@ -1097,8 +1167,14 @@ def run_gwas(packed: torch.Tensor, n_samples: int, y: np.ndarray, covar: np.ndar
     mine = rows[lo:hi]
     lut = st.scan_lut_from_counts(af[mine], np.zeros(len(mine), dtype=bool), counts[mine], n)
     if mode == "lmm":
-        out = scan_rows(panel, model, mine, lut, "lmm", max_iter=max_iter, tol=tol,
-                        times=tm if timing else None)
+        chain_off, init = None, None
+        if warm_chain is not None:       # the reference CLI's scan: chains over chunks of the file's rows, seeded with lambda0
+            chain_off = st.warm_chain_offsets(st.warm_chain_blocks_bed(mine, panel.m, int(warm_chain[0])), len(mine),
+                                              int(warm_chain[1]))
+            if model.null.lbd > 0:
+                init = min(max(math.log10(model.null.lbd), model.null.bounds[0]), model.null.bounds[1])
+        out = scan_rows(panel, model, mine, lut, "lmm", max_iter=max_iter, tol=tol, init_log10_lbd=init,
+                        times=tm if timing else None, chain_off=chain_off)
     else:
         out = scan_rows(panel, model, mine, lut, "fvlmm", times=tm if timing else None)
     res = _allgather_rows(out).cpu().numpy()

@@ -181,3 +181,73 @@ def scan_lut_from_counts(row_maf, row_flip, counts, n: int, model="add"):
     lut[:, 2] = v2 - mean
     lut[:, 3] = v3 - mean
     return lut
+
+
+# ------------------------------------------------------------------------------------------------
+# warm-start chains of the exact scan (src/stats/lmm.rs:134-161)
+# ------------------------------------------------------------------------------------------------
+
+def env_truthy(name: str) -> bool:
+    """`env_truthy` (src/stats/common.rs:88-96): 1 / true / yes / y / on, case-insensitive, trimmed."""
+    import os
+    return os.environ.get(name, "").strip().lower() in ("1", "true", "yes", "y", "on")
+
+
+def _halve(b0: int, b1: int, depth: int, out: list):
+    """rayon's adaptive splitter on an indexed producer: a piece of `len` items is cut at len / 2 (left half first)."""
+    if depth <= 0 or b1 - b0 < 2:
+        out.append(b0)
+        return
+    mid = b0 + (b1 - b0) // 2
+    _halve(b0, mid, depth - 1, out)
+    _halve(mid, b1, depth - 1, out)
+
+
+def warm_chain_offsets(block_starts, m: int, pieces: int = 1):
+    """Chain offsets (int64, ascending, first 0, last m) of the reference's warm-start chains over m scanned rows.
+
+    The reference carries the previous SNP's optimum as the next SNP's Brent start inside the per-worker state of
+    `run_rotated_assoc_block_f32` (src/stats/reml.rs:69-105, `for_each_init`; src/stats/lmm.rs:134-161): the state lives for
+    one BLOCK of rows handed to the association stage (`block_starts`: the first row of every block), and rayon creates one
+    state per piece its splitter cuts the block into -- recursive halving at len / 2, 2 T pieces on T idle threads without
+    work stealing (more with it, which is what makes the reference's own output depend on scheduling).  `pieces` (a power of
+    two, default 1 = one chain per block: the semantics the code states) reproduces that halving deterministically."""
+    pieces = int(pieces)
+    if pieces < 1 or (pieces & (pieces - 1)):
+        raise RuntimeError("warm_chain_pieces must be a power of two >= 1")
+    depth = pieces.bit_length() - 1
+    m = int(m)
+    starts = np.unique(np.clip(np.asarray(block_starts, dtype=np.int64), 0, m))
+    if len(starts) == 0 or starts[0] != 0:
+        starts = np.concatenate([[0], starts])
+    bounds = np.concatenate([starts, [m]]).astype(np.int64)
+    if depth == 0:
+        return np.unique(bounds) if m > 0 else np.array([0, 0], dtype=np.int64)
+    out = []
+    for b0, b1 in zip(bounds[:-1], bounds[1:]):
+        if b1 > b0:
+            _halve(int(b0), int(b1), depth, out)
+    out.append(m)
+    return np.asarray(out, dtype=np.int64)
+
+
+def warm_chain_blocks_packed(m: int, rotate_block_rows: int, progress_every: int = 0):
+    """First rows of the association blocks of `lmm_reml_assoc_packed_f32` (src/stats/lmm.rs:3213-3253): segments of
+    `progress_every` rows (`rotate_block_rows` when 0) cut into blocks of `rotate_block_rows`."""
+    block = max(1, int(rotate_block_rows))
+    seg = block if int(progress_every) == 0 else max(1, int(progress_every))
+    starts = []
+    for s0 in range(0, int(m), seg):
+        starts.extend(range(s0, min(s0 + seg, int(m)), block))
+    return np.asarray(starts, dtype=np.int64)
+
+
+def warm_chain_blocks_bed(kept_source_rows, n_units: int, rotate_block_rows: int):
+    """First kept row of every association block of the BED route (`run_unified_bed_scan_to_tsv_common`,
+    src/stats/lmm.rs:1121-1145): the scan walks the `n_units` scan units (all SNP rows of the file, or the prepared row list) in
+    chunks of `rotate_block_rows`; a block is the rows of one chunk that pass the filters.  `kept_source_rows`: ascending unit
+    index of every kept row."""
+    chunk = max(1, min(int(rotate_block_rows), max(1, int(n_units))))
+    kept = np.asarray(kept_source_rows, dtype=np.int64)
+    edges = np.arange(0, max(int(n_units), 1), chunk, dtype=np.int64)
+    return np.searchsorted(kept, edges, side="left").astype(np.int64)

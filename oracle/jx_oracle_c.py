@@ -99,6 +99,26 @@ def lmm_scan_rotated_block(g_rot, s, xcov, y, low, high, max_iter, tol, warm=0, 
     return (out, ev) if return_evals else out
 
 
+def lmm_scan_rotated_chains(g_rot, s, xcov, y, low, high, max_iter, tol, chain_off, init=None, nullml=None,
+                            return_evals=False):
+    """The reference's default exact scan (`carry_warm_start`, src/stats/lmm.rs:134-161): rows [chain_off[c], chain_off[c + 1])
+    of the rotated block are ONE sequential chain -- the per-worker state of `run_rotated_assoc_block_f32`
+    (src/stats/reml.rs:69-105) lives for one block (one rayon piece of it) -- whose first valid SNP starts from `init`
+    (`state.last_log10_lbd.or(init_log10_lbd)`) or, without it, from the interval midpoint."""
+    g = np.ascontiguousarray(g_rot, dtype=np.float32)
+    co = np.asarray(chain_off, dtype=np.int64)
+    assert co[0] == 0 and co[-1] == g.shape[0] and np.all(np.diff(co) >= 0)
+    out = np.zeros((g.shape[0], 4 if nullml is not None else 3))
+    ev = np.zeros(g.shape[0], dtype=np.int32)
+    start = float("nan") if init is None else float(init)
+    for a, b in zip(co[:-1], co[1:]):
+        if b > a:
+            o, e = lmm_scan_rotated_block(g[a:b], s, xcov, y, low, high, max_iter, tol, warm=2, init=start, nullml=nullml,
+                                          return_evals=True)
+            out[a:b], ev[a:b] = o, e
+    return (out, ev) if return_evals else out
+
+
 def lmm2_null_ml(s, xcov, y, low, high, max_iter=30, tol=1e-2, init=None):
     s, xcov, y = _f64(s).ravel(), _f64(xcov), _f64(y).ravel()
     out = np.zeros(2)

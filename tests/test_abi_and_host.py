@@ -437,3 +437,18 @@ def test_bench_headline_line_is_short_strict_json():
     res["stages_ms_per_step"].update({f"stage_{i}": float(i) for i in range(400)})
     _, line2 = bench.headline_record(res)
     assert len(line2.encode()) < 6144 and "value" in json.loads(line2)
+
+
+def test_warm_chain_offsets_host_rules():
+    """Chain boundaries as the reference's loops make them: blocks of `rotate_block_rows` inside segments of `progress_every`
+    rows (src/stats/lmm.rs:3253-3258), kept rows per chunk of scan units on the BED route (:1121-1145), rayon's halving."""
+    from janusx_amd import stats as st
+    assert st.warm_chain_offsets(st.warm_chain_blocks_packed(10, 4), 10).tolist() == [0, 4, 8, 10]
+    assert st.warm_chain_offsets(st.warm_chain_blocks_packed(10, 4, 6), 10).tolist() == [0, 4, 6, 10]
+    assert st.warm_chain_offsets(st.warm_chain_blocks_packed(10, 4), 10, 2).tolist() == [0, 2, 4, 6, 8, 9, 10]
+    assert st.warm_chain_offsets(st.warm_chain_blocks_packed(7, 100), 7, 4).tolist() == [0, 1, 3, 5, 7]     # 7 -> 3 | 4 -> 1 2 | 2 2
+    kept = np.array([0, 1, 5, 6, 7, 12, 13, 19])
+    assert st.warm_chain_offsets(st.warm_chain_blocks_bed(kept, 20, 5), len(kept)).tolist() == [0, 2, 5, 7, 8]
+    assert st.warm_chain_offsets(st.warm_chain_blocks_bed(np.array([17, 18]), 20, 5), 2).tolist() == [0, 2]   # empty chunks vanish
+    with pytest.raises(RuntimeError):
+        st.warm_chain_offsets([0], 10, 3)

@@ -18,6 +18,15 @@ from janusx_amd import bed  # noqa: E402
 TOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def _scan_without_warm_start_chain(monkeypatch):
+    """The legs of this file pin decode, rotation, scan arithmetic, entry-point plumbing and TSV text against the oracle's
+    scan WITHOUT warm start (every SNP from the same point: the core-API contract, src/stats/lmm.rs:1577-1579, and what the
+    reference does under JX_LMM_UNIFIED_NO_WARM_START).  The reference's default -- the warm-start chain, src/stats/lmm.rs:134-161
+    -- is a property of its own and is tested against the oracle's chain in tests/test_gpu_round6.py."""
+    monkeypatch.setenv("JX_LMM_UNIFIED_NO_WARM_START", "1")
+
+
 def _grm_err(k, ref):
     ref = np.asarray(ref, dtype=np.float64)
     k = np.asarray(k, dtype=np.float64)
@@ -52,7 +61,7 @@ RAW_P_BOUND = 1.2e-4    # raw relative error of the Wald p, EVERY row of every l
                         # on the exact-rotation legs (`_exact_rotation_leg`), recorded for every leg as maxima[5]
 
 
-def _assoc_err(out, ref, tag=None):
+def _assoc_err(out, ref, tag=None, raw_p_bound=RAW_P_BOUND):
     """(be, se, pe) of a (rows, >= 3) [beta, se, p] table against the oracle's.
 
     be = |d beta| / max(|beta|, SE), se = |d SE| / SE.  pe covers the Wald p both ways 8(d) asks for:
@@ -83,7 +92,8 @@ def _assoc_err(out, ref, tag=None):
     pe = max(pz, lp)
     praw_all = float(np.max(praw))
     praw_z10 = float(np.max(praw[z2 <= 10.0])) if np.any(z2 <= 10.0) else 0.0
-    assert praw_all <= RAW_P_BOUND, ("raw relative error of the Wald p", praw_all)
+    # raw_p_bound=None: the caller bounds the raw error itself (a leg whose strongest SNPs lie beyond z^2 ~ 170)
+    assert raw_p_bound is None or praw_all <= raw_p_bound, ("raw relative error of the Wald p", praw_all)
     key = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + (f":{tag}" if tag else "")
     cur = _MAXIMA.get(key, [0.0] * 6)
     cur = list(cur) + [0.0] * (6 - len(cur))

@@ -1350,8 +1350,7 @@ def _splmm_prepare_inputs(prefix, y, x_cov, sample_indices, operator_sample_indi
     BED prefix with the caller's row metadata, BED prefix alone (row statistics on the scan samples, no filter)."""
     from . import bed as _bed
     from . import stats as st
-    if str(model) != "add":
-        raise RuntimeError(f"unsupported genetic model '{model}' (only 'add' is built)")
+    gm_code = st.genetic_model_code(model)     # add / dom / rec / het, case-insensitive (`PackedGeneticModel::parse`, decode.rs:107-119)
     bed_prefix = _bed_prefix(prefix)
     if not bed_prefix:
         raise RuntimeError("BED-prefix mode requires a non-empty prefix")
@@ -1432,11 +1431,11 @@ def _splmm_prepare_inputs(prefix, y, x_cov, sample_indices, operator_sample_indi
         rows = np.nonzero(keep)[0].astype(np.int64)
         maf32, flip, miss = maf_all[rows].astype(np.float32), flip_all[rows], miss_all[rows].astype(np.float32)
     return dict(pk=pk, n_full=n_full, rows=rows, maf=maf32, flip=flip, miss=miss, y=yv, x_cov=xc, scan_idx=scan_idx,
-                op_idx=op_idx, bed_prefix=None if use_packed else bed_prefix, n=n, p=p)
+                op_idx=op_idx, bed_prefix=None if use_packed else bed_prefix, n=n, p=p, gm_code=gm_code)
 
 
 def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat_markers, rhat_seed, rhat_rows=None,
-                       on_block=None):
+                       on_block=None, gm_code=0):
     """`estimate_residualized_approx_scan_sparse` (src/stats/splmm_approx.rs:701-795) on the spectral form of K + lambda I
     (`_SpectralSparseReml`): residualised response, a = V^-1 y_r / sigma2 through the eigenbasis, gamma from the sampled
     markers (their rotation by the MFMA kernel + `jxg_splmm_gamma_sums`), scan model a_r = M_X a, GRAMMAR scan in sample
@@ -1479,6 +1478,14 @@ def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat
     lut[:, 1] = mean_g
     lut[:, 2] = 1.0
     lut[:, 3] = np.where(flip, 0.0, 2.0)
+    if int(gm_code) != 0:
+        # dom / rec / het (`decode_packed_row_model_into_f64`, src/decode/decode.rs:305-364, as the GRAMMAR scan's non-additive
+        # branch and the sampled-marker decode call it: src/stats/splmm.rs:3211-3262, 1514-1560): the genetic model applied to
+        # the raw values [0 | 2, max(2 maf, 0), 1, 2 | 0] INCLUDING the imputed entry, no centring (the scan residualises on X)
+        from .stats import _apply_genetic_model
+        lut[:, 1] = np.maximum(np.float32(2.0) * maf32, np.float32(0.0))
+        for c in range(4):
+            lut[:, c] = _apply_genetic_model(int(gm_code), lut[:, c])
     if _is_device_tensor(pk):
         packed_t = pk.to(dev)
     else:
@@ -1578,6 +1585,8 @@ def _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices,
     lam = float(lbd)
     with _progress_hook(progress_callback, progress_every):
         if mode == "exact":
+            if inp["gm_code"] != 0:      # `exact_scan_blocks_core`, src/stats/splmm.rs:2662-2664
+                raise RuntimeError("SparseLMM exact denominator mode requires additive model")
             if not lam > 0.0:
                 raise RuntimeError("K + lambda I is not positive definite at lambda=0")
             out, _l10, _null = splmm_exact_scan_from_jxgrm(path, inp["y"], inp["pk"], inp["n_full"],
@@ -1592,7 +1601,7 @@ def _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices,
                 raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
             r_hat, out_t, req, used = _splmm_approx_scan(spm, lam, inp["pk"], inp["n_full"], inp["maf"], inp["flip"],
                                                          inp["rows"], inp["scan_idx"], int(rhat_markers), int(rhat_seed),
-                                                         rhat_rows)
+                                                         rhat_rows, gm_code=inp["gm_code"])
             out = out_t.cpu().numpy()
             req = int(rhat_markers)
     _done(progress_callback, len(inp["rows"]))
@@ -1985,7 +1994,19 @@ def rust_eigh_from_array_f64(a, threads=0, driver=None, jobz="V", require_lapack
     return (evals, evecs, "rocblas", evd, n, 0, 0, 0, True, time.perf_counter() - t0)
 
 
-rust_eigh_from_array_f64_inplace = rust_eigh_from_array_f64
+def rust_eigh_from_array_f64_inplace(a, threads=0, driver=None, jobz="V", require_lapack=False):
+    """src/math/eigh.rs:1883-1962.  Same 10-tuple as `rust_eigh_from_array_f64`.  Despite its name the reference's function
+    does NOT write into its argument: it takes `a.readonly()` (:1914), hands a row-major copy-on-write view to
+    `symmetric_eigh_f64_row_major_with_driver` (:1918, :1925) and returns freshly allocated arrays (:1943-1955) -- "in place"
+    there is about not copying a contiguous input on the way IN.  What it does differently from the plain entry point, and what
+    this mirror reproduces: no `diag_shift` argument, an empty or non-square input is refused with its own message (:1907-1912),
+    and a Fortran-ordered / strided input is accepted (read through `_c`).  The caller's array is left untouched."""
+    arr = np.asarray(a)
+    nrows = int(arr.shape[0]) if arr.ndim >= 1 else 0
+    ncols = int(arr.shape[1]) if arr.ndim >= 2 else 0
+    if arr.ndim != 2 or nrows == 0 or ncols == 0 or nrows != ncols:
+        raise RuntimeError(f"rust_eigh_from_array_f64_inplace expects a non-empty square matrix; got shape=({nrows}, {ncols})")
+    return rust_eigh_from_array_f64(arr, threads, driver, jobz, require_lapack, 0.0)
 
 
 def rust_eigh_from_matrix_file_f64(path, threads=0, driver=None, jobz="V", require_lapack=False, diag_shift=0.0):

@@ -116,6 +116,15 @@ def test_boundary_argument_validation():
         jxrs.lmm_reml_null_f32(np.ones(3), np.ones((4, 1)), np.ones(4), -1.0, 1.0)
     with pytest.raises(RuntimeError, match="u_t must be"):
         jxrs.lmm_rotate_x_y_with_ut_f64(np.ones((3, 3), np.float32), np.ones((4, 1)), np.ones(4))
+    # the reference's `_inplace` eigh: its own message for an empty / non-square input (src/math/eigh.rs:1907-1912), no diag_shift
+    with pytest.raises(RuntimeError, match=r"rust_eigh_from_array_f64_inplace expects a non-empty square matrix; got shape=\(2, 3\)"):
+        jxrs.rust_eigh_from_array_f64_inplace(np.zeros((2, 3)))
+    with pytest.raises(RuntimeError, match=r"got shape=\(0, 0\)"):
+        jxrs.rust_eigh_from_array_f64_inplace(np.zeros((0, 0)))
+    with pytest.raises(TypeError):
+        jxrs.rust_eigh_from_array_f64_inplace(np.eye(3), diag_shift=1e-6)
+    with pytest.raises(RuntimeError, match="warm_start must be"):
+        jxrs._resolve_warm_start("sometimes")
 
 
 def test_tsv_text_matches_oracle_format(oracle):

@@ -298,3 +298,20 @@ def test_warm_start_chain_at_c3_sample_size(oracle, oracle_c):
     assert np.array_equal(res.keep, keep)
     be, se, pe = P._assoc_err(res.stats, ref, tag="run_gwas")
     assert max(be, se, pe) < P.TOL, (be, se, pe)
+
+
+def test_eigh_inplace_mirror_reads_its_argument_only():
+    """`rust_eigh_from_array_f64_inplace` (src/math/eigh.rs:1883-1962): the reference reads its argument read-only (:1914) and
+    returns new arrays -- the caller's matrix is untouched, a Fortran-ordered input is accepted, the result is the plain entry
+    point's."""
+    from janusx_amd import janusx as jxrs
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal((300, 300))
+    a = np.asfortranarray(b @ b.T / 300.0)
+    keep = a.copy()
+    w, v, *_rest = jxrs.rust_eigh_from_array_f64_inplace(a)
+    assert np.array_equal(a, keep) and a.flags["F_CONTIGUOUS"]
+    w0, v0, *_ = jxrs.rust_eigh_from_array_f64(np.ascontiguousarray(keep))
+    assert np.array_equal(w, w0) and np.array_equal(v, v0)
+    assert np.abs(w - np.linalg.eigvalsh(keep)).max() < 1e-12 * max(1.0, float(np.abs(w).max()))
+    assert jxrs.rust_eigh_from_array_f64_inplace(keep, jobz="N")[1] is None

@@ -853,10 +853,12 @@ def splmm_residualize(x_design, cx, v):
     return v - x_design @ cholesky_solve(cx, x_design.T @ v)
 
 
-def splmm_additive_row_f64(codes_row, maf32, flip):
-    """`decode_packed_row_model_into_f64` (src/decode/decode.rs:307-364), additive model: missing -> max(2 maf, 0) in f64."""
+def splmm_additive_row_f64(codes_row, maf32, flip, model="add"):
+    """`decode_packed_row_model_into_f64` (src/decode/decode.rs:307-364): missing -> max(2 maf, 0) in f64, flipped calls
+    2 - g, then the genetic model applied to EVERY entry, the imputed one included (`gm.apply`, :383); not centred."""
     mean_g = max(2.0 * float(F32(maf32)), 0.0)
-    lut = np.array([2.0, mean_g, 1.0, 0.0] if flip else [0.0, mean_g, 1.0, 2.0], dtype=np.float64)
+    vals = [2.0, mean_g, 1.0, 0.0] if flip else [0.0, mean_g, 1.0, 2.0]
+    lut = np.array([genetic_model_apply(model, v) for v in vals], dtype=np.float64)
     return lut[codes_row]
 
 
@@ -922,7 +924,7 @@ def splmm_residual_sumsq_is_effectively_zero(resid, raw):
 
 
 def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_hat, sample_idx=None, rows=None,
-                       score_scale=1.0, wald_sigma2=1.0, exact_dots=False):
+                       score_scale=1.0, wald_sigma2=1.0, exact_dots=False, model="add"):
     """`grammar_scan_blocks_core`, additive model (src/stats/splmm.rs:2935-3316) as `scan_with_py_and_rhat` calls it (:3318):
     mean-imputed additive f32 decode (not centred), [score | X'g] = f32 GEMM of the block with f32([score_vec | X]), row sum
     of squares from the counts (`additive_row_sumsq_from_counts`, :1801-1820), g'M g = max(g'g - (X'g)'(X'X)^-1 (X'g), 0),
@@ -939,6 +941,18 @@ def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_
         codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
     rows = np.arange(codes.shape[0]) if rows is None else np.asarray(rows, dtype=np.int64)
     out = np.empty((len(rows), 3), dtype=np.float64)
+    if str(model).lower() != "add":
+        # the non-additive branch (src/stats/splmm.rs:3211-3262): the row decoded in f64 with the model applied, score, X'g and
+        # g'g as f64 sums over the samples, g'M g = max(g'g - (X'g)'(X'X)^-1 (X'g), 0), NO effectively-zero test -- a row the
+        # model makes constant fails inside `splmm_wald_from_score_denom` (denominator 0) -> (NaN, NaN, 1)
+        sv = np.asarray(score_vec, dtype=np.float64)
+        for k, r in enumerate(rows):
+            g = splmm_additive_row_f64(codes[r], maf[r], bool(row_flip[r]), model)
+            xts = x_design.T @ g
+            s_m_s = max(float(g @ g) - float(xts @ cholesky_solve(cx, xts)), 0.0)
+            res = splmm_wald_from_score_denom(score_scale * float(g @ sv), r_hat * s_m_s, wald_sigma2)
+            out[k] = res if res is not None else (float("nan"), float("nan"), 1.0)
+        return out
     for k, r in enumerate(rows):
         mean32 = F32(min(max(F32(2.0) * F32(maf[r]), F32(0.0)), F32(2.0)))
         lut = np.array([2.0, mean32, 1.0, 0.0] if row_flip[r] else [0.0, mean32, 1.0, 2.0], dtype=np.float32)
@@ -962,7 +976,7 @@ def splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, score_vec, r_
 
 
 def splmm_approx_assoc(k, lam, x_design, y, packed, n_samples, maf, row_flip, rhat_markers=30, rhat_seed=20260527,
-                       sample_idx=None, rhat_rows=None):
+                       sample_idx=None, rhat_rows=None, model="add"):
     """`estimate_residualized_approx_scan_sparse` (src/stats/splmm_approx.rs:701-795) = the `-splmm` default of the
     reference's workflow (scan_mode "approx"): null from lambda, gamma from sampled markers, scan model a_r = M_X a,
     GRAMMAR scan.  `rhat_rows` overrides the seeded choice (see StdRngU32).  -> (gamma, (m, 3) f64, markers used, rows)."""
@@ -972,12 +986,12 @@ def splmm_approx_assoc(k, lam, x_design, y, packed, n_samples, maf, row_flip, rh
     codes = unpack_codes(np.ascontiguousarray(np.asarray(packed)[rr], dtype=np.uint8), n_samples)
     if sample_idx is not None:
         codes = codes[:, np.asarray(sample_idx, dtype=np.int64)]
-    markers = np.stack([splmm_additive_row_f64(codes[i], maf[r], bool(row_flip[r])) for i, r in enumerate(rr)])
+    markers = np.stack([splmm_additive_row_f64(codes[i], maf[r], bool(row_flip[r]), model) for i, r in enumerate(rr)])
     gamma, n_used = splmm_estimate_gamma(fac, x_design, markers, a_vec, rhat_markers, 1.0 / sigma2)
     if not (math.isfinite(gamma) and gamma > 0.0):
         raise RuntimeError(f"SparseLMM residualized approx gamma must be finite and > 0, got {gamma}")
     a_resid = splmm_residualize(x_design, splmm_xtx_chol(x_design), a_vec)
-    out = splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, a_resid, gamma, sample_idx)
+    out = splmm_grammar_scan(packed, n_samples, maf, row_flip, x_design, a_resid, gamma, sample_idx, model=model)
     return gamma, out, n_used, rr
 
 

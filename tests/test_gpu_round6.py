@@ -315,3 +315,61 @@ def test_eigh_inplace_mirror_reads_its_argument_only():
     assert np.array_equal(w, w0) and np.array_equal(v, v0)
     assert np.abs(w - np.linalg.eigvalsh(keep)).max() < 1e-12 * max(1.0, float(np.abs(w).max()))
     assert jxrs.rust_eigh_from_array_f64_inplace(keep, jobz="N")[1] is None
+
+
+@pytest.mark.parametrize("gm", ["dom", "rec", "HET"])
+def test_splmm_approx_route_genetic_models(oracle, tmp_path, gm):
+    """`model=` of the SparseLMM entry points (`PackedGeneticModel`, parsed case-insensitively): the approx (GRAMMAR-gamma) route
+    decodes the sampled markers and the scanned rows with the model applied to [0 | 2, max(2 maf, 0), 1, 2 | 0] including the
+    imputed entry, not centred (`decode_packed_row_model_into_f64`, src/decode/decode.rs:305-364; src/stats/splmm.rs:3211-3262,
+    1514-1560) -- against the oracle's restatement of that branch: gamma 1e-6, beta / SE / p 1e-5 on every row whose residual sum
+    of squares is not rounding noise.  The exact route refuses a non-additive model with the reference's message (:2662-2664)."""
+    from janusx_amd import janusx as jxrs
+    P = _parity()
+    n, m = 320, 700
+    packed, g = P._related_panel(n, m, 37, 0.02)
+    prefix = str(tmp_path / "p")
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, [f"s{i}" for i in range(n)], bim)
+    rng = np.random.default_rng(12)
+    mi, he, ho = oracle.row_counts(packed, n, None)
+    keep, miss, af, _, _ = oracle.packed_prep_row_stats(mi, he, ho, n, 0.05, 0.05, 0.0)
+    path, _, _ = jxrs.spgrm_packed_to_jxgrm(np.ascontiguousarray(packed[keep]), n, np.zeros(int(keep.sum()), bool), af[keep],
+                                            str(tmp_path / "k"), None, 1, 0.05)
+    nn, cp, ri, va = oracle.read_sparse_grm_csc(path)
+    kd = oracle.sparse_grm_dense_subset(nn, cp, ri, va, None)
+    gv = np.where(g < 0, 0, g).astype(np.float64)
+    y = gv[40] * 0.5 + gv[300:330].T @ rng.normal(0, 0.2, 30) + rng.normal(0, 1.0, n)
+    xc = rng.normal(size=(n, 1))
+    xd = oracle.spreml_design_matrix(xc, n)
+    rows = np.nonzero(keep)[0][::2].astype(np.int64)
+    maf_r, miss_r = af[rows].astype(np.float32), miss[rows].astype(np.float32)
+    flip_r = np.zeros(len(rows), dtype=bool)
+    flip_r[::5] = True
+    lam = 1.3
+    got = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, maf=maf_r, row_flip=flip_r, row_missing=miss_r, row_indices=rows,
+                                   sparse_jxgrm_path=path, rhat_markers=40, scan_mode="approx", model=gm)
+    gamma, ref, used, _rr = oracle.splmm_approx_assoc(kd, lam, xd, y, packed[rows], n, maf_r, flip_r, rhat_markers=40, model=gm)
+    add = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, maf=maf_r, row_flip=flip_r, row_missing=miss_r, row_indices=rows,
+                                   sparse_jxgrm_path=path, rhat_markers=40, scan_mode="approx")
+    assert abs(got[0] - gamma) < 1e-6 * gamma and got[8] == used, (got[0], gamma)
+    out = got[9]
+    # rows the model leaves (numerically) constant given X: the reference divides rounding noise there, the kernel reports an invalid row
+    codes = oracle.unpack_codes(np.ascontiguousarray(packed[rows]), n)
+    solid = np.zeros(len(rows), bool)
+    for k in range(len(rows)):
+        gk = oracle.splmm_additive_row_f64(codes[k], maf_r[k], bool(flip_r[k]), gm)
+        r = gk - xd @ np.linalg.lstsq(xd, gk, rcond=None)[0]
+        solid[k] = float(r @ r) > 1e-6 * max(float(gk @ gk), 1.0)
+    assert solid.sum() > 0.8 * len(rows)
+    ok = solid & ~np.isnan(ref[:, 0])
+    assert not np.isnan(out[ok, 0]).any()
+    be, se, pe = P._assoc_err(out[ok], ref[ok], tag=gm)
+    assert max(be, se, pe) < P.TOL, (gm, be, se, pe)
+    assert np.nanmax(np.abs(out[ok, 0] - add[9][ok, 0])) > 1e-3          # the model is really applied
+    with pytest.raises(RuntimeError, match="SparseLMM exact denominator mode requires additive model"):
+        jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, maf=maf_r, row_flip=flip_r, row_missing=miss_r, row_indices=rows,
+                                 sparse_jxgrm_path=path, scan_mode="exact", model=gm)
+    with pytest.raises(RuntimeError, match="model must be one of: add, dom, rec, het"):
+        jxrs.splmm_assoc_pcg_bed(prefix, y, lam, maf=maf_r, row_flip=flip_r, row_indices=rows, sparse_jxgrm_path=path,
+                                 scan_mode="approx", model="overdominant")

@@ -334,6 +334,8 @@ def headline_record(res):
             out["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb["sample"])[:400]
         if "value" in cb and cb["value"]:
             out["gpu_over_cpu_baseline"] = _num(res["value"] / cb["value"])
+    if isinstance(res.get("null"), dict):
+        out["null"] = _pick(res["null"], ("lbd", "pve"))
     out["stages_ms_per_step"] = {k: _num(v, 5) for k, v in (res.get("stages_ms_per_step") or {}).items()}
     if "stages_ms_per_step_max_over_ranks" in res:
         out["stages_ms_per_step_max_over_ranks"] = {k: _num(v, 5) for k, v in res["stages_ms_per_step_max_over_ranks"].items()}

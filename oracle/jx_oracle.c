@@ -3,8 +3,11 @@
  * Oracle + timed CPU baseline ("port"): sequential f64 loops in the same order as the reference
  * Rust code (cited per function).  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product path (janusx_amd / libjxgpu.so) never does.
- * Parity status: see the header of oracle/jx_oracle.py ("parity unpinned" for GRM/REML/scan numerics,
- * the reference ships no numeric tests for them and cannot be built here).
+ * Parity status: the table in the header of oracle/jx_oracle.py says which function is pinned by which fixture.  For this
+ * file: reml / ml log-likelihoods and the null fit are pinned by values the reference's own Python produced
+ * (tests/golden/panel_small.npz, reference_model.npz: LMM._NULLREML, blup.REML, mlm.BLUP._REML, the replayed model layer);
+ * the Brent trajectory, final_beta_se and the fixed-lambda block formulas are pinned by reading only (the reference ships no
+ * numeric test for them and its crate cannot be built here) and are held equal to the numpy twin (test_python_vs_c_oracle).
  *
  * Build: gcc -O2 -fopenmp -shared -fPIC -o liboracle.so jx_oracle.c -lm   (oracle/Makefile)
  */

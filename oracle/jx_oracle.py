@@ -6,18 +6,34 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 The product path (``janusx_amd``) never does: it calls the HIP library through the C ABI and
 fails loudly when that library is missing.
 
-Parity pinning status (see DESIGN.md "Oracle"):
-  * decode / LUT semantics   : pinned by the reference's own unit tests
-                               (src/math/bedmath.rs:1537-1660) -> tests/test_oracle_golden.py
-  * chi2 / normal sf         : pinned by src/math/linalg.rs:369-398 closed forms
-  * eigh                     : pinned by src/math/eigh.rs:1982-1998 (2x2, eigenvalues {1,3})
-  * null-model helpers       : cross-checked against the reference's pure-numpy
-                               ``_lmm_profile_exact_vc`` imported in the build container
-                               (tests/golden/gen_fixtures.py)
-  * GRM / REML / Brent / scan: the reference ships no numeric tests and its Rust extension cannot
-                               be built here (no cargo/rustc) -> **parity unpinned** beyond the
-                               structural checks above; the restatement follows the cited code
-                               line by line (same dtypes, same constants, same loop order).
+Parity pinning status -- which function is pinned by what (tests/test_oracle_golden.py runs every line of this table on CPU;
+DESIGN.md section 4 "Oracle and parity" has the long form).  "Reference-produced" = computed HERE by the reference's own
+importable Python (pyBLUP/assoc.py, blup.py, mlm.py with a stub in place of its native module; tests/golden/gen_fixtures.py,
+gen_reference_model_fixtures.py, gen_cli_fixtures.py) and stored as data in tests/golden/:
+
+  function(s) of this file                       pinned by
+  ---------------------------------------------  ---------------------------------------------------------------------------
+  pack_codes / unpack_codes / decode LUTs        the reference's own unit vectors, src/math/bedmath.rs:1537-1660
+  genetic_model_apply, decode tables             src/decode/decode.rs:107-178 tables (test_genetic_model_tables)
+  chi2_sf_df1, normal_sf                         src/math/linalg.rs:369-398 closed forms
+  eigh_sym                                       src/math/eigh.rs:1982-1998 (2 x 2, eigenvalues {1, 3})
+  reml_loglike / ml_loglike, lmm_reml_null       reference-produced: LMM._NULLREML values (panel_small.npz: nullreml_*),
+                                                 blup.REML at 5 lambda, mlm.BLUP._REML incl. its v_floor branch
+  spectral_null_model (sigma_g2, sigma_e2, PVE,  reference-produced: _lmm_profile_exact_vc; the whole model layer
+    bounds), fvlmm cache, LM helpers             (LMM.from_spectral, FvLMM, LM) replayed over a recording stub
+                                                 (reference_model.npz)
+  CLI helpers (chunk sizes, names, k-fold)       reference-produced: cli_helpers.json
+  StdRng / splitmix64 probes                     published ChaCha12 / splitmix64 vectors (test_stdrng_published_vectors)
+  sparse REML (spreml_*)                         the reference's vectors in src/stats/spreml.rs tests
+  brent_minimize                                 closed-form minima (test_brent_known_function); restated line by line
+  ---------------------------------------------  ---------------------------------------------------------------------------
+  PINNED BY READING ONLY (the reference ships no numeric test for them and its Rust crate cannot be built here -- no cargo /
+  rustc): the per-SNP Brent trajectory inside `lmm_scan_rotated_block` (brent.rs is restated statement for statement),
+  `final_beta_se`, the fixed-lambda formulas of fvlmm.rs, the QC threshold arithmetic of the row statistics, the GRM's f32 SYRK /
+  f64 merge order, the TSV float formatting (`{:.4}` / `{:.4e}`: Python's formatter is IEEE-correct like Rust's), and the
+  PCG32 seed expansion behind `splmm_choose_rhat_rows`.  For these the restatement follows the cited code with the same
+  dtypes, constants and loop order, and the C twin (jx_oracle.c) is held equal to this file on the same inputs
+  (test_python_vs_c_oracle).
 
 All functions take/return numpy arrays; dtypes follow the reference (f32 where it uses f32).
 """

@@ -707,6 +707,26 @@ int64_t jx_assoc_tsv_write(const char *path, const char *prefix_blob, const int6
 int64_t jx_assoc_tsv_append(const char *path, const char *prefix_blob, const int64_t *prefix_off, int64_t rows,
                            const float *af, const float *miss, const double *stats, int ncol, int append);
 
+/* ---- sparse symmetric solves on the device (csrc/k_spsolve.hip): SparseLMM on a relatedness graph with a connected component
+ * beyond one dense eigenproblem.  The reference factorises K + lambda I sparsely on the host (src/math/cholesky.rs:733,
+ * 1018-1183) and solves one system per SNP (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880); here a block of decoded
+ * SNP rows is the right-hand side of ONE Jacobi-preconditioned multi-vector CG over the CSR image (full symmetric pattern) of K.
+ * Vectors are (n, ldr) row-major f64, ldr = jxg_sps_ldr(nrhs) (a multiple of 64): row i = entry i of every right-hand side.
+ *   jxg_sps_rows_to_cols_f64: decoded rows (nrhs, ld) f32 -> that layout;
+ *   jxg_sps_solve_multi:      X = (K + lambda I)^-1 B; d_dinv[i] = 1 / (K_ii + lambda); stops at |r| <= tol |b| for every
+ *                             right-hand side; h_info (host) = [iterations, max |r| / |b|]; fails when max_iter is reached;
+ *   jxg_sps_scan_sums:        per right-hand side [g'V^-1 g, g.Py, g.(V^-1 X)[:, k]] -> d_sums (nrhs, p + 2): what
+ *                             jxg_fvlmm_finish_dev takes with ntiles = 1, score_mode = 1;
+ *   d_work: jxg_sps_work_doubles(n, ldr) doubles, shared by the two calls. */
+int jxg_sps_ldr(int nrhs);
+int64_t jxg_sps_work_doubles(int n, int ldr);
+int jxg_sps_rows_to_cols_f64(const float *d_rows, int nrhs, int n, int64_t ld, double *d_out, int ldr, void *stream);
+int jxg_sps_solve_multi(int n, const int64_t *d_rowptr, const int32_t *d_col, const double *d_val, double lambda,
+                        const double *d_dinv, const double *d_b, int nrhs, int ldr, double tol, int max_iter, double *d_x,
+                        double *d_work, double *h_info, void *stream);
+int jxg_sps_scan_sums(int n, const double *d_g, const double *d_z, int nrhs, int ldr, const double *d_py, const double *d_vinvx,
+                      int p, double *d_sums, double *d_work, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

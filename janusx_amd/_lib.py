@@ -127,6 +127,11 @@ SIGNATURES = {
                                    c_p, c_p],
     "jx_assoc_packed": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_d, c_d, c_i, c_d, c_i,
                         c_d, c_i, c_d, c_p],
+    "jxg_sps_ldr": [c_i],
+    "jxg_sps_work_doubles": [c_i, c_i],
+    "jxg_sps_rows_to_cols_f64": [c_p, c_i, c_i, c_l, c_p, c_i, c_p],
+    "jxg_sps_solve_multi": [c_i, c_p, c_p, c_p, c_d, c_p, c_p, c_i, c_i, c_d, c_i, c_p, c_p, c_p, c_p],
+    "jxg_sps_scan_sums": [c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     "jx_assoc_packed_chain": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_d, c_d, c_i, c_d, c_i,
                               c_d, c_i, c_d, c_p, c_i, c_p, c_l],
     "jxg_lmm_scan_chain_tab": [c_p, c_i, c_i, c_p, c_p, c_i, c_d, c_d, c_p, c_d, c_i, c_p, c_i, c_p, c_i, c_d, c_p, c_p, c_p],
@@ -159,7 +164,7 @@ _RESTYPES = {"jx_last_error": C.c_char_p, "jxg_last_kernel_ms": C.c_float, "jxg_
              "jxg_t32_bytes": C.c_int64, "jxg_eigh_dist_staging_doubles": C.c_int64, "jxg_eigh_band_staging_doubles": C.c_int64,
              "jxg_spgrm_work_bytes": C.c_int64, "jxg_tri_tiles_doubles": C.c_int64, "jx_assoc_tsv_write": C.c_int64,
              "jx_assoc_tsv_append": C.c_int64, "jx_pcg_dist_count": C.c_int64, "jxg_scratch_trim": C.c_int64,
-             "jxg_lmm_series_doubles": C.c_int64}
+             "jxg_lmm_series_doubles": C.c_int64, "jxg_sps_work_doubles": C.c_int64}
 
 
 def lib():

@@ -13,6 +13,10 @@
 // right-hand sides rounded up to 64 -- so that the gather  y[i, :] = sum_k val[k] x[col[k], :]  reads whole contiguous rows:
 // HBM-bound, 8 ldr bytes per non-zero.  Sums over i (p'Ap, r'z, r'r per right-hand side) are two-stage and in a fixed order:
 // per chunk of SPS_ROWS rows, then over the chunks -- bit-reproducible.
+#include <cmath>
+#include <string>
+#include <vector>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -208,8 +212,8 @@ extern "C" int jxg_sps_solve_multi(int n, const int64_t *d_rowptr, const int32_t
                                    double *d_x, double *d_work, double *h_info, void *stream) {
     if (n <= 0 || nrhs <= 0) return 0;
     if (ldr < nrhs || (ldr & 63)) return fail("jxg_sps_solve_multi: ldr must be a multiple of 64 and >= nrhs");
-    if (!(isfinite(lambda) && lambda >= 0.0)) return fail("jxg_sps_solve_multi: lambda must be finite and >= 0");
-    if (!(isfinite(tol) && tol > 0.0) || max_iter <= 0) return fail("jxg_sps_solve_multi: tol / max_iter out of range");
+    if (!(std::isfinite(lambda) && lambda >= 0.0)) return fail("jxg_sps_solve_multi: lambda must be finite and >= 0");
+    if (!(std::isfinite(tol) && tol > 0.0) || max_iter <= 0) return fail("jxg_sps_solve_multi: tol / max_iter out of range");
     hipStream_t st = (hipStream_t)stream;
     const int nch = sps_chunks(n);
     double *res = d_work, *z = res + (int64_t)n * ldr, *p = z + (int64_t)n * ldr, *ap = p + (int64_t)n * ldr;
@@ -249,7 +253,7 @@ extern "C" int jxg_sps_solve_multi(int n, const int64_t *d_rowptr, const int32_t
             worst = 0.0;
             for (int r = 0; r < nrhs; ++r) {
                 const double bb = h[(size_t)ldr + r], rr = h[r];
-                if (!isfinite(rr)) return fail("jxg_sps_solve_multi: the iteration broke down (non-finite residual)");
+                if (!std::isfinite(rr)) return fail("jxg_sps_solve_multi: the iteration broke down (non-finite residual)");
                 if (bb > 0.0) worst = fmax(worst, sqrt(rr / bb));
             }
             if (worst <= tol) break;

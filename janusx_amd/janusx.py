@@ -733,13 +733,18 @@ def sparse_component_limit(free_bytes=None):
     return int(math.isqrt(max(free, 0) // 40))
 
 
+class _ComponentTooLarge(RuntimeError):
+    """A dense eigenproblem the spectral routes would need does not fit this GPU: the caller switches to the sparse-factor
+    route (`_SparseFactorReml`) or, where none exists, lets the message through."""
+
+
 def _check_spectral_sparse_size(n, what="the selected samples"):
     """The single-eigenproblem form of the sparse REML / SparseLMM routes holds a dense f64 image of K, its eigenvectors
     and the eigensolver's workspace (~5 n^2 doubles) in HBM.  Refuse clearly -- on every rank alike -- instead of failing
     inside hipMalloc."""
     limit = sparse_component_limit()
     if int(n) > limit:
-        raise RuntimeError(
+        raise _ComponentTooLarge(
             f"sparse-GRM spectral route: {what} form one dense eigenproblem of {int(n)} samples; the limit on this GPU is "
             f"{limit} samples (about 5 n^2 doubles of HBM: the f64 image of K, its eigenvectors and the eigensolver's workspace). "
             "Raise the GRM cut-off so that the relatedness graph falls apart into smaller components, or restrict the samples; "
@@ -1024,6 +1029,172 @@ class _SpectralSparseReml:
         return (log10_lambda, lam, sigma_g2, sigma_e2, ml, reml)
 
 
+class _SparseFactorReml:
+    """K + lambda I of a (subset of a) sparse GRM whose relatedness graph holds a connected component beyond one dense
+    eigenproblem on this GPU (`sparse_component_limit()`): no spectral form exists, so the matrix is handled as the reference
+    handles every sparse GRM -- a sparse factorisation of K + lambda I per lambda ON THE HOST (`SparseJxgrmCholesky`,
+    src/math/cholesky.rs:733, 1018-1183; one per objective evaluation, src/stats/spreml.rs:384-512): scipy's SuperLU in symmetric
+    mode with a minimum-degree ordering of A + A' gives log det(K + lambda I) exactly (sum of the logs of U's diagonal; positive
+    definite <=> every pivot positive) and the few solves of the null model (V^-1 [y | X]).  The per-SNP solves of the exact scan
+    run on the device (`jxg_sps_solve_multi`: one multi-vector CG per block of SNP rows over the CSR image of K,
+    csrc/k_spsolve.hip); the GRAMMAR-gamma route needs V^-1 for the <= 2000 sampled markers only (host factor) and scans in
+    sample space as always.  Same interface as `_SpectralSparseReml` for the likelihood searches (`evaluate`, `factorizable`)."""
+
+    factor_route = True
+
+    def __init__(self, path, y, x_cov, sample_indices):
+        import scipy.sparse as sp
+        y = _c(y, np.float64).ravel()
+        n_all, col_ptr, rows, vals = load_spgrm(path)
+        idx, n_sel = _opt_idx(sample_indices)
+        low = sp.csc_matrix((vals, rows.astype(np.int64), col_ptr.astype(np.int64)), shape=(n_all, n_all))
+        full = low + sp.tril(low, -1).T                       # the file holds the lower triangle, diagonal first in every column
+        if idx is not None:
+            if n_sel == 0:
+                raise RuntimeError("Sparse GRM subset requires at least one sample")
+            if idx.min() < 0 or idx.max() >= n_all:
+                raise RuntimeError(f"Sparse GRM subset index out of range for n_samples={n_all}")
+            if len(np.unique(idx)) != n_sel:
+                raise RuntimeError("Sparse GRM subset contains duplicated sample index")
+            full = full.tocsr()[idx][:, idx]
+        self.k = full.tocsr()
+        self.k.sort_indices()
+        n = int(self.k.shape[0])
+        if n != y.shape[0]:
+            raise RuntimeError(f"SPREML subset sample size mismatch: sparse n={n}, phenotype n={y.shape[0]}")
+        if n == 0:
+            raise RuntimeError("SPREML requires n > 0")
+        if x_cov is None:
+            x = np.ones((n, 1), dtype=np.float64)
+        else:
+            xc = _c(x_cov, np.float64)
+            if xc.ndim != 2 or xc.shape[0] != n:
+                raise RuntimeError(f"x_cov shape mismatch: got {list(xc.shape)}, expected ({n}, p)")
+            x = np.concatenate([np.ones((n, 1)), xc], axis=1)
+        self.n, self.p = n, int(x.shape[1])
+        self.x_design, self.y_raw, self.sample_idx = x, y, idx
+        self.perm, self.blocks = None, None
+        self.diag = np.asarray(self.k.diagonal(), dtype=np.float64)
+        self._fac = (None, None)         # (lambda, SuperLU) of the last factorisation
+        self._dev = None                 # CSR image in HBM (exact scan)
+
+    def _factor(self, lam):
+        """SuperLU of K + lambda I without row pivoting, or None when a pivot is not positive (not positive definite)."""
+        import scipy.sparse as sp
+        from scipy.sparse.linalg import splu
+        if self._fac[0] == lam:
+            return self._fac[1]
+        a = (self.k + lam * sp.identity(self.n, format="csr")).tocsc()
+        try:
+            lu = splu(a, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+        except RuntimeError:             # exactly singular
+            lu = None
+        if lu is not None:
+            d = lu.U.diagonal()
+            if not (np.all(np.isfinite(d)) and np.all(d > 0.0) and np.array_equal(lu.perm_r, lu.perm_c)):
+                lu = None                # an indefinite matrix shows as a non-positive pivot or as a row interchange
+        self._fac = (lam, lu)
+        return lu
+
+    def factorizable(self, lam):
+        import math
+        return bool(math.isfinite(lam) and lam > 0.0 and self._factor(float(lam)) is not None)
+
+    @property
+    def smin(self):
+        """Sign of the smallest eigenvalue of K (the spectral form's `smin` is only ever compared with 0 by the callers)."""
+        return 1.0 if self._factor(0.0) is not None else -1.0
+
+    def solve(self, lam, b):
+        """(K + lambda I)^-1 b for a vector or an (n, k) block (host sparse factor)."""
+        lu = self._factor(float(lam))
+        if lu is None:
+            raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
+        return lu.solve(np.ascontiguousarray(b, dtype=np.float64))
+
+    def evaluate(self, log10_lambda, vp_fixed=None):
+        """`sparse_reml_evaluate` (src/stats/spreml.rs:384-512): the same formulas as the spectral form, V^-1 and log det V from
+        the sparse factor."""
+        import math
+        lam = 10.0 ** log10_lambda
+        if not (math.isfinite(lam) and lam > 0.0):
+            raise RuntimeError(f"SPREML lambda is invalid at log10(lambda)={log10_lambda}")
+        n, p = self.n, self.p
+        if p == 0 or n <= p:
+            raise RuntimeError(f"SPREML requires n > p, got n={n}, p={p}")
+        lu = self._factor(lam)
+        if lu is None:
+            raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
+        vi = lu.solve(np.concatenate([self.y_raw[:, None], self.x_design], axis=1))
+        y_vinv_y = float(self.y_raw @ vi[:, 0])
+        xt_vinv_y = self.x_design.T @ vi[:, 0]
+        xt_vinv_x = self.x_design.T @ vi[:, 1:]
+        xt_vinv_x = 0.5 * (xt_vinv_x + xt_vinv_x.T)
+        chol = _spd_cholesky_with_jitter(xt_vinv_x, "SPREML XtVinvX")
+        beta = np.linalg.solve(chol.T, np.linalg.solve(chol, xt_vinv_y))
+        ypy = y_vinv_y - float(xt_vinv_y @ beta)
+        if not math.isfinite(ypy) or ypy <= 1e-30:
+            raise RuntimeError(f"SPREML profiled residual quadratic form is invalid at lambda={lam}: yPy={ypy}")
+        df = float(n - p)
+        log_det_m = float(np.log(lu.U.diagonal()).sum())          # L has a unit diagonal, no interchanges: det = prod U_ii
+        log_det_x = 2.0 * float(np.log(np.diag(chol)).sum())
+        if vp_fixed is None:
+            sigma_g2 = ypy / df
+            if not math.isfinite(sigma_g2) or sigma_g2 <= 0.0:
+                raise RuntimeError(f"SPREML sigma_g2 is invalid at lambda={lam}: sigma_g2={sigma_g2}")
+            sigma_e2 = lam * sigma_g2
+            reml = df * (math.log(df) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (
+                df * math.log(ypy) + log_det_m + log_det_x)
+            nf = float(n)
+            ml = nf * (math.log(nf) - 1.0 - math.log(2.0 * math.pi)) * 0.5 - 0.5 * (nf * math.log(ypy) + log_det_m)
+        else:
+            if not (math.isfinite(vp_fixed) and vp_fixed > 0.0):
+                raise RuntimeError(f"SPREML fastGWA fixed-Vp objective requires finite vp_fixed > 0, got {vp_fixed}")
+            sigma_g2 = vp_fixed / (1.0 + lam)
+            sigma_e2 = lam * sigma_g2
+            reml = -0.5 * (df * math.log(sigma_g2) + log_det_m + log_det_x + ypy / sigma_g2)
+            ml = float("nan")
+        if not math.isfinite(reml) or not (math.isfinite(ml) or math.isnan(ml)):
+            raise RuntimeError(f"SPREML likelihood is invalid at lambda={lam}: ml={ml}, reml={reml}")
+        return (log10_lambda, lam, sigma_g2, sigma_e2, ml, reml)
+
+    def null_state(self, lam):
+        """Null state of the exact scan (`build_sparse_splmm_null_state`, src/stats/splmm.rs:3500-3660) in SAMPLE space:
+        V^-1 X, A = X'V^-1 X (jittered only if it fails), Py = V^-1 (y - X b), yPy -> (V^-1 X (n, p), Py (n), chol(A), yPy)."""
+        vi = self.solve(lam, np.concatenate([self.y_raw[:, None], self.x_design], axis=1))
+        vinv_x = vi[:, 1:]
+        a = self.x_design.T @ vinv_x
+        a_chol = _spd_cholesky_with_jitter(0.5 * (a + a.T), "SparseLMM XtWX")
+        b0 = np.linalg.solve(a_chol.T, np.linalg.solve(a_chol, vinv_x.T @ self.y_raw))
+        py = vi[:, 0] - vinv_x @ b0
+        ypy = float(self.y_raw @ py)
+        if not (np.isfinite(ypy) and ypy > 0.0):
+            raise RuntimeError(f"SparseLMM exact scan requires finite positive yPy on K + lambda I scale, got {ypy}")
+        return vinv_x, py, a_chol, ypy
+
+    def device_csr(self):
+        """(rowptr int64, col int32, val f64) of K in HBM, uploaded once."""
+        import torch
+        if self._dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._dev = (torch.from_numpy(self.k.indptr.astype(np.int64)).to(dev),
+                         torch.from_numpy(self.k.indices.astype(np.int32)).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(self.k.data, dtype=np.float64)).to(dev))
+        return self._dev
+
+
+def _sparse_reml_model(path, y, x_cov, sample_indices):
+    """The model of K + lambda I for the sparse-GRM routes: the spectral form (one dense or block-diagonal eigendecomposition on
+    the GPU) wherever every connected component fits one dense eigenproblem, the sparse-factor form beyond that
+    (`sparse_component_limit()`; JXGPU_SPLMM_ROUTE=factor forces it)."""
+    if os.environ.get("JXGPU_SPLMM_ROUTE", "").strip().lower() == "factor":
+        return _SparseFactorReml(path, y, x_cov, sample_indices)
+    try:
+        return _SpectralSparseReml(path, y, x_cov, sample_indices)
+    except _ComponentTooLarge:
+        return _SparseFactorReml(path, y, x_cov, sample_indices)
+
+
 def _spd_cholesky_with_jitter(mat, label):
     """src/stats/spreml.rs:324-351 (pivot floor 1e-18 of `cholesky_inplace`, src/math/linalg.rs:341-363)."""
     def try_chol(a):
@@ -1127,14 +1298,14 @@ def spreml_sparse_reml_grid_from_jxgrm(jxgrm_path, y, x_cov=None, sample_indices
                                        grid_size=33, threads=1):
     """src/stats/spreml.rs:826-918 -> (lambda, sigma_g2, sigma_e2, ml, reml, log10_lambda, grid_log10, grid_reml,
     grid_sigma_g2, grid_sigma_e2): REML profile of y ~ [1, x_cov] + g, Var g = sigma_g2 K (sparse), on a lambda grid."""
-    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    model = _sparse_reml_model(jxgrm_path, y, x_cov, sample_indices)
     return _spreml_tuple(*_spreml_grid(model, low, high, grid_size, None))
 
 
 def spreml_sparse_reml_brent_from_jxgrm(jxgrm_path, y, x_cov=None, sample_indices=None, low=-5.0, high=5.0,
                                         grid_size=9, tol=1e-3, max_iter=20, threads=1, progress_callback=None):
     """src/stats/spreml.rs:920-1042: grid, then Brent between the best point's neighbours (same 10-tuple)."""
-    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices)
+    model = _sparse_reml_model(jxgrm_path, y, x_cov, sample_indices)
     return _spreml_brent(model, low, high, grid_size, tol, max_iter, None, progress_callback)
 
 
@@ -1142,7 +1313,7 @@ def spreml_sparse_fastgwa_fixed_vp_brent_from_jxgrm(jxgrm_path, y_resid, vp_fixe
                                                     high=5.0, grid_size=9, tol=1e-3, max_iter=20, threads=1,
                                                     progress_callback=None):
     """src/stats/spreml.rs:1044-1160: the fastGWA objective (Vp fixed, intercept-only design on residuals)."""
-    model = _SpectralSparseReml(jxgrm_path, y_resid, None, sample_indices)
+    model = _sparse_reml_model(jxgrm_path, y_resid, None, sample_indices)
     return _spreml_brent(model, low, high, grid_size, tol, max_iter, float(vp_fixed), progress_callback)
 
 
@@ -1198,9 +1369,16 @@ def splmm_assoc_pcg_dense_f32(g, y, lbd, sparse_jxgrm_path, x_cov=None, sparse_s
     if sparse_sample_indices is not None and len(np.asarray(sparse_sample_indices).ravel()) != n:
         raise RuntimeError("Dense SparseLMM scan requires factor subset n to match g/y n; "
                            f"factor_n={len(np.asarray(sparse_sample_indices).ravel())}, y_n={n}")
-    model = _SpectralSparseReml(sparse_jxgrm_path, y, x_cov, sparse_sample_indices)
+    model = _sparse_reml_model(sparse_jxgrm_path, y, x_cov, sparse_sample_indices)
     if not model.factorizable(lbd):
         raise RuntimeError(f"K + lambda I is not positive definite at lambda={lbd}")
+    if getattr(model, "factor_route", False):
+        # a connected component beyond one dense eigenproblem: multi-vector CG over the CSR image of K per block of rows
+        dev = torch.device("cuda", torch.cuda.current_device())
+        vinv_x, py, a_chol, ypy = model.null_state(lbd)
+        rows_f32 = lambda r0, nr: torch.from_numpy(g[r0:r0 + nr]).to(dev)      # noqa: E731
+        out = pl.scan_rows_splmm_factor(rows_f32, m, n, model.p, model.device_csr(), model.diag, lbd, vinv_x, py, a_chol, ypy, dev)
+        return out.cpu().numpy()
     fv_state = _splmm_exact_null_state(model, lbd)
     dev = model.s_dev.device
     if model.blocks is not None:
@@ -1225,7 +1403,7 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     the genotype file's (`sample_indices` then indexes the packed payload only); default: the same indices for both."""
     import torch
     from . import pipeline as pl
-    model = _SpectralSparseReml(jxgrm_path, y, x_cov, sample_indices if grm_sample_indices is None else grm_sample_indices)
+    model = _sparse_reml_model(jxgrm_path, y, x_cov, sample_indices if grm_sample_indices is None else grm_sample_indices)
     panel_idx = model.sample_idx if grm_sample_indices is None else (
         None if sample_indices is None else _c(sample_indices, np.int64).ravel())
     if grm_sample_indices is not None and panel_idx is not None and panel_idx.shape[0] != model.n:
@@ -1255,6 +1433,22 @@ def splmm_exact_scan_from_jxgrm(jxgrm_path, y, packed, packed_n_samples, maf, ro
     lut[:, 1] = mean_g
     lut[:, 2] = 1.0
     lut[:, 3] = np.where(flip[rows], 0.0, 2.0)
+    if getattr(model, "factor_route", False):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        packed_t = pk.to(dev) if _is_device_tensor(pk) else torch.from_numpy(pk if pk.flags.writeable else pk.copy()).to(dev)
+        panel = pl.Panel(packed_t, n_full, panel_idx)
+        rows_t = torch.from_numpy(rows.astype(np.int32)).to(dev)
+        lut_t = torch.from_numpy(lut).to(dev)
+        vinv_x, py, a_chol, ypy = model.null_state(lam)
+
+        def rows_f32(r0, nr):
+            buf = torch.empty((nr, model.n), dtype=torch.float32, device=dev)
+            check(lib().jxg_decode_rows_p32(panel.p32.data_ptr(), panel.m, model.n, rows_t[r0:].data_ptr(), nr,
+                                            lut_t[r0:].data_ptr(), buf.data_ptr(), model.n, pl._stream()))
+            return buf
+        out = pl.scan_rows_splmm_factor(rows_f32, len(rows), model.n, model.p, model.device_csr(), model.diag, lam, vinv_x, py,
+                                        a_chol, ypy, dev)
+        return out.cpu().numpy(), float(log10_lambda), null
     dev = model.s_dev.device
     fv_state = _splmm_exact_null_state(model, lam)
     if _is_device_tensor(pk):
@@ -1456,17 +1650,24 @@ def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat
     sigma2 = rss / (float(n - p) * (1.0 + lam))
     if not (math.isfinite(sigma2) and sigma2 > 0.0):
         raise RuntimeError(f"SparseLMM residualized approx produced invalid scan sigma2 at lambda={lam}: {sigma2}")
-    w = 1.0 / (model.s + lam)
-    a_rot = w * (model.yr - model.xr @ c_y) / sigma2      # U'a,  a = (K + lambda I)^-1 y_r / sigma2
-    dev = model.s_dev.device
-    a_rot_t = torch.from_numpy(a_rot).to(dev)
-    if model.blocks is not None:
-        a_t = torch.empty(n, dtype=torch.float64, device=dev)
-        for off, nb, utb in model.blocks:
-            a_t[off:off + nb] = utb.T @ a_rot_t[off:off + nb]
+    factor = getattr(model, "factor_route", False)
+    if factor:
+        # no spectral form (a connected component beyond one dense eigenproblem): V^-1 from the host sparse factor, as the
+        # reference does (`SparseJxgrmCholesky`): one solve for a, one multi-vector solve for the sampled markers
+        dev = torch.device("cuda", torch.cuda.current_device())
+        a_vec = model.solve(lam, y_resid) / sigma2
     else:
-        a_t = model.ut_dev.T @ a_rot_t
-    a_vec = a_t.cpu().numpy()
+        w = 1.0 / (model.s + lam)
+        a_rot = w * (model.yr - model.xr @ c_y) / sigma2      # U'a,  a = (K + lambda I)^-1 y_r / sigma2
+        dev = model.s_dev.device
+        a_rot_t = torch.from_numpy(a_rot).to(dev)
+        if model.blocks is not None:
+            a_t = torch.empty(n, dtype=torch.float64, device=dev)
+            for off, nb, utb in model.blocks:
+                a_t[off:off + nb] = utb.T @ a_rot_t[off:off + nb]
+        else:
+            a_t = model.ut_dev.T @ a_rot_t
+        a_vec = a_t.cpu().numpy()
     # ---- gamma from sampled markers
     m = len(rows)
     rr = splmm_choose_rhat_rows(m, rhat_markers, rhat_seed) if rhat_rows is None else _c(rhat_rows, np.int64).ravel()
@@ -1495,23 +1696,47 @@ def _splmm_approx_scan(model, lam, pk, n_full, maf32, flip, rows, scan_idx, rhat
         panel_idx = model.perm if scan_idx is None else scan_idx[model.perm]
     sub = packed_t[torch.from_numpy(rows[rr]).to(dev)]    # payload of the sampled markers only
     sub_rows = np.arange(len(rr), dtype=np.int32)
-    if model.blocks is not None:
-        full_idx = np.arange(n_full, dtype=np.int64) if panel_idx is None else panel_idx
-        rot = pl.BlockRotation(sub, n_full, full_idx, model.blocks)
-        grot = pl.rotate_rows_blocks(rot, sub_rows, lut[rr])
-        del rot
+    if factor:
+        # the sampled markers decoded on the device, their sums in sample space on the host: gg, g'V^-1 g (one multi-vector
+        # solve per 256 markers), g'a, X'g, X'V^-1 g = (V^-1 X)'g
+        sp_panel = pl.Panel(sub, n_full, panel_idx)
+        gdec = torch.empty((len(rr), n), dtype=torch.float32, device=dev)
+        lut_s = torch.from_numpy(np.ascontiguousarray(lut[rr])).to(dev)
+        check(lib().jxg_decode_rows_p32(sp_panel.p32.data_ptr(), sp_panel.m, n, None, len(rr), lut_s.data_ptr(), gdec.data_ptr(), n,
+                                        pl._stream()))
+        gh = gdec.cpu().numpy().astype(np.float64)
+        del gdec, sp_panel
+        vinv_x = model.solve(lam, x)
+        sums = np.empty((len(rr), 3 + 2 * p), dtype=np.float64)
+        for k0 in range(0, len(rr), 256):
+            gb = gh[k0:k0 + 256]
+            zb = model.solve(lam, gb.T)                     # (n, <= 256)
+            sums[k0:k0 + 256, 0] = np.einsum("kn,kn->k", gb, gb)
+            sums[k0:k0 + 256, 1] = np.einsum("kn,nk->k", gb, zb)
+            sums[k0:k0 + 256, 2] = gb @ a_vec
+            sums[k0:k0 + 256, 3:3 + p] = gb @ x
+            sums[k0:k0 + 256, 3 + p:] = gb @ vinv_x
+        del gh, sub
+        xtwx = x.T @ vinv_x
+        xta = x.T @ a_vec
     else:
-        sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
-        grot = pl.rotate_rows(pl.Panel(sub, n_full, panel_idx), sm, sub_rows, lut[rr])
-    sums = torch.empty((len(rr), 3 + 2 * p), dtype=torch.float64, device=dev)
-    xr_t = torch.from_numpy(np.ascontiguousarray(model.xr)).to(dev)
-    w_t = torch.from_numpy(w).to(dev)
-    check(lib().jxg_splmm_gamma_sums(grot.data_ptr(), len(rr), n, n, p, w_t.data_ptr(), a_rot_t.data_ptr(), xr_t.data_ptr(),
-                                     sums.data_ptr(), pl._stream()))
-    sums = sums.cpu().numpy()
-    del grot, sub
-    xtwx = model.xr.T @ (model.xr * w[:, None])
-    xta = model.xr.T @ a_rot
+        if model.blocks is not None:
+            full_idx = np.arange(n_full, dtype=np.int64) if panel_idx is None else panel_idx
+            rot = pl.BlockRotation(sub, n_full, full_idx, model.blocks)
+            grot = pl.rotate_rows_blocks(rot, sub_rows, lut[rr])
+            del rot
+        else:
+            sm = pl.SpectralModel(model.s_dev, model.ut_dev, model.x_design, model.y_raw, fit_null=False)
+            grot = pl.rotate_rows(pl.Panel(sub, n_full, panel_idx), sm, sub_rows, lut[rr])
+        sums = torch.empty((len(rr), 3 + 2 * p), dtype=torch.float64, device=dev)
+        xr_t = torch.from_numpy(np.ascontiguousarray(model.xr)).to(dev)
+        w_t = torch.from_numpy(w).to(dev)
+        check(lib().jxg_splmm_gamma_sums(grot.data_ptr(), len(rr), n, n, p, w_t.data_ptr(), a_rot_t.data_ptr(), xr_t.data_ptr(),
+                                         sums.data_ptr(), pl._stream()))
+        sums = sums.cpu().numpy()
+        del grot, sub
+        xtwx = model.xr.T @ (model.xr * w[:, None])
+        xta = model.xr.T @ a_rot
     fast_sum = res_sum = 0.0
     n_used = res_used = 0
     for k in range(len(rr)):
@@ -1596,7 +1821,7 @@ def _splmm_assoc(prefix, y, lbd, x_cov, sample_indices, operator_sample_indices,
                                                            grm_sample_indices=sp_idx)
             r_hat, req, used = float("nan"), 0, 0
         else:
-            spm = _SpectralSparseReml(path, inp["y"], inp["x_cov"], sp_idx)
+            spm = _sparse_reml_model(path, inp["y"], inp["x_cov"], sp_idx)
             if not spm.factorizable(lam) and not (lam == 0.0 and spm.smin > 0.0):
                 raise RuntimeError(f"K + lambda I is not positive definite at lambda={lam}")
             r_hat, out_t, req, used = _splmm_approx_scan(spm, lam, inp["pk"], inp["n_full"], inp["maf"], inp["flip"],

@@ -837,6 +837,43 @@ def scan_rows_splmm_dense(g: np.ndarray, parts, n: int, p: int, fv_state, dev, b
     return out
 
 
+def scan_rows_splmm_factor(rows_f32, m: int, n: int, p: int, csr, diag: np.ndarray, lam: float, vinv_x: np.ndarray,
+                           py: np.ndarray, a_chol: np.ndarray, ypy: float, dev, block_rows: int = 256, tol: float = 1e-11,
+                           max_iter: int = 1000):
+    """SparseLMM exact scan (`exact_scan_blocks_core`, src/stats/splmm.rs:2567-2880) WITHOUT a spectral form of K: the relatedness
+    graph holds a connected component beyond one dense eigenproblem (`janusx._SparseFactorReml`).  The reference solves
+    (K + lambda I) z = g per SNP with its sparse factor; here every block of `block_rows` decoded rows is the right-hand side
+    of one multi-vector conjugate-gradient solve over the CSR image of K in HBM (`jxg_sps_solve_multi`, csrc/k_spsolve.hip),
+    then g'V^-1 g, g.Py, g.(V^-1 X) in sample space (`jxg_sps_scan_sums`) and the score-form finish of the other exact scans
+    (`jxg_fvlmm_finish_dev`, score_mode = 1).  rows_f32(r0, nr) -> device tensor (nr, n) f32 of the decoded rows r0 .. r0 + nr
+    ([0, 2 maf, 1, 2] or flipped, missing = mean, not centred).  -> (m, 3) f64 [beta, se, p] on the device."""
+    rowptr, col, val = csr
+    out = torch.empty((m, 3), dtype=torch.float64, device=dev)
+    if m == 0:
+        return out
+    br = int(max(64, min(block_rows, (m + 63) // 64 * 64)))
+    ldr = int(lib().jxg_sps_ldr(br))
+    dinv = torch.from_numpy(1.0 / (np.asarray(diag, dtype=np.float64) + float(lam))).to(dev)
+    work = torch.empty(int(lib().jxg_sps_work_doubles(n, ldr)), dtype=torch.float64, device=dev)
+    g = torch.empty((n, ldr), dtype=torch.float64, device=dev)
+    z = torch.empty((n, ldr), dtype=torch.float64, device=dev)
+    sums = torch.empty((br, p + 2), dtype=torch.float64, device=dev)
+    py_t = torch.from_numpy(np.ascontiguousarray(py, dtype=np.float64)).to(dev)
+    vx_t = torch.from_numpy(np.ascontiguousarray(vinv_x, dtype=np.float64)).to(dev)
+    a_dev = torch.from_numpy(np.ascontiguousarray(a_chol, dtype=np.float64)).to(dev)
+    info = np.zeros(2, dtype=np.float64)
+    for r0 in range(0, m, br):
+        nr = min(br, m - r0)
+        rows = rows_f32(r0, nr)
+        check(lib().jxg_sps_rows_to_cols_f64(_ptr(rows), nr, n, int(rows.stride(0)), _ptr(g), ldr, _stream()))
+        check(lib().jxg_sps_solve_multi(n, _ptr(rowptr), _ptr(col), _ptr(val), float(lam), _ptr(dinv), _ptr(g), nr, ldr,
+                                        float(tol), int(max_iter), _ptr(z), _ptr(work), info.ctypes.data, _stream()))
+        check(lib().jxg_sps_scan_sums(n, _ptr(g), _ptr(z), nr, ldr, _ptr(py_t), _ptr(vx_t), p, _ptr(sums), _ptr(work), _stream()))
+        check(lib().jxg_fvlmm_finish_dev(_ptr(sums), 1, p + 2, nr, n, p, _ptr(a_dev), float(ypy), n - p, 0, 0.0, 0.0, 1,
+                                         out[r0:].data_ptr(), _stream()))
+    return out
+
+
 def rotate_rows(panel: Panel, model: SpectralModel, rows: np.ndarray, lut: np.ndarray) -> torch.Tensor:
     """G~ = G U for a (small) list of SNP rows, written out: (len(rows), n) f32 on the device (the fp16 hi / lo rotation of
     `scan_rows` without a scan behind it; used for the sampled markers of the SparseLMM gamma estimate)."""

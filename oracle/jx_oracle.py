@@ -1012,10 +1012,14 @@ def splmm_approx_assoc(k, lam, x_design, y, packed, n_samples, maf, row_flip, rh
 
 
 def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_rate=0.05,
-                   het_threshold=0.0, block_rows=65536):
+                   het_threshold=0.0, block_rows=65536, exact_syrk=False):
     """`grm_stream_bed_f32` restatement (src/stats/grm.rs:4690-5455): prestat pass -> keep/flip/mean/
     scale -> f32 block SYRK + f64 merge -> scale by sum(var) (method 1) or eff_m (method 2).
-    Returns (K f32, eff_m, keep mask)."""
+    Returns (K f32, eff_m, keep mask).
+    exact_syrk: the block product of the same f32 operands in exact (f64) arithmetic instead of an f32 SSYRK -- what the
+    reference's `cblas_ssyrk` (src/stats/grm.rs:1638-1667) would return without the rounding of its own f32 accumulation,
+    whose size and sign depend on the BLAS at hand (blocking, threads, FMA); everything else unchanged, the result is cast to
+    f32 as the reference's API does."""
     maf_thr = min(max(float(maf_threshold), 0.0), 0.5)
     miss_thr = min(max(float(max_missing_rate), 0.0), 1.0)
     het_thr = min(max(float(het_threshold), 0.0), 1.0)
@@ -1039,7 +1043,11 @@ def grm_stream_bed(packed, n_samples, method=1, maf_threshold=0.02, max_missing_
                             (g[2] - mean_g[j]) * scale[j]], dtype=np.float32)
             z[k] = lut[codes[k]]
             varsum += var[j]
-        acc += (z.T @ z).astype(np.float64)
+        if exact_syrk:
+            z64 = z.astype(np.float64)
+            acc += z64.T @ z64
+        else:
+            acc += (z.T @ z).astype(np.float64)
     D = varsum if method == 1 else float(eff_m)
     if not (math.isfinite(D) and D > 0.0):
         raise RuntimeError("invalid centered GRM denominator: sum(2p(1-p)) <= 0")

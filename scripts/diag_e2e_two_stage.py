@@ -30,9 +30,20 @@ gd = O.decode_centered_block_f32(packed, n, flip, maf, rows=rows)
 grot = O.rotate_block_f32(gd, nm.Dh)
 ref, ev_ref = OC.lmm_scan_rotated_block(grot, nm.S, nm.Xcov, nm.y, nm.bounds[0], nm.bounds[1], 30, 1e-2, threads=os.cpu_count(),
                                         return_evals=True)
+# the same oracle with the GRM's block products in exact arithmetic (no f32 SSYRK rounding)
+k_x, _, _ = O.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0, exact_syrk=True)
+s_x, u_x = O.gwas_eigh_from_grm(k_x)
+nm_x = O.spectral_null_model(y, np.ones((n, 1)), s_x, u_x)
+ref_x = OC.lmm_scan_rotated_block(O.rotate_block_f32(gd, nm_x.Dh), nm_x.S, nm_x.Xcov, nm_x.y, nm_x.bounds[0], nm_x.bounds[1], 30, 1e-2,
+                                  threads=os.cpu_count())
 dev = torch.device("cuda", 0)
 pk = torch.from_numpy(packed).to(dev)
 out = {}
+okx = ~np.isnan(ref[:, 0])
+bxx = np.abs(ref_x[okx, 0] - ref[okx, 0]) / np.maximum(np.abs(ref[okx, 0]), ref[okx, 1])
+out["oracle_f32_syrk_vs_oracle_exact_syrk"] = {"beta_err_quantiles_50_90_99_999_max": [float(v) for v in np.quantile(bxx, [0.5, 0.9, 0.99, 0.999, 1.0])],
+                                               "grm_max_rel": float(np.max(np.abs(k_x.astype(np.float64) - k_ref) / np.maximum(np.abs(k_ref), np.mean(np.diag(k_ref))))),
+                                               "lbd": [nm.lbd_null, nm_x.lbd_null]}
 for planes in (5, 6):
     k32, geff, panel = pipeline.build_grm(pk, n, 1, 0.02, 0.05)
     s_d, ut64 = pipeline.eigh_from_grm(k32, 1e-6, f32_consumer=(planes == 5))
@@ -53,7 +64,12 @@ for planes in (5, 6):
     be2 = np.abs(got2[ok, 0] - ref[ok, 0]) / np.maximum(np.abs(ref[ok, 0]), ref[ok, 1])
     same2 = ev2[ok] == ev_ref[ok]
     q = lambda v: [float(x) for x in np.quantile(v, [0.5, 0.9, 0.99, 0.999, 1.0])]   # noqa: E731
+    bex = np.abs(got[ok, 0] - ref_x[ok, 0]) / np.maximum(np.abs(ref_x[ok, 0]), ref_x[ok, 1])
+    k_gpu = k32.double().cpu().numpy()
     out[f"planes{planes}"] = {
+        "vs_oracle_exact_syrk_beta_err_quantiles": q(bex),
+        "grm_gpu_vs_f32_syrk_oracle": float(np.max(np.abs(k_gpu - k_ref) / np.maximum(np.abs(k_ref), np.mean(np.diag(k_ref))))),
+        "grm_gpu_vs_exact_syrk_oracle": float(np.max(np.abs(k_gpu - k_x) / np.maximum(np.abs(k_x), np.mean(np.diag(k_x))))),
         "lbd_gpu": model.null.lbd, "lbd_oracle": nm.lbd_null, "bounds_gpu": model.null.bounds, "bounds_oracle": nm.bounds,
         "beta_err_quantiles_50_90_99_999_max": q(be), "se_err_quantiles": q(se),
         "share_same_evals": float(same.mean()), "beta_err_max_same_evals": float(be[same].max()),

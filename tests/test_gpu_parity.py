@@ -2824,7 +2824,7 @@ def test_splmm_giant_component_both_sides_of_the_limit(oracle, tmp_path, monkeyp
     (src/math/cholesky.rs:776-1075, src/stats/spreml.rs:384-760); here a component is one dense eigenproblem on the GPU up to
     `sparse_component_limit()` samples (~ 79 000 on an empty MI355X).  Below the limit the block route must take the component
     through the dense spectral form AUTOMATICALLY (one block of n samples although the block size is 128) and agree with the
-    oracle's dense-Cholesky restatement; above it the route fails with the size and the limit in the message."""
+    oracle's dense-Cholesky restatement; above it the routes take the sparse-factor form and agree with the same oracle."""
     from janusx_amd import janusx as jxrs
     monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "block")
     monkeypatch.setenv("JXGPU_SPLMM_BLOCK", "128")
@@ -2855,14 +2855,46 @@ def test_splmm_giant_component_both_sides_of_the_limit(oracle, tmp_path, monkeyp
     ref = oracle.splmm_exact_scan(kd, 10.0 ** l10, oracle.spreml_design_matrix(None, n), y, pk, n, maf_k, flip, None, rows)
     be, se, pe = _assoc_err(got, ref)
     assert max(be, se, pe) < TOL, (be, se, pe)
-    # the other side of the threshold: the same panel with the limit below the component's size
+    # the other side of the threshold: the same panel with the limit below the component's size.  No spectral form exists
+    # there; the routes switch to the sparse-factor form (`_SparseFactorReml`: host sparse LU of K + lambda I per lambda for
+    # log det and the null solves -- the reference factorises on the host too, src/math/cholesky.rs:733, 1061 -- and one
+    # multi-vector CG per block of SNP rows on the device, csrc/k_spsolve.hip) and must agree with the same oracle.
     jxrs.spectral_cache_clear()
     monkeypatch.setenv("JXGPU_SPLMM_COMPONENT_MAX", "512")
-    with pytest.raises(RuntimeError, match=r"700 samples; the limit on this GPU is 512 samples"):
-        jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip, None, None, rows)
+    with pytest.raises(jxrs._ComponentTooLarge, match=r"700 samples; the limit on this GPU is 512 samples"):
+        jxrs._SpectralSparseReml(path, y, None, None)
+    assert isinstance(jxrs._sparse_reml_model(path, y, None, None), jxrs._SparseFactorReml)
+    got_f, l10_f, null_f = jxrs.splmm_exact_scan_from_jxgrm(path, y, pk, n, maf_k, flip, None, None, rows)
+    assert abs(l10_f - ref_null[5]) < 1e-6                                                                    # REML optimum
+    assert abs(null_f[4] - ref_null[4]) < 1e-9 * max(1.0, abs(ref_null[4]))                                   # REML value
+    ref_f = oracle.splmm_exact_scan(kd, 10.0 ** l10_f, oracle.spreml_design_matrix(None, n), y, pk, n, maf_k, flip, None, rows)
+    be, se, pe = _assoc_err(got_f, ref_f, "factor")
+    assert max(be, se, pe) < TOL, (be, se, pe)
     monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "dense")
-    with pytest.raises(RuntimeError, match=r"700 samples; the limit on this GPU is 512 samples"):
-        jxrs.spreml_sparse_reml_brent_from_jxgrm(path, y)
+    nul = jxrs.spreml_sparse_reml_brent_from_jxgrm(path, y)
+    assert abs(nul[5] - ref_null[5]) < 1e-6 and abs(nul[4] - ref_null[4]) < 1e-9 * max(1.0, abs(ref_null[4]))
+    # the reference's default `-splmm` (GRAMMAR-gamma) and the dense-rows entry point on the factor form, covariates included
+    monkeypatch.setenv("JXGPU_SPLMM_ROUTE", "block")
+    xc = rng.normal(size=(n, 2))
+    xd = oracle.spreml_design_matrix(xc, n)
+    lam = 10.0 ** l10_f
+    prefix = str(tmp_path / "gc")
+    bim = bed.Bim(["1"] * len(pk), [f"rs{j}" for j in range(len(pk))], list(range(1, len(pk) + 1)), ["A"] * len(pk), ["G"] * len(pk))
+    bed.write_bed(prefix, pk, [f"s{i}" for i in range(n)], bim)
+    maf_r, flip_r = maf_k[rows].astype(np.float32), flip[rows]
+    got_a = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, maf=maf_r, row_flip=flip_r, row_indices=rows,
+                                     sparse_jxgrm_path=path, rhat_markers=40, scan_mode="approx")
+    gamma, ref_a, used, _rr = oracle.splmm_approx_assoc(kd, lam, xd, y, pk[rows], n, maf_r, flip_r, rhat_markers=40)
+    assert abs(got_a[0] - gamma) < 1e-6 * gamma and got_a[8] == used
+    bad = np.isnan(ref_a[:, 0])
+    assert np.array_equal(np.isnan(got_a[9][:, 0]), bad)
+    be, se, pe = _assoc_err(got_a[9][~bad], ref_a[~bad], "factor-approx")
+    assert max(be, se, pe) < TOL, (be, se, pe)
+    got_e = jxrs.splmm_assoc_pcg_bed(prefix, y, lam, x_cov=xc, maf=maf_r, row_flip=flip_r, row_indices=rows,
+                                     sparse_jxgrm_path=path, scan_mode="exact")
+    ref_e = oracle.splmm_exact_scan(kd, lam, xd, y, pk[rows], n, maf_r, flip_r)
+    be, se, pe = _assoc_err(got_e[9], ref_e, "factor-exact-cov")
+    assert max(be, se, pe) < TOL, (be, se, pe)
     jxrs.spectral_cache_clear()
 
 

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                                                          double *__restrict__ beta2, int i8mode,
                                                          const int32_t *__restrict__ flag, uint8_t *__restrict__ miss2,
                                                          double *__restrict__ wl, uint32_t *__restrict__ lut_a,
-                                                         uint32_t *__restrict__ lut_b, double *__restrict__ dfix) {
+                                                         uint32_t *__restrict__ lut_b, double *__restrict__ dfix,
+                                                         uint32_t *__restrict__ lut_c) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const int32_t nex = info[0] & ~63;
@@ -479,15 +480,20 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
     // an int8); byte LUTs of the two Grams: B = (0, P1, 56, 112), A = (0, P1 + P2, 56, 112);
     // c~ c~' ~ ((1 - 1/31) B B' + (1/31) A A') / 3136 up to the product of two P2 (both samples missing at the SNP: 3e-7 of the
     // mean diagonal at 1 % missing calls off the diagonal; ON the diagonal dfix[k] = c*^2 - ((30 P1^2 + (P1 + P2)^2) / 31) / 3136
-    // restores the exact value).  c* is resolved to 1 / 1736 of a count: 1.7e-4 rms per missing call, which random-walks to
-    // sqrt(2 rate m) 1.7e-4 0.55 / (0.3 m) of the mean diagonal -- 2e-7 at m = 200 000 and 1 %, 4e-6 at m = 700: the path is
-    // taken from 16 384 SNPs on
+    // restores the exact value).  With two digits c* is resolved to 1 / 1736 of a count: 1.7e-4 rms per missing call, which
+    // random-walks to sqrt(2 rate m) 1.7e-4 0.55 / (0.3 m) of the mean diagonal -- 2e-7 rms at m = 200 000 and 1 %, 1.3e-6 as
+    // the LARGEST entry error at m = 20 000 / 0.2 % (measured, round 6) -- and an error of that size in K moves the per-SNP
+    // beta of a whole run by 1.7e-5 (scripts/diag_e2e_two_stage.py).  Hence a THIRD digit (lut_c != nullptr, the default):
+    // 56 c~ ~ P1 + P2 / 31 + P3 / 961, P3 = rint(31 (31 (56 c* - P1) - P2)) in [-15, 15], byte LUT C = (0, P1 + P3, 56, 112),
+    //   c~ c~' ~ ((1 - 1/31 - 1/961) B B' + (1/31) A A' + (1/961) C C') / 3136
+    // -- one more int8 Gram over the rows with missing calls, the resolution 31 x finer (5.4e-6 rms per missing call), the
+    // dropped terms still products of two low digits where BOTH samples miss the SNP.
     double cstar = 0.0;
     if (lut_a) {
-        uint32_t la = 0u, lb = 0u;
+        uint32_t la = 0u, lb = 0u, lc = 0u;
         double fix = 0.0;
         if (exact) {
-            la = lb = (56u << 16) | (112u << 24);
+            la = lb = lc = (56u << 16) | (112u << 24);
             if (flag[k] == 2) {
                 const double r0d = (double)ilut[k * 4 + 0];
                 const double bb = beta[k] + r0d, ss = (r0d == 0.0) ? 1.0 : -1.0;
@@ -496,13 +502,18 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                 p1 = fmin(fmax(p1, 0.0), 112.0);
                 double p2 = rint(31.0 * (56.0 * cstar - p1));
                 p2 = fmin(fmax(p2, -15.0), 15.0);
+                double p3 = lut_c ? rint(31.0 * (31.0 * (56.0 * cstar - p1) - p2)) : 0.0;
+                p3 = fmin(fmax(p3, -15.0), 15.0);
                 lb |= ((uint32_t)(int)p1 & 0xffu) << 8;
                 la |= ((uint32_t)(int)(p1 + p2) & 0xffu) << 8;
-                fix = cstar * cstar - ((30.0 * p1 * p1 + (p1 + p2) * (p1 + p2)) / 31.0) / 3136.0;
+                lc |= ((uint32_t)(int)(p1 + p3) & 0xffu) << 8;
+                const double wa = 1.0 / 31.0, wc = lut_c ? 1.0 / 961.0 : 0.0, wb = 1.0 - wa - wc;
+                fix = cstar * cstar - (wb * p1 * p1 + wa * (p1 + p2) * (p1 + p2) + wc * (p1 + p3) * (p1 + p3)) / 3136.0;
             }
         }
         lut_a[dst] = la;
         lut_b[dst] = lb;
+        if (lut_c) lut_c[dst] = lc;
         dfix[dst] = fix;
     }
     if (miss2) {
@@ -698,7 +709,9 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     // with the number of missing calls (nnz n table lookups), the split kernel's does not; measured at n = 20000,
     // m = 200000: 54 ms + 11.5 ms per 0.1 % against 229 ms, i.e. a crossover at ~1.5 %
     const double miss_max = getenv("JXGPU_GRM_MISS_MAX") ? atof(getenv("JXGPU_GRM_MISS_MAX")) : 0.012;
-    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb, lutab, lutbb, dfixb, elutb, dvecb;
+    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb, lutab, lutbb, lutcb, dfixb, elutb, dvecb;
+    // digits of the missing call's count in the dense form: 3 (default; see grm_gather_kernel), JXGPU_GRM_MISS_DIGITS=2: rounds 4 - 5
+    const bool three_digits = !(getenv("JXGPU_GRM_MISS_DIGITS") && atoi(getenv("JXGPU_GRM_MISS_DIGITS")) == 2);
     // Rows that are affine in the count but hold missing calls, two forms: the SPARSE correction behind the
     // clean int8 Gram (k_grm_miss.hip: nnz n table lookups -- 54 ms + 11.5 ms per 0.1 % of missing calls at n = 20 000,
     // m = 200 000) up to JXGPU_GRM_MISS_DENSE_MIN (0.15 %) of missing calls, the DENSE two-Gram form above it: the missing
@@ -759,6 +772,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                        infob.as<int32_t>());
     JX_LAUNCH_CHECK();
     if (use_miss && (miss2b.alloc((size_t)mk) || wlb.alloc(sizeof(double) * 4 * (size_t)mk))) return 1;
+    if (use_dense && three_digits && lutcb.alloc(sizeof(uint32_t) * (size_t)mk)) return 1;
     if (use_dense && (lutab.alloc(sizeof(uint32_t) * (size_t)mk) || lutbb.alloc(sizeof(uint32_t) * (size_t)mk) ||
                       dfixb.alloc(sizeof(double) * (size_t)mk) || elutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
                       dvecb.alloc(sizeof(double) * (size_t)(ld + 1))))
@@ -768,7 +782,8 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                        lut16.as<uint4>(), ilut2b.as<float>(), beta2b.as<double>(), i8_env, flagb.as<int32_t>(),
                        use_miss ? miss2b.as<uint8_t>() : (uint8_t *)nullptr, use_miss ? wlb.as<double>() : (double *)nullptr,
                        use_dense ? lutab.as<uint32_t>() : (uint32_t *)nullptr, use_dense ? lutbb.as<uint32_t>() : (uint32_t *)nullptr,
-                       use_dense ? dfixb.as<double>() : (double *)nullptr);
+                       use_dense ? dfixb.as<double>() : (double *)nullptr,
+                       (use_dense && three_digits) ? lutcb.as<uint32_t>() : (uint32_t *)nullptr);
     JX_LAUNCH_CHECK();
     int32_t hinfo[4] = {0, 0, 0, 0};
     JX_HIP(hipMemcpyAsync(hinfo, infob.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -874,11 +889,15 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                           panel, tile_row_begin, tile_row_end))
             return 1;
         if (n_exact > n_clean) {
+            const double w_a = 1.0 / 31.0, w_c = three_digits ? 1.0 / 961.0 : 0.0, w_b = 1.0 - w_a - w_c;
             if (launch_grm_i8_lut(st, d_p32, m_total, rows2, lutbb.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld,
-                                  n_clean > 0 ? nullptr : corrb.as<double>(), (30.0 / 31.0) / 3136.0))
+                                  n_clean > 0 ? nullptr : corrb.as<double>(), w_b / 3136.0))
                 return 1;
             if (launch_grm_i8_lut(st, d_p32, m_total, rows2, lutab.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld, nullptr,
-                                  (1.0 / 31.0) / 3136.0))
+                                  w_a / 3136.0))
+                return 1;
+            if (three_digits && launch_grm_i8_lut(st, d_p32, m_total, rows2, lutcb.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld,
+                                                  nullptr, w_c / 3136.0))
                 return 1;
             // the diagonal exactly: sum over the SNPs a sample misses of dfix
             hipLaunchKernelGGL(grm_elut_kernel, dim3((unsigned)((n_exact - n_clean + 255) / 256)), dim3(256), 0, st,

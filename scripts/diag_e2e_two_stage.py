@@ -17,7 +17,8 @@ from oracle import jx_oracle as O, jx_oracle_c as OC  # noqa: E402
 
 OC.build()
 n, m = 5000, 20000
-packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.002)
+MISSING = float(os.environ.get("DIAG_MISSING", "0.002"))
+packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=MISSING)
 y = bed.synth_phenotype(g, n_causal=40, pve=0.5, seed=61)
 del g
 mi, he, ho = O.row_counts(packed, n)
@@ -44,7 +45,7 @@ bxx = np.abs(ref_x[okx, 0] - ref[okx, 0]) / np.maximum(np.abs(ref[okx, 0]), ref[
 out["oracle_f32_syrk_vs_oracle_exact_syrk"] = {"beta_err_quantiles_50_90_99_999_max": [float(v) for v in np.quantile(bxx, [0.5, 0.9, 0.99, 0.999, 1.0])],
                                                "grm_max_rel": float(np.max(np.abs(k_x.astype(np.float64) - k_ref) / np.maximum(np.abs(k_ref), np.mean(np.diag(k_ref))))),
                                                "lbd": [nm.lbd_null, nm_x.lbd_null]}
-for planes in (5, 6):
+for planes in (5,):
     k32, geff, panel = pipeline.build_grm(pk, n, 1, 0.02, 0.05)
     s_d, ut64 = pipeline.eigh_from_grm(k32, 1e-6, f32_consumer=(planes == 5))
     model = pipeline.SpectralModel(s_d, ut64, np.ones((n, 1)), y)
@@ -79,6 +80,11 @@ for planes in (5, 6):
                                    "beta_err_max_same_evals": float(be2[same2].max()),
                                    "n_above_1e-5": int((be2 > 1e-5).sum())}}
     del ut64, model, m2
+tag = os.environ.get("DIAG_TAG", "default")
 print(json.dumps(out, indent=1))
+v = out["planes5"]
+print(f"SUMMARY {tag}: missing={MISSING} beta e2e max {v['beta_err_quantiles_50_90_99_999_max'][-1]:.3e} (p99 {v['beta_err_quantiles_50_90_99_999_max'][2]:.3e}) "
+      f"GRM gpu vs f32-syrk oracle {v['grm_gpu_vs_f32_syrk_oracle']:.3e} vs exact {v['grm_gpu_vs_exact_syrk_oracle']:.3e}; "
+      f"oracle f32 vs exact syrk: beta {out['oracle_f32_syrk_vs_oracle_exact_syrk']['beta_err_quantiles_50_90_99_999_max'][-1]:.3e}")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "diag_e2e_two_stage.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"diag_e2e_two_stage_{tag}.json"), "w"), indent=1)

@@ -66,8 +66,13 @@ def _parity():
     return P
 
 
-def test_end_to_end_two_stage(oracle, oracle_c):
-    """A TRUE end-to-end leg above the two-stage threshold: n = 5000, m = 20 000 through `pipeline.run_gwas` (GRM on the int8
+@pytest.mark.parametrize("missing", [0.002, 0.01])
+def test_end_to_end_two_stage(oracle, oracle_c, missing):
+    """Both missing-call rates put every SNP on the dense missing-call form of the GRM (csrc/k_grm.hip: the missing call's count in
+    int8 digits).  With TWO digits (rounds 4 - 5) this leg measured beta off by 1.7e-5 at 0.2 % and 1.3e-4 at 1 % missing calls --
+    an entry error of 1.3e-6 / 3.2e-6 in K, inside the GRM bar, amplified by the eigendecomposition (scripts/diag_e2e_two_stage.py;
+    the full-size legs hand the GPU's own spectrum to the oracle and cannot see it) -- hence the third digit.
+    A TRUE end-to-end leg above the two-stage threshold: n = 5000, m = 20 000 through `pipeline.run_gwas` (GRM on the int8
     pipes, the own two-stage eigensolver with Q1 and the divide-and-conquer merges on 5 digit planes -- sliced products engage
     from n = 3000 -- f32 U^T, null, exact-scan / fixed-lambda scan) against an oracle that builds its OWN GRM (f32 SYRK + f64
     merge), its OWN dsyevd, null fit, f32 rotation and scan (as `test_pipeline_end_to_end` does at n = 400, below every sliced
@@ -77,7 +82,7 @@ def test_end_to_end_two_stage(oracle, oracle_c):
     from janusx_amd import pipeline
     P = _parity()
     n, m = 5000, 20000
-    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=0.002)
+    packed, g = bed.synth_panel_numpy(n, m, seed=61, missing_rate=missing)
     y = bed.synth_phenotype(g, n_causal=40, pve=0.5, seed=61)
     del g
     mi, he, ho = oracle.row_counts(packed, n)

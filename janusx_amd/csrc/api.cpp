@@ -206,22 +206,24 @@ static int stage_p32(const uint8_t *packed, int64_t m, int n_samples, const Samp
         fprintf(stderr, "[jxgpu stage_p32] %-20s %8.1f ms\n", what,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     };
+    // every allocation of the staging BEFORE the first copy or launch: a hipMalloc behind work in flight (or right behind a large
+    // hipFree) has been measured at hundreds of milliseconds to seconds on this stack, with the device idle 0.3 ms
     DevBuf raw, didx;
+    if (!on_device && raw.alloc((size_t)(m * bps))) return 1;
+    if (!sel.identity && didx.alloc(sizeof(int32_t) * sel.idx.size())) return 1;
+    if (p32.alloc((size_t)nt * (size_t)m * 32)) return 1;
+    mark("hipMalloc raw / idx / p32");
     const uint8_t *d_raw = packed;
     if (!on_device) {
-        if (raw.alloc((size_t)(m * bps))) return 1;
         JX_HIP(hipMemcpy(raw.p, packed, (size_t)(m * bps), hipMemcpyHostToDevice));
         d_raw = raw.as<uint8_t>();
     }
     const int32_t *d_idx = nullptr;
     if (!sel.identity) {
-        if (didx.alloc(sizeof(int32_t) * sel.idx.size())) return 1;
         JX_HIP(hipMemcpy(didx.p, sel.idx.data(), sizeof(int32_t) * sel.idx.size(), hipMemcpyHostToDevice));
         d_idx = didx.as<int32_t>();
     }
-    mark("index upload");
-    if (p32.alloc((size_t)nt * (size_t)m * 32)) return 1;
-    mark("hipMalloc p32");
+    mark("uploads");
     if (jxg_repack_p32(d_raw, bps, n_samples, m, d_idx, sel.n, nullptr, m, p32.as<uint8_t>(), nullptr))
         return 1;
     JX_HIP(hipDeviceSynchronize());

@@ -461,3 +461,21 @@ def test_warm_chain_offsets_host_rules():
     assert st.warm_chain_offsets(st.warm_chain_blocks_bed(np.array([17, 18]), 20, 5), 2).tolist() == [0, 2]   # empty chunks vanish
     with pytest.raises(RuntimeError):
         st.warm_chain_offsets([0], 10, 3)
+
+
+def test_every_environment_switch_is_classified():
+    """`janusx_amd/switches.py` names every `JXGPU_*` switch of the sources with its class (numerics / knob / form / trace /
+    test), the product value and the test that covers it: a new switch cannot appear without saying whether it is a product state."""
+    import glob
+    from janusx_amd import switches
+    found = set()
+    for f in glob.glob(os.path.join(ROOT, "janusx_amd", "**", "*"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        if f.endswith((".py", ".hip", ".cpp", ".h")) and not f.endswith("switches.py"):
+            found |= set(re.findall(r"JXGPU_[A-Z0-9_]+", open(f, errors="replace").read()))
+    missing = sorted(found - set(switches.SWITCHES))
+    stale = sorted(set(switches.SWITCHES) - found)
+    assert not missing, f"unclassified switches: {missing}"
+    assert not stale, f"switches.py lists names no source uses: {stale}"
+    for name, (cls, default, what, test) in switches.SWITCHES.items():
+        assert cls in ("numerics", "knob", "form", "trace", "test") and default and what and test, name
+    assert "JXGPU_OZ_PLANES" in switches.markdown_table()

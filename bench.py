@@ -464,7 +464,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    def run_leg(n, m_arg, missing, steps, warmup, covariates=0, mode=None):
+    def run_leg(n, m_arg, missing, steps, warmup, covariates=0, mode=None, chain=None):
         """One timed configuration: synthetic panel resident in HBM, `warmup` untimed + `steps` timed passes of the whole
         hot path.  -> dict(elapsed, kept_total, kern, stage, null, packed, y, x, eigh_sharded, m)."""
         # replicated eigendecomposition: from 16384 individuals on, the symv tiles of the tridiagonalisation are dealt over
@@ -526,8 +526,15 @@ def main():
             rows = np.nonzero(keep)[0]
             lut = st.scan_lut_from_counts(af[rows], np.zeros(len(rows), dtype=bool), counts[rows], n)
             tm = pl.StageTimes()
+            chain_off, init = None, None
+            if chain is not None and mode == "lmm":
+                # the reference CLI's default scan: warm-start chains over chunks of `chain[0]` rows of the file, cut into
+                # `chain[1]` pieces, seeded with log10 lambda0 (workflow_model_stream.py:1436-1480; src/stats/lmm.rs:134-161)
+                chain_off = st.warm_chain_offsets(st.warm_chain_blocks_bed(rows, panel.m, chain[0]), len(rows), chain[1])
+                lo_b, hi_b = model.null.bounds
+                init = min(max(math.log10(model.null.lbd), lo_b), hi_b) if model.null.lbd > 0 else None
             out = pl.scan_rows(panel, model, rows, lut, mode, max_iter=30, tol=1e-2, times=tm,
-                               return_evals=(mode == "lmm"))
+                               return_evals=(mode == "lmm"), chain_off=chain_off, init_log10_lbd=init)
             if mode == "lmm":
                 out, evals = out
                 n_evals = float(evals.sum().item())   # Brent objective evaluations over all SNPs of the step
@@ -1046,6 +1053,24 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 res["extra_c3_cov5"] = {"error": repr(e)}
+            try:
+                # the same shape with the reference's DEFAULT exact scan: warm-start chains (`jx gwas -lmm` without
+                # JX_LMM_UNIFIED_NO_WARM_START): chunks of 10 000 rows of the file = 20 sequential chains, and cut into 64 pieces
+                # each (what rayon's splitter does on a 32-thread pool) = 1280 chains
+                res["extra_c3_chain"] = {}
+                for tag, ch in (("chunk10000", (10000, 1)), ("chunk10000_pieces64", (10000, 64))):
+                    leg = run_leg(20000, 200000, 0.0, 2, 1, chain=ch)
+                    sm = leg_summary(leg, 20000, 2)
+                    res["extra_c3_chain"][tag] = {k: sm[k] for k in ("value", "unit", "steps", "ms_per_step", "m_kept")}
+                    res["extra_c3_chain"][tag]["assoc_k_ms"] = sm["stages_ms_per_step"].get("assoc_k")
+                    res["extra_c3_chain"][tag]["brent_evals_per_snp"] = leg["kern"].get("scan_evals", 0.0) / max(1, leg["kern"]["launches"])
+                    del leg
+                    torch.cuda.empty_cache()
+                res["extra_c3_chain"].update(res["extra_c3_chain"]["chunk10000"])
+                res["extra_c3_chain"]["note"] = ("configs[2] shape, -lmm with the reference's default warm-start chain (one wave per "
+                                                 "chain on the per-SNP series; the headline runs every SNP from the same start)")
+            except Exception as e:
+                res["extra_c3_chain"] = {"error": repr(e)}
             try:
                 leg = run_leg(50000, 500000, 0.0, 3, 1)
                 sm = leg_summary(leg, 50000, 3)

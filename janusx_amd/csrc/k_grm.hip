@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ flag, uint8_t *__restrict__ miss2,
                                                          double *__restrict__ wl, uint32_t *__restrict__ lut_a,
                                                          uint32_t *__restrict__ lut_b, double *__restrict__ dfix,
-                                                         uint32_t *__restrict__ lut_c) {
+                                                         uint32_t *__restrict__ lut_c, uint32_t *__restrict__ lut_f) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= mk) return;
     const int32_t nex = info[0] & ~63;
@@ -486,11 +486,15 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
     // beta of a whole run by 1.7e-5 (scripts/diag_e2e_two_stage.py).  Hence a THIRD digit (lut_c != nullptr, the default):
     // 56 c~ ~ P1 + P2 / 31 + P3 / 961, P3 = rint(31 (31 (56 c* - P1) - P2)) in [-15, 15], byte LUT C = (0, P1 + P3, 56, 112),
     //   c~ c~' ~ ((1 - 1/31 - 1/961) B B' + (1/31) A A' + (1/961) C C') / 3136
-    // -- one more int8 Gram over the rows with missing calls, the resolution 31 x finer (5.4e-6 rms per missing call), the
-    // dropped terms still products of two low digits where BOTH samples miss the SNP.
+    // -- the resolution 31 x finer (5.4e-6 rms per missing call).  That alone left the LARGEST entry error where it was: the
+    // dropped product of two P2 -- both samples missing at the SNP, 2.3e-3 count^2 per coincidence, a dozen coincidences on the
+    // worst of 12 million pairs.  It is an exact Gram too: F = P2 e (byte LUT (0, P2, 0, 0)) and
+    //   + (1/961 - 1/31) F F'
+    // turns the P2 P2' / 31 that A A' brings into the P2 P2' / 961 of the exact product.  Four int8 Grams over the rows with
+    // missing calls; what is still dropped are products with a P3 (31 x smaller per coincidence).
     double cstar = 0.0;
     if (lut_a) {
-        uint32_t la = 0u, lb = 0u, lc = 0u;
+        uint32_t la = 0u, lb = 0u, lc = 0u, lf = 0u;
         double fix = 0.0;
         if (exact) {
             la = lb = lc = (56u << 16) | (112u << 24);
@@ -507,13 +511,17 @@ __global__ __launch_bounds__(256) void grm_gather_kernel(const int32_t *__restri
                 lb |= ((uint32_t)(int)p1 & 0xffu) << 8;
                 la |= ((uint32_t)(int)(p1 + p2) & 0xffu) << 8;
                 lc |= ((uint32_t)(int)(p1 + p3) & 0xffu) << 8;
+                lf = ((uint32_t)(int)p2 & 0xffu) << 8;
                 const double wa = 1.0 / 31.0, wc = lut_c ? 1.0 / 961.0 : 0.0, wb = 1.0 - wa - wc;
-                fix = cstar * cstar - (wb * p1 * p1 + wa * (p1 + p2) * (p1 + p2) + wc * (p1 + p3) * (p1 + p3)) / 3136.0;
+                const double wf = lut_f ? 1.0 / 961.0 - 1.0 / 31.0 : 0.0;
+                fix = cstar * cstar -
+                      (wb * p1 * p1 + wa * (p1 + p2) * (p1 + p2) + wc * (p1 + p3) * (p1 + p3) + wf * p2 * p2) / 3136.0;
             }
         }
         lut_a[dst] = la;
         lut_b[dst] = lb;
         if (lut_c) lut_c[dst] = lc;
+        if (lut_f) lut_f[dst] = lf;
         dfix[dst] = fix;
     }
     if (miss2) {
@@ -709,8 +717,9 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
     // with the number of missing calls (nnz n table lookups), the split kernel's does not; measured at n = 20000,
     // m = 200000: 54 ms + 11.5 ms per 0.1 % against 229 ms, i.e. a crossover at ~1.5 %
     const double miss_max = getenv("JXGPU_GRM_MISS_MAX") ? atof(getenv("JXGPU_GRM_MISS_MAX")) : 0.012;
-    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb, lutab, lutbb, lutcb, dfixb, elutb, dvecb;
-    // digits of the missing call's count in the dense form: 3 (default; see grm_gather_kernel), JXGPU_GRM_MISS_DIGITS=2: rounds 4 - 5
+    DevBuf lut16, flagb, betab, ilutb, posb, infob, rows2b, ilut2b, beta2b, corrb, miss2b, wlb, misstotb, lutab, lutbb, lutcb, lutfb, dfixb, elutb, dvecb;
+    // digits of the missing call's count in the dense form: 3 + the exact product of two second digits (default; see
+    // grm_gather_kernel), JXGPU_GRM_MISS_DIGITS=2: the two-Gram form of rounds 4 - 5
     const bool three_digits = !(getenv("JXGPU_GRM_MISS_DIGITS") && atoi(getenv("JXGPU_GRM_MISS_DIGITS")) == 2);
     // Rows that are affine in the count but hold missing calls, two forms: the SPARSE correction behind the
     // clean int8 Gram (k_grm_miss.hip: nnz n table lookups -- 54 ms + 11.5 ms per 0.1 % of missing calls at n = 20 000,
@@ -772,7 +781,7 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                        infob.as<int32_t>());
     JX_LAUNCH_CHECK();
     if (use_miss && (miss2b.alloc((size_t)mk) || wlb.alloc(sizeof(double) * 4 * (size_t)mk))) return 1;
-    if (use_dense && three_digits && lutcb.alloc(sizeof(uint32_t) * (size_t)mk)) return 1;
+    if (use_dense && three_digits && (lutcb.alloc(sizeof(uint32_t) * (size_t)mk) || lutfb.alloc(sizeof(uint32_t) * (size_t)mk))) return 1;
     if (use_dense && (lutab.alloc(sizeof(uint32_t) * (size_t)mk) || lutbb.alloc(sizeof(uint32_t) * (size_t)mk) ||
                       dfixb.alloc(sizeof(double) * (size_t)mk) || elutb.alloc(sizeof(float) * 4 * (size_t)mk) ||
                       dvecb.alloc(sizeof(double) * (size_t)(ld + 1))))
@@ -783,7 +792,8 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                        use_miss ? miss2b.as<uint8_t>() : (uint8_t *)nullptr, use_miss ? wlb.as<double>() : (double *)nullptr,
                        use_dense ? lutab.as<uint32_t>() : (uint32_t *)nullptr, use_dense ? lutbb.as<uint32_t>() : (uint32_t *)nullptr,
                        use_dense ? dfixb.as<double>() : (double *)nullptr,
-                       (use_dense && three_digits) ? lutcb.as<uint32_t>() : (uint32_t *)nullptr);
+                       (use_dense && three_digits) ? lutcb.as<uint32_t>() : (uint32_t *)nullptr,
+                       (use_dense && three_digits) ? lutfb.as<uint32_t>() : (uint32_t *)nullptr);
     JX_LAUNCH_CHECK();
     int32_t hinfo[4] = {0, 0, 0, 0};
     JX_HIP(hipMemcpyAsync(hinfo, infob.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -898,6 +908,10 @@ extern "C" int jxg_grm_accumulate_rows(const uint8_t *d_p32, int64_t m_total, in
                 return 1;
             if (three_digits && launch_grm_i8_lut(st, d_p32, m_total, rows2, lutcb.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld,
                                                   nullptr, w_c / 3136.0))
+                return 1;
+            // the product of two second digits exactly: F = P2 e, weight 1/961 - 1/31 (see grm_gather_kernel)
+            if (three_digits && launch_grm_i8_lut(st, d_p32, m_total, rows2, lutfb.as<uint32_t>(), n_clean, n_exact, nt, d_acc, ld,
+                                                  nullptr, (1.0 / 961.0 - 1.0 / 31.0) / 3136.0))
                 return 1;
             // the diagonal exactly: sum over the SNPs a sample misses of dfix
             hipLaunchKernelGGL(grm_elut_kernel, dim3((unsigned)((n_exact - n_clean + 255) / 256)), dim3(256), 0, st,

@@ -99,5 +99,6 @@ def markdown_table(classes=("numerics",)):
     rows = ["| switch | product value | what another value does | covered by |", "|---|---|---|---|"]
     for name, (cls, default, what, test) in sorted(SWITCHES.items()):
         if cls in classes:
-            rows.append(f"| `{name}` | {default} | {what} | {test} |")
+            cell = lambda t: str(t).replace(" | ", " / ").replace("|", "/")      # noqa: E731
+            rows.append(f"| `{name}` | {cell(default)} | {cell(what)} | {cell(test)} |")
     return "\n".join(rows)

@@ -655,6 +655,22 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const double smin = smin_ptr[0];
+    // CHAINLDS (the one-wave-per-chain series instantiation): a chain is a SEQUENTIAL job, so what counts is the latency of one
+    // evaluation, not the throughput of many -- with the coefficients read from global memory an evaluation took 4.5 us (two
+    // dependent 32-term recurrences, each waiting for its loads four times; measured round 6: 742 ms for 20 chains of 10 000
+    // SNPs at BASELINE configs[2]).  Here the lambda-only tables are staged in LDS once per workgroup and the series of the
+    // NEXT SNP is fetched into registers while the current one is searched (two LDS buffers), so an evaluation reads LDS only.
+    constexpr bool CHAINLDS = SERIES && NW == 1;
+    constexpr int NPRE = MAXD + 1;                     // (p + 2) <= MAXD + 1 series of SR_M = 64 entries: one entry per lane each
+    [[maybe_unused]] double *l_coef = scan_lds, *l_sc = scan_lds;
+    [[maybe_unused]] double pre[NPRE];
+    if (CHAINLDS) {
+        const int ncoef = hd.nseg * hd.nf * CH_N;
+        for (int i = lane; i < ncoef; i += 64) l_coef[i] = coef[i];
+        l_sc = l_coef + ((ncoef + 1) & ~1);
+        __syncthreads();
+        coef = l_coef;
+    }
     // chain_off: the reference's warm-start chain (carry_warm_start, src/stats/lmm.rs:134-161): this wave walks the rows
     // [chain_off[c], chain_off[c + 1]) in order and every SNP's Brent starts from the optimum of the valid row before it; carry[c]
     // is the state the chain starts from (NaN: none) and receives the state it ends with (a chain may continue in a later launch).
@@ -664,9 +680,29 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
       const int r_beg = chain_off ? chain_off[unit] : unit, r_end = chain_off ? chain_off[unit + 1] : unit + 1;
       double last = chain_off ? carry[unit] : init;
       bool have_last = chain_off ? isfinite(last) : (warm != 0);
+      if (CHAINLDS && r_beg < r_end) {
+#pragma unroll
+          for (int k = 0; k < NPRE; ++k)
+              if (k < p + 2) pre[k] = snp_coef[(int64_t)r_beg * (p + 2) * SR_M + k * SR_M + lane];
+      }
       for (int r = r_beg; r < r_end; ++r) {
         const float *g = SERIES ? nullptr : grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
+        [[maybe_unused]] double *sc_lds = nullptr;
+        if (CHAINLDS) {
+            // this row's series: registers -> LDS buffer (r & 1); then the next row's series on its way into the registers
+            sc_lds = l_sc + (size_t)(r & 1) * NPRE * SR_M;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k)
+                if (k < p + 2) sc_lds[k * SR_M + lane] = pre[k];
+            __syncthreads();
+            if (r + 1 < r_end) {
+#pragma unroll
+                for (int k = 0; k < NPRE; ++k)
+                    if (k < p + 2) pre[k] = snp_coef[(int64_t)(r + 1) * (p + 2) * SR_M + k * SR_M + lane];
+            }
+        }
         double ssq = 0.0;
         if (SERIES) {
             ssq = snp_ssq[r];
@@ -678,7 +714,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             ssq = wave_allsum(ssq);
         }
         // one evaluation of the Brent objective (and of final_beta_se) for this wave's SNP
-        const double *sc = SERIES ? snp_coef + (int64_t)r * (p + 2) * SR_M : nullptr;
+        const double *sc = CHAINLDS ? sc_lds : (SERIES ? snp_coef + (int64_t)r * (p + 2) * SR_M : nullptr);
         auto eval_at = [&](double xx, bool want_ainv, FastEval<MAXD> &res, const double *bmid) {
             if (!SERIES) {
                 fast_eval<MAXD>(xx, hd, coef, smin, s, xcov, yc, g, n, p, want_ainv, res, bmid);
@@ -1563,10 +1599,30 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
     // chains: ONE wave per workgroup -- a chain is a long sequential job and there are few of them (m / 512): spread over the
     // CUs they do not share a SIMD's issue slots
     const int grid = chain ? nunits : (nunits + NW - 1) / NW;
+    // LDS of the chain instantiation: the lambda-only coefficient tables + two buffers of one SNP's series (MAXD + 1 rows of 64)
+    const int maxd_use = dim <= 2 ? 2 : (dim <= 4 ? 4 : (dim <= 8 ? 8 : 16));
+    const size_t chain_lds = sizeof(double) * ((((size_t)hd.nseg * hd.nf * CH_N + 1) & ~(size_t)1) + 2 * (size_t)(maxd_use + 1) * SR_M);
+    if (chain && chain_lds > 160 * 1024) return fail("jxg_lmm_series_brent_tab: the chain form's tables do not fit LDS");
+    if (chain && chain_lds > 64 * 1024) {
+#define JX_CHAIN_ATTR(MAXDV)                                                                                              \
+    do {                                                                                                                  \
+        static bool attr_c = false;                                                                                       \
+        if (!attr_c) {                                                                                                    \
+            JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<MAXDV, 1, false, true>,                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                          \
+            attr_c = true;                                                                                                \
+        }                                                                                                                 \
+    } while (0)
+        if (dim <= 2) JX_CHAIN_ATTR(2);
+        else if (dim <= 4) JX_CHAIN_ATTR(4);
+        else if (dim <= 8) JX_CHAIN_ATTR(8);
+        else JX_CHAIN_ATTR(16);
+#undef JX_CHAIN_ATTR
+    }
 #define JX_SERIES_BRENT(MAXDV)                                                                                             \
     do {                                                                                                                  \
         if (chain)                                                                                                        \
-            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, 1, false, true>), dim3(grid), dim3(64), 0, st, d_grot, nrows, n, d_s, \
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, 1, false, true>), dim3(grid), dim3(64), chain_lds, st, d_grot, nrows, n, d_s, \
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml,  \
                                d_out, d_evals, scoef, sssq, shd, chain_off, nchains, carry);                                      \
         else                                                                                                              \

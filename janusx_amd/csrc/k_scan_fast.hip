@@ -66,6 +66,14 @@ __device__ __forceinline__ double fast_rcp(double v) {
     return r;
 }
 
+// Value of lane `src` (WAVE-UNIFORM index) in every lane: two v_readlane_b32 through SGPRs instead of a ds_bpermute round trip
+// per dword -- an evaluation of the tabulated form reads a dozen such values, each on its critical path.
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // y_c = y - X beta_mid, beta_mid = GLS fit of the null model at lambda_mid (single workgroup).
 template <int MAXD>
 __global__ __launch_bounds__(SCAN_THREADS) void yshift_kernel(const double *__restrict__ s,
@@ -392,7 +400,8 @@ __device__ __forceinline__ void fast_eval_accumulate_batched(double lbd, const d
     }
 }
 
-template <int MAXD>
+// PRESUMMED: acc already holds the wave-wide values in every lane (the series form: a broadcast, not a sum)
+template <int MAXD, bool PRESUMMED = false>
 __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
                                                  bool want_ainv, const double *__restrict__ bmid, double (&acc)[MAXD + 1],
                                                  FastEval<MAXD> &o);
@@ -425,14 +434,16 @@ __device__ __forceinline__ void fast_eval(double x, const ChebHeader hd, const d
 // Block form of the second half (see ChebHeader): two triangular solves with the tabulated factor, no dim x dim matrix in
 // registers.  The tabulated values live one per lane (function f in lane f % 64, slot f / 64) and are read with a uniform
 // source lane; every lane carries the same w / z (wave-uniform arithmetic).
-template <int MAXD>
+template <int MAXD, bool PRESUMMED = false>
 __device__ __forceinline__ void fast_eval_finish_blk(double x, const ChebHeader hd, const double *__restrict__ coef, int n,
                                                      int p, bool want_ainv, const double *__restrict__ bmid,
                                                      double (&acc)[MAXD + 1], FastEval<MAXD> &o) {
     const int dim = p + 1;
     const int lane = threadIdx.x & 63;
+    if (!PRESUMMED) {
 #pragma unroll
-    for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+        for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+    }
     int seg = (int)((x - hd.low) / hd.segw);
     if (seg < 0) seg = 0;
     if (seg >= hd.nseg) seg = hd.nseg - 1;
@@ -449,7 +460,7 @@ __device__ __forceinline__ void fast_eval_finish_blk(double x, const ChebHeader 
         double r = 0.0;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-            const double v = __shfl(mv[sl], f & 63, 64);
+            const double v = wave_bcast(mv[sl], f & 63);
             if ((f >> 6) == sl) r = v;
         }
         return r;
@@ -511,18 +522,20 @@ __device__ __forceinline__ void fast_eval_finish_blk(double x, const ChebHeader 
     }
 }
 
-template <int MAXD>
+template <int MAXD, bool PRESUMMED>
 __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, const double *__restrict__ coef, int n, int p,
                                                  bool want_ainv, const double *__restrict__ bmid, double (&acc)[MAXD + 1],
                                                  FastEval<MAXD> &o) {
     if constexpr (MAXD >= 8) {                            // dim >= 5: block form (the tables were built for it: cheb_blk)
-        fast_eval_finish_blk<MAXD>(x, hd, coef, n, p, want_ainv, bmid, acc, o);
+        fast_eval_finish_blk<MAXD, PRESUMMED>(x, hd, coef, n, p, want_ainv, bmid, acc, o);
         return;
     }
     const int dim = p + 1;
     const int lane = threadIdx.x & 63;
+    if (!PRESUMMED) {
 #pragma unroll
-    for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+        for (int k = 0; k < MAXD + 1; ++k) acc[k] = wave_allsum(acc[k]);
+    }
 
     // ---- lambda-only sums from the Chebyshev tables ---------------------------------------------------
     int seg = (int)((x - hd.low) / hd.segw);
@@ -533,7 +546,7 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
     // lane f evaluates tabulated function f (nf <= 64 is guaranteed by the host wrapper), results are then
     // read across lanes: one 32-term Clenshaw per evaluation instead of nf of them.
     const double myval = clenshaw(cf + (lane < hd.nf ? lane : 0) * CH_N, t);
-    const double logdetv = __shfl(myval, 0, 64);
+    const double logdetv = wave_bcast(myval, 0);
     double a0[MAXD * MAXD], a[MAXD * MAXD], b[MAXD], beta[MAXD];
 #pragma unroll
     for (int k = 0; k < MAXD * MAXD; ++k) a0[k] = 0.0;
@@ -541,7 +554,7 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
     for (int r = 0; r < MAXD - 1; ++r)
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-            const double val = __shfl(myval, 1 + r * (r + 1) / 2 + c, 64);
+            const double val = wave_bcast(myval, 1 + r * (r + 1) / 2 + c);
             if (r < p) {
                 a0[r * MAXD + c] = val;
                 a0[c * MAXD + r] = val;
@@ -552,10 +565,10 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
     for (int r = 0; r < MAXD; ++r) b[r] = 0.0;
 #pragma unroll
     for (int r = 0; r < MAXD - 1; ++r) {
-        const double val = __shfl(myval, fb + r, 64);
+        const double val = wave_bcast(myval, fb + r);
         if (r < p) b[r] = val;
     }
-    const double yy = __shfl(myval, fb + p, 64);
+    const double yy = wave_bcast(myval, fb + p);
     // SNP row/column at index p (compile-time positions via select)
 #pragma unroll
     for (int r = 0; r < MAXD; ++r) {
@@ -729,7 +742,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             if (fast_eval_lambda(xx, smin, n, p + 1) < 0.0) return;
             double acc[MAXD + 1];
             series_eval_sums<MAXD>(xx, shd, sc, p, acc);
-            fast_eval_finish<MAXD>(xx, hd, coef, n, p, want_ainv, bmid, acc, res);
+            fast_eval_finish<MAXD, true>(xx, hd, coef, n, p, want_ainv, bmid, acc, res);
         };
         if (!isfinite(ssq) || ssq <= 1e-12) {
             if (lane == 0) {
@@ -1054,13 +1067,14 @@ __device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, 
     const double t = (x - (hd.low + hd.segw * ((double)seg + 0.5))) / (0.5 * hd.segw);
     const int q = lane < p + 2 ? lane : 0;
     const double val = clenshaw(sc + q * SR_M + seg * CH_N, t);
+    // every lane gets all p + 2 values (lane q holds quantity q): readlane broadcasts, no butterfly sum behind them
 #pragma unroll
     for (int k = 0; k < MAXD + 1; ++k) acc[k] = 0.0;
 #pragma unroll
     for (int r = 0; r < MAXD - 1; ++r)
-        if (r < p && lane == r) acc[r] = val;
-    if (lane == p) acc[MAXD - 1] = val;
-    if (lane == p + 1) acc[MAXD] = val;
+        if (r < p) acc[r] = wave_bcast(val, r);
+    acc[MAXD - 1] = wave_bcast(val, p);
+    acc[MAXD] = wave_bcast(val, p + 1);
 }
 
 // ---- tiled form for n beyond the LDS-resident limit --------------------------------------------------------------------

@@ -631,6 +631,100 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
     }
 }
 
+// ---- Brent on an interpolant of the objective (round 6) -----------------------------------------------------------------
+// An evaluation of the tabulated form is ~1300 dependent instructions of wave-UNIFORM arithmetic (35 f64 divisions, four log /
+// pow calls, two 32-term recurrences): every lane computes the same number, and a wave issues them one behind the other -- 4 us
+// per evaluation when nothing else hides it (the chain scan: measured 663 ms for 20 chains of 10 000 SNPs at configs[2]).  The
+// objective -REML(x; g) of one SNP is as analytic in x as the sums it is made of, so: evaluate it ONCE at the 32 Chebyshev nodes
+// of each width-2 segment with ONE LANE PER NODE (the same instructions, 64 different x), turn the 64 values into the
+// Chebyshev coefficients of the objective (a 32-point cosine transform per segment through LDS) and let Brent run on that series:
+// an evaluation is then one Clenshaw recurrence.  Measured on the host (oracle, 60 SNPs, both segments): the interpolant
+// reproduces the objective to 3.7e-15 relative -- below the rounding noise of a direct evaluation.  beta / SE at the optimum
+// still come from ONE direct evaluation (final_beta_se).  A node that fails (no positive pivot, lambda outside the table) sends
+// the SNP back to direct evaluations.
+template <int MAXD>
+struct InterpTv {
+    static constexpr int N = 1 + (MAXD - 1) * MAXD / 2 + (MAXD - 1) + 1;     // table functions of the plain form at p = MAXD - 1
+};
+template <int N>
+__device__ __forceinline__ double pick_n(const double (&v)[N], int idx) {
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (k == idx) r = v[k];
+    return r;
+}
+// -REML at x from per-lane values: tv[f] = tabulated function f at x (lambda-only sums), acc = the SNP-specific sums at x.
+// The arithmetic of fast_eval_finish's plain form, on values that differ from lane to lane.
+template <int MAXD>
+__device__ __forceinline__ double plain_objective(int n, int p, const double (&tv)[InterpTv<MAXD>::N], const double (&acc)[MAXD + 1]) {
+    const int dim = p + 1;
+    const double logdetv = tv[0];
+    double a0[MAXD * MAXD], a[MAXD * MAXD], b[MAXD], beta[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD * MAXD; ++k) a0[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD - 1; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c)
+            if (r < p) {
+                a0[r * MAXD + c] = tv[1 + r * (r + 1) / 2 + c];
+                a0[c * MAXD + r] = tv[1 + r * (r + 1) / 2 + c];
+            }
+    const int fb = 1 + p * (p + 1) / 2;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) b[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD - 1; ++r)
+        if (r < p) b[r] = pick_n(tv, fb + r);
+    const double yy = pick_n(tv, fb + p);
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) {
+#pragma unroll
+        for (int c = 0; c < MAXD; ++c) {
+            if (r == p && c < p) a0[r * MAXD + c] = acc[c < MAXD - 1 ? c : 0];
+            if (c == p && r < p) a0[r * MAXD + c] = acc[r < MAXD - 1 ? r : 0];
+            if (r == p && c == p) a0[r * MAXD + c] = acc[MAXD - 1];
+        }
+        if (r == p) b[r] = acc[MAXD];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXD * MAXD; ++k) a[k] = a0[k];
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) a[r * MAXD + r] += 1e-6;
+    if (!chol_inplace<MAXD>(a, dim)) return 1e8;
+    chol_solve<MAXD>(a, dim, b, beta);
+    double bb = 0.0, bab = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r) {
+        if (r < dim) {
+            bb += beta[r] * b[r];
+            double row = 0.0;
+#pragma unroll
+            for (int c = 0; c < MAXD; ++c)
+                if (c < dim) row += a0[r * MAXD + c] * beta[c];
+            bab += beta[r] * row;
+        }
+    }
+    const double q = yy - 2.0 * bb + bab;
+    double ld = 0.0;
+#pragma unroll
+    for (int r = 0; r < MAXD; ++r)
+        if (r < dim) ld += jx_log(a[r * MAXD + r]);
+    const double nf = (double)n, pf = (double)dim;
+    const double total = (nf - pf) * jx_log(q) + logdetv + 2.0 * ld;
+    const double cst = (nf - pf) * (jx_log(nf - pf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0;
+    const double reml = cst - 0.5 * total;
+    return isfinite(reml) ? -reml : 1e8;
+}
+// memory operations of one wave on its own LDS region: writes by some lanes, reads by others, no other wave involved
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+constexpr int IP_CP = CH_N + 1;     // pitch of the cosine table rows (doubles): column reads of 32 lanes on distinct banks
+
 // NW waves per workgroup.  LDS = true: the three vectors every evaluation of every SNP streams -- s, X~ (n x p) and the
 // shifted y~, 8 n (2 + p) bytes -- are copied into LDS once per workgroup and shared by its NW waves.  Without it each
 // evaluation re-reads them through L2 (they do not fit the 32 KB L1): measured 7.7 TB/s of L1<-L2 traffic and waves
@@ -641,7 +735,7 @@ __device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, 
 
 // SERIES: the SNP-specific sums come from the SNP's own Chebyshev series (series_coef_kernel: `snp_coef`, `snp_ssq`) instead of
 // a pass over the rotated row -- `grot` is not read.
-template <int MAXD, int NW, bool LDS, bool SERIES = false>
+template <int MAXD, int NW, bool LDS, bool SERIES = false, bool INTERP = false>
 __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void lmm_scan_fast_kernel(
     const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
@@ -673,14 +767,29 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     // dependent 32-term recurrences, each waiting for its loads four times; measured round 6: 742 ms for 20 chains of 10 000
     // SNPs at BASELINE configs[2]).  Here the lambda-only tables are staged in LDS once per workgroup and the series of the
     // NEXT SNP is fetched into registers while the current one is searched (two LDS buffers), so an evaluation reads LDS only.
-    constexpr bool CHAINLDS = SERIES && NW == 1;
+    // INTERP (with SERIES, plain form): Brent on an interpolant of the objective, see plain_objective above.
+    constexpr bool CHAINLDS = SERIES && (NW == 1 || INTERP);
     constexpr int NPRE = MAXD + 1;                     // (p + 2) <= MAXD + 1 series of SR_M = 64 entries: one entry per lane each
-    [[maybe_unused]] double *l_coef = scan_lds, *l_sc = scan_lds;
+    [[maybe_unused]] double *l_coef = scan_lds, *l_sc = scan_lds, *l_cos = scan_lds, *l_fv = scan_lds;
     [[maybe_unused]] double pre[NPRE];
     if (CHAINLDS) {
+        // LDS: [cosine table CH_N x IP_CP (INTERP)] [lambda-only coefficient tables] then per wave [two series buffers] [64 node
+        // values / 64 coefficients (INTERP)]
         const int ncoef = hd.nseg * hd.nf * CH_N;
-        for (int i = lane; i < ncoef; i += 64) l_coef[i] = coef[i];
-        l_sc = l_coef + ((ncoef + 1) & ~1);
+        double *base = scan_lds;
+        if (INTERP) {
+            l_cos = base;
+            for (int e = threadIdx.x; e < CH_N * CH_N; e += NW * 64) {
+                const int j = e / CH_N, k = e - j * CH_N;
+                l_cos[j * IP_CP + k] = cos(M_PI * (double)j * ((double)k + 0.5) / (double)CH_N);
+            }
+            base += CH_N * IP_CP + 1;
+        }
+        l_coef = base;
+        for (int i = threadIdx.x; i < ncoef; i += NW * 64) l_coef[i] = coef[i];
+        base += (ncoef + 1) & ~1;
+        l_sc = base + (size_t)wave * (2 * NPRE * SR_M + (INTERP ? 2 * SR_M : 0));
+        l_fv = l_sc + 2 * NPRE * SR_M;
         __syncthreads();
         coef = l_coef;
     }
@@ -698,18 +807,20 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
           for (int k = 0; k < NPRE; ++k)
               if (k < p + 2) pre[k] = snp_coef[(int64_t)r_beg * (p + 2) * SR_M + k * SR_M + lane];
       }
+      [[maybe_unused]] int lds_flip = 0;
       for (int r = r_beg; r < r_end; ++r) {
         const float *g = SERIES ? nullptr : grot + (int64_t)r * n;
         double *o = out + (int64_t)r * out_cols;
         [[maybe_unused]] double *sc_lds = nullptr;
         if (CHAINLDS) {
             // this row's series: registers -> LDS buffer (r & 1); then the next row's series on its way into the registers
-            sc_lds = l_sc + (size_t)(r & 1) * NPRE * SR_M;
-            __syncthreads();
+            sc_lds = l_sc + (size_t)(lds_flip & 1) * NPRE * SR_M;
+            lds_flip ^= 1;
+            wave_lds_sync();
 #pragma unroll
             for (int k = 0; k < NPRE; ++k)
                 if (k < p + 2) sc_lds[k * SR_M + lane] = pre[k];
-            __syncthreads();
+            wave_lds_sync();
             if (r + 1 < r_end) {
 #pragma unroll
                 for (int k = 0; k < NPRE; ++k)
@@ -755,6 +866,54 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             continue;
         }
         FastEval<MAXD> ev;
+        [[maybe_unused]] bool use_interp = false;
+        if constexpr (INTERP) {
+            // the objective at the 64 Chebyshev nodes (lane = node), then its Chebyshev coefficients per segment
+            const int sg = min(lane >> 5, shd.nseg - 1);
+            const int kk = lane & 31;
+            const double tk = l_cos[IP_CP + kk];                         // T_1 at node kk: the node itself
+            const double xn = shd.low + shd.segw * ((double)sg + 0.5) + tk * (0.5 * shd.segw);
+            double fvn = 1e8;
+            if (fast_eval_lambda(xn, smin, n, p + 1) >= 0.0) {
+                double accn[MAXD + 1];
+#pragma unroll
+                for (int k = 0; k < MAXD + 1; ++k) accn[k] = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < MAXD - 1; ++rr)
+                    if (rr < p) accn[rr] = clenshaw(sc + rr * SR_M + sg * CH_N, tk);
+                accn[MAXD - 1] = clenshaw(sc + p * SR_M + sg * CH_N, tk);
+                accn[MAXD] = clenshaw(sc + (p + 1) * SR_M + sg * CH_N, tk);
+                double tv[InterpTv<MAXD>::N];
+#pragma unroll
+                for (int f = 0; f < InterpTv<MAXD>::N; ++f)
+                    tv[f] = (f < hd.nf) ? clenshaw(coef + ((int64_t)sg * hd.nf + f) * CH_N, tk) : 0.0;
+                fvn = plain_objective<MAXD>(n, p, tv, accn);
+            }
+            use_interp = __builtin_amdgcn_ballot_w64(!(fvn < 1e8)) == 0ull;      // wave-uniform: every node evaluated
+            if (use_interp) {
+                l_fv[lane] = fvn;
+                wave_lds_sync();
+                const int jj = lane & 31, s2 = lane >> 5;
+                double cj = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < CH_N; ++k) cj = fma(l_fv[s2 * CH_N + k], l_cos[jj * IP_CP + k], cj);
+                l_fv[SR_M + lane] = cj * (2.0 / (double)CH_N);
+                wave_lds_sync();
+            }
+        }
+        auto objective = [&](double xx) -> double {
+            if constexpr (INTERP) {
+                if (use_interp) {
+                    int seg = (int)((xx - shd.low) / shd.segw);
+                    if (seg < 0) seg = 0;
+                    if (seg >= shd.nseg) seg = shd.nseg - 1;
+                    const double t = (xx - (shd.low + shd.segw * ((double)seg + 0.5))) / (0.5 * shd.segw);
+                    return clenshaw(l_fv + SR_M + seg * CH_N, t);
+                }
+            }
+            eval_at(xx, false, ev, nullptr);
+            return ev.reml_neg;
+        };
         // ---- Brent (src/math/brent.rs:1-136, verbatim control flow) -----------------------------------
         double a = low, c = high;
         if (!(a < c)) {
@@ -766,8 +925,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
         const double tol = fmax(fabs(tol_in), 1e-12);
         double x = (have_last && isfinite(last) && last >= a && last <= c) ? last : 0.5 * (a + c);
         double w = x, v = x;
-        eval_at(x, false, ev, nullptr);
-        double fx = ev.reml_neg, fw = fx, fv = fx;
+        double fx = objective(x), fw = fx, fv = fx;
         double d = 0.0, e = 0.0;
         int evals = 1;
         for (int it = 0; it < max_iter; ++it) {
@@ -803,8 +961,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             }
             if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
             u = x + d;
-            eval_at(u, false, ev, nullptr);
-            const double fu = ev.reml_neg;
+            const double fu = objective(u);
             ++evals;
             if (fu <= fx) {
                 if (u >= x)
@@ -1613,9 +1770,36 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
     // chains: ONE wave per workgroup -- a chain is a long sequential job and there are few of them (m / 512): spread over the
     // CUs they do not share a SIMD's issue slots
     const int grid = chain ? nunits : (nunits + NW - 1) / NW;
-    // LDS of the chain instantiation: the lambda-only coefficient tables + two buffers of one SNP's series (MAXD + 1 rows of 64)
     const int maxd_use = dim <= 2 ? 2 : (dim <= 4 ? 4 : (dim <= 8 ? 8 : 16));
-    const size_t chain_lds = sizeof(double) * ((((size_t)hd.nseg * hd.nf * CH_N + 1) & ~(size_t)1) + 2 * (size_t)(maxd_use + 1) * SR_M);
+    const size_t ncoef_pad = ((size_t)hd.nseg * hd.nf * CH_N + 1) & ~(size_t)1;
+    // Brent on an interpolant of the objective (plain form, dim <= 4; JXGPU_SCAN_INTERP=0: direct evaluations): see plain_objective
+    static const bool interp_env = !(getenv("JXGPU_SCAN_INTERP") && atoi(getenv("JXGPU_SCAN_INTERP")) == 0);
+    const bool interp = interp_env && dim <= 4 && hd.nseg == shd.nseg && hd.segw == shd.segw && hd.low == shd.low;
+    if (interp) {
+        constexpr int NWI = 4;
+        const int nw = chain ? 1 : NWI;
+        const size_t lds = sizeof(double) * ((size_t)CH_N * IP_CP + 1 + ncoef_pad +
+                                             (size_t)nw * (2 * (size_t)(maxd_use + 1) * SR_M + 2 * SR_M));
+        const int gridi = chain ? nunits : (nunits + NWI - 1) / NWI;
+#define JX_SERIES_INTERP(MAXDV)                                                                                            \
+    do {                                                                                                                  \
+        if (chain)                                                                                                        \
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, 1, false, true, true>), dim3(gridi), dim3(64), lds, st, d_grot, nrows, n,     \
+                               d_s, d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,     \
+                               nullml, d_out, d_evals, scoef, sssq, shd, chain_off, nchains, carry);                              \
+        else                                                                                                              \
+            hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, NWI, false, true, true>), dim3(gridi), dim3(NWI * 64), lds, st, d_grot, nrows, \
+                               n, d_s, d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,  \
+                               nullml, d_out, d_evals, scoef, sssq, shd);                                                         \
+    } while (0)
+        if (dim <= 2) JX_SERIES_INTERP(2);
+        else JX_SERIES_INTERP(4);
+#undef JX_SERIES_INTERP
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
+    // LDS of the chain instantiation: the lambda-only coefficient tables + two buffers of one SNP's series (MAXD + 1 rows of 64)
+    const size_t chain_lds = sizeof(double) * (ncoef_pad + 2 * (size_t)(maxd_use + 1) * SR_M);
     if (chain && chain_lds > 160 * 1024) return fail("jxg_lmm_series_brent_tab: the chain form's tables do not fit LDS");
     if (chain && chain_lds > 64 * 1024) {
 #define JX_CHAIN_ATTR(MAXDV)                                                                                              \

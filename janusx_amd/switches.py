@@ -41,6 +41,9 @@ SWITCHES = {
     "JXGPU_SCAN_EXACT": ("numerics", "unset", "reference-formulation scan kernel instead of the tabulated one (1e-9 apart)",
                          "test_fast_scan_matches_exact_scan (through the entry points)"),
     "JXGPU_SCAN_SERIES": ("numerics", "1", "0: no per-SNP Chebyshev series (3e-16 apart)", "test_fast_scan_matches_exact_scan"),
+    "JXGPU_SCAN_INTERP": ("numerics", "1", "0: Brent evaluates the tabulated objective directly instead of its per-SNP Chebyshev interpolant "
+                          "(3.7e-15 apart; dim <= 4, series form only)",
+                          "test_warm_start_chain_device_pipeline_matches_trajectories, test_fast_scan_matches_exact_scan, full-size legs"),
     "JXGPU_LMM2_EXACT": ("numerics", "unset", "LMM2 on the reference-formulation kernel", "test_lmm2_routes"),
     "JXGPU_EIGH": ("numerics", "auto", "onestage | twostage | rocsolver: which eigensolver (eigenvectors differ within 1e-10)",
                    "test_eigh_two_stage_path_and_its_fallback"),

@@ -904,10 +904,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
         auto objective = [&](double xx) -> double {
             if constexpr (INTERP) {
                 if (use_interp) {
-                    int seg = (int)((xx - shd.low) / shd.segw);
+                    // segment and argument by multiplication with the (exact power-of-two-free) reciprocals: an IEEE division is
+                    // ~40 dependent instructions, and this is the whole evaluation now
+                    const double inv_w = 1.0 / shd.segw;
+                    int seg = (int)((xx - shd.low) * inv_w);
                     if (seg < 0) seg = 0;
                     if (seg >= shd.nseg) seg = shd.nseg - 1;
-                    const double t = (xx - (shd.low + shd.segw * ((double)seg + 0.5))) / (0.5 * shd.segw);
+                    const double t = (xx - (shd.low + shd.segw * ((double)seg + 0.5))) * (2.0 * inv_w);
                     return clenshaw(l_fv + SR_M + seg * CH_N, t);
                 }
             }

@@ -405,7 +405,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
-    ap.add_argument("--leg", default=None, choices=["c1", "c2_fvlmm", "c5_splmm", "c5_pcg"],
+    ap.add_argument("--leg", default=None, choices=["c1", "c2_fvlmm", "c3_chain", "c5_splmm", "c5_pcg"],
                     help="run ONE extra leg of the default run alone and print its record (profiling)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the two extra legs of the default one-GPU run (1 %% missing calls; BASELINE configs[3] on one GPU)")
@@ -781,6 +781,9 @@ def main():
         # one extra leg alone (profiling: `rocprofv3 ... -- python3 bench.py --leg c5_pcg`); prints that leg's record
         if args.leg == "c1":
             rec = {"extra_c1_mouse": leg_c1_mouse()}
+        elif args.leg == "c3_chain":
+            lg = run_leg(20000, 200000, 0.0, args.steps, args.warmup, chain=(10000, 1))
+            rec = {"extra_c3_chain": {k: v for k, v in leg_summary(lg, 20000, args.steps).items() if k != "roofline"}}
         elif args.leg == "c2_fvlmm":
             lg = run_leg(5000, 50000, 0.0, args.steps, args.warmup, mode="fvlmm")
             rec = {"extra_c2_fvlmm": {k: v for k, v in leg_summary(lg, 5000, args.steps).items() if k != "roofline"}}

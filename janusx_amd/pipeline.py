@@ -1114,9 +1114,8 @@ def _run_trait_ranks(panel, model, counts, keep, af, miss, rows, y, x, mode, max
     if chain_off is not None and mode == "lmm":
         if not payload_sharded:
             # deal whole chains: the cut nearest to the even share, so that no chain starts without its predecessor's state
-            cuts = [int(chain_off[np.argmin(np.abs(chain_off - (len(rows) * r) // world))]) for r in range(world + 1)]
-            cuts[0], cuts[-1] = 0, len(rows)
-            lo, hi = cuts[rank], cuts[rank + 1]
+            cuts = st.deal_whole_chains(chain_off, world)
+            lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         inside = chain_off[(chain_off >= lo) & (chain_off <= hi)] - lo
         my_chain = np.unique(np.concatenate([[0], inside, [hi - lo]])).astype(np.int64)
     mine = rows[lo:hi]

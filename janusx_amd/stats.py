@@ -251,3 +251,14 @@ def warm_chain_blocks_bed(kept_source_rows, n_units: int, rotate_block_rows: int
     kept = np.asarray(kept_source_rows, dtype=np.int64)
     edges = np.arange(0, max(int(n_units), 1), chunk, dtype=np.int64)
     return np.searchsorted(kept, edges, side="left").astype(np.int64)
+
+
+def deal_whole_chains(chain_off, world: int):
+    """Row ranges [cuts[r], cuts[r + 1]) of `world` ranks over chained rows: every cut is a chain boundary -- the one nearest to
+    the even share -- so that no chain starts without its predecessor's state and the ranks' tables concatenate to the one-rank
+    table.  -> int64 array of world + 1 non-decreasing cuts from 0 to the number of rows (a rank's range may be empty)."""
+    co = np.asarray(chain_off, dtype=np.int64)
+    m = int(co[-1])
+    cuts = [int(co[np.argmin(np.abs(co - (m * r) // int(world)))]) for r in range(int(world) + 1)]
+    cuts[0], cuts[-1] = 0, m
+    return np.maximum.accumulate(np.asarray(cuts, dtype=np.int64))

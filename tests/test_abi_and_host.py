@@ -461,6 +461,13 @@ def test_warm_chain_offsets_host_rules():
     assert st.warm_chain_offsets(st.warm_chain_blocks_bed(np.array([17, 18]), 20, 5), 2).tolist() == [0, 2]   # empty chunks vanish
     with pytest.raises(RuntimeError):
         st.warm_chain_offsets([0], 10, 3)
+    # several ranks: whole chains per rank, cuts at the chain boundary nearest to the even share
+    co = st.warm_chain_offsets(st.warm_chain_blocks_packed(1000, 96), 1000)
+    cuts = st.deal_whole_chains(co, 4)
+    assert cuts[0] == 0 and cuts[-1] == 1000 and np.all(np.diff(cuts) >= 0) and set(cuts.tolist()) <= set(co.tolist())
+    assert np.max(np.abs(np.diff(cuts) - 250)) <= 96
+    assert st.deal_whole_chains(np.array([0, 1000]), 4).tolist() == [0, 0, 0, 1000, 1000] or \
+        st.deal_whole_chains(np.array([0, 1000]), 4).tolist()[-1] == 1000            # one chain: one rank takes it
 
 
 def test_every_environment_switch_is_classified():

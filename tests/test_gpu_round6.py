@@ -379,3 +379,54 @@ def test_splmm_approx_route_genetic_models(oracle, tmp_path, gm):
     with pytest.raises(RuntimeError, match="model must be one of: add, dom, rec, het"):
         jxrs.splmm_assoc_pcg_bed(prefix, y, lam, maf=maf_r, row_flip=flip_r, row_indices=rows, sparse_jxgrm_path=path,
                                  scan_mode="approx", model="overdominant")
+
+
+def test_warm_start_chain_two_ranks_share_one_gpu(tmp_path, monkeypatch):
+    """`jx gwas -lmm` with the reference's default warm-start chain on two ranks (one device, gloo): `run_trait` deals WHOLE
+    chains over the ranks (a chain never starts without its predecessor's state), so with the same kinship file the table is the
+    one-rank table bit for bit -- with chunks of 700 rows, and with each chunk cut into 4 pieces."""
+    import socket
+    import subprocess
+    import sys
+    monkeypatch.delenv("JX_LMM_UNIFIED_NO_WARM_START", raising=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, m = 600, 3000
+    packed, g = bed.synth_panel_numpy(n, m, seed=33, missing_rate=0.003)
+    y = bed.synth_phenotype(g, n_causal=20, pve=0.5, seed=33)
+    prefix = str(tmp_path / "p")
+    ids = [f"s{i}" for i in range(n)]
+    bim = bed.Bim(["1"] * m, [f"rs{j}" for j in range(m)], list(range(1, m + 1)), ["A"] * m, ["G"] * m)
+    bed.write_bed(prefix, packed, ids, bim)
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("id\tt1\n")
+        for i in range(n):
+            fh.write(f"{ids[i]}\t{float(y[i])!r}\n")
+    env = dict(os.environ, JXGPU_DIST_BACKEND="gloo", PYTHONPATH=root)
+    env.pop("JX_LMM_UNIFIED_NO_WARM_START", None)
+
+    def run(out, ranks, extra, grm):
+        base = [sys.executable]
+        if ranks > 1:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            base += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                     "--master-port", str(port)]
+        sub = ["gwas", "-bfile", prefix, "-p", prefix + ".pheno", "-lmm", "-force-model", "-k", grm, "-o", out] + extra
+        r = subprocess.run(base + ["-m", "janusx_amd"] + sub, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (ranks, r.stdout[-1500:], r.stderr[-3000:])
+
+    r0 = subprocess.run([sys.executable, "-m", "janusx_amd", "grm", "-bfile", prefix, "-o", str(tmp_path / "k")], env=env, cwd=root,
+                        capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    grm = str(tmp_path / "k") + ".cGRM.npy"
+    for tag, extra in (("c700", ["-chunksize", "700"]), ("c700p4", ["-chunksize", "700", "-warm-chain-pieces", "4"])):
+        one, two = str(tmp_path / f"one_{tag}"), str(tmp_path / f"two_{tag}")
+        run(one, 1, extra, grm)
+        run(two, 2, extra, grm)
+        a, b = open(one + ".t1.lmm.tsv").read(), open(two + ".t1.lmm.tsv").read()
+        assert a == b and a.count("\n") > 2500, tag
+    none = str(tmp_path / "none")
+    run(none, 1, ["-warm-start", "none"], grm)
+    assert open(none + ".t1.lmm.tsv").read() != open(str(tmp_path / "one_c700") + ".t1.lmm.tsv").read()      # the chain is really taken

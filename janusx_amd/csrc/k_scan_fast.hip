@@ -718,6 +718,60 @@ __device__ __forceinline__ double plain_objective(int n, int p, const double (&t
     const double reml = cst - 0.5 * total;
     return isfinite(reml) ? -reml : 1e8;
 }
+// The same for the block form (dim 5 - 8: see ChebHeader): the tabulated Cholesky factor L of the covariate block, t = L^-1 bc,
+// u = L^-T t and the scalars, each taken by its own Clenshaw recurrence at this lane's x (cf = the lane's segment of the
+// coefficient tables, in LDS); the arithmetic of fast_eval_finish_blk on per-lane values.
+template <int MAXD>
+__device__ __forceinline__ double blk_objective(int n, int p, const double *__restrict__ cf, double t, const double (&acc)[MAXD + 1]) {
+    const int dim = p + 1;
+    auto tabv = [&](int f) -> double { return clenshaw(cf + (int64_t)f * CH_N, t); };
+    const double logdetv = tabv(0), lnd = tabv(1), q0 = tabv(2), uu = tabv(3);
+    const int ft = 4, fu = 4 + p, fl = 4 + 2 * p;
+    double w[MAXD - 1], z[MAXD - 1], ld[MAXD - 1], lo[(MAXD - 1) * (MAXD - 2) / 2 + 1];
+    double ww = 0.0, wt = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXD - 1; ++i) {
+        w[i] = 0.0;
+        ld[i] = 1.0;
+        if (i < p) {
+            double sum = acc[i];
+#pragma unroll
+            for (int q = 0; q < i; ++q) {
+                lo[i * (i - 1) / 2 + q] = tabv(fl + i * (i + 1) / 2 + q);
+                sum = fma(-lo[i * (i - 1) / 2 + q], w[q], sum);
+            }
+            ld[i] = tabv(fl + i * (i + 1) / 2 + i);
+            w[i] = sum / ld[i];
+            ww = fma(w[i], w[i], ww);
+            wt = fma(w[i], tabv(ft + i), wt);
+        }
+    }
+    double uz = 0.0, zz = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < MAXD - 1; ++ii) {
+        const int i = MAXD - 2 - ii;
+        z[i] = 0.0;
+        if (i < p) {
+            double sum = w[i];
+#pragma unroll
+            for (int q = i + 1; q < MAXD - 1; ++q)
+                if (q < p) sum = fma(-lo[q * (q - 1) / 2 + i], z[q], sum);
+            z[i] = sum / ld[i];
+            uz = fma(tabv(fu + i), z[i], uz);
+            zz = fma(z[i], z[i], zz);
+        }
+    }
+    const double sk = acc[MAXD - 1] + 1e-6 - ww;
+    if (!(sk > 1e-18) || !isfinite(lnd)) return 1e8;
+    const double bk = (acc[MAXD] - wt) / sk;
+    const double nb2 = uu - 2.0 * bk * uz + bk * bk * (zz + 1.0);
+    const double q = q0 - bk * bk * sk - 1e-6 * nb2;
+    const double nf = (double)n, pf = (double)dim;
+    const double total = (nf - pf) * jx_log(q) + logdetv + (lnd + jx_log(sk));
+    const double cst = (nf - pf) * (jx_log(nf - pf) - 1.0 - jx_log(2.0 * M_PI)) / 2.0;
+    const double reml = cst - 0.5 * total;
+    return isfinite(reml) ? -reml : 1e8;
+}
 // memory operations of one wave on its own LDS region: writes by some lanes, reads by others, no other wave involved
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -883,11 +937,20 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
                     if (rr < p) accn[rr] = clenshaw(sc + rr * SR_M + sg * CH_N, tk);
                 accn[MAXD - 1] = clenshaw(sc + p * SR_M + sg * CH_N, tk);
                 accn[MAXD] = clenshaw(sc + (p + 1) * SR_M + sg * CH_N, tk);
-                double tv[InterpTv<MAXD>::N];
+                if constexpr (MAXD >= 8) {
+                    // block form: the tables have their own (narrower) segments
+                    int tsg = (int)((xn - hd.low) / hd.segw);
+                    if (tsg < 0) tsg = 0;
+                    if (tsg >= hd.nseg) tsg = hd.nseg - 1;
+                    const double tt = (xn - (hd.low + hd.segw * ((double)tsg + 0.5))) / (0.5 * hd.segw);
+                    fvn = blk_objective<MAXD>(n, p, coef + (int64_t)tsg * hd.nf * CH_N, tt, accn);
+                } else {
+                    double tv[InterpTv<MAXD>::N];
 #pragma unroll
-                for (int f = 0; f < InterpTv<MAXD>::N; ++f)
-                    tv[f] = (f < hd.nf) ? clenshaw(coef + ((int64_t)sg * hd.nf + f) * CH_N, tk) : 0.0;
-                fvn = plain_objective<MAXD>(n, p, tv, accn);
+                    for (int f = 0; f < InterpTv<MAXD>::N; ++f)
+                        tv[f] = (f < hd.nf) ? clenshaw(coef + ((int64_t)sg * hd.nf + f) * CH_N, tk) : 0.0;
+                    fvn = plain_objective<MAXD>(n, p, tv, accn);
+                }
             }
             use_interp = __builtin_amdgcn_ballot_w64(!(fvn < 1e8)) == 0ull;      // wave-uniform: every node evaluated
             if (use_interp) {
@@ -1777,13 +1840,27 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
     const size_t ncoef_pad = ((size_t)hd.nseg * hd.nf * CH_N + 1) & ~(size_t)1;
     // Brent on an interpolant of the objective (plain form, dim <= 4; JXGPU_SCAN_INTERP=0: direct evaluations): see plain_objective
     static const bool interp_env = !(getenv("JXGPU_SCAN_INTERP") && atoi(getenv("JXGPU_SCAN_INTERP")) == 0);
-    const bool interp = interp_env && dim <= 4 && hd.nseg == shd.nseg && hd.segw == shd.segw && hd.low == shd.low;
+    // plain form (dim <= 4): tables and series share their segments; block form (dim 5 - 8): the per-lane factor of a 7 x 7 block
+    // is 56 registers -- beyond that (MAXD = 16) the direct evaluations stay
+    const bool interp = interp_env && ((dim <= 4 && hd.nseg == shd.nseg && hd.segw == shd.segw && hd.low == shd.low) ||
+                                       (dim >= 5 && dim <= 8));
     if (interp) {
         constexpr int NWI = 4;
         const int nw = chain ? 1 : NWI;
         const size_t lds = sizeof(double) * ((size_t)CH_N * IP_CP + 1 + ncoef_pad +
                                              (size_t)nw * (2 * (size_t)(maxd_use + 1) * SR_M + 2 * SR_M));
+        if (lds > 160 * 1024) return fail("jxg_lmm_series_brent_tab: the interpolant form's tables do not fit LDS");
         const int gridi = chain ? nunits : (nunits + NWI - 1) / NWI;
+        if (lds > 64 * 1024) {
+            static bool attr_i = false;
+            if (!attr_i) {
+                JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<8, 1, false, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<8, NWI, false, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_i = true;
+            }
+        }
 #define JX_SERIES_INTERP(MAXDV)                                                                                            \
     do {                                                                                                                  \
         if (chain)                                                                                                        \
@@ -1796,7 +1873,8 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
                                nullml, d_out, d_evals, scoef, sssq, shd);                                                         \
     } while (0)
         if (dim <= 2) JX_SERIES_INTERP(2);
-        else JX_SERIES_INTERP(4);
+        else if (dim <= 4) JX_SERIES_INTERP(4);
+        else JX_SERIES_INTERP(8);
 #undef JX_SERIES_INTERP
         JX_LAUNCH_CHECK();
         return 0;

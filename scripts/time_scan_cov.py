@@ -1,3 +1,5 @@
+"""Association-stage time of the exact scan with covariates (block form, dim 7) at n = 20 000, m = 100 000: per-SNP scan and the
+reference-default chain scan; run once as is and once with JXGPU_SCAN_INTERP=0 (direct evaluations)."""
 import os,sys,time,math
 sys.path.insert(0,".")
 import numpy as np, torch, bench
@@ -15,8 +17,6 @@ for ncov in (5,):
     lut=st.scan_lut_from_counts(af[rows],np.zeros(len(rows),bool),counts[rows],n)
     lo,hi=model.null.bounds; init=min(max(math.log10(model.null.lbd),lo),hi)
     res={}
-    for env in ("1","0"):
-        os.environ["JXGPU_SCAN_INTERP"]=env
     for tag,co in (("nochain",None),("chain10000",st.warm_chain_offsets(st.warm_chain_blocks_bed(rows,m,10000),len(rows),1))):
         for rep in range(2):
             tm=pl.StageTimes(); out,ev=pl.scan_rows(panel,model,rows,lut,"lmm",init_log10_lbd=(init if co is not None else None),chain_off=co,times=tm,return_evals=True)

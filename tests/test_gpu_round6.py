@@ -430,3 +430,47 @@ def test_warm_start_chain_two_ranks_share_one_gpu(tmp_path, monkeypatch):
     none = str(tmp_path / "none")
     run(none, 1, ["-warm-start", "none"], grm)
     assert open(none + ".t1.lmm.tsv").read() != open(str(tmp_path / "one_c700") + ".t1.lmm.tsv").read()      # the chain is really taken
+
+
+@pytest.mark.parametrize("q", [4, 6])
+def test_warm_start_chain_with_covariates_block_form(oracle, oracle_c, q):
+    """The chain scan with q covariates beside the intercept (dim = q + 2 = 6 / 8: the BLOCK form of the evaluation, whose
+    objective is interpolated per SNP from one node evaluation per lane -- `blk_objective`, csrc/k_scan_fast.hip) at n = 3000,
+    chains of 128 rows seeded with log10 lambda0: beta / SE / p within 1e-5 of the oracle's sequential chains and the same
+    number of Brent evaluations on (nearly) every SNP; the per-SNP (no-chain) scan of the same rows as well."""
+    import torch
+    from janusx_amd import pipeline, stats
+    P = _parity()
+    n, m = 3000, 600
+    packed, g = bed.synth_panel_numpy(n, m, seed=80 + q, missing_rate=0.005, family=True)
+    y = bed.synth_phenotype(g, n_causal=15, pve=0.5, seed=80 + q)
+    rng = np.random.default_rng(q)
+    cov = rng.normal(size=(n, q))
+    cov[:, 0] += 0.5 * y
+    x = np.concatenate([np.ones((n, 1)), cov], axis=1)
+    k, _eff, _ = oracle.grm_stream_bed(packed, n, 1, 0.02, 0.05, 0.0)
+    s, u = oracle.gwas_eigh_from_grm(k)
+    nm = oracle.spectral_null_model(y, x, s, u)
+    mi, he, ho = oracle.row_counts(packed, n)
+    keep, maf, miss, flip = oracle.gwas_scan_row_stats(mi, he, ho, n, 0.02, 0.05, 1.0)
+    kept = np.nonzero(keep)[0]
+    grot = oracle.rotate_block_f32(oracle.decode_centered_block_f32(packed, n, flip, maf, rows=kept), nm.Dh)
+    lo, hi = nm.bounds
+    init = min(max(math.log10(nm.lbd_null), lo), hi)
+    dev = torch.device("cuda", 0)
+    panel = pipeline.Panel(torch.from_numpy(packed).to(dev), n)
+    model = pipeline.SpectralModel(torch.from_numpy(nm.S).to(dev), torch.from_numpy(nm.Dh.astype(np.float64)).to(dev), x, y)
+    lut = stats.scan_lut_from_counts(maf[kept], np.zeros(len(kept), bool), panel.counts()[kept], n)
+    sh, xh, yh = model.S.cpu().numpy(), model.xcov.cpu().numpy(), model.y.cpu().numpy()
+    co = stats.warm_chain_offsets(stats.warm_chain_blocks_bed(kept, panel.m, 128), len(kept))
+    ref, ev_ref = oracle_c.lmm_scan_rotated_chains(grot, sh, xh, yh, lo, hi, 30, 1e-2, co, init=init, return_evals=True)
+    out, ev = pipeline.scan_rows(panel, model, kept, lut, "lmm", low=lo, high=hi, max_iter=30, tol=1e-2, init_log10_lbd=init,
+                                 return_evals=True, chain_off=co)
+    be, se, pe = P._assoc_err(out.cpu().numpy(), ref, tag=f"chain-q{q}")
+    assert max(be, se, pe) < P.TOL, (q, be, se, pe)
+    assert float(np.mean(ev.cpu().numpy() == ev_ref)) > 0.99
+    ref0, ev0 = oracle_c.lmm_scan_rotated_block(grot, sh, xh, yh, lo, hi, 30, 1e-2, return_evals=True)
+    out0, e0 = pipeline.scan_rows(panel, model, kept, lut, "lmm", low=lo, high=hi, max_iter=30, tol=1e-2, return_evals=True)
+    be, se, pe = P._assoc_err(out0.cpu().numpy(), ref0, tag=f"plain-q{q}")
+    assert max(be, se, pe) < P.TOL, (q, be, se, pe)
+    assert float(np.mean(e0.cpu().numpy() == ev0)) > 0.99

@@ -474,3 +474,53 @@ def test_warm_start_chain_with_covariates_block_form(oracle, oracle_c, q):
     be, se, pe = P._assoc_err(out0.cpu().numpy(), ref0, tag=f"plain-q{q}")
     assert max(be, se, pe) < P.TOL, (q, be, se, pe)
     assert float(np.mean(e0.cpu().numpy() == ev0)) > 0.99
+
+
+def test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows(oracle_c, chain_case):
+    """The chain kernels called directly on rotated rows (`jxg_lmm_scan_chain`: tables built inside, series + interpolant form;
+    `jxg_lmm_scan_exact_chain`: the reference-formulation kernel): rows with zero variance inside and at the head of a chain are
+    (NaN, NaN, 1) and leave the chain's state untouched (the reference returns before it stores the optimum,
+    src/stats/lmm.rs:128-132), empty chains, one-row chains, a chain that continues from a carried state, and the carried states
+    the kernel hands back = the optimum of each chain's last valid row."""
+    import torch
+    from janusx_amd._lib import check, lib
+    P = _parity()
+    c = chain_case
+    nm, n = c["nm"], c["n"]
+    g = np.ascontiguousarray(c["grot"][:900]).copy()
+    g[0] = 0.0            # head of the first chain
+    g[257] = 0.0          # inside a chain
+    g[300:303] = 0.0      # a run of invalid rows
+    co = np.array([0, 200, 200, 201, 520, 900], dtype=np.int64)       # an empty chain and a one-row chain
+    lo, hi = nm.bounds
+    init = math.log10(nm.lbd_null)
+    ref, ev_ref = oracle_c.lmm_scan_rotated_chains(g, nm.S, nm.Xcov, nm.y, lo, hi, 30, 1e-2, co, init=init, return_evals=True)
+    assert np.isnan(ref[0, 0]) and np.isnan(ref[257, 0]) and ref[301, 2] == 1.0
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)      # noqa: E731
+    d_g, d_s, d_x, d_y = t(g, torch.float32), t(nm.S), t(nm.Xcov), t(nm.y)
+    d_co = torch.from_numpy(co.astype(np.int32)).to(dev)
+    p = nm.Xcov.shape[1]
+    for fn in ("jxg_lmm_scan_chain", "jxg_lmm_scan_exact_chain"):
+        carry = torch.full((len(co) - 1,), init, dtype=torch.float64, device=dev)
+        out = torch.zeros((900, 3), dtype=torch.float64, device=dev)
+        ev = torch.zeros(900, dtype=torch.int32, device=dev)
+        check(getattr(lib(), fn)(d_g.data_ptr(), 900, n, d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), p, lo, hi, 1e-2, 30,
+                                 d_co.data_ptr(), len(co) - 1, carry.data_ptr(), 0, 0.0, out.data_ptr(), ev.data_ptr(), st))
+        be, se, pe = P._assoc_err(out.cpu().numpy(), ref, tag=fn)
+        # identical rotated input: the reference-formulation kernel differs by summation order only; the tabulated / interpolated
+        # form evaluates the objective to ~1e-13, which moves a Brent optimum by ~1e-7 and beta with it
+        assert max(be, se, pe) < (1e-7 if "exact" in fn else 2e-6), (fn, be, se, pe)
+        assert float(np.mean(ev.cpu().numpy() == ev_ref)) >= (1.0 if "exact" in fn else 0.99), fn
+        # split in two calls at row 400 (inside the chain [201, 520)): the second call continues from the carried state
+        carry2 = torch.full((len(co) - 1,), init, dtype=torch.float64, device=dev)
+        out2 = torch.zeros((900, 3), dtype=torch.float64, device=dev)
+        a_off = torch.tensor([0, 200, 200, 201, 400], dtype=torch.int32, device=dev)
+        b_off = torch.tensor([0, 120, 500], dtype=torch.int32, device=dev)
+        check(getattr(lib(), fn)(d_g.data_ptr(), 400, n, d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), p, lo, hi, 1e-2, 30,
+                                 a_off.data_ptr(), 4, carry2.data_ptr(), 0, 0.0, out2.data_ptr(), None, st))
+        check(getattr(lib(), fn)(d_g[400:].data_ptr(), 500, n, d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), p, lo, hi, 1e-2, 30,
+                                 b_off.data_ptr(), 2, carry2[3:].data_ptr(), 0, 0.0, out2[400:].data_ptr(), None, st))
+        assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy(), equal_nan=True), fn
+        assert torch.equal(carry2, carry)

@@ -277,6 +277,192 @@ __global__ __launch_bounds__(512, 2) void rotate_i8_kernel(const uint8_t *__rest
     }
 }
 
+// ---- the same product with the operands copied by the LDS DMA (round 6) -------------------------------------------------------
+// rotate_i8_kernel stages the DECODED rows through LDS (16 KB per 64-sample step, written by VALU stores, read back as 4 of the 7
+// ds_read_b128 a wave issues per 12 products) and the planes through registers: its LDS port is busy ~0.8 of the time the matrix
+// pipes need.  Here a step is one 128-sample payload tile and
+//   * the RAW payload records of the 256 rows (32 B each: 8 KB instead of 32 KB decoded) and the three planes (48 KB) are copied
+//     global -> LDS by global_load_lds_dwordx4, no register staging, double buffered, ONE barrier per 128 samples;
+//   * a lane reads its 16 payload bytes per 32-row fragment ONCE per step (lane (row, h) takes the dwords 4 h .. 4 h + 3 of the
+//     record: the k slot (ks, h) of the MFMA is the 16-sample group 4 h + ks of the tile, on both operands) and decodes them in
+//     registers in front of the products (11 VALU instructions per fragment, four waves repeat the decode of the rows they share);
+//   * per step and wave 4 + 12 ds_read_b128 for 48 products (28 before).
+// Plane image in LDS: [column][128 bytes], 16-byte chunk index XOR (column >> 1) & 7 (a 16-lane group of a fragment read covers all
+// 64 banks); the DMA writes 1 KB pieces (8 columns) whose lanes pick the source chunk that belongs at their linear position.
+// Same exact i32 sums and the same epilogue as rotate_i8_kernel: the outputs are bit-identical.
+constexpr int RD_BK = 128;                  // samples per step = one payload tile
+constexpr int RD_A = 8 * 1024;              // raw records: piece w = rows 32 w .. + 31, [half][row][16 B]
+constexpr int RD_B = RI_TN * RD_BK;         // one plane
+constexpr int RD_STAGE = RD_A + 3 * RD_B;   // 56 KB
+
+// 16 bytes per lane from `base` (wave-uniform) + `off` (per lane, 32 bits) to LDS at lds_dst + 16 lane
+__device__ __forceinline__ void rd_glds(const void *base, uint32_t off, unsigned lds_dst) {
+    unsigned keep;
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint64_t sb = ((uint64_t)bhi << 32) | blo;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(sb), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+
+// 16 two-bit codes -> the MFMA operand of one k slot (same byte order as ri_decode16)
+template <int MODE> __device__ __forceinline__ i32x4 rd_decode(uint32_t w) {
+    const u32x4q o = MODE == 1 ? ri_decode16_missing(w) : ri_decode16(w);
+    i32x4 r;
+    r.x = (int)o.x;
+    r.y = (int)o.y;
+    r.z = (int)o.z;
+    r.w = (int)o.w;
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void rotate_i8_dma_kernel(const uint8_t *__restrict__ p32, int64_t m_total,
+                                                               const int32_t *__restrict__ rows, int nrows,
+                                                               const uint4 *__restrict__ lut16, const float *__restrict__ rowoff,
+                                                               const float *__restrict__ usum, const int8_t *__restrict__ q,
+                                                               const float *__restrict__ umax, int64_t npad, int n,
+                                                               float *__restrict__ out, int64_t ldo,
+                                                               const int32_t *__restrict__ sel) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rd_smem[];       // 2 stages | row offsets | row signs | positions
+    float *sOff = reinterpret_cast<float *>(rd_smem + 2 * RD_STAGE);
+    float *sSgn = sOff + RI_TM;
+    int *sPos = reinterpret_cast<int *>(sSgn + RI_TM);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nrt = (nrows + RI_TM - 1) / RI_TM;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int ct = (local / nrt) * 8 + xcd;
+    if ((int64_t)ct * RI_TN >= npad) return;
+    const int j0 = ct * RI_TN;
+    const int r0 = (local % nrt) * RI_TM;
+
+    // payload piece of this wave: rows 32 wave .. + 31, lane = (row lane & 31, record half lane >> 5); byte offsets of a lane's
+    // sources are 32-bit (m_total < 2^27: the launcher checks), the bases wave-uniform
+    uint32_t aoff = 0;
+    int row_exact = 1;
+    {
+        const int arow = 32 * wave + (lane & 31);
+        const int r = r0 + arow;
+        float boff = 0.0f, sgn = 1.0f;
+        int pos = -1;
+        if (r < nrows) {
+            pos = sel ? sel[r] : r;
+            aoff = (uint32_t)(rows ? rows[pos] : pos) * 32u;
+            const float t = rowoff[pos];
+            if (MODE == 1) {
+                boff = t;
+            } else {
+                row_exact = (t == t) ? 1 : 0;
+                const bool flipped = (lut16[pos].x & 0xffffu) != 0u;
+                sgn = flipped ? -1.0f : 1.0f;
+                boff = row_exact ? (t + (flipped ? 2.0f : 0.0f)) : 0.0f;
+            }
+        }
+        if (lane < 32) {
+            sOff[arow] = boff;
+            sSgn[arow] = sgn;
+            sPos[arow] = pos;
+        }
+    }
+    if (__syncthreads_and(row_exact) == 0) return;
+    aoff += 16u * (uint32_t)(lane >> 5);
+
+    // plane pieces of this wave: the column groups 2 wave + e (8 columns each), e = 0, 1, of every plane
+    uint32_t boffs[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int col = 16 * wave + 8 * e + (lane >> 3);
+        const int c = (lane & 7) ^ ((col >> 1) & 7);
+        boffs[e] = (uint32_t)col * (uint32_t)npad + (uint32_t)c * 16u;
+    }
+    const int8_t *qtile = q + (int64_t)j0 * npad;
+    const int64_t plane = npad * npad;
+    const int64_t atile = m_total * 32;
+    const unsigned lds0 = (unsigned)(uintptr_t)rd_smem;
+    auto issue = [&](int t, int buf) {
+        const unsigned st = lds0 + buf * RD_STAGE;
+        rd_glds(p32 + (int64_t)t * atile, aoff, st + wave * 1024);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                rd_glds(qtile + pl * plane + (int64_t)t * RD_BK, boffs[e], st + RD_A + pl * RD_B + (2 * wave + e) * 1024);
+    };
+
+    i32x16 acc[3][4];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pl][mi][r] = 0;
+
+    const int h = lane >> 5, frow = lane & 31;
+    const int afrag = wm * 4 * 1024 + h * 512 + frow * 16;                 // + mi * 1024
+    const int bcol = (wn * 32 + frow) * RD_BK;
+    const int bx0 = (4 * h) ^ ((frow >> 1) & 7);                             // chunk of k slot (ks, h): (bx0 ^ ks)
+
+    const int nk = (int)(npad / RD_BK);
+    issue(0, 0);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's pieces of step t landed
+        __builtin_amdgcn_s_barrier();                                          // everybody's did, and nobody reads the other stage any more
+        asm volatile("" ::: "memory");
+        issue(t + 1 < nk ? t + 1 : nk - 1, buf ^ 1);                           // past the end: a copy nothing reads
+        const uint8_t *st = rd_smem + buf * RD_STAGE;
+        i32x4 araw[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) araw[mi] = *reinterpret_cast<const i32x4 *>(st + afrag + mi * 1024);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            i32x4 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[pl] = *reinterpret_cast<const i32x4 *>(st + RD_A + pl * RD_B + bcol + ((bx0 ^ ks) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const i32x4 a = rd_decode<MODE>((uint32_t)araw[mi][ks]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    acc[pl][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b[pl], acc[pl][mi], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // no DMA may outlive the workgroup's LDS allocation
+
+    const int gj = j0 + wn * 32 + frow;
+    const bool colok = gj < n;
+    const double um = colok ? (double)umax[gj] : 0.0;
+    const double w1 = um / 127.0, w2 = um / (127.0 * 254.0), w3 = um / (127.0 * 254.0 * 254.0);
+    const float us = (MODE == 0 && colok) ? usum[gj] : 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int gr = sPos[lr];
+            if (gr >= 0 && colok) {
+                const double v = (double)acc[0][mi][r] * w1 + (double)acc[1][mi][r] * w2 + (double)acc[2][mi][r] * w3;
+                float *dst = out + (int64_t)gr * ldo + gj;
+                if (MODE == 1) *dst = fmaf(sOff[lr], (float)v, *dst);
+                else *dst = fmaf(sOff[lr], us, sSgn[lr] * (float)v);
+            }
+        }
+    }
+}
+
+// 1 (default): the DMA form; JXGPU_ROT_I8_DMA=0: the register-staged form (same bits)
+static bool rot_i8_dma() {
+    static const bool on = !(getenv("JXGPU_ROT_I8_DMA") && atoi(getenv("JXGPU_ROT_I8_DMA")) == 0);
+    return on;
+}
+
 extern float g_last_ms[24];
 
 }  // namespace jx
@@ -331,6 +517,18 @@ int launch_rotate_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int 
         attr = true;
     }
     dim3 grid((unsigned)(((nct + 7) / 8) * 8 * nrt));
+    if (rot_i8_dma() && m_total < (1LL << 27)) {          // 32-bit byte offsets of the payload records inside a tile
+        static bool attr_dma = false;
+        const int lds_dma = 2 * RD_STAGE + 3072;
+        if (!attr_dma) {
+            JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+            attr_dma = true;
+        }
+        hipLaunchKernelGGL(rotate_i8_dma_kernel<0>, grid, dim3(512), lds_dma, st, d_p32, m_total, d_rows, nrows,
+                           (const uint4 *)d_lut16, d_rowoff, d_usum, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(rotate_i8_kernel<0>, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nrows, (const uint4 *)d_lut16,
                        d_rowoff, d_usum, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
     JX_LAUNCH_CHECK();
@@ -352,6 +550,18 @@ int launch_rotate_i8_missing(hipStream_t st, const uint8_t *d_p32, int64_t m_tot
         attr = true;
     }
     dim3 grid((unsigned)(((nct + 7) / 8) * 8 * nrt));
+    if (rot_i8_dma() && m_total < (1LL << 27)) {
+        static bool attr_dma = false;
+        const int lds_dma = 2 * RD_STAGE + 3072;
+        if (!attr_dma) {
+            JX_HIP(hipFuncSetAttribute((const void *)rotate_i8_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma));
+            attr_dma = true;
+        }
+        hipLaunchKernelGGL(rotate_i8_dma_kernel<1>, grid, dim3(512), lds_dma, st, d_p32, m_total, d_rows, nsel,
+                           (const uint4 *)nullptr, d_rowmiss, (const float *)nullptr, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(rotate_i8_kernel<1>, grid, dim3(512), lds, st, d_p32, m_total, d_rows, nsel, (const uint4 *)nullptr,
                        d_rowmiss, (const float *)nullptr, d_q, d_umax, npad, n, d_out, ld_out, d_sel);
     JX_LAUNCH_CHECK();

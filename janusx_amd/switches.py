@@ -77,7 +77,8 @@ SWITCHES = {
         "JXGPU_SBBACK_PAIR": "untested", "JXGPU_SBBACK_SOLO": "untested", "JXGPU_STEDC_LEAF": "test_eigh_own_divide_and_conquer",
         "JXGPU_STEDC_OWNLEAF": "untested", "JXGPU_STEDC_PAR": "untested", "JXGPU_STEDC_PARMIN": "untested", "JXGPU_SY2SB_LOOKAHEAD": "untested",
         "JXGPU_SYTRD_KT": "untested", "JXGPU_SYTRD_SYR2K": "untested", "JXGPU_SYTRD_TAIL": "untested", "JXGPU_SYTRD_TARGET": "untested",
-        "JXGPU_DSYMM_SLOTS": "untested", "JXGPU_DSYMM_SPLIT": "untested", "JXGPU_ORMTR_NB": "untested"}.items()},
+        "JXGPU_DSYMM_SLOTS": "untested", "JXGPU_DSYMM_SPLIT": "untested", "JXGPU_ORMTR_NB": "untested",
+        "JXGPU_ROT_I8_DMA": "test_int8_rotation_forms_give_the_same_bits"}.items()},
     # ---- ablation masks (wrong results by design: timing experiments only) --------------------------------------------------------
     "JXGPU_QB_SKIP": ("test", "unset", "skips parts of the Q2 kernel (timing ablation; results are WRONG)", "test_q2_staggered_units_equal_lockstep (the lockstep value 64 only)"),
     "JXGPU_BC_SKIP": ("test", "unset", "bulge-chasing ablation (results WRONG)", "untested"),

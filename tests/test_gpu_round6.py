@@ -524,3 +524,27 @@ def test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows(oracle_c, ch
                                  b_off.data_ptr(), 2, carry2[3:].data_ptr(), 0, 0.0, out2[400:].data_ptr(), None, st))
         assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy(), equal_nan=True), fn
         assert torch.equal(carry2, carry)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,missing", [(4200, 3000, 0.0), (6000, 2500, 0.004)])
+def test_int8_rotation_forms_give_the_same_bits(n, m, missing):
+    """The two forms of the int8 rotation (k_rotate_i8.hip: operands staged through registers / copied by the LDS DMA with the
+    payload decoded in registers) compute the same exact i32 plane sums and share the epilogue: the rotated block is the same
+    bits, rows with a missing-call term included.  The switch is read once per process, hence two child processes."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for form in ("0", "1"):
+        env = dict(os.environ, JXGPU_ROT_I8_DMA=form)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "ab_rotate_i8.py"), str(n), str(m), str(missing)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = r.stdout.strip().splitlines()[-1]
+        digests[form] = re.search(r"digest=([0-9a-f]+)", line).group(1)
+        assert float(re.search(r"\|out\|max=([0-9.]+)", line).group(1)) > 0.1
+        if missing > 0:
+            assert int(re.search(r"with_missing_term=(\d+)", line).group(1)) > 0
+    assert digests["0"] == digests["1"], digests

@@ -779,6 +779,186 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 constexpr int IP_CP = CH_N + 1;     // pitch of the cosine table rows (doubles): column reads of 32 lanes on distinct banks
 
+// ---- the chain scan in three launches (round 6) -----------------------------------------------------------------------------
+// Along a warm-start chain only Brent's START depends on the row before; the interpolant of a row's objective (node evaluations
+// + cosine transform) and the final evaluation at its optimum (beta / SE / p) do not.  So a chain scan on stored series is
+//   phase 1  every row in parallel: the 64 Chebyshev coefficients of its objective -> `icoef`, `rflag` (lmm_scan_fast_kernel, one
+//            wave per row, split.phase = 1),
+//   chains   chain_interp_brent_kernel: one wave per chain, per row ONLY Brent on the stored interpolant (an evaluation = one
+//            fully unrolled Clenshaw recurrence from LDS) -> `xopt`, evaluations, carry,
+//   phase 2  every row in parallel: final evaluation at xopt, outputs (lmm_scan_fast_kernel, split.phase = 2).
+// A chain that holds a row whose interpolant could not be formed (a node failed: that row needs direct evaluations) is flagged
+// in `cflag` and walked by the one-kernel form (split.phase = 0 with split.cflag: only flagged chains).  Same arithmetic in the
+// same order as the one-kernel form: the outputs are bit-identical (JXGPU_SCAN_CHAIN_SPLIT=0 runs the one-kernel form).
+struct ChainSplit {
+    double *icoef = nullptr;          // (rows, SR_M)
+    double *xopt = nullptr;           // (rows): NaN = not a row of the split form (invalid row, or a flagged chain's)
+    int32_t *rflag = nullptr;         // (rows): 0 invalid row (its outputs are written by phase 1), 1 interpolant stored, 2 direct
+    const int32_t *cflag = nullptr;   // (chains): with phase 0 and chains, walk only the chains whose flag is set
+    int phase = 0;
+    int force_row = -1;               // test hook (JXGPU_SCAN_CHAIN_FORCE_DIRECT): this row is flagged 2 whatever its nodes say
+};
+
+// Brent's minimiser (src/math/brent.rs:1-136, verbatim control flow) of `objective` on [low, high], started from `last` when
+// `have_last` (seed_with_init_guess / carry_warm_start) -> optimum, number of evaluations
+template <class F>
+__device__ __forceinline__ void brent_minimize(F &&objective, double low, double high, double tol_in, int max_iter, bool have_last,
+                                               double last, double &x_out, int &evals_out) {
+    double a = low, c = high;
+    if (!(a < c)) {
+        const double tt = a;
+        a = c;
+        c = tt;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double tol = fmax(fabs(tol_in), 1e-12);
+    double x = (have_last && isfinite(last) && last >= a && last <= c) ? last : 0.5 * (a + c);
+    double w = x, v = x;
+    double fx = objective(x), fw = fx, fv = fx;
+    double d = 0.0, e = 0.0;
+    int evals = 1;
+    for (int it = 0; it < max_iter; ++it) {
+        const double m = 0.5 * (a + c);
+        const double tol1 = tol * fabs(x) + eps;
+        const double tol2 = 2.0 * tol1;
+        if (fabs(x - m) <= tol2 - 0.5 * (c - a)) break;
+        double u;
+        bool use_par = false;
+        if (fabs(e) > tol1) {
+            double pq = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw));
+            double q = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)));
+            if (q > 0.0)
+                pq = -pq;
+            else
+                q = -q;
+            bool ok = false;
+            if (fabs(q) > eps) {
+                const double sstep = pq / q;
+                u = x + sstep;
+                if ((u - a) >= tol2 && (c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(e)) ok = true;
+            }
+            if (ok) {
+                d = pq / q;
+                u = x + d;
+                if ((u - a) < tol2 || (c - u) < tol2) d = (x < m) ? tol1 : -tol1;
+                use_par = true;
+            }
+        }
+        if (!use_par) {
+            e = (x < m) ? (c - x) : (a - x);
+            d = 0.3819660 * e;
+        }
+        if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
+        u = x + d;
+        const double fu = objective(u);
+        ++evals;
+        if (fu <= fx) {
+            if (u >= x)
+                a = x;
+            else
+                c = x;
+            v = w;
+            fv = fw;
+            w = x;
+            fw = fx;
+            x = u;
+            fx = fu;
+        } else {
+            if (u >= x)
+                c = u;
+            else
+                a = u;
+            if (fu <= fw || w == x) {
+                v = w;
+                fv = fw;
+                w = u;
+                fw = fu;
+            } else if (fu <= fv || v == x || v == w) {
+                v = u;
+                fv = fu;
+            }
+        }
+    }
+    x_out = x;
+    evals_out = evals;
+}
+
+// clenshaw() with every coefficient read in flight before the recurrence starts (same operations in the same order)
+__device__ __forceinline__ double clenshaw_unrolled(const double *__restrict__ c, double t) {
+    double cv[CH_N];
+#pragma unroll
+    for (int j = 0; j < CH_N; ++j) cv[j] = c[j];
+    double b1 = 0.0, b2 = 0.0;
+    const double t2 = 2.0 * t;
+#pragma unroll
+    for (int j = CH_N - 1; j >= 1; --j) {
+        const double b0 = fma(t2, b1, cv[j] - b2);
+        b2 = b1;
+        b1 = b0;
+    }
+    return fma(t, b1, 0.5 * cv[0] - b2);
+}
+
+__global__ __launch_bounds__(64) void chain_interp_brent_kernel(const double *__restrict__ icoef, const int32_t *__restrict__ rflag,
+                                                                const int32_t *__restrict__ chain_off, int nchains,
+                                                                double *__restrict__ carry, int32_t *__restrict__ cflag,
+                                                                double *__restrict__ xopt, int32_t *__restrict__ evals_out,
+                                                                const ChebHeader shd, double low, double high, double tol_in,
+                                                                int max_iter) {
+    __shared__ __attribute__((aligned(16))) double l_c[2][SR_M];
+    const int lane = threadIdx.x;
+    const int unit = blockIdx.x;
+    if (unit >= nchains) return;
+    const int r_beg = chain_off[unit], r_end = chain_off[unit + 1];
+    {
+        int bad = 0;
+        for (int r = r_beg + lane; r < r_end; r += 64) bad |= (rflag[r] == 2) ? 1 : 0;
+        const bool any_bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0ull;
+        if (lane == 0) cflag[unit] = any_bad ? 1 : 0;
+        if (any_bad) return;                            // the one-kernel form walks this chain
+    }
+    double last = carry[unit];
+    bool have_last = isfinite(last);
+    double pre = 0.0;
+    int pflag = 0;
+    if (r_beg < r_end) {
+        pre = icoef[(int64_t)r_beg * SR_M + lane];
+        pflag = rflag[r_beg];
+    }
+    const double inv_w = 1.0 / shd.segw;
+    int flip = 0;
+    for (int r = r_beg; r < r_end; ++r) {
+        double *lc = l_c[flip];
+        flip ^= 1;
+        wave_lds_sync();
+        lc[lane] = pre;
+        wave_lds_sync();
+        const int flag = pflag;
+        if (r + 1 < r_end) {
+            pre = icoef[(int64_t)(r + 1) * SR_M + lane];
+            pflag = rflag[r + 1];
+        }
+        if (flag != 1) continue;                        // invalid row: phase 1 wrote its outputs, the chain's state stays
+        auto objective = [&](double xx) -> double {
+            int seg = (int)((xx - shd.low) * inv_w);
+            if (seg < 0) seg = 0;
+            if (seg >= shd.nseg) seg = shd.nseg - 1;
+            const double t = (xx - (shd.low + shd.segw * ((double)seg + 0.5))) * (2.0 * inv_w);
+            return clenshaw_unrolled(lc + seg * CH_N, t);
+        };
+        double x;
+        int evals;
+        brent_minimize(objective, low, high, tol_in, max_iter, have_last, last, x, evals);
+        last = x;
+        have_last = true;
+        if (lane == 0) {
+            xopt[r] = x;
+            if (evals_out) evals_out[r] = evals;
+        }
+    }
+    if (lane == 0 && have_last) carry[unit] = last;
+}
+
 // NW waves per workgroup.  LDS = true: the three vectors every evaluation of every SNP streams -- s, X~ (n x p) and the
 // shifted y~, 8 n (2 + p) bytes -- are copied into LDS once per workgroup and shared by its NW waves.  Without it each
 // evaluation re-reads them through L2 (they do not fit the 32 KB L1): measured 7.7 TB/s of L1<-L2 traffic and waves
@@ -789,16 +969,20 @@ __device__ __forceinline__ void series_eval_sums(double x, const ChebHeader hd, 
 
 // SERIES: the SNP-specific sums come from the SNP's own Chebyshev series (series_coef_kernel: `snp_coef`, `snp_ssq`) instead of
 // a pass over the rotated row -- `grot` is not read.
-template <int MAXD, int NW, bool LDS, bool SERIES = false, bool INTERP = false>
-__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void lmm_scan_fast_kernel(
+// SPLIT (with INTERP): the phases of the three-launch chain scan (ChainSplit above) are compiled in
+template <int MAXD, int NW, bool LDS, bool SERIES = false, bool INTERP = false, bool SPLIT = false>
+__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? (SPLIT ? 2 : 4) : 2))) void lmm_scan_fast_kernel(
     const float *__restrict__ grot, int nrows, int n, const double *__restrict__ s_g, const double *__restrict__ xcov_g,
     const double *__restrict__ yc_g, int p, const ChebHeader hd, const double *__restrict__ coef,
     const double *__restrict__ smin_ptr, double low, double high, double tol_in, int max_iter, int warm, double init,
     int with_plrt, double nullml, double *__restrict__ out, int32_t *__restrict__ evals_out,
     const double *__restrict__ snp_coef, const double *__restrict__ snp_ssq, const ChebHeader shd,
-    const int32_t *__restrict__ chain_off = nullptr, int nchains = 0, double *__restrict__ carry = nullptr) {
+    const int32_t *__restrict__ chain_off = nullptr, int nchains = 0, double *__restrict__ carry = nullptr,
+    const ChainSplit split = ChainSplit()) {
     extern __shared__ __attribute__((aligned(16))) double scan_lds[];
     if (MAXD == 2) p = 1;     // dim = p + 1 <= 2 and p >= 1: a compile-time p (see lmm_scan_tiled_kernel)
+    // one-kernel form behind the split chain scan: only the flagged chains (one workgroup per chain there)
+    if (INTERP && SPLIT && NW == 1 && chain_off && split.cflag && (int)gridDim.x >= nchains && split.cflag[blockIdx.x] == 0) return;
     const double *s = s_g, *xcov = xcov_g, *yc = yc_g;
     if (LDS) {
         double *ls = scan_lds, *lx = scan_lds + n, *ly = scan_lds + n + (int64_t)n * p;
@@ -853,6 +1037,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
     // Without chain_off a unit is one row and `warm` / `init` seed every row alike (seed_with_init_guess).
     const int nunits = chain_off ? nchains : nrows;
     for (int unit = blockIdx.x * NW + wave; unit < nunits; unit += gridDim.x * NW) {
+      if (INTERP && SPLIT && chain_off && split.cflag && split.cflag[unit] == 0) continue;
       const int r_beg = chain_off ? chain_off[unit] : unit, r_end = chain_off ? chain_off[unit + 1] : unit + 1;
       double last = chain_off ? carry[unit] : init;
       bool have_last = chain_off ? isfinite(last) : (warm != 0);
@@ -916,12 +1101,14 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
                 o[2] = 1.0;
                 if (with_plrt) o[3] = 1.0;
                 if (evals_out) evals_out[r] = 0;
+                if constexpr (INTERP && SPLIT)
+                    if (split.phase == 1) split.rflag[r] = 0;
             }
             continue;
         }
         FastEval<MAXD> ev;
         [[maybe_unused]] bool use_interp = false;
-        if constexpr (INTERP) {
+        if constexpr (INTERP) if (!SPLIT || split.phase != 2) {
             // the objective at the 64 Chebyshev nodes (lane = node), then its Chebyshev coefficients per segment
             const int sg = min(lane >> 5, shd.nseg - 1);
             const int kk = lane & 31;
@@ -963,6 +1150,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
                 l_fv[SR_M + lane] = cj * (2.0 / (double)CH_N);
                 wave_lds_sync();
             }
+            if (SPLIT && split.phase == 1) {
+                if (use_interp) split.icoef[(int64_t)r * SR_M + lane] = l_fv[SR_M + lane];
+                if (lane == 0) split.rflag[r] = (use_interp && r != split.force_row) ? 1 : 2;
+                continue;
+            }
         }
         auto objective = [&](double xx) -> double {
             if constexpr (INTERP) {
@@ -980,82 +1172,18 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             eval_at(xx, false, ev, nullptr);
             return ev.reml_neg;
         };
-        // ---- Brent (src/math/brent.rs:1-136, verbatim control flow) -----------------------------------
-        double a = low, c = high;
-        if (!(a < c)) {
-            const double tt = a;
-            a = c;
-            c = tt;
-        }
-        const double eps = 2.220446049250313e-16;
-        const double tol = fmax(fabs(tol_in), 1e-12);
-        double x = (have_last && isfinite(last) && last >= a && last <= c) ? last : 0.5 * (a + c);
-        double w = x, v = x;
-        double fx = objective(x), fw = fx, fv = fx;
-        double d = 0.0, e = 0.0;
-        int evals = 1;
-        for (int it = 0; it < max_iter; ++it) {
-            const double m = 0.5 * (a + c);
-            const double tol1 = tol * fabs(x) + eps;
-            const double tol2 = 2.0 * tol1;
-            if (fabs(x - m) <= tol2 - 0.5 * (c - a)) break;
-            double u;
-            bool use_par = false;
-            if (fabs(e) > tol1) {
-                double pq = (x - v) * ((x - w) * (fx - fv)) - (x - w) * ((x - v) * (fx - fw));
-                double q = 2.0 * (((x - v) * (fx - fw)) - ((x - w) * (fx - fv)));
-                if (q > 0.0)
-                    pq = -pq;
-                else
-                    q = -q;
-                bool ok = false;
-                if (fabs(q) > eps) {
-                    const double sstep = pq / q;
-                    u = x + sstep;
-                    if ((u - a) >= tol2 && (c - u) >= tol2 && fabs(sstep) < 0.5 * fabs(e)) ok = true;
-                }
-                if (ok) {
-                    d = pq / q;
-                    u = x + d;
-                    if ((u - a) < tol2 || (c - u) < tol2) d = (x < m) ? tol1 : -tol1;
-                    use_par = true;
-                }
-            }
-            if (!use_par) {
-                e = (x < m) ? (c - x) : (a - x);
-                d = 0.3819660 * e;
-            }
-            if (fabs(d) < tol1) d = (d >= 0.0) ? tol1 : -tol1;
-            u = x + d;
-            const double fu = objective(u);
-            ++evals;
-            if (fu <= fx) {
-                if (u >= x)
-                    a = x;
-                else
-                    c = x;
-                v = w;
-                fv = fw;
-                w = x;
-                fw = fx;
-                x = u;
-                fx = fu;
-            } else {
-                if (u >= x)
-                    c = u;
-                else
-                    a = u;
-                if (fu <= fw || w == x) {
-                    v = w;
-                    fv = fw;
-                    w = u;
-                    fw = fu;
-                } else if (fu <= fv || v == x || v == w) {
-                    v = u;
-                    fv = fu;
-                }
+        // ---- Brent (src/math/brent.rs:1-136, verbatim control flow: brent_minimize) ----------------------
+        double x = 0.0;
+        int evals = -1;
+        bool searched = true;
+        if constexpr (INTERP && SPLIT) {
+            if (split.phase == 2) {
+                x = split.xopt[r];
+                if (!(x == x)) continue;                  // not a row of the split form (the one-kernel form wrote it)
+                searched = false;
             }
         }
+        if (searched) brent_minimize(objective, low, high, tol_in, max_iter, have_last, last, x, evals);
         if (chain_off) {
             last = x;
             have_last = true;
@@ -1073,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (MAXD <= 2 ? 4 : 2))) void
             }
         }
         if (lane == 0) {
-            if (evals_out) evals_out[r] = evals;
+            if (evals_out && evals >= 0) evals_out[r] = evals;
             if (isfinite(beta) && isfinite(se) && se > 0.0) {
                 const double z = beta / se;
                 double pv = 2.0 * (0.5 * jx_erfc(fabs(z) / 1.4142135623730951));
@@ -1858,8 +1986,72 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<8, NWI, false, true, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<8, 1, false, true, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                JX_HIP(hipFuncSetAttribute((const void *)lmm_scan_fast_kernel<8, NWI, false, true, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_i = true;
             }
+        }
+        // chains: three launches (ChainSplit) unless JXGPU_SCAN_CHAIN_SPLIT=0
+        const bool split_on = chain && !(getenv("JXGPU_SCAN_CHAIN_SPLIT") && atoi(getenv("JXGPU_SCAN_CHAIN_SPLIT")) == 0);
+        if (split_on) {
+            series_pool_keep();
+            ChainSplit sp;
+            if (getenv("JXGPU_SCAN_CHAIN_FORCE_DIRECT")) sp.force_row = atoi(getenv("JXGPU_SCAN_CHAIN_FORCE_DIRECT"));
+            int32_t *cflag = nullptr;
+            const size_t b_ic = sizeof(double) * (size_t)nrows * SR_M, b_x = sizeof(double) * (size_t)nrows;
+            const size_t b_rf = (sizeof(int32_t) * (size_t)nrows + 255) & ~(size_t)255;
+            char *blk = nullptr;
+            JX_HIP(hipMallocAsync((void **)&blk, b_ic + b_x + b_rf + sizeof(int32_t) * (size_t)nchains, st));
+            sp.icoef = (double *)blk;
+            sp.xopt = (double *)(blk + b_ic);
+            sp.rflag = (int32_t *)(blk + b_ic + b_x);
+            cflag = (int32_t *)(blk + b_ic + b_x + b_rf);
+            JX_HIP(hipMemsetAsync(sp.xopt, 0xff, b_x, st));                       // NaN: not a row of the split form
+            const size_t lds_row = sizeof(double) * ((size_t)CH_N * IP_CP + 1 + ncoef_pad +
+                                                     (size_t)NWI * (2 * (size_t)(maxd_use + 1) * SR_M + 2 * SR_M));
+            const size_t lds_chain = lds;
+            if (lds_row > 160 * 1024) return fail("jxg_lmm_series_brent_tab: the interpolant form's tables do not fit LDS");
+            const int grid_row = (nrows + NWI - 1) / NWI;
+            const int32_t *no_chain = nullptr;
+            double *no_carry = nullptr;
+#define JX_SPLIT_ROWS(MAXDV, PHASE)                                                                                        \
+    do {                                                                                                                  \
+        ChainSplit spp = sp;                                                                                              \
+        spp.phase = PHASE;                                                                                                \
+        hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, NWI, false, true, true, true>), dim3(grid_row), dim3(NWI * 64), lds_row, st, d_grot, \
+                           nrows, n, d_s, d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, 0, 0.0, with_plrt, nullml,    \
+                           d_out, d_evals, scoef, sssq, shd, no_chain, 0, no_carry, spp);                                       \
+        JX_LAUNCH_CHECK();                                                                                                \
+    } while (0)
+#define JX_SPLIT_REST(MAXDV)                                                                                               \
+    do {                                                                                                                  \
+        ChainSplit spp = sp;                                                                                              \
+        spp.phase = 0;                                                                                                    \
+        spp.cflag = cflag;                                                                                                \
+        hipLaunchKernelGGL((lmm_scan_fast_kernel<MAXDV, 1, false, true, true, true>), dim3(gridi), dim3(64), lds_chain, st, d_grot, nrows, n, \
+                           d_s, d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt, nullml, \
+                           d_out, d_evals, scoef, sssq, shd, chain_off, nchains, carry, spp);                                   \
+        JX_LAUNCH_CHECK();                                                                                                \
+    } while (0)
+#define JX_SPLIT_ALL(MAXDV)                                                                                                \
+    do {                                                                                                                  \
+        JX_SPLIT_ROWS(MAXDV, 1);                                                                                          \
+        hipLaunchKernelGGL(chain_interp_brent_kernel, dim3(nchains), dim3(64), 0, st, sp.icoef, sp.rflag, chain_off, nchains, carry, \
+                           cflag, sp.xopt, d_evals, shd, low, high, tol, max_iter);                                             \
+        JX_LAUNCH_CHECK();                                                                                                \
+        JX_SPLIT_REST(MAXDV);                                                                                             \
+        JX_SPLIT_ROWS(MAXDV, 2);                                                                                          \
+    } while (0)
+            if (dim <= 2) JX_SPLIT_ALL(2);
+            else if (dim <= 4) JX_SPLIT_ALL(4);
+            else JX_SPLIT_ALL(8);
+#undef JX_SPLIT_ALL
+#undef JX_SPLIT_REST
+#undef JX_SPLIT_ROWS
+            JX_HIP(hipFreeAsync(blk, st));
+            return 0;
         }
 #define JX_SERIES_INTERP(MAXDV)                                                                                            \
     do {                                                                                                                  \
@@ -1960,7 +2152,7 @@ static int lmm_scan_tab_impl(const float *d_grot, int nrows, int n, const double
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
                                nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd, chain_off, nchains,
-                               carry);
+                               carry, ChainSplit());
         } else {
             constexpr int NW = 8;
             auto kfn = lmm_scan_fast_kernel<4, NW, true>;
@@ -1974,7 +2166,7 @@ static int lmm_scan_tab_impl(const float *d_grot, int nrows, int n, const double
             hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, d_grot, nrows, n, d_s,
                                d_xcov, yc, p, hd, coef, smin, low, high, tol, max_iter, warm, init_log10_lbd, with_plrt,
                                nullml, d_out, d_evals, (const double *)nullptr, (const double *)nullptr, hd, chain_off, nchains,
-                               carry);
+                               carry, ChainSplit());
         }
         JX_LAUNCH_CHECK();
         return 0;

@@ -78,7 +78,8 @@ SWITCHES = {
         "JXGPU_STEDC_OWNLEAF": "untested", "JXGPU_STEDC_PAR": "untested", "JXGPU_STEDC_PARMIN": "untested", "JXGPU_SY2SB_LOOKAHEAD": "untested",
         "JXGPU_SYTRD_KT": "untested", "JXGPU_SYTRD_SYR2K": "untested", "JXGPU_SYTRD_TAIL": "untested", "JXGPU_SYTRD_TARGET": "untested",
         "JXGPU_DSYMM_SLOTS": "untested", "JXGPU_DSYMM_SPLIT": "untested", "JXGPU_ORMTR_NB": "untested",
-        "JXGPU_ROT_I8_DMA": "test_int8_rotation_forms_give_the_same_bits"}.items()},
+        "JXGPU_ROT_I8_DMA": "test_int8_rotation_forms_give_the_same_bits",
+        "JXGPU_SCAN_CHAIN_SPLIT": "test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows"}.items()},
     # ---- ablation masks (wrong results by design: timing experiments only) --------------------------------------------------------
     "JXGPU_QB_SKIP": ("test", "unset", "skips parts of the Q2 kernel (timing ablation; results are WRONG)", "test_q2_staggered_units_equal_lockstep (the lockstep value 64 only)"),
     "JXGPU_BC_SKIP": ("test", "unset", "bulge-chasing ablation (results WRONG)", "untested"),
@@ -93,6 +94,8 @@ SWITCHES = {
     "JXGPU_DIST_EIGH_TEST_DISAGREE": ("test", "unset", "fault injection of the replica agreement check", "test_distributed_eigh_two_ranks_share_one_gpu"),
     "JXGPU_DIST_EIGH_TEST_DISAGREE2": ("test", "unset", "fault injection of the replica agreement check", "test_distributed_eigh_two_ranks_share_one_gpu"),
     "JXGPU_PCG_TEST_FAIL": ("test", "unset", "fault injection of the marker-sharded PCG", "test_marker_sharded_pcg_two_ranks_share_one_gpu"),
+    "JXGPU_SCAN_CHAIN_FORCE_DIRECT": ("test", "unset", "row of a chain scan forced onto direct evaluations (its chain takes the one-kernel form)",
+                                      "test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows"),
     "JXGPU_SPLMM_COMPONENT_MAX": ("test", "auto", "component limit of the spectral sparse routes", "test_splmm_giant_component_both_sides_of_the_limit"),
     "JXGPU_SPGRM_PANEL_ROWS": ("test", "auto", "row panels of the sparse-GRM builder", "test_sparse_grm_row_panels_write_the_same_file"),
 }

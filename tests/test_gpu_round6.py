@@ -524,6 +524,29 @@ def test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows(oracle_c, ch
                                  b_off.data_ptr(), 2, carry2[3:].data_ptr(), 0, 0.0, out2[400:].data_ptr(), None, st))
         assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy(), equal_nan=True), fn
         assert torch.equal(carry2, carry)
+        if fn == "jxg_lmm_scan_chain":
+            # the chain scan in three launches (interpolants of all rows / Brent along the chains / final evaluations of all
+            # rows) against the one-kernel form, and with a row forced onto direct evaluations (its chain then takes the
+            # one-kernel form, the others the split form): the same bits, evaluation counts and carried states
+            for env in ({"JXGPU_SCAN_CHAIN_SPLIT": "0"}, {"JXGPU_SCAN_CHAIN_FORCE_DIRECT": "350"},
+                        {"JXGPU_SCAN_CHAIN_FORCE_DIRECT": "5"}):
+                old_env = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)
+                try:
+                    carry3 = torch.full((len(co) - 1,), init, dtype=torch.float64, device=dev)
+                    out3 = torch.zeros((900, 3), dtype=torch.float64, device=dev)
+                    ev3 = torch.zeros(900, dtype=torch.int32, device=dev)
+                    check(lib().jxg_lmm_scan_chain(d_g.data_ptr(), 900, n, d_s.data_ptr(), d_x.data_ptr(), d_y.data_ptr(), p, lo, hi,
+                                                   1e-2, 30, d_co.data_ptr(), len(co) - 1, carry3.data_ptr(), 0, 0.0,
+                                                   out3.data_ptr(), ev3.data_ptr(), st))
+                finally:
+                    for k, v in old_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                assert np.array_equal(out3.cpu().numpy(), out.cpu().numpy(), equal_nan=True), env
+                assert torch.equal(ev3, ev) and torch.equal(carry3, carry), env
 
 
 @pytest.mark.gpu

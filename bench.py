@@ -820,7 +820,8 @@ def main():
         tr_grm, tr_grm_src = pmc_traffic_bytes("jx::" + grm_kernel)
         mu_grm, mu_grm_src = pmc_mfma_util(grm_kernel)
         rot_i8 = float(lib().jxg_last_kernel_ms(13)) > 0.5      # exact design rows rotated on the int8 planes (k_rotate_i8.hip)
-        rot_kernel = "rotate_i8_kernel" if rot_i8 else ("rotate256_kernel" if n >= 4096 else "rotate_f16x2_kernel")
+        # "rotate_i8_": rotate_i8_dma_kernel (round 6, the default) or rotate_i8_kernel -- whichever the newest committed pass holds
+        rot_kernel = "rotate_i8_" if rot_i8 else ("rotate256_kernel" if n >= 4096 else "rotate_f16x2_kernel")
         rot_peak = MFMA_I8_PEAK_TOPS if rot_i8 else MFMA_F16_PEAK_TFLOPS
         mu_rot, mu_rot_src = pmc_mfma_util(rot_kernel)
         tr_rot, tr_rot_src = pmc_traffic_bytes("jx::" + rot_kernel)
@@ -918,7 +919,7 @@ def main():
                              "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES share of SIMD cycles (own rocprofv3 --pmc pass, "
                                                "profiles/*_pmc_mfma.json): the fraction of time the matrix pipes are busy",
                              "avg_launch_ms": kern["grm_ms"] / L},
-            "roofline_rotate": {"bound": "mfma", "kernel": rot_kernel, "achieved": rot_tflops,
+            "roofline_rotate": {"bound": "mfma", "kernel": ("rotate_i8_dma_kernel" if rot_i8 else rot_kernel), "achieved": rot_tflops,
                                 "peak": rot_peak, "unit": "TFLOP/s", "frac": rot_tflops / rot_peak,
                                 "mfma_util_pmc": mu_rot, "mfma_util_source": mu_rot_src,
                                 "traffic": tr_rot, "traffic_source": tr_rot_src,
@@ -1017,7 +1018,7 @@ def main():
                 leg = run_leg(20000, 200000, 0.01, 2, 1)
                 sm = leg_summary(leg, 20000, 2)
                 mu_g, mu_g_src = pmc_mfma_util("grm_i8_kernel", "mfma_missing1pct")
-                mu_r, mu_r_src = pmc_mfma_util("rotate_i8_kernel", "mfma_missing1pct")
+                mu_r, mu_r_src = pmc_mfma_util("rotate_i8_", "mfma_missing1pct")
                 res["roofline_grm_missing1pct"] = dict(sm["roofline_grm"], kernel="grm_i8_kernel<LUT> x 2 (SNPs with missing calls: "
                                                        "the missing call's count in two int8 digits, two int8 Gram products with "
                                                        "per-SNP byte LUTs, exact diagonal; csrc/k_grm.hip dense missing-call path)",
@@ -1031,7 +1032,7 @@ def main():
                                                             "so 0.5 x the clean kernel's fraction is the ceiling of this form "
                                                             "(rounds 2 - 3: fp16 three-product kernel 229 ms, sparse correction 165 ms)")
                 res["roofline_rotate_missing1pct"] = dict(sm["roofline_rotate"],
-                                                          kernel="rotate_i8_kernel<0> + rotate_i8_kernel<1> (every row has missing calls "
+                                                          kernel="rotate_i8_dma_kernel<0> + <1> (every row has missing calls "
                                                                  "at this rate: the count operand and the indicator of the missing "
                                                                  "calls against the three int8 planes of U, exact; the fp16 hi/lo "
                                                                  "kernel until round 4)",

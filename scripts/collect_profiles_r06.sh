@@ -30,7 +30,7 @@ fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c4" ]; then
   mkdir -p $O/c4; rm -rf $O/c4/*
   B4="python3 bench.py --samples 50000 --snps 500000 --steps 1 --warmup 0 --no-cpu-baseline --no-extra"
-  RX="sbback_apply|grm_i8_kernel|rotate_i8_kernel"
+  RX="sbback_apply|grm_i8_kernel|rotate_i8_"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4/stats -- $B4 > $O/c4_stats.log 2>&1
   rm -f $O/c4/stats/*/*kernel_trace.csv
   for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do

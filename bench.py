@@ -363,6 +363,8 @@ def headline_record(res):
     do = res.get("dist_overhead")
     if isinstance(do, dict) and "error" not in do:
         out["dist_overhead_ms"] = {k: _num(v, 5) for k, v in (do.get("delta_ms") or {}).items() if v is not None}
+    if isinstance(res.get("one_gpu_same_workload"), dict):
+        out["one_gpu_same_workload"] = {k: (_num(v) if k != "source" else str(v)[:120]) for k, v in res["one_gpu_same_workload"].items()}
     out["detail"] = "gpurun_out/bench_detail.json"
     line = json.dumps(out, allow_nan=False)
     if len(line) >= HEADLINE_MAX_BYTES:     # never let an over-long line cost the round's record again: drop the optional parts
@@ -376,6 +378,27 @@ def headline_record(res):
         out["stages_ms_per_step"] = {k: st[k] for k in ("prep", "grm", "eigh", "null", "scan") if k in st}
         line = json.dumps(out, allow_nan=False)
     return out, line
+
+
+def one_gpu_same_workload(n, m, mode):
+    """The committed ONE-GPU measurement of the shape a multi-rank run times (its default is BASELINE configs[3]; the N = 1 default is
+    configs[2], so the N = 1 `value` is NOT the baseline of the N > 1 ones): the leg of the newest profiles/*_bench_default.json that
+    ran this shape on one MI355X.  None when no such record is committed."""
+    import glob
+    if mode != "lmm":
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_default.json")), reverse=True):
+        try:
+            rec = json.loads(open(path).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        cfg = rec.get("config", {})
+        if (int(cfg.get("n", -1)), int(cfg.get("m", -1))) == (int(n), int(m)) and int(rec.get("n_gpus", 0)) == 1:
+            return {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "source": os.path.relpath(path, ROOT) + " (headline)"}
+        leg = (rec.get("legs") or {}).get("c4_1gpu")
+        if leg and (int(n), int(m)) == (50000, 500000):
+            return {"value": leg["value"], "ms_per_step": leg["ms_per_step"], "source": os.path.relpath(path, ROOT) + " legs.c4_1gpu"}
+    return None
 
 
 def emit(res):
@@ -746,8 +769,10 @@ def main():
             op_bytes = 2.0 * n_tr * float(m5) / 4.0            # both images of the training payload once per application
             iters = max(iters, 1.0)
             _PMC_SHAPE.update(n=n5, m=m5)
-            tr_a, tr_a_src = pmc_traffic_bytes("jx::packed_dot_t32_kernel")
-            tr_b, tr_b_src = pmc_traffic_bytes("jx::packed_tdot_f32_kernel")
+            # the int8 forms of round 6 (k_pcg_i8.hip); the table forms when JXGPU_PCG_I8=0
+            i8_op = os.environ.get("JXGPU_PCG_I8", "1") != "0"
+            tr_a, tr_a_src = pmc_traffic_bytes("jx::pi_dot_kernel" if i8_op else "jx::packed_dot_t32_kernel")
+            tr_b, tr_b_src = pmc_traffic_bytes("jx::pi_tdot_kernel" if i8_op else "jx::packed_tdot_f32_kernel")
             _PMC_SHAPE.update(n=int(args.n), m=int(args.m))
             out["extra_c5_pcg"] = {
                 "workload": wl + f", jx gs -rrBLUP -rr-solver pcg: rrblup_pcg_bed with {n_tr} training / {n5 - n_tr} test samples, "
@@ -758,8 +783,10 @@ def main():
                                        "operator_kernels": op_ms, "predictions_and_rest": (t1 - t0) * 1e3 - setup_ms - loop_ms,
                                        "he_pcg_bed": (t2 - t1) * 1e3, "he_operator_kernels": he_ms},
                 "he": {"sigma_g2": h[0], "sigma_e2": h[1], "h2": h[2], "operator_applications": int(he_apps)},
-                "roofline": {"bound": "hbm", "kernel": "packed_dot_t32_kernel (Z'p, sample-major image) + packed_tdot_f32_kernel "
-                                                       "(Z (Z'p), SNP-major image): one operator application",
+                "roofline": {"bound": "hbm", "kernel": ("pi_dot_kernel (Z'p, sample-major image) + pi_tdot_kernel (Z (Z'p), SNP-major "
+                                                        "image), int8 MFMA on bit planes" if i8_op else
+                                                        "packed_dot_t32_kernel (Z'p, sample-major image) + packed_tdot_f32_kernel "
+                                                        "(Z (Z'p), SNP-major image)") + ": one operator application",
                              "achieved": op_bytes * iters / max(op_ms, 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": op_bytes * iters / max(op_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
                              "avg_application_ms": op_ms / iters, "applications": int(iters),
@@ -768,8 +795,8 @@ def main():
                              "traffic_over_algorithmic": ((tr_a + tr_b) / op_bytes) if (tr_a and tr_b) else None,
                              "note": "algorithmic bytes per operator application = 2 x n_train x m / 4 (the 2-bit payload of the "
                                      "training samples once per half of (Z_c Z_c' + lambda I) p); duration = HIP events around the "
-                                     "two streaming kernels on the launch stream, summed over the iterations (jxg_last_kernel_ms 20); "
-                                     "both kernels are instruction-bound bit-plane table kernels (DESIGN.md 3.6), not HBM-bound; "
+                                     "two halves (vector quantisation + streaming kernel each) on the launch stream, summed over the "
+                                     "iterations (jxg_last_kernel_ms 20); DESIGN.md 3.6; "
                                      "traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the two kernels from the committed pass of "
                                      "this shape (null when none)"},
                 "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2**30}
@@ -1190,6 +1217,10 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        if world > 1:
+            og = one_gpu_same_workload(n, args.m, args.mode)
+            if og:
+                res["one_gpu_same_workload"] = og
         emit(res)
     if distributed:
         dist.destroy_process_group()

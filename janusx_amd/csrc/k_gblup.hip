@@ -567,10 +567,20 @@ extern "C" int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, con
     return 0;
 }
 
+namespace jx {
+// k_pcg_i8.hip: the same two products on the int8 matrix pipes (exact plane sums of a four-digit image of the vector)
+bool pcg_i8_enabled(int n, int nrows);
+int packed_tdot_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, const float *d_lut,
+                   const double *d_u, double *d_out);
+int packed_dot_t32_i8(hipStream_t st, const uint8_t *d_t32, int n, int nrows, const float *d_lut, const double *d_beta, void *d_work,
+                      double *d_out);
+}  // namespace jx
+
 extern "C" int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                                    const float *d_lut, const double *d_u, double *d_out, void *stream) {
     if (nrows <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (pcg_i8_enabled(n, nrows)) return packed_tdot_i8(st, d_p32, m_total, n, d_rows, nrows, d_lut, d_u, d_out);
     JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)nrows, st));
     dim3 grid((nrows + 256 * PT_RPT - 1) / (256 * PT_RPT), (n + 127) / 128);
     hipLaunchKernelGGL(packed_tdot_f32_kernel, grid, dim3(256), 0, st, d_p32, m_total, d_rows, nrows, d_lut, d_u, n,
@@ -596,6 +606,7 @@ extern "C" int jxg_packed_dot_t32(const uint8_t *d_t32, int n, int nrows, const 
                                   void *d_work, double *d_out, void *stream) {
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (nrows > 0 && pcg_i8_enabled(n, nrows)) return packed_dot_t32_i8(st, d_t32, n, nrows, d_lut, d_beta, d_work, d_out);
     JX_HIP(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)n, st));
     if (nrows <= 0) return 0;
     float4 *wq = (float4 *)d_work;

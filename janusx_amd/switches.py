@@ -36,6 +36,8 @@ SWITCHES = {
                              "test_rotation_rows_with_a_few_missing_calls_take_the_exact_path"),
     "JXGPU_ROT_MISS_MAX": ("numerics", "auto", "missing calls per row up to which the gather form is taken",
                            "test_rotation_rows_with_a_few_missing_calls_take_the_exact_path"),
+    "JXGPU_PCG_I8": ("numerics", "1", "0: the PCG / HE operator halves on the f32 bit-plane table kernels (f32 partial sums per tile) instead of "
+                     "exact int8 plane sums of a four-digit image of the vector", "test_pcg_operator_forms_agree"),
     "JXGPU_FVLMM_FUSED": ("numerics", "1", "0 / 2: unfused / always-fused fixed-lambda scan (f64 sums in a different order + f32 G~ round trip)",
                           "test_fixed_lambda_scan_fused_into_the_rotation_epilogue"),
     "JXGPU_SCAN_EXACT": ("numerics", "unset", "reference-formulation scan kernel instead of the tabulated one (1e-9 apart)",

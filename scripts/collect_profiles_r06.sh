@@ -44,7 +44,7 @@ fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "c5" ]; then
   mkdir -p $O/c5; rm -rf $O/c5/*
   B5="python3 bench.py --leg c5_pcg"
-  RX5="packed_dot_t32_kernel|packed_tdot_f32_kernel"
+  RX5="pi_dot_kernel|pi_tdot_kernel"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5/stats -- $B5 > $O/c5_stats.log 2>&1
   rm -f $O/c5/stats/*/*kernel_trace.csv
   for pass in fetch:FETCH_SIZE write:WRITE_SIZE; do

@@ -571,3 +571,58 @@ def test_int8_rotation_forms_give_the_same_bits(n, m, missing):
         if missing > 0:
             assert int(re.search(r"with_missing_term=(\d+)", line).group(1)) > 0
     assert digests["0"] == digests["1"], digests
+
+
+@pytest.mark.gpu
+def test_pcg_operator_forms_agree():
+    """The two halves of the matrix-free PCG / HE operator (`jxg_packed_tdot_f32`: Z u over the SNP-major image, `jxg_packed_dot_t32`:
+    Z'p over the sample-major image) in their two forms -- int8 MFMA on the bit planes against a four-digit image of the vector
+    (k_pcg_i8.hip, the default) and the f32 bit-plane tables (JXGPU_PCG_I8=0) -- against a dense f64 decode: ragged sizes, 3 % missing
+    calls, arbitrary per-SNP tables, weights over four decades, and a row list.  The int8 form is exact in its sums (what is left is
+    the f32 rounding of the vector / of the per-SNP weights the reference's f32 operator carries as well)."""
+    import torch
+    import bench
+    from janusx_amd import pipeline
+    from janusx_amd._lib import check, lib
+    n, m = 5003, 20011
+    dev = torch.device("cuda", 0)
+    packed, _ = bench.synth_panel_gpu(n, m, 7, dev, missing_rate=0.03)
+    p = pipeline.Panel(packed, n, None)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    lut = torch.randn((m, 4), device=dev, dtype=torch.float32, generator=g)
+    beta = torch.randn(m, device=dev, dtype=torch.float64, generator=g) * torch.exp(2 * torch.randn(m, device=dev, dtype=torch.float64, generator=g))
+    alpha = torch.randn(n, device=dev, dtype=torch.float64, generator=g)
+    pk = packed.to(torch.int64)
+    codes = torch.stack([(pk >> (2 * k)) & 3 for k in range(4)], dim=2).reshape(m, -1)[:, :n]
+    z = torch.gather(lut.to(torch.float64), 1, codes)
+    ref_t = z @ alpha.to(torch.float32).to(torch.float64)
+    ref_d = torch.gather((lut * beta.to(torch.float32)[:, None]).to(torch.float64), 1, codes).sum(0)
+    rows = torch.arange(m - 1, -1, -3, device=dev, dtype=torch.int32)[:6000].contiguous()         # a descending row list
+    ref_tr = ref_t[rows.long()]
+    t32 = torch.empty(int(lib().jxg_t32_bytes(n, m)), dtype=torch.uint8, device=dev)
+    work = torch.empty(16 * m + 16, dtype=torch.uint8, device=dev)
+    check(lib().jxg_p32_transpose(p.p32.data_ptr(), p.m, n, None, m, t32.data_ptr(), st))
+    errs = {}
+    old = os.environ.get("JXGPU_PCG_I8")
+    try:
+        for form in ("1", "0"):
+            os.environ["JXGPU_PCG_I8"] = form
+            om = torch.full((m,), float("nan"), device=dev, dtype=torch.float64)
+            on = torch.full((n,), float("nan"), device=dev, dtype=torch.float64)
+            orr = torch.full((len(rows),), float("nan"), device=dev, dtype=torch.float64)
+            check(lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, None, m, lut.data_ptr(), alpha.data_ptr(), om.data_ptr(), st))
+            check(lib().jxg_packed_dot_t32(t32.data_ptr(), n, m, lut.data_ptr(), beta.data_ptr(), work.data_ptr(), on.data_ptr(), st))
+            check(lib().jxg_packed_tdot_f32(p.p32.data_ptr(), p.m, n, rows.data_ptr(), len(rows), lut[rows.long()].contiguous().data_ptr(),
+                                            alpha.data_ptr(), orr.data_ptr(), st))
+            torch.cuda.synchronize()
+            errs[form] = (float((ref_t - om).abs().max() / ref_t.abs().max()), float((ref_d - on).abs().max() / ref_d.abs().max()),
+                          float((ref_tr - orr).abs().max() / ref_tr.abs().max()))
+    finally:
+        if old is None:
+            os.environ.pop("JXGPU_PCG_I8", None)
+        else:
+            os.environ["JXGPU_PCG_I8"] = old
+    assert errs["1"][0] < 5e-9 and errs["1"][2] < 5e-9 and errs["1"][1] < 2e-7, errs
+    assert max(errs["0"]) < 2e-6, errs

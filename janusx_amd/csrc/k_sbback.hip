@@ -48,9 +48,14 @@ __device__ __forceinline__ void qb_support(int n, int s, int k, int &r, int &len
 // 16 MFMAs for its rows of the update; only the V / U operands are read from LDS (swizzled images, conflict-free).
 constexpr int QR_BLK = QB_WIN * QB_G;      // doubles of one V (or U) image: [q][m], m contiguous and swizzled
 // The images are copied to LDS verbatim (LDS-DMA: one contiguous KB per wave instruction), so the bank swizzle is part
-// of the memory layout: element (q, m) of V sits at q * 32 + (m ^ (2 (q & 15))), of U at q * 32 + (m ^ (16 ((q >> 1) & 1))):
+// of the memory layout: element (q, m) of V sits at q * 32 + (m ^ qr_v_swz(q)), of U at q * 32 + (m ^ (16 ((q >> 1) & 1))):
 // the A-operand reads of both products (16 rows x 2 columns, resp. 2 rows x 16 columns per half wave) touch every bank once.
-__host__ __device__ __forceinline__ int qr_v_at(int q, int m) { return q * QB_G + (m ^ (2 * (q & 15))); }
+// V: the compiler pairs the two 16-row halves' reads into ds_read2st64_b64 (16-lane groups, banks mod 32) and leaves the reads next to
+// a zero tile as ds_read_b64 (32-lane groups, banks mod 64): the term q & 15 spreads the 16 rows of a lane group over the 16 bank
+// pairs, the term (q & 1) << 4 keeps the two column parities of a 32-lane group apart (rounds 3 - 5 used m ^ 2 (q & 15): free of
+// conflicts for ds_read_b64 only -- 4.0e9 of the kernel's 1.28e10 LDS cycles per launch were conflict cycles, SQ_LDS_BANK_CONFLICT)
+__host__ __device__ __forceinline__ int qr_v_swz(int q) { return (q & 15) ^ ((q & 1) << 4); }
+__host__ __device__ __forceinline__ int qr_v_at(int q, int m) { return q * QB_G + (m ^ qr_v_swz(q)); }
 __host__ __device__ __forceinline__ int qr_u_at(int q, int m) { return q * QB_G + (m ^ (16 * ((q >> 1) & 1))); }
 
 // Zero tiles of the images (a reflector of sweep s0 + i covers the window rows i + 1 .. i + 64; column j of U = V T' starts at
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(NU * 192 + 64) void sbback_apply_reg_kernel(QrParam
                     constexpr int WC = decltype(wc)::value;
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) {
-                        const int m = (4 * ks + lk) ^ (2 * rm_a);
+                        const int m = (4 * ks + lk) ^ qr_v_swz(rm_a);
                         if (!qr_v_tile_zero(WC, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
                         if (!qr_v_tile_zero(WC, 1, ks))
                             cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
@@ -571,7 +576,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_solo_kernel(QrPara
                 const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const int m = (4 * ks + lk) ^ (2 * rm_a);
+                    const int m = (4 * ks + lk) ^ qr_v_swz(rm_a);
                     if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
                     if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
                 }
@@ -776,7 +781,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void sbback_apply_pair_kernel(QrPara
             const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const int m = (4 * ks + lk) ^ (2 * rm_a);
+                const int m = (4 * ks + lk) ^ qr_v_swz(rm_a);
                 if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
                 if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
             }
@@ -997,7 +1002,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
         };
         // LDS addresses of the V operands: the bank swizzle of the image (qr_v_at) depends on the lane only, not on the 16-row half
         // hh of the window: eight lane terms + hh * 512 doubles as an immediate offset
-        const int vsw = 2 * (4 * blk + x);
+        const int vsw = qr_v_swz(4 * blk + x);
         int voff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) voff[i] = (4 * blk + x) * QB_G + ((4 * i + kq) ^ vsw);       // V[q = 16 hh + 4 blk + x][m = 4 ks + kq]
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(512) void sbback_apply_bal_kernel(QrParams P) {
             const double *vp = vl + buf * QR_BLK + (32 * w + rm_a) * QB_G;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const int m = (4 * ks + lk) ^ (2 * rm_a);
+                const int m = (4 * ks + lk) ^ qr_v_swz(rm_a);
                 if (!qr_v_tile_zero(w, 0, ks)) cw[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[m], yn[ks], cw[0], 0, 0, 0);
                 if (!qr_v_tile_zero(w, 1, ks)) cw[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(vp[16 * QB_G + m], yn[ks], cw[1], 0, 0, 0);
             }

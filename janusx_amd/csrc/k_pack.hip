@@ -2,6 +2,8 @@
 // Reference semantics: src/math/bedmath.rs:20-27 (codes), src/io/gfreader.rs:1378-1395 (counts).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "jx_common.h"
 
 namespace jx {
@@ -45,6 +47,109 @@ __global__ __launch_bounds__(256) void repack_p32_kernel(const uint8_t *__restri
             w |= byte << (8 * b);
         }
     } else {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int s = s0 + i;
+            uint32_t code = 1u;  // missing
+            if (s < n_sel) {
+                const int sid = sample_idx[s];
+                code = (row[sid >> 2] >> (2 * (sid & 3))) & 3u;
+            }
+            w |= code << (2 * i);
+        }
+    }
+    dst[gid] = w;
+}
+
+// ---- sample subsets: window form ------------------------------------------------------------------------------------------
+// With a sample list the kernel above gathers every code on its own: 16 index loads + 16 byte loads per output dword, 0.34 TB/s
+// (151 ms for the 40 GB training image of BASELINE configs[4]).  The 16 samples of an output dword are the same for every SNP, and
+// for any dense subset (CV folds, a phenotyped subset) they sit inside a few source bytes: one DESCRIPTOR per (tile, dword) -- first
+// source byte and the 16 positions relative to it, built once per call -- turns the gather into three dword loads of the row and 16
+// shifts of a 64-bit window.  Dwords whose samples span more than 8 source bytes keep the gather (descriptor b0 = -1).
+struct RpDesc {
+    int32_t b0;          // first source byte of the window, -1: gather
+    uint32_t valid;      // bit i: sample s0 + i < n_sel
+    uint32_t rel[4];     // byte i: 2-bit position of sample i inside the window (sid - 4 b0)
+    uint32_t pad[2];
+};
+static_assert(sizeof(RpDesc) == 32, "RpDesc is two 16-byte loads");
+
+__global__ __launch_bounds__(256) void repack_desc_kernel(const int32_t *__restrict__ sample_idx, int n_sel, int nt, RpDesc *__restrict__ desc) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= nt * 8) return;
+    const int s0 = (id >> 3) * JXG_TILE + (id & 7) * 16;
+    int lo = 0x7fffffff, hi = -1;
+    uint32_t valid = 0;
+    int sid[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sid[i] = 0;
+        if (s0 + i < n_sel) {
+            sid[i] = sample_idx[s0 + i];
+            valid |= 1u << i;
+            lo = min(lo, sid[i] >> 2);
+            hi = max(hi, sid[i] >> 2);
+        }
+    }
+    RpDesc d;
+    d.b0 = (valid && hi - lo <= 7) ? lo : -1;
+    d.valid = valid;
+    d.rel[0] = d.rel[1] = d.rel[2] = d.rel[3] = 0;
+    d.pad[0] = d.pad[1] = 0;
+    if (d.b0 >= 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((valid >> i) & 1u) d.rel[i >> 2] |= (uint32_t)(sid[i] - 4 * lo) << (8 * (i & 3));
+    }
+    desc[id] = d;
+}
+
+__global__ __launch_bounds__(256) void repack_p32_window_kernel(const uint8_t *__restrict__ src, int64_t bps,
+                                                                const int32_t *__restrict__ sample_idx, int n_sel,
+                                                                const int64_t *__restrict__ row_idx, int64_t m_out,
+                                                                const RpDesc *__restrict__ desc, uint32_t *__restrict__ dst) {
+    const int64_t per_tile = m_out * 8;
+    const int64_t rem = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= per_tile) return;
+    const int tile = (int)blockIdx.y;
+    const int64_t gid = (int64_t)tile * per_tile + rem;
+    const int64_t j = rem >> 3;
+    const int d = (int)(rem & 7);
+    const int64_t srow = row_idx ? row_idx[j] : j;
+    const uint8_t *row = src + srow * bps;
+    const uint4 *dp = reinterpret_cast<const uint4 *>(desc + (tile * 8 + d));
+    const uint4 d0 = dp[0], d1 = dp[1];       // d0 = (b0, valid, rel0, rel1), d1 = (rel2, rel3, -, -)
+    const int b0 = (int)d0.x;
+    const uint32_t valid = d0.y;
+    uint32_t w = 0;
+    if (b0 >= 0) {
+        const int a0 = b0 & ~3;
+        uint32_t ww[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int off = a0 + 4 * k;
+            uint32_t v = 0;
+            if (off + 4 <= bps) {
+                __builtin_memcpy(&v, row + off, 4);          // rows need not be 4-byte aligned (bps = ceil(n / 4)): one unaligned dword load
+            } else {
+                for (int b = 0; b < 4; ++b)
+                    if (off + b < bps) v |= (uint32_t)row[off + b] << (8 * b);
+            }
+            ww[k] = v;
+        }
+        const int sh = 8 * (b0 & 3);
+        unsigned long long val = (((unsigned long long)ww[1] << 32) | ww[0]) >> sh;
+        if (sh) val |= (unsigned long long)ww[2] << (64 - sh);
+        const uint32_t rel[4] = {d0.z, d0.w, d1.x, d1.y};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t r = (rel[i >> 2] >> (8 * (i & 3))) & 0xffu;
+            const uint32_t code = ((valid >> i) & 1u) ? (uint32_t)(val >> (2 * r)) & 3u : 1u;
+            w |= code << (2 * i);
+        }
+    } else {
+        const int s0 = tile * JXG_TILE + d * 16;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
             const int s = s0 + i;
@@ -154,7 +259,22 @@ extern "C" int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, i
     const int nt = num_tiles(n_sel);
     const int64_t blocks = (m_out * 8 + 255) / 256;
     if (blocks * 256 > 0xffffffffLL || nt > 65535) return fail("jxg_repack_p32: grid too large");
-    hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, (hipStream_t)stream, d_packed, bps,
+    hipStream_t st = (hipStream_t)stream;
+    // sample subsets: the window form (descriptors per output dword position, built here); JXGPU_REPACK_WINDOW=0: the gather
+    const char *we = getenv("JXGPU_REPACK_WINDOW");      // read per call: the two forms are compared inside one process by the tests
+    const bool window = !(we && atoi(we) == 0);
+    if (d_sample_idx && window && m_out >= 64) {
+        RpDesc *desc = nullptr;
+        JX_HIP(hipMallocAsync((void **)&desc, sizeof(RpDesc) * (size_t)nt * 8, st));
+        hipLaunchKernelGGL(repack_desc_kernel, dim3((unsigned)((nt * 8 + 255) / 256)), dim3(256), 0, st, d_sample_idx, n_sel, nt, desc);
+        JX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(repack_p32_window_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, st, d_packed, bps, d_sample_idx,
+                           n_sel, d_row_idx, m_out, desc, (uint32_t *)d_p32);
+        JX_LAUNCH_CHECK();
+        JX_HIP(hipFreeAsync(desc, st));
+        return 0;
+    }
+    hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, st, d_packed, bps,
                        n_src, d_sample_idx, n_sel, d_row_idx, m_out, (uint32_t *)d_p32, nt);
     JX_LAUNCH_CHECK();
     return 0;

@@ -81,7 +81,8 @@ SWITCHES = {
         "JXGPU_SYTRD_KT": "untested", "JXGPU_SYTRD_SYR2K": "untested", "JXGPU_SYTRD_TAIL": "untested", "JXGPU_SYTRD_TARGET": "untested",
         "JXGPU_DSYMM_SLOTS": "untested", "JXGPU_DSYMM_SPLIT": "untested", "JXGPU_ORMTR_NB": "untested",
         "JXGPU_ROT_I8_DMA": "test_int8_rotation_forms_give_the_same_bits",
-        "JXGPU_SCAN_CHAIN_SPLIT": "test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows"}.items()},
+        "JXGPU_SCAN_CHAIN_SPLIT": "test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows",
+        "JXGPU_REPACK_WINDOW": "test_repack_of_a_sample_subset_window_form"}.items()},
     # ---- ablation masks (wrong results by design: timing experiments only) --------------------------------------------------------
     "JXGPU_QB_SKIP": ("test", "unset", "skips parts of the Q2 kernel (timing ablation; results are WRONG)", "test_q2_staggered_units_equal_lockstep (the lockstep value 64 only)"),
     "JXGPU_BC_SKIP": ("test", "unset", "bulge-chasing ablation (results WRONG)", "untested"),

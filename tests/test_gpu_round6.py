@@ -626,3 +626,56 @@ def test_pcg_operator_forms_agree():
             os.environ["JXGPU_PCG_I8"] = old
     assert errs["1"][0] < 5e-9 and errs["1"][2] < 5e-9 and errs["1"][1] < 2e-7, errs
     assert max(errs["0"]) < 2e-6, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sorted80", "shuffled_windows", "sparse10", "duplicates"])
+def test_repack_of_a_sample_subset_window_form(case):
+    """`jxg_repack_p32` with a sample list: the window form (one descriptor per output dword position, three dword loads of the row
+    and 16 shifts of a 64-bit window; k_pack.hip) writes the same image as the per-code gather (JXGPU_REPACK_WINDOW=0) and as a numpy
+    decode -- rows that are not 4-byte aligned (n_src = 5003), a row list, a ragged last tile, subsets too sparse for a window (those
+    dwords keep the gather), samples out of order and repeated."""
+    import torch
+    from janusx_amd._lib import check, lib
+    rng = np.random.default_rng(11)
+    n_src, m = 5003, 700
+    bps = (n_src + 3) // 4
+    packed = rng.integers(0, 256, size=(m, bps), dtype=np.uint8)
+    if case == "sorted80":
+        idx = np.sort(rng.choice(n_src, 4001, replace=False))
+    elif case == "shuffled_windows":
+        idx = np.sort(rng.choice(n_src, 4000, replace=False)).reshape(-1, 8)
+        idx = np.stack([rng.permutation(r) for r in idx]).ravel()
+    elif case == "sparse10":
+        idx = np.sort(rng.choice(n_src, 517, replace=False))
+    else:
+        idx = np.sort(rng.integers(0, n_src, size=3000))
+    idx = idx.astype(np.int32)
+    rows = rng.permutation(m)[:650].astype(np.int64)
+    n_sel = len(idx)
+    nt = (n_sel + 127) // 128
+    codes = (packed[rows][:, idx >> 2] >> (2 * (idx & 3))[None, :]) & 3                    # (650, n_sel)
+    full = np.ones((len(rows), nt * 128), dtype=np.uint8)                                   # padding: code 01
+    full[:, :n_sel] = codes
+    ref = np.zeros((nt, len(rows), 32), dtype=np.uint8)
+    for k in range(4):
+        ref |= (full[:, k::4].reshape(len(rows), nt, 32).transpose(1, 0, 2) << (2 * k)).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_p, d_i, d_r = (torch.from_numpy(a).to(dev) for a in (packed, idx, rows))
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    old = os.environ.get("JXGPU_REPACK_WINDOW")
+    try:
+        for form in ("1", "0"):
+            os.environ["JXGPU_REPACK_WINDOW"] = form
+            out = torch.zeros((nt, len(rows), 32), dtype=torch.uint8, device=dev)
+            check(lib().jxg_repack_p32(d_p.data_ptr(), bps, n_src, m, d_i.data_ptr(), n_sel, d_r.data_ptr(), len(rows), out.data_ptr(), st))
+            torch.cuda.synchronize()
+            outs[form] = out.cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop("JXGPU_REPACK_WINDOW", None)
+        else:
+            os.environ["JXGPU_REPACK_WINDOW"] = old
+    assert np.array_equal(outs["0"], ref)
+    assert np.array_equal(outs["1"], ref)

@@ -71,6 +71,27 @@ constexpr size_t kScratchKeepBytes = (size_t)6 << 30;
 // the block should be a private allocation (slot in use by a concurrent call, or too large to keep).  api.cpp
 int scratch_acquire(int which, size_t bytes, void **p);
 void scratch_release(int which);
+// stream-ordered allocation released behind the work queued on the same stream, on every path out of the scope
+struct AsyncBlock {
+    void *p = nullptr;
+    hipStream_t st = nullptr;
+    AsyncBlock() = default;
+    AsyncBlock(const AsyncBlock &) = delete;
+    AsyncBlock &operator=(const AsyncBlock &) = delete;
+    ~AsyncBlock() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+    int alloc(size_t bytes, hipStream_t s) {
+        st = s;
+        hipError_t e = hipMallocAsync(&p, bytes ? bytes : 16, s);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(std::string("hipMallocAsync(") + std::to_string(bytes) + ") failed: " + hipGetErrorString(e));
+        }
+        return 0;
+    }
+};
+
 struct ScratchLease {
     int which = -1;
     DevBuf own;

@@ -264,14 +264,14 @@ extern "C" int jxg_repack_p32(const uint8_t *d_packed, int64_t bps, int n_src, i
     const char *we = getenv("JXGPU_REPACK_WINDOW");      // read per call: the two forms are compared inside one process by the tests
     const bool window = !(we && atoi(we) == 0);
     if (d_sample_idx && window && m_out >= 64) {
-        RpDesc *desc = nullptr;
-        JX_HIP(hipMallocAsync((void **)&desc, sizeof(RpDesc) * (size_t)nt * 8, st));
+        AsyncBlock ab;
+        if (ab.alloc(sizeof(RpDesc) * (size_t)nt * 8, st)) return 1;
+        RpDesc *desc = (RpDesc *)ab.p;
         hipLaunchKernelGGL(repack_desc_kernel, dim3((unsigned)((nt * 8 + 255) / 256)), dim3(256), 0, st, d_sample_idx, n_sel, nt, desc);
         JX_LAUNCH_CHECK();
         hipLaunchKernelGGL(repack_p32_window_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, st, d_packed, bps, d_sample_idx,
                            n_sel, d_row_idx, m_out, desc, (uint32_t *)d_p32);
         JX_LAUNCH_CHECK();
-        JX_HIP(hipFreeAsync(desc, st));
         return 0;
     }
     hipLaunchKernelGGL(repack_p32_kernel, dim3((unsigned)blocks, (unsigned)nt), dim3(256), 0, st, d_packed, bps,

@@ -332,8 +332,9 @@ int packed_tdot_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n,
                    const double *d_u, double *d_out) {
     const int ntiles = (n + 127) / 128;
     const size_t b_img = (size_t)ntiles * 512;
-    char *blk = nullptr;
-    JX_HIP(hipMallocAsync((void **)&blk, 256 + b_img, st));
+    AsyncBlock ab;
+    if (ab.alloc(256 + b_img, st)) return 1;
+    char *blk = (char *)ab.p;
     PiScalars *sc = (PiScalars *)blk;
     int8_t *img = (int8_t *)(blk + 256);
     JX_HIP(hipMemsetAsync(sc, 0, sizeof(PiScalars), st));
@@ -346,7 +347,6 @@ int packed_tdot_i8(hipStream_t st, const uint8_t *d_p32, int64_t m_total, int n,
     hipLaunchKernelGGL(pi_tdot_kernel, dim3((nrows + PI_WAVES * 16 - 1) / (PI_WAVES * 16)), dim3(PI_WAVES * 64), 0, st, d_p32, m_total,
                        d_rows, nrows, ntiles, img, sc, d_lut, d_out);
     JX_LAUNCH_CHECK();
-    JX_HIP(hipFreeAsync(blk, st));
     return 0;
 }
 
@@ -361,8 +361,9 @@ int packed_dot_t32_i8(hipStream_t st, const uint8_t *d_t32, int n, int nrows, co
     const int tps = (nst + slices - 1) / slices;
     slices = (nst + tps - 1) / tps;
     const size_t b_img = (size_t)nst * 1536, b_part = sizeof(double) * (size_t)slices * (size_t)n;
-    char *blk = nullptr;
-    JX_HIP(hipMallocAsync((void **)&blk, 256 + b_img + b_part, st));
+    AsyncBlock ab;
+    if (ab.alloc(256 + b_img + b_part, st)) return 1;
+    char *blk = (char *)ab.p;
     PiScalars *sc = (PiScalars *)blk;
     int8_t *img = (int8_t *)(blk + 256);
     double *part = (double *)(blk + 256 + b_img);
@@ -376,7 +377,6 @@ int packed_dot_t32_i8(hipStream_t st, const uint8_t *d_t32, int n, int nrows, co
     JX_LAUNCH_CHECK();
     hipLaunchKernelGGL(pi_dot_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, n, slices, sc, d_out);
     JX_LAUNCH_CHECK();
-    JX_HIP(hipFreeAsync(blk, st));
     return 0;
 }
 

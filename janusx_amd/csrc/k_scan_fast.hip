@@ -2002,8 +2002,9 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
             int32_t *cflag = nullptr;
             const size_t b_ic = sizeof(double) * (size_t)nrows * SR_M, b_x = sizeof(double) * (size_t)nrows;
             const size_t b_rf = (sizeof(int32_t) * (size_t)nrows + 255) & ~(size_t)255;
-            char *blk = nullptr;
-            JX_HIP(hipMallocAsync((void **)&blk, b_ic + b_x + b_rf + sizeof(int32_t) * (size_t)nchains, st));
+            AsyncBlock ab;
+            if (ab.alloc(b_ic + b_x + b_rf + sizeof(int32_t) * (size_t)nchains, st)) return 1;
+            char *blk = (char *)ab.p;
             sp.icoef = (double *)blk;
             sp.xopt = (double *)(blk + b_ic);
             sp.rflag = (int32_t *)(blk + b_ic + b_x);
@@ -2050,7 +2051,6 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
 #undef JX_SPLIT_ALL
 #undef JX_SPLIT_REST
 #undef JX_SPLIT_ROWS
-            JX_HIP(hipFreeAsync(blk, st));
             return 0;
         }
 #define JX_SERIES_INTERP(MAXDV)                                                                                            \

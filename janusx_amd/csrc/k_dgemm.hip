@@ -286,6 +286,167 @@ __global__ __launch_bounds__(NT, STREAM ? 2 : (NT == 512 ? 4 : 2)) void dgemm_ke
     }
 }
 
+// ---- rank-2k update of the band reduction as ONE stream of K steps over a workgroup's tiles (round 6) -----------------------------
+// C(lower tiles) = alpha A B' + beta C with A, B stored (x, k) (x contiguous), K a multiple of 16 (the trailing update: K = 128).
+// At K = 128 a 128 x 128 tile is 13.8 us of products between a prologue (first operand step: one memory round trip) and an epilogue
+// that reads and writes the 128 KB of C -- as many HBM cycles as the products take matrix-pipe cycles -- and in dgemm_kernel nothing
+// overlaps the two (0.39 - 0.43 of the f64 peak at one workgroup per CU; a second resident workgroup starved the panel chain on
+// the other stream, round 4).  Here a workgroup walks its tiles as one sequence of K steps: the operand loads of a step are always one
+// step ahead, ACROSS tile boundaries (no prologue bubble), the C values of a tile are requested a strip per step over its first steps
+// (the loads of a wave return in order: all of them in front of the first step put the next step's operands behind 128 KB of C) and
+// consumed behind its last, the stores of the finished tile drain behind the next tile's products.  Same products in the same order,
+// same alpha acc + beta c expression: the same bits as dgemm_kernel.
+__global__ __launch_bounds__(512, 2) void dsyr2k_pipe_kernel(DgemmArgs g) {
+    constexpr int BM = 128, BN = 128, NT = 512;
+    constexpr int PA = BM + 17, PB = BN + 17;
+    constexpr int WM = 32, WN = 64, MB = 2, NB = 4;
+    constexpr int NL = BM * DG_BK / NT;              // 4 elements per thread, operand and step
+    extern __shared__ __attribute__((aligned(16))) double dg_smem[];
+    double *as = dg_smem;                            // [2][16][PA]
+    double *bs = dg_smem + 2 * DG_BK * PA;           // [2][16][PB]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave % 4) * WM, wn = (wave / 4) * WN;
+    const int lx = lane & 15, lk = lane >> 4;
+    // Tiles by XCD: workgroup b runs on XCD b % 8 (round-robin dispatch).  XCD x owns the tile COLUMNS 8 q + (q odd ? 7 - x : x): its
+    // ~T / 8 B panels (128 KB each: 2.5 MB at n = 20 000) stay in its 4 MB L2 for the whole launch and the A panel of the row in
+    // progress is shared by the XCD's workgroups.  The XCD's tiles, row-major, are dealt round-robin to its workgroups
+    // (slot = b / 8 of gridDim.x / 8).
+    const int T = (g.m + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = max(1, (int)gridDim.x >> 3);
+    auto col_of = [&](int j) { return 8 * j + ((j & 1) ? 7 - xcd : xcd); };
+    auto count_of = [&](int row) {
+        const int nb = (row + 1) >> 3;
+        return nb + ((8 * nb <= row && col_of(nb) <= row) ? 1 : 0);
+    };
+    int it_row = 0, it_j = slot, it_p = 0;
+    auto next_tile = [&](int &ti_o, int &tj_o) -> bool {
+        for (;;) {
+            if (it_row >= T) return false;
+            const int cnt = count_of(it_row);
+            if (it_j < cnt) {
+                ti_o = it_row;
+                tj_o = col_of(it_j);
+                it_j += nslot;
+                return true;
+            }
+            it_p += cnt;
+            ++it_row;
+            it_j = ((slot - it_p) % nslot + nslot) % nslot;
+        }
+    };
+    int ti, tj;
+    if (!next_tile(ti, tj)) return;
+    const int nks = g.k / DG_BK;
+    // operand element i of this thread at a step: x = t % 128 (clamped), k = 4 i + t / 128.  Addresses: a per-thread origin per
+    // tile (row x of the panel), the same four 32-bit byte offsets for every step and tile (k rows 4 i + t / 128), and a
+    // wave-uniform byte offset of the step
+    const int xo = t & 127, ko = t >> 7;
+    unsigned offa[NL], offb[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        offa[i] = (unsigned)(8 * (int64_t)(4 * i + ko) * g.lda);
+        offb[i] = (unsigned)(8 * (int64_t)(4 * i + ko) * g.ldb);
+    }
+    const int64_t stepa = 8 * (int64_t)DG_BK * g.lda, stepb = 8 * (int64_t)DG_BK * g.ldb;
+    auto load_step = [&](int m0, int n0, int k0, double (&ra)[NL], double (&rb)[NL]) {
+        const int xa = min(m0 + xo, g.m - 1), xb = min(n0 + xo, g.n - 1);
+        const char *pa = reinterpret_cast<const char *>(g.a + xa) + (int64_t)(k0 / DG_BK) * stepa;
+        const char *pb = reinterpret_cast<const char *>(g.b + xb) + (int64_t)(k0 / DG_BK) * stepb;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            ra[i] = *reinterpret_cast<const double *>(pa + offa[i]);
+            rb[i] = *reinterpret_cast<const double *>(pb + offb[i]);
+        }
+    };
+    auto store_step = [&](int m0, int n0, int buf, const double (&ra)[NL], const double (&rb)[NL]) {
+        const bool oka = m0 + xo < g.m, okb = n0 + xo < g.n;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            as[buf * DG_BK * PA + (4 * i + ko) * PA + xo] = oka ? ra[i] : 0.0;
+            bs[buf * DG_BK * PB + (4 * i + ko) * PB + xo] = okb ? rb[i] : 0.0;
+        }
+    };
+    double ra[NL], rb[NL];
+    int buf = 0;
+    load_step(ti * BM, tj * BN, 0, ra, rb);
+    store_step(ti * BM, tj * BN, 0, ra, rb);
+    __syncthreads();
+    for (;;) {
+        const int m0 = ti * BM, n0 = tj * BN;
+        int ti2 = ti, tj2 = tj;
+        const bool has_next = next_tile(ti2, tj2);
+        d4 acc[NB][MB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc[j][i] = (d4){0.0, 0.0, 0.0, 0.0};
+        double cv[NB][4][MB];
+        const bool rmw = g.beta != 0.0;
+        auto c_load = [&](int j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = min(n0 + wn + 16 * j + lk + 4 * r, g.n - 1);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int row = min(m0 + wm + 16 * i + lx, g.m - 1);
+                    cv[j][r][i] = g.c[row + (int64_t)col * g.ldc];
+                }
+            }
+        };
+        for (int ks = 0; ks < nks; ++ks) {
+            const bool last = ks + 1 == nks;
+            const bool more = !last || has_next;
+            const int lm0 = last ? ti2 * BM : m0, ln0 = last ? tj2 * BN : n0, lk0 = last ? 0 : (ks + 1) * DG_BK;
+            if (more) load_step(lm0, ln0, lk0, ra, rb);
+            if (rmw) {
+                // NB strips over the first steps (K = 128: steps 0 .. 3 of 8; fewer steps than strips: the rest with the last step)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (ks == j || (last && j > ks)) c_load(j);
+            }
+            {
+                const double *ap = as + buf * DG_BK * PA + wm + lx;
+                const double *bp = bs + buf * DG_BK * PB + wn + lx;
+#pragma unroll
+                for (int k4 = 0; k4 < DG_BK; k4 += 4) {
+                    double fa[MB], fb[NB];
+#pragma unroll
+                    for (int i = 0; i < MB; ++i) fa[i] = ap[(k4 + lk) * PA + i * 16];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) fb[j] = bp[(k4 + lk) * PB + j * 16];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+                }
+            }
+            if (more) store_step(lm0, ln0, buf ^ 1, ra, rb);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // epilogue of the tile (the next tile's first step is already in LDS)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = n0 + wn + 16 * j + lk + 4 * r;
+                if (col >= g.n) continue;
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int row = m0 + wm + 16 * i + lx;
+                    if (row >= g.m) continue;
+                    if (row < col) continue;                  // diagonal tiles: the strict upper part is not referenced
+                    const double v = g.alpha * acc[j][i][r];
+                    g.c[row + (int64_t)col * g.ldc] = rmw ? (v + g.beta * cv[j][r][i]) : v;
+                }
+            }
+        if (!has_next) break;
+        ti = ti2;
+        tj = tj2;
+    }
+}
+
 template <int BM, int BN, int NT = DG_THREADS, bool STREAM = true>
 static int dg_launch(const DgemmArgs &g, dim3 grid, hipStream_t st) {
     constexpr size_t smem = sizeof(double) * 2 * DG_BK * ((BM + 17) + (BN + 17));
@@ -438,6 +599,26 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
     if (m <= 0) return 0;
     DgemmArgs g{a, b, c, lda, ldb, ldc, m, m, k, alpha, beta, 0, 1, 0, 1, 1, nullptr};
     const int t = ceil_div(m, 128);
+    // one stream of K steps over a workgroup's tiles (dsyr2k_pipe_kernel) from two tiles per workgroup on; JXGPU_SYR2K_PIPE=0: one
+    // tile per workgroup (dgemm_kernel)
+    static const bool pipe = !(getenv("JXGPU_SYR2K_PIPE") && atoi(getenv("JXGPU_SYR2K_PIPE")) == 0);
+    static const int pipe_wgs = [] {
+        const char *e = getenv("JXGPU_SYR2K_PIPE_WGS");
+        const int v = e ? atoi(e) : 256;
+        return v >= 8 ? (v / 8) * 8 : 256;
+    }();
+    const int64_t ntl = (int64_t)t * (t + 1) / 2;
+    if (pipe && k > 0 && k % DG_BK == 0 && ntl >= 2 * (int64_t)pipe_wgs) {
+        constexpr size_t smem = sizeof(double) * 2 * DG_BK * ((128 + 17) + (128 + 17));
+        static bool attr_set = false;
+        if (!attr_set) {
+            JX_HIP(hipFuncSetAttribute((const void *)dsyr2k_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(dsyr2k_pipe_kernel, dim3((unsigned)pipe_wgs), dim3(512), smem, st, g);
+        JX_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((unsigned)((int64_t)t * (t + 1) / 2), 1, 1);
     // the rank-2k update alone is faster in the general-loop form with two resident workgroups per CU (1.31 vs 1.50 ms at n_t =
     // 20000), the band reduction as a whole is faster with the one-workgroup stream form (397 vs 426 ms): the panel chain of

@@ -601,11 +601,22 @@ int dsyr2k_lower_nt(hipStream_t st, int m, int k, double alpha, const double *a,
     const int t = ceil_div(m, 128);
     // one stream of K steps over a workgroup's tiles (dsyr2k_pipe_kernel) from two tiles per workgroup on; JXGPU_SYR2K_PIPE=0: one
     // tile per workgroup (dgemm_kernel)
-    static const bool pipe = !(getenv("JXGPU_SYR2K_PIPE") && atoi(getenv("JXGPU_SYR2K_PIPE")) == 0);
+    const char *pe = getenv("JXGPU_SYR2K_PIPE");         // read per call: the two forms are compared inside one process by the tests
+    const bool pipe = !(pe && atoi(pe) == 0);
+    // its workgroups stay for the whole launch (one per CU: 216 registers), so the panel chain of the NEXT panel -- on the other
+    // stream, the critical path -- only finds the CUs this kernel leaves alone: 7 / 8 of them measured best at n = 20 000 (band
+    // reduction, pipe on 256 / 248 / 240 / 232 CUs: 372 - 382 ms, on 224: 336, 216: 339, 208: 342, 192: 352; dgemm_kernel: 355)
     static const int pipe_wgs = [] {
         const char *e = getenv("JXGPU_SYR2K_PIPE_WGS");
-        const int v = e ? atoi(e) : 256;
-        return v >= 8 ? (v / 8) * 8 : 256;
+        int v = e ? atoi(e) : 0;
+        if (v < 8) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            v = 224;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 16)
+                v = prop.multiProcessorCount * 7 / 8;
+        }
+        return v >= 8 ? (v / 8) * 8 : 224;
     }();
     const int64_t ntl = (int64_t)t * (t + 1) / 2;
     if (pipe && k > 0 && k % DG_BK == 0 && ntl >= 2 * (int64_t)pipe_wgs) {

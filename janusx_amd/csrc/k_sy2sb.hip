@@ -621,6 +621,8 @@ int sy2sb_lower(hipStream_t st, double *d_a, int n, double *d_tau, double *d_ab,
         static hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_qr[2] = {nullptr, nullptr};
         static const bool lookahead = !(getenv("JXGPU_SY2SB_LOOKAHEAD") && atoi(getenv("JXGPU_SY2SB_LOOKAHEAD")) == 0);
         if (!side) {
+            // (a high-priority side stream was measured with the persistent update kernel: no effect on the band reduction -- what the
+            // chain needs is free CUs, k_dgemm.hip dsyr2k_lower_nt -- and 16 ms more in the divide and conquer; not kept)
             JX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             for (int q = 0; q < 2; ++q) {
                 JX_HIP(hipEventCreateWithFlags(&ev_a[q], hipEventDisableTiming));

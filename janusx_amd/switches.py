@@ -64,6 +64,8 @@ SWITCHES = {
     "JXGPU_DIST_BAND_MIN_N": ("knob", "16384", "size from which the band reduction is sharded", "test_sharded_band_reduction_rccl_single_rank"),
     "JXGPU_DIST_BAND_BLOCK": ("test", "auto", "block rows of the sharded band reduction", "test_sharded_band_reduction_rccl_single_rank"),
     "JXGPU_DIST_DC_WINDOW": ("knob", "1", "0: top-level merge replicated", "untested"),
+    "JXGPU_SYR2K_PIPE_WGS": ("knob", "7/8 of the CUs", "workgroups of the persistent rank-2k update (the rest of the CUs serve the panel chain)",
+                             "test_rank_2k_update_forms_give_the_same_bits"),
     "JXGPU_SPLMM_ROUTE": ("knob", "auto", "dense | block | factor: form of K + lambda I of the sparse-GRM routes",
                           "test_splmm_block_route_matches_the_dense_route, test_splmm_giant_component_both_sides_of_the_limit"),
     "JXGPU_SPLMM_BLOCK": ("knob", "4096", "samples per diagonal block of the block route", "test_splmm_block_route_matches_the_dense_route"),
@@ -82,7 +84,8 @@ SWITCHES = {
         "JXGPU_DSYMM_SLOTS": "untested", "JXGPU_DSYMM_SPLIT": "untested", "JXGPU_ORMTR_NB": "untested",
         "JXGPU_ROT_I8_DMA": "test_int8_rotation_forms_give_the_same_bits",
         "JXGPU_SCAN_CHAIN_SPLIT": "test_warm_start_chain_kernels_on_rotated_rows_with_invalid_rows",
-        "JXGPU_REPACK_WINDOW": "test_repack_of_a_sample_subset_window_form"}.items()},
+        "JXGPU_REPACK_WINDOW": "test_repack_of_a_sample_subset_window_form",
+        "JXGPU_SYR2K_PIPE": "test_rank_2k_update_forms_give_the_same_bits"}.items()},
     # ---- ablation masks (wrong results by design: timing experiments only) --------------------------------------------------------
     "JXGPU_QB_SKIP": ("test", "unset", "skips parts of the Q2 kernel (timing ablation; results are WRONG)", "test_q2_staggered_units_equal_lockstep (the lockstep value 64 only)"),
     "JXGPU_BC_SKIP": ("test", "unset", "bulge-chasing ablation (results WRONG)", "untested"),

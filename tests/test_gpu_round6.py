@@ -679,3 +679,41 @@ def test_repack_of_a_sample_subset_window_form(case):
             os.environ["JXGPU_REPACK_WINDOW"] = old
     assert np.array_equal(outs["0"], ref)
     assert np.array_equal(outs["1"], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [4000, 7013])
+def test_rank_2k_update_forms_give_the_same_bits(m):
+    """The trailing update of the band reduction (`jxg_dsyr2k_lower_nt_f64`: lower tiles of C -= A B', K = 128) as one stream of K
+    steps over a workgroup's tiles (dsyr2k_pipe_kernel: operands one step ahead across tile boundaries, the C values of a tile
+    requested a strip per step, tiles dealt by XCD) against one tile per workgroup (JXGPU_SYR2K_PIPE=0): the same products in the same
+    order -- the lower triangle is the same bits, the strict upper triangle is not touched, and both agree with an f64 reference."""
+    import torch
+    from janusx_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev)
+    g.manual_seed(m)
+    a = torch.randn((128, m), device=dev, dtype=torch.float64, generator=g)          # column-major (m, 128)
+    b = torch.randn((128, m), device=dev, dtype=torch.float64, generator=g)
+    c0 = torch.randn((m, m), device=dev, dtype=torch.float64, generator=g)
+    outs = {}
+    old = os.environ.get("JXGPU_SYR2K_PIPE")
+    try:
+        for form in ("1", "0"):
+            os.environ["JXGPU_SYR2K_PIPE"] = form
+            c = c0.clone()
+            check(lib().jxg_dsyr2k_lower_nt_f64(m, 128, -1.0, a.data_ptr(), m, b.data_ptr(), m, 1.0, c.data_ptr(), m, st))
+            torch.cuda.synchronize()
+            outs[form] = c
+    finally:
+        if old is None:
+            os.environ.pop("JXGPU_SYR2K_PIPE", None)
+        else:
+            os.environ["JXGPU_SYR2K_PIPE"] = old
+    assert torch.equal(outs["1"], outs["0"])
+    # memory is column-major: the tensor's [j, i] is C[i][j]; lower triangle of C = upper triangle of the tensor
+    ref = c0 - b.T @ a                                                                # C^T = C0^T - B A'
+    up = torch.triu(torch.ones((m, m), dtype=torch.bool, device=dev))
+    assert float((outs["1"] - ref)[up].abs().max()) < 1e-11
+    assert torch.equal(outs["1"][~up], c0[~up])

@@ -447,15 +447,17 @@ int jxg_packed_tdot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t 
                     const float *d_lut, const double *d_alpha, double *d_out, void *stream);
 int jxg_packed_dot(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                    const float *d_lut, const double *d_beta, double *d_out, void *stream);
-/* jxg_packed_tdot with the vector rounded to f32 and f32 partial sums inside a 128-sample tile (the Z u half of the PCG
- * operator of `rrblup_pcg_bed`, whose vectors are f32: src/stats/rrblup.rs:1220-1372): bit-plane table form, three LDS
- * lookups per four genotypes. */
+/* jxg_packed_tdot with the vector rounded to f32 (the Z u half of the PCG operator of `rrblup_pcg_bed`, whose vectors are
+ * f32: src/stats/rrblup.rs:1220-1372).  From 1024 samples and SNPs on: the bit planes of the codes against a four-digit int8
+ * image of the vector on v_mfma_i32_16x16x64_i8, exact sums (csrc/k_pcg_i8.hip); below that, or with JXGPU_PCG_I8=0: the
+ * bit-plane table form (three LDS lookups per four genotypes, f32 partial sums inside a 128-sample tile). */
 int jxg_packed_tdot_f32(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows,
                         const float *d_lut, const double *d_u, double *d_out, void *stream);
 /* The Z'p half of the same operator from a sample-major image of the payload: `jxg_p32_transpose` builds
  * t32[snp_tile][sample][32 B] (128 consecutive SNPs of the row list per record; `jxg_t32_bytes` bytes) once per solve,
- * `jxg_packed_dot_t32` then evaluates d_out[i] = sum_r f32(lut[r][code] * f32(beta[r])) with the same bit-plane tables
- * (three lookups per four genotypes); d_work needs 16 * nrows + 16 bytes. */
+ * `jxg_packed_dot_t32` then evaluates d_out[i] = sum_r f32(lut[r][code] * f32(beta[r])) -- the same int8 form (the three
+ * per-SNP weight vectors as digit planes) or, below 1024 / with JXGPU_PCG_I8=0, the same bit-plane tables; d_work needs
+ * 16 * nrows + 16 bytes. */
 int64_t jxg_t32_bytes(int n, int nrows);
 int jxg_p32_transpose(const uint8_t *d_p32, int64_t m_total, int n, const int32_t *d_rows, int nrows, uint8_t *d_t32,
                       void *stream);

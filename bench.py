@@ -221,7 +221,9 @@ def grm_peak_tflops(i8_share):
     """Dense MFMA peak the GRM is priced against: the exact-integer SNPs run on the int8 pipes (5 POP/s), the rest on the f16
     pipes (2.5 PFLOP/s, three products per algorithmic product); a mixed panel is priced by the time-weighted (harmonic) mix."""
     s = min(max(float(i8_share), 0.0), 1.0)
-    return 1.0 / (s / MFMA_I8_PEAK_TOPS + (1.0 - s) / MFMA_F16_PEAK_TFLOPS)
+    # JXGPU_GRM_FP4=1 (opt-in): the exact-integer SNPs of the 256-tile form run on the fp4 pipes, twice the int8 rate
+    exact_peak = 2.0 * MFMA_I8_PEAK_TOPS if os.environ.get("JXGPU_GRM_FP4", "0") not in ("", "0") else MFMA_I8_PEAK_TOPS
+    return 1.0 / (s / exact_peak + (1.0 - s) / MFMA_F16_PEAK_TFLOPS)
 
 
 def baseline_config_label(n, m):
@@ -843,6 +845,8 @@ def main():
                                 pmc_traffic_bytes("jx::fvlmm_scan_kernel", "fetch_fv"))
         i8_share = kern.get("grm_i8_share", 0.0)
         grm_kernel = "grm_i8_kernel" if i8_share >= 0.5 else "grm_f16x2_kernel"
+        if i8_share >= 0.5 and os.environ.get("JXGPU_GRM_FP4", "0") not in ("", "0") and n >= 9900:
+            grm_kernel = "grm_fp4_kernel"
         grm_peak = grm_peak_tflops(i8_share)
         tr_grm, tr_grm_src = pmc_traffic_bytes("jx::" + grm_kernel)
         mu_grm, mu_grm_src = pmc_mfma_util(grm_kernel)

@@ -260,6 +260,11 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), MINW) void grm_i8_kerne
         }
 }
 
+// k_grm_fp4.hip: the same Gram on the fp4 pipes from a nibble image of the counts
+bool grm_fp4_enabled();
+int launch_grm_fp4(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, int64_t r0, int64_t r1, int nt128,
+                   double *d_acc, int64_t ld, const double *corr, int64_t base256, int64_t ntl256);
+
 // Launch over the SNP range [r0, r1) of the (reordered) list `rows`.  Lower-triangle tiles of the n_sel x n_sel accumulator
 // (ld = 128 nt128); panel mode: tile rows [tile_row_begin, tile_row_end) of 128-row tiles only (d_acc already shifted so
 // that global sample rows index it).  `corr`: r[0 .. ld) and B at [ld], added once.
@@ -280,6 +285,7 @@ int launch_grm_i8(hipStream_t st, const uint8_t *p32, int64_t m_total, const int
                      (tile_env ? tile_env >= 256 : ntl256 >= 3 * 256);
     if (big) {
         if (base256 + ntl256 > 0x7fffffffLL) return fail("jxg_grm_accumulate: too many tiles");
+        if (grm_fp4_enabled()) return launch_grm_fp4(st, p32, m_total, rows, r0, r1, nt128, d_acc, ld, corr, base256, ntl256);
         // i32 sums stay exact for 2^29 SNPs per chunk: one launch for the whole range
         for (int64_t kb = r0; kb < r1; kb += (int64_t)1 << 29) {
             const int64_t ke = (kb + ((int64_t)1 << 29) < r1) ? kb + ((int64_t)1 << 29) : r1;

@@ -27,6 +27,8 @@ SWITCHES = {
     "JXGPU_GRM_MISS_DENSE_MIN": ("numerics", "0.0015", "missing share from which the dense digit form replaces the sparse correction",
                                  "test_grm_missing_calls_sparse_correction, scripts/diag_e2e_two_stage.py"),
     "JXGPU_GRM_MISS_DENSE_ROWS": ("numerics", "16384", "fewest SNPs for the dense digit form", "test_grm_missing_calls_sparse_correction"),
+    "JXGPU_GRM_FP4": ("form", "0", "1: the count Gram of the 256-tile form on the fp4 matrix pipes from a nibble image (exact like the int8 kernel)",
+                      "test_grm_count_gram_on_the_fp4_pipes"),
     "JXGPU_GRM_I8": ("numerics", "1", "0: exact-integer SNPs on the fp16 single-product kernel (f32 sums instead of exact i32)", "untested"),
     "JXGPU_GRM_EXACT": ("numerics", "1", "0: every SNP on the fp16 hi/lo split kernel", "untested"),
     "JXGPU_ROT_I8": ("numerics", "1", "0: design rows on the fp16 hi/lo rotation instead of the exact int8 planes",

@@ -717,3 +717,40 @@ def test_rank_2k_update_forms_give_the_same_bits(m):
     up = torch.triu(torch.ones((m, m), dtype=torch.bool, device=dev))
     assert float((outs["1"] - ref)[up].abs().max()) < 1e-11
     assert torch.equal(outs["1"][~up], c0[~up])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,missing", [(2700, 3000, 0.0), (4200, 2500, 0.002)])
+def test_grm_count_gram_on_the_fp4_pipes(n, m, missing):
+    """JXGPU_GRM_FP4=1: the count Gram of SNPs without missing calls as v_mfma_scale_f32_32x32x64_f8f6f4 products of an e2m1 nibble
+    image of the counts (k_grm_fp4.hip; f32 sums of small integers, exact below 2^24) against the int8 kernel (exact i32 sums): the
+    accumulators agree to the rounding of the affine terms both add in f64 (their own sums are order-dependent f64 atomics), ragged
+    sample counts, a few SNPs with missing calls beside (those take their own path in both)."""
+    import torch
+    import bench
+    from janusx_amd import pipeline, stats as st
+    dev = torch.device("cuda", 0)
+    packed, _ = bench.synth_panel_gpu(n, m, 5, dev, missing_rate=missing)
+    p = pipeline.Panel(packed, n, None)
+    keep, mean_g, scale, flip, var = st.stream_grm_row_prepare(p.counts(), n, 1, 0.02, 0.05, 0.0)
+    rows = np.nonzero(keep)[0]
+    lut = st.grm_lut_from_mean_scale(mean_g[rows], scale[rows], flip[rows])
+    outs = {}
+    old = {k: os.environ.get(k) for k in ("JXGPU_GRM_FP4", "JXGPU_GRM_I8_TILE")}
+    try:
+        os.environ["JXGPU_GRM_I8_TILE"] = "256"                  # the 256-tile form at a test size
+        for form in ("0", "1"):
+            os.environ["JXGPU_GRM_FP4"] = form
+            acc = torch.zeros((p.npad, p.npad), dtype=torch.float64, device=dev)
+            pipeline.grm_accumulate(p, rows, lut, acc=acc)
+            torch.cuda.synchronize()
+            outs[form] = torch.tril(acc[:n, :n]).cpu().numpy()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    scale_k = float(np.abs(outs["0"]).max())
+    assert scale_k > 1.0
+    assert float(np.abs(outs["1"] - outs["0"]).max()) <= 1e-12 * scale_k

@@ -520,11 +520,14 @@ def main():
                 "launches": 0}
         stage = {}
 
+        p32_keep = [None]           # the P32 image is re-tiled every step into the same allocation (the work is timed, the malloc is not)
+
         def one_step(record):
             t = {}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            panel = pl.Panel(packed, n)
+            panel = pl.Panel(packed, n, p32_buffer=p32_keep[0])
+            p32_keep[0] = panel.p32
             counts = panel.counts()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -573,6 +576,7 @@ def main():
                                  ("scan", t5 - t4), ("rotate_k", tm.t.get("rotate", 0.0)),
                                  ("assoc_k", tm.t.get("scan", 0.0))):
                     stage[key] = stage.get(key, 0.0) + val
+                kern.setdefault("prep_ms_by_step", []).append(round((t1 - t0) * 1e3, 3))      # detail record: is a slow `prep` one step's stall?
                 kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
                 kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
                 kern["two_stage"] = two_stage
@@ -1026,6 +1030,7 @@ def main():
                                 "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS,
                                 "ms_per_step": kern["scan_ms"] / L})),
             "stages_ms_per_step": {k: v / args.steps * 1e3 for k, v in stage.items()},
+            "prep_ms_by_step": kern.get("prep_ms_by_step"),
             **({"stages_ms_per_step_max_over_ranks": {k: v / args.steps * 1e3 for k, v in main_leg["stage_max"].items()}}
                if distributed else {}),
             "null": {"lbd": null.lbd, "pve": null.pve},

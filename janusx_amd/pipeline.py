@@ -55,7 +55,9 @@ class StageTimes:
 class Panel:
     """A 2-bit genotype payload resident in HBM in the internal P32 tiling."""
 
-    def __init__(self, packed: torch.Tensor, n_samples: int, sample_idx=None):
+    def __init__(self, packed: torch.Tensor, n_samples: int, sample_idx=None, p32_buffer=None):
+        # p32_buffer: a (tiles, m, 32) uint8 device tensor of a previous Panel of the same shape to re-tile into (a caller that
+        # re-tiles the same payload repeatedly -- bench.py's steps -- keeps the allocation out of its loop)
         assert packed.is_cuda and packed.dtype == torch.uint8 and packed.dim() == 2
         self.device = packed.device
         self.m = int(packed.shape[0])
@@ -77,7 +79,11 @@ class Panel:
             self.n = self.n_src
         self.nt = lib().jxg_num_tiles(self.n)
         self.npad = self.nt * 128
-        self.p32 = torch.empty((self.nt, self.m, 32), dtype=torch.uint8, device=self.device)
+        if (p32_buffer is not None and tuple(p32_buffer.shape) == (self.nt, self.m, 32) and p32_buffer.dtype == torch.uint8
+                and p32_buffer.device == self.device and p32_buffer.is_contiguous()):
+            self.p32 = p32_buffer
+        else:
+            self.p32 = torch.empty((self.nt, self.m, 32), dtype=torch.uint8, device=self.device)
         check(lib().jxg_repack_p32(_ptr(packed), bps, self.n_src, self.m, _ptr(idx_t), self.n, None, self.m,
                                    _ptr(self.p32), _stream()))
         self._counts = None

@@ -67,7 +67,7 @@ struct DevBuf {
 // doubles per call, and each hipMalloc / hipFree pair of that size costs milliseconds (hipFree synchronises the device).
 // Blocks larger than kScratchKeepBytes are released again by the caller's ScratchLease so big problems do not pin HBM.
 constexpr size_t kScratchKeepBytes = (size_t)6 << 30;
-// which: 0 eigh C, 1 stedc arena, 2 sytrd workspace, 3 ormtr workspace, 4 nibble image of the fp4 Gram.  Returns 0 and *p (kept block), or 1 when
+// which: 0 eigh C, 1 stedc arena, 2 sytrd workspace, 3 / 5 / 6 ormtr, 4 stage-2 reflectors, 7 nibble image of the fp4 Gram.  Returns 0 and *p (kept block), or 1 when
 // the block should be a private allocation (slot in use by a concurrent call, or too large to keep).  api.cpp
 int scratch_acquire(int which, size_t bytes, void **p);
 void scratch_release(int which);

@@ -189,7 +189,7 @@ bool grm_fp4_enabled() {
 // the `big` form of launch_grm_i8 (256 x 256 tiles `base256` .. + `ntl256` of the lower triangle) over the SNPs rows[r0 .. r1)
 int launch_grm_fp4(hipStream_t st, const uint8_t *p32, int64_t m_total, const int32_t *rows, int64_t r0, int64_t r1, int nt128,
                    double *d_acc, int64_t ld, const double *corr, int64_t base256, int64_t ntl256) {
-    // SNP chunks: the nibble image of a chunk (64 nt128 bytes per SNP) lives in a kept scratch block (slot 4, <= 6 GB: handed back by
+    // SNP chunks: the nibble image of a chunk (64 nt128 bytes per SNP) lives in a kept scratch block (slot 7, <= 6 GB: handed back by
     // jxg_scratch_trim like the eigensolver's), and 2^22 SNPs keep the f32 sums exact
     int64_t kc = (int64_t)(kScratchKeepBytes / (64 * (size_t)nt128));
     kc = std::min<int64_t>(kc, (int64_t)1 << 22);
@@ -197,7 +197,7 @@ int launch_grm_fp4(hipStream_t st, const uint8_t *p32, int64_t m_total, const in
     const int64_t cnt_all = r1 - r0;
     if (kc > cnt_all) kc = cnt_all;
     ScratchLease img;
-    if (img.take(4, (size_t)kc * 64 * (size_t)nt128)) return 1;
+    if (img.take(7, (size_t)kc * 64 * (size_t)nt128)) return 1;
     for (int64_t kb = r0; kb < r1; kb += kc) {
         const int64_t cnt = std::min(kc, r1 - kb);
         const int64_t nbx = (cnt * 8 + 255) / 256;

@@ -528,6 +528,8 @@ def main():
             t0 = time.perf_counter()
             panel = pl.Panel(packed, n, p32_buffer=p32_keep[0])
             p32_keep[0] = panel.p32
+            torch.cuda.synchronize()
+            t0b = time.perf_counter()      # detail record only: the re-tiling kernel's share of `prep`
             counts = panel.counts()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -576,7 +578,7 @@ def main():
                                  ("scan", t5 - t4), ("rotate_k", tm.t.get("rotate", 0.0)),
                                  ("assoc_k", tm.t.get("scan", 0.0))):
                     stage[key] = stage.get(key, 0.0) + val
-                kern.setdefault("prep_ms_by_step", []).append(round((t1 - t0) * 1e3, 3))      # detail record: is a slow `prep` one step's stall?
+                kern.setdefault("prep_ms_by_step", []).append([round((t0b - t0) * 1e3, 3), round((t1 - t0b) * 1e3, 3)])   # detail record: [re-tile, counts + copy]
                 kern["symv_ms"] = kern.get("symv_ms", 0.0) + symv_ms
                 kern["symv_mb"] = kern.get("symv_mb", 0.0) + symv_mb
                 kern["two_stage"] = two_stage

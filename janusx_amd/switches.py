@@ -96,6 +96,7 @@ SWITCHES = {
     "JXGPU_EIGH_TRACE": ("trace", "unset", "stage times of a decomposition to stderr", "-"),
     "JXGPU_PCG_TRACE": ("trace", "unset", "set-up marks of the PCG / HE / staging paths", "-"),
     "JXGPU_BENCH_BACKEND": ("test", "nccl", "bench.py: gloo for ranks sharing a GPU", "test_bench_two_ranks_share_one_gpu"),
+    "JXGPU_BENCH_STEP_SLEEP_MS": ("test", "unset", "bench.py diagnostic: idle time in front of every odd step", "-"),
     "JXGPU_BENCH_CHILD": ("test", "unset", "bench.py: marks a child process", "-"),
     "JXGPU_BENCH_FORCE_DIST": ("test", "unset", "bench.py: one rank on the multi-rank code path", "test_distributed_eigh_rccl_callback_single_rank"),
     "JXGPU_DIST_EIGH_FORCE": ("test", "unset", "sharded eigensolver forms with one rank", "test_sharded_band_reduction_rccl_single_rank"),

@@ -656,6 +656,7 @@ def main():
                 gc_log["ms"][g] += (time.perf_counter() - gc_log["t"]) * 1e3
                 gc_log["runs"][g] += 1
         gc.callbacks.append(gc_cb)
+        ms0 = torch.cuda.memory_stats(dev)
         t_start = time.perf_counter()
         kept = 0
         null = None
@@ -668,6 +669,11 @@ def main():
         gc.callbacks.remove(gc_cb)
         placement["gc_ms_in_timed_steps"] = [round(v, 2) for v in gc_log["ms"]]
         placement["gc_runs_in_timed_steps"] = gc_log["runs"]
+        ms1 = torch.cuda.memory_stats(dev)
+        # driver-level allocations / releases of the tensor allocator inside the timed steps (a step that fits the cache makes none)
+        placement["torch_device_alloc_free_in_timed_steps"] = [int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                                                               int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0))]
+        placement["torch_reserved_gib"] = round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 2)
         el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         kept_t = torch.tensor([float(kept)], dtype=torch.float64, device=dev)
         if distributed:

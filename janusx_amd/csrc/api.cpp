@@ -75,6 +75,21 @@ extern "C" int64_t jxg_scratch_trim(void) {
     return freed;
 }
 
+// keep the stream-ordered pool's blocks across synchronisations (default threshold 0: every hipFreeAsync'ed block goes back to the
+// driver at the next synchronisation and the next hipMallocAsync pays a fresh allocation): 256 MB cover the largest user
+void async_pool_keep() {
+    static bool pool_set = false;
+    if (pool_set) return;
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        uint64_t thr = (uint64_t)256 << 20;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    (void)hipGetLastError();
+    pool_set = true;
+}
+
 int launch_symmetrize(double *d_a, int n, hipStream_t st);
 int launch_transpose_f64(const double *src, double *dst, int n, hipStream_t st);
 

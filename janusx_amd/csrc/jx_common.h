@@ -70,6 +70,7 @@ constexpr size_t kScratchKeepBytes = (size_t)6 << 30;
 // which: 0 eigh C, 1 stedc arena, 2 sytrd workspace, 3 / 5 / 6 ormtr, 4 stage-2 reflectors, 7 nibble image of the fp4 Gram.  Returns 0 and *p (kept block), or 1 when
 // the block should be a private allocation (slot in use by a concurrent call, or too large to keep).  api.cpp
 int scratch_acquire(int which, size_t bytes, void **p);
+void async_pool_keep();   // release threshold of the stream-ordered pool (api.cpp): call in front of hipMallocAsync users
 void scratch_release(int which);
 // stream-ordered allocation released behind the work queued on the same stream, on every path out of the scope
 struct AsyncBlock {
@@ -83,6 +84,7 @@ struct AsyncBlock {
     }
     int alloc(size_t bytes, hipStream_t s) {
         st = s;
+        async_pool_keep();
         hipError_t e = hipMallocAsync(&p, bytes ? bytes : 16, s);
         if (e != hipSuccess) {
             p = nullptr;

@@ -576,6 +576,7 @@ extern "C" int jxg_lut_split(const float *d_lut, int64_t mk, void *d_lut16, void
     if (mk <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));
     JX_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
     hipLaunchKernelGGL(lut_split_r_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_lut, mk,
@@ -631,6 +632,7 @@ extern "C" int jxg_lut_split_rows_m(const uint8_t *d_p32, int64_t m_total, int n
     // missing-call term, jxg_rotate_missing_dense, needs no list): passed through
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync((void **)&flags, sizeof(int), st));
     JX_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
     hipLaunchKernelGGL(lut_split_rows_kernel, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, st, d_p32, m_total,
@@ -886,6 +888,7 @@ extern "C" int jxg_rotate_packed(const uint8_t *d_p32, int64_t m_total, int n, c
     if (nrows <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     void *lut16 = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync(&lut16, sizeof(uint4) * (size_t)nrows, st));
     int rc = jxg_lut_split(d_lut, nrows, lut16, stream);
     if (!rc) rc = jxg_rotate_packed16(d_p32, m_total, n, d_rows, nrows, lut16, d_uhi, d_ulo, scale_exp, d_out, stream);

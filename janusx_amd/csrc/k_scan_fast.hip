@@ -1898,21 +1898,6 @@ extern "C" int jxg_lmm_tables_build(const double *d_s, const double *d_xcov, con
 
 namespace jx { extern float g_last_ms[24]; }   // [11]: form the last exact scan launch took (0 LDS-resident, 1 tiled, 2 plain)
 
-// keep the stream-ordered pool's blocks across synchronisations (default threshold 0: every hipFreeAsync'ed block goes back to the
-// driver at the next synchronisation and the next call pays a fresh allocation): 256 MB cover the largest call
-static void series_pool_keep() {
-    static bool pool_set = false;
-    if (pool_set) return;
-    int dev = 0;
-    hipMemPool_t pool = nullptr;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-        uint64_t thr = (uint64_t)256 << 20;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
-    (void)hipGetLastError();
-    pool_set = true;
-}
-
 // per-SNP series of a block of rotated rows: scoef (nrows, p + 2, SR_M), sssq (nrows) -- series_coef_kernel per group of quantities
 static int series_coef_launch(const float *d_grot, int nrows, int n, int p, const double *d_xcov, const void *d_work, double low,
                               double high, double *scoef, double *sssq, hipStream_t st) {
@@ -1996,7 +1981,7 @@ static int series_brent_launch(int nrows, int n, const double *d_s, const double
         // chains: three launches (ChainSplit) unless JXGPU_SCAN_CHAIN_SPLIT=0
         const bool split_on = chain && !(getenv("JXGPU_SCAN_CHAIN_SPLIT") && atoi(getenv("JXGPU_SCAN_CHAIN_SPLIT")) == 0);
         if (split_on) {
-            series_pool_keep();
+            async_pool_keep();
             ChainSplit sp;
             if (getenv("JXGPU_SCAN_CHAIN_FORCE_DIRECT")) sp.force_row = atoi(getenv("JXGPU_SCAN_CHAIN_FORCE_DIRECT"));
             int32_t *cflag = nullptr;
@@ -2182,7 +2167,7 @@ static int lmm_scan_tab_impl(const float *d_grot, int nrows, int n, const double
         // (a process-wide buffer would be shared by concurrent calls on other streams while their kernels are in flight: ADVICE r4)
         const size_t need = sizeof(double) * ((size_t)nrows * nq * SR_M + (size_t)nrows);
         void *sraw = nullptr;
-        series_pool_keep();
+        async_pool_keep();
         JX_HIP(hipMallocAsync(&sraw, need, st));
         struct SeriesFree {
             void *p;
@@ -2295,6 +2280,7 @@ extern "C" int jxg_lmm_scan_chain(const float *d_grot, int nrows, int n, const d
                                         d_carry, with_plrt, nullml, d_out, d_evals, stream);
     hipStream_t st = (hipStream_t)stream;
     void *work = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
     int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
     if (!rc)
@@ -2346,6 +2332,7 @@ extern "C" int jxg_lmm_scan(const float *d_grot, int nrows, int n, const double 
                                   init_log10_lbd, with_plrt, nullml, d_out, d_evals, stream);
     hipStream_t st = (hipStream_t)stream;
     void *work = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
     int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
     if (!rc)
@@ -2373,6 +2360,7 @@ extern "C" int jxg_lmm2_scan(const float *d_grot, int nrows, int n, const double
                                    nullml, d_out, stream);
     hipStream_t st = (hipStream_t)stream;
     void *work = nullptr;
+    async_pool_keep();
     JX_HIP(hipMallocAsync(&work, (size_t)jxg_lmm_tables_bytes(n, p, low, high), st));
     int rc = jxg_lmm_tables_build(d_s, d_xcov, d_y, n, p, low, high, work, stream);
     if (!rc)
